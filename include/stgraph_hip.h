@@ -1,0 +1,153 @@
+/*
+ * stgraph_hip.h -- C ABI of libstgraph_hip.so, the MI355X (gfx950) replacement
+ * for the native side of STGraph's Seastar hot path.
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes, returns
+ * 0 on success or a non-zero code (a hipError_t value, or STG_ERR_* below), and
+ * leaves a human readable message in stg_last_error_string() (thread local).
+ * Device pointers are marked [dev], host pointers [host].  `stream` is a
+ * hipStream_t passed as void* (NULL = the null stream, which is what the
+ * reference launches on: compiler/execution_unit.py:363-370).
+ * No entry point allocates or synchronises; scratch memory is passed in.
+ *
+ * "Replaces" cites the reference interface (paths relative to
+ * /root/reference/stgraph) that a maintainer would rebind to this symbol; the
+ * binding stubs are shown in INTEGRATION.md.
+ */
+#ifndef STGRAPH_HIP_H
+#define STGRAPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STG_ABI_VERSION 1
+
+#define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
+#define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
+#define STG_ERR_VERTEX_RANGE     10003   /* an edge endpoint is outside [0, N)       */
+#define STG_ERR_WORKSPACE        10004   /* workspace too small                       */
+
+int         stg_abi_version(void);
+const char *stg_last_error_string(void);
+
+/* Launch-time knobs (performance only, never results).  Unknown keys return
+ * STG_ERR_INVALID_ARGUMENT.  Keys: "gcn_lanes_per_row" (0 = auto, else a power
+ * of two <= 64), "gcn_unroll" (0 = auto, 2/4/8). */
+int stg_set_tuning(const char *key, int value);
+
+/* ---------------------------------------------------------------- CSR, host
+ * Replaces the pybind class `CSR(edge_list, edge_weight, num_nodes,
+ * is_edge_reverse)` -- graph/static/csr.cu:68-157, bound at csr.cu:181-201.
+ * (a[i], b[i], eid[i]) are the triples in the order the Python caller prepared
+ * them; edge_weight is indexed by eid and may be NULL (all ones).  All arrays
+ * [host]; outputs sized N+1, E, E, N, N, N, N.
+ */
+int stg_csr_ctor_host(const int32_t *a, const int32_t *b, const int32_t *eid,
+                      const float *edge_weight, int64_t E, int32_t N, int is_edge_reverse,
+                      int32_t *row_offset, int32_t *column_indices, int32_t *eids,
+                      int32_t *node_ids, int32_t *in_degrees, int32_t *out_degrees,
+                      float *weighted_out_degrees);
+
+/* Replaces StaticGraph._prepare_edge_lst_fwd/_bwd + the two CSR constructions
+ * of StaticGraph.__init__ -- graph/static/static_graph.py:40-78 (and, per
+ * snapshot, NaiveGraph.__init__ -- graph/dynamic/naive/naive_graph.py:45-94).
+ * Input: E (src,dst) pairs in caller order [host].
+ * Output [host]: perm_fwd[E] (caller position of the edge that received eid j,
+ * i.e. the (dst,src)-stable-sorted order the reference sorts the caller's list
+ * into), forward CSR (rows = dst, cols = src, eids = 0..E-1), backward CSR
+ * (rows = src, cols = dst, eids = forward positions), node_ids of both
+ * (rows by non-increasing degree, ties by ascending id), and the graph's
+ * in/out degrees.
+ */
+int stg_graph_build_host(const int32_t *src, const int32_t *dst, int64_t E, int32_t N,
+                         int64_t *perm_fwd,
+                         int32_t *fwd_row_offset, int32_t *fwd_column_indices,
+                         int32_t *fwd_eids, int32_t *fwd_node_ids,
+                         int32_t *bwd_row_offset, int32_t *bwd_column_indices,
+                         int32_t *bwd_eids, int32_t *bwd_node_ids,
+                         int32_t *in_degrees, int32_t *out_degrees);
+
+/* -------------------------------------------------------------- CSR, device
+ * Same contract as stg_graph_build_host with every array [dev]; runs entirely
+ * on `stream` (radix sort + binary-search row offsets), no host round trip.
+ * This is the per-snapshot rebuild of the dynamic-temporal configuration.
+ * Additionally validates endpoints: *status [dev, int32] is set to 0, or to
+ * STG_ERR_VERTEX_RANGE if any endpoint is outside [0, N).
+ * workspace [dev] must hold stg_graph_build_device_workspace_bytes(E, N) bytes.
+ */
+size_t stg_graph_build_device_workspace_bytes(int64_t E, int32_t N);
+int stg_graph_build_device(const int32_t *src, const int32_t *dst, int64_t E, int32_t N,
+                           int64_t *perm_fwd,
+                           int32_t *fwd_row_offset, int32_t *fwd_column_indices,
+                           int32_t *fwd_eids, int32_t *fwd_node_ids,
+                           int32_t *bwd_row_offset, int32_t *bwd_column_indices,
+                           int32_t *bwd_eids, int32_t *bwd_node_ids,
+                           int32_t *in_degrees, int32_t *out_degrees,
+                           int32_t *status, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
+/* ------------------------------------------------------- fused GCN aggregation
+ * Replaces the compiler-emitted FA kernels K0/K1 of GCNConv (tracer
+ * nn/pytorch/static/gcn_conv.py:162-182; template
+ * compiler/code_gen/templates/fa/tpl_fa_csr{,_unsorted}.jinja; launch
+ * compiler/execution_unit.py:359-372,407-415).  All pointers [dev], fp32 / int32.
+ *
+ *   out[r,f] = norm_row[r] * sum_{e in row r, c = column_indices[e]}
+ *                              ((norm_col[c] * x[c,f]) * (ew ? ew[eids[e]] : 1))
+ *   for f in [0, F_active); columns [F_active, F) of `out` are not written.
+ *
+ * One fp32 accumulator per (r,f), edges in CSR order, no FMA contraction: the
+ * result is bit-identical to the reference's sequential loop.
+ * forward : dst-major CSR, x = h,        norm_row = norm_col = norm
+ * backward: src-major CSR, x = grad_out, norm_row = norm_col = norm
+ * ew may be NULL; node_ids may be NULL ('csr_unsorted' graphs) or the row
+ * processing order of 'csr' graphs (tpl_fa_csr.jinja:13-18).
+ * x and out rows have stride F floats and must be 16-byte aligned.
+ */
+int stg_gcn_agg(const float *x, const float *norm_row, const float *norm_col, const float *ew,
+                float *out,
+                const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
+                const int32_t *node_ids, int32_t N, int32_t F, int32_t F_active, void *stream);
+
+/* ----------------------------------------------------------------- fused GAT
+ * Replace the emitted units K0, K1 (forward) and K2 (backward) of GATConv
+ * (tracer nn/pytorch/static/gat_conv.py:48-56; listing SURVEY.md Appendix B.3).
+ * Layouts: el, er, S, grad_el, grad_er [N,H]; A [E,H]; feat, out, g, grad_feat
+ * [N,H,D]; all [dev] fp32.
+ *
+ * k0 : s = el[u,h] + er[v,h]; z = s - s; a = exp(z > 0 ? z : slope*z);
+ *      A[eid,h] = a; S[v,h] = sum_e a            (dst-major CSR, h < H_active)
+ * k1 : out[v,h,d] = sum_e (A[eid,h] / S[v,h]) * feat[u,h,d]      (tx < HD_active)
+ * bwd: src-major CSR.  grad_feat[u,h,d] = sum_e g[v,h,d] * (A/S);
+ *      t = ((g*feat[u])*(1/S[v]) + (-1*((g/S[v])*out[v]))) * A * (z>0 ? 1 : slope)
+ *      grad_el[u,h] = sum_e sum_d t   (in-wave reduction, no atomics)
+ *      T[eid,h]     = sum_d t         (edge scratch, [E,H])
+ * bwd_er: grad_er[v,h] = sum_{e in in(v)} T[eid,h]   (dst-major CSR; replaces the
+ *      reference's atomicAdd inside the edge loop, deterministic)
+ */
+int stg_gat_fwd_k0(const float *el, const float *er, float *A, float *S,
+                   const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
+                   const int32_t *node_ids, int32_t N, int32_t H, int32_t H_active, float slope,
+                   void *stream);
+int stg_gat_fwd_k1(const float *A, const float *S, const float *feat, float *out,
+                   const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
+                   const int32_t *node_ids, int32_t N, int32_t H, int32_t D, int32_t HD_active,
+                   void *stream);
+int stg_gat_bwd(const float *A, const float *S, const float *out, const float *g,
+                const float *el, const float *er, const float *feat,
+                float *grad_feat, float *grad_el, float *T,
+                const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
+                const int32_t *node_ids, int32_t N, int32_t H, int32_t D, int32_t HD_active,
+                float slope, void *stream);
+int stg_gat_bwd_er(const float *T, float *grad_er,
+                   const int32_t *row_offsets, const int32_t *eids, const int32_t *node_ids,
+                   int32_t N, int32_t H, int32_t H_active, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STGRAPH_HIP_H */

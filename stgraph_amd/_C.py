@@ -1,0 +1,85 @@
+"""ctypes binding of libstgraph_hip.so (include/stgraph_hip.h).
+
+This is the ONLY way the Python host side reaches the HIP kernels.  There is no
+CPU or eager-PyTorch fallback: if the library has not been built, importing this
+module raises, and every wrapper raises ``RuntimeError`` with the library's own
+message when an entry point reports an error.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
+
+ABI_VERSION = 1
+
+STG_ERR_INVALID_ARGUMENT = 10001
+STG_ERR_UNSUPPORTED = 10002
+STG_ERR_VERTEX_RANGE = 10003
+STG_ERR_WORKSPACE = 10004
+
+# every symbol include/stgraph_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTED_SYMBOLS = (
+    "stg_abi_version", "stg_last_error_string", "stg_set_tuning",
+    "stg_csr_ctor_host", "stg_graph_build_host",
+    "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
+    "stg_gcn_agg", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_er",
+)
+
+
+class StgError(RuntimeError):
+    """An entry point of libstgraph_hip.so returned a non-zero code."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libstgraph_hip error {code}: {message}")
+        self.code = code
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing. stgraph_amd has no CPU fallback: build the HIP library first "
+            "(`make -C stgraph_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`).")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    lib.stg_abi_version.restype = ctypes.c_int
+    lib.stg_abi_version.argtypes = []
+    lib.stg_last_error_string.restype = ctypes.c_char_p
+    lib.stg_last_error_string.argtypes = []
+    lib.stg_set_tuning.restype = ctypes.c_int
+    lib.stg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.stg_csr_ctor_host.restype = ctypes.c_int
+    lib.stg_csr_ctor_host.argtypes = [vp, vp, vp, vp, i64, i32, ctypes.c_int] + [vp] * 7
+    lib.stg_graph_build_host.restype = ctypes.c_int
+    lib.stg_graph_build_host.argtypes = [vp, vp, i64, i32] + [vp] * 11
+    lib.stg_graph_build_device_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_graph_build_device_workspace_bytes.argtypes = [i64, i32]
+    lib.stg_graph_build_device.restype = ctypes.c_int
+    lib.stg_graph_build_device.argtypes = [vp, vp, i64, i32] + [vp] * 11 + [vp, vp, ctypes.c_size_t, vp]
+    lib.stg_gcn_agg.restype = ctypes.c_int
+    lib.stg_gcn_agg.argtypes = [vp] * 9 + [i32, i32, i32, vp]
+    lib.stg_gat_fwd_k0.restype = ctypes.c_int
+    lib.stg_gat_fwd_k0.argtypes = [vp] * 8 + [i32, i32, i32, f32, vp]
+    lib.stg_gat_fwd_k1.restype = ctypes.c_int
+    lib.stg_gat_fwd_k1.argtypes = [vp] * 8 + [i32, i32, i32, i32, vp]
+    lib.stg_gat_bwd.restype = ctypes.c_int
+    lib.stg_gat_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, f32, vp]
+    lib.stg_gat_bwd_er.restype = ctypes.c_int
+    lib.stg_gat_bwd_er.argtypes = [vp] * 5 + [i32, i32, i32, vp]
+    if lib.stg_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.stg_abi_version()} != expected {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise StgError(rc, lib.stg_last_error_string().decode(errors="replace"))
+
+
+def set_tuning(key: str, value: int) -> None:
+    check(lib.stg_set_tuning(key.encode(), int(value)))

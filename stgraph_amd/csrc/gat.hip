@@ -1,0 +1,509 @@
+// Fused GAT units for gfx950 (MI355X) -- stgraph_hip.h "fused GAT".
+//
+// Same wave64 row mapping as gcn_agg.hip: G lanes own one CSR row, a batch of G
+// (column, eid) pairs is fetched one-per-lane and broadcast, UNROLL neighbour-row
+// gathers are in flight per row before the first is consumed, accumulation is
+// sequential in CSR order with one fp32 accumulator per (row, feature).
+//
+//   k0     : edge score a = exp(leaky_relu(s - s)), per-dst sum S        (lane = head)
+//   k1     : out = sum_e (A/S) * feat[u]                                 (lane = VEC features)
+//   bwd    : grad_feat, grad_el and the per-edge scalar T = sum_d t      (src-major CSR)
+//   bwd_er : grad_er[v] = sum_{e in in(v)} T[e]                          (dst-major CSR)
+//
+// The reference accumulates grad_el / grad_er with fp32 atomicAdd from every
+// feature lane.  Here the sum over the D lanes of a
+// head is an in-wave butterfly (ds_swizzle/DPP via __shfl_xor) and the sum over a
+// vertex's in-edges is a second, tiny dst-major pass: no atomics, run-to-run
+// deterministic.
+#include "stg_common.hpp"
+
+namespace stg {
+
+template <int G>
+__device__ __forceinline__ int gbcast_i(int v, int src)
+{
+    if constexpr (G == 64) return __builtin_amdgcn_readlane(v, src);
+    else if constexpr (G == 1) return v;
+    else return __shfl(v, src, G);
+}
+
+struct RowInfo {
+    int r, beg, deg, max_deg;
+    bool valid;
+};
+
+template <int LOG2G>
+__device__ __forceinline__ RowInfo row_prologue(const int *__restrict__ row_offsets,
+                                                const int *__restrict__ node_ids, int N)
+{
+    constexpr int G = 1 << LOG2G;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int idx = wave_global * (kWave / G) + (lane >> LOG2G);
+    RowInfo ri{0, 0, 0, 0, idx < N};
+    if (ri.valid) {
+        ri.r = node_ids ? node_ids[idx] : idx;
+        ri.beg = row_offsets[ri.r];
+        ri.deg = row_offsets[ri.r + 1] - ri.beg;
+    }
+    ri.max_deg = __builtin_amdgcn_readfirstlane(wave_max(ri.deg));
+    return ri;
+}
+
+// ------------------------------------------------------------------------------ K0
+template <int LOG2G>
+__global__ __launch_bounds__(kBlock) void gat_k0_kernel(
+    const float *__restrict__ el, const float *__restrict__ er, float *__restrict__ A,
+    float *__restrict__ S, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, const int *__restrict__ eids,
+    const int *__restrict__ node_ids, int N, int H, int H_active, float slope)
+{
+    constexpr int G = 1 << LOG2G;
+    constexpr int U = G < 4 ? G : 4;
+    const int j = threadIdx.x & (G - 1);
+    const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+
+    for (int hbase = 0; hbase < H_active; hbase += G) {
+        const int h = hbase + j;
+        const bool hok = h < H_active;
+        const float erv = (ri.valid && hok) ? er[(int64_t)ri.r * H + h] : 0.f;
+        float acc = 0.f;
+        for (int base = 0; base < ri.max_deg; base += G) {
+            const int cnt = ri.deg - base;
+            const int cnt_max = min(G, ri.max_deg - base);
+            int c = 0, ev = 0;
+            if (j < cnt) {
+                c = column_indices[ri.beg + base + j];
+                ev = eids[ri.beg + base + j];
+            }
+            for (int k = 0; k < cnt_max; k += U) {
+                float elv[U];
+                int ek[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kk = k + u;
+                    const int ck = gbcast_i<G>(c, kk & (G - 1));
+                    ek[u] = gbcast_i<G>(ev, kk & (G - 1));
+                    elv[u] = (kk < cnt && hok) ? el[(int64_t)ck * H + h] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (k + u < cnt && hok) {
+                        const float s = elv[u] + erv;       // Add(el_inb, er_cen)
+                        const float z = s - s;              // Sub(emb, max([emb])) == emb - emb
+                        const float l = z > 0 ? z : slope * z;
+                        const float a = expf(l);
+                        A[(int64_t)ek[u] * H + h] = a;
+                        acc = acc + a;
+                    }
+                }
+            }
+        }
+        if (ri.valid && hok) S[(int64_t)ri.r * H + h] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------ K1
+template <int VEC, int LOG2G, int CHUNKS, int UNROLL>
+__global__ __launch_bounds__(kBlock) void gat_k1_kernel(
+    const float *__restrict__ A, const float *__restrict__ S, const float *__restrict__ feat,
+    float *__restrict__ out, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, const int *__restrict__ eids,
+    const int *__restrict__ node_ids, int N, int H, int D, int HD_active)
+{
+    constexpr int G = 1 << LOG2G;
+    constexpr int U = UNROLL < G ? UNROLL : G;
+    const int j = threadIdx.x & (G - 1);
+    const int HD = H * D;
+    const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+
+    for (int fbase = 0; fbase < HD_active; fbase += G * VEC * CHUNKS) {
+        float acc[CHUNKS][VEC];
+        float sv[CHUNKS];
+        int foff[CHUNKS], hh[CHUNKS];
+        bool fok[CHUNKS];
+#pragma unroll
+        for (int ch = 0; ch < CHUNKS; ++ch) {
+            foff[ch] = fbase + (ch * G + j) * VEC;
+            fok[ch] = foff[ch] < HD_active;
+            hh[ch] = fok[ch] ? foff[ch] / D : 0;
+            sv[ch] = (ri.valid && fok[ch]) ? S[(int64_t)ri.r * H + hh[ch]] : 1.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[ch][i] = 0.f;
+        }
+        for (int base = 0; base < ri.max_deg; base += G) {
+            const int cnt = ri.deg - base;
+            const int cnt_max = min(G, ri.max_deg - base);
+            int c = 0, ev = 0;
+            if (j < cnt) {
+                c = column_indices[ri.beg + base + j];
+                ev = eids[ri.beg + base + j];
+            }
+            for (int k = 0; k < cnt_max; k += U) {
+                float v[U][CHUNKS][VEC];
+                float a[U][CHUNKS];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kk = k + u;
+                    const int ck = gbcast_i<G>(c, kk & (G - 1));
+                    const int ek = gbcast_i<G>(ev, kk & (G - 1));
+                    const float *row = feat + (int64_t)ck * HD;
+#pragma unroll
+                    for (int ch = 0; ch < CHUNKS; ++ch) {
+                        if (kk < cnt && fok[ch]) {
+                            a[u][ch] = A[(int64_t)ek * H + hh[ch]];
+                            vec_load<VEC>(v[u][ch], row + foff[ch]);
+                        } else {
+                            a[u][ch] = 0.f;
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) v[u][ch][i] = 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (k + u < cnt) {
+#pragma unroll
+                        for (int ch = 0; ch < CHUNKS; ++ch) {
+                            if (fok[ch]) {
+                                const float alpha = a[u][ch] / sv[ch];          // TrueDiv(c, s)
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i)
+                                    acc[ch][i] = acc[ch][i] + alpha * v[u][ch][i];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (ri.valid) {
+            float *orow = out + (int64_t)ri.r * HD;
+#pragma unroll
+            for (int ch = 0; ch < CHUNKS; ++ch)
+                if (fok[ch]) vec_store<VEC>(orow + foff[ch], acc[ch]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ K2
+// Sum of `p` over the LH consecutive lanes that share a head.  LH is a power of two
+// (butterfly, every lane gets the total) or arbitrary (LDS staging, ascending-lane
+// order; only the head's first lane gets the total).
+template <bool POW2>
+__device__ __forceinline__ float head_sum(float p, int LH, float *lds_wave, int lane, int j, int G)
+{
+    if constexpr (POW2) {
+        for (int off = LH >> 1; off > 0; off >>= 1) p = p + __shfl_xor(p, off, 64);
+        return p;
+    } else {
+        lds_wave[lane] = p;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+        float s = 0.f;
+        for (int q = 0; q < LH && j + q < G; ++q) s = s + lds_wave[lane + q];
+        __builtin_amdgcn_wave_barrier();
+        return s;
+    }
+}
+
+template <int VEC, int LOG2G, int CHUNKS, int UNROLL, bool POW2>
+__global__ __launch_bounds__(kBlock) void gat_bwd_kernel(
+    const float *__restrict__ A, const float *__restrict__ S, const float *__restrict__ outp,
+    const float *__restrict__ g, const float *__restrict__ el, const float *__restrict__ er,
+    const float *__restrict__ feat, float *__restrict__ grad_feat, float *__restrict__ grad_el,
+    float *__restrict__ T, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, const int *__restrict__ eids,
+    const int *__restrict__ node_ids, int N, int H, int D, int HD_active, float slope)
+{
+    constexpr int G = 1 << LOG2G;
+    constexpr int U = UNROLL < G ? UNROLL : G;
+    __shared__ float lds[POW2 ? 1 : kBlock];
+    float *lds_wave = lds + (POW2 ? 0 : (threadIdx.x & ~(kWave - 1)));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int j = lane & (G - 1);
+    const int HD = H * D;
+    const int LH = D / VEC;                       // lanes per head (host guarantees D % VEC == 0)
+    const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+
+    for (int fbase = 0; fbase < HD_active; fbase += G * VEC * CHUNKS) {
+        float a13[CHUNKS][VEC], a29[CHUNKS][VEC], fu[CHUNKS][VEC];
+        float elu[CHUNKS];
+        int foff[CHUNKS], hh[CHUNKS];
+        bool fok[CHUNKS], lead[CHUNKS];
+#pragma unroll
+        for (int ch = 0; ch < CHUNKS; ++ch) {
+            foff[ch] = fbase + (ch * G + j) * VEC;
+            fok[ch] = foff[ch] < HD_active;
+            hh[ch] = foff[ch] < HD ? foff[ch] / D : 0;
+            lead[ch] = foff[ch] < HD && (foff[ch] % D) == 0;
+            elu[ch] = (ri.valid && fok[ch]) ? el[(int64_t)ri.r * H + hh[ch]] : 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { a13[ch][i] = 0.f; a29[ch][i] = 0.f; fu[ch][i] = 0.f; }
+            if (ri.valid && fok[ch]) vec_load<VEC>(fu[ch], feat + (int64_t)ri.r * HD + foff[ch]);
+        }
+        for (int base = 0; base < ri.max_deg; base += G) {
+            const int cnt = ri.deg - base;
+            const int cnt_max = min(G, ri.max_deg - base);
+            int c = 0, ev = 0;
+            if (j < cnt) {
+                c = column_indices[ri.beg + base + j];
+                ev = eids[ri.beg + base + j];
+            }
+            for (int k = 0; k < cnt_max; k += U) {
+                float gv[U][CHUNKS][VEC], ov[U][CHUNKS][VEC];
+                float av[U][CHUNKS], sv[U][CHUNKS], erv[U][CHUNKS];
+                int ek[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kk = k + u;
+                    const int ck = gbcast_i<G>(c, kk & (G - 1));
+                    ek[u] = gbcast_i<G>(ev, kk & (G - 1));
+#pragma unroll
+                    for (int ch = 0; ch < CHUNKS; ++ch) {
+                        if (kk < cnt && fok[ch]) {
+                            av[u][ch] = A[(int64_t)ek[u] * H + hh[ch]];
+                            sv[u][ch] = S[(int64_t)ck * H + hh[ch]];
+                            erv[u][ch] = er[(int64_t)ck * H + hh[ch]];
+                            vec_load<VEC>(gv[u][ch], g + (int64_t)ck * HD + foff[ch]);
+                            vec_load<VEC>(ov[u][ch], outp + (int64_t)ck * HD + foff[ch]);
+                        } else {
+                            av[u][ch] = 0.f; sv[u][ch] = 1.f; erv[u][ch] = 0.f;
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) { gv[u][ch][i] = 0.f; ov[u][ch][i] = 0.f; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool on = k + u < cnt;           // uniform within the row group
+#pragma unroll
+                    for (int ch = 0; ch < CHUNKS; ++ch) {
+                        float p = 0.f;
+                        if (on && fok[ch]) {
+                            const float V3 = av[u][ch], V4 = sv[u][ch];
+                            const float V5 = V3 / V4;
+                            const float V0 = elu[ch] + erv[u][ch];
+                            const float V1 = V0 - V0;
+                            const float V14 = 1.0f / V4;
+                            const float V24 = V1 > 0 ? 1.0f : slope;
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                const float V8 = gv[u][ch][i];
+                                a13[ch][i] = a13[ch][i] + V8 * V5;
+                                const float V15 = (V8 * fu[ch][i]) * V14;
+                                const float V17 = (V8 / V4) * ov[u][ch][i];
+                                const float V22 = V15 + (-1.0f * V17);
+                                const float V25 = (V22 * V3) * V24;
+                                a29[ch][i] = a29[ch][i] + V25;
+                                p = p + V25;
+                            }
+                        }
+                        // every lane of the wave takes part (inactive lanes contribute 0)
+                        const float tot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
+                        if (on && lead[ch] && foff[ch] < HD_active) T[(int64_t)ek[u] * H + hh[ch]] = tot;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < CHUNKS; ++ch) {
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) p = p + a29[ch][i];
+            const float tot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
+            if (ri.valid && lead[ch] && foff[ch] < HD_active) grad_el[(int64_t)ri.r * H + hh[ch]] = tot;
+            if (ri.valid && fok[ch]) vec_store<VEC>(grad_feat + (int64_t)ri.r * HD + foff[ch], a13[ch]);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------- bwd_er
+template <int LOG2G>
+__global__ __launch_bounds__(kBlock) void gat_bwd_er_kernel(
+    const float *__restrict__ T, float *__restrict__ grad_er, const int *__restrict__ row_offsets,
+    const int *__restrict__ eids, const int *__restrict__ node_ids, int N, int H, int H_active)
+{
+    constexpr int G = 1 << LOG2G;
+    constexpr int U = G < 4 ? G : 4;
+    const int j = threadIdx.x & (G - 1);
+    const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+    for (int hbase = 0; hbase < H_active; hbase += G) {
+        const int h = hbase + j;
+        const bool hok = h < H_active;
+        float acc = 0.f;
+        for (int base = 0; base < ri.max_deg; base += G) {
+            const int cnt = ri.deg - base;
+            const int cnt_max = min(G, ri.max_deg - base);
+            int ev = 0;
+            if (j < cnt) ev = eids[ri.beg + base + j];
+            for (int k = 0; k < cnt_max; k += U) {
+                float t[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kk = k + u;
+                    const int ek = gbcast_i<G>(ev, kk & (G - 1));
+                    t[u] = (kk < cnt && hok) ? T[(int64_t)ek * H + h] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (k + u < cnt && hok) acc = acc + t[u];
+            }
+        }
+        if (ri.valid && hok) grad_er[(int64_t)ri.r * H + h] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------ dispatch
+namespace {
+
+inline unsigned grid_for(int N, int log2g)
+{
+    const int rows_per_block = (kWave >> log2g) * kWavesPerBlock;
+    return (unsigned)(((int64_t)N + rows_per_block - 1) / rows_per_block);
+}
+
+struct FeatPlan {
+    int vec, log2g, chunks;
+};
+
+// Lane plan for a [H, D] feature row of which the first `active` floats are computed.
+FeatPlan plan_features(int HD, int D, int active, uintptr_t align, bool need_head_lanes)
+{
+    int vec = 1;
+    if (HD % 4 == 0 && active % 4 == 0 && D % 4 == 0 && align % 16 == 0) vec = 4;
+    else if (HD % 2 == 0 && active % 2 == 0 && D % 2 == 0 && align % 8 == 0) vec = 2;
+    (void)need_head_lanes;
+    const int lanes = (active + vec - 1) / vec;
+    int log2g = ilog2_ceil(lanes), chunks = 1;
+    if (log2g > 6) {
+        log2g = 6;
+        chunks = ((lanes + kWave - 1) / kWave) >= 3 ? 4 : 2;
+    }
+    return {vec, log2g, chunks};
+}
+
+#define STG_SWITCH_LOG2G(L, ...)                       \
+    switch (L) {                                       \
+        case 0: { constexpr int LG = 0; __VA_ARGS__; break; } \
+        case 1: { constexpr int LG = 1; __VA_ARGS__; break; } \
+        case 2: { constexpr int LG = 2; __VA_ARGS__; break; } \
+        case 3: { constexpr int LG = 3; __VA_ARGS__; break; } \
+        case 4: { constexpr int LG = 4; __VA_ARGS__; break; } \
+        case 5: { constexpr int LG = 5; __VA_ARGS__; break; } \
+        default: { constexpr int LG = 6; __VA_ARGS__; break; } \
+    }
+
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_gat_fwd_k0(const float *el, const float *er, float *A, float *S,
+                              const int32_t *row_offsets, const int32_t *column_indices,
+                              const int32_t *eids, const int32_t *node_ids, int32_t N, int32_t H,
+                              int32_t H_active, float slope, void *stream)
+{
+    using namespace stg;
+    if (N < 0 || H <= 0 || H_active < 0 || H_active > H)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k0: bad shape N=%d H=%d H_active=%d", N, H, H_active);
+    if (N == 0 || H_active == 0) return 0;
+    if (!el || !er || !A || !S || !row_offsets || !column_indices || !eids)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k0: NULL pointer argument");
+    const int log2g = std::min(6, ilog2_ceil(H_active));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    STG_SWITCH_LOG2G(log2g, hipLaunchKernelGGL((gat_k0_kernel<LG>), dim3(grid_for(N, LG)), dim3(kBlock), 0, st,
+                                               el, er, A, S, row_offsets, column_indices, eids, node_ids,
+                                               N, H, H_active, slope));
+    return check_launch("stg_gat_fwd_k0");
+}
+
+extern "C" int stg_gat_fwd_k1(const float *A, const float *S, const float *feat, float *out,
+                              const int32_t *row_offsets, const int32_t *column_indices,
+                              const int32_t *eids, const int32_t *node_ids, int32_t N, int32_t H,
+                              int32_t D, int32_t HD_active, void *stream)
+{
+    using namespace stg;
+    if (N < 0 || H <= 0 || D <= 0 || HD_active < 0 || (int64_t)HD_active > (int64_t)H * D)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k1: bad shape N=%d H=%d D=%d HD_active=%d", N, H, D, HD_active);
+    if (N == 0 || HD_active == 0) return 0;
+    if (!A || !S || !feat || !out || !row_offsets || !column_indices || !eids)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k1: NULL pointer argument");
+    const uintptr_t align = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out);
+    const FeatPlan p = plan_features(H * D, D, HD_active, align, false);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define STG_K1(VEC, CH, UN)                                                                              \
+    STG_SWITCH_LOG2G(p.chunks > 1 ? 6 : p.log2g,                                                         \
+                     hipLaunchKernelGGL((gat_k1_kernel<VEC, (CH > 1 ? 6 : LG), CH, UN>),                 \
+                                        dim3(grid_for(N, (CH > 1 ? 6 : LG))), dim3(kBlock), 0, st, A, S, \
+                                        feat, out, row_offsets, column_indices, eids, node_ids, N, H, D, \
+                                        HD_active))
+#define STG_K1_VEC(VEC)                          \
+    if (p.chunks == 4) { STG_K1(VEC, 4, 2); }    \
+    else if (p.chunks == 2) { STG_K1(VEC, 2, 4); } \
+    else { STG_K1(VEC, 1, 8); }
+    if (p.vec == 4) { STG_K1_VEC(4) } else if (p.vec == 2) { STG_K1_VEC(2) } else { STG_K1_VEC(1) }
+#undef STG_K1_VEC
+#undef STG_K1
+    return check_launch("stg_gat_fwd_k1");
+}
+
+extern "C" int stg_gat_bwd(const float *A, const float *S, const float *out, const float *g,
+                           const float *el, const float *er, const float *feat, float *grad_feat,
+                           float *grad_el, float *T, const int32_t *row_offsets,
+                           const int32_t *column_indices, const int32_t *eids,
+                           const int32_t *node_ids, int32_t N, int32_t H, int32_t D,
+                           int32_t HD_active, float slope, void *stream)
+{
+    using namespace stg;
+    if (N < 0 || H <= 0 || D <= 0 || HD_active < 0 || (int64_t)HD_active > (int64_t)H * D)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd: bad shape N=%d H=%d D=%d HD_active=%d", N, H, D, HD_active);
+    if (N == 0 || HD_active == 0) return 0;
+    if (!A || !S || !out || !g || !el || !er || !feat || !grad_feat || !grad_el || !T ||
+        !row_offsets || !column_indices || !eids)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd: NULL pointer argument");
+    const uintptr_t align = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
+                            reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(grad_feat);
+    const FeatPlan p = plan_features(H * D, D, HD_active, align, true);
+    const int LH = D / p.vec;
+    // butterfly needs: power-of-two lanes per head that tile the row group exactly
+    const bool pow2 = (LH & (LH - 1)) == 0 && LH <= (1 << p.log2g);
+    // a head must live inside one row-group chunk, otherwise its per-edge sum would be split
+    if (LH > kWave || (!pow2 && (HD_active + p.vec - 1) / p.vec > kWave))
+        return fail(STG_ERR_UNSUPPORTED,
+                    "stg_gat_bwd: head width D=%d (H=%d) is outside the supported range "
+                    "(D/vec <= 64; non power-of-two D/vec needs H*D/vec <= 64)", D, H);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define STG_K2(VEC, CH, UN, P2)                                                                          \
+    STG_SWITCH_LOG2G(p.chunks > 1 ? 6 : p.log2g,                                                         \
+                     hipLaunchKernelGGL((gat_bwd_kernel<VEC, (CH > 1 ? 6 : LG), CH, UN, P2>),            \
+                                        dim3(grid_for(N, (CH > 1 ? 6 : LG))), dim3(kBlock), 0, st, A, S, \
+                                        out, g, el, er, feat, grad_feat, grad_el, T, row_offsets,        \
+                                        column_indices, eids, node_ids, N, H, D, HD_active, slope))
+#define STG_K2_VEC(VEC, P2)                          \
+    if (p.chunks == 4) { STG_K2(VEC, 4, 2, P2); }    \
+    else if (p.chunks == 2) { STG_K2(VEC, 2, 2, P2); } \
+    else { STG_K2(VEC, 1, 4, P2); }
+    if (pow2) {
+        if (p.vec == 4) { STG_K2_VEC(4, true) } else if (p.vec == 2) { STG_K2_VEC(2, true) } else { STG_K2_VEC(1, true) }
+    } else {
+        if (p.vec == 4) { STG_K2_VEC(4, false) } else if (p.vec == 2) { STG_K2_VEC(2, false) } else { STG_K2_VEC(1, false) }
+    }
+#undef STG_K2_VEC
+#undef STG_K2
+    return check_launch("stg_gat_bwd");
+}
+
+extern "C" int stg_gat_bwd_er(const float *T, float *grad_er, const int32_t *row_offsets,
+                              const int32_t *eids, const int32_t *node_ids, int32_t N, int32_t H,
+                              int32_t H_active, void *stream)
+{
+    using namespace stg;
+    if (N < 0 || H <= 0 || H_active < 0 || H_active > H)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_er: bad shape N=%d H=%d H_active=%d", N, H, H_active);
+    if (N == 0 || H_active == 0) return 0;
+    if (!T || !grad_er || !row_offsets || !eids)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_er: NULL pointer argument");
+    const int log2g = std::min(6, ilog2_ceil(H_active));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    STG_SWITCH_LOG2G(log2g, hipLaunchKernelGGL((gat_bwd_er_kernel<LG>), dim3(grid_for(N, LG)), dim3(kBlock), 0, st,
+                                               T, grad_er, row_offsets, eids, node_ids, N, H, H_active));
+    return check_launch("stg_gat_bwd_er");
+}

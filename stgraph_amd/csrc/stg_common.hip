@@ -1,0 +1,59 @@
+// Error reporting, ABI version and tuning knobs of libstgraph_hip.so.
+#include "stg_common.hpp"
+
+#include <cstring>
+
+namespace stg {
+
+char *last_error_buffer()
+{
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(static_cast<int>(e), "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+Tuning &tuning()
+{
+    static Tuning t;
+    return t;
+}
+
+}  // namespace stg
+
+extern "C" int stg_abi_version(void) { return STG_ABI_VERSION; }
+
+extern "C" const char *stg_last_error_string(void) { return stg::last_error_buffer(); }
+
+extern "C" int stg_set_tuning(const char *key, int value)
+{
+    using namespace stg;
+    if (!key) return fail(STG_ERR_INVALID_ARGUMENT, "stg_set_tuning: NULL key");
+    if (!std::strcmp(key, "gcn_lanes_per_row")) {
+        if (value != 0 && (value < 1 || value > 64 || (value & (value - 1))))
+            return fail(STG_ERR_INVALID_ARGUMENT, "gcn_lanes_per_row must be 0 or a power of two <= 64");
+        tuning().gcn_lanes_per_row = value;
+        return 0;
+    }
+    if (!std::strcmp(key, "gcn_unroll")) {
+        if (value != 0 && value != 2 && value != 4 && value != 8)
+            return fail(STG_ERR_INVALID_ARGUMENT, "gcn_unroll must be 0, 2, 4 or 8");
+        tuning().gcn_unroll = value;
+        return 0;
+    }
+    return fail(STG_ERR_INVALID_ARGUMENT, "stg_set_tuning: unknown key '%s'", key);
+}

@@ -1,0 +1,143 @@
+"""``NaiveGraph`` -- per-snapshot CSR dynamic graph, drop-in for
+``stgraph.graph.NaiveGraph`` (reference graph/dynamic/naive/naive_graph.py:12-151).
+
+The reference builds T forward + T backward CSRs on the host up front and keeps
+all 2T resident on the GPU; moving between timestamps only swaps pointers.  Here a
+snapshot's CSR pair is built ON THE DEVICE (``stg_graph_build_device``: radix sort
++ binary search) -- either all up front (``resident=True``, the reference's memory
+behaviour) or on first use (``resident=False``: "per-snapshot CSR rebuild", with
+``max_cached`` most-recent snapshots kept so that a BPTT window can walk back
+through the snapshots its forward pass just used).  ``graph_type()`` is ``'csr'``:
+kernels visit rows in ``node_ids`` (degree-descending) order, as tpl_fa_csr.jinja does.
+
+``_get_cached_graph`` implements the intended semantics (SURVEY.md Appendix A, D5:
+the reference's override lacks the ``timestamp`` parameter and raises TypeError).
+"""
+from __future__ import annotations
+
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .... import kernels
+from ...static.csr import _LIVE, default_device
+from ...static.static_graph import count_distinct_edges, edge_arrays, reorder_inplace
+from ..dynamic_graph import DynamicGraph
+
+
+class NaiveGraph(DynamicGraph):
+    def __init__(self, edge_list, max_num_nodes: int, device=None, resident: bool = True,
+                 max_cached: int | None = None, sort_inplace: bool = True):
+        super().__init__(edge_list, max_num_nodes)
+        self._device = torch.device(device) if device is not None else default_device()
+        self._sort_inplace = sort_inplace
+        self._resident = bool(resident)
+        self._max_cached = max_cached
+        self._snapshots: "OrderedDict[int, kernels.GraphCSR]" = OrderedDict()
+        self._edges = []                       # per-t (src, dst) device tensors in caller order
+        t0 = time.time()
+        for t in range(self._num_timestamps):
+            s, d = edge_arrays(edge_list[t])
+            to = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(a)).to(  # noqa: E731
+                device=self._device, dtype=torch.int32)
+            self._edges.append((to(s), to(d)))
+        self.move_to_gpu_time += time.time() - t0
+        self.build_count = 0
+        self.build_time = 0.0
+        if self._resident:
+            for t in range(self._num_timestamps):
+                self._snapshot(t)
+        self._update_count = 0
+        self._total_update_time = 0
+        self._gpu_move_time = 0
+        if self._num_timestamps:
+            self._get_graph_csr_ptrs(0)
+
+    # -- snapshot store -------------------------------------------------------------------------
+    def _snapshot(self, t: int) -> kernels.GraphCSR:
+        g = self._snapshots.get(t)
+        if g is None:
+            t0 = time.time()
+            s, d = self._edges[t]
+            g = kernels.build_graph_csr(s, d, self.max_num_nodes, self._device)
+            self.build_count += 1
+            if t not in self._distinct_edges:
+                self._distinct_edges[t] = count_distinct_edges(g)
+                if self._sort_inplace and g.num_edges:
+                    reorder_inplace(self._edge_list_ref[t], g.perm_fwd.cpu().numpy())
+                    self._edges[t] = (s[g.perm_fwd], d[g.perm_fwd])     # keep in step with the caller's list
+                    g.perm_fwd = torch.arange(g.num_edges, device=self._device)
+            self._snapshots[t] = g
+            self.build_time += time.time() - t0
+            if not self._resident and self._max_cached is not None:
+                while len(self._snapshots) > max(1, self._max_cached):
+                    self._snapshots.popitem(last=False)
+        else:
+            self._snapshots.move_to_end(t)
+        return g
+
+    def _num_edges_at(self, timestamp: int) -> int:
+        if timestamp not in self._distinct_edges:
+            self._snapshot(timestamp)
+        return self._distinct_edges[timestamp]
+
+    def csr(self, direction: str, timestamp=None) -> kernels.DeviceCSR:
+        g = self._snapshot(self.current_timestamp if timestamp is None else timestamp)
+        return g.fwd if direction == "fwd" else g.bwd
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    def graph_type(self) -> str:
+        return "csr"
+
+    def _cache_graph(self) -> None:
+        pass
+
+    def _get_cached_graph(self, timestamp=None) -> bool:
+        return False
+
+    def in_degrees(self) -> np.ndarray:
+        return self._snapshot(self.current_timestamp).in_degrees.cpu().numpy().astype("int32")
+
+    def out_degrees(self) -> np.ndarray:
+        return self._snapshot(self.current_timestamp).out_degrees.cpu().numpy().astype("int32")
+
+    def in_degrees_tensor(self) -> torch.Tensor:
+        """Device-resident in-degrees of the current snapshot (avoids the D2H copy of ``in_degrees``)."""
+        return self._snapshot(self.current_timestamp).in_degrees
+
+    def _get_graph_csr_ptrs(self, timestamp: int) -> None:
+        g = self._snapshot(timestamp)
+        if self._is_backprop_state:
+            b = g.bwd
+            self.bwd_row_offset_ptr, self.bwd_column_indices_ptr = b.row_offset_ptr, b.column_indices_ptr
+            self.bwd_eids_ptr, self.bwd_node_ids_ptr = b.eids_ptr, b.node_ids_ptr
+            c = b
+        else:
+            f = g.fwd
+            self.fwd_row_offset_ptr, self.fwd_column_indices_ptr = f.row_offset_ptr, f.column_indices_ptr
+            self.fwd_eids_ptr, self.fwd_node_ids_ptr = f.eids_ptr, f.node_ids_ptr
+            c = f
+        for t in (c.row_offset, c.column_indices, c.eids, c.node_ids):
+            _LIVE[t.data_ptr()] = t
+
+    def _on_timestamp_change(self) -> None:
+        if self._num_timestamps:
+            self._get_graph_csr_ptrs(self.current_timestamp)
+
+    def _update_graph_forward(self) -> None:
+        if self.current_timestamp + 1 >= self._num_timestamps:
+            raise RuntimeError("⏰ Invalid timestamp during STGraphBase.update_graph_forward()")
+        self._get_graph_csr_ptrs(self.current_timestamp + 1)
+
+    def _init_reverse_graph(self) -> None:
+        self._get_graph_csr_ptrs(self.current_timestamp)
+
+    def _update_graph_backward(self) -> None:
+        if self.current_timestamp < 0:
+            raise RuntimeError("⏰ Invalid timestamp during STGraphBase.update_graph_backward()")
+        self._get_graph_csr_ptrs(self.current_timestamp - 1)

@@ -1,0 +1,313 @@
+"""Tensor-level launch wrappers over the C ABI (include/stgraph_hip.h).
+
+PyTorch is used for device memory and the current HIP stream only; all compute
+on this path happens in libstgraph_hip.so.  Every wrapper validates shapes,
+dtypes, contiguity and device placement on the host BEFORE launching (a faulting
+kernel can take the whole node down), and raises instead of falling back.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _C
+
+_REF_COMPAT = False
+
+
+def set_reference_compat(enabled: bool) -> None:
+    """Reproduce reference defect D1.
+
+    The reference's launch geometry (compiler/execution_unit.py:92-106) computes
+    only the first ``2**floor(log2 F)`` feature columns when F < 64 is not a power
+    of two and leaves the rest zero.  Off (default): all F columns are computed.
+    """
+    global _REF_COMPAT
+    _REF_COMPAT = bool(enabled)
+
+
+def reference_compat() -> bool:
+    return _REF_COMPAT
+
+
+def ref_active_columns(feat_size: int) -> int:
+    """Columns the reference computes (execution_unit.py:92-116)."""
+    if feat_size >= 64:
+        return feat_size
+    ub = 64
+    while ub > feat_size:
+        ub //= 2
+    return max(ub, 1)
+
+
+def active_columns(feat_size: int) -> int:
+    return ref_active_columns(feat_size) if _REF_COMPAT else feat_size
+
+
+# ----------------------------------------------------------------------- launch timing
+_TIMING: list | None = None
+
+
+def enable_launch_timing(records: list | None) -> None:
+    """Bracket every aggregation launch with HIP events on its own stream (bench.py uses this
+    to measure the dominant kernel inside the timed region).  ``None`` switches it off."""
+    global _TIMING
+    _TIMING = records
+
+
+def gcn_agg_algorithmic_bytes(N: int, E: int, F: int, edge_weighted: bool) -> int:
+    """neighbour-row gather + output + row_offsets + column_indices +
+    norm[col] per edge + norm[row] (+ eids and weights)."""
+    return 4 * E * F + 4 * N * F + 4 * (N + 1) + 4 * E + 4 * E + 4 * N + (8 * E if edge_weighted else 0)
+
+
+# --------------------------------------------------------------------------- helpers
+def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} lives on {t.device}; the Seastar kernels run only on an MI355X (HIP) device "
+            "and stgraph_amd has no CPU fallback")
+
+
+def _f32(t: torch.Tensor, name: str, device: torch.device | None = None) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    _require_gpu(t, name)
+    if device is not None and t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    return t if t.is_contiguous() else t.contiguous()       # reference defect D6: raw data_ptr of strided grads
+
+
+def _ptr(t: torch.Tensor | None) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ------------------------------------------------------------------------------- CSR
+@dataclass
+class DeviceCSR:
+    """One CSR (the four arrays of the reference's ``CSR`` object, csr.cu:35-59)."""
+
+    row_offset: torch.Tensor       # int32 [N+1]
+    column_indices: torch.Tensor   # int32 [E]
+    eids: torch.Tensor             # int32 [E]
+    node_ids: torch.Tensor         # int32 [N]  rows by non-increasing degree
+
+    @property
+    def num_nodes(self) -> int:
+        return self.row_offset.shape[0] - 1
+
+    @property
+    def num_edges(self) -> int:
+        return self.column_indices.shape[0]
+
+    # attribute names of the pybind class (csr.cu:186-189)
+    @property
+    def row_offset_ptr(self) -> int:
+        return self.row_offset.data_ptr()
+
+    @property
+    def column_indices_ptr(self) -> int:
+        return self.column_indices.data_ptr()
+
+    @property
+    def eids_ptr(self) -> int:
+        return self.eids.data_ptr()
+
+    @property
+    def node_ids_ptr(self) -> int:
+        return self.node_ids.data_ptr()
+
+
+@dataclass
+class GraphCSR:
+    """Forward (dst-major) + backward (src-major) CSR of one graph / snapshot."""
+
+    num_nodes: int
+    fwd: DeviceCSR
+    bwd: DeviceCSR
+    in_degrees: torch.Tensor       # int32 [N]
+    out_degrees: torch.Tensor      # int32 [N]
+    perm_fwd: torch.Tensor         # int64 [E]: caller position of the edge that became eid j
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def num_edges(self) -> int:
+        return self.fwd.num_edges
+
+
+def _as_i32(a, device: torch.device) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32))
+    return t.to(device=device, dtype=torch.int32).contiguous()
+
+
+def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str) -> GraphCSR:
+    """Build both CSRs of a graph from (src, dst) arrays (static_graph.py:40-78).
+
+    ``device`` cuda -> stg_graph_build_device (sort + search on the GPU, stream
+    ordered); ``device`` cpu -> stg_graph_build_host (host arrays; used for host
+    logic tests and as the upload source the reference itself uses).
+    """
+    device = torch.device(device)
+    N = int(num_nodes)
+    s, d = _as_i32(src, device), _as_i32(dst, device)
+    if s.dim() != 1 or s.shape != d.shape:
+        raise ValueError("src and dst must be 1-D arrays of equal length")
+    E = int(s.shape[0])
+    if N < 0:
+        raise ValueError("num_nodes must be >= 0")
+    i32 = dict(dtype=torch.int32, device=device)
+    perm = torch.empty(E, dtype=torch.int64, device=device)
+    fwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32))
+    bwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32))
+    indeg, outdeg = torch.empty(N, **i32), torch.empty(N, **i32)
+    arrays = [perm, fwd.row_offset, fwd.column_indices, fwd.eids, fwd.node_ids,
+              bwd.row_offset, bwd.column_indices, bwd.eids, bwd.node_ids, indeg, outdeg]
+    if device.type == "cuda":
+        ws_bytes = int(_C.lib.stg_graph_build_device_workspace_bytes(E, N))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        status = torch.empty(1, **i32)
+        with torch.cuda.device(device):
+            _C.check(_C.lib.stg_graph_build_device(
+                _ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays],
+                _ptr(status), _ptr(ws), ws_bytes, _stream_ptr(device)))
+        code = int(status.item())          # one 4-byte sync per graph build, for endpoint validation
+        if code != 0:
+            raise ValueError(f"edge endpoint outside [0, {N}) (libstgraph_hip status {code})")
+    else:
+        _C.check(_C.lib.stg_graph_build_host(_ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays]))
+    return GraphCSR(N, fwd, bwd, indeg, outdeg, perm)
+
+
+def csr_ctor_host(a, b, eid, edge_weight, num_nodes: int, is_edge_reverse: bool = False):
+    """Host counterpart of the pybind ``CSR`` constructor (csr.cu:68-157); numpy in/out."""
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    eid = np.ascontiguousarray(eid, dtype=np.int32)
+    E, N = int(a.shape[0]), int(num_nodes)
+    ew = None if edge_weight is None else np.ascontiguousarray(edge_weight, dtype=np.float32)
+    if ew is not None and ew.shape[0] < E:
+        raise ValueError("edge_weight shorter than the edge list")
+    out = dict(
+        row_offset=np.empty(N + 1, np.int32), column_indices=np.empty(E, np.int32),
+        eids=np.empty(E, np.int32), node_ids=np.empty(N, np.int32),
+        in_degrees=np.empty(N, np.int32), out_degrees=np.empty(N, np.int32),
+        weighted_out_degrees=np.empty(N, np.float32))
+    p = lambda x: ctypes.c_void_p(0 if x is None else x.ctypes.data)  # noqa: E731
+    _C.check(_C.lib.stg_csr_ctor_host(p(a), p(b), p(eid), p(ew), E, N, int(bool(is_edge_reverse)),
+                                      *[p(v) for v in out.values()]))
+    return out
+
+
+# ------------------------------------------------------------------------------- GCN
+def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr: DeviceCSR,
+            ew: torch.Tensor | None = None, use_node_ids: bool = False,
+            f_active: int | None = None) -> torch.Tensor:
+    """out[r,:] = norm_row[r] * sum_e (norm_col[c] * x[c,:]) * ew[eid]   (stg_gcn_agg)."""
+    x = _f32(x, "x")
+    dev = x.device
+    N = csr.num_nodes
+    if x.dim() < 1 or x.shape[0] != N:
+        raise ValueError(f"x has {x.shape[0] if x.dim() else 0} rows, graph has {N} nodes")
+    F = int(x[0].numel()) if N > 0 else int(np.prod(x.shape[1:]))
+    if F <= 0:
+        raise ValueError("empty feature dimension")
+    norm_row, norm_col = _f32(norm_row, "norm_row", dev), _f32(norm_col, "norm_col", dev)
+    if norm_row.numel() != N or norm_col.numel() != N:
+        raise ValueError("norm tensors must hold one value per node")
+    if csr.row_offset.device != dev:
+        raise RuntimeError(f"graph arrays are on {csr.row_offset.device}, features on {dev}")
+    if ew is not None:
+        ew = _f32(ew, "edge_weight", dev)
+        if ew.numel() < csr.num_edges:
+            raise ValueError(f"edge_weight has {ew.numel()} entries, graph has {csr.num_edges} edges")
+    fa = F if f_active is None else int(f_active)
+    out = (torch.empty_like(x) if fa == F else torch.zeros_like(x))
+    with torch.cuda.device(dev):
+        if _TIMING is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _C.check(_C.lib.stg_gcn_agg(
+            _ptr(x), _ptr(norm_row), _ptr(norm_col), _ptr(ew), _ptr(out),
+            _ptr(csr.row_offset), _ptr(csr.column_indices), _ptr(csr.eids),
+            _ptr(csr.node_ids if use_node_ids else None), N, F, fa, _stream_ptr(dev)))
+        if _TIMING is not None:
+            e1.record()
+            _TIMING.append(("gcn_agg", e0, e1, gcn_agg_algorithmic_bytes(N, csr.num_edges, fa, ew is not None),
+                            csr.num_edges * fa))
+    return out
+
+
+# ------------------------------------------------------------------------------- GAT
+def gat_fwd(el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor, csr: DeviceCSR,
+            slope: float, use_node_ids: bool = False):
+    """Forward units K0 + K1.  Returns (out[N,H,D], A[E,H,1], S[N,H,1])."""
+    feat = _f32(feat, "feat_src")
+    dev = feat.device
+    if feat.dim() != 3:
+        raise ValueError("feat_src must be [N, H, D]")
+    N, H, D = feat.shape
+    el, er = _f32(el, "el", dev), _f32(er, "er", dev)
+    if N != csr.num_nodes or el.numel() != N * H or er.numel() != N * H:
+        raise ValueError("el/er must be [N, H, 1] and match the graph")
+    if csr.row_offset.device != dev:
+        raise RuntimeError(f"graph arrays are on {csr.row_offset.device}, features on {dev}")
+    E = csr.num_edges
+    h_act, hd_act = active_columns(H), active_columns(H * D)
+    full = (h_act == H and hd_act == H * D)
+    alloc = torch.empty if full else torch.zeros
+    A = alloc((E, H, 1), dtype=torch.float32, device=dev)
+    S = alloc((N, H, 1), dtype=torch.float32, device=dev)
+    out = alloc((N, H, D), dtype=torch.float32, device=dev)
+    nid = _ptr(csr.node_ids if use_node_ids else None)
+    with torch.cuda.device(dev):
+        st = _stream_ptr(dev)
+        _C.check(_C.lib.stg_gat_fwd_k0(_ptr(el), _ptr(er), _ptr(A), _ptr(S), _ptr(csr.row_offset),
+                                       _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, h_act,
+                                       float(slope), st))
+        _C.check(_C.lib.stg_gat_fwd_k1(_ptr(A), _ptr(S), _ptr(feat), _ptr(out), _ptr(csr.row_offset),
+                                       _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, D, hd_act, st))
+    return out, A, S
+
+
+def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: float,
+            use_node_ids: bool = False):
+    """Backward unit K2 (+ the dst-major grad_er pass).  Returns (grad_feat, grad_el, grad_er)."""
+    feat = _f32(feat, "feat_src")
+    dev = feat.device
+    N, H, D = feat.shape
+    A, S, out, g, el, er = (_f32(t, n, dev) for t, n in
+                            ((A, "A"), (S, "S"), (out, "out"), (g, "grad_out"), (el, "el"), (er, "er")))
+    if g.shape != feat.shape or out.shape != feat.shape:
+        raise ValueError("grad_out / out must be [N, H, D]")
+    E = bwd.num_edges
+    if A.numel() != E * H or S.numel() != N * H or fwd.num_edges != E or bwd.num_nodes != N:
+        raise ValueError("A/S do not match the graph")
+    h_act, hd_act = active_columns(H), active_columns(H * D)
+    full = (h_act == H and hd_act == H * D)
+    alloc = torch.empty if full else torch.zeros
+    grad_feat = alloc((N, H, D), dtype=torch.float32, device=dev)
+    grad_el = alloc((N, H, 1), dtype=torch.float32, device=dev)
+    grad_er = alloc((N, H, 1), dtype=torch.float32, device=dev)
+    T = alloc((E, H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _stream_ptr(dev)
+        _C.check(_C.lib.stg_gat_bwd(
+            _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(el), _ptr(er), _ptr(feat),
+            _ptr(grad_feat), _ptr(grad_el), _ptr(T), _ptr(bwd.row_offset), _ptr(bwd.column_indices),
+            _ptr(bwd.eids), _ptr(bwd.node_ids if use_node_ids else None), N, H, D, hd_act,
+            float(slope), st))
+        # heads the backward unit touched: those with at least one active feature column
+        h_touched = H if full else min(H, (hd_act + D - 1) // D)
+        _C.check(_C.lib.stg_gat_bwd_er(_ptr(T), _ptr(grad_er), _ptr(fwd.row_offset), _ptr(fwd.eids),
+                                       _ptr(fwd.node_ids if use_node_ids else None), N, H, h_touched, st))
+    return grad_feat, grad_el, grad_er

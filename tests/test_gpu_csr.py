@@ -1,0 +1,86 @@
+"""GPU parity of the device CSR builder (stg_graph_build_device): bit-exact integers."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stg_oracle as orc
+from tests.util import golden, random_graph
+
+pytestmark = pytest.mark.gpu
+KEYS = ("row_offset", "column_indices", "eids")
+
+
+def _check(g, og):
+    for side, c, oc in (("fwd", g.fwd, og.fwd), ("bwd", g.bwd, og.bwd)):
+        for k in KEYS + ("node_ids",):
+            assert np.array_equal(getattr(c, k).cpu().numpy(), getattr(oc, k)), (side, k)
+    assert np.array_equal(g.in_degrees.cpu().numpy(), og.in_degrees())
+    assert np.array_equal(g.out_degrees.cpu().numpy(), og.out_degrees())
+    assert np.array_equal(g.perm_fwd.cpu().numpy(), og.perm_fwd)
+
+
+@pytest.mark.parametrize("tag", ["n1", "n5", "n64", "n2708"])
+def test_golden(cuda, tag):
+    from stgraph_amd import kernels
+    d = golden(f"csr_{tag}.npz")
+    n = int(d["num_nodes"])
+    g = kernels.build_graph_csr(d["src"], d["dst"], n, cuda)
+    for side, c in (("fwd", g.fwd), ("bwd", g.bwd)):
+        for k in KEYS:
+            assert np.array_equal(getattr(c, k).cpu().numpy(), d[f"{side}_{k}"]), (side, k)
+        # node_ids: the reference's tie order is unspecified (std::sort) => permutation + monotone degrees
+        nid = c.node_ids.cpu().numpy()
+        deg = np.diff(c.row_offset.cpu().numpy())
+        assert sorted(nid.tolist()) == list(range(n)) and np.all(np.diff(deg[nid]) <= 0)
+    assert np.array_equal(g.in_degrees.cpu().numpy(), d["in_degrees"])
+    assert np.array_equal(g.out_degrees.cpu().numpy(), d["out_degrees"])
+    pair = np.stack([d["src"], d["dst"]], 1)[g.perm_fwd.cpu().numpy()]
+    assert np.array_equal(pair, d["sorted_inplace"])
+
+
+@pytest.mark.parametrize("n,e,dup", [(1, 0, False), (7, 0, False), (2, 4, False), (50, 600, True),
+                                     (1000, 20000, False), (70000, 300000, True), (300000, 2000000, False)])
+def test_oracle_random(cuda, n, e, dup):
+    from stgraph_amd import kernels
+    if e == 0:
+        src = dst = np.empty(0, np.int32)
+    else:
+        src, dst = random_graph(n + e, n, e, duplicates=dup, hub=e > 100)
+    g = kernels.build_graph_csr(src, dst, n, cuda)
+    _check(g, orc.build_graph(src, dst, n))
+
+
+def test_vertex_out_of_range_is_reported(cuda):
+    from stgraph_amd import kernels
+    with pytest.raises(ValueError):
+        kernels.build_graph_csr(np.array([0, 5], np.int32), np.array([1, 1], np.int32), 3, cuda)
+
+
+def test_full_size_properties(cuda):
+    """16M-edge build: sortedness, permutation and degree checksums instead of a CPU recomputation."""
+    from stgraph_amd import kernels
+    n, e = 1_000_000, 16_000_000
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    src = torch.randint(0, n, (e,), generator=gen, device=cuda, dtype=torch.int32)
+    dst = torch.randint(0, n, (e,), generator=gen, device=cuda, dtype=torch.int32)
+    g = kernels.build_graph_csr(src, dst, n, cuda)
+    for csr, rows_in, cols_in in ((g.fwd, dst, src), (g.bwd, src, dst)):
+        ro = csr.row_offset.long()
+        assert ro[0] == 0 and ro[-1] == e and bool((ro[1:] >= ro[:-1]).all())
+        rows = torch.repeat_interleave(torch.arange(n, device=cuda), ro[1:] - ro[:-1])
+        key = rows * n + csr.column_indices.long()
+        assert bool((key[1:] >= key[:-1]).all())                       # (row, col) sorted
+        assert torch.equal(torch.sort(rows_in.long() * n + cols_in.long()).values, key)   # same multiset
+    assert torch.equal(g.fwd.eids.long(), torch.arange(e, device=cuda))
+    assert torch.equal(torch.sort(g.bwd.eids.long()).values, torch.arange(e, device=cuda))
+    # eids of the backward CSR point at the forward position of the same (src, dst) pair
+    rows_b = torch.repeat_interleave(torch.arange(n, device=cuda), (g.bwd.row_offset[1:] - g.bwd.row_offset[:-1]).long())
+    rows_f = torch.repeat_interleave(torch.arange(n, device=cuda), (g.fwd.row_offset[1:] - g.fwd.row_offset[:-1]).long())
+    be = g.bwd.eids.long()
+    assert torch.equal(g.fwd.column_indices.long()[be], rows_b) and torch.equal(rows_f[be], g.bwd.column_indices.long())
+    assert torch.equal(src.long()[g.perm_fwd], g.fwd.column_indices.long())
+    assert int(g.in_degrees.sum()) == e and int(g.out_degrees.sum()) == e
+    for csr in (g.fwd, g.bwd):
+        deg = (csr.row_offset[1:] - csr.row_offset[:-1])[csr.node_ids.long()]
+        assert bool((deg[1:] <= deg[:-1]).all())
+        assert torch.equal(torch.sort(csr.node_ids.long()).values, torch.arange(n, device=cuda))
