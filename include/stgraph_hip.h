@@ -106,7 +106,8 @@ int stg_graph_build_device(const int32_t *src, const int32_t *dst, int64_t E, in
  * backward: src-major CSR, x = grad_out, norm_row = norm_col = norm
  * ew may be NULL; node_ids may be NULL ('csr_unsorted' graphs) or the row
  * processing order of 'csr' graphs (tpl_fa_csr.jinja:13-18).
- * x and out rows have stride F floats and must be 16-byte aligned.
+ * x and out rows have stride F floats.  Edge arrays (column_indices, eids, ew) may be
+ * NULL only for a graph without edges.
  */
 int stg_gcn_agg(const float *x, const float *norm_row, const float *norm_col, const float *ew,
                 float *out,

@@ -405,7 +405,7 @@ extern "C" int stg_gat_fwd_k0(const float *el, const float *er, float *A, float 
     if (N < 0 || H <= 0 || H_active < 0 || H_active > H)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k0: bad shape N=%d H=%d H_active=%d", N, H, H_active);
     if (N == 0 || H_active == 0) return 0;
-    if (!el || !er || !A || !S || !row_offsets || !column_indices || !eids)
+    if (!el || !er || !S || !row_offsets)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k0: NULL pointer argument");
     const int log2g = std::min(6, ilog2_ceil(H_active));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -424,7 +424,7 @@ extern "C" int stg_gat_fwd_k1(const float *A, const float *S, const float *feat,
     if (N < 0 || H <= 0 || D <= 0 || HD_active < 0 || (int64_t)HD_active > (int64_t)H * D)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k1: bad shape N=%d H=%d D=%d HD_active=%d", N, H, D, HD_active);
     if (N == 0 || HD_active == 0) return 0;
-    if (!A || !S || !feat || !out || !row_offsets || !column_indices || !eids)
+    if (!S || !feat || !out || !row_offsets)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k1: NULL pointer argument");
     const uintptr_t align = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out);
     const FeatPlan p = plan_features(H * D, D, HD_active, align, false);
@@ -456,8 +456,7 @@ extern "C" int stg_gat_bwd(const float *A, const float *S, const float *out, con
     if (N < 0 || H <= 0 || D <= 0 || HD_active < 0 || (int64_t)HD_active > (int64_t)H * D)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd: bad shape N=%d H=%d D=%d HD_active=%d", N, H, D, HD_active);
     if (N == 0 || HD_active == 0) return 0;
-    if (!A || !S || !out || !g || !el || !er || !feat || !grad_feat || !grad_el || !T ||
-        !row_offsets || !column_indices || !eids)
+    if (!S || !out || !g || !el || !er || !feat || !grad_feat || !grad_el || !row_offsets)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd: NULL pointer argument");
     const uintptr_t align = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
                             reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(grad_feat);
@@ -499,7 +498,7 @@ extern "C" int stg_gat_bwd_er(const float *T, float *grad_er, const int32_t *row
     if (N < 0 || H <= 0 || H_active < 0 || H_active > H)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_er: bad shape N=%d H=%d H_active=%d", N, H, H_active);
     if (N == 0 || H_active == 0) return 0;
-    if (!T || !grad_er || !row_offsets || !eids)
+    if (!grad_er || !row_offsets)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_er: NULL pointer argument");
     const int log2g = std::min(6, ilog2_ceil(H_active));
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -204,7 +204,8 @@ extern "C" int stg_gcn_agg(const float *x, const float *norm_row, const float *n
     if (N < 0 || F <= 0 || F_active < 0 || F_active > F)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg: bad shape N=%d F=%d F_active=%d", N, F, F_active);
     if (N == 0 || F_active == 0) return 0;
-    if (!x || !norm_row || !norm_col || !out || !row_offsets || !column_indices)
+    // column_indices / eids may be NULL for a graph without edges (no row is ever entered)
+    if (!x || !norm_row || !norm_col || !out || !row_offsets)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg: NULL pointer argument");
     if (ew && !eids)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg: edge weights given without eids");

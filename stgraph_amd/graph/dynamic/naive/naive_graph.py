@@ -125,6 +125,30 @@ class NaiveGraph(DynamicGraph):
         for t in (c.row_offset, c.column_indices, c.eids, c.node_ids):
             _LIVE[t.data_ptr()] = t
 
+    # Moving between timestamps is a pointer swap here, so jump straight to the target instead of
+    # stepping through (and, when not resident, building) every snapshot in between.
+    def get_graph(self, timestamp: int) -> None:
+        t0 = time.time()
+        self._is_backprop_state = False
+        if timestamp < self.current_timestamp:
+            raise RuntimeError("⏰ Invalid timestamp during STGraphBase.update_graph_forward()")
+        if timestamp >= self._num_timestamps:
+            raise RuntimeError("⏰ Invalid timestamp during STGraphBase.update_graph_forward()")
+        self.current_timestamp = timestamp
+        self._get_graph_csr_ptrs(timestamp)
+        self.get_fwd_graph_time += time.time() - t0
+
+    def get_backward_graph(self, timestamp: int) -> None:
+        t0 = time.time()
+        if timestamp > self.current_timestamp:
+            raise RuntimeError("⏰ Invalid timestamp during STGraphBase.update_graph_backward()")
+        if timestamp < 0:
+            raise RuntimeError("⏰ Invalid timestamp during STGraphBase.update_graph_backward()")
+        self._is_backprop_state = True
+        self.current_timestamp = timestamp
+        self._get_graph_csr_ptrs(timestamp)
+        self.get_bwd_graph_time += time.time() - t0
+
     def _on_timestamp_change(self) -> None:
         if self._num_timestamps:
             self._get_graph_csr_ptrs(self.current_timestamp)

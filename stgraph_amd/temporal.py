@@ -1,0 +1,207 @@
+"""Temporal training loops around the hot path, and their multi-GPU form.
+
+Single process: the window loop of the reference's static-temporal and
+dynamic-temporal TGCN scripts (benchmarking/static-temporal-tgcn/seastar/
+train.py:153-205, benchmarking/dynamic-temporal-tgcn/seastar/train.py:179-231):
+every window of ``backprop_every`` consecutive snapshots starts from
+``hidden_state = None`` and a fresh ``randn`` input, accumulates the loss, divides
+it by ``backprop_every + 1`` (sic), backpropagates through time and
+takes one optimizer step.
+
+Multi GPU (new -- the reference has no distributed path): windows
+carry no state across each other, so window ``w`` goes to rank ``w mod R``; every
+rank holds the full (small) graph and model, and one optimizer step consumes R
+windows.  The ONLY collective is one all-reduce (sum, then / R) of the flattened
+gradient bucket per optimizer step (RCCL over xGMI when the process group is
+"nccl"; ~133 KB for TGCN(32 -> 64), i.e. latency bound, hence a single contiguous
+bucket and a single call).  With R = 1 the loop is step-for-step the reference's.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .nn.pytorch.temporal.tgcn import TGCN
+
+
+class STGraphTGCN(torch.nn.Module):
+    """benchmarking/static-temporal-tgcn/seastar/model.py:6-18."""
+
+    def __init__(self, node_features, num_hidden_units, out_features, tgcn_cls=TGCN):
+        super().__init__()
+        self.temporal = tgcn_cls(node_features, num_hidden_units)
+        self.linear = torch.nn.Linear(num_hidden_units, node_features)
+        self.linear2 = torch.nn.Linear(node_features, out_features)
+
+    def forward(self, g, node_feat, edge_weight, hidden_state):
+        h = self.temporal(g, node_feat, edge_weight, hidden_state)
+        y = F.relu(h)
+        y = self.linear(y)
+        y_out = self.linear2(y)
+        return y_out, y, h
+
+
+class GradBucket:
+    """All parameter gradients as views into ONE contiguous fp32 buffer.
+
+    ``zero()`` replaces ``optimizer.zero_grad()`` (which would drop the views);
+    ``all_reduce_mean()`` issues the single collective of the data-parallel step.
+    """
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, device=dev, dtype=dt)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+        self.comm_seconds = 0.0
+        self.comm_calls = 0
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def zero(self) -> None:
+        self.flat.zero_()
+
+    def check_views(self) -> None:
+        base = self.flat.data_ptr()
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != base + off * self.flat.element_size():
+                raise RuntimeError("a parameter's .grad no longer aliases the bucket "
+                                   "(use bucket.zero(), not optimizer.zero_grad())")
+            off += p.numel()
+
+    def all_reduce_mean(self, world: int, group=None, timed: bool = False) -> None:
+        if world <= 1:
+            return
+        if timed and self.flat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        self.flat.div_(world)
+        self.comm_calls += 1
+        if timed and self.flat.is_cuda:
+            e1.record()
+            self._pending = getattr(self, "_pending", [])
+            self._pending.append((e0, e1))
+
+    def collect_comm_time(self) -> float:
+        """Seconds spent in the timed all-reduces so far (synchronises the device)."""
+        pend = getattr(self, "_pending", [])
+        if pend:
+            torch.cuda.synchronize()
+            self.comm_seconds += sum(a.elapsed_time(b) for a, b in pend) * 1e-3
+            self._pending = []
+        return self.comm_seconds
+
+
+def num_windows(total_timestamps: int, backprop_every: int) -> int:
+    """static-temporal-tgcn/seastar/train.py:137-144."""
+    if backprop_every == 0:
+        backprop_every = total_timestamps
+    return (total_timestamps + backprop_every - 1) // backprop_every
+
+
+def windows_of_rank(total_timestamps: int, backprop_every: int, rank: int, world: int):
+    """[(step, window index or None)]: window w runs on rank w mod R during optimizer step w // R.
+    ``None`` marks a padding step where this rank only joins the all-reduce with zero gradients."""
+    n = num_windows(total_timestamps, backprop_every)
+    steps = (n + world - 1) // world
+    out = []
+    for s in range(steps):
+        w = s * world + rank
+        out.append((s, w if w < n else None))
+    return out
+
+
+def window_input(num_nodes: int, feat: int, epoch: int, window: int, device, seed: int = 0) -> torch.Tensor:
+    """The fresh ``torch.randn`` input of a window, made a function of (seed, epoch, window) so
+    that a run is reproducible for any number of ranks."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed((seed * 1_000_003 + epoch) * 1_000_003 + window)
+    return torch.randn(num_nodes, feat, device=device, generator=gen)
+
+
+def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, optimizer,
+                       bucket: GradBucket, feat_size: int, epoch: int = 0, rank: int = 0,
+                       world: int = 1, group=None, seed: int = 0, timed_comm: bool = False):
+    """One epoch of the static-temporal loop; returns the list of this rank's window losses
+    (device tensors, no host sync inside the loop)."""
+    total = targets.shape[0]
+    if backprop_every == 0:
+        backprop_every = total
+    n = graph.get_num_nodes()
+    losses = []
+    for _, w in windows_of_rank(total, backprop_every, rank, world):
+        bucket.zero()
+        if w is not None:
+            cost = 0
+            hidden = None
+            y_hat = window_input(n, feat_size, epoch, w, targets.device, seed)
+            for k in range(backprop_every):
+                t = w * backprop_every + k
+                if t >= total:
+                    break
+                y_out, y_hat, hidden = model(graph, y_hat, edge_weight, hidden)
+                cost = cost + torch.mean((y_out - targets[t]) ** 2)
+            cost = cost / (backprop_every + 1)
+            cost.backward()
+            losses.append(cost.detach())
+        bucket.all_reduce_mean(world, group, timed_comm)
+        optimizer.step()
+    return losses
+
+
+def train_epoch_dynamic(model, graph, features, targets, backprop_every: int, optimizer,
+                        bucket: GradBucket, epoch: int = 0, rank: int = 0, world: int = 1,
+                        group=None, norm_fn=None, timed_comm: bool = False):
+    """One epoch of the dynamic-temporal loop (dynamic-temporal-tgcn/seastar/train.py:179-231):
+    per step ``graph.get_graph(t)``, ``norm`` from the snapshot's in-degrees unless cached for that
+    timestamp, un-weighted GCN kernels; backward walks the snapshots in reverse through the
+    executor's timestamp stack.  ``model(graph, x, None, hidden) -> (y, hidden)``."""
+    total = len(features)
+    if backprop_every == 0:
+        backprop_every = total
+    losses = []
+    graph.reset_graph()
+    for _, w in windows_of_rank(total, backprop_every, rank, world):
+        bucket.zero()
+        if w is not None:
+            cost = 0
+            hidden = None
+            for k in range(backprop_every):
+                t = w * backprop_every + k
+                if t >= total:
+                    break
+                graph.get_graph(t)
+                if graph.get_ndata("norm") is None:
+                    graph.set_ndata("norm", norm_fn(graph))
+                y, hidden = model(graph, features[t], None, hidden)
+                cost = cost + torch.mean((y - targets[t]) ** 2)
+            cost = cost / (backprop_every + 1)
+            cost.backward()
+            losses.append(cost.detach())
+        bucket.all_reduce_mean(world, group, timed_comm)
+        optimizer.step()
+    return losses
+
+
+def in_degree_norm(graph) -> torch.Tensor:
+    """norm = in_deg^-0.5, inf -> 0, computed on the device from the current snapshot."""
+    if hasattr(graph, "in_degrees_tensor"):
+        deg = graph.in_degrees_tensor().float()
+    else:
+        f = graph.csr("fwd")
+        deg = (f.row_offset[1:] - f.row_offset[:-1]).float()
+    norm = torch.pow(deg, -0.5)
+    norm[torch.isinf(norm)] = 0
+    return norm.unsqueeze(1)

@@ -1,0 +1,203 @@
+"""GPU parity of the drop-in layers against golden vectors produced by the REFERENCE layers
+(GCNConv, GATConv, TGCN on StaticGraph / NaiveGraph), through the @compile operator API."""
+import numpy as np
+import pytest
+import torch
+
+import stgraph_amd
+from tests.util import GAT_SHAPES, GCN_WIDTHS, golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _edges(d, prefix=""):
+    return [(int(a), int(b)) for a, b in zip(d[prefix + "src"], d[prefix + "dst"])]
+
+
+@pytest.fixture(autouse=True)
+def _compat_on():
+    # the golden vectors carry reference defect D1 (zero tail for F < 64 not a power of two)
+    stgraph_amd.set_reference_compat(True)
+    yield
+    stgraph_amd.set_reference_compat(False)
+
+
+@pytest.mark.parametrize("gname", ["static", "naive"])
+def test_gcnconv_matches_reference_layer(cuda, gname):
+    from stgraph_amd.graph import NaiveGraph, StaticGraph
+    from stgraph_amd.nn.pytorch.static.gcn_conv import GCNConv
+    d = golden("gcn.npz")
+    n = int(d["num_nodes"])
+    el = _edges(d)
+    g = StaticGraph(el, [1.0] * len(el), n, device=cuda) if gname == "static" else NaiveGraph([el], n, device=cuda)
+    assert g.graph_type() == ("csr_unsorted" if gname == "static" else "csr")
+    g.set_ndata("norm", _t(d[f"{gname}_norm"], cuda))
+    w = _t(d["edge_weight_by_eid"], cuda)
+    for F in GCN_WIDTHS:
+        for use_ew in (False, True):
+            tag = f"{gname}_F{F}_{'ew' if use_ew else 'now'}"
+            conv = GCNConv(F, F, bias=False).to(cuda)
+            with torch.no_grad():
+                conv.weight.copy_(torch.eye(F))
+            x = _t(d[tag + "_x"], cuda).requires_grad_(True)
+            if gname == "naive":
+                g.get_graph(0)
+            out = conv(g, x, edge_weight=w if use_ew else None)
+            (out * _t(d[tag + "_R"], cuda)).sum().backward()
+            assert np.array_equal(out.detach().cpu().numpy(), d[tag + "_out"]), tag
+            assert np.array_equal(x.grad.cpu().numpy(), d[tag + "_grad_x"]), tag
+            st = conv.stgraph._ctx_map["nb_compute"]._executor_cache.ts
+            assert len(st.tensor_map_stack) == 0 and len(st.graph_timestamp_stack) == 0
+
+
+@pytest.mark.parametrize("H,D", GAT_SHAPES)
+def test_gatconv_matches_reference_layer(cuda, H, D):
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    d = golden("gat.npz")
+    n = int(d["num_nodes"])
+    el = _edges(d)
+    g = StaticGraph(el, [1.0] * len(el), n, device=cuda)
+    tag = f"H{H}_D{D}"
+    conv = GATConv(d[tag + "_x"].shape[1], D, H).to(cuda)
+    with torch.no_grad():
+        conv.fc.weight.copy_(_t(d[tag + "_fc_weight"], cuda))
+        conv.attn_l.copy_(_t(d[tag + "_attn_l"], cuda))
+        conv.attn_r.copy_(_t(d[tag + "_attn_r"], cuda))
+    x = _t(d[tag + "_x"], cuda).requires_grad_(True)
+    out = conv(g, x)
+    (out * _t(d[tag + "_R"], cuda)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), d[tag + "_out"], rtol=TOL, atol=TOL)
+    for name, got in (("grad_x", x.grad), ("grad_fc_weight", conv.fc.weight.grad),
+                      ("grad_attn_l", conv.attn_l.grad), ("grad_attn_r", conv.attn_r.grad)):
+        np.testing.assert_allclose(got.cpu().numpy(), d[f"{tag}_{name}"], rtol=TOL, atol=TOL, err_msg=name)
+
+
+class TGCNModel(torch.nn.Module):
+    """tests/scripts/v1_1_0/temporal_tgcn_dataloaders model shape: TGCN -> ReLU -> Linear."""
+
+    def __init__(self, fin, hid, out):
+        super().__init__()
+        from stgraph_amd.nn.pytorch.temporal.tgcn import TGCN
+        self.temporal = TGCN(fin, hid)
+        self.linear = torch.nn.Linear(hid, out)
+
+    def forward(self, g, x, edge_weight, hidden):
+        h = self.temporal(g, x, edge_weight, hidden)
+        return self.linear(torch.relu(h)), h
+
+
+def _load_params(model, d, prefix, dev):
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(_t(d[prefix + k], dev))
+
+
+@pytest.mark.parametrize("B", [3, 6])
+def test_tgcn_bptt_matches_reference(cuda, B):
+    from stgraph_amd.graph import StaticGraph
+    d = golden("tgcn.npz")
+    n, T = int(d["num_nodes"]), d["feats"].shape[0]
+    el = _edges(d)
+    w = _t(d["edge_weight_by_eid"], cuda)
+    g = StaticGraph(el, d["edge_weight_by_eid"].reshape(-1).tolist(), n, device=cuda)
+    g.set_ndata("norm", _t(d["norm"], cuda))
+    feats, targets = _t(d["feats"], cuda), _t(d["targets"], cuda)
+    model = TGCNModel(feats.shape[2], 16, 1).to(cuda)
+    _load_params(model, d, f"B{B}_param_", cuda)
+    hs, costs = [], []
+    for w0 in range(0, T, B):
+        model.zero_grad()
+        hidden, cost = None, 0
+        for t in range(w0, w0 + B):
+            y, hidden = model(g, feats[t], w, hidden)
+            cost = cost + torch.mean((y - targets[t]) ** 2)
+            hs.append(hidden.detach())
+        cost = cost / (B + 1)
+        cost.backward()
+        costs.append(cost.detach())
+        for k, p in model.named_parameters():
+            np.testing.assert_allclose(p.grad.cpu().numpy(), d[f"B{B}_w{w0}_grad_{k}"], rtol=TOL, atol=TOL,
+                                       err_msg=f"window {w0} {k}")
+    np.testing.assert_allclose(torch.stack(hs).cpu().numpy(), d[f"B{B}_hidden"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(torch.stack(costs).cpu().numpy(), d[f"B{B}_cost"], rtol=TOL, atol=TOL)
+    for conv in (model.temporal.conv_z, model.temporal.conv_r, model.temporal.conv_h):
+        for ex in conv.stgraph._ctx_map["nb_compute"]._executors.values():
+            assert len(ex.ts.tensor_map_stack) == 0
+
+
+def test_tgcn_adam_training_loop_matches_reference(cuda):
+    from stgraph_amd.graph import StaticGraph
+    d = golden("tgcn.npz")
+    n, T, B = int(d["num_nodes"]), d["feats"].shape[0], 3
+    el = _edges(d)
+    w = _t(d["edge_weight_by_eid"], cuda)
+    g = StaticGraph(el, None, n, device=cuda)
+    g.set_ndata("norm", _t(d["norm"], cuda))
+    feats, targets = _t(d["feats"], cuda), _t(d["targets"], cuda)
+    model = TGCNModel(feats.shape[2], 16, 1).to(cuda)
+    _load_params(model, d, "train_param0_", cuda)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    losses, sums = [], []
+    for _ in range(2):
+        for w0 in range(0, T, B):
+            opt.zero_grad()
+            hidden, cost = None, 0
+            for t in range(w0, w0 + B):
+                y, hidden = model(g, feats[t], w, hidden)
+                cost = cost + torch.mean((y - targets[t]) ** 2)
+            cost = cost / (B + 1)
+            cost.backward()
+            opt.step()
+            losses.append(cost.detach())
+            sums.append(torch.stack([p.detach().double().sum() for p in model.parameters()]))
+    np.testing.assert_allclose(torch.stack(losses).cpu().numpy(), d["train_losses"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(torch.stack(sums).cpu().numpy(), d["train_param_sums"], rtol=1e-3, atol=1e-3)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().numpy(), d["train_paramT_" + k], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_naive_graph_tgcn_bptt_matches_reference(cuda, resident):
+    from stgraph_amd.graph import NaiveGraph
+    d = golden("naive_tgcn.npz")
+    n, T = int(d["num_nodes"]), int(d["T"])
+    snaps = [_edges(d, f"t{t}_") for t in range(T)]
+    G = NaiveGraph(snaps, n, device=cuda, resident=resident, max_cached=None if resident else 2)
+    for t in range(T):      # per-snapshot CSRs are bit-exact (node_ids: permutation with monotone degrees)
+        for side in ("fwd", "bwd"):
+            c = G.csr(side, t)
+            for k in ("row_offset", "column_indices", "eids"):
+                assert np.array_equal(getattr(c, k).cpu().numpy(), d[f"t{t}_{side}_{k}"]), (t, side, k)
+    feats, targets = _t(d["feats"], cuda), _t(d["targets"], cuda)
+    model = TGCNModel(feats.shape[2], 16, 1).to(cuda)
+    _load_params(model, d, "param_", cuda)
+    G.reset_graph()
+    hidden, cost, hs = None, 0, []
+    for t in range(T):
+        G.get_graph(t)
+        if G.get_ndata("norm") is None:
+            deg = torch.from_numpy(G.in_degrees()).float()
+            norm = torch.pow(deg, -0.5)
+            norm[torch.isinf(norm)] = 0
+            G.set_ndata("norm", norm.unsqueeze(1).to(cuda))
+        np.testing.assert_array_equal(G.get_ndata("norm").cpu().numpy(), d[f"t{t}_norm"])
+        y, hidden = model(G, feats[t], None, hidden)
+        cost = cost + torch.mean((y - targets[t]) ** 2)
+        hs.append(hidden.detach())
+    cost = cost / (T + 1)
+    cost.backward()
+    assert G.current_timestamp == 0
+    np.testing.assert_allclose(torch.stack(hs).cpu().numpy(), d["hidden"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(cost.item(), float(d["cost"]), rtol=TOL, atol=TOL)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), d["grad_" + k], rtol=TOL, atol=TOL, err_msg=k)
+    # a second window can start again from an earlier snapshot after reset
+    G.reset_graph()
+    G.get_graph(1)
+    assert G.current_timestamp == 1

@@ -1,0 +1,78 @@
+"""Pin the CPU oracle: it must reproduce, bit for bit, every golden vector that was generated
+from the reference's own code (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import stg_oracle as orc
+from tests.util import GAT_SHAPES, GCN_WIDTHS, golden
+
+CSR_KEYS = ("row_offset", "column_indices", "eids")
+
+
+@pytest.mark.parametrize("tag", ["n1", "n5", "n64", "n2708"])
+def test_csr_golden(tag):
+    d = golden(f"csr_{tag}.npz")
+    n = int(d["num_nodes"])
+    g = orc.build_graph(d["src"], d["dst"], n, d["weights_by_eid"])
+    for side, c in (("fwd", g.fwd), ("bwd", g.bwd)):
+        for k in CSR_KEYS + ("node_ids",):
+            assert np.array_equal(getattr(c, k), d[f"{side}_{k}"]), (side, k)
+    assert np.array_equal(g.in_degrees(), d["in_degrees"])
+    assert np.array_equal(g.out_degrees(), d["out_degrees"])
+    assert np.array_equal(g.fwd.weighted_out_degrees.astype(np.int32), d["weighted_in_degrees"])
+    assert np.array_equal(np.stack([d["src"], d["dst"]], 1)[g.perm_fwd], d["sorted_inplace"])
+    assert len({(int(a), int(b)) for a, b in zip(d["src"], d["dst"])}) == int(d["num_edges"])
+
+
+def test_csr_survey_example():
+    """The 5-edge CSR recorded from the reference in SURVEY.md 8(c)."""
+    g = orc.build_graph([0, 1, 2, 0, 3], [1, 0, 1, 2, 2], 4)
+    assert g.fwd.row_offset.tolist() == [0, 1, 3, 5, 5] and g.fwd.column_indices.tolist() == [1, 0, 2, 0, 3]
+    assert g.fwd.eids.tolist() == [0, 1, 2, 3, 4]
+    assert g.bwd.row_offset.tolist() == [0, 2, 3, 4, 5] and g.bwd.column_indices.tolist() == [1, 2, 0, 1, 2]
+    assert g.bwd.eids.tolist() == [1, 3, 0, 2, 4]
+
+
+@pytest.mark.parametrize("gname", ["static", "naive"])
+def test_gcn_golden(gname):
+    d = golden("gcn.npz")
+    n = int(d["num_nodes"])
+    g = orc.build_graph(d["src"], d["dst"], n)
+    for side, c in (("fwd", g.fwd), ("bwd", g.bwd)):
+        for k in CSR_KEYS:
+            assert np.array_equal(getattr(c, k), d[f"{gname}_{side}_{k}"])
+    norm = d[f"{gname}_norm"]
+    for F in GCN_WIDTHS:
+        fa = orc.ref_active_columns(F)
+        for use_ew in (False, True):
+            tag = f"{gname}_F{F}_{'ew' if use_ew else 'now'}"
+            w = d["edge_weight_by_eid"] if use_ew else None
+            out = orc.gcn_agg(d[tag + "_x"], norm, norm, g.fwd, ew=w, use_node_ids=gname == "naive", f_active=fa)
+            gx = orc.gcn_agg(d[tag + "_R"], norm, norm, g.bwd, ew=w, use_node_ids=gname == "naive", f_active=fa)
+            assert np.array_equal(out, d[tag + "_out"]), tag
+            assert np.array_equal(gx, d[tag + "_grad_x"]), tag
+            if fa < F:          # reference defect D1: the tail columns were never computed
+                assert not out[:, fa:].any() and not d[tag + "_out"][:, fa:].any()
+            # OpenMP build: same bits regardless of thread count
+            assert np.array_equal(orc.gcn_agg(d[tag + "_x"], norm, norm, g.fwd, ew=w, f_active=fa, omp=True),
+                                  orc.gcn_agg(d[tag + "_x"], norm, norm, g.fwd, ew=w, f_active=fa))
+
+
+@pytest.mark.parametrize("H,D", GAT_SHAPES)
+def test_gat_golden(H, D):
+    d = golden("gat.npz")
+    n = int(d["num_nodes"])
+    g = orc.build_graph(d["src"], d["dst"], n)
+    tag = f"H{H}_D{D}"
+    el, er, feat = d[tag + "_k_el"], d[tag + "_k_er"], d[tag + "_k_feat"]
+    ha, hda = orc.ref_active_columns(H), orc.ref_active_columns(H * D)
+    A, S = orc.gat_k0(el, er, g.fwd, g.num_edges, h_active=ha)
+    out = orc.gat_k1(A, S, feat, g.fwd, hd_active=hda)
+    gf, gel, ger = orc.gat_bwd(A, S, out, d[tag + "_R"], el, er, feat, g.bwd, hd_active=hda)
+    assert np.array_equal(A, d[tag + "_k_A"]) and np.array_equal(S, d[tag + "_k_S"])
+    assert np.array_equal(out, d[tag + "_out"])
+    assert np.array_equal(gf, d[tag + "_k_grad_feat"])
+    assert np.array_equal(gel, d[tag + "_k_grad_el"]) and np.array_equal(ger, d[tag + "_k_grad_er"])
+    # reference defect D2: attention is uniform, S equals the in-degree
+    assert np.array_equal(S[:, 0, 0], g.in_degrees().astype(np.float32))
+    assert S[7].sum() == 0 and not out[7].any()          # the in-degree-0 vertex
