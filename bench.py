@@ -1,24 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the Seastar hot path on MI355X (contract: see the task statement).
 
-    python bench.py --gpus N --steps K --warmup W [--workload gcn|tgcn]
+    python bench.py --gpus N --steps K --warmup W
 
-N = 1 (default workload "gcn"): BASELINE.json configs[1] -- 2-layer GCN
-128->128->128 on a synthetic CSR with |V| = 1M, |E| = 16M (uniform, seed 1).  One
-step = one training epoch (forward, cross-entropy on the train mask, backward,
-Adam), inputs resident in HBM.  `value` = edges*feat/s = (aggregation launches per
-step x E x F) / wall time, whole job.  N > 1 runs N independent replicas of that
-workload (single-graph GCN does not shard: SURVEY.md 8(e) "replicas only").
+Main line, N = 1: BASELINE.json configs[1] -- 2-layer GCN 128->128->128 on a synthetic CSR
+with |V| = 1M, |E| = 16M (uniform, duplicate-free, seed 1).  One step = one training epoch
+(forward, cross-entropy on the train mask, backward, Adam), inputs resident in HBM.
+`value` = edges*feat/s = (aggregation launches per step x E x F) / wall time, whole job.
+N > 1: N independent replicas of that workload (a single-graph GCN does not shard:
+SURVEY.md 8(e) "replicas only"), `value` = sum over ranks.
 
-Every line also carries a "tgcn" object: BASELINE.json configs[3] (static-temporal
-TGCN, |V| = 50K, |E| = 500K, T = 1000, feat 32, hidden 64, backprop_every 25) with
-its BPTT windows sharded over the N ranks and ONE RCCL all-reduce of the flattened
-gradient bucket per optimizer step -- the path the north star scales to 8 GPUs.
+Every line also carries a "tgcn" object: BASELINE.json configs[3] (static-temporal TGCN,
+|V| = 50K, |E| = 500K, T = 1000, feat 32, hidden 64, backprop_every 25 => 40 BPTT windows)
+with the windows sharded over the N ranks and ONE RCCL all-reduce of the flattened gradient
+bucket per optimizer step -- the path the north star scales to 8 GPUs ("scaling": "strong":
+the epoch is fixed, ranks split its windows).
 
-"roofline": dominant kernel gcn_agg, algorithmic bytes per launch
-over its mean launch time measured with HIP events on the launch stream inside the
-timed region.  "cpu_baseline": the C oracle (OpenMP port) timed on this host's
-cores on a bounded sample of the same workload.
+"roofline": dominant kernel gcn_agg -- algorithmic bytes per launch over its
+mean launch time, measured with HIP events on the launch stream inside the timed region.
+"cpu_baseline": the C oracle (OpenMP port of the emitted kernel) timed on this host's cores
+on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -62,7 +63,7 @@ class GCN(nn.Module):
 
 
 def synthetic_graph(n, e, seed, device):
-    """Uniform random directed edges (duplicates removed on the device), as (src, dst) int32."""
+    """Uniform random duplicate-free directed edges as (src, dst) int32 device tensors."""
     gen = torch.Generator(device=device).manual_seed(seed)
     m = int(e * 1.02) + 1024
     key = torch.randint(0, n * n, (m,), generator=gen, device=device, dtype=torch.int64)
@@ -72,24 +73,28 @@ def synthetic_graph(n, e, seed, device):
     return (key // n).to(torch.int32), (key % n).to(torch.int32)
 
 
-def gcn_setup(device, seed, n=1_000_000, e=16_000_000, feat=128):
+def degree_norm(g):
+    f = g.csr("fwd")
+    norm = torch.pow((f.row_offset[1:] - f.row_offset[:-1]).float(), -0.5)
+    norm[torch.isinf(norm)] = 0                          # benchmarking/gcn/seastar/train.py:53-57
+    return norm.unsqueeze(1)
+
+
+# ------------------------------------------------------------------------------ GCN (cfg 2)
+def gcn_setup(device, seed, n, e, feat):
     from stgraph_amd.graph import StaticGraph
     src, dst = synthetic_graph(n, e, seed, device)
     g = StaticGraph((src, dst), None, n, device=device, sort_inplace=False)
-    deg = g.csr("fwd").row_offset[1:] - g.csr("fwd").row_offset[:-1]
-    norm = torch.pow(deg.float(), -0.5)
-    norm[torch.isinf(norm)] = 0
-    g.set_ndata("norm", norm.unsqueeze(1))
+    norm = degree_norm(g)
+    g.set_ndata("norm", norm)
     gen = torch.Generator(device=device).manual_seed(seed + 100)
     x = torch.randn(n, feat, device=device, generator=gen)
     labels = torch.randint(0, feat, (n,), device=device, generator=gen)
-    train_mask = torch.zeros(n, dtype=torch.bool, device=device)
-    train_mask[: int(0.6 * n)] = True                      # benchmarking/gcn/seastar/utils.py:25-27
+    train_idx = torch.arange(int(0.6 * n), device=device)     # benchmarking/gcn/seastar/utils.py:25-27
     torch.manual_seed(seed)
     model = GCN(feat, feat, feat, 1, F.relu).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4)
     loss_fn = nn.CrossEntropyLoss()
-    train_idx = train_mask.nonzero().squeeze(1)
 
     def step():
         model.train()
@@ -100,22 +105,20 @@ def gcn_setup(device, seed, n=1_000_000, e=16_000_000, feat=128):
         opt.step()
         return loss
 
-    meta = dict(n=n, e=e, feat=feat, agg_launches_per_step=4, graph=g, norm=norm, x=x)
-    return step, meta
+    return step, dict(n=n, e=e, feat=feat, agg_launches_per_step=4, graph=g, norm=norm, x=x)
 
 
 def cpu_baseline_gcn(meta, budget_s=20.0):
     """Oracle (C/OpenMP port of the emitted kernel) on this host: full-size aggregation launches
-    of the same graph/features until ~budget_s of CPU time has been spent (at least one)."""
+    of the same graph/features until ~budget_s of wall time has been spent (at least one)."""
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     from oracle import stg_oracle as orc
-    g = meta["graph"]
-    f = g.csr("fwd")
+    f = meta["graph"].csr("fwd")
     csr = orc.OracleCSR(f.row_offset.cpu().numpy(), f.column_indices.cpu().numpy(), f.eids.cpu().numpy(),
                         f.node_ids.cpu().numpy(), None, None, None)
     x = meta["x"].cpu().numpy()
     norm = meta["norm"].cpu().numpy().reshape(-1, 1)
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     t0 = time.time()
     launches = 0
     while True:
@@ -126,8 +129,62 @@ def cpu_baseline_gcn(meta, budget_s=20.0):
     dt = time.time() - t0
     return {"value": launches * meta["e"] * meta["feat"] / dt, "unit": "edges*feat/s", "cores": cores,
             "kind": "port",
-            "sample": f"{launches} full-size gcn_agg launches (|V|={meta['n']}, |E|={meta['e']}, F={meta['feat']}) "
-                      f"by oracle/stg_oracle.c with OpenMP over rows, {dt:.1f} s"}
+            "sample": f"{launches} full-size gcn_agg launch(es) (|V|={meta['n']}, |E|={meta['e']}, F={meta['feat']}) "
+                      f"by oracle/stg_oracle.c, OpenMP over rows, {dt:.1f} s wall"}
+
+
+# ----------------------------------------------------------------------------- TGCN (cfg 4)
+def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, B):
+    from stgraph_amd import kernels, temporal
+    from stgraph_amd.graph import StaticGraph
+    src, dst = synthetic_graph(n, e, 3, device)                 # same graph on every rank
+    g = StaticGraph((src, dst), None, n, device=device, sort_inplace=False)
+    g.set_ndata("norm", degree_norm(g))
+    gen = torch.Generator(device=device).manual_seed(3)
+    ew = torch.rand(e, 1, device=device, generator=gen) + 0.5    # U(0.5, 1.5), indexed by eid
+    targets = torch.randn(T, n, 1, device=device, generator=gen)
+    torch.manual_seed(3)                                         # identical replicas
+    model = temporal.STGraphTGCN(feat, hidden, 1).to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    bucket = temporal.GradBucket(model.parameters())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for ep in range(warmup_epochs):
+        temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, feat, epoch=ep, rank=rank, world=world)
+    records = []
+    kernels.enable_launch_timing(records)
+    barrier()
+    t0 = time.perf_counter()
+    for ep in range(epochs):
+        temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, feat, epoch=warmup_epochs + ep,
+                                    rank=rank, world=world, timed_comm=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernels.enable_launch_timing(None)
+    comm = bucket.collect_comm_time()
+    agg_ms = float(np.sum([a.elapsed_time(b) for (_, a, b, _, _) in records]))
+    if world > 1:
+        t = torch.tensor([dt, comm], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, comm = float(t[0]), float(t[1])
+    bucket.check_views()
+    launches_per_epoch = 6 * T                                   # 3 gates x (fwd + bwd) per snapshot
+    return {
+        "workload": f"static-temporal TGCN |V|={n} |E|={e} T={T} feat={feat} hidden={hidden} backprop_every={B} "
+                    f"(BASELINE configs[3]), windows sharded over {world} rank(s), Adam",
+        "metric": "epochs/s", "value": epochs / dt, "epochs": epochs, "seconds_per_epoch": dt / epochs,
+        "edges_feat_per_s": launches_per_epoch * e * hidden * epochs / dt,
+        "scaling": "strong", "n_gpus": world,
+        "windows_per_epoch": temporal.num_windows(T, B), "optimizer_steps_per_epoch":
+            (temporal.num_windows(T, B) + world - 1) // world,
+        "allreduce": {"bytes": bucket.nbytes, "calls": bucket.comm_calls,
+                      "seconds_max_rank": comm, "share_of_epoch": comm / dt if dt else None},
+        "rank0_gcn_agg_kernel_seconds": agg_ms * 1e-3, "rank0_gcn_agg_share": agg_ms * 1e-3 / dt,
+    }
 
 
 def main():
@@ -135,18 +192,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="gcn", choices=["gcn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tgcn", action="store_true")
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--edges", type=int, default=16_000_000)
     ap.add_argument("--feat", type=int, default=128)
+    ap.add_argument("--tgcn-epochs", type=int, default=2)
+    ap.add_argument("--tgcn-timestamps", type=int, default=1000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -156,13 +215,12 @@ def main():
 
     from stgraph_amd import kernels
 
-    step, meta = gcn_setup(device, seed=1 + rank, n=args.nodes, e=args.edges, feat=args.feat)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    step, meta = gcn_setup(device, seed=1 + rank, n=args.nodes, e=args.edges, feat=args.feat)
     for _ in range(args.warmup):
         step()
     records = []
@@ -180,31 +238,38 @@ def main():
         dt = float(t.item())
 
     ef_per_step = meta["agg_launches_per_step"] * meta["e"] * meta["feat"]
-    value = world * args.steps * ef_per_step / dt
     ms = [a.elapsed_time(b) for (_, a, b, _, _) in records]
     bytes_alg = records[0][3]
     mean_ms = float(np.mean(ms))
     achieved = bytes_alg / (mean_ms * 1e-3) / 1e9
     line = {
-        "metric": "edges*feat/s (GCN epoch throughput)", "value": value, "unit": "edges*feat/s",
+        "metric": "edges*feat/s (2-layer GCN training epoch, BASELINE configs[1])",
+        "value": world * args.steps * ef_per_step / dt, "unit": "edges*feat/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "epochs_per_s": args.steps / dt,
-        "config": {"workload": f"2-layer GCN {args.feat}->{args.feat}->{args.feat}, synthetic CSR "
-                               f"|V|={meta['n']} |E|={meta['e']} (BASELINE configs[1]), fwd+CE+bwd+Adam per step",
-                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
+        "epochs_per_s": world * args.steps / dt,
+        "config": {"workload": f"2-layer GCN {args.feat}->{args.feat}->{args.feat} on a synthetic CSR |V|={meta['n']} "
+                               f"|E|={meta['e']} (BASELINE configs[1]); step = fwd + cross-entropy + bwd + Adam",
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
                    "agg_launches_per_step": meta["agg_launches_per_step"],
+                   "edges_feat_per_step": ef_per_step,
                    "reference_compat_D1": kernels.reference_compat()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "gcn_agg_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "stg::gcn_agg_kernel",
                      "algorithmic_bytes_per_launch": bytes_alg, "mean_launch_ms": mean_ms,
-                     "launches_timed": len(ms)},
+                     "launches_timed": len(ms),
+                     "gcn_agg_share_of_step": float(np.sum(ms)) * 1e-3 / dt},
     }
+    cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_gcn(meta)
-    elif rank == 0:
-        line["cpu_baseline"] = None
+        cpu = cpu_baseline_gcn(meta)
+    line["cpu_baseline"] = cpu
+    del step, meta
+    torch.cuda.empty_cache()
+    if not args.no_tgcn:
+        line["tgcn"] = tgcn_run(device, rank, world, epochs=args.tgcn_epochs, warmup_epochs=1, n=50_000, e=500_000,
+                                T=args.tgcn_timestamps, feat=32, hidden=64, B=25)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -58,6 +58,36 @@ def enable_launch_timing(records: list | None) -> None:
     _TIMING = records
 
 
+class _Timed:
+    """Context manager recording (name, start event, stop event, algorithmic bytes, units)."""
+
+    def __init__(self, name: str, nbytes: int, units: int):
+        self.rec = (name, nbytes, units)
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMING is not None and exc[0] is None:
+            self.e1.record()
+            _TIMING.append((self.rec[0], self.e0, self.e1, self.rec[1], self.rec[2]))
+        return False
+
+
+def gat_algorithmic_bytes(N: int, E: int, H: int, D: int) -> dict:
+    """SURVEY.md 8(d), per launch."""
+    idx = 4 * (N + 1) + 4 * E
+    return {
+        "gat_k0": 4 * E * H + 4 * E * H + 8 * N * H + idx + 4 * E,
+        "gat_k1": 4 * E * H * D + 4 * E * H + 4 * N * H + 4 * N * H * D + idx + 4 * E,
+        "gat_bwd": 2 * 4 * E * H * D + 2 * 4 * E * H + 2 * 4 * N * H * D + 8 * N * H + idx + 4 * E + 4 * E * H,
+        "gat_bwd_er": 4 * E * H + 4 * N * H + idx,
+    }
+
+
 def gcn_agg_algorithmic_bytes(N: int, E: int, F: int, edge_weighted: bool) -> int:
     """neighbour-row gather + output + row_offsets + column_indices +
     norm[col] per edge + norm[row] (+ eids and weights)."""
@@ -232,18 +262,12 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
             raise ValueError(f"edge_weight has {ew.numel()} entries, graph has {csr.num_edges} edges")
     fa = F if f_active is None else int(f_active)
     out = (torch.empty_like(x) if fa == F else torch.zeros_like(x))
-    with torch.cuda.device(dev):
-        if _TIMING is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+    with torch.cuda.device(dev), _Timed("gcn_agg", gcn_agg_algorithmic_bytes(N, csr.num_edges, fa, ew is not None),
+                                        csr.num_edges * fa):
         _C.check(_C.lib.stg_gcn_agg(
             _ptr(x), _ptr(norm_row), _ptr(norm_col), _ptr(ew), _ptr(out),
             _ptr(csr.row_offset), _ptr(csr.column_indices), _ptr(csr.eids),
             _ptr(csr.node_ids if use_node_ids else None), N, F, fa, _stream_ptr(dev)))
-        if _TIMING is not None:
-            e1.record()
-            _TIMING.append(("gcn_agg", e0, e1, gcn_agg_algorithmic_bytes(N, csr.num_edges, fa, ew is not None),
-                            csr.num_edges * fa))
     return out
 
 
@@ -269,13 +293,16 @@ def gat_fwd(el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor, csr: DeviceC
     S = alloc((N, H, 1), dtype=torch.float32, device=dev)
     out = alloc((N, H, D), dtype=torch.float32, device=dev)
     nid = _ptr(csr.node_ids if use_node_ids else None)
+    ab = gat_algorithmic_bytes(N, E, H, D)
     with torch.cuda.device(dev):
         st = _stream_ptr(dev)
-        _C.check(_C.lib.stg_gat_fwd_k0(_ptr(el), _ptr(er), _ptr(A), _ptr(S), _ptr(csr.row_offset),
-                                       _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, h_act,
-                                       float(slope), st))
-        _C.check(_C.lib.stg_gat_fwd_k1(_ptr(A), _ptr(S), _ptr(feat), _ptr(out), _ptr(csr.row_offset),
-                                       _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, D, hd_act, st))
+        with _Timed("gat_k0", ab["gat_k0"], E * H):
+            _C.check(_C.lib.stg_gat_fwd_k0(_ptr(el), _ptr(er), _ptr(A), _ptr(S), _ptr(csr.row_offset),
+                                           _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, h_act,
+                                           float(slope), st))
+        with _Timed("gat_k1", ab["gat_k1"], E * H * D):
+            _C.check(_C.lib.stg_gat_fwd_k1(_ptr(A), _ptr(S), _ptr(feat), _ptr(out), _ptr(csr.row_offset),
+                                           _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, D, hd_act, st))
     return out, A, S
 
 
@@ -299,15 +326,18 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
     grad_el = alloc((N, H, 1), dtype=torch.float32, device=dev)
     grad_er = alloc((N, H, 1), dtype=torch.float32, device=dev)
     T = alloc((E, H), dtype=torch.float32, device=dev)
+    ab = gat_algorithmic_bytes(N, E, H, D)
     with torch.cuda.device(dev):
         st = _stream_ptr(dev)
-        _C.check(_C.lib.stg_gat_bwd(
-            _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(el), _ptr(er), _ptr(feat),
-            _ptr(grad_feat), _ptr(grad_el), _ptr(T), _ptr(bwd.row_offset), _ptr(bwd.column_indices),
-            _ptr(bwd.eids), _ptr(bwd.node_ids if use_node_ids else None), N, H, D, hd_act,
-            float(slope), st))
+        with _Timed("gat_bwd", ab["gat_bwd"], E * H * D):
+            _C.check(_C.lib.stg_gat_bwd(
+                _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(el), _ptr(er), _ptr(feat),
+                _ptr(grad_feat), _ptr(grad_el), _ptr(T), _ptr(bwd.row_offset), _ptr(bwd.column_indices),
+                _ptr(bwd.eids), _ptr(bwd.node_ids if use_node_ids else None), N, H, D, hd_act,
+                float(slope), st))
         # heads the backward unit touched: those with at least one active feature column
         h_touched = H if full else min(H, (hd_act + D - 1) // D)
-        _C.check(_C.lib.stg_gat_bwd_er(_ptr(T), _ptr(grad_er), _ptr(fwd.row_offset), _ptr(fwd.eids),
-                                       _ptr(fwd.node_ids if use_node_ids else None), N, H, h_touched, st))
+        with _Timed("gat_bwd_er", ab["gat_bwd_er"], E * H):
+            _C.check(_C.lib.stg_gat_bwd_er(_ptr(T), _ptr(grad_er), _ptr(fwd.row_offset), _ptr(fwd.eids),
+                                           _ptr(fwd.node_ids if use_node_ids else None), N, H, h_touched, st))
     return grad_feat, grad_el, grad_er

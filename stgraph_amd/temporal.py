@@ -161,16 +161,39 @@ def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, 
     return losses
 
 
-def train_epoch_dynamic(model, graph, features, targets, backprop_every: int, optimizer,
-                        bucket: GradBucket, epoch: int = 0, rank: int = 0, world: int = 1,
-                        group=None, norm_fn=None, timed_comm: bool = False):
+class DynamicSTGraphTGCN(torch.nn.Module):
+    """benchmarking/dynamic-temporal-tgcn/seastar/model.py:5-21 (link-prediction head)."""
+
+    def __init__(self, node_features, num_hidden_units, tgcn_cls=TGCN):
+        super().__init__()
+        self.temporal = tgcn_cls(node_features, num_hidden_units)
+        self.linear = torch.nn.Linear(num_hidden_units, node_features)
+
+    def forward(self, g, node_feat, edge_weight, hidden_state):
+        h = self.temporal(g, node_feat, edge_weight, hidden_state)
+        y = F.relu(h)
+        y = self.linear(y)
+        return y, h
+
+    def decode(self, z, edge_label_index):
+        return (z[edge_label_index[0]] * z[edge_label_index[1]]).sum(dim=-1)
+
+
+def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_every: int, optimizer,
+                        bucket: GradBucket, feat_size: int, epoch: int = 0, rank: int = 0, world: int = 1,
+                        group=None, seed: int = 0, norm_fn=None, timed_comm: bool = False):
     """One epoch of the dynamic-temporal loop (dynamic-temporal-tgcn/seastar/train.py:179-231):
-    per step ``graph.get_graph(t)``, ``norm`` from the snapshot's in-degrees unless cached for that
-    timestamp, un-weighted GCN kernels; backward walks the snapshots in reverse through the
-    executor's timestamp stack.  ``model(graph, x, None, hidden) -> (y, hidden)``."""
-    total = len(features)
+    per step ``graph.get_graph(t)``, ``norm`` from the snapshot's in-degrees unless already cached
+    for that timestamp, un-weighted GCN kernels, link-prediction loss on ``pos_neg_edges[t]``;
+    the last timestamp has no prediction target (``t >= T - 1`` stops).  Backward walks the
+    snapshots in reverse through the executor's timestamp stack."""
+    total = len(pos_neg_edges)
     if backprop_every == 0:
         backprop_every = total
+    norm_fn = norm_fn or in_degree_norm
+    criterion = torch.nn.BCEWithLogitsLoss()
+    n = graph.get_num_nodes()
+    dev = pos_neg_targets[0].device
     losses = []
     graph.reset_graph()
     for _, w in windows_of_rank(total, backprop_every, rank, world):
@@ -178,18 +201,22 @@ def train_epoch_dynamic(model, graph, features, targets, backprop_every: int, op
         if w is not None:
             cost = 0
             hidden = None
+            y_hat = window_input(n, feat_size, epoch, w, dev, seed)
+            graph.get_graph(w * backprop_every)
             for k in range(backprop_every):
                 t = w * backprop_every + k
-                if t >= total:
+                if t >= total - 1:
                     break
                 graph.get_graph(t)
                 if graph.get_ndata("norm") is None:
                     graph.set_ndata("norm", norm_fn(graph))
-                y, hidden = model(graph, features[t], None, hidden)
-                cost = cost + torch.mean((y - targets[t]) ** 2)
-            cost = cost / (backprop_every + 1)
-            cost.backward()
-            losses.append(cost.detach())
+                y_hat, hidden = model(graph, y_hat, None, hidden)
+                out = model.decode(y_hat, pos_neg_edges[t]).view(-1)
+                cost = cost + criterion(out, pos_neg_targets[t])
+            if not isinstance(cost, int):
+                cost = cost / (backprop_every + 1)
+                cost.backward()
+                losses.append(cost.detach())
         bucket.all_reduce_mean(world, group, timed_comm)
         optimizer.step()
     return losses

@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Measure every BASELINE.json configuration on one MI355X and print one JSON line each.
+
+  cfg1  2-layer GCN 1433->16->7 on a Cora-SHAPED synthetic graph (|V|=2708, |E|=10556), epochs/s,
+        plus the roofline variant "Cora x K": K disjoint replicas so the kernel is bandwidth- not
+        launch-bound
+  cfg2  -> bench.py (main line)
+  cfg3  GAT 8 heads, |V|=256K |E|=8M, in=64, D=64: per-kernel time + roofline fraction, layer fwd+bwd
+  cfg4  -> bench.py ("tgcn" object)
+  cfg5  dynamic-temporal TGCN, |V|=25K, E0=250K, +-6250 edges/step, T=40, B=20, per-snapshot device
+        CSR rebuild; epochs/s and the CSR-build share
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from bench import GCN, HBM_PEAK_GBS, degree_norm, synthetic_graph
+from stgraph_amd import kernels, temporal
+from stgraph_amd.graph import NaiveGraph, StaticGraph
+
+
+def kernel_table(records):
+    out = {}
+    for name, a, b, nbytes, units in records:
+        d = out.setdefault(name, {"ms": [], "bytes": nbytes, "units": units})
+        d["ms"].append(a.elapsed_time(b))
+    return {k: {"launches": len(v["ms"]), "mean_ms": float(np.mean(v["ms"])), "algorithmic_bytes": v["bytes"],
+                "GBps": v["bytes"] / np.mean(v["ms"]) / 1e6, "frac_of_hbm_peak": v["bytes"] / np.mean(v["ms"]) / 1e6 / HBM_PEAK_GBS}
+            for k, v in out.items()}
+
+
+def cora_shaped(seed=0, n=2708, pairs=5278, max_deg=168):
+    """Chung-Lu style: power-law expected degrees capped at max_deg, undirected pairs mirrored."""
+    rng = np.random.default_rng(seed)
+    w = (np.arange(1, n + 1, dtype=np.float64)) ** -0.6
+    w = np.minimum(w / w.sum() * 2 * pairs, max_deg)
+    p = w / w.sum()
+    got = set()
+    while len(got) < pairs:
+        a = rng.choice(n, size=2 * pairs, p=p)
+        b = rng.choice(n, size=2 * pairs, p=p)
+        for u, v in zip(a, b):
+            if u != v and (min(u, v), max(u, v)) not in got and len(got) < pairs:
+                got.add((min(u, v), max(u, v)))
+    und = np.array(sorted(got), np.int32)
+    src = np.concatenate([und[:, 0], und[:, 1]])
+    dst = np.concatenate([und[:, 1], und[:, 0]])
+    return src, dst
+
+
+def cfg1(dev, epochs=200, K=1024):
+    src, dst = cora_shaped()
+    n, e = 2708, len(src)
+    g = StaticGraph((src, dst), None, n, device=dev, sort_inplace=False)
+    g.set_ndata("norm", degree_norm(g))
+    gen = torch.Generator(device=dev).manual_seed(0)
+    x = (torch.rand(n, 1433, device=dev, generator=gen) < 0.0127).float()
+    labels = torch.randint(0, 7, (n,), device=dev, generator=gen)
+    ntrain = int(0.6 * n)
+    torch.manual_seed(0)
+    model = GCN(1433, 16, 7, 1, F.relu).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    dur = []
+    for ep in range(epochs):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        logits = model(g, x)
+        loss = loss_fn(logits[:ntrain], labels[:ntrain])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        if ep >= 3:
+            dur.append(time.time() - t0)
+    line = {"config": "cfg1 GCN Cora-shaped (|V|=2708 |E|=%d) 1433->16->7, Adam, CE" % e,
+            "epochs_per_s": 1.0 / float(np.mean(dur)), "ms_per_epoch": float(np.mean(dur)) * 1e3,
+            "edges_feat_per_s": 2 * e * (16 + 7) / float(np.mean(dur)), "final_loss": float(loss)}
+    # roofline variant: K disjoint replicas
+    big_src = np.concatenate([src + k * n for k in range(K)]).astype(np.int32)
+    big_dst = np.concatenate([dst + k * n for k in range(K)]).astype(np.int32)
+    gk = kernels.build_graph_csr(big_src, big_dst, n * K, dev)
+    norm = torch.rand(n * K, 1, device=dev) + 0.5
+    tab = {}
+    for Fw in (16, 7, 64, 128):
+        xk = torch.randn(n * K, Fw, device=dev)
+        rec = []
+        for _ in range(3):
+            kernels.gcn_agg(xk, norm, norm, gk.fwd)
+        kernels.enable_launch_timing(rec)
+        for _ in range(10):
+            kernels.gcn_agg(xk, norm, norm, gk.fwd)
+            kernels.gcn_agg(xk, norm, norm, gk.bwd)
+        torch.cuda.synchronize()
+        kernels.enable_launch_timing(None)
+        tab[f"F{Fw}"] = kernel_table(rec)["gcn_agg"]
+    line[f"cora_x{K}"] = {"nodes": n * K, "edges": e * K, "gcn_agg_fwd_bwd": tab}
+    return line
+
+
+def cfg3(dev):
+    n, e, fin, H, D = 256_000, 8_000_000, 64, 8, 64
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    src, dst = synthetic_graph(n, e, 2, dev)
+    g = StaticGraph((src, dst), None, n, device=dev, sort_inplace=False)
+    torch.manual_seed(2)
+    conv = GATConv(fin, D, H).to(dev)
+    x = torch.randn(n, fin, device=dev, requires_grad=True)
+    R = torch.randn(n, H, D, device=dev)
+    for _ in range(3):
+        (conv(g, x) * R).sum().backward()
+    rec = []
+    kernels.enable_launch_timing(rec)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 10
+    for _ in range(iters):
+        conv.zero_grad()
+        x.grad = None
+        (conv(g, x) * R).sum().backward()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    kernels.enable_launch_timing(None)
+    return {"config": f"cfg3 GATConv in={fin} H={H} D={D} on |V|={n} |E|={e}: layer fwd+bwd",
+            "ms_per_fwd_bwd": dt * 1e3, "edges_feat_per_s": 2 * e * H * D / dt, "kernels": kernel_table(rec)}
+
+
+def cfg5(dev, epochs=6):
+    n, e0, churn, T, B, feat, hid = 25_000, 250_000, 6250, 40, 20, 32, 64
+    rng = np.random.default_rng(4)
+    stream = rng.choice(n * n, size=e0 + churn * T, replace=False)       # sliding window over an edge stream
+    snaps, pn_edges, pn_targets = [], [], []
+    for t in range(T):
+        keys = stream[t * churn: t * churn + e0]
+        s, d = (keys // n).astype(np.int32), (keys % n).astype(np.int32)
+        snaps.append((torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)))
+        m = 10_000
+        pos = torch.from_numpy(np.stack([s[:m], d[:m]]).astype(np.int64)).to(dev)
+        neg = torch.randint(0, n, (2, m), device=dev)
+        pn_edges.append(torch.cat([pos, neg], 1))
+        pn_targets.append(torch.cat([torch.ones(m, device=dev), torch.zeros(m, device=dev)]))
+    out = {}
+    for mode, kw in (("rebuild_per_snapshot", dict(resident=False, max_cached=B + 1)), ("resident", dict(resident=True))):
+        G = NaiveGraph(snaps, n, device=dev, sort_inplace=False, **kw)
+        torch.manual_seed(4)
+        model = temporal.DynamicSTGraphTGCN(feat, hid).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        bucket = temporal.GradBucket(model.parameters())
+        dur = []
+        for ep in range(epochs):
+            if mode == "rebuild_per_snapshot":
+                G._snapshots.clear()
+                G._ndata.clear()
+            b0, bt0 = G.build_count, G.build_time
+            torch.cuda.synchronize()
+            t0 = time.time()
+            temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep)
+            torch.cuda.synchronize()
+            if ep >= 3:
+                dur.append((time.time() - t0, G.build_count - b0, G.build_time - bt0))
+        out[mode] = {"epochs_per_s": 1.0 / float(np.mean([d[0] for d in dur])),
+                     "s_per_epoch": float(np.mean([d[0] for d in dur])),
+                     "csr_builds_per_epoch": float(np.mean([d[1] for d in dur])),
+                     "csr_build_host_seconds_per_epoch": float(np.mean([d[2] for d in dur]))}
+    # device CSR build alone (fwd + bwd + degrees + node_ids), stream-ordered
+    s, d = snaps[0]
+    for _ in range(3):
+        kernels.build_graph_csr(s, d, n, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        kernels.build_graph_csr(s, d, n, dev)
+    torch.cuda.synchronize()
+    out["device_csr_build_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    return {"config": f"cfg5 dynamic-temporal TGCN |V|={n} E0={e0} +-{churn}/step T={T} B={B} feat={feat} hidden={hid}", **out}
+
+
+def csr_build_cfg2(dev):
+    n, e = 1_000_000, 16_000_000
+    src, dst = synthetic_graph(n, e, 1, dev)
+    kernels.build_graph_csr(src, dst, n, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        kernels.build_graph_csr(src, dst, n, dev)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    return {"config": "device CSR build (fwd+bwd+degrees+node_ids) |V|=1M |E|=16M", "ms": dt * 1e3,
+            "algorithmic_bytes": 2 * 16 * e, "GBps": 2 * 16 * e / dt / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="cfg1,cfg3,cfg5,csr")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    fns = {"cfg1": cfg1, "cfg3": cfg3, "cfg5": cfg5, "csr": csr_build_cfg2}
+    for k in args.only.split(","):
+        print(json.dumps(fns[k](dev)), flush=True)
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
