@@ -114,6 +114,20 @@ int stg_gcn_agg(const float *x, const float *norm_row, const float *norm_col, co
                 const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
                 const int32_t *node_ids, int32_t N, int32_t F, int32_t F_active, void *stream);
 
+/* Same computation with the two per-edge scalars already gathered into CSR order:
+ *   norm_col_edge[e] = norm_col[column_indices[e]],  ew_edge[e] = ew[eids[e]] (or NULL)
+ * (build them once per graph with stg_edge_gather_f32).  The scattered 4-byte gathers of
+ * stg_gcn_agg -- a 64-B sector and a dependent round trip each -- become coalesced streams;
+ * values and results are bit-identical.  This is what the Python executor launches.
+ */
+int stg_gcn_agg_edge(const float *x, const float *norm_row, const float *norm_col_edge,
+                     const float *ew_edge, float *out,
+                     const int32_t *row_offsets, const int32_t *column_indices,
+                     const int32_t *node_ids, int32_t N, int32_t F, int32_t F_active, void *stream);
+
+/* dst[i] = table[idx[i]], i < n.  All [dev]. */
+int stg_edge_gather_f32(float *dst, const float *table, const int32_t *idx, int64_t n, void *stream);
+
 /* ----------------------------------------------------------------- fused GAT
  * Replace the emitted units K0, K1 (forward) and K2 (backward) of GATConv
  * (tracer nn/pytorch/static/gat_conv.py:48-56; listing SURVEY.md Appendix B.3).

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "stg_abi_version", "stg_last_error_string", "stg_set_tuning",
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
-    "stg_gcn_agg", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_er",
+    "stg_gcn_agg", "stg_gcn_agg_edge", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_er",
 )
 
 
@@ -60,6 +60,10 @@ def _load() -> ctypes.CDLL:
     lib.stg_graph_build_device.argtypes = [vp, vp, i64, i32] + [vp] * 11 + [vp, vp, ctypes.c_size_t, vp]
     lib.stg_gcn_agg.restype = ctypes.c_int
     lib.stg_gcn_agg.argtypes = [vp] * 9 + [i32, i32, i32, vp]
+    lib.stg_gcn_agg_edge.restype = ctypes.c_int
+    lib.stg_gcn_agg_edge.argtypes = [vp] * 8 + [i32, i32, i32, vp]
+    lib.stg_edge_gather_f32.restype = ctypes.c_int
+    lib.stg_edge_gather_f32.argtypes = [vp, vp, vp, i64, vp]
     lib.stg_gat_fwd_k0.restype = ctypes.c_int
     lib.stg_gat_fwd_k0.argtypes = [vp] * 8 + [i32, i32, i32, f32, vp]
     lib.stg_gat_fwd_k1.restype = ctypes.c_int

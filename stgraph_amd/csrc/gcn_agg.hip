@@ -8,10 +8,10 @@
 //     Each lane owns VEC contiguous features per chunk (VEC*4 B per load: 16 B
 //     when F % 4 == 0), so one row gather is a single fully coalesced
 //     G*VEC*4-byte request per chunk.
-//   * The row's column indices / norm[col] / edge weights are fetched G at a
-//     time, one per lane (coalesced), then broadcast lane -> row-group with
-//     v_readlane (G = 64, the index lands in an SGPR and the row base address
-//     becomes scalar) or ds_bpermute (G < 64).
+//   * The row's column indices / per-edge coefficients are fetched G at a time,
+//     one per lane (coalesced), then broadcast lane -> row-group with v_readlane
+//     (G = 64, the index lands in an SGPR and the row base address becomes
+//     scalar) or ds_bpermute (G < 64).
 //   * UNROLL row gathers are issued back to back before the first is consumed,
 //     so each wave keeps UNROLL * 64/G rows in flight; the accumulation itself
 //     stays strictly in CSR order with ONE fp32 accumulator per (row, feature)
@@ -19,6 +19,12 @@
 //     reference's sequential loop.
 //   * All loop bounds are wave-uniform (SGPR); per-row raggedness is handled by
 //     predication, so no lane ever leaves a shuffle early.
+//
+// PRE (stg_gcn_agg_edge): norm[col[e]] and w[eid[e]] arrive already gathered into
+// CSR order (stg_edge_gather_f32, done once per graph by the caller).  The two
+// scattered 4-byte gathers per edge -- each of which costs a whole 64-B sector of
+// fabric traffic and a dependent round trip -- become coalesced streams; the
+// values, and therefore the results, are identical.
 #include "stg_common.hpp"
 
 namespace stg {
@@ -37,7 +43,7 @@ __device__ __forceinline__ float bcast_f(float v, int src)
     return __int_as_float(bcast_i<G>(__float_as_int(v), src));
 }
 
-template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, int UNROLL>
+template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL>
 __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
     const float *__restrict__ x, const float *__restrict__ norm_row,
     const float *__restrict__ norm_col, const float *__restrict__ ew, float *__restrict__ out,
@@ -82,9 +88,15 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
             int c = 0;
             float nc = 0.f, w = 1.f;
             if (j < cnt) {
-                c = column_indices[beg + base + j];
-                nc = norm_col[c];
-                if constexpr (HAS_EW) w = ew[eids[beg + base + j]];
+                const int e = beg + base + j;
+                c = column_indices[e];
+                if constexpr (PRE) {
+                    nc = norm_col[e];                         // = norm[col[e]], gathered once per graph
+                    if constexpr (HAS_EW) w = ew[e];          // = w[eid[e]]
+                } else {
+                    nc = norm_col[c];
+                    if constexpr (HAS_EW) w = ew[eids[e]];
+                }
             }
             for (int k = 0; k < cnt_max; k += U) {
                 float v[U][CHUNKS][VEC];
@@ -138,6 +150,15 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
     }
 }
 
+// dst[i] = table[idx[i]]  (or table[idx[perm[i]]] when perm != NULL)
+__global__ void edge_gather_kernel(float *__restrict__ dst, const float *__restrict__ table,
+                                   const int *__restrict__ idx, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = table[idx[i]];
+}
+
 namespace {
 
 struct GcnArgs {
@@ -145,15 +166,16 @@ struct GcnArgs {
     float *out;
     const int *row_offsets, *column_indices, *eids, *node_ids;
     int N, F, F_active;
+    bool pre;
     hipStream_t stream;
 };
 
-template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, int UNROLL>
+template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL>
 void launch(const GcnArgs &a)
 {
     constexpr int rows_per_block = (kWave >> LOG2G) * kWavesPerBlock;
     const int64_t blocks = ((int64_t)a.N + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, UNROLL>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL>), dim3((unsigned)blocks),
                        dim3(kBlock), 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out,
                        a.row_offsets, a.column_indices, a.eids, a.node_ids, a.N, a.F, a.F_active);
 }
@@ -161,8 +183,13 @@ void launch(const GcnArgs &a)
 template <int VEC, int LOG2G, int CHUNKS, int UNROLL>
 void launch_ew(const GcnArgs &a)
 {
-    if (a.ew) launch<VEC, LOG2G, CHUNKS, true, UNROLL>(a);
-    else launch<VEC, LOG2G, CHUNKS, false, UNROLL>(a);
+    if (a.pre) {
+        if (a.ew) launch<VEC, LOG2G, CHUNKS, true, true, UNROLL>(a);
+        else launch<VEC, LOG2G, CHUNKS, false, true, UNROLL>(a);
+    } else {
+        if (a.ew) launch<VEC, LOG2G, CHUNKS, true, false, UNROLL>(a);
+        else launch<VEC, LOG2G, CHUNKS, false, false, UNROLL>(a);
+    }
 }
 
 template <int VEC, int LOG2G, int CHUNKS>
@@ -191,6 +218,47 @@ void launch_vec(const GcnArgs &a, int log2g, int chunks, int unroll)
     }
 }
 
+int gcn_agg_dispatch(GcnArgs a, const char *what)
+{
+    if (a.N < 0 || a.F <= 0 || a.F_active < 0 || a.F_active > a.F)
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad shape N=%d F=%d F_active=%d", what, a.N, a.F, a.F_active);
+    if (a.N == 0 || a.F_active == 0) return 0;
+    // column_indices / eids / per-edge arrays may be NULL for a graph without edges
+    if (!a.x || !a.norm_row || !a.out || !a.row_offsets || (!a.pre && !a.norm_col))
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
+    if (!a.pre && a.ew && !a.eids)
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: edge weights given without eids", what);
+
+    const uintptr_t align = reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.out);
+    int vec = 1;
+    if (a.F % 4 == 0 && a.F_active % 4 == 0 && align % 16 == 0) vec = 4;
+    else if (a.F % 2 == 0 && a.F_active % 2 == 0 && align % 8 == 0) vec = 2;
+
+    // performance knob: force the number of lanes per row (shrinks VEC if the row is too narrow)
+    const int forced = tuning().gcn_lanes_per_row;
+    if (forced > 0) {
+        while (vec > 1 && a.F_active / vec < forced) vec /= 2;
+    } else if (vec == 4 && a.F_active == 128) {
+        vec = 2;      // measured (profiles/r01): one 512-B row per wave (G = 64, 8 B/lane, scalar row
+                      // base via v_readlane) beats two rows per wave (G = 32, 16 B/lane) by ~3 %
+    }
+    const int lanes = (a.F_active + vec - 1) / vec;
+    int log2g = ilog2_ceil(lanes);
+    int chunks = 1;
+    if (log2g > 6) {
+        log2g = 6;
+        const int need = (lanes + kWave - 1) / kWave;
+        chunks = need >= 3 ? 4 : 2;           // wider rows loop over super-chunks inside the kernel
+    }
+    const int unroll = tuning().gcn_unroll > 0 ? tuning().gcn_unroll : (log2g == 6 && chunks == 1 ? 4 : 8);
+    switch (vec) {
+        case 4: launch_vec<4>(a, log2g, chunks, unroll); break;
+        case 2: launch_vec<2>(a, log2g, chunks, unroll); break;
+        default: launch_vec<1>(a, log2g, chunks, unroll); break;
+    }
+    return check_launch(what);
+}
+
 }  // namespace
 }  // namespace stg
 
@@ -200,42 +268,29 @@ extern "C" int stg_gcn_agg(const float *x, const float *norm_row, const float *n
                            const int32_t *node_ids, int32_t N, int32_t F, int32_t F_active,
                            void *stream)
 {
+    return stg::gcn_agg_dispatch({x, norm_row, norm_col, ew, out, row_offsets, column_indices, eids, node_ids,
+                                  N, F, F_active, false, static_cast<hipStream_t>(stream)}, "stg_gcn_agg");
+}
+
+extern "C" int stg_gcn_agg_edge(const float *x, const float *norm_row, const float *norm_col_edge,
+                                const float *ew_edge, float *out, const int32_t *row_offsets,
+                                const int32_t *column_indices, const int32_t *node_ids, int32_t N,
+                                int32_t F, int32_t F_active, void *stream)
+{
+    return stg::gcn_agg_dispatch({x, norm_row, norm_col_edge, ew_edge, out, row_offsets, column_indices, nullptr,
+                                  node_ids, N, F, F_active, true, static_cast<hipStream_t>(stream)},
+                                 "stg_gcn_agg_edge");
+}
+
+extern "C" int stg_edge_gather_f32(float *dst, const float *table, const int32_t *idx, int64_t n,
+                                   void *stream)
+{
     using namespace stg;
-    if (N < 0 || F <= 0 || F_active < 0 || F_active > F)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg: bad shape N=%d F=%d F_active=%d", N, F, F_active);
-    if (N == 0 || F_active == 0) return 0;
-    // column_indices / eids may be NULL for a graph without edges (no row is ever entered)
-    if (!x || !norm_row || !norm_col || !out || !row_offsets)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg: NULL pointer argument");
-    if (ew && !eids)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg: edge weights given without eids");
-
-    const uintptr_t align = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out);
-    int vec = 1;
-    if (F % 4 == 0 && F_active % 4 == 0 && align % 16 == 0) vec = 4;
-    else if (F % 2 == 0 && F_active % 2 == 0 && align % 8 == 0) vec = 2;
-
-    // performance knob: force the number of lanes per row (shrinks VEC if the row is too narrow)
-    const int forced = tuning().gcn_lanes_per_row;
-    if (forced > 0) {
-        while (vec > 1 && F_active / vec < forced) vec /= 2;
-    }
-    const int lanes = (F_active + vec - 1) / vec;
-    int log2g = ilog2_ceil(lanes);
-    int chunks = 1;
-    if (log2g > 6) {
-        log2g = 6;
-        const int need = (lanes + kWave - 1) / kWave;
-        chunks = need >= 3 ? 4 : 2;           // wider rows loop over super-chunks inside the kernel
-    }
-    const int unroll = tuning().gcn_unroll > 0 ? tuning().gcn_unroll : 8;
-
-    GcnArgs a{x, norm_row, norm_col, ew, out, row_offsets, column_indices, eids, node_ids,
-              N, F, F_active, static_cast<hipStream_t>(stream)};
-    switch (vec) {
-        case 4: launch_vec<4>(a, log2g, chunks, unroll); break;
-        case 2: launch_vec<2>(a, log2g, chunks, unroll); break;
-        default: launch_vec<1>(a, log2g, chunks, unroll); break;
-    }
-    return check_launch("stg_gcn_agg");
+    if (n < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edge_gather_f32: negative size");
+    if (n == 0) return 0;
+    if (!dst || !table || !idx) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edge_gather_f32: NULL pointer argument");
+    const int blocks = (int)std::min<int64_t>((n + kBlock - 1) / kBlock, 256 * 16);
+    hipLaunchKernelGGL(edge_gather_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), dst,
+                       table, idx, n);
+    return check_launch("stg_edge_gather_f32");
 }

@@ -239,6 +239,31 @@ def csr_ctor_host(a, b, eid, edge_weight, num_nodes: int, is_edge_reverse: bool 
 
 
 # ------------------------------------------------------------------------------- GCN
+_EDGE_CACHE = True
+
+
+def set_edge_cache(enabled: bool) -> None:
+    """Per-CSR cache of the per-edge scalars in CSR order (norm[col[e]], w[eid[e]]); on by default.
+    Off: every launch gathers them itself (stg_gcn_agg), as the reference's kernels do."""
+    global _EDGE_CACHE
+    _EDGE_CACHE = bool(enabled)
+
+
+def _edge_gathered(csr: "DeviceCSR", kind: str, table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """table[idx] in CSR order, cached on the CSR object.  The cache entry keeps a reference to the
+    source tensor and its version counter, so an in-place update or a new tensor invalidates it and
+    a freed tensor's address can never be mistaken for a live one."""
+    cache = csr.__dict__.setdefault("_edge_cache", {})
+    hit = cache.get(kind)
+    if hit is not None and hit[0] is table and hit[1] == table._version:
+        return hit[2]
+    dst = torch.empty(csr.num_edges, dtype=torch.float32, device=table.device)
+    _C.check(_C.lib.stg_edge_gather_f32(_ptr(dst), _ptr(table), _ptr(idx), csr.num_edges,
+                                        _stream_ptr(table.device)))
+    cache[kind] = (table, table._version, dst)
+    return dst
+
+
 def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr: DeviceCSR,
             ew: torch.Tensor | None = None, use_node_ids: bool = False,
             f_active: int | None = None) -> torch.Tensor:
@@ -262,12 +287,21 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
             raise ValueError(f"edge_weight has {ew.numel()} entries, graph has {csr.num_edges} edges")
     fa = F if f_active is None else int(f_active)
     out = (torch.empty_like(x) if fa == F else torch.zeros_like(x))
-    with torch.cuda.device(dev), _Timed("gcn_agg", gcn_agg_algorithmic_bytes(N, csr.num_edges, fa, ew is not None),
-                                        csr.num_edges * fa):
-        _C.check(_C.lib.stg_gcn_agg(
-            _ptr(x), _ptr(norm_row), _ptr(norm_col), _ptr(ew), _ptr(out),
-            _ptr(csr.row_offset), _ptr(csr.column_indices), _ptr(csr.eids),
-            _ptr(csr.node_ids if use_node_ids else None), N, F, fa, _stream_ptr(dev)))
+    nid = _ptr(csr.node_ids if use_node_ids else None)
+    with torch.cuda.device(dev):
+        if _EDGE_CACHE:
+            nc_e = _edge_gathered(csr, "norm", norm_col, csr.column_indices)
+            ew_e = None if ew is None else _edge_gathered(csr, "ew", ew, csr.eids)
+        with _Timed("gcn_agg", gcn_agg_algorithmic_bytes(N, csr.num_edges, fa, ew is not None), csr.num_edges * fa):
+            if _EDGE_CACHE:
+                _C.check(_C.lib.stg_gcn_agg_edge(
+                    _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(out),
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, N, F, fa, _stream_ptr(dev)))
+            else:
+                _C.check(_C.lib.stg_gcn_agg(
+                    _ptr(x), _ptr(norm_row), _ptr(norm_col), _ptr(ew), _ptr(out),
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), _ptr(csr.eids), nid, N, F, fa,
+                    _stream_ptr(dev)))
     return out
 
 

@@ -33,7 +33,9 @@ class GCNConv(nn.Module):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
 
-    def forward(self, graph, h, edge_weight=None):
+    @staticmethod
+    def check_norm(graph) -> None:
+        """reference gcn_conv.py:151-156"""
         if graph.get_ndata("norm") is None:
             raise KeyError("StaticGraph passed to GCNConv forward pass does not contain 'norm' node data")
         if (len(graph.get_ndata("norm").shape) != SizeConstants.NODE_NORM_SIZE.value or
@@ -41,32 +43,36 @@ class GCNConv(nn.Module):
                 graph.get_ndata("norm").shape[0] != graph.get_num_nodes()):
             raise ValueError("Node data 'norm' passed to GCNConv should be of shape (num_nodes, 1)")
 
-        h = torch.mm(h, self.weight)
-
+    def aggregate(self, graph, h, edge_weight=None):
+        """The vertex-centric part of the layer (reference gcn_conv.py:160-182) on an already
+        transformed feature matrix ``h``."""
         if edge_weight is None:
 
             @self.stgraph.compile(gnn_module=self)
             def nb_compute(v):
                 return sum([nb.h * nb.norm for nb in v.innbs]) * v.norm
 
-            h = nb_compute(g=graph, n_feats={"norm": graph.get_ndata("norm"), "h": h})
-        else:
+            return nb_compute(g=graph, n_feats={"norm": graph.get_ndata("norm"), "h": h})
 
-            @self.stgraph.compile(gnn_module=self)
-            def nb_compute(v):
-                return sum(
-                    [
-                        nb_edge.src.norm * nb_edge.src.h * nb_edge.edge_weight
-                        for nb_edge in v.inedges
-                    ],
-                ) * v.norm
+        @self.stgraph.compile(gnn_module=self)
+        def nb_compute(v):  # noqa: F811
+            return sum(
+                [
+                    nb_edge.src.norm * nb_edge.src.h * nb_edge.edge_weight
+                    for nb_edge in v.inedges
+                ],
+            ) * v.norm
 
-            h = nb_compute(
-                g=graph,
-                n_feats={"norm": graph.get_ndata("norm"), "h": h},
-                e_feats={"edge_weight": edge_weight},
-            )
+        return nb_compute(
+            g=graph,
+            n_feats={"norm": graph.get_ndata("norm"), "h": h},
+            e_feats={"edge_weight": edge_weight},
+        )
 
+    def forward(self, graph, h, edge_weight=None):
+        self.check_norm(graph)
+        h = torch.mm(h, self.weight)
+        h = self.aggregate(graph, h, edge_weight)
         if self.bias is not None:
             h = h + self.bias
         if self.activation:

@@ -1,6 +1,15 @@
 """``TGCN`` -- drop-in for ``stgraph.nn.pytorch.temporal.tgcn.TGCN``
 (reference nn/pytorch/temporal/tgcn.py:4-55): three GCNConv gates + GRU update.
 Module names (``conv_z/r/h``, ``linear_z/r/h``) match for ``state_dict`` exchange.
+
+``fuse_gates`` (default on): the three gates aggregate the SAME input
+over the SAME graph, ``A_hat (X W_g) + b_g`` for g in {z, r, h}.  Aggregation is column
+independent, so one launch at width 3*out over ``X [W_z | W_r | W_h]`` produces exactly the
+columns the three separate launches produce (same per-column summation order), with one
+third of the launches and 768-byte instead of 256-byte gathered rows.  The only numerical
+difference is rocBLAS choosing its tiling for a [N, in] x [in, 3*out] product instead of three
+[in, out] ones (fp32 rounding of the K = in dot products).  ``fuse_gates = False`` runs the
+reference's three separate layers.
 """
 from __future__ import annotations
 
@@ -10,6 +19,8 @@ from ..static.gcn_conv import GCNConv
 
 
 class TGCN(torch.nn.Module):
+    fuse_gates = True
+
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.in_channels = in_channels
@@ -26,25 +37,31 @@ class TGCN(torch.nn.Module):
             H = torch.zeros(X.shape[0], self.out_channels).to(X.device)
         return H
 
-    def _calculate_update_gate(self, g, X, edge_weight, H):
-        h = self.conv_z(g, X, edge_weight=edge_weight)
-        h = torch.clamp(h, min=-1e6, max=1e6)
+    def _gate_convs(self, g, X, edge_weight):
+        """(conv_z(X), conv_r(X), conv_h(X)), clamped as in tgcn.py:22,30,38."""
+        convs = (self.conv_z, self.conv_r, self.conv_h)
+        if self.fuse_gates and all(type(c) is GCNConv and c.bias is not None for c in convs):
+            GCNConv.check_norm(g)
+            W = torch.cat([c.weight for c in convs], dim=1)
+            b = torch.cat([c.bias for c in convs], dim=0)
+            h = self.conv_z.aggregate(g, torch.mm(X, W), edge_weight) + b
+            h = torch.clamp(h, min=-1e6, max=1e6)
+            return torch.split(h, self.out_channels, dim=1)
+        return tuple(torch.clamp(c(g, X, edge_weight=edge_weight), min=-1e6, max=1e6) for c in convs)
+
+    def _calculate_update_gate(self, h, H):
         Z = torch.cat((h, H), dim=1)
         Z = self.linear_z(Z)
         Z = torch.sigmoid(Z)
         return Z
 
-    def _calculate_reset_gate(self, g, X, edge_weight, H):
-        h = self.conv_r(g, X, edge_weight=edge_weight)
-        h = torch.clamp(h, min=-1e6, max=1e6)
+    def _calculate_reset_gate(self, h, H):
         R = torch.cat((h, H), dim=1)
         R = self.linear_r(R)
         R = torch.sigmoid(R)
         return R
 
-    def _calculate_candidate_state(self, g, X, edge_weight, H, R):
-        h = self.conv_h(g, X, edge_weight=edge_weight)
-        h = torch.clamp(h, min=-1e6, max=1e6)
+    def _calculate_candidate_state(self, h, H, R):
         H_tilde = torch.cat((h, H * R), dim=1)
         H_tilde = self.linear_h(H_tilde)
         H_tilde = torch.tanh(H_tilde)
@@ -56,8 +73,9 @@ class TGCN(torch.nn.Module):
 
     def forward(self, g, X, edge_weight=None, H=None):
         H = self._set_hidden_state(X, H)
-        Z = self._calculate_update_gate(g, X, edge_weight, H)
-        R = self._calculate_reset_gate(g, X, edge_weight, H)
-        H_tilde = self._calculate_candidate_state(g, X, edge_weight, H, R)
+        hz, hr, hh = self._gate_convs(g, X, edge_weight)
+        Z = self._calculate_update_gate(hz, H)
+        R = self._calculate_reset_gate(hr, H)
+        H_tilde = self._calculate_candidate_state(hh, H, R)
         H = self._calculate_hidden_state(Z, H, H_tilde)
         return H

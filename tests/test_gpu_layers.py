@@ -98,8 +98,9 @@ def _load_params(model, d, prefix, dev):
             p.copy_(_t(d[prefix + k], dev))
 
 
+@pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("B", [3, 6])
-def test_tgcn_bptt_matches_reference(cuda, B):
+def test_tgcn_bptt_matches_reference(cuda, B, fuse):
     from stgraph_amd.graph import StaticGraph
     d = golden("tgcn.npz")
     n, T = int(d["num_nodes"]), d["feats"].shape[0]
@@ -109,6 +110,7 @@ def test_tgcn_bptt_matches_reference(cuda, B):
     g.set_ndata("norm", _t(d["norm"], cuda))
     feats, targets = _t(d["feats"], cuda), _t(d["targets"], cuda)
     model = TGCNModel(feats.shape[2], 16, 1).to(cuda)
+    model.temporal.fuse_gates = fuse
     _load_params(model, d, f"B{B}_param_", cuda)
     hs, costs = [], []
     for w0 in range(0, T, B):
@@ -127,8 +129,12 @@ def test_tgcn_bptt_matches_reference(cuda, B):
     np.testing.assert_allclose(torch.stack(hs).cpu().numpy(), d[f"B{B}_hidden"], rtol=TOL, atol=TOL)
     np.testing.assert_allclose(torch.stack(costs).cpu().numpy(), d[f"B{B}_cost"], rtol=TOL, atol=TOL)
     for conv in (model.temporal.conv_z, model.temporal.conv_r, model.temporal.conv_h):
-        for ex in conv.stgraph._ctx_map["nb_compute"]._executors.values():
-            assert len(ex.ts.tensor_map_stack) == 0
+        if "nb_compute" in conv.stgraph._ctx_map:
+            for ex in conv.stgraph._ctx_map["nb_compute"]._executors.values():
+                assert len(ex.ts.tensor_map_stack) == 0
+    used = [c for c in (model.temporal.conv_z, model.temporal.conv_r, model.temporal.conv_h)
+            if "nb_compute" in c.stgraph._ctx_map]
+    assert len(used) == (1 if fuse else 3)        # fused gates: ONE aggregation launch per step
 
 
 def test_tgcn_adam_training_loop_matches_reference(cuda):
@@ -201,3 +207,71 @@ def test_naive_graph_tgcn_bptt_matches_reference(cuda, resident):
     G.reset_graph()
     G.get_graph(1)
     assert G.current_timestamp == 1
+
+
+def test_fused_gates_equal_separate_gates(cuda):
+    """One width-3H aggregation == three width-H aggregations, column for column."""
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn.pytorch.temporal.tgcn import TGCN
+    from tests.util import random_graph
+    n, e = 4000, 50000
+    src, dst = random_graph(77, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    f = g.csr("fwd")
+    deg = (f.row_offset[1:] - f.row_offset[:-1]).float()
+    norm = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg)).unsqueeze(1)
+    g.set_ndata("norm", norm)
+    h3 = torch.randn(n, 192, device=cuda)
+    fused = kernels.gcn_agg(h3, norm, norm, f)
+    for k in range(3):
+        part = kernels.gcn_agg(h3[:, 64 * k:64 * (k + 1)].contiguous(), norm, norm, f)
+        assert torch.equal(fused[:, 64 * k:64 * (k + 1)], part)
+    torch.manual_seed(0)
+    m = TGCN(32, 64).to(cuda)
+    x = torch.randn(n, 32, device=cuda)
+    w = torch.rand(len(src), 1, device=cuda) + 0.5
+    outs = []
+    for fuse in (True, False):
+        m.fuse_gates = fuse
+        m.zero_grad()
+        H = m(g, x, w, None)
+        H = m(g, x, w, H)
+        (H ** 2).sum().backward()
+        outs.append((H.detach().clone(), [p.grad.clone() for p in m.parameters()]))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+    for a, b in zip(outs[0][1], outs[1][1]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_captured_window_replays_the_eager_loop(cuda):
+    """HIP-graph replay of a BPTT window == the eager loop (losses and parameters after 2 epochs)."""
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import StaticGraph
+    from tests.util import random_graph
+    n, e, feat, hid, T, B = 3000, 30000, 8, 16, 12, 4
+    src, dst = random_graph(5, n, e)
+    e = len(src)
+    results = []
+    for captured in (False, True):
+        g = StaticGraph((src.copy(), dst.copy()), None, n, device=cuda, sort_inplace=False)
+        g.set_ndata("norm", temporal.in_degree_norm(g))
+        gen = torch.Generator(device=cuda).manual_seed(9)
+        ew = torch.rand(e, 1, device=cuda, generator=gen) + 0.5
+        targets = torch.randn(T, n, 1, device=cuda, generator=gen)
+        torch.manual_seed(1)
+        model = temporal.STGraphTGCN(feat, hid, 1).to(cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True)
+        bucket = temporal.GradBucket(model.parameters())
+        losses = []
+        if captured:
+            cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, feat)
+        for ep in range(2):
+            if captured:
+                losses += temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat, epoch=ep)
+            else:
+                losses += temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, feat, epoch=ep)
+        results.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+    torch.testing.assert_close(results[0][0], results[1][0], rtol=1e-5, atol=1e-7)
+    for a, b in zip(results[0][1], results[1][1]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--ew", action="store_true")
-    ap.add_argument("--configs", default="0:0,32:8,32:4,64:8,64:4,16:8,32:2,64:2")
+    ap.add_argument("--configs", default="0:0:1,0:0:0,64:4:1,64:4:0,64:2:1,32:4:1")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     src, dst = synthetic_graph(args.nodes, args.edges, 1, dev)
@@ -30,7 +30,9 @@ def main():
     ew = (torch.rand(args.edges, 1, device=dev) + 0.5) if args.ew else None
     nbytes = kernels.gcn_agg_algorithmic_bytes(args.nodes, args.edges, args.feat, args.ew)
     for cfg in args.configs.split(","):
-        lanes, unroll = map(int, cfg.split(":"))
+        parts = list(map(int, cfg.split(":")))
+        lanes, unroll = parts[0], parts[1]
+        kernels.set_edge_cache(bool(parts[2]) if len(parts) > 2 else True)
         _C.set_tuning("gcn_lanes_per_row", lanes)
         _C.set_tuning("gcn_unroll", unroll)
         for csr_name, csr in (("fwd", g.fwd), ("bwd", g.bwd)):
@@ -45,7 +47,7 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(a.elapsed_time(b))
             med = float(np.median(ts))
-            print(json.dumps({"lanes": lanes, "unroll": unroll, "csr": csr_name, "F": args.feat, "ms": round(med, 4),
+            print(json.dumps({"edge_cache": kernels._EDGE_CACHE, "lanes": lanes, "unroll": unroll, "csr": csr_name, "F": args.feat, "ms": round(med, 4),
                               "min_ms": round(min(ts), 4), "GBps_alg": round(nbytes / med / 1e6, 1),
                               "frac_of_8TBps": round(nbytes / med / 1e6 / 8000, 3)}), flush=True)
 
