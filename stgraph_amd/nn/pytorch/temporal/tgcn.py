@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import torch
 
+from .... import kernels
 from ..static.gcn_conv import GCNConv
 
 
@@ -34,13 +35,15 @@ class TGCN(torch.nn.Module):
 
     def _set_hidden_state(self, X, H):
         if H is None:
-            H = torch.zeros(X.shape[0], self.out_channels).to(X.device)
+            H = torch.zeros(X.shape[0], self.out_channels, device=X.device)   # no host copy: capturable
         return H
 
     def _gate_convs(self, g, X, edge_weight):
         """(conv_z(X), conv_r(X), conv_h(X)), clamped as in tgcn.py:22,30,38."""
         convs = (self.conv_z, self.conv_r, self.conv_h)
-        if self.fuse_gates and all(type(c) is GCNConv and c.bias is not None for c in convs):
+        # (reference-compat mode keeps the three launches: defect D1 depends on the launch width)
+        if self.fuse_gates and not kernels.reference_compat() and \
+                all(type(c) is GCNConv and c.bias is not None for c in convs):
             GCNConv.check_norm(g)
             W = torch.cat([c.weight for c in convs], dim=1)
             b = torch.cat([c.bias for c in convs], dim=0)
