@@ -162,6 +162,18 @@ int stg_gat_bwd_er(const float *T, float *grad_er,
                    const int32_t *row_offsets, const int32_t *eids, const int32_t *node_ids,
                    int32_t N, int32_t H, int32_t H_active, void *stream);
 
+/* ------------------------------------------------- dense neighbour: weight gradient
+ * C[M,N] = A[K,M]^T * B[K,N], all fp32 row-major [dev]; K = number of vertices (large), M, N =
+ * feature widths (small).  This is dW = X^T dY of `torch.mm(h, self.weight)`
+ * (nn/pytorch/static/gcn_conv.py:158) and of TGCN's gate Linears (nn/pytorch/temporal/tgcn.py:21-47),
+ * which the reference leaves to cuBLAS.  Split-K over the whole chip on fp32 matrix cores
+ * (exact fp32 fma chain per slice), slices added in a fixed order: deterministic, no atomics.
+ * workspace [dev] must hold stg_gemm_tn_workspace_bytes(K, M, N) bytes.
+ */
+size_t stg_gemm_tn_workspace_bytes(int64_t K, int32_t M, int32_t N);
+int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t M, int32_t N,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

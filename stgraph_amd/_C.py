@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_er",
+    "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32",
 )
 
 
@@ -72,6 +73,10 @@ def _load() -> ctypes.CDLL:
     lib.stg_gat_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, f32, vp]
     lib.stg_gat_bwd_er.restype = ctypes.c_int
     lib.stg_gat_bwd_er.argtypes = [vp] * 5 + [i32, i32, i32, vp]
+    lib.stg_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_gemm_tn_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.stg_gemm_tn_f32.restype = ctypes.c_int
+    lib.stg_gemm_tn_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp, ctypes.c_size_t, vp]
     if lib.stg_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.stg_abi_version()} != expected {ABI_VERSION}; rebuild")
     return lib

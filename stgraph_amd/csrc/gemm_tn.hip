@@ -1,0 +1,243 @@
+// C[M,N] = A[K,M]^T * B[K,N]  for tall-skinny operands (K = number of vertices, M,N = feature
+// widths): the weight-gradient contraction  dW = X^T dY  of every dense layer next to the Seastar
+// kernels (GCNConv's X W, TGCN's gate Linears).  rocBLAS/hipBLASLt pick a 32x32..32x64 macro-tile
+// without split-K for these shapes, i.e. 4-16 workgroups on a 256-CU chip (measured: 194 us for
+// 64x128xK=50K, 1.82 ms for 128x128xK=1M; profiles/r01).  This kernel splits K over the whole chip.
+//
+// fp32 in, fp32 accumulate on the matrix cores: v_mfma_f32_32x32x2_f32 is an exact k-ordered fmaf
+// chain (no xf32/TF32 on gfx950), so the only difference from a sequential sum is the fixed split
+// of K into slices, each summed in order, slices added in order (deterministic, no atomics).
+//
+// Layout trick: A is [K,M] row-major and the MFMA wants A^T fragments "lane l holds A^T[i=l&31]
+// [k=l>>5]" = A[k][m0 + (l&31)]: for a fixed k that is 32 CONSECUTIVE floats, so both operands load
+// straight from global memory in fragment layout as two coalesced 128-B segments per instruction;
+// no LDS transpose, no bank conflicts.  Addresses are (wave-uniform row base in SGPRs) + (one
+// loop-invariant 32-bit lane offset), so the two in-flight operand sets cost no address VGPRs.
+// LDS is used only to add the 4 waves of a block (4 adjacent K sub-slices of the same output tile)
+// before one slab write.
+#include "stg_common.hpp"
+
+namespace stg {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kGemmKStep = 16;             // K slices are multiples of this (covers KU = 4 and 8)
+
+// NT = 32-column tiles per wave, KU = k-pairs per operand set (KU * (1 + NT) dword loads in flight)
+template <int NT, int KU>
+__global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
+    const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ slab, int64_t K,
+    int M, int N, int64_t kslice_wave, int m_tiles, int n_groups)
+{
+    extern __shared__ float lds[];                       // 3 waves x NT x 16 x 64 floats
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mi = blockIdx.x % m_tiles;
+    const int t = blockIdx.x / m_tiles;
+    const int nj = t % n_groups;
+    const int s = t / n_groups;
+
+    const int64_t k0 = ((int64_t)s * kWavesPerBlock + wave) * kslice_wave;      // wave-uniform
+    const int64_t k1 = min(K, k0 + kslice_wave);
+    const int kh = lane >> 5;
+    // Rows >= M / columns >= N of the tile are never written back, so out-of-range lanes read a
+    // clamped (valid) address: no per-load m/n predicates.  Only the K tail needs masking.
+    const int m = mi * 32 + (lane & 31);
+    const unsigned la = (unsigned)(kh * M + min(m, M - 1));                     // lane offset into an A row pair
+    int n[NT];
+    unsigned lb[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        n[j] = (nj * NT + j) * 32 + (lane & 31);
+        nok[j] = n[j] < N;
+        lb[j] = (unsigned)(kh * N + min(n[j], N - 1));
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    constexpr int STEP = 2 * KU;
+    // Buffer descriptors over THIS wave's K slice: the hardware range check returns 0 for rows
+    // >= k1, which is exactly the zero padding the tail needs, and every load is
+    // (descriptor in SGPRs) + (loop-invariant 32-bit lane offset) + (scalar row offset).
+    const int64_t rows = k1 > k0 ? k1 - k0 : 0;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + k0 * M), 0,
+                                                       (int)(rows * M * (int64_t)sizeof(float)), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + k0 * N), 0,
+                                                       (int)(rows * N * (int64_t)sizeof(float)), 0x00020000);
+    const int voA = (int)(la * sizeof(float));
+    int voB[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) voB[j] = (int)(lb[j] * sizeof(float));
+    auto load_set = [&](float (&a)[KU], float (&b)[KU][NT], int64_t k) {
+        const int r0 = (int)(k - k0);                                           // uniform
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int soA = (r0 + 2 * u) * M * (int)sizeof(float);
+            const int soB = (r0 + 2 * u) * N * (int)sizeof(float);
+            a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voA, soA, 0));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                b[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voB[j], soB, 0));
+        }
+    };
+    auto mfma_set = [&](const float (&a)[KU], const float (&b)[KU][NT]) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][j], acc[j], 0, 0, 0);
+    };
+
+    // two operand sets: the loads of the next STEP rows are in flight while the matrix pipe
+    // consumes the current set (fp32 MFMA: 64 cycles each, KU*NT of them per set)
+    float a0[KU], b0[KU][NT], a1[KU], b1[KU][NT];
+    if (k0 < k1) load_set(a0, b0, k0);
+    for (int64_t k = k0; k < k1; k += 2 * STEP) {
+        const bool more1 = k + STEP < k1;
+        if (more1) load_set(a1, b1, k + STEP);
+        mfma_set(a0, b0);
+        if (more1) {
+            if (k + 2 * STEP < k1) load_set(a0, b0, k + 2 * STEP);
+            mfma_set(a1, b1);
+        }
+    }
+
+    // add the block's 4 K sub-slices in wave order (fixed => deterministic), wave 0 writes the slab
+    if (wave > 0) {
+        float *dst = lds + (size_t)(wave - 1) * NT * 16 * kWave + lane;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[(j * 16 + i) * kWave] = acc[j][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < kWavesPerBlock - 1; ++w) {
+            const float *src = lds + (size_t)w * NT * 16 * kWave + lane;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] += src[(j * 16 + i) * kWave];
+        }
+        // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        const int row0 = mi * 32 + 4 * kh;
+        float *out = slab + (int64_t)s * M * N + (int64_t)row0 * N;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (!nok[j]) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int dr = (i & 3) + 8 * (i >> 2);
+                if (row0 + dr < M) out[dr * N + n[j]] = acc[j][i];
+            }
+        }
+    }
+}
+
+// C[o] = sum_s slab[s][o]: 64 outputs per block, the 4 waves take s = w, w+4, ... (8 loads in
+// flight each) and are combined in wave order through LDS -- fixed order, deterministic.
+__global__ __launch_bounds__(kBlock) void gemm_tn_reduce_kernel(const float *__restrict__ slab,
+                                                                float *__restrict__ C, int64_t MN, int S)
+{
+    __shared__ float part[kWavesPerBlock][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x >> 6;
+    const int64_t o = (int64_t)blockIdx.x * kWave + lane;
+    float acc = 0.f;
+    if (o < MN) {
+        int s = w;
+        for (; s + 7 * kWavesPerBlock < S; s += 8 * kWavesPerBlock) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(s + u * kWavesPerBlock) * MN + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; s < S; s += kWavesPerBlock) acc += slab[(int64_t)s * MN + o];
+    }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && o < MN) C[o] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
+namespace {
+
+struct GemmPlan {
+    int nt, m_tiles, n_groups, S;
+    int64_t kslice_wave;
+};
+
+GemmPlan plan_gemm_tn(int64_t K, int M, int N)
+{
+    GemmPlan p{};
+    p.nt = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
+    p.m_tiles = (M + 31) / 32;
+    p.n_groups = (N + 32 * p.nt - 1) / (32 * p.nt);
+    const int64_t tiles = (int64_t)p.m_tiles * p.n_groups;
+    // ~512 blocks = 2 waves on every SIMD; never slice below 64 rows per wave
+    int64_t S = (512 + tiles - 1) / tiles;
+    const int64_t max_S = std::max<int64_t>(1, K / (64 * kWavesPerBlock));
+    S = std::max<int64_t>(1, std::min(S, max_S));
+    int64_t per_wave = (K + S * kWavesPerBlock - 1) / (S * kWavesPerBlock);
+    per_wave = (per_wave + kGemmKStep - 1) / kGemmKStep * kGemmKStep;
+    p.kslice_wave = std::max<int64_t>(per_wave, kGemmKStep);
+    p.S = (int)((K + p.kslice_wave * kWavesPerBlock - 1) / (p.kslice_wave * kWavesPerBlock));
+    if (p.S < 1) p.S = 1;
+    return p;
+}
+
+}  // namespace
+}  // namespace stg
+
+extern "C" size_t stg_gemm_tn_workspace_bytes(int64_t K, int32_t M, int32_t N)
+{
+    if (K <= 0 || M <= 0 || N <= 0) return 0;
+    const stg::GemmPlan p = stg::plan_gemm_tn(K, M, N);
+    return (size_t)p.S * (size_t)M * (size_t)N * sizeof(float);
+}
+
+extern "C" int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t M, int32_t N,
+                               void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (K < 0 || M <= 0 || N <= 0)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_f32: bad shape K=%lld M=%d N=%d", (long long)K, M, N);
+    if ((int64_t)2 * M * N > INT32_MAX || (int64_t)2 * M > INT32_MAX / 2)
+        return fail(STG_ERR_UNSUPPORTED, "stg_gemm_tn_f32: output %d x %d too large for the tall-skinny kernel", M, N);
+    if (!C) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_f32: NULL output");
+    if (K == 0) {
+        const hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, stream);
+        return e == hipSuccess ? 0 : fail((int)e, "stg_gemm_tn_f32: %s", hipGetErrorString(e));
+    }
+    if (!A || !B || !workspace) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_f32: NULL pointer argument");
+    const GemmPlan p = plan_gemm_tn(K, M, N);
+    const size_t need = (size_t)p.S * (size_t)M * (size_t)N * sizeof(float);
+    if (workspace_bytes < need)
+        return fail(STG_ERR_WORKSPACE, "stg_gemm_tn_f32: workspace %zu < required %zu", workspace_bytes, need);
+    float *slab = static_cast<float *>(workspace);
+    const int64_t blocks = (int64_t)p.S * p.m_tiles * p.n_groups;
+    const size_t lds = (size_t)(kWavesPerBlock - 1) * p.nt * 16 * kWave * sizeof(float);
+    switch (p.nt) {
+        case 1:
+            hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 8>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, A,
+                               B, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups);
+            break;
+        case 2:
+            hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 8>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, A,
+                               B, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups);
+            break;
+        default:
+            hipLaunchKernelGGL((gemm_tn_partial_kernel<4, 4>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, A,
+                               B, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups);
+            break;
+    }
+    const int64_t MN = (int64_t)M * N;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MN + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
+                       slab, C, MN, p.S);
+    return check_launch("stg_gemm_tn_f32");
+}

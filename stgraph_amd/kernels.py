@@ -375,3 +375,22 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
             _C.check(_C.lib.stg_gat_bwd_er(_ptr(T), _ptr(grad_er), _ptr(fwd.row_offset), _ptr(fwd.eids),
                                            _ptr(fwd.node_ids if use_node_ids else None), N, H, h_touched, st))
     return grad_feat, grad_el, grad_er
+
+
+# ------------------------------------------------------- dense neighbour: weight gradient
+def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``a.T @ b`` for tall-skinny fp32 operands ``a [K, M]``, ``b [K, N]`` (stg_gemm_tn_f32)."""
+    a, b = _f32(a, "a"), _f32(b, "b", a.device)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
+        raise ValueError(f"gemm_tn expects [K,M] and [K,N], got {tuple(a.shape)} and {tuple(b.shape)}")
+    K, M = a.shape
+    N = b.shape[1]
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if M == 0 or N == 0:
+        return c
+    ws_bytes = int(_C.lib.stg_gemm_tn_workspace_bytes(K, M, N))
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device), _Timed("gemm_tn", 4 * K * (M + N) + 4 * M * N, 2 * K * M * N):
+        _C.check(_C.lib.stg_gemm_tn_f32(_ptr(a), _ptr(b), _ptr(c), K, M, N, _ptr(ws), ws_bytes,
+                                        _stream_ptr(a.device)))
+    return c

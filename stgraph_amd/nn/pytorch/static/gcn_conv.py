@@ -14,6 +14,7 @@ from torch import nn
 from ....compiler import STGraph
 from ....compiler.backend.pytorch.torch_callback import STGraphBackendTorch
 from ....utils.constants import SizeConstants
+from ... import functional as SF
 
 
 class GCNConv(nn.Module):
@@ -71,7 +72,7 @@ class GCNConv(nn.Module):
 
     def forward(self, graph, h, edge_weight=None):
         self.check_norm(graph)
-        h = torch.mm(h, self.weight)
+        h = SF.mm(h, self.weight)            # torch.mm forward; weight gradient on the fp32 matrix cores
         h = self.aggregate(graph, h, edge_weight)
         if self.bias is not None:
             h = h + self.bias

@@ -10,12 +10,16 @@ third of the launches and 768-byte instead of 256-byte gathered rows.  The only 
 difference is rocBLAS choosing its tiling for a [N, in] x [in, 3*out] product instead of three
 [in, out] ones (fp32 rounding of the K = in dot products).  ``fuse_gates = False`` runs the
 reference's three separate layers.
+
+The gate ``Linear`` layers keep their modules (and parameter names) but are applied through
+``stgraph_amd.nn.functional.linear``: same forward, weight gradient by the split-K MFMA kernel.
 """
 from __future__ import annotations
 
 import torch
 
 from .... import kernels
+from ... import functional as SF
 from ..static.gcn_conv import GCNConv
 
 
@@ -47,26 +51,30 @@ class TGCN(torch.nn.Module):
             GCNConv.check_norm(g)
             W = torch.cat([c.weight for c in convs], dim=1)
             b = torch.cat([c.bias for c in convs], dim=0)
-            h = self.conv_z.aggregate(g, torch.mm(X, W), edge_weight) + b
+            h = self.conv_z.aggregate(g, SF.mm(X, W), edge_weight) + b
             h = torch.clamp(h, min=-1e6, max=1e6)
             return torch.split(h, self.out_channels, dim=1)
         return tuple(torch.clamp(c(g, X, edge_weight=edge_weight), min=-1e6, max=1e6) for c in convs)
 
+    @staticmethod
+    def _apply_linear(lin: torch.nn.Linear, x):
+        return SF.linear(x, lin.weight, lin.bias)
+
     def _calculate_update_gate(self, h, H):
         Z = torch.cat((h, H), dim=1)
-        Z = self.linear_z(Z)
+        Z = self._apply_linear(self.linear_z, Z)
         Z = torch.sigmoid(Z)
         return Z
 
     def _calculate_reset_gate(self, h, H):
         R = torch.cat((h, H), dim=1)
-        R = self.linear_r(R)
+        R = self._apply_linear(self.linear_r, R)
         R = torch.sigmoid(R)
         return R
 
     def _calculate_candidate_state(self, h, H, R):
         H_tilde = torch.cat((h, H * R), dim=1)
-        H_tilde = self.linear_h(H_tilde)
+        H_tilde = self._apply_linear(self.linear_h, H_tilde)
         H_tilde = torch.tanh(H_tilde)
         return H_tilde
 

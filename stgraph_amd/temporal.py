@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from .nn import functional as SF
 from .nn.pytorch.temporal.tgcn import TGCN
 
 
@@ -37,8 +38,8 @@ class STGraphTGCN(torch.nn.Module):
     def forward(self, g, node_feat, edge_weight, hidden_state):
         h = self.temporal(g, node_feat, edge_weight, hidden_state)
         y = F.relu(h)
-        y = self.linear(y)
-        y_out = self.linear2(y)
+        y = SF.linear(y, self.linear.weight, self.linear.bias)
+        y_out = SF.linear(y, self.linear2.weight, self.linear2.bias)
         return y_out, y, h
 
 
@@ -172,7 +173,7 @@ class DynamicSTGraphTGCN(torch.nn.Module):
     def forward(self, g, node_feat, edge_weight, hidden_state):
         h = self.temporal(g, node_feat, edge_weight, hidden_state)
         y = F.relu(h)
-        y = self.linear(y)
+        y = SF.linear(y, self.linear.weight, self.linear.bias)
         return y, h
 
     def decode(self, z, edge_label_index):

@@ -1,0 +1,57 @@
+"""stg_gemm_tn_f32 (split-K fp32 MFMA weight gradient) against torch, incl. ragged shapes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("K,M,N", [(1, 1, 1), (7, 3, 5), (64, 32, 32), (1000, 33, 65), (4096, 64, 128),
+                                   (50_000, 64, 128), (50_000, 32, 192), (50_000, 1, 32), (50_001, 128, 64),
+                                   (200_000, 128, 128), (30_000, 200, 300), (2708, 1433, 16)])
+def test_matches_torch(cuda, K, M, N):
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(K + M + N)
+    a = torch.randn(K, M, device=cuda, generator=gen)
+    b = torch.randn(K, N, device=cuda, generator=gen)
+    got = kernels.gemm_tn(a, b)
+    want = (a.double().t() @ b.double())
+    err = (got.double() - want).abs().max().item()
+    scale = (a.double().abs().t() @ b.double().abs()).max().item()
+    assert err <= 2e-6 * scale + 1e-6, (err, scale)            # fp32 fma-chain accuracy (guide: ~1e-7 * sum|ab|)
+    assert torch.equal(got, kernels.gemm_tn(a, b))              # deterministic: fixed slice order, no atomics
+
+
+def test_asymmetric_integer_data_exact(cuda):
+    """Catches any row/col or lane-map mix-up: exact small-integer data, asymmetric operands."""
+    from stgraph_amd import kernels
+    K, M, N = 4100, 70, 150
+    a = (torch.arange(K * M, device=cuda) % 7 - 3).float().view(K, M)
+    b = (torch.arange(K * N, device=cuda) % 5 - 2).float().view(K, N)
+    assert torch.equal(kernels.gemm_tn(a, b), (a.double().t() @ b.double()).float())
+
+
+def test_autograd_wrappers_match_torch(cuda):
+    """mm / linear with the native weight gradient against an fp64 reference (the stock fp32 path is
+    held to the same bar, so the comparison is about accuracy, not about agreeing with rocBLAS)."""
+    from stgraph_amd.nn import functional as SF
+    torch.manual_seed(0)
+    x = torch.randn(20_000, 48, device=cuda, requires_grad=True)
+    w = torch.randn(48, 96, device=cuda, requires_grad=True)
+    lw = torch.randn(24, 96, device=cuda, requires_grad=True)
+    lb = torch.randn(24, device=cuda, requires_grad=True)
+    R = torch.randn(20_000, 24, device=cuda)
+    leaves = (x, w, lw, lb)
+
+    def run(native, dtype):
+        SF.set_native_weight_grad(native)
+        xs = [t.detach().to(dtype).requires_grad_(True) for t in leaves]
+        (SF.linear(torch.relu(SF.mm(xs[0], xs[1])), xs[2], xs[3]) * R.to(dtype)).sum().backward()
+        return [t.grad.double() for t in xs]
+    try:
+        ref = run(False, torch.float64)
+        for native in (True, False):
+            got = run(native, torch.float32)
+            for g, r in zip(got, ref):
+                assert (g - r).abs().max() <= 2e-5 * r.abs().max() + 1e-5, native
+    finally:
+        SF.set_native_weight_grad(True)
