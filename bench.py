@@ -145,7 +145,7 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
     targets = torch.randn(T, n, 1, device=device, generator=gen)
     torch.manual_seed(3)                                         # identical replicas
     model = temporal.STGraphTGCN(feat, hidden, 1).to(device)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
     bucket = temporal.GradBucket(model.parameters())
 
     def barrier():
@@ -175,6 +175,7 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
                                                            rank=rank, world=world, timed_comm=True), 1)
     kernels.enable_launch_timing(None)
     comm = bucket.collect_comm_time()
+    records = [r for r in records if r[0] == "gcn_agg"]
     agg_s = float(np.sum([a.elapsed_time(b) for (_, a, b, _, _) in records])) * 1e-3
     agg_launches = len(records)
     if world > 1:
@@ -187,8 +188,15 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
         temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat, epoch=2 + ep, rank=rank,
                                              world=world)
     calls0 = bucket.comm_calls
+    comm0 = bucket.collect_comm_time()
     dt = timed(lambda i: temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat,
-                                                              epoch=10 + i, rank=rank, world=world), epochs)
+                                                              epoch=10 + i, rank=rank, world=world,
+                                                              timed_comm=True), epochs)
+    comm_g = bucket.collect_comm_time() - comm0
+    if world > 1:
+        t = torch.tensor([comm_g], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm_g = float(t.item())
     bucket.check_views()
     fused = bool(model.temporal.fuse_gates)
     agg_per_step = 2 if fused else 6                             # (fwd + bwd) x (1 fused | 3 separate) gates
@@ -197,7 +205,8 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
         "workload": f"static-temporal TGCN |V|={n} |E|={e} T={T} feat={feat} hidden={hidden} backprop_every={B} "
                     f"(BASELINE configs[3]), windows sharded over {world} rank(s), Adam; "
                     f"{'fused 3-gate aggregation (width 192)' if fused else 'three width-64 aggregations'} per snapshot, "
-                    "each BPTT window (fwd + bwd + all-reduce + Adam) replayed from a HIP graph",
+                    "the compute of each BPTT window (fwd + bwd through time) replayed from a HIP graph, then one eager "
+                    "all-reduce of the gradient bucket and one Adam step",
         "metric": "epochs/s", "value": epochs / dt, "epochs": epochs, "seconds_per_epoch": dt / epochs,
         "edges_feat_per_s": agg_per_step * T * e * width * epochs / dt,
         "scaling": "strong", "n_gpus": world,
@@ -208,6 +217,7 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
                   "rank0_gcn_agg_share": agg_s / dt_eager,
                   "allreduce_seconds_max_rank": comm, "allreduce_share": comm / dt_eager},
         "allreduce": {"bytes": bucket.nbytes, "calls_per_epoch": (bucket.comm_calls - calls0) / max(epochs, 1),
+                      "seconds_max_rank": comm_g, "share_of_epoch": comm_g / dt if dt else None,
                       "collective": "one all-reduce(sum)/N of the flattened gradient bucket per optimizer step"},
     }
 
@@ -263,6 +273,8 @@ def main():
         dt = float(t.item())
 
     ef_per_step = meta["agg_launches_per_step"] * meta["e"] * meta["feat"]
+    gemm_ms = [a.elapsed_time(b) for (name, a, b, _, _) in records if name == "gemm_tn"]
+    records = [r for r in records if r[0] == "gcn_agg"]           # the dominant kernel
     ms = [a.elapsed_time(b) for (_, a, b, _, _) in records]
     bytes_alg = records[0][3]
     mean_ms = float(np.mean(ms))
@@ -284,8 +296,20 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "stg::gcn_agg_kernel",
                      "algorithmic_bytes_per_launch": bytes_alg, "mean_launch_ms": mean_ms,
                      "launches_timed": len(ms),
-                     "gcn_agg_share_of_step": float(np.sum(ms)) * 1e-3 / dt},
+                     "gcn_agg_share_of_step": float(np.sum(ms)) * 1e-3 / dt,
+                     "weight_grad_gemm_tn_mean_ms": float(np.mean(gemm_ms)) if gemm_ms else None},
     }
+    # HBM-side traffic per launch: PMC counters cannot be read inside this process, so the figure
+    # comes from the committed rocprofv3 --pmc passes over the SAME kernel/shape (tools/pmc_gcn.py,
+    # FETCH_SIZE corrected with the factor measured on a known-bytes launch, + WRITE_SIZE).
+    if (meta["n"], meta["e"], meta["feat"]) == (1_000_000, 16_000_000, 128):
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gcn_agg_edge*.json")))
+        if pmc_files:
+            pmc = json.load(open(pmc_files[-1]))
+            line["roofline"]["traffic"] = 0.5 * (pmc["cfg2_forward_csr"]["traffic_bytes"] +
+                                                 pmc["cfg2_backward_csr"]["traffic_bytes"])
+            line["roofline"]["traffic_source"] = os.path.relpath(pmc_files[-1], ROOT)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_gcn(meta)

@@ -224,17 +224,17 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
 
 
 class CapturedStaticWindow:
-    """One full BPTT window of the static-temporal loop -- bucket.zero, ``backprop_every`` model
-    steps, loss, backward through time, gradient all-reduce, optimizer step -- captured ONCE into
-    a HIP graph and replayed per window.
+    """The compute of one full BPTT window of the static-temporal loop -- bucket.zero,
+    ``backprop_every`` model steps, loss, backward through time -- captured ONCE into a HIP graph
+    and replayed per window; the gradient all-reduce and the optimizer step follow eagerly.
 
-    The window loop is launch-bound (|V| = 50K: ~120 small kernels per snapshot, each a few
-    microseconds), so on MI355X the eager loop spends >90 % of its time in host launch overhead;
-    the graph replays the identical kernel sequence (same kernels, same order, same numerics)
-    from device-side descriptors.  Inputs that change per window live in static buffers that are
-    overwritten before each replay: the window's ``randn`` input and its slice of ``targets``.
-    The optimizer must be constructed with ``capturable=True``.  The all-reduce is captured too
-    (RCCL supports stream capture); every rank captures and replays the same sequence.
+    Eagerly the window issues ~6 000 small kernels (|V| = 50K: a few microseconds each) and is
+    bound by host launch overhead; the graph replays the identical kernel sequence (same kernels,
+    same order, same numerics) from device-side descriptors.  Inputs that change per window live
+    in static buffers overwritten before each replay: the window's ``randn`` input and its slice of
+    ``targets``.  The collective is deliberately NOT captured: one eager RCCL all-reduce and one
+    eager (foreach) Adam step per window cost microseconds next to the window itself, and it keeps
+    the N > 1 path free of stream-capture constraints on the communicator.
     """
 
     def __init__(self, model, graph, edge_weight, targets, backprop_every: int, optimizer,
@@ -244,7 +244,7 @@ class CapturedStaticWindow:
         dev = targets.device
         self.static_y0 = torch.zeros(n, feat_size, device=dev)
         self.static_targets = torch.zeros((backprop_every,) + tuple(targets.shape[1:]), device=dev)
-        self.bucket, self.world, self.group = bucket, world, group
+        self.bucket, self.world, self.group, self.optimizer = bucket, world, group, optimizer
 
         def body():
             bucket.zero()
@@ -256,16 +256,10 @@ class CapturedStaticWindow:
                 cost = cost + torch.mean((y_out - self.static_targets[k]) ** 2)
             cost = cost / (self.B + 1)
             cost.backward()
-            if world > 1:
-                dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=group)
-                bucket.flat.div_(world)
-            optimizer.step()
             return cost.detach()
 
-        # Warm up on a side stream (allocator + lazily built per-edge caches + tracing), saving and
-        # restoring parameters/optimizer state so that capturing has no effect on the training run.
-        params = [p.detach().clone() for p in bucket.params]
-        opt_state = _clone_state(optimizer.state_dict())
+        # Warm up on a side stream (allocator, lazily built per-edge caches, tracing).  The body
+        # only writes gradients, so warming up and capturing leave the training state untouched.
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -276,50 +270,20 @@ class CapturedStaticWindow:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.cost = body()
-        # capture does not execute; undo the warm-up steps
-        with torch.no_grad():
-            for p, saved in zip(bucket.params, params):
-                p.copy_(saved)
-        _load_state_inplace(optimizer, opt_state)
         bucket.zero()
 
-    def run(self, y0: torch.Tensor, targets_window: torch.Tensor) -> torch.Tensor:
+    def run(self, y0: torch.Tensor, targets_window: torch.Tensor, timed_comm: bool = False) -> torch.Tensor:
         self.static_y0.copy_(y0)
         self.static_targets.copy_(targets_window)
         self.graph.replay()
-        if self.world > 1:
-            self.bucket.comm_calls += 1
+        self.bucket.all_reduce_mean(self.world, self.group, timed_comm)
+        self.optimizer.step()
         return self.cost.clone()
-
-
-def _clone_state(sd):
-    def cl(v):
-        if isinstance(v, torch.Tensor):
-            return v.detach().clone()
-        if isinstance(v, dict):
-            return {k: cl(x) for k, x in v.items()}
-        if isinstance(v, (list, tuple)):
-            return type(v)(cl(x) for x in v)
-        return v
-    return cl(sd)
-
-
-def _load_state_inplace(optimizer, saved) -> None:
-    """Restore optimizer state IN PLACE (a captured graph holds pointers to the state tensors)."""
-    cur = optimizer.state_dict()["state"]
-    for k, st in cur.items():
-        old = saved["state"].get(k)
-        for name, t in st.items():
-            if isinstance(t, torch.Tensor):
-                if old is not None and name in old:
-                    t.copy_(old[name])
-                else:
-                    t.zero_()
 
 
 def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_weight, targets, optimizer,
                                 bucket: GradBucket, feat_size: int, epoch: int = 0, rank: int = 0,
-                                world: int = 1, group=None, seed: int = 0):
+                                world: int = 1, group=None, seed: int = 0, timed_comm: bool = False):
     """``train_epoch_static`` with full windows replayed from the captured graph; a trailing short
     window or a padding step (more ranks than windows left) runs eagerly."""
     total = targets.shape[0]
@@ -329,7 +293,7 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
     for _, w in windows_of_rank(total, B, rank, world):
         if w is not None and (w + 1) * B <= total:
             y0 = window_input(n, feat_size, epoch, w, targets.device, seed)
-            losses.append(cw.run(y0, targets[w * B:(w + 1) * B]))
+            losses.append(cw.run(y0, targets[w * B:(w + 1) * B], timed_comm))
             continue
         bucket.zero()
         if w is not None:

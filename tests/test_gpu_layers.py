@@ -262,7 +262,7 @@ def test_captured_window_replays_the_eager_loop(cuda):
         targets = torch.randn(T, n, 1, device=cuda, generator=gen)
         torch.manual_seed(1)
         model = temporal.STGraphTGCN(feat, hid, 1).to(cuda)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
         bucket = temporal.GradBucket(model.parameters())
         losses = []
         if captured:
