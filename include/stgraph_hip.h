@@ -158,6 +158,16 @@ int stg_gat_bwd(const float *A, const float *S, const float *out, const float *g
                 const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
                 const int32_t *node_ids, int32_t N, int32_t H, int32_t D, int32_t HD_active,
                 float slope, void *stream);
+/* K2 with the target-only part hoisted: P[v,h] = sum_d (g/S)*out (one pass over the vertices,
+ * P is an [N,H] scratch array) and per edge T = ((sum_d g*feat[u]) / S - P) * A * slope, so the
+ * per-edge out[v] row gather (half of K2's traffic) disappears.  Same outputs as stg_gat_bwd
+ * (grad_feat bit-identical; grad_el / T regrouped sums -- the reference forms them with atomicAdd
+ * in an undefined order).  Computes all H*D columns (no *_active argument). */
+int stg_gat_bwd_factored(const float *A, const float *S, const float *out, const float *g,
+                         const float *feat, float *grad_feat, float *grad_el, float *T, float *P,
+                         const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
+                         const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope,
+                         void *stream);
 int stg_gat_bwd_er(const float *T, float *grad_er,
                    const int32_t *row_offsets, const int32_t *eids, const int32_t *node_ids,
                    int32_t N, int32_t H, int32_t H_active, void *stream);

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "stg_abi_version", "stg_last_error_string", "stg_set_tuning",
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
-    "stg_gcn_agg", "stg_gcn_agg_edge", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_er",
+    "stg_gcn_agg", "stg_gcn_agg_edge", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32",
 )
 
@@ -71,6 +71,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_gat_fwd_k1.argtypes = [vp] * 8 + [i32, i32, i32, i32, vp]
     lib.stg_gat_bwd.restype = ctypes.c_int
     lib.stg_gat_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, f32, vp]
+    lib.stg_gat_bwd_factored.restype = ctypes.c_int
+    lib.stg_gat_bwd_factored.argtypes = [vp] * 13 + [i32, i32, i32, f32, vp]
     lib.stg_gat_bwd_er.restype = ctypes.c_int
     lib.stg_gat_bwd_er.argtypes = [vp] * 5 + [i32, i32, i32, vp]
     lib.stg_gemm_tn_workspace_bytes.restype = ctypes.c_size_t

@@ -317,6 +317,147 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_kernel(
     }
 }
 
+// ----------------------------------------------------------------- K2, factored form
+// The per-lane term of K2 is  t_d = ((g_d f_d)(1/S) - (g_d/S) o_d) * A * slope  with g, o read at the
+// edge's TARGET v and f at its source u.  Summed over the head:
+//     sum_d t_d = A * slope * ( (1/S) * sum_d g_d f_d  -  P[v,h] ),   P[v,h] = sum_d (g_d/S) o_d
+// P depends on the target only, so it is computed once per vertex (gat_bwd_prepass_kernel, reads g
+// and out once) instead of once per edge -- the out[v] row gather (half of K2's traffic: 16.4 GB of
+// 34.7 GB at |E| = 8M, H*D = 512) disappears.  The reference sums these terms with atomicAdd in an
+// undefined order, so the regrouping stays inside its own run-to-run spread (tested to 1e-4).
+// (z = s - s is 0 or NaN, so the LeakyReLU derivative `z > 0 ? 1 : slope` is always `slope`.)
+template <int VEC, int LOG2G, int CHUNKS, bool POW2>
+__global__ __launch_bounds__(kBlock) void gat_bwd_prepass_kernel(
+    const float *__restrict__ S, const float *__restrict__ outp, const float *__restrict__ g,
+    float *__restrict__ P, int N, int H, int D)
+{
+    constexpr int G = 1 << LOG2G;
+    __shared__ float lds[POW2 ? 1 : kBlock];
+    float *lds_wave = lds + (POW2 ? 0 : (threadIdx.x & ~(kWave - 1)));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int j = lane & (G - 1);
+    const int HD = H * D;
+    const int LH = D / VEC;
+    const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int v = wave_global * (kWave / G) + (lane >> LOG2G);
+    const bool valid = v < N;
+    for (int fbase = 0; fbase < HD; fbase += G * VEC * CHUNKS) {
+#pragma unroll
+        for (int ch = 0; ch < CHUNKS; ++ch) {
+            const int foff = fbase + (ch * G + j) * VEC;
+            const bool fok = valid && foff < HD;
+            const int h = foff < HD ? foff / D : 0;
+            float p = 0.f;
+            if (fok) {
+                float gv[VEC], ov[VEC];
+                vec_load<VEC>(gv, g + (int64_t)v * HD + foff);
+                vec_load<VEC>(ov, outp + (int64_t)v * HD + foff);
+                const float s = S[(int64_t)v * H + h];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) p = p + (gv[i] / s) * ov[i];
+            }
+            const float tot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
+            if (fok && (foff % D) == 0) P[(int64_t)v * H + h] = tot;
+        }
+    }
+}
+
+template <int VEC, int LOG2G, int CHUNKS, int UNROLL, bool POW2>
+__global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
+    const float *__restrict__ A, const float *__restrict__ S, const float *__restrict__ P,
+    const float *__restrict__ g, const float *__restrict__ feat, float *__restrict__ grad_feat,
+    float *__restrict__ grad_el, float *__restrict__ T, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, const int *__restrict__ eids,
+    const int *__restrict__ node_ids, int N, int H, int D, float slope)
+{
+    constexpr int G = 1 << LOG2G;
+    constexpr int U = UNROLL < G ? UNROLL : G;
+    __shared__ float lds[POW2 ? 1 : kBlock];
+    float *lds_wave = lds + (POW2 ? 0 : (threadIdx.x & ~(kWave - 1)));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int j = lane & (G - 1);
+    const int HD = H * D;
+    const int LH = D / VEC;
+    const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+
+    for (int fbase = 0; fbase < HD; fbase += G * VEC * CHUNKS) {
+        float a13[CHUNKS][VEC], fu[CHUNKS][VEC], gel[CHUNKS];
+        int foff[CHUNKS], hh[CHUNKS];
+        bool fok[CHUNKS], lead[CHUNKS];
+#pragma unroll
+        for (int ch = 0; ch < CHUNKS; ++ch) {
+            foff[ch] = fbase + (ch * G + j) * VEC;
+            fok[ch] = foff[ch] < HD;
+            hh[ch] = fok[ch] ? foff[ch] / D : 0;
+            lead[ch] = fok[ch] && (foff[ch] % D) == 0;
+            gel[ch] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { a13[ch][i] = 0.f; fu[ch][i] = 0.f; }
+            if (ri.valid && fok[ch]) vec_load<VEC>(fu[ch], feat + (int64_t)ri.r * HD + foff[ch]);
+        }
+        for (int base = 0; base < ri.max_deg; base += G) {
+            const int cnt = ri.deg - base;
+            const int cnt_max = min(G, ri.max_deg - base);
+            int c = 0, ev = 0;
+            if (j < cnt) {
+                c = column_indices[ri.beg + base + j];
+                ev = eids[ri.beg + base + j];
+            }
+            for (int k = 0; k < cnt_max; k += U) {
+                float gv[U][CHUNKS][VEC];
+                float av[U][CHUNKS], sv[U][CHUNKS], pv[U][CHUNKS];
+                int ek[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kk = k + u;
+                    const int ck = gbcast_i<G>(c, kk & (G - 1));
+                    ek[u] = gbcast_i<G>(ev, kk & (G - 1));
+#pragma unroll
+                    for (int ch = 0; ch < CHUNKS; ++ch) {
+                        if (kk < cnt && fok[ch]) {
+                            av[u][ch] = A[(int64_t)ek[u] * H + hh[ch]];
+                            sv[u][ch] = S[(int64_t)ck * H + hh[ch]];
+                            pv[u][ch] = P[(int64_t)ck * H + hh[ch]];
+                            vec_load<VEC>(gv[u][ch], g + (int64_t)ck * HD + foff[ch]);
+                        } else {
+                            av[u][ch] = 0.f; sv[u][ch] = 1.f; pv[u][ch] = 0.f;
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) gv[u][ch][i] = 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool on = k + u < cnt;
+#pragma unroll
+                    for (int ch = 0; ch < CHUNKS; ++ch) {
+                        float p = 0.f;
+                        if (on && fok[ch]) {
+                            const float alpha = av[u][ch] / sv[u][ch];
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                a13[ch][i] = a13[ch][i] + gv[u][ch][i] * alpha;
+                                p = p + gv[u][ch][i] * fu[ch][i];
+                            }
+                        }
+                        const float dot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
+                        if (on && lead[ch]) {
+                            const float tv = ((dot * (1.0f / sv[u][ch]) - pv[u][ch]) * av[u][ch]) * slope;
+                            T[(int64_t)ek[u] * H + hh[ch]] = tv;
+                            gel[ch] = gel[ch] + tv;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < CHUNKS; ++ch) {
+            if (ri.valid && lead[ch]) grad_el[(int64_t)ri.r * H + hh[ch]] = gel[ch];
+            if (ri.valid && fok[ch]) vec_store<VEC>(grad_feat + (int64_t)ri.r * HD + foff[ch], a13[ch]);
+        }
+    }
+}
+
 // -------------------------------------------------------------------------- bwd_er
 template <int LOG2G>
 __global__ __launch_bounds__(kBlock) void gat_bwd_er_kernel(
@@ -488,6 +629,52 @@ extern "C" int stg_gat_bwd(const float *A, const float *S, const float *out, con
 #undef STG_K2_VEC
 #undef STG_K2
     return check_launch("stg_gat_bwd");
+}
+
+extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float *out, const float *g,
+                                    const float *feat, float *grad_feat, float *grad_el, float *T,
+                                    float *P, const int32_t *row_offsets,
+                                    const int32_t *column_indices, const int32_t *eids,
+                                    const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope,
+                                    void *stream)
+{
+    using namespace stg;
+    if (N < 0 || H <= 0 || D <= 0)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_factored: bad shape N=%d H=%d D=%d", N, H, D);
+    if (N == 0) return 0;
+    if (!S || !out || !g || !feat || !grad_feat || !grad_el || !P || !row_offsets)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_factored: NULL pointer argument");
+    const uintptr_t align = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
+                            reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(grad_feat);
+    const FeatPlan p = plan_features(H * D, D, H * D, align, true);
+    const int LH = D / p.vec;
+    const bool pow2 = (LH & (LH - 1)) == 0 && LH <= (1 << p.log2g);
+    if (LH > kWave || (!pow2 && (H * D + p.vec - 1) / p.vec > kWave))
+        return fail(STG_ERR_UNSUPPORTED,
+                    "stg_gat_bwd_factored: head width D=%d (H=%d) is outside the supported range "
+                    "(D/vec <= 64; non power-of-two D/vec needs H*D/vec <= 64)", D, H);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define STG_K2F(VEC, CH, UN, P2)                                                                           \
+    STG_SWITCH_LOG2G(p.chunks > 1 ? 6 : p.log2g, {                                                         \
+        constexpr int LGE = (CH > 1 ? 6 : LG);                                                             \
+        hipLaunchKernelGGL((gat_bwd_prepass_kernel<VEC, LGE, CH, P2>), dim3(grid_for(N, LGE)), dim3(kBlock), \
+                           0, st, S, out, g, P, N, H, D);                                                  \
+        hipLaunchKernelGGL((gat_bwd_fact_kernel<VEC, LGE, CH, UN, P2>), dim3(grid_for(N, LGE)),            \
+                           dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,      \
+                           column_indices, eids, node_ids, N, H, D, slope);                                \
+    })
+#define STG_K2F_VEC(VEC, P2)                           \
+    if (p.chunks == 4) { STG_K2F(VEC, 4, 2, P2); }     \
+    else if (p.chunks == 2) { STG_K2F(VEC, 2, 4, P2); } \
+    else { STG_K2F(VEC, 1, 8, P2); }
+    if (pow2) {
+        if (p.vec == 4) { STG_K2F_VEC(4, true) } else if (p.vec == 2) { STG_K2F_VEC(2, true) } else { STG_K2F_VEC(1, true) }
+    } else {
+        if (p.vec == 4) { STG_K2F_VEC(4, false) } else if (p.vec == 2) { STG_K2F_VEC(2, false) } else { STG_K2F_VEC(1, false) }
+    }
+#undef STG_K2F_VEC
+#undef STG_K2F
+    return check_launch("stg_gat_bwd_factored");
 }
 
 extern "C" int stg_gat_bwd_er(const float *T, float *grad_er, const int32_t *row_offsets,

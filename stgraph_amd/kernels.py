@@ -340,6 +340,17 @@ def gat_fwd(el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor, csr: DeviceC
     return out, A, S
 
 
+_GAT_FACTORED = True
+
+
+def set_gat_factored_backward(enabled: bool) -> None:
+    """True (default): K2 runs in its factored form (stg_gat_bwd_factored: the target-only term is
+    hoisted into a per-vertex pre-pass, halving the gather).  False: the literal per-lane form of the
+    reference's emitted kernel (stg_gat_bwd).  Reference-compat mode (D1) always uses the literal form."""
+    global _GAT_FACTORED
+    _GAT_FACTORED = bool(enabled)
+
+
 def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: float,
             use_node_ids: bool = False):
     """Backward unit K2 (+ the dst-major grad_er pass).  Returns (grad_feat, grad_el, grad_er)."""
@@ -364,11 +375,18 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
     with torch.cuda.device(dev):
         st = _stream_ptr(dev)
         with _Timed("gat_bwd", ab["gat_bwd"], E * H * D):
-            _C.check(_C.lib.stg_gat_bwd(
-                _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(el), _ptr(er), _ptr(feat),
-                _ptr(grad_feat), _ptr(grad_el), _ptr(T), _ptr(bwd.row_offset), _ptr(bwd.column_indices),
-                _ptr(bwd.eids), _ptr(bwd.node_ids if use_node_ids else None), N, H, D, hd_act,
-                float(slope), st))
+            if full and _GAT_FACTORED:
+                P = torch.empty((N, H), dtype=torch.float32, device=dev)
+                _C.check(_C.lib.stg_gat_bwd_factored(
+                    _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(feat), _ptr(grad_feat), _ptr(grad_el), _ptr(T),
+                    _ptr(P), _ptr(bwd.row_offset), _ptr(bwd.column_indices), _ptr(bwd.eids),
+                    _ptr(bwd.node_ids if use_node_ids else None), N, H, D, float(slope), st))
+            else:
+                _C.check(_C.lib.stg_gat_bwd(
+                    _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(el), _ptr(er), _ptr(feat),
+                    _ptr(grad_feat), _ptr(grad_el), _ptr(T), _ptr(bwd.row_offset), _ptr(bwd.column_indices),
+                    _ptr(bwd.eids), _ptr(bwd.node_ids if use_node_ids else None), N, H, D, hd_act,
+                    float(slope), st))
         # heads the backward unit touched: those with at least one active feature column
         h_touched = H if full else min(H, (hd_act + D - 1) // D)
         with _Timed("gat_bwd_er", ab["gat_bwd_er"], E * H):

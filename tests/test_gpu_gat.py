@@ -81,6 +81,16 @@ def test_oracle_random_graph(cuda, H, D, nid):
     scale = max(1.0, float(np.abs(gel0).max()), float(np.abs(ger0).max()))
     np.testing.assert_allclose(gel.cpu().numpy(), gel0, rtol=TOL, atol=TOL * scale)
     np.testing.assert_allclose(ger.cpu().numpy(), ger0, rtol=TOL, atol=TOL * scale)
+    # literal form of the emitted kernel (stg_gat_bwd) agrees with the default factored form
+    kernels.set_gat_factored_backward(False)
+    try:
+        gfl, gell, gerl = kernels.gat_bwd(A, S, out, _t(R, cuda), _t(el, cuda), _t(er, cuda), _t(feat, cuda),
+                                          g.fwd, g.bwd, 0.2, nid)
+    finally:
+        kernels.set_gat_factored_backward(True)
+    assert np.array_equal(gfl.cpu().numpy(), gf0)
+    np.testing.assert_allclose(gell.cpu().numpy(), gel0, rtol=TOL, atol=TOL * scale)
+    np.testing.assert_allclose(gerl.cpu().numpy(), ger0, rtol=TOL, atol=TOL * scale)
     # determinism: no atomics anywhere
     gf2, gel2, ger2 = kernels.gat_bwd(A, S, out, _t(R, cuda), _t(el, cuda), _t(er, cuda), _t(feat, cuda),
                                       g.fwd, g.bwd, 0.2, nid)
