@@ -123,7 +123,8 @@ int stg_gcn_agg(const float *x, const float *norm_row, const float *norm_col, co
 int stg_gcn_agg_edge(const float *x, const float *norm_row, const float *norm_col_edge,
                      const float *ew_edge, float *out,
                      const int32_t *row_offsets, const int32_t *column_indices,
-                     const int32_t *node_ids, int32_t N, int32_t F, int32_t F_active, void *stream);
+                     const int32_t *node_ids, int32_t N, int64_t E, int32_t F, int32_t F_active,
+                     void *stream);      /* E = number of edges (lane-mapping heuristic only; 0 = unknown) */
 
 /* dst[i] = table[idx[i]], i < n.  All [dev]. */
 int stg_edge_gather_f32(float *dst, const float *table, const int32_t *idx, int64_t n, void *stream);

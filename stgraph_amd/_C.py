@@ -62,7 +62,7 @@ def _load() -> ctypes.CDLL:
     lib.stg_gcn_agg.restype = ctypes.c_int
     lib.stg_gcn_agg.argtypes = [vp] * 9 + [i32, i32, i32, vp]
     lib.stg_gcn_agg_edge.restype = ctypes.c_int
-    lib.stg_gcn_agg_edge.argtypes = [vp] * 8 + [i32, i32, i32, vp]
+    lib.stg_gcn_agg_edge.argtypes = [vp] * 8 + [i32, i64, i32, i32, vp]
     lib.stg_edge_gather_f32.restype = ctypes.c_int
     lib.stg_edge_gather_f32.argtypes = [vp, vp, vp, i64, vp]
     lib.stg_gat_fwd_k0.restype = ctypes.c_int

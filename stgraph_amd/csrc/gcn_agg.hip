@@ -168,6 +168,7 @@ struct GcnArgs {
     int N, F, F_active;
     bool pre;
     hipStream_t stream;
+    int64_t E = 0;      // number of edges if the caller knows it (mapping heuristic only), else 0
 };
 
 template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL>
@@ -238,9 +239,10 @@ int gcn_agg_dispatch(GcnArgs a, const char *what)
     const int forced = tuning().gcn_lanes_per_row;
     if (forced > 0) {
         while (vec > 1 && a.F_active / vec < forced) vec /= 2;
-    } else if (vec == 4 && a.F_active == 128) {
-        vec = 2;      // measured (profiles/r01): one 512-B row per wave (G = 64, 8 B/lane, scalar row
-                      // base via v_readlane) beats two rows per wave (G = 32, 16 B/lane) by ~3 %
+    } else if (vec == 4 && a.F_active == 128 && a.E >= 8 * (int64_t)a.N) {
+        vec = 2;      // measured (profiles/r01): at average degree >= 8 one 512-B row per wave (G = 64,
+                      // 8 B/lane, scalar row base via v_readlane) beats two rows per wave (G = 32,
+                      // 16 B/lane) by ~3 %; on low-degree graphs (Cora-shaped, degree ~4) it loses 25 %
     }
     const int lanes = (a.F_active + vec - 1) / vec;
     int log2g = ilog2_ceil(lanes);
@@ -275,10 +277,10 @@ extern "C" int stg_gcn_agg(const float *x, const float *norm_row, const float *n
 extern "C" int stg_gcn_agg_edge(const float *x, const float *norm_row, const float *norm_col_edge,
                                 const float *ew_edge, float *out, const int32_t *row_offsets,
                                 const int32_t *column_indices, const int32_t *node_ids, int32_t N,
-                                int32_t F, int32_t F_active, void *stream)
+                                int64_t E, int32_t F, int32_t F_active, void *stream)
 {
     return stg::gcn_agg_dispatch({x, norm_row, norm_col_edge, ew_edge, out, row_offsets, column_indices, nullptr,
-                                  node_ids, N, F, F_active, true, static_cast<hipStream_t>(stream)},
+                                  node_ids, N, F, F_active, true, static_cast<hipStream_t>(stream), E},
                                  "stg_gcn_agg_edge");
 }
 

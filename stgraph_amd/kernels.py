@@ -296,7 +296,8 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
             if _EDGE_CACHE:
                 _C.check(_C.lib.stg_gcn_agg_edge(
                     _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(out),
-                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, N, F, fa, _stream_ptr(dev)))
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, N, csr.num_edges, F, fa,
+                    _stream_ptr(dev)))
             else:
                 _C.check(_C.lib.stg_gcn_agg(
                     _ptr(x), _ptr(norm_row), _ptr(norm_col), _ptr(ew), _ptr(out),
