@@ -10,7 +10,8 @@ with |V| = 1M, |E| = 16M (uniform, duplicate-free, seed 1).  One step = one trai
 N > 1: N independent replicas of that workload (a single-graph GCN does not shard:
 SURVEY.md 8(e) "replicas only"), `value` = sum over ranks.
 
-Every line also carries a "tgcn" object: BASELINE.json configs[3] (static-temporal TGCN,
+Every line also carries a "cora" object (BASELINE configs[0]: GCN on a Cora-shaped graph, epochs/s,
+rank 0 only) and a "tgcn" object: BASELINE.json configs[3] (static-temporal TGCN,
 |V| = 50K, |E| = 500K, T = 1000, feat 32, hidden 64, backprop_every 25 => 40 BPTT windows)
 with the windows sharded over the N ranks and ONE RCCL all-reduce of the flattened gradient
 bucket per optimizer step -- the path the north star scales to 8 GPUs ("scaling": "strong":
@@ -133,6 +134,71 @@ def cpu_baseline_gcn(meta, budget_s=20.0):
                       f"by oracle/stg_oracle.c, OpenMP over rows, {dt:.1f} s wall"}
 
 
+# ------------------------------------------------------------------------- GCN-Cora (cfg 1)
+def cora_shaped(seed=0, n=2708, pairs=5278, max_deg=168):
+    """Cora-SHAPED synthetic graph (the real dataset needs the network): Chung-Lu style power-law
+    expected degrees capped at max_deg, 5278 undirected pairs mirrored => |E| = 10556, no self loops."""
+    rng = np.random.default_rng(seed)
+    w = (np.arange(1, n + 1, dtype=np.float64)) ** -0.6
+    w = np.minimum(w / w.sum() * 2 * pairs, max_deg)
+    p = w / w.sum()
+    got = set()
+    while len(got) < pairs:
+        a = rng.choice(n, size=2 * pairs, p=p)
+        b = rng.choice(n, size=2 * pairs, p=p)
+        for u, v in zip(a, b):
+            if u != v and (min(u, v), max(u, v)) not in got and len(got) < pairs:
+                got.add((min(u, v), max(u, v)))
+    und = np.array(sorted(got), np.int32)
+    return np.concatenate([und[:, 0], und[:, 1]]), np.concatenate([und[:, 1], und[:, 0]])
+
+
+def cora_run(device, epochs=200):
+    """BASELINE configs[0] shape: 2-layer GCN 1433 -> 16 -> 7, Adam(1e-2, wd 5e-4), cross-entropy on
+    the first 60 % (benchmarking/gcn/seastar/train.py:63-101).  Timing rule of the reference: wall
+    clock between device syncs around each epoch, epochs 0-2 discarded.  Reported eagerly and with the
+    whole epoch (fwd + loss + bwd + Adam) replayed from one HIP graph."""
+    from stgraph_amd.capture import CapturedTrainStep
+    from stgraph_amd.graph import StaticGraph
+    src, dst = cora_shaped()
+    n, e = 2708, len(src)
+    g = StaticGraph((src, dst), None, n, device=device, sort_inplace=False)
+    g.set_ndata("norm", degree_norm(g))
+    gen = torch.Generator(device=device).manual_seed(0)
+    x = (torch.rand(n, 1433, device=device, generator=gen) < 0.0127).float()
+    labels = torch.randint(0, 7, (n,), device=device, generator=gen)
+    ntrain = int(0.6 * n)
+    loss_fn = nn.CrossEntropyLoss()
+    out = {"workload": f"2-layer GCN 1433->16->7 on a Cora-shaped synthetic graph |V|={n} |E|={e} "
+                       "(BASELINE configs[0]), Adam, cross-entropy, 200 epochs"}
+    for mode in ("eager", "hip_graph"):
+        torch.manual_seed(0)
+        model = GCN(1433, 16, 7, 1, F.relu).to(device)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4, capturable=(mode == "hip_graph"))
+
+        def step():
+            logits = model(g, x)
+            loss = loss_fn(logits[:ntrain], labels[:ntrain])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+
+        run = step if mode == "eager" else CapturedTrainStep(step, opt, list(model.parameters()))
+        dur = []
+        for ep in range(epochs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = run()
+            torch.cuda.synchronize()
+            if ep >= 3:
+                dur.append(time.perf_counter() - t0)
+        out[mode] = {"epochs_per_s": 1.0 / float(np.mean(dur)), "ms_per_epoch": float(np.mean(dur)) * 1e3,
+                     "edges_feat_per_s": 2 * e * (16 + 7) / float(np.mean(dur)), "final_loss": float(loss)}
+    out["metric"], out["value"] = "epochs/s", out["hip_graph"]["epochs_per_s"]
+    return out
+
+
 # ----------------------------------------------------------------------------- TGCN (cfg 4)
 def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, B):
     from stgraph_amd import kernels, temporal
@@ -234,6 +300,10 @@ def main():
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--tgcn-epochs", type=int, default=2)
     ap.add_argument("--tgcn-timestamps", type=int, default=1000)
+    ap.add_argument("--no-cora", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-device: exercise the multi-rank logic on a single GPU (testing only)")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (testing only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -243,10 +313,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     from stgraph_amd import kernels
 
@@ -316,6 +390,8 @@ def main():
     line["cpu_baseline"] = cpu
     del step, meta
     torch.cuda.empty_cache()
+    if rank == 0 and not args.no_cora:
+        line["cora"] = cora_run(device)
     if not args.no_tgcn:
         line["tgcn"] = tgcn_run(device, rank, world, epochs=args.tgcn_epochs, warmup_epochs=1, n=50_000, e=500_000,
                                 T=args.tgcn_timestamps, feat=32, hidden=64, B=25)

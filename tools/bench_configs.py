@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from bench import GCN, HBM_PEAK_GBS, degree_norm, synthetic_graph
+from bench import GCN, HBM_PEAK_GBS, cora_run, cora_shaped, degree_norm, synthetic_graph
 from stgraph_amd import kernels, temporal
 from stgraph_amd.graph import NaiveGraph, StaticGraph
 
@@ -36,53 +36,10 @@ def kernel_table(records):
             for k, v in out.items()}
 
 
-def cora_shaped(seed=0, n=2708, pairs=5278, max_deg=168):
-    """Chung-Lu style: power-law expected degrees capped at max_deg, undirected pairs mirrored."""
-    rng = np.random.default_rng(seed)
-    w = (np.arange(1, n + 1, dtype=np.float64)) ** -0.6
-    w = np.minimum(w / w.sum() * 2 * pairs, max_deg)
-    p = w / w.sum()
-    got = set()
-    while len(got) < pairs:
-        a = rng.choice(n, size=2 * pairs, p=p)
-        b = rng.choice(n, size=2 * pairs, p=p)
-        for u, v in zip(a, b):
-            if u != v and (min(u, v), max(u, v)) not in got and len(got) < pairs:
-                got.add((min(u, v), max(u, v)))
-    und = np.array(sorted(got), np.int32)
-    src = np.concatenate([und[:, 0], und[:, 1]])
-    dst = np.concatenate([und[:, 1], und[:, 0]])
-    return src, dst
-
-
 def cfg1(dev, epochs=200, K=1024):
+    line = {"config": "cfg1", **cora_run(dev, epochs)}
     src, dst = cora_shaped()
     n, e = 2708, len(src)
-    g = StaticGraph((src, dst), None, n, device=dev, sort_inplace=False)
-    g.set_ndata("norm", degree_norm(g))
-    gen = torch.Generator(device=dev).manual_seed(0)
-    x = (torch.rand(n, 1433, device=dev, generator=gen) < 0.0127).float()
-    labels = torch.randint(0, 7, (n,), device=dev, generator=gen)
-    ntrain = int(0.6 * n)
-    torch.manual_seed(0)
-    model = GCN(1433, 16, 7, 1, F.relu).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4)
-    loss_fn = torch.nn.CrossEntropyLoss()
-    dur = []
-    for ep in range(epochs):
-        torch.cuda.synchronize()
-        t0 = time.time()
-        logits = model(g, x)
-        loss = loss_fn(logits[:ntrain], labels[:ntrain])
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        torch.cuda.synchronize()
-        if ep >= 3:
-            dur.append(time.time() - t0)
-    line = {"config": "cfg1 GCN Cora-shaped (|V|=2708 |E|=%d) 1433->16->7, Adam, CE" % e,
-            "epochs_per_s": 1.0 / float(np.mean(dur)), "ms_per_epoch": float(np.mean(dur)) * 1e3,
-            "edges_feat_per_s": 2 * e * (16 + 7) / float(np.mean(dur)), "final_loss": float(loss)}
     # roofline variant: K disjoint replicas
     big_src = np.concatenate([src + k * n for k in range(K)]).astype(np.int32)
     big_dst = np.concatenate([dst + k * n for k in range(K)]).astype(np.int32)

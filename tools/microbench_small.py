@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from stgraph_amd import _C, kernels
-from tools.bench_configs import cora_shaped
+from bench import cora_shaped
 
 
 def main():
