@@ -185,6 +185,37 @@ size_t stg_gemm_tn_workspace_bytes(int64_t K, int32_t M, int32_t N);
 int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t M, int32_t N,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same, additionally colsum_A[m] = sum_k A[k][m] (the bias gradient that goes with the weight
+ * gradient) from one extra MFMA per k-pair; colsum_A [dev, M floats]. */
+int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *colsum_A, int64_t K, int32_t M,
+                           int32_t N, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ----------------------------------------------- dense neighbour: TGCN row-local glue
+ * Fused elementwise stages of one TGCN step (nn/pytorch/temporal/tgcn.py:21-55); the three gate
+ * GEMMs between them stay on rocBLAS.  C = hidden width (multiple of 4), all [dev] fp32 row-major,
+ * 16-byte aligned.  a3 [N,3C] = aggregated X [Wz|Wr|Wh]; b3 [3C]; H, Z, R, Ht, Hn, zl, rl, hl [N,C];
+ * CZ, CR, CH [N,2C] are the GEMM operands [hz|H], [hr|H], [hh|H*R] written in place (no cat).
+ *   prep_fwd  : h = clamp(a3 + b3, lo, hi); CZ = [hz|H]; CR = [hr|H]; CH[:, :C] = hh
+ *   gates_fwd : Z = sigmoid(zl); R = sigmoid(rl); CH[:, C:] = H * R
+ *   update_fwd: Ht = tanh(hl); Hn = Z*H + (1-Z)*Ht
+ *   update_bwd: dhl = dHn (1-Z)(1-Ht^2); dzl = dHn (H-Ht) Z (1-Z); dH = dHn Z
+ *   gates_bwd : drl = dCH[:, C:] H R (1-R); dH += dCH[:, C:] R
+ *   prep_bwd  : da3 = [dCZ[:, :C]|dCR[:, :C]|dCH[:, :C]] where lo <= a3+b3 <= hi else 0;
+ *               dH += dCZ[:, C:] + dCR[:, C:]
+ */
+int stg_tgcn_cell_prep_fwd(const float *a3, const float *b3, const float *H, float *CZ, float *CR, float *CH,
+                           int64_t N, int32_t C, float lo, float hi, void *stream);
+int stg_tgcn_cell_gates_fwd(const float *zl, const float *rl, const float *H, float *Z, float *R, float *CH,
+                            int64_t N, int32_t C, void *stream);
+int stg_tgcn_cell_update_fwd(const float *hl, const float *Z, const float *H, float *Ht, float *Hn, int64_t N,
+                             int32_t C, void *stream);
+int stg_tgcn_cell_update_bwd(const float *dHn, const float *Z, const float *H, const float *Ht, float *dhl,
+                             float *dzl, float *dH, int64_t N, int32_t C, void *stream);
+int stg_tgcn_cell_gates_bwd(const float *dCH, const float *R, const float *H, float *drl, float *dH, int64_t N,
+                            int32_t C, void *stream);
+int stg_tgcn_cell_prep_bwd(const float *dCZ, const float *dCR, const float *dCH, const float *a3, const float *b3,
+                           float *da3, float *dH, int64_t N, int32_t C, float lo, float hi, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,9 @@ EXPORTED_SYMBOLS = (
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
-    "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32",
+    "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
+    "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
+    "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
 )
 
 
@@ -79,6 +81,17 @@ def _load() -> ctypes.CDLL:
     lib.stg_gemm_tn_workspace_bytes.argtypes = [i64, i32, i32]
     lib.stg_gemm_tn_f32.restype = ctypes.c_int
     lib.stg_gemm_tn_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp, ctypes.c_size_t, vp]
+    lib.stg_gemm_tn_colsum_f32.restype = ctypes.c_int
+    lib.stg_gemm_tn_colsum_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, ctypes.c_size_t, vp]
+    for name, nptr, tail in (("stg_tgcn_cell_prep_fwd", 6, [i64, i32, f32, f32, vp]),
+                             ("stg_tgcn_cell_gates_fwd", 6, [i64, i32, vp]),
+                             ("stg_tgcn_cell_update_fwd", 5, [i64, i32, vp]),
+                             ("stg_tgcn_cell_update_bwd", 7, [i64, i32, vp]),
+                             ("stg_tgcn_cell_gates_bwd", 5, [i64, i32, vp]),
+                             ("stg_tgcn_cell_prep_bwd", 7, [i64, i32, f32, f32, vp])):
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp] * nptr + tail
     if lib.stg_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.stg_abi_version()} != expected {ABI_VERSION}; rebuild")
     return lib

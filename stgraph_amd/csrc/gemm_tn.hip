@@ -24,7 +24,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kGemmKStep = 16;             // K slices are multiples of this (covers KU = 4 and 8)
 
 // NT = 32-column tiles per wave, KU = k-pairs per operand set (KU * (1 + NT) dword loads in flight)
-template <int NT, int KU>
+// CS: additionally emit the column sums of A (sum_k A[k][m]) -- the bias gradient that accompanies
+// every weight gradient -- from one extra MFMA per k-pair against a constant-one B fragment.
+template <int NT, int KU, bool CS>
 __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ slab, int64_t K,
     int M, int N, int64_t kslice_wave, int m_tiles, int n_groups)
@@ -53,11 +55,14 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
         nok[j] = n[j] < N;
         lb[j] = (unsigned)(kh * N + min(n[j], N - 1));
     }
-    f32x16 acc[NT];
+    f32x16 acc[NT], accs;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accs[i] = 0.f;
+    const bool do_cs = CS && nj == 0;                                           // block-uniform
 
     constexpr int STEP = 2 * KU;
     // Buffer descriptors over THIS wave's K slice: the hardware range check returns 0 for rows
@@ -86,10 +91,14 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     };
     auto mfma_set = [&](const float (&a)[KU], const float (&b)[KU][NT]) {
 #pragma unroll
-        for (int u = 0; u < KU; ++u)
+        for (int u = 0; u < KU; ++u) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][j], acc[j], 0, 0, 0);
+            if constexpr (CS) {
+                if (do_cs) accs = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], 1.0f, accs, 0, 0, 0);
+            }
+        }
     };
 
     // two operand sets: the loads of the next STEP rows are in flight while the matrix pipe
@@ -107,25 +116,45 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     }
 
     // add the block's 4 K sub-slices in wave order (fixed => deterministic), wave 0 writes the slab
+    constexpr int NTS = NT + (CS ? 1 : 0);
     if (wave > 0) {
-        float *dst = lds + (size_t)(wave - 1) * NT * 16 * kWave + lane;
+        float *dst = lds + (size_t)(wave - 1) * NTS * 16 * kWave + lane;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) dst[(j * 16 + i) * kWave] = acc[j][i];
+        if constexpr (CS) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[(NT * 16 + i) * kWave] = accs[i];
+        }
     }
     __syncthreads();
     if (wave == 0) {
         for (int w = 0; w < kWavesPerBlock - 1; ++w) {
-            const float *src = lds + (size_t)w * NT * 16 * kWave + lane;
+            const float *src = lds + (size_t)w * NTS * 16 * kWave + lane;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[j][i] += src[(j * 16 + i) * kWave];
+            if constexpr (CS) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accs[i] += src[(NT * 16 + i) * kWave];
+            }
         }
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         const int row0 = mi * 32 + 4 * kh;
-        float *out = slab + (int64_t)s * M * N + (int64_t)row0 * N;
+        const int64_t slab_stride = (int64_t)M * N + (CS ? M : 0);
+        if constexpr (CS) {
+            if (do_cs && (lane & 31) == 0) {                    // every column of accs holds the same sums
+                float *cs = slab + (int64_t)s * slab_stride + (int64_t)M * N;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = row0 + (i & 3) + 8 * (i >> 2);
+                    if (row < M) cs[row] = accs[i];
+                }
+            }
+        }
+        float *out = slab + (int64_t)s * slab_stride + (int64_t)row0 * N;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             if (!nok[j]) continue;
@@ -141,27 +170,33 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
 // C[o] = sum_s slab[s][o]: 64 outputs per block, the 4 waves take s = w, w+4, ... (8 loads in
 // flight each) and are combined in wave order through LDS -- fixed order, deterministic.
 __global__ __launch_bounds__(kBlock) void gemm_tn_reduce_kernel(const float *__restrict__ slab,
-                                                                float *__restrict__ C, int64_t MN, int S)
+                                                                float *__restrict__ C, float *__restrict__ CS,
+                                                                int64_t MNc, int64_t MN, int S)
 {
     __shared__ float part[kWavesPerBlock][kWave];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = threadIdx.x >> 6;
+    // slab rows are MNc = MN (+ M column sums) long; outputs [0, MN) go to C, [MN, MNc) to CS
     const int64_t o = (int64_t)blockIdx.x * kWave + lane;
     float acc = 0.f;
-    if (o < MN) {
+    if (o < MNc) {
         int s = w;
         for (; s + 7 * kWavesPerBlock < S; s += 8 * kWavesPerBlock) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(s + u * kWavesPerBlock) * MN + o];
+            for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(s + u * kWavesPerBlock) * MNc + o];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        for (; s < S; s += kWavesPerBlock) acc += slab[(int64_t)s * MN + o];
+        for (; s < S; s += kWavesPerBlock) acc += slab[(int64_t)s * MNc + o];
     }
     part[w][lane] = acc;
     __syncthreads();
-    if (w == 0 && o < MN) C[o] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (w == 0 && o < MNc) {
+        const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        if (o < MN) C[o] = tot;
+        else CS[o - MN] = tot;
+    }
 }
 
 namespace {
@@ -197,47 +232,61 @@ extern "C" size_t stg_gemm_tn_workspace_bytes(int64_t K, int32_t M, int32_t N)
 {
     if (K <= 0 || M <= 0 || N <= 0) return 0;
     const stg::GemmPlan p = stg::plan_gemm_tn(K, M, N);
-    return (size_t)p.S * (size_t)M * (size_t)N * sizeof(float);
+    return (size_t)p.S * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
 }
 
-extern "C" int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t M, int32_t N,
-                               void *workspace, size_t workspace_bytes, void *stream_)
+namespace stg {
+namespace {
+int gemm_tn_run(const float *A, const float *B, float *C, float *colsum, int64_t K, int32_t M, int32_t N,
+                void *workspace, size_t workspace_bytes, void *stream_, const char *what)
 {
-    using namespace stg;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (K < 0 || M <= 0 || N <= 0)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_f32: bad shape K=%lld M=%d N=%d", (long long)K, M, N);
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad shape K=%lld M=%d N=%d", what, (long long)K, M, N);
     if ((int64_t)2 * M * N > INT32_MAX || (int64_t)2 * M > INT32_MAX / 2)
-        return fail(STG_ERR_UNSUPPORTED, "stg_gemm_tn_f32: output %d x %d too large for the tall-skinny kernel", M, N);
-    if (!C) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_f32: NULL output");
+        return fail(STG_ERR_UNSUPPORTED, "%s: output %d x %d too large for the tall-skinny kernel", what, M, N);
+    if (!C) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL output", what);
     if (K == 0) {
-        const hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, stream);
-        return e == hipSuccess ? 0 : fail((int)e, "stg_gemm_tn_f32: %s", hipGetErrorString(e));
+        hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, stream);
+        if (e == hipSuccess && colsum) e = hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)M, stream);
+        return e == hipSuccess ? 0 : fail((int)e, "%s: %s", what, hipGetErrorString(e));
     }
-    if (!A || !B || !workspace) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_f32: NULL pointer argument");
+    if (!A || !B || !workspace) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
     const GemmPlan p = plan_gemm_tn(K, M, N);
-    const size_t need = (size_t)p.S * (size_t)M * (size_t)N * sizeof(float);
+    const bool cs = colsum != nullptr;
+    const int64_t MN = (int64_t)M * N, MNc = MN + (cs ? M : 0);
+    const size_t need = (size_t)p.S * (size_t)MNc * sizeof(float);
     if (workspace_bytes < need)
-        return fail(STG_ERR_WORKSPACE, "stg_gemm_tn_f32: workspace %zu < required %zu", workspace_bytes, need);
+        return fail(STG_ERR_WORKSPACE, "%s: workspace %zu < required %zu", what, workspace_bytes, need);
     float *slab = static_cast<float *>(workspace);
     const int64_t blocks = (int64_t)p.S * p.m_tiles * p.n_groups;
-    const size_t lds = (size_t)(kWavesPerBlock - 1) * p.nt * 16 * kWave * sizeof(float);
-    switch (p.nt) {
-        case 1:
-            hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 8>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, A,
-                               B, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups);
-            break;
-        case 2:
-            hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 8>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, A,
-                               B, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups);
-            break;
-        default:
-            hipLaunchKernelGGL((gemm_tn_partial_kernel<4, 4>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, A,
-                               B, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups);
-            break;
+    const size_t lds = (size_t)(kWavesPerBlock - 1) * (p.nt + (cs ? 1 : 0)) * 16 * kWave * sizeof(float);
+#define STG_GEMM_LAUNCH(NT_, KU_, CS_)                                                                        \
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<NT_, KU_, CS_>), dim3((unsigned)blocks), dim3(kBlock), lds,    \
+                       stream, A, B, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups)
+    if (cs) {
+        if (p.nt == 1) STG_GEMM_LAUNCH(1, 8, true); else if (p.nt == 2) STG_GEMM_LAUNCH(2, 8, true); else STG_GEMM_LAUNCH(4, 4, true);
+    } else {
+        if (p.nt == 1) STG_GEMM_LAUNCH(1, 8, false); else if (p.nt == 2) STG_GEMM_LAUNCH(2, 8, false); else STG_GEMM_LAUNCH(4, 4, false);
     }
-    const int64_t MN = (int64_t)M * N;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MN + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
-                       slab, C, MN, p.S);
-    return check_launch("stg_gemm_tn_f32");
+#undef STG_GEMM_LAUNCH
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MNc + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
+                       slab, C, colsum, MNc, MN, p.S);
+    return check_launch(what);
+}
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t M, int32_t N,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    return stg::gemm_tn_run(A, B, C, nullptr, K, M, N, workspace, workspace_bytes, stream, "stg_gemm_tn_f32");
+}
+
+extern "C" int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *colsum_A, int64_t K,
+                                      int32_t M, int32_t N, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!colsum_A) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_colsum_f32: NULL colsum output");
+    return stg::gemm_tn_run(A, B, C, colsum_A, K, M, N, workspace, workspace_bytes, stream,
+                            "stg_gemm_tn_colsum_f32");
 }

@@ -397,19 +397,36 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
 
 
 # ------------------------------------------------------- dense neighbour: weight gradient
-def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """``a.T @ b`` for tall-skinny fp32 operands ``a [K, M]``, ``b [K, N]`` (stg_gemm_tn_f32)."""
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, colsum: bool = False):
+    """``a.T @ b`` for tall-skinny fp32 operands ``a [K, M]``, ``b [K, N]`` (stg_gemm_tn_f32).
+    ``colsum=True`` also returns ``a.sum(0)`` from the same launch (stg_gemm_tn_colsum_f32)."""
     a, b = _f32(a, "a"), _f32(b, "b", a.device)
     if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
         raise ValueError(f"gemm_tn expects [K,M] and [K,N], got {tuple(a.shape)} and {tuple(b.shape)}")
     K, M = a.shape
     N = b.shape[1]
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    cs = torch.empty(M, dtype=torch.float32, device=a.device) if colsum else None
     if M == 0 or N == 0:
-        return c
+        return (c, cs) if colsum else c
     ws_bytes = int(_C.lib.stg_gemm_tn_workspace_bytes(K, M, N))
     ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=a.device)
     with torch.cuda.device(a.device), _Timed("gemm_tn", 4 * K * (M + N) + 4 * M * N, 2 * K * M * N):
-        _C.check(_C.lib.stg_gemm_tn_f32(_ptr(a), _ptr(b), _ptr(c), K, M, N, _ptr(ws), ws_bytes,
-                                        _stream_ptr(a.device)))
-    return c
+        if colsum:
+            _C.check(_C.lib.stg_gemm_tn_colsum_f32(_ptr(a), _ptr(b), _ptr(c), _ptr(cs), K, M, N, _ptr(ws), ws_bytes,
+                                                   _stream_ptr(a.device)))
+        else:
+            _C.check(_C.lib.stg_gemm_tn_f32(_ptr(a), _ptr(b), _ptr(c), K, M, N, _ptr(ws), ws_bytes,
+                                            _stream_ptr(a.device)))
+    return (c, cs) if colsum else c
+
+
+def tgcn_cell_call(name: str, tensors, N: int, C: int, *scalars) -> None:
+    """Launch one fused TGCN row-local stage (stg_tgcn_cell_<name>); tensors are validated here."""
+    dev = tensors[0].device
+    for t in tensors:
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError(f"tgcn_cell_{name}: operands must be contiguous fp32 tensors on one HIP device")
+    fn = getattr(_C.lib, "stg_tgcn_cell_" + name)
+    with torch.cuda.device(dev):
+        _C.check(fn(*[_ptr(t) for t in tensors], N, C, *[float(x) for x in scalars], _stream_ptr(dev)))

@@ -11,6 +11,10 @@ difference is rocBLAS choosing its tiling for a [N, in] x [in, 3*out] product in
 [in, out] ones (fp32 rounding of the K = in dot products).  ``fuse_gates = False`` runs the
 reference's three separate layers.
 
+``fuse_cell`` (default on, needs ``fuse_gates``): bias + clamp, the two ``cat``s, sigmoid / tanh and
+the GRU blend run as six fused HIP kernels around the three rocBLAS gate GEMMs inside one autograd
+node (``cell.TGCNCellFn``) instead of ~57 torch launches per snapshot.
+
 The gate ``Linear`` layers keep their modules (and parameter names) but are applied through
 ``stgraph_amd.nn.functional.linear``: same forward, weight gradient by the split-K MFMA kernel.
 """
@@ -21,10 +25,12 @@ import torch
 from .... import kernels
 from ... import functional as SF
 from ..static.gcn_conv import GCNConv
+from . import cell
 
 
 class TGCN(torch.nn.Module):
     fuse_gates = True
+    fuse_cell = True     # everything after the aggregation as ONE autograd node (temporal/cell.py)
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -82,8 +88,22 @@ class TGCN(torch.nn.Module):
         H = Z * H + (1 - Z) * H_tilde
         return H
 
+    def _fused_cell(self, g, X, edge_weight, H):
+        """One aggregation launch + ``cell.TGCNCellFn`` (fused row-local stages); same math as below."""
+        convs = (self.conv_z, self.conv_r, self.conv_h)
+        GCNConv.check_norm(g)
+        W = torch.cat([c.weight for c in convs], dim=1)
+        b3 = torch.cat([c.bias for c in convs], dim=0)
+        a3 = self.conv_z.aggregate(g, SF.mm(X, W), edge_weight)
+        return cell.TGCNCellFn.apply(a3, b3, H, self.linear_z.weight, self.linear_z.bias,
+                                     self.linear_r.weight, self.linear_r.bias,
+                                     self.linear_h.weight, self.linear_h.bias)
+
     def forward(self, g, X, edge_weight=None, H=None):
         H = self._set_hidden_state(X, H)
+        if self.fuse_cell and self.fuse_gates and not kernels.reference_compat() and cell.usable(X, H) and \
+                all(type(c) is GCNConv and c.bias is not None for c in (self.conv_z, self.conv_r, self.conv_h)):
+            return self._fused_cell(g, X, edge_weight, H)
         hz, hr, hh = self._gate_convs(g, X, edge_weight)
         Z = self._calculate_update_gate(hz, H)
         R = self._calculate_reset_gate(hr, H)

@@ -19,6 +19,10 @@ def test_matches_torch(cuda, K, M, N):
     scale = (a.double().abs().t() @ b.double().abs()).max().item()
     assert err <= 2e-6 * scale + 1e-6, (err, scale)            # fp32 fma-chain accuracy (guide: ~1e-7 * sum|ab|)
     assert torch.equal(got, kernels.gemm_tn(a, b))              # deterministic: fixed slice order, no atomics
+    got2, cs = kernels.gemm_tn(a, b, colsum=True)              # weight + bias gradient in one launch
+    assert torch.equal(got2, got)
+    csd = a.double().sum(0)
+    assert (cs.double() - csd).abs().max().item() <= 2e-6 * a.double().abs().sum(0).max().item() + 1e-6
 
 
 def test_asymmetric_integer_data_exact(cuda):

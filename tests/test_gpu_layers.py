@@ -210,6 +210,40 @@ def test_naive_graph_tgcn_bptt_matches_reference(cuda, resident):
     assert G.current_timestamp == 1
 
 
+def test_fused_cell_matches_unfused_tgcn(cuda):
+    """cell.TGCNCellFn (fused row-local stages) == the torch formulation: outputs and every gradient."""
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn.pytorch.temporal.tgcn import TGCN
+    from tests.util import random_graph
+    n, e = 5000, 60000
+    src, dst = random_graph(78, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    f = g.csr("fwd")
+    deg = (f.row_offset[1:] - f.row_offset[:-1]).float()
+    g.set_ndata("norm", torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg)).unsqueeze(1))
+    torch.manual_seed(3)
+    m = TGCN(16, 32).to(cuda)
+    with torch.no_grad():                                  # make the clamp bite on a few entries
+        m.conv_z.bias[:4] = 2e6
+        m.conv_h.bias[-3:] = -3e6
+    x = torch.randn(n, 16, device=cuda, requires_grad=True)
+    w = torch.rand(len(src), 1, device=cuda) + 0.5
+    res = []
+    for fuse in (True, False):
+        m.fuse_cell = fuse
+        m.zero_grad()
+        x.grad = None
+        H = None
+        for _ in range(3):
+            H = m(g, x, w, H)
+        (H * torch.linspace(-1, 1, 32, device=cuda)).sum().backward()
+        res.append((H.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-5)
+    for k in res[0][2]:
+        torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=1e-4, atol=1e-4, msg=k)
+
+
 def test_fused_gates_equal_separate_gates(cuda):
     """One width-3H aggregation == three width-H aggregations, column for column."""
     from stgraph_amd import kernels
