@@ -241,7 +241,13 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
                                                            rank=rank, world=world, timed_comm=True), 1)
     kernels.enable_launch_timing(None)
     comm = bucket.collect_comm_time()
-    records = [r for r in records if r[0] == "gcn_agg"]
+    ktab = {}
+    for name, a, b, nbytes, _ in records:                        # per-kernel HIP-event times of the eager epoch
+        d = ktab.setdefault(name, {"ms": [], "bytes": nbytes})
+        d["ms"].append(a.elapsed_time(b))
+    ktab = {k: {"launches": len(v["ms"]), "mean_ms": float(np.mean(v["ms"])),
+                "algorithmic_GBps": v["bytes"] / float(np.mean(v["ms"])) / 1e6} for k, v in ktab.items()}
+    records = [r for r in records if r[0] in ("gcn_agg", "gcn_agg_transform")]
     agg_s = float(np.sum([a.elapsed_time(b) for (_, a, b, _, _) in records])) * 1e-3
     agg_launches = len(records)
     if world > 1:
@@ -266,11 +272,11 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
     bucket.check_views()
     fused = bool(model.temporal.fuse_gates)
     agg_per_step = 2 if fused else 6                             # (fwd + bwd) x (1 fused | 3 separate) gates
-    width = (3 if fused else 1) * hidden
+    width = (3 if fused else 1) * hidden                         # width of the layer's aggregation A_hat (X W)
     return {
         "workload": f"static-temporal TGCN |V|={n} |E|={e} T={T} feat={feat} hidden={hidden} backprop_every={B} "
                     f"(BASELINE configs[3]), windows sharded over {world} rank(s), Adam; "
-                    f"{'fused 3-gate aggregation (width 192)' if fused else 'three width-64 aggregations'} per snapshot, "
+                    f"{'fused 3-gate aggregation (one launch; aggregate-then-transform on the matrix cores)' if fused else 'three width-64 aggregations'} per snapshot, fused row-local GRU cell, "
                     "the compute of each BPTT window (fwd + bwd through time) replayed from a HIP graph, then one eager "
                     "all-reduce of the gradient bucket and one Adam step",
         "metric": "epochs/s", "value": epochs / dt, "epochs": epochs, "seconds_per_epoch": dt / epochs,
@@ -280,7 +286,7 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
         "optimizer_steps_per_epoch": (temporal.num_windows(T, B) + world - 1) // world,
         "eager": {"seconds_per_epoch": dt_eager, "epochs_per_s": 1.0 / dt_eager,
                   "rank0_gcn_agg_kernel_seconds": agg_s, "rank0_gcn_agg_launches": agg_launches,
-                  "rank0_gcn_agg_share": agg_s / dt_eager,
+                  "rank0_gcn_agg_share": agg_s / dt_eager, "rank0_native_kernels": ktab,
                   "allreduce_seconds_max_rank": comm, "allreduce_share": comm / dt_eager},
         "allreduce": {"bytes": bucket.nbytes, "calls_per_epoch": (bucket.comm_calls - calls0) / max(epochs, 1),
                       "seconds_max_rank": comm_g, "share_of_epoch": comm_g / dt if dt else None,

@@ -126,6 +126,18 @@ int stg_gcn_agg_edge(const float *x, const float *norm_row, const float *norm_co
                      const int32_t *node_ids, int32_t N, int64_t E, int32_t F, int32_t F_active,
                      void *stream);      /* E = number of edges (lane-mapping heuristic only; 0 = unknown) */
 
+/* Fused aggregate-then-transform:  out[N,Fout] = (A_hat x) W  in one kernel:
+ * the rows of A_hat x (aggregated exactly as stg_gcn_agg_edge does, width Fin) are staged in an LDS
+ * tile and multiplied by W [Fin,Fout] on the fp32 matrix cores.  Equals the layer's A_hat (x W) up to
+ * fp32 rounding (aggregation is linear); pays when Fin < Fout (TGCN gates: gather 32 instead of 192
+ * floats per edge).  P_out (nullable) [N,Fin] receives A_hat x for the backward pass.
+ * Needs Fin % 4 == 0, 16 <= Fin, Fout % 32 == 0, 4 (64 (Fin+1) + Fin Fout) <= 64 KiB, else
+ * STG_ERR_UNSUPPORTED (callers then run the two-kernel form). */
+int stg_gcn_agg_transform(const float *x, const float *norm_row, const float *norm_col_edge,
+                          const float *ew_edge, const float *W, float *out, float *P_out,
+                          const int32_t *row_offsets, const int32_t *column_indices,
+                          const int32_t *node_ids, int32_t N, int32_t Fin, int32_t Fout, void *stream);
+
 /* dst[i] = table[idx[i]], i < n.  All [dev]. */
 int stg_edge_gather_f32(float *dst, const float *table, const int32_t *idx, int64_t n, void *stream);
 

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "stg_abi_version", "stg_last_error_string", "stg_set_tuning",
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
-    "stg_gcn_agg", "stg_gcn_agg_edge", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
+    "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
@@ -65,6 +65,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_gcn_agg.argtypes = [vp] * 9 + [i32, i32, i32, vp]
     lib.stg_gcn_agg_edge.restype = ctypes.c_int
     lib.stg_gcn_agg_edge.argtypes = [vp] * 8 + [i32, i64, i32, i32, vp]
+    lib.stg_gcn_agg_transform.restype = ctypes.c_int
+    lib.stg_gcn_agg_transform.argtypes = [vp] * 10 + [i32, i32, i32, vp]
     lib.stg_edge_gather_f32.restype = ctypes.c_int
     lib.stg_edge_gather_f32.argtypes = [vp, vp, vp, i64, vp]
     lib.stg_gat_fwd_k0.restype = ctypes.c_int

@@ -1,0 +1,198 @@
+// Fused aggregate-then-transform:  out = (A_hat X) W   in ONE kernel  (SURVEY.md 8(f) rank 1).
+//
+//   P[r,:]  = norm_row[r] * sum_{e in row r} (nc[e] * x[col[e],:]) * w[e]        (as gcn_agg_kernel)
+//   out[r,:] = P[r,:] W                                                          (fp32 MFMA)
+//
+// A GCN layer computes A_hat (X W); aggregation is linear, so (A_hat X) W is the same map and when
+// F_in < F_out the gather runs at the NARROW width: TGCN's fused gates gather 32 floats per edge
+// instead of 192 (6x less gather traffic), and the [N, F_out] intermediate X W is never written or
+// re-read.  Rounding differs from the reference's order (A_hat applied after W) at the 1e-7 level;
+// parity is 1e-4 (tests/test_gpu_agg_transform.py).
+//
+// Workgroup = 256 threads = 64 CSR rows.
+//   phase 1  each wave aggregates its rows exactly like gcn_agg_kernel (G lanes per row, 16-B row
+//            gathers, UNROLL in flight, CSR order, one accumulator per feature) and drops the
+//            scaled row into an LDS tile Ps[64][F_in + 1] (the +1 pad makes the column reads of
+//            phase 2 conflict-free); W [F_in, F_out] is staged into LDS once per workgroup.
+//   phase 2  v_mfma_f32_32x32x2_f32 over the tile: A fragment = Ps[row = l&31][k + (l>>5)] (LDS),
+//            B fragment = Ws[k + (l>>5)][n0 + (l&31)] (LDS, bank = column), 32x32 output tiles
+//            dealt round-robin to the 4 waves; results stored as 128-B row segments.
+// LDS = 4 (64 (F_in+1) + F_in F_out) bytes: 33 KB at 32 -> 192, so 4 workgroups (16 waves) per CU.
+// Optionally P itself is written out ([N, F_in]): the backward pass needs it for dW = P^T dOut.
+#include "stg_common.hpp"
+
+namespace stg {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kXwRows = 64;
+
+template <int LOG2G, bool HAS_EW>
+__global__ __launch_bounds__(kBlock) void gcn_agg_xw_kernel(
+    const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
+    const float *__restrict__ ew_edge, const float *__restrict__ W, float *__restrict__ out,
+    float *__restrict__ P_out, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, const int *__restrict__ node_ids, int N, int Fin, int Fout)
+{
+    constexpr int G = 1 << LOG2G;
+    constexpr int VEC = 4;
+    constexpr int ROWS_PER_WAVE = kWave / G;
+    constexpr int ROWS_PER_PASS = ROWS_PER_WAVE * kWavesPerBlock;
+    constexpr int U = G < 8 ? G : 8;
+    extern __shared__ float lds[];
+    const int ldp = Fin + 1;
+    float *Ps = lds;                                  // [kXwRows][Fin + 1]
+    float *Ws = lds + kXwRows * ldp;                  // [Fin][Fout]
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & (G - 1);
+    const int row_base = blockIdx.x * kXwRows;
+
+    // stage W (read once per workgroup, L2 resident)
+    for (int i = threadIdx.x * 4; i < Fin * Fout; i += kBlock * 4)
+        *reinterpret_cast<float4 *>(Ws + i) = *reinterpret_cast<const float4 *>(W + i);
+
+    // ---- phase 1: aggregate into the LDS tile
+    const int foff = j * VEC;
+    const bool fok = foff < Fin;
+    for (int pass = 0; pass < kXwRows / ROWS_PER_PASS; ++pass) {
+        const int lr = pass * ROWS_PER_PASS + wave * ROWS_PER_WAVE + (lane >> LOG2G);   // row inside the tile
+        const int idx = row_base + lr;
+        const bool row_valid = idx < N;
+        int r = 0, beg = 0, deg = 0;
+        float nr = 0.f;
+        if (row_valid) {
+            r = node_ids ? node_ids[idx] : idx;
+            beg = row_offsets[r];
+            deg = row_offsets[r + 1] - beg;
+            nr = norm_row[r];
+        }
+        const int max_deg = __builtin_amdgcn_readfirstlane(wave_max(deg));
+        float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+        for (int base = 0; base < max_deg; base += G) {
+            const int cnt = deg - base;
+            const int cnt_max = min(G, max_deg - base);
+            int c = 0;
+            float nc = 0.f, w = 1.f;
+            if (j < cnt) {
+                const int e = beg + base + j;
+                c = column_indices[e];
+                nc = nc_edge[e];
+                if constexpr (HAS_EW) w = ew_edge[e];
+            }
+            for (int k = 0; k < cnt_max; k += U) {
+                float v[U][VEC];
+                float ncs[U], ws[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kk = k + u;
+                    const int ck = __shfl(c, kk & (G - 1), G);
+                    ncs[u] = __shfl(nc, kk & (G - 1), G);
+                    if constexpr (HAS_EW) ws[u] = __shfl(w, kk & (G - 1), G);
+                    if (kk < cnt && fok) {
+                        vec_load<VEC>(v[u], x + (int64_t)ck * Fin + foff);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (k + u < cnt) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            float t = ncs[u] * v[u][i];
+                            if constexpr (HAS_EW) t = t * ws[u];
+                            acc[i] = acc[i] + t;
+                        }
+                    }
+                }
+            }
+        }
+        if (fok) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) Ps[lr * ldp + foff + i] = acc[i] * nr;       // rows >= N hold zeros
+            if (P_out && row_valid) {
+                float o[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) o[i] = acc[i] * nr;
+                vec_store<VEC>(P_out + (int64_t)r * Fin + foff, o);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: out tile = Ps (64 x Fin) * Ws (Fin x Fout) on the fp32 matrix cores
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int col_tiles = Fout / 32;
+    const int tiles = (kXwRows / 32) * col_tiles;
+    for (int t = wave; t < tiles; t += kWavesPerBlock) {
+        const int rt = t / col_tiles, ct = t - rt * col_tiles;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float *pa = Ps + (rt * 32 + l31) * ldp + kh;
+        const float *pb = Ws + kh * Fout + ct * 32 + l31;
+#pragma unroll 4
+        for (int k = 0; k < Fin; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k * Fout], acc, 0, 0, 0);
+        // C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int lr = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+            const int idx = row_base + lr;
+            if (idx < N) {
+                const int r = node_ids ? node_ids[idx] : idx;
+                out[(int64_t)r * Fout + ct * 32 + l31] = acc[i];
+            }
+        }
+    }
+}
+
+}  // namespace stg
+
+extern "C" int stg_gcn_agg_transform(const float *x, const float *norm_row, const float *norm_col_edge,
+                                     const float *ew_edge, const float *W, float *out, float *P_out,
+                                     const int32_t *row_offsets, const int32_t *column_indices,
+                                     const int32_t *node_ids, int32_t N, int32_t Fin, int32_t Fout, void *stream)
+{
+    using namespace stg;
+    if (N < 0 || Fin <= 0 || Fout <= 0)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg_transform: bad shape N=%d Fin=%d Fout=%d", N, Fin, Fout);
+    if (Fin % 4 != 0 || Fin < 16 || Fin > 256 || Fout % 32 != 0)
+        return fail(STG_ERR_UNSUPPORTED,
+                    "stg_gcn_agg_transform: needs Fin %% 4 == 0, 16 <= Fin <= 256, Fout %% 32 == 0 (got %d -> %d)", Fin, Fout);
+    const size_t lds = sizeof(float) * ((size_t)kXwRows * (Fin + 1) + (size_t)Fin * Fout);
+    if (lds > 64 * 1024)
+        return fail(STG_ERR_UNSUPPORTED, "stg_gcn_agg_transform: W (%d x %d) does not fit the 64 KB LDS budget", Fin, Fout);
+    if (N == 0) return 0;
+    if (!x || !norm_row || !W || !out || !row_offsets)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg_transform: NULL pointer argument");
+    const uintptr_t align = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W) |
+                            reinterpret_cast<uintptr_t>(P_out);
+    if (align % 16 != 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg_transform: operands must be 16-byte aligned");
+    const int lanes = Fin / 4;
+    const int log2g = ilog2_ceil(lanes);
+    const unsigned blocks = (unsigned)(((int64_t)N + kXwRows - 1) / kXwRows);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define STG_XW(LG)                                                                                             \
+    if (ew_edge)                                                                                               \
+        hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, true>), dim3(blocks), dim3(kBlock), lds, st, x, norm_row,    \
+                           norm_col_edge, ew_edge, W, out, P_out, row_offsets, column_indices, node_ids, N, Fin, \
+                           Fout);                                                                              \
+    else                                                                                                       \
+        hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, false>), dim3(blocks), dim3(kBlock), lds, st, x, norm_row,   \
+                           norm_col_edge, ew_edge, W, out, P_out, row_offsets, column_indices, node_ids, N, Fin, \
+                           Fout)
+    switch (log2g) {
+        case 0: STG_XW(0); break;
+        case 1: STG_XW(1); break;
+        case 2: STG_XW(2); break;
+        case 3: STG_XW(3); break;
+        case 4: STG_XW(4); break;
+        case 5: STG_XW(5); break;
+        default: STG_XW(6); break;
+    }
+#undef STG_XW
+    return check_launch("stg_gcn_agg_transform");
+}

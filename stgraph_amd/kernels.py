@@ -306,6 +306,45 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
     return out
 
 
+def agg_transform_supported(fin: int, fout: int) -> bool:
+    return fin % 4 == 0 and fin >= 16 and fout % 32 == 0 and 4 * (64 * (fin + 1) + fin * fout) <= 64 * 1024
+
+
+def gcn_agg_transform(x: torch.Tensor, W: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor,
+                      csr: DeviceCSR, ew: torch.Tensor | None = None, use_node_ids: bool = False,
+                      want_p: bool = True):
+    """(out, P) with P = A_hat x (as gcn_agg) and out = P @ W, in one launch (stg_gcn_agg_transform)."""
+    x = _f32(x, "x")
+    dev = x.device
+    W = _f32(W, "W", dev)
+    N = csr.num_nodes
+    if x.dim() != 2 or x.shape[0] != N or W.dim() != 2 or W.shape[0] != x.shape[1]:
+        raise ValueError(f"gcn_agg_transform: x {tuple(x.shape)} / W {tuple(W.shape)} do not match the graph ({N} nodes)")
+    fin, fout = int(W.shape[0]), int(W.shape[1])
+    if not agg_transform_supported(fin, fout):
+        raise ValueError(f"gcn_agg_transform does not cover {fin} -> {fout}")
+    norm_row, norm_col = _f32(norm_row, "norm_row", dev), _f32(norm_col, "norm_col", dev)
+    if norm_row.numel() != N or norm_col.numel() != N or csr.row_offset.device != dev:
+        raise ValueError("norm tensors must hold one value per node and live with the graph")
+    if ew is not None:
+        ew = _f32(ew, "edge_weight", dev)
+        if ew.numel() < csr.num_edges:
+            raise ValueError("edge_weight shorter than the edge list")
+    out = torch.empty(N, fout, dtype=torch.float32, device=dev)
+    P = torch.empty(N, fin, dtype=torch.float32, device=dev) if want_p else None
+    E = csr.num_edges
+    with torch.cuda.device(dev):
+        nc_e = _edge_gathered(csr, "norm", norm_col, csr.column_indices)
+        ew_e = None if ew is None else _edge_gathered(csr, "ew", ew, csr.eids)
+        nbytes = gcn_agg_algorithmic_bytes(N, E, fin, ew is not None) + 4 * N * fout + 4 * fin * fout
+        with _Timed("gcn_agg_transform", nbytes, E * fin):
+            _C.check(_C.lib.stg_gcn_agg_transform(
+                _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(W), _ptr(out), _ptr(P),
+                _ptr(csr.row_offset), _ptr(csr.column_indices), _ptr(csr.node_ids if use_node_ids else None),
+                N, fin, fout, _stream_ptr(dev)))
+    return out, P
+
+
 # ------------------------------------------------------------------------------- GAT
 def gat_fwd(el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor, csr: DeviceCSR,
             slope: float, use_node_ids: bool = False):

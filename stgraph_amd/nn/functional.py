@@ -78,3 +78,43 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None) -> t
     if x.dim() == 2 and _use_native(x, x.shape[0], w.shape[0], w.shape[1]):
         return _Linear.apply(x, w, b)
     return F.linear(x, w, b)
+
+
+class _AggTransform(torch.autograd.Function):
+    """``A_hat(x W)`` computed as ``(A_hat x) W`` by the fused kernel (kernels.gcn_agg_transform)."""
+
+    @staticmethod
+    def forward(ctx, x, W, norm, ew, fwd_csr, bwd_csr, use_nid):
+        out, P = kernels.gcn_agg_transform(x, W, norm, norm, fwd_csr, ew=ew, use_node_ids=use_nid)
+        ctx.save_for_backward(P, W, norm, ew if ew is not None else norm.new_empty(0))
+        ctx.has_ew = ew is not None
+        ctx.bwd_csr, ctx.use_nid = bwd_csr, use_nid
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        P, W, norm, ew = ctx.saved_tensors
+        ew = ew if ctx.has_ew else None
+        g = g.contiguous()
+        dW = dx = None
+        if ctx.needs_input_grad[1]:
+            dW = kernels.gemm_tn(P, g) if _use_native(P, P.shape[0], P.shape[1], g.shape[1]) else torch.mm(P.t(), g)
+        if ctx.needs_input_grad[0]:
+            z = torch.mm(g, W.t())                                    # d(A_hat x) = g W^T          [N, Fin]
+            dx = kernels.gcn_agg(z, norm, norm, ctx.bwd_csr, ew=ew, use_node_ids=ctx.use_nid)   # A_hat^T z
+        return dx, dW, None, None, None, None, None
+
+
+def agg_transform_usable(graph, x: torch.Tensor, W: torch.Tensor) -> bool:
+    """The fused kernel pays (and is supported) when the gather can run at the narrow input width."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and W.shape[0] < W.shape[1]
+            and kernels.agg_transform_supported(int(W.shape[0]), int(W.shape[1]))
+            and kernels._EDGE_CACHE and not kernels.reference_compat() and hasattr(graph, "csr"))
+
+
+def agg_transform(graph, x: torch.Tensor, W: torch.Tensor, edge_weight=None) -> torch.Tensor:
+    """``GCNConv``'s ``aggregate(graph, x @ W)`` as one fused launch; captures the graph's CURRENT
+    forward/backward CSR (dynamic graphs: the snapshot of this timestamp) for the backward pass."""
+    norm = graph.get_ndata("norm")
+    return _AggTransform.apply(x, W, norm, edge_weight, graph.csr("fwd"), graph.csr("bwd"),
+                               graph.graph_type() == "csr")

@@ -31,6 +31,7 @@ from . import cell
 class TGCN(torch.nn.Module):
     fuse_gates = True
     fuse_cell = True     # everything after the aggregation as ONE autograd node (temporal/cell.py)
+    fuse_transform = True  # aggregate at the narrow input width, transform on the matrix cores (one kernel)
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -94,7 +95,10 @@ class TGCN(torch.nn.Module):
         GCNConv.check_norm(g)
         W = torch.cat([c.weight for c in convs], dim=1)
         b3 = torch.cat([c.bias for c in convs], dim=0)
-        a3 = self.conv_z.aggregate(g, SF.mm(X, W), edge_weight)
+        if self.fuse_transform and SF.agg_transform_usable(g, X, W):
+            a3 = SF.agg_transform(g, X, W, edge_weight)          # (A_hat X) W: gather at width in_channels
+        else:
+            a3 = self.conv_z.aggregate(g, SF.mm(X, W), edge_weight)
         return cell.TGCNCellFn.apply(a3, b3, H, self.linear_z.weight, self.linear_z.bias,
                                      self.linear_r.weight, self.linear_r.bias,
                                      self.linear_h.weight, self.linear_h.bias)
