@@ -202,6 +202,15 @@ int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t
 int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *colsum_A, int64_t K, int32_t M,
                            int32_t N, void *workspace, size_t workspace_bytes, void *stream);
 
+/* C = sum_{t < T} A_t^T B_t (and colsum_A = sum_t colsum(A_t), nullable) in ONE launch: A, B are HOST
+ * arrays of T <= 32 device pointers, every A_t [K,M], B_t [K,N].  The pointers travel by value in
+ * the kernel arguments, so the call is HIP-graph capturable.  Used to turn a BPTT window's weight
+ * gradient (one contribution per timestep) into a single split-K launch. */
+size_t stg_gemm_tn_multi_workspace_bytes(int32_t T, int64_t K, int32_t M, int32_t N);
+int stg_gemm_tn_multi_f32(const float *const *A, const float *const *B, int32_t T, float *C, float *colsum_A,
+                          int64_t K, int32_t M, int32_t N, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
 /* ----------------------------------------------- dense neighbour: TGCN row-local glue
  * Fused elementwise stages of one TGCN step (nn/pytorch/temporal/tgcn.py:21-55); the three gate
  * GEMMs between them stay on rocBLAS.  C = hidden width (multiple of 4), all [dev] fp32 row-major,

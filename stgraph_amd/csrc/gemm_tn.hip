@@ -26,10 +26,19 @@ constexpr int kGemmKStep = 16;             // K slices are multiples of this (co
 // NT = 32-column tiles per wave, KU = k-pairs per operand set (KU * (1 + NT) dword loads in flight)
 // CS: additionally emit the column sums of A (sum_k A[k][m]) -- the bias gradient that accompanies
 // every weight gradient -- from one extra MFMA per k-pair against a constant-one B fragment.
+// Operand segments: C = sum_t A_t^T B_t over up to kGemmMaxSeg (A_t, B_t) pairs of K rows each, passed
+// BY VALUE in the kernel arguments (no device-side pointer table to build, HIP-graph capturable).
+// This is how a BPTT window's weight gradient -- one contribution per timestep -- becomes ONE launch.
+constexpr int kGemmMaxSeg = 32;
+struct GemmSegs {
+    const float *a[kGemmMaxSeg];
+    const float *b[kGemmMaxSeg];
+};
+
 template <int NT, int KU, bool CS>
 __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
-    const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ slab, int64_t K,
-    int M, int N, int64_t kslice_wave, int m_tiles, int n_groups)
+    const GemmSegs segs, float *__restrict__ slab, int64_t K, int M, int N, int64_t kslice_wave,
+    int m_tiles, int n_groups, int s_per_seg)
 {
     extern __shared__ float lds[];                       // 3 waves x NT x 16 x 64 floats
     const int lane = threadIdx.x & (kWave - 1);
@@ -37,9 +46,13 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     const int mi = blockIdx.x % m_tiles;
     const int t = blockIdx.x / m_tiles;
     const int nj = t % n_groups;
-    const int s = t / n_groups;
+    const int s = t / n_groups;                          // slab index = segment * s_per_seg + slice
+    const int seg = s / s_per_seg;
+    const int sl = s - seg * s_per_seg;
+    const float *__restrict__ A = segs.a[seg];
+    const float *__restrict__ B = segs.b[seg];
 
-    const int64_t k0 = ((int64_t)s * kWavesPerBlock + wave) * kslice_wave;      // wave-uniform
+    const int64_t k0 = ((int64_t)sl * kWavesPerBlock + wave) * kslice_wave;     // wave-uniform, inside the segment
     const int64_t k1 = min(K, k0 + kslice_wave);
     const int kh = lane >> 5;
     // Rows >= M / columns >= N of the tile are never written back, so out-of-range lanes read a
@@ -206,7 +219,7 @@ struct GemmPlan {
     int64_t kslice_wave;
 };
 
-GemmPlan plan_gemm_tn(int64_t K, int M, int N)
+GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1)
 {
     GemmPlan p{};
     p.nt = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
@@ -214,7 +227,7 @@ GemmPlan plan_gemm_tn(int64_t K, int M, int N)
     p.n_groups = (N + 32 * p.nt - 1) / (32 * p.nt);
     const int64_t tiles = (int64_t)p.m_tiles * p.n_groups;
     // ~512 blocks = 2 waves on every SIMD; never slice below 64 rows per wave
-    int64_t S = (512 + tiles - 1) / tiles;
+    int64_t S = (512 + tiles * T - 1) / (tiles * T);            // slices PER SEGMENT
     const int64_t max_S = std::max<int64_t>(1, K / (64 * kWavesPerBlock));
     S = std::max<int64_t>(1, std::min(S, max_S));
     int64_t per_wave = (K + S * kWavesPerBlock - 1) / (S * kWavesPerBlock);
@@ -235,14 +248,22 @@ extern "C" size_t stg_gemm_tn_workspace_bytes(int64_t K, int32_t M, int32_t N)
     return (size_t)p.S * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
 }
 
+extern "C" size_t stg_gemm_tn_multi_workspace_bytes(int32_t T, int64_t K, int32_t M, int32_t N)
+{
+    if (T <= 0 || T > stg::kGemmMaxSeg || K <= 0 || M <= 0 || N <= 0) return 0;
+    const stg::GemmPlan p = stg::plan_gemm_tn(K, M, N, T);
+    return (size_t)T * (size_t)p.S * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+}
+
 namespace stg {
 namespace {
-int gemm_tn_run(const float *A, const float *B, float *C, float *colsum, int64_t K, int32_t M, int32_t N,
-                void *workspace, size_t workspace_bytes, void *stream_, const char *what)
+int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C, float *colsum, int64_t K,
+                int32_t M, int32_t N, void *workspace, size_t workspace_bytes, void *stream_, const char *what)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (K < 0 || M <= 0 || N <= 0)
-        return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad shape K=%lld M=%d N=%d", what, (long long)K, M, N);
+    if (K < 0 || M <= 0 || N <= 0 || T <= 0 || T > kGemmMaxSeg)
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad shape T=%d K=%lld M=%d N=%d (T <= %d)", what, T,
+                    (long long)K, M, N, kGemmMaxSeg);
     if ((int64_t)2 * M * N > INT32_MAX || (int64_t)2 * M > INT32_MAX / 2)
         return fail(STG_ERR_UNSUPPORTED, "%s: output %d x %d too large for the tall-skinny kernel", what, M, N);
     if (!C) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL output", what);
@@ -251,19 +272,26 @@ int gemm_tn_run(const float *A, const float *B, float *C, float *colsum, int64_t
         if (e == hipSuccess && colsum) e = hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)M, stream);
         return e == hipSuccess ? 0 : fail((int)e, "%s: %s", what, hipGetErrorString(e));
     }
-    if (!A || !B || !workspace) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
-    const GemmPlan p = plan_gemm_tn(K, M, N);
+    if (!As || !Bs || !workspace) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
+    GemmSegs segs{};
+    for (int t = 0; t < T; ++t) {
+        if (!As[t] || !Bs[t]) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL operand in segment %d", what, t);
+        segs.a[t] = As[t];
+        segs.b[t] = Bs[t];
+    }
+    const GemmPlan p = plan_gemm_tn(K, M, N, T);
     const bool cs = colsum != nullptr;
     const int64_t MN = (int64_t)M * N, MNc = MN + (cs ? M : 0);
-    const size_t need = (size_t)p.S * (size_t)MNc * sizeof(float);
+    const int S_total = T * p.S;
+    const size_t need = (size_t)S_total * (size_t)MNc * sizeof(float);
     if (workspace_bytes < need)
         return fail(STG_ERR_WORKSPACE, "%s: workspace %zu < required %zu", what, workspace_bytes, need);
     float *slab = static_cast<float *>(workspace);
-    const int64_t blocks = (int64_t)p.S * p.m_tiles * p.n_groups;
+    const int64_t blocks = (int64_t)S_total * p.m_tiles * p.n_groups;
     const size_t lds = (size_t)(kWavesPerBlock - 1) * (p.nt + (cs ? 1 : 0)) * 16 * kWave * sizeof(float);
 #define STG_GEMM_LAUNCH(NT_, KU_, CS_)                                                                        \
     hipLaunchKernelGGL((gemm_tn_partial_kernel<NT_, KU_, CS_>), dim3((unsigned)blocks), dim3(kBlock), lds,    \
-                       stream, A, B, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups)
+                       stream, segs, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S)
     if (cs) {
         if (p.nt == 1) STG_GEMM_LAUNCH(1, 8, true); else if (p.nt == 2) STG_GEMM_LAUNCH(2, 8, true); else STG_GEMM_LAUNCH(4, 4, true);
     } else {
@@ -271,7 +299,7 @@ int gemm_tn_run(const float *A, const float *B, float *C, float *colsum, int64_t
     }
 #undef STG_GEMM_LAUNCH
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MNc + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
-                       slab, C, colsum, MNc, MN, p.S);
+                       slab, C, colsum, MNc, MN, S_total);
     return check_launch(what);
 }
 }  // namespace
@@ -280,13 +308,21 @@ int gemm_tn_run(const float *A, const float *B, float *C, float *colsum, int64_t
 extern "C" int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t M, int32_t N,
                                void *workspace, size_t workspace_bytes, void *stream)
 {
-    return stg::gemm_tn_run(A, B, C, nullptr, K, M, N, workspace, workspace_bytes, stream, "stg_gemm_tn_f32");
+    return stg::gemm_tn_run(&A, &B, 1, C, nullptr, K, M, N, workspace, workspace_bytes, stream, "stg_gemm_tn_f32");
 }
 
 extern "C" int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *colsum_A, int64_t K,
                                       int32_t M, int32_t N, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!colsum_A) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_colsum_f32: NULL colsum output");
-    return stg::gemm_tn_run(A, B, C, colsum_A, K, M, N, workspace, workspace_bytes, stream,
+    return stg::gemm_tn_run(&A, &B, 1, C, colsum_A, K, M, N, workspace, workspace_bytes, stream,
                             "stg_gemm_tn_colsum_f32");
+}
+
+extern "C" int stg_gemm_tn_multi_f32(const float *const *A, const float *const *B, int32_t T, float *C,
+                                     float *colsum_A, int64_t K, int32_t M, int32_t N, void *workspace,
+                                     size_t workspace_bytes, void *stream)
+{
+    return stg::gemm_tn_run(A, B, T, C, colsum_A, K, M, N, workspace, workspace_bytes, stream,
+                            "stg_gemm_tn_multi_f32");
 }

@@ -460,6 +460,41 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, colsum: bool = False):
     return (c, cs) if colsum else c
 
 
+MAX_GEMM_SEGMENTS = 32
+
+
+def gemm_tn_multi(As, Bs, colsum: bool = False):
+    """``sum_t As[t].T @ Bs[t]`` (all ``[K, M]`` / ``[K, N]`` fp32) in one launch per 32 segments
+    (stg_gemm_tn_multi_f32); with ``colsum`` also ``sum_t As[t].sum(0)``."""
+    if len(As) != len(Bs) or not As:
+        raise ValueError("gemm_tn_multi needs equally long, non-empty operand lists")
+    dev = As[0].device
+    As = [_f32(a, "a", dev) for a in As]
+    Bs = [_f32(b, "b", dev) for b in Bs]
+    K, M = As[0].shape
+    N = Bs[0].shape[1]
+    for a, b in zip(As, Bs):
+        if a.shape != (K, M) or b.shape != (K, N):
+            raise ValueError("gemm_tn_multi: all segments must share one shape")
+    c_tot = cs_tot = None
+    for i in range(0, len(As), MAX_GEMM_SEGMENTS):
+        a_chunk, b_chunk = As[i:i + MAX_GEMM_SEGMENTS], Bs[i:i + MAX_GEMM_SEGMENTS]
+        T = len(a_chunk)
+        c = torch.empty(M, N, dtype=torch.float32, device=dev)
+        cs = torch.empty(M, dtype=torch.float32, device=dev) if colsum else None
+        ws_bytes = int(_C.lib.stg_gemm_tn_multi_workspace_bytes(T, K, M, N))
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        pa = (ctypes.c_void_p * T)(*[t.data_ptr() for t in a_chunk])
+        pb = (ctypes.c_void_p * T)(*[t.data_ptr() for t in b_chunk])
+        with torch.cuda.device(dev), _Timed("gemm_tn_multi", 4 * T * K * (M + N) + 4 * M * N, 2 * T * K * M * N):
+            _C.check(_C.lib.stg_gemm_tn_multi_f32(pa, pb, T, _ptr(c), _ptr(cs), K, M, N, _ptr(ws), ws_bytes,
+                                                  _stream_ptr(dev)))
+        c_tot = c if c_tot is None else c_tot + c
+        if colsum:
+            cs_tot = cs if cs_tot is None else cs_tot + cs
+    return (c_tot, cs_tot) if colsum else c_tot
+
+
 def tgcn_cell_call(name: str, tensors, N: int, C: int, *scalars) -> None:
     """Launch one fused TGCN row-local stage (stg_tgcn_cell_<name>); tensors are validated here."""
     dev = tensors[0].device

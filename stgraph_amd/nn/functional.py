@@ -12,8 +12,10 @@ import torch
 import torch.nn.functional as F
 
 from .. import kernels
+from . import deferred
 
 _NATIVE_WGRAD = True
+_DEFER = True
 MIN_K = 4096          # below this the stock GEMM is launch-bound either way
 MAX_MN = 1 << 18      # output elements; larger outputs are ordinary GEMMs
 
@@ -21,6 +23,18 @@ MAX_MN = 1 << 18      # output elements; larger outputs are ordinary GEMMs
 def set_native_weight_grad(enabled: bool) -> None:
     global _NATIVE_WGRAD
     _NATIVE_WGRAD = bool(enabled)
+
+
+def set_deferred_weight_grads(enabled: bool) -> None:
+    """True (default): weight/bias gradients of this package's dense nodes are accumulated once per
+    backward pass with one launch per parameter (see ``nn/deferred.py``).  False: computed per call and
+    returned through autograd."""
+    global _DEFER
+    _DEFER = bool(enabled)
+
+
+def deferred_weight_grads() -> bool:
+    return _DEFER and _NATIVE_WGRAD
 
 
 def _use_native(x: torch.Tensor, k: int, m: int, n: int) -> bool:
@@ -33,6 +47,7 @@ class _MM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
+        ctx.w = w
         return torch.mm(x, w)
 
     @staticmethod
@@ -42,7 +57,12 @@ class _MM(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.mm(g, w.t())
         if ctx.needs_input_grad[1]:
-            gw = kernels.gemm_tn(x, g) if _use_native(x, x.shape[0], x.shape[1], g.shape[1]) else torch.mm(x.t(), g)
+            native = _use_native(x, x.shape[0], x.shape[1], g.shape[1])
+            if native and deferred_weight_grads() and ctx.w.is_leaf:
+                W = ctx.w
+                deferred.current().add(("mm", id(W)), x, g.contiguous(), sink=lambda d, W=W: deferred.add_to_grad(W, d))
+            else:
+                gw = kernels.gemm_tn(x, g) if native else torch.mm(x.t(), g)
         return gx, gw
 
 
@@ -53,6 +73,7 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.w, ctx.b = w, b
         return F.linear(x, w, b)
 
     @staticmethod
@@ -61,9 +82,21 @@ class _Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.mm(g, w)
-        if ctx.needs_input_grad[1]:
-            gw = kernels.gemm_tn(g, x) if _use_native(x, x.shape[0], g.shape[1], x.shape[1]) else torch.mm(g.t(), x)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        native = _use_native(x, x.shape[0], g.shape[1], x.shape[1])
+        W, b = ctx.w, ctx.b
+        if native and want_w and deferred_weight_grads() and W.is_leaf and (not want_b or b.is_leaf):
+            deferred.current().add(("linear", id(W)), g.contiguous(), x,
+                                   sink=lambda d, W=W: deferred.add_to_grad(W, d),
+                                   colsum_sink=(lambda d, b=b: deferred.add_to_grad(b, d)) if want_b else None)
+            return gx, None, None
+        if want_w:
+            if native and want_b:
+                gw, gb = kernels.gemm_tn(g, x, colsum=True)
+                return gx, gw, gb
+            gw = kernels.gemm_tn(g, x) if native else torch.mm(g.t(), x)
+        if want_b:
             gb = g.sum(0)
         return gx, gw, gb
 
@@ -105,10 +138,12 @@ class _AggTransform(torch.autograd.Function):
         return dx, dW, None, None, None, None, None
 
 
-def agg_transform_usable(graph, x: torch.Tensor, W: torch.Tensor) -> bool:
-    """The fused kernel pays (and is supported) when the gather can run at the narrow input width."""
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and W.shape[0] < W.shape[1]
-            and kernels.agg_transform_supported(int(W.shape[0]), int(W.shape[1]))
+def agg_transform_usable(graph, x: torch.Tensor, W) -> bool:
+    """The fused kernel pays (and is supported) when the gather can run at the narrow input width.
+    ``W``: the weight tensor or its (in, out) shape."""
+    fin, fout = (int(W.shape[0]), int(W.shape[1])) if isinstance(W, torch.Tensor) else (int(W[0]), int(W[1]))
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and fin < fout
+            and kernels.agg_transform_supported(fin, fout)
             and kernels._EDGE_CACHE and not kernels.reference_compat() and hasattr(graph, "csr"))
 
 

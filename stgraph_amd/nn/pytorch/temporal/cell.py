@@ -1,68 +1,151 @@
-"""Fused row-local part of one TGCN step as a single autograd node.
+"""One TGCN step as a single autograd node.
 
-Input: the aggregated gate pre-activations ``a3 = A_hat (X [Wz|Wr|Wh])`` ([N, 3C], output of the
-fused gcn_agg launch), the concatenated GCN biases, the previous hidden state and the three gate
-``Linear`` layers.  Output: the new hidden state.  Mathematically identical to
-reference nn/pytorch/temporal/tgcn.py:21-55 (bias add, clamp to +-1e6, ``cat``/``Linear``/sigmoid
-for Z and R, ``cat``/``Linear``/tanh for the candidate, GRU blend).
+Mathematically identical to reference nn/pytorch/temporal/tgcn.py:21-55 (three GCNConv gates: bias
+add and clamp to +-1e6; ``cat``/``Linear``/sigmoid for Z and R; ``cat``/``Linear``/tanh for the
+candidate; GRU blend); what changes is how many kernels it takes.
 
-Per snapshot the eager formulation costs ~57 elementwise/cat/fill launches (forward + backward) plus
-autograd bookkeeping; here: 3 fused forward kernels + 3 rocBLAS GEMMs, and in backward 3 fused kernels
-+ 3 rocBLAS GEMMs (input gradients) + 3 split-K MFMA launches that produce each gate's weight AND
-bias gradient together (stg_gemm_tn_colsum_f32).  The concatenated GEMM operands ([hz|H], [hr|H],
-[hh|H*R]) are written in place by the fused kernels, so no ``cat`` exists.
+``TGCNCellFn``  : everything AFTER the aggregation (input: ``a3 = A_hat (X [Wz|Wr|Wh])``).
+``TGCNStepFn``  : the whole step including the aggregation, run as the fused aggregate-then-transform
+                  kernel (``kernels.gcn_agg_transform``: gather at width ``in_channels``, the
+                  [in, 3*out] weight applied on the matrix cores from LDS).
+
+Per snapshot the eager torch formulation costs ~100 launches (forward + backward); ``TGCNStepFn`` takes
+1 fused aggregation + 3 fused row-local kernels + 3 rocBLAS GEMMs forward, and 3 fused kernels +
+4 rocBLAS GEMMs + 1 aggregation backward.  The concatenated GEMM operands ([hz|H], [hr|H], [hh|H*R])
+are written in place by the fused kernels (no ``cat``).  Weight and bias gradients are not produced per
+step at all: they are registered with ``nn.deferred`` and computed once per backward pass, one split-K
+MFMA launch per parameter over all timesteps (``functional.set_deferred_weight_grads(False)`` computes
+them per step instead and returns them through autograd as usual).
 """
 from __future__ import annotations
 
 import torch
 
 from .... import kernels
+from ... import deferred
+from ... import functional as SF
 
 CLAMP = 1e6      # tgcn.py:22,30,38
 
 
+def _cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh):
+    N, C = H.shape
+    dev = H.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    CZ, CR, CH = new(N, 2 * C), new(N, 2 * C), new(N, 2 * C)
+    kernels.tgcn_cell_call("prep_fwd", (a3, b3, H, CZ, CR, CH), N, C, -CLAMP, CLAMP)
+    zl = torch.addmm(bz, CZ, Wz.t())
+    rl = torch.addmm(br, CR, Wr.t())
+    Z, R = new(N, C), new(N, C)
+    kernels.tgcn_cell_call("gates_fwd", (zl, rl, H, Z, R, CH), N, C)
+    hl = torch.addmm(bh, CH, Wh.t())
+    Ht, Hn = new(N, C), new(N, C)
+    kernels.tgcn_cell_call("update_fwd", (hl, Z, H, Ht, Hn), N, C)
+    return Hn, (CZ, CR, CH, Z, R, Ht)
+
+
+def _cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht):
+    """Returns da3, dH and the three (d_preactivation, operand) pairs of the gate Linears."""
+    N, C = H.shape
+    dev = H.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    dhl, dzl, dH = new(N, C), new(N, C), new(N, C)
+    kernels.tgcn_cell_call("update_bwd", (dHn, Z, H, Ht, dhl, dzl, dH), N, C)
+    dCH = torch.mm(dhl, Wh)                               # [N, 2C] = grad of [hh | H*R]
+    drl = new(N, C)
+    kernels.tgcn_cell_call("gates_bwd", (dCH, R, H, drl, dH), N, C)
+    dCZ = torch.mm(dzl, Wz)
+    dCR = torch.mm(drl, Wr)
+    da3 = new(N, 3 * C)
+    kernels.tgcn_cell_call("prep_bwd", (dCZ, dCR, dCH, a3, b3, da3, dH), N, C, -CLAMP, CLAMP)
+    return da3, dH, ((dzl, CZ), (drl, CR), (dhl, CH))
+
+
+def _linear_grads(pairs, params, defer: bool):
+    """Weight/bias gradients of the gate Linears: dW = dpre^T operand, db = colsum(dpre).
+    ``params`` = ((W, b), ...) leaf parameters.  Deferred: registered, returns Nones."""
+    out = []
+    for (dpre, operand), (W, b) in zip(pairs, params):
+        if defer and W.is_leaf and b.is_leaf:
+            deferred.current().add(("lin", id(W)), dpre, operand,
+                                   sink=lambda dW, W=W: deferred.add_to_grad(W, dW),
+                                   colsum_sink=lambda db, b=b: deferred.add_to_grad(b, db))
+            out += [None, None]
+        else:
+            dW, db = kernels.gemm_tn(dpre, operand, colsum=True)
+            out += [dW, db]
+    return out
+
+
 class TGCNCellFn(torch.autograd.Function):
+    """Hn = cell(a3, b3, H; gate Linears) -- the row-local part only."""
+
     @staticmethod
     def forward(ctx, a3, b3, H, Wz, bz, Wr, br, Wh, bh):
-        a3, H = a3.contiguous(), H.contiguous()
-        b3 = b3.contiguous()
-        N, C = H.shape
-        dev = H.device
-        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-        CZ, CR, CH = new(N, 2 * C), new(N, 2 * C), new(N, 2 * C)
-        kernels.tgcn_cell_call("prep_fwd", (a3, b3, H, CZ, CR, CH), N, C, -CLAMP, CLAMP)
-        zl = torch.addmm(bz, CZ, Wz.t())
-        rl = torch.addmm(br, CR, Wr.t())
-        Z, R = new(N, C), new(N, C)
-        kernels.tgcn_cell_call("gates_fwd", (zl, rl, H, Z, R, CH), N, C)
-        hl = torch.addmm(bh, CH, Wh.t())
-        Ht, Hn = new(N, C), new(N, C)
-        kernels.tgcn_cell_call("update_fwd", (hl, Z, H, Ht, Hn), N, C)
-        ctx.save_for_backward(a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht)
+        a3, b3, H = a3.contiguous(), b3.contiguous(), H.contiguous()
+        Hn, extra = _cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh)
+        ctx.save_for_backward(a3, b3, H, Wz, Wr, Wh, *extra)
+        ctx.params = ((Wz, bz), (Wr, br), (Wh, bh))
         return Hn
 
     @staticmethod
     def backward(ctx, dHn):
         a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht = ctx.saved_tensors
-        dHn = dHn.contiguous()
-        N, C = H.shape
-        dev = H.device
-        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-        dhl, dzl, dH = new(N, C), new(N, C), new(N, C)
-        kernels.tgcn_cell_call("update_bwd", (dHn, Z, H, Ht, dhl, dzl, dH), N, C)
-        dCH = torch.mm(dhl, Wh)                               # [N, 2C] = grad of [hh | H*R]
-        drl = new(N, C)
-        kernels.tgcn_cell_call("gates_bwd", (dCH, R, H, drl, dH), N, C)
-        dCZ = torch.mm(dzl, Wz)
-        dCR = torch.mm(drl, Wr)
-        da3 = new(N, 3 * C)
-        kernels.tgcn_cell_call("prep_bwd", (dCZ, dCR, dCH, a3, b3, da3, dH), N, C, -CLAMP, CLAMP)
-        # weight + bias gradients of the three gate Linears: dW = dpre^T [h|H], db = colsum(dpre)
-        dWz, dbz = kernels.gemm_tn(dzl, CZ, colsum=True)
-        dWr, dbr = kernels.gemm_tn(drl, CR, colsum=True)
-        dWh, dbh = kernels.gemm_tn(dhl, CH, colsum=True)
+        da3, dH, pairs = _cell_backward(dHn.contiguous(), a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht)
+        g = _linear_grads(pairs, ctx.params, SF.deferred_weight_grads())
         db3 = da3.sum(0) if ctx.needs_input_grad[1] else None
-        return da3, db3, dH, dWz, dbz, dWr, dbr, dWh, dbh
+        return (da3, db3, dH, g[0], g[1], g[2], g[3], g[4], g[5])
+
+
+class TGCNStepFn(torch.autograd.Function):
+    """Hn = TGCN(graph, x, H): aggregation (fused aggregate-then-transform) + cell, one node."""
+
+    @staticmethod
+    def forward(ctx, x, H, norm, ew, fwd_csr, bwd_csr, use_nid,
+                Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh):
+        x, H = x.contiguous(), H.contiguous()
+        Wcat = torch.cat([Wcz, Wcr, Wch], dim=1)
+        b3 = torch.cat([bcz, bcr, bch], dim=0)
+        a3, P = kernels.gcn_agg_transform(x, Wcat, norm, norm, fwd_csr, ew=ew, use_node_ids=use_nid)
+        Hn, extra = _cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh)
+        ctx.save_for_backward(a3, b3, H, Wz, Wr, Wh, *extra, P, Wcat, norm,
+                              ew if ew is not None else norm.new_empty(0))
+        ctx.has_ew = ew is not None
+        ctx.bwd_csr, ctx.use_nid = bwd_csr, use_nid
+        ctx.params = ((Wz, bz), (Wr, br), (Wh, bh))
+        ctx.conv_params = ((Wcz, Wcr, Wch), (bcz, bcr, bch))
+        return Hn
+
+    @staticmethod
+    def backward(ctx, dHn):
+        a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht, P, Wcat, norm, ew = ctx.saved_tensors
+        ew = ew if ctx.has_ew else None
+        defer = SF.deferred_weight_grads()
+        da3, dH, pairs = _cell_backward(dHn.contiguous(), a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht)
+        g = _linear_grads(pairs, ctx.params, defer)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            z = torch.mm(da3, Wcat.t())                               # d(A_hat x) = da3 Wcat^T      [N, in]
+            dx = kernels.gcn_agg(z, norm, norm, ctx.bwd_csr, ew=ew, use_node_ids=ctx.use_nid)
+        # GCN weights/biases: dWcat^T = da3^T P  ([3C, in]),  db3 = colsum(da3)
+        Ws, bs = ctx.conv_params
+        C = H.shape[1]
+
+        def sink_w(dWt, Ws=Ws):
+            for i, W in enumerate(Ws):
+                deferred.add_to_grad(W, dWt[i * C:(i + 1) * C].t())
+
+        def sink_b(db, bs=bs):
+            for i, b in enumerate(bs):
+                deferred.add_to_grad(b, db[i * C:(i + 1) * C])
+
+        if defer and all(t.is_leaf for t in (*Ws, *bs)):
+            deferred.current().add(("conv", id(Ws[0])), da3, P, sink=sink_w, colsum_sink=sink_b)
+            gw = [None] * 6
+        else:
+            dWt, db = kernels.gemm_tn(da3, P, colsum=True)
+            gw = [dWt[i * C:(i + 1) * C].t() for i in range(3)] + [db[i * C:(i + 1) * C] for i in range(3)]
+        return (dx, dH, None, None, None, None, None, *gw, *g)
 
 
 def usable(a3: torch.Tensor, H: torch.Tensor) -> bool:

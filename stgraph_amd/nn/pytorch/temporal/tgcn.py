@@ -93,12 +93,17 @@ class TGCN(torch.nn.Module):
         """One aggregation launch + ``cell.TGCNCellFn`` (fused row-local stages); same math as below."""
         convs = (self.conv_z, self.conv_r, self.conv_h)
         GCNConv.check_norm(g)
+        if self.fuse_transform and SF.agg_transform_usable(g, X, (self.in_channels, 3 * self.out_channels)):
+            # whole step as one autograd node: (A_hat X) W on the matrix cores (gather at width in_channels),
+            # fused row-local stages, weight gradients deferred to the end of the backward pass
+            return cell.TGCNStepFn.apply(
+                X, H, g.get_ndata("norm"), edge_weight, g.csr("fwd"), g.csr("bwd"), g.graph_type() == "csr",
+                convs[0].weight, convs[1].weight, convs[2].weight, convs[0].bias, convs[1].bias, convs[2].bias,
+                self.linear_z.weight, self.linear_z.bias, self.linear_r.weight, self.linear_r.bias,
+                self.linear_h.weight, self.linear_h.bias)
         W = torch.cat([c.weight for c in convs], dim=1)
         b3 = torch.cat([c.bias for c in convs], dim=0)
-        if self.fuse_transform and SF.agg_transform_usable(g, X, W):
-            a3 = SF.agg_transform(g, X, W, edge_weight)          # (A_hat X) W: gather at width in_channels
-        else:
-            a3 = self.conv_z.aggregate(g, SF.mm(X, W), edge_weight)
+        a3 = self.conv_z.aggregate(g, SF.mm(X, W), edge_weight)
         return cell.TGCNCellFn.apply(a3, b3, H, self.linear_z.weight, self.linear_z.bias,
                                      self.linear_r.weight, self.linear_r.bias,
                                      self.linear_h.weight, self.linear_h.bias)

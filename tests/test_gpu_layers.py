@@ -310,3 +310,40 @@ def test_captured_window_replays_the_eager_loop(cuda):
     torch.testing.assert_close(results[0][0], results[1][0], rtol=1e-5, atol=1e-7)
     for a, b in zip(results[0][1], results[1][1]):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_deferred_weight_grads_equal_per_step_grads(cuda):
+    """nn.deferred: one launch per parameter per backward pass == per-step gradients through autograd
+    (TGCN over a 5-step window with the fused step node, head Linears included)."""
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from tests.util import random_graph
+    n, e, feat, hid, B = 6000, 70000, 32, 64, 5
+    src, dst = random_graph(8, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    g.set_ndata("norm", temporal.in_degree_norm(g))
+    gen = torch.Generator(device=cuda).manual_seed(2)
+    ew = torch.rand(len(src), 1, device=cuda, generator=gen) + 0.5
+    targets = torch.randn(B, n, 1, device=cuda, generator=gen)
+    x0 = torch.randn(n, feat, device=cuda, generator=gen)
+    torch.manual_seed(4)
+    model = temporal.STGraphTGCN(feat, hid, 1).to(cuda)
+    grads = []
+    try:
+        for defer in (True, False):
+            SF.set_deferred_weight_grads(defer)
+            model.zero_grad()
+            cost, hidden, y = 0, None, x0
+            for t in range(B):
+                y_out, y, hidden = model(g, y, ew, hidden)
+                cost = cost + torch.mean((y_out - targets[t]) ** 2)
+            (cost / (B + 1)).backward()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+            assert all(p.grad is not None for p in model.parameters())
+    finally:
+        SF.set_deferred_weight_grads(True)
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        scale = max(1e-6, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, k
