@@ -202,6 +202,14 @@ int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t
 int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *colsum_A, int64_t K, int32_t M,
                            int32_t N, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Y[N,M] = X[N,K] * op(W) + bias (bias nullable): forward / input-gradient GEMM of the dense layers
+ * for N = number of vertices and small K, M.  op(W) = W [K,M] (trans_w = 0) or W^T with W [M,K]
+ * (trans_w = 1, i.e. torch's Linear weight layout).  64-row X tile + W in LDS, fp32 matrix cores.
+ * stg_rowgemm_supported(K, M) != 0 iff K % 4 == 0, M % 32 == 0 and the tiles fit 96 KiB of LDS. */
+int stg_rowgemm_supported(int32_t K, int32_t M);
+int stg_rowgemm_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K,
+                    int32_t M, int trans_w, void *stream);
+
 /* C = sum_{t < T} A_t^T B_t (and colsum_A = sum_t colsum(A_t), nullable) in ONE launch: A, B are HOST
  * arrays of T <= 32 device pointers, every A_t [K,M], B_t [K,N].  The pointers travel by value in
  * the kernel arguments, so the call is HIP-graph capturable.  Used to turn a BPTT window's weight

@@ -460,6 +460,63 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, colsum: bool = False):
     return (c, cs) if colsum else c
 
 
+_ROWGEMM = False
+
+
+def set_native_rowgemm(enabled: bool) -> None:
+    """True: skinny forward / input-gradient GEMMs run on stg_rowgemm_f32; False (default): torch (rocBLAS).
+    Measured on MI355X (tools/microbench_rowgemm.py, round 1): 0.5-1.3x rocBLAS depending on the shape, so
+    it is not the default yet; the kernel restages W per 64-row tile and does not overlap staging with MFMA."""
+    global _ROWGEMM
+    _ROWGEMM = bool(enabled)
+
+
+def rowgemm_usable(x: torch.Tensor, K: int, M: int) -> bool:
+    return (_ROWGEMM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 4096
+            and bool(_C.lib.stg_rowgemm_supported(int(K), int(M))))
+
+
+def rowgemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, trans_w: bool = False) -> torch.Tensor:
+    """``x @ w`` (``trans_w=False``, w [K,M]) or ``x @ w.T`` (``trans_w=True``, w [M,K]) ``+ bias``."""
+    x = _f32(x, "x")
+    dev = x.device
+    w = _f32(w, "w", dev)
+    N, K = x.shape
+    M = int(w.shape[0] if trans_w else w.shape[1])
+    if int(w.shape[1] if trans_w else w.shape[0]) != K:
+        raise ValueError(f"rowgemm: x {tuple(x.shape)} and w {tuple(w.shape)} (trans_w={trans_w}) do not match")
+    if bias is not None:
+        bias = _f32(bias, "bias", dev)
+        if bias.numel() != M:
+            raise ValueError("rowgemm: bias length != output width")
+    y = torch.empty(N, M, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("rowgemm", 4 * N * (K + M) + 4 * K * M, 2 * N * K * M):
+        _C.check(_C.lib.stg_rowgemm_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), N, K, M, int(bool(trans_w)),
+                                        _stream_ptr(dev)))
+    return y
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None) -> torch.Tensor:
+    """``x @ w.T + b`` (torch Linear layout) on the native kernel when the shape is covered."""
+    if rowgemm_usable(x, w.shape[1], w.shape[0]):
+        return rowgemm(x, w, b, trans_w=True)
+    return torch.addmm(b, x, w.t()) if b is not None else torch.mm(x, w.t())
+
+
+def matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``x @ w`` (w [K,M]) on the native kernel when the shape is covered."""
+    if rowgemm_usable(x, w.shape[0], w.shape[1]):
+        return rowgemm(x, w, None, trans_w=False)
+    return torch.mm(x, w)
+
+
+def matmul_t(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``x @ w.T`` (w [M,K])."""
+    if rowgemm_usable(x, w.shape[1], w.shape[0]):
+        return rowgemm(x, w, None, trans_w=True)
+    return torch.mm(x, w.t())
+
+
 MAX_GEMM_SEGMENTS = 32
 
 

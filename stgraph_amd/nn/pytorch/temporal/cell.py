@@ -34,11 +34,11 @@ def _cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh):
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
     CZ, CR, CH = new(N, 2 * C), new(N, 2 * C), new(N, 2 * C)
     kernels.tgcn_cell_call("prep_fwd", (a3, b3, H, CZ, CR, CH), N, C, -CLAMP, CLAMP)
-    zl = torch.addmm(bz, CZ, Wz.t())
-    rl = torch.addmm(br, CR, Wr.t())
+    zl = kernels.linear_fwd(CZ, Wz, bz)
+    rl = kernels.linear_fwd(CR, Wr, br)
     Z, R = new(N, C), new(N, C)
     kernels.tgcn_cell_call("gates_fwd", (zl, rl, H, Z, R, CH), N, C)
-    hl = torch.addmm(bh, CH, Wh.t())
+    hl = kernels.linear_fwd(CH, Wh, bh)
     Ht, Hn = new(N, C), new(N, C)
     kernels.tgcn_cell_call("update_fwd", (hl, Z, H, Ht, Hn), N, C)
     return Hn, (CZ, CR, CH, Z, R, Ht)
@@ -51,11 +51,11 @@ def _cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht):
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
     dhl, dzl, dH = new(N, C), new(N, C), new(N, C)
     kernels.tgcn_cell_call("update_bwd", (dHn, Z, H, Ht, dhl, dzl, dH), N, C)
-    dCH = torch.mm(dhl, Wh)                               # [N, 2C] = grad of [hh | H*R]
+    dCH = kernels.matmul(dhl, Wh)                         # [N, 2C] = grad of [hh | H*R]
     drl = new(N, C)
     kernels.tgcn_cell_call("gates_bwd", (dCH, R, H, drl, dH), N, C)
-    dCZ = torch.mm(dzl, Wz)
-    dCR = torch.mm(drl, Wr)
+    dCZ = kernels.matmul(dzl, Wz)
+    dCR = kernels.matmul(drl, Wr)
     da3 = new(N, 3 * C)
     kernels.tgcn_cell_call("prep_bwd", (dCZ, dCR, dCH, a3, b3, da3, dH), N, C, -CLAMP, CLAMP)
     return da3, dH, ((dzl, CZ), (drl, CR), (dhl, CH))
@@ -125,7 +125,7 @@ class TGCNStepFn(torch.autograd.Function):
         g = _linear_grads(pairs, ctx.params, defer)
         dx = None
         if ctx.needs_input_grad[0]:
-            z = torch.mm(da3, Wcat.t())                               # d(A_hat x) = da3 Wcat^T      [N, in]
+            z = kernels.matmul_t(da3, Wcat)                           # d(A_hat x) = da3 Wcat^T      [N, in]
             dx = kernels.gcn_agg(z, norm, norm, ctx.bwd_csr, ew=ew, use_node_ids=ctx.use_nid)
         # GCN weights/biases: dWcat^T = da3^T P  ([3C, in]),  db3 = colsum(da3)
         Ws, bs = ctx.conv_params

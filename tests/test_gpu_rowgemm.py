@@ -1,0 +1,40 @@
+"""stg_rowgemm_f32 (64-row tile + W in LDS, fp32 MFMA) against an fp64 reference."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,K,M", [(1, 4, 32), (63, 8, 32), (64, 64, 128), (65, 128, 64), (5000, 192, 32),
+                                   (50_000, 128, 64), (50_000, 64, 128), (20_001, 32, 192), (4097, 100, 96)])
+@pytest.mark.parametrize("trans_w,use_bias", [(False, False), (True, True), (True, False)])
+def test_matches_reference(cuda, N, K, M, trans_w, use_bias):
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(N + K + M)
+    x = torch.randn(N, K, device=cuda, generator=gen)
+    w = torch.randn((M, K) if trans_w else (K, M), device=cuda, generator=gen)
+    b = torch.randn(M, device=cuda, generator=gen) if use_bias else None
+    got = kernels.rowgemm(x, w, b, trans_w=trans_w)
+    wd = w.double().t() if trans_w else w.double()
+    want = x.double() @ wd + (b.double() if use_bias else 0)
+    scale = x.double().abs() @ wd.abs() + 1
+    assert ((got.double() - want).abs() <= 2e-6 * scale).all()
+
+
+def test_asymmetric_integer_data_exact(cuda):
+    from stgraph_amd import kernels
+    N, K, M = 300, 36, 64
+    x = (torch.arange(N * K, device=cuda) % 7 - 3).float().view(N, K)
+    w = (torch.arange(K * M, device=cuda) % 5 - 2).float().view(K, M)
+    assert torch.equal(kernels.rowgemm(x, w), (x.double() @ w.double()).float())
+    wt = (torch.arange(K * M, device=cuda) % 11 - 5).float().view(M, K)
+    assert torch.equal(kernels.rowgemm(x, wt, trans_w=True), (x.double() @ wt.double().t()).float())
+
+
+def test_unsupported_shapes(cuda):
+    from stgraph_amd import _C, kernels
+    assert not _C.lib.stg_rowgemm_supported(30, 64) and not _C.lib.stg_rowgemm_supported(64, 48)
+    assert not _C.lib.stg_rowgemm_supported(256, 256)
+    x = torch.zeros(10, 30, device=cuda)
+    with pytest.raises(_C.StgError):
+        kernels.rowgemm(x, torch.zeros(30, 64, device=cuda))
