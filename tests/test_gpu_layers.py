@@ -284,7 +284,8 @@ def test_captured_window_replays_the_eager_loop(cuda):
     from stgraph_amd import temporal
     from stgraph_amd.graph import StaticGraph
     from tests.util import random_graph
-    n, e, feat, hid, T, B = 3000, 30000, 8, 16, 12, 4
+    # n >= 4096 and feat 16 -> 48: the native path (fused step node, deferred weight gradients) is what gets captured
+    n, e, feat, hid, T, B = 5000, 50000, 16, 16, 12, 4
     src, dst = random_graph(5, n, e)
     e = len(src)
     results = []
