@@ -309,7 +309,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--edges", type=int, default=16_000_000)
     ap.add_argument("--feat", type=int, default=128)
-    ap.add_argument("--tgcn-epochs", type=int, default=2)
+    ap.add_argument("--tgcn-epochs", type=int, default=4)
     ap.add_argument("--tgcn-timestamps", type=int, default=1000)
     ap.add_argument("--no-cora", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
     }
 }
 
-// dst[i] = table[idx[i]]  (or table[idx[perm[i]]] when perm != NULL)
+// dst[i] = table[idx[i]]
 __global__ void edge_gather_kernel(float *__restrict__ dst, const float *__restrict__ table,
                                    const int *__restrict__ idx, int64_t n)
 {

@@ -26,11 +26,6 @@ struct Tuning {
 };
 Tuning &tuning();
 
-template <int VEC> struct Vec;
-template <> struct Vec<1> { using type = float; };
-template <> struct Vec<2> { using type = float2; };
-template <> struct Vec<4> { using type = float4; };
-
 template <int VEC>
 __device__ __forceinline__ void vec_load(float (&dst)[VEC], const float *p)
 {

@@ -8,7 +8,7 @@ kernel can take the whole node down), and raises instead of falling back.
 from __future__ import annotations
 
 import ctypes
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 import torch
@@ -165,7 +165,6 @@ class GraphCSR:
     in_degrees: torch.Tensor       # int32 [N]
     out_degrees: torch.Tensor      # int32 [N]
     perm_fwd: torch.Tensor         # int64 [E]: caller position of the edge that became eid j
-    extra: dict = field(default_factory=dict)
 
     @property
     def num_edges(self) -> int:
