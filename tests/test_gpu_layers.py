@@ -348,3 +348,81 @@ def test_deferred_weight_grads_equal_per_step_grads(cuda):
         a, b = grads[0][k], grads[1][k]
         scale = max(1e-6, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, k
+
+
+def test_strided_and_missing_gradients_are_handled(cuda):
+    """Reference defect D6: the reference reads grad tensors through raw data_ptr, so an expanded
+    (stride-0) gradient such as the one ``out.sum().backward()`` produces is read as garbage.  Here it
+    is made contiguous; result must equal the dense formula."""
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn.pytorch.static.gcn_conv import GCNConv
+    from tests.util import random_graph
+    stgraph_amd.set_reference_compat(False)                  # F = 12: all columns (D1 would stop at 8)
+    n, e, F = 500, 4000, 12
+    src, dst = random_graph(31, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    norm = torch.rand(n, 1, device=cuda) + 0.5
+    g.set_ndata("norm", norm)
+    conv = GCNConv(F, F, bias=False).to(cuda)
+    with torch.no_grad():
+        conv.weight.copy_(torch.eye(F))
+    x = torch.randn(n, F, device=cuda, requires_grad=True)
+    conv(g, x).sum().backward()                               # grad_out is an expanded scalar (stride 0)
+    want = kernels.gcn_agg(torch.ones(n, F, device=cuda), norm, norm, g.csr("bwd"))
+    torch.testing.assert_close(x.grad, want, rtol=1e-6, atol=1e-6)
+
+
+def test_gcnconv_with_duplicate_edges_and_self_loops(cuda):
+    """Multigraph input: the CSR keeps duplicates and the layer sums over all of them."""
+    from oracle import stg_oracle as orc
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn.pytorch.static.gcn_conv import GCNConv
+    stgraph_amd.set_reference_compat(False)
+    src = np.array([0, 0, 1, 2, 2, 2, 3, 3], np.int32)
+    dst = np.array([1, 1, 1, 2, 0, 0, 3, 0], np.int32)
+    g = StaticGraph(np.stack([src, dst], 1), None, 4, device=cuda, sort_inplace=False)
+    assert g.get_num_edges() == 6 and g.csr("fwd").num_edges == 8
+    norm_np = np.array([[0.5], [1.0], [2.0], [0.25]], np.float32)
+    g.set_ndata("norm", torch.from_numpy(norm_np).to(cuda))
+    conv = GCNConv(5, 5, bias=False).to(cuda)
+    with torch.no_grad():
+        conv.weight.copy_(torch.eye(5))
+    x_np = np.arange(20, dtype=np.float32).reshape(4, 5) / 7
+    out = conv(g, torch.from_numpy(x_np).to(cuda)).detach().cpu().numpy()
+    og = orc.build_graph(src, dst, 4)
+    assert np.array_equal(out, orc.gcn_agg(x_np, norm_np, norm_np, og.fwd))
+
+
+def test_gatconv_on_naive_graph_snapshots(cuda):
+    """GAT through the per-snapshot CSR path ('csr' type, node_ids order, timestamp stack)."""
+    from oracle import stg_oracle as orc
+    from stgraph_amd.graph import NaiveGraph
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    d = golden("naive_tgcn.npz")
+    n, T = int(d["num_nodes"]), int(d["T"])
+    snaps = [_edges(d, f"t{t}_") for t in range(T)]
+    G = NaiveGraph(snaps, n, device=cuda)
+    stgraph_amd.set_reference_compat(False)
+    torch.manual_seed(0)
+    conv = GATConv(6, 8, 2).to(cuda)
+    xs = [torch.randn(n, 6, device=cuda, requires_grad=True) for _ in range(T)]
+    G.reset_graph()
+    total = 0
+    outs = []
+    for t in range(T):
+        G.get_graph(t)
+        o = conv(G, xs[t])
+        outs.append(o)
+        total = total + (o * (t + 1)).sum()
+    total.backward()
+    assert G.current_timestamp == 0
+    for t in range(T):                                       # forward of every snapshot == oracle on that snapshot
+        og = orc.build_graph(d[f"t{t}_src"], d[f"t{t}_dst"], n)
+        feat = conv.fc(xs[t]).view(-1, 2, 8)
+        el = (feat * conv.attn_l).sum(-1).unsqueeze(-1)
+        er = (feat * conv.attn_r).sum(-1).unsqueeze(-1)
+        A0, S0 = orc.gat_k0(el.detach().cpu().numpy(), er.detach().cpu().numpy(), og.fwd, og.num_edges, use_node_ids=True)
+        o0 = orc.gat_k1(A0, S0, feat.detach().cpu().numpy(), og.fwd, use_node_ids=True)
+        np.testing.assert_allclose(outs[t].detach().cpu().numpy(), o0, rtol=1e-5, atol=1e-6)
+        assert xs[t].grad is not None and bool(torch.isfinite(xs[t].grad).all())

@@ -151,3 +151,38 @@ def test_naive_graph_snapshots_and_timestamp_protocol(resident):
     assert set(upd["1"]["add"]) == set(snaps[1]) - set(snaps[0])
     assert set(upd["1"]["delete"]) == set(snaps[0]) - set(snaps[1])
     assert upd["2"]["add"] == sorted(upd["2"]["add"], key=lambda x: (x[1], x[0]))
+
+
+def test_host_builder_property_based():
+    """hypothesis: arbitrary multigraphs (duplicates, self loops, isolated vertices, any order) --
+    the host builder equals the oracle's restatement of the reference pipeline, and the CSR
+    invariants the kernels rely on hold."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from stgraph_amd import kernels
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 40).flatmap(lambda n: st.tuples(
+        st.just(n), st.lists(st.tuples(st.integers(0, n - 1), st.integers(0, n - 1)), max_size=200))))
+    def check(case):
+        n, edges = case
+        src = np.array([a for a, _ in edges], np.int32)
+        dst = np.array([b for _, b in edges], np.int32)
+        g = kernels.build_graph_csr(src, dst, n, "cpu")
+        og = orc.build_graph(src, dst, n)
+        _eq(g.fwd, og.fwd)
+        _eq(g.bwd, og.bwd)
+        e = len(edges)
+        ro = g.fwd.row_offset.numpy()
+        assert ro[0] == 0 and ro[-1] == e and np.all(np.diff(ro) >= 0)
+        assert g.fwd.eids.numpy().tolist() == list(range(e))                  # forward eids are the identity
+        assert sorted(g.bwd.eids.numpy().tolist()) == list(range(e))          # backward eids: a permutation
+        # every backward entry points at the forward position of the same (src, dst) pair
+        frows = np.repeat(np.arange(n), np.diff(ro))
+        brows = np.repeat(np.arange(n), np.diff(g.bwd.row_offset.numpy()))
+        be = g.bwd.eids.numpy()
+        assert np.array_equal(g.fwd.column_indices.numpy()[be], brows)
+        assert np.array_equal(frows[be], g.bwd.column_indices.numpy())
+
+    check()
