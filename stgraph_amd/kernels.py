@@ -8,6 +8,7 @@ kernel can take the whole node down), and raises instead of falling back.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -459,7 +460,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, colsum: bool = False):
     return (c, cs) if colsum else c
 
 
-_ROWGEMM = False
+_ROWGEMM = os.environ.get("STGRAPH_AMD_ROWGEMM", "0") == "1"
 
 
 def set_native_rowgemm(enabled: bool) -> None:
