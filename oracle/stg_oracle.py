@@ -42,8 +42,8 @@ def _lib(omp: bool = False) -> ctypes.CDLL:
     if omp not in _LIBS:
         name = "libstg_oracle_omp.so" if omp else "libstg_oracle.so"
         path = os.path.join(_HERE, name)
-        src = os.path.join(_HERE, "stg_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        srcs = [os.path.join(_HERE, f) for f in ("stg_oracle.c", "stg_pcsr_oracle.c")]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
             build()
         lib = ctypes.CDLL(path)
         lib.orc_csr_ctor.restype = ctypes.c_int

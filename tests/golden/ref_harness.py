@@ -18,11 +18,15 @@ What is substituted, and why:
      termcolor, cuda-python, pynvrtc) and for the pcsr/gpma extension modules
      that stgraph/graph/__init__.py imports eagerly.  None of them computes
      anything on this path.
-  2. ``stgraph.graph.static.csr`` (csr.cu needs cuda_runtime/thrust/cub/nvcc:
-     unbuildable here).  Its ``CSR`` class is backed by oracle.orc_csr_ctor and
-     hands out HOST addresses.  Consequently the CSR arrays inside the fixtures
-     are inputs produced by the oracle's restatement of csr.cu:68-157, while
-     the edge ordering / eid assignment feeding it is the reference's own.
+  2. ``stgraph.graph.static.csr`` / ``stgraph.graph.dynamic.pcsr.pcsr`` (csr.cu and
+     pcsr.cu need cuda_runtime/thrust/cub/nvcc: unbuildable here, and the shipped
+     csr.so / pcsr.so are CPython-3.8 modules this interpreter refuses to import).
+     The ``CSR`` / ``PCSR`` classes installed here call the reference's OWN compiled
+     C++ classes inside those .so files through oracle/_ref/libref_shim.so
+     (oracle/ref_shim.cpp) and hand out HOST addresses instead of device ones; only
+     the pybind glue is replaced.  (Without the shim -- it needs /root/reference --
+     ``CSR`` falls back to oracle.orc_csr_ctor, which tests/test_oracle_ref_shim.py
+     shows to be identical.)
   3. the nvcc -> PTX -> cuModuleLoad step (code_gen/compiler.py:36-44): the
      CUDA source the reference EMITS is compiled verbatim with g++ behind a
      10-line header that serialises the SIMT launch (blockIdx/threadIdx loops,
@@ -50,6 +54,7 @@ REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__fi
 if REPO_ROOT not in sys.path:
     sys.path.insert(0, REPO_ROOT)
 
+from oracle import ref_shim  # noqa: E402
 from oracle import stg_oracle as orc  # noqa: E402
 
 _WORKDIR = tempfile.mkdtemp(prefix="stg_ref_harness_")
@@ -92,12 +97,17 @@ class _CudaDriverStub(types.ModuleType):
 
 
 class _RefCSR:
-    """Stand-in for the pybind class of csr.cu:181-201, backed by the oracle."""
+    """The pybind class of csr.cu:181-201: the reference's compiled ``CSR::CSR`` (csr.so) when the shim
+    is available, else the oracle's restatement."""
 
     def __init__(self, edge_list, edge_weight, num_nodes, is_edge_reverse=False):
         arr = np.asarray(edge_list, dtype=np.int64).reshape(-1, 3)
-        c = orc.csr_ctor(arr[:, 0], arr[:, 1], arr[:, 2],
-                         np.asarray(edge_weight, dtype=np.float32), num_nodes, is_edge_reverse)
+        w = np.asarray(edge_weight, dtype=np.float32)
+        if ref_shim.available():
+            c = types.SimpleNamespace(**ref_shim.csr_ctor(arr[:, 0], arr[:, 1], arr[:, 2], w, num_nodes,
+                                                          is_edge_reverse))
+        else:
+            c = orc.csr_ctor(arr[:, 0], arr[:, 1], arr[:, 2], w, num_nodes, is_edge_reverse)
         self._c = c                      # keeps the host arrays alive
         self.row_offset_ptr = c.row_offset.ctypes.data
         self.column_indices_ptr = c.column_indices.ctypes.data
@@ -106,6 +116,63 @@ class _RefCSR:
         self.out_degrees = c.out_degrees.tolist()
         self.in_degrees = c.in_degrees.tolist()
         self.weighted_out_degrees = c.weighted_out_degrees.tolist()
+
+
+class _RefPCSR:
+    """The pybind class of pcsr.cu:916-939 on top of the reference's compiled ``PCSR`` (pcsr.so).
+    Like the original, an object owns ONE set of output arrays ("device" arrays, here host memory)
+    that every build overwrites and that copies share (the copy constructor copies the pointers)."""
+
+    BUILD_LOG: list = []                 # (kind, arrays) of every build, for the fixture generator
+
+    def __init__(self, init_n, max_edge_count, _p=None, _dev=None):
+        self._p = _p if _p is not None else ref_shim.RefPCSR(init_n, max_edge_count)
+        self._dev = _dev if _dev is not None else [np.zeros(init_n + 1, np.int32), np.zeros(max_edge_count, np.int32),
+                                                   np.zeros(max_edge_count, np.int32), np.zeros(init_n, np.int32)]
+
+    def __deepcopy__(self, memo):
+        return _RefPCSR(self._p.n, self._p.max_edges, self._p.copy(), self._dev)
+
+    __copy__ = lambda self: self.__deepcopy__({})  # noqa: E731
+
+    @property
+    def in_degrees(self):
+        return self._p.degrees()[0].tolist()
+
+    @property
+    def out_degrees(self):
+        return self._p.degrees()[1].tolist()
+
+    @property
+    def edge_count(self):
+        return self._p.edge_count
+
+    def get_n(self):
+        return self._p.n
+
+    def edge_update_list(self, edge_list, is_delete=False, is_reverse_edge=False):
+        self._p.edge_update_list(edge_list, is_delete, is_reverse_edge)
+
+    def label_edges(self):
+        self._p.label_edges()
+
+    def get_edges(self):
+        return [tuple(map(int, r)) for r in self._p.get_edges()]
+
+    def _publish(self, kind, out):
+        for dst, k in zip(self._dev, ("row_offset", "column_indices", "eids", "node_ids")):
+            dst[: len(out[k])] = out[k].astype(np.int32)
+        _RefPCSR.BUILD_LOG.append((kind, {k: v.copy() for k, v in out.items()}))
+        return 0.0
+
+    def build_csr(self):
+        return self._publish("fwd", self._p.build_csr())
+
+    def build_reverse_csr(self):
+        return self._publish("bwd", self._p.build_reverse_csr())
+
+    def get_csr_ptrs(self):
+        return tuple(a.ctypes.data for a in self._dev)
 
 
 def _get_array(ptr, size):
@@ -143,7 +210,7 @@ def install_stubs() -> None:
 
     sys.path.insert(0, REFERENCE_ROOT)
     _module("stgraph.graph.static.csr", CSR=_RefCSR, get_array=_get_array)
-    _module("stgraph.graph.dynamic.pcsr.pcsr", PCSR=object)
+    _module("stgraph.graph.dynamic.pcsr.pcsr", PCSR=_RefPCSR if ref_shim.available() else object)
     names = ["GPMA", "build_backward_csr", "edge_update_t", "free_backward_csr", "get_csr_ptrs",
              "get_in_degrees", "get_out_degrees", "init_gpma", "init_graph_updates", "label_edges"]
     _module("stgraph.graph.dynamic.gpma.gpma", **{n: object for n in names})

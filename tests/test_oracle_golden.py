@@ -15,8 +15,13 @@ def test_csr_golden(tag):
     n = int(d["num_nodes"])
     g = orc.build_graph(d["src"], d["dst"], n, d["weights_by_eid"])
     for side, c in (("fwd", g.fwd), ("bwd", g.bwd)):
-        for k in CSR_KEYS + ("node_ids",):
+        for k in CSR_KEYS:
             assert np.array_equal(getattr(c, k), d[f"{side}_{k}"]), (side, k)
+        # node_ids come from the reference's compiled std::sort (tie order unspecified): the same
+        # degree sequence, and a permutation of the vertices
+        deg, ref_nid = np.diff(c.row_offset), d[f"{side}_node_ids"]
+        assert np.array_equal(deg[c.node_ids], deg[ref_nid]) and np.all(np.diff(deg[ref_nid]) <= 0)
+        assert sorted(c.node_ids.tolist()) == sorted(ref_nid.tolist()) == list(range(n))
     assert np.array_equal(g.in_degrees(), d["in_degrees"])
     assert np.array_equal(g.out_degrees(), d["out_degrees"])
     assert np.array_equal(g.fwd.weighted_out_degrees.astype(np.int32), d["weighted_in_degrees"])
