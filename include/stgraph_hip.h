@@ -90,6 +90,51 @@ int stg_graph_build_device(const int32_t *src, const int32_t *dst, int64_t E, in
                            int32_t *status, void *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* ------------------------------------------------------- dynamic edge store (PCSR)
+ * Replaces the reference's PCSR class: graph/dynamic/pcsr/pcsr.cu:273-939
+ * (PCSR::edge_update_list :759-779, label_edges :745-757, build_csr :829-879,
+ * build_reverse_csr :781-827, move_pinned_to_gpu :881-886), as driven by
+ * graph/dynamic/pcsr/pcsr_graph.py:46-166.
+ *
+ * State = the current edge SET as two dense, ascending arrays of packed keys
+ *   keys_fwd[i] = (uint64)dst << 32 | src        keys_bwd[i] = (uint64)src << 32 | dst
+ * (the PMA's "source" is the graph's dst: every call site passes is_reverse_edge=True).
+ *
+ * update: keys_out = (keys_in \ del) U add for both orientations, out of place
+ *   (E_out = E + n_add - n_del entries each).  Contract, as for the reference's
+ *   own update streams (dynamic_graph.py:56-79): added edges are absent, deleted
+ *   edges are present, ids < N, no duplicates inside a batch.  *status [dev for
+ *   _device / host for _host] = 0, or a bit set: 1 vertex id out of range, 2 added
+ *   edge already present, 4 deleted edge absent, 8 edge both added and deleted;
+ *   the outputs are unspecified then.  Batches may arrive in any order.
+ * emit: the CSR the reference's build_csr (reverse = 0: rows = dst) or
+ *   build_reverse_csr (reverse = 1: rows = src) would have produced: columns of a
+ *   row in DESCENDING order (the PMA row is emitted back to front), eids1 = the
+ *   1-based labels of label_edges (1 + rank in (dst, src) order; what
+ *   tpl_fa_pcsr.jinja:32-34 subtracts 1 from), eids0 = eids1 - 1 (what the
+ *   stg_gcn_agg / stg_gat_* entry points take); either may be NULL.  node_ids =
+ *   rows by non-increasing length (ties: ascending id); degrees = row lengths.
+ * All arrays [dev] for *_device, [host] for *_host; no call synchronises.
+ */
+size_t stg_edgeset_update_workspace_bytes(int64_t n_add, int64_t n_del);
+int stg_edgeset_update_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E,
+                              const int32_t *add_src, const int32_t *add_dst, int64_t n_add,
+                              const int32_t *del_src, const int32_t *del_dst, int64_t n_del, int32_t N,
+                              uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *status,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int stg_edgeset_update_host(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E,
+                            const int32_t *add_src, const int32_t *add_dst, int64_t n_add,
+                            const int32_t *del_src, const int32_t *del_dst, int64_t n_del, int32_t N,
+                            uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *status);
+size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N);
+int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
+                                int reverse, int32_t *row_offset, int32_t *column_indices,
+                                int32_t *eids1, int32_t *eids0, int32_t *node_ids, int32_t *degrees,
+                                void *workspace, size_t workspace_bytes, void *stream);
+int stg_edgeset_emit_csr_host(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
+                              int reverse, int32_t *row_offset, int32_t *column_indices,
+                              int32_t *eids1, int32_t *eids0, int32_t *node_ids, int32_t *degrees);
+
 /* ------------------------------------------------------- fused GCN aggregation
  * Replaces the compiler-emitted FA kernels K0/K1 of GCNConv (tracer
  * nn/pytorch/static/gcn_conv.py:162-182; template

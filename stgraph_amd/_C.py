@@ -25,6 +25,8 @@ EXPORTED_SYMBOLS = (
     "stg_abi_version", "stg_last_error_string", "stg_set_tuning",
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
+    "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host",
+    "stg_edgeset_emit_csr_workspace_bytes", "stg_edgeset_emit_csr_device", "stg_edgeset_emit_csr_host",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_rowgemm_supported", "stg_rowgemm_f32",
@@ -62,6 +64,18 @@ def _load() -> ctypes.CDLL:
     lib.stg_graph_build_device_workspace_bytes.argtypes = [i64, i32]
     lib.stg_graph_build_device.restype = ctypes.c_int
     lib.stg_graph_build_device.argtypes = [vp, vp, i64, i32] + [vp] * 11 + [vp, vp, ctypes.c_size_t, vp]
+    lib.stg_edgeset_update_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_edgeset_update_workspace_bytes.argtypes = [i64, i64]
+    lib.stg_edgeset_update_device.restype = ctypes.c_int
+    lib.stg_edgeset_update_device.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.stg_edgeset_update_host.restype = ctypes.c_int
+    lib.stg_edgeset_update_host.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp]
+    lib.stg_edgeset_emit_csr_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_edgeset_emit_csr_workspace_bytes.argtypes = [i32]
+    lib.stg_edgeset_emit_csr_device.restype = ctypes.c_int
+    lib.stg_edgeset_emit_csr_device.argtypes = [vp, vp, i64, i32, ctypes.c_int] + [vp] * 6 + [vp, ctypes.c_size_t, vp]
+    lib.stg_edgeset_emit_csr_host.restype = ctypes.c_int
+    lib.stg_edgeset_emit_csr_host.argtypes = [vp, vp, i64, i32, ctypes.c_int] + [vp] * 6
     lib.stg_gcn_agg.restype = ctypes.c_int
     lib.stg_gcn_agg.argtypes = [vp] * 9 + [i32, i32, i32, vp]
     lib.stg_gcn_agg_edge.restype = ctypes.c_int

@@ -63,7 +63,7 @@ class GcnPlan:
         F = int(x[0].numel()) if x.shape[0] else 1
         ew = e_feats[self.ew] if self.ew else None
         out = kernels.gcn_agg(x, n_feats[self.norm_dst], n_feats[self.norm_src], graph.csr("fwd"),
-                              ew=ew, use_node_ids=(graph.graph_type() == "csr"),
+                              ew=ew, use_node_ids=(kernels.rows_by_node_ids(graph.graph_type())),
                               f_active=kernels.active_columns(F))
         saved = {"norm_src": n_feats[self.norm_src], "norm_dst": n_feats[self.norm_dst], "ew": ew}
         return (out,), saved
@@ -73,7 +73,7 @@ class GcnPlan:
         F = int(g[0].numel()) if g.shape[0] else 1
         # acc += grad[dst]*norm_cen[dst]; grad_h[src] = acc*norm_inb[src]
         gx = kernels.gcn_agg(g, saved["norm_src"], saved["norm_dst"], graph.csr("bwd"), ew=saved["ew"],
-                             use_node_ids=(graph.graph_type() == "csr"),
+                             use_node_ids=(kernels.rows_by_node_ids(graph.graph_type())),
                              f_active=kernels.active_columns(F))
         return {("n", self.x): gx}
 
@@ -97,13 +97,13 @@ class GatPlan:
 
     def forward(self, graph, n_feats, e_feats):
         el, er, feat = n_feats[self.el], n_feats[self.er], n_feats[self.feat]
-        use_nid = graph.graph_type() == "csr"
+        use_nid = kernels.rows_by_node_ids(graph.graph_type())
         out, A, S = kernels.gat_fwd(el, er, feat, graph.csr("fwd"), self.slope, use_nid)
         return (out,), {"A": A, "S": S, "out": out, "el": el, "er": er, "feat": feat}
 
     def backward(self, graph, saved, grads):
         (g,) = grads
-        use_nid = graph.graph_type() == "csr"
+        use_nid = kernels.rows_by_node_ids(graph.graph_type())
         gf, gel, ger = kernels.gat_bwd(saved["A"], saved["S"], saved["out"], g, saved["el"], saved["er"],
                                        saved["feat"], graph.csr("fwd"), graph.csr("bwd"), self.slope, use_nid)
         # el is read at the neighbour (grad_el), er at the centre (grad_er); when both keys name the

@@ -15,6 +15,7 @@
 //   node_ids = rows by non-increasing degree (csr.cu:142-154; ties are
 //              unspecified there, ascending id here).
 #include "stg_common.hpp"
+#include "csr_kernels.hpp"
 
 #include <cstring>   // rocprim/iterator/texture_cache_iterator.hpp calls memset without including it
 
@@ -51,13 +52,6 @@ void radix_sort_pairs_host(std::vector<uint64_t> &keys, std::vector<int64_t> &va
         keys.swap(k2);
         vals.swap(v2);
     }
-}
-
-int key_bits_for(int32_t N)
-{
-    int b = 1;
-    while (b < 31 && (int64_t(1) << b) < int64_t(N)) ++b;
-    return b;
 }
 
 // ------------------------------------------------------------------ device kernels
@@ -100,33 +94,6 @@ __global__ void split_bwd(const uint64_t *__restrict__ bkeys, int64_t E, int bit
         bwd_col[j] = (int)(bkeys[j] & mask);
 }
 
-// row_offset[v] = first position whose row (key >> bits) is >= v   (v in [0, N])
-__global__ void row_offsets_by_search(const uint64_t *__restrict__ keys, int64_t E, int bits, int N,
-                                      int *__restrict__ row_offset)
-{
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v > N) return;
-    int64_t lo = 0, hi = E;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)(keys[mid] >> bits) < (int64_t)v) lo = mid + 1;
-        else hi = mid;
-    }
-    row_offset[v] = (int)lo;
-}
-
-__global__ void degrees_and_iota(const int *__restrict__ row_offset, int N, int *__restrict__ deg,
-                                 unsigned *__restrict__ sort_key, int *__restrict__ iota)
-{
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    const int d = row_offset[v + 1] - row_offset[v];
-    deg[v] = d;
-    sort_key[v] = (unsigned)d;
-    iota[v] = v;
-}
-
-inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
 
 struct DeviceLayout {
     size_t keys_a, keys_b, pos_b, vals_a, vals_b, deg_key_a, deg_key_b, iota, deg_tmp, sort_tmp, total;

@@ -1,0 +1,375 @@
+// Dynamic edge store -- the MI355X counterpart of the reference's PCSR class
+// (graph/dynamic/pcsr/pcsr.cu:273-939; driven by graph/dynamic/pcsr/pcsr_graph.py:46-166).
+//
+// What the reference does per timestamp: insert / delete the update lists one edge at a time into a
+// host packed-memory array (O(log^2) amortised each, pointer chasing), relabel every slot
+// (label_edges: O(capacity)), walk the whole array again to emit a CSR into pinned memory
+// (build_csr / build_reverse_csr: O(capacity)), then four cudaMemcpy H2D.  Since the CSR is re-emitted
+// from scratch at every step anyway, the gapped array buys nothing here; what the kernels need is the
+// emitted CSR, which for a valid update stream is a pure function of the current edge SET
+// (tests/test_oracle_pcsr.py::test_pcsr_csr_is_the_static_csr_with_reversed_rows_and_one_based_eids):
+//
+//   forward  CSR: rows = dst, columns = src DESCENDING (the PMA row is emitted back to front,
+//                 pcsr.cu:842-853), eids = 1 + rank of (dst, src) in ascending order (label_edges)
+//   backward CSR: rows = src, columns = dst DESCENDING, eids = the same labels       (pcsr.cu:791-804)
+//   node_ids    : rows by non-increasing length (ties unspecified in the reference; ascending id here)
+//
+// State here: the edge set as TWO dense sorted arrays of packed keys, resident in HBM:
+//   keys_fwd = (dst << 32 | src) ascending,   keys_bwd = (src << 32 | dst) ascending.
+// update : new = (old \ del) U add by ONE scatter pass per orientation -- every surviving old key and
+//          every added key computes its output slot from binary searches over the (small, sorted,
+//          L2-resident) batches; no atomics, no temporaries of size E, deterministic.  16 B of HBM
+//          traffic per stored edge per orientation.
+// emit   : row offsets by binary search over the keys, then one pass that writes column / label into
+//          the row-reversed slot.  Labels of the backward CSR are found by searching keys_fwd.
+// Everything is stream ordered and capturable; violations of the stream contract (adding a present
+// edge, deleting an absent one, a vertex id out of range) are reported through a device status word.
+#include "stg_common.hpp"
+#include "csr_kernels.hpp"
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+namespace stg {
+namespace {
+
+constexpr int kStoreBits = 32;
+
+__device__ __forceinline__ int64_t lower_bound_dev(const uint64_t *__restrict__ a, int64_t n, uint64_t k)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < k) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// Pack an update batch in both orientations.
+__global__ void pack_batch(const int *__restrict__ src, const int *__restrict__ dst, int64_t n, int N,
+                           uint64_t *__restrict__ kf, uint64_t *__restrict__ kb, int *__restrict__ status)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned s = (unsigned)src[i], d = (unsigned)dst[i];
+        if (s >= (unsigned)N || d >= (unsigned)N) atomicOr(status, 1);
+        kf[i] = ((uint64_t)d << kStoreBits) | s;
+        kb[i] = ((uint64_t)s << kStoreBits) | d;
+    }
+}
+
+// Surviving old keys: slot = i - #(deleted keys below) + #(added keys below).
+__global__ void scatter_old(const uint64_t *__restrict__ old, int64_t E, const uint64_t *__restrict__ add,
+                            int64_t na, const uint64_t *__restrict__ del, int64_t nd,
+                            uint64_t *__restrict__ out, int64_t E_out, int *__restrict__ status)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+        const uint64_t k = old[i];
+        const int64_t d = lower_bound_dev(del, nd, k);
+        if (d < nd && del[d] == k) continue;                       // deleted
+        const int64_t a = lower_bound_dev(add, na, k);
+        if (a < na && add[a] == k) { atomicOr(status, 2); continue; }   // adding an edge that is present
+        const int64_t o = i - d + a;
+        if (o < E_out) out[o] = k;
+    }
+}
+
+// Added keys: slot = j + #(old keys below) - #(deleted keys below); deleted keys: must exist.
+__global__ void scatter_add_check_del(const uint64_t *__restrict__ old, int64_t E,
+                                      const uint64_t *__restrict__ add, int64_t na,
+                                      const uint64_t *__restrict__ del, int64_t nd,
+                                      uint64_t *__restrict__ out, int64_t E_out, int *__restrict__ status)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < na + nd; j += stride) {
+        if (j < na) {
+            const uint64_t k = add[j];
+            if (j > 0 && add[j - 1] == k) { atomicOr(status, 2); continue; }      // duplicate inside the batch
+            const int64_t o_lt = lower_bound_dev(old, E, k);
+            const int64_t d_lt = lower_bound_dev(del, nd, k);
+            if (d_lt < nd && del[d_lt] == k) atomicOr(status, 8);                  // added and deleted at once
+            const int64_t o = j + o_lt - d_lt;
+            if (o >= 0 && o < E_out) out[o] = k;
+        } else {
+            const int64_t q = j - na;
+            const uint64_t k = del[q];
+            const int64_t o = lower_bound_dev(old, E, k);
+            if (o >= E || old[o] != k || (q > 0 && del[q - 1] == k)) atomicOr(status, 4);   // deleting an absent edge
+        }
+    }
+}
+
+// One pass over the sorted keys of one orientation: column + label into the row-reversed slot.
+template <bool REVERSE>
+__global__ void emit_rows(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ keys_fwd, int64_t E,
+                          const int *__restrict__ row_offset, int *__restrict__ col, int *__restrict__ eids1,
+                          int *__restrict__ eids0)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+        const uint64_t k = keys[i];
+        const unsigned row = (unsigned)(k >> kStoreBits), c = (unsigned)k;
+        const int64_t o = (int64_t)row_offset[row] + ((int64_t)row_offset[row + 1] - 1 - i);
+        int64_t rank = i;                                                    // forward: the label is the position
+        if (REVERSE) rank = lower_bound_dev(keys_fwd, E, ((uint64_t)c << kStoreBits) | row);
+        col[o] = (int)c;
+        if (eids1) eids1[o] = (int)(rank + 1);
+        if (eids0) eids0[o] = (int)rank;
+    }
+}
+
+struct StoreLayout {
+    size_t add_f, add_b, del_f, del_b, sorted, sort_tmp, total, sort_tmp_bytes;
+};
+
+StoreLayout update_layout(int64_t n_add, int64_t n_del)
+{
+    StoreLayout L{};
+    const size_t na = (size_t)std::max<int64_t>(n_add, 1), nd = (size_t)std::max<int64_t>(n_del, 1);
+    size_t t = 0;
+    (void)rocprim::radix_sort_keys(nullptr, t, (uint64_t *)nullptr, (uint64_t *)nullptr, std::max(na, nd), 0, 64);
+    L.sort_tmp_bytes = t;
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { const size_t o = off; off += align_up(bytes); return o; };
+    L.add_f = take(na * 8);
+    L.add_b = take(na * 8);
+    L.del_f = take(nd * 8);
+    L.del_b = take(nd * 8);
+    L.sorted = take(std::max(na, nd) * 8);         // unsorted staging for one batch at a time
+    L.sort_tmp = take(t);
+    L.total = off;
+    return L;
+}
+
+struct EmitLayout {
+    size_t key_a, key_b, iota, sort_tmp, total, sort_tmp_bytes;
+};
+
+EmitLayout emit_layout(int32_t N)
+{
+    EmitLayout L{};
+    const size_t n = (size_t)std::max<int32_t>(N, 1);
+    size_t t = 0;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, t, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
+                                         (int *)nullptr, n, 0, 32);
+    L.sort_tmp_bytes = t;
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { const size_t o = off; off += align_up(bytes); return o; };
+    L.key_a = take(n * 4);
+    L.key_b = take(n * 4);
+    L.iota = take(n * 4);
+    L.sort_tmp = take(t);
+    L.total = off;
+    return L;
+}
+
+inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, 256 * 16)); }
+
+}  // namespace
+}  // namespace stg
+
+// ------------------------------------------------------------------------------------- host
+// Same contract on host arrays (used when the graph lives on the CPU: tests without a GPU).
+extern "C" int stg_edgeset_update_host(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E,
+                                       const int32_t *add_src, const int32_t *add_dst, int64_t n_add,
+                                       const int32_t *del_src, const int32_t *del_dst, int64_t n_del, int32_t N,
+                                       uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *status)
+{
+    using namespace stg;
+    if (E < 0 || n_add < 0 || n_del < 0 || N < 0 || !status)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_update_host: bad argument");
+    if (E + n_add - n_del < 0 || E + n_add >= (int64_t(1) << 31))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_update_host: edge count out of range");
+    int st = 0;
+    for (int side = 0; side < 2; ++side) {
+        std::vector<uint64_t> add((size_t)n_add), del((size_t)n_del);
+        auto pack = [&](const int32_t *s, const int32_t *d, int64_t n, std::vector<uint64_t> &out) {
+            for (int64_t i = 0; i < n; ++i) {
+                const unsigned a = (unsigned)s[i], b = (unsigned)d[i];
+                if (a >= (unsigned)N || b >= (unsigned)N) st |= 1;
+                out[(size_t)i] = side == 0 ? ((uint64_t)b << 32) | a : ((uint64_t)a << 32) | b;
+            }
+            std::sort(out.begin(), out.end());
+        };
+        pack(add_src, add_dst, n_add, add);
+        pack(del_src, del_dst, n_del, del);
+        const uint64_t *old = side == 0 ? keys_fwd_in : keys_bwd_in;
+        uint64_t *out = side == 0 ? keys_fwd_out : keys_bwd_out;
+        if (std::adjacent_find(add.begin(), add.end()) != add.end()) st |= 2;
+        if (std::adjacent_find(del.begin(), del.end()) != del.end()) st |= 4;
+        std::vector<uint64_t> kept;
+        kept.reserve((size_t)E);
+        size_t q = 0, found = 0;
+        for (int64_t i = 0; i < E; ++i) {
+            while (q < del.size() && del[q] < old[i]) ++q;
+            if (q < del.size() && del[q] == old[i]) { ++found; continue; }
+            kept.push_back(old[i]);
+        }
+        if (found != del.size()) st |= 4;
+        for (uint64_t k : add) {
+            if (std::binary_search(old, old + E, k)) st |= 2;
+            if (std::binary_search(del.begin(), del.end(), k)) st |= 8;
+        }
+        if (st) continue;                                      // contract violated: leave the outputs untouched
+        std::merge(kept.begin(), kept.end(), add.begin(), add.end(), out);
+    }
+    *status = st;
+    return 0;
+}
+
+extern "C" int stg_edgeset_emit_csr_host(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
+                                         int reverse, int32_t *row_offset, int32_t *column_indices, int32_t *eids1,
+                                         int32_t *eids0, int32_t *node_ids, int32_t *degrees)
+{
+    using namespace stg;
+    if (E < 0 || N < 0 || !row_offset || (E > 0 && (!keys_fwd || !keys_bwd || !column_indices)) ||
+        (N > 0 && (!node_ids || !degrees)))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_host: bad argument");
+    const uint64_t *keys = reverse ? keys_bwd : keys_fwd;
+    int64_t p = 0;
+    for (int32_t v = 0; v <= N; ++v) {
+        while (p < E && (int64_t)(keys[p] >> 32) < (int64_t)v) ++p;
+        row_offset[v] = (int32_t)p;
+    }
+    for (int64_t i = 0; i < E; ++i) {
+        const uint64_t k = keys[i];
+        const unsigned row = (unsigned)(k >> 32), c = (unsigned)k;
+        if (row >= (unsigned)N) return fail(STG_ERR_VERTEX_RANGE, "stg_edgeset_emit_csr_host: vertex id out of range");
+        const int64_t o = (int64_t)row_offset[row] + ((int64_t)row_offset[row + 1] - 1 - i);
+        int64_t rank = i;
+        if (reverse) rank = std::lower_bound(keys_fwd, keys_fwd + E, ((uint64_t)c << 32) | row) - keys_fwd;
+        column_indices[o] = (int32_t)c;
+        if (eids1) eids1[o] = (int32_t)(rank + 1);
+        if (eids0) eids0[o] = (int32_t)rank;
+    }
+    for (int32_t v = 0; v < N; ++v) degrees[v] = row_offset[v + 1] - row_offset[v];
+    if (N > 0) {
+        std::iota(node_ids, node_ids + N, 0);
+        std::stable_sort(node_ids, node_ids + N, [degrees](int32_t l, int32_t r) { return degrees[l] > degrees[r]; });
+    }
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------- device
+extern "C" size_t stg_edgeset_update_workspace_bytes(int64_t n_add, int64_t n_del)
+{
+    if (n_add < 0 || n_del < 0) return 0;
+    return stg::update_layout(n_add, n_del).total;
+}
+
+extern "C" int stg_edgeset_update_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E,
+                                         const int32_t *add_src, const int32_t *add_dst, int64_t n_add,
+                                         const int32_t *del_src, const int32_t *del_dst, int64_t n_del, int32_t N,
+                                         uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *status,
+                                         void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (E < 0 || n_add < 0 || n_del < 0 || N < 0)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_update_device: negative size");
+    const int64_t E_out = E + n_add - n_del;
+    if (E_out < 0 || E + n_add >= (int64_t(1) << 31))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_update_device: edge count %lld out of range", (long long)E_out);
+    if (!status || !workspace || (E > 0 && (!keys_fwd_in || !keys_bwd_in)) ||
+        (E_out > 0 && (!keys_fwd_out || !keys_bwd_out)) || (n_add > 0 && (!add_src || !add_dst)) ||
+        (n_del > 0 && (!del_src || !del_dst)))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_update_device: NULL pointer argument");
+    if (keys_fwd_out == keys_fwd_in || keys_bwd_out == keys_bwd_in)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_update_device: the update is out of place");
+    const StoreLayout L = update_layout(n_add, n_del);
+    if (workspace_bytes < L.total)
+        return fail(STG_ERR_WORKSPACE, "stg_edgeset_update_device: workspace %zu < required %zu", workspace_bytes, L.total);
+    char *ws = static_cast<char *>(workspace);
+    uint64_t *batch[4] = {reinterpret_cast<uint64_t *>(ws + L.add_f), reinterpret_cast<uint64_t *>(ws + L.add_b),
+                          reinterpret_cast<uint64_t *>(ws + L.del_f), reinterpret_cast<uint64_t *>(ws + L.del_b)};
+    auto *staging = reinterpret_cast<uint64_t *>(ws + L.sorted);
+    void *sort_tmp = ws + L.sort_tmp;
+    const unsigned end_bit = (unsigned)(kStoreBits + key_bits_for(N));
+
+    hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), stream);
+    if (e != hipSuccess) return fail((int)e, "stg_edgeset_update_device: memset: %s", hipGetErrorString(e));
+
+    // pack + sort the two batches in both orientations (batches are small next to E)
+    for (int which = 0; which < 2; ++which) {
+        const int64_t n = which == 0 ? n_add : n_del;
+        if (n == 0) continue;
+        const int32_t *s = which == 0 ? add_src : del_src, *d = which == 0 ? add_dst : del_dst;
+        uint64_t *kf = batch[2 * which], *kb = batch[2 * which + 1];
+        // pack forward keys into the staging buffer and backward keys into kb; sort staging -> kf; then kb -> staging -> kb
+        hipLaunchKernelGGL(pack_batch, dim3(grid_for(n)), dim3(kBlock), 0, stream, s, d, n, N, staging, kb, status);
+        size_t tmp = L.sort_tmp_bytes;
+        e = rocprim::radix_sort_keys(sort_tmp, tmp, staging, kf, (size_t)n, 0, end_bit, stream);
+        if (e != hipSuccess) return fail((int)e, "stg_edgeset_update_device: sort: %s", hipGetErrorString(e));
+        tmp = L.sort_tmp_bytes;
+        e = rocprim::radix_sort_keys(sort_tmp, tmp, kb, staging, (size_t)n, 0, end_bit, stream);
+        if (e != hipSuccess) return fail((int)e, "stg_edgeset_update_device: sort: %s", hipGetErrorString(e));
+        e = hipMemcpyAsync(kb, staging, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return fail((int)e, "stg_edgeset_update_device: copy: %s", hipGetErrorString(e));
+    }
+    for (int side = 0; side < 2; ++side) {
+        const uint64_t *old = side == 0 ? keys_fwd_in : keys_bwd_in;
+        uint64_t *out = side == 0 ? keys_fwd_out : keys_bwd_out;
+        const uint64_t *add = batch[side], *del = batch[2 + side];
+        if (E > 0)
+            hipLaunchKernelGGL(scatter_old, dim3(grid_for(E)), dim3(kBlock), 0, stream, old, E, add, n_add, del, n_del,
+                               out, E_out, status);
+        if (n_add + n_del > 0)
+            hipLaunchKernelGGL(scatter_add_check_del, dim3(grid_for(n_add + n_del)), dim3(kBlock), 0, stream, old, E,
+                               add, n_add, del, n_del, out, E_out, status);
+    }
+    return check_launch("stg_edgeset_update_device");
+}
+
+extern "C" size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N)
+{
+    if (N < 0) return 0;
+    return stg::emit_layout(N).total;
+}
+
+extern "C" int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
+                                           int reverse, int32_t *row_offset, int32_t *column_indices, int32_t *eids1,
+                                           int32_t *eids0, int32_t *node_ids, int32_t *degrees, void *workspace,
+                                           size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (E < 0 || N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_device: negative size");
+    if (E >= (int64_t(1) << 31)) return fail(STG_ERR_UNSUPPORTED, "stg_edgeset_emit_csr_device: E does not fit int32");
+    if (!row_offset || !workspace || (E > 0 && (!keys_fwd || !keys_bwd || !column_indices)) ||
+        (N > 0 && (!node_ids || !degrees)))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_device: NULL pointer argument");
+    const EmitLayout L = emit_layout(N);
+    if (workspace_bytes < L.total)
+        return fail(STG_ERR_WORKSPACE, "stg_edgeset_emit_csr_device: workspace %zu < required %zu", workspace_bytes, L.total);
+    char *ws = static_cast<char *>(workspace);
+    const uint64_t *keys = reverse ? keys_bwd : keys_fwd;
+    hipLaunchKernelGGL(row_offsets_by_search, dim3((N + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, keys, E,
+                       kStoreBits, N, row_offset);
+    if (E > 0) {
+        if (reverse)
+            hipLaunchKernelGGL((emit_rows<true>), dim3(grid_for(E)), dim3(kBlock), 0, stream, keys, keys_fwd, E,
+                               row_offset, column_indices, eids1, eids0);
+        else
+            hipLaunchKernelGGL((emit_rows<false>), dim3(grid_for(E)), dim3(kBlock), 0, stream, keys, keys_fwd, E,
+                               row_offset, column_indices, eids1, eids0);
+    }
+    if (N > 0) {
+        auto *key_a = reinterpret_cast<unsigned *>(ws + L.key_a);
+        auto *key_b = reinterpret_cast<unsigned *>(ws + L.key_b);
+        auto *iota = reinterpret_cast<int *>(ws + L.iota);
+        hipLaunchKernelGGL(degrees_and_iota, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, row_offset, N,
+                           degrees, key_a, iota);
+        size_t tmp = L.sort_tmp_bytes;
+        const hipError_t e = rocprim::radix_sort_pairs_desc(ws + L.sort_tmp, tmp, key_a, key_b, iota, node_ids,
+                                                            (size_t)N, 0, 32, stream);
+        if (e != hipSuccess) return fail((int)e, "stg_edgeset_emit_csr_device: node_ids sort: %s", hipGetErrorString(e));
+    }
+    return check_launch("stg_edgeset_emit_csr_device");
+}

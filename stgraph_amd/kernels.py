@@ -238,6 +238,105 @@ def csr_ctor_host(a, b, eid, edge_weight, num_nodes: int, is_edge_reverse: bool 
     return out
 
 
+# ---------------------------------------------------------------------- dynamic edge store
+@dataclass
+class EdgeSet:
+    """The edge set of one timestamp of a dynamic graph: two ascending arrays of packed keys
+    (``dst << 32 | src`` and ``src << 32 | dst``; int64 tensors).  The state behind
+    :class:`stgraph_amd.graph.dynamic.pcsr.pcsr.PCSR` (reference pcsr.cu:273-318).  Immutable:
+    an update returns a new set, so caching a timestamp is keeping a reference."""
+
+    num_nodes: int
+    keys_fwd: torch.Tensor
+    keys_bwd: torch.Tensor
+    status: torch.Tensor | None = None      # int32[1] written by the update that produced this set
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.keys_fwd.shape[0])
+
+    @property
+    def device(self) -> torch.device:
+        return self.keys_fwd.device
+
+
+_STATUS_TEXT = {1: "vertex id out of range", 2: "added edge already present (or repeated in the batch)",
+                4: "deleted edge absent (or repeated in the batch)", 8: "edge added and deleted in the same update"}
+
+
+def edgeset_empty(num_nodes: int, device) -> EdgeSet:
+    device = torch.device(device)
+    z = torch.empty(0, dtype=torch.int64, device=device)
+    return EdgeSet(int(num_nodes), z, z.clone())
+
+
+def edgeset_update(es: EdgeSet, add_src, add_dst, del_src=None, del_dst=None) -> EdgeSet:
+    """(es \\ del) U add, both orientations (stg_edgeset_update_device / _host).  The stream contract
+    (added edges absent, deleted edges present) is checked on the device; call
+    :func:`edgeset_check` to fetch the verdict (one 4-byte sync)."""
+    device, N = es.device, es.num_nodes
+    a_s, a_d = _as_i32(add_src, device), _as_i32(add_dst, device)
+    empty = torch.empty(0, dtype=torch.int32, device=device)
+    d_s = _as_i32(del_src, device) if del_src is not None else empty
+    d_d = _as_i32(del_dst, device) if del_dst is not None else empty
+    if a_s.shape != a_d.shape or d_s.shape != d_d.shape or a_s.dim() != 1 or d_s.dim() != 1:
+        raise ValueError("update lists must be 1-D (src, dst) arrays of equal length")
+    E, na, nd = es.num_edges, int(a_s.shape[0]), int(d_s.shape[0])
+    if E + na - nd < 0:
+        raise ValueError("more deletions than edges")
+    kf = torch.empty(E + na - nd, dtype=torch.int64, device=device)
+    kb = torch.empty(E + na - nd, dtype=torch.int64, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    if device.type == "cuda":
+        ws_bytes = int(_C.lib.stg_edgeset_update_workspace_bytes(na, nd))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _C.check(_C.lib.stg_edgeset_update_device(
+                _ptr(es.keys_fwd), _ptr(es.keys_bwd), E, _ptr(a_s), _ptr(a_d), na, _ptr(d_s), _ptr(d_d), nd, N,
+                _ptr(kf), _ptr(kb), _ptr(status), _ptr(ws), ws_bytes, _stream_ptr(device)))
+    else:
+        _C.check(_C.lib.stg_edgeset_update_host(
+            _ptr(es.keys_fwd), _ptr(es.keys_bwd), E, _ptr(a_s), _ptr(a_d), na, _ptr(d_s), _ptr(d_d), nd, N,
+            _ptr(kf), _ptr(kb), _ptr(status)))
+    return EdgeSet(N, kf, kb, status)
+
+
+def edgeset_check(es: EdgeSet) -> None:
+    """Raise if the update that produced ``es`` violated the stream contract (synchronises)."""
+    if es.status is None:
+        return
+    code = int(es.status.item())
+    if code:
+        what = "; ".join(t for b, t in _STATUS_TEXT.items() if code & b)
+        raise ValueError(f"invalid edge update stream: {what} (libstgraph_hip status {code})")
+
+
+def edgeset_emit_csr(es: EdgeSet, reverse: bool):
+    """The CSR the reference's ``build_csr`` (``reverse=False``, rows = dst) / ``build_reverse_csr``
+    (rows = src) emits for this edge set (pcsr.cu:781-879): returns ``(DeviceCSR with 0-based eids,
+    eids1 = the 1-based labels, degrees)``."""
+    device, N, E = es.device, es.num_nodes, es.num_edges
+    i32 = dict(dtype=torch.int32, device=device)
+    csr = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32))
+    eids1, deg = torch.empty(E, **i32), torch.empty(N, **i32)
+    args = [_ptr(es.keys_fwd), _ptr(es.keys_bwd), E, N, int(bool(reverse)), _ptr(csr.row_offset),
+            _ptr(csr.column_indices), _ptr(eids1), _ptr(csr.eids), _ptr(csr.node_ids), _ptr(deg)]
+    if device.type == "cuda":
+        ws_bytes = int(_C.lib.stg_edgeset_emit_csr_workspace_bytes(N))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _C.check(_C.lib.stg_edgeset_emit_csr_device(*args, _ptr(ws), ws_bytes, _stream_ptr(device)))
+    else:
+        _C.check(_C.lib.stg_edgeset_emit_csr_host(*args))
+    return csr, eids1, deg
+
+
+def rows_by_node_ids(graph_type: str) -> bool:
+    """Graph types whose kernels visit rows through ``node_ids`` (tpl_fa_csr.jinja / tpl_fa_pcsr.jinja,
+    code_gen.py:96-103); 'csr_unsorted' walks rows in id order."""
+    return graph_type in ("csr", "pcsr")
+
+
 # ------------------------------------------------------------------------------- GCN
 _EDGE_CACHE = True
 

@@ -152,4 +152,4 @@ def agg_transform(graph, x: torch.Tensor, W: torch.Tensor, edge_weight=None) -> 
     forward/backward CSR (dynamic graphs: the snapshot of this timestamp) for the backward pass."""
     norm = graph.get_ndata("norm")
     return _AggTransform.apply(x, W, norm, edge_weight, graph.csr("fwd"), graph.csr("bwd"),
-                               graph.graph_type() == "csr")
+                               kernels.rows_by_node_ids(graph.graph_type()))

@@ -97,7 +97,7 @@ class TGCN(torch.nn.Module):
             # whole step as one autograd node: (A_hat X) W on the matrix cores (gather at width in_channels),
             # fused row-local stages, weight gradients deferred to the end of the backward pass
             return cell.TGCNStepFn.apply(
-                X, H, g.get_ndata("norm"), edge_weight, g.csr("fwd"), g.csr("bwd"), g.graph_type() == "csr",
+                X, H, g.get_ndata("norm"), edge_weight, g.csr("fwd"), g.csr("bwd"), kernels.rows_by_node_ids(g.graph_type()),
                 convs[0].weight, convs[1].weight, convs[2].weight, convs[0].bias, convs[1].bias, convs[2].bias,
                 self.linear_z.weight, self.linear_z.bias, self.linear_r.weight, self.linear_r.bias,
                 self.linear_h.weight, self.linear_h.bias)

@@ -1,0 +1,147 @@
+"""GPU parity of the dynamic edge store (csrc/edge_store.hip) and of the layers running on a
+``PCSRGraph``: the reference-recorded streams and protocol, the reference's GCNConv / TGCN outputs on
+its own PCSRGraph, and -- at bench scale -- size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+import stgraph_amd
+from tests.test_gpu_layers import TGCNModel, _edges, _load_params, _t
+from tests.test_host_pcsr import replay_protocol, replay_streams
+from tests.util import golden, random_graph
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def test_pcsr_streams_device(cuda):
+    replay_streams(cuda)
+
+
+def test_pcsr_graph_protocol_device(cuda):
+    replay_protocol(cuda)
+
+
+def test_gcnconv_on_pcsr_graph_matches_reference(cuda):
+    """The reference's emitted 'pcsr' kernels walk each row back to front and index edge weights by label-1:
+    bit-identical outputs and input gradients."""
+    from stgraph_amd.graph import PCSRGraph
+    from stgraph_amd.nn.pytorch.static.gcn_conv import GCNConv
+    stgraph_amd.set_reference_compat(True)                      # fixtures carry defect D1 for F = 7
+    try:
+        d = golden("pcsr_gcn.npz")
+        n, el = int(d["num_nodes"]), _edges(d)
+        w = _t(d["edge_weight_by_eid"], cuda)
+        for F in (7, 16, 64):
+            for use_ew in (False, True):
+                G = PCSRGraph([el], n, device=cuda)
+                G.get_graph(0)
+                G.set_ndata("norm", _t(d["norm"], cuda))
+                tag = f"F{F}_{'ew' if use_ew else 'now'}"
+                conv = GCNConv(F, F, bias=False).to(cuda)
+                with torch.no_grad():
+                    conv.weight.copy_(torch.eye(F))
+                x = _t(d[tag + "_x"], cuda).requires_grad_(True)
+                out = conv(G, x, edge_weight=w if use_ew else None)
+                (out * _t(d[tag + "_R"], cuda)).sum().backward()
+                assert np.array_equal(out.detach().cpu().numpy(), d[tag + "_out"]), tag
+                assert np.array_equal(x.grad.cpu().numpy(), d[tag + "_grad_x"]), tag
+    finally:
+        stgraph_amd.set_reference_compat(False)
+
+
+def test_pcsr_graph_tgcn_bptt_matches_reference(cuda):
+    from stgraph_amd.graph import PCSRGraph
+    d = golden("pcsr_tgcn.npz")
+    n, T, B = int(d["num_nodes"]), int(d["T"]), int(d["B"])
+    G = PCSRGraph([_edges(d, f"t{t}_") for t in range(T)], n, device=cuda)
+    feats, targets = _t(d["feats"], cuda), _t(d["targets"], cuda)
+    model = TGCNModel(feats.shape[2], 16, 1).to(cuda)
+    _load_params(model, d, "param_", cuda)
+    for epoch in range(2):                                      # epoch 2: from the restored base graph (D14)
+        G.reset_graph()
+        hs = []
+        for i, w0 in enumerate(range(0, T, B)):
+            model.zero_grad()
+            hidden, cost = None, 0
+            ts = list(range(w0, min(w0 + B, T)))
+            G.get_graph(w0)
+            for t in ts:
+                G.get_graph(t)
+                if G.get_ndata("norm") is None:
+                    deg = torch.from_numpy(G.in_degrees()).float()
+                    norm = torch.pow(deg, -0.5)
+                    norm[torch.isinf(norm)] = 0
+                    G.set_ndata("norm", norm.unsqueeze(1).to(cuda))
+                np.testing.assert_array_equal(G.get_ndata("norm").cpu().numpy(), d[f"t{t}_norm"])
+                y, hidden = model(G, feats[t], None, hidden)
+                cost = cost + torch.mean((y - targets[t]) ** 2)
+                hs.append(hidden.detach())
+            cost = cost / (B + 1)
+            cost.backward()
+            assert G.current_timestamp == w0
+            np.testing.assert_allclose(cost.item(), d["cost"][i], rtol=TOL, atol=TOL)
+            for k, p in model.named_parameters():
+                np.testing.assert_allclose(p.grad.cpu().numpy(), d[f"w{w0}_grad_{k}"], rtol=TOL, atol=TOL, err_msg=k)
+        np.testing.assert_allclose(torch.stack(hs).cpu().numpy(), d["hidden"], rtol=TOL, atol=TOL)
+    G.check()
+
+
+def _reversed_rows(csr):
+    """Static CSR -> what the PMA emits: every row back to front."""
+    ro = csr.row_offset.long()
+    n, e = ro.shape[0] - 1, csr.column_indices.shape[0]
+    row = torch.repeat_interleave(torch.arange(n, device=ro.device), ro[1:] - ro[:-1])
+    pos = torch.arange(e, device=ro.device)
+    src = ro[row] + (ro[row + 1] - 1 - pos)
+    return csr.column_indices[src], csr.eids[src]
+
+
+@pytest.mark.parametrize("n,e,churn", [(1000, 20000, 0.3), (1 << 20, 1 << 24, 0.05)])
+def test_update_equals_rebuild_at_scale(cuda, n, e, churn):
+    """Size-independent properties at BASELINE's |V| = 1M, |E| = 16M: (i) a store updated by a delta equals a
+    store built from the new edge list, bit for bit; (ii) the emitted CSRs are the static builder's with every
+    row reversed and eids + 1; (iii) applying the inverse delta restores the original keys."""
+    from stgraph_amd import kernels
+    src, dst = random_graph(11, n, e, hub=False)
+    src, dst = torch.from_numpy(src).to(cuda), torch.from_numpy(dst).to(cuda)
+    k = int(e * churn)
+    base = kernels.edgeset_update(kernels.edgeset_empty(n, cuda), src[k:], dst[k:])        # edges [k, e)
+    new = kernels.edgeset_update(base, src[:k], dst[:k], src[-k:], dst[-k:])               # + [0, k) - [e-k, e)
+    kernels.edgeset_check(base)
+    kernels.edgeset_check(new)
+    fresh = kernels.edgeset_update(kernels.edgeset_empty(n, cuda), src[:-k], dst[:-k])
+    assert torch.equal(new.keys_fwd, fresh.keys_fwd) and torch.equal(new.keys_bwd, fresh.keys_bwd)
+    assert bool((new.keys_fwd[1:] > new.keys_fwd[:-1]).all()) and bool((new.keys_bwd[1:] > new.keys_bwd[:-1]).all())
+    back = kernels.edgeset_update(new, src[-k:], dst[-k:], src[:k], dst[:k])
+    assert torch.equal(back.keys_fwd, base.keys_fwd) and torch.equal(back.keys_bwd, base.keys_bwd)
+    g = kernels.build_graph_csr(src[:-k], dst[:-k], n, cuda)
+    for rev, side in ((False, g.fwd), (True, g.bwd)):
+        csr, eids1, deg = kernels.edgeset_emit_csr(new, rev)
+        col, eid = _reversed_rows(side)
+        assert torch.equal(csr.row_offset, side.row_offset)
+        assert torch.equal(csr.column_indices, col) and torch.equal(eids1, eid + 1) and torch.equal(csr.eids, eid)
+        assert torch.equal(deg, (side.row_offset[1:] - side.row_offset[:-1]))
+        d = deg[csr.node_ids.long()]
+        assert bool((d[1:] <= d[:-1]).all()) and torch.equal(torch.sort(csr.node_ids).values,
+                                                             torch.arange(n, device=cuda, dtype=torch.int32))
+    # the aggregation over the emitted CSR equals the one over the static CSR up to summation order
+    x = torch.randn(n, 8, device=cuda)
+    norm = torch.rand(n, 1, device=cuda)
+    a = kernels.gcn_agg(x, norm, norm, kernels.edgeset_emit_csr(new, False)[0], use_node_ids=True)
+    b = kernels.gcn_agg(x, norm, norm, g.fwd)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_invalid_updates_are_flagged_on_device(cuda):
+    from stgraph_amd import kernels
+    s = torch.tensor([0, 1, 2], dtype=torch.int32, device=cuda)
+    d = torch.tensor([1, 2, 0], dtype=torch.int32, device=cuda)
+    base = kernels.edgeset_update(kernels.edgeset_empty(3, cuda), s, d)
+    kernels.edgeset_check(base)
+    for add, dele in (((s[:1], d[:1]), None), (None, (d[:1], s[:1])), ((s[:1] + 5, d[:1]), None)):
+        e = torch.empty(0, dtype=torch.int32, device=cuda)
+        a = add or (e, e)
+        q = dele or (e, e)
+        with pytest.raises(ValueError):
+            kernels.edgeset_check(kernels.edgeset_update(base, a[0], a[1], q[0], q[1]))
