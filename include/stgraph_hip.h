@@ -112,8 +112,11 @@ int stg_graph_build_device(const int32_t *src, const int32_t *dst, int64_t E, in
  *   row in DESCENDING order (the PMA row is emitted back to front), eids1 = the
  *   1-based labels of label_edges (1 + rank in (dst, src) order; what
  *   tpl_fa_pcsr.jinja:32-34 subtracts 1 from), eids0 = eids1 - 1 (what the
- *   stg_gcn_agg / stg_gat_* entry points take); either may be NULL.  node_ids =
- *   rows by non-increasing length (ties: ascending id); degrees = row lengths.
+ *   stg_gcn_agg / stg_gat_* entry points take).  node_ids = rows by non-increasing
+ *   length (ties: ascending id); degrees = row lengths.  row_offset is always
+ *   written; column_indices, eids1, eids0 may each be NULL and node_ids + degrees
+ *   may both be NULL -- those parts are skipped (the un-weighted GCN kernels never
+ *   read eids, so a training step emits structure only and labels on demand).
  * All arrays [dev] for *_device, [host] for *_host; no call synchronises.
  */
 size_t stg_edgeset_update_workspace_bytes(int64_t n_add, int64_t n_del);
@@ -126,6 +129,13 @@ int stg_edgeset_update_host(const uint64_t *keys_fwd_in, const uint64_t *keys_bw
                             const int32_t *add_src, const int32_t *add_dst, int64_t n_add,
                             const int32_t *del_src, const int32_t *del_dst, int64_t n_del, int32_t N,
                             uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *status);
+/* One orientation, batches already packed and strictly ascending (a PCSRGraph packs and sorts its
+ * per-timestamp add/delete lists once, at construction): keys_out = (keys_in \ del) U add in one
+ * scatter pass, no workspace.  status as above, plus 16 = a batch was not ascending.
+ * The caller zeroes *status (it accumulates over the calls of one update). */
+int stg_edgeset_merge_device(const uint64_t *keys_in, int64_t E, const uint64_t *add_sorted, int64_t n_add,
+                             const uint64_t *del_sorted, int64_t n_del, uint64_t *keys_out,
+                             int32_t *status, void *stream);
 size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N);
 int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
                                 int reverse, int32_t *row_offset, int32_t *column_indices,

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "stg_abi_version", "stg_last_error_string", "stg_set_tuning",
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
-    "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host",
+    "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host", "stg_edgeset_merge_device",
     "stg_edgeset_emit_csr_workspace_bytes", "stg_edgeset_emit_csr_device", "stg_edgeset_emit_csr_host",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
@@ -70,6 +70,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_edgeset_update_device.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.stg_edgeset_update_host.restype = ctypes.c_int
     lib.stg_edgeset_update_host.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp]
+    lib.stg_edgeset_merge_device.restype = ctypes.c_int
+    lib.stg_edgeset_merge_device.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, vp]
     lib.stg_edgeset_emit_csr_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_edgeset_emit_csr_workspace_bytes.argtypes = [i32]
     lib.stg_edgeset_emit_csr_device.restype = ctypes.c_int

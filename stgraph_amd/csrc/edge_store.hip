@@ -64,21 +64,73 @@ __global__ void pack_batch(const int *__restrict__ src, const int *__restrict__ 
     }
 }
 
-// Surviving old keys: slot = i - #(deleted keys below) + #(added keys below).
-__global__ void scatter_old(const uint64_t *__restrict__ old, int64_t E, const uint64_t *__restrict__ add,
-                            int64_t na, const uint64_t *__restrict__ del, int64_t nd,
-                            uint64_t *__restrict__ out, int64_t E_out, int *__restrict__ status)
+// Surviving old keys: slot = i - #(deleted keys below) + #(added keys below).  A workgroup owns a
+// contiguous tile of old keys; four lanes bracket the tile inside the two batches first, so the per-key
+// searches run over a handful of batch entries (tile x churn) that stay in L1 instead of over the
+// whole batch.
+constexpr int kMergeItems = 8;
+constexpr int kMergeSlice = 1024;        // batch entries per tile kept in LDS (2 x 8 KiB)
+
+__device__ __forceinline__ int64_t upper_bound_dev(const uint64_t *__restrict__ a, int64_t n, uint64_t k)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
-        const uint64_t k = old[i];
-        const int64_t d = lower_bound_dev(del, nd, k);
-        if (d < nd && del[d] == k) continue;                       // deleted
-        const int64_t a = lower_bound_dev(add, na, k);
-        if (a < na && add[a] == k) { atomicOr(status, 2); continue; }   // adding an edge that is present
-        const int64_t o = i - d + a;
-        if (o < E_out) out[o] = k;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] <= k) lo = mid + 1;
+        else hi = mid;
     }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_old(const uint64_t *__restrict__ old, int64_t E,
+                                                      const uint64_t *__restrict__ add, int64_t na,
+                                                      const uint64_t *__restrict__ del, int64_t nd,
+                                                      uint64_t *__restrict__ out, int64_t E_out,
+                                                      int *__restrict__ status)
+{
+    __shared__ int64_t bounds[4];
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * kMergeItems);
+    const int64_t last = min(base + (int64_t)kBlock * kMergeItems, E) - 1;
+    if (threadIdx.x < 4) {
+        const bool hi = threadIdx.x & 1, use_del = threadIdx.x & 2;
+        const uint64_t *arr = use_del ? del : add;
+        const int64_t n = use_del ? nd : na;
+        bounds[threadIdx.x] = hi ? upper_bound_dev(arr, n, old[last]) : lower_bound_dev(arr, n, old[base]);
+    }
+    __syncthreads();
+    const int64_t a0 = bounds[0], a1 = bounds[1], d0 = bounds[2], d1 = bounds[3];
+    // the slices of the two batches that can touch this tile, staged in LDS when they fit (the usual case:
+    // tile x churn entries); the per-key searches then never leave the CU
+    __shared__ uint64_t slice[2][kMergeSlice];
+    const bool staged = (a1 - a0) <= kMergeSlice && (d1 - d0) <= kMergeSlice;
+    if (staged) {
+        for (int64_t t = threadIdx.x; t < a1 - a0; t += kBlock) slice[0][t] = add[a0 + t];
+        for (int64_t t = threadIdx.x; t < d1 - d0; t += kBlock) slice[1][t] = del[d0 + t];
+        __syncthreads();
+    }
+    uint64_t key[kMergeItems];
+#pragma unroll
+    for (int j = 0; j < kMergeItems; ++j) {                            // all loads of the tile in flight first
+        const int64_t i = base + (int64_t)j * kBlock + threadIdx.x;
+        key[j] = i < E ? old[i] : 0;
+    }
+    auto place = [&](const uint64_t *addp, const uint64_t *delp) {
+        const int64_t an = a1 - a0, dn = d1 - d0;
+#pragma unroll
+        for (int j = 0; j < kMergeItems; ++j) {
+            const int64_t i = base + (int64_t)j * kBlock + threadIdx.x;
+            if (i >= E) break;
+            const uint64_t k = key[j];
+            const int64_t d = lower_bound_dev(delp, dn, k);
+            if (d < dn && delp[d] == k) continue;                          // deleted
+            const int64_t a = lower_bound_dev(addp, an, k);
+            if (a < an && addp[a] == k) { atomicOr(status, 2); continue; } // adding an edge that is present
+            const int64_t o = i - (d0 + d) + (a0 + a);
+            if (o < E_out) out[o] = k;
+        }
+    };
+    if (staged) place(slice[0], slice[1]);                                 // ds_read searches
+    else place(add + a0, del + d0);
 }
 
 // Added keys: slot = j + #(old keys below) - #(deleted keys below); deleted keys: must exist.
@@ -91,7 +143,7 @@ __global__ void scatter_add_check_del(const uint64_t *__restrict__ old, int64_t 
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < na + nd; j += stride) {
         if (j < na) {
             const uint64_t k = add[j];
-            if (j > 0 && add[j - 1] == k) { atomicOr(status, 2); continue; }      // duplicate inside the batch
+            if (j > 0 && add[j - 1] >= k) { atomicOr(status, add[j - 1] == k ? 2 : 16); continue; }   // duplicate / unsorted
             const int64_t o_lt = lower_bound_dev(old, E, k);
             const int64_t d_lt = lower_bound_dev(del, nd, k);
             if (d_lt < nd && del[d_lt] == k) atomicOr(status, 8);                  // added and deleted at once
@@ -101,16 +153,19 @@ __global__ void scatter_add_check_del(const uint64_t *__restrict__ old, int64_t 
             const int64_t q = j - na;
             const uint64_t k = del[q];
             const int64_t o = lower_bound_dev(old, E, k);
+            if (q > 0 && del[q - 1] > k) atomicOr(status, 16);                              // batch not sorted
             if (o >= E || old[o] != k || (q > 0 && del[q - 1] == k)) atomicOr(status, 4);   // deleting an absent edge
         }
     }
 }
 
 // One pass over the sorted keys of one orientation: column + label into the row-reversed slot.
+// Reverse CSR: the label of (src -> dst) is its rank in keys_fwd; row_offset_fwd[dst] (L2 resident) narrows the
+// search to that destination's row, i.e. to one or two cache lines of keys_fwd.
 template <bool REVERSE>
 __global__ void emit_rows(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ keys_fwd, int64_t E,
-                          const int *__restrict__ row_offset, int *__restrict__ col, int *__restrict__ eids1,
-                          int *__restrict__ eids0)
+                          const int *__restrict__ row_offset, const int *__restrict__ row_offset_fwd,
+                          int *__restrict__ col, int *__restrict__ eids1, int *__restrict__ eids0)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
@@ -118,8 +173,11 @@ __global__ void emit_rows(const uint64_t *__restrict__ keys, const uint64_t *__r
         const unsigned row = (unsigned)(k >> kStoreBits), c = (unsigned)k;
         const int64_t o = (int64_t)row_offset[row] + ((int64_t)row_offset[row + 1] - 1 - i);
         int64_t rank = i;                                                    // forward: the label is the position
-        if (REVERSE) rank = lower_bound_dev(keys_fwd, E, ((uint64_t)c << kStoreBits) | row);
-        col[o] = (int)c;
+        if (REVERSE && (eids1 || eids0)) {
+            const int64_t lo = row_offset_fwd[c];
+            rank = lo + lower_bound_dev(keys_fwd + lo, (int64_t)row_offset_fwd[c + 1] - lo, ((uint64_t)c << kStoreBits) | row);
+        }
+        if (col) col[o] = (int)c;
         if (eids1) eids1[o] = (int)(rank + 1);
         if (eids0) eids0[o] = (int)rank;
     }
@@ -149,7 +207,7 @@ StoreLayout update_layout(int64_t n_add, int64_t n_del)
 }
 
 struct EmitLayout {
-    size_t key_a, key_b, iota, sort_tmp, total, sort_tmp_bytes;
+    size_t key_a, key_b, iota, ro_fwd, sort_tmp, total, sort_tmp_bytes;
 };
 
 EmitLayout emit_layout(int32_t N)
@@ -165,12 +223,29 @@ EmitLayout emit_layout(int32_t N)
     L.key_a = take(n * 4);
     L.key_b = take(n * 4);
     L.iota = take(n * 4);
+    L.ro_fwd = take((n + 1) * 4);
     L.sort_tmp = take(t);
     L.total = off;
     return L;
 }
 
+void launch_merge(const uint64_t *old, int64_t E, const uint64_t *add, int64_t na, const uint64_t *del, int64_t nd,
+                  uint64_t *out, int64_t E_out, int32_t *status, hipStream_t stream);
+
 inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, 256 * 16)); }
+
+void launch_merge(const uint64_t *old, int64_t E, const uint64_t *add, int64_t na, const uint64_t *del, int64_t nd,
+                  uint64_t *out, int64_t E_out, int32_t *status, hipStream_t stream)
+{
+    if (E > 0) {
+        const int64_t tile = (int64_t)kBlock * kMergeItems;
+        hipLaunchKernelGGL(scatter_old, dim3((unsigned)((E + tile - 1) / tile)), dim3(kBlock), 0, stream, old, E, add,
+                           na, del, nd, out, E_out, status);
+    }
+    if (na + nd > 0)
+        hipLaunchKernelGGL(scatter_add_check_del, dim3(grid_for(na + nd)), dim3(kBlock), 0, stream, old, E, add, na,
+                           del, nd, out, E_out, status);
+}
 
 }  // namespace
 }  // namespace stg
@@ -229,8 +304,7 @@ extern "C" int stg_edgeset_emit_csr_host(const uint64_t *keys_fwd, const uint64_
                                          int32_t *eids0, int32_t *node_ids, int32_t *degrees)
 {
     using namespace stg;
-    if (E < 0 || N < 0 || !row_offset || (E > 0 && (!keys_fwd || !keys_bwd || !column_indices)) ||
-        (N > 0 && (!node_ids || !degrees)))
+    if (E < 0 || N < 0 || !row_offset || (E > 0 && (!keys_fwd || !keys_bwd)) || (!node_ids != !degrees))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_host: bad argument");
     const uint64_t *keys = reverse ? keys_bwd : keys_fwd;
     int64_t p = 0;
@@ -244,11 +318,12 @@ extern "C" int stg_edgeset_emit_csr_host(const uint64_t *keys_fwd, const uint64_
         if (row >= (unsigned)N) return fail(STG_ERR_VERTEX_RANGE, "stg_edgeset_emit_csr_host: vertex id out of range");
         const int64_t o = (int64_t)row_offset[row] + ((int64_t)row_offset[row + 1] - 1 - i);
         int64_t rank = i;
-        if (reverse) rank = std::lower_bound(keys_fwd, keys_fwd + E, ((uint64_t)c << 32) | row) - keys_fwd;
-        column_indices[o] = (int32_t)c;
+        if (reverse && (eids1 || eids0)) rank = std::lower_bound(keys_fwd, keys_fwd + E, ((uint64_t)c << 32) | row) - keys_fwd;
+        if (column_indices) column_indices[o] = (int32_t)c;
         if (eids1) eids1[o] = (int32_t)(rank + 1);
         if (eids0) eids0[o] = (int32_t)rank;
     }
+    if (!degrees) return 0;
     for (int32_t v = 0; v < N; ++v) degrees[v] = row_offset[v + 1] - row_offset[v];
     if (N > 0) {
         std::iota(node_ids, node_ids + N, 0);
@@ -317,14 +392,27 @@ extern "C" int stg_edgeset_update_device(const uint64_t *keys_fwd_in, const uint
         const uint64_t *old = side == 0 ? keys_fwd_in : keys_bwd_in;
         uint64_t *out = side == 0 ? keys_fwd_out : keys_bwd_out;
         const uint64_t *add = batch[side], *del = batch[2 + side];
-        if (E > 0)
-            hipLaunchKernelGGL(scatter_old, dim3(grid_for(E)), dim3(kBlock), 0, stream, old, E, add, n_add, del, n_del,
-                               out, E_out, status);
-        if (n_add + n_del > 0)
-            hipLaunchKernelGGL(scatter_add_check_del, dim3(grid_for(n_add + n_del)), dim3(kBlock), 0, stream, old, E,
-                               add, n_add, del, n_del, out, E_out, status);
+        launch_merge(old, E, add, n_add, del, n_del, out, E_out, status, stream);
     }
     return check_launch("stg_edgeset_update_device");
+}
+
+extern "C" int stg_edgeset_merge_device(const uint64_t *keys_in, int64_t E, const uint64_t *add_sorted, int64_t n_add,
+                                        const uint64_t *del_sorted, int64_t n_del, uint64_t *keys_out,
+                                        int32_t *status, void *stream_)
+{
+    using namespace stg;
+    if (E < 0 || n_add < 0 || n_del < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_merge_device: negative size");
+    const int64_t E_out = E + n_add - n_del;
+    if (E_out < 0 || E + n_add >= (int64_t(1) << 31))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_merge_device: edge count %lld out of range", (long long)E_out);
+    if (!status || (E > 0 && !keys_in) || (E_out > 0 && !keys_out) || (n_add > 0 && !add_sorted) ||
+        (n_del > 0 && !del_sorted))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_merge_device: NULL pointer argument");
+    if (keys_out == keys_in) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_merge_device: the merge is out of place");
+    launch_merge(keys_in, E, add_sorted, n_add, del_sorted, n_del, keys_out, E_out, status,
+                 static_cast<hipStream_t>(stream_));
+    return check_launch("stg_edgeset_merge_device");
 }
 
 extern "C" size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N)
@@ -342,8 +430,7 @@ extern "C" int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint6
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (E < 0 || N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_device: negative size");
     if (E >= (int64_t(1) << 31)) return fail(STG_ERR_UNSUPPORTED, "stg_edgeset_emit_csr_device: E does not fit int32");
-    if (!row_offset || !workspace || (E > 0 && (!keys_fwd || !keys_bwd || !column_indices)) ||
-        (N > 0 && (!node_ids || !degrees)))
+    if (!row_offset || !workspace || (E > 0 && (!keys_fwd || !keys_bwd)) || (!node_ids != !degrees))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_device: NULL pointer argument");
     const EmitLayout L = emit_layout(N);
     if (workspace_bytes < L.total)
@@ -352,15 +439,22 @@ extern "C" int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint6
     const uint64_t *keys = reverse ? keys_bwd : keys_fwd;
     hipLaunchKernelGGL(row_offsets_by_search, dim3((N + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, keys, E,
                        kStoreBits, N, row_offset);
-    if (E > 0) {
-        if (reverse)
+    if (E > 0 && (column_indices || eids1 || eids0)) {
+        if (reverse && (eids1 || eids0)) {
+            auto *ro_fwd = reinterpret_cast<int *>(ws + L.ro_fwd);
+            hipLaunchKernelGGL(row_offsets_by_search, dim3((N + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                               keys_fwd, E, kStoreBits, N, ro_fwd);
             hipLaunchKernelGGL((emit_rows<true>), dim3(grid_for(E)), dim3(kBlock), 0, stream, keys, keys_fwd, E,
-                               row_offset, column_indices, eids1, eids0);
-        else
+                               row_offset, ro_fwd, column_indices, eids1, eids0);
+        } else if (reverse) {
+            hipLaunchKernelGGL((emit_rows<true>), dim3(grid_for(E)), dim3(kBlock), 0, stream, keys, keys_fwd, E,
+                               row_offset, nullptr, column_indices, nullptr, nullptr);
+        } else {
             hipLaunchKernelGGL((emit_rows<false>), dim3(grid_for(E)), dim3(kBlock), 0, stream, keys, keys_fwd, E,
-                               row_offset, column_indices, eids1, eids0);
+                               row_offset, nullptr, column_indices, eids1, eids0);
+        }
     }
-    if (N > 0) {
+    if (N > 0 && node_ids) {
         auto *key_a = reinterpret_cast<unsigned *>(ws + L.key_a);
         auto *key_b = reinterpret_cast<unsigned *>(ws + L.key_b);
         auto *iota = reinterpret_cast<int *>(ws + L.iota);

@@ -44,7 +44,7 @@ class PCSR:
         self.max_edge_count = int(max_edge_count)
         self._set = kernels.edgeset_empty(self._n, self._device)
         self._pending = {"add": [], "delete": []}       # (store src, store dst) tensor pairs, not yet merged
-        self._emitted = {}                              # reverse(bool) -> (DeviceCSR, eids1, degrees) of self._set
+        self._emitted = {}                              # reverse(bool) -> kernels.StoreCSR of self._set
         self._published = None                          # the arrays the last build_* call handed out
         self.update_count = 0                           # merge passes issued (two orientations each)
 
@@ -86,6 +86,16 @@ class PCSR:
         self._emitted = {}
         self.update_count += 1
 
+    def merge_sorted(self, add_keys, del_keys) -> None:
+        """Fast path for update batches that were packed + sorted up front (``kernels.edgeset_pack_sorted``,
+        graph orientation): adds and deletes of one timestamp in two scatter passes."""
+        self._flush()
+        if add_keys[0].numel() == 0 and del_keys[0].numel() == 0:
+            return
+        self._set = kernels.edgeset_merge(self._set, add_keys, del_keys)
+        self._emitted = {}
+        self.update_count += 1
+
     def label_edges(self) -> None:
         """Labels are positions in the sorted key array: nothing to compute (pcsr.cu:745-757 walks the PMA)."""
         self._flush()
@@ -106,10 +116,7 @@ class PCSR:
         return hit
 
     def _publish(self, reverse: bool) -> float:
-        csr, eids1, _ = self._emit(reverse)
-        self._published = (csr.row_offset, csr.column_indices, eids1, csr.node_ids)
-        for t in self._published:
-            _LIVE[t.data_ptr()] = t
+        self._published = self._emit(reverse)
         return 0.0                                       # "move to GPU" time: there is no transfer
 
     def build_csr(self) -> float:
@@ -119,20 +126,26 @@ class PCSR:
         return self._publish(True)
 
     def get_csr_ptrs(self):
+        """(row_offset, column_indices, eids, node_ids) device addresses of the last build, eids 1-based as in
+        the reference (pcsr.cu:888-895).  Asking for them emits the labels."""
         if self._published is None:
             self._publish(False)
-        return tuple(int(t.data_ptr()) for t in self._published)
+        c = self._published
+        arrays = (c.row_offset, c.column_indices, c.eids1, c.node_ids)
+        for t in arrays:
+            _LIVE[t.data_ptr()] = t
+        return tuple(int(t.data_ptr()) for t in arrays)
 
-    def csr(self, reverse: bool = False) -> kernels.DeviceCSR:
-        """The CSR as the launch wrappers take it (0-based eids); emitted on first use per edge set."""
-        return self._emit(reverse)[0]
+    def csr(self, reverse: bool = False) -> kernels.StoreCSR:
+        """The CSR as the launch wrappers take it (0-based eids, emitted lazily); one emission per edge set."""
+        return self._emit(reverse)
 
     def labels(self, reverse: bool = False) -> torch.Tensor:
         """1-based edge labels in CSR order (what the reference's ``eids`` array holds)."""
-        return self._emit(reverse)[1]
+        return self._emit(reverse).eids1
 
     def row_lengths(self, reverse: bool = False) -> torch.Tensor:
-        return self._emit(reverse)[2]
+        return self._emit(reverse).degrees
 
     # -- the pybind attributes -----------------------------------------------------------------------------
     @property

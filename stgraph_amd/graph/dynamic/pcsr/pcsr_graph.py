@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .... import kernels
-from ...static.csr import default_device
+from ...static.csr import _LIVE, default_device
 from ...static.static_graph import edge_arrays
 from ..dynamic_graph import DynamicGraph
 from .pcsr import PCSR
@@ -34,6 +34,7 @@ def _keys(edges) -> np.ndarray:
 
 class PCSRGraph(DynamicGraph):
     def __init__(self, edge_list, max_num_nodes: int, device=None) -> None:
+        self._ptr_src = {}
         super().__init__(edge_list, max_num_nodes)
         self._device = torch.device(device) if device is not None else default_device()
         t0 = time.time()
@@ -45,7 +46,11 @@ class PCSRGraph(DynamicGraph):
             cur = _keys(edge_list[t])
             add = np.setdiff1d(cur, prev, assume_unique=True)
             dele = np.setdiff1d(prev, cur, assume_unique=True)
-            self._updates.append({"add": self._to_device(add), "delete": self._to_device(dele)})
+            u = {"add": self._to_device(add), "delete": self._to_device(dele)}
+            if self._device.type == "cuda":       # packed + sorted once, here; a step is then two scatter passes
+                u["add_keys"] = kernels.edgeset_pack_sorted(*u["add"], self._device)
+                u["delete_keys"] = kernels.edgeset_pack_sorted(*u["delete"], self._device)
+            self._updates.append(u)
             self._distinct_edges[t] = int(cur.shape[0])
             ever = np.union1d(ever, add)
             prev = cur
@@ -103,11 +108,18 @@ class PCSRGraph(DynamicGraph):
         return self._forward_graph.row_lengths(False)
 
     def _get_graph_csr_ptrs(self, *_):
-        p = self._forward_graph.get_csr_ptrs()
-        if self._is_backprop_state:
-            self.bwd_row_offset_ptr, self.bwd_column_indices_ptr, self.bwd_eids_ptr, self.bwd_node_ids_ptr = p
-        else:
-            self.fwd_row_offset_ptr, self.fwd_column_indices_ptr, self.fwd_eids_ptr, self.fwd_node_ids_ptr = p
+        """Remember which build the eight ``fwd_*/bwd_*_ptr`` attributes refer to; the addresses themselves
+        (and with them the 1-based label array) are produced when an attribute is read."""
+        self._ptr_src["bwd" if self._is_backprop_state else "fwd"] = self._forward_graph._published
+
+    def _ptrs(self, side: str):
+        c = self._ptr_src.get(side)
+        if c is None:
+            return (None, None, None, None)
+        arrays = (c.row_offset, c.column_indices, c.eids1, c.node_ids)
+        for t in arrays:
+            _LIVE[t.data_ptr()] = t
+        return tuple(int(t.data_ptr()) for t in arrays)
 
     def _on_timestamp_change(self) -> None:
         if self._is_backprop_state:
@@ -116,17 +128,21 @@ class PCSRGraph(DynamicGraph):
             self._forward_graph.build_csr()
         self._get_graph_csr_ptrs()
 
-    def _apply(self, add, dele) -> None:
+    def _apply(self, u: dict, inverse: bool = False) -> None:
         g = self._forward_graph
-        g.edge_update_list(add, is_reverse_edge=True)
-        g.edge_update_list(dele, is_delete=True, is_reverse_edge=True)
+        a, d = ("delete", "add") if inverse else ("add", "delete")
+        if "add_keys" in u:
+            g.merge_sorted(u[a + "_keys"], u[d + "_keys"])
+        else:
+            g.edge_update_list(u[a], is_reverse_edge=True)
+            g.edge_update_list(u[d], is_delete=True, is_reverse_edge=True)
         g.label_edges()
 
     def _update_graph_forward(self) -> None:
         t = self.current_timestamp + 1
         if t >= self._num_timestamps:
             raise RuntimeError("⏰ Invalid timestamp during STGraphBase.update_graph_forward()")
-        self._apply(self._updates[t]["add"], self._updates[t]["delete"])
+        self._apply(self._updates[t])
         self.move_to_gpu_time += self._forward_graph.build_csr()
         self._get_graph_csr_ptrs()
 
@@ -138,7 +154,7 @@ class PCSRGraph(DynamicGraph):
         t = self.current_timestamp
         if t <= 0:
             raise RuntimeError("⏰ Invalid timestamp during STGraphBase.update_graph_backward()")
-        self._apply(self._updates[t]["delete"], self._updates[t]["add"])     # undo the step t-1 -> t
+        self._apply(self._updates[t], inverse=True)                          # undo the step t-1 -> t
         self.move_to_gpu_time += self._forward_graph.build_reverse_csr()
         self._get_graph_csr_ptrs()
 
@@ -150,3 +166,18 @@ class PCSRGraph(DynamicGraph):
 
     def check(self) -> None:
         self._forward_graph.check()
+
+
+def _ptr_property(side: str, index: int):
+    def get(self):
+        return self._ptrs(side)[index]
+
+    def set_(self, value):          # STGraphBase.__init__ assigns None to all eight
+        if value is not None:
+            raise AttributeError("PCSRGraph publishes its own CSR pointers")
+    return property(get, set_)
+
+
+for _side in ("fwd", "bwd"):
+    for _i, _name in enumerate(("row_offset", "column_indices", "eids", "node_ids")):
+        setattr(PCSRGraph, f"{_side}_{_name}_ptr", _ptr_property(_side, _i))

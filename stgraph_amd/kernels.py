@@ -261,7 +261,8 @@ class EdgeSet:
 
 
 _STATUS_TEXT = {1: "vertex id out of range", 2: "added edge already present (or repeated in the batch)",
-                4: "deleted edge absent (or repeated in the batch)", 8: "edge added and deleted in the same update"}
+                4: "deleted edge absent (or repeated in the batch)", 8: "edge added and deleted in the same update",
+                16: "pre-sorted batch is not ascending"}
 
 
 def edgeset_empty(num_nodes: int, device) -> EdgeSet:
@@ -301,6 +302,35 @@ def edgeset_update(es: EdgeSet, add_src, add_dst, del_src=None, del_dst=None) ->
     return EdgeSet(N, kf, kb, status)
 
 
+def edgeset_pack_sorted(src, dst, device):
+    """An update batch packed and sorted in both orientations (int64 key tensors), ready for
+    :func:`edgeset_merge`.  Done once per batch (a PCSRGraph does it at construction)."""
+    device = torch.device(device)
+    s, d = _as_i32(src, device).long(), _as_i32(dst, device).long()
+    return torch.sort((d << 32) | s).values, torch.sort((s << 32) | d).values
+
+
+def edgeset_merge(es: EdgeSet, add_keys, del_keys) -> EdgeSet:
+    """(es \\ del) U add from batches already packed + sorted (``edgeset_pack_sorted``): two scatter
+    passes (stg_edgeset_merge_device), no sort, no workspace."""
+    device, N, E = es.device, es.num_nodes, es.num_edges
+    if device.type != "cuda":
+        raise ValueError("edgeset_merge is the device fast path; use edgeset_update on host arrays")
+    na, nd = int(add_keys[0].shape[0]), int(del_keys[0].shape[0])
+    if E + na - nd < 0:
+        raise ValueError("more deletions than edges")
+    kf = torch.empty(E + na - nd, dtype=torch.int64, device=device)
+    kb = torch.empty(E + na - nd, dtype=torch.int64, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        st = _stream_ptr(device)
+        _C.check(_C.lib.stg_edgeset_merge_device(_ptr(es.keys_fwd), E, _ptr(add_keys[0]), na, _ptr(del_keys[0]), nd,
+                                                 _ptr(kf), _ptr(status), st))
+        _C.check(_C.lib.stg_edgeset_merge_device(_ptr(es.keys_bwd), E, _ptr(add_keys[1]), na, _ptr(del_keys[1]), nd,
+                                                 _ptr(kb), _ptr(status), st))
+    return EdgeSet(N, kf, kb, status)
+
+
 def edgeset_check(es: EdgeSet) -> None:
     """Raise if the update that produced ``es`` violated the stream contract (synchronises)."""
     if es.status is None:
@@ -311,16 +341,38 @@ def edgeset_check(es: EdgeSet) -> None:
         raise ValueError(f"invalid edge update stream: {what} (libstgraph_hip status {code})")
 
 
-def edgeset_emit_csr(es: EdgeSet, reverse: bool):
-    """The CSR the reference's ``build_csr`` (``reverse=False``, rows = dst) / ``build_reverse_csr``
-    (rows = src) emits for this edge set (pcsr.cu:781-879): returns ``(DeviceCSR with 0-based eids,
-    eids1 = the 1-based labels, degrees)``."""
+class StoreCSR(DeviceCSR):
+    """CSR emitted from an :class:`EdgeSet`.  Structure (row_offset, column_indices, node_ids, degrees)
+    is emitted eagerly; the edge labels -- ``eids`` (0-based, what the launch wrappers index edge
+    tensors with) and ``eids1`` (the reference's 1-based array) -- on first access: the un-weighted GCN
+    kernels never read them, and for the reverse CSR they cost a search per edge."""
+
+    def __init__(self, es: EdgeSet, reverse: bool, row_offset, column_indices, node_ids, degrees):
+        self.row_offset, self.column_indices, self.node_ids, self.degrees = row_offset, column_indices, node_ids, degrees
+        self._es, self._reverse, self._labels = es, bool(reverse), None
+
+    def _emit_labels(self):
+        if self._labels is None:
+            E = self._es.num_edges
+            i32 = dict(dtype=torch.int32, device=self.row_offset.device)
+            e1, e0 = torch.empty(E, **i32), torch.empty(E, **i32)
+            _emit(self._es, self._reverse, self.row_offset, None, e1, e0, None, None)
+            self._labels = (e1, e0)
+        return self._labels
+
+    @property
+    def eids(self) -> torch.Tensor:
+        return self._emit_labels()[1]
+
+    @property
+    def eids1(self) -> torch.Tensor:
+        return self._emit_labels()[0]
+
+
+def _emit(es: EdgeSet, reverse: bool, row_offset, col, eids1, eids0, node_ids, degrees) -> None:
     device, N, E = es.device, es.num_nodes, es.num_edges
-    i32 = dict(dtype=torch.int32, device=device)
-    csr = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32))
-    eids1, deg = torch.empty(E, **i32), torch.empty(N, **i32)
-    args = [_ptr(es.keys_fwd), _ptr(es.keys_bwd), E, N, int(bool(reverse)), _ptr(csr.row_offset),
-            _ptr(csr.column_indices), _ptr(eids1), _ptr(csr.eids), _ptr(csr.node_ids), _ptr(deg)]
+    args = [_ptr(es.keys_fwd), _ptr(es.keys_bwd), E, N, int(bool(reverse)), _ptr(row_offset), _ptr(col),
+            _ptr(eids1), _ptr(eids0), _ptr(node_ids), _ptr(degrees)]
     if device.type == "cuda":
         ws_bytes = int(_C.lib.stg_edgeset_emit_csr_workspace_bytes(N))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
@@ -328,7 +380,16 @@ def edgeset_emit_csr(es: EdgeSet, reverse: bool):
             _C.check(_C.lib.stg_edgeset_emit_csr_device(*args, _ptr(ws), ws_bytes, _stream_ptr(device)))
     else:
         _C.check(_C.lib.stg_edgeset_emit_csr_host(*args))
-    return csr, eids1, deg
+
+
+def edgeset_emit_csr(es: EdgeSet, reverse: bool) -> StoreCSR:
+    """The CSR the reference's ``build_csr`` (``reverse=False``, rows = dst) / ``build_reverse_csr``
+    (rows = src) emits for this edge set (pcsr.cu:781-879), as a :class:`StoreCSR`."""
+    device, N, E = es.device, es.num_nodes, es.num_edges
+    i32 = dict(dtype=torch.int32, device=device)
+    ro, col, nid, deg = torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
+    _emit(es, reverse, ro, col, None, None, nid, deg)
+    return StoreCSR(es, reverse, ro, col, nid, deg)
 
 
 def rows_by_node_ids(graph_type: str) -> bool:

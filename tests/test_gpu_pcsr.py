@@ -117,7 +117,8 @@ def test_update_equals_rebuild_at_scale(cuda, n, e, churn):
     assert torch.equal(back.keys_fwd, base.keys_fwd) and torch.equal(back.keys_bwd, base.keys_bwd)
     g = kernels.build_graph_csr(src[:-k], dst[:-k], n, cuda)
     for rev, side in ((False, g.fwd), (True, g.bwd)):
-        csr, eids1, deg = kernels.edgeset_emit_csr(new, rev)
+        csr = kernels.edgeset_emit_csr(new, rev)
+        eids1, deg = csr.eids1, csr.degrees
         col, eid = _reversed_rows(side)
         assert torch.equal(csr.row_offset, side.row_offset)
         assert torch.equal(csr.column_indices, col) and torch.equal(eids1, eid + 1) and torch.equal(csr.eids, eid)
@@ -128,7 +129,7 @@ def test_update_equals_rebuild_at_scale(cuda, n, e, churn):
     # the aggregation over the emitted CSR equals the one over the static CSR up to summation order
     x = torch.randn(n, 8, device=cuda)
     norm = torch.rand(n, 1, device=cuda)
-    a = kernels.gcn_agg(x, norm, norm, kernels.edgeset_emit_csr(new, False)[0], use_node_ids=True)
+    a = kernels.gcn_agg(x, norm, norm, kernels.edgeset_emit_csr(new, False), use_node_ids=True)
     b = kernels.gcn_agg(x, norm, norm, g.fwd)
     torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
 

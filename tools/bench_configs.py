@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from bench import GCN, HBM_PEAK_GBS, cora_run, cora_shaped, degree_norm, synthetic_graph
 from stgraph_amd import kernels, temporal
-from stgraph_amd.graph import NaiveGraph, StaticGraph
+from stgraph_amd.graph import NaiveGraph, PCSRGraph, StaticGraph
 
 
 def kernel_table(records):
@@ -104,8 +104,9 @@ def cfg5(dev, epochs=6):
         pn_edges.append(torch.cat([pos, neg], 1))
         pn_targets.append(torch.cat([torch.ones(m, device=dev), torch.zeros(m, device=dev)]))
     out = {}
-    for mode, kw in (("rebuild_per_snapshot", dict(resident=False, max_cached=B + 1)), ("resident", dict(resident=True))):
-        G = NaiveGraph(snaps, n, device=dev, sort_inplace=False, **kw)
+    for mode, kw in (("rebuild_per_snapshot", dict(resident=False, max_cached=B + 1)), ("resident", dict(resident=True)),
+                     ("pcsr_store", None)):
+        G = PCSRGraph(snaps, n, device=dev) if kw is None else NaiveGraph(snaps, n, device=dev, sort_inplace=False, **kw)
         torch.manual_seed(4)
         model = temporal.DynamicSTGraphTGCN(feat, hid).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-2)
@@ -115,11 +116,17 @@ def cfg5(dev, epochs=6):
             if mode == "rebuild_per_snapshot":
                 G._snapshots.clear()
                 G._ndata.clear()
+            if mode == "pcsr_store":
+                G._ndata.clear()
+                G.build_count, G.build_time = G._forward_graph.update_count, 0.0
             b0, bt0 = G.build_count, G.build_time
             torch.cuda.synchronize()
             t0 = time.time()
             temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep)
             torch.cuda.synchronize()
+            if mode == "pcsr_store":
+                G.build_count = G._forward_graph.update_count
+                G.check()
             if ep >= 3:
                 dur.append((time.time() - t0, G.build_count - b0, G.build_time - bt0))
         out[mode] = {"epochs_per_s": 1.0 / float(np.mean([d[0] for d in dur])),
@@ -153,12 +160,52 @@ def csr_build_cfg2(dev):
             "algorithmic_bytes": 2 * 16 * e, "GBps": 2 * 16 * e / dt / 1e9}
 
 
+def edge_store_cfg2(dev):
+    """Dynamic edge store at |V|=1M, |E|=16M with 5 % churn per step: one update (both orientations),
+    forward emit, reverse emit (structure: 8 B key read + 4 B column written per edge), labels on demand.
+    Algorithmic bytes of an update = 2 orientations x (8 B read + 8 B written) per stored edge."""
+    n, e, k = 1_000_000, 16_000_000, 800_000
+    src, dst = synthetic_graph(n, e + k, 1, dev)
+    base = kernels.edgeset_update(kernels.edgeset_empty(n, dev), src[:e], dst[:e])
+    kernels.edgeset_check(base)
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+
+    def timed(fn, iters=10):
+        fn()
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+    upd = timed(lambda: kernels.edgeset_update(base, src[e:], dst[e:], src[:k], dst[:k]))
+    new = kernels.edgeset_update(base, src[e:], dst[e:], src[:k], dst[:k])
+    kernels.edgeset_check(new)
+    ak, dk = kernels.edgeset_pack_sorted(src[e:], dst[e:], dev), kernels.edgeset_pack_sorted(src[:k], dst[:k], dev)
+    mrg = timed(lambda: kernels.edgeset_merge(base, ak, dk))
+    m = kernels.edgeset_merge(base, ak, dk)
+    kernels.edgeset_check(m)
+    assert torch.equal(m.keys_fwd, new.keys_fwd) and torch.equal(m.keys_bwd, new.keys_bwd)
+    fwd = timed(lambda: kernels.edgeset_emit_csr(new, False))
+    bwd = timed(lambda: kernels.edgeset_emit_csr(new, True))
+    lab_f = timed(lambda: kernels.edgeset_emit_csr(new, False).eids) - fwd
+    lab_b = timed(lambda: kernels.edgeset_emit_csr(new, True).eids) - bwd
+    full = timed(lambda: kernels.build_graph_csr(src[k:], dst[k:], n, dev), 5)
+    return {"config": f"dynamic edge store |V|={n} |E|={e} +-{k} edges per step",
+            "update_unsorted_lists_ms": upd, "merge_presorted_ms": mrg, "merge_GBps": 2 * 16 * e / mrg / 1e6,
+            "emit_fwd_ms": fwd, "emit_fwd_GBps": 12 * e / fwd / 1e6,
+            "emit_bwd_ms": bwd, "emit_bwd_GBps": 12 * e / bwd / 1e6,
+            "labels_fwd_ms (on demand)": lab_f, "labels_bwd_ms (on demand)": lab_b,
+            "step_forward_ms": mrg + fwd, "step_backward_ms": mrg + bwd, "full_rebuild_ms (NaiveGraph path: 2 radix sorts)": full}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="cfg1,cfg3,cfg5,csr")
+    ap.add_argument("--only", default="cfg1,cfg3,cfg5,csr,store")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    fns = {"cfg1": cfg1, "cfg3": cfg3, "cfg5": cfg5, "csr": csr_build_cfg2}
+    fns = {"cfg1": cfg1, "cfg3": cfg3, "cfg5": cfg5, "csr": csr_build_cfg2, "store": edge_store_cfg2}
     for k in args.only.split(","):
         print(json.dumps(fns[k](dev)), flush=True)
         torch.cuda.empty_cache()
