@@ -30,6 +30,7 @@ extern "C" {
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
 #define STG_ERR_VERTEX_RANGE     10003   /* an edge endpoint is outside [0, N)       */
 #define STG_ERR_WORKSPACE        10004   /* workspace too small                       */
+#define STG_ERR_JIT              10005   /* run-time compilation of a generated kernel failed */
 
 int         stg_abi_version(void);
 const char *stg_last_error_string(void);
@@ -144,6 +145,27 @@ int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint64_t *keys_b
 int stg_edgeset_emit_csr_host(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
                               int reverse, int32_t *row_offset, int32_t *column_indices,
                               int32_t *eids1, int32_t *eids0, int32_t *node_ids, int32_t *degrees);
+
+/* ------------------------------------------------------- JIT for generated kernels
+ * Replaces the reference's run-time kernel build and launch for vertex functions
+ * that are not one of the hand-written units: nvcc -> PTX (compiler/code_gen/
+ * compiler.py:14-44), cuModuleLoadData / cuModuleGetFunction (compiler/
+ * execution_unit.py:241-269) and cuLaunchKernel (execution_unit.py:359-372).
+ * The HIP source is generated by stgraph_amd/compiler/codegen.py from the traced GIR.
+ *
+ * stg_jit_compile: hiprtc, --offload-arch=gfx950 -O3 -ffp-contract=off; needs no GPU.
+ *   *code_out (malloc'ed code object, release with stg_jit_free), optional *log_out.
+ * stg_jit_load / stg_jit_get_function / stg_jit_unload: hipModule API on the
+ *   current device.  stg_jit_launch: 1-D launch; the generated kernels take
+ *   n_ptr pointer arguments followed by n_int int32 arguments.
+ */
+int  stg_jit_compile(const char *source, const char *name, char **code_out, size_t *code_size_out, char **log_out);
+void stg_jit_free(void *p);
+int  stg_jit_load(const void *code, void **module_out);
+int  stg_jit_get_function(void *module, const char *name, void **function_out);
+int  stg_jit_unload(void *module);
+int  stg_jit_launch(void *function, uint32_t grid, uint32_t block, const void *const *ptr_args, int32_t n_ptr,
+                    const int32_t *int_args, int32_t n_int, void *stream);
 
 /* ------------------------------------------------------- fused GCN aggregation
  * Replaces the compiler-emitted FA kernels K0/K1 of GCNConv (tracer

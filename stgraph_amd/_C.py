@@ -19,6 +19,7 @@ STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
 STG_ERR_VERTEX_RANGE = 10003
 STG_ERR_WORKSPACE = 10004
+STG_ERR_JIT = 10005
 
 # every symbol include/stgraph_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = (
@@ -27,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
     "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host", "stg_edgeset_merge_device",
     "stg_edgeset_emit_csr_workspace_bytes", "stg_edgeset_emit_csr_device", "stg_edgeset_emit_csr_host",
+    "stg_jit_compile", "stg_jit_free", "stg_jit_load", "stg_jit_get_function", "stg_jit_unload", "stg_jit_launch",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_rowgemm_supported", "stg_rowgemm_f32",
@@ -78,6 +80,19 @@ def _load() -> ctypes.CDLL:
     lib.stg_edgeset_emit_csr_device.argtypes = [vp, vp, i64, i32, ctypes.c_int] + [vp] * 6 + [vp, ctypes.c_size_t, vp]
     lib.stg_edgeset_emit_csr_host.restype = ctypes.c_int
     lib.stg_edgeset_emit_csr_host.argtypes = [vp, vp, i64, i32, ctypes.c_int] + [vp] * 6
+    lib.stg_jit_compile.restype = ctypes.c_int
+    lib.stg_jit_compile.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t),
+                                    ctypes.POINTER(vp)]
+    lib.stg_jit_free.restype = None
+    lib.stg_jit_free.argtypes = [vp]
+    lib.stg_jit_load.restype = ctypes.c_int
+    lib.stg_jit_load.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.stg_jit_get_function.restype = ctypes.c_int
+    lib.stg_jit_get_function.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp)]
+    lib.stg_jit_unload.restype = ctypes.c_int
+    lib.stg_jit_unload.argtypes = [vp]
+    lib.stg_jit_launch.restype = ctypes.c_int
+    lib.stg_jit_launch.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, i32, vp, i32, vp]
     lib.stg_gcn_agg.restype = ctypes.c_int
     lib.stg_gcn_agg.argtypes = [vp] * 9 + [i32, i32, i32, vp]
     lib.stg_gcn_agg_edge.restype = ctypes.c_int

@@ -9,8 +9,8 @@ Multiplication order matters for bit-level parity, so patterns match the exact
 association the reference would emit (operands of one ``Mul`` may be swapped --
 that does not change the rounding -- but ``(a*b)*c`` is not ``a*(b*c)``).
 
-Anything else raises ``NotImplementedError`` with the traced program: there is no
-interpreter fallback (generic code generation is the "next" row of SURVEY.md 8(f)).
+Any other vertex function goes to the code generator (``codegen.py``: GIR -> HIP source ->
+hiprtc), which plays the role of the reference's fusion + autodiff + template pipeline.
 """
 from __future__ import annotations
 
@@ -176,9 +176,19 @@ def _match_gat(ret: Node):
     return GatPlan(el.name, er.name, feat.name, float(slope)), [el, er, feat]
 
 
+_FORCE_GENERATED = False
+
+
+def set_force_generated(enabled: bool) -> None:
+    """Testing aid: route EVERY vertex function (also the GCN / GAT ones) through the code generator."""
+    global _FORCE_GENERATED
+    _FORCE_GENERATED = bool(enabled)
+
+
 def make_plan(rets: list, program) -> object:
-    """Return the kernel plan for a traced vertex function, or raise NotImplementedError."""
-    if len(rets) == 1:
+    """The kernel plan of a traced vertex function: the hand-written units where the GIR is one of theirs,
+    generated kernels (``codegen.GenericPlan``) for everything else."""
+    if len(rets) == 1 and not _FORCE_GENERATED:
         for matcher in (_match_gcn, _match_gat):
             hit = matcher(rets[0])
             if hit is not None:
@@ -190,9 +200,10 @@ def make_plan(rets: list, program) -> object:
                         f"gradient w.r.t. {sorted(unsupported)} is not emitted by the '{plan.name}' kernels "
                         "(the reference scripts never request it); detach() those inputs")
                 return plan
-    raise NotImplementedError(
-        "this vertex function does not map onto the hand-written MI355X kernels.\n"
-        "Supported (SURVEY.md Appendix B): GCN  sum([nb.h * nb.norm for nb in v.innbs]) * v.norm ; "
-        "GCN with edge weight  sum([e.src.norm * e.src.h * e.w for e in v.inedges]) * v.norm ; "
-        "GAT  edge-softmax aggregation of gat_conv.py.\nTraced program:\n" + str(program) +
-        "\nreturn: " + ", ".join(r.key for r in rets))
+    from .codegen import GenericPlan
+    try:
+        return GenericPlan(rets, program)
+    except NotImplementedError as e:
+        raise NotImplementedError(
+            f"this vertex function cannot be compiled for the MI355X yet: {e}\nTraced program:\n" + str(program) +
+            "\nreturn: " + ", ".join(r.key for r in rets)) from e
