@@ -257,10 +257,13 @@ def _canonical_cond(shape: tuple, full: tuple) -> str | None:
 
 
 def _lit(v) -> str:
+    """Constants as the reference's emitter prints them (registry.py: the Python value is formatted into the
+    CUDA text): integral values are int literals (float arithmetic), anything else is a DOUBLE literal, so
+    ``x * 0.2`` is a double multiply rounded once on assignment -- kept for bit parity."""
     f = float(v)
     if f == int(f) and abs(f) < 1e9:
-        return f"{int(f)}.0f"
-    return f"{f!r}f"
+        return f"{int(f)}"
+    return repr(f)
 
 
 @dataclass
@@ -348,13 +351,13 @@ def _op_code(n: Node, a: list) -> str:
         return f"expf({a[0]})"
     slope = dict(n.params).get("negative_slope", 0.01)
     if n.op == "LeakyRelu":
-        return f"{a[0]} > 0.0f ? {a[0]} : {_lit(slope)} * {a[0]}"
+        return f"{a[0]} > 0 ? {a[0]} : {_lit(slope)} * {a[0]}"
     if n.op == "Relu":
-        return f"{a[0]} > 0.0f ? {a[0]} : 0.0f"
+        return f"{a[0]} > 0 ? {a[0]} : 0"
     if n.op == "BwdLeakyRelu":
-        return f"{a[0]} > 0.0f ? 1.0f : {_lit(slope)}"
+        return f"{a[0]} > 0 ? 1 : {_lit(slope)}"
     if n.op == "BwdRelu":
-        return f"{a[0]} > 0.0f ? {a[1]} : 0.0f"
+        return f"{a[0]} > 0 ? {a[1]} : 0"
     raise NotImplementedError(f"no code for op {n.op}")
 
 

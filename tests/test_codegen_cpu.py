@@ -1,0 +1,103 @@
+"""CPU half of the code-generator tests: (i) the plain-torch vertex-function evaluator used as the GPU tests'
+reference reproduces what the REFERENCE's compiler computed for the same functions (tests/golden/codegen.npz,
+recorded from the reference's emitted kernels); (ii) placement / reverse mode / emission produce the
+expected units and the generated HIP compiles for gfx950 (hiprtc needs no GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import eval_vertex_function, golden, trace_vertex_function
+
+LEAKY = torch.nn.LeakyReLU(0.2)
+GOLDEN_FUNCTIONS = {
+    "mean": lambda v: sum([nb.h for nb in v.innbs]) / v.deg,
+    "relu_gcn": lambda v: torch.relu(sum([nb.h * nb.norm for nb in v.innbs]) * v.norm),
+    "leaky_edge": lambda v: sum([torch.nn.functional.leaky_relu(e.src.h * e.w, 0.2) for e in v.inedges]),
+    "two_level": lambda v: sum([nb.h * sum([n2.g for n2 in v.innbs]) for nb in v.innbs]),
+}
+
+
+def golden_case(name, device="cpu", dtype=torch.float64):
+    """Inputs of one recorded function + the edge endpoints by eid ((dst, src)-sorted rank, as StaticGraph assigns)."""
+    d = golden("codegen.npz")
+    assert name in d["functions"]
+    n = int(d["num_nodes"])
+    src, dst = d["src"].astype(np.int64), d["dst"].astype(np.int64)
+    order = np.lexsort((src, dst))
+    src_e, dst_e = torch.from_numpy(src[order]).to(device), torch.from_numpy(dst[order]).to(device)
+    nf, ef = {}, {}
+    for k in d.files:
+        if k.startswith(f"{name}_in_"):
+            key = k[len(name) + 4:]
+            t = torch.from_numpy(d[k]).to(device=device, dtype=dtype)
+            t.requires_grad_(f"{name}_grad_{key}" in d.files)
+            (ef if t.shape[0] == len(src) and key in ("w", "b") else nf)[key] = t
+    return d, n, src_e, dst_e, nf, ef
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_FUNCTIONS))
+def test_torch_evaluator_reproduces_the_reference_compiler(name):
+    d, n, src_e, dst_e, nf, ef = golden_case(name)
+    (out,) = eval_vertex_function(GOLDEN_FUNCTIONS[name], src_e, dst_e, n, nf, ef)
+    np.testing.assert_allclose(out.detach().numpy(), d[f"{name}_out"], rtol=1e-5, atol=1e-5)
+    (out * torch.from_numpy(d[f"{name}_R"]).double()).sum().backward()
+    for k, t in {**nf, **ef}.items():
+        if (name, k) == ("two_level", "g"):
+            # the reference's reverse mode is wrong for the input of the INNER aggregation (its grad_g is off by
+            # O(10); forward and grad_h agree) -- DESIGN.md D16.  torch autograd is the reference there.
+            assert np.abs(t.grad.numpy() - d[f"{name}_grad_{k}"]).max() > 1.0
+            continue
+        if t.requires_grad:
+            np.testing.assert_allclose(t.grad.numpy(), d[f"{name}_grad_{k}"], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def _plan(fn, nshapes, eshapes, diff):
+    from stgraph_amd.compiler.codegen import GenericPlan
+    nf = {k: torch.zeros((3,) + s, requires_grad=k in diff) for k, s in nshapes.items()}
+    ef = {k: torch.zeros((5,) + s, requires_grad=k in diff) for k, s in eshapes.items()}
+    rets, prog = trace_vertex_function(fn, nf, ef)
+    return GenericPlan(rets, prog)
+
+
+def test_units_of_generated_plans():
+    from stgraph_amd.compiler.gir import ValType
+    # GCN: one dst-parallel forward unit, one src-parallel backward unit (the reference's K0 / K1)
+    p = _plan(lambda v: sum([nb.h * nb.norm for nb in v.innbs]) * v.norm, {"h": (16,), "norm": (1,)}, {}, ["h"])
+    assert [(k.row_type, k.has_loop) for k in p.fwd_kernels] == [(ValType.DEST, True)]
+    assert [(k.row_type, k.has_loop) for k in p.bwd_kernels] == [(ValType.SRC, True)]
+    assert not p.fwd_kernels[0].uses_eids and p.saved_nodes == []
+    # a value read at both ends of the edge: per-source gradient over out-edges, per-destination over in-edges
+    p = _plan(lambda v: sum([torch.exp(nb.h - v.h) for nb in v.innbs]), {"h": (8,)}, {}, ["h"])
+    assert sorted(k.row_type.name for k in p.bwd_kernels) == ["DEST", "SRC"]
+    # nested aggregation: two forward stages, the first one's result is materialised and saved for backward
+    p = _plan(lambda v: sum([nb.h * sum([n2.g for n2 in v.innbs]) for nb in v.innbs]), {"h": (8,), "g": (8,)}, {}, ["h", "g"])
+    assert [k.stage for k in p.fwd_kernels] == [0, 1] and len(p.saved_nodes) == 1
+    # per-edge inputs: eids are read, their gradients are per-edge writes
+    p = _plan(lambda v: sum([e.src.h * e.w + e.b for e in v.inedges]), {"h": (8,)}, {"w": (1,), "b": (8,)}, ["h", "w", "b"])
+    assert p.fwd_kernels[0].uses_eids and any(k.name.endswith("_edge") for k in p.bwd_kernels)
+    assert p.differentiable() == [("e", "b"), ("e", "w"), ("n", "h")]
+    # broadcast [H,1] x [H,D]: lanes enumerate H*D features
+    p = _plan(lambda v: sum([nb.a * nb.f for nb in v.innbs]), {"a": (4, 1), "f": (4, 8)}, {}, ["a", "f"])
+    assert p.fwd_kernels[0].lanes_per_row == 32 and "tx / 8" in p.fwd_kernels[0].source
+    # no differentiable input: no backward kernels at all
+    p = _plan(lambda v: sum([nb.h for nb in v.innbs]), {"h": (8,)}, {}, [])
+    assert p.bwd_kernels == [] and "expf" not in p.source
+
+
+def test_unsupported_constructs_fail_loudly():
+    from stgraph_amd.compiler.dispatch import make_plan
+    w = torch.nn.Parameter(torch.ones(8))
+    nf = {"h": torch.zeros(3, 8)}
+    rets, prog = trace_vertex_function(lambda v: sum([nb.h * w for nb in v.innbs]), nf, {})
+    with pytest.raises(NotImplementedError, match="module parameters"):
+        make_plan(rets, prog)
+    with pytest.raises(NotImplementedError):
+        trace_vertex_function(lambda v: sum([torch.tanh(nb.h) for nb in v.innbs]), nf, {})
+
+
+def test_jit_reports_compile_errors():
+    import ctypes
+    from stgraph_amd import _C
+    code, size = ctypes.c_void_p(), ctypes.c_size_t()
+    rc = _C.lib.stg_jit_compile(b"this is not HIP", b"bad.hip", ctypes.byref(code), ctypes.byref(size), None)
+    assert rc == _C.STG_ERR_JIT and b"error" in _C.lib.stg_last_error_string()
