@@ -462,6 +462,9 @@ def _finish(em: _Emitter, init: list, edge_lines: list, post: list, has_loop: bo
     body.append(f"    for (int tx = (int)(threadIdx.x % {G}); tx < {fmax}; tx += {G}) {{")
     body += ["        " + s for s in init]
     if has_loop:
+        # unrolled so that the column / eid / gather loads of several edges are in flight together; the adds stay
+        # in CSR order (no reassociation without fast-math), so the sums are unchanged
+        body.append("#pragma unroll 4")
         body.append("        for (int e = beg; e < end; ++e) {")
         body.append(ind + "const int c = col_idx[e]; (void)c;")
         if em.uses_eids:
