@@ -624,7 +624,7 @@ class GenericPlan:
         for key in spec.tensors:
             t = env[key]
             if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
-                raise ValueError("generated kernels take contiguous fp32 HIP tensors (no CPU fallback)")
+                raise RuntimeError("generated kernels take contiguous fp32 HIP tensors (no CPU fallback)")
             ptrs.append(t.data_ptr())
         eids = csr.eids if spec.uses_eids else None
         ptrs += [csr.row_offset.data_ptr(), csr.column_indices.data_ptr(), eids.data_ptr() if eids is not None else 0,
@@ -644,7 +644,7 @@ class GenericPlan:
         for kind, name in self._inputs:
             t = (e_feats if kind == "e" else n_feats)[name]
             if not t.is_cuda:
-                raise ValueError("stgraph_amd has no CPU fallback: vertex-function inputs must be HIP tensors")
+                raise RuntimeError("stgraph_amd has no CPU fallback: vertex-function inputs must be HIP tensors")
             env[("leaf", kind, name)] = t.detach().contiguous().float()
         return env
 

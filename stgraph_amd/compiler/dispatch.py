@@ -194,11 +194,8 @@ def make_plan(rets: list, program) -> object:
             if hit is not None:
                 plan, leaves = hit
                 diff = {(("e" if l.val_type == ValType.EDGE else "n"), l.name) for l in leaves if l.requires_grad}
-                unsupported = diff - set(plan.differentiable())
-                if unsupported:
-                    raise NotImplementedError(
-                        f"gradient w.r.t. {sorted(unsupported)} is not emitted by the '{plan.name}' kernels "
-                        "(the reference scripts never request it); detach() those inputs")
+                if diff - set(plan.differentiable()):
+                    break          # e.g. d/d(norm): not one of the hand-written backward units -> generate
                 return plan
     from .codegen import GenericPlan
     try:

@@ -30,6 +30,7 @@ FUNCTIONS = {
                    {"h": (8,)}, {"w": (8,)}, ["h", "w"]),
     "two_outputs": (lambda v: (sum([nb.h for nb in v.innbs]), sum([nb.h * nb.h for nb in v.innbs]) * v.norm),
                     {"h": (8,), "norm": (1,)}, {}, ["h"]),
+    "gcn_all_grads": (lambda v: sum([nb.h * nb.norm for nb in v.innbs]) * v.norm, {"h": (16,), "norm": (1,)}, {}, ["h", "norm"]),
     "wide": (lambda v: sum([nb.h * nb.norm for nb in v.innbs]) * v.norm + v.h, {"h": (300,), "norm": (1,)}, {}, ["h"]),
 }
 
@@ -172,3 +173,32 @@ def test_generated_kernels_match_the_reference_compiler(cuda, name):
     for k, t in {**nf, **ef}.items():
         if t.requires_grad and (name, k) != ("two_level", "g"):       # reference defect D16
             np.testing.assert_allclose(t.grad.cpu().numpy(), d[f"{name}_grad_{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
+
+
+def test_forced_generation_of_gat_forward_matches_the_hand_written_units(cuda):
+    """GATConv's vertex function (gat_conv.py:48-56, incl. the emb - max([emb]) quirk) through the generator: same
+    forward as the hand-written K0/K1 units.  The BACKWARD differs on purpose: the hand-written K2 reproduces the
+    reference's emitted gradient, in which Sub passes +g to both operands, so attn_l / attn_r receive a
+    gradient although d(emb - emb) = 0; the generator differentiates correctly (grad_el = grad_er = 0), which is
+    what torch autograd gives for the same function ("softmax_like" above covers a non-degenerate softmax)."""
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    n, e = 500, 6000
+    src, dst = random_graph(21, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    x0 = torch.randn(n, 12, device=cuda)
+    res = {}
+    for forced in (False, True):
+        dispatch.set_force_generated(forced)
+        try:
+            torch.manual_seed(1)
+            conv = GATConv(12, 8, 4).to(cuda)
+            x = x0.clone().requires_grad_(True)
+            out = conv(g, x)
+            out.square().sum().backward()
+            res[forced] = (out.detach(), conv.attn_l.grad.clone(), conv.fc.weight.grad.clone())
+        finally:
+            dispatch.set_force_generated(False)
+    torch.testing.assert_close(res[False][0], res[True][0], rtol=1e-5, atol=1e-5)
+    assert float(res[True][1].abs().max()) == 0.0 and float(res[False][1].abs().max()) > 0.0
+    assert torch.isfinite(res[True][2]).all()

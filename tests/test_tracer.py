@@ -79,23 +79,33 @@ def test_gat_vertex_function_maps_to_gat_kernels():
     assert "Sub(Add(D:er[2x1],S:el[2x1]),Add(D:er[2x1],S:el[2x1]))" in str(nb_forward._executor_cache.program)
 
 
-def test_unsupported_programs_and_api_errors_fail_loudly():
+def test_other_vertex_functions_are_generated_and_api_errors_fail_loudly():
     m, g = Probe(), _graph()
 
     @m.stgraph.compile(gnn_module=m)
     def weird(v):
         return sum([nb.h * nb.h for nb in v.innbs])
 
-    with pytest.raises(NotImplementedError) as ei:
+    with pytest.raises(RuntimeError) as ei:                 # compiles (hiprtc, no GPU needed) but CPU tensors: no fallback
         weird(g=g, n_feats={"h": torch.randn(4, 3)})
-    assert "Traced program" in str(ei.value)
+    assert "no CPU fallback" in str(ei.value)
+    assert weird._executors and next(iter(weird._executors.values())).plan.name == "generated"
 
     @m.stgraph.compile(gnn_module=m)
-    def wrong_assoc(v):      # h * (norm * w) rounds differently from (norm * h) * w: not silently accepted
+    def wrong_assoc(v):      # h * (norm * w) rounds differently from (norm * h) * w: never mapped onto the GCN kernel
         return sum([e.src.h * (e.src.norm * e.w) for e in v.inedges]) * v.norm
 
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):
         wrong_assoc(g=g, n_feats={"h": torch.randn(4, 3), "norm": torch.ones(4, 1)}, e_feats={"w": torch.ones(5, 1)})
+    assert next(iter(wrong_assoc._executors.values())).plan.name == "generated"
+
+    @m.stgraph.compile(gnn_module=m)
+    def unsupported_op(v):
+        return sum([torch.tanh(nb.h) for nb in v.innbs])
+
+    with pytest.raises(NotImplementedError) as ei:          # outside the reference's op set
+        unsupported_op(g=g, n_feats={"h": torch.randn(4, 3)})
+    assert "tanh" in str(ei.value)
 
     @m.stgraph.compile(gnn_module=m)
     def nb_compute(v):
@@ -103,11 +113,14 @@ def test_unsupported_programs_and_api_errors_fail_loudly():
 
     with pytest.raises(NameError):                          # reference: compiler/stgraph.py:50-51
         nb_compute(n_feats={"h": torch.randn(4, 3), "norm": torch.ones(4, 1)})
-    with pytest.raises(NotImplementedError):                # grad w.r.t. norm is never emitted
-        nb_compute(g=g, n_feats={"h": torch.randn(4, 3), "norm": torch.ones(4, 1, requires_grad=True)})
     with pytest.raises(RuntimeError) as ei:                 # CPU tensors: no fallback
         nb_compute(g=g, n_feats={"h": torch.randn(4, 3), "norm": torch.ones(4, 1)})
     assert "no CPU fallback" in str(ei.value)
+    assert next(iter(nb_compute._executors.values())).plan.name == "gcn_agg"
+    # d/d(norm) is not one of the hand-written backward units: that signature gets generated kernels
+    with pytest.raises(RuntimeError):
+        nb_compute(g=g, n_feats={"h": torch.randn(4, 3), "norm": torch.ones(4, 1, requires_grad=True)})
+    assert sorted(e.plan.name for e in nb_compute._executors.values()) == ["gcn_agg", "generated"]
 
     @m.stgraph.compile(gnn_module=m)
     def returns_nothing(v):
