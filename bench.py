@@ -17,6 +17,9 @@ with the windows sharded over the N ranks and ONE RCCL all-reduce of the flatten
 bucket per optimizer step -- the path the north star scales to 8 GPUs ("scaling": "strong":
 the epoch is fixed, ranks split its windows).
 
+A "dynamic" object carries BASELINE configs[4] (dynamic-temporal TGCN): epochs/s with the per-snapshot device
+CSR rebuild (its `value`) and on the dynamic edge store (PCSRGraph), windows sharded over the ranks.
+
 "roofline": dominant kernel gcn_agg -- algorithmic bytes per launch over its
 mean launch time, measured with HIP events on the launch stream inside the timed region.
 "cpu_baseline": the C oracle (OpenMP port of the emitted kernel) timed on this host's cores
@@ -299,6 +302,68 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
     }
 
 
+def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, T=160, B=20, feat=32, hidden=64):
+    """BASELINE.json configs[4]: dynamic-temporal TGCN (benchmarking/dynamic-temporal-tgcn/seastar/train.py loop:
+    link prediction on a sliding window over an edge stream, un-weighted GCN gates), once with the per-snapshot
+    device CSR rebuild (NaiveGraph(resident=False)) and once on the dynamic edge store (PCSRGraph: one resident
+    graph + per-timestamp deltas).  BPTT windows are sharded over the ranks like the static configuration."""
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import NaiveGraph, PCSRGraph
+    rng = np.random.default_rng(4)
+    stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
+    snaps, pn_edges, pn_targets = [], [], []
+    gen = torch.Generator(device=device).manual_seed(4)
+    m = 10_000
+    for t in range(T):
+        keys = stream[t * churn: t * churn + e0]
+        s, d = (keys // n).astype(np.int32), (keys % n).astype(np.int32)
+        snaps.append((torch.from_numpy(s).to(device), torch.from_numpy(d).to(device)))
+        pos = torch.from_numpy(np.stack([s[:m], d[:m]]).astype(np.int64)).to(device)
+        neg = torch.randint(0, n, (2, m), device=device, generator=gen)
+        pn_edges.append(torch.cat([pos, neg], 1))
+        pn_targets.append(torch.cat([torch.ones(m, device=device), torch.zeros(m, device=device)]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = {}
+    for mode in ("rebuild_per_snapshot", "pcsr_store"):
+        G = (NaiveGraph(snaps, n, device=device, sort_inplace=False, resident=False, max_cached=B + 1)
+             if mode == "rebuild_per_snapshot" else PCSRGraph(snaps, n, device=device))
+        torch.manual_seed(4)
+        model = temporal.DynamicSTGraphTGCN(feat, hidden).to(device)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        bucket = temporal.GradBucket(model.parameters())
+
+        def epoch(ep):
+            if mode == "rebuild_per_snapshot":
+                G._snapshots.clear()                 # every epoch rebuilds every snapshot it touches
+            G._ndata.clear()
+            temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep, rank=rank,
+                                         world=world)
+        epoch(0)
+        barrier()
+        t0 = time.perf_counter()
+        for ep in range(epochs):
+            epoch(1 + ep)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if mode == "pcsr_store":
+            G.check()
+        out[mode] = {"epochs_per_s": epochs / dt, "seconds_per_epoch": dt / epochs}
+        del G, model, opt, bucket
+    return {"workload": f"dynamic-temporal TGCN |V|={n} E0={e0} +-{churn} edges/step T={T} backprop_every={B} feat={feat} "
+                        f"hidden={hidden} (BASELINE configs[4]), link-prediction loss, windows sharded over {world} rank(s)",
+            "metric": "epochs/s", "value": out["rebuild_per_snapshot"]["epochs_per_s"], "scaling": "strong",
+            "n_gpus": world, "epochs": epochs, "windows_per_epoch": temporal.num_windows(T, B), **out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,6 +377,8 @@ def main():
     ap.add_argument("--tgcn-epochs", type=int, default=4)
     ap.add_argument("--tgcn-timestamps", type=int, default=1000)
     ap.add_argument("--no-cora", action="store_true")
+    ap.add_argument("--no-dynamic", action="store_true")
+    ap.add_argument("--dynamic-epochs", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device: exercise the multi-rank logic on a single GPU (testing only)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (testing only)")
@@ -406,6 +473,8 @@ def main():
     if not args.no_tgcn:
         line["tgcn"] = tgcn_run(device, rank, world, epochs=args.tgcn_epochs, warmup_epochs=1, n=50_000, e=500_000,
                                 T=args.tgcn_timestamps, feat=32, hidden=64, B=25)
+    if not args.no_dynamic:
+        line["dynamic"] = dynamic_run(device, rank, world, epochs=args.dynamic_epochs)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
