@@ -620,18 +620,23 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, colsum: bool = False):
     return (c, cs) if colsum else c
 
 
-_ROWGEMM = os.environ.get("STGRAPH_AMD_ROWGEMM", "0") == "1"
+_ROWGEMM_MODE = os.environ.get("STGRAPH_AMD_ROWGEMM", "0")     # "0" | "1" | "auto" (only where measured faster)
+_ROWGEMM = _ROWGEMM_MODE != "0"
 
 
 def set_native_rowgemm(enabled: bool) -> None:
     """True: skinny forward / input-gradient GEMMs run on stg_rowgemm_f32; False (default): torch (rocBLAS).
     Measured on MI355X (tools/microbench_rowgemm.py, round 1): 0.5-1.3x rocBLAS depending on the shape, so
     it is not the default yet; the kernel restages W per 64-row tile and does not overlap staging with MFMA."""
-    global _ROWGEMM
-    _ROWGEMM = bool(enabled)
+    global _ROWGEMM, _ROWGEMM_MODE
+    _ROWGEMM, _ROWGEMM_MODE = bool(enabled), ("1" if enabled else "0")
 
 
-def rowgemm_usable(x: torch.Tensor, K: int, M: int) -> bool:
+def rowgemm_usable(x: torch.Tensor, K: int, M: int, trans_w: bool = False) -> bool:
+    # "auto": in situ (TGCN, |V| = 50K) the kernel beats rocBLAS's 64x32 macro tile on x @ W with W [K, M] wider
+    # than deep (19.9 vs 29.7 us for [50K,64] x [64,128]) and loses on the transposed forward shapes (24.4 vs 17.5 us)
+    if _ROWGEMM_MODE == "auto" and (trans_w or M < 2 * K):
+        return False
     return (_ROWGEMM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 4096
             and bool(_C.lib.stg_rowgemm_supported(int(K), int(M))))
 
@@ -658,7 +663,7 @@ def rowgemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
 
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None) -> torch.Tensor:
     """``x @ w.T + b`` (torch Linear layout) on the native kernel when the shape is covered."""
-    if rowgemm_usable(x, w.shape[1], w.shape[0]):
+    if rowgemm_usable(x, w.shape[1], w.shape[0], True):
         return rowgemm(x, w, b, trans_w=True)
     return torch.addmm(b, x, w.t()) if b is not None else torch.mm(x, w.t())
 
@@ -672,7 +677,7 @@ def matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 def matmul_t(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """``x @ w.T`` (w [M,K])."""
-    if rowgemm_usable(x, w.shape[1], w.shape[0]):
+    if rowgemm_usable(x, w.shape[1], w.shape[0], True):
         return rowgemm(x, w, None, trans_w=True)
     return torch.mm(x, w.t())
 
