@@ -305,10 +305,10 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
 def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, T=160, B=20, feat=32, hidden=64):
     """BASELINE.json configs[4]: dynamic-temporal TGCN (benchmarking/dynamic-temporal-tgcn/seastar/train.py loop:
     link prediction on a sliding window over an edge stream, un-weighted GCN gates), once with the per-snapshot
-    device CSR rebuild (NaiveGraph(resident=False)) and once on the dynamic edge store (PCSRGraph: one resident
-    graph + per-timestamp deltas).  BPTT windows are sharded over the ranks like the static configuration."""
+    device CSR rebuild (NaiveGraph(resident=False)) and on the dynamic edge store behind both of the reference's
+    delta-based graph classes (PCSRGraph, GPMAGraph: one resident graph + per-timestamp deltas).  BPTT windows are sharded over the ranks like the static configuration."""
     from stgraph_amd import temporal
-    from stgraph_amd.graph import NaiveGraph, PCSRGraph
+    from stgraph_amd.graph import GPMAGraph, NaiveGraph, PCSRGraph
     rng = np.random.default_rng(4)
     stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
     snaps, pn_edges, pn_targets = [], [], []
@@ -329,9 +329,9 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
         torch.cuda.synchronize()
 
     out = {}
-    for mode in ("rebuild_per_snapshot", "pcsr_store"):
+    for mode in ("rebuild_per_snapshot", "pcsr_store", "gpma_store"):
         G = (NaiveGraph(snaps, n, device=device, sort_inplace=False, resident=False, max_cached=B + 1)
-             if mode == "rebuild_per_snapshot" else PCSRGraph(snaps, n, device=device))
+             if mode == "rebuild_per_snapshot" else (PCSRGraph if mode == "pcsr_store" else GPMAGraph)(snaps, n, device=device))
         torch.manual_seed(4)
         model = temporal.DynamicSTGraphTGCN(feat, hidden).to(device)
         opt = torch.optim.Adam(model.parameters(), lr=1e-2)
@@ -354,7 +354,7 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        if mode == "pcsr_store":
+        if mode != "rebuild_per_snapshot":
             G.check()
         out[mode] = {"epochs_per_s": epochs / dt, "seconds_per_epoch": dt / epochs}
         del G, model, opt, bucket

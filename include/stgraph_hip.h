@@ -91,11 +91,14 @@ int stg_graph_build_device(const int32_t *src, const int32_t *dst, int64_t E, in
                            int32_t *status, void *workspace, size_t workspace_bytes,
                            void *stream);
 
-/* ------------------------------------------------------- dynamic edge store (PCSR)
+/* ------------------------------------------------------- dynamic edge store (PCSR, GPMA)
  * Replaces the reference's PCSR class: graph/dynamic/pcsr/pcsr.cu:273-939
  * (PCSR::edge_update_list :759-779, label_edges :745-757, build_csr :829-879,
  * build_reverse_csr :781-827, move_pinned_to_gpu :881-886), as driven by
- * graph/dynamic/pcsr/pcsr_graph.py:46-166.
+ * graph/dynamic/pcsr/pcsr_graph.py:46-166 -- and the reference's GPMA functions:
+ * graph/dynamic/gpma/gpma.cu (update_gpma :838-911 as called by edge_update_t
+ * :1064-1119, label_edges :1121-1163, count_sort_kernel + build_backward_csr
+ * :1165-1231, get_csr_ptrs :1239-1270), as driven by gpma_graph.py:58-152.
  *
  * State = the current edge SET as two dense, ascending arrays of packed keys
  *   keys_fwd[i] = (uint64)dst << 32 | src        keys_bwd[i] = (uint64)src << 32 | dst
@@ -108,8 +111,9 @@ int stg_graph_build_device(const int32_t *src, const int32_t *dst, int64_t E, in
  *   _device / host for _host] = 0, or a bit set: 1 vertex id out of range, 2 added
  *   edge already present, 4 deleted edge absent, 8 edge both added and deleted;
  *   the outputs are unspecified then.  Batches may arrive in any order.
- * emit: the CSR the reference's build_csr (reverse = 0: rows = dst) or
- *   build_reverse_csr (reverse = 1: rows = src) would have produced: columns of a
+ * emit: flags = STG_EMIT_REVERSE? | STG_EMIT_KEY_ORDER?.  Without KEY_ORDER, the
+ *   CSR the reference's build_csr (rows = dst) or build_reverse_csr (REVERSE:
+ *   rows = src) would have produced: columns of a
  *   row in DESCENDING order (the PMA row is emitted back to front), eids1 = the
  *   1-based labels of label_edges (1 + rank in (dst, src) order; what
  *   tpl_fa_pcsr.jinja:32-34 subtracts 1 from), eids0 = eids1 - 1 (what the
@@ -118,6 +122,12 @@ int stg_graph_build_device(const int32_t *src, const int32_t *dst, int64_t E, in
  *   written; column_indices, eids1, eids0 may each be NULL and node_ids + degrees
  *   may both be NULL -- those parts are skipped (the un-weighted GCN kernels never
  *   read eids, so a training step emits structure only and labels on demand).
+ *   With STG_EMIT_KEY_ORDER the slot of an edge is its position in the key array:
+ *   columns of a row ASCENDING.  That is the GPMA view: the forward array the
+ *   reference's kernels walk (tpl_fa_gpma.jinja:28-43) with its holes squeezed out,
+ *   labels = label_edges' running count in key order (gpma.cu:1121-1146); REVERSE =
+ *   build_backward_csr's rows (gpma.cu:1165-1188), whose in-row order the reference
+ *   leaves to atomicSub ("no longer a stable sort") and this build fixes ascending.
  * All arrays [dev] for *_device, [host] for *_host; no call synchronises.
  */
 size_t stg_edgeset_update_workspace_bytes(int64_t n_add, int64_t n_del);
@@ -137,13 +147,15 @@ int stg_edgeset_update_host(const uint64_t *keys_fwd_in, const uint64_t *keys_bw
 int stg_edgeset_merge_device(const uint64_t *keys_in, int64_t E, const uint64_t *add_sorted, int64_t n_add,
                              const uint64_t *del_sorted, int64_t n_del, uint64_t *keys_out,
                              int32_t *status, void *stream);
+#define STG_EMIT_REVERSE   1   /* rows = src (build_reverse_csr / build_backward_csr) */
+#define STG_EMIT_KEY_ORDER 2   /* GPMA view: rows and columns in key order; default = PCSR's back-to-front rows */
 size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N);
 int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
-                                int reverse, int32_t *row_offset, int32_t *column_indices,
+                                int flags, int32_t *row_offset, int32_t *column_indices,
                                 int32_t *eids1, int32_t *eids0, int32_t *node_ids, int32_t *degrees,
                                 void *workspace, size_t workspace_bytes, void *stream);
 int stg_edgeset_emit_csr_host(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
-                              int reverse, int32_t *row_offset, int32_t *column_indices,
+                              int flags, int32_t *row_offset, int32_t *column_indices,
                               int32_t *eids1, int32_t *eids0, int32_t *node_ids, int32_t *degrees);
 
 /* ------------------------------------------------------- JIT for generated kernels

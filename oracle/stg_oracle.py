@@ -42,7 +42,7 @@ def _lib(omp: bool = False) -> ctypes.CDLL:
     if omp not in _LIBS:
         name = "libstg_oracle_omp.so" if omp else "libstg_oracle.so"
         path = os.path.join(_HERE, name)
-        srcs = [os.path.join(_HERE, f) for f in ("stg_oracle.c", "stg_pcsr_oracle.c")]
+        srcs = [os.path.join(_HERE, f) for f in ("stg_oracle.c", "stg_pcsr_oracle.c", "stg_gpma_oracle.c")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
             build()
         lib = ctypes.CDLL(path)

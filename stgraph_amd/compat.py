@@ -15,6 +15,12 @@ _ALIASES = {
     "stgraph.graph.dynamic.dynamic_graph": "stgraph_amd.graph.dynamic.dynamic_graph",
     "stgraph.graph.dynamic.naive": "stgraph_amd.graph.dynamic.naive",
     "stgraph.graph.dynamic.naive.naive_graph": "stgraph_amd.graph.dynamic.naive.naive_graph",
+    "stgraph.graph.dynamic.pcsr": "stgraph_amd.graph.dynamic.pcsr",
+    "stgraph.graph.dynamic.pcsr.pcsr": "stgraph_amd.graph.dynamic.pcsr.pcsr",
+    "stgraph.graph.dynamic.pcsr.pcsr_graph": "stgraph_amd.graph.dynamic.pcsr.pcsr_graph",
+    "stgraph.graph.dynamic.gpma": "stgraph_amd.graph.dynamic.gpma",
+    "stgraph.graph.dynamic.gpma.gpma": "stgraph_amd.graph.dynamic.gpma.gpma",
+    "stgraph.graph.dynamic.gpma.gpma_graph": "stgraph_amd.graph.dynamic.gpma.gpma_graph",
     "stgraph.compiler": "stgraph_amd.compiler",
     "stgraph.compiler.node": "stgraph_amd.compiler.node",
     "stgraph.compiler.backend": "stgraph_amd.compiler.backend",

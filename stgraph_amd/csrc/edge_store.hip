@@ -162,7 +162,7 @@ __global__ void scatter_add_check_del(const uint64_t *__restrict__ old, int64_t 
 // One pass over the sorted keys of one orientation: column + label into the row-reversed slot.
 // Reverse CSR: the label of (src -> dst) is its rank in keys_fwd; row_offset_fwd[dst] (L2 resident) narrows the
 // search to that destination's row, i.e. to one or two cache lines of keys_fwd.
-template <bool REVERSE>
+template <bool REVERSE, bool KEY_ORDER>
 __global__ void emit_rows(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ keys_fwd, int64_t E,
                           const int *__restrict__ row_offset, const int *__restrict__ row_offset_fwd,
                           int *__restrict__ col, int *__restrict__ eids1, int *__restrict__ eids0)
@@ -171,7 +171,8 @@ __global__ void emit_rows(const uint64_t *__restrict__ keys, const uint64_t *__r
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
         const uint64_t k = keys[i];
         const unsigned row = (unsigned)(k >> kStoreBits), c = (unsigned)k;
-        const int64_t o = (int64_t)row_offset[row] + ((int64_t)row_offset[row + 1] - 1 - i);
+        // PCSR layout: rows back to front (the PMA walk, pcsr.cu:784-876); key-order layout: slot = position
+        const int64_t o = KEY_ORDER ? i : (int64_t)row_offset[row] + ((int64_t)row_offset[row + 1] - 1 - i);
         int64_t rank = i;                                                    // forward: the label is the position
         if (REVERSE && (eids1 || eids0)) {
             const int64_t lo = row_offset_fwd[c];
@@ -300,12 +301,14 @@ extern "C" int stg_edgeset_update_host(const uint64_t *keys_fwd_in, const uint64
 }
 
 extern "C" int stg_edgeset_emit_csr_host(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
-                                         int reverse, int32_t *row_offset, int32_t *column_indices, int32_t *eids1,
+                                         int flags, int32_t *row_offset, int32_t *column_indices, int32_t *eids1,
                                          int32_t *eids0, int32_t *node_ids, int32_t *degrees)
 {
     using namespace stg;
-    if (E < 0 || N < 0 || !row_offset || (E > 0 && (!keys_fwd || !keys_bwd)) || (!node_ids != !degrees))
+    if (E < 0 || N < 0 || !row_offset || (E > 0 && (!keys_fwd || !keys_bwd)) || (!node_ids != !degrees) ||
+        (flags & ~(STG_EMIT_REVERSE | STG_EMIT_KEY_ORDER)))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_host: bad argument");
+    const bool reverse = flags & STG_EMIT_REVERSE, key_order = flags & STG_EMIT_KEY_ORDER;
     const uint64_t *keys = reverse ? keys_bwd : keys_fwd;
     int64_t p = 0;
     for (int32_t v = 0; v <= N; ++v) {
@@ -316,7 +319,7 @@ extern "C" int stg_edgeset_emit_csr_host(const uint64_t *keys_fwd, const uint64_
         const uint64_t k = keys[i];
         const unsigned row = (unsigned)(k >> 32), c = (unsigned)k;
         if (row >= (unsigned)N) return fail(STG_ERR_VERTEX_RANGE, "stg_edgeset_emit_csr_host: vertex id out of range");
-        const int64_t o = (int64_t)row_offset[row] + ((int64_t)row_offset[row + 1] - 1 - i);
+        const int64_t o = key_order ? i : (int64_t)row_offset[row] + ((int64_t)row_offset[row + 1] - 1 - i);
         int64_t rank = i;
         if (reverse && (eids1 || eids0)) rank = std::lower_bound(keys_fwd, keys_fwd + E, ((uint64_t)c << 32) | row) - keys_fwd;
         if (column_indices) column_indices[o] = (int32_t)c;
@@ -422,7 +425,7 @@ extern "C" size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N)
 }
 
 extern "C" int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint64_t *keys_bwd, int64_t E, int32_t N,
-                                           int reverse, int32_t *row_offset, int32_t *column_indices, int32_t *eids1,
+                                           int flags, int32_t *row_offset, int32_t *column_indices, int32_t *eids1,
                                            int32_t *eids0, int32_t *node_ids, int32_t *degrees, void *workspace,
                                            size_t workspace_bytes, void *stream_)
 {
@@ -430,6 +433,9 @@ extern "C" int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint6
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (E < 0 || N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_device: negative size");
     if (E >= (int64_t(1) << 31)) return fail(STG_ERR_UNSUPPORTED, "stg_edgeset_emit_csr_device: E does not fit int32");
+    if (flags & ~(STG_EMIT_REVERSE | STG_EMIT_KEY_ORDER))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_device: unknown flag");
+    const bool reverse = flags & STG_EMIT_REVERSE, key_order = flags & STG_EMIT_KEY_ORDER;
     if (!row_offset || !workspace || (E > 0 && (!keys_fwd || !keys_bwd)) || (!node_ids != !degrees))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_csr_device: NULL pointer argument");
     const EmitLayout L = emit_layout(N);
@@ -440,19 +446,27 @@ extern "C" int stg_edgeset_emit_csr_device(const uint64_t *keys_fwd, const uint6
     hipLaunchKernelGGL(row_offsets_by_search, dim3((N + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, keys, E,
                        kStoreBits, N, row_offset);
     if (E > 0 && (column_indices || eids1 || eids0)) {
+        const int *ro_fwd = nullptr;
+        int *e1 = eids1, *e0 = eids0;
         if (reverse && (eids1 || eids0)) {
-            auto *ro_fwd = reinterpret_cast<int *>(ws + L.ro_fwd);
+            auto *ro = reinterpret_cast<int *>(ws + L.ro_fwd);
             hipLaunchKernelGGL(row_offsets_by_search, dim3((N + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-                               keys_fwd, E, kStoreBits, N, ro_fwd);
-            hipLaunchKernelGGL((emit_rows<true>), dim3(grid_for(E)), dim3(kBlock), 0, stream, keys, keys_fwd, E,
-                               row_offset, ro_fwd, column_indices, eids1, eids0);
-        } else if (reverse) {
-            hipLaunchKernelGGL((emit_rows<true>), dim3(grid_for(E)), dim3(kBlock), 0, stream, keys, keys_fwd, E,
-                               row_offset, nullptr, column_indices, nullptr, nullptr);
-        } else {
-            hipLaunchKernelGGL((emit_rows<false>), dim3(grid_for(E)), dim3(kBlock), 0, stream, keys, keys_fwd, E,
-                               row_offset, nullptr, column_indices, eids1, eids0);
+                               keys_fwd, E, kStoreBits, N, ro);
+            ro_fwd = ro;
         }
+        const dim3 grid(grid_for(E)), block(kBlock);
+        if (reverse && key_order)
+            hipLaunchKernelGGL((emit_rows<true, true>), grid, block, 0, stream, keys, keys_fwd, E, row_offset, ro_fwd,
+                               column_indices, e1, e0);
+        else if (reverse)
+            hipLaunchKernelGGL((emit_rows<true, false>), grid, block, 0, stream, keys, keys_fwd, E, row_offset, ro_fwd,
+                               column_indices, e1, e0);
+        else if (key_order)
+            hipLaunchKernelGGL((emit_rows<false, true>), grid, block, 0, stream, keys, keys_fwd, E, row_offset, ro_fwd,
+                               column_indices, e1, e0);
+        else
+            hipLaunchKernelGGL((emit_rows<false, false>), grid, block, 0, stream, keys, keys_fwd, E, row_offset, ro_fwd,
+                               column_indices, e1, e0);
     }
     if (N > 0 && node_ids) {
         auto *key_a = reinterpret_cast<unsigned *>(ws + L.key_a);

@@ -38,6 +38,8 @@ def _pairs(edge_list, device):
 
 
 class PCSR:
+    _key_order = False      # emission layout: PCSR rows come out back to front (the GPMA subclass sets True)
+
     def __init__(self, init_n: int, max_edge_count: int, device=None):
         self._device = torch.device(device) if device is not None else default_device()
         self._n = int(init_n)
@@ -51,7 +53,7 @@ class PCSR:
     # -- copies share everything immutable (the reference's copies share the device arrays too) --------
     def __copy__(self) -> "PCSR":
         self._flush()
-        c = PCSR.__new__(PCSR)
+        c = type(self).__new__(type(self))
         c.__dict__.update(self.__dict__)
         c._pending = {"add": [], "delete": []}
         c._emitted = dict(self._emitted)
@@ -112,7 +114,7 @@ class PCSR:
         self._flush()
         hit = self._emitted.get(reverse)
         if hit is None:
-            hit = self._emitted[reverse] = kernels.edgeset_emit_csr(self._set, reverse)
+            hit = self._emitted[reverse] = kernels.edgeset_emit_csr(self._set, reverse, self._key_order)
         return hit
 
     def _publish(self, reverse: bool) -> float:

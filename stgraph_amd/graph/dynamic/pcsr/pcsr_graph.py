@@ -57,13 +57,21 @@ class PCSRGraph(DynamicGraph):
         self.max_num_edges = int(ever.shape[0])                              # pcsr_graph.py:64-71
         self.move_to_gpu_time += time.time() - t0
 
-        self._forward_graph = PCSR(self.max_num_nodes, self.max_num_edges, self._device)
+        self._forward_graph = self._new_store()
         if self._num_timestamps:
             self._forward_graph.edge_update_list(self._updates[0]["add"], is_reverse_edge=True)
         self._forward_graph.label_edges()
         self._forward_graph.build_csr()
         self._get_graph_csr_ptrs()
         self.graph_cache = {"base": copy.deepcopy(self._forward_graph)}
+
+    def _new_store(self):
+        return PCSR(self.max_num_nodes, self.max_num_edges, self._device)
+
+    @staticmethod
+    def _published_arrays(c):
+        """The four arrays behind ``*_row_offset_ptr, *_column_indices_ptr, *_eids_ptr, *_node_ids_ptr``."""
+        return (c.row_offset, c.column_indices, c.eids1, c.node_ids)
 
     def _to_device(self, keys: np.ndarray):
         src = torch.from_numpy((keys & 0xFFFFFFFF).astype(np.int32)).to(self._device)
@@ -116,7 +124,7 @@ class PCSRGraph(DynamicGraph):
         c = self._ptr_src.get(side)
         if c is None:
             return (None, None, None, None)
-        arrays = (c.row_offset, c.column_indices, c.eids1, c.node_ids)
+        arrays = self._published_arrays(c)
         for t in arrays:
             _LIVE[t.data_ptr()] = t
         return tuple(int(t.data_ptr()) for t in arrays)
@@ -178,6 +186,6 @@ def _ptr_property(side: str, index: int):
     return property(get, set_)
 
 
-for _side in ("fwd", "bwd"):
+for _side in ("fwd", "bwd"):          # inherited by GPMAGraph
     for _i, _name in enumerate(("row_offset", "column_indices", "eids", "node_ids")):
         setattr(PCSRGraph, f"{_side}_{_name}_ptr", _ptr_property(_side, _i))

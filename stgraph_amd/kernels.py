@@ -347,18 +347,28 @@ class StoreCSR(DeviceCSR):
     tensors with) and ``eids1`` (the reference's 1-based array) -- on first access: the un-weighted GCN
     kernels never read them, and for the reverse CSR they cost a search per edge."""
 
-    def __init__(self, es: EdgeSet, reverse: bool, row_offset, column_indices, node_ids, degrees):
+    def __init__(self, es: EdgeSet, reverse: bool, row_offset, column_indices, node_ids, degrees,
+                 key_order: bool = False):
         self.row_offset, self.column_indices, self.node_ids, self.degrees = row_offset, column_indices, node_ids, degrees
-        self._es, self._reverse, self._labels = es, bool(reverse), None
+        self._es, self._reverse, self._labels, self._key_order = es, bool(reverse), None, bool(key_order)
 
     def _emit_labels(self):
         if self._labels is None:
             E = self._es.num_edges
             i32 = dict(dtype=torch.int32, device=self.row_offset.device)
             e1, e0 = torch.empty(E, **i32), torch.empty(E, **i32)
-            _emit(self._es, self._reverse, self.row_offset, None, e1, e0, None, None)
+            _emit(self._es, self._reverse, self.row_offset, None, e1, e0, None, None, self._key_order)
             self._labels = (e1, e0)
         return self._labels
+
+    @property
+    def keys(self) -> torch.Tensor:
+        """The packed 64-bit keys in row order (``row << 32 | column``) -- what the reference's GPMA kernels
+        take as ``column_indices`` (tpl_fa_gpma.jinja:5,30-37).  Key-order layout only: there the emitted
+        CSR *is* the key array, so this is the store's own tensor, not a copy."""
+        if not self._key_order:
+            raise ValueError("packed keys follow key order; this CSR was emitted back to front (PCSR layout)")
+        return self._es.keys_bwd if self._reverse else self._es.keys_fwd
 
     @property
     def eids(self) -> torch.Tensor:
@@ -369,9 +379,13 @@ class StoreCSR(DeviceCSR):
         return self._emit_labels()[0]
 
 
-def _emit(es: EdgeSet, reverse: bool, row_offset, col, eids1, eids0, node_ids, degrees) -> None:
+EMIT_REVERSE, EMIT_KEY_ORDER = 1, 2          # include/stgraph_hip.h STG_EMIT_*
+
+
+def _emit(es: EdgeSet, reverse: bool, row_offset, col, eids1, eids0, node_ids, degrees, key_order: bool = False) -> None:
     device, N, E = es.device, es.num_nodes, es.num_edges
-    args = [_ptr(es.keys_fwd), _ptr(es.keys_bwd), E, N, int(bool(reverse)), _ptr(row_offset), _ptr(col),
+    flags = (EMIT_REVERSE if reverse else 0) | (EMIT_KEY_ORDER if key_order else 0)
+    args = [_ptr(es.keys_fwd), _ptr(es.keys_bwd), E, N, flags, _ptr(row_offset), _ptr(col),
             _ptr(eids1), _ptr(eids0), _ptr(node_ids), _ptr(degrees)]
     if device.type == "cuda":
         ws_bytes = int(_C.lib.stg_edgeset_emit_csr_workspace_bytes(N))
@@ -382,20 +396,21 @@ def _emit(es: EdgeSet, reverse: bool, row_offset, col, eids1, eids0, node_ids, d
         _C.check(_C.lib.stg_edgeset_emit_csr_host(*args))
 
 
-def edgeset_emit_csr(es: EdgeSet, reverse: bool) -> StoreCSR:
+def edgeset_emit_csr(es: EdgeSet, reverse: bool, key_order: bool = False) -> StoreCSR:
     """The CSR the reference's ``build_csr`` (``reverse=False``, rows = dst) / ``build_reverse_csr``
-    (rows = src) emits for this edge set (pcsr.cu:781-879), as a :class:`StoreCSR`."""
+    (rows = src) emits for this edge set (pcsr.cu:781-879), as a :class:`StoreCSR`.  ``key_order=True``:
+    the GPMA view instead (rows and columns ascending, gpma.cu:1121-1188) -- see include/stgraph_hip.h."""
     device, N, E = es.device, es.num_nodes, es.num_edges
     i32 = dict(dtype=torch.int32, device=device)
     ro, col, nid, deg = torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
-    _emit(es, reverse, ro, col, None, None, nid, deg)
-    return StoreCSR(es, reverse, ro, col, nid, deg)
+    _emit(es, reverse, ro, col, None, None, nid, deg, key_order)
+    return StoreCSR(es, reverse, ro, col, nid, deg, key_order)
 
 
 def rows_by_node_ids(graph_type: str) -> bool:
-    """Graph types whose kernels visit rows through ``node_ids`` (tpl_fa_csr.jinja / tpl_fa_pcsr.jinja,
-    code_gen.py:96-103); 'csr_unsorted' walks rows in id order."""
-    return graph_type in ("csr", "pcsr")
+    """Graph types whose kernels visit rows through ``node_ids`` (tpl_fa_csr.jinja / tpl_fa_pcsr.jinja /
+    tpl_fa_gpma.jinja, code_gen.py:96-107); the '*_unsorted' types walk rows in id order."""
+    return graph_type in ("csr", "pcsr", "gpma")
 
 
 # ------------------------------------------------------------------------------- GCN
