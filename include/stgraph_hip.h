@@ -215,6 +215,31 @@ int stg_gcn_agg_edge(const float *x, const float *norm_row, const float *norm_co
                      const int32_t *node_ids, int32_t N, int64_t E, int32_t F, int32_t F_active,
                      void *stream);      /* E = number of edges (lane-mapping heuristic only; 0 = unknown) */
 
+/* GCNConv's tail fused into the aggregation's store (nn/pytorch/static/gcn_conv.py:185-188:
+ * `h = h + self.bias`, `h = self.activation(h)`):
+ *   out[r,f] = act( stg_gcn_agg_edge(...)[r,f] + bias[f] )      bias [F] or NULL, act = STG_ACT_*
+ * The sum is formed exactly as above and the two extra roundings happen in the order torch applies
+ * them, so `out` is bit-identical to aggregation -> torch add -> torch relu; two elementwise passes
+ * over [N,F] (4 x 4NF bytes of traffic) disappear.  Every column is active (no F_active).
+ */
+#define STG_ACT_NONE 0
+#define STG_ACT_RELU 1
+int stg_gcn_layer_fwd(const float *x, const float *norm_row, const float *norm_col_edge,
+                      const float *ew_edge, const float *bias, int32_t act, float *out,
+                      const int32_t *row_offsets, const int32_t *column_indices,
+                      const int32_t *node_ids, int32_t N, int64_t E, int32_t F, void *stream);
+
+/* Backward of that tail in one pass over [N,F] (torch: threshold_backward + sum(0), two passes + a
+ * single-block-per-column reduction):
+ *   g_act[r,f] = out ? (out[r,f] > 0 ? g[r,f] : 0) : (not written)      -- ReLU mask, `out` = the layer output
+ *   colsum[f]  = sum_r (out ? g_act[r,f] : g[r,f])                       -- the bias gradient
+ * out == NULL: no activation (g_act must be NULL too: g itself is what flows on).  colsum may be NULL.
+ * Deterministic: fixed grid, per-workgroup partial sums in `workspace`, one final reduction per column.
+ */
+size_t stg_bias_act_bwd_workspace_bytes(int32_t N, int32_t F);
+int stg_bias_act_bwd(const float *g, const float *out, float *g_act, float *colsum,
+                     int32_t N, int32_t F, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Fused aggregate-then-transform:  out[N,Fout] = (A_hat x) W  in one kernel:
  * the rows of A_hat x (aggregated exactly as stg_gcn_agg_edge does, width Fin) are staged in an LDS
  * tile and multiplied by W [Fin,Fout] on the fp32 matrix cores.  Equals the layer's A_hat (x W) up to

@@ -43,12 +43,13 @@ __device__ __forceinline__ float bcast_f(float v, int src)
     return __int_as_float(bcast_i<G>(__float_as_int(v), src));
 }
 
-template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL>
+template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false>
 __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
     const float *__restrict__ x, const float *__restrict__ norm_row,
     const float *__restrict__ norm_col, const float *__restrict__ ew, float *__restrict__ out,
     const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
-    const int *__restrict__ eids, const int *__restrict__ node_ids, int N, int F, int F_active)
+    const int *__restrict__ eids, const int *__restrict__ node_ids, int N, int F, int F_active,
+    const float *__restrict__ bias, int act)
 {
     constexpr int G = 1 << LOG2G;
     constexpr int ROWS_PER_WAVE = kWave / G;
@@ -143,6 +144,16 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
                     float o[VEC];
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) o[i] = acc[ch][i] * nr;   // Mul(., norm_cen)
+                    if constexpr (EPI) {   // layer epilogue (gcn_conv.py:185-188), wave-uniform switches: + bias, ReLU
+                        if (bias) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) o[i] = o[i] + bias[foff[ch] + i];
+                        }
+                        if (act == STG_ACT_RELU) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) o[i] = o[i] < 0.f ? 0.f : o[i];
+                        }
+                    }
                     vec_store<VEC>(orow + foff[ch], o);
                 }
             }
@@ -169,22 +180,27 @@ struct GcnArgs {
     bool pre;
     hipStream_t stream;
     int64_t E = 0;      // number of edges if the caller knows it (mapping heuristic only), else 0
+    const float *bias = nullptr;   // layer epilogue: out = act(out + bias)
+    int act = STG_ACT_NONE;
 };
 
-template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL>
+template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false>
 void launch(const GcnArgs &a)
 {
     constexpr int rows_per_block = (kWave >> LOG2G) * kWavesPerBlock;
     const int64_t blocks = ((int64_t)a.N + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI>), dim3((unsigned)blocks),
                        dim3(kBlock), 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out,
-                       a.row_offsets, a.column_indices, a.eids, a.node_ids, a.N, a.F, a.F_active);
+                       a.row_offsets, a.column_indices, a.eids, a.node_ids, a.N, a.F, a.F_active, a.bias, a.act);
 }
 
 template <int VEC, int LOG2G, int CHUNKS, int UNROLL>
 void launch_ew(const GcnArgs &a)
 {
-    if (a.pre) {
+    if (a.pre && (a.bias || a.act != STG_ACT_NONE)) {
+        if (a.ew) launch<VEC, LOG2G, CHUNKS, true, true, UNROLL, true>(a);
+        else launch<VEC, LOG2G, CHUNKS, false, true, UNROLL, true>(a);
+    } else if (a.pre) {
         if (a.ew) launch<VEC, LOG2G, CHUNKS, true, true, UNROLL>(a);
         else launch<VEC, LOG2G, CHUNKS, false, true, UNROLL>(a);
     } else {
@@ -229,6 +245,10 @@ int gcn_agg_dispatch(GcnArgs a, const char *what)
         return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
     if (!a.pre && a.ew && !a.eids)
         return fail(STG_ERR_INVALID_ARGUMENT, "%s: edge weights given without eids", what);
+    if (a.act != STG_ACT_NONE && a.act != STG_ACT_RELU)
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: unknown activation %d", what, a.act);
+    if ((a.bias || a.act != STG_ACT_NONE) && (a.F_active != a.F || !a.pre))
+        return fail(STG_ERR_UNSUPPORTED, "%s: the layer epilogue needs every column active and pre-gathered scalars", what);
 
     const uintptr_t align = reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.out);
     int vec = 1;
@@ -282,6 +302,18 @@ extern "C" int stg_gcn_agg_edge(const float *x, const float *norm_row, const flo
     return stg::gcn_agg_dispatch({x, norm_row, norm_col_edge, ew_edge, out, row_offsets, column_indices, nullptr,
                                   node_ids, N, F, F_active, true, static_cast<hipStream_t>(stream), E},
                                  "stg_gcn_agg_edge");
+}
+
+extern "C" int stg_gcn_layer_fwd(const float *x, const float *norm_row, const float *norm_col_edge,
+                                 const float *ew_edge, const float *bias, int32_t act, float *out,
+                                 const int32_t *row_offsets, const int32_t *column_indices,
+                                 const int32_t *node_ids, int32_t N, int64_t E, int32_t F, void *stream)
+{
+    stg::GcnArgs a{x, norm_row, norm_col_edge, ew_edge, out, row_offsets, column_indices, nullptr,
+                   node_ids, N, F, F, true, static_cast<hipStream_t>(stream), E};
+    a.bias = bias;
+    a.act = act;
+    return stg::gcn_agg_dispatch(a, "stg_gcn_layer_fwd");
 }
 
 extern "C" int stg_edge_gather_f32(float *dst, const float *table, const int32_t *idx, int64_t n,

@@ -1,0 +1,176 @@
+// Backward of GCNConv's tail (bias + ReLU, nn/pytorch/static/gcn_conv.py:185-188) in one pass:
+// ReLU mask and bias gradient (column sums) together.  HBM bound: reads g (+ out), writes g_act.
+//
+// Mapping: L = min(ceil(F / VEC), 256) lanes cover a row (VEC = 4 when F % 4 == 0: 16-B accesses,
+// a row is one coalesced request), R = 256 / L rows per pass, a workgroup strides over the rows; each
+// thread keeps up to KMAX column slots of running sums; the R row-lanes of a column meet in LDS; one
+// partial row per workgroup goes to the workspace and a second tiny kernel adds the partials in a fixed
+// order (no atomics: run-to-run identical).
+#include <algorithm>
+
+#include "stg_common.hpp"
+
+namespace stg {
+namespace {
+
+constexpr int kMaxSlots = 4;
+constexpr int kMaxGrid = 2048;     // partial rows; 8 workgroups per CU with kRowUnroll rows in flight each
+constexpr int kRowUnroll = 4;
+constexpr int kFinCols = 8, kFinGroups = kBlock / kFinCols;
+
+template <int VEC, bool MASK>
+__global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__restrict__ g, const float *__restrict__ out,
+                                                              float *__restrict__ g_act, float *__restrict__ partial,
+                                                              int N, int F, int L, int slots)
+{
+    __shared__ float red[kBlock * VEC];
+    const int R = kBlock / L;
+    const int cl = threadIdx.x % L, rl = threadIdx.x / L;
+    float acc[kMaxSlots][VEC];
+#pragma unroll
+    for (int k = 0; k < kMaxSlots; ++k)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+
+    if (rl < R) {
+        // kRowUnroll rows in flight per thread (loads first, sums after, in row order)
+        const int64_t step = (int64_t)gridDim.x * R;
+        for (int64_t r0 = (int64_t)blockIdx.x * R + rl; r0 < N; r0 += step * kRowUnroll) {
+#pragma unroll
+            for (int k = 0; k < kMaxSlots; ++k) {
+                const int col = (cl + k * L) * VEC;
+                if (k < slots && col < F) {
+                    float gv[kRowUnroll][VEC], ov[kRowUnroll][VEC];
+#pragma unroll
+                    for (int u = 0; u < kRowUnroll; ++u) {
+                        const int64_t r = r0 + u * step;
+                        if (r < N) {
+                            vec_load<VEC>(gv[u], g + r * F + col);
+                            if constexpr (MASK) vec_load<VEC>(ov[u], out + r * F + col);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kRowUnroll; ++u) {
+                        const int64_t r = r0 + u * step;
+                        if (r < N) {
+                            if constexpr (MASK) {
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) gv[u][i] = ov[u][i] > 0.f ? gv[u][i] : 0.f;   // threshold_backward
+                                vec_store<VEC>(g_act + r * F + col, gv[u]);
+                            }
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) acc[k][i] += gv[u][i];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!partial) return;
+    for (int k = 0; k < slots; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) red[threadIdx.x * VEC + i] = acc[k][i];
+        __syncthreads();
+        const int col = (cl + k * L) * VEC;
+        if (rl == 0 && col < F) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float s = 0.f;
+                for (int q = 0; q < R; ++q) s += red[(q * L + cl) * VEC + i];
+                partial[(int64_t)blockIdx.x * F + col + i] = s;
+            }
+        }
+    }
+}
+
+// colsum[f] = sum_b partial[b][f]: kFinCols columns per workgroup, the partial rows dealt to kFinGroups
+// thread groups (independent loads), then one fixed-order pass over the groups in LDS.
+__global__ __launch_bounds__(kBlock) void colsum_finish_kernel(const float *__restrict__ partial, float *__restrict__ colsum,
+                                                              int blocks, int F)
+{
+    __shared__ float red[kFinGroups][kFinCols];
+    const int c = threadIdx.x % kFinCols, grp = threadIdx.x / kFinCols;
+    const int f = blockIdx.x * kFinCols + c;
+    float s = 0.f;
+    if (f < F) {
+#pragma unroll 4
+        for (int b = grp; b < blocks; b += kFinGroups) s += partial[(int64_t)b * F + f];
+    }
+    red[grp][c] = s;
+    __syncthreads();
+    if (grp == 0 && f < F) {
+        float t = 0.f;
+        for (int q = 0; q < kFinGroups; ++q) t += red[q][c];
+        colsum[f] = t;
+    }
+}
+
+struct Shape {
+    int vec, L, slots, grid;
+};
+
+bool shape_for(int32_t N, int32_t F, Shape &s)
+{
+    s.vec = (F % 4 == 0) ? 4 : 1;
+    const int lanes = (F + s.vec - 1) / s.vec;
+    s.L = std::min(lanes, kBlock);
+    s.slots = (lanes + s.L - 1) / s.L;
+    if (s.slots > kMaxSlots) return false;
+    const int R = kBlock / s.L;
+    // enough workgroups to fill 256 CUs several times over, few enough that the partials stay small
+    s.grid = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)N + R - 1) / R / kRowUnroll + 1, kMaxGrid));
+    return true;
+}
+
+}  // namespace
+}  // namespace stg
+
+extern "C" size_t stg_bias_act_bwd_workspace_bytes(int32_t N, int32_t F)
+{
+    stg::Shape s;
+    if (N <= 0 || F <= 0 || !stg::shape_for(N, F, s)) return 0;
+    return (size_t)s.grid * (size_t)F * sizeof(float);
+}
+
+extern "C" int stg_bias_act_bwd(const float *g, const float *out, float *g_act, float *colsum, int32_t N, int32_t F,
+                                void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (N < 0 || F <= 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_bias_act_bwd: bad shape N=%d F=%d", N, F);
+    if (!out != !g_act) return fail(STG_ERR_INVALID_ARGUMENT, "stg_bias_act_bwd: out and g_act go together");
+    if (!out && !colsum) return 0;
+    Shape s;
+    if (!shape_for(std::max(N, 1), F, s)) return fail(STG_ERR_UNSUPPORTED, "stg_bias_act_bwd: F=%d too wide", F);
+    if (N == 0) {
+        if (colsum) return (int)hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)F, stream);
+        return 0;
+    }
+    if (!g) return fail(STG_ERR_INVALID_ARGUMENT, "stg_bias_act_bwd: NULL pointer argument");
+    const uintptr_t align = reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(g_act);
+    if (s.vec == 4 && align % 16 != 0) {          // unaligned views: scalar lanes
+        s.vec = 1;
+        s.L = std::min(F, kBlock);
+        s.slots = (F + s.L - 1) / s.L;
+        if (s.slots > kMaxSlots) return fail(STG_ERR_UNSUPPORTED, "stg_bias_act_bwd: F=%d too wide for unaligned rows", F);
+    }
+    float *partial = nullptr;
+    if (colsum) {
+        const size_t need = (size_t)s.grid * (size_t)F * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return fail(STG_ERR_WORKSPACE, "stg_bias_act_bwd: workspace %zu < required %zu", workspace_bytes, need);
+        partial = static_cast<float *>(workspace);
+    }
+    const dim3 grid(s.grid), block(kBlock);
+    if (s.vec == 4) {
+        if (out) hipLaunchKernelGGL((bias_act_bwd_kernel<4, true>), grid, block, 0, stream, g, out, g_act, partial, N, F, s.L, s.slots);
+        else hipLaunchKernelGGL((bias_act_bwd_kernel<4, false>), grid, block, 0, stream, g, out, g_act, partial, N, F, s.L, s.slots);
+    } else {
+        if (out) hipLaunchKernelGGL((bias_act_bwd_kernel<1, true>), grid, block, 0, stream, g, out, g_act, partial, N, F, s.L, s.slots);
+        else hipLaunchKernelGGL((bias_act_bwd_kernel<1, false>), grid, block, 0, stream, g, out, g_act, partial, N, F, s.L, s.slots);
+    }
+    if (colsum)
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((F + kFinCols - 1) / kFinCols), block, 0, stream, partial, colsum, s.grid, F);
+    return check_launch("stg_bias_act_bwd");
+}

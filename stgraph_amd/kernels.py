@@ -439,10 +439,19 @@ def _edge_gathered(csr: "DeviceCSR", kind: str, table: torch.Tensor, idx: torch.
     return dst
 
 
+ACT_NONE, ACT_RELU = 0, 1                     # include/stgraph_hip.h STG_ACT_*
+
+
+def layer_epilogue_usable() -> bool:
+    """The bias/activation epilogue rides on the pre-gathered-scalar kernel and writes every column."""
+    return _EDGE_CACHE and not reference_compat()
+
+
 def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr: DeviceCSR,
             ew: torch.Tensor | None = None, use_node_ids: bool = False,
-            f_active: int | None = None) -> torch.Tensor:
-    """out[r,:] = norm_row[r] * sum_e (norm_col[c] * x[c,:]) * ew[eid]   (stg_gcn_agg)."""
+            f_active: int | None = None, bias: torch.Tensor | None = None, act: int = ACT_NONE) -> torch.Tensor:
+    """out[r,:] = norm_row[r] * sum_e (norm_col[c] * x[c,:]) * ew[eid]   (stg_gcn_agg);
+    with ``bias`` / ``act``: ``act(out + bias)`` in the same launch (stg_gcn_layer_fwd)."""
     x = _f32(x, "x")
     dev = x.device
     N = csr.num_nodes
@@ -461,6 +470,14 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
         if ew.numel() < csr.num_edges:
             raise ValueError(f"edge_weight has {ew.numel()} entries, graph has {csr.num_edges} edges")
     fa = F if f_active is None else int(f_active)
+    epilogue = bias is not None or act != ACT_NONE
+    if epilogue:
+        if not _EDGE_CACHE or fa != F:
+            raise ValueError("the bias/activation epilogue needs the edge cache and every column active")
+        if bias is not None:
+            bias = _f32(bias, "bias", dev)
+            if bias.numel() != F:
+                raise ValueError(f"bias has {bias.numel()} entries, rows have {F}")
     out = (torch.empty_like(x) if fa == F else torch.zeros_like(x))
     nid = _ptr(csr.node_ids if use_node_ids else None)
     with torch.cuda.device(dev):
@@ -468,7 +485,11 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
             nc_e = _edge_gathered(csr, "norm", norm_col, csr.column_indices)
             ew_e = None if ew is None else _edge_gathered(csr, "ew", ew, csr.eids)
         with _Timed("gcn_agg", gcn_agg_algorithmic_bytes(N, csr.num_edges, fa, ew is not None), csr.num_edges * fa):
-            if _EDGE_CACHE:
+            if epilogue:
+                _C.check(_C.lib.stg_gcn_layer_fwd(
+                    _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(bias), int(act), _ptr(out),
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, N, csr.num_edges, F, _stream_ptr(dev)))
+            elif _EDGE_CACHE:
                 _C.check(_C.lib.stg_gcn_agg_edge(
                     _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(out),
                     _ptr(csr.row_offset), _ptr(csr.column_indices), nid, N, csr.num_edges, F, fa,
@@ -479,6 +500,29 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
                     _ptr(csr.row_offset), _ptr(csr.column_indices), _ptr(csr.eids), nid, N, F, fa,
                     _stream_ptr(dev)))
     return out
+
+
+def bias_act_bwd(g: torch.Tensor, out: torch.Tensor | None, want_colsum: bool = True):
+    """Backward of ``act(y + bias)`` in one pass (stg_bias_act_bwd): returns ``(g_act, colsum)`` with
+    ``g_act = g * (out > 0)`` when ``out`` (the ReLU output) is given, else ``g`` itself, and ``colsum`` =
+    the bias gradient ``g_act.sum(0)`` (None unless asked for)."""
+    g = _f32(g, "g")
+    dev = g.device
+    N = int(g.shape[0])
+    F = int(g[0].numel()) if N > 0 else int(np.prod(g.shape[1:]))
+    if out is not None:
+        out = _f32(out, "out", dev)
+        if out.shape != g.shape:
+            raise ValueError("out and g must have the same shape")
+    g_act = torch.empty_like(g) if out is not None else None
+    colsum = torch.empty(F, dtype=torch.float32, device=dev) if want_colsum else None
+    ws_bytes = int(_C.lib.stg_bias_act_bwd_workspace_bytes(N, F)) if want_colsum else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    nbytes = 4 * N * F * (1 + 2 * (out is not None))
+    with torch.cuda.device(dev), _Timed("bias_act_bwd", nbytes, N * F):
+        _C.check(_C.lib.stg_bias_act_bwd(_ptr(g), _ptr(out), _ptr(g_act), _ptr(colsum), N, F, _ptr(ws), ws_bytes,
+                                         _stream_ptr(dev)))
+    return (g_act if out is not None else g), colsum
 
 
 def agg_transform_supported(fin: int, fout: int) -> bool:

@@ -138,6 +138,61 @@ class _AggTransform(torch.autograd.Function):
         return dx, dW, None, None, None, None, None
 
 
+class _GcnLayerTail(torch.autograd.Function):
+    """``act(A_hat h + bias)`` as ONE launch (kernels.gcn_agg with the layer epilogue), and its backward as
+    two: ReLU mask + bias gradient in one pass (kernels.bias_act_bwd), then the transposed aggregation.
+    Reference: the emitted GCN unit followed by ``h + self.bias`` and ``self.activation(h)``
+    (nn/pytorch/static/gcn_conv.py:160-188)."""
+
+    @staticmethod
+    def forward(ctx, h, bias, norm, ew, fwd_csr, bwd_csr, use_nid, act):
+        out = kernels.gcn_agg(h, norm, norm, fwd_csr, ew=ew, use_node_ids=use_nid, bias=bias, act=act)
+        ctx.save_for_backward(out if act != kernels.ACT_NONE else norm.new_empty(0), norm,
+                              ew if ew is not None else norm.new_empty(0))
+        ctx.has_ew, ctx.act, ctx.has_bias = ew is not None, act, bias is not None
+        ctx.bwd_csr, ctx.use_nid, ctx.bias = bwd_csr, use_nid, bias
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, norm, ew = ctx.saved_tensors
+        ew = ew if ctx.has_ew else None
+        g = g.contiguous()
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        gb = None
+        if ctx.act != kernels.ACT_NONE or want_b:
+            g, gb = kernels.bias_act_bwd(g, out if ctx.act != kernels.ACT_NONE else None, want_colsum=want_b)
+        gh = None
+        if ctx.needs_input_grad[0]:
+            gh = kernels.gcn_agg(g, norm, norm, ctx.bwd_csr, ew=ew, use_node_ids=ctx.use_nid)
+        return gh, gb, None, None, None, None, None, None
+
+
+def activation_code(activation):
+    """STG_ACT_* of a GCNConv ``activation`` argument, or None if it is not one the epilogue implements."""
+    if activation is None:
+        return kernels.ACT_NONE
+    if activation in (torch.relu, F.relu, torch.nn.functional.relu) or (
+            isinstance(activation, torch.nn.ReLU)):
+        return kernels.ACT_RELU
+    return None
+
+
+def gcn_layer_tail_usable(graph, h: torch.Tensor, activation) -> bool:
+    """Static graphs only: a dynamic graph's backward CSR is reached through the executor's timestamp
+    stack (compiler/executor.py), which this shortcut does not enter."""
+    from ..graph.dynamic.dynamic_graph import DynamicGraph
+    return (h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and hasattr(graph, "csr")
+            and not isinstance(graph, DynamicGraph) and kernels.layer_epilogue_usable()
+            and activation_code(activation) is not None)
+
+
+def gcn_layer_tail(graph, h: torch.Tensor, bias, activation, edge_weight=None) -> torch.Tensor:
+    norm = graph.get_ndata("norm")
+    return _GcnLayerTail.apply(h, bias, norm, edge_weight, graph.csr("fwd"), graph.csr("bwd"),
+                               kernels.rows_by_node_ids(graph.graph_type()), activation_code(activation))
+
+
 def agg_transform_usable(graph, x: torch.Tensor, W) -> bool:
     """The fused kernel pays (and is supported) when the gather can run at the narrow input width.
     ``W``: the weight tensor or its (in, out) shape."""

@@ -73,6 +73,10 @@ class GCNConv(nn.Module):
     def forward(self, graph, h, edge_weight=None):
         self.check_norm(graph)
         h = SF.mm(h, self.weight)            # torch.mm forward; weight gradient on the fp32 matrix cores
+        if (self.bias is not None or self.activation is not None) and SF.gcn_layer_tail_usable(graph, h, self.activation):
+            # same aggregation kernel as the compiled vertex function below, with `+ bias` and the
+            # activation applied at its store instead of in two more passes over [N, F]
+            return SF.gcn_layer_tail(graph, h, self.bias, self.activation, edge_weight)
         h = self.aggregate(graph, h, edge_weight)
         if self.bias is not None:
             h = h + self.bias
