@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define STG_ABI_VERSION 1
+#define STG_ABI_VERSION 2
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -37,7 +37,8 @@ const char *stg_last_error_string(void);
 
 /* Launch-time knobs (performance only, never results).  Unknown keys return
  * STG_ERR_INVALID_ARGUMENT.  Keys: "gcn_lanes_per_row" (0 = auto, else a power
- * of two <= 64), "gcn_unroll" (0 = auto, 2/4/8). */
+ * of two <= 64), "gcn_unroll" (0 = auto, 2/4/8), "gcn_long_threshold" (0 = auto; rows with more
+ * edges take the wave-per-row path of stg_gcn_agg_edge). */
 int stg_set_tuning(const char *key, int value);
 
 /* ---------------------------------------------------------------- CSR, host
@@ -208,11 +209,19 @@ int stg_gcn_agg(const float *x, const float *norm_row, const float *norm_col, co
  * (build them once per graph with stg_edge_gather_f32).  The scattered 4-byte gathers of
  * stg_gcn_agg -- a 64-B sector and a dependent round trip each -- become coalesced streams;
  * values and results are bit-identical.  This is what the Python executor launches.
+ * rows_by_degree (nullable): the rows in non-increasing degree order -- the `node_ids` array every CSR
+ * builder emits (csr.cu:142-154).  When given and a row is narrower than a wave (F_active / vector width
+ * < 64 lanes), long rows are taken out of the row-group mapping and summed by the launch's FIRST workgroups,
+ * one wave per row: the wave gathers 16-128 of the row's edges at a time into an LDS tile [edge][feature]
+ * and adds them in CSR order, one feature per lane (same additions, same bits).  "Long" = more than 16
+ * edges while the whole grid is resident at once (the launch then lasts as long as its longest row:
+ * 19 -> 6 us on a Cora-shaped graph with a degree-168 vertex), more than 1024 edges on larger graphs.
  */
 int stg_gcn_agg_edge(const float *x, const float *norm_row, const float *norm_col_edge,
                      const float *ew_edge, float *out,
                      const int32_t *row_offsets, const int32_t *column_indices,
-                     const int32_t *node_ids, int32_t N, int64_t E, int32_t F, int32_t F_active,
+                     const int32_t *node_ids, const int32_t *rows_by_degree,
+                     int32_t N, int64_t E, int32_t F, int32_t F_active,
                      void *stream);      /* E = number of edges (lane-mapping heuristic only; 0 = unknown) */
 
 /* GCNConv's tail fused into the aggregation's store (nn/pytorch/static/gcn_conv.py:185-188:
@@ -227,7 +236,8 @@ int stg_gcn_agg_edge(const float *x, const float *norm_row, const float *norm_co
 int stg_gcn_layer_fwd(const float *x, const float *norm_row, const float *norm_col_edge,
                       const float *ew_edge, const float *bias, int32_t act, float *out,
                       const int32_t *row_offsets, const int32_t *column_indices,
-                      const int32_t *node_ids, int32_t N, int64_t E, int32_t F, void *stream);
+                      const int32_t *node_ids, const int32_t *rows_by_degree,
+                      int32_t N, int64_t E, int32_t F, void *stream);
 
 /* Backward of that tail in one pass over [N,F] (torch: threshold_backward + sum(0), two passes + a
  * single-block-per-column reduction):

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -97,9 +97,9 @@ def _load() -> ctypes.CDLL:
     lib.stg_gcn_agg.restype = ctypes.c_int
     lib.stg_gcn_agg.argtypes = [vp] * 9 + [i32, i32, i32, vp]
     lib.stg_gcn_agg_edge.restype = ctypes.c_int
-    lib.stg_gcn_agg_edge.argtypes = [vp] * 8 + [i32, i64, i32, i32, vp]
+    lib.stg_gcn_agg_edge.argtypes = [vp] * 9 + [i32, i64, i32, i32, vp]
     lib.stg_gcn_layer_fwd.restype = ctypes.c_int
-    lib.stg_gcn_layer_fwd.argtypes = [vp] * 5 + [i32] + [vp] * 4 + [i32, i64, i32, vp]
+    lib.stg_gcn_layer_fwd.argtypes = [vp] * 5 + [i32] + [vp] * 5 + [i32, i64, i32, vp]
     lib.stg_bias_act_bwd_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_bias_act_bwd_workspace_bytes.argtypes = [i32, i32]
     lib.stg_bias_act_bwd.restype = ctypes.c_int

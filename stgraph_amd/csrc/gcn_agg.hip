@@ -25,6 +25,8 @@
 // scattered 4-byte gathers per edge -- each of which costs a whole 64-B sector of
 // fabric traffic and a dependent round trip -- become coalesced streams; the
 // values, and therefore the results, are identical.
+#include <algorithm>
+
 #include "stg_common.hpp"
 
 namespace stg {
@@ -43,31 +45,205 @@ __device__ __forceinline__ float bcast_f(float v, int src)
     return __int_as_float(bcast_i<G>(__float_as_int(v), src));
 }
 
-template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false>
+// ---- long rows ------------------------------------------------------------------------------------------
+// Rows with more than `threshold` edges when a row is narrower than a wave (L = 2^LOG2L < 64 lanes per row).
+// In the main path below a row's L lanes walk its edges UNROLL at a time, so a hub of degree d costs
+// d / UNROLL dependent round trips (a degree-168 row at F = 16: 21 of the launch's 26 us on a Cora-shaped
+// graph, whose other rows need 5).  Here ONE WAVE owns one long row: its S = 64 / L lane groups fetch
+// B = S * U different edges' rows at once (the coefficient products nc * x (* w) are formed by the fetching
+// lane exactly as in the main path), stage the B products in an LDS tile [edge][feature], and lane group 0
+// adds them to its single accumulator in CSR order -- the same sequence of fp32 additions as the
+// reference's loop, with B rows in flight instead of UNROLL.  Two-deep pipeline: the index loads of batch
+// b + 2 and the row gathers of batch b + 1 are in flight while batch b is summed.
+// Long rows are found through `rows_by_degree` (non-increasing degree: every CSR builder emits it as
+// node_ids); the FIRST `long_blocks` workgroups of the launch stride over that list and stop at the first
+// row that is not long, so hubs start first and overlap the short rows instead of trailing them.
+template <int VEC, int LOG2L>
+struct LongTile {
+    static constexpr int L = 1 << LOG2L, S = kWave / L, W = L * VEC;     // W floats per staged row
+    static constexpr int kFloats = 1024;                                  // 4 KB per wave, 16 KB per workgroup
+    static constexpr int B0 = kFloats / W < 128 ? kFloats / W : 128;
+    static constexpr int B = B0 < S ? S : B0;                             // edges per batch, >= one per lane group
+    static constexpr int U = B / S;
+    static_assert(U >= 1 && U * S == B && (B & (B - 1)) == 0, "batch must be a power of two multiple of S");
+};
+
+template <int VEC, int LOG2L, bool HAS_EW, bool EPI>
+__device__ __forceinline__ void gcn_agg_long_rows(
+    float *__restrict__ tile, int first_wave, int total_waves,
+    const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
+    const float *__restrict__ ew_edge, float *__restrict__ out, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, const int *__restrict__ rows_by_degree, int N, int F, int F_active,
+    const float *__restrict__ bias, int act, int threshold)
+{
+    using T = LongTile<VEC, LOG2L>;
+    constexpr int L = T::L, S = T::S, W = T::W, B = T::B, U = T::U;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int sub = lane >> LOG2L, j = lane & (L - 1);
+    const int foff = j * VEC;
+    const bool fok = foff < F_active;
+
+    for (int i = first_wave; i < N; i += total_waves) {
+        const int r = rows_by_degree[i];
+        const int beg = row_offsets[r];
+        const int deg = row_offsets[r + 1] - beg;                    // wave-uniform
+        if (deg <= threshold) break;
+
+        // summation mapping: lane f owns feature f (+ 64 m): one LDS dword and one add per edge and lane, so
+        // the order-preserving chain costs ~one dependent v_add per edge however wide the row is
+        constexpr int M = (W + kWave - 1) / kWave;
+        float acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = 0.f;
+        int ci[U];
+        float nc[U], w[U], v[U][VEC];
+        auto load_idx = [&](int base) {                              // coalesced: column, norm[col], w[eid]
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = base + u * S + sub;
+                ci[u] = -1;
+                nc[u] = 0.f;
+                w[u] = 1.f;
+                if (k < deg) {
+                    const int e = beg + k;
+                    ci[u] = column_indices[e];
+                    nc[u] = nc_edge[e];
+                    if constexpr (HAS_EW) w[u] = ew_edge[e];
+                }
+            }
+        };
+        auto gather = [&](float (&dst)[U][VEC]) {                    // the rows the current ci[] name
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) dst[u][q] = 0.f;
+                if (ci[u] >= 0 && fok) vec_load<VEC>(dst[u], x + (int64_t)ci[u] * F + foff);
+            }
+        };
+        load_idx(0);
+        gather(v);
+        float ncb[U], wb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) ncb[u] = nc[u], wb[u] = w[u];
+        if (B < deg) load_idx(B);
+        for (int base = 0; base < deg; base += B) {
+            const int cnt = min(B, deg - base);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                            // products -> LDS tile [edge][feature]
+                float t[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    t[q] = ncb[u] * v[u][q];                         // Mul(norm_inb, h_inb)
+                    if constexpr (HAS_EW) t[q] = t[q] * wb[u];       // Mul(., edge_weight)
+                }
+                if (fok) vec_store<VEC>(tile + (u * S + sub) * W + foff, t);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (base + B < deg) {                                    // next batch's gathers fly during the sums
+                gather(v);
+#pragma unroll
+                for (int u = 0; u < U; ++u) ncb[u] = nc[u], wb[u] = w[u];
+                if (base + 2 * B < deg) load_idx(base + 2 * B);
+            }
+            {
+                constexpr int kRead = B < 16 ? B : 16;               // LDS reads in flight ahead of the add chain
+                for (int k = 0; k < cnt; k += kRead) {
+                    float t[kRead][M];
+#pragma unroll
+                    for (int u = 0; u < kRead; ++u)                  // (slots past cnt hold stale data, never added)
+#pragma unroll
+                        for (int m = 0; m < M; ++m)
+                            t[u][m] = tile[((k + u) & (B - 1)) * W + ((lane + m * kWave) & (W - 1))];
+#pragma unroll
+                    for (int u = 0; u < kRead; ++u) {
+                        if (k + u < cnt) {
+#pragma unroll
+                            for (int m = 0; m < M; ++m) acc[m] = acc[m] + t[u][m];     // AggSum, CSR order
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const float nr = norm_row[r];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int f = lane + m * kWave;
+            if (f < W && f < F_active) {
+                float o = acc[m] * nr;                               // Mul(., norm_cen)
+                if constexpr (EPI) {
+                    if (bias) o = o + bias[f];
+                    if (act == STG_ACT_RELU) o = o < 0.f ? 0.f : o;
+                }
+                out[(int64_t)r * F + f] = o;
+            }
+        }
+    }
+}
+
+// The long-row workgroups as a launch of their own: used behind the main kernel on graphs too large to be
+// resident at once, where only giant hubs are taken out (there the main kernel must keep its registers and LDS
+// to itself: inlining this path costs it 2x at F = 7, |V| = 2.8M).
+template <int VEC, int LOG2L, bool HAS_EW, bool EPI>
+__global__ __launch_bounds__(kBlock) void gcn_agg_long_kernel(
+    const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
+    const float *__restrict__ ew_edge, float *__restrict__ out, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, const int *__restrict__ rows_by_degree, int N, int F, int F_active,
+    const float *__restrict__ bias, int act, int threshold)
+{
+    __shared__ __attribute__((aligned(16))) float tiles[kWavesPerBlock][LongTile<VEC, LOG2L>::kFloats];
+    gcn_agg_long_rows<VEC, LOG2L, HAS_EW, EPI>(
+        tiles[threadIdx.x >> 6], blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), gridDim.x * kWavesPerBlock,
+        x, norm_row, nc_edge, ew_edge, out, row_offsets, column_indices, rows_by_degree, N, F, F_active, bias, act,
+        threshold);
+}
+
+template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false, bool LONG = false>
 __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
     const float *__restrict__ x, const float *__restrict__ norm_row,
     const float *__restrict__ norm_col, const float *__restrict__ ew, float *__restrict__ out,
     const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
     const int *__restrict__ eids, const int *__restrict__ node_ids, int N, int F, int F_active,
-    const float *__restrict__ bias, int act)
+    const float *__restrict__ bias, int act, const int *__restrict__ rows_by_degree, int long_blocks,
+    int long_threshold)
 {
     constexpr int G = 1 << LOG2G;
     constexpr int ROWS_PER_WAVE = kWave / G;
     constexpr int U = UNROLL < G ? UNROLL : G;
 
+    if constexpr (LONG) {
+        // the first `long_blocks` workgroups take the long rows (see gcn_agg_long_rows)
+        __shared__ __attribute__((aligned(16))) float tiles[kWavesPerBlock][LongTile<VEC, LOG2G>::kFloats];
+        if ((int)blockIdx.x < long_blocks) {
+            gcn_agg_long_rows<VEC, LOG2G, HAS_EW, EPI>(
+                tiles[threadIdx.x >> 6], blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), long_blocks * kWavesPerBlock,
+                x, norm_row, norm_col, ew, out, row_offsets, column_indices, rows_by_degree, N, F, F_active, bias, act,
+                long_threshold);
+            return;
+        }
+    }
+
     const int lane = threadIdx.x & (kWave - 1);
     const int j = lane & (G - 1);
-    const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int wave_global = ((int)blockIdx.x - long_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
     const int idx = wave_global * ROWS_PER_WAVE + (lane >> LOG2G);
-    const bool row_valid = idx < N;
 
     int r = 0, beg = 0, deg = 0;
     float nr = 0.f;
+    bool row_valid = idx < N;
     if (row_valid) {
         r = node_ids ? node_ids[idx] : idx;
         beg = row_offsets[r];
         deg = row_offsets[r + 1] - beg;
         nr = norm_row[r];
+        if (deg > long_threshold) {          // taken by the long-row workgroups of this launch
+            deg = 0;
+            row_valid = false;
+        }
     }
     const int max_deg = __builtin_amdgcn_readfirstlane(wave_max(deg));
 
@@ -182,16 +358,55 @@ struct GcnArgs {
     int64_t E = 0;      // number of edges if the caller knows it (mapping heuristic only), else 0
     const float *bias = nullptr;   // layer epilogue: out = act(out + bias)
     int act = STG_ACT_NONE;
+    const int *rows_by_degree = nullptr;   // rows by non-increasing degree: enables the long-row launch
 };
+
+constexpr int kLongRowThreshold = 16;      // edges; rows above it go to gcn_agg_long_kernel (G < 64 only)
+constexpr int kGiantRowThreshold = 1024;
+constexpr int kNoLongRows = 0x7fffffff;
+
+inline bool long_rows_enabled(const GcnArgs &a, int log2g) { return a.pre && a.rows_by_degree && log2g < 6; }
 
 template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false>
 void launch(const GcnArgs &a)
 {
     constexpr int rows_per_block = (kWave >> LOG2G) * kWavesPerBlock;
+    constexpr bool kCanLong = PRE && LOG2G < 6 && CHUNKS == 1;
     const int64_t blocks = ((int64_t)a.N + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI>), dim3((unsigned)blocks),
-                       dim3(kBlock), 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out,
-                       a.row_offsets, a.column_indices, a.eids, a.node_ids, a.N, a.F, a.F_active, a.bias, a.act);
+    const dim3 block(kBlock);
+    if constexpr (kCanLong) {
+        if (long_rows_enabled(a, LOG2G)) {
+            // Long-row workgroups: how many rows are long is not known on the host (no sync), so one wave per 16
+            // rows, at least 64 and at most 16384 waves; a wave that meets a short row first leaves at once.
+            const int long_blocks = (int)std::max<int64_t>(
+                std::min<int64_t>({((int64_t)a.N + kWavesPerBlock - 1) / kWavesPerBlock,
+                                   std::max<int64_t>((int64_t)a.N / 64, 16), (int64_t)4096}), 1);
+            const int forced = tuning().gcn_long_threshold;
+            if (blocks <= 256 * 8) {
+                // The whole grid is resident at once: the launch lasts as long as its longest row, so every row
+                // above 16 edges gets a wave of its own, in the SAME launch (long rows first, overlapping the rest).
+                hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI, true>),
+                                   dim3((unsigned)(blocks + long_blocks)), block, 0, a.stream, a.x, a.norm_row, a.norm_col,
+                                   a.ew, a.out, a.row_offsets, a.column_indices, a.eids, a.node_ids, a.N, a.F, a.F_active,
+                                   a.bias, a.act, a.rows_by_degree, long_blocks, forced > 0 ? forced : kLongRowThreshold);
+                return;
+            }
+            // Larger graphs: the main path's many waves hide row latency; only giant hubs (> 1024 edges) would
+            // still trail the launch.  They get their own launch so the main kernel keeps its registers and LDS.
+            const int threshold = forced > 0 ? forced : kGiantRowThreshold;
+            hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI, false>), dim3((unsigned)blocks),
+                               block, 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets,
+                               a.column_indices, a.eids, a.node_ids, a.N, a.F, a.F_active, a.bias, a.act,
+                               a.rows_by_degree, 0, threshold);
+            hipLaunchKernelGGL((gcn_agg_long_kernel<VEC, LOG2G, HAS_EW, EPI>), dim3((unsigned)std::min(long_blocks, 512)),
+                               block, 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets,
+                               a.column_indices, a.rows_by_degree, a.N, a.F, a.F_active, a.bias, a.act, threshold);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI, false>), dim3((unsigned)blocks), block, 0,
+                       a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets, a.column_indices, a.eids,
+                       a.node_ids, a.N, a.F, a.F_active, a.bias, a.act, nullptr, 0, kNoLongRows);
 }
 
 template <int VEC, int LOG2G, int CHUNKS, int UNROLL>
@@ -296,21 +511,25 @@ extern "C" int stg_gcn_agg(const float *x, const float *norm_row, const float *n
 
 extern "C" int stg_gcn_agg_edge(const float *x, const float *norm_row, const float *norm_col_edge,
                                 const float *ew_edge, float *out, const int32_t *row_offsets,
-                                const int32_t *column_indices, const int32_t *node_ids, int32_t N,
-                                int64_t E, int32_t F, int32_t F_active, void *stream)
+                                const int32_t *column_indices, const int32_t *node_ids,
+                                const int32_t *rows_by_degree, int32_t N, int64_t E, int32_t F, int32_t F_active,
+                                void *stream)
 {
-    return stg::gcn_agg_dispatch({x, norm_row, norm_col_edge, ew_edge, out, row_offsets, column_indices, nullptr,
-                                  node_ids, N, F, F_active, true, static_cast<hipStream_t>(stream), E},
-                                 "stg_gcn_agg_edge");
+    stg::GcnArgs a{x, norm_row, norm_col_edge, ew_edge, out, row_offsets, column_indices, nullptr,
+                   node_ids, N, F, F_active, true, static_cast<hipStream_t>(stream), E};
+    a.rows_by_degree = rows_by_degree;
+    return stg::gcn_agg_dispatch(a, "stg_gcn_agg_edge");
 }
 
 extern "C" int stg_gcn_layer_fwd(const float *x, const float *norm_row, const float *norm_col_edge,
                                  const float *ew_edge, const float *bias, int32_t act, float *out,
                                  const int32_t *row_offsets, const int32_t *column_indices,
-                                 const int32_t *node_ids, int32_t N, int64_t E, int32_t F, void *stream)
+                                 const int32_t *node_ids, const int32_t *rows_by_degree, int32_t N, int64_t E,
+                                 int32_t F, void *stream)
 {
     stg::GcnArgs a{x, norm_row, norm_col_edge, ew_edge, out, row_offsets, column_indices, nullptr,
                    node_ids, N, F, F, true, static_cast<hipStream_t>(stream), E};
+    a.rows_by_degree = rows_by_degree;
     a.bias = bias;
     a.act = act;
     return stg::gcn_agg_dispatch(a, "stg_gcn_layer_fwd");

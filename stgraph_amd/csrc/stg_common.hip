@@ -55,5 +55,10 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().gcn_unroll = value;
         return 0;
     }
+    if (!std::strcmp(key, "gcn_long_threshold")) {
+        if (value < 0) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_long_threshold must be >= 0");
+        tuning().gcn_long_threshold = value;
+        return 0;
+    }
     return fail(STG_ERR_INVALID_ARGUMENT, "stg_set_tuning: unknown key '%s'", key);
 }

@@ -23,6 +23,7 @@ int check_launch(const char *what);
 struct Tuning {
     int gcn_lanes_per_row = 0;     // 0 = auto
     int gcn_unroll = 0;            // 0 = auto
+    int gcn_long_threshold = 0;    // 0 = default (16 edges); rows above it take the wave-per-row path
 };
 Tuning &tuning();
 

@@ -415,6 +415,14 @@ def rows_by_node_ids(graph_type: str) -> bool:
 
 # ------------------------------------------------------------------------------- GCN
 _EDGE_CACHE = True
+_LONG_ROWS = True
+
+
+def set_long_row_path(enabled: bool) -> None:
+    """On (default): long rows are summed by wave-per-row, LDS-staged workgroups when a row is narrower than a
+    wave (see stg_gcn_agg_edge in include/stgraph_hip.h).  Off: every row goes through the row-group mapping."""
+    global _LONG_ROWS
+    _LONG_ROWS = bool(enabled)
 
 
 def set_edge_cache(enabled: bool) -> None:
@@ -488,12 +496,13 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
             if epilogue:
                 _C.check(_C.lib.stg_gcn_layer_fwd(
                     _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(bias), int(act), _ptr(out),
-                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, N, csr.num_edges, F, _stream_ptr(dev)))
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids if _LONG_ROWS else None),
+                    N, csr.num_edges, F, _stream_ptr(dev)))
             elif _EDGE_CACHE:
                 _C.check(_C.lib.stg_gcn_agg_edge(
                     _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(out),
-                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, N, csr.num_edges, F, fa,
-                    _stream_ptr(dev)))
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids if _LONG_ROWS else None),
+                    N, csr.num_edges, F, fa, _stream_ptr(dev)))
             else:
                 _C.check(_C.lib.stg_gcn_agg(
                     _ptr(x), _ptr(norm_row), _ptr(norm_col), _ptr(ew), _ptr(out),

@@ -13,8 +13,11 @@ from tools.microbench_gemm import t_ms
 
 def main():
     dev = torch.device("cuda", 0)
-    for N, K, M, tw in ((50_000, 128, 64, True), (50_000, 64, 128, False), (50_000, 192, 32, True),
-                        (50_000, 64, 32, True), (25_000, 128, 64, True), (1_000_000, 64, 128, False)):
+    only = int(sys.argv[1]) if len(sys.argv) > 1 else None      # one shape per run: per-shape device times under rocprofv3
+    for idx, (N, K, M, tw) in enumerate(((50_000, 128, 64, True), (50_000, 64, 128, False), (50_000, 192, 32, True),
+                        (50_000, 64, 32, True), (25_000, 128, 64, True), (1_000_000, 64, 128, False))):
+        if only is not None and idx != only:
+            continue
         x = torch.randn(N, K, device=dev)
         w = torch.randn((M, K) if tw else (K, M), device=dev)
         b = torch.randn(M, device=dev)

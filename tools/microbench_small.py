@@ -18,7 +18,9 @@ def main():
     ap.add_argument("--K", type=int, default=1024)
     ap.add_argument("--feats", default="16,7,32,64")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--no-long", action="store_true", help="switch the long-row workgroups off")
     args = ap.parse_args()
+    kernels.set_long_row_path(not args.no_long)
     dev = torch.device("cuda", 0)
     src, dst = cora_shaped()
     n, K = 2708, args.K
