@@ -329,7 +329,8 @@ int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *cols
 /* Y[N,M] = X[N,K] * op(W) + bias (bias nullable): forward / input-gradient GEMM of the dense layers
  * for N = number of vertices and small K, M.  op(W) = W [K,M] (trans_w = 0) or W^T with W [M,K]
  * (trans_w = 1, i.e. torch's Linear weight layout).  64-row X tile + W in LDS, fp32 matrix cores.
- * stg_rowgemm_supported(K, M) != 0 iff K % 4 == 0, M % 32 == 0 and the tiles fit 96 KiB of LDS. */
+ * stg_rowgemm_supported(K, M) != 0 iff K % 4 == 0, K <= 192, M / 32 in {1,2,3,4,6} and the A tile plus the
+ * accumulators fit the register budget (K / 2 + M / 2 <= 176). */
 int stg_rowgemm_supported(int32_t K, int32_t M);
 int stg_rowgemm_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K,
                     int32_t M, int trans_w, void *stream);
@@ -342,6 +343,18 @@ size_t stg_gemm_tn_multi_workspace_bytes(int32_t T, int64_t K, int32_t M, int32_
 int stg_gemm_tn_multi_f32(const float *const *A, const float *const *B, int32_t T, float *C, float *colsum_A,
                           int64_t K, int32_t M, int32_t N, void *workspace, size_t workspace_bytes,
                           void *stream);
+
+/* The whole forward chain of the six stages below in ONE launch for C = 32 or 64 (hidden width): bias + clamp,
+ * the three gate GEMMs on the fp32 matrix cores with the gate weights (torch Linear layout [C][2C]) resident in
+ * LDS, sigmoid / tanh and the GRU blend -- one wave per 32-row tile, see csrc/tgcn_cell_fused.hip.  Outputs are
+ * exactly what prep_fwd + gates_fwd + update_fwd and the three Linears produce: CZ = [hz|H], CR = [hr|H],
+ * CH = [hh|H*R] ([N,2C] each, read again by the weight gradients), Z, R, Ht, Hn ([N,C]).  Elementwise formulas
+ * are identical; the GEMM k-order differs from rocBLAS', so results agree to fp32 rounding (tested at 1e-5). */
+int stg_tgcn_cell_fused_supported(int32_t C);
+int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const float *H, const float *Wz, const float *bz,
+                            const float *Wr, const float *br, const float *Wh, const float *bh, float *CZ,
+                            float *CR, float *CH, float *Z, float *R, float *Ht, float *Hn, int64_t N, int32_t C,
+                            float lo, float hi, void *stream);
 
 /* ----------------------------------------------- dense neighbour: TGCN row-local glue
  * Fused elementwise stages of one TGCN step (nn/pytorch/temporal/tgcn.py:21-55); the three gate

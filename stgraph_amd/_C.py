@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_rowgemm_supported", "stg_rowgemm_f32",
+    "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd",
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
 )
@@ -132,6 +133,10 @@ def _load() -> ctypes.CDLL:
     lib.stg_rowgemm_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, ctypes.c_int, vp]
     lib.stg_gemm_tn_colsum_f32.restype = ctypes.c_int
     lib.stg_gemm_tn_colsum_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, ctypes.c_size_t, vp]
+    lib.stg_tgcn_cell_fused_supported.restype = ctypes.c_int
+    lib.stg_tgcn_cell_fused_supported.argtypes = [i32]
+    lib.stg_tgcn_cell_fused_fwd.restype = ctypes.c_int
+    lib.stg_tgcn_cell_fused_fwd.argtypes = [vp] * 16 + [i64, i32, f32, f32, vp]
     for name, nptr, tail in (("stg_tgcn_cell_prep_fwd", 6, [i64, i32, f32, f32, vp]),
                              ("stg_tgcn_cell_gates_fwd", 6, [i64, i32, vp]),
                              ("stg_tgcn_cell_update_fwd", 5, [i64, i32, vp]),

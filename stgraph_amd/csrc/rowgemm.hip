@@ -1,45 +1,52 @@
 // Y[N,M] = X[N,K] * op(W) + bias   with N = number of vertices (large) and K, M = feature widths
-// (<= 256): the forward / input-gradient GEMMs of the dense layers next to the Seastar kernels
+// (<= 192): the forward / input-gradient GEMMs of the dense layers next to the Seastar kernels
 // (TGCN gate Linears: K = 128 -> M = 64 and back).  rocBLAS/hipBLASLt choose 64x32- or 128x224-wide
 // macro tiles for these skinny shapes and land at 2-4x the memory-bound time (measured in situ: 29.7 us
-// for [50K,64] x [64,128], whose 38 MB of traffic take 7 us; profiles/r01).
-//
-// Persistent workgroups (256 threads, up to 3 per CU): W is staged into LDS ONCE per workgroup, then
-// the workgroup walks 64-row tiles of X: the global loads of tile i+1 are issued (into registers)
-// before the MFMA loop of tile i and written to LDS after it (issue-early / write-late), so the matrix
-// pipe and the memory pipe overlap inside a workgroup and across the co-resident ones.  X rows are padded by one
-// float (conflict-free MFMA A-fragment column reads), W is stored [K][M+1] (conflict-free transposing
-// stage and B-fragment reads).  v_mfma_f32_32x32x2_f32 over 32x32 output tiles dealt round-robin to the
-// 4 waves, results stored as 128-B row segments.  fp32 in / fp32 accumulate, k-ordered fma chain.
+// for [50K,128] x [128,64]^T, whose 38 MB of traffic take 7 us; profiles/r01).
+#include <algorithm>
+
 #include "stg_common.hpp"
 
 namespace stg {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kRgRows = 64;
-constexpr int kRgMaxK = 256;
-constexpr int kRgRegs = kRgRows * (kRgMaxK / 4) / kBlock;       // float4 registers per thread for one X tile
 
-template <bool TRANS_W>
-__global__ __launch_bounds__(kBlock) void rowgemm_kernel(const float *__restrict__ X,
-                                                         const float *__restrict__ W,
-                                                         const float *__restrict__ bias,
-                                                         float *__restrict__ Y, int64_t N, int K, int M,
-                                                         int num_tiles)
+// One WAVE owns a 32-row tile of X and ALL M output columns (M / 32 accumulators of v_mfma_f32_32x32x2_f32):
+//   * its A operands come straight from global memory into registers in MFMA layout -- lane (row, kh) loads the
+//     float4s X[row][8 j + 4 kh .. + 3]; the k index is permuted inside each block of 8 (lane half kh supplies
+//     k = 8 j + 4 kh + i at step (j, i)), which a sum over k does not care about as long as B follows;
+//   * W is staged ONCE per workgroup into LDS as Ws[k][M + 1] (transposing on the way for the torch Linear layout)
+//     and read as B operands Ws[8 j + 4 kh + i][32 ct + lane % 32] (conflict-free: odd row stride);
+//   * no workgroup barrier after the staging: waves walk tiles independently, so while one wave waits for its X
+//     rows the other two or three on the SIMD keep the matrix pipe busy.  The X loads of the first tile are issued
+//     before the staging, those of the next tile right after the last MFMA of the current one.
+// fp32 in, fp32 accumulate, the k-chain of each output in a fixed order (bias is the initial accumulator).
+template <int KBMAX, int MT, bool TRANS_W>
+__global__ __launch_bounds__(kBlock) void rowgemm_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, float *__restrict__ Y,
+                                                         int64_t N, int K, int M, int num_tiles)
 {
-    extern __shared__ float lds[];
-    const int ldx = K + 1;
+    extern __shared__ float Ws[];                      // [KB * 8][M + 1]
     const int ldw = M + 1;
-    float *Ws = lds;                                   // [K][M + 1]
-    float *Xs = lds + K * ldw;                         // one X tile [kRgRows][K + 1]
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const int q = K / 4;                               // float4 per row
-    const int per_tile = kRgRows * q;                  // float4 per tile
+    const int KB = (K + 7) / 8;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int total = gridDim.x * kWavesPerBlock;
+    int tile = blockIdx.x * kWavesPerBlock + wave;
 
-    // stage W as Ws[k][m]: batches of 8 independent 16-B loads per thread are issued before the first
-    // LDS write (a one-load-one-store loop serialises on global latency: ~1 us per iteration)
-    {
+    float4 xa[KBMAX];
+    auto load_x = [&](int t) {
+        const int64_t row = (int64_t)t * 32 + l31;
+        const float *src = X + row * K + 4 * kh;
+#pragma unroll
+        for (int j = 0; j < KBMAX; ++j) {
+            xa[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < KB && row < N && 8 * j + 4 * kh < K) xa[j] = *reinterpret_cast<const float4 *>(src + 8 * j);
+        }
+    };
+    if (tile < num_tiles) load_x(tile);
+
+    {   // stage W (zero rows K .. 8 KB): batches of 8 independent 16-B loads per thread before the first LDS write
         const int total4 = K * M / 4;
         for (int base = 0; base < total4; base += 8 * kBlock) {
             float4 w4[8];
@@ -57,83 +64,111 @@ __global__ __launch_bounds__(kBlock) void rowgemm_kernel(const float *__restrict
                     if constexpr (TRANS_W) {           // W is [M][K]: element i = (m, k), 4 consecutive k
                         const int m = i / K, k = i - m * K;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) Ws[(k + j) * ldw + m] = v[j];
+                        for (int q = 0; q < 4; ++q) Ws[(k + q) * ldw + m] = v[q];
                     } else {                           // W is [K][M]: element i = (k, m), 4 consecutive m
                         const int k = i / M, m = i - k * M;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) Ws[k * ldw + m + j] = v[j];
+                        for (int q = 0; q < 4; ++q) Ws[k * ldw + m + q] = v[q];
                     }
                 }
             }
         }
-    }
-
-    // per-thread slots of an X tile (tile independent: computed once, no division in the loop)
-    float4 regs[kRgRegs];
-    int goff[kRgRegs], loff[kRgRegs], rrow[kRgRegs];
-#pragma unroll
-    for (int s = 0; s < kRgRegs; ++s) {
-        const int i = threadIdx.x + s * kBlock;
-        const int r = i / q, c = (i - r * q) * 4;
-        const bool ok = i < per_tile;
-        rrow[s] = ok ? r : (1 << 30);                  // a row index that is never < N - row_base
-        goff[s] = r * K + c;
-        loff[s] = r * ldx + c;
-    }
-    auto load_tile = [&](int tile) {                   // global -> registers (rows beyond N are zero)
-        const int64_t row_base = (int64_t)tile * kRgRows;
-        const float *src = X + row_base * K;
-        const int64_t rows_left = N - row_base;
-#pragma unroll
-        for (int s = 0; s < kRgRegs; ++s) {
-            regs[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rrow[s] < rows_left) regs[s] = *reinterpret_cast<const float4 *>(src + goff[s]);
-        }
-    };
-    auto store_tile = [&]() {                          // registers -> LDS
-#pragma unroll
-        for (int s = 0; s < kRgRegs; ++s) {
-            if (rrow[s] < kRgRows) {
-                float *d = Xs + loff[s];
-                d[0] = regs[s].x; d[1] = regs[s].y; d[2] = regs[s].z; d[3] = regs[s].w;
-            }
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile < num_tiles) {
-        load_tile(tile);
-        store_tile();
+        for (int i = K * ldw + threadIdx.x; i < KB * 8 * ldw; i += kBlock) Ws[i] = 0.f;
     }
     __syncthreads();
 
-    const int kh = lane >> 5, l31 = lane & 31;
-    const int col_tiles = M / 32;
-    const int tiles = (kRgRows / 32) * col_tiles;
-    for (; tile < num_tiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        if (next < num_tiles) load_tile(next);                         // in flight during the MFMA loop below
-        const int64_t row_base = (int64_t)tile * kRgRows;
-        for (int t = wave; t < tiles; t += kWavesPerBlock) {
-            const int rt = t / col_tiles, ct = t - rt * col_tiles;
-            f32x16 acc;
+    for (; tile < num_tiles; tile += total) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int ct = 0; ct < MT; ++ct) {
             const float b = bias ? bias[ct * 32 + l31] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = b;                   // bias as the initial accumulator
-            const float *pa = Xs + (rt * 32 + l31) * ldx + kh;
-            const float *pb = Ws + kh * ldw + ct * 32 + l31;
-#pragma unroll 8
-            for (int k = 0; k < K; k += 2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k * ldw], acc, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) acc[ct][i] = b;
+        }
+        const float *pb = Ws + (4 * kh) * ldw + l31;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t r = row_base + rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-                if (r < N) Y[r * M + ct * 32 + l31] = acc[i];
+        for (int j = 0; j < KBMAX; ++j) {
+            if (j < KB) {
+                const float av[4] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int ct = 0; ct < MT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], pb[(8 * j + i) * ldw + ct * 32], acc[ct], 0, 0, 0);
+                }
             }
         }
-        __syncthreads();                                               // every wave is done reading Xs
-        if (next < num_tiles) store_tile();
-        __syncthreads();
+        const int64_t row_base = (int64_t)tile * 32;
+        const int next = tile + total;
+        if (next < num_tiles) load_x(next);            // in flight during the stores and the other waves' MFMAs
+#pragma unroll
+        for (int ct = 0; ct < MT; ++ct) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t r = row_base + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                if (r < N) Y[r * M + ct * 32 + l31] = acc[ct][i];
+            }
+        }
+    }
+}
+
+struct RowGemmShape {
+    int kbmax, mt;
+    size_t lds;
+};
+
+inline bool rowgemm_shape(int32_t K, int32_t M, RowGemmShape &s)
+{
+    if (K <= 0 || M <= 0 || K % 4 != 0 || M % 32 != 0) return false;
+    const int kb = (K + 7) / 8;
+    s.kbmax = kb <= 4 ? 4 : kb <= 8 ? 8 : kb <= 16 ? 16 : kb <= 24 ? 24 : 0;
+    s.mt = M / 32;
+    if (!s.kbmax || (s.mt != 1 && s.mt != 2 && s.mt != 3 && s.mt != 4 && s.mt != 6)) return false;
+    if (4 * s.kbmax + 16 * s.mt > 176) return false;                 // registers: A tile + accumulators
+    s.lds = sizeof(float) * (size_t)kb * 8 * (size_t)(M + 1);
+    return s.lds <= 150 * 1024;
+}
+
+template <int KBMAX, int MT>
+int rowgemm_launch(const float *X, const float *W, const float *bias, float *Y, int64_t N, int K, int M, bool trans_w,
+                   size_t lds, hipStream_t st)
+{
+    const int64_t tiles = (N + 31) / 32;
+    if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: too many rows");
+    // dynamic LDS above 64 KiB has to be enabled per kernel (host-side attribute, no sync)
+    static bool raised[2] = {false, false};
+    if (lds > 64 * 1024 && !raised[trans_w ? 1 : 0]) {
+        const hipError_t e = trans_w
+            ? hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<KBMAX, MT, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
+            : hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<KBMAX, MT, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return fail((int)e, "stg_rowgemm_f32: %s", hipGetErrorString(e));
+        raised[trans_w ? 1 : 0] = true;
+    }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (lds + 1024)));
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, 256 * per_cu);
+    if (trans_w)
+        hipLaunchKernelGGL((rowgemm_kernel<KBMAX, MT, true>), dim3(blocks), dim3(kBlock), lds, st, X, W, bias, Y, N, K, M,
+                           (int)tiles);
+    else
+        hipLaunchKernelGGL((rowgemm_kernel<KBMAX, MT, false>), dim3(blocks), dim3(kBlock), lds, st, X, W, bias, Y, N, K, M,
+                           (int)tiles);
+    return check_launch("stg_rowgemm_f32");
+}
+
+template <int KBMAX>
+int rowgemm_mt(int mt, const float *X, const float *W, const float *bias, float *Y, int64_t N, int K, int M, bool tw,
+               size_t lds, hipStream_t st)
+{
+    switch (mt) {
+        case 1: return rowgemm_launch<KBMAX, 1>(X, W, bias, Y, N, K, M, tw, lds, st);
+        case 2: return rowgemm_launch<KBMAX, 2>(X, W, bias, Y, N, K, M, tw, lds, st);
+        case 3: return rowgemm_launch<KBMAX, 3>(X, W, bias, Y, N, K, M, tw, lds, st);
+        case 4: return rowgemm_launch<KBMAX, 4>(X, W, bias, Y, N, K, M, tw, lds, st);
+        default:
+            if constexpr (4 * KBMAX + 16 * 6 <= 176) return rowgemm_launch<KBMAX, 6>(X, W, bias, Y, N, K, M, tw, lds, st);
+            else return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: shape not covered");
     }
 }
 
@@ -141,9 +176,8 @@ __global__ __launch_bounds__(kBlock) void rowgemm_kernel(const float *__restrict
 
 extern "C" int stg_rowgemm_supported(int32_t K, int32_t M)
 {
-    if (K <= 0 || M <= 0 || K % 4 != 0 || K > stg::kRgMaxK || M % 32 != 0) return 0;
-    const size_t lds = sizeof(float) * ((size_t)stg::kRgRows * (K + 1) + (size_t)K * (M + 1));
-    return lds <= 150 * 1024 ? 1 : 0;
+    stg::RowGemmShape s;
+    return stg::rowgemm_shape(K, M, s) ? 1 : 0;
 }
 
 extern "C" int stg_rowgemm_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K,
@@ -152,35 +186,19 @@ extern "C" int stg_rowgemm_f32(const float *X, const float *W, const float *bias
     using namespace stg;
     if (N < 0 || K <= 0 || M <= 0)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_f32: bad shape N=%lld K=%d M=%d", (long long)N, K, M);
-    if (!stg_rowgemm_supported(K, M))
-        return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: needs K %% 4 == 0, K <= %d, M %% 32 == 0 and "
-                    "4 (128 (K+1) + K (M+1)) <= 150 KiB (got K=%d M=%d)", kRgMaxK, K, M);
+    RowGemmShape s;
+    if (!rowgemm_shape(K, M, s))
+        return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: needs K %% 4 == 0, K <= 192, M %% 32 == 0, M / 32 in {1,2,3,4,6} and "
+                    "K / 2 + M / 2 <= 176 registers (got K=%d M=%d)", K, M);
     if (N == 0) return 0;
     if (!X || !W || !Y) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_f32: NULL pointer argument");
     if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) % 16 != 0)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_f32: X and W must be 16-byte aligned");
-    const size_t lds = sizeof(float) * ((size_t)kRgRows * (K + 1) + (size_t)K * (M + 1));
-    // dynamic LDS above 64 KiB has to be enabled per kernel (host-side attribute, no sync)
-    static bool raised[2] = {false, false};
-    if (lds > 64 * 1024 && !raised[trans_w ? 1 : 0]) {
-        const hipError_t e = trans_w
-            ? hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
-            : hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return fail((int)e, "stg_rowgemm_f32: %s", hipGetErrorString(e));
-        raised[trans_w ? 1 : 0] = true;
-    }
-    const int64_t num_tiles = (N + kRgRows - 1) / kRgRows;
-    if (num_tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: too many rows");
-    const int per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);   // 160 KiB of LDS per CU
-    const unsigned blocks = (unsigned)std::min<int64_t>(num_tiles, 256 * per_cu);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (trans_w)
-        hipLaunchKernelGGL((rowgemm_kernel<true>), dim3(blocks), dim3(kBlock), lds, st, X, W, bias, Y, N, K, M,
-                           (int)num_tiles);
-    else
-        hipLaunchKernelGGL((rowgemm_kernel<false>), dim3(blocks), dim3(kBlock), lds, st, X, W, bias, Y, N, K, M,
-                           (int)num_tiles);
-    return check_launch("stg_rowgemm_f32");
+    switch (s.kbmax) {
+        case 4: return rowgemm_mt<4>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st);
+        case 8: return rowgemm_mt<8>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st);
+        case 16: return rowgemm_mt<16>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st);
+        default: return rowgemm_mt<24>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st);
+    }
 }

@@ -1,0 +1,270 @@
+// One TGCN step's row-local part as ONE kernel (reference nn/pytorch/temporal/tgcn.py:21-55):
+//   h_g = clamp(a3[:, g] + b3[g])                       g in {z, r, h}      (GCNConv bias + clamp, :22,30,38)
+//   Z = sigmoid([hz | H] Wz^T + bz)   R = sigmoid([hr | H] Wr^T + br)       (:24-27, :32-35)
+//   Ht = tanh([hh | H*R] Wh^T + bh)   Hn = Z*H + (1 - Z)*Ht                 (:40-47)
+// The unfused form runs 3 elementwise kernels around 3 rocBLAS GEMMs of 0.8 GFLOP each; at |V| = 50K each of
+// those GEMMs is 17-30 us of mostly fixed cost (launch, weight staging, first-load latency), 3-6x their matrix
+// time.  Here one wave owns a 32-row tile for the whole chain:
+//   * the three weight matrices (torch Linear layout [C][2C]) are staged ONCE per workgroup into LDS, transposed
+//     to [k][C + 1];
+//   * A operands come straight from global memory in MFMA layout (lane (row, kh) holds the float4s
+//     x[row][8 j + 4 kh ..], k permuted inside blocks of 8 -- see rowgemm.hip); bias + clamp are applied in
+//     those registers, which are also what gets written out as the concatenated GEMM operands [h_g | H] the
+//     backward pass (weight gradients) reads;
+//   * Z, R come out of v_mfma_f32_32x32x2_f32 in accumulator layout; R goes through a per-wave LDS tile to
+//     reach the A layout for H*R; the GRU blend runs in accumulator layout (H re-read as 128-B row segments).
+// Measured at |V| = 50K, C = 64 (phases switched off one at a time): loads + elementwise 23 us, MFMA +22, the
+// [N,2C] operand stores +20, the [N,C] accumulator-layout stores +21, staging +4 = 86 us against ~135 us for the six
+// launches it replaces; 180 MB of traffic, most of it the saved operands -- the next step is to stop saving the
+// concatenations.
+// fp32 in / fp32 accumulate.  Against the unfused stages of tgcn_cell.hip: the GEMM k-order differs from rocBLAS'
+// and sigmoid / tanh use the hardware exp2 / rcp forms, so outputs agree to ~1e-6 (tested at 1e-5).
+#include <algorithm>
+
+#include "stg_common.hpp"
+
+namespace stg {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// One wave per SIMD runs the whole chain, so the 192 transcendental evaluations per lane and tile are on the
+// critical path next to the MFMAs: hardware exp2 / rcp forms (|error| < 2e-7 absolute on (0,1) / (-1,1) outputs).
+__device__ __forceinline__ float sigmoid_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int C>
+struct CellShape {
+    static constexpr int K = 2 * C, KB = K / 8, KH = C / 8, MT = C / 32, LDW = C + 1;
+    static constexpr int kWeights = 3 * K * LDW;              // floats
+    static constexpr int kBias = 6 * C;                       // b3 [3C], bz, br, bh
+    static constexpr int kTile = 32 * LDW;                    // per wave
+    static constexpr size_t kLds = sizeof(float) * (size_t)(kWeights + kBias + kWavesPerBlock * kTile);
+};
+
+// row of accumulator element i for lane half kh (v_mfma_f32_32x32x2_f32 C/D layout)
+__device__ __forceinline__ int acc_row(int i, int kh) { return (i & 3) + 8 * (i >> 2) + 4 * kh; }
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void cell_fused_fwd_kernel(
+    const float *__restrict__ a3, const float *__restrict__ b3, const float *__restrict__ H,
+    const float *__restrict__ Wz, const float *__restrict__ bz, const float *__restrict__ Wr,
+    const float *__restrict__ br, const float *__restrict__ Wh, const float *__restrict__ bh,
+    float *__restrict__ CZ, float *__restrict__ CR, float *__restrict__ CH, float *__restrict__ Z,
+    float *__restrict__ R, float *__restrict__ Ht, float *__restrict__ Hn, int64_t N, float lo, float hi,
+    int num_tiles)
+{
+    using S = CellShape<C>;
+    constexpr int K = S::K, KH = S::KH, MT = S::MT, LDW = S::LDW;
+    extern __shared__ float lds[];
+    float *Ws = lds;                                   // 3 x [K][LDW]
+    float *bs = lds + S::kWeights;                     // b3 | bz | br | bh
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    float *T = bs + S::kBias + wave * S::kTile;        // [32][LDW] transpose tile of this wave
+
+    {   // stage the weights (W is [C][K]: element i = (m, k), 4 consecutive k) and the biases
+        const float *src[3] = {Wz, Wr, Wh};
+        constexpr int total4 = C * K / 4;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            float *dst = Ws + g * K * LDW;
+            for (int base = 0; base < total4; base += 8 * kBlock) {
+                float4 w4[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int i4 = base + s * kBlock + threadIdx.x;
+                    w4[s] = i4 < total4 ? *reinterpret_cast<const float4 *>(src[g] + (int64_t)i4 * 4)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int i = (base + s * kBlock + threadIdx.x) * 4;
+                    if (i < C * K) {
+                        const int m = i / K, k = i - m * K;
+                        dst[(k + 0) * LDW + m] = w4[s].x;
+                        dst[(k + 1) * LDW + m] = w4[s].y;
+                        dst[(k + 2) * LDW + m] = w4[s].z;
+                        dst[(k + 3) * LDW + m] = w4[s].w;
+                    }
+                }
+            }
+        }
+        for (int i = threadIdx.x; i < 3 * C; i += kBlock) bs[i] = b3[i];
+        for (int i = threadIdx.x; i < C; i += kBlock) {
+            bs[3 * C + i] = bz[i];
+            bs[4 * C + i] = br[i];
+            bs[5 * C + i] = bh[i];
+        }
+    }
+    __syncthreads();
+
+    const int total = gridDim.x * kWavesPerBlock;
+    for (int tile = blockIdx.x * kWavesPerBlock + wave; tile < num_tiles; tile += total) {
+        const int64_t row_base = (int64_t)tile * 32;
+        const int64_t row = row_base + l31;
+        const bool rok = row < N;
+
+        // ---- A operands: h_g = clamp(a3[:, g] + b3[g]) and H, in MFMA layout; written out as [h_g | H] ------
+        float4 ag[3][KH], hh[KH];
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            const int c = 8 * j + 4 * kh;
+            hh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rok) hh[j] = *reinterpret_cast<const float4 *>(H + row * C + c);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok) a = *reinterpret_cast<const float4 *>(a3 + row * 3 * C + g * C + c);
+                const float4 b = *reinterpret_cast<const float4 *>(bs + g * C + c);
+                a.x = fminf(fmaxf(a.x + b.x, lo), hi);
+                a.y = fminf(fmaxf(a.y + b.y, lo), hi);
+                a.z = fminf(fmaxf(a.z + b.z, lo), hi);
+                a.w = fminf(fmaxf(a.w + b.w, lo), hi);
+                ag[g][j] = a;
+            }
+        }
+        if (rok) {
+            float *dst[3] = {CZ, CR, CH};
+#pragma unroll
+            for (int j = 0; j < KH; ++j) {
+                const int c = 8 * j + 4 * kh;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) *reinterpret_cast<float4 *>(dst[g] + row * K + c) = ag[g][j];
+                *reinterpret_cast<float4 *>(CZ + row * K + C + c) = hh[j];
+                *reinterpret_cast<float4 *>(CR + row * K + C + c) = hh[j];
+            }
+        }
+
+        // ---- zl = [hz | H] Wz^T + bz,  rl = [hr | H] Wr^T + br  ----------------------------------------------
+        f32x16 accz[MT], accr[MT];
+#pragma unroll
+        for (int ct = 0; ct < MT; ++ct) {
+            const float vz = bs[3 * C + ct * 32 + l31], vr = bs[4 * C + ct * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accz[ct][i] = vz, accr[ct][i] = vr;
+        }
+        const float *pz = Ws + (4 * kh) * LDW + l31, *pr = pz + K * LDW, *ph = pr + K * LDW;
+#pragma unroll
+        for (int j = 0; j < 2 * KH; ++j) {
+            const float4 az4 = j < KH ? ag[0][j % KH] : hh[j % KH];
+            const float4 ar4 = j < KH ? ag[1][j % KH] : hh[j % KH];
+            const float az[4] = {az4.x, az4.y, az4.z, az4.w}, ar[4] = {ar4.x, ar4.y, ar4.z, ar4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int ct = 0; ct < MT; ++ct) {
+                    accz[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[i], pz[(8 * j + i) * LDW + ct * 32], accz[ct], 0, 0, 0);
+                    accr[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i], pr[(8 * j + i) * LDW + ct * 32], accr[ct], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- Z, R (accumulator layout) -> global; R -> LDS tile -> A layout; H*R ----------------------------
+#pragma unroll
+        for (int ct = 0; ct < MT; ++ct) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float z = sigmoid_(accz[ct][i]), r = sigmoid_(accr[ct][i]);
+                accz[ct][i] = z;
+                const int rr = acc_row(i, kh);
+                T[rr * LDW + ct * 32 + l31] = r;
+                if (row_base + rr < N) {
+                    Z[(row_base + rr) * C + ct * 32 + l31] = z;
+                    R[(row_base + rr) * C + ct * 32 + l31] = r;
+                }
+            }
+        }
+        wave_lds_sync();
+        float4 hr[KH];
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            const float *t = T + l31 * LDW + 8 * j + 4 * kh;
+            hr[j] = make_float4(hh[j].x * t[0], hh[j].y * t[1], hh[j].z * t[2], hh[j].w * t[3]);
+            if (rok) *reinterpret_cast<float4 *>(CH + row * K + C + 8 * j + 4 * kh) = hr[j];
+        }
+        wave_lds_sync();                               // T is rewritten by the next tile
+
+        // ---- hl = [hh | H*R] Wh^T + bh;  Ht = tanh(hl);  Hn = Z*H + (1 - Z)*Ht --------------------------------
+#pragma unroll
+        for (int ct = 0; ct < MT; ++ct) {
+            const float vh = bs[5 * C + ct * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accr[ct][i] = vh;
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * KH; ++j) {
+            const float4 a4 = j < KH ? ag[2][j % KH] : hr[j % KH];
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int ct = 0; ct < MT; ++ct)
+                    accr[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], ph[(8 * j + i) * LDW + ct * 32], accr[ct], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < MT; ++ct) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t r = row_base + acc_row(i, kh);
+                if (r < N) {
+                    const int64_t o = r * C + ct * 32 + l31;
+                    const float t = tanh_(accr[ct][i]), z = accz[ct][i], h = H[o];
+                    Ht[o] = t;
+                    Hn[o] = z * h + (1.0f - z) * t;
+                }
+            }
+        }
+    }
+}
+
+template <int C>
+int launch_fwd(const float *a3, const float *b3, const float *H, const float *Wz, const float *bz, const float *Wr,
+               const float *br, const float *Wh, const float *bh, float *CZ, float *CR, float *CH, float *Z, float *R,
+               float *Ht, float *Hn, int64_t N, float lo, float hi, hipStream_t stream)
+{
+    using S = CellShape<C>;
+    static bool raised = false;
+    if (S::kLds > 64 * 1024 && !raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_fwd_kernel<C>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
+        if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_fwd: %s", hipGetErrorString(e));
+        raised = true;
+    }
+    const int64_t tiles = (N + 31) / 32;
+    if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_fwd: too many rows");
+    const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / (S::kLds + 512));
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, 256 * per_cu);
+    hipLaunchKernelGGL((cell_fused_fwd_kernel<C>), dim3(blocks), dim3(kBlock), S::kLds, stream, a3, b3, H, Wz, bz, Wr, br,
+                       Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, (int)tiles);
+    return check_launch("stg_tgcn_cell_fused_fwd");
+}
+
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_tgcn_cell_fused_supported(int32_t C) { return C == 32 || C == 64; }
+
+extern "C" int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const float *H, const float *Wz, const float *bz,
+                                       const float *Wr, const float *br, const float *Wh, const float *bh, float *CZ,
+                                       float *CR, float *CH, float *Z, float *R, float *Ht, float *Hn, int64_t N, int32_t C,
+                                       float lo, float hi, void *stream)
+{
+    using namespace stg;
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_fwd: negative N");
+    if (!stg_tgcn_cell_fused_supported(C)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_fwd: C must be 32 or 64 (got %d)", C);
+    if (N == 0) return 0;
+    if (!a3 || !b3 || !H || !Wz || !bz || !Wr || !br || !Wh || !bh || !CZ || !CR || !CH || !Z || !R || !Ht || !Hn)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_fwd: NULL pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (C == 64) return launch_fwd<64>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
+    return launch_fwd<32>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
+}

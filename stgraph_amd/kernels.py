@@ -785,6 +785,31 @@ def gemm_tn_multi(As, Bs, colsum: bool = False):
     return (c_tot, cs_tot) if colsum else c_tot
 
 
+def tgcn_cell_fused_supported(C: int) -> bool:
+    return bool(_C.lib.stg_tgcn_cell_fused_supported(int(C)))
+
+
+def tgcn_cell_fused_fwd(a3, b3, H, Wz, bz, Wr, br, Wh, bh, lo: float, hi: float):
+    """The forward row-local chain of one TGCN step in one launch (stg_tgcn_cell_fused_fwd).
+    Returns (Hn, (CZ, CR, CH, Z, R, Ht))."""
+    N, C = H.shape
+    dev = H.device
+    ins = (a3, b3, H, Wz, bz, Wr, br, Wh, bh)
+    for t in ins:
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError("tgcn_cell_fused_fwd: operands must be contiguous fp32 tensors on one HIP device")
+    if a3.shape != (N, 3 * C) or b3.numel() != 3 * C or any(w.shape != (C, 2 * C) for w in (Wz, Wr, Wh)) or \
+            any(b.numel() != C for b in (bz, br, bh)):
+        raise ValueError("tgcn_cell_fused_fwd: operand shapes do not match hidden width C")
+    new = lambda w: torch.empty(N, w, dtype=torch.float32, device=dev)  # noqa: E731
+    CZ, CR, CH, Z, R, Ht, Hn = new(2 * C), new(2 * C), new(2 * C), new(C), new(C), new(C), new(C)
+    outs = (CZ, CR, CH, Z, R, Ht, Hn)
+    with torch.cuda.device(dev), _Timed("tgcn_cell_fused_fwd", 4 * N * C * 14, 12 * N * C * C):
+        _C.check(_C.lib.stg_tgcn_cell_fused_fwd(*[_ptr(t) for t in ins], *[_ptr(t) for t in outs], N, C,
+                                                float(lo), float(hi), _stream_ptr(dev)))
+    return Hn, (CZ, CR, CH, Z, R, Ht)
+
+
 def tgcn_cell_call(name: str, tensors, N: int, C: int, *scalars) -> None:
     """Launch one fused TGCN row-local stage (stg_tgcn_cell_<name>); tensors are validated here."""
     dev = tensors[0].device

@@ -26,11 +26,23 @@ from ... import deferred
 from ... import functional as SF
 
 CLAMP = 1e6      # tgcn.py:22,30,38
+_FUSED_FWD = True
+
+
+def set_fused_forward(enabled: bool) -> None:
+    """True (default): the forward chain (bias + clamp, three gate GEMMs, sigmoid / tanh, GRU blend) is ONE launch
+    (kernels.tgcn_cell_fused_fwd) when the hidden width is 32 or 64.  False: three fused elementwise kernels
+    around three rocBLAS GEMMs."""
+    global _FUSED_FWD
+    _FUSED_FWD = bool(enabled)
 
 
 def _cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh):
     N, C = H.shape
     dev = H.device
+    if _FUSED_FWD and kernels.tgcn_cell_fused_supported(C) and all(
+            t.is_contiguous() for t in (Wz, bz, Wr, br, Wh, bh)):
+        return kernels.tgcn_cell_fused_fwd(a3, b3, H, Wz, bz, Wr, br, Wh, bh, -CLAMP, CLAMP)
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
     CZ, CR, CH = new(N, 2 * C), new(N, 2 * C), new(N, 2 * C)
     kernels.tgcn_cell_call("prep_fwd", (a3, b3, H, CZ, CR, CH), N, C, -CLAMP, CLAMP)

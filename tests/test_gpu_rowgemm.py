@@ -1,4 +1,5 @@
-"""stg_rowgemm_f32 (64-row tile + W in LDS, fp32 MFMA) against an fp64 reference."""
+"""stg_rowgemm_f32 (one wave per 32-row tile, A operands from registers, W in LDS, fp32 MFMA) against an fp64
+reference."""
 import pytest
 import torch
 
@@ -34,7 +35,8 @@ def test_asymmetric_integer_data_exact(cuda):
 def test_unsupported_shapes(cuda):
     from stgraph_amd import _C, kernels
     assert not _C.lib.stg_rowgemm_supported(30, 64) and not _C.lib.stg_rowgemm_supported(64, 48)
-    assert not _C.lib.stg_rowgemm_supported(256, 256)
+    assert not _C.lib.stg_rowgemm_supported(256, 256) and not _C.lib.stg_rowgemm_supported(192, 192)
+    assert _C.lib.stg_rowgemm_supported(192, 128) and _C.lib.stg_rowgemm_supported(128, 192)
     x = torch.zeros(10, 30, device=cuda)
     with pytest.raises(_C.StgError):
         kernels.rowgemm(x, torch.zeros(30, 64, device=cuda))
