@@ -326,6 +326,21 @@ int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t
 int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *colsum_A, int64_t K, int32_t M,
                            int32_t N, void *workspace, size_t workspace_bytes, void *stream);
 
+/* GATConv's attention projections and their backward (nn/pytorch/static/gat_conv.py:43-45; torch ops in the
+ * reference), one streaming pass each over feat [N,H,D]:
+ *   fwd: el[n,h] = sum_d feat[n,h,d] attn_l[h,d],  er likewise with attn_r                  (el, er: [N,H])
+ *   bwd: dfeat = g + del (x) attn_l + der (x) attn_r   (g = gradient w.r.t. feat from stg_gat_bwd*, nullable = 0,
+ *        may alias dfeat);  dattn_l[h,d] = sum_n del[n,h] feat[n,h,d],  dattn_r likewise    (fixed-order partial sums)
+ * stg_gat_proj_supported(H, D) != 0 iff D % 4 == 0, D / 4 a power of two <= 64 and H D / 4 divides or is a
+ * multiple (<= 16x) of 256. */
+int stg_gat_proj_supported(int32_t H, int32_t D);
+int stg_gat_proj_fwd(const float *feat, const float *attn_l, const float *attn_r, float *el, float *er,
+                     int64_t N, int32_t H, int32_t D, void *stream);
+size_t stg_gat_proj_bwd_workspace_bytes(int64_t N, int32_t H, int32_t D);
+int stg_gat_proj_bwd(const float *feat, const float *attn_l, const float *attn_r, const float *del, const float *der,
+                     const float *g, float *dfeat, float *dattn_l, float *dattn_r, int64_t N, int32_t H, int32_t D,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 /* Y[N,M] = X[N,K] * op(W) + bias (bias nullable): forward / input-gradient GEMM of the dense layers
  * for N = number of vertices and small K, M.  op(W) = W [K,M] (trans_w = 0) or W^T with W [M,K]
  * (trans_w = 1, i.e. torch's Linear weight layout).  64-row X tile + W in LDS, fp32 matrix cores.

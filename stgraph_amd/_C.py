@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "stg_jit_compile", "stg_jit_free", "stg_jit_load", "stg_jit_get_function", "stg_jit_unload", "stg_jit_launch",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_layer_fwd", "stg_bias_act_bwd_workspace_bytes", "stg_bias_act_bwd",
     "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
+    "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_rowgemm_supported", "stg_rowgemm_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd",
@@ -119,6 +120,14 @@ def _load() -> ctypes.CDLL:
     lib.stg_gat_bwd_factored.argtypes = [vp] * 13 + [i32, i32, i32, f32, vp]
     lib.stg_gat_bwd_er.restype = ctypes.c_int
     lib.stg_gat_bwd_er.argtypes = [vp] * 5 + [i32, i32, i32, vp]
+    lib.stg_gat_proj_supported.restype = ctypes.c_int
+    lib.stg_gat_proj_supported.argtypes = [i32, i32]
+    lib.stg_gat_proj_fwd.restype = ctypes.c_int
+    lib.stg_gat_proj_fwd.argtypes = [vp] * 5 + [i64, i32, i32, vp]
+    lib.stg_gat_proj_bwd_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_gat_proj_bwd_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.stg_gat_proj_bwd.restype = ctypes.c_int
+    lib.stg_gat_proj_bwd.argtypes = [vp] * 9 + [i64, i32, i32, vp, ctypes.c_size_t, vp]
     lib.stg_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_gemm_tn_workspace_bytes.argtypes = [i64, i32, i32]
     lib.stg_gemm_tn_f32.restype = ctypes.c_int

@@ -664,6 +664,50 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
 
 
 # ------------------------------------------------------- dense neighbour: weight gradient
+def gat_proj_supported(H: int, D: int) -> bool:
+    return bool(_C.lib.stg_gat_proj_supported(int(H), int(D)))
+
+
+def gat_proj_fwd(feat: torch.Tensor, attn_l: torch.Tensor, attn_r: torch.Tensor):
+    """(el, er) [N,H,1] = sum_d feat[n,h,d] * attn_{l,r}[h,d] in one pass (stg_gat_proj_fwd)."""
+    feat = _f32(feat, "feat_src")
+    dev = feat.device
+    N, H, D = feat.shape
+    al, ar = _f32(attn_l, "attn_l", dev), _f32(attn_r, "attn_r", dev)
+    if al.numel() != H * D or ar.numel() != H * D:
+        raise ValueError("attn_l / attn_r must be [H, D]")
+    el = torch.empty(N, H, 1, dtype=torch.float32, device=dev)
+    er = torch.empty(N, H, 1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("gat_proj_fwd", 4 * N * H * (D + 2), 4 * N * H * D):
+        _C.check(_C.lib.stg_gat_proj_fwd(_ptr(feat), _ptr(al), _ptr(ar), _ptr(el), _ptr(er), N, H, D, _stream_ptr(dev)))
+    return el, er
+
+
+def gat_proj_bwd(feat, attn_l, attn_r, d_el, d_er, g: torch.Tensor | None, inplace: bool = False):
+    """(dfeat, dattn_l, dattn_r): ``dfeat = g + d_el*attn_l + d_er*attn_r`` (into ``g`` itself with ``inplace``),
+    ``dattn_* = sum_n d_e*[n,h] feat[n,h,:]`` (stg_gat_proj_bwd)."""
+    feat = _f32(feat, "feat_src")
+    dev = feat.device
+    N, H, D = feat.shape
+    al, ar = _f32(attn_l, "attn_l", dev), _f32(attn_r, "attn_r", dev)
+    d_el, d_er = _f32(d_el, "d_el", dev), _f32(d_er, "d_er", dev)
+    if d_el.numel() != N * H or d_er.numel() != N * H:
+        raise ValueError("d_el / d_er must be [N, H, 1]")
+    if g is not None:
+        g = _f32(g, "g", dev)
+        if g.shape != feat.shape:
+            raise ValueError("g must have feat's shape")
+    dfeat = g if (inplace and g is not None) else torch.empty_like(feat)
+    dal = torch.empty(H, D, dtype=torch.float32, device=dev)
+    dar = torch.empty(H, D, dtype=torch.float32, device=dev)
+    ws_bytes = int(_C.lib.stg_gat_proj_bwd_workspace_bytes(N, H, D))
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _Timed("gat_proj_bwd", 4 * N * H * D * (3 if g is not None else 2), 8 * N * H * D):
+        _C.check(_C.lib.stg_gat_proj_bwd(_ptr(feat), _ptr(al), _ptr(ar), _ptr(d_el), _ptr(d_er), _ptr(g), _ptr(dfeat),
+                                         _ptr(dal), _ptr(dar), N, H, D, _ptr(ws), ws_bytes, _stream_ptr(dev)))
+    return dfeat, dal, dar
+
+
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, colsum: bool = False):
     """``a.T @ b`` for tall-skinny fp32 operands ``a [K, M]``, ``b [K, N]`` (stg_gemm_tn_f32).
     ``colsum=True`` also returns ``a.sum(0)`` from the same launch (stg_gemm_tn_colsum_f32)."""

@@ -193,6 +193,41 @@ def gcn_layer_tail(graph, h: torch.Tensor, bias, activation, edge_weight=None) -
                                kernels.rows_by_node_ids(graph.graph_type()), activation_code(activation))
 
 
+class _GatLayer(torch.autograd.Function):
+    """GATConv from the projected features on: attention projections (one pass), the emitted GAT units K0/K1
+    forward; K2 backward followed by ONE pass that adds the projection terms to the feature gradient and forms
+    the attn_l / attn_r gradients (reference nn/pytorch/static/gat_conv.py:43-56)."""
+
+    @staticmethod
+    def forward(ctx, feat, attn_l, attn_r, fwd_csr, bwd_csr, use_nid, slope):
+        feat = feat.contiguous()
+        el, er = kernels.gat_proj_fwd(feat, attn_l, attn_r)
+        out, A, S = kernels.gat_fwd(el, er, feat, fwd_csr, slope, use_nid)
+        ctx.save_for_backward(feat, attn_l, attn_r, el, er, A, S, out)
+        ctx.csrs, ctx.use_nid, ctx.slope = (fwd_csr, bwd_csr), use_nid, slope
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, attn_l, attn_r, el, er, A, S, out = ctx.saved_tensors
+        fwd_csr, bwd_csr = ctx.csrs
+        gf, gel, ger = kernels.gat_bwd(A, S, out, g.contiguous(), el, er, feat, fwd_csr, bwd_csr, ctx.slope, ctx.use_nid)
+        dfeat, dal, dar = kernels.gat_proj_bwd(feat, attn_l, attn_r, gel, ger, gf, inplace=True)
+        return dfeat, dal.view_as(attn_l), dar.view_as(attn_r), None, None, None, None
+
+
+def gat_layer_usable(graph, feat3: torch.Tensor) -> bool:
+    from ..graph.dynamic.dynamic_graph import DynamicGraph
+    return (feat3.is_cuda and feat3.dtype == torch.float32 and feat3.dim() == 3 and hasattr(graph, "csr")
+            and not isinstance(graph, DynamicGraph) and not kernels.reference_compat()
+            and kernels.gat_proj_supported(feat3.shape[1], feat3.shape[2]))
+
+
+def gat_layer(graph, feat3: torch.Tensor, attn_l, attn_r, slope: float) -> torch.Tensor:
+    return _GatLayer.apply(feat3, attn_l, attn_r, graph.csr("fwd"), graph.csr("bwd"),
+                           kernels.rows_by_node_ids(graph.graph_type()), float(slope))
+
+
 def agg_transform_usable(graph, x: torch.Tensor, W) -> bool:
     """The fused kernel pays (and is supported) when the gather can run at the narrow input width.
     ``W``: the weight tensor or its (in, out) shape."""

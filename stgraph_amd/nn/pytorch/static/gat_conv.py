@@ -14,6 +14,7 @@ from torch import nn
 
 from ....compiler import STGraph
 from ....compiler.backend.pytorch.torch_callback import STGraphBackendTorch
+from ... import functional as SF
 
 
 class GATConv(nn.Module):
@@ -44,6 +45,11 @@ class GATConv(nn.Module):
     def forward(self, graph, feat):
         h_dst = h_src = self.feat_drop(feat)  # noqa: F841
         feat_src = feat_dst = self.fc(h_src).view(-1, self._num_heads, self._out_feats)
+        if SF.gat_layer_usable(graph, feat_src):
+            # static graphs: projections, the three GAT units and the projection gradients as one autograd node
+            # (the same kernels the compiled vertex function below dispatches to, minus ~15 torch passes over [N,H,D])
+            rst = SF.gat_layer(graph, feat_src, self.attn_l, self.attn_r, self.negative_slope)
+            return self.activation(rst) if self.activation else rst
         el = (feat_src * self.attn_l).sum(dim=-1).unsqueeze(-1)
         er = (feat_dst * self.attn_r).sum(dim=-1).unsqueeze(-1)
 

@@ -1,0 +1,75 @@
+"""GATConv's attention projections fused (csrc/gat_proj.hip) and the one-node GAT layer built on them, against
+torch's own ops for reference nn/pytorch/static/gat_conv.py:43-45 and against the compiled-vertex-function path."""
+import pytest
+import torch
+
+from tests.util import random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,H,D", [(1, 1, 4), (7, 2, 4), (1000, 8, 8), (5000, 8, 64), (3000, 4, 256), (2049, 16, 64),
+                                   (257, 1, 64), (40_000, 8, 64)])
+def test_projection_kernels_match_torch(cuda, N, H, D):
+    from stgraph_amd import kernels
+    assert kernels.gat_proj_supported(H, D)
+    g = torch.Generator(device=cuda).manual_seed(N + H + D)
+    r = lambda *s: torch.randn(*s, device=cuda, generator=g)  # noqa: E731
+    feat, al, ar = r(N, H, D), r(H, D), r(H, D)
+    el, er = kernels.gat_proj_fwd(feat, al, ar)
+    torch.testing.assert_close(el, (feat * al).sum(-1, keepdim=True), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(er, (feat * ar).sum(-1, keepdim=True), rtol=1e-5, atol=1e-5)
+    d_el, d_er, gin = r(N, H, 1), r(N, H, 1), r(N, H, D)
+    want_f = gin + d_el * al + d_er * ar
+    want_l = (d_el.double() * feat.double()).sum(0)
+    want_r = (d_er.double() * feat.double()).sum(0)
+    for inplace in (False, True):
+        gsrc = gin.clone()
+        df, dl, dr = kernels.gat_proj_bwd(feat, al, ar, d_el, d_er, gsrc, inplace=inplace)
+        assert (df.data_ptr() == gsrc.data_ptr()) == inplace
+        torch.testing.assert_close(df, want_f, rtol=1e-6, atol=1e-6)
+        scale = float((d_el.abs().double() * feat.abs().double()).sum(0).max()) + 1
+        torch.testing.assert_close(dl.double(), want_l, rtol=1e-5, atol=2e-6 * scale)
+        torch.testing.assert_close(dr.double(), want_r, rtol=1e-5, atol=2e-6 * scale)
+    df0, dl0, _ = kernels.gat_proj_bwd(feat, al, ar, d_el, d_er, None)
+    torch.testing.assert_close(df0, d_el * al + d_er * ar, rtol=1e-6, atol=1e-6)
+    dl1 = kernels.gat_proj_bwd(feat, al, ar, d_el, d_er, None)[1]
+    assert torch.equal(dl0, dl1)                                   # fixed reduction order
+
+
+def test_unsupported_shapes_fall_back(cuda):
+    from stgraph_amd import kernels
+    assert not kernels.gat_proj_supported(8, 7) and not kernels.gat_proj_supported(8, 48)
+    assert not kernels.gat_proj_supported(3, 64) or 3 * 64 // 4 in (48,)      # 48 float4 per row does not tile 256
+    assert not kernels.gat_proj_supported(3, 64)
+
+
+@pytest.mark.parametrize("H,D", [(2, 4), (8, 8), (8, 64)])
+def test_gatconv_fused_layer_equals_compiled_path(cuda, H, D):
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    n, e, fin = 3000, 40000, 24
+    src, dst = random_graph(H * D, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    torch.manual_seed(1)
+    conv = GATConv(fin, D, H).to(cuda)
+    x0 = torch.randn(n, fin, device=cuda)
+    R = torch.randn(n, H, D, device=cuda)
+    res = []
+    for fused in (True, False):
+        usable = SF.gat_layer_usable
+        if not fused:
+            SF.gat_layer_usable = lambda *a: False
+        try:
+            conv.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            out = conv(g, x)
+            (out * R).sum().backward()
+        finally:
+            SF.gat_layer_usable = usable
+        res.append((out.detach().clone(), x.grad.clone(), conv.attn_l.grad.clone(), conv.attn_r.grad.clone(),
+                    conv.fc.weight.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])                       # the output does not depend on el / er (D2)
+    for a, b, name in zip(res[0][1:], res[1][1:], ("x", "attn_l", "attn_r", "fc.weight")):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max() + 1), msg=lambda m, n=name: f"{n}: {m}")
