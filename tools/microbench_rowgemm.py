@@ -15,7 +15,8 @@ def main():
     dev = torch.device("cuda", 0)
     only = int(sys.argv[1]) if len(sys.argv) > 1 else None      # one shape per run: per-shape device times under rocprofv3
     for idx, (N, K, M, tw) in enumerate(((50_000, 128, 64, True), (50_000, 64, 128, False), (50_000, 192, 32, True),
-                        (50_000, 64, 32, True), (25_000, 128, 64, True), (1_000_000, 64, 128, False))):
+                        (50_000, 64, 32, True), (25_000, 128, 64, True), (1_000_000, 64, 128, False),
+                                            (1_000_000, 128, 128, False), (1_000_000, 128, 128, True), (256_000, 64, 128, True))):
         if only is not None and idx != only:
             continue
         x = torch.randn(N, K, device=dev)
