@@ -465,6 +465,11 @@ def main():
             line["roofline"]["traffic"] = 0.5 * (pmc["cfg2_forward_csr"]["traffic_bytes"] +
                                                  pmc["cfg2_backward_csr"]["traffic_bytes"])
             line["roofline"]["traffic_source"] = os.path.relpath(pmc_files[-1], ROOT)
+            # the same counters under the microarch guide's flat rule (FETCH_SIZE x 2 for wide coalesced reads);
+            # `traffic` uses the factor measured on a known-bytes launch of this kernel's own access shape
+            # (8 B per lane: 1.65), see DESIGN.md section 3
+            line["roofline"]["traffic_guide_x2_rule"] = 0.5 * (pmc["cfg2_forward_csr"]["traffic_bytes_x2_rule"] +
+                                                               pmc["cfg2_backward_csr"]["traffic_bytes_x2_rule"])
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_gcn(meta)
