@@ -35,7 +35,8 @@ class CSR:
         h = kernels.csr_ctor_host(arr[:, 0], arr[:, 1], arr[:, 2], edge_weight, num_nodes, is_edge_reverse)
         dev = torch.device(device) if device is not None else default_device()
         up = lambda k: torch.from_numpy(h[k]).to(dev)  # noqa: E731
-        self._csr = kernels.DeviceCSR(up("row_offset"), up("column_indices"), up("eids"), up("node_ids"))
+        self._csr = kernels.DeviceCSR(up("row_offset"), up("column_indices"), up("eids"), up("node_ids"),
+                                      degree_sorted=True)      # csr.cu:142-154
         self.out_degrees = h["out_degrees"].tolist()
         self.in_degrees = h["in_degrees"].tolist()
         self.weighted_out_degrees = h["weighted_out_degrees"].tolist()

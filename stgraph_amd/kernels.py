@@ -129,6 +129,10 @@ class DeviceCSR:
     column_indices: torch.Tensor   # int32 [E]
     eids: torch.Tensor             # int32 [E]
     node_ids: torch.Tensor         # int32 [N]  rows by non-increasing degree
+    # True when node_ids is KNOWN to be ordered by non-increasing degree (set by this package's builders).  Only
+    # then may the aggregation find its long rows through it (stg_gcn_agg_edge's rows_by_degree); a CSR assembled
+    # by hand keeps every row on the row-group path.
+    degree_sorted: bool = False
 
     @property
     def num_nodes(self) -> int:
@@ -197,8 +201,8 @@ def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str) -> Gra
         raise ValueError("num_nodes must be >= 0")
     i32 = dict(dtype=torch.int32, device=device)
     perm = torch.empty(E, dtype=torch.int64, device=device)
-    fwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32))
-    bwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32))
+    fwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32), True)
+    bwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32), True)
     indeg, outdeg = torch.empty(N, **i32), torch.empty(N, **i32)
     arrays = [perm, fwd.row_offset, fwd.column_indices, fwd.eids, fwd.node_ids,
               bwd.row_offset, bwd.column_indices, bwd.eids, bwd.node_ids, indeg, outdeg]
@@ -350,6 +354,7 @@ class StoreCSR(DeviceCSR):
     def __init__(self, es: EdgeSet, reverse: bool, row_offset, column_indices, node_ids, degrees,
                  key_order: bool = False):
         self.row_offset, self.column_indices, self.node_ids, self.degrees = row_offset, column_indices, node_ids, degrees
+        self.degree_sorted = True
         self._es, self._reverse, self._labels, self._key_order = es, bool(reverse), None, bool(key_order)
 
     def _emit_labels(self):
@@ -496,12 +501,12 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
             if epilogue:
                 _C.check(_C.lib.stg_gcn_layer_fwd(
                     _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(bias), int(act), _ptr(out),
-                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids if _LONG_ROWS else None),
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids if (_LONG_ROWS and csr.degree_sorted) else None),
                     N, csr.num_edges, F, _stream_ptr(dev)))
             elif _EDGE_CACHE:
                 _C.check(_C.lib.stg_gcn_agg_edge(
                     _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(out),
-                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids if _LONG_ROWS else None),
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids if (_LONG_ROWS and csr.degree_sorted) else None),
                     N, csr.num_edges, F, fa, _stream_ptr(dev)))
             else:
                 _C.check(_C.lib.stg_gcn_agg(

@@ -47,6 +47,7 @@ def test_long_rows_bit_exact(cuda, F, use_ew):
     w_np = (rng.random(len(src)) + 0.5).astype(np.float32)
     x = torch.from_numpy(x_np).to(cuda)
     w = torch.from_numpy(w_np).to(cuda) if use_ew else None
+    assert g.csr("fwd").degree_sorted and g.csr("bwd").degree_sorted       # what enables the long-row workgroups
     assert int((g.csr("fwd").row_offset[1:] - g.csr("fwd").row_offset[:-1]).max()) > 32
     assert int((g.csr("bwd").row_offset[1:] - g.csr("bwd").row_offset[:-1]).max()) > 32
     for side, ocsr in (("fwd", og.fwd), ("bwd", og.bwd)):
@@ -115,3 +116,19 @@ def test_skewed_graph_at_scale_properties(cuda):
             for e in range(ro[r], ro[r + 1]):
                 acc = acc + nh[col[e]] * xh[col[e]]
             assert np.array_equal(ah[r], acc * nh[r])
+
+
+def test_hand_built_csr_keeps_every_row_on_the_row_group_path(cuda):
+    """A DeviceCSR assembled by hand (node_ids in arbitrary order) must not be searched for long rows through it."""
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    n = 500
+    src, dst = skewed_graph(9, n, 4000)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    f = g.csr("fwd")
+    shuffled = f.node_ids[torch.randperm(n, device=cuda)]
+    mine = kernels.DeviceCSR(f.row_offset, f.column_indices, f.eids, shuffled)
+    assert not mine.degree_sorted
+    x = torch.randn(n, 16, device=cuda)
+    norm = torch.rand(n, 1, device=cuda) + 0.5
+    assert torch.equal(kernels.gcn_agg(x, norm, norm, mine, use_node_ids=True), kernels.gcn_agg(x, norm, norm, f))
