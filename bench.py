@@ -10,8 +10,9 @@ with |V| = 1M, |E| = 16M (uniform, duplicate-free, seed 1).  One step = one trai
 N > 1: N independent replicas of that workload (a single-graph GCN does not shard:
 SURVEY.md 8(e) "replicas only"), `value` = sum over ranks.
 
-Every line also carries a "cora" object (BASELINE configs[0]: GCN on a Cora-shaped graph, epochs/s,
-rank 0 only) and a "tgcn" object: BASELINE.json configs[3] (static-temporal TGCN,
+Every line also carries a "cora" object (BASELINE configs[0]: GCN on a Cora-shaped graph, epochs/s, plus
+"roofline_x1024": the aggregation at the Cora widths on 1024 disjoint replicas of that graph, fraction of the
+HBM roofline -- rank 0 only) and a "tgcn" object: BASELINE.json configs[3] (static-temporal TGCN,
 |V| = 50K, |E| = 500K, T = 1000, feat 32, hidden 64, backprop_every 25 => 40 BPTT windows)
 with the windows sharded over the N ranks and ONE RCCL all-reduce of the flattened gradient
 bucket per optimizer step -- the path the north star scales to 8 GPUs ("scaling": "strong":
@@ -207,7 +208,42 @@ def cora_run(device, epochs=200):
         out[mode] = {"epochs_per_s": 1.0 / float(np.mean(dur)), "ms_per_epoch": float(np.mean(dur)) * 1e3,
                      "edges_feat_per_s": 2 * e * (16 + 7) / float(np.mean(dur)), "final_loss": float(loss)}
     out["metric"], out["value"] = "epochs/s", out["hip_graph"]["epochs_per_s"]
+    out["roofline_x1024"] = cora_roofline(device, src, dst, n)
     return out
+
+
+def cora_roofline(device, src, dst, n, K=1024, iters=10):
+    """SURVEY.md 8(d) "Cora x K": K disjoint replicas of the Cora-shaped graph (block diagonal, |V| = 2.77M,
+    |E| = 10.8M), so that the aggregation at the layer widths of the Cora model (16, 7) is bandwidth- instead of
+    launch-bound.  Forward + backward launch per width, HIP events, algorithmic bytes of SURVEY.md 8(d)."""
+    from stgraph_amd import kernels
+    big_src = np.concatenate([src + k * n for k in range(K)]).astype(np.int32)
+    big_dst = np.concatenate([dst + k * n for k in range(K)]).astype(np.int32)
+    N, E = n * K, len(big_src)
+    g = kernels.build_graph_csr(big_src, big_dst, N, device)
+    norm = torch.rand(N, 1, device=device) + 0.5
+    res = {"workload": f"gcn_agg forward + backward launch on {K} disjoint replicas of the Cora-shaped graph "
+                       f"(|V|={N}, |E|={E})"}
+    for F_ in (16, 7):
+        x = torch.randn(N, F_, device=device)
+        nbytes = kernels.gcn_agg_algorithmic_bytes(N, E, F_, False)
+        ms = []
+        for csr in (g.fwd, g.bwd):
+            for _ in range(2):
+                kernels.gcn_agg(x, norm, norm, csr)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                kernels.gcn_agg(x, norm, norm, csr)
+            b.record()
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(b) / iters)
+        gbps = 2 * nbytes / (sum(ms) * 1e-3) / 1e9
+        res[f"F{F_}"] = {"fwd_ms": ms[0], "bwd_ms": ms[1], "algorithmic_bytes_per_launch": nbytes,
+                         "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
+    del g, x, norm
+    torch.cuda.empty_cache()
+    return res
 
 
 # ----------------------------------------------------------------------------- TGCN (cfg 4)
