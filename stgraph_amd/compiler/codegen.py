@@ -283,8 +283,18 @@ class KernelSpec:
         return "bwd" if self.row_type == ValType.SRC else "fwd"
 
     @property
+    def vec(self) -> int:
+        """Consecutive feature indices per lane: 4 when the innermost enumerated dimension is a multiple of 4
+        (a lane's four elements are then contiguous in every tensor that is indexed by the feature at all, and
+        16-byte aligned: the compiler fuses their loads / stores into dwordx4 accesses)."""
+        inner = self.full[-1] if self.full else 1
+        # measured at |V| = 1M, |E| = 16M (profiles/r01_codegen_vs_handwritten.jsonl): F = 128: 0.60 -> 0.78 of the
+        # HBM roofline, F = 64: 0.66 -> 0.67, F = 16: 0.35 -> 0.32 (four lanes per row leave too few rows in flight)
+        return 4 if inner % 4 == 0 and _numel(self.full) >= 64 else 1
+
+    @property
     def lanes_per_row(self) -> int:
-        return min(256, _pow2_at_least(max(1, _numel(self.full))))
+        return min(256, _pow2_at_least(max(1, _numel(self.full) // self.vec)))
 
 
 class _Emitter:
@@ -447,31 +457,48 @@ def emit_edge_outputs(an: Analysis, key_of, name: str, roots: list) -> KernelSpe
 def _finish(em: _Emitter, init: list, edge_lines: list, post: list, has_loop: bool) -> KernelSpec:
     spec = KernelSpec(em.name, em.row_type, has_loop, em.full or (1,), em.tensors, em.outputs, em.uses_eids,
                       stage=em.stage)
-    G = spec.lanes_per_row
+    G, V = spec.lanes_per_row, spec.vec
     fmax = _numel(spec.full)
-    ind = "            "
-    params = "".join(f"float *__restrict__ T{i}, " for i in range(len(em.tensors)))
+    naccs = len(init)
+    params = "".join(f"float *__restrict__ T{i}_, " for i in range(len(em.tensors)))
     body = [f'extern "C" __global__ void __launch_bounds__(256) {em.name}(', f"    {params}",
             "    const int *__restrict__ row_offset, const int *__restrict__ col_idx, const int *__restrict__ eids,",
-            "    const int *__restrict__ node_ids, int N)", "{",
-            f"    const int r_idx = blockIdx.x * {256 // G} + (int)(threadIdx.x / {G});",
-            "    if (r_idx >= N) return;",
-            "    const int row = node_ids ? node_ids[r_idx] : r_idx;"]
+            "    const int *__restrict__ node_ids, int N)", "{"]
+    # torch allocations are 256-byte aligned and row sizes that reach the vector path are multiples of 4 floats
+    body += [f"    float *__restrict__ T{i} = (float *)__builtin_assume_aligned(T{i}_, 16);" for i in range(len(em.tensors))]
+    body += [f"    const int r_idx = blockIdx.x * {256 // G} + (int)(threadIdx.x / {G});",
+             "    if (r_idx >= N) return;",
+             "    const int row = node_ids ? node_ids[r_idx] : r_idx;"]
     if has_loop:
         body.append("    const int beg = row_offset[row], end = row_offset[row + 1];")
-    body.append(f"    for (int tx = (int)(threadIdx.x % {G}); tx < {fmax}; tx += {G}) {{")
-    body += ["        " + s for s in init]
+    body.append(f"    for (int tx0 = (int)(threadIdx.x % {G}) * {V}; tx0 < {fmax}; tx0 += {G * V}) {{")
+    ind1, ind2, ind3 = " " * 8, " " * 12, " " * 16
+    for k in range(naccs):
+        body.append(ind1 + f"float acc{k}_[{V}];")
+    if naccs:
+        body.append(ind1 + f"for (int q = 0; q < {V}; ++q) {{ " + " ".join(f"acc{k}_[q] = 0.0f;" for k in range(naccs)) + " }")
+    refs = [f"float &acc{k} = acc{k}_[q];" for k in range(naccs)]
     if has_loop:
         # unrolled so that the column / eid / gather loads of several edges are in flight together; the adds stay
-        # in CSR order (no reassociation without fast-math), so the sums are unchanged
+        # in CSR order per (row, feature) (no reassociation without fast-math), so the sums are unchanged
         body.append("#pragma unroll 4")
-        body.append("        for (int e = beg; e < end; ++e) {")
-        body.append(ind + "const int c = col_idx[e]; (void)c;")
+        body.append(ind1 + "for (int e = beg; e < end; ++e) {")
+        body.append(ind2 + "const int c = col_idx[e]; (void)c;")
         if em.uses_eids:
-            body.append(ind + "const int eid = eids[e];")
-        body += [ind + s for s in edge_lines]
-        body.append("        }")
-    body += ["        " + s for s in post]
+            body.append(ind2 + "const int eid = eids[e];")
+        body.append("#pragma unroll")
+        body.append(ind2 + f"for (int q = 0; q < {V}; ++q) {{")
+        body.append(ind3 + "const int tx = tx0 + q; (void)tx;")
+        body += [ind3 + r for r in refs]
+        body += [ind3 + s for s in edge_lines]
+        body.append(ind2 + "}")
+        body.append(ind1 + "}")
+    body.append("#pragma unroll")
+    body.append(ind1 + f"for (int q = 0; q < {V}; ++q) {{")
+    body.append(ind2 + "const int tx = tx0 + q; (void)tx;")
+    body += [ind2 + r for r in refs]
+    body += [ind2 + s for s in post]
+    body.append(ind1 + "}")
     body += ["    }", "}", ""]
     spec.source = "\n".join(body)
     return spec

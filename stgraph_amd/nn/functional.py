@@ -181,9 +181,11 @@ def activation_code(activation):
 def gcn_layer_tail_usable(graph, h: torch.Tensor, activation) -> bool:
     """Static graphs only: a dynamic graph's backward CSR is reached through the executor's timestamp
     stack (compiler/executor.py), which this shortcut does not enter."""
+    from ..compiler import dispatch
     from ..graph.dynamic.dynamic_graph import DynamicGraph
     return (h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and hasattr(graph, "csr")
             and not isinstance(graph, DynamicGraph) and kernels.layer_epilogue_usable()
+            and not dispatch._FORCE_GENERATED
             and activation_code(activation) is not None)
 
 
@@ -217,9 +219,11 @@ class _GatLayer(torch.autograd.Function):
 
 
 def gat_layer_usable(graph, feat3: torch.Tensor) -> bool:
+    from ..compiler import dispatch
     from ..graph.dynamic.dynamic_graph import DynamicGraph
     return (feat3.is_cuda and feat3.dtype == torch.float32 and feat3.dim() == 3 and hasattr(graph, "csr")
             and not isinstance(graph, DynamicGraph) and not kernels.reference_compat()
+            and not dispatch._FORCE_GENERATED
             and kernels.gat_proj_supported(feat3.shape[1], feat3.shape[2]))
 
 

@@ -78,7 +78,13 @@ def test_units_of_generated_plans():
     assert p.differentiable() == [("e", "b"), ("e", "w"), ("n", "h")]
     # broadcast [H,1] x [H,D]: lanes enumerate H*D features
     p = _plan(lambda v: sum([nb.a * nb.f for nb in v.innbs]), {"a": (4, 1), "f": (4, 8)}, {}, ["a", "f"])
-    assert p.fwd_kernels[0].lanes_per_row == 32 and "tx / 8" in p.fwd_kernels[0].source
+    assert p.fwd_kernels[0].vec == 1 and p.fwd_kernels[0].lanes_per_row == 32 and "tx / 8" in p.fwd_kernels[0].source
+    # wide rows (>= 64 features, innermost dimension a multiple of 4): four consecutive features per lane
+    p = _plan(lambda v: sum([nb.a * nb.f for nb in v.innbs]), {"a": (8, 1), "f": (8, 16)}, {}, ["a", "f"])
+    assert p.fwd_kernels[0].vec == 4 and p.fwd_kernels[0].lanes_per_row == 32 and "tx / 16" in p.fwd_kernels[0].source
+    # an innermost dimension that is not a multiple of 4 keeps one feature per lane
+    p = _plan(lambda v: sum([nb.h for nb in v.innbs]), {"h": (7,)}, {}, ["h"])
+    assert p.fwd_kernels[0].vec == 1 and p.fwd_kernels[0].lanes_per_row == 8
     # no differentiable input: no backward kernels at all
     p = _plan(lambda v: sum([nb.h for nb in v.innbs]), {"h": (8,)}, {}, [])
     assert p.bwd_kernels == [] and "expf" not in p.source
