@@ -663,9 +663,11 @@ extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float 
                            dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,      \
                            column_indices, eids, node_ids, N, H, D, slope);                                \
     })
+    /* two-chunk rows (H*D = 512 at cfg3): unroll 2, not 4 -- 101 -> 80-odd VGPRs buys a fifth and sixth wave per   \
+       SIMD, worth more than the deeper gather queue (measured 3.42 -> 2.90 ms; unroll 1: 3.1) */                  \
 #define STG_K2F_VEC(VEC, P2)                           \
     if (p.chunks == 4) { STG_K2F(VEC, 4, 2, P2); }     \
-    else if (p.chunks == 2) { STG_K2F(VEC, 2, 4, P2); } \
+    else if (p.chunks == 2) { STG_K2F(VEC, 2, 2, P2); } \
     else { STG_K2F(VEC, 1, 8, P2); }
     if (pow2) {
         if (p.vec == 4) { STG_K2F_VEC(4, true) } else if (p.vec == 2) { STG_K2F_VEC(2, true) } else { STG_K2F_VEC(1, true) }
