@@ -11,12 +11,15 @@
 //     x[row][8 j + 4 kh ..], k permuted inside blocks of 8 -- see rowgemm.hip); bias + clamp are applied in
 //     those registers, which are also what gets written out as the concatenated GEMM operands [h_g | H] the
 //     backward pass (weight gradients) reads;
-//   * Z, R come out of v_mfma_f32_32x32x2_f32 in accumulator layout; R goes through a per-wave LDS tile to
-//     reach the A layout for H*R; the GRU blend runs in accumulator layout (H re-read as 128-B row segments).
-// Measured at |V| = 50K, C = 64 (phases switched off one at a time): loads + elementwise 23 us, MFMA +22, the
-// [N,2C] operand stores +20, the [N,C] accumulator-layout stores +21, staging +4 = 86 us against ~135 us for the six
-// launches it replaces; 180 MB of traffic, most of it the saved operands -- the next step is to stop saving the
-// concatenations.
+//   * Z, R, Ht come out of v_mfma_f32_32x32x2_f32 in accumulator layout and go through a per-wave LDS tile
+//     (one 32x32 block at a time) to the A layout, where a lane holds pieces of its own row: H*R and the GRU
+//     blend happen there against the H registers, and every [N,C] output leaves as 16-byte row pieces.
+// Measured at |V| = 50K, C = 64.  With one wave per SIMD (4-wave workgroups, the 100 KB of weights allow one per CU)
+// the phases simply add up (switched off one at a time: loads + elementwise 23 us, MFMA +22, operand stores +20,
+// [N,C] stores +21, staging +4 = 86-100 us); with 8-wave workgroups -- two waves per SIMD, 256 registers each --
+// one wave's memory phases overlap the other's MFMAs: 75-79 us, against ~135 us for the six launches it replaces.
+// 180 MB of traffic, most of it the saved operands: the next step is to stop saving the concatenations
+// (DESIGN.md section 8).
 // fp32 in / fp32 accumulate.  Against the unfused stages of tgcn_cell.hip: the GEMM k-order differs from rocBLAS'
 // and sigmoid / tanh use the hardware exp2 / rcp forms, so outputs agree to ~1e-6 (tested at 1e-5).
 #include <algorithm>
@@ -40,20 +43,23 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int C>
+template <int C, int WAVES>
 struct CellShape {
-    static constexpr int K = 2 * C, KB = K / 8, KH = C / 8, MT = C / 32, LDW = C + 1;
+    static constexpr int K = 2 * C, KB = K / 8, KH = C / 8, MT = C / 32, LDW = C + 1, TLD = 33;
+    static constexpr int kThreads = WAVES * kWave;
     static constexpr int kWeights = 3 * K * LDW;              // floats
     static constexpr int kBias = 6 * C;                       // b3 [3C], bz, br, bh
-    static constexpr int kTile = 32 * LDW;                    // per wave
-    static constexpr size_t kLds = sizeof(float) * (size_t)(kWeights + kBias + kWavesPerBlock * kTile);
+    static constexpr int kTile = 32 * TLD;                    // per wave: one 32x32 block of R at a time
+    static constexpr size_t kLds = sizeof(float) * (size_t)(kWeights + kBias + WAVES * kTile);
 };
 
 // row of accumulator element i for lane half kh (v_mfma_f32_32x32x2_f32 C/D layout)
 __device__ __forceinline__ int acc_row(int i, int kh) { return (i & 3) + 8 * (i >> 2) + 4 * kh; }
 
-template <int C>
-__global__ __launch_bounds__(kBlock) void cell_fused_fwd_kernel(
+// WAVES = 8 (C = 64: the 100 KB of weights allow one workgroup per CU, so the workgroup itself brings two waves per
+// SIMD -- one wave's loads and stores overlap the other's MFMAs) or 4 (C = 32: three workgroups per CU).
+template <int C, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void cell_fused_fwd_kernel(
     const float *__restrict__ a3, const float *__restrict__ b3, const float *__restrict__ H,
     const float *__restrict__ Wz, const float *__restrict__ bz, const float *__restrict__ Wr,
     const float *__restrict__ br, const float *__restrict__ Wh, const float *__restrict__ bh,
@@ -61,14 +67,14 @@ __global__ __launch_bounds__(kBlock) void cell_fused_fwd_kernel(
     float *__restrict__ R, float *__restrict__ Ht, float *__restrict__ Hn, int64_t N, float lo, float hi,
     int num_tiles)
 {
-    using S = CellShape<C>;
-    constexpr int K = S::K, KH = S::KH, MT = S::MT, LDW = S::LDW;
+    using S = CellShape<C, WAVES>;
+    constexpr int K = S::K, KH = S::KH, MT = S::MT, LDW = S::LDW, TLD = S::TLD, NT = S::kThreads;
     extern __shared__ float lds[];
     float *Ws = lds;                                   // 3 x [K][LDW]
     float *bs = lds + S::kWeights;                     // b3 | bz | br | bh
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    float *T = bs + S::kBias + wave * S::kTile;        // [32][LDW] transpose tile of this wave
+    float *T = bs + S::kBias + wave * S::kTile;        // [32][TLD] transpose tile of this wave
 
     {   // stage the weights (W is [C][K]: element i = (m, k), 4 consecutive k) and the biases
         const float *src[3] = {Wz, Wr, Wh};
@@ -76,17 +82,17 @@ __global__ __launch_bounds__(kBlock) void cell_fused_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             float *dst = Ws + g * K * LDW;
-            for (int base = 0; base < total4; base += 8 * kBlock) {
+            for (int base = 0; base < total4; base += 8 * NT) {
                 float4 w4[8];
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const int i4 = base + s * kBlock + threadIdx.x;
+                    const int i4 = base + s * NT + threadIdx.x;
                     w4[s] = i4 < total4 ? *reinterpret_cast<const float4 *>(src[g] + (int64_t)i4 * 4)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const int i = (base + s * kBlock + threadIdx.x) * 4;
+                    const int i = (base + s * NT + threadIdx.x) * 4;
                     if (i < C * K) {
                         const int m = i / K, k = i - m * K;
                         dst[(k + 0) * LDW + m] = w4[s].x;
@@ -97,8 +103,8 @@ __global__ __launch_bounds__(kBlock) void cell_fused_fwd_kernel(
                 }
             }
         }
-        for (int i = threadIdx.x; i < 3 * C; i += kBlock) bs[i] = b3[i];
-        for (int i = threadIdx.x; i < C; i += kBlock) {
+        for (int i = threadIdx.x; i < 3 * C; i += NT) bs[i] = b3[i];
+        for (int i = threadIdx.x; i < C; i += NT) {
             bs[3 * C + i] = bz[i];
             bs[4 * C + i] = br[i];
             bs[5 * C + i] = bh[i];
@@ -106,38 +112,40 @@ __global__ __launch_bounds__(kBlock) void cell_fused_fwd_kernel(
     }
     __syncthreads();
 
-    const int total = gridDim.x * kWavesPerBlock;
-    for (int tile = blockIdx.x * kWavesPerBlock + wave; tile < num_tiles; tile += total) {
+    const int total = gridDim.x * WAVES;
+    for (int tile = blockIdx.x * WAVES + wave; tile < num_tiles; tile += total) {
         const int64_t row_base = (int64_t)tile * 32;
         const int64_t row = row_base + l31;
         const bool rok = row < N;
 
         // ---- A operands: h_g = clamp(a3[:, g] + b3[g]) and H, in MFMA layout; written out as [h_g | H] ------
+        // (the candidate's block g = 2 is fetched after the z / r GEMMs: 32 registers less while they run)
         float4 ag[3][KH], hh[KH];
+        auto load_gate = [&](int g, int j) {
+            const int c = 8 * j + 4 * kh;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rok) a = *reinterpret_cast<const float4 *>(a3 + row * 3 * C + g * C + c);
+            const float4 b = *reinterpret_cast<const float4 *>(bs + g * C + c);
+            a.x = fminf(fmaxf(a.x + b.x, lo), hi);
+            a.y = fminf(fmaxf(a.y + b.y, lo), hi);
+            a.z = fminf(fmaxf(a.z + b.z, lo), hi);
+            a.w = fminf(fmaxf(a.w + b.w, lo), hi);
+            return a;
+        };
 #pragma unroll
         for (int j = 0; j < KH; ++j) {
             const int c = 8 * j + 4 * kh;
             hh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rok) hh[j] = *reinterpret_cast<const float4 *>(H + row * C + c);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rok) a = *reinterpret_cast<const float4 *>(a3 + row * 3 * C + g * C + c);
-                const float4 b = *reinterpret_cast<const float4 *>(bs + g * C + c);
-                a.x = fminf(fmaxf(a.x + b.x, lo), hi);
-                a.y = fminf(fmaxf(a.y + b.y, lo), hi);
-                a.z = fminf(fmaxf(a.z + b.z, lo), hi);
-                a.w = fminf(fmaxf(a.w + b.w, lo), hi);
-                ag[g][j] = a;
-            }
+            ag[0][j] = load_gate(0, j);
+            ag[1][j] = load_gate(1, j);
         }
         if (rok) {
-            float *dst[3] = {CZ, CR, CH};
 #pragma unroll
             for (int j = 0; j < KH; ++j) {
                 const int c = 8 * j + 4 * kh;
-#pragma unroll
-                for (int g = 0; g < 3; ++g) *reinterpret_cast<float4 *>(dst[g] + row * K + c) = ag[g][j];
+                *reinterpret_cast<float4 *>(CZ + row * K + c) = ag[0][j];
+                *reinterpret_cast<float4 *>(CR + row * K + c) = ag[1][j];
                 *reinterpret_cast<float4 *>(CZ + row * K + C + c) = hh[j];
                 *reinterpret_cast<float4 *>(CR + row * K + C + c) = hh[j];
             }
@@ -167,30 +175,44 @@ __global__ __launch_bounds__(kBlock) void cell_fused_fwd_kernel(
             }
         }
 
-        // ---- Z, R (accumulator layout) -> global; R -> LDS tile -> A layout; H*R ----------------------------
+        // ---- Z, R: accumulator layout -> LDS tile (one 32x32 block at a time) -> A layout (a lane's own row), where
+        //      H lives: H*R, and later the GRU blend; all [N,C] outputs leave as 16-byte row pieces -----------------
+        float4 hr[KH], za[KH];
+        auto to_rows = [&](const f32x16 &acc, int ct, float4 (&dst)[KH]) {      // 32x32 block ct of acc -> dst[4 ct ..]
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T[acc_row(i, kh) * TLD + l31] = acc[i];
+            wave_lds_sync();
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {                         // columns 32 ct .. 32 ct + 31 = j in [4 ct, 4 ct + 4)
+                const float *t = T + l31 * TLD + 8 * jj + 4 * kh;
+                dst[4 * ct + jj] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            wave_lds_sync();                                         // T is rewritten by the next block / tile
+        };
 #pragma unroll
         for (int ct = 0; ct < MT; ++ct) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float z = sigmoid_(accz[ct][i]), r = sigmoid_(accr[ct][i]);
-                accz[ct][i] = z;
-                const int rr = acc_row(i, kh);
-                T[rr * LDW + ct * 32 + l31] = r;
-                if (row_base + rr < N) {
-                    Z[(row_base + rr) * C + ct * 32 + l31] = z;
-                    R[(row_base + rr) * C + ct * 32 + l31] = r;
-                }
-            }
+            for (int i = 0; i < 16; ++i) accz[ct][i] = sigmoid_(accz[ct][i]), accr[ct][i] = sigmoid_(accr[ct][i]);
+            to_rows(accz[ct], ct, za);
+            to_rows(accr[ct], ct, hr);                               // hr holds R until multiplied below
         }
-        wave_lds_sync();
-        float4 hr[KH];
 #pragma unroll
         for (int j = 0; j < KH; ++j) {
-            const float *t = T + l31 * LDW + 8 * j + 4 * kh;
-            hr[j] = make_float4(hh[j].x * t[0], hh[j].y * t[1], hh[j].z * t[2], hh[j].w * t[3]);
-            if (rok) *reinterpret_cast<float4 *>(CH + row * K + C + 8 * j + 4 * kh) = hr[j];
+            const int c = 8 * j + 4 * kh;
+            if (rok) {
+                *reinterpret_cast<float4 *>(Z + row * C + c) = za[j];
+                *reinterpret_cast<float4 *>(R + row * C + c) = hr[j];
+            }
+            hr[j] = make_float4(hh[j].x * hr[j].x, hh[j].y * hr[j].y, hh[j].z * hr[j].z, hh[j].w * hr[j].w);
         }
-        wave_lds_sync();                               // T is rewritten by the next tile
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            ag[2][j] = load_gate(2, j);
+            if (rok) {
+                *reinterpret_cast<float4 *>(CH + row * K + 8 * j + 4 * kh) = ag[2][j];
+                *reinterpret_cast<float4 *>(CH + row * K + C + 8 * j + 4 * kh) = hr[j];
+            }
+        }
 
         // ---- hl = [hh | H*R] Wh^T + bh;  Ht = tanh(hl);  Hn = Z*H + (1 - Z)*Ht --------------------------------
 #pragma unroll
@@ -210,41 +232,46 @@ __global__ __launch_bounds__(kBlock) void cell_fused_fwd_kernel(
                     accr[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], ph[(8 * j + i) * LDW + ct * 32], accr[ct], 0, 0, 0);
             }
         }
+        float4 ht[KH];
 #pragma unroll
         for (int ct = 0; ct < MT; ++ct) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t r = row_base + acc_row(i, kh);
-                if (r < N) {
-                    const int64_t o = r * C + ct * 32 + l31;
-                    const float t = tanh_(accr[ct][i]), z = accz[ct][i], h = H[o];
-                    Ht[o] = t;
-                    Hn[o] = z * h + (1.0f - z) * t;
-                }
+            for (int i = 0; i < 16; ++i) accr[ct][i] = tanh_(accr[ct][i]);
+            to_rows(accr[ct], ct, ht);
+        }
+        if (rok) {
+#pragma unroll
+            for (int j = 0; j < KH; ++j) {
+                const int c = 8 * j + 4 * kh;
+                const float4 z = za[j], h = hh[j], t = ht[j];
+                *reinterpret_cast<float4 *>(Ht + row * C + c) = t;
+                *reinterpret_cast<float4 *>(Hn + row * C + c) =
+                    make_float4(z.x * h.x + (1.0f - z.x) * t.x, z.y * h.y + (1.0f - z.y) * t.y,
+                                z.z * h.z + (1.0f - z.z) * t.z, z.w * h.w + (1.0f - z.w) * t.w);
             }
         }
     }
 }
 
-template <int C>
+template <int C, int WAVES>
 int launch_fwd(const float *a3, const float *b3, const float *H, const float *Wz, const float *bz, const float *Wr,
                const float *br, const float *Wh, const float *bh, float *CZ, float *CR, float *CH, float *Z, float *R,
                float *Ht, float *Hn, int64_t N, float lo, float hi, hipStream_t stream)
 {
-    using S = CellShape<C>;
+    using S = CellShape<C, WAVES>;
     static bool raised = false;
     if (S::kLds > 64 * 1024 && !raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_fwd_kernel<C>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_fwd_kernel<C, WAVES>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
         if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_fwd: %s", hipGetErrorString(e));
         raised = true;
     }
     const int64_t tiles = (N + 31) / 32;
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_fwd: too many rows");
-    const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / (S::kLds + 512));
-    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, 256 * per_cu);
-    hipLaunchKernelGGL((cell_fused_fwd_kernel<C>), dim3(blocks), dim3(kBlock), S::kLds, stream, a3, b3, H, Wz, bz, Wr, br,
-                       Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, (int)tiles);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + WAVES - 1) / WAVES, 256 * per_cu);
+    hipLaunchKernelGGL((cell_fused_fwd_kernel<C, WAVES>), dim3(blocks), dim3(S::kThreads), S::kLds, stream, a3, b3, H, Wz, bz,
+                       Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, (int)tiles);
     return check_launch("stg_tgcn_cell_fused_fwd");
 }
 
@@ -265,6 +292,6 @@ extern "C" int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const f
     if (!a3 || !b3 || !H || !Wz || !bz || !Wr || !br || !Wh || !bh || !CZ || !CR || !CH || !Z || !R || !Ht || !Hn)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_fwd: NULL pointer argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (C == 64) return launch_fwd<64>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
-    return launch_fwd<32>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
+    if (C == 64) return launch_fwd<64, 8>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
+    return launch_fwd<32, 4>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
 }
