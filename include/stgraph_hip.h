@@ -366,6 +366,14 @@ int stg_gemm_tn_multi_f32(const float *const *A, const float *const *B, int32_t 
  * CH = [hh|H*R] ([N,2C] each, read again by the weight gradients), Z, R, Ht, Hn ([N,C]).  Elementwise formulas
  * are identical; the GEMM k-order differs from rocBLAS', so results agree to fp32 rounding (tested at 1e-5). */
 int stg_tgcn_cell_fused_supported(int32_t C);
+/* ... and the backward chain likewise (update_bwd + gates_bwd + prep_bwd and the three input-gradient GEMMs
+ * dhl Wh, dzl Wz, drl Wr, whose [N,2C] results never leave the chip): outputs dhl, dzl, drl [N,C] (the
+ * pre-activation gradients the weight gradients contract with CH, CZ, CR), da3 [N,3C] (clamp mask applied) and
+ * dH [N,C]. */
+int stg_tgcn_cell_fused_bwd(const float *dHn, const float *Z, const float *H, const float *Ht, const float *R,
+                            const float *a3, const float *b3, const float *Wz, const float *Wr, const float *Wh,
+                            float *dhl, float *dzl, float *drl, float *da3, float *dH, int64_t N, int32_t C,
+                            float lo, float hi, void *stream);
 int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const float *H, const float *Wz, const float *bz,
                             const float *Wr, const float *br, const float *Wh, const float *bh, float *CZ,
                             float *CR, float *CH, float *Z, float *R, float *Ht, float *Hn, int64_t N, int32_t C,

@@ -275,6 +275,256 @@ int launch_fwd(const float *a3, const float *b3, const float *H, const float *Wz
     return check_launch("stg_tgcn_cell_fused_fwd");
 }
 
+
+// ---------------------------------------------------------------------------------------------- backward
+// The backward row-local chain of one TGCN step in one launch (unfused: cell_update_bwd, cell_gates_bwd,
+// cell_prep_bwd of tgcn_cell.hip around three rocBLAS input-gradient GEMMs, whose [N,2C] results dCH, dCZ, dCR
+// make a 154 MB round trip through HBM per step):
+//   dhl = (dHn (1-Z)) (1-Ht^2)     dzl = (dHn (H-Ht)) (Z (1-Z))     dH = dHn Z
+//   dCH = dhl Wh  -> d(hh) = dCH[:, :C],  dHR = dCH[:, C:]
+//   drl = (dHR H) (R (1-R))        dH += dHR R
+//   dCZ = dzl Wz,  dCR = drl Wr    -> d(hz), d(hr) = [:, :C];   dH += dCZ[:, C:] + dCR[:, C:]
+//   da3[:, g] = lo <= a3[:, g] + b3[g] <= hi ? d(h_g) : 0                              (clamp backward)
+// Same machinery as the forward kernel: torch Linear weights [C][2C] are already [k][n] for these products and
+// sit in LDS as [k][2C + 1]; dhl / dzl / drl are formed in MFMA A layout from row pieces loaded straight from HBM
+// (and stored from there: the weight gradients read them later); each 32x32 block of a product goes through
+// the per-wave LDS tile back to row pieces, where the mask, the dH sums and all stores happen.
+template <int C, int WAVES>
+struct CellBwdShape {
+    static constexpr int K2 = 2 * C, KH = C / 8, NT = K2 / 32, LDB = K2 + 1, TLD = 33;
+    static constexpr int kThreads = WAVES * kWave;
+    static constexpr int kWeights = 3 * C * LDB;              // floats
+    static constexpr int kBias = 3 * C;                       // b3
+    static constexpr int kTile = 32 * TLD;
+    static constexpr size_t kLds = sizeof(float) * (size_t)(kWeights + kBias + WAVES * kTile);
+};
+
+template <int C, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd_kernel(
+    const float *__restrict__ dHn, const float *__restrict__ Z, const float *__restrict__ H,
+    const float *__restrict__ Ht, const float *__restrict__ R, const float *__restrict__ a3,
+    const float *__restrict__ b3, const float *__restrict__ Wz, const float *__restrict__ Wr,
+    const float *__restrict__ Wh, float *__restrict__ dhl_o, float *__restrict__ dzl_o, float *__restrict__ drl_o,
+    float *__restrict__ da3, float *__restrict__ dH_o, int64_t N, float lo, float hi, int num_tiles)
+{
+    using S = CellBwdShape<C, WAVES>;
+    constexpr int KH = S::KH, LDB = S::LDB, TLD = S::TLD, NTHR = S::kThreads, HB = C / 32;
+    extern __shared__ float lds[];
+    float *Ws = lds;                                   // Wz | Wr | Wh, each [C][LDB]
+    float *bs = lds + S::kWeights;                     // b3
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    float *T = bs + S::kBias + wave * S::kTile;
+
+    {
+        const float *src[3] = {Wz, Wr, Wh};
+        constexpr int total4 = C * 2 * C / 4;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            float *dst = Ws + g * C * LDB;
+            for (int base = 0; base < total4; base += 8 * NTHR) {
+                float4 w4[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int i4 = base + s * NTHR + threadIdx.x;
+                    w4[s] = i4 < total4 ? *reinterpret_cast<const float4 *>(src[g] + (int64_t)i4 * 4)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int i = (base + s * NTHR + threadIdx.x) * 4;
+                    if (i < C * 2 * C) {
+                        const int k = i / (2 * C), n = i - k * 2 * C;       // W[k][n .. n+3]
+                        dst[k * LDB + n + 0] = w4[s].x;
+                        dst[k * LDB + n + 1] = w4[s].y;
+                        dst[k * LDB + n + 2] = w4[s].z;
+                        dst[k * LDB + n + 3] = w4[s].w;
+                    }
+                }
+            }
+        }
+        for (int i = threadIdx.x; i < 3 * C; i += NTHR) bs[i] = b3[i];
+    }
+    __syncthreads();
+
+    const int total = gridDim.x * WAVES;
+    for (int tile = blockIdx.x * WAVES + wave; tile < num_tiles; tile += total) {
+        const int64_t row = (int64_t)tile * 32 + l31;
+        const bool rok = row < N;
+        auto ldrow = [&](const float *p, int j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rok) v = *reinterpret_cast<const float4 *>(p + row * C + 8 * j + 4 * kh);
+            return v;
+        };
+        // 32x32 block of an accumulator -> 4 row pieces (columns 32 blk + 8 jj + 4 kh .. + 3) of this lane's row
+        auto to_rows = [&](const f32x16 &acc, float4 (&dst)[4]) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T[acc_row(i, kh) * TLD + l31] = acc[i];
+            wave_lds_sync();
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float *t = T + l31 * TLD + 8 * jj + 4 * kh;
+                dst[jj] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            wave_lds_sync();
+        };
+        // da3[:, g*C + cols of block blk] = clamp mask * piece
+        auto store_da3 = [&](int g, int blk, const float4 (&piece)[4]) {
+            if (!rok) return;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int c = g * C + 32 * blk + 8 * jj + 4 * kh;
+                const float4 a = *reinterpret_cast<const float4 *>(a3 + row * 3 * C + c);
+                const float4 b = *reinterpret_cast<const float4 *>(bs + c);
+                const float v0 = a.x + b.x, v1 = a.y + b.y, v2 = a.z + b.z, v3 = a.w + b.w;
+                float4 o;
+                o.x = (v0 >= lo && v0 <= hi) ? piece[jj].x : 0.f;
+                o.y = (v1 >= lo && v1 <= hi) ? piece[jj].y : 0.f;
+                o.z = (v2 >= lo && v2 <= hi) ? piece[jj].z : 0.f;
+                o.w = (v3 >= lo && v3 <= hi) ? piece[jj].w : 0.f;
+                *reinterpret_cast<float4 *>(da3 + row * 3 * C + c) = o;
+            }
+        };
+        // acc[b] = A (row pieces, K = C) x W_g[:, half * C + 32 b ..]  (W_g is [C][2C] in LDS; one half of the 2C
+        // output columns at a time: C / 32 accumulators live instead of 2C / 32)
+        auto gemm = [&](const float4 (&A)[KH], int g, int half, f32x16 (&acc)[HB]) {
+            const float *pw = Ws + g * C * LDB + (4 * kh) * LDB + half * C + l31;
+#pragma unroll
+            for (int b = 0; b < HB; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < KH; ++j) {
+                const float av[4] = {A[j].x, A[j].y, A[j].z, A[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int b = 0; b < HB; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], pw[(8 * j + i) * LDB + b * 32], acc[b], 0, 0, 0);
+                }
+            }
+        };
+
+        // ---- update backward (row pieces) --------------------------------------------------------------------
+        // (register budget: 256 per wave at two waves per SIMD.  dzl is stored here and re-read by the same lane before
+        // its GEMM, H is re-read where dHR needs it -- both hit in L2 -- instead of living through the first GEMM)
+        float4 dhl[KH], dHa[KH];
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            const float4 g = ldrow(dHn, j), z = ldrow(Z, j), t = ldrow(Ht, j);
+            const float4 h = ldrow(H, j);
+            float4 dzl[1];
+            dhl[j] = make_float4((g.x * (1.0f - z.x)) * (1.0f - t.x * t.x), (g.y * (1.0f - z.y)) * (1.0f - t.y * t.y),
+                                 (g.z * (1.0f - z.z)) * (1.0f - t.z * t.z), (g.w * (1.0f - z.w)) * (1.0f - t.w * t.w));
+            dzl[0] = make_float4((g.x * (h.x - t.x)) * (z.x * (1.0f - z.x)), (g.y * (h.y - t.y)) * (z.y * (1.0f - z.y)),
+                                 (g.z * (h.z - t.z)) * (z.z * (1.0f - z.z)), (g.w * (h.w - t.w)) * (z.w * (1.0f - z.w)));
+            dHa[j] = make_float4(g.x * z.x, g.y * z.y, g.z * z.z, g.w * z.w);
+            if (rok) {
+                *reinterpret_cast<float4 *>(dhl_o + row * C + 8 * j + 4 * kh) = dhl[j];
+                *reinterpret_cast<float4 *>(dzl_o + row * C + 8 * j + 4 * kh) = dzl[0];
+            }
+            if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // at most 16 row pieces in flight at a time
+        }
+
+        // (phase fences: without them the scheduler hoists the mask / R / H loads of every later phase to the top of the
+        // tile and spills 40+ registers)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[HB];
+        float4 piece[4];
+        // ---- dCH = dhl Wh: d(hh) -> da3[:, 2C..];  dHR -> drl, dH -------------------------------------------------
+        gemm(dhl, 2, 0, acc);
+#pragma unroll
+        for (int blk = 0; blk < HB; ++blk) {
+            to_rows(acc[blk], piece);
+            store_da3(2, blk, piece);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gemm(dhl, 2, 1, acc);
+        float4 drl[KH];
+#pragma unroll
+        for (int blk = 0; blk < HB; ++blk) {
+            to_rows(acc[blk], piece);                                            // dHR, columns 32 blk ..
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * blk + jj;
+                const float4 r = ldrow(R, j), h = ldrow(H, j), d = piece[jj];
+                drl[j] = make_float4((d.x * h.x) * (r.x * (1.0f - r.x)), (d.y * h.y) * (r.y * (1.0f - r.y)),
+                                     (d.z * h.z) * (r.z * (1.0f - r.z)), (d.w * h.w) * (r.w * (1.0f - r.w)));
+                dHa[j] = make_float4(dHa[j].x + d.x * r.x, dHa[j].y + d.y * r.y, dHa[j].z + d.z * r.z, dHa[j].w + d.w * r.w);
+                if (rok) *reinterpret_cast<float4 *>(drl_o + row * C + 8 * j + 4 * kh) = drl[j];
+            }
+        }
+        // ---- dCZ = dzl Wz,  dCR = drl Wr: d(hz), d(hr) -> da3;  second halves -> dH, dCZ's first, then dCR's --------
+        // (the order cell_prep_bwd_kernel adds them in: (dH + x) + y)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            float4 dzl[KH];
+#pragma unroll
+            for (int j = 0; j < KH; ++j) dzl[j] = ldrow(dzl_o, j);              // this lane's own stores, above
+            gemm(dzl, 0, 0, acc);
+#pragma unroll
+            for (int blk = 0; blk < HB; ++blk) {
+                to_rows(acc[blk], piece);
+                store_da3(0, blk, piece);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            gemm(dzl, 0, 1, acc);
+#pragma unroll
+            for (int blk = 0; blk < HB; ++blk) {
+                to_rows(acc[blk], piece);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float4 &d = dHa[4 * blk + jj];
+                    d = make_float4(d.x + piece[jj].x, d.y + piece[jj].y, d.z + piece[jj].z, d.w + piece[jj].w);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gemm(drl, 1, 0, acc);
+#pragma unroll
+        for (int blk = 0; blk < HB; ++blk) {
+            to_rows(acc[blk], piece);
+            store_da3(1, blk, piece);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gemm(drl, 1, 1, acc);
+#pragma unroll
+        for (int blk = 0; blk < HB; ++blk) {
+            to_rows(acc[blk], piece);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * blk + jj;
+                const float4 y = piece[jj], d = dHa[j];
+                if (rok)
+                    *reinterpret_cast<float4 *>(dH_o + row * C + 8 * j + 4 * kh) =
+                        make_float4(d.x + y.x, d.y + y.y, d.z + y.z, d.w + y.w);
+            }
+        }
+    }
+}
+
+template <int C, int WAVES>
+int launch_bwd(const float *dHn, const float *Z, const float *H, const float *Ht, const float *R, const float *a3,
+               const float *b3, const float *Wz, const float *Wr, const float *Wh, float *dhl, float *dzl, float *drl,
+               float *da3, float *dH, int64_t N, float lo, float hi, hipStream_t stream)
+{
+    using S = CellBwdShape<C, WAVES>;
+    static bool raised = false;
+    if (S::kLds > 64 * 1024 && !raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_bwd_kernel<C, WAVES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
+        if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_bwd: %s", hipGetErrorString(e));
+        raised = true;
+    }
+    const int64_t tiles = (N + 31) / 32;
+    if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_bwd: too many rows");
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + WAVES - 1) / WAVES, 256 * per_cu);
+    hipLaunchKernelGGL((cell_fused_bwd_kernel<C, WAVES>), dim3(blocks), dim3(S::kThreads), S::kLds, stream, dHn, Z, H, Ht, R,
+                       a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, (int)tiles);
+    return check_launch("stg_tgcn_cell_fused_bwd");
+}
+
 }  // namespace
 }  // namespace stg
 
@@ -294,4 +544,20 @@ extern "C" int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (C == 64) return launch_fwd<64, 8>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
     return launch_fwd<32, 4>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
+}
+
+extern "C" int stg_tgcn_cell_fused_bwd(const float *dHn, const float *Z, const float *H, const float *Ht, const float *R,
+                                       const float *a3, const float *b3, const float *Wz, const float *Wr, const float *Wh,
+                                       float *dhl, float *dzl, float *drl, float *da3, float *dH, int64_t N, int32_t C,
+                                       float lo, float hi, void *stream)
+{
+    using namespace stg;
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_bwd: negative N");
+    if (!stg_tgcn_cell_fused_supported(C)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_bwd: C must be 32 or 64 (got %d)", C);
+    if (N == 0) return 0;
+    if (!dHn || !Z || !H || !Ht || !R || !a3 || !b3 || !Wz || !Wr || !Wh || !dhl || !dzl || !drl || !da3 || !dH)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_bwd: NULL pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (C == 64) return launch_bwd<64, 8>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
+    return launch_bwd<32, 4>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
 }

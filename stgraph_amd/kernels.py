@@ -859,6 +859,26 @@ def tgcn_cell_fused_fwd(a3, b3, H, Wz, bz, Wr, br, Wh, bh, lo: float, hi: float)
     return Hn, (CZ, CR, CH, Z, R, Ht)
 
 
+def tgcn_cell_fused_bwd(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, lo: float, hi: float):
+    """The backward row-local chain of one TGCN step in one launch (stg_tgcn_cell_fused_bwd).
+    Returns (da3, dH, dzl, drl, dhl)."""
+    N, C = H.shape
+    dev = H.device
+    ins = (dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh)
+    for t in ins:
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError("tgcn_cell_fused_bwd: operands must be contiguous fp32 tensors on one HIP device")
+    if a3.shape != (N, 3 * C) or b3.numel() != 3 * C or any(w.shape != (C, 2 * C) for w in (Wz, Wr, Wh)) or \
+            any(t.shape != (N, C) for t in (dHn, Z, Ht, R)):
+        raise ValueError("tgcn_cell_fused_bwd: operand shapes do not match hidden width C")
+    new = lambda w: torch.empty(N, w, dtype=torch.float32, device=dev)  # noqa: E731
+    dhl, dzl, drl, da3, dH = new(C), new(C), new(C), new(3 * C), new(C)
+    with torch.cuda.device(dev), _Timed("tgcn_cell_fused_bwd", 4 * N * C * 15, 12 * N * C * C):
+        _C.check(_C.lib.stg_tgcn_cell_fused_bwd(*[_ptr(t) for t in ins], _ptr(dhl), _ptr(dzl), _ptr(drl), _ptr(da3), _ptr(dH),
+                                                N, C, float(lo), float(hi), _stream_ptr(dev)))
+    return da3, dH, dzl, drl, dhl
+
+
 def tgcn_cell_call(name: str, tensors, N: int, C: int, *scalars) -> None:
     """Launch one fused TGCN row-local stage (stg_tgcn_cell_<name>); tensors are validated here."""
     dev = tensors[0].device

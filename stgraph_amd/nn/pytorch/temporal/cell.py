@@ -27,6 +27,14 @@ from ... import functional as SF
 
 CLAMP = 1e6      # tgcn.py:22,30,38
 _FUSED_FWD = True
+_FUSED_BWD = True
+
+
+def set_fused_backward(enabled: bool) -> None:
+    """True (default): the backward chain (GRU / gate / clamp backward and the three input-gradient GEMMs) is ONE
+    launch (kernels.tgcn_cell_fused_bwd) when the hidden width is 32 or 64."""
+    global _FUSED_BWD
+    _FUSED_BWD = bool(enabled)
 
 
 def set_fused_forward(enabled: bool) -> None:
@@ -60,6 +68,9 @@ def _cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht):
     """Returns da3, dH and the three (d_preactivation, operand) pairs of the gate Linears."""
     N, C = H.shape
     dev = H.device
+    if _FUSED_BWD and kernels.tgcn_cell_fused_supported(C) and all(t.is_contiguous() for t in (Wz, Wr, Wh)):
+        da3, dH, dzl, drl, dhl = kernels.tgcn_cell_fused_bwd(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, -CLAMP, CLAMP)
+        return da3, dH, ((dzl, CZ), (drl, CR), (dhl, CH))
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
     dhl, dzl, dH = new(N, C), new(N, C), new(N, C)
     kernels.tgcn_cell_call("update_bwd", (dHn, Z, H, Ht, dhl, dzl, dH), N, C)

@@ -50,6 +50,34 @@ def test_fused_forward_matches_unfused_and_fp64(cuda, N, C):
     torch.testing.assert_close(res[0][5].double(), R, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("N", [1, 33, 4097, 50_000])
+@pytest.mark.parametrize("C", [32, 64])
+def test_fused_backward_matches_unfused(cuda, N, C):
+    from stgraph_amd.nn.pytorch.temporal import cell
+    a3, b3, H, (Wz, Wr, Wh), (bz, br, bh) = _operands(cuda, N, C, 7 * N + C)
+    cell.set_fused_forward(False)
+    try:
+        Hn, (CZ, CR, CH, Z, R, Ht) = cell._cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh)
+    finally:
+        cell.set_fused_forward(True)
+    dHn = torch.randn(N, C, device=cuda)
+    res = []
+    for fused in (True, False):
+        cell.set_fused_backward(fused)
+        try:
+            da3, dH, pairs = cell._cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht)
+        finally:
+            cell.set_fused_backward(True)
+        res.append((da3, dH, pairs[0][0], pairs[1][0], pairs[2][0]))
+    for name, a, b in zip(("da3", "dH", "dzl", "drl", "dhl"), *res):
+        if name in ("dzl", "dhl"):
+            assert torch.equal(a, b), name                       # elementwise only
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m, n=name: f"{n}: {m}")
+    if N > 3:                                                    # the clamp mask bit: rows 0 and 2 were pushed outside
+        assert float(res[0][0][0, :5].abs().max()) == 0.0 and float(res[0][0][2, C + 1].abs()) == 0.0
+
+
 def test_tgcn_bptt_with_fused_forward_equals_unfused(cuda):
     """hidden = 64 TGCN, 4 steps of BPTT: loss and every gradient with the fused forward chain == without."""
     from stgraph_amd.graph import StaticGraph
@@ -69,6 +97,7 @@ def test_tgcn_bptt_with_fused_forward_equals_unfused(cuda):
         torch.manual_seed(5)
         m = TGCN(32, 64).to(cuda)
         cell.set_fused_forward(fused)
+        cell.set_fused_backward(fused)
         try:
             Hs, loss = None, 0
             for t in range(4):
@@ -77,6 +106,7 @@ def test_tgcn_bptt_with_fused_forward_equals_unfused(cuda):
             loss.backward()
         finally:
             cell.set_fused_forward(True)
+            cell.set_fused_backward(True)
         res.append([loss.detach()] + [p.grad.clone() for p in m.parameters()])
     for a, b in zip(*res):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5)
