@@ -138,9 +138,7 @@ __device__ __forceinline__ void gcn_agg_long_rows(
                 }
                 if (fok) vec_store<VEC>(tile + (u * S + sub) * W + foff, t);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_lds_fence();
             if (base + B < deg) {                                    // next batch's gathers fly during the sums
                 gather(v);
 #pragma unroll
@@ -165,9 +163,7 @@ __device__ __forceinline__ void gcn_agg_long_rows(
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_lds_fence();
         }
         const float nr = norm_row[r];
 #pragma unroll

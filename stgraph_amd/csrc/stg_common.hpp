@@ -61,6 +61,17 @@ __device__ __forceinline__ int wave_max(int v)
     return v;
 }
 
+// Order LDS traffic inside ONE wave (lanes exchange data through an LDS tile that no other wave touches): LDS
+// instructions of a wave execute in issue order, so all that is needed is (a) the compiler not moving memory
+// operations across this point and (b) outstanding LDS results having landed.  A wavefront-scope fence would do
+// (a) and (b) too but also drains vmcnt, i.e. stalls on every global load / store in flight -- measured: the fused
+// TGCN cell kernels call this 12-24 times per tile.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 inline int ilog2_ceil(int v)
 {
     int l = 0;

@@ -36,12 +36,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ float sigmoid_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+__device__ __forceinline__ void wave_lds_sync() { wave_lds_fence(); }
 
 template <int C, int WAVES>
 struct CellShape {
@@ -423,12 +418,8 @@ __global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd_kernel(
                 *reinterpret_cast<float4 *>(dhl_o + row * C + 8 * j + 4 * kh) = dhl[j];
                 *reinterpret_cast<float4 *>(dzl_o + row * C + 8 * j + 4 * kh) = dzl[0];
             }
-            if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // at most 16 row pieces in flight at a time
         }
 
-        // (phase fences: without them the scheduler hoists the mask / R / H loads of every later phase to the top of the
-        // tile and spills 40+ registers)
-        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[HB];
         float4 piece[4];
         // ---- dCH = dhl Wh: d(hh) -> da3[:, 2C..];  dHR -> drl, dH -------------------------------------------------
@@ -438,7 +429,6 @@ __global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd_kernel(
             to_rows(acc[blk], piece);
             store_da3(2, blk, piece);
         }
-        __builtin_amdgcn_sched_barrier(0);
         gemm(dhl, 2, 1, acc);
         float4 drl[KH];
 #pragma unroll
@@ -456,7 +446,6 @@ __global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd_kernel(
         }
         // ---- dCZ = dzl Wz,  dCR = drl Wr: d(hz), d(hr) -> da3;  second halves -> dH, dCZ's first, then dCR's --------
         // (the order cell_prep_bwd_kernel adds them in: (dH + x) + y)
-        __builtin_amdgcn_sched_barrier(0);
         {
             float4 dzl[KH];
 #pragma unroll
@@ -467,8 +456,7 @@ __global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd_kernel(
                 to_rows(acc[blk], piece);
                 store_da3(0, blk, piece);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            gemm(dzl, 0, 1, acc);
+                gemm(dzl, 0, 1, acc);
 #pragma unroll
             for (int blk = 0; blk < HB; ++blk) {
                 to_rows(acc[blk], piece);
@@ -479,14 +467,12 @@ __global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd_kernel(
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
         gemm(drl, 1, 0, acc);
 #pragma unroll
         for (int blk = 0; blk < HB; ++blk) {
             to_rows(acc[blk], piece);
             store_da3(1, blk, piece);
         }
-        __builtin_amdgcn_sched_barrier(0);
         gemm(drl, 1, 1, acc);
 #pragma unroll
         for (int blk = 0; blk < HB; ++blk) {
