@@ -68,13 +68,13 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
         nok[j] = n[j] < N;
         lb[j] = (unsigned)(kh * N + min(n[j], N - 1));
     }
-    f32x16 acc[NT], accs;
+    f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accs[i] = 0.f;
+    float cs_lane = 0.f;            // CS: this lane's share of sum_k A[k][m] (k of its parity); a VALU add per k-pair
+                                    // instead of a fifth MFMA on the pipe that bounds the kernel
     const bool do_cs = CS && nj == 0;                                           // block-uniform
 
     constexpr int STEP = 2 * KU;
@@ -108,9 +108,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][j], acc[j], 0, 0, 0);
-            if constexpr (CS) {
-                if (do_cs) accs = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], 1.0f, accs, 0, 0, 0);
-            }
+            if constexpr (CS) cs_lane += a[u];
         }
     };
 
@@ -136,10 +134,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) dst[(j * 16 + i) * kWave] = acc[j][i];
-        if constexpr (CS) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dst[(NT * 16 + i) * kWave] = accs[i];
-        }
+        if constexpr (CS) dst[(NT * 16) * kWave] = cs_lane;
     }
     __syncthreads();
     if (wave == 0) {
@@ -149,23 +144,14 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[j][i] += src[(j * 16 + i) * kWave];
-            if constexpr (CS) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) accs[i] += src[(NT * 16 + i) * kWave];
-            }
+            if constexpr (CS) cs_lane += src[(NT * 16) * kWave];
         }
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         const int row0 = mi * 32 + 4 * kh;
         const int64_t slab_stride = (int64_t)M * N + (CS ? M : 0);
         if constexpr (CS) {
-            if (do_cs && (lane & 31) == 0) {                    // every column of accs holds the same sums
-                float *cs = slab + (int64_t)s * slab_stride + (int64_t)M * N;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = row0 + (i & 3) + 8 * (i >> 2);
-                    if (row < M) cs[row] = accs[i];
-                }
-            }
+            const float both = cs_lane + __shfl_xor(cs_lane, 32, kWave);        // even + odd k of column m
+            if (do_cs && kh == 0 && m < M) slab[(int64_t)s * slab_stride + (int64_t)M * N + m] = both;
         }
         float *out = slab + (int64_t)s * slab_stride + (int64_t)row0 * N;
 #pragma unroll
@@ -226,8 +212,9 @@ GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1)
     p.m_tiles = (M + 31) / 32;
     p.n_groups = (N + 32 * p.nt - 1) / (32 * p.nt);
     const int64_t tiles = (int64_t)p.m_tiles * p.n_groups;
-    // ~512 blocks = 2 waves on every SIMD; never slice below 64 rows per wave
-    int64_t S = (512 + tiles * T - 1) / (tiles * T);            // slices PER SEGMENT
+    // at most 512 blocks = ONE resident round (2 per CU): a 550-block grid (T = 25, 2 tiles: S rounded up to 11)
+    // ran a second round for its last 38 blocks, i.e. at half speed; never slice below 64 rows per wave
+    int64_t S = std::max<int64_t>(1, 512 / (tiles * T));        // slices PER SEGMENT
     const int64_t max_S = std::max<int64_t>(1, K / (64 * kWavesPerBlock));
     S = std::max<int64_t>(1, std::min(S, max_S));
     int64_t per_wave = (K + S * kWavesPerBlock - 1) / (S * kWavesPerBlock);
