@@ -108,7 +108,9 @@ __global__ __launch_bounds__(WAVES * kWave) void cell_fused_fwd_kernel(
     __syncthreads();
 
     const int total = gridDim.x * WAVES;
-    for (int tile = blockIdx.x * WAVES + wave; tile < num_tiles; tile += total) {
+    // tiles are dealt wave-major (wave w of workgroup b: tile w * grid + b), so every CU gets its share of a grid
+    // smaller than WAVES * CUs (cfg4: 1563 tiles = 6.1 per CU on 256 CUs instead of 8 on 196)
+    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < num_tiles; tile += total) {
         const int64_t row_base = (int64_t)tile * 32;
         const int64_t row = row_base + l31;
         const bool rok = row < N;
@@ -264,7 +266,7 @@ int launch_fwd(const float *a3, const float *b3, const float *H, const float *Wz
     const int64_t tiles = (N + 31) / 32;
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_fwd: too many rows");
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
-    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + WAVES - 1) / WAVES, 256 * per_cu);
+    const unsigned blocks = (unsigned)std::min<int64_t>(tiles, 256 * per_cu);
     hipLaunchKernelGGL((cell_fused_fwd_kernel<C, WAVES>), dim3(blocks), dim3(S::kThreads), S::kLds, stream, a3, b3, H, Wz, bz,
                        Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, (int)tiles);
     return check_launch("stg_tgcn_cell_fused_fwd");
@@ -343,7 +345,9 @@ __global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd_kernel(
     __syncthreads();
 
     const int total = gridDim.x * WAVES;
-    for (int tile = blockIdx.x * WAVES + wave; tile < num_tiles; tile += total) {
+    // tiles are dealt wave-major (wave w of workgroup b: tile w * grid + b), so every CU gets its share of a grid
+    // smaller than WAVES * CUs (cfg4: 1563 tiles = 6.1 per CU on 256 CUs instead of 8 on 196)
+    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < num_tiles; tile += total) {
         const int64_t row = (int64_t)tile * 32 + l31;
         const bool rok = row < N;
         auto ldrow = [&](const float *p, int j) {
@@ -505,7 +509,7 @@ int launch_bwd(const float *dHn, const float *Z, const float *H, const float *Ht
     const int64_t tiles = (N + 31) / 32;
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_bwd: too many rows");
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
-    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + WAVES - 1) / WAVES, 256 * per_cu);
+    const unsigned blocks = (unsigned)std::min<int64_t>(tiles, 256 * per_cu);
     hipLaunchKernelGGL((cell_fused_bwd_kernel<C, WAVES>), dim3(blocks), dim3(S::kThreads), S::kLds, stream, dHn, Z, H, Ht, R,
                        a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, (int)tiles);
     return check_launch("stg_tgcn_cell_fused_bwd");
