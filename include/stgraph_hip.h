@@ -92,6 +92,31 @@ int stg_graph_build_device(const int32_t *src, const int32_t *dst, int64_t E, in
                            int32_t *status, void *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* The same build without a global sort, for graphs whose rows are short (the per-snapshot rebuild of dynamic graphs:
+ * BASELINE configs[4] runs it once per timestep): degrees by atomic histogram, row offsets by a one-workgroup scan,
+ * entries scattered into their rows and ranked inside the row by counting smaller keys (ties broken by the caller
+ * position, i.e. the stable (dst, src) order of static_graph.py:65-72) -- 6 launches instead of the 59 three rocPRIM
+ * sorts take at |E| = 250K.  Outputs are bit-identical to stg_graph_build_device.  If a row is longer than 2048
+ * entries nothing but the degrees and row offsets is produced and *status gets STG_BUILD_NEEDS_SORT: call
+ * stg_graph_build_device instead.  fwd_node_ids / bwd_node_ids may both be NULL (they only fix a processing
+ * order, and sorting |V| degrees costs more launches than everything else here). */
+/* node_ids of a CSR after the fact: rows by non-increasing degree, ties by ascending id (csr.cu:142-154 leaves
+ * tie order open) -- for builds that skipped them. */
+size_t stg_rows_by_degree_workspace_bytes(int32_t N);
+int stg_rows_by_degree_device(const int32_t *degrees, int32_t N, int32_t *node_ids, void *workspace,
+                              size_t workspace_bytes, void *stream);
+#define STG_BUILD_NEEDS_SORT 32
+size_t stg_graph_build_direct_workspace_bytes(int64_t E, int32_t N);
+int stg_graph_build_direct_device(const int32_t *src, const int32_t *dst, int64_t E, int32_t N,
+                                  int64_t *perm_fwd,
+                                  int32_t *fwd_row_offset, int32_t *fwd_column_indices,
+                                  int32_t *fwd_eids, int32_t *fwd_node_ids,
+                                  int32_t *bwd_row_offset, int32_t *bwd_column_indices,
+                                  int32_t *bwd_eids, int32_t *bwd_node_ids,
+                                  int32_t *in_degrees, int32_t *out_degrees,
+                                  int32_t *status, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+
 /* ------------------------------------------------------- dynamic edge store (PCSR, GPMA)
  * Replaces the reference's PCSR class: graph/dynamic/pcsr/pcsr.cu:273-939
  * (PCSR::edge_update_list :759-779, label_edges :745-757, build_csr :829-879,

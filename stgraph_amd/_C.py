@@ -26,6 +26,8 @@ EXPORTED_SYMBOLS = (
     "stg_abi_version", "stg_last_error_string", "stg_set_tuning",
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
+    "stg_graph_build_direct_workspace_bytes", "stg_graph_build_direct_device",
+    "stg_rows_by_degree_workspace_bytes", "stg_rows_by_degree_device",
     "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host", "stg_edgeset_merge_device",
     "stg_edgeset_emit_csr_workspace_bytes", "stg_edgeset_emit_csr_device", "stg_edgeset_emit_csr_host",
     "stg_jit_compile", "stg_jit_free", "stg_jit_load", "stg_jit_get_function", "stg_jit_unload", "stg_jit_launch",
@@ -69,6 +71,14 @@ def _load() -> ctypes.CDLL:
     lib.stg_graph_build_device_workspace_bytes.argtypes = [i64, i32]
     lib.stg_graph_build_device.restype = ctypes.c_int
     lib.stg_graph_build_device.argtypes = [vp, vp, i64, i32] + [vp] * 11 + [vp, vp, ctypes.c_size_t, vp]
+    lib.stg_graph_build_direct_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_graph_build_direct_workspace_bytes.argtypes = [i64, i32]
+    lib.stg_graph_build_direct_device.restype = ctypes.c_int
+    lib.stg_graph_build_direct_device.argtypes = [vp, vp, i64, i32] + [vp] * 11 + [vp, vp, ctypes.c_size_t, vp]
+    lib.stg_rows_by_degree_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_rows_by_degree_workspace_bytes.argtypes = [i32]
+    lib.stg_rows_by_degree_device.restype = ctypes.c_int
+    lib.stg_rows_by_degree_device.argtypes = [vp, i32, vp, vp, ctypes.c_size_t, vp]
     lib.stg_edgeset_update_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_edgeset_update_workspace_bytes.argtypes = [i64, i64]
     lib.stg_edgeset_update_device.restype = ctypes.c_int

@@ -655,7 +655,7 @@ class GenericPlan:
             ptrs.append(t.data_ptr())
         eids = csr.eids if spec.uses_eids else None
         ptrs += [csr.row_offset.data_ptr(), csr.column_indices.data_ptr(), eids.data_ptr() if eids is not None else 0,
-                 csr.node_ids.data_ptr() if use_nid else 0]
+                 (csr.node_ids_if_ready.data_ptr() if (use_nid and csr.node_ids_if_ready is not None) else 0)]
         G = spec.lanes_per_row
         rows_per_block = 256 // G
         grid = (N + rows_per_block - 1) // rows_per_block

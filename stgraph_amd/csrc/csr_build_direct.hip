@@ -1,0 +1,286 @@
+// Direct (counting) build of both CSRs of a graph -- same inputs, outputs and bits as stg_graph_build_device
+// (csr_build.hip; reference graph/static/csr.cu:68-157 + graph/static/static_graph.py:40-78), without a global sort.
+//
+// The sort-based builder runs three rocPRIM radix sorts.  Below ~1M items rocPRIM sorts by block sort + log2(n/1K)
+// merge passes, so the per-snapshot rebuild of a small dynamic graph (BASELINE configs[4]: |V| = 25K, |E| = 250K)
+// is 59 launches of 5-6 us: 0.35 ms of launch gaps, a third of a training step.  Rows of a graph are short, so here
+// the order inside a row is found by COUNTING instead:
+//   1. degrees by atomic histogram (+ id validation)                                             1 launch
+//   2. row offsets: one workgroup per direction scans its degree array, notes the longest row    1 launch
+//   3. forward scatter: edge i -> any free slot of row dst[i]  (key = src << 32 | i)             1 launch
+//   4. forward rank: the slot of an entry inside its row = number of smaller keys in the row
+//      (keys are unique: ties in src are broken by the caller position i, which is exactly the stable
+//      (dst, src) order static_graph.py:65-72 defines); writes column, eid, perm_fwd and scatters the entry
+//      into its backward row (key = eid << 32 | dst)                                             1 launch
+//   5. backward rank: by eid, which for a fixed src is the (dst, eid) order of static_graph.py:75-78   1 launch
+//   6. node_ids: rocPRIM sort of |V| degrees per direction (optional: NULL skips it)
+// Ranking costs (row length) reads per entry, so rows longer than kDirectMaxRow are left to the sort-based
+// builder: the scan raises status bit STG_BUILD_NEEDS_SORT and the caller falls back.
+#include "stg_common.hpp"
+#include "csr_kernels.hpp"
+
+#include <cstring>   // rocprim/iterator/texture_cache_iterator.hpp calls memset without including it
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+
+namespace stg {
+namespace {
+
+constexpr int kDirectMaxRow = 2048;
+constexpr int kScanThreads = 1024;
+
+__global__ void direct_init(int *__restrict__ status, int *__restrict__ cursors, int *__restrict__ in_deg,
+                            int *__restrict__ out_deg, int N)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v == 0) *status = 0;
+    if (v < N) {
+        cursors[v] = 0;
+        cursors[N + v] = 0;
+        in_deg[v] = 0;
+        out_deg[v] = 0;
+    }
+}
+
+__global__ void direct_histogram(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int N,
+                                 int *__restrict__ in_deg, int *__restrict__ out_deg, int *__restrict__ status)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+        const int s = src[i], d = dst[i];
+        if ((unsigned)s >= (unsigned)N || (unsigned)d >= (unsigned)N) {
+            atomicOr(status, 1);               // same code as make_fwd_keys: endpoint out of range
+            continue;
+        }
+        atomicAdd(in_deg + d, 1);
+        atomicAdd(out_deg + s, 1);
+    }
+}
+
+// blockIdx.x = 0: forward (rows = dst, lengths = in_deg); 1: backward.  Exclusive scan of N lengths by one workgroup.
+__global__ __launch_bounds__(kScanThreads) void direct_scan(const int *__restrict__ in_deg, const int *__restrict__ out_deg,
+                                                           int N, int *__restrict__ fwd_ro, int *__restrict__ bwd_ro,
+                                                           int *__restrict__ status)
+{
+    __shared__ int part[kScanThreads];
+    const int *deg = blockIdx.x == 0 ? in_deg : out_deg;
+    int *ro = blockIdx.x == 0 ? fwd_ro : bwd_ro;
+    const int chunk = (N + kScanThreads - 1) / kScanThreads;
+    const int beg = min(N, (int)threadIdx.x * chunk), end = min(N, beg + chunk);
+    int sum = 0, longest = 0;
+    for (int v = beg; v < end; ++v) {
+        sum += deg[v];
+        longest = max(longest, deg[v]);
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kScanThreads; off <<= 1) {              // inclusive Hillis-Steele over the 1024 partials
+        const int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;                               // exclusive prefix of this thread's chunk
+    for (int v = beg; v < end; ++v) {
+        ro[v] = run;
+        run += deg[v];
+    }
+    if (threadIdx.x == kScanThreads - 1) ro[N] = part[kScanThreads - 1];
+    if (longest > kDirectMaxRow) atomicOr(status, STG_BUILD_NEEDS_SORT);
+}
+
+__global__ void direct_scatter_fwd(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int N,
+                                   const int *__restrict__ fwd_ro, int *__restrict__ cursor,
+                                   uint64_t *__restrict__ key, int *__restrict__ row)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+        const int s = src[i], d = dst[i];
+        if ((unsigned)s >= (unsigned)N || (unsigned)d >= (unsigned)N) continue;
+        const int slot = fwd_ro[d] + atomicAdd(cursor + d, 1);
+        key[slot] = ((uint64_t)(unsigned)s << 32) | (uint64_t)(unsigned)i;
+        row[slot] = d;
+    }
+}
+
+// number of keys of [beg, end) smaller than `mine`
+__device__ __forceinline__ int rank_in_row(const uint64_t *__restrict__ key, int beg, int end, uint64_t mine)
+{
+    int r = 0;
+    for (int t = beg; t < end; ++t) r += key[t] < mine ? 1 : 0;
+    return r;
+}
+
+__global__ void direct_rank_fwd(const uint64_t *__restrict__ key, const int *__restrict__ row, int64_t E,
+                                const int *__restrict__ fwd_ro, const int *__restrict__ bwd_ro,
+                                int *__restrict__ cursor_b, int *__restrict__ fwd_col, int *__restrict__ fwd_eid,
+                                int64_t *__restrict__ perm_fwd, uint64_t *__restrict__ key_b, int *__restrict__ row_b,
+                                const int *__restrict__ status)
+{
+    if (*status) return;                        // a row too long to rank by counting, or an endpoint out of range
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < E; t += stride) {
+        const uint64_t mine = key[t];
+        const int d = row[t];
+        const int beg = fwd_ro[d];
+        const int e = beg + rank_in_row(key, beg, fwd_ro[d + 1], mine);   // = eid
+        const int s = (int)(mine >> 32);
+        fwd_col[e] = s;
+        fwd_eid[e] = e;
+        perm_fwd[e] = (int64_t)(unsigned)mine;
+        const int slot = bwd_ro[s] + atomicAdd(cursor_b + s, 1);
+        key_b[slot] = ((uint64_t)(unsigned)e << 32) | (uint64_t)(unsigned)d;
+        row_b[slot] = s;
+    }
+}
+
+__global__ void direct_rank_bwd(const uint64_t *__restrict__ key_b, const int *__restrict__ row_b, int64_t E,
+                                const int *__restrict__ bwd_ro, int *__restrict__ bwd_col, int *__restrict__ bwd_eid,
+                                const int *__restrict__ status)
+{
+    if (*status) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < E; t += stride) {
+        const uint64_t mine = key_b[t];
+        const int s = row_b[t];
+        const int beg = bwd_ro[s];
+        const int o = beg + rank_in_row(key_b, beg, bwd_ro[s + 1], mine);
+        bwd_eid[o] = (int)(mine >> 32);
+        bwd_col[o] = (int)(unsigned)mine;
+    }
+}
+
+__global__ void direct_sort_keys(const int *__restrict__ deg, int N, unsigned *__restrict__ sort_key, int *__restrict__ iota)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    sort_key[v] = (unsigned)deg[v];
+    iota[v] = v;
+}
+
+struct DirectLayout {
+    size_t key_f, row_f, key_b, row_b, cursors, deg_key_a, deg_key_b, iota, sort_tmp, total, sort_tmp_bytes;
+};
+
+DirectLayout direct_layout(int64_t E, int32_t N)
+{
+    DirectLayout L{};
+    const size_t e = (size_t)std::max<int64_t>(E, 1), n = (size_t)std::max<int32_t>(N, 1);
+    size_t t = 0;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, t, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
+                                         (int *)nullptr, n, 0, 32);
+    L.sort_tmp_bytes = t;
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { const size_t o = off; off += align_up(bytes); return o; };
+    L.key_f = take(e * 8);
+    L.row_f = take(e * 4);
+    L.key_b = take(e * 8);
+    L.row_b = take(e * 4);
+    L.cursors = take(2 * n * 4);
+    L.deg_key_a = take(n * 4);
+    L.deg_key_b = take(n * 4);
+    L.iota = take(n * 4);
+    L.sort_tmp = take(t);
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+}  // namespace stg
+
+extern "C" size_t stg_graph_build_direct_workspace_bytes(int64_t E, int32_t N)
+{
+    if (E < 0 || N < 0) return 0;
+    return stg::direct_layout(E, N).total;
+}
+
+extern "C" int stg_graph_build_direct_device(const int32_t *src, const int32_t *dst, int64_t E, int32_t N,
+                                             int64_t *perm_fwd, int32_t *fwd_row_offset, int32_t *fwd_column_indices,
+                                             int32_t *fwd_eids, int32_t *fwd_node_ids, int32_t *bwd_row_offset,
+                                             int32_t *bwd_column_indices, int32_t *bwd_eids, int32_t *bwd_node_ids,
+                                             int32_t *in_degrees, int32_t *out_degrees, int32_t *status, void *workspace,
+                                             size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (E < 0 || N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_graph_build_direct_device: negative size");
+    if (E >= (int64_t(1) << 31))
+        return fail(STG_ERR_UNSUPPORTED, "stg_graph_build_direct_device: E=%lld does not fit int32 edge ids", (long long)E);
+    if ((E > 0 && (!src || !dst || !perm_fwd || !fwd_column_indices || !fwd_eids || !bwd_column_indices || !bwd_eids)) ||
+        !fwd_row_offset || !bwd_row_offset || !status || !workspace || (N > 0 && (!in_degrees || !out_degrees)) ||
+        (!fwd_node_ids != !bwd_node_ids))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_graph_build_direct_device: NULL pointer argument");
+    const DirectLayout L = direct_layout(E, N);
+    if (workspace_bytes < L.total)
+        return fail(STG_ERR_WORKSPACE, "stg_graph_build_direct_device: workspace %zu < required %zu", workspace_bytes, L.total);
+    char *ws = static_cast<char *>(workspace);
+    auto *key_f = reinterpret_cast<uint64_t *>(ws + L.key_f);
+    auto *row_f = reinterpret_cast<int *>(ws + L.row_f);
+    auto *key_b = reinterpret_cast<uint64_t *>(ws + L.key_b);
+    auto *row_b = reinterpret_cast<int *>(ws + L.row_b);
+    auto *cursors = reinterpret_cast<int *>(ws + L.cursors);
+
+    hipError_t e = hipSuccess;
+    hipLaunchKernelGGL(direct_init, dim3((std::max(N, 1) + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, status, cursors,
+                       in_degrees, out_degrees, N);
+
+    const int eblocks = (int)std::max<int64_t>(1, std::min<int64_t>((E + kBlock - 1) / kBlock, 256 * 16));
+    if (E > 0)
+        hipLaunchKernelGGL(direct_histogram, dim3(eblocks), dim3(kBlock), 0, stream, src, dst, E, N, in_degrees, out_degrees, status);
+    hipLaunchKernelGGL(direct_scan, dim3(2), dim3(kScanThreads), 0, stream, in_degrees, out_degrees, N, fwd_row_offset,
+                       bwd_row_offset, status);
+    if (E > 0) {
+        hipLaunchKernelGGL(direct_scatter_fwd, dim3(eblocks), dim3(kBlock), 0, stream, src, dst, E, N, fwd_row_offset, cursors,
+                           key_f, row_f);
+        hipLaunchKernelGGL(direct_rank_fwd, dim3(eblocks), dim3(kBlock), 0, stream, key_f, row_f, E, fwd_row_offset,
+                           bwd_row_offset, cursors + N, fwd_column_indices, fwd_eids, perm_fwd, key_b, row_b, status);
+        hipLaunchKernelGGL(direct_rank_bwd, dim3(eblocks), dim3(kBlock), 0, stream, key_b, row_b, E, bwd_row_offset,
+                           bwd_column_indices, bwd_eids, status);
+    }
+    if (N > 0 && fwd_node_ids) {
+        auto *ka = reinterpret_cast<unsigned *>(ws + L.deg_key_a);
+        auto *kb = reinterpret_cast<unsigned *>(ws + L.deg_key_b);
+        auto *iota = reinterpret_cast<int *>(ws + L.iota);
+        const int vblocks = (N + kBlock - 1) / kBlock;
+        const int *degs[2] = {in_degrees, out_degrees};
+        int32_t *outs[2] = {fwd_node_ids, bwd_node_ids};
+        for (int side = 0; side < 2; ++side) {
+            hipLaunchKernelGGL(direct_sort_keys, dim3(vblocks), dim3(kBlock), 0, stream, degs[side], N, ka, iota);
+            size_t tmp = L.sort_tmp_bytes;
+            e = rocprim::radix_sort_pairs_desc(ws + L.sort_tmp, tmp, ka, kb, iota, outs[side], (size_t)N, 0, 32, stream);
+            if (e != hipSuccess) return fail((int)e, "stg_graph_build_direct_device: node_ids sort: %s", hipGetErrorString(e));
+        }
+    }
+    return check_launch("stg_graph_build_direct_device");
+}
+
+extern "C" size_t stg_rows_by_degree_workspace_bytes(int32_t N)
+{
+    if (N < 0) return 0;
+    const stg::DirectLayout L = stg::direct_layout(1, N);
+    return L.total;
+}
+
+extern "C" int stg_rows_by_degree_device(const int32_t *degrees, int32_t N, int32_t *node_ids, void *workspace,
+                                         size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rows_by_degree_device: negative N");
+    if (N == 0) return 0;
+    if (!degrees || !node_ids || !workspace) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rows_by_degree_device: NULL pointer argument");
+    const DirectLayout L = direct_layout(1, N);
+    if (workspace_bytes < L.total)
+        return fail(STG_ERR_WORKSPACE, "stg_rows_by_degree_device: workspace %zu < required %zu", workspace_bytes, L.total);
+    char *ws = static_cast<char *>(workspace);
+    auto *ka = reinterpret_cast<unsigned *>(ws + L.deg_key_a);
+    auto *kb = reinterpret_cast<unsigned *>(ws + L.deg_key_b);
+    auto *iota = reinterpret_cast<int *>(ws + L.iota);
+    hipLaunchKernelGGL(direct_sort_keys, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, degrees, N, ka, iota);
+    size_t tmp = L.sort_tmp_bytes;
+    const hipError_t e = rocprim::radix_sort_pairs_desc(ws + L.sort_tmp, tmp, ka, kb, iota, node_ids, (size_t)N, 0, 32, stream);
+    if (e != hipSuccess) return fail((int)e, "stg_rows_by_degree_device: %s", hipGetErrorString(e));
+    return check_launch("stg_rows_by_degree_device");
+}

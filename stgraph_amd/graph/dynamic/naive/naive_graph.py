@@ -3,8 +3,9 @@
 
 The reference builds T forward + T backward CSRs on the host up front and keeps
 all 2T resident on the GPU; moving between timestamps only swaps pointers.  Here a
-snapshot's CSR pair is built ON THE DEVICE (``stg_graph_build_device``: radix sort
-+ binary search) -- either all up front (``resident=True``, the reference's memory
+snapshot's CSR pair is built ON THE DEVICE (``stg_graph_build_direct_device``: histogram,
+scan, scatter and rank-by-counting in 6 launches; ``stg_graph_build_device`` -- radix sort
++ binary search -- above 2M edges or when a row is longer than 2048 entries) -- either all up front (``resident=True``, the reference's memory
 behaviour) or on first use (``resident=False``: "per-snapshot CSR rebuild", with
 ``max_cached`` most-recent snapshots kept so that a BPTT window can walk back
 through the snapshots its forward pass just used).  ``graph_type()`` is ``'csr'``:
@@ -30,6 +31,7 @@ from ..dynamic_graph import DynamicGraph
 class NaiveGraph(DynamicGraph):
     def __init__(self, edge_list, max_num_nodes: int, device=None, resident: bool = True,
                  max_cached: int | None = None, sort_inplace: bool = True):
+        self._ptr_src = {}
         super().__init__(edge_list, max_num_nodes)
         self._device = torch.device(device) if device is not None else default_device()
         self._sort_inplace = sort_inplace
@@ -61,7 +63,8 @@ class NaiveGraph(DynamicGraph):
         if g is None:
             t0 = time.time()
             s, d = self._edges[t]
-            g = kernels.build_graph_csr(s, d, self.max_num_nodes, self._device)
+            # snapshots built on demand live for one training step: their degree sorts (node_ids) wait for a reader
+            g = kernels.build_graph_csr(s, d, self.max_num_nodes, self._device, lazy_node_ids=not self._resident)
             self.build_count += 1
             if t not in self._distinct_edges:
                 self._distinct_edges[t] = count_distinct_edges(g)
@@ -111,19 +114,19 @@ class NaiveGraph(DynamicGraph):
         return self._snapshot(self.current_timestamp).in_degrees
 
     def _get_graph_csr_ptrs(self, timestamp: int) -> None:
+        """Remember which snapshot the ``fwd_*/bwd_*_ptr`` attributes refer to; the addresses (and with them a
+        lazily built snapshot's ``node_ids``) are produced when an attribute is read."""
         g = self._snapshot(timestamp)
-        if self._is_backprop_state:
-            b = g.bwd
-            self.bwd_row_offset_ptr, self.bwd_column_indices_ptr = b.row_offset_ptr, b.column_indices_ptr
-            self.bwd_eids_ptr, self.bwd_node_ids_ptr = b.eids_ptr, b.node_ids_ptr
-            c = b
-        else:
-            f = g.fwd
-            self.fwd_row_offset_ptr, self.fwd_column_indices_ptr = f.row_offset_ptr, f.column_indices_ptr
-            self.fwd_eids_ptr, self.fwd_node_ids_ptr = f.eids_ptr, f.node_ids_ptr
-            c = f
-        for t in (c.row_offset, c.column_indices, c.eids, c.node_ids):
+        self._ptr_src["bwd" if self._is_backprop_state else "fwd"] = g.bwd if self._is_backprop_state else g.fwd
+
+    def _ptrs(self, side: str):
+        c = self._ptr_src.get(side)
+        if c is None:
+            return (None, None, None, None)
+        arrays = (c.row_offset, c.column_indices, c.eids, c.node_ids)
+        for t in arrays:
             _LIVE[t.data_ptr()] = t
+        return tuple(int(t.data_ptr()) for t in arrays)
 
     # Moving between timestamps is a pointer swap here, so jump straight to the target instead of
     # stepping through (and, when not resident, building) every snapshot in between.
@@ -165,3 +168,18 @@ class NaiveGraph(DynamicGraph):
         if self.current_timestamp < 0:
             raise RuntimeError("⏰ Invalid timestamp during STGraphBase.update_graph_backward()")
         self._get_graph_csr_ptrs(self.current_timestamp - 1)
+
+
+def _ptr_property(side: str, index: int):
+    def get(self):
+        return self._ptrs(side)[index]
+
+    def set_(self, value):          # STGraphBase.__init__ assigns None to all eight
+        if value is not None:
+            raise AttributeError("NaiveGraph publishes its own CSR pointers")
+    return property(get, set_)
+
+
+for _side in ("fwd", "bwd"):
+    for _i, _name in enumerate(("row_offset", "column_indices", "eids", "node_ids")):
+        setattr(NaiveGraph, f"{_side}_{_name}_ptr", _ptr_property(_side, _i))

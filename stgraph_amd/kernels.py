@@ -121,18 +121,40 @@ def _ptr(t: torch.Tensor | None) -> ctypes.c_void_p:
 
 
 # ------------------------------------------------------------------------------- CSR
-@dataclass
 class DeviceCSR:
-    """One CSR (the four arrays of the reference's ``CSR`` object, csr.cu:35-59)."""
+    """One CSR (the four arrays of the reference's ``CSR`` object, csr.cu:35-59).
 
-    row_offset: torch.Tensor       # int32 [N+1]
-    column_indices: torch.Tensor   # int32 [E]
-    eids: torch.Tensor             # int32 [E]
-    node_ids: torch.Tensor         # int32 [N]  rows by non-increasing degree
-    # True when node_ids is KNOWN to be ordered by non-increasing degree (set by this package's builders).  Only
-    # then may the aggregation find its long rows through it (stg_gcn_agg_edge's rows_by_degree); a CSR assembled
-    # by hand keeps every row on the row-group path.
-    degree_sorted: bool = False
+    ``node_ids`` (rows by non-increasing degree) only fixes a processing ORDER -- results never depend on it --
+    and sorting |V| degrees costs more launches than the rest of a small graph's build, so a builder may leave it
+    to first use (``degrees`` given, ``node_ids=None``).  ``node_ids_if_ready`` is what the launch wrappers ask
+    for: a snapshot that is built, used for one training step and dropped never sorts its degrees."""
+
+    def __init__(self, row_offset, column_indices, eids, node_ids=None, degree_sorted: bool = False, degrees=None):
+        self.row_offset = row_offset           # int32 [N+1]
+        self.column_indices = column_indices   # int32 [E]
+        self.eids = eids                       # int32 [E]
+        self._node_ids = node_ids              # int32 [N] or None (lazy)
+        self._degrees = degrees                # int32 [N] row lengths, needed only for the lazy case
+        # True when node_ids is KNOWN to be ordered by non-increasing degree (set by this package's builders).  Only
+        # then may the aggregation find its long rows through it (stg_gcn_agg_edge's rows_by_degree); a CSR assembled
+        # by hand keeps every row on the row-group path.
+        self.degree_sorted = bool(degree_sorted)
+
+    @property
+    def node_ids(self) -> torch.Tensor:
+        if self._node_ids is None:
+            self._node_ids = rows_by_degree(self._degrees if self._degrees is not None
+                                            else (self.row_offset[1:] - self.row_offset[:-1]).contiguous())
+            self.degree_sorted = True
+        return self._node_ids
+
+    @node_ids.setter
+    def node_ids(self, value) -> None:
+        self._node_ids = value
+
+    @property
+    def node_ids_if_ready(self):
+        return self._node_ids
 
     @property
     def num_nodes(self) -> int:
@@ -184,7 +206,36 @@ def _as_i32(a, device: torch.device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.int32).contiguous()
 
 
-def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str) -> GraphCSR:
+def rows_by_degree(degrees: torch.Tensor) -> torch.Tensor:
+    """Rows by non-increasing degree, ties by ascending id (stg_rows_by_degree_device / a stable host sort)."""
+    N = int(degrees.shape[0])
+    out = torch.empty(N, dtype=torch.int32, device=degrees.device)
+    if N == 0:
+        return out
+    if degrees.device.type != "cuda":
+        return torch.sort(degrees.to(torch.int64), descending=True, stable=True).indices.to(torch.int32)
+    ws_bytes = int(_C.lib.stg_rows_by_degree_workspace_bytes(N))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=degrees.device)
+    with torch.cuda.device(degrees.device):
+        _C.check(_C.lib.stg_rows_by_degree_device(_ptr(degrees.contiguous()), N, _ptr(out), _ptr(ws), ws_bytes,
+                                                  _stream_ptr(degrees.device)))
+    return out
+
+
+BUILD_NEEDS_SORT = 32                  # include/stgraph_hip.h STG_BUILD_NEEDS_SORT
+# measured (MI355X): 250K edges 0.22 vs 0.35 ms, 500K 0.33 vs 0.44, 16M 6.9 vs 1.9 (one-workgroup scan, atomics)
+DIRECT_BUILD_MAX_EDGES = 2_000_000
+_DIRECT_BUILD = True
+
+
+def set_direct_build(enabled: bool) -> None:
+    """True (default): device graphs are built by counting (stg_graph_build_direct_device), falling back to the
+    sort-based builder when a row is longer than 2048 entries.  False: always the sort-based builder."""
+    global _DIRECT_BUILD
+    _DIRECT_BUILD = bool(enabled)
+
+
+def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_node_ids: bool = False) -> GraphCSR:
     """Build both CSRs of a graph from (src, dst) arrays (static_graph.py:40-78).
 
     ``device`` cuda -> stg_graph_build_device (sort + search on the GPU, stream
@@ -201,20 +252,37 @@ def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str) -> Gra
         raise ValueError("num_nodes must be >= 0")
     i32 = dict(dtype=torch.int32, device=device)
     perm = torch.empty(E, dtype=torch.int64, device=device)
-    fwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32), True)
-    bwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(N, **i32), True)
     indeg, outdeg = torch.empty(N, **i32), torch.empty(N, **i32)
-    arrays = [perm, fwd.row_offset, fwd.column_indices, fwd.eids, fwd.node_ids,
-              bwd.row_offset, bwd.column_indices, bwd.eids, bwd.node_ids, indeg, outdeg]
+    # ``lazy_node_ids`` (honoured by the direct device build only): leave the two degree sorts to first use
+    lazy = bool(lazy_node_ids) and device.type == "cuda" and _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES
+    nid_f, nid_b = (None, None) if lazy else (torch.empty(N, **i32), torch.empty(N, **i32))
+    fwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), nid_f, not lazy, indeg)
+    bwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), nid_b, not lazy, outdeg)
+    arrays = [perm, fwd.row_offset, fwd.column_indices, fwd.eids, nid_f,
+              bwd.row_offset, bwd.column_indices, bwd.eids, nid_b, indeg, outdeg]
     if device.type == "cuda":
-        ws_bytes = int(_C.lib.stg_graph_build_device_workspace_bytes(E, N))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         status = torch.empty(1, **i32)
-        with torch.cuda.device(device):
-            _C.check(_C.lib.stg_graph_build_device(
-                _ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays],
-                _ptr(status), _ptr(ws), ws_bytes, _stream_ptr(device)))
-        code = int(status.item())          # one 4-byte sync per graph build, for endpoint validation
+        code = BUILD_NEEDS_SORT
+        if _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES:      # counting build: 6 launches + the node_ids sorts
+            ws_bytes = int(_C.lib.stg_graph_build_direct_workspace_bytes(E, N))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                _C.check(_C.lib.stg_graph_build_direct_device(
+                    _ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays],
+                    _ptr(status), _ptr(ws), ws_bytes, _stream_ptr(device)))
+            code = int(status.item())      # one 4-byte sync per graph build: endpoint validation / long-row verdict
+        if code & BUILD_NEEDS_SORT:        # a row longer than 2048 entries (or the direct path is off): sort-based build
+            if lazy:
+                fwd.node_ids, bwd.node_ids = torch.empty(N, **i32), torch.empty(N, **i32)
+                fwd.degree_sorted = bwd.degree_sorted = True
+                arrays[4], arrays[8] = fwd.node_ids, bwd.node_ids
+            ws_bytes = int(_C.lib.stg_graph_build_device_workspace_bytes(E, N))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                _C.check(_C.lib.stg_graph_build_device(
+                    _ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays],
+                    _ptr(status), _ptr(ws), ws_bytes, _stream_ptr(device)))
+            code = int(status.item())
         if code != 0:
             raise ValueError(f"edge endpoint outside [0, {N}) (libstgraph_hip status {code})")
     else:
@@ -353,7 +421,8 @@ class StoreCSR(DeviceCSR):
 
     def __init__(self, es: EdgeSet, reverse: bool, row_offset, column_indices, node_ids, degrees,
                  key_order: bool = False):
-        self.row_offset, self.column_indices, self.node_ids, self.degrees = row_offset, column_indices, node_ids, degrees
+        self.row_offset, self.column_indices, self._node_ids, self.degrees = row_offset, column_indices, node_ids, degrees
+        self._degrees = degrees
         self.degree_sorted = True
         self._es, self._reverse, self._labels, self._key_order = es, bool(reverse), None, bool(key_order)
 
@@ -492,7 +561,7 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
             if bias.numel() != F:
                 raise ValueError(f"bias has {bias.numel()} entries, rows have {F}")
     out = (torch.empty_like(x) if fa == F else torch.zeros_like(x))
-    nid = _ptr(csr.node_ids if use_node_ids else None)
+    nid = _ptr(csr.node_ids_if_ready if use_node_ids else None)     # an order hint: skipped if not sorted yet
     with torch.cuda.device(dev):
         if _EDGE_CACHE:
             nc_e = _edge_gathered(csr, "norm", norm_col, csr.column_indices)
@@ -501,12 +570,12 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
             if epilogue:
                 _C.check(_C.lib.stg_gcn_layer_fwd(
                     _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(bias), int(act), _ptr(out),
-                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids if (_LONG_ROWS and csr.degree_sorted) else None),
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids_if_ready if (_LONG_ROWS and csr.degree_sorted) else None),
                     N, csr.num_edges, F, _stream_ptr(dev)))
             elif _EDGE_CACHE:
                 _C.check(_C.lib.stg_gcn_agg_edge(
                     _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(out),
-                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids if (_LONG_ROWS and csr.degree_sorted) else None),
+                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids_if_ready if (_LONG_ROWS and csr.degree_sorted) else None),
                     N, csr.num_edges, F, fa, _stream_ptr(dev)))
             else:
                 _C.check(_C.lib.stg_gcn_agg(
@@ -573,7 +642,7 @@ def gcn_agg_transform(x: torch.Tensor, W: torch.Tensor, norm_row: torch.Tensor, 
         with _Timed("gcn_agg_transform", nbytes, E * fin):
             _C.check(_C.lib.stg_gcn_agg_transform(
                 _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(W), _ptr(out), _ptr(P),
-                _ptr(csr.row_offset), _ptr(csr.column_indices), _ptr(csr.node_ids if use_node_ids else None),
+                _ptr(csr.row_offset), _ptr(csr.column_indices), _ptr(csr.node_ids_if_ready if use_node_ids else None),
                 N, fin, fout, _stream_ptr(dev)))
     return out, P
 
@@ -599,7 +668,7 @@ def gat_fwd(el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor, csr: DeviceC
     A = alloc((E, H, 1), dtype=torch.float32, device=dev)
     S = alloc((N, H, 1), dtype=torch.float32, device=dev)
     out = alloc((N, H, D), dtype=torch.float32, device=dev)
-    nid = _ptr(csr.node_ids if use_node_ids else None)
+    nid = _ptr(csr.node_ids_if_ready if use_node_ids else None)
     ab = gat_algorithmic_bytes(N, E, H, D)
     with torch.cuda.device(dev):
         st = _stream_ptr(dev)
@@ -653,18 +722,18 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
                 _C.check(_C.lib.stg_gat_bwd_factored(
                     _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(feat), _ptr(grad_feat), _ptr(grad_el), _ptr(T),
                     _ptr(P), _ptr(bwd.row_offset), _ptr(bwd.column_indices), _ptr(bwd.eids),
-                    _ptr(bwd.node_ids if use_node_ids else None), N, H, D, float(slope), st))
+                    _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, H, D, float(slope), st))
             else:
                 _C.check(_C.lib.stg_gat_bwd(
                     _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(el), _ptr(er), _ptr(feat),
                     _ptr(grad_feat), _ptr(grad_el), _ptr(T), _ptr(bwd.row_offset), _ptr(bwd.column_indices),
-                    _ptr(bwd.eids), _ptr(bwd.node_ids if use_node_ids else None), N, H, D, hd_act,
+                    _ptr(bwd.eids), _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, H, D, hd_act,
                     float(slope), st))
         # heads the backward unit touched: those with at least one active feature column
         h_touched = H if full else min(H, (hd_act + D - 1) // D)
         with _Timed("gat_bwd_er", ab["gat_bwd_er"], E * H):
             _C.check(_C.lib.stg_gat_bwd_er(_ptr(T), _ptr(grad_er), _ptr(fwd.row_offset), _ptr(fwd.eids),
-                                           _ptr(fwd.node_ids if use_node_ids else None), N, H, h_touched, st))
+                                           _ptr(fwd.node_ids_if_ready if use_node_ids else None), N, H, h_touched, st))
     return grad_feat, grad_el, grad_er
 
 
