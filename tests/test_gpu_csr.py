@@ -84,3 +84,42 @@ def test_full_size_properties(cuda):
         deg = (csr.row_offset[1:] - csr.row_offset[:-1])[csr.node_ids.long()]
         assert bool((deg[1:] <= deg[:-1]).all())
         assert torch.equal(torch.sort(csr.node_ids.long()).values, torch.arange(n, device=cuda))
+
+
+@pytest.mark.parametrize("n,e,dup", [(1, 1, False), (7, 40, True), (300, 5000, True), (25_000, 250_000, False)])
+def test_direct_build_equals_sort_build_and_lazy_node_ids(cuda, n, e, dup):
+    """The counting build (stg_graph_build_direct_device) and the sort-based build give the same arrays, also with
+    duplicate edges / self loops; node_ids left to first use equal the eagerly sorted ones; a row longer than the
+    direct path's limit falls back to the sort-based build transparently."""
+    from stgraph_amd import kernels
+    src, dst = random_graph(n + e, n, e, duplicates=dup, hub=False)       # rows stay under the direct path's limit
+    res = []
+    for direct in (True, False):
+        kernels.set_direct_build(direct)
+        try:
+            res.append(kernels.build_graph_csr(src, dst, n, cuda))
+        finally:
+            kernels.set_direct_build(True)
+    a, b = res
+    for x, y in ((a.fwd, b.fwd), (a.bwd, b.bwd)):
+        for k in ("row_offset", "column_indices", "eids", "node_ids"):
+            assert torch.equal(getattr(x, k), getattr(y, k)), k
+    assert torch.equal(a.perm_fwd, b.perm_fwd) and torch.equal(a.in_degrees, b.in_degrees)
+    lazy = kernels.build_graph_csr(src, dst, n, cuda, lazy_node_ids=True)
+    assert lazy.fwd.node_ids_if_ready is None and not lazy.fwd.degree_sorted
+    assert torch.equal(lazy.fwd.node_ids, a.fwd.node_ids) and torch.equal(lazy.bwd.node_ids, a.bwd.node_ids)
+    assert lazy.fwd.degree_sorted and lazy.fwd.node_ids_if_ready is not None
+
+
+def test_direct_build_falls_back_on_a_long_row(cuda):
+    from stgraph_amd import kernels
+    n = 5000
+    hub = np.arange(1, 3001, dtype=np.int32)                        # 3000 edges into vertex 0: longer than 2048
+    src = np.concatenate([hub, np.arange(n - 1, dtype=np.int32)])
+    dst = np.concatenate([np.zeros(3000, np.int32), np.arange(1, n, dtype=np.int32)])
+    g = kernels.build_graph_csr(src, dst, n, cuda, lazy_node_ids=True)
+    og = orc.build_graph(src, dst, n)
+    for side, o in ((g.fwd, og.fwd), (g.bwd, og.bwd)):
+        for k in ("row_offset", "column_indices", "eids"):
+            assert np.array_equal(getattr(side, k).cpu().numpy(), getattr(o, k)), k
+    assert g.fwd.degree_sorted and int(g.fwd.node_ids[0]) == 0
