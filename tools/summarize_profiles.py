@@ -30,7 +30,8 @@ def stats(src, dst, top=25):
 
 def _counter(d, name):
     f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "gcn_agg" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    # the row-group kernel only: on large narrow-row graphs a (nearly empty) long-row launch follows each call
+    rows = [r for r in csv.DictReader(open(f)) if "gcn_agg_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return [(float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6) for r in rows]
 
