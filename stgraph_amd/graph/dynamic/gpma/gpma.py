@@ -29,9 +29,6 @@ from __future__ import annotations
 
 import time
 
-import numpy as np
-import torch
-
 from .... import kernels
 from ...static.csr import _LIVE
 from ..pcsr.pcsr import PCSR, _pairs
