@@ -35,16 +35,20 @@ struct GemmSegs {
     const float *b[kGemmMaxSeg];
 };
 
-template <int NT, int KU, bool CS>
+// MT = 32-row M tiles per wave: every B dword a wave loads feeds MT MFMAs and every A dword NT of them.  With MT = 1
+// a k-pair costs 1 + NT dword loads for NT MFMAs; the kernel then runs at the rate the texture addresser issues
+// those loads (16 cycles per wave instruction, 8 waves per CU: 262 us of address cycles against 210 us of MFMA at
+// 1M x 128 x 128), and B is fetched once per M tile.  MT = 2: MT + NT loads for MT * NT MFMAs.
+template <int NT, int KU, bool CS, int MT>
 __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     const GemmSegs segs, float *__restrict__ slab, int64_t K, int M, int N, int64_t kslice_wave,
-    int m_tiles, int n_groups, int s_per_seg)
+    int m_groups, int n_groups, int s_per_seg)
 {
-    extern __shared__ float lds[];                       // 3 waves x NT x 16 x 64 floats
+    extern __shared__ float lds[];                       // one wave's accumulators: (MT * NT) x 16 x 64 floats (+ 64 * MT)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mi = blockIdx.x % m_tiles;
-    const int t = blockIdx.x / m_tiles;
+    const int mi = blockIdx.x % m_groups;                // group of MT M tiles
+    const int t = blockIdx.x / m_groups;
     const int nj = t % n_groups;
     const int s = t / n_groups;                          // slab index = segment * s_per_seg + slice
     const int seg = s / s_per_seg;
@@ -57,8 +61,13 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     const int kh = lane >> 5;
     // Rows >= M / columns >= N of the tile are never written back, so out-of-range lanes read a
     // clamped (valid) address: no per-load m/n predicates.  Only the K tail needs masking.
-    const int m = mi * 32 + (lane & 31);
-    const unsigned la = (unsigned)(kh * M + min(m, M - 1));                     // lane offset into an A row pair
+    int m[MT];
+    unsigned la[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        m[i] = (mi * MT + i) * 32 + (lane & 31);
+        la[i] = (unsigned)(kh * M + min(m[i], M - 1));                          // lane offset into an A row pair
+    }
     int n[NT];
     unsigned lb[NT];
     bool nok[NT];
@@ -68,13 +77,16 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
         nok[j] = n[j] < N;
         lb[j] = (unsigned)(kh * N + min(n[j], N - 1));
     }
-    f32x16 acc[NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    float cs_lane = 0.f;            // CS: this lane's share of sum_k A[k][m] (k of its parity); a VALU add per k-pair
-                                    // instead of a fifth MFMA on the pipe that bounds the kernel
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float cs_lane[MT];              // CS: this lane's share of sum_k A[k][m] (k of its parity); a VALU add per k-pair
+#pragma unroll                      // instead of another MFMA on the pipe that bounds the kernel
+    for (int i = 0; i < MT; ++i) cs_lane[i] = 0.f;
     const bool do_cs = CS && nj == 0;                                           // block-uniform
 
     constexpr int STEP = 2 * KU;
@@ -86,35 +98,41 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
                                                        (int)(rows * M * (int64_t)sizeof(float)), 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + k0 * N), 0,
                                                        (int)(rows * N * (int64_t)sizeof(float)), 0x00020000);
-    const int voA = (int)(la * sizeof(float));
-    int voB[NT];
+    int voA[MT], voB[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) voA[i] = (int)(la[i] * sizeof(float));
 #pragma unroll
     for (int j = 0; j < NT; ++j) voB[j] = (int)(lb[j] * sizeof(float));
-    auto load_set = [&](float (&a)[KU], float (&b)[KU][NT], int64_t k) {
+    auto load_set = [&](float (&a)[KU][MT], float (&b)[KU][NT], int64_t k) {
         const int r0 = (int)(k - k0);                                           // uniform
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int soA = (r0 + 2 * u) * M * (int)sizeof(float);
             const int soB = (r0 + 2 * u) * N * (int)sizeof(float);
-            a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voA, soA, 0));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                a[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voA[i], soA, 0));
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 b[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voB[j], soB, 0));
         }
     };
-    auto mfma_set = [&](const float (&a)[KU], const float (&b)[KU][NT]) {
+    auto mfma_set = [&](const float (&a)[KU][MT], const float (&b)[KU][NT]) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][j], acc[j], 0, 0, 0);
-            if constexpr (CS) cs_lane += a[u];
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+                if constexpr (CS) cs_lane[i] += a[u][i];
+            }
         }
     };
 
     // two operand sets: the loads of the next STEP rows are in flight while the matrix pipe
-    // consumes the current set (fp32 MFMA: 64 cycles each, KU*NT of them per set)
-    float a0[KU], b0[KU][NT], a1[KU], b1[KU][NT];
+    // consumes the current set (fp32 MFMA: 64 cycles each, KU*MT*NT of them per set)
+    float a0[KU][MT], b0[KU][NT], a1[KU][MT], b1[KU][NT];
     if (k0 < k1) load_set(a0, b0, k0);
     for (int64_t k = k0; k < k1; k += 2 * STEP) {
         const bool more1 = k + STEP < k1;
@@ -126,41 +144,58 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
         }
     }
 
-    // add the block's 4 K sub-slices in wave order (fixed => deterministic), wave 0 writes the slab
-    constexpr int NTS = NT + (CS ? 1 : 0);
-    if (wave > 0) {
-        float *dst = lds + (size_t)(wave - 1) * NTS * 16 * kWave + lane;
+    // add the block's 4 K sub-slices in wave order (fixed => deterministic): waves 1..3 hand their accumulators to
+    // wave 0 through ONE wave-sized LDS buffer, one after the other; wave 0 writes the slab
+    constexpr int kAccFloats = MT * NT * 16 * kWave;
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+        if (wave == w) {
+            float *dst = lds + lane;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dst[(j * 16 + i) * kWave] = acc[j][i];
-        if constexpr (CS) dst[(NT * 16) * kWave] = cs_lane;
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((i * NT + j) * 16 + r) * kWave] = acc[i][j][r];
+            if constexpr (CS) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) lds[kAccFloats + i * kWave + lane] = cs_lane[i];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float *src = lds + lane;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * NT + j) * 16 + r) * kWave];
+            if constexpr (CS) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) cs_lane[i] += lds[kAccFloats + i * kWave + lane];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (wave == 0) {
-        for (int w = 0; w < kWavesPerBlock - 1; ++w) {
-            const float *src = lds + (size_t)w * NTS * 16 * kWave + lane;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[j][i] += src[(j * 16 + i) * kWave];
-            if constexpr (CS) cs_lane += src[(NT * 16) * kWave];
-        }
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-        const int row0 = mi * 32 + 4 * kh;
         const int64_t slab_stride = (int64_t)M * N + (CS ? M : 0);
-        if constexpr (CS) {
-            const float both = cs_lane + __shfl_xor(cs_lane, 32, kWave);        // even + odd k of column m
-            if (do_cs && kh == 0 && m < M) slab[(int64_t)s * slab_stride + (int64_t)M * N + m] = both;
-        }
-        float *out = slab + (int64_t)s * slab_stride + (int64_t)row0 * N;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if (!nok[j]) continue;
+        for (int i = 0; i < MT; ++i) {
+            if constexpr (CS) {
+                const float both = cs_lane[i] + __shfl_xor(cs_lane[i], 32, kWave);   // even + odd k of column m
+                if (do_cs && kh == 0 && m[i] < M) slab[(int64_t)s * slab_stride + (int64_t)M * N + m[i]] = both;
+            }
+            const int row0 = (mi * MT + i) * 32 + 4 * kh;
+            float *out = slab + (int64_t)s * slab_stride + (int64_t)row0 * N;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int dr = (i & 3) + 8 * (i >> 2);
-                if (row0 + dr < M) out[dr * N + n[j]] = acc[j][i];
+            for (int j = 0; j < NT; ++j) {
+                if (!nok[j]) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (row0 + dr < M) out[dr * N + n[j]] = acc[i][j][r];
+                }
             }
         }
     }
@@ -201,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void gemm_tn_reduce_kernel(const float *__r
 namespace {
 
 struct GemmPlan {
-    int nt, m_tiles, n_groups, S;
+    int nt, mt, m_tiles, n_groups, S;          // m_tiles = groups of mt 32-row tiles
     int64_t kslice_wave;
 };
 
@@ -209,7 +244,8 @@ GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1)
 {
     GemmPlan p{};
     p.nt = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
-    p.m_tiles = (M + 31) / 32;
+    p.mt = M > 32 ? 2 : 1;
+    p.m_tiles = (M + 32 * p.mt - 1) / (32 * p.mt);
     p.n_groups = (N + 32 * p.nt - 1) / (32 * p.nt);
     const int64_t tiles = (int64_t)p.m_tiles * p.n_groups;
     // at most 512 blocks = ONE resident round (2 per CU): a 550-block grid (T = 25, 2 tiles: S rounded up to 11)
@@ -275,15 +311,19 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         return fail(STG_ERR_WORKSPACE, "%s: workspace %zu < required %zu", what, workspace_bytes, need);
     float *slab = static_cast<float *>(workspace);
     const int64_t blocks = (int64_t)S_total * p.m_tiles * p.n_groups;
-    const size_t lds = (size_t)(kWavesPerBlock - 1) * (p.nt + (cs ? 1 : 0)) * 16 * kWave * sizeof(float);
-#define STG_GEMM_LAUNCH(NT_, KU_, CS_)                                                                        \
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<NT_, KU_, CS_>), dim3((unsigned)blocks), dim3(kBlock), lds,    \
+    const size_t lds = ((size_t)p.mt * p.nt * 16 + p.mt) * kWave * sizeof(float);
+#define STG_GEMM_LAUNCH(NT_, KU_, CS_, MT_)                                                                       \
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<NT_, KU_, CS_, MT_>), dim3((unsigned)blocks), dim3(kBlock), lds,   \
                        stream, segs, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S)
+#define STG_GEMM_NT(CS_, MT_)                                                                                     \
+    if (p.nt == 1) STG_GEMM_LAUNCH(1, 8, CS_, MT_); else if (p.nt == 2) STG_GEMM_LAUNCH(2, 8, CS_, MT_);         \
+    else STG_GEMM_LAUNCH(4, 4, CS_, MT_)
     if (cs) {
-        if (p.nt == 1) STG_GEMM_LAUNCH(1, 8, true); else if (p.nt == 2) STG_GEMM_LAUNCH(2, 8, true); else STG_GEMM_LAUNCH(4, 4, true);
+        if (p.mt == 2) { STG_GEMM_NT(true, 2); } else { STG_GEMM_NT(true, 1); }
     } else {
-        if (p.nt == 1) STG_GEMM_LAUNCH(1, 8, false); else if (p.nt == 2) STG_GEMM_LAUNCH(2, 8, false); else STG_GEMM_LAUNCH(4, 4, false);
+        if (p.mt == 2) { STG_GEMM_NT(false, 2); } else { STG_GEMM_NT(false, 1); }
     }
+#undef STG_GEMM_NT
 #undef STG_GEMM_LAUNCH
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MNc + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
                        slab, C, colsum, MNc, MN, S_total);
