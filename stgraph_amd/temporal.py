@@ -153,7 +153,7 @@ def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, 
                 if t >= total:
                     break
                 y_out, y_hat, hidden = model(graph, y_hat, edge_weight, hidden)
-                cost = cost + F.mse_loss(y_out, targets[t])       # = torch.mean((y_out - targets[t]) ** 2) (train.py:178), 2 launches instead of 7
+                cost = cost + torch.mean((y_out - targets[t]) ** 2)
             cost = cost / (backprop_every + 1)
             cost.backward()
             losses.append(cost.detach())
@@ -253,7 +253,7 @@ class CapturedStaticWindow:
             y_hat = self.static_y0
             for k in range(self.B):
                 y_out, y_hat, hidden = model(graph, y_hat, edge_weight, hidden)
-                cost = cost + F.mse_loss(y_out, self.static_targets[k])
+                cost = cost + torch.mean((y_out - self.static_targets[k]) ** 2)
             cost = cost / (self.B + 1)
             cost.backward()
             return cost.detach()
@@ -302,7 +302,7 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
             y_hat = window_input(n, feat_size, epoch, w, targets.device, seed)
             for t in range(w * B, min((w + 1) * B, total)):
                 y_out, y_hat, hidden = model(graph, y_hat, edge_weight, hidden)
-                cost = cost + F.mse_loss(y_out, targets[t])       # = torch.mean((y_out - targets[t]) ** 2) (train.py:178), 2 launches instead of 7
+                cost = cost + torch.mean((y_out - targets[t]) ** 2)
             cost = cost / (B + 1)
             cost.backward()
             losses.append(cost.detach())
