@@ -374,6 +374,10 @@ int stg_gat_proj_bwd(const float *feat, const float *attn_l, const float *attn_r
 int stg_rowgemm_supported(int32_t K, int32_t M);
 int stg_rowgemm_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K,
                     int32_t M, int trans_w, void *stream);
+/* Same with an output row stride ldy >= M (floats): writes the column block Y[:, 0:M] of a wider row-major matrix,
+ * so an output wider than one launch covers (M > 192) is produced in column slices of W / bias. */
+int stg_rowgemm_strided_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K,
+                            int32_t M, int32_t ldy, int trans_w, void *stream);
 
 /* C = sum_{t < T} A_t^T B_t (and colsum_A = sum_t colsum(A_t), nullable) in ONE launch: A, B are HOST
  * arrays of T <= 32 device pointers, every A_t [K,M], B_t [K,N].  The pointers travel by value in

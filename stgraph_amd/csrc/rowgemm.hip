@@ -24,7 +24,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 template <int KBMAX, int MT, bool TRANS_W>
 __global__ __launch_bounds__(kBlock) void rowgemm_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                          const float *__restrict__ bias, float *__restrict__ Y,
-                                                         int64_t N, int K, int M, int num_tiles)
+                                                         int64_t N, int K, int M, int num_tiles, int ldy)
 {
     extern __shared__ float Ws[];                      // [KB * 8][M + 1]
     const int ldw = M + 1;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void rowgemm_kernel(const float *__restrict
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int64_t r = row_base + (i & 3) + 8 * (i >> 2) + 4 * kh;
-                if (r < N) Y[r * M + ct * 32 + l31] = acc[ct][i];
+                if (r < N) Y[r * ldy + ct * 32 + l31] = acc[ct][i];
             }
         }
     }
@@ -131,7 +131,7 @@ inline bool rowgemm_shape(int32_t K, int32_t M, RowGemmShape &s)
 
 template <int KBMAX, int MT>
 int rowgemm_launch(const float *X, const float *W, const float *bias, float *Y, int64_t N, int K, int M, bool trans_w,
-                   size_t lds, hipStream_t st)
+                   size_t lds, hipStream_t st, int ldy)
 {
     const int64_t tiles = (N + 31) / 32;
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: too many rows");
@@ -150,24 +150,24 @@ int rowgemm_launch(const float *X, const float *W, const float *bias, float *Y, 
     const unsigned blocks = (unsigned)std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, 256 * per_cu);
     if (trans_w)
         hipLaunchKernelGGL((rowgemm_kernel<KBMAX, MT, true>), dim3(blocks), dim3(kBlock), lds, st, X, W, bias, Y, N, K, M,
-                           (int)tiles);
+                           (int)tiles, ldy);
     else
         hipLaunchKernelGGL((rowgemm_kernel<KBMAX, MT, false>), dim3(blocks), dim3(kBlock), lds, st, X, W, bias, Y, N, K, M,
-                           (int)tiles);
+                           (int)tiles, ldy);
     return check_launch("stg_rowgemm_f32");
 }
 
 template <int KBMAX>
 int rowgemm_mt(int mt, const float *X, const float *W, const float *bias, float *Y, int64_t N, int K, int M, bool tw,
-               size_t lds, hipStream_t st)
+               size_t lds, hipStream_t st, int ldy)
 {
     switch (mt) {
-        case 1: return rowgemm_launch<KBMAX, 1>(X, W, bias, Y, N, K, M, tw, lds, st);
-        case 2: return rowgemm_launch<KBMAX, 2>(X, W, bias, Y, N, K, M, tw, lds, st);
-        case 3: return rowgemm_launch<KBMAX, 3>(X, W, bias, Y, N, K, M, tw, lds, st);
-        case 4: return rowgemm_launch<KBMAX, 4>(X, W, bias, Y, N, K, M, tw, lds, st);
+        case 1: return rowgemm_launch<KBMAX, 1>(X, W, bias, Y, N, K, M, tw, lds, st, ldy);
+        case 2: return rowgemm_launch<KBMAX, 2>(X, W, bias, Y, N, K, M, tw, lds, st, ldy);
+        case 3: return rowgemm_launch<KBMAX, 3>(X, W, bias, Y, N, K, M, tw, lds, st, ldy);
+        case 4: return rowgemm_launch<KBMAX, 4>(X, W, bias, Y, N, K, M, tw, lds, st, ldy);
         default:
-            if constexpr (4 * KBMAX + 16 * 6 <= 176) return rowgemm_launch<KBMAX, 6>(X, W, bias, Y, N, K, M, tw, lds, st);
+            if constexpr (4 * KBMAX + 16 * 6 <= 176) return rowgemm_launch<KBMAX, 6>(X, W, bias, Y, N, K, M, tw, lds, st, ldy);
             else return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: shape not covered");
     }
 }
@@ -180,10 +180,20 @@ extern "C" int stg_rowgemm_supported(int32_t K, int32_t M)
     return stg::rowgemm_shape(K, M, s) ? 1 : 0;
 }
 
+extern "C" int stg_rowgemm_strided_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N,
+                                       int32_t K, int32_t M, int32_t ldy, int trans_w, void *stream);
+
 extern "C" int stg_rowgemm_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K,
                                int32_t M, int trans_w, void *stream)
 {
+    return stg_rowgemm_strided_f32(X, W, bias, Y, N, K, M, M, trans_w, stream);
+}
+
+extern "C" int stg_rowgemm_strided_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N,
+                                       int32_t K, int32_t M, int32_t ldy, int trans_w, void *stream)
+{
     using namespace stg;
+    if (ldy < M) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_strided_f32: ldy=%d < M=%d", ldy, M);
     if (N < 0 || K <= 0 || M <= 0)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_f32: bad shape N=%lld K=%d M=%d", (long long)N, K, M);
     RowGemmShape s;
@@ -196,9 +206,9 @@ extern "C" int stg_rowgemm_f32(const float *X, const float *W, const float *bias
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_f32: X and W must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (s.kbmax) {
-        case 4: return rowgemm_mt<4>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st);
-        case 8: return rowgemm_mt<8>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st);
-        case 16: return rowgemm_mt<16>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st);
-        default: return rowgemm_mt<24>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st);
+        case 4: return rowgemm_mt<4>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st, ldy);
+        case 8: return rowgemm_mt<8>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st, ldy);
+        case 16: return rowgemm_mt<16>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st, ldy);
+        default: return rowgemm_mt<24>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st, ldy);
     }
 }

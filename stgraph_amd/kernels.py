@@ -806,6 +806,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, colsum: bool = False):
     return (c, cs) if colsum else c
 
 
+_WIDE_LINEAR = True
 _ROWGEMM_MODE = os.environ.get("STGRAPH_AMD_ROWGEMM", "0")     # "0" | "1" | "auto" (only where measured faster)
 _ROWGEMM = _ROWGEMM_MODE != "0"
 
@@ -847,10 +848,39 @@ def rowgemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
     return y
 
 
+WIDE_SLICE = 128
+
+
+def wide_linear_usable(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """``x @ w.T`` with a WIDE output from a narrow input over many rows (GATConv's ``fc``: [256K, 64] -> 512): rocBLAS
+    picks a 64x32 macro tile there (0.6 ms where four 128-column launches of it take 0.25); the row kernel computes it
+    in 128-column slices of ``w`` written straight into the output (stg_rowgemm_strided_f32)."""
+    M, K = int(w.shape[0]), int(w.shape[1])
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 65536 and M >= 256
+            and M % WIDE_SLICE == 0 and K <= 64 and w.is_contiguous()
+            and bool(_C.lib.stg_rowgemm_supported(K, WIDE_SLICE)))
+
+
+def wide_linear_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None) -> torch.Tensor:
+    x = _f32(x, "x")
+    dev = x.device
+    N, K = x.shape
+    M = int(w.shape[0])
+    y = torch.empty(N, M, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("rowgemm_wide", 4 * N * (K + M) + 4 * K * M, 2 * N * K * M):
+        for c in range(0, M, WIDE_SLICE):
+            _C.check(_C.lib.stg_rowgemm_strided_f32(
+                _ptr(x), ctypes.c_void_p(w.data_ptr() + 4 * c * K), ctypes.c_void_p(b.data_ptr() + 4 * c) if b is not None else None,
+                ctypes.c_void_p(y.data_ptr() + 4 * c), N, K, WIDE_SLICE, M, 1, _stream_ptr(dev)))
+    return y
+
+
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None) -> torch.Tensor:
     """``x @ w.T + b`` (torch Linear layout) on the native kernel when the shape is covered."""
     if rowgemm_usable(x, w.shape[1], w.shape[0], True):
         return rowgemm(x, w, b, trans_w=True)
+    if _WIDE_LINEAR and wide_linear_usable(x, w):
+        return wide_linear_fwd(x, w, b)
     return torch.addmm(b, x, w.t()) if b is not None else torch.mm(x, w.t())
 
 

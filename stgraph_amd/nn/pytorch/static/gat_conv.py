@@ -44,7 +44,9 @@ class GATConv(nn.Module):
 
     def forward(self, graph, feat):
         h_dst = h_src = self.feat_drop(feat)  # noqa: F841
-        feat_src = feat_dst = self.fc(h_src).view(-1, self._num_heads, self._out_feats)
+        # self.fc through functional.linear: same Linear, wide outputs in 128-column slices of the row GEMM (rocBLAS'
+        # tile choice for [N, in] x [in, H*D] costs 3x its M = 128 launches), weight gradient on the split-K MFMA kernel
+        feat_src = feat_dst = SF.linear(h_src, self.fc.weight, self.fc.bias).view(-1, self._num_heads, self._out_feats)
         if SF.gat_layer_usable(graph, feat_src):
             # static graphs: projections, the three GAT units and the projection gradients as one autograd node
             # (the same kernels the compiled vertex function below dispatches to, minus ~15 torch passes over [N,H,D])

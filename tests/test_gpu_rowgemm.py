@@ -40,3 +40,18 @@ def test_unsupported_shapes(cuda):
     x = torch.zeros(10, 30, device=cuda)
     with pytest.raises(_C.StgError):
         kernels.rowgemm(x, torch.zeros(30, 64, device=cuda))
+
+
+def test_wide_linear_in_column_slices(cuda):
+    """[N, 64] -> 512 (GATConv's fc at cfg3) as four 128-column slices written into one output."""
+    from stgraph_amd import kernels
+    x = torch.randn(70_000, 64, device=cuda)
+    w = torch.randn(512, 64, device=cuda)
+    b = torch.randn(512, device=cuda)
+    assert kernels.wide_linear_usable(x, w)
+    for bias in (b, None):
+        got = kernels.linear_fwd(x, w, bias)
+        want = x.double() @ w.double().t() + (bias.double() if bias is not None else 0)
+        scale = x.double().abs() @ w.double().abs().t() + 1
+        assert ((got.double() - want).abs() <= 2e-6 * scale).all()
+    assert not kernels.wide_linear_usable(x[:1000], w) and not kernels.wide_linear_usable(x, w[:200])
