@@ -38,6 +38,7 @@ class NaiveGraph(DynamicGraph):
         self._resident = bool(resident)
         self._max_cached = max_cached
         self._snapshots: "OrderedDict[int, kernels.GraphCSR]" = OrderedDict()
+        self._built_by = {}                    # t -> builder that produced snapshot t last time ('direct' | 'sort')
         self._edges = []                       # per-t (src, dst) device tensors in caller order
         t0 = time.time()
         for t in range(self._num_timestamps):
@@ -64,7 +65,9 @@ class NaiveGraph(DynamicGraph):
             t0 = time.time()
             s, d = self._edges[t]
             # snapshots built on demand live for one training step: their degree sorts (node_ids) wait for a reader
-            g = kernels.build_graph_csr(s, d, self.max_num_nodes, self._device, lazy_node_ids=not self._resident)
+            g = kernels.build_graph_csr(s, d, self.max_num_nodes, self._device, lazy_node_ids=not self._resident,
+                                        known_path=self._built_by.get(t))       # validated once: no status sync on rebuilds
+            self._built_by[t] = g.built_by
             self.build_count += 1
             if t not in self._distinct_edges:
                 self._distinct_edges[t] = count_distinct_edges(g)

@@ -192,6 +192,7 @@ class GraphCSR:
     in_degrees: torch.Tensor       # int32 [N]
     out_degrees: torch.Tensor      # int32 [N]
     perm_fwd: torch.Tensor         # int64 [E]: caller position of the edge that became eid j
+    built_by: str = ""             # 'direct' | 'sort' | 'host': which builder produced (and validated) it
 
     @property
     def num_edges(self) -> int:
@@ -235,12 +236,17 @@ def set_direct_build(enabled: bool) -> None:
     _DIRECT_BUILD = bool(enabled)
 
 
-def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_node_ids: bool = False) -> GraphCSR:
+def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_node_ids: bool = False,
+                    known_path: str | None = None) -> GraphCSR:
     """Build both CSRs of a graph from (src, dst) arrays (static_graph.py:40-78).
 
-    ``device`` cuda -> stg_graph_build_device (sort + search on the GPU, stream
-    ordered); ``device`` cpu -> stg_graph_build_host (host arrays; used for host
-    logic tests and as the upload source the reference itself uses).
+    ``device`` cuda -> the direct (counting) build for small graphs, the sort-based build otherwise or when a
+    row is too long (stream ordered); ``device`` cpu -> stg_graph_build_host (host arrays; used for host logic
+    tests and as the upload source the reference itself uses).
+
+    The device builds report through a status word whose read is the one host sync of a build (endpoint
+    validation, long-row verdict).  ``known_path`` ('direct' | 'sort', from ``GraphCSR.built_by`` of an earlier,
+    validated build of the SAME edge list -- a dynamic graph rebuilding a snapshot every epoch) skips that read.
     """
     device = torch.device(device)
     N = int(num_nodes)
@@ -260,10 +266,22 @@ def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_n
     bwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), nid_b, not lazy, outdeg)
     arrays = [perm, fwd.row_offset, fwd.column_indices, fwd.eids, nid_f,
               bwd.row_offset, bwd.column_indices, bwd.eids, nid_b, indeg, outdeg]
+    built_by = "host"
     if device.type == "cuda":
         status = torch.empty(1, **i32)
         code = BUILD_NEEDS_SORT
-        if _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES:      # counting build: 6 launches + the node_ids sorts
+        built_by = "sort"
+        if known_path == "direct" and lazy == bool(lazy_node_ids) and _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES:
+            ws_bytes = int(_C.lib.stg_graph_build_direct_workspace_bytes(E, N))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                _C.check(_C.lib.stg_graph_build_direct_device(
+                    _ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays],
+                    _ptr(status), _ptr(ws), ws_bytes, _stream_ptr(device)))
+            g = GraphCSR(N, fwd, bwd, indeg, outdeg, perm)
+            g.built_by = "direct"
+            return g
+        if known_path != "sort" and _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES:      # counting build: 6 launches (+ node_ids)
             ws_bytes = int(_C.lib.stg_graph_build_direct_workspace_bytes(E, N))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
             with torch.cuda.device(device):
@@ -271,7 +289,9 @@ def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_n
                     _ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays],
                     _ptr(status), _ptr(ws), ws_bytes, _stream_ptr(device)))
             code = int(status.item())      # one 4-byte sync per graph build: endpoint validation / long-row verdict
-        if code & BUILD_NEEDS_SORT:        # a row longer than 2048 entries (or the direct path is off): sort-based build
+            built_by = "direct"
+        if code & BUILD_NEEDS_SORT:
+            built_by = "sort"        # a row longer than 2048 entries (or the direct path is off): sort-based build
             if lazy:
                 fwd.node_ids, bwd.node_ids = torch.empty(N, **i32), torch.empty(N, **i32)
                 fwd.degree_sorted = bwd.degree_sorted = True
@@ -282,12 +302,14 @@ def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_n
                 _C.check(_C.lib.stg_graph_build_device(
                     _ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays],
                     _ptr(status), _ptr(ws), ws_bytes, _stream_ptr(device)))
-            code = int(status.item())
+            code = 0 if known_path == "sort" else int(status.item())
         if code != 0:
             raise ValueError(f"edge endpoint outside [0, {N}) (libstgraph_hip status {code})")
     else:
         _C.check(_C.lib.stg_graph_build_host(_ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays]))
-    return GraphCSR(N, fwd, bwd, indeg, outdeg, perm)
+    g = GraphCSR(N, fwd, bwd, indeg, outdeg, perm)
+    g.built_by = built_by
+    return g
 
 
 def csr_ctor_host(a, b, eid, edge_weight, num_nodes: int, is_edge_reverse: bool = False):
