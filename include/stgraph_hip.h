@@ -38,7 +38,9 @@ const char *stg_last_error_string(void);
 /* Launch-time knobs (performance only, never results).  Unknown keys return
  * STG_ERR_INVALID_ARGUMENT.  Keys: "gcn_lanes_per_row" (0 = auto, else a power
  * of two <= 64), "gcn_unroll" (0 = auto, 2/4/8), "gcn_long_threshold" (0 = auto; rows with more
- * edges take the wave-per-row path of stg_gcn_agg_edge). */
+ * edges take the wave-per-row path of stg_gcn_agg_edge), "gcn_xcd_tile" (0 = auto; T >= 1: each XCD takes runs
+ * of T consecutive workgroups' rows, 1 = plain round robin), "gcn_addr32" (0 = auto, 1 = never use 32-bit gather
+ * offsets). */
 int stg_set_tuning(const char *key, int value);
 
 /* ---------------------------------------------------------------- CSR, host

@@ -26,6 +26,7 @@
 // fabric traffic and a dependent round trip -- become coalesced streams; the
 // values, and therefore the results, are identical.
 #include <algorithm>
+#include <type_traits>
 
 #include "stg_common.hpp"
 
@@ -45,6 +46,39 @@ __device__ __forceinline__ float bcast_f(float v, int src)
     return __int_as_float(bcast_i<G>(__float_as_int(v), src));
 }
 
+// Broadcast inside a G-lane row group from a source lane that is a compile-time constant after unrolling: quad
+// permutes (DPP, no LDS crossbar trip) for G = 2 and 4.
+template <int CTRL>
+__device__ __forceinline__ int dpp_quad(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);       // every lane of a quad has a source
+}
+
+template <int G>
+__device__ __forceinline__ int bcast_const_i(int v, int src)
+{
+    if constexpr (G == 1) {
+        return v;
+    } else if constexpr (G == 2) {
+        return src ? dpp_quad<0xF5>(v) : dpp_quad<0xA0>(v);          // lanes {0,1} <- src, {2,3} <- 2 + src
+    } else if constexpr (G == 4) {
+        switch (src) {
+            case 0: return dpp_quad<0x00>(v);
+            case 1: return dpp_quad<0x55>(v);
+            case 2: return dpp_quad<0xAA>(v);
+            default: return dpp_quad<0xFF>(v);
+        }
+    } else {
+        return bcast_i<G>(v, src);
+    }
+}
+
+template <int G>
+__device__ __forceinline__ float bcast_const_f(float v, int src)
+{
+    return __int_as_float(bcast_const_i<G>(__float_as_int(v), src));
+}
+
 // ---- long rows ------------------------------------------------------------------------------------------
 // Rows with more than `threshold` edges when a row is narrower than a wave (L = 2^LOG2L < 64 lanes per row).
 // In the main path below a row's L lanes walk its edges UNROLL at a time, so a hub of degree d costs
@@ -58,6 +92,10 @@ __device__ __forceinline__ float bcast_f(float v, int src)
 // Long rows are found through `rows_by_degree` (non-increasing degree: every CSR builder emits it as
 // node_ids); the FIRST `long_blocks` workgroups of the launch stride over that list and stop at the first
 // row that is not long, so hubs start first and overlap the short rows instead of trailing them.
+#ifndef STG_GCN_ROUND
+#define STG_GCN_ROUND 8
+#endif
+
 template <int VEC, int LOG2L>
 struct LongTile {
     static constexpr int L = 1 << LOG2L, S = kWave / L, W = L * VEC;     // W floats per staged row
@@ -80,8 +118,12 @@ __device__ __forceinline__ void gcn_agg_long_rows(
     constexpr int L = T::L, S = T::S, W = T::W, B = T::B, U = T::U;
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane >> LOG2L, j = lane & (L - 1);
-    const int foff = j * VEC;
+    const int foff = j * VEC;                                        // position in the staged row
     const bool fok = foff < F_active;
+    const int goff = VEC > 1 ? min(foff, F_active - VEC) : foff;     // ragged width: overlapping last window
+    // feature f sits at tile position f, except in the last (shifted) window
+    const int last = ((F_active + VEC - 1) / VEC - 1) * VEC;
+    const int shift = last + VEC - F_active;
 
     for (int i = first_wave; i < N; i += total_waves) {
         const int r = rows_by_degree[i];
@@ -93,8 +135,13 @@ __device__ __forceinline__ void gcn_agg_long_rows(
         // the order-preserving chain costs ~one dependent v_add per edge however wide the row is
         constexpr int M = (W + kWave - 1) / kWave;
         float acc[M];
+        int pos[M];
 #pragma unroll
-        for (int m = 0; m < M; ++m) acc[m] = 0.f;
+        for (int m = 0; m < M; ++m) {
+            acc[m] = 0.f;
+            const int f = lane + m * kWave;
+            pos[m] = (f >= last ? f + shift : f) & (W - 1);
+        }
         int ci[U];
         float nc[U], w[U], v[U][VEC];
         auto load_idx = [&](int base) {                              // coalesced: column, norm[col], w[eid]
@@ -117,7 +164,7 @@ __device__ __forceinline__ void gcn_agg_long_rows(
             for (int u = 0; u < U; ++u) {
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) dst[u][q] = 0.f;
-                if (ci[u] >= 0 && fok) vec_load<VEC>(dst[u], x + (int64_t)ci[u] * F + foff);
+                if (ci[u] >= 0 && fok) vec_load_g<VEC>(dst[u], x + (int64_t)ci[u] * F + goff);
             }
         };
         load_idx(0);
@@ -153,7 +200,7 @@ __device__ __forceinline__ void gcn_agg_long_rows(
                     for (int u = 0; u < kRead; ++u)                  // (slots past cnt hold stale data, never added)
 #pragma unroll
                         for (int m = 0; m < M; ++m)
-                            t[u][m] = tile[((k + u) & (B - 1)) * W + ((lane + m * kWave) & (W - 1))];
+                            t[u][m] = tile[((k + u) & (B - 1)) * W + pos[m]];
 #pragma unroll
                     for (int u = 0; u < kRead; ++u) {
                         if (k + u < cnt) {
@@ -198,18 +245,24 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_long_kernel(
         threshold);
 }
 
-template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false, bool LONG = false>
+template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false, bool LONG = false,
+          bool A32 = false>
 __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
     const float *__restrict__ x, const float *__restrict__ norm_row,
     const float *__restrict__ norm_col, const float *__restrict__ ew, float *__restrict__ out,
     const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
     const int *__restrict__ eids, const int *__restrict__ node_ids, int N, int F, int F_active,
     const float *__restrict__ bias, int act, const int *__restrict__ rows_by_degree, int long_blocks,
-    int long_threshold)
+    int long_threshold, int xcd_tile)
 {
     constexpr int G = 1 << LOG2G;
     constexpr int ROWS_PER_WAVE = kWave / G;
-    constexpr int U = UNROLL < G ? UNROLL : G;
+    // One round = the R edges whose indices a row's G lanes hold at once, i.e. the gathers one index round trip
+    // buys.  Narrow rows (G < 8 lanes) hold several edges per lane so that a round is still 8 edges: with R = G a
+    // 2-lane row (F = 7) would need deg / 2 dependent index -> gather round trips.
+    constexpr int R = G < STG_GCN_ROUND ? STG_GCN_ROUND : G;
+    constexpr int I = R / G;
+    constexpr int U = I > 1 ? R : (UNROLL < G ? UNROLL : G);
 
     if constexpr (LONG) {
         // the first `long_blocks` workgroups take the long rows (see gcn_agg_long_rows)
@@ -225,7 +278,16 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
 
     const int lane = threadIdx.x & (kWave - 1);
     const int j = lane & (G - 1);
-    const int wave_global = ((int)blockIdx.x - long_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
+    // Workgroups go round-robin to the 8 XCDs, each with an L2 of its own.  Deal the rows to the XCDs in runs of
+    // `xcd_tile` consecutive workgroups (grid = a multiple of 8 * xcd_tile) instead of one workgroup at a time: on
+    // graphs with locality (neighbours near the row in vertex order) a source row is then fetched into one L2
+    // instead of eight, while runs stay short enough that a degree trend along the vertex order still spreads.
+    int vb = (int)blockIdx.x - long_blocks;
+    if (xcd_tile > 1) {
+        const int s = vb >> 3;
+        vb = ((s / xcd_tile) * 8 + (vb & 7)) * xcd_tile + s % xcd_tile;
+    }
+    const int wave_global = vb * kWavesPerBlock + (threadIdx.x >> 6);
     const int idx = wave_global * ROWS_PER_WAVE + (lane >> LOG2G);
 
     int r = 0, beg = 0, deg = 0;
@@ -241,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
             row_valid = false;
         }
     }
-    const int max_deg = __builtin_amdgcn_readfirstlane(wave_max(deg));
+    const int max_deg = wave_max_nonneg(deg);
 
     for (int fbase = 0; fbase < F_active; fbase += G * VEC * CHUNKS) {
         float acc[CHUNKS][VEC];
@@ -251,24 +313,31 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
         for (int ch = 0; ch < CHUNKS; ++ch) {
             foff[ch] = fbase + (ch * G + j) * VEC;
             fok[ch] = foff[ch] < F_active;
+            if constexpr (VEC > 1) foff[ch] = min(foff[ch], F_active - VEC);   // ragged width: overlapping last window
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[ch][i] = 0.f;
         }
 
-        for (int base = 0; base < max_deg; base += G) {
+        for (int base = 0; base < max_deg; base += R) {
             const int cnt = deg - base;                       // edges left in MY row (may be <= 0)
-            const int cnt_max = min(G, max_deg - base);       // wave-uniform
-            int c = 0;
-            float nc = 0.f, w = 1.f;
-            if (j < cnt) {
-                const int e = beg + base + j;
-                c = column_indices[e];
-                if constexpr (PRE) {
-                    nc = norm_col[e];                         // = norm[col[e]], gathered once per graph
-                    if constexpr (HAS_EW) w = ew[e];          // = w[eid[e]]
-                } else {
-                    nc = norm_col[c];
-                    if constexpr (HAS_EW) w = ew[eids[e]];
+            const int cnt_max = min(R, max_deg - base);       // wave-uniform
+            int c[I];
+            float nc[I], w[I];
+#pragma unroll
+            for (int i = 0; i < I; ++i) {                     // lane j holds edges j, j + G, ... of the round
+                c[i] = 0;
+                nc[i] = 0.f;
+                w[i] = 1.f;
+                if (i * G + j < cnt) {
+                    const int e = beg + base + i * G + j;
+                    c[i] = column_indices[e];
+                    if constexpr (PRE) {
+                        nc[i] = norm_col[e];                  // = norm[col[e]], gathered once per graph
+                        if constexpr (HAS_EW) w[i] = ew[e];   // = w[eid[e]]
+                    } else {
+                        nc[i] = norm_col[c[i]];
+                        if constexpr (HAS_EW) w[i] = ew[eids[e]];
+                    }
                 }
             }
             for (int k = 0; k < cnt_max; k += U) {
@@ -277,30 +346,57 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int kk = k + u;
-                    const int ck = bcast_i<G>(c, kk & (G - 1));
-                    ncs[u] = bcast_f<G>(nc, kk & (G - 1));
-                    if constexpr (HAS_EW) ws[u] = bcast_f<G>(w, kk & (G - 1));
-                    const float *row = x + (int64_t)ck * F;
+                    const int el = I == 1 ? 0 : u >> LOG2G;   // I > 1: U == R, so k == 0 and kk == u
+                    int ck;
+                    if constexpr (I > 1) {                    // source lane u & (G - 1) is a constant here
+                        ck = bcast_const_i<G>(c[el], u & (G - 1));
+                        ncs[u] = bcast_const_f<G>(nc[el], u & (G - 1));
+                        if constexpr (HAS_EW) ws[u] = bcast_const_f<G>(w[el], u & (G - 1));
+                    } else {
+                        ck = bcast_i<G>(c[el], kk & (G - 1));
+                        ncs[u] = bcast_f<G>(nc[el], kk & (G - 1));
+                        if constexpr (HAS_EW) ws[u] = bcast_f<G>(w[el], kk & (G - 1));
+                    }
 #pragma unroll
                     for (int ch = 0; ch < CHUNKS; ++ch) {
                         if (kk < cnt && fok[ch]) {
-                            vec_load<VEC>(v[u][ch], row + foff[ch]);
+                            if constexpr (A32) {
+                                // whole matrix < 4 GB and < 2^24 rows (host-checked): one full-rate 24-bit multiply-add
+                                // yields the byte offset and the load takes the scalar base, instead of a 64-bit
+                                // multiply-add plus a 64-bit shift-add (each several issue cycles) per gather
+                                const uint32_t off = __umul24((uint32_t)ck, (uint32_t)F * 4u) + (uint32_t)foff[ch] * 4u;
+                                vec_load_g<VEC>(v[u][ch], reinterpret_cast<const float *>(
+                                                              reinterpret_cast<const char *>(x) + off));
+                            } else {
+                                vec_load_g<VEC>(v[u][ch], x + (int64_t)ck * F + foff[ch]);
+                            }
                         } else {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) v[u][ch][i] = 0.f;
                         }
                     }
                 }
+                // A slot past the end of a row holds nc = +0 and v = +0 (w = 1): its term is +0, and adding +0 to an
+                // accumulator that started at +0 changes nothing (such a sum is never -0), so the sums need no guard.
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (k + u < cnt) {
 #pragma unroll
-                        for (int ch = 0; ch < CHUNKS; ++ch) {
+                    for (int ch = 0; ch < CHUNKS; ++ch) {
+                        if constexpr (VEC == 1) {
+                            float t = ncs[u] * v[u][ch][0];          // Mul(norm_inb, h_inb)
+                            if constexpr (HAS_EW) t = t * ws[u];     // Mul(., edge_weight)
+                            acc[ch][0] = acc[ch][0] + t;             // AggSum
+                        } else {
+                            // the same three operations on float pairs (packed fp32 instructions)
 #pragma unroll
-                            for (int i = 0; i < VEC; ++i) {
-                                float t = ncs[u] * v[u][ch][i];          // Mul(norm_inb, h_inb)
-                                if constexpr (HAS_EW) t = t * ws[u];     // Mul(., edge_weight)
-                                acc[ch][i] = acc[ch][i] + t;             // AggSum
+                            for (int i = 0; i < VEC; i += 2) {
+                                gvec_t<2> t = {v[u][ch][i], v[u][ch][i + 1]};
+                                gvec_t<2> a = {acc[ch][i], acc[ch][i + 1]};
+                                t = t * ncs[u];
+                                if constexpr (HAS_EW) t = t * ws[u];
+                                a = a + t;
+                                acc[ch][i] = a.x;
+                                acc[ch][i + 1] = a.y;
                             }
                         }
                     }
@@ -326,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
                             for (int i = 0; i < VEC; ++i) o[i] = o[i] < 0.f ? 0.f : o[i];
                         }
                     }
-                    vec_store<VEC>(orow + foff[ch], o);
+                    vec_store_g<VEC>(orow + foff[ch], o);
                 }
             }
         }
@@ -360,6 +456,7 @@ struct GcnArgs {
 constexpr int kLongRowThreshold = 16;      // edges; rows above it go to gcn_agg_long_kernel (G < 64 only)
 constexpr int kGiantRowThreshold = 1024;
 constexpr int kNoLongRows = 0x7fffffff;
+constexpr int kXcdTile = 64;
 
 inline bool long_rows_enabled(const GcnArgs &a, int log2g) { return a.pre && a.rows_by_degree && log2g < 6; }
 
@@ -368,8 +465,33 @@ void launch(const GcnArgs &a)
 {
     constexpr int rows_per_block = (kWave >> LOG2G) * kWavesPerBlock;
     constexpr bool kCanLong = PRE && LOG2G < 6 && CHUNKS == 1;
-    const int64_t blocks = ((int64_t)a.N + rows_per_block - 1) / rows_per_block;
+    constexpr bool kCanA32 = PRE && LOG2G <= 3 && CHUNKS == 1;      // narrow rows: instruction-, not bandwidth-bound
+    int64_t blocks = ((int64_t)a.N + rows_per_block - 1) / rows_per_block;
+    // XCD runs (see the kernel): whole eighths of a grid that is resident at once, runs of 64 workgroups otherwise
+    int xcd_tile = tuning().gcn_xcd_tile;
+    if (xcd_tile == 0) xcd_tile = blocks <= 256 * 8 ? (int)((blocks + 7) / 8) : kXcdTile;
+    if (blocks < 16) xcd_tile = 1;
+    if (xcd_tile > 1) blocks = (blocks + 8 * xcd_tile - 1) / (8 * xcd_tile) * (8 * xcd_tile);
     const dim3 block(kBlock);
+    const bool a32 = kCanA32 && tuning().gcn_addr32 != 1 && a.N <= (1 << 24) && a.F < (1 << 22) &&
+                     (uint64_t)a.N * (uint64_t)a.F * 4u <= 0xffffffffull;
+
+    auto main_kernel = [&](auto long_tag, int64_t grid, const int *rows_by_degree, int long_blocks, int threshold) {
+        constexpr bool L = decltype(long_tag)::value;
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((unsigned)grid), block, 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out,
+                               a.row_offsets, a.column_indices, a.eids, a.node_ids, a.N, a.F, a.F_active, a.bias, a.act,
+                               rows_by_degree, long_blocks, threshold, xcd_tile);
+        };
+        if constexpr (kCanA32) {
+            if (a32) {
+                go(gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI, L, true>);
+                return;
+            }
+        }
+        go(gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI, L, false>);
+    };
+
     if constexpr (kCanLong) {
         if (long_rows_enabled(a, LOG2G)) {
             // Long-row workgroups: how many rows are long is not known on the host (no sync), so one wave per 16
@@ -381,28 +503,21 @@ void launch(const GcnArgs &a)
             if (blocks <= 256 * 8) {
                 // The whole grid is resident at once: the launch lasts as long as its longest row, so every row
                 // above 16 edges gets a wave of its own, in the SAME launch (long rows first, overlapping the rest).
-                hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI, true>),
-                                   dim3((unsigned)(blocks + long_blocks)), block, 0, a.stream, a.x, a.norm_row, a.norm_col,
-                                   a.ew, a.out, a.row_offsets, a.column_indices, a.eids, a.node_ids, a.N, a.F, a.F_active,
-                                   a.bias, a.act, a.rows_by_degree, long_blocks, forced > 0 ? forced : kLongRowThreshold);
+                main_kernel(std::true_type{}, blocks + long_blocks, a.rows_by_degree, long_blocks,
+                            forced > 0 ? forced : kLongRowThreshold);
                 return;
             }
             // Larger graphs: the main path's many waves hide row latency; only giant hubs (> 1024 edges) would
             // still trail the launch.  They get their own launch so the main kernel keeps its registers and LDS.
             const int threshold = forced > 0 ? forced : kGiantRowThreshold;
-            hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI, false>), dim3((unsigned)blocks),
-                               block, 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets,
-                               a.column_indices, a.eids, a.node_ids, a.N, a.F, a.F_active, a.bias, a.act,
-                               a.rows_by_degree, 0, threshold);
+            main_kernel(std::false_type{}, blocks, a.rows_by_degree, 0, threshold);
             hipLaunchKernelGGL((gcn_agg_long_kernel<VEC, LOG2G, HAS_EW, EPI>), dim3((unsigned)std::min(long_blocks, 512)),
                                block, 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets,
                                a.column_indices, a.rows_by_degree, a.N, a.F, a.F_active, a.bias, a.act, threshold);
             return;
         }
     }
-    hipLaunchKernelGGL((gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI, false>), dim3((unsigned)blocks), block, 0,
-                       a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets, a.column_indices, a.eids,
-                       a.node_ids, a.N, a.F, a.F_active, a.bias, a.act, nullptr, 0, kNoLongRows);
+    main_kernel(std::false_type{}, blocks, nullptr, 0, kNoLongRows);
 }
 
 template <int VEC, int LOG2G, int CHUNKS, int UNROLL>
@@ -461,10 +576,10 @@ int gcn_agg_dispatch(GcnArgs a, const char *what)
     if ((a.bias || a.act != STG_ACT_NONE) && (a.F_active != a.F || !a.pre))
         return fail(STG_ERR_UNSUPPORTED, "%s: the layer epilogue needs every column active and pre-gathered scalars", what);
 
-    const uintptr_t align = reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.out);
-    int vec = 1;
-    if (a.F % 4 == 0 && a.F_active % 4 == 0 && align % 16 == 0) vec = 4;
-    else if (a.F % 2 == 0 && a.F_active % 2 == 0 && align % 8 == 0) vec = 2;
+    // Lanes own VEC consecutive features; global dwordx2 / dwordx4 accesses only need dword alignment on gfx950 and
+    // a width that is not a multiple of VEC is covered by an overlapping last window, so any row of >= 4 floats is
+    // read 16 B per lane (F = 7: 2 lanes per row, 32 rows per gather instruction instead of 8).
+    int vec = a.F_active >= 4 ? 4 : a.F_active >= 2 ? 2 : 1;
 
     // performance knob: force the number of lanes per row (shrinks VEC if the row is too narrow)
     const int forced = tuning().gcn_lanes_per_row;

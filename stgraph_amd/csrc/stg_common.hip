@@ -60,5 +60,15 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().gcn_long_threshold = value;
         return 0;
     }
+    if (!std::strcmp(key, "gcn_addr32")) {
+        if (value != 0 && value != 1) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_addr32 must be 0 or 1");
+        tuning().gcn_addr32 = value;
+        return 0;
+    }
+    if (!std::strcmp(key, "gcn_xcd_tile")) {
+        if (value < 0 || value > 4096) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_xcd_tile must be in [0, 4096]");
+        tuning().gcn_xcd_tile = value;
+        return 0;
+    }
     return fail(STG_ERR_INVALID_ARGUMENT, "stg_set_tuning: unknown key '%s'", key);
 }

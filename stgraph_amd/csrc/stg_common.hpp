@@ -24,6 +24,8 @@ struct Tuning {
     int gcn_lanes_per_row = 0;     // 0 = auto
     int gcn_unroll = 0;            // 0 = auto
     int gcn_long_threshold = 0;    // 0 = default (16 edges); rows above it take the wave-per-row path
+    int gcn_addr32 = 0;            // 0 = auto (32-bit gather offsets when the matrix allows); 1 = always 64-bit
+    int gcn_xcd_tile = 0;          // 0 = auto; 1 = workgroups round-robin over XCDs; T = runs of T workgroups per XCD
 };
 Tuning &tuning();
 
@@ -53,12 +55,91 @@ __device__ __forceinline__ void vec_store(float *p, const float (&src)[VEC])
     }
 }
 
+// Global-memory variants that only assume the 4-byte alignment of a float: gfx950 takes dwordx2 / dwordx4 global
+// accesses at any dword address, which is what lets a row whose width is not a multiple of VEC be covered by
+// OVERLAPPING windows (the last lane's window starts at F - VEC) instead of falling back to one float per lane.
+typedef float stg_f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float stg_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int VEC>
+__device__ __forceinline__ void vec_load_g(float (&dst)[VEC], const float *p)
+{
+    if constexpr (VEC == 1) {
+        dst[0] = *p;
+    } else if constexpr (VEC == 2) {
+        const stg_f2u v = *reinterpret_cast<const stg_f2u *>(p);
+        dst[0] = v.x; dst[1] = v.y;
+    } else {
+        const stg_f4u v = *reinterpret_cast<const stg_f4u *>(p);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void vec_store_g(float *p, const float (&src)[VEC])
+{
+    if constexpr (VEC == 1) {
+        *p = src[0];
+    } else if constexpr (VEC == 2) {
+        stg_f2u v; v.x = src[0]; v.y = src[1];
+        *reinterpret_cast<stg_f2u *>(p) = v;
+    } else {
+        stg_f4u v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+        *reinterpret_cast<stg_f4u *>(p) = v;
+    }
+}
+
+// The same accesses with the lane's VEC floats kept as ONE vector value (float for VEC = 1): a conditional gather
+// then merges as a single 64/128-bit register tuple instead of VEC scalar values, and `vector * scalar`,
+// `vector + vector` become packed fp32 instructions.
+template <int VEC> struct GVec;
+template <> struct GVec<1> { typedef float type; };
+template <> struct GVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct GVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int VEC> using gvec_t = typename GVec<VEC>::type;
+
+template <int VEC>
+__device__ __forceinline__ gvec_t<VEC> gvec_load(const float *p)
+{
+    if constexpr (VEC == 1) return *p;
+    else if constexpr (VEC == 2) return *reinterpret_cast<const stg_f2u *>(p);
+    else return *reinterpret_cast<const stg_f4u *>(p);
+}
+
+template <int VEC>
+__device__ __forceinline__ gvec_t<VEC> gvec_zero()
+{
+    if constexpr (VEC == 1) return 0.f;
+    else return (gvec_t<VEC>)(0.f);
+}
+
+template <int VEC>
+__device__ __forceinline__ float gvec_get(const gvec_t<VEC> &v, int i)
+{
+    if constexpr (VEC == 1) return v;
+    else return v[i];
+}
+
 // max over the 64 lanes of a wave (all lanes must be active)
 __device__ __forceinline__ int wave_max(int v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
     return v;
+}
+
+// Same for non-negative values, on the DPP network (no LDS crossbar trips): running max along each row of 16
+// lanes (row_shr 1, 2, 4, 8), then row_bcast:15 / row_bcast:31 carry it across rows; lane 63 holds the result,
+// returned wave-uniform.  Lanes whose DPP source is out of range keep their own value (old = v).
+__device__ __forceinline__ int wave_max_nonneg(int v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Order LDS traffic inside ONE wave (lanes exchange data through an LDS tile that no other wave touches): LDS

@@ -54,7 +54,7 @@ def test_golden_all_widths(cuda, gname, use_ew, compat):
         np.testing.assert_allclose(out[:, :fa_ref], d[tag + "_out"][:, :fa_ref], rtol=TOL, atol=TOL)
 
 
-@pytest.mark.parametrize("F", [1, 2, 3, 8, 16, 33, 64, 96, 128, 200, 512, 1100])
+@pytest.mark.parametrize("F", [1, 2, 3, 5, 6, 8, 9, 13, 16, 33, 64, 65, 96, 128, 129, 200, 257, 512, 1100])
 @pytest.mark.parametrize("use_ew", [False, True])
 def test_oracle_random_graph(cuda, F, use_ew):
     from stgraph_amd import kernels

@@ -31,7 +31,7 @@ def skewed_graph(seed, n, e, hubs=6):
     return arr[:, 0].copy(), arr[:, 1].copy()
 
 
-@pytest.mark.parametrize("F", [1, 2, 3, 4, 7, 8, 16, 24, 32, 50, 64, 100, 128])
+@pytest.mark.parametrize("F", [1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 16, 24, 32, 50, 64, 100, 128])
 @pytest.mark.parametrize("use_ew", [False, True])
 def test_long_rows_bit_exact(cuda, F, use_ew):
     from stgraph_amd import kernels
