@@ -410,6 +410,28 @@ int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const float *H, co
                             float *CR, float *CH, float *Z, float *R, float *Ht, float *Hn, int64_t N, int32_t C,
                             float lo, float hi, void *stream);
 
+/* ----------------------------------------------- dense neighbour: the TGCN harness head
+ * The model head and loss of the static-temporal TGCN training step
+ * (benchmarking/static-temporal-tgcn/seastar/model.py:6-18: relu -> Linear(C, F) -> Linear(F, 1); train.py:
+ * `cost = cost + torch.mean((y_out - y[t]) ** 2)`) as one launch forward and one backward, see csrc/tgcn_head.hip.
+ * h [N,C]; W1 [F,C], b1 [F] (torch.nn.Linear layout); W2 [1,F], b2 [1]; target [N]; all [dev] fp32, 16-byte aligned.
+ *   fwd: r = relu(h) [N,C], y = r W1^T + b1 [N,F], y_out = y W2^T + b2 [N], loss[0] = mean((y_out - target)^2);
+ *        workspace: stg_tgcn_head_workspace_bytes(N) (per-tile partial sums, added in a fixed order).
+ *   bwd: g_loss [1] = d cost / d loss, g_y [N,F] = gradient reaching y from its other consumer (the next step's
+ *        input), g_yout [N] likewise for y_out; each may be NULL (= zero).  dyo = 2 (y_out - target) / N * g_loss
+ *        + g_yout [N]; dyt = g_y + dyo W2 [N,F]; dh = (h > 0) (dyt W1) [N,C].  The weight gradients are
+ *        dW1 = dyt^T r, db1 = colsum(dyt), dW2 = dyo^T y, db2 = sum(dyo) (stg_gemm_tn_*).
+ * Supported: C in {32, 64, 128}, F = 32, one output column (stg_tgcn_head_supported); anything else is the
+ * caller's torch composition. */
+int stg_tgcn_head_supported(int32_t C, int32_t F, int32_t O);
+size_t stg_tgcn_head_workspace_bytes(int64_t N);
+int stg_tgcn_head_fwd(const float *h, const float *W1, const float *b1, const float *W2, const float *b2,
+                      const float *target, float *r, float *y, float *y_out, float *loss, int64_t N, int32_t C,
+                      int32_t F, void *workspace, size_t workspace_bytes, void *stream);
+int stg_tgcn_head_bwd(const float *g_loss, const float *g_y, const float *g_yout, const float *h, const float *y_out,
+                      const float *target, const float *W1, const float *W2, float *dh, float *dyt, float *dyo,
+                      int64_t N, int32_t C, int32_t F, void *stream);
+
 /* ----------------------------------------------- dense neighbour: TGCN row-local glue
  * Fused elementwise stages of one TGCN step (nn/pytorch/temporal/tgcn.py:21-55); the three gate
  * GEMMs between them stay on rocBLAS.  C = hidden width (multiple of 4), all [dev] fp32 row-major,

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
         const int s = vb >> 3;
         vb = ((s / xcd_tile) * 8 + (vb & 7)) * xcd_tile + s % xcd_tile;
     }
-    const int wave_global = vb * kWavesPerBlock + (threadIdx.x >> 6);
+    const int wave_global = vb * ((int)blockDim.x >> 6) + (threadIdx.x >> 6);     // LONG: always kBlock threads
     const int idx = wave_global * ROWS_PER_WAVE + (lane >> LOG2G);
 
     int r = 0, beg = 0, deg = 0;
@@ -457,22 +457,31 @@ constexpr int kLongRowThreshold = 16;      // edges; rows above it go to gcn_agg
 constexpr int kGiantRowThreshold = 1024;
 constexpr int kNoLongRows = 0x7fffffff;
 constexpr int kXcdTile = 64;
+constexpr int kPlainBlock = 64;
 
 inline bool long_rows_enabled(const GcnArgs &a, int log2g) { return a.pre && a.rows_by_degree && log2g < 6; }
 
 template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false>
 void launch(const GcnArgs &a)
 {
-    constexpr int rows_per_block = (kWave >> LOG2G) * kWavesPerBlock;
     constexpr bool kCanLong = PRE && LOG2G < 6 && CHUNKS == 1;
     constexpr bool kCanA32 = PRE && LOG2G <= 3 && CHUNKS == 1;      // narrow rows: instruction-, not bandwidth-bound
+    // Workgroup size of the plain (non-merged) launch: a workgroup's wave slots are refilled only when ALL of its
+    // waves have left, and the waves of this kernel are short-lived with ragged lifetimes -- one-wave workgroups
+    // keep the SIMDs fuller (measured occupancy 5.5 -> see DESIGN.md) than 4-wave ones.
+    int threads = tuning().gcn_block > 0 ? tuning().gcn_block : kPlainBlock;
+    const int64_t blocks256 = ((int64_t)a.N + (kWave >> LOG2G) * kWavesPerBlock - 1) / ((kWave >> LOG2G) * kWavesPerBlock);
+    const bool merged = kCanLong && long_rows_enabled(a, LOG2G) && blocks256 <= 256 * 8;
+    if (merged) threads = kBlock;                                   // its LDS tiles are laid out for kBlock threads
+    const int rows_per_block = (kWave >> LOG2G) * (threads / kWave);
     int64_t blocks = ((int64_t)a.N + rows_per_block - 1) / rows_per_block;
-    // XCD runs (see the kernel): whole eighths of a grid that is resident at once, runs of 64 workgroups otherwise
+    // XCD runs (see the kernel): whole eighths of a grid that is resident at once, runs of 64 (x 256 threads)
+    // workgroups otherwise
     int xcd_tile = tuning().gcn_xcd_tile;
-    if (xcd_tile == 0) xcd_tile = blocks <= 256 * 8 ? (int)((blocks + 7) / 8) : kXcdTile;
+    if (xcd_tile == 0) xcd_tile = blocks256 <= 256 * 8 ? (int)((blocks + 7) / 8) : kXcdTile * (kBlock / threads);
     if (blocks < 16) xcd_tile = 1;
     if (xcd_tile > 1) blocks = (blocks + 8 * xcd_tile - 1) / (8 * xcd_tile) * (8 * xcd_tile);
-    const dim3 block(kBlock);
+    const dim3 block(threads);
     const bool a32 = kCanA32 && tuning().gcn_addr32 != 1 && a.N <= (1 << 24) && a.F < (1 << 22) &&
                      (uint64_t)a.N * (uint64_t)a.F * 4u <= 0xffffffffull;
 
@@ -500,7 +509,7 @@ void launch(const GcnArgs &a)
                 std::min<int64_t>({((int64_t)a.N + kWavesPerBlock - 1) / kWavesPerBlock,
                                    std::max<int64_t>((int64_t)a.N / 64, 16), (int64_t)4096}), 1);
             const int forced = tuning().gcn_long_threshold;
-            if (blocks <= 256 * 8) {
+            if (merged) {
                 // The whole grid is resident at once: the launch lasts as long as its longest row, so every row
                 // above 16 edges gets a wave of its own, in the SAME launch (long rows first, overlapping the rest).
                 main_kernel(std::true_type{}, blocks + long_blocks, a.rows_by_degree, long_blocks,
@@ -512,7 +521,7 @@ void launch(const GcnArgs &a)
             const int threshold = forced > 0 ? forced : kGiantRowThreshold;
             main_kernel(std::false_type{}, blocks, a.rows_by_degree, 0, threshold);
             hipLaunchKernelGGL((gcn_agg_long_kernel<VEC, LOG2G, HAS_EW, EPI>), dim3((unsigned)std::min(long_blocks, 512)),
-                               block, 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets,
+                               dim3(kBlock), 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets,
                                a.column_indices, a.rows_by_degree, a.N, a.F, a.F_active, a.bias, a.act, threshold);
             return;
         }

@@ -60,6 +60,12 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().gcn_long_threshold = value;
         return 0;
     }
+    if (!std::strcmp(key, "gcn_block")) {
+        if (value != 0 && value != 64 && value != 128 && value != 256)
+            return fail(STG_ERR_INVALID_ARGUMENT, "gcn_block must be 0, 64, 128 or 256");
+        tuning().gcn_block = value;
+        return 0;
+    }
     if (!std::strcmp(key, "gcn_addr32")) {
         if (value != 0 && value != 1) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_addr32 must be 0 or 1");
         tuning().gcn_addr32 = value;

@@ -1,0 +1,275 @@
+// The model head of the static-temporal TGCN training step as two launches (forward, backward).
+//
+// Reference: benchmarking/static-temporal-tgcn/seastar/model.py:6-18 (relu -> Linear(hidden, feat) ->
+// Linear(feat, 1)) and the training loop's per-timestep `torch.mean((y_out - y[t]) ** 2)` (train.py).  In torch that
+// is ~20 launches per step forward + backward (relu, two skinny GEMMs with bias, sub, pow, mean, add, and their
+// backward counterparts plus the gradient accumulations of the two tensors that fan out), each a few microseconds
+// on |V| = 50K -- together as long as the fused TGCN cell itself.
+//
+//   forward : r = relu(h) [N,C]; y = r W1^T + b1 [N,32]; y_out = y W2^T + b2 [N]; partial[tile] = sum (y_out - t)^2
+//             (a one-workgroup finish kernel adds the partials in a fixed order: loss = sum / N)
+//   backward: dyo = 2 (y_out - t) / N * gl (+ g_yout); dyt = g_y + dyo W2 [N,32]; dh = (h > 0) (dyt W1) [N,C]
+//             dyt and dyo leave the kernel too: the weight gradients dW1 = dyt^T r, db1 = colsum(dyt), dW2 = dyo^T y,
+//             db2 = sum(dyo) are tall-skinny contractions done once per backward pass (stg_gemm_tn_multi_f32).
+//
+// One wave per 32-row tile, both GEMMs on v_mfma_f32_32x32x2_f32.  As in tgcn_cell_fused.hip the A operands are
+// read from HBM directly in MFMA layout (lane = (row, k-half), 16-byte pieces, k permuted inside blocks of 8 --
+// the B operand is read with the same permutation, so the products pair up correctly); the y_out row sums run on
+// the DPP network.  The GEMM summation order differs from rocBLAS': results agree to fp32 rounding (tests: 1e-5).
+#include "stg_common.hpp"
+
+namespace stg {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kHeadF = 32;            // width of y: one 32-column MFMA block
+
+// row of accumulator element i for lane half kh (v_mfma_f32_32x32x2_f32 C/D layout)
+__device__ __forceinline__ int acc_row(int i, int kh) { return (i & 3) + 8 * (i >> 2) + 4 * kh; }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    // lanes without a source (or outside ROW_MASK) add 0
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// sum over each half (32 lanes) of the wave; valid in lanes 31 and 63
+__device__ __forceinline__ float half_sum(float v)
+{
+    v = dpp_add<0x111, 0xf>(v);       // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);       // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);       // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);       // row_shr:8   -> lane 15 of every row of 16 holds the row's sum
+    v = dpp_add<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void head_fwd_kernel(
+    const float *__restrict__ h, const float *__restrict__ W1, const float *__restrict__ b1,
+    const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ target,
+    float *__restrict__ r_out, float *__restrict__ y, float *__restrict__ y_out, float *__restrict__ partial,
+    int64_t N, int num_tiles)
+{
+    constexpr int KB = C / 8;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= num_tiles) return;                                   // whole wave
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int64_t row = (int64_t)tile * 32 + l31;
+    const bool rok = row < N;
+
+    f32x16 acc;
+    {
+        const float bias = b1[l31];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bias;
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int k0 = kb * 8 + kh * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rok) {
+            a = *reinterpret_cast<const float4 *>(h + row * C + k0);
+            a.x = a.x < 0.f ? 0.f : a.x;
+            a.y = a.y < 0.f ? 0.f : a.y;
+            a.z = a.z < 0.f ? 0.f : a.z;
+            a.w = a.w < 0.f ? 0.f : a.w;
+            *reinterpret_cast<float4 *>(r_out + row * C + k0) = a;
+        }
+        const float4 b = *reinterpret_cast<const float4 *>(W1 + l31 * C + k0);      // B[k][n] = W1[n][k]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+
+    const float w2 = W2[l31], bias2 = b2[0];
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t orow = (int64_t)tile * 32 + acc_row(i, kh);
+        const bool ok = orow < N;
+        if (ok) y[orow * kHeadF + l31] = acc[i];
+        const float s = half_sum(acc[i] * w2);                       // every lane takes part
+        if (l31 == 31 && ok) {
+            const float yo = s + bias2;
+            y_out[orow] = yo;
+            const float d = yo - target[orow];
+            lsum = lsum + d * d;
+        }
+    }
+    const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lsum), 31)) +
+                      __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lsum), 63));
+    if (lane == 0) partial[tile] = tot;
+}
+
+// loss = (sum of the tile partials, in a fixed order) / N
+__global__ __launch_bounds__(kBlock) void head_loss_kernel(const float *__restrict__ partial, int num_tiles,
+                                                           float inv_n, float *__restrict__ loss)
+{
+    __shared__ float s[kBlock];
+    float v = 0.f;
+    for (int t = threadIdx.x; t < num_tiles; t += kBlock) v = v + partial[t];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = s[0] * inv_n;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void head_bwd_kernel(
+    const float *__restrict__ g_loss, const float *__restrict__ g_y, const float *__restrict__ g_yout,
+    const float *__restrict__ h, const float *__restrict__ y_out, const float *__restrict__ target,
+    const float *__restrict__ W1, const float *__restrict__ W2, float *__restrict__ dh, float *__restrict__ dyt,
+    float *__restrict__ dyo, int64_t N, float two_over_n, int num_tiles)
+{
+    constexpr int KB = kHeadF / 8, CT = C / 32;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= num_tiles) return;                                   // whole wave
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int64_t row = (int64_t)tile * 32 + l31;
+    const bool rok = row < N;
+
+    float d = 0.f;
+    if (rok) {
+        if (g_loss) d = two_over_n * g_loss[0] * (y_out[row] - target[row]);
+        if (g_yout) d = d + g_yout[row];
+        if (kh == 0) dyo[row] = d;
+    }
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int k0 = kb * 8 + kh * 4;
+        const float4 w = *reinterpret_cast<const float4 *>(W2 + k0);
+        float4 a = make_float4(d * w.x, d * w.y, d * w.z, d * w.w);
+        if (rok) {
+            if (g_y) {
+                const float4 g = *reinterpret_cast<const float4 *>(g_y + row * kHeadF + k0);
+                a = make_float4(g.x + a.x, g.y + a.y, g.z + a.z, g.w + a.w);
+            }
+            *reinterpret_cast<float4 *>(dyt + row * kHeadF + k0) = a;
+        } else {
+            a = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float b = W1[(k0 + i) * C + ct * 32 + l31];   // B[k][n] = W1[k][n]
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b, acc[ct], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t orow = (int64_t)tile * 32 + acc_row(i, kh);
+            if (orow < N) {
+                const int64_t at = orow * C + ct * 32 + l31;
+                dh[at] = h[at] <= 0.f ? 0.f : acc[ct][i];           // threshold_backward
+            }
+        }
+    }
+}
+
+inline int head_tiles(int64_t N) { return (int)((N + 31) / 32); }
+
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_tgcn_head_supported(int32_t C, int32_t F, int32_t O)
+{
+    return (C == 32 || C == 64 || C == 128) && F == stg::kHeadF && O == 1;
+}
+
+extern "C" size_t stg_tgcn_head_workspace_bytes(int64_t N)
+{
+    return N <= 0 ? 0 : sizeof(float) * (size_t)stg::head_tiles(N);
+}
+
+extern "C" int stg_tgcn_head_fwd(const float *h, const float *W1, const float *b1, const float *W2, const float *b2,
+                                 const float *target, float *r, float *y, float *y_out, float *loss, int64_t N,
+                                 int32_t C, int32_t F, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    if (!stg_tgcn_head_supported(C, F, 1))
+        return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_head_fwd: C=%d F=%d not supported", C, F);
+    if (N < 0 || N > (int64_t)32 * 0x3fffffff) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_head_fwd: bad N");
+    if (!loss) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_head_fwd: NULL pointer argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (N == 0) {
+        hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(kBlock), 0, stream, nullptr, 0, __builtin_nanf(""), loss);   // mean of nothing
+        return check_launch("stg_tgcn_head_fwd");
+    }
+    if (!h || !W1 || !b1 || !W2 || !b2 || !target || !r || !y || !y_out || !workspace)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_head_fwd: NULL pointer argument");
+    if (workspace_bytes < stg_tgcn_head_workspace_bytes(N))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_head_fwd: workspace too small");
+    const int tiles = head_tiles(N);
+    const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    float *partial = static_cast<float *>(workspace);
+    switch (C) {
+        case 32:
+            hipLaunchKernelGGL(head_fwd_kernel<32>, dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, W2, b2, target, r, y,
+                               y_out, partial, N, tiles);
+            break;
+        case 64:
+            hipLaunchKernelGGL(head_fwd_kernel<64>, dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, W2, b2, target, r, y,
+                               y_out, partial, N, tiles);
+            break;
+        default:
+            hipLaunchKernelGGL(head_fwd_kernel<128>, dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, W2, b2, target, r,
+                               y, y_out, partial, N, tiles);
+            break;
+    }
+    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(kBlock), 0, stream, partial, tiles, 1.0f / (float)N, loss);
+    return check_launch("stg_tgcn_head_fwd");
+}
+
+extern "C" int stg_tgcn_head_bwd(const float *g_loss, const float *g_y, const float *g_yout, const float *h,
+                                 const float *y_out, const float *target, const float *W1, const float *W2, float *dh,
+                                 float *dyt, float *dyo, int64_t N, int32_t C, int32_t F, void *stream_)
+{
+    using namespace stg;
+    if (!stg_tgcn_head_supported(C, F, 1))
+        return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_head_bwd: C=%d F=%d not supported", C, F);
+    if (N < 0 || N > (int64_t)32 * 0x3fffffff) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_head_bwd: bad N");
+    if (N == 0) return 0;
+    if (!h || !y_out || !target || !W1 || !W2 || !dh || !dyt || !dyo)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_head_bwd: NULL pointer argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tiles = head_tiles(N);
+    const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const float two_over_n = 2.0f / (float)N;
+    switch (C) {
+        case 32:
+            hipLaunchKernelGGL(head_bwd_kernel<32>, dim3(blocks), dim3(kBlock), 0, stream, g_loss, g_y, g_yout, h, y_out,
+                               target, W1, W2, dh, dyt, dyo, N, two_over_n, tiles);
+            break;
+        case 64:
+            hipLaunchKernelGGL(head_bwd_kernel<64>, dim3(blocks), dim3(kBlock), 0, stream, g_loss, g_y, g_yout, h, y_out,
+                               target, W1, W2, dh, dyt, dyo, N, two_over_n, tiles);
+            break;
+        default:
+            hipLaunchKernelGGL(head_bwd_kernel<128>, dim3(blocks), dim3(kBlock), 0, stream, g_loss, g_y, g_yout, h, y_out,
+                               target, W1, W2, dh, dyt, dyo, N, two_over_n, tiles);
+            break;
+    }
+    return check_launch("stg_tgcn_head_bwd");
+}

@@ -955,6 +955,42 @@ def gemm_tn_multi(As, Bs, colsum: bool = False):
     return (c_tot, cs_tot) if colsum else c_tot
 
 
+def tgcn_head_supported(C: int, F: int, O: int) -> bool:
+    return bool(_C.lib.stg_tgcn_head_supported(int(C), int(F), int(O)))
+
+
+def tgcn_head_fwd(h, W1, b1, W2, b2, target):
+    """relu -> Linear -> Linear -> mean squared error of one TGCN step in one launch (stg_tgcn_head_fwd).
+    Returns (r, y, y_out [N,1], loss [1])."""
+    N, C = h.shape
+    F_ = W1.shape[0]
+    dev = h.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    r, y, y_out, loss = new(N, C), new(N, F_), new(N, 1), new(1)
+    ws_bytes = int(_C.lib.stg_tgcn_head_workspace_bytes(N))
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+    nbytes = 4 * N * (2 * C + F_ + 2)
+    with torch.cuda.device(dev), _Timed("tgcn_head_fwd", nbytes, 2 * N * F_ * (C + 1)):
+        _C.check(_C.lib.stg_tgcn_head_fwd(_ptr(h), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(target), _ptr(r), _ptr(y),
+                                          _ptr(y_out), _ptr(loss), N, C, F_, _ptr(ws), ws_bytes, _stream_ptr(dev)))
+    return r, y, y_out, loss
+
+
+def tgcn_head_bwd(g_loss, g_y, g_yout, h, y_out, target, W1, W2):
+    """Backward of tgcn_head_fwd up to the weight gradients (stg_tgcn_head_bwd).  Returns (dh, dyt, dyo [N,1])."""
+    N, C = h.shape
+    F_ = W1.shape[0]
+    dev = h.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    dh, dyt, dyo = new(N, C), new(N, F_), new(N, 1)
+    nbytes = 4 * N * (2 * C + 2 * F_ + 3)
+    with torch.cuda.device(dev), _Timed("tgcn_head_bwd", nbytes, 2 * N * F_ * (C + 1)):
+        _C.check(_C.lib.stg_tgcn_head_bwd(_ptr(g_loss), _ptr(g_y), _ptr(g_yout), _ptr(h), _ptr(y_out), _ptr(target),
+                                          _ptr(W1), _ptr(W2), _ptr(dh), _ptr(dyt), _ptr(dyo), N, C, F_,
+                                          _stream_ptr(dev)))
+    return dh, dyt, dyo
+
+
 def tgcn_cell_fused_supported(C: int) -> bool:
     return bool(_C.lib.stg_tgcn_cell_fused_supported(int(C)))
 

@@ -101,6 +101,60 @@ class _Linear(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _TgcnHead(torch.autograd.Function):
+    """(y, y_out, loss) = head(h): ``y = relu(h) W1^T + b1``, ``y_out = y W2^T + b2``, ``loss = mean((y_out - t)^2)``
+    -- the model head and per-timestep loss of the static-temporal TGCN harness
+    (benchmarking/static-temporal-tgcn/seastar/model.py:6-18 and its train loop) as one launch forward, one backward.
+    Weight and bias gradients go through ``nn.deferred`` like every other Linear of the step."""
+
+    @staticmethod
+    def forward(ctx, h, W1, b1, W2, b2, target):
+        h = h.contiguous()
+        target = target.contiguous()
+        r, y, y_out, loss = kernels.tgcn_head_fwd(h, W1, b1, W2, b2, target)
+        ctx.save_for_backward(h, r, y, y_out, target, W1, W2)
+        ctx.params = (W1, b1, W2, b2)
+        ctx.set_materialize_grads(False)
+        return y, y_out, loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_y, g_yout, g_loss):
+        h, r, y, y_out, target, W1, W2 = ctx.saved_tensors
+        W1p, b1p, W2p, b2p = ctx.params
+        cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        dh, dyt, dyo = kernels.tgcn_head_bwd(cont(g_loss), cont(g_y), cont(g_yout), h, y_out, target, W1, W2)
+        grads = [None, None, None, None]
+        if deferred_weight_grads() and all(p.is_leaf for p in ctx.params):
+            acc = deferred.current()
+            acc.add(("head1", id(W1p)), dyt, r, sink=lambda d, W=W1p: deferred.add_to_grad(W, d),
+                    colsum_sink=lambda d, b=b1p: deferred.add_to_grad(b, d))
+            acc.add(("head2", id(W2p)), dyo, y, sink=lambda d, W=W2p: deferred.add_to_grad(W, d),
+                    colsum_sink=lambda d, b=b2p: deferred.add_to_grad(b, d))
+        else:
+            gW1, gb1 = kernels.gemm_tn(dyt, r, colsum=True)
+            gW2, gb2 = kernels.gemm_tn(dyo, y, colsum=True)
+            grads = [gW1, gb1, gW2, gb2]
+        return (dh, *grads, None)
+
+
+def tgcn_head_usable(h: torch.Tensor, W1: torch.Tensor, b1, W2: torch.Tensor, b2, target: torch.Tensor) -> bool:
+    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and b1 is not None and b2 is not None
+            and W1.dim() == 2 and W2.dim() == 2 and W1.shape[1] == h.shape[1] and W2.shape[1] == W1.shape[0]
+            and target.dtype == torch.float32 and target.numel() == h.shape[0] * W2.shape[0]
+            and all(t.is_contiguous() for t in (W1, b1, W2, b2))
+            and kernels.tgcn_head_supported(h.shape[1], W1.shape[0], W2.shape[0]))
+
+
+def tgcn_head(h, W1, b1, W2, b2, target):
+    """Returns ``(y, y_out, loss)`` as ``relu -> F.linear -> F.linear -> torch.mean((y_out - target) ** 2)`` would
+    (fp32 rounding apart); the fused launch when ``tgcn_head_usable``, that composition otherwise."""
+    if tgcn_head_usable(h, W1, b1, W2, b2, target):
+        return _TgcnHead.apply(h, W1, b1, W2, b2, target)
+    y = linear(F.relu(h), W1, b1)
+    y_out = linear(y, W2, b2)
+    return y, y_out, torch.mean((y_out - target) ** 2)
+
+
 def mm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     if x.dim() == 2 and _use_native(x, x.shape[0], x.shape[1], w.shape[1]):
         return _MM.apply(x, w)

@@ -127,8 +127,7 @@ class TGCNStepFn(torch.autograd.Function):
     def forward(ctx, x, H, norm, ew, fwd_csr, bwd_csr, use_nid,
                 Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh):
         x, H = x.contiguous(), H.contiguous()
-        Wcat = torch.cat([Wcz, Wcr, Wch], dim=1)
-        b3 = torch.cat([bcz, bcr, bch], dim=0)
+        Wcat, b3 = _concatenated((Wcz, Wcr, Wch), (bcz, bcr, bch))
         a3, P = kernels.gcn_agg_transform(x, Wcat, norm, norm, fwd_csr, ew=ew, use_node_ids=use_nid)
         Hn, extra = _cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh)
         ctx.save_for_backward(a3, b3, H, Wz, Wr, Wh, *extra, P, Wcat, norm,
@@ -169,6 +168,34 @@ class TGCNStepFn(torch.autograd.Function):
             dWt, db = kernels.gemm_tn(da3, P, colsum=True)
             gw = [dWt[i * C:(i + 1) * C].t() for i in range(3)] + [db[i * C:(i + 1) * C] for i in range(3)]
         return (dx, dH, None, None, None, None, None, *gw, *g)
+
+
+_CAT_CACHE = {}
+_CAPTURE = [False, 0]          # was the previous call made under stream capture; number of captures seen
+
+
+def _concatenated(ws, bs):
+    """``cat(ws, dim=1)``, ``cat(bs)`` of the three GCN gates, kept until one of them changes: a BPTT window applies
+    the same parameters at every step, so the two concatenations run once per optimizer step (or once per captured
+    graph replay -- the cache is filled inside the capture, by the first step of the window) instead of per step.
+    Keyed on storage address and in-place version counter of every part, and on the stream capture the call is made
+    under: a captured graph must contain its own concatenation (replays see new parameter values), so nothing
+    computed outside a capture -- or in an earlier one -- is reused inside it."""
+    capturing = ws[0].is_cuda and torch.cuda.is_current_stream_capturing()
+    if capturing and not _CAPTURE[0]:
+        _CAPTURE[1] += 1
+    _CAPTURE[0] = capturing
+    key = tuple(id(t) for t in (*ws, *bs))
+    stamp = (_CAPTURE[1] if capturing else 0,) + tuple((t.data_ptr(), t._version) for t in (*ws, *bs))
+    hit = _CAT_CACHE.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1], hit[2]
+    if len(_CAT_CACHE) > 64:
+        _CAT_CACHE.clear()
+    with torch.no_grad():
+        wcat, b3 = torch.cat(list(ws), dim=1), torch.cat(list(bs), dim=0)
+    _CAT_CACHE[key] = (stamp, wcat, b3)
+    return wcat, b3
 
 
 def usable(a3: torch.Tensor, H: torch.Tensor) -> bool:

@@ -26,6 +26,17 @@ from .nn import functional as SF
 from .nn.pytorch.temporal.tgcn import TGCN
 
 
+_FUSED_HEAD = True
+
+
+def set_fused_head(enabled: bool) -> None:
+    """True (default): the training loops below run the model head and the per-step loss as one fused launch
+    (nn.functional.tgcn_head); False: ``model(...)`` followed by ``torch.mean((y_out - target) ** 2)``, as the
+    reference's script spells it."""
+    global _FUSED_HEAD
+    _FUSED_HEAD = bool(enabled)
+
+
 class STGraphTGCN(torch.nn.Module):
     """benchmarking/static-temporal-tgcn/seastar/model.py:6-18."""
 
@@ -41,6 +52,17 @@ class STGraphTGCN(torch.nn.Module):
         y = SF.linear(y, self.linear.weight, self.linear.bias)
         y_out = SF.linear(y, self.linear2.weight, self.linear2.bias)
         return y_out, y, h
+
+    def step_loss(self, g, node_feat, edge_weight, hidden_state, target):
+        """``forward`` plus the training loop's ``torch.mean((y_out - target) ** 2)``: returns (loss, y, h).  With
+        the fused head on (``set_fused_head``, default) relu, both Linears and the loss are one launch."""
+        if _FUSED_HEAD:
+            h = self.temporal(g, node_feat, edge_weight, hidden_state)
+            y, _, loss = SF.tgcn_head(h, self.linear.weight, self.linear.bias, self.linear2.weight,
+                                      self.linear2.bias, target)
+            return loss, y, h
+        y_out, y, h = self(g, node_feat, edge_weight, hidden_state)
+        return torch.mean((y_out - target) ** 2), y, h
 
 
 class GradBucket:
@@ -152,8 +174,8 @@ def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, 
                 t = w * backprop_every + k
                 if t >= total:
                     break
-                y_out, y_hat, hidden = model(graph, y_hat, edge_weight, hidden)
-                cost = cost + torch.mean((y_out - targets[t]) ** 2)
+                loss_t, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, targets[t])
+                cost = cost + loss_t
             cost = cost / (backprop_every + 1)
             cost.backward()
             losses.append(cost.detach())
@@ -252,8 +274,8 @@ class CapturedStaticWindow:
             hidden = None
             y_hat = self.static_y0
             for k in range(self.B):
-                y_out, y_hat, hidden = model(graph, y_hat, edge_weight, hidden)
-                cost = cost + torch.mean((y_out - self.static_targets[k]) ** 2)
+                loss_k, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, self.static_targets[k])
+                cost = cost + loss_k
             cost = cost / (self.B + 1)
             cost.backward()
             return cost.detach()
@@ -301,8 +323,8 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
             hidden = None
             y_hat = window_input(n, feat_size, epoch, w, targets.device, seed)
             for t in range(w * B, min((w + 1) * B, total)):
-                y_out, y_hat, hidden = model(graph, y_hat, edge_weight, hidden)
-                cost = cost + torch.mean((y_out - targets[t]) ** 2)
+                loss_t, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, targets[t])
+                cost = cost + loss_t
             cost = cost / (B + 1)
             cost.backward()
             losses.append(cost.detach())
