@@ -25,9 +25,12 @@ namespace stg {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kXwRows = 64;
+constexpr bool kXwWide = false;      // measured (TGCN cfg4, Fin = 32): 8-wave workgroups 39 us vs 35 us with 4
 
-template <int LOG2G, bool HAS_EW>
-__global__ __launch_bounds__(kBlock) void gcn_agg_xw_kernel(
+// WAVES per workgroup: 4, or 8 when a row takes 8+ lanes (then 4 waves would need several passes over the 64-row
+// tile, one after the other; 8 waves halve that chain and put twice the gathers in flight per tile).
+template <int LOG2G, bool HAS_EW, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void gcn_agg_xw_kernel(
     const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
     const float *__restrict__ ew_edge, const float *__restrict__ W, float *__restrict__ out,
     float *__restrict__ P_out, const int *__restrict__ row_offsets,
@@ -36,8 +39,10 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_xw_kernel(
     constexpr int G = 1 << LOG2G;
     constexpr int VEC = 4;
     constexpr int ROWS_PER_WAVE = kWave / G;
-    constexpr int ROWS_PER_PASS = ROWS_PER_WAVE * kWavesPerBlock;
-    constexpr int U = G < 8 ? G : 8;
+    constexpr int ROWS_PER_PASS = ROWS_PER_WAVE * WAVES;
+    constexpr int PASSES = kXwRows / ROWS_PER_PASS > 0 ? kXwRows / ROWS_PER_PASS : 1;
+    constexpr int NT = WAVES * kWave;
+    constexpr int R = G < 16 ? 16 : G, I = R / G, U = 8;
     extern __shared__ float lds[];
     const int ldp = Fin + 1;
     float *Ps = lds;                                  // [kXwRows][Fin + 1]
@@ -49,16 +54,16 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_xw_kernel(
     const int row_base = blockIdx.x * kXwRows;
 
     // stage W (read once per workgroup, L2 resident)
-    for (int i = threadIdx.x * 4; i < Fin * Fout; i += kBlock * 4)
+    for (int i = threadIdx.x * 4; i < Fin * Fout; i += NT * 4)
         *reinterpret_cast<float4 *>(Ws + i) = *reinterpret_cast<const float4 *>(W + i);
 
     // ---- phase 1: aggregate into the LDS tile
     const int foff = j * VEC;
     const bool fok = foff < Fin;
-    for (int pass = 0; pass < kXwRows / ROWS_PER_PASS; ++pass) {
+    for (int pass = 0; pass < PASSES; ++pass) {
         const int lr = pass * ROWS_PER_PASS + wave * ROWS_PER_WAVE + (lane >> LOG2G);   // row inside the tile
         const int idx = row_base + lr;
-        const bool row_valid = idx < N;
+        const bool row_valid = idx < N && lr < kXwRows;
         int r = 0, beg = 0, deg = 0;
         float nr = 0.f;
         if (row_valid) {
@@ -67,49 +72,60 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_xw_kernel(
             deg = row_offsets[r + 1] - beg;
             nr = norm_row[r];
         }
-        const int max_deg = __builtin_amdgcn_readfirstlane(wave_max(deg));
+        const int max_deg = wave_max_nonneg(deg);
         float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
-        for (int base = 0; base < max_deg; base += G) {
+        // One round = R edges per row (lane j holds edges j, j + G, ...): at least 16, so that rows of typical
+        // degree take ONE index round trip; the gathers go U at a time, later batches under a wave-uniform guard.
+        for (int base = 0; base < max_deg; base += R) {
             const int cnt = deg - base;
-            const int cnt_max = min(G, max_deg - base);
-            int c = 0;
-            float nc = 0.f, w = 1.f;
-            if (j < cnt) {
-                const int e = beg + base + j;
-                c = column_indices[e];
-                nc = nc_edge[e];
-                if constexpr (HAS_EW) w = ew_edge[e];
-            }
-            for (int k = 0; k < cnt_max; k += U) {
-                float v[U][VEC];
-                float ncs[U], ws[U];
+            const int cnt_max = min(R, max_deg - base);
+            int c[I];
+            float nc[I], w[I];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int kk = k + u;
-                    const int ck = __shfl(c, kk & (G - 1), G);
-                    ncs[u] = __shfl(nc, kk & (G - 1), G);
-                    if constexpr (HAS_EW) ws[u] = __shfl(w, kk & (G - 1), G);
-                    if (kk < cnt && fok) {
-                        vec_load<VEC>(v[u], x + (int64_t)ck * Fin + foff);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
-                    }
+            for (int i = 0; i < I; ++i) {
+                c[i] = 0;
+                nc[i] = 0.f;
+                w[i] = 1.f;
+                if (i * G + j < cnt) {
+                    const int e = beg + base + i * G + j;
+                    c[i] = column_indices[e];
+                    nc[i] = nc_edge[e];
+                    if constexpr (HAS_EW) w[i] = ew_edge[e];
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (k + u < cnt) {
+            for (int k = 0; k < R; k += U) {
+                if (k < cnt_max) {
+                    float v[U][VEC];
+                    float ncs[U], ws[U];
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            float t = ncs[u] * v[u][i];
-                            if constexpr (HAS_EW) t = t * ws[u];
-                            acc[i] = acc[i] + t;
+                    for (int u = 0; u < U; ++u) {
+                        const int kk = k + u, el = kk >> LOG2G, src = kk & (G - 1);
+                        const int ck = __shfl(c[el], src, G);
+                        ncs[u] = __shfl(nc[el], src, G);
+                        if constexpr (HAS_EW) ws[u] = __shfl(w[el], src, G);
+                        if (kk < cnt && fok) {
+                            vec_load<VEC>(v[u], x + (int64_t)ck * Fin + foff);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (k + u < cnt) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                float t = ncs[u] * v[u][i];
+                                if constexpr (HAS_EW) t = t * ws[u];
+                                acc[i] = acc[i] + t;
+                            }
                         }
                     }
                 }
             }
         }
-        if (fok) {
+        if (fok && lr < kXwRows) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) Ps[lr * ldp + foff + i] = acc[i] * nr;       // rows >= N hold zeros
             if (P_out && row_valid) {
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_xw_kernel(
     const int kh = lane >> 5, l31 = lane & 31;
     const int col_tiles = Fout / 32;
     const int tiles = (kXwRows / 32) * col_tiles;
-    for (int t = wave; t < tiles; t += kWavesPerBlock) {
+    for (int t = wave; t < tiles; t += WAVES) {
         const int rt = t / col_tiles, ct = t - rt * col_tiles;
         f32x16 acc;
 #pragma unroll
@@ -175,15 +191,21 @@ extern "C" int stg_gcn_agg_transform(const float *x, const float *norm_row, cons
     const int log2g = ilog2_ceil(lanes);
     const unsigned blocks = (unsigned)(((int64_t)N + kXwRows - 1) / kXwRows);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define STG_XW(LG)                                                                                             \
-    if (ew_edge)                                                                                               \
-        hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, true>), dim3(blocks), dim3(kBlock), lds, st, x, norm_row,    \
-                           norm_col_edge, ew_edge, W, out, P_out, row_offsets, column_indices, node_ids, N, Fin, \
-                           Fout);                                                                              \
-    else                                                                                                       \
-        hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, false>), dim3(blocks), dim3(kBlock), lds, st, x, norm_row,   \
-                           norm_col_edge, ew_edge, W, out, P_out, row_offsets, column_indices, node_ids, N, Fin, \
-                           Fout)
+#define STG_XW_(LG, WVS)                                                                                           \
+    {                                                                                                          \
+        constexpr int WV = WVS;                                                                                \
+        if (ew_edge)                                                                                           \
+            hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, true, WV>), dim3(blocks), dim3(WV * kWave), lds, st, x,  \
+                               norm_row, norm_col_edge, ew_edge, W, out, P_out, row_offsets, column_indices,   \
+                               node_ids, N, Fin, Fout);                                                        \
+        else                                                                                                   \
+            hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, false, WV>), dim3(blocks), dim3(WV * kWave), lds, st, x, \
+                               norm_row, norm_col_edge, ew_edge, W, out, P_out, row_offsets, column_indices,   \
+                               node_ids, N, Fin, Fout);                                                        \
+    }
+    // 8 waves per workgroup where 4 would need several passes over the tile (rows of 8+ lanes); "xw_waves" forces
+#define STG_XW(LG)                                                   \
+    if (tuning().xw_waves == 8 || (tuning().xw_waves == 0 && kXwWide && LG >= 3)) STG_XW_(LG, 8) else STG_XW_(LG, 4)
     switch (log2g) {
         case 0: STG_XW(0); break;
         case 1: STG_XW(1); break;
@@ -194,5 +216,6 @@ extern "C" int stg_gcn_agg_transform(const float *x, const float *norm_row, cons
         default: STG_XW(6); break;
     }
 #undef STG_XW
+#undef STG_XW_
     return check_launch("stg_gcn_agg_transform");
 }

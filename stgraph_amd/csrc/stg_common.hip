@@ -60,6 +60,11 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().gcn_long_threshold = value;
         return 0;
     }
+    if (!std::strcmp(key, "xw_waves")) {
+        if (value != 0 && value != 4 && value != 8) return fail(STG_ERR_INVALID_ARGUMENT, "xw_waves must be 0, 4 or 8");
+        tuning().xw_waves = value;
+        return 0;
+    }
     if (!std::strcmp(key, "gcn_block")) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
             return fail(STG_ERR_INVALID_ARGUMENT, "gcn_block must be 0, 64, 128 or 256");
