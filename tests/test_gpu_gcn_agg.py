@@ -111,6 +111,60 @@ def test_tuning_knobs_do_not_change_results(cuda):
         _C.set_tuning("gcn_unroll", 0)
 
 
+@pytest.mark.parametrize("F", [7, 16, 32, 100])
+def test_launch_mapping_knobs_do_not_change_results(cuda, F):
+    """Workgroup size, XCD runs and 32-bit gather offsets only move work around: bit-identical output, on a graph
+    large enough (> 2048 workgroups) to take the plain launch and on a small one (merged long-row launch), with and
+    without the degree-sorted row order, and against the oracle."""
+    from stgraph_amd import _C, kernels
+    rng = np.random.default_rng(F)
+    for n, e in ((300_000, 1_200_000), (3000, 20000)):
+        src, dst = random_graph(F, n, e)
+        g = _dev_graph(src, dst, n, cuda)
+        x_np = rng.standard_normal((n, F)).astype(np.float32)
+        norm_np = rng.uniform(0.1, 1, (n, 1)).astype(np.float32)
+        x, norm = torch.from_numpy(x_np).to(cuda), torch.from_numpy(norm_np).to(cuda)
+        base = kernels.gcn_agg(x, norm, norm, g.fwd)
+        if n <= 3000:
+            og = orc.build_graph(src, dst, n)
+            assert np.array_equal(base.cpu().numpy(), orc.gcn_agg(x_np, norm_np, norm_np, og.fwd))
+        try:
+            for block in (64, 128, 256):
+                for tile in (1, 3, 64):
+                    for a32 in (0, 1):
+                        _C.set_tuning("gcn_block", block)
+                        _C.set_tuning("gcn_xcd_tile", tile)
+                        _C.set_tuning("gcn_addr32", a32)
+                        for nid in (False, True):
+                            got = kernels.gcn_agg(x, norm, norm, g.fwd, use_node_ids=nid)
+                            assert torch.equal(got, base), (n, block, tile, a32, nid)
+        finally:
+            _C.set_tuning("gcn_block", 0)
+            _C.set_tuning("gcn_xcd_tile", 0)
+            _C.set_tuning("gcn_addr32", 0)
+
+
+def test_unaligned_operands(cuda):
+    """x / out at a 4-byte (not 16-byte) aligned address, as a slice of a larger buffer can be."""
+    from stgraph_amd import kernels
+    n, e = 2000, 16000
+    src, dst = random_graph(3, n, e)
+    g = _dev_graph(src, dst, n, cuda)
+    og = orc.build_graph(src, dst, n)
+    rng = np.random.default_rng(3)
+    norm_np = rng.uniform(0.1, 1, (n, 1)).astype(np.float32)
+    norm = torch.from_numpy(norm_np).to(cuda)
+    for F in (4, 7, 16, 33):
+        x_np = rng.standard_normal((n, F)).astype(np.float32)
+        buf = torch.zeros(n * F + 3, device=cuda)
+        for shift in (1, 2, 3):
+            x = buf[shift:shift + n * F].view(n, F)
+            x.copy_(torch.from_numpy(x_np))
+            assert x.data_ptr() % 16 != 0
+            got = kernels.gcn_agg(x, norm, norm, g.fwd)
+            assert np.array_equal(got.cpu().numpy(), orc.gcn_agg(x_np, norm_np, norm_np, og.fwd)), (F, shift)
+
+
 def test_full_size_properties(cuda):
     """BASELINE config 2 shape (|V|=1M, |E|=16M, F=128): size-independent properties."""
     from stgraph_amd import kernels

@@ -17,7 +17,7 @@ import sys
 
 
 def stats(src, dst, top=25):
-    f = glob.glob(src + "/**/*_kernel_stats.csv", recursive=True)[0]
+    f = glob.glob(src + "/**/*kernel_stats.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     with open(dst, "w", newline="") as out:
         w = csv.writer(out)
