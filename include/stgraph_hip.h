@@ -40,7 +40,8 @@ const char *stg_last_error_string(void);
  * of two <= 64), "gcn_unroll" (0 = auto, 2/4/8), "gcn_long_threshold" (0 = auto; rows with more
  * edges take the wave-per-row path of stg_gcn_agg_edge), "gcn_xcd_tile" (0 = auto; T >= 1: each XCD takes runs
  * of T consecutive workgroups' rows, 1 = plain round robin), "gcn_addr32" (0 = auto, 1 = never use 32-bit gather
- * offsets). */
+ * offsets), "gcn_block" (0 = auto; 64 / 128 / 256 threads per workgroup of the plain stg_gcn_agg* launch),
+ * "xw_waves" (0 = auto; 4 / 8 waves per workgroup of stg_gcn_agg_transform). */
 int stg_set_tuning(const char *key, int value);
 
 /* ---------------------------------------------------------------- CSR, host

@@ -2,6 +2,8 @@
 # usage: tools/pmc_passes.sh <tag> <kernel-name-substring> <python script + args...>
 # Separate rocprofv3 --pmc passes (counters only: no trace domains), one CSV per pass, reduced to per-dispatch
 # sums for the kernels whose name contains the substring -> gpurun_out/pmc_<tag>.json
+# (a TA_* counter pass aborted rocprofv3 with signal 6 on this pool and the call then sat until it was killed:
+# TA / TCP counters are not in the list)
 tag=$1; shift
 match=$1; shift
 cd /tmp && export TMPDIR=/tmp
@@ -11,14 +13,13 @@ passes=(
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD"
  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE"
  "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_INSTS_VMEM_WR SQ_CYCLES"
- "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum"
- "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_32B_sum"
 )
 i=0
 for p in "${passes[@]}"; do
   out=/tmp/pmc_${tag}_$i
   rm -rf "$out"
+  echo "pass $i: $p"
   rocprofv3 --pmc $p --output-format csv -d "$out" -- python3 "$@" > gpurun_out/pmc_${tag}_$i.stdout 2> gpurun_out/pmc_${tag}_$i.stderr || { echo "pass $i failed"; tail -5 gpurun_out/pmc_${tag}_$i.stderr; }
   find "$out" -name "*counter_collection.csv" -exec cp {} gpurun_out/pmc_${tag}_$i.csv \;
   i=$((i+1))
