@@ -429,6 +429,145 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
     }
 }
 
+// ---- narrow rows, edge-dealt: a workgroup's rows through an LDS tile ------------------------------------------
+// The row-group kernel above runs a wave to the LONGEST of its 8-64 rows, slot by slot: on a low-degree graph about
+// half of the 8 slots of a round are empty and one longer row sends the wave into a second (index, gather) round
+// trip (Cora-shaped, 16 rows per wave: 69 % of the waves; measured there: 38 % VALU utilisation, 65 % of a wave's
+// life spent waiting).  Here a workgroup owns 256 / G consecutive rows = ONE CONTIGUOUS EDGE RANGE, and deals the
+// EDGES, not the rows, to its 256 / G lane groups:
+//   A  row offsets of the workgroup's rows -> LDS
+//   B  lane group g takes edges g, g + groups, ... of a chunk of CAP = 4 x groups edges (a 16 KB tile): index + coefficients (coalesced, every
+//      slot used), the 16-byte row pieces, and writes the PRODUCT nc * x (* w) -- formed exactly as above -- into an
+//      LDS tile [edge][feature]
+//   C  the lane group of a row adds its row's products from the tile in CSR order (one accumulator per feature, the
+//      same sequence of fp32 additions); chunks follow each other in edge order
+//   D  scale by the row norm (+ bias, ReLU) and store
+// Hubs need no special path: their edges are dealt like any others and summed at one LDS read per edge.
+// Measured on Cora x 1024 against the row-group kernel (same process): F = 4: 0.37 -> 0.58 of the roofline, F = 7:
+// 0.48 -> 0.53; F = 12 / 16 / 32 (4 and 8 lanes per row, fewer rows per wave, so less to gain): 0.58 -> 0.50,
+// 0.72 -> 0.63, 0.92 -> 0.72 -- used for rows of one or two lanes only.  A one-wave-per-workgroup variant (no
+// barriers, 4 KB tile) was slower at every width (F = 4: 0.43, F = 7: 0.44).
+template <int LOG2G, bool HAS_EW, bool EPI, bool A32>
+__global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
+    const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
+    const float *__restrict__ ew_edge, float *__restrict__ out, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, int N, int F, int F_active, const float *__restrict__ bias, int act,
+    int xcd_tile)
+{
+    constexpr int G = 1 << LOG2G, VEC = 4, W = G * VEC;
+    constexpr int RB = kBlock / G;                  // rows per workgroup = lane groups per workgroup
+    constexpr int CAP = 4096 / W;                   // edges per chunk: a 16 KB tile
+    constexpr int U = CAP / RB;                     // = 4 edges per lane group and chunk
+    static_assert(U == 4, "tile shape");
+    __shared__ int offs[RB + 1];
+    __shared__ __attribute__((aligned(16))) float tile[CAP * W];
+
+    int vb = (int)blockIdx.x;
+    if (xcd_tile > 1) {
+        const int s = vb >> 3;
+        vb = ((s / xcd_tile) * 8 + (vb & 7)) * xcd_tile + s % xcd_tile;
+    }
+    const int r0 = vb * RB;
+    if (r0 >= N) return;                            // whole workgroup (grid padded to a multiple of 8 runs)
+    const int group = threadIdx.x >> LOG2G, j = threadIdx.x & (G - 1);
+    const int foff = j * VEC;
+    const bool fok = foff < F_active;
+    const int goff = min(foff, F_active - VEC);     // ragged width: overlapping last window
+
+    for (int i = threadIdx.x; i <= RB; i += kBlock) offs[i] = row_offsets[min(r0 + i, N)];
+    __syncthreads();
+    const int e0 = offs[0], e1 = offs[RB];
+    const int row = r0 + group;
+    const int rb = offs[group], re = offs[group + 1];            // rows >= N: empty (both = row_offsets[N])
+
+    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    for (int cb = e0; cb < e1; cb += CAP) {
+        const int cnt = min(CAP, e1 - cb);
+        // ---- B
+        {
+            int c[U];
+            float nc[U], w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int el = group + u * RB;
+                c[u] = 0;
+                nc[u] = 0.f;
+                w[u] = 1.f;
+                if (el < cnt) {
+                    c[u] = column_indices[cb + el];
+                    nc[u] = nc_edge[cb + el];
+                    if constexpr (HAS_EW) w[u] = ew_edge[cb + el];
+                }
+            }
+            float v[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (group + u * RB < cnt && fok) {
+                    if constexpr (A32) {
+                        const uint32_t off = __umul24((uint32_t)c[u], (uint32_t)F * 4u) + (uint32_t)goff * 4u;
+                        vec_load_g<VEC>(v[u], reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + off));
+                    } else {
+                        vec_load_g<VEC>(v[u], x + (int64_t)c[u] * F + goff);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) v[u][q] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int el = group + u * RB;
+                if (el < cnt && fok) {
+                    float t[VEC];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        t[q] = nc[u] * v[u][q];                     // Mul(norm_inb, h_inb)
+                        if constexpr (HAS_EW) t[q] = t[q] * w[u];   // Mul(., edge_weight)
+                    }
+                    vec_store<VEC>(tile + el * W + foff, t);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- C
+        if (fok) {
+            const int lo = max(rb, cb) - cb, hi = min(re, cb + cnt) - cb;
+            for (int el = lo; el < hi; el += 4) {
+                float t[4][VEC];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    vec_load<VEC>(t[u], tile + min(el + u, CAP - 1) * W + foff);       // reads past hi are not added
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (el + u < hi) {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] + t[u][q];       // AggSum, CSR order
+                    }
+                }
+            }
+        }
+        if (cb + CAP < e1) __syncthreads();         // the tile is rewritten by the next chunk
+    }
+    // ---- D
+    if (row < N && fok) {
+        const float nr = norm_row[row];
+        float o[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) o[q] = acc[q] * nr;           // Mul(., norm_cen)
+        if constexpr (EPI) {
+            if (bias) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) o[q] = o[q] + bias[goff + q];
+            }
+            if (act == STG_ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) o[q] = o[q] < 0.f ? 0.f : o[q];
+            }
+        }
+        vec_store_g<VEC>(out + (int64_t)row * F + goff, o);
+    }
+}
+
 // dst[i] = table[idx[i]]
 __global__ void edge_gather_kernel(float *__restrict__ dst, const float *__restrict__ table,
                                    const int *__restrict__ idx, int64_t n)
@@ -501,6 +640,24 @@ void launch(const GcnArgs &a)
         go(gcn_agg_kernel<VEC, LOG2G, CHUNKS, HAS_EW, PRE, UNROLL, EPI, L, false>);
     };
 
+    if constexpr (kCanA32 && VEC == 4) {
+        // rows of one or two lanes in vertex order on a graph larger than one resident grid: deal edges, not rows
+        if (!a.node_ids && a.F_active >= 4 &&
+            (tuning().gcn_tile == 2 || (tuning().gcn_tile == 0 && LOG2G <= 1 && !merged && blocks256 > 256 * 8))) {
+            constexpr int rb = kBlock >> LOG2G;
+            int64_t tb = ((int64_t)a.N + rb - 1) / rb;
+            int tt = tuning().gcn_xcd_tile > 0 ? tuning().gcn_xcd_tile : kXcdTile;
+            if (tb < 16 * tt) tt = 1;
+            if (tt > 1) tb = (tb + 8 * tt - 1) / (8 * tt) * (8 * tt);
+            auto go = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3((unsigned)tb), dim3(kBlock), 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew,
+                                   a.out, a.row_offsets, a.column_indices, a.N, a.F, a.F_active, a.bias, a.act, tt);
+            };
+            if (a32) go(gcn_agg_tile_kernel<LOG2G, HAS_EW, EPI, true>);
+            else go(gcn_agg_tile_kernel<LOG2G, HAS_EW, EPI, false>);
+            return;
+        }
+    }
     if constexpr (kCanLong) {
         if (long_rows_enabled(a, LOG2G)) {
             // Long-row workgroups: how many rows are long is not known on the host (no sync), so one wave per 16

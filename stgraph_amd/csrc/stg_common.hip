@@ -65,6 +65,11 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().xw_waves = value;
         return 0;
     }
+    if (!std::strcmp(key, "gcn_tile")) {
+        if (value < 0 || value > 2) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_tile must be 0, 1 or 2");
+        tuning().gcn_tile = value;
+        return 0;
+    }
     if (!std::strcmp(key, "gcn_block")) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
             return fail(STG_ERR_INVALID_ARGUMENT, "gcn_block must be 0, 64, 128 or 256");
