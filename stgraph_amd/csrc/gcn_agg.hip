@@ -447,18 +447,19 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
 // 0.48 -> 0.53; F = 12 / 16 / 32 (4 and 8 lanes per row, fewer rows per wave, so less to gain): 0.58 -> 0.50,
 // 0.72 -> 0.63, 0.92 -> 0.72 -- used for rows of one or two lanes only.  A one-wave-per-workgroup variant (no
 // barriers, 4 KB tile) was slower at every width (F = 4: 0.43, F = 7: 0.44).
-template <int LOG2G, bool HAS_EW, bool EPI, bool A32>
+// VPL = 16-byte pieces per lane.  Only 1 is instantiated: with 2 (rows of 9-16 floats as two lanes, a 32 KB tile)
+// F = 16 drops to 0.54 and F = 12 to 0.45 -- the time follows the bytes through LDS, not the lane count.
+template <int LOG2G, int VPL, bool HAS_EW, bool EPI, bool A32>
 __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
     const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
     const float *__restrict__ ew_edge, float *__restrict__ out, const int *__restrict__ row_offsets,
     const int *__restrict__ column_indices, int N, int F, int F_active, const float *__restrict__ bias, int act,
     int xcd_tile)
 {
-    constexpr int G = 1 << LOG2G, VEC = 4, W = G * VEC;
+    constexpr int G = 1 << LOG2G, VEC = 4, W = G * VEC * VPL;
     constexpr int RB = kBlock / G;                  // rows per workgroup = lane groups per workgroup
-    constexpr int CAP = 4096 / W;                   // edges per chunk: a 16 KB tile
-    constexpr int U = CAP / RB;                     // = 4 edges per lane group and chunk
-    static_assert(U == 4, "tile shape");
+    constexpr int U = 4;                            // edges per lane group and chunk
+    constexpr int CAP = U * RB;                     // edges per chunk: a 16 KB (VPL = 1) / 32 KB tile
     __shared__ int offs[RB + 1];
     __shared__ __attribute__((aligned(16))) float tile[CAP * W];
 
@@ -470,9 +471,14 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
     const int r0 = vb * RB;
     if (r0 >= N) return;                            // whole workgroup (grid padded to a multiple of 8 runs)
     const int group = threadIdx.x >> LOG2G, j = threadIdx.x & (G - 1);
-    const int foff = j * VEC;
-    const bool fok = foff < F_active;
-    const int goff = min(foff, F_active - VEC);     // ragged width: overlapping last window
+    int foff[VPL], goff[VPL];
+    bool fok[VPL];
+#pragma unroll
+    for (int p = 0; p < VPL; ++p) {
+        foff[p] = (j * VPL + p) * VEC;
+        fok[p] = foff[p] < F_active;
+        goff[p] = min(foff[p], F_active - VEC);     // ragged width: overlapping last window
+    }
 
     for (int i = threadIdx.x; i <= RB; i += kBlock) offs[i] = row_offsets[min(r0 + i, N)];
     __syncthreads();
@@ -480,7 +486,11 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
     const int row = r0 + group;
     const int rb = offs[group], re = offs[group + 1];            // rows >= N: empty (both = row_offsets[N])
 
-    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    float acc[VPL][VEC];
+#pragma unroll
+    for (int p = 0; p < VPL; ++p)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[p][q] = 0.f;
     for (int cb = e0; cb < e1; cb += CAP) {
         const int cnt = min(CAP, e1 - cb);
         // ---- B
@@ -499,49 +509,60 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
                     if constexpr (HAS_EW) w[u] = ew_edge[cb + el];
                 }
             }
-            float v[U][VEC];
+            float v[U][VPL][VEC];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (group + u * RB < cnt && fok) {
-                    if constexpr (A32) {
-                        const uint32_t off = __umul24((uint32_t)c[u], (uint32_t)F * 4u) + (uint32_t)goff * 4u;
-                        vec_load_g<VEC>(v[u], reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + off));
-                    } else {
-                        vec_load_g<VEC>(v[u], x + (int64_t)c[u] * F + goff);
-                    }
-                } else {
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) v[u][q] = 0.f;
+                for (int p = 0; p < VPL; ++p) {
+                    if (group + u * RB < cnt && fok[p]) {
+                        if constexpr (A32) {
+                            const uint32_t off = __umul24((uint32_t)c[u], (uint32_t)F * 4u) + (uint32_t)goff[p] * 4u;
+                            vec_load_g<VEC>(v[u][p],
+                                            reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + off));
+                        } else {
+                            vec_load_g<VEC>(v[u][p], x + (int64_t)c[u] * F + goff[p]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) v[u][p][q] = 0.f;
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int el = group + u * RB;
-                if (el < cnt && fok) {
-                    float t[VEC];
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) {
-                        t[q] = nc[u] * v[u][q];                     // Mul(norm_inb, h_inb)
-                        if constexpr (HAS_EW) t[q] = t[q] * w[u];   // Mul(., edge_weight)
+                for (int p = 0; p < VPL; ++p) {
+                    if (el < cnt && fok[p]) {
+                        float t[VEC];
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            t[q] = nc[u] * v[u][p][q];                   // Mul(norm_inb, h_inb)
+                            if constexpr (HAS_EW) t[q] = t[q] * w[u];    // Mul(., edge_weight)
+                        }
+                        vec_store<VEC>(tile + el * W + foff[p], t);
                     }
-                    vec_store<VEC>(tile + el * W + foff, t);
                 }
             }
         }
         __syncthreads();
         // ---- C
-        if (fok) {
+        {
             const int lo = max(rb, cb) - cb, hi = min(re, cb + cnt) - cb;
             for (int el = lo; el < hi; el += 4) {
-                float t[4][VEC];
+                float t[4][VPL][VEC];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    vec_load<VEC>(t[u], tile + min(el + u, CAP - 1) * W + foff);       // reads past hi are not added
+#pragma unroll
+                    for (int p = 0; p < VPL; ++p)
+                        vec_load<VEC>(t[u][p], tile + min(el + u, CAP - 1) * W + foff[p]);   // past hi: not added
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (el + u < hi) {
 #pragma unroll
-                        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] + t[u][q];       // AggSum, CSR order
+                        for (int p = 0; p < VPL; ++p)
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) acc[p][q] = acc[p][q] + t[u][p][q];   // AggSum, CSR order
                     }
                 }
             }
@@ -549,22 +570,27 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
         if (cb + CAP < e1) __syncthreads();         // the tile is rewritten by the next chunk
     }
     // ---- D
-    if (row < N && fok) {
+    if (row < N) {
         const float nr = norm_row[row];
-        float o[VEC];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) o[q] = acc[q] * nr;           // Mul(., norm_cen)
-        if constexpr (EPI) {
-            if (bias) {
+        for (int p = 0; p < VPL; ++p) {
+            if (fok[p]) {
+                float o[VEC];
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) o[q] = o[q] + bias[goff + q];
-            }
-            if (act == STG_ACT_RELU) {
+                for (int q = 0; q < VEC; ++q) o[q] = acc[p][q] * nr;    // Mul(., norm_cen)
+                if constexpr (EPI) {
+                    if (bias) {
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) o[q] = o[q] < 0.f ? 0.f : o[q];
+                        for (int q = 0; q < VEC; ++q) o[q] = o[q] + bias[goff[p] + q];
+                    }
+                    if (act == STG_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) o[q] = o[q] < 0.f ? 0.f : o[q];
+                    }
+                }
+                vec_store_g<VEC>(out + (int64_t)row * F + goff[p], o);
             }
         }
-        vec_store_g<VEC>(out + (int64_t)row * F + goff, o);
     }
 }
 
@@ -644,7 +670,8 @@ void launch(const GcnArgs &a)
         // rows of one or two lanes in vertex order on a graph larger than one resident grid: deal edges, not rows
         if (!a.node_ids && a.F_active >= 4 &&
             (tuning().gcn_tile == 2 || (tuning().gcn_tile == 0 && LOG2G <= 1 && !merged && blocks256 > 256 * 8))) {
-            constexpr int rb = kBlock >> LOG2G;
+            constexpr int TLG = LOG2G, VPL = 1;
+            constexpr int rb = kBlock >> TLG;
             int64_t tb = ((int64_t)a.N + rb - 1) / rb;
             int tt = tuning().gcn_xcd_tile > 0 ? tuning().gcn_xcd_tile : kXcdTile;
             if (tb < 16 * tt) tt = 1;
@@ -653,8 +680,8 @@ void launch(const GcnArgs &a)
                 hipLaunchKernelGGL(kernel, dim3((unsigned)tb), dim3(kBlock), 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew,
                                    a.out, a.row_offsets, a.column_indices, a.N, a.F, a.F_active, a.bias, a.act, tt);
             };
-            if (a32) go(gcn_agg_tile_kernel<LOG2G, HAS_EW, EPI, true>);
-            else go(gcn_agg_tile_kernel<LOG2G, HAS_EW, EPI, false>);
+            if (a32) go(gcn_agg_tile_kernel<TLG, VPL, HAS_EW, EPI, true>);
+            else go(gcn_agg_tile_kernel<TLG, VPL, HAS_EW, EPI, false>);
             return;
         }
     }
