@@ -144,6 +144,39 @@ def test_launch_mapping_knobs_do_not_change_results(cuda, F):
             _C.set_tuning("gcn_addr32", 0)
 
 
+@pytest.mark.parametrize("n,F", [(1 << 24, 4), (1 << 24, 32), ((1 << 24) + 5, 4), (40_000_000, 16), (30_000_000, 32)])
+def test_32_bit_gather_offsets_at_their_limits(cuda, n, F):
+    """Narrow rows use 24-bit x 24-bit offset arithmetic when |V| <= 2^24 and the matrix is < 4 GB: the largest
+    such shapes, the first ones beyond (64-bit path), edges into the last rows; against the 64-bit path and a
+    torch restatement of the touched rows."""
+    from stgraph_amd import _C, kernels
+    gen = torch.Generator(device=cuda).manual_seed(n % 1000)
+    e = 300_000
+    src = torch.randint(0, n, (e,), generator=gen, device=cuda, dtype=torch.int32)
+    src[:1000] = n - 1 - torch.arange(1000, device=cuda, dtype=torch.int32)          # the last rows as sources
+    dst = torch.randint(0, n, (e,), generator=gen, device=cuda, dtype=torch.int32)
+    dst[:500] = n - 1                                                                 # ... and a hub at the last row
+    keys = torch.unique(src.long() * n + dst.long())
+    src, dst = (keys // n).int(), (keys % n).int()
+    g = kernels.build_graph_csr(src, dst, n, cuda)
+    x = torch.randn(n, F, device=cuda, generator=gen)
+    ones = torch.ones(n, 1, device=cuda)
+    got = kernels.gcn_agg(x, ones, ones, g.fwd)
+    _C.set_tuning("gcn_addr32", 1)
+    try:
+        wide = kernels.gcn_agg(x, ones, ones, g.fwd)
+    finally:
+        _C.set_tuning("gcn_addr32", 0)
+    assert torch.equal(got, wide)
+    want = torch.zeros(n, F, device=cuda, dtype=torch.float64)
+    want.index_add_(0, dst.long(), x[src.long()].double())
+    rows = torch.unique(dst.long())
+    torch.testing.assert_close(got[rows].double(), want[rows], rtol=1e-5, atol=1e-5)
+    assert not got[n - 2].any() or (dst == n - 2).any()
+    del x, got, wide, want
+    torch.cuda.empty_cache()
+
+
 def test_unaligned_operands(cuda):
     """x / out at a 4-byte (not 16-byte) aligned address, as a slice of a larger buffer can be."""
     from stgraph_amd import kernels

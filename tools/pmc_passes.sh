@@ -2,8 +2,9 @@
 # usage: tools/pmc_passes.sh <tag> <kernel-name-substring> <python script + args...>
 # Separate rocprofv3 --pmc passes (counters only: no trace domains), one CSV per pass, reduced to per-dispatch
 # sums for the kernels whose name contains the substring -> gpurun_out/pmc_<tag>.json
-# (a TA_* counter pass aborted rocprofv3 with signal 6 on this pool and the call then sat until it was killed:
-# TA / TCP counters are not in the list)
+# (a fourth pass -- first with TA_* counters, then with six TCC_* counters -- aborted rocprofv3 with signal 6 on this
+# pool and the call then sat until it was killed: only the three SQ passes are run; TCC hit / miss come from
+# tools/pmc_gcn.sh, two counters per pass)
 tag=$1; shift
 match=$1; shift
 cd /tmp && export TMPDIR=/tmp
@@ -13,7 +14,6 @@ passes=(
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD"
  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE"
  "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_INSTS_VMEM_WR SQ_CYCLES"
- "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_32B_sum"
 )
 i=0
 for p in "${passes[@]}"; do
