@@ -95,6 +95,9 @@ __device__ __forceinline__ float bcast_const_f(float v, int src)
 #ifndef STG_GCN_ROUND
 #define STG_GCN_ROUND 8
 #endif
+#ifndef STG_GCN_ROUND4
+#define STG_GCN_ROUND4 16
+#endif
 
 template <int VEC, int LOG2L>
 struct LongTile {
@@ -260,9 +263,11 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
     // One round = the R edges whose indices a row's G lanes hold at once, i.e. the gathers one index round trip
     // buys.  Narrow rows (G < 8 lanes) hold several edges per lane so that a round is still 8 edges: with R = G a
     // 2-lane row (F = 7) would need deg / 2 dependent index -> gather round trips.
-    constexpr int R = G < STG_GCN_ROUND ? STG_GCN_ROUND : G;
+    // Rows of four lanes hold 16 edges per round (two batches of 8 gathers, the second under a wave-uniform guard):
+    // with 16 rows per wave some row usually has more than 8 edges, and a second ROUND is two dependent round trips.
+    constexpr int R = (G == 4 || G == 8) ? STG_GCN_ROUND4 : (G < STG_GCN_ROUND ? STG_GCN_ROUND : G);
     constexpr int I = R / G;
-    constexpr int U = I > 1 ? R : (UNROLL < G ? UNROLL : G);
+    constexpr int U = I > 1 ? STG_GCN_ROUND : (UNROLL < G ? UNROLL : G);
 
     if constexpr (LONG) {
         // the first `long_blocks` workgroups take the long rows (see gcn_agg_long_rows)
@@ -340,13 +345,16 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
                     }
                 }
             }
-            for (int k = 0; k < cnt_max; k += U) {
+            // one batch = U gathers in flight, then their sums.  I > 1: k is the compile-time constant KC (so that the
+            // element of c[] and the source lane are constants); I == 1: KC = 0 and k is the loop variable.
+            auto batch = [&](auto kc, int k) {
+                constexpr int KC = decltype(kc)::value;
                 float v[U][CHUNKS][VEC];
                 float ncs[U], ws[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int kk = k + u;
-                    const int el = I == 1 ? 0 : u >> LOG2G;   // I > 1: U == R, so k == 0 and kk == u
+                    const int el = I == 1 ? 0 : (KC + u) >> LOG2G;
                     int ck;
                     if constexpr (I > 1) {                    // source lane u & (G - 1) is a constant here
                         ck = bcast_const_i<G>(c[el], u & (G - 1));
@@ -401,6 +409,14 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
                         }
                     }
                 }
+            };
+            if constexpr (I > 1) {
+                batch(std::integral_constant<int, 0>{}, 0);
+                if constexpr (R > U) {
+                    if (U < cnt_max) batch(std::integral_constant<int, U>{}, U);
+                }
+            } else {
+                for (int k = 0; k < cnt_max; k += U) batch(std::integral_constant<int, 0>{}, k);
             }
         }
 
