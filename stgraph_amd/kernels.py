@@ -436,17 +436,23 @@ def edgeset_check(es: EdgeSet) -> None:
 
 
 class StoreCSR(DeviceCSR):
-    """CSR emitted from an :class:`EdgeSet`.  Structure (row_offset, column_indices, node_ids, degrees)
-    is emitted eagerly; the edge labels -- ``eids`` (0-based, what the launch wrappers index edge
-    tensors with) and ``eids1`` (the reference's 1-based array) -- on first access: the un-weighted GCN
-    kernels never read them, and for the reverse CSR they cost a search per edge."""
+    """CSR emitted from an :class:`EdgeSet`.  ``row_offset`` and ``column_indices`` are emitted eagerly (two
+    launches); everything else on first access: ``degrees`` (row lengths), ``node_ids`` (a sort of the degrees --
+    only a processing order, ~10 launches a training step on a snapshot never needs), and the edge labels ``eids``
+    (0-based, what the launch wrappers index edge tensors with) / ``eids1`` (the reference's 1-based array), which
+    the un-weighted GCN kernels never read and which cost a search per edge for the reverse CSR."""
 
-    def __init__(self, es: EdgeSet, reverse: bool, row_offset, column_indices, node_ids, degrees,
+    def __init__(self, es: EdgeSet, reverse: bool, row_offset, column_indices, node_ids=None, degrees=None,
                  key_order: bool = False):
-        self.row_offset, self.column_indices, self._node_ids, self.degrees = row_offset, column_indices, node_ids, degrees
-        self._degrees = degrees
-        self.degree_sorted = True
+        self.row_offset, self.column_indices, self._node_ids, self._degrees = row_offset, column_indices, node_ids, degrees
+        self.degree_sorted = node_ids is not None
         self._es, self._reverse, self._labels, self._key_order = es, bool(reverse), None, bool(key_order)
+
+    @property
+    def degrees(self) -> torch.Tensor:
+        if self._degrees is None:
+            self._degrees = (self.row_offset[1:] - self.row_offset[:-1]).contiguous()
+        return self._degrees
 
     def _emit_labels(self):
         if self._labels is None:
@@ -498,9 +504,9 @@ def edgeset_emit_csr(es: EdgeSet, reverse: bool, key_order: bool = False) -> Sto
     the GPMA view instead (rows and columns ascending, gpma.cu:1121-1188) -- see include/stgraph_hip.h."""
     device, N, E = es.device, es.num_nodes, es.num_edges
     i32 = dict(dtype=torch.int32, device=device)
-    ro, col, nid, deg = torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
-    _emit(es, reverse, ro, col, None, None, nid, deg, key_order)
-    return StoreCSR(es, reverse, ro, col, nid, deg, key_order)
+    ro, col = torch.empty(N + 1, **i32), torch.empty(E, **i32)
+    _emit(es, reverse, ro, col, None, None, None, None, key_order)
+    return StoreCSR(es, reverse, ro, col, None, None, key_order)
 
 
 def rows_by_node_ids(graph_type: str) -> bool:
