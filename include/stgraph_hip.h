@@ -434,6 +434,24 @@ int stg_tgcn_head_bwd(const float *g_loss, const float *g_y, const float *g_yout
                       const float *target, const float *W1, const float *W2, float *dh, float *dyt, float *dyo,
                       int64_t N, int32_t C, int32_t F, void *stream);
 
+/* The link-prediction head of the dynamic-temporal harness (benchmarking/dynamic-temporal-tgcn/seastar/model.py:5-21:
+ * relu -> Linear(C, F); decode = (z[src] * z[dst]).sum(-1); train.py: BCEWithLogitsLoss, mean over the M label edges).
+ *   fwd: r = relu(h) [N,C], y = r W1^T + b1 [N,F], logits[e] = <y[src[e]], y[dst[e]]> [M],
+ *        loss[0] = mean(max(x,0) - x t + log1p(exp(-|x|))); src / dst int64 [M] (a [2,M] index tensor's rows).
+ *   bwd: dy[v] = g_y[v] + sum over the label edges incident to v of (sigmoid(logit) - t) / M * g_loss * y[other end],
+ *        taken in the order of a node-sorted incidence list (row_ptr [N+1], other [2M], eid [2M], int32, built once
+ *        per index tensor by the caller) -- no atomics; dyt = dy; dh = (h > 0) (dy W1).  g_y / g_loss may be NULL.
+ * Weight gradients as for stg_tgcn_head_*: dW1 = dyt^T r, db1 = colsum(dyt).  C in {32, 64, 128}, F = 32. */
+int stg_link_head_supported(int32_t C, int32_t F);
+size_t stg_link_head_workspace_bytes(int64_t M);
+int stg_link_head_fwd(const float *h, const float *W1, const float *b1, const int64_t *src, const int64_t *dst,
+                      const float *target, float *r, float *y, float *logits, float *loss, int64_t N, int64_t M,
+                      int32_t C, int32_t F, void *workspace, size_t workspace_bytes, void *stream);
+int stg_link_head_bwd(const float *g_loss, const float *g_y, const float *h, const float *y, const float *logits,
+                      const float *target, const int32_t *row_ptr, const int32_t *other, const int32_t *eid,
+                      const float *W1, float *dy, float *dh, float *dyt, int64_t N, int64_t M, int32_t C, int32_t F,
+                      void *stream);
+
 /* ----------------------------------------------- dense neighbour: TGCN row-local glue
  * Fused elementwise stages of one TGCN step (nn/pytorch/temporal/tgcn.py:21-55); the three gate
  * GEMMs between them stay on rocBLAS.  C = hidden width (multiple of 4), all [dev] fp32 row-major,

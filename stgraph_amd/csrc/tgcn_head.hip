@@ -46,7 +46,8 @@ __device__ __forceinline__ float half_sum(float v)
     return v;
 }
 
-template <int C>
+// OUT = false: only r = relu(h) and y = r W1^T + b1 (the dynamic-temporal model's head, whose loss works on edges).
+template <int C, bool OUT = true>
 __global__ __launch_bounds__(kBlock) void head_fwd_kernel(
     const float *__restrict__ h, const float *__restrict__ W1, const float *__restrict__ b1,
     const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ target,
@@ -86,6 +87,14 @@ __global__ __launch_bounds__(kBlock) void head_fwd_kernel(
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     }
 
+    if constexpr (!OUT) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t orow = (int64_t)tile * 32 + acc_row(i, kh);
+            if (orow < N) y[orow * kHeadF + l31] = acc[i];
+        }
+        return;
+    }
     const float w2 = W2[l31], bias2 = b2[0];
     float lsum = 0.f;
 #pragma unroll
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void head_bwd_kernel(
     if (rok) {
         if (g_loss) d = two_over_n * g_loss[0] * (y_out[row] - target[row]);
         if (g_yout) d = d + g_yout[row];
-        if (kh == 0) dyo[row] = d;
+        if (kh == 0 && dyo) dyo[row] = d;
     }
 
     f32x16 acc[CT];
@@ -153,8 +162,11 @@ __global__ __launch_bounds__(kBlock) void head_bwd_kernel(
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int k0 = kb * 8 + kh * 4;
-        const float4 w = *reinterpret_cast<const float4 *>(W2 + k0);
-        float4 a = make_float4(d * w.x, d * w.y, d * w.z, d * w.w);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_loss || g_yout) {                                     // (wave-uniform) the y_out branch of the head
+            const float4 w = *reinterpret_cast<const float4 *>(W2 + k0);
+            a = make_float4(d * w.x, d * w.y, d * w.z, d * w.w);
+        }
         if (rok) {
             if (g_y) {
                 const float4 g = *reinterpret_cast<const float4 *>(g_y + row * kHeadF + k0);
@@ -186,6 +198,83 @@ __global__ __launch_bounds__(kBlock) void head_bwd_kernel(
             }
         }
     }
+}
+
+// ---- link-prediction head of the dynamic-temporal harness (dynamic-temporal-tgcn/seastar/model.py:5-21, train.py:
+// decode = (z[src] * z[dst]).sum(-1), BCEWithLogitsLoss) -----------------------------------------------------------
+constexpr int kLinkLanes = 8;                 // lanes per edge / node: 8 x 16 bytes = one row of y
+
+__device__ __forceinline__ float group8_sum(float v)
+{
+    v += __shfl_xor(v, 1, kLinkLanes);
+    v += __shfl_xor(v, 2, kLinkLanes);
+    v += __shfl_xor(v, 4, kLinkLanes);
+    return v;
+}
+
+// logits[e] = <y[src[e]], y[dst[e]]>; partial[block] = sum of the stable BCE-with-logits terms of the block's edges
+__global__ __launch_bounds__(kBlock) void link_decode_bce_kernel(const float *__restrict__ y, const int64_t *__restrict__ src,
+                                                                 const int64_t *__restrict__ dst,
+                                                                 const float *__restrict__ target,
+                                                                 float *__restrict__ logits, float *__restrict__ partial,
+                                                                 int64_t M)
+{
+    __shared__ float s[kBlock / kLinkLanes];
+    const int g = threadIdx.x / kLinkLanes, j = threadIdx.x % kLinkLanes;
+    const int64_t e = (int64_t)blockIdx.x * (kBlock / kLinkLanes) + g;
+    float term = 0.f;
+    if (e < M) {
+        const float4 a = *reinterpret_cast<const float4 *>(y + src[e] * kHeadF + j * 4);
+        const float4 b = *reinterpret_cast<const float4 *>(y + dst[e] * kHeadF + j * 4);
+        float d = a.x * b.x;
+        d = d + a.y * b.y;
+        d = d + a.z * b.z;
+        d = d + a.w * b.w;
+        const float x = group8_sum(d);
+        if (j == 0) {
+            logits[e] = x;
+            term = fmaxf(x, 0.f) - x * target[e] + log1pf(__expf(-fabsf(x)));
+        }
+    } else {
+        (void)group8_sum(0.f);
+    }
+    if (j == 0) s[g] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < kBlock / kLinkLanes; ++i) t = t + s[i];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// dy[v] = g_y[v] + sum over the label edges incident to v, in the order of the node-sorted incidence list, of
+// (sigmoid(logit) - target) * scale * y[other endpoint]: no atomics, so the gradient is reproducible
+__global__ __launch_bounds__(kBlock) void link_bwd_nodes_kernel(const float *__restrict__ g_loss, const float *__restrict__ g_y,
+                                                                const float *__restrict__ y, const float *__restrict__ logits,
+                                                                const float *__restrict__ target,
+                                                                const int *__restrict__ row_ptr, const int *__restrict__ other,
+                                                                const int *__restrict__ eid, float *__restrict__ dy, int64_t N,
+                                                                float inv_m)
+{
+    const int g = threadIdx.x / kLinkLanes, j = threadIdx.x % kLinkLanes;
+    const int64_t v = (int64_t)blockIdx.x * (kBlock / kLinkLanes) + g;
+    if (v >= N) return;
+    float4 acc = g_y ? *reinterpret_cast<const float4 *>(g_y + v * kHeadF + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_loss) {
+        const float scale = g_loss[0] * inv_m;
+        for (int k = row_ptr[v]; k < row_ptr[v + 1]; ++k) {
+            const int e = eid[k];
+            const float x = logits[e];
+            const float sig = 1.0f / (1.0f + __expf(-x));
+            const float coef = (sig - target[e]) * scale;
+            const float4 o = *reinterpret_cast<const float4 *>(y + (int64_t)other[k] * kHeadF + j * 4);
+            acc.x = acc.x + coef * o.x;
+            acc.y = acc.y + coef * o.y;
+            acc.z = acc.z + coef * o.z;
+            acc.w = acc.w + coef * o.w;
+        }
+    }
+    *reinterpret_cast<float4 *>(dy + v * kHeadF + j * 4) = acc;
 }
 
 inline int head_tiles(int64_t N) { return (int)((N + 31) / 32); }
@@ -272,4 +361,81 @@ extern "C" int stg_tgcn_head_bwd(const float *g_loss, const float *g_y, const fl
             break;
     }
     return check_launch("stg_tgcn_head_bwd");
+}
+
+extern "C" int stg_link_head_supported(int32_t C, int32_t F) { return (C == 32 || C == 64 || C == 128) && F == stg::kHeadF; }
+
+extern "C" size_t stg_link_head_workspace_bytes(int64_t M)
+{
+    return M <= 0 ? sizeof(float) : sizeof(float) * (size_t)((M + 31) / 32);
+}
+
+extern "C" int stg_link_head_fwd(const float *h, const float *W1, const float *b1, const int64_t *src, const int64_t *dst,
+                                 const float *target, float *r, float *y, float *logits, float *loss, int64_t N,
+                                 int64_t M, int32_t C, int32_t F, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    if (!stg_link_head_supported(C, F)) return fail(STG_ERR_UNSUPPORTED, "stg_link_head_fwd: C=%d F=%d not supported", C, F);
+    if (N <= 0 || M <= 0 || N > (int64_t)32 * 0x3fffffff || M > (int64_t)32 * 0x3fffffff)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_head_fwd: bad N / M");
+    if (!h || !W1 || !b1 || !src || !dst || !target || !r || !y || !logits || !loss || !workspace)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_head_fwd: NULL pointer argument");
+    if (workspace_bytes < stg_link_head_workspace_bytes(M))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_head_fwd: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tiles = head_tiles(N);
+    const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    float *partial = static_cast<float *>(workspace);
+    switch (C) {
+        case 32:
+            hipLaunchKernelGGL((head_fwd_kernel<32, false>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, nullptr,
+                               nullptr, nullptr, r, y, nullptr, nullptr, N, tiles);
+            break;
+        case 64:
+            hipLaunchKernelGGL((head_fwd_kernel<64, false>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, nullptr,
+                               nullptr, nullptr, r, y, nullptr, nullptr, N, tiles);
+            break;
+        default:
+            hipLaunchKernelGGL((head_fwd_kernel<128, false>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, nullptr,
+                               nullptr, nullptr, r, y, nullptr, nullptr, N, tiles);
+            break;
+    }
+    const int eblocks = (int)((M + 31) / 32);
+    hipLaunchKernelGGL(link_decode_bce_kernel, dim3(eblocks), dim3(kBlock), 0, stream, y, src, dst, target, logits, partial, M);
+    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(kBlock), 0, stream, partial, eblocks, 1.0f / (float)M, loss);
+    return check_launch("stg_link_head_fwd");
+}
+
+extern "C" int stg_link_head_bwd(const float *g_loss, const float *g_y, const float *h, const float *y,
+                                 const float *logits, const float *target, const int32_t *row_ptr, const int32_t *other,
+                                 const int32_t *eid, const float *W1, float *dy, float *dh, float *dyt, int64_t N,
+                                 int64_t M, int32_t C, int32_t F, void *stream_)
+{
+    using namespace stg;
+    if (!stg_link_head_supported(C, F)) return fail(STG_ERR_UNSUPPORTED, "stg_link_head_bwd: C=%d F=%d not supported", C, F);
+    if (N <= 0 || M <= 0 || N > (int64_t)32 * 0x3fffffff) return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_head_bwd: bad N / M");
+    if (!h || !y || !logits || !target || !row_ptr || !other || !eid || !W1 || !dy || !dh || !dyt)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_head_bwd: NULL pointer argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(link_bwd_nodes_kernel, dim3((unsigned)((N + 31) / 32)), dim3(kBlock), 0, stream, g_loss, g_y, y, logits,
+                       target, row_ptr, other, eid, dy, N, 1.0f / (float)M);
+    // dh = (h > 0) (dy W1), dyt = dy: the relu -> Linear backward is head_bwd_kernel without its y_out branch (W2 is
+    // not read then)
+    const int tiles = head_tiles(N);
+    const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    switch (C) {
+        case 32:
+            hipLaunchKernelGGL(head_bwd_kernel<32>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, dy, nullptr, h, nullptr,
+                               nullptr, W1, nullptr, dh, dyt, nullptr, N, 0.f, tiles);
+            break;
+        case 64:
+            hipLaunchKernelGGL(head_bwd_kernel<64>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, dy, nullptr, h, nullptr,
+                               nullptr, W1, nullptr, dh, dyt, nullptr, N, 0.f, tiles);
+            break;
+        default:
+            hipLaunchKernelGGL(head_bwd_kernel<128>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, dy, nullptr, h, nullptr,
+                               nullptr, W1, nullptr, dh, dyt, nullptr, N, 0.f, tiles);
+            break;
+    }
+    return check_launch("stg_link_head_bwd");
 }

@@ -997,6 +997,59 @@ def tgcn_head_bwd(g_loss, g_y, g_yout, h, y_out, target, W1, W2):
     return dh, dyt, dyo
 
 
+def link_head_supported(C: int, F: int) -> bool:
+    return bool(_C.lib.stg_link_head_supported(int(C), int(F)))
+
+
+def link_incidence(edge_index: torch.Tensor, N: int):
+    """Node-sorted incidence list of ``M`` label edges (``edge_index`` int64 [2, M]): ``row_ptr [N+1]``, and per
+    entry the other endpoint and the edge id (int32), entries of a node in ascending (role, edge id) order --
+    what stg_link_head_bwd sums over.  Built with a stable sort, once per index tensor."""
+    M = int(edge_index.shape[1])
+    nodes = torch.cat([edge_index[0], edge_index[1]])
+    order = torch.sort(nodes, stable=True).indices
+    other = torch.cat([edge_index[1], edge_index[0]])[order].to(torch.int32).contiguous()
+    eid = (order % M).to(torch.int32).contiguous()
+    counts = torch.bincount(nodes, minlength=N)
+    row_ptr = torch.zeros(N + 1, dtype=torch.int32, device=edge_index.device)
+    row_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return row_ptr, other, eid
+
+
+def link_head_fwd(h, W1, b1, edge_index, target):
+    """relu -> Linear -> dot-product decode -> BCE-with-logits mean, three launches (stg_link_head_fwd).
+    Returns (r, y, logits [M], loss [1])."""
+    N, C = h.shape
+    F_ = W1.shape[0]
+    M = int(edge_index.shape[1])
+    dev = h.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    r, y, logits, loss = new(N, C), new(N, F_), new(M), new(1)
+    ws_bytes = int(_C.lib.stg_link_head_workspace_bytes(M))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _Timed("link_head_fwd", 4 * N * (2 * C + F_) + 4 * M * (2 * F_ + 6), 2 * N * F_ * C):
+        _C.check(_C.lib.stg_link_head_fwd(_ptr(h), _ptr(W1), _ptr(b1), _ptr(edge_index[0]), _ptr(edge_index[1]),
+                                          _ptr(target), _ptr(r), _ptr(y), _ptr(logits), _ptr(loss), N, M, C, F_,
+                                          _ptr(ws), ws_bytes, _stream_ptr(dev)))
+    return r, y, logits, loss
+
+
+def link_head_bwd(g_loss, g_y, h, y, logits, target, incidence, W1):
+    """Backward of link_head_fwd up to the weight gradients (stg_link_head_bwd): returns (dh, dyt)."""
+    N, C = h.shape
+    F_ = W1.shape[0]
+    M = int(logits.shape[0])
+    dev = h.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    dy, dh, dyt = new(N, F_), new(N, C), new(N, F_)
+    row_ptr, other, eid = incidence
+    with torch.cuda.device(dev), _Timed("link_head_bwd", 4 * N * (2 * C + 3 * F_) + 4 * M * (2 * F_ + 6), 2 * N * F_ * C):
+        _C.check(_C.lib.stg_link_head_bwd(_ptr(g_loss), _ptr(g_y), _ptr(h), _ptr(y), _ptr(logits), _ptr(target),
+                                          _ptr(row_ptr), _ptr(other), _ptr(eid), _ptr(W1), _ptr(dy), _ptr(dh), _ptr(dyt),
+                                          N, M, C, F_, _stream_ptr(dev)))
+    return dh, dyt
+
+
 def tgcn_cell_fused_supported(C: int) -> bool:
     return bool(_C.lib.stg_tgcn_cell_fused_supported(int(C)))
 

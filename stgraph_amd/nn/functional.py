@@ -155,6 +155,74 @@ def tgcn_head(h, W1, b1, W2, b2, target):
     return y, y_out, torch.mean((y_out - target) ** 2)
 
 
+class _LinkHead(torch.autograd.Function):
+    """(y, loss) = link_head(h): ``y = relu(h) W1^T + b1``, ``logit_e = <y[src_e], y[dst_e]>``,
+    ``loss = BCEWithLogits(logits, target)`` (mean) -- the head, decoder and per-timestep loss of the
+    dynamic-temporal harness (benchmarking/dynamic-temporal-tgcn/seastar/model.py:5-21 and its train loop) as
+    three launches forward, two backward; the backward sums per node over a sorted incidence list (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, h, W1, b1, edge_index, target, incidence):
+        h = h.contiguous()
+        r, y, logits, loss = kernels.link_head_fwd(h, W1, b1, edge_index, target)
+        ctx.save_for_backward(h, r, y, logits, target, W1, *incidence)
+        ctx.params = (W1, b1)
+        ctx.set_materialize_grads(False)
+        return y, loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_y, g_loss):
+        h, r, y, logits, target, W1, row_ptr, other, eid = ctx.saved_tensors
+        W1p, b1p = ctx.params
+        cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        dh, dyt = kernels.link_head_bwd(cont(g_loss), cont(g_y), h, y, logits, target, (row_ptr, other, eid), W1)
+        if deferred_weight_grads() and W1p.is_leaf and b1p.is_leaf:
+            deferred.current().add(("head1", id(W1p)), dyt, r, sink=lambda d, W=W1p: deferred.add_to_grad(W, d),
+                                   colsum_sink=lambda d, b=b1p: deferred.add_to_grad(b, d))
+            gW1 = gb1 = None
+        else:
+            gW1, gb1 = kernels.gemm_tn(dyt, r, colsum=True)
+        return dh, gW1, gb1, None, None, None
+
+
+_INCIDENCE = {}
+
+
+def _incidence_of(edge_index: torch.Tensor, N: int):
+    """kernels.link_incidence(edge_index, N), kept per index tensor (a training loop passes the same tensor for
+    a timestamp every epoch); keyed on identity, storage address and version counter."""
+    key = id(edge_index)
+    stamp = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), N)
+    hit = _INCIDENCE.get(key)
+    if hit is not None and hit[0] == stamp and hit[1]() is edge_index:
+        return hit[2]
+    if len(_INCIDENCE) > 4096:
+        _INCIDENCE.clear()
+    import weakref
+    inc = kernels.link_incidence(edge_index, N)
+    _INCIDENCE[key] = (stamp, weakref.ref(edge_index), inc)
+    return inc
+
+
+def link_head_usable(h, W1, b1, edge_index, target) -> bool:
+    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and b1 is not None and W1.dim() == 2
+            and W1.shape[1] == h.shape[1] and edge_index.dtype == torch.int64 and edge_index.dim() == 2
+            and edge_index.shape[0] == 2 and edge_index.shape[1] > 0 and edge_index.is_contiguous()
+            and target.dtype == torch.float32 and target.is_contiguous() and target.numel() == edge_index.shape[1]
+            and h.shape[0] > 0 and W1.is_contiguous() and b1.is_contiguous()
+            and kernels.link_head_supported(h.shape[1], W1.shape[0]))
+
+
+def link_head(h, W1, b1, edge_index, target):
+    """Returns ``(y, loss)`` as ``y = linear(relu(h))``, ``BCEWithLogitsLoss()((y[ei[0]] * y[ei[1]]).sum(-1), target)``
+    would (fp32 rounding apart); the fused launches when ``link_head_usable``, that composition otherwise."""
+    if link_head_usable(h, W1, b1, edge_index, target):
+        return _LinkHead.apply(h, W1, b1, edge_index, target, _incidence_of(edge_index, h.shape[0]))
+    y = linear(F.relu(h), W1, b1)
+    out = (y[edge_index[0]] * y[edge_index[1]]).sum(dim=-1).view(-1)
+    return y, F.binary_cross_entropy_with_logits(out, target)
+
+
 def mm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     if x.dim() == 2 and _use_native(x, x.shape[0], x.shape[1], w.shape[1]):
         return _MM.apply(x, w)

@@ -201,6 +201,17 @@ class DynamicSTGraphTGCN(torch.nn.Module):
     def decode(self, z, edge_label_index):
         return (z[edge_label_index[0]] * z[edge_label_index[1]]).sum(dim=-1)
 
+    def step_loss(self, g, node_feat, edge_weight, hidden_state, edge_label_index, target):
+        """``forward`` + ``decode`` + the training loop's ``BCEWithLogitsLoss``: returns (loss, y, h).  With the fused
+        head on (``set_fused_head``, default) everything after the TGCN cell is five launches forward + backward."""
+        if _FUSED_HEAD:
+            h = self.temporal(g, node_feat, edge_weight, hidden_state)
+            y, loss = SF.link_head(h, self.linear.weight, self.linear.bias, edge_label_index, target)
+            return loss, y, h
+        y, h = self(g, node_feat, edge_weight, hidden_state)
+        out = self.decode(y, edge_label_index).view(-1)
+        return F.binary_cross_entropy_with_logits(out, target), y, h
+
 
 def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_every: int, optimizer,
                         bucket: GradBucket, feat_size: int, epoch: int = 0, rank: int = 0, world: int = 1,
@@ -214,7 +225,6 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
     if backprop_every == 0:
         backprop_every = total
     norm_fn = norm_fn or in_degree_norm
-    criterion = torch.nn.BCEWithLogitsLoss()
     n = graph.get_num_nodes()
     dev = pos_neg_targets[0].device
     losses = []
@@ -233,9 +243,8 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
                 graph.get_graph(t)
                 if graph.get_ndata("norm") is None:
                     graph.set_ndata("norm", norm_fn(graph))
-                y_hat, hidden = model(graph, y_hat, None, hidden)
-                out = model.decode(y_hat, pos_neg_edges[t]).view(-1)
-                cost = cost + criterion(out, pos_neg_targets[t])
+                loss_t, y_hat, hidden = model.step_loss(graph, y_hat, None, hidden, pos_neg_edges[t], pos_neg_targets[t])
+                cost = cost + loss_t
             if not isinstance(cost, int):
                 cost = cost / (backprop_every + 1)
                 cost.backward()
