@@ -100,11 +100,11 @@ def gcn_setup(device, seed, n, e, feat):
     model = GCN(feat, feat, feat, 1, F.relu).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4)
     # Same loss as the reference's nn.CrossEntropyLoss() on logits[train_mask] (mean over the masked rows).
-    # Written as a slice (the mask is a prefix: a view, no gather/scatter) and as the mean of the per-row
-    # losses: torch's fused 'mean' reduction runs single-block nll_loss kernels on ROCm (1.3 + 1.0 ms for
-    # 600K rows, profiles/r01_bench_gcn_cfg2_kernel_stats.csv); the per-row form is the same arithmetic.
-    def loss_fn(logits, target):
-        return F.cross_entropy(logits, target, reduction="none").mean()
+    # Written as a slice (the mask is a prefix: a view, no gather/scatter); the loss itself is the library's fused
+    # softmax cross-entropy (csrc/xent.hip; torch's fused 'mean' reduction runs single-block nll_loss kernels on
+    # ROCm: 1.3 + 1.0 ms for 600K rows, profiles/r01_bench_gcn_cfg2_kernel_stats.csv).
+    from stgraph_amd.nn import functional as SF
+    loss_fn = SF.cross_entropy
 
     def step():
         model.train()
@@ -177,7 +177,8 @@ def cora_run(device, epochs=200):
     x = (torch.rand(n, 1433, device=device, generator=gen) < 0.0127).float()
     labels = torch.randint(0, 7, (n,), device=device, generator=gen)
     ntrain = int(0.6 * n)
-    loss_fn = nn.CrossEntropyLoss()
+    from stgraph_amd.nn import functional as SF
+    loss_fn = SF.cross_entropy                  # nn.CrossEntropyLoss() as one launch each way (csrc/xent.hip)
     out = {"workload": f"2-layer GCN 1433->16->7 on a Cora-shaped synthetic graph |V|={n} |E|={e} "
                        "(BASELINE configs[0]), Adam, cross-entropy, 200 epochs"}
     for mode in ("eager", "hip_graph"):

@@ -412,6 +412,19 @@ int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const float *H, co
                             float *CR, float *CH, float *Z, float *R, float *Ht, float *Hn, int64_t N, int32_t C,
                             float lo, float hi, void *stream);
 
+/* ----------------------------------------------- dense neighbour: softmax cross-entropy
+ * `nn.CrossEntropyLoss()(logits, labels)` of the GCN training scripts (benchmarking/gcn/seastar/train.py:63-101),
+ * mean over the n rows, one launch each way (+ a one-workgroup finish): see csrc/xent.hip.
+ *   fwd: lse[i] = logsumexp(logits[i, :]) [n] (kept for the backward), loss[0] = mean(lse[i] - logits[i, labels[i]]);
+ *        status[0] |= 1 if a label is outside [0, K) (that row contributes 0).  labels int64 [n].
+ *   bwd: dlogits[i, c] = (exp(logits[i, c] - lse[i]) - [c == labels[i]]) * g_loss[0] / n.
+ * All [dev]; workspace: stg_xent_workspace_bytes(n, K). */
+size_t stg_xent_workspace_bytes(int64_t n, int32_t K);
+int stg_xent_fwd(const float *logits, const int64_t *labels, float *lse, float *loss, int32_t *status, int64_t n,
+                 int32_t K, void *workspace, size_t workspace_bytes, void *stream);
+int stg_xent_bwd(const float *g_loss, const float *logits, const int64_t *labels, const float *lse, float *dlogits,
+                 int64_t n, int32_t K, void *stream);
+
 /* ----------------------------------------------- dense neighbour: the TGCN harness head
  * The model head and loss of the static-temporal TGCN training step
  * (benchmarking/static-temporal-tgcn/seastar/model.py:6-18: relu -> Linear(C, F) -> Linear(F, 1); train.py:

@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_bwd",
+    "stg_xent_workspace_bytes", "stg_xent_fwd", "stg_xent_bwd",
     "stg_link_head_supported", "stg_link_head_workspace_bytes", "stg_link_head_fwd", "stg_link_head_bwd",
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
@@ -170,6 +171,12 @@ def _load() -> ctypes.CDLL:
     lib.stg_tgcn_head_fwd.argtypes = [vp] * 10 + [i64, i32, i32, vp, ctypes.c_size_t, vp]
     lib.stg_tgcn_head_bwd.restype = ctypes.c_int
     lib.stg_tgcn_head_bwd.argtypes = [vp] * 11 + [i64, i32, i32, vp]
+    lib.stg_xent_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_xent_workspace_bytes.argtypes = [i64, i32]
+    lib.stg_xent_fwd.restype = ctypes.c_int
+    lib.stg_xent_fwd.argtypes = [vp] * 5 + [i64, i32, vp, ctypes.c_size_t, vp]
+    lib.stg_xent_bwd.restype = ctypes.c_int
+    lib.stg_xent_bwd.argtypes = [vp] * 5 + [i64, i32, vp]
     lib.stg_link_head_supported.restype = ctypes.c_int
     lib.stg_link_head_supported.argtypes = [i32, i32]
     lib.stg_link_head_workspace_bytes.restype = ctypes.c_size_t

@@ -997,6 +997,31 @@ def tgcn_head_bwd(g_loss, g_y, g_yout, h, y_out, target, W1, W2):
     return dh, dyt, dyo
 
 
+def xent_fwd(logits: torch.Tensor, labels: torch.Tensor):
+    """Mean softmax cross-entropy (stg_xent_fwd).  Returns (loss [1], lse [n], status [1] int32: non-zero if a label
+    is out of range -- not read here, the caller decides whether to pay the sync)."""
+    n, K = logits.shape
+    dev = logits.device
+    lse = torch.empty(n, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    ws_bytes = int(_C.lib.stg_xent_workspace_bytes(n, K))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _Timed("xent_fwd", 4 * n * (K + 3), 4 * n * K):
+        _C.check(_C.lib.stg_xent_fwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(loss), _ptr(status), n, K, _ptr(ws),
+                                     ws_bytes, _stream_ptr(dev)))
+    return loss, lse, status
+
+
+def xent_bwd(g_loss: torch.Tensor, logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor) -> torch.Tensor:
+    n, K = logits.shape
+    d = torch.empty_like(logits)
+    with torch.cuda.device(logits.device), _Timed("xent_bwd", 4 * n * (2 * K + 3), 4 * n * K):
+        _C.check(_C.lib.stg_xent_bwd(_ptr(g_loss), _ptr(logits), _ptr(labels), _ptr(lse), _ptr(d), n, K,
+                                     _stream_ptr(logits.device)))
+    return d
+
+
 def link_head_supported(C: int, F: int) -> bool:
     return bool(_C.lib.stg_link_head_supported(int(C), int(F)))
 

@@ -155,6 +155,32 @@ def tgcn_head(h, W1, b1, W2, b2, target):
     return y, y_out, torch.mean((y_out - target) ** 2)
 
 
+class _CrossEntropy(torch.autograd.Function):
+    """``F.cross_entropy(logits, labels)`` (mean) as one launch each way (csrc/xent.hip)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        loss, lse, _ = kernels.xent_fwd(logits, labels)
+        ctx.save_for_backward(logits, labels, lse)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse = ctx.saved_tensors
+        return kernels.xent_bwd(g.contiguous(), logits, labels, lse), None
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """``nn.CrossEntropyLoss()(logits, labels)``: the fused launches for 2-D fp32 device logits and int64 class
+    labels, ``F.cross_entropy`` otherwise (same value and gradient up to fp32 rounding)."""
+    if (logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and labels.dtype == torch.int64
+            and labels.dim() == 1 and labels.shape[0] == logits.shape[0] and logits.shape[0] > 0):
+        return _CrossEntropy.apply(logits, labels)
+    return F.cross_entropy(logits, labels)
+
+
 class _LinkHead(torch.autograd.Function):
     """(y, loss) = link_head(h): ``y = relu(h) W1^T + b1``, ``logit_e = <y[src_e], y[dst_e]>``,
     ``loss = BCEWithLogits(logits, target)`` (mean) -- the head, decoder and per-timestep loss of the

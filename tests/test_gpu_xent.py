@@ -1,0 +1,61 @@
+"""Fused softmax cross-entropy (csrc/xent.hip, nn.functional.cross_entropy) against torch's F.cross_entropy in fp32
+and an fp64 restatement: value, gradient, a loss that enters the cost with a factor, slices of a larger logits
+matrix (the train-mask prefix of the GCN scripts), out-of-range labels reported through the status word."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 5, 1624, 70_001, 600_000])
+@pytest.mark.parametrize("K", [2, 7, 16, 32, 33, 128, 1000])
+def test_matches_torch(cuda, n, K):
+    from stgraph_amd.nn import functional as SF
+    if n * K > 100_000_000:
+        pytest.skip("too large")
+    g = torch.Generator(device=cuda).manual_seed(n + K)
+    logits = torch.randn(n, K, device=cuda, generator=g) * 3
+    if n > 2:
+        logits[1] = 50.0                       # a saturated row
+        logits[2, 0] = -80.0
+    labels = torch.randint(0, K, (n,), device=cuda, generator=g)
+    res = []
+    for fn, dt in ((SF.cross_entropy, torch.float32), (F.cross_entropy, torch.float32), (F.cross_entropy, torch.float64)):
+        x = logits.to(dt).clone().requires_grad_(True)
+        loss = fn(x, labels)
+        (loss * 0.37).backward()
+        res.append((loss.detach(), x.grad))
+    (l0, g0), (l1, g1), (l2, g2) = res
+    for a, b, c, name in ((l0, l1, l2, "loss"), (g0, g1, g2, "grad")):
+        scale = float(c.abs().max()) + 1e-30
+        err_ours = float((a.double() - c).abs().max()) / scale
+        err_torch = float((b.double() - c).abs().max()) / scale
+        assert err_ours <= max(4 * err_torch, 2e-6), (name, err_ours, err_torch)
+
+
+def test_prefix_slice_and_fallbacks(cuda):
+    from stgraph_amd.nn import functional as SF
+    g = torch.Generator(device=cuda).manual_seed(0)
+    full = torch.randn(2708, 7, device=cuda, generator=g).requires_grad_(True)
+    labels = torch.randint(0, 7, (2708,), device=cuda, generator=g)
+    loss = SF.cross_entropy(full[:1624], labels[:1624])
+    loss.backward()
+    ref = full.detach().clone().requires_grad_(True)
+    F.cross_entropy(ref[:1624], labels[:1624]).backward()
+    torch.testing.assert_close(full.grad, ref.grad, rtol=1e-5, atol=1e-8)
+    assert not full.grad[1624:].any()
+    # double logits / int32 labels: torch's path
+    x64 = torch.randn(10, 3, device=cuda, dtype=torch.float64)
+    torch.testing.assert_close(SF.cross_entropy(x64, labels[:10] % 3), F.cross_entropy(x64, labels[:10] % 3))
+
+
+def test_out_of_range_label_sets_the_status_word(cuda):
+    from stgraph_amd import kernels
+    logits = torch.randn(100, 5, device=cuda)
+    labels = torch.randint(0, 5, (100,), device=cuda)
+    _, _, status = kernels.xent_fwd(logits, labels)
+    assert int(status.item()) == 0
+    labels[17] = 5
+    _, _, status = kernels.xent_fwd(logits, labels)
+    assert int(status.item()) != 0
