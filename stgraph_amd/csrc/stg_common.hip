@@ -65,6 +65,11 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().xw_waves = value;
         return 0;
     }
+    if (!std::strcmp(key, "cell_rows")) {
+        if (value != 0 && value != 16 && value != 32) return fail(STG_ERR_INVALID_ARGUMENT, "cell_rows must be 0, 16 or 32");
+        tuning().cell_rows = value;
+        return 0;
+    }
     if (!std::strcmp(key, "gcn_tile")) {
         if (value < 0 || value > 2) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_tile must be 0, 1 or 2");
         tuning().gcn_tile = value;

@@ -25,6 +25,7 @@ struct Tuning {
     int gcn_unroll = 0;            // 0 = auto
     int gcn_long_threshold = 0;    // 0 = default (16 edges); rows above it take the wave-per-row path
     int xw_waves = 0;              // gcn_agg_xw: 0 = auto, 4 / 8 waves per workgroup
+    int cell_rows = 0;             // fused TGCN forward cell: 0 = auto (32-row tiles), 16 = 16-row tiles, 32
     int gcn_tile = 0;              // edge-dealt narrow-row kernel: 0 = auto (large grids), 1 = never, 2 = whenever legal
     int gcn_block = 0;             // 0 = auto; 64 / 128 / 256 = threads per workgroup of the plain gcn_agg launch
     int gcn_addr32 = 0;            // 0 = auto (32-bit gather offsets when the matrix allows); 1 = always 64-bit

@@ -273,6 +273,224 @@ int launch_fwd(const float *a3, const float *b3, const float *H, const float *Wz
 }
 
 
+// ---------------------------------------------------------------------------------------------- forward, 16-row tiles
+// The same chain on v_mfma_f32_16x16x4_f32 with one wave per 16-ROW tile: twice the tiles (cfg4: 3125 instead of
+// 1563, i.e. 12 instead of 6 per CU) at half the work each, and 16-wave workgroups (four waves per SIMD at <= 128
+// registers) so that more of one wave's load / LDS / store phases hide behind other waves' MFMAs.
+// Layouts: lane = (n16 = lane & 15, kq = lane >> 4).  A operand of step i of k block j: element k = 16 j + 4 kq + i of
+// row n16 -- a lane's 16-byte piece at column 16 j + 4 kq, as read from HBM; B operand: Ws[k][16 ct + n16]
+// (LDW = C + 4 keeps the four k rows of a step on different LDS banks); accumulator element i of block ct:
+// row 4 kq + i, column 16 ct + n16.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int C, int WAVES>
+struct CellShape16 {
+    static constexpr int K = 2 * C, KQ = C / 16, CT = C / 16, LDW = C + 4, TLD = 17;
+    static constexpr int kThreads = WAVES * kWave;
+    static constexpr int kWeights = 3 * K * LDW;              // floats
+    static constexpr int kBias = 6 * C;                       // b3 [3C], bz, br, bh
+    static constexpr int kTile = 16 * TLD;                    // per wave: one 16x16 block at a time
+    static constexpr size_t kLds = sizeof(float) * (size_t)(kWeights + kBias + WAVES * kTile);
+};
+
+template <int C, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void cell_fused_fwd16_kernel(
+    const float *__restrict__ a3, const float *__restrict__ b3, const float *__restrict__ H,
+    const float *__restrict__ Wz, const float *__restrict__ bz, const float *__restrict__ Wr,
+    const float *__restrict__ br, const float *__restrict__ Wh, const float *__restrict__ bh,
+    float *__restrict__ CZ, float *__restrict__ CR, float *__restrict__ CH, float *__restrict__ Z,
+    float *__restrict__ R, float *__restrict__ Ht, float *__restrict__ Hn, int64_t N, float lo, float hi,
+    int num_tiles)
+{
+    using S = CellShape16<C, WAVES>;
+    constexpr int K = S::K, KQ = S::KQ, CT = S::CT, LDW = S::LDW, TLD = S::TLD, NT = S::kThreads;
+    extern __shared__ float lds[];
+    float *Ws = lds;                                   // 3 x [K][LDW]
+    float *bs = lds + S::kWeights;                     // b3 | bz | br | bh
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int n16 = lane & 15, kq = lane >> 4;
+    float *T = bs + S::kBias + wave * S::kTile;        // [16][TLD] transpose tile of this wave
+
+    {   // stage the weights (W is [C][K]: element i = (m, k), 4 consecutive k) and the biases
+        const float *src[3] = {Wz, Wr, Wh};
+        constexpr int total4 = C * K / 4;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            float *dst = Ws + g * K * LDW;
+            for (int i4 = threadIdx.x; i4 < total4; i4 += NT) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(src[g] + (int64_t)i4 * 4);
+                const int i = i4 * 4, m = i / K, k = i - m * K;
+                dst[(k + 0) * LDW + m] = w4.x;
+                dst[(k + 1) * LDW + m] = w4.y;
+                dst[(k + 2) * LDW + m] = w4.z;
+                dst[(k + 3) * LDW + m] = w4.w;
+            }
+        }
+        for (int i = threadIdx.x; i < 3 * C; i += NT) bs[i] = b3[i];
+        for (int i = threadIdx.x; i < C; i += NT) {
+            bs[3 * C + i] = bz[i];
+            bs[4 * C + i] = br[i];
+            bs[5 * C + i] = bh[i];
+        }
+    }
+    __syncthreads();
+
+    const int total = gridDim.x * WAVES;
+    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < num_tiles; tile += total) {
+        const int64_t row = (int64_t)tile * 16 + n16;
+        const bool rok = row < N;
+
+        float4 ag[3][KQ], hh[KQ];
+        auto load_gate = [&](int g, int j) {
+            const int c = 16 * j + 4 * kq;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rok) a = *reinterpret_cast<const float4 *>(a3 + row * 3 * C + g * C + c);
+            const float4 b = *reinterpret_cast<const float4 *>(bs + g * C + c);
+            a.x = fminf(fmaxf(a.x + b.x, lo), hi);
+            a.y = fminf(fmaxf(a.y + b.y, lo), hi);
+            a.z = fminf(fmaxf(a.z + b.z, lo), hi);
+            a.w = fminf(fmaxf(a.w + b.w, lo), hi);
+            return a;
+        };
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const int c = 16 * j + 4 * kq;
+            hh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rok) hh[j] = *reinterpret_cast<const float4 *>(H + row * C + c);
+            ag[0][j] = load_gate(0, j);
+            ag[1][j] = load_gate(1, j);
+        }
+        if (rok) {
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const int c = 16 * j + 4 * kq;
+                *reinterpret_cast<float4 *>(CZ + row * K + c) = ag[0][j];
+                *reinterpret_cast<float4 *>(CR + row * K + c) = ag[1][j];
+                *reinterpret_cast<float4 *>(CZ + row * K + C + c) = hh[j];
+                *reinterpret_cast<float4 *>(CR + row * K + C + c) = hh[j];
+            }
+        }
+
+        // ---- zl = [hz | H] Wz^T + bz,  rl = [hr | H] Wr^T + br
+        f32x4 accz[CT], accr[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float vz = bs[3 * C + ct * 16 + n16], vr = bs[4 * C + ct * 16 + n16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accz[ct][i] = vz, accr[ct][i] = vr;
+        }
+        const float *pz = Ws + (4 * kq) * LDW + n16, *pr = pz + K * LDW, *ph = pr + K * LDW;
+#pragma unroll
+        for (int j = 0; j < 2 * KQ; ++j) {
+            const float4 az4 = j < KQ ? ag[0][j % KQ] : hh[j % KQ];
+            const float4 ar4 = j < KQ ? ag[1][j % KQ] : hh[j % KQ];
+            const float az[4] = {az4.x, az4.y, az4.z, az4.w}, ar[4] = {ar4.x, ar4.y, ar4.z, ar4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    accz[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i], pz[(16 * j + i) * LDW + ct * 16], accz[ct], 0, 0, 0);
+                    accr[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i], pr[(16 * j + i) * LDW + ct * 16], accr[ct], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- accumulator layout -> per-wave LDS tile (one 16x16 block at a time) -> A layout (a lane's own row)
+        float4 hr[KQ], za[KQ];
+        auto to_rows = [&](const f32x4 &acc, float4 &dst) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) T[(4 * kq + i) * TLD + n16] = acc[i];
+            wave_lds_sync();
+            const float *t = T + n16 * TLD + 4 * kq;
+            dst = make_float4(t[0], t[1], t[2], t[3]);
+            wave_lds_sync();                                         // T is rewritten by the next block / tile
+        };
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accz[ct][i] = sigmoid_(accz[ct][i]), accr[ct][i] = sigmoid_(accr[ct][i]);
+            to_rows(accz[ct], za[ct]);
+            to_rows(accr[ct], hr[ct]);                               // hr holds R until multiplied below
+        }
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const int c = 16 * j + 4 * kq;
+            if (rok) {
+                *reinterpret_cast<float4 *>(Z + row * C + c) = za[j];
+                *reinterpret_cast<float4 *>(R + row * C + c) = hr[j];
+            }
+            hr[j] = make_float4(hh[j].x * hr[j].x, hh[j].y * hr[j].y, hh[j].z * hr[j].z, hh[j].w * hr[j].w);
+        }
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            ag[2][j] = load_gate(2, j);
+            if (rok) {
+                *reinterpret_cast<float4 *>(CH + row * K + 16 * j + 4 * kq) = ag[2][j];
+                *reinterpret_cast<float4 *>(CH + row * K + C + 16 * j + 4 * kq) = hr[j];
+            }
+        }
+
+        // ---- hl = [hh | H*R] Wh^T + bh;  Ht = tanh(hl);  Hn = Z*H + (1 - Z)*Ht
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float vh = bs[5 * C + ct * 16 + n16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accr[ct][i] = vh;
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * KQ; ++j) {
+            const float4 a4 = j < KQ ? ag[2][j % KQ] : hr[j % KQ];
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    accr[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], ph[(16 * j + i) * LDW + ct * 16], accr[ct], 0, 0, 0);
+            }
+        }
+        float4 ht[KQ];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accr[ct][i] = tanh_(accr[ct][i]);
+            to_rows(accr[ct], ht[ct]);
+        }
+        if (rok) {
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const int c = 16 * j + 4 * kq;
+                const float4 z = za[j], h = hh[j], t = ht[j];
+                *reinterpret_cast<float4 *>(Ht + row * C + c) = t;
+                *reinterpret_cast<float4 *>(Hn + row * C + c) =
+                    make_float4(z.x * h.x + (1.0f - z.x) * t.x, z.y * h.y + (1.0f - z.y) * t.y,
+                                z.z * h.z + (1.0f - z.z) * t.z, z.w * h.w + (1.0f - z.w) * t.w);
+            }
+        }
+    }
+}
+
+template <int C, int WAVES>
+int launch_fwd16(const float *a3, const float *b3, const float *H, const float *Wz, const float *bz, const float *Wr,
+                 const float *br, const float *Wh, const float *bh, float *CZ, float *CR, float *CH, float *Z, float *R,
+                 float *Ht, float *Hn, int64_t N, float lo, float hi, hipStream_t stream)
+{
+    using S = CellShape16<C, WAVES>;
+    static bool raised = false;
+    if (S::kLds > 64 * 1024 && !raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_fwd16_kernel<C, WAVES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
+        if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_fwd: %s", hipGetErrorString(e));
+        raised = true;
+    }
+    const int64_t tiles = (N + 15) / 16;
+    if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_fwd: too many rows");
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + WAVES - 1) / WAVES, 256 * per_cu);
+    hipLaunchKernelGGL((cell_fused_fwd16_kernel<C, WAVES>), dim3(blocks), dim3(S::kThreads), S::kLds, stream, a3, b3, H, Wz,
+                       bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, (int)tiles);
+    return check_launch("stg_tgcn_cell_fused_fwd");
+}
+
 // ---------------------------------------------------------------------------------------------- backward
 // The backward row-local chain of one TGCN step in one launch (unfused: cell_update_bwd, cell_gates_bwd,
 // cell_prep_bwd of tgcn_cell.hip around three rocBLAS input-gradient GEMMs, whose [N,2C] results dCH, dCZ, dCR
@@ -532,6 +750,12 @@ extern "C" int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const f
     if (!a3 || !b3 || !H || !Wz || !bz || !Wr || !br || !Wh || !bh || !CZ || !CR || !CH || !Z || !R || !Ht || !Hn)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_fwd: NULL pointer argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // measured (tools/microbench_cell.py, C = 64): N = 50 K 83 -> 78 us, 400 K 470 -> 436 us, but 25 K 61 -> 73 us (the
+    // 1024-thread workgroup's weight staging is a fixed cost): 16-row tiles from 40 K rows on
+    if (tuning().cell_rows == 16 || (tuning().cell_rows == 0 && N >= 40000)) {
+        if (C == 64) return launch_fwd16<64, 16>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
+        return launch_fwd16<32, 16>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
+    }
     if (C == 64) return launch_fwd<64, 8>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
     return launch_fwd<32, 4>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
 }

@@ -110,3 +110,27 @@ def test_tgcn_bptt_with_fused_forward_equals_unfused(cuda):
         res.append([loss.detach()] + [p.grad.clone() for p in m.parameters()])
     for a, b in zip(*res):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("N", [1, 15, 16, 17, 4097, 50_000])
+@pytest.mark.parametrize("C", [32, 64])
+def test_sixteen_row_tiles_match_thirty_two_row_tiles(cuda, N, C):
+    """The v_mfma_f32_16x16x4_f32 variant of the forward chain (`cell_rows` = 16): same outputs as the 32-row kernel
+    (operand copies bit-identical, GEMM results to fp32 rounding of a different k order)."""
+    from stgraph_amd import _C
+    from stgraph_amd.nn.pytorch.temporal import cell
+    a3, b3, H, (Wz, Wr, Wh), (bz, br, bh) = _operands(cuda, N, C, N + C)
+    res = []
+    for rows in (16, 32):
+        _C.set_tuning("cell_rows", rows)
+        try:
+            Hn, extra = cell._cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh)
+        finally:
+            _C.set_tuning("cell_rows", 0)
+        res.append((Hn, *extra))
+    names = ("Hn", "CZ", "CR", "CH", "Z", "R", "Ht")
+    for name, a, b in zip(names, *res):
+        if name in ("CZ", "CR"):
+            assert torch.equal(a, b), name
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m, n=name: f"{n}: {m}")
