@@ -733,6 +733,199 @@ int launch_bwd(const float *dHn, const float *Z, const float *H, const float *Ht
     return check_launch("stg_tgcn_cell_fused_bwd");
 }
 
+// ---------------------------------------------------------------------------------------------- backward, 16-row tiles
+// (see cell_fused_fwd16_kernel: v_mfma_f32_16x16x4_f32, lane = (n16, kq), pieces at column 16 j + 4 kq, one 16x16
+// block of a product = one row piece per lane after the LDS transpose; LDB = 2C + 4 for conflict-free B reads)
+template <int C, int WAVES>
+struct CellBwdShape16 {
+    static constexpr int K2 = 2 * C, KQ = C / 16, HB = C / 16, LDB = K2 + 4, TLD = 17;
+    static constexpr int kThreads = WAVES * kWave;
+    static constexpr int kWeights = 3 * C * LDB;              // floats
+    static constexpr int kBias = 3 * C;                       // b3
+    static constexpr int kTile = 16 * TLD;
+    static constexpr size_t kLds = sizeof(float) * (size_t)(kWeights + kBias + WAVES * kTile);
+};
+
+template <int C, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd16_kernel(
+    const float *__restrict__ dHn, const float *__restrict__ Z, const float *__restrict__ H,
+    const float *__restrict__ Ht, const float *__restrict__ R, const float *__restrict__ a3,
+    const float *__restrict__ b3, const float *__restrict__ Wz, const float *__restrict__ Wr,
+    const float *__restrict__ Wh, float *__restrict__ dhl_o, float *__restrict__ dzl_o, float *__restrict__ drl_o,
+    float *__restrict__ da3, float *__restrict__ dH_o, int64_t N, float lo, float hi, int num_tiles)
+{
+    using S = CellBwdShape16<C, WAVES>;
+    constexpr int KQ = S::KQ, HB = S::HB, LDB = S::LDB, TLD = S::TLD, NTHR = S::kThreads;
+    extern __shared__ float lds[];
+    float *Ws = lds;                                   // Wz | Wr | Wh, each [C][LDB]
+    float *bs = lds + S::kWeights;                     // b3
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int n16 = lane & 15, kq = lane >> 4;
+    float *T = bs + S::kBias + wave * S::kTile;
+
+    {
+        const float *src[3] = {Wz, Wr, Wh};
+        constexpr int total4 = C * 2 * C / 4;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            float *dst = Ws + g * C * LDB;
+            for (int i4 = threadIdx.x; i4 < total4; i4 += NTHR) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(src[g] + (int64_t)i4 * 4);
+                const int i = i4 * 4, k = i / (2 * C), n = i - k * 2 * C;       // W[k][n .. n+3]
+                *reinterpret_cast<float4 *>(dst + k * LDB + n) = w4;            // LDB % 4 == 0: aligned
+            }
+        }
+        for (int i = threadIdx.x; i < 3 * C; i += NTHR) bs[i] = b3[i];
+    }
+    __syncthreads();
+
+    const int total = gridDim.x * WAVES;
+    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < num_tiles; tile += total) {
+        const int64_t row = (int64_t)tile * 16 + n16;
+        const bool rok = row < N;
+        auto ldrow = [&](const float *p, int j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rok) v = *reinterpret_cast<const float4 *>(p + row * C + 16 * j + 4 * kq);
+            return v;
+        };
+        // 16x16 block of an accumulator -> the row piece (columns 16 blk + 4 kq .. + 3) of this lane's row
+        auto to_rows = [&](const f32x4 &acc, float4 &dst) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) T[(4 * kq + i) * TLD + n16] = acc[i];
+            wave_lds_sync();
+            const float *t = T + n16 * TLD + 4 * kq;
+            dst = make_float4(t[0], t[1], t[2], t[3]);
+            wave_lds_sync();
+        };
+        auto store_da3 = [&](int g, int blk, const float4 &piece) {
+            if (!rok) return;
+            const int c = g * C + 16 * blk + 4 * kq;
+            const float4 a = *reinterpret_cast<const float4 *>(a3 + row * 3 * C + c);
+            const float4 b = *reinterpret_cast<const float4 *>(bs + c);
+            const float v0 = a.x + b.x, v1 = a.y + b.y, v2 = a.z + b.z, v3 = a.w + b.w;
+            float4 o;
+            o.x = (v0 >= lo && v0 <= hi) ? piece.x : 0.f;
+            o.y = (v1 >= lo && v1 <= hi) ? piece.y : 0.f;
+            o.z = (v2 >= lo && v2 <= hi) ? piece.z : 0.f;
+            o.w = (v3 >= lo && v3 <= hi) ? piece.w : 0.f;
+            *reinterpret_cast<float4 *>(da3 + row * 3 * C + c) = o;
+        };
+        // acc[b] = A (row pieces, K = C) x W_g[:, half * C + 16 b ..]
+        auto gemm = [&](const float4 (&A)[KQ], int g, int half, f32x4 (&acc)[HB]) {
+            const float *pw = Ws + g * C * LDB + (4 * kq) * LDB + half * C + n16;
+#pragma unroll
+            for (int b = 0; b < HB; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[b][i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const float av[4] = {A[j].x, A[j].y, A[j].z, A[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int b = 0; b < HB; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], pw[(16 * j + i) * LDB + b * 16], acc[b], 0, 0, 0);
+                }
+            }
+        };
+
+        // ---- update backward (row pieces)
+        float4 dhl[KQ], dHa[KQ];
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const float4 g = ldrow(dHn, j), z = ldrow(Z, j), t = ldrow(Ht, j);
+            const float4 h = ldrow(H, j);
+            dhl[j] = make_float4((g.x * (1.0f - z.x)) * (1.0f - t.x * t.x), (g.y * (1.0f - z.y)) * (1.0f - t.y * t.y),
+                                 (g.z * (1.0f - z.z)) * (1.0f - t.z * t.z), (g.w * (1.0f - z.w)) * (1.0f - t.w * t.w));
+            const float4 dz = make_float4((g.x * (h.x - t.x)) * (z.x * (1.0f - z.x)), (g.y * (h.y - t.y)) * (z.y * (1.0f - z.y)),
+                                          (g.z * (h.z - t.z)) * (z.z * (1.0f - z.z)), (g.w * (h.w - t.w)) * (z.w * (1.0f - z.w)));
+            dHa[j] = make_float4(g.x * z.x, g.y * z.y, g.z * z.z, g.w * z.w);
+            if (rok) {
+                *reinterpret_cast<float4 *>(dhl_o + row * C + 16 * j + 4 * kq) = dhl[j];
+                *reinterpret_cast<float4 *>(dzl_o + row * C + 16 * j + 4 * kq) = dz;
+            }
+        }
+
+        f32x4 acc[HB];
+        float4 piece;
+        // ---- dCH = dhl Wh: d(hh) -> da3[:, 2C..];  dHR -> drl, dH
+        gemm(dhl, 2, 0, acc);
+#pragma unroll
+        for (int blk = 0; blk < HB; ++blk) {
+            to_rows(acc[blk], piece);
+            store_da3(2, blk, piece);
+        }
+        gemm(dhl, 2, 1, acc);
+        float4 drl[KQ];
+#pragma unroll
+        for (int blk = 0; blk < HB; ++blk) {
+            to_rows(acc[blk], piece);                                            // dHR, columns 16 blk ..
+            const float4 r = ldrow(R, blk), h = ldrow(H, blk), d = piece;
+            drl[blk] = make_float4((d.x * h.x) * (r.x * (1.0f - r.x)), (d.y * h.y) * (r.y * (1.0f - r.y)),
+                                   (d.z * h.z) * (r.z * (1.0f - r.z)), (d.w * h.w) * (r.w * (1.0f - r.w)));
+            dHa[blk] = make_float4(dHa[blk].x + d.x * r.x, dHa[blk].y + d.y * r.y, dHa[blk].z + d.z * r.z,
+                                   dHa[blk].w + d.w * r.w);
+            if (rok) *reinterpret_cast<float4 *>(drl_o + row * C + 16 * blk + 4 * kq) = drl[blk];
+        }
+        // ---- dCZ = dzl Wz,  dCR = drl Wr: d(hz), d(hr) -> da3;  second halves -> dH, dCZ's first, then dCR's
+        {
+            float4 dzl[KQ];
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) dzl[j] = ldrow(dzl_o, j);              // this lane's own stores, above
+            gemm(dzl, 0, 0, acc);
+#pragma unroll
+            for (int blk = 0; blk < HB; ++blk) {
+                to_rows(acc[blk], piece);
+                store_da3(0, blk, piece);
+            }
+            gemm(dzl, 0, 1, acc);
+#pragma unroll
+            for (int blk = 0; blk < HB; ++blk) {
+                to_rows(acc[blk], piece);
+                float4 &d = dHa[blk];
+                d = make_float4(d.x + piece.x, d.y + piece.y, d.z + piece.z, d.w + piece.w);
+            }
+        }
+        gemm(drl, 1, 0, acc);
+#pragma unroll
+        for (int blk = 0; blk < HB; ++blk) {
+            to_rows(acc[blk], piece);
+            store_da3(1, blk, piece);
+        }
+        gemm(drl, 1, 1, acc);
+#pragma unroll
+        for (int blk = 0; blk < HB; ++blk) {
+            to_rows(acc[blk], piece);
+            const float4 y = piece, d = dHa[blk];
+            if (rok)
+                *reinterpret_cast<float4 *>(dH_o + row * C + 16 * blk + 4 * kq) =
+                    make_float4(d.x + y.x, d.y + y.y, d.z + y.z, d.w + y.w);
+        }
+    }
+}
+
+template <int C, int WAVES>
+int launch_bwd16(const float *dHn, const float *Z, const float *H, const float *Ht, const float *R, const float *a3,
+                 const float *b3, const float *Wz, const float *Wr, const float *Wh, float *dhl, float *dzl, float *drl,
+                 float *da3, float *dH, int64_t N, float lo, float hi, hipStream_t stream)
+{
+    using S = CellBwdShape16<C, WAVES>;
+    static bool raised = false;
+    if (S::kLds > 64 * 1024 && !raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_bwd16_kernel<C, WAVES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
+        if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_bwd: %s", hipGetErrorString(e));
+        raised = true;
+    }
+    const int64_t tiles = (N + 15) / 16;
+    if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_bwd: too many rows");
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + WAVES - 1) / WAVES, 256 * per_cu);
+    hipLaunchKernelGGL((cell_fused_bwd16_kernel<C, WAVES>), dim3(blocks), dim3(S::kThreads), S::kLds, stream, dHn, Z, H, Ht, R,
+                       a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, (int)tiles);
+    return check_launch("stg_tgcn_cell_fused_bwd");
+}
+
 }  // namespace
 }  // namespace stg
 
@@ -772,6 +965,12 @@ extern "C" int stg_tgcn_cell_fused_bwd(const float *dHn, const float *Z, const f
     if (!dHn || !Z || !H || !Ht || !R || !a3 || !b3 || !Wz || !Wr || !Wh || !dhl || !dzl || !drl || !da3 || !dH)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_bwd: NULL pointer argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // measured (tools/microbench_cell.py): C = 32, N = 50 K: 34.8 -> 28.4 us; C = 64: N = 400 K 552 -> 495 us, but
+    // N = 50 K 81 -> 85 us (59 spilled registers at the 128-register budget of 16-wave workgroups) and N = 25 K 43 -> 56
+    if (tuning().cell_rows == 16 || (tuning().cell_rows == 0 && ((C == 32 && N >= 40000) || N >= 200000))) {
+        if (C == 64) return launch_bwd16<64, 16>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
+        return launch_bwd16<32, 16>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
+    }
     if (C == 64) return launch_bwd<64, 8>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
     return launch_bwd<32, 4>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
 }

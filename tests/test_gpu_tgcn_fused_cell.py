@@ -134,3 +134,28 @@ def test_sixteen_row_tiles_match_thirty_two_row_tiles(cuda, N, C):
             assert torch.equal(a, b), name
         else:
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m, n=name: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("N", [1, 15, 16, 17, 4097, 50_000])
+@pytest.mark.parametrize("C", [32, 64])
+def test_sixteen_row_backward_matches_thirty_two_row_backward(cuda, N, C):
+    from stgraph_amd import _C
+    from stgraph_amd.nn.pytorch.temporal import cell
+    a3, b3, H, (Wz, Wr, Wh), (bz, br, bh) = _operands(cuda, N, C, 11 * N + C)
+    Hn, (CZ, CR, CH, Z, R, Ht) = cell._cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh)
+    dHn = torch.randn(N, C, device=cuda)
+    res = []
+    for rows in (16, 32):
+        _C.set_tuning("cell_rows", rows)
+        try:
+            da3, dH, pairs = cell._cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht)
+        finally:
+            _C.set_tuning("cell_rows", 0)
+        res.append((da3, dH, pairs[0][0], pairs[1][0], pairs[2][0]))
+    for name, a, b in zip(("da3", "dH", "dzl", "drl", "dhl"), *res):
+        if name in ("dzl", "dhl"):
+            assert torch.equal(a, b), name                       # elementwise only
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m, n=name: f"{n}: {m}")
+    if N > 3:
+        assert float(res[0][0][0, :5].abs().max()) == 0.0 and float(res[0][0][2, C + 1].abs()) == 0.0

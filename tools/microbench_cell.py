@@ -21,19 +21,25 @@ def main():
         a3, b3, H = r(N, 3 * C), r(3 * C), r(N, C)
         Ws = [r(C, 2 * C) * 0.2 for _ in range(3)]
         bs = [r(C) for _ in range(3)]
+        dHn = r(N, C)
         for rows in (32, 16, 32, 16):
             _C.set_tuning("cell_rows", rows)
             for _ in range(3):
-                cell._cell_forward(a3, b3, H, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2])
-            ts = []
+                Hn, (CZ, CR, CH, Z, R, Ht) = cell._cell_forward(a3, b3, H, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2])
+                cell._cell_backward(dHn, a3, b3, H, Ws[0], Ws[1], Ws[2], CZ, CR, CH, Z, R, Ht)
+            tf, tb = [], []
             for _ in range(20):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 a.record()
                 cell._cell_forward(a3, b3, H, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2])
                 b.record()
+                cell._cell_backward(dHn, a3, b3, H, Ws[0], Ws[1], Ws[2], CZ, CR, CH, Z, R, Ht)
+                c.record()
                 torch.cuda.synchronize()
-                ts.append(a.elapsed_time(b))
-            print(json.dumps({"N": N, "C": C, "tile_rows": rows, "us": round(float(np.median(ts)) * 1e3, 1)}), flush=True)
+                tf.append(a.elapsed_time(b))
+                tb.append(b.elapsed_time(c))
+            print(json.dumps({"N": N, "C": C, "tile_rows": rows, "fwd_us": round(float(np.median(tf)) * 1e3, 1),
+                              "bwd_us": round(float(np.median(tb)) * 1e3, 1)}), flush=True)
     _C.set_tuning("cell_rows", 0)
 
 
