@@ -943,10 +943,10 @@ extern "C" int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const f
     if (!a3 || !b3 || !H || !Wz || !bz || !Wr || !br || !Wh || !bh || !CZ || !CR || !CH || !Z || !R || !Ht || !Hn)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_fwd: NULL pointer argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // measured (tools/microbench_cell.py, C = 64): N = 50 K 83 -> 78 us, 400 K 470 -> 436 us, but 25 K 61 -> 73 us (the
-    // 1024-thread workgroup's weight staging is a fixed cost): 16-row tiles from 40 K rows on
+    // measured (tools/microbench_cell.py, C = 64, 12-wave workgroups): N = 50 K 83 -> 75 us, 400 K 421 -> 384 us, 25 K
+    // 61 -> 62 us (with 16 waves: 78 / 436 / 73): 16-row tiles from 40 K rows on
     if (tuning().cell_rows == 16 || (tuning().cell_rows == 0 && N >= 40000)) {
-        if (C == 64) return launch_fwd16<64, 16>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
+        if (C == 64) return launch_fwd16<64, 12>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
         return launch_fwd16<32, 16>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
     }
     if (C == 64) return launch_fwd<64, 8>(a3, b3, H, Wz, bz, Wr, br, Wh, bh, CZ, CR, CH, Z, R, Ht, Hn, N, lo, hi, st);
@@ -965,10 +965,10 @@ extern "C" int stg_tgcn_cell_fused_bwd(const float *dHn, const float *Z, const f
     if (!dHn || !Z || !H || !Ht || !R || !a3 || !b3 || !Wz || !Wr || !Wh || !dhl || !dzl || !drl || !da3 || !dH)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_bwd: NULL pointer argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // measured (tools/microbench_cell.py): C = 32, N = 50 K: 34.8 -> 28.4 us; C = 64: N = 400 K 552 -> 495 us, but
-    // N = 50 K 81 -> 85 us (59 spilled registers at the 128-register budget of 16-wave workgroups) and N = 25 K 43 -> 56
-    if (tuning().cell_rows == 16 || (tuning().cell_rows == 0 && ((C == 32 && N >= 40000) || N >= 200000))) {
-        if (C == 64) return launch_bwd16<64, 16>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
+    // measured (tools/microbench_cell.py): C = 64 with 12-wave workgroups (168 registers, no spills; 16 waves spill 59
+    // and lose): N = 25 K 43 -> 39 us, 50 K 82 -> 67 us, 400 K 570 -> 404 us; C = 32 (16 waves): 50 K 34.8 -> 28.4 us
+    if (tuning().cell_rows == 16 || (tuning().cell_rows == 0 && N >= 20000)) {
+        if (C == 64) return launch_bwd16<64, 12>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
         return launch_bwd16<32, 16>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
     }
     if (C == 64) return launch_bwd<64, 8>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
