@@ -24,6 +24,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kHeadF = 32;            // width of y: one 32-column MFMA block
+constexpr int64_t kHead16MinRows = 4096;   // N = 10 K .. 400 K: never slower, backward up to -24 % (N = 50 K: 21.4 -> 16.3 us)
 
 // row of accumulator element i for lane half kh (v_mfma_f32_32x32x2_f32 C/D layout)
 __device__ __forceinline__ int acc_row(int i, int kh) { return (i & 3) + 8 * (i >> 2) + 4 * kh; }
@@ -113,6 +114,169 @@ __global__ __launch_bounds__(kBlock) void head_fwd_kernel(
     const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lsum), 31)) +
                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lsum), 63));
     if (lane == 0) partial[tile] = tot;
+}
+
+// ---- 16-row tiles (v_mfma_f32_16x16x4_f32): twice the waves at half the work each -- these kernels are one tile per
+// wave and latency bound, so more waves per CU hide more of it.  lane = (n16 = lane & 15, kq = lane >> 4); A piece at
+// column 16 j + 4 kq; accumulator element i of 16-column block ct: row 4 kq + i, column 16 ct + n16.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// sum over each DPP row of 16 lanes; valid in lanes 15, 31, 47, 63
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    return v;
+}
+
+template <int C, bool OUT = true>
+__global__ __launch_bounds__(kBlock) void head_fwd16_kernel(
+    const float *__restrict__ h, const float *__restrict__ W1, const float *__restrict__ b1,
+    const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ target,
+    float *__restrict__ r_out, float *__restrict__ y, float *__restrict__ y_out, float *__restrict__ partial,
+    int64_t N, int num_tiles)
+{
+    constexpr int KQ = C / 16, CT = kHeadF / 16;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= num_tiles) return;                                   // whole wave
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int64_t row = (int64_t)tile * 16 + n16;
+    const bool rok = row < N;
+
+    f32x4 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const float bias = b1[ct * 16 + n16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[ct][i] = bias;
+    }
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+        const int k0 = 16 * j + 4 * kq;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rok) {
+            a = *reinterpret_cast<const float4 *>(h + row * C + k0);
+            a.x = a.x < 0.f ? 0.f : a.x;
+            a.y = a.y < 0.f ? 0.f : a.y;
+            a.z = a.z < 0.f ? 0.f : a.z;
+            a.w = a.w < 0.f ? 0.f : a.w;
+            *reinterpret_cast<float4 *>(r_out + row * C + k0) = a;
+        }
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float4 b = *reinterpret_cast<const float4 *>(W1 + (ct * 16 + n16) * C + k0);   // B[k][n] = W1[n][k]
+            const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc[ct], 0, 0, 0);
+        }
+    }
+
+    float w2[CT], bias2 = 0.f, lsum = 0.f;
+    if constexpr (OUT) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w2[ct] = W2[ct * 16 + n16];
+        bias2 = b2[0];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t orow = (int64_t)tile * 16 + 4 * kq + i;
+        const bool ok = orow < N;
+        if (ok) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) y[orow * kHeadF + ct * 16 + n16] = acc[ct][i];
+        }
+        if constexpr (OUT) {
+            float p = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) p = p + acc[ct][i] * w2[ct];
+            const float s = row16_sum(p);                            // every lane takes part
+            if (n16 == 15 && ok) {
+                const float yo = s + bias2;
+                y_out[orow] = yo;
+                const float d = yo - target[orow];
+                lsum = lsum + d * d;
+            }
+        }
+    }
+    if constexpr (OUT) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tot = tot + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lsum), 16 * q + 15));
+        if (lane == 0) partial[tile] = tot;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void head_bwd16_kernel(
+    const float *__restrict__ g_loss, const float *__restrict__ g_y, const float *__restrict__ g_yout,
+    const float *__restrict__ h, const float *__restrict__ y_out, const float *__restrict__ target,
+    const float *__restrict__ W1, const float *__restrict__ W2, float *__restrict__ dh, float *__restrict__ dyt,
+    float *__restrict__ dyo, int64_t N, float two_over_n, int num_tiles)
+{
+    constexpr int KQ = kHeadF / 16, CT = C / 16;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= num_tiles) return;                                   // whole wave
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int64_t row = (int64_t)tile * 16 + n16;
+    const bool rok = row < N;
+
+    float d = 0.f;
+    if (rok) {
+        if (g_loss) d = two_over_n * g_loss[0] * (y_out[row] - target[row]);
+        if (g_yout) d = d + g_yout[row];
+        if (kq == 0 && dyo) dyo[row] = d;
+    }
+
+    f32x4 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[ct][i] = 0.f;
+
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+        const int k0 = 16 * j + 4 * kq;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_loss || g_yout) {                                     // (wave-uniform) the y_out branch of the head
+            const float4 w = *reinterpret_cast<const float4 *>(W2 + k0);
+            a = make_float4(d * w.x, d * w.y, d * w.z, d * w.w);
+        }
+        if (rok) {
+            if (g_y) {
+                const float4 g = *reinterpret_cast<const float4 *>(g_y + row * kHeadF + k0);
+                a = make_float4(g.x + a.x, g.y + a.y, g.z + a.z, g.w + a.w);
+            }
+            *reinterpret_cast<float4 *>(dyt + row * kHeadF + k0) = a;
+        } else {
+            a = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float b = W1[(k0 + i) * C + ct * 16 + n16];   // B[k][n] = W1[k][n]
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b, acc[ct], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t orow = (int64_t)tile * 16 + 4 * kq + i;
+            if (orow < N) {
+                const int64_t at = orow * C + ct * 16 + n16;
+                dh[at] = h[at] <= 0.f ? 0.f : acc[ct][i];           // threshold_backward
+            }
+        }
+    }
 }
 
 // loss = (sum of the tile partials, in a fixed order) / N
@@ -278,6 +442,10 @@ __global__ __launch_bounds__(kBlock) void link_bwd_nodes_kernel(const float *__r
 }
 
 inline int head_tiles(int64_t N) { return (int)((N + 31) / 32); }
+inline int head_tiles16(int64_t N) { return (int)((N + 15) / 16); }
+// 16-row tiles from this many rows on ("cell_rows" forces either): measured in tools/microbench_head.py
+inline bool head_rows16(int64_t N) { return tuning().cell_rows == 16 || (tuning().cell_rows == 0 && N >= kHead16MinRows); }
+
 
 }  // namespace
 }  // namespace stg
@@ -289,7 +457,7 @@ extern "C" int stg_tgcn_head_supported(int32_t C, int32_t F, int32_t O)
 
 extern "C" size_t stg_tgcn_head_workspace_bytes(int64_t N)
 {
-    return N <= 0 ? 0 : sizeof(float) * (size_t)stg::head_tiles(N);
+    return N <= 0 ? 0 : sizeof(float) * (size_t)stg::head_tiles16(N);
 }
 
 extern "C" int stg_tgcn_head_fwd(const float *h, const float *W1, const float *b1, const float *W2, const float *b2,
@@ -310,23 +478,23 @@ extern "C" int stg_tgcn_head_fwd(const float *h, const float *W1, const float *b
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_head_fwd: NULL pointer argument");
     if (workspace_bytes < stg_tgcn_head_workspace_bytes(N))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_head_fwd: workspace too small");
-    const int tiles = head_tiles(N);
+    const bool r16 = head_rows16(N);
+    const int tiles = r16 ? head_tiles16(N) : head_tiles(N);
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     float *partial = static_cast<float *>(workspace);
+#define STG_HEAD_FWD(CC)                                                                                               \
+    if (r16)                                                                                                           \
+        hipLaunchKernelGGL((head_fwd16_kernel<CC, true>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, W2, b2,    \
+                           target, r, y, y_out, partial, N, tiles);                                                    \
+    else                                                                                                               \
+        hipLaunchKernelGGL((head_fwd_kernel<CC, true>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, W2, b2,      \
+                           target, r, y, y_out, partial, N, tiles)
     switch (C) {
-        case 32:
-            hipLaunchKernelGGL(head_fwd_kernel<32>, dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, W2, b2, target, r, y,
-                               y_out, partial, N, tiles);
-            break;
-        case 64:
-            hipLaunchKernelGGL(head_fwd_kernel<64>, dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, W2, b2, target, r, y,
-                               y_out, partial, N, tiles);
-            break;
-        default:
-            hipLaunchKernelGGL(head_fwd_kernel<128>, dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, W2, b2, target, r,
-                               y, y_out, partial, N, tiles);
-            break;
+        case 32: STG_HEAD_FWD(32); break;
+        case 64: STG_HEAD_FWD(64); break;
+        default: STG_HEAD_FWD(128); break;
     }
+#undef STG_HEAD_FWD
     hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(kBlock), 0, stream, partial, tiles, 1.0f / (float)N, loss);
     return check_launch("stg_tgcn_head_fwd");
 }
@@ -343,23 +511,23 @@ extern "C" int stg_tgcn_head_bwd(const float *g_loss, const float *g_y, const fl
     if (!h || !y_out || !target || !W1 || !W2 || !dh || !dyt || !dyo)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_head_bwd: NULL pointer argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int tiles = head_tiles(N);
+    const bool r16 = head_rows16(N);
+    const int tiles = r16 ? head_tiles16(N) : head_tiles(N);
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const float two_over_n = 2.0f / (float)N;
+#define STG_HEAD_BWD(CC)                                                                                               \
+    if (r16)                                                                                                           \
+        hipLaunchKernelGGL(head_bwd16_kernel<CC>, dim3(blocks), dim3(kBlock), 0, stream, g_loss, g_y, g_yout, h, y_out, \
+                           target, W1, W2, dh, dyt, dyo, N, two_over_n, tiles);                                        \
+    else                                                                                                               \
+        hipLaunchKernelGGL(head_bwd_kernel<CC>, dim3(blocks), dim3(kBlock), 0, stream, g_loss, g_y, g_yout, h, y_out,  \
+                           target, W1, W2, dh, dyt, dyo, N, two_over_n, tiles)
     switch (C) {
-        case 32:
-            hipLaunchKernelGGL(head_bwd_kernel<32>, dim3(blocks), dim3(kBlock), 0, stream, g_loss, g_y, g_yout, h, y_out,
-                               target, W1, W2, dh, dyt, dyo, N, two_over_n, tiles);
-            break;
-        case 64:
-            hipLaunchKernelGGL(head_bwd_kernel<64>, dim3(blocks), dim3(kBlock), 0, stream, g_loss, g_y, g_yout, h, y_out,
-                               target, W1, W2, dh, dyt, dyo, N, two_over_n, tiles);
-            break;
-        default:
-            hipLaunchKernelGGL(head_bwd_kernel<128>, dim3(blocks), dim3(kBlock), 0, stream, g_loss, g_y, g_yout, h, y_out,
-                               target, W1, W2, dh, dyt, dyo, N, two_over_n, tiles);
-            break;
+        case 32: STG_HEAD_BWD(32); break;
+        case 64: STG_HEAD_BWD(64); break;
+        default: STG_HEAD_BWD(128); break;
     }
+#undef STG_HEAD_BWD
     return check_launch("stg_tgcn_head_bwd");
 }
 
@@ -383,23 +551,23 @@ extern "C" int stg_link_head_fwd(const float *h, const float *W1, const float *b
     if (workspace_bytes < stg_link_head_workspace_bytes(M))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_head_fwd: workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int tiles = head_tiles(N);
+    const bool r16 = head_rows16(N);
+    const int tiles = r16 ? head_tiles16(N) : head_tiles(N);
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     float *partial = static_cast<float *>(workspace);
+#define STG_LINK_FWD(CC)                                                                                               \
+    if (r16)                                                                                                           \
+        hipLaunchKernelGGL((head_fwd16_kernel<CC, false>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, nullptr,  \
+                           nullptr, nullptr, r, y, nullptr, nullptr, N, tiles);                                        \
+    else                                                                                                               \
+        hipLaunchKernelGGL((head_fwd_kernel<CC, false>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, nullptr,    \
+                           nullptr, nullptr, r, y, nullptr, nullptr, N, tiles)
     switch (C) {
-        case 32:
-            hipLaunchKernelGGL((head_fwd_kernel<32, false>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, nullptr,
-                               nullptr, nullptr, r, y, nullptr, nullptr, N, tiles);
-            break;
-        case 64:
-            hipLaunchKernelGGL((head_fwd_kernel<64, false>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, nullptr,
-                               nullptr, nullptr, r, y, nullptr, nullptr, N, tiles);
-            break;
-        default:
-            hipLaunchKernelGGL((head_fwd_kernel<128, false>), dim3(blocks), dim3(kBlock), 0, stream, h, W1, b1, nullptr,
-                               nullptr, nullptr, r, y, nullptr, nullptr, N, tiles);
-            break;
+        case 32: STG_LINK_FWD(32); break;
+        case 64: STG_LINK_FWD(64); break;
+        default: STG_LINK_FWD(128); break;
     }
+#undef STG_LINK_FWD
     const int eblocks = (int)((M + 31) / 32);
     hipLaunchKernelGGL(link_decode_bce_kernel, dim3(eblocks), dim3(kBlock), 0, stream, y, src, dst, target, logits, partial, M);
     hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(kBlock), 0, stream, partial, eblocks, 1.0f / (float)M, loss);
@@ -421,21 +589,21 @@ extern "C" int stg_link_head_bwd(const float *g_loss, const float *g_y, const fl
                        target, row_ptr, other, eid, dy, N, 1.0f / (float)M);
     // dh = (h > 0) (dy W1), dyt = dy: the relu -> Linear backward is head_bwd_kernel without its y_out branch (W2 is
     // not read then)
-    const int tiles = head_tiles(N);
+    const bool r16 = head_rows16(N);
+    const int tiles = r16 ? head_tiles16(N) : head_tiles(N);
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+#define STG_LINK_BWD(CC)                                                                                               \
+    if (r16)                                                                                                           \
+        hipLaunchKernelGGL(head_bwd16_kernel<CC>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, dy, nullptr, h,      \
+                           nullptr, nullptr, W1, nullptr, dh, dyt, nullptr, N, 0.f, tiles);                            \
+    else                                                                                                               \
+        hipLaunchKernelGGL(head_bwd_kernel<CC>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, dy, nullptr, h, nullptr, \
+                           nullptr, W1, nullptr, dh, dyt, nullptr, N, 0.f, tiles)
     switch (C) {
-        case 32:
-            hipLaunchKernelGGL(head_bwd_kernel<32>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, dy, nullptr, h, nullptr,
-                               nullptr, W1, nullptr, dh, dyt, nullptr, N, 0.f, tiles);
-            break;
-        case 64:
-            hipLaunchKernelGGL(head_bwd_kernel<64>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, dy, nullptr, h, nullptr,
-                               nullptr, W1, nullptr, dh, dyt, nullptr, N, 0.f, tiles);
-            break;
-        default:
-            hipLaunchKernelGGL(head_bwd_kernel<128>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, dy, nullptr, h, nullptr,
-                               nullptr, W1, nullptr, dh, dyt, nullptr, N, 0.f, tiles);
-            break;
+        case 32: STG_LINK_BWD(32); break;
+        case 64: STG_LINK_BWD(64); break;
+        default: STG_LINK_BWD(128); break;
     }
+#undef STG_LINK_BWD
     return check_launch("stg_link_head_bwd");
 }

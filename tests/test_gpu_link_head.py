@@ -46,17 +46,20 @@ NAMES = ("y", "loss", "dh", "dW1", "db1")
 
 @pytest.mark.parametrize("N,M", [(1, 1), (33, 7), (1000, 5000), (25_000, 20_000)])
 @pytest.mark.parametrize("C", [32, 64, 128])
-@pytest.mark.parametrize("defer", [True, False])
-def test_fused_link_head_matches_torch_composition(cuda, N, M, C, defer):
+@pytest.mark.parametrize("defer,rows", [(True, 32), (False, 32), (True, 16)])
+def test_fused_link_head_matches_torch_composition(cuda, N, M, C, defer, rows):
+    from stgraph_amd import _C
     from stgraph_amd.nn import functional as SF
     ops = _operands(cuda, N, C, M, 3 * N + C + M)
     assert SF.link_head_usable(*ops[:5])
     SF.set_deferred_weight_grads(defer)
+    _C.set_tuning("cell_rows", rows)
     try:
         got = _run(SF.link_head, ops, 1.0 / 21)
         again = _run(SF.link_head, ops, 1.0 / 21)
     finally:
         SF.set_deferred_weight_grads(True)
+        _C.set_tuning("cell_rows", 0)
     want = _run(_composition, ops, 1.0 / 21)
     want64 = _run(_composition, [t.double() if t.is_floating_point() else t for t in ops], 1.0 / 21)
     for name, a, a2, b, c in zip(NAMES, got, again, want, want64):
@@ -127,7 +130,9 @@ def test_dynamic_training_epochs_same_with_and_without_the_fused_head(cuda):
             G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False)
             torch.manual_seed(4)
             model = temporal.DynamicSTGraphTGCN(feat, hid).to(cuda)
-            opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+            # plain SGD: parameter differences then scale with gradient differences (Adam's normalised step turns
+            # rounding noise on near-zero gradients into lr-sized differences)
+            opt = torch.optim.SGD(model.parameters(), lr=1e-2)
             bucket = temporal.GradBucket(model.parameters())
             losses = []
             for ep in range(2):
