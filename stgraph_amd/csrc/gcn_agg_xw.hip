@@ -24,12 +24,13 @@
 namespace stg {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kXwRows = 64;
+constexpr int kXwRowsMax = 64;
 constexpr bool kXwWide = false;      // measured (TGCN cfg4, Fin = 32): 8-wave workgroups 39 us vs 35 us with 4
 
 // WAVES per workgroup: 4, or 8 when a row takes 8+ lanes (then 4 waves would need several passes over the 64-row
 // tile, one after the other; 8 waves halve that chain and put twice the gathers in flight per tile).
-template <int LOG2G, bool HAS_EW, int WAVES>
+// kXwRows rows per workgroup: 64, or 32 ("xw_rows") -- twice the workgroups at half the tile each.
+template <int LOG2G, bool HAS_EW, int WAVES, int kXwRows = 64>
 __global__ __launch_bounds__(WAVES * kWave) void gcn_agg_xw_kernel(
     const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
     const float *__restrict__ ew_edge, const float *__restrict__ W, float *__restrict__ out,
@@ -178,7 +179,9 @@ extern "C" int stg_gcn_agg_transform(const float *x, const float *norm_row, cons
     if (Fin % 4 != 0 || Fin < 16 || Fin > 256 || Fout % 32 != 0)
         return fail(STG_ERR_UNSUPPORTED,
                     "stg_gcn_agg_transform: needs Fin %% 4 == 0, 16 <= Fin <= 256, Fout %% 32 == 0 (got %d -> %d)", Fin, Fout);
-    const size_t lds = sizeof(float) * ((size_t)kXwRows * (Fin + 1) + (size_t)Fin * Fout);
+    // measured (tools/microbench_xw.py): N = 1M / E = 16M: 456 -> 423 us with 32-row workgroups, N = 50 K: equal
+    const int rows = tuning().xw_rows == 32 || (tuning().xw_rows == 0 && N >= 400000) ? 32 : 64;
+    const size_t lds = sizeof(float) * ((size_t)rows * (Fin + 1) + (size_t)Fin * Fout);
     if (lds > 64 * 1024)
         return fail(STG_ERR_UNSUPPORTED, "stg_gcn_agg_transform: W (%d x %d) does not fit the 64 KB LDS budget", Fin, Fout);
     if (N == 0) return 0;
@@ -189,12 +192,21 @@ extern "C" int stg_gcn_agg_transform(const float *x, const float *norm_row, cons
     if (align % 16 != 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg_transform: operands must be 16-byte aligned");
     const int lanes = Fin / 4;
     const int log2g = ilog2_ceil(lanes);
-    const unsigned blocks = (unsigned)(((int64_t)N + kXwRows - 1) / kXwRows);
+    const unsigned blocks = (unsigned)(((int64_t)N + rows - 1) / rows);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define STG_XW_(LG, WVS)                                                                                           \
     {                                                                                                          \
         constexpr int WV = WVS;                                                                                \
-        if (ew_edge)                                                                                           \
+        if (rows == 32) {                                                                                      \
+            if (ew_edge)                                                                                       \
+                hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, true, WV, 32>), dim3(blocks), dim3(WV * kWave), lds, st, x, \
+                                   norm_row, norm_col_edge, ew_edge, W, out, P_out, row_offsets, column_indices, \
+                                   node_ids, N, Fin, Fout);                                                    \
+            else                                                                                               \
+                hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, false, WV, 32>), dim3(blocks), dim3(WV * kWave), lds, st, x, \
+                                   norm_row, norm_col_edge, ew_edge, W, out, P_out, row_offsets, column_indices, \
+                                   node_ids, N, Fin, Fout);                                                    \
+        } else if (ew_edge)                                                                                    \
             hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, true, WV>), dim3(blocks), dim3(WV * kWave), lds, st, x,  \
                                norm_row, norm_col_edge, ew_edge, W, out, P_out, row_offsets, column_indices,   \
                                node_ids, N, Fin, Fout);                                                        \

@@ -60,6 +60,11 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().gcn_long_threshold = value;
         return 0;
     }
+    if (!std::strcmp(key, "xw_rows")) {
+        if (value != 0 && value != 32 && value != 64) return fail(STG_ERR_INVALID_ARGUMENT, "xw_rows must be 0, 32 or 64");
+        tuning().xw_rows = value;
+        return 0;
+    }
     if (!std::strcmp(key, "xw_waves")) {
         if (value != 0 && value != 4 && value != 8) return fail(STG_ERR_INVALID_ARGUMENT, "xw_waves must be 0, 4 or 8");
         tuning().xw_waves = value;

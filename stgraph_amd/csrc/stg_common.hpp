@@ -24,6 +24,7 @@ struct Tuning {
     int gcn_lanes_per_row = 0;     // 0 = auto
     int gcn_unroll = 0;            // 0 = auto
     int gcn_long_threshold = 0;    // 0 = default (16 edges); rows above it take the wave-per-row path
+    int xw_rows = 0;               // gcn_agg_xw: 0 = auto, 32 / 64 rows per workgroup
     int xw_waves = 0;              // gcn_agg_xw: 0 = auto, 4 / 8 waves per workgroup
     int cell_rows = 0;             // fused TGCN forward cell: 0 = auto (32-row tiles), 16 = 16-row tiles, 32
     int gcn_tile = 0;              // edge-dealt narrow-row kernel: 0 = auto (large grids), 1 = never, 2 = whenever legal

@@ -22,8 +22,9 @@ def main():
         norm = torch.rand(n, 1, device=dev) + 0.5
         ew = torch.rand(e, 1, device=dev) + 0.5
         ref = None
-        for waves in (4, 8, 4, 8):
+        for waves, rows in ((4, 64), (4, 32), (8, 32), (4, 64), (4, 32), (8, 32)):
             _C.set_tuning("xw_waves", waves)
+            _C.set_tuning("xw_rows", rows)
             for _ in range(3):
                 out, P = kernels.gcn_agg_transform(x, W, norm, norm, g.fwd, ew=ew)
             if ref is None:
@@ -37,9 +38,10 @@ def main():
                 b.record()
                 torch.cuda.synchronize()
                 ts.append(a.elapsed_time(b))
-            print(json.dumps({"N": n, "E": e, "Fin": fin, "Fout": fout, "waves": waves, "us": round(float(np.median(ts)) * 1e3, 1)}),
+            print(json.dumps({"N": n, "E": e, "Fin": fin, "Fout": fout, "waves": waves, "rows": rows, "us": round(float(np.median(ts)) * 1e3, 1)}),
                   flush=True)
     _C.set_tuning("xw_waves", 0)
+    _C.set_tuning("xw_rows", 0)
 
 
 if __name__ == "__main__":
