@@ -32,6 +32,17 @@ def test_matches_two_kernel_form_and_oracle(cuda, fin, fout, use_ew, nid):
     assert (np.abs(out.cpu().numpy() - want) <= 1e-6 * scale + 1e-6).all()
     ref = kernels.gcn_agg(t(x) @ t(W), t(norm), t(norm), g.fwd, ew=t(ew), use_node_ids=nid)   # the layer's order
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    # launch shapes (rows / waves per workgroup) only move work around: same bits
+    from stgraph_amd import _C
+    try:
+        for rows, waves in ((32, 4), (32, 8), (64, 8)):
+            _C.set_tuning("xw_rows", rows)
+            _C.set_tuning("xw_waves", waves)
+            out2, P2 = kernels.gcn_agg_transform(t(x), t(W), t(norm), t(norm), g.fwd, ew=t(ew), use_node_ids=nid)
+            assert torch.equal(out2, out) and torch.equal(P2, P), (rows, waves)
+    finally:
+        _C.set_tuning("xw_rows", 0)
+        _C.set_tuning("xw_waves", 0)
 
 
 def test_unsupported_shapes_are_reported(cuda):
