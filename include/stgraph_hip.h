@@ -412,6 +412,16 @@ int stg_tgcn_cell_fused_fwd(const float *a3, const float *b3, const float *H, co
                             const float *Wr, const float *br, const float *Wh, const float *bh, float *CZ,
                             float *CR, float *CH, float *Z, float *R, float *Ht, float *Hn, int64_t N, int32_t C,
                             float lo, float hi, void *stream);
+/* stg_tgcn_cell_fused_bwd that also returns dx = da3 Wcat^T [N,Fin] -- the gradient reaching the aggregated input of
+ * the fused gate aggregation (Wcat [Fin][3C] = the three GCNConv weights side by side): da3's row pieces are MFMA
+ * operands at the moment they are stored, so the product rides along instead of a GEMM launch that re-reads da3.
+ * Supported: C in {32, 64}, Fin = 32 (stg_tgcn_cell_fused_bwd_dx_supported). */
+int stg_tgcn_cell_fused_bwd_dx_supported(int32_t C, int32_t Fin);
+int stg_tgcn_cell_fused_bwd_dx(const float *dHn, const float *Z, const float *H, const float *Ht, const float *R,
+                               const float *a3, const float *b3, const float *Wz, const float *Wr, const float *Wh,
+                               const float *Wcat, float *dhl, float *dzl, float *drl, float *da3, float *dH, float *dx,
+                               int64_t N, int32_t C, int32_t Fin, float lo, float hi, void *stream);
+
 
 /* ----------------------------------------------- dense neighbour: softmax cross-entropy
  * `nn.CrossEntropyLoss()(logits, labels)` of the GCN training scripts (benchmarking/gcn/seastar/train.py:63-101),

@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
+    "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_bwd",
     "stg_xent_workspace_bytes", "stg_xent_fwd", "stg_xent_bwd",
     "stg_link_head_supported", "stg_link_head_workspace_bytes", "stg_link_head_fwd", "stg_link_head_bwd",
@@ -163,6 +164,10 @@ def _load() -> ctypes.CDLL:
     lib.stg_tgcn_cell_fused_fwd.argtypes = [vp] * 16 + [i64, i32, f32, f32, vp]
     lib.stg_tgcn_cell_fused_bwd.restype = ctypes.c_int
     lib.stg_tgcn_cell_fused_bwd.argtypes = [vp] * 15 + [i64, i32, f32, f32, vp]
+    lib.stg_tgcn_cell_fused_bwd_dx_supported.restype = ctypes.c_int
+    lib.stg_tgcn_cell_fused_bwd_dx_supported.argtypes = [i32, i32]
+    lib.stg_tgcn_cell_fused_bwd_dx.restype = ctypes.c_int
+    lib.stg_tgcn_cell_fused_bwd_dx.argtypes = [vp] * 17 + [i64, i32, i32, f32, f32, vp]
     lib.stg_tgcn_head_supported.restype = ctypes.c_int
     lib.stg_tgcn_head_supported.argtypes = [i32, i32, i32]
     lib.stg_tgcn_head_workspace_bytes.restype = ctypes.c_size_t

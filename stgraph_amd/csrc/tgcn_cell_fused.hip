@@ -736,32 +736,44 @@ int launch_bwd(const float *dHn, const float *Z, const float *H, const float *Ht
 // ---------------------------------------------------------------------------------------------- backward, 16-row tiles
 // (see cell_fused_fwd16_kernel: v_mfma_f32_16x16x4_f32, lane = (n16, kq), pieces at column 16 j + 4 kq, one 16x16
 // block of a product = one row piece per lane after the LDS transpose; LDB = 2C + 4 for conflict-free B reads)
-template <int C, int WAVES>
+// FIN > 0: the kernel also forms dx = da3 Wcat^T [N,FIN] (the gradient reaching the aggregated input: Wcat [FIN][3C]
+// is the three GCN gate weights side by side) -- da3's row pieces are already MFMA A operands when they are stored,
+// so the product costs 25 % more MFMAs here instead of a rocBLAS launch that re-reads da3.
+template <int C, int WAVES, int FIN = 0>
 struct CellBwdShape16 {
-    static constexpr int K2 = 2 * C, KQ = C / 16, HB = C / 16, LDB = K2 + 4, TLD = 17;
+    static constexpr int K2 = 2 * C, KQ = C / 16, HB = C / 16, LDB = K2 + 4, TLD = 17, LDZ = FIN + 4, XT = FIN / 16;
     static constexpr int kThreads = WAVES * kWave;
     static constexpr int kWeights = 3 * C * LDB;              // floats
     static constexpr int kBias = 3 * C;                       // b3
     static constexpr int kTile = 16 * TLD;
-    static constexpr size_t kLds = sizeof(float) * (size_t)(kWeights + kBias + WAVES * kTile);
+    static constexpr int kDx = FIN > 0 ? 3 * C * LDZ : 0;     // Wcat^T [3C][LDZ]
+    static constexpr size_t kLds = sizeof(float) * (size_t)(kWeights + kBias + WAVES * kTile + kDx);
 };
 
-template <int C, int WAVES>
+template <int C, int WAVES, int FIN = 0>
 __global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd16_kernel(
     const float *__restrict__ dHn, const float *__restrict__ Z, const float *__restrict__ H,
     const float *__restrict__ Ht, const float *__restrict__ R, const float *__restrict__ a3,
     const float *__restrict__ b3, const float *__restrict__ Wz, const float *__restrict__ Wr,
     const float *__restrict__ Wh, float *__restrict__ dhl_o, float *__restrict__ dzl_o, float *__restrict__ drl_o,
-    float *__restrict__ da3, float *__restrict__ dH_o, int64_t N, float lo, float hi, int num_tiles)
+    float *__restrict__ da3, float *__restrict__ dH_o, int64_t N, float lo, float hi, int num_tiles,
+    const float *__restrict__ Wcat, float *__restrict__ dx_o)
 {
-    using S = CellBwdShape16<C, WAVES>;
-    constexpr int KQ = S::KQ, HB = S::HB, LDB = S::LDB, TLD = S::TLD, NTHR = S::kThreads;
+    using S = CellBwdShape16<C, WAVES, FIN>;
+    constexpr int KQ = S::KQ, HB = S::HB, LDB = S::LDB, TLD = S::TLD, NTHR = S::kThreads, LDZ = S::LDZ, XT = S::XT;
     extern __shared__ float lds[];
     float *Ws = lds;                                   // Wz | Wr | Wh, each [C][LDB]
     float *bs = lds + S::kWeights;                     // b3
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int n16 = lane & 15, kq = lane >> 4;
     float *T = bs + S::kBias + wave * S::kTile;
+    float *Xs = bs + S::kBias + WAVES * S::kTile;      // FIN > 0: Wcat^T [3C][LDZ]
+    if constexpr (FIN > 0) {
+        for (int i = threadIdx.x; i < FIN * 3 * C; i += NTHR) {
+            const int k = i / (3 * C), c = i - k * 3 * C;           // Wcat[k][c]
+            Xs[c * LDZ + k] = Wcat[i];
+        }
+    }
 
     {
         const float *src[3] = {Wz, Wr, Wh};
@@ -797,18 +809,35 @@ __global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd16_kernel(
             dst = make_float4(t[0], t[1], t[2], t[3]);
             wave_lds_sync();
         };
+        f32x4 accx[XT > 0 ? XT : 1];
+        if constexpr (FIN > 0) {
+#pragma unroll
+            for (int ct = 0; ct < XT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accx[ct][i] = 0.f;
+        }
         auto store_da3 = [&](int g, int blk, const float4 &piece) {
-            if (!rok) return;
             const int c = g * C + 16 * blk + 4 * kq;
-            const float4 a = *reinterpret_cast<const float4 *>(a3 + row * 3 * C + c);
-            const float4 b = *reinterpret_cast<const float4 *>(bs + c);
-            const float v0 = a.x + b.x, v1 = a.y + b.y, v2 = a.z + b.z, v3 = a.w + b.w;
-            float4 o;
-            o.x = (v0 >= lo && v0 <= hi) ? piece.x : 0.f;
-            o.y = (v1 >= lo && v1 <= hi) ? piece.y : 0.f;
-            o.z = (v2 >= lo && v2 <= hi) ? piece.z : 0.f;
-            o.w = (v3 >= lo && v3 <= hi) ? piece.w : 0.f;
-            *reinterpret_cast<float4 *>(da3 + row * 3 * C + c) = o;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rok) {
+                const float4 a = *reinterpret_cast<const float4 *>(a3 + row * 3 * C + c);
+                const float4 b = *reinterpret_cast<const float4 *>(bs + c);
+                const float v0 = a.x + b.x, v1 = a.y + b.y, v2 = a.z + b.z, v3 = a.w + b.w;
+                o.x = (v0 >= lo && v0 <= hi) ? piece.x : 0.f;
+                o.y = (v1 >= lo && v1 <= hi) ? piece.y : 0.f;
+                o.z = (v2 >= lo && v2 <= hi) ? piece.z : 0.f;
+                o.w = (v3 >= lo && v3 <= hi) ? piece.w : 0.f;
+                *reinterpret_cast<float4 *>(da3 + row * 3 * C + c) = o;
+            }
+            if constexpr (FIN > 0) {                                 // dx += da3 piece x Wcat^T rows c .. c + 3
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+                const float *px = Xs + c * LDZ + n16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < XT; ++ct)
+                        accx[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ov[i], px[i * LDZ + ct * 16], accx[ct], 0, 0, 0);
+            }
         };
         // acc[b] = A (row pieces, K = C) x W_g[:, half * C + 16 b ..]
         auto gemm = [&](const float4 (&A)[KQ], int g, int half, f32x4 (&acc)[HB]) {
@@ -901,18 +930,26 @@ __global__ __launch_bounds__(WAVES * kWave) void cell_fused_bwd16_kernel(
                 *reinterpret_cast<float4 *>(dH_o + row * C + 16 * blk + 4 * kq) =
                     make_float4(d.x + y.x, d.y + y.y, d.z + y.z, d.w + y.w);
         }
+        if constexpr (FIN > 0) {
+#pragma unroll
+            for (int ct = 0; ct < XT; ++ct) {
+                to_rows(accx[ct], piece);
+                if (rok) *reinterpret_cast<float4 *>(dx_o + row * FIN + 16 * ct + 4 * kq) = piece;
+            }
+        }
     }
 }
 
-template <int C, int WAVES>
+template <int C, int WAVES, int FIN = 0>
 int launch_bwd16(const float *dHn, const float *Z, const float *H, const float *Ht, const float *R, const float *a3,
                  const float *b3, const float *Wz, const float *Wr, const float *Wh, float *dhl, float *dzl, float *drl,
-                 float *da3, float *dH, int64_t N, float lo, float hi, hipStream_t stream)
+                 float *da3, float *dH, int64_t N, float lo, float hi, hipStream_t stream, const float *Wcat = nullptr,
+                 float *dx = nullptr)
 {
-    using S = CellBwdShape16<C, WAVES>;
+    using S = CellBwdShape16<C, WAVES, FIN>;
     static bool raised = false;
     if (S::kLds > 64 * 1024 && !raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_bwd16_kernel<C, WAVES>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_bwd16_kernel<C, WAVES, FIN>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
         if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_bwd: %s", hipGetErrorString(e));
         raised = true;
@@ -921,8 +958,8 @@ int launch_bwd16(const float *dHn, const float *Z, const float *H, const float *
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_bwd: too many rows");
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
     const unsigned blocks = (unsigned)std::min<int64_t>((tiles + WAVES - 1) / WAVES, 256 * per_cu);
-    hipLaunchKernelGGL((cell_fused_bwd16_kernel<C, WAVES>), dim3(blocks), dim3(S::kThreads), S::kLds, stream, dHn, Z, H, Ht, R,
-                       a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, (int)tiles);
+    hipLaunchKernelGGL((cell_fused_bwd16_kernel<C, WAVES, FIN>), dim3(blocks), dim3(S::kThreads), S::kLds, stream, dHn, Z, H,
+                       Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, (int)tiles, Wcat, dx);
     return check_launch("stg_tgcn_cell_fused_bwd");
 }
 
@@ -973,4 +1010,25 @@ extern "C" int stg_tgcn_cell_fused_bwd(const float *dHn, const float *Z, const f
     }
     if (C == 64) return launch_bwd<64, 8>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
     return launch_bwd<32, 4>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st);
+}
+
+extern "C" int stg_tgcn_cell_fused_bwd_dx_supported(int32_t C, int32_t Fin) { return (C == 32 || C == 64) && Fin == 32; }
+
+extern "C" int stg_tgcn_cell_fused_bwd_dx(const float *dHn, const float *Z, const float *H, const float *Ht, const float *R,
+                                          const float *a3, const float *b3, const float *Wz, const float *Wr,
+                                          const float *Wh, const float *Wcat, float *dhl, float *dzl, float *drl,
+                                          float *da3, float *dH, float *dx, int64_t N, int32_t C, int32_t Fin, float lo,
+                                          float hi, void *stream)
+{
+    using namespace stg;
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_bwd_dx: negative N");
+    if (!stg_tgcn_cell_fused_bwd_dx_supported(C, Fin))
+        return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_bwd_dx: C = %d, Fin = %d not supported", C, Fin);
+    if (N == 0) return 0;
+    if (!dHn || !Z || !H || !Ht || !R || !a3 || !b3 || !Wz || !Wr || !Wh || !Wcat || !dhl || !dzl || !drl || !da3 || !dH || !dx)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_cell_fused_bwd_dx: NULL pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (C == 64)
+        return launch_bwd16<64, 8, 32>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st, Wcat, dx);
+    return launch_bwd16<32, 16, 32>(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, dhl, dzl, drl, da3, dH, N, lo, hi, st, Wcat, dx);
 }

@@ -1100,9 +1100,14 @@ def tgcn_cell_fused_fwd(a3, b3, H, Wz, bz, Wr, br, Wh, bh, lo: float, hi: float)
     return Hn, (CZ, CR, CH, Z, R, Ht)
 
 
-def tgcn_cell_fused_bwd(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, lo: float, hi: float):
+def tgcn_cell_fused_bwd_dx_supported(C: int, Fin: int) -> bool:
+    return bool(_C.lib.stg_tgcn_cell_fused_bwd_dx_supported(int(C), int(Fin)))
+
+
+def tgcn_cell_fused_bwd(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, lo: float, hi: float, Wcat=None):
     """The backward row-local chain of one TGCN step in one launch (stg_tgcn_cell_fused_bwd).
-    Returns (da3, dH, dzl, drl, dhl)."""
+    Returns (da3, dH, dzl, drl, dhl); with ``Wcat`` [Fin, 3C] also ``dx = da3 @ Wcat.T`` as a sixth element
+    (stg_tgcn_cell_fused_bwd_dx)."""
     N, C = H.shape
     dev = H.device
     ins = (dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh)
@@ -1114,6 +1119,16 @@ def tgcn_cell_fused_bwd(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, lo: float, hi: flo
         raise ValueError("tgcn_cell_fused_bwd: operand shapes do not match hidden width C")
     new = lambda w: torch.empty(N, w, dtype=torch.float32, device=dev)  # noqa: E731
     dhl, dzl, drl, da3, dH = new(C), new(C), new(C), new(3 * C), new(C)
+    if Wcat is not None:
+        Fin = int(Wcat.shape[0])
+        if Wcat.shape != (Fin, 3 * C) or not Wcat.is_contiguous() or Wcat.dtype != torch.float32 or Wcat.device != dev:
+            raise ValueError("tgcn_cell_fused_bwd: Wcat must be a contiguous fp32 [Fin, 3C] tensor on the same device")
+        dx = new(Fin)
+        with torch.cuda.device(dev), _Timed("tgcn_cell_fused_bwd", 4 * N * (C * 15 + Fin), 12 * N * C * C + 6 * N * C * Fin):
+            _C.check(_C.lib.stg_tgcn_cell_fused_bwd_dx(*[_ptr(t) for t in ins], _ptr(Wcat), _ptr(dhl), _ptr(dzl), _ptr(drl),
+                                                       _ptr(da3), _ptr(dH), _ptr(dx), N, C, Fin, float(lo), float(hi),
+                                                       _stream_ptr(dev)))
+        return da3, dH, dzl, drl, dhl, dx
     with torch.cuda.device(dev), _Timed("tgcn_cell_fused_bwd", 4 * N * C * 15, 12 * N * C * C):
         _C.check(_C.lib.stg_tgcn_cell_fused_bwd(*[_ptr(t) for t in ins], _ptr(dhl), _ptr(dzl), _ptr(drl), _ptr(da3), _ptr(dH),
                                                 N, C, float(lo), float(hi), _stream_ptr(dev)))

@@ -64,13 +64,29 @@ def _cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh):
     return Hn, (CZ, CR, CH, Z, R, Ht)
 
 
-def _cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht):
-    """Returns da3, dH and the three (d_preactivation, operand) pairs of the gate Linears."""
+_FUSED_DX = True
+
+
+def set_fused_dx(enabled: bool) -> None:
+    """True (default): where supported (hidden 32 / 64, 32 input features) the backward launch also forms
+    ``da3 @ Wcat.T`` (kernels.tgcn_cell_fused_bwd with ``Wcat``) instead of a separate GEMM."""
+    global _FUSED_DX
+    _FUSED_DX = bool(enabled)
+
+
+def _cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht, Wcat=None):
+    """Returns da3, dH and the three (d_preactivation, operand) pairs of the gate Linears; with ``Wcat`` (and the fused
+    path able to take it) a fourth element ``dx = da3 @ Wcat.T``, else None there."""
     N, C = H.shape
     dev = H.device
     if _FUSED_BWD and kernels.tgcn_cell_fused_supported(C) and all(t.is_contiguous() for t in (Wz, Wr, Wh)):
+        if Wcat is not None and _FUSED_DX and kernels.tgcn_cell_fused_bwd_dx_supported(C, Wcat.shape[0]):
+            da3, dH, dzl, drl, dhl, dx = kernels.tgcn_cell_fused_bwd(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, -CLAMP, CLAMP,
+                                                                     Wcat=Wcat)
+            return da3, dH, ((dzl, CZ), (drl, CR), (dhl, CH)), dx
         da3, dH, dzl, drl, dhl = kernels.tgcn_cell_fused_bwd(dHn, Z, H, Ht, R, a3, b3, Wz, Wr, Wh, -CLAMP, CLAMP)
-        return da3, dH, ((dzl, CZ), (drl, CR), (dhl, CH))
+        return (da3, dH, ((dzl, CZ), (drl, CR), (dhl, CH))) if Wcat is None else \
+            (da3, dH, ((dzl, CZ), (drl, CR), (dhl, CH)), None)
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
     dhl, dzl, dH = new(N, C), new(N, C), new(N, C)
     kernels.tgcn_cell_call("update_bwd", (dHn, Z, H, Ht, dhl, dzl, dH), N, C)
@@ -81,6 +97,8 @@ def _cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht):
     dCR = kernels.matmul(drl, Wr)
     da3 = new(N, 3 * C)
     kernels.tgcn_cell_call("prep_bwd", (dCZ, dCR, dCH, a3, b3, da3, dH), N, C, -CLAMP, CLAMP)
+    if Wcat is not None:
+        return da3, dH, ((dzl, CZ), (drl, CR), (dhl, CH)), None
     return da3, dH, ((dzl, CZ), (drl, CR), (dhl, CH))
 
 
@@ -143,11 +161,16 @@ class TGCNStepFn(torch.autograd.Function):
         a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht, P, Wcat, norm, ew = ctx.saved_tensors
         ew = ew if ctx.has_ew else None
         defer = SF.deferred_weight_grads()
-        da3, dH, pairs = _cell_backward(dHn.contiguous(), a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht)
+        want_dx = ctx.needs_input_grad[0]
+        if want_dx:
+            da3, dH, pairs, z = _cell_backward(dHn.contiguous(), a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht, Wcat=Wcat)
+        else:
+            (da3, dH, pairs), z = _cell_backward(dHn.contiguous(), a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht), None
         g = _linear_grads(pairs, ctx.params, defer)
         dx = None
-        if ctx.needs_input_grad[0]:
-            z = kernels.matmul_t(da3, Wcat)                           # d(A_hat x) = da3 Wcat^T      [N, in]
+        if want_dx:
+            if z is None:
+                z = kernels.matmul_t(da3, Wcat)                       # d(A_hat x) = da3 Wcat^T      [N, in]
             dx = kernels.gcn_agg(z, norm, norm, ctx.bwd_csr, ew=ew, use_node_ids=ctx.use_nid)
         # GCN weights/biases: dWcat^T = da3^T P  ([3C, in]),  db3 = colsum(da3)
         Ws, bs = ctx.conv_params

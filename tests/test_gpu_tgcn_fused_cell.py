@@ -159,3 +159,35 @@ def test_sixteen_row_backward_matches_thirty_two_row_backward(cuda, N, C):
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m, n=name: f"{n}: {m}")
     if N > 3:
         assert float(res[0][0][0, :5].abs().max()) == 0.0 and float(res[0][0][2, C + 1].abs()) == 0.0
+
+
+@pytest.mark.parametrize("N", [1, 17, 4097, 50_000])
+@pytest.mark.parametrize("C", [32, 64])
+def test_backward_with_the_input_gradient_product(cuda, N, C):
+    """stg_tgcn_cell_fused_bwd_dx: the same five outputs as the plain 16-row backward (bit for bit) plus
+    dx = da3 @ Wcat.T."""
+    from stgraph_amd import _C, kernels
+    from stgraph_amd.nn.pytorch.temporal import cell
+    a3, b3, H, (Wz, Wr, Wh), (bz, br, bh) = _operands(cuda, N, C, 13 * N + C)
+    Hn, (CZ, CR, CH, Z, R, Ht) = cell._cell_forward(a3, b3, H, Wz, bz, Wr, br, Wh, bh)
+    dHn = torch.randn(N, C, device=cuda)
+    Wcat = torch.randn(32, 3 * C, device=cuda) * 0.2
+    assert kernels.tgcn_cell_fused_bwd_dx_supported(C, 32) and not kernels.tgcn_cell_fused_bwd_dx_supported(C, 48)
+    da3, dH, pairs, dx = cell._cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht, Wcat=Wcat)
+    _C.set_tuning("cell_rows", 16)
+    try:
+        da3_p, dH_p, pairs_p = cell._cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht)
+    finally:
+        _C.set_tuning("cell_rows", 0)
+    assert torch.equal(da3, da3_p) and torch.equal(dH, dH_p)
+    for (a, _), (b, _) in zip(pairs, pairs_p):
+        assert torch.equal(a, b)
+    want = (da3.double() @ Wcat.double().t())
+    scale = (da3.double().abs() @ Wcat.double().abs().t())
+    assert bool(((dx.double() - want).abs() <= 1e-6 * scale + 1e-6).all())
+    cell.set_fused_dx(False)
+    try:
+        _, _, _, none = cell._cell_backward(dHn, a3, b3, H, Wz, Wr, Wh, CZ, CR, CH, Z, R, Ht, Wcat=Wcat)
+    finally:
+        cell.set_fused_dx(True)
+    assert none is None
