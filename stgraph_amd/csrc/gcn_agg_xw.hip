@@ -55,8 +55,20 @@ __global__ __launch_bounds__(WAVES * kWave) void gcn_agg_xw_kernel(
     const int row_base = blockIdx.x * kXwRows;
 
     // stage W (read once per workgroup, L2 resident)
-    for (int i = threadIdx.x * 4; i < Fin * Fout; i += NT * 4)
-        *reinterpret_cast<float4 *>(Ws + i) = *reinterpret_cast<const float4 *>(W + i);
+    // (8 loads in flight per thread before the first LDS write: one round trip per 8 NT float4s instead of one each)
+    for (int base = threadIdx.x * 4; base < Fin * Fout; base += 8 * NT * 4) {
+        float4 w4[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int i = base + s * NT * 4;
+            w4[s] = i < Fin * Fout ? *reinterpret_cast<const float4 *>(W + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int i = base + s * NT * 4;
+            if (i < Fin * Fout) *reinterpret_cast<float4 *>(Ws + i) = w4[s];
+        }
+    }
 
     // ---- phase 1: aggregate into the LDS tile
     const int foff = j * VEC;
