@@ -39,6 +39,7 @@ class NaiveGraph(DynamicGraph):
         self._max_cached = max_cached
         self._snapshots: "OrderedDict[int, kernels.GraphCSR]" = OrderedDict()
         self._built_by = {}                    # t -> builder that produced snapshot t last time ('direct' | 'sort')
+        self._pending_status = []              # status words of rebuilds whose read was skipped; checked in bulk
         self._edges = []                       # per-t (src, dst) device tensors in caller order
         t0 = time.time()
         for t in range(self._num_timestamps):
@@ -68,6 +69,10 @@ class NaiveGraph(DynamicGraph):
             g = kernels.build_graph_csr(s, d, self.max_num_nodes, self._device, lazy_node_ids=not self._resident,
                                         known_path=self._built_by.get(t))       # validated once: no status sync on rebuilds
             self._built_by[t] = g.built_by
+            if g.unchecked_status is not None:
+                self._pending_status.append(g.unchecked_status)
+                if len(self._pending_status) >= 4096:
+                    self.verify_builds()
             self.build_count += 1
             if t not in self._distinct_edges:
                 self._distinct_edges[t] = count_distinct_edges(g)
@@ -83,6 +88,16 @@ class NaiveGraph(DynamicGraph):
         else:
             self._snapshots.move_to_end(t)
         return g
+
+    def verify_builds(self) -> None:
+        """One host sync for all rebuilds since the last call whose per-build status read was skipped (a snapshot that
+        was validated when first built).  ``reset_graph`` -- the start of every epoch of the reference's loops -- calls it."""
+        pending, self._pending_status = self._pending_status, []
+        kernels.check_build_statuses(pending)
+
+    def reset_graph(self) -> None:
+        self.verify_builds()
+        super().reset_graph()
 
     def _num_edges_at(self, timestamp: int) -> int:
         if timestamp not in self._distinct_edges:

@@ -193,6 +193,7 @@ class GraphCSR:
     out_degrees: torch.Tensor      # int32 [N]
     perm_fwd: torch.Tensor         # int64 [E]: caller position of the edge that became eid j
     built_by: str = ""             # 'direct' | 'sort' | 'host': which builder produced (and validated) it
+    unchecked_status: "torch.Tensor | None" = None    # the build's status word when its read was skipped (known_path)
 
     @property
     def num_edges(self) -> int:
@@ -227,6 +228,20 @@ BUILD_NEEDS_SORT = 32                  # include/stgraph_hip.h STG_BUILD_NEEDS_S
 # measured (MI355X): 250K edges 0.22 vs 0.35 ms, 500K 0.33 vs 0.44, 16M 6.9 vs 1.9 (one-workgroup scan, atomics)
 DIRECT_BUILD_MAX_EDGES = 2_000_000
 _DIRECT_BUILD = True
+
+
+def check_build_statuses(statuses) -> None:
+    """Verify, with ONE host sync, the status words of builds whose read was skipped (``known_path``): a snapshot
+    whose edge list changed since it was validated (an endpoint out of range, a row too long for the counting
+    build) is reported here instead of never."""
+    statuses = [s for s in statuses if s is not None]
+    if not statuses:
+        return
+    codes = torch.stack([s.reshape(()) for s in statuses]).cpu().tolist()
+    bad = [c for c in codes if c != 0]
+    if bad:
+        raise ValueError(f"{len(bad)} per-snapshot CSR build(s) whose validation was deferred failed "
+                         f"(libstgraph_hip status {bad[0]}): the edge list changed after it was first built")
 
 
 def set_direct_build(enabled: bool) -> None:
@@ -280,6 +295,7 @@ def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_n
                     _ptr(status), _ptr(ws), ws_bytes, _stream_ptr(device)))
             g = GraphCSR(N, fwd, bwd, indeg, outdeg, perm)
             g.built_by = "direct"
+            g.unchecked_status = status            # the caller verifies it later, in bulk (check_build_statuses)
             return g
         if known_path != "sort" and _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES:      # counting build: 6 launches (+ node_ids)
             ws_bytes = int(_C.lib.stg_graph_build_direct_workspace_bytes(E, N))

@@ -123,3 +123,30 @@ def test_direct_build_falls_back_on_a_long_row(cuda):
         for k in ("row_offset", "column_indices", "eids"):
             assert np.array_equal(getattr(side, k).cpu().numpy(), getattr(o, k)), k
     assert g.fwd.degree_sorted and int(g.fwd.node_ids[0]) == 0
+
+
+def test_rebuilt_snapshots_are_verified_in_bulk(cuda):
+    """NaiveGraph(resident=False) rebuilds a validated snapshot without reading the build's status word; the words are
+    checked together at the next reset_graph -- so an edge list that changed under it (here: an endpoint pushed out of
+    range in place) is still reported."""
+    from stgraph_amd.graph import NaiveGraph
+    n = 500
+    rng = np.random.default_rng(0)
+    snaps = []
+    for t in range(3):
+        keys = rng.choice(n * n, size=4000, replace=False)
+        snaps.append((torch.from_numpy((keys // n).astype(np.int32)).to(cuda), torch.from_numpy((keys % n).astype(np.int32)).to(cuda)))
+    G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False, resident=False, max_cached=1)
+    first = [G.csr("fwd", t).row_offset.clone() for t in range(3)]          # first builds: validated, status read
+    G._snapshots.clear()
+    again = [G.csr("fwd", t).row_offset.clone() for t in range(3)]          # rebuilds: status read skipped
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+    assert len(G._pending_status) == 3
+    G.reset_graph()                                                          # bulk check passes (and moves to t = 0)
+    G.verify_builds()
+    assert not G._pending_status
+    G._edges[1][0][7] = n + 3                                                # corrupt snapshot 1 in place
+    G._snapshots.clear()
+    G.csr("fwd", 1)
+    with pytest.raises(ValueError, match="deferred"):
+        G.reset_graph()
