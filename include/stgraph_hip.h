@@ -454,6 +454,10 @@ size_t stg_tgcn_head_workspace_bytes(int64_t N);
 int stg_tgcn_head_fwd(const float *h, const float *W1, const float *b1, const float *W2, const float *b2,
                       const float *target, float *r, float *y, float *y_out, float *loss, int64_t N, int32_t C,
                       int32_t F, void *workspace, size_t workspace_bytes, void *stream);
+/* ... with the training loop's `cost = cost + loss` folded in: loss[0] = loss_in[0] + mean(...) (loss_in may be NULL). */
+int stg_tgcn_head_fwd_acc(const float *h, const float *W1, const float *b1, const float *W2, const float *b2,
+                          const float *target, const float *loss_in, float *r, float *y, float *y_out, float *loss,
+                          int64_t N, int32_t C, int32_t F, void *workspace, size_t workspace_bytes, void *stream);
 int stg_tgcn_head_bwd(const float *g_loss, const float *g_y, const float *g_yout, const float *h, const float *y_out,
                       const float *target, const float *W1, const float *W2, float *dh, float *dyt, float *dyo,
                       int64_t N, int32_t C, int32_t F, void *stream);

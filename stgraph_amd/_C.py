@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = (
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
-    "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_bwd",
+    "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
     "stg_xent_workspace_bytes", "stg_xent_fwd", "stg_xent_bwd",
     "stg_link_head_supported", "stg_link_head_workspace_bytes", "stg_link_head_fwd", "stg_link_head_bwd",
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
@@ -174,6 +174,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_tgcn_head_workspace_bytes.argtypes = [i64]
     lib.stg_tgcn_head_fwd.restype = ctypes.c_int
     lib.stg_tgcn_head_fwd.argtypes = [vp] * 10 + [i64, i32, i32, vp, ctypes.c_size_t, vp]
+    lib.stg_tgcn_head_fwd_acc.restype = ctypes.c_int
+    lib.stg_tgcn_head_fwd_acc.argtypes = [vp] * 11 + [i64, i32, i32, vp, ctypes.c_size_t, vp]
     lib.stg_tgcn_head_bwd.restype = ctypes.c_int
     lib.stg_tgcn_head_bwd.argtypes = [vp] * 11 + [i64, i32, i32, vp]
     lib.stg_xent_workspace_bytes.restype = ctypes.c_size_t

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(kBlock) void head_bwd16_kernel(
 
 // loss = (sum of the tile partials, in a fixed order) / N
 __global__ __launch_bounds__(kBlock) void head_loss_kernel(const float *__restrict__ partial, int num_tiles,
-                                                           float inv_n, float *__restrict__ loss)
+                                                           float inv_n, float *__restrict__ loss,
+                                                           const float *__restrict__ loss_in = nullptr)
 {
     __shared__ float s[kBlock];
     float v = 0.f;
@@ -292,7 +293,8 @@ __global__ __launch_bounds__(kBlock) void head_loss_kernel(const float *__restri
         if ((int)threadIdx.x < off) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = s[0] * inv_n;
+    // loss_in: the running cost of the training loop (`cost = cost + mean(...)`): added here instead of by a launch
+    if (threadIdx.x == 0) loss[0] = loss_in ? loss_in[0] + s[0] * inv_n : s[0] * inv_n;
 }
 
 template <int C>
@@ -460,9 +462,23 @@ extern "C" size_t stg_tgcn_head_workspace_bytes(int64_t N)
     return N <= 0 ? 0 : sizeof(float) * (size_t)stg::head_tiles16(N);
 }
 
+extern "C" int stg_tgcn_head_fwd_acc(const float *h, const float *W1, const float *b1, const float *W2, const float *b2,
+                                     const float *target, const float *loss_in, float *r, float *y, float *y_out,
+                                     float *loss, int64_t N, int32_t C, int32_t F, void *workspace,
+                                     size_t workspace_bytes, void *stream_);
+
 extern "C" int stg_tgcn_head_fwd(const float *h, const float *W1, const float *b1, const float *W2, const float *b2,
                                  const float *target, float *r, float *y, float *y_out, float *loss, int64_t N,
                                  int32_t C, int32_t F, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    return stg_tgcn_head_fwd_acc(h, W1, b1, W2, b2, target, nullptr, r, y, y_out, loss, N, C, F, workspace, workspace_bytes,
+                                 stream_);
+}
+
+extern "C" int stg_tgcn_head_fwd_acc(const float *h, const float *W1, const float *b1, const float *W2, const float *b2,
+                                     const float *target, const float *loss_in, float *r, float *y, float *y_out,
+                                     float *loss, int64_t N, int32_t C, int32_t F, void *workspace,
+                                     size_t workspace_bytes, void *stream_)
 {
     using namespace stg;
     if (!stg_tgcn_head_supported(C, F, 1))
@@ -495,7 +511,7 @@ extern "C" int stg_tgcn_head_fwd(const float *h, const float *W1, const float *b
         default: STG_HEAD_FWD(128); break;
     }
 #undef STG_HEAD_FWD
-    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(kBlock), 0, stream, partial, tiles, 1.0f / (float)N, loss);
+    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(kBlock), 0, stream, partial, tiles, 1.0f / (float)N, loss, loss_in);
     return check_launch("stg_tgcn_head_fwd");
 }
 

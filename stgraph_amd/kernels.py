@@ -981,9 +981,10 @@ def tgcn_head_supported(C: int, F: int, O: int) -> bool:
     return bool(_C.lib.stg_tgcn_head_supported(int(C), int(F), int(O)))
 
 
-def tgcn_head_fwd(h, W1, b1, W2, b2, target):
+def tgcn_head_fwd(h, W1, b1, W2, b2, target, loss_in=None):
     """relu -> Linear -> Linear -> mean squared error of one TGCN step in one launch (stg_tgcn_head_fwd).
-    Returns (r, y, y_out [N,1], loss [1])."""
+    Returns (r, y, y_out [N,1], loss [1]); with ``loss_in`` (a one-element tensor: the loop's running cost) the
+    returned loss is ``loss_in + mean(...)`` (stg_tgcn_head_fwd_acc)."""
     N, C = h.shape
     F_ = W1.shape[0]
     dev = h.device
@@ -993,8 +994,9 @@ def tgcn_head_fwd(h, W1, b1, W2, b2, target):
     ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
     nbytes = 4 * N * (2 * C + F_ + 2)
     with torch.cuda.device(dev), _Timed("tgcn_head_fwd", nbytes, 2 * N * F_ * (C + 1)):
-        _C.check(_C.lib.stg_tgcn_head_fwd(_ptr(h), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(target), _ptr(r), _ptr(y),
-                                          _ptr(y_out), _ptr(loss), N, C, F_, _ptr(ws), ws_bytes, _stream_ptr(dev)))
+        _C.check(_C.lib.stg_tgcn_head_fwd_acc(_ptr(h), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(target), _ptr(loss_in),
+                                              _ptr(r), _ptr(y), _ptr(y_out), _ptr(loss), N, C, F_, _ptr(ws), ws_bytes,
+                                              _stream_ptr(dev)))
     return r, y, y_out, loss
 
 

@@ -108,12 +108,14 @@ class _TgcnHead(torch.autograd.Function):
     Weight and bias gradients go through ``nn.deferred`` like every other Linear of the step."""
 
     @staticmethod
-    def forward(ctx, h, W1, b1, W2, b2, target):
+    def forward(ctx, h, W1, b1, W2, b2, target, cost=None):
         h = h.contiguous()
         target = target.contiguous()
-        r, y, y_out, loss = kernels.tgcn_head_fwd(h, W1, b1, W2, b2, target)
+        r, y, y_out, loss = kernels.tgcn_head_fwd(h, W1, b1, W2, b2, target,
+                                                  loss_in=None if cost is None else cost.contiguous())
         ctx.save_for_backward(h, r, y, y_out, target, W1, W2)
         ctx.params = (W1, b1, W2, b2)
+        ctx.has_cost = cost is not None
         ctx.set_materialize_grads(False)
         return y, y_out, loss.reshape(())
 
@@ -134,7 +136,8 @@ class _TgcnHead(torch.autograd.Function):
             gW1, gb1 = kernels.gemm_tn(dyt, r, colsum=True)
             gW2, gb2 = kernels.gemm_tn(dyo, y, colsum=True)
             grads = [gW1, gb1, gW2, gb2]
-        return (dh, *grads, None)
+        # the running cost passes its gradient through: d(cost + loss) / d cost = 1
+        return (dh, *grads, None, g_loss if ctx.has_cost else None)
 
 
 def tgcn_head_usable(h: torch.Tensor, W1: torch.Tensor, b1, W2: torch.Tensor, b2, target: torch.Tensor) -> bool:
@@ -145,14 +148,20 @@ def tgcn_head_usable(h: torch.Tensor, W1: torch.Tensor, b1, W2: torch.Tensor, b2
             and kernels.tgcn_head_supported(h.shape[1], W1.shape[0], W2.shape[0]))
 
 
-def tgcn_head(h, W1, b1, W2, b2, target):
+def tgcn_head(h, W1, b1, W2, b2, target, cost=None):
     """Returns ``(y, y_out, loss)`` as ``relu -> F.linear -> F.linear -> torch.mean((y_out - target) ** 2)`` would
-    (fp32 rounding apart); the fused launch when ``tgcn_head_usable``, that composition otherwise."""
+    (fp32 rounding apart); the fused launch when ``tgcn_head_usable``, that composition otherwise.  ``cost`` (a 0-dim
+    or one-element tensor): the training loop's running cost -- the third result is then ``cost + loss``."""
     if tgcn_head_usable(h, W1, b1, W2, b2, target):
-        return _TgcnHead.apply(h, W1, b1, W2, b2, target)
+        if cost is not None and not (torch.is_tensor(cost) and cost.is_cuda and cost.dtype == torch.float32
+                                     and cost.numel() == 1):
+            y, y_out, loss = _TgcnHead.apply(h, W1, b1, W2, b2, target)
+            return y, y_out, cost + loss
+        return _TgcnHead.apply(h, W1, b1, W2, b2, target, cost)
     y = linear(F.relu(h), W1, b1)
     y_out = linear(y, W2, b2)
-    return y, y_out, torch.mean((y_out - target) ** 2)
+    loss = torch.mean((y_out - target) ** 2)
+    return y, y_out, loss if cost is None else cost + loss
 
 
 class _CrossEntropy(torch.autograd.Function):

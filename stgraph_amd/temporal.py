@@ -53,16 +53,18 @@ class STGraphTGCN(torch.nn.Module):
         y_out = SF.linear(y, self.linear2.weight, self.linear2.bias)
         return y_out, y, h
 
-    def step_loss(self, g, node_feat, edge_weight, hidden_state, target):
-        """``forward`` plus the training loop's ``torch.mean((y_out - target) ** 2)``: returns (loss, y, h).  With
-        the fused head on (``set_fused_head``, default) relu, both Linears and the loss are one launch."""
+    def step_loss(self, g, node_feat, edge_weight, hidden_state, target, cost=None):
+        """``forward`` plus the training loop's ``cost = cost + torch.mean((y_out - target) ** 2)``: returns
+        (cost, y, h) (``cost`` None: the loss alone).  With the fused head on (``set_fused_head``, default) relu,
+        both Linears, the loss and that addition are one launch."""
         if _FUSED_HEAD:
             h = self.temporal(g, node_feat, edge_weight, hidden_state)
             y, _, loss = SF.tgcn_head(h, self.linear.weight, self.linear.bias, self.linear2.weight,
-                                      self.linear2.bias, target)
+                                      self.linear2.bias, target, cost=cost if torch.is_tensor(cost) else None)
             return loss, y, h
         y_out, y, h = self(g, node_feat, edge_weight, hidden_state)
-        return torch.mean((y_out - target) ** 2), y, h
+        loss = torch.mean((y_out - target) ** 2)
+        return (loss if not torch.is_tensor(cost) else cost + loss), y, h
 
 
 class GradBucket:
@@ -174,8 +176,7 @@ def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, 
                 t = w * backprop_every + k
                 if t >= total:
                     break
-                loss_t, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, targets[t])
-                cost = cost + loss_t
+                cost, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, targets[t], cost)
             cost = cost / (backprop_every + 1)
             cost.backward()
             losses.append(cost.detach())
@@ -283,8 +284,7 @@ class CapturedStaticWindow:
             hidden = None
             y_hat = self.static_y0
             for k in range(self.B):
-                loss_k, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, self.static_targets[k])
-                cost = cost + loss_k
+                cost, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, self.static_targets[k], cost)
             cost = cost / (self.B + 1)
             cost.backward()
             return cost.detach()
@@ -332,8 +332,7 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
             hidden = None
             y_hat = window_input(n, feat_size, epoch, w, targets.device, seed)
             for t in range(w * B, min((w + 1) * B, total)):
-                loss_t, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, targets[t])
-                cost = cost + loss_t
+                cost, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, targets[t], cost)
             cost = cost / (B + 1)
             cost.backward()
             losses.append(cost.detach())

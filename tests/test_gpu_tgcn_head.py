@@ -137,3 +137,23 @@ def test_training_epoch_same_with_and_without_the_fused_head(cuda):
     torch.testing.assert_close(out[0][0], out[1][0], rtol=2e-4, atol=1e-6)
     for a, b in zip(out[0][1], out[1][1]):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4)
+
+
+def test_running_cost_is_folded_into_the_loss_kernel(cuda):
+    """`cost = cost + loss` of the training loop inside the launch: two chained heads, value and every gradient equal
+    to the spelled-out additions."""
+    from stgraph_amd.nn import functional as SF
+    ops_a, ops_b = _operands(cuda, 3000, 64, 1), _operands(cuda, 3000, 64, 2)
+    res = []
+    for fused in (True, False):
+        la = [t.clone().requires_grad_(True) for t in ops_a[:5]]
+        lb = [t.clone().requires_grad_(True) for t in ops_b[:5]]
+        if fused:
+            _, _, cost = SF.tgcn_head(*la, ops_a[5])
+            _, _, cost = SF.tgcn_head(*lb, ops_b[5], cost=cost)
+        else:
+            cost = _composition(*la, ops_a[5])[2] + _composition(*lb, ops_b[5])[2]
+        (cost / 3).backward()
+        res.append([cost.detach()] + [t.grad for t in la + lb])
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
