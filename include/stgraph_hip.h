@@ -465,7 +465,8 @@ int stg_tgcn_head_bwd(const float *g_loss, const float *g_y, const float *g_yout
 /* The link-prediction head of the dynamic-temporal harness (benchmarking/dynamic-temporal-tgcn/seastar/model.py:5-21:
  * relu -> Linear(C, F); decode = (z[src] * z[dst]).sum(-1); train.py: BCEWithLogitsLoss, mean over the M label edges).
  *   fwd: r = relu(h) [N,C], y = r W1^T + b1 [N,F], logits[e] = <y[src[e]], y[dst[e]]> [M],
- *        loss[0] = mean(max(x,0) - x t + log1p(exp(-|x|))); src / dst int64 [M] (a [2,M] index tensor's rows).
+ *        loss[0] = (loss_in ? loss_in[0] : 0) + mean(max(x,0) - x t + log1p(exp(-|x|))) -- loss_in: the loop's running
+ *        cost; src / dst int64 [M] (a [2,M] index tensor's rows).
  *   bwd: dy[v] = g_y[v] + sum over the label edges incident to v of (sigmoid(logit) - t) / M * g_loss * y[other end],
  *        taken in the order of a node-sorted incidence list (row_ptr [N+1], other [2M], eid [2M], int32, built once
  *        per index tensor by the caller) -- no atomics; dyt = dy; dh = (h > 0) (dy W1).  g_y / g_loss may be NULL.
@@ -473,8 +474,8 @@ int stg_tgcn_head_bwd(const float *g_loss, const float *g_y, const float *g_yout
 int stg_link_head_supported(int32_t C, int32_t F);
 size_t stg_link_head_workspace_bytes(int64_t M);
 int stg_link_head_fwd(const float *h, const float *W1, const float *b1, const int64_t *src, const int64_t *dst,
-                      const float *target, float *r, float *y, float *logits, float *loss, int64_t N, int64_t M,
-                      int32_t C, int32_t F, void *workspace, size_t workspace_bytes, void *stream);
+                      const float *target, const float *loss_in, float *r, float *y, float *logits, float *loss,
+                      int64_t N, int64_t M, int32_t C, int32_t F, void *workspace, size_t workspace_bytes, void *stream);
 int stg_link_head_bwd(const float *g_loss, const float *g_y, const float *h, const float *y, const float *logits,
                       const float *target, const int32_t *row_ptr, const int32_t *other, const int32_t *eid,
                       const float *W1, float *dy, float *dh, float *dyt, int64_t N, int64_t M, int32_t C, int32_t F,

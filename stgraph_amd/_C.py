@@ -189,7 +189,7 @@ def _load() -> ctypes.CDLL:
     lib.stg_link_head_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_link_head_workspace_bytes.argtypes = [i64]
     lib.stg_link_head_fwd.restype = ctypes.c_int
-    lib.stg_link_head_fwd.argtypes = [vp] * 10 + [i64, i64, i32, i32, vp, ctypes.c_size_t, vp]
+    lib.stg_link_head_fwd.argtypes = [vp] * 11 + [i64, i64, i32, i32, vp, ctypes.c_size_t, vp]
     lib.stg_link_head_bwd.restype = ctypes.c_int
     lib.stg_link_head_bwd.argtypes = [vp] * 13 + [i64, i64, i32, i32, vp]
     for name, nptr, tail in (("stg_tgcn_cell_prep_fwd", 6, [i64, i32, f32, f32, vp]),

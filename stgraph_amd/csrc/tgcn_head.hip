@@ -555,8 +555,9 @@ extern "C" size_t stg_link_head_workspace_bytes(int64_t M)
 }
 
 extern "C" int stg_link_head_fwd(const float *h, const float *W1, const float *b1, const int64_t *src, const int64_t *dst,
-                                 const float *target, float *r, float *y, float *logits, float *loss, int64_t N,
-                                 int64_t M, int32_t C, int32_t F, void *workspace, size_t workspace_bytes, void *stream_)
+                                 const float *target, const float *loss_in, float *r, float *y, float *logits,
+                                 float *loss, int64_t N, int64_t M, int32_t C, int32_t F, void *workspace,
+                                 size_t workspace_bytes, void *stream_)
 {
     using namespace stg;
     if (!stg_link_head_supported(C, F)) return fail(STG_ERR_UNSUPPORTED, "stg_link_head_fwd: C=%d F=%d not supported", C, F);
@@ -586,7 +587,7 @@ extern "C" int stg_link_head_fwd(const float *h, const float *W1, const float *b
 #undef STG_LINK_FWD
     const int eblocks = (int)((M + 31) / 32);
     hipLaunchKernelGGL(link_decode_bce_kernel, dim3(eblocks), dim3(kBlock), 0, stream, y, src, dst, target, logits, partial, M);
-    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(kBlock), 0, stream, partial, eblocks, 1.0f / (float)M, loss);
+    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(kBlock), 0, stream, partial, eblocks, 1.0f / (float)M, loss, loss_in);
     return check_launch("stg_link_head_fwd");
 }
 

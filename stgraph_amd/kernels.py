@@ -1059,7 +1059,7 @@ def link_incidence(edge_index: torch.Tensor, N: int):
     return row_ptr, other, eid
 
 
-def link_head_fwd(h, W1, b1, edge_index, target):
+def link_head_fwd(h, W1, b1, edge_index, target, loss_in=None):
     """relu -> Linear -> dot-product decode -> BCE-with-logits mean, three launches (stg_link_head_fwd).
     Returns (r, y, logits [M], loss [1])."""
     N, C = h.shape
@@ -1072,8 +1072,8 @@ def link_head_fwd(h, W1, b1, edge_index, target):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev), _Timed("link_head_fwd", 4 * N * (2 * C + F_) + 4 * M * (2 * F_ + 6), 2 * N * F_ * C):
         _C.check(_C.lib.stg_link_head_fwd(_ptr(h), _ptr(W1), _ptr(b1), _ptr(edge_index[0]), _ptr(edge_index[1]),
-                                          _ptr(target), _ptr(r), _ptr(y), _ptr(logits), _ptr(loss), N, M, C, F_,
-                                          _ptr(ws), ws_bytes, _stream_ptr(dev)))
+                                          _ptr(target), _ptr(loss_in), _ptr(r), _ptr(y), _ptr(logits), _ptr(loss), N, M, C,
+                                          F_, _ptr(ws), ws_bytes, _stream_ptr(dev)))
     return r, y, logits, loss
 
 

@@ -197,11 +197,13 @@ class _LinkHead(torch.autograd.Function):
     three launches forward, two backward; the backward sums per node over a sorted incidence list (no atomics)."""
 
     @staticmethod
-    def forward(ctx, h, W1, b1, edge_index, target, incidence):
+    def forward(ctx, h, W1, b1, edge_index, target, incidence, cost=None):
         h = h.contiguous()
-        r, y, logits, loss = kernels.link_head_fwd(h, W1, b1, edge_index, target)
+        r, y, logits, loss = kernels.link_head_fwd(h, W1, b1, edge_index, target,
+                                                   loss_in=None if cost is None else cost.contiguous())
         ctx.save_for_backward(h, r, y, logits, target, W1, *incidence)
         ctx.params = (W1, b1)
+        ctx.has_cost = cost is not None
         ctx.set_materialize_grads(False)
         return y, loss.reshape(())
 
@@ -217,7 +219,7 @@ class _LinkHead(torch.autograd.Function):
             gW1 = gb1 = None
         else:
             gW1, gb1 = kernels.gemm_tn(dyt, r, colsum=True)
-        return dh, gW1, gb1, None, None, None
+        return dh, gW1, gb1, None, None, None, (g_loss if ctx.has_cost else None)
 
 
 _INCIDENCE = {}
@@ -248,14 +250,21 @@ def link_head_usable(h, W1, b1, edge_index, target) -> bool:
             and kernels.link_head_supported(h.shape[1], W1.shape[0]))
 
 
-def link_head(h, W1, b1, edge_index, target):
+def link_head(h, W1, b1, edge_index, target, cost=None):
     """Returns ``(y, loss)`` as ``y = linear(relu(h))``, ``BCEWithLogitsLoss()((y[ei[0]] * y[ei[1]]).sum(-1), target)``
-    would (fp32 rounding apart); the fused launches when ``link_head_usable``, that composition otherwise."""
+    would (fp32 rounding apart); the fused launches when ``link_head_usable``, that composition otherwise.  ``cost``
+    (a one-element device tensor): the loop's running cost -- the second result is then ``cost + loss``."""
     if link_head_usable(h, W1, b1, edge_index, target):
-        return _LinkHead.apply(h, W1, b1, edge_index, target, _incidence_of(edge_index, h.shape[0]))
+        inc = _incidence_of(edge_index, h.shape[0])
+        if cost is not None and not (torch.is_tensor(cost) and cost.is_cuda and cost.dtype == torch.float32
+                                     and cost.numel() == 1):
+            y, loss = _LinkHead.apply(h, W1, b1, edge_index, target, inc)
+            return y, cost + loss
+        return _LinkHead.apply(h, W1, b1, edge_index, target, inc, cost)
     y = linear(F.relu(h), W1, b1)
     out = (y[edge_index[0]] * y[edge_index[1]]).sum(dim=-1).view(-1)
-    return y, F.binary_cross_entropy_with_logits(out, target)
+    loss = F.binary_cross_entropy_with_logits(out, target)
+    return y, loss if cost is None else cost + loss
 
 
 def mm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

@@ -202,16 +202,19 @@ class DynamicSTGraphTGCN(torch.nn.Module):
     def decode(self, z, edge_label_index):
         return (z[edge_label_index[0]] * z[edge_label_index[1]]).sum(dim=-1)
 
-    def step_loss(self, g, node_feat, edge_weight, hidden_state, edge_label_index, target):
-        """``forward`` + ``decode`` + the training loop's ``BCEWithLogitsLoss``: returns (loss, y, h).  With the fused
-        head on (``set_fused_head``, default) everything after the TGCN cell is five launches forward + backward."""
+    def step_loss(self, g, node_feat, edge_weight, hidden_state, edge_label_index, target, cost=None):
+        """``forward`` + ``decode`` + the training loop's ``cost = cost + BCEWithLogitsLoss()(...)``: returns
+        (cost, y, h) (``cost`` None: the loss alone).  With the fused head on (``set_fused_head``, default) everything
+        after the TGCN cell is five launches forward + backward."""
         if _FUSED_HEAD:
             h = self.temporal(g, node_feat, edge_weight, hidden_state)
-            y, loss = SF.link_head(h, self.linear.weight, self.linear.bias, edge_label_index, target)
+            y, loss = SF.link_head(h, self.linear.weight, self.linear.bias, edge_label_index, target,
+                                   cost=cost if torch.is_tensor(cost) else None)
             return loss, y, h
         y, h = self(g, node_feat, edge_weight, hidden_state)
         out = self.decode(y, edge_label_index).view(-1)
-        return F.binary_cross_entropy_with_logits(out, target), y, h
+        loss = F.binary_cross_entropy_with_logits(out, target)
+        return (loss if not torch.is_tensor(cost) else cost + loss), y, h
 
 
 def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_every: int, optimizer,
@@ -244,8 +247,7 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
                 graph.get_graph(t)
                 if graph.get_ndata("norm") is None:
                     graph.set_ndata("norm", norm_fn(graph))
-                loss_t, y_hat, hidden = model.step_loss(graph, y_hat, None, hidden, pos_neg_edges[t], pos_neg_targets[t])
-                cost = cost + loss_t
+                cost, y_hat, hidden = model.step_loss(graph, y_hat, None, hidden, pos_neg_edges[t], pos_neg_targets[t], cost)
             if not isinstance(cost, int):
                 cost = cost / (backprop_every + 1)
                 cost.backward()
