@@ -109,7 +109,7 @@ def gcn_setup(device, seed, n, e, feat):
     def step():
         model.train()
         logits = model(g, x)
-        loss = loss_fn(logits[:ntrain], labels[:ntrain])
+        loss = loss_fn(logits, labels, ntrain)            # = nn.CrossEntropyLoss()(logits[:ntrain], labels[:ntrain])
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -191,7 +191,7 @@ def cora_run(device, epochs=200):
 
         def step():
             logits = model(g, x)
-            loss = loss_fn(logits[:ntrain], labels[:ntrain])
+            loss = loss_fn(logits, labels, ntrain)        # = nn.CrossEntropyLoss()(logits[:ntrain], labels[:ntrain])
             opt.zero_grad()
             loss.backward()
             opt.step()

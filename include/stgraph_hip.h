@@ -428,13 +428,14 @@ int stg_tgcn_cell_fused_bwd_dx(const float *dHn, const float *Z, const float *H,
  * mean over the n rows, one launch each way (+ a one-workgroup finish): see csrc/xent.hip.
  *   fwd: lse[i] = logsumexp(logits[i, :]) [n] (kept for the backward), loss[0] = mean(lse[i] - logits[i, labels[i]]);
  *        status[0] |= 1 if a label is outside [0, K) (that row contributes 0).  labels int64 [n].
- *   bwd: dlogits[i, c] = (exp(logits[i, c] - lse[i]) - [c == labels[i]]) * g_loss[0] / n.
+ *   bwd: dlogits[i, c] = (exp(logits[i, c] - lse[i]) - [c == labels[i]]) * g_loss[0] / n for i < n, and 0 for the rows
+ *        n <= i < n_total (the loss of the scripts is taken on the train-mask prefix of an [n_total, K] matrix).
  * All [dev]; workspace: stg_xent_workspace_bytes(n, K). */
 size_t stg_xent_workspace_bytes(int64_t n, int32_t K);
 int stg_xent_fwd(const float *logits, const int64_t *labels, float *lse, float *loss, int32_t *status, int64_t n,
                  int32_t K, void *workspace, size_t workspace_bytes, void *stream);
 int stg_xent_bwd(const float *g_loss, const float *logits, const int64_t *labels, const float *lse, float *dlogits,
-                 int64_t n, int32_t K, void *stream);
+                 int64_t n, int64_t n_total, int32_t K, void *stream);
 
 /* ----------------------------------------------- dense neighbour: the TGCN harness head
  * The model head and loss of the static-temporal TGCN training step

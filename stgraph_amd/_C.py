@@ -183,7 +183,7 @@ def _load() -> ctypes.CDLL:
     lib.stg_xent_fwd.restype = ctypes.c_int
     lib.stg_xent_fwd.argtypes = [vp] * 5 + [i64, i32, vp, ctypes.c_size_t, vp]
     lib.stg_xent_bwd.restype = ctypes.c_int
-    lib.stg_xent_bwd.argtypes = [vp] * 5 + [i64, i32, vp]
+    lib.stg_xent_bwd.argtypes = [vp] * 5 + [i64, i64, i32, vp]
     lib.stg_link_head_supported.restype = ctypes.c_int
     lib.stg_link_head_supported.argtypes = [i32, i32]
     lib.stg_link_head_workspace_bytes.restype = ctypes.c_size_t

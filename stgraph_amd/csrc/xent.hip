@@ -96,17 +96,24 @@ __global__ __launch_bounds__(kBlock) void xent_finish_kernel(const float *__rest
     if (threadIdx.x == 0) loss[0] = s[0] * inv_n;
 }
 
+// rows [n, n_total) of dlogits are zeroed: the loss was taken on a prefix of the logits matrix (the train mask of the
+// GCN scripts), and the gradient of the whole matrix comes out of this one launch instead of a fill + a strided copy
 __global__ __launch_bounds__(kBlock) void xent_bwd_kernel(const float *__restrict__ g_loss, const float *__restrict__ logits,
                                                           const int64_t *__restrict__ labels, const float *__restrict__ lse,
-                                                          float *__restrict__ dlogits, int64_t n, int K, float inv_n)
+                                                          float *__restrict__ dlogits, int64_t n, int64_t n_total, int K,
+                                                          float inv_n)
 {
-    const int64_t total = n * K;
+    const int64_t total = n_total * K, live = n * K;
     const float scale = g_loss[0] * inv_n;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t row = i / K;
-        const int c = (int)(i - row * K);
-        const float p = expf(logits[i] - lse[row]);
-        dlogits[i] = (p - (labels[row] == c ? 1.f : 0.f)) * scale;
+        float v = 0.f;
+        if (i < live) {
+            const int64_t row = i / K;
+            const int c = (int)(i - row * K);
+            const float p = expf(logits[i] - lse[row]);
+            v = (p - (labels[row] == c ? 1.f : 0.f)) * scale;
+        }
+        dlogits[i] = v;
     }
 }
 
@@ -160,14 +167,14 @@ extern "C" int stg_xent_fwd(const float *logits, const int64_t *labels, float *l
 }
 
 extern "C" int stg_xent_bwd(const float *g_loss, const float *logits, const int64_t *labels, const float *lse,
-                            float *dlogits, int64_t n, int32_t K, void *stream_)
+                            float *dlogits, int64_t n, int64_t n_total, int32_t K, void *stream_)
 {
     using namespace stg;
-    if (n <= 0 || K <= 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd: bad shape");
+    if (n <= 0 || K <= 0 || n_total < n) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd: bad shape");
     if (!g_loss || !logits || !labels || !lse || !dlogits) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd: NULL pointer argument");
-    const int64_t total = n * (int64_t)K;
+    const int64_t total = n_total * (int64_t)K;
     const int blocks = (int)std::min<int64_t>((total + kBlock - 1) / kBlock, 256 * 16);
     hipLaunchKernelGGL(xent_bwd_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream_), g_loss, logits, labels,
-                       lse, dlogits, n, K, 1.0f / (float)n);
+                       lse, dlogits, n, n_total, K, 1.0f / (float)n);
     return check_launch("stg_xent_bwd");
 }

@@ -1015,10 +1015,12 @@ def tgcn_head_bwd(g_loss, g_y, g_yout, h, y_out, target, W1, W2):
     return dh, dyt, dyo
 
 
-def xent_fwd(logits: torch.Tensor, labels: torch.Tensor):
-    """Mean softmax cross-entropy (stg_xent_fwd).  Returns (loss [1], lse [n], status [1] int32: non-zero if a label
-    is out of range -- not read here, the caller decides whether to pay the sync)."""
+def xent_fwd(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None):
+    """Mean softmax cross-entropy over the first ``rows`` rows (default: all) (stg_xent_fwd).  Returns (loss [1],
+    lse [rows], status [1] int32: non-zero if a label is out of range -- not read here, the caller decides whether
+    to pay the sync)."""
     n, K = logits.shape
+    n = n if rows is None else int(rows)
     dev = logits.device
     lse = torch.empty(n, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
@@ -1032,10 +1034,12 @@ def xent_fwd(logits: torch.Tensor, labels: torch.Tensor):
 
 
 def xent_bwd(g_loss: torch.Tensor, logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor) -> torch.Tensor:
-    n, K = logits.shape
+    """Gradient of xent_fwd for the WHOLE logits matrix: rows beyond ``lse.shape[0]`` (not part of the loss) are zero."""
+    n_total, K = logits.shape
+    n = int(lse.shape[0])
     d = torch.empty_like(logits)
-    with torch.cuda.device(logits.device), _Timed("xent_bwd", 4 * n * (2 * K + 3), 4 * n * K):
-        _C.check(_C.lib.stg_xent_bwd(_ptr(g_loss), _ptr(logits), _ptr(labels), _ptr(lse), _ptr(d), n, K,
+    with torch.cuda.device(logits.device), _Timed("xent_bwd", 4 * n * (2 * K + 3) + 4 * (n_total - n) * K, 4 * n * K):
+        _C.check(_C.lib.stg_xent_bwd(_ptr(g_loss), _ptr(logits), _ptr(labels), _ptr(lse), _ptr(d), n, n_total, K,
                                      _stream_ptr(logits.device)))
     return d
 

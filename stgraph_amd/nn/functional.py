@@ -168,26 +168,29 @@ class _CrossEntropy(torch.autograd.Function):
     """``F.cross_entropy(logits, labels)`` (mean) as one launch each way (csrc/xent.hip)."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, rows=None):
         logits = logits.contiguous()
         labels = labels.contiguous()
-        loss, lse, _ = kernels.xent_fwd(logits, labels)
+        loss, lse, _ = kernels.xent_fwd(logits, labels, rows)
         ctx.save_for_backward(logits, labels, lse)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         logits, labels, lse = ctx.saved_tensors
-        return kernels.xent_bwd(g.contiguous(), logits, labels, lse), None
+        return kernels.xent_bwd(g.contiguous(), logits, labels, lse), None, None
 
 
-def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None) -> torch.Tensor:
     """``nn.CrossEntropyLoss()(logits, labels)``: the fused launches for 2-D fp32 device logits and int64 class
-    labels, ``F.cross_entropy`` otherwise (same value and gradient up to fp32 rounding)."""
+    labels, ``F.cross_entropy`` otherwise (same value and gradient up to fp32 rounding).  ``rows``: take the loss on
+    ``logits[:rows]`` / ``labels[:rows]`` (the train-mask prefix of the GCN scripts) without slicing -- the backward then
+    writes the whole gradient matrix (zero beyond ``rows``) in its one launch instead of autograd's fill + copy."""
+    n = logits.shape[0] if rows is None else int(rows)
     if (logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and labels.dtype == torch.int64
-            and labels.dim() == 1 and labels.shape[0] == logits.shape[0] and logits.shape[0] > 0):
-        return _CrossEntropy.apply(logits, labels)
-    return F.cross_entropy(logits, labels)
+            and labels.dim() == 1 and labels.shape[0] >= n and 0 < n <= logits.shape[0]):
+        return _CrossEntropy.apply(logits, labels, None if rows is None else n)
+    return F.cross_entropy(logits[:n], labels[:n])
 
 
 class _LinkHead(torch.autograd.Function):

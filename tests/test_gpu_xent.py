@@ -59,3 +59,21 @@ def test_out_of_range_label_sets_the_status_word(cuda):
     labels[17] = 5
     _, _, status = kernels.xent_fwd(logits, labels)
     assert int(status.item()) != 0
+
+
+@pytest.mark.parametrize("n_total,rows,K", [(2708, 1624, 7), (100_000, 60_000, 128), (50, 50, 3), (10, 1, 5)])
+def test_row_prefix_without_slicing(cuda, n_total, rows, K):
+    """`rows`: the loss on logits[:rows] with the whole gradient matrix (zero tail) from the one backward launch."""
+    from stgraph_amd.nn import functional as SF
+    g = torch.Generator(device=cuda).manual_seed(rows)
+    base = torch.randn(n_total, K, device=cuda, generator=g)
+    labels = torch.randint(0, K, (n_total,), device=cuda, generator=g)
+    a = base.clone().requires_grad_(True)
+    la = SF.cross_entropy(a, labels, rows)
+    (la * 0.5).backward()
+    b = base.clone().requires_grad_(True)
+    lb = F.cross_entropy(b[:rows], labels[:rows])
+    (lb * 0.5).backward()
+    torch.testing.assert_close(la, lb, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-9)
+    assert not a.grad[rows:].any()
