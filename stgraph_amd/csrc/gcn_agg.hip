@@ -95,6 +95,9 @@ __device__ __forceinline__ float bcast_const_f(float v, int src)
 #ifndef STG_GCN_ROUND
 #define STG_GCN_ROUND 8
 #endif
+#ifndef STG_TILE_U
+#define STG_TILE_U 4
+#endif
 #ifndef STG_GCN_ROUND4
 #define STG_GCN_ROUND4 16
 #endif
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
 {
     constexpr int G = 1 << LOG2G, VEC = 4, W = G * VEC * VPL;
     constexpr int RB = kBlock / G;                  // rows per workgroup = lane groups per workgroup
-    constexpr int U = 4;                            // edges per lane group and chunk
+    constexpr int U = STG_TILE_U;                   // 4: measured best (8: F = 7 0.53 -> 0.46)                           // edges per lane group and chunk
     constexpr int CAP = U * RB;                     // edges per chunk: a 16 KB (VPL = 1) / 32 KB tile
     __shared__ int offs[RB + 1];
     __shared__ __attribute__((aligned(16))) float tile[CAP * W];
