@@ -189,11 +189,13 @@ def cora_run(device, epochs=200):
         opt = (torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4, capturable=True, fused=True)
                if mode == "hip_graph" else torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4))
 
+        one = torch.ones((), device=device)     # d loss / d loss, kept instead of filled anew by every backward()
+
         def step():
             logits = model(g, x)
             loss = loss_fn(logits, labels, ntrain)        # = nn.CrossEntropyLoss()(logits[:ntrain], labels[:ntrain])
             opt.zero_grad()
-            loss.backward()
+            loss.backward(one)
             opt.step()
             return loss.detach()
 

@@ -427,7 +427,8 @@ int stg_tgcn_cell_fused_bwd_dx(const float *dHn, const float *Z, const float *H,
  * `nn.CrossEntropyLoss()(logits, labels)` of the GCN training scripts (benchmarking/gcn/seastar/train.py:63-101),
  * mean over the n rows, one launch each way (+ a one-workgroup finish): see csrc/xent.hip.
  *   fwd: lse[i] = logsumexp(logits[i, :]) [n] (kept for the backward), loss[0] = mean(lse[i] - logits[i, labels[i]]);
- *        status[0] |= 1 if a label is outside [0, K) (that row contributes 0).  labels int64 [n].
+ *        status[0] |= 1 if a label is outside [0, K) (that row contributes 0): OR-ed into, never cleared here -- the
+ *        caller zeroes the word once and may keep it across calls (a sticky flag, no launch per call).  labels int64 [n].
  *   bwd: dlogits[i, c] = (exp(logits[i, c] - lse[i]) - [c == labels[i]]) * g_loss[0] / n for i < n, and 0 for the rows
  *        n <= i < n_total (the loss of the scripts is taken on the train-mask prefix of an [n_total, K] matrix).
  * All [dev]; workspace: stg_xent_workspace_bytes(n, K). */

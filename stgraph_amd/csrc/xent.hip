@@ -144,8 +144,6 @@ extern "C" int stg_xent_fwd(const float *logits, const int64_t *labels, float *l
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_fwd: NULL pointer argument");
     if (workspace_bytes < stg_xent_workspace_bytes(n, K)) return fail(STG_ERR_WORKSPACE, "stg_xent_fwd: workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), stream);
-    if (e != hipSuccess) return fail((int)e, "stg_xent_fwd: memset: %s", hipGetErrorString(e));
     const int blocks = xent_blocks(n, K);
     float *partial = static_cast<float *>(workspace);
     const bool v4 = K % 4 == 0 && reinterpret_cast<uintptr_t>(logits) % 16 == 0;

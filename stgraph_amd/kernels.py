@@ -1015,16 +1015,21 @@ def tgcn_head_bwd(g_loss, g_y, g_yout, h, y_out, target, W1, W2):
     return dh, dyt, dyo
 
 
+_XENT_STATUS = {}
+
+
 def xent_fwd(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None):
     """Mean softmax cross-entropy over the first ``rows`` rows (default: all) (stg_xent_fwd).  Returns (loss [1],
-    lse [rows], status [1] int32: non-zero if a label is out of range -- not read here, the caller decides whether
-    to pay the sync)."""
+    lse [rows], status [1] int32: non-zero if a label was out of range in this or an earlier call on the device -- a
+    sticky word that is not read here: the caller decides whether to pay the sync)."""
     n, K = logits.shape
     n = n if rows is None else int(rows)
     dev = logits.device
     lse = torch.empty(n, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
-    status = torch.empty(1, dtype=torch.int32, device=dev)
+    status = _XENT_STATUS.get(dev)
+    if status is None:                          # one sticky word per device, zeroed once (the kernel only ORs into it)
+        status = _XENT_STATUS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
     ws_bytes = int(_C.lib.stg_xent_workspace_bytes(n, K))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev), _Timed("xent_fwd", 4 * n * (K + 3), 4 * n * K):
