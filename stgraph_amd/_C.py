@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -181,9 +181,9 @@ def _load() -> ctypes.CDLL:
     lib.stg_xent_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_xent_workspace_bytes.argtypes = [i64, i32]
     lib.stg_xent_fwd.restype = ctypes.c_int
-    lib.stg_xent_fwd.argtypes = [vp] * 5 + [i64, i32, vp, ctypes.c_size_t, vp]
+    lib.stg_xent_fwd.argtypes = [vp] * 6 + [i64, i32, vp, ctypes.c_size_t, vp]
     lib.stg_xent_bwd.restype = ctypes.c_int
-    lib.stg_xent_bwd.argtypes = [vp] * 5 + [i64, i64, i32, vp]
+    lib.stg_xent_bwd.argtypes = [vp] * 6 + [i64, i64, i32, vp]
     lib.stg_link_head_supported.restype = ctypes.c_int
     lib.stg_link_head_supported.argtypes = [i32, i32]
     lib.stg_link_head_workspace_bytes.restype = ctypes.c_size_t

@@ -73,6 +73,9 @@ class Executor:
     def execute(self, FuncWrapper):
         """Forward pass: one autograd node around the fused forward unit(s)."""
         tensors = [self.ts.current_tensor_map[k] for k in self._inputs]
+        # A call that autograd will never walk back through (torch.no_grad() evaluation, no differentiable input)
+        # keeps nothing: its entry would otherwise stay on the stack for good (only backward_cb pops).
+        self._track = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
         rets = FuncWrapper.apply(self, 0, self._inputs, None, *tensors)
         return rets if isinstance(rets, tuple) else (rets,)
 
@@ -81,12 +84,14 @@ class Executor:
         n_feats = {name: t for (kind, name), t in zip(kernel_args, tensor_list) if kind == "n"}
         e_feats = {name: t for (kind, name), t in zip(kernel_args, tensor_list) if kind == "e"}
         outs, saved = self.plan.forward(self.graph, n_feats, e_feats)
+        self.ts.current_tensor_map = {}
+        if not getattr(self, "_track", True):
+            return outs, None
         self._serial += 1
         saved["__serial__"] = self._serial
         self.ts.tensor_map_stack.push(saved)
         if isinstance(self.graph, DynamicGraph):
             self.ts.graph_timestamp_stack.push(self.graph.current_timestamp)
-        self.ts.current_tensor_map = {}
         return outs, self._serial
 
     def backward_cb(self, kid, grad_list, serial=None):

@@ -255,6 +255,11 @@ GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1)
     S = std::max<int64_t>(1, std::min(S, max_S));
     int64_t per_wave = (K + S * kWavesPerBlock - 1) / (S * kWavesPerBlock);
     per_wave = (per_wave + kGemmKStep - 1) / kGemmKStep * kGemmKStep;
+    // a wave addresses its K slice through 32-bit buffer descriptors and scalar row offsets: rows * max(M, N) * 4
+    // bytes must stay below 2^31 (more slices instead of longer ones; 0 = no slice length fits: unsupported)
+    const int64_t cap = ((int64_t)INT32_MAX / (4 * (int64_t)std::max(M, N))) / kGemmKStep * kGemmKStep;
+    if (cap < kGemmKStep) { p.S = 0; return p; }
+    per_wave = std::min(per_wave, cap);
     p.kslice_wave = std::max<int64_t>(per_wave, kGemmKStep);
     p.S = (int)((K + p.kslice_wave * kWavesPerBlock - 1) / (p.kslice_wave * kWavesPerBlock));
     if (p.S < 1) p.S = 1;
@@ -303,6 +308,9 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         segs.b[t] = Bs[t];
     }
     const GemmPlan p = plan_gemm_tn(K, M, N, T);
+    if (p.S < 1 || (int64_t)T * p.S > INT32_MAX / 2)
+        return fail(STG_ERR_UNSUPPORTED, "%s: K=%lld x max(M, N)=%d is outside the 32-bit slice addressing", what,
+                    (long long)K, std::max(M, N));
     const bool cs = colsum != nullptr;
     const int64_t MN = (int64_t)M * N, MNc = MN + (cs ? M : 0);
     const int S_total = T * p.S;

@@ -136,15 +136,16 @@ int rowgemm_launch(const float *X, const float *W, const float *bias, float *Y, 
     const int64_t tiles = (N + 31) / 32;
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: too many rows");
     // dynamic LDS above 64 KiB has to be enabled per kernel (host-side attribute, no sync)
-    static bool raised[2] = {false, false};
-    if (lds > 64 * 1024 && !raised[trans_w ? 1 : 0]) {
+    static PerDeviceOnce once[2];
+    bool *raised = once[trans_w ? 1 : 0].slot();
+    if (lds > 64 * 1024 && !*raised) {
         const hipError_t e = trans_w
             ? hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<KBMAX, MT, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
             : hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<KBMAX, MT, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return fail((int)e, "stg_rowgemm_f32: %s", hipGetErrorString(e));
-        raised[trans_w ? 1 : 0] = true;
+        *raised = true;
     }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (lds + 1024)));
     const unsigned blocks = (unsigned)std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, 256 * per_cu);

@@ -165,4 +165,18 @@ inline int ilog2_ceil(int v)
     return l;
 }
 
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per kernel AND per device: a launcher keeps one of these as a
+// function-local static and raises the limit the first time it launches on each device of the process.
+struct PerDeviceOnce {
+    bool done[64] = {};
+    // returns the slot of the calling thread's current device (devices >= 64 share slot 63 and simply re-raise)
+    bool *slot()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+        if (dev >= 63) { done[63] = false; return &done[63]; }
+        return &done[dev];
+    }
+};
 }  // namespace stg

@@ -256,12 +256,13 @@ int launch_fwd(const float *a3, const float *b3, const float *H, const float *Wz
                float *Ht, float *Hn, int64_t N, float lo, float hi, hipStream_t stream)
 {
     using S = CellShape<C, WAVES>;
-    static bool raised = false;
-    if (S::kLds > 64 * 1024 && !raised) {
+    static PerDeviceOnce once;
+    bool *raised = once.slot();
+    if (S::kLds > 64 * 1024 && !*raised) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_fwd_kernel<C, WAVES>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
         if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_fwd: %s", hipGetErrorString(e));
-        raised = true;
+        *raised = true;
     }
     const int64_t tiles = (N + 31) / 32;
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_fwd: too many rows");
@@ -475,12 +476,13 @@ int launch_fwd16(const float *a3, const float *b3, const float *H, const float *
                  float *Ht, float *Hn, int64_t N, float lo, float hi, hipStream_t stream)
 {
     using S = CellShape16<C, WAVES>;
-    static bool raised = false;
-    if (S::kLds > 64 * 1024 && !raised) {
+    static PerDeviceOnce once;
+    bool *raised = once.slot();
+    if (S::kLds > 64 * 1024 && !*raised) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_fwd16_kernel<C, WAVES>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
         if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_fwd: %s", hipGetErrorString(e));
-        raised = true;
+        *raised = true;
     }
     const int64_t tiles = (N + 15) / 16;
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_fwd: too many rows");
@@ -717,12 +719,13 @@ int launch_bwd(const float *dHn, const float *Z, const float *H, const float *Ht
                float *da3, float *dH, int64_t N, float lo, float hi, hipStream_t stream)
 {
     using S = CellBwdShape<C, WAVES>;
-    static bool raised = false;
-    if (S::kLds > 64 * 1024 && !raised) {
+    static PerDeviceOnce once;
+    bool *raised = once.slot();
+    if (S::kLds > 64 * 1024 && !*raised) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_bwd_kernel<C, WAVES>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
         if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_bwd: %s", hipGetErrorString(e));
-        raised = true;
+        *raised = true;
     }
     const int64_t tiles = (N + 31) / 32;
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_bwd: too many rows");
@@ -947,12 +950,13 @@ int launch_bwd16(const float *dHn, const float *Z, const float *H, const float *
                  float *dx = nullptr)
 {
     using S = CellBwdShape16<C, WAVES, FIN>;
-    static bool raised = false;
-    if (S::kLds > 64 * 1024 && !raised) {
+    static PerDeviceOnce once;
+    bool *raised = once.slot();
+    if (S::kLds > 64 * 1024 && !*raised) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cell_fused_bwd16_kernel<C, WAVES, FIN>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
         if (e != hipSuccess) return fail((int)e, "stg_tgcn_cell_fused_bwd: %s", hipGetErrorString(e));
-        raised = true;
+        *raised = true;
     }
     const int64_t tiles = (N + 15) / 16;
     if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_cell_fused_bwd: too many rows");

@@ -5,8 +5,12 @@
 // reduction of nll_loss runs in ONE workgroup (10 us on 1624 rows of Cora, 1.3 ms on 600 K rows).  Here:
 //   forward : G lanes per row (8 up to 32 classes, 32 up to 256, else 64; 16-byte loads when K % 4 == 0): row max,
 //             sum of exp, lse = max + log(sum); loss_row = lse - logits[label]; rows dealt grid-stride to at most
-//             2048 workgroups, whose partial sums a finish kernel adds in a fixed order; lse [n] kept for the backward
-//   backward: dlogits[i, c] = (exp(logits[i, c] - lse[i]) - [c == label[i]]) * g / n
+//             2048 workgroups, whose partial sums and counts of counted rows a finish kernel adds in a fixed order;
+//             loss = sum / count; lse [n] and the count kept for the backward
+//   backward: dlogits[i, c] = (exp(logits[i, c] - lse[i]) - [c == label[i]]) * g / count, zero for a row not counted
+// Rows whose label is nn.CrossEntropyLoss's default ignore_index (-100) are not counted (no loss term, no gradient,
+// not in the mean's denominator), as in torch.  Any other label outside [0, K) -- torch raises a device assert --
+// is treated the same way and reported through bit 0 of the status word.
 // expf / logf are the accurate library versions: results agree with torch to fp32 rounding (tests: 1e-6 relative).
 #include <algorithm>
 
@@ -14,6 +18,8 @@
 
 namespace stg {
 namespace {
+
+constexpr int64_t kIgnoreIndex = -100;                           // nn.CrossEntropyLoss() default
 
 template <int G>
 __device__ __forceinline__ float group_max(float v)
@@ -36,12 +42,15 @@ __device__ __forceinline__ float group_sum(float v)
 template <int G, bool VEC4>
 __global__ __launch_bounds__(kBlock) void xent_fwd_kernel(const float *__restrict__ logits, const int64_t *__restrict__ labels,
                                                           float *__restrict__ lse, float *__restrict__ partial,
-                                                          int64_t n, int K, int *__restrict__ status)
+                                                          int *__restrict__ partial_cnt, int64_t n, int K,
+                                                          int *__restrict__ status)
 {
     constexpr int ROWS = kBlock / G;
     __shared__ float s[ROWS];
+    __shared__ int sc[ROWS];
     const int g = threadIdx.x / G, j = threadIdx.x % G;
     float term = 0.f;                                            // this lane group's rows, in row order
+    int counted = 0;
     for (int64_t row = (int64_t)blockIdx.x * ROWS + g; row < n; row += (int64_t)gridDim.x * ROWS) {
         const float *x = logits + row * K;
         float m = -INFINITY, sum = 0.f;
@@ -68,32 +77,45 @@ __global__ __launch_bounds__(kBlock) void xent_fwd_kernel(const float *__restric
             const float l = m + logf(sum);
             lse[row] = l;
             const int64_t t = labels[row];
-            if (t < 0 || t >= K) atomicOr(status, 1);             // label outside [0, K): reported, row skipped
-            else term = term + (l - x[t]);
+            if (t >= 0 && t < K) term = term + (l - x[t]), ++counted;
+            else if (t != kIgnoreIndex) atomicOr(status, 1);      // neither a class nor ignore_index: reported, not counted
         }
     }
-    if (j == 0) s[g] = term;
+    if (j == 0) s[g] = term, sc[g] = counted;
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
-        for (int i = 0; i < ROWS; ++i) t = t + s[i];
+        int c = 0;
+        for (int i = 0; i < ROWS; ++i) t = t + s[i], c += sc[i];
         partial[blockIdx.x] = t;
+        partial_cnt[blockIdx.x] = c;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void xent_finish_kernel(const float *__restrict__ partial, int count, float inv_n,
-                                                             float *__restrict__ loss)
+__global__ __launch_bounds__(kBlock) void xent_finish_kernel(const float *__restrict__ partial,
+                                                             const int *__restrict__ partial_cnt, int count,
+                                                             float *__restrict__ loss, float *__restrict__ n_counted)
 {
     __shared__ float s[kBlock];
+    __shared__ long long c[kBlock];
     float v = 0.f;
-    for (int t = threadIdx.x; t < count; t += kBlock) v = v + partial[t];
+    long long k = 0;
+    for (int t = threadIdx.x; t < count; t += kBlock) v = v + partial[t], k += partial_cnt[t];
     s[threadIdx.x] = v;
+    c[threadIdx.x] = k;
     __syncthreads();
     for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + off];
+        if ((int)threadIdx.x < off) {
+            s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + off];
+            c[threadIdx.x] += c[threadIdx.x + off];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = s[0] * inv_n;
+    if (threadIdx.x == 0) {
+        const float cnt = (float)c[0];
+        n_counted[0] = cnt;
+        loss[0] = s[0] / cnt;                                    // no counted row: 0 / 0 = NaN, as torch
+    }
 }
 
 // rows [n, n_total) of dlogits are zeroed: the loss was taken on a prefix of the logits matrix (the train mask of the
@@ -101,17 +123,20 @@ __global__ __launch_bounds__(kBlock) void xent_finish_kernel(const float *__rest
 __global__ __launch_bounds__(kBlock) void xent_bwd_kernel(const float *__restrict__ g_loss, const float *__restrict__ logits,
                                                           const int64_t *__restrict__ labels, const float *__restrict__ lse,
                                                           float *__restrict__ dlogits, int64_t n, int64_t n_total, int K,
-                                                          float inv_n)
+                                                          const float *__restrict__ n_counted)
 {
     const int64_t total = n_total * K, live = n * K;
-    const float scale = g_loss[0] * inv_n;
+    const float scale = g_loss[0] / n_counted[0];
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         float v = 0.f;
         if (i < live) {
             const int64_t row = i / K;
             const int c = (int)(i - row * K);
-            const float p = expf(logits[i] - lse[row]);
-            v = (p - (labels[row] == c ? 1.f : 0.f)) * scale;
+            const int64_t t = labels[row];
+            if (t >= 0 && t < K) {                               // rows not counted by the forward get no gradient
+                const float p = expf(logits[i] - lse[row]);
+                v = (p - (t == c ? 1.f : 0.f)) * scale;
+            }
         }
         dlogits[i] = v;
     }
@@ -131,48 +156,49 @@ inline int xent_blocks(int64_t n, int K)
 
 extern "C" size_t stg_xent_workspace_bytes(int64_t n, int32_t K)
 {
-    if (n <= 0 || K <= 0) return sizeof(float) + sizeof(int32_t);
-    return sizeof(float) * (size_t)stg::xent_blocks(n, K) + sizeof(int32_t);
+    if (n <= 0 || K <= 0) return 2 * sizeof(float);
+    return 2 * sizeof(float) * (size_t)stg::xent_blocks(n, K);
 }
 
-extern "C" int stg_xent_fwd(const float *logits, const int64_t *labels, float *lse, float *loss, int32_t *status,
-                            int64_t n, int32_t K, void *workspace, size_t workspace_bytes, void *stream_)
+extern "C" int stg_xent_fwd(const float *logits, const int64_t *labels, float *lse, float *loss, float *n_counted,
+                            int32_t *status, int64_t n, int32_t K, void *workspace, size_t workspace_bytes, void *stream_)
 {
     using namespace stg;
     if (n <= 0 || K <= 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_fwd: bad shape n=%lld K=%d", (long long)n, K);
-    if (!logits || !labels || !lse || !loss || !status || !workspace)
+    if (!logits || !labels || !lse || !loss || !n_counted || !status || !workspace)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_fwd: NULL pointer argument");
     if (workspace_bytes < stg_xent_workspace_bytes(n, K)) return fail(STG_ERR_WORKSPACE, "stg_xent_fwd: workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int blocks = xent_blocks(n, K);
     float *partial = static_cast<float *>(workspace);
+    int *partial_cnt = reinterpret_cast<int *>(partial + blocks);
     const bool v4 = K % 4 == 0 && reinterpret_cast<uintptr_t>(logits) % 16 == 0;
 #define STG_XENT(G)                                                                                                    \
     if (v4)                                                                                                            \
         hipLaunchKernelGGL((xent_fwd_kernel<G, true>), dim3(blocks), dim3(kBlock), 0, stream, logits, labels, lse,     \
-                           partial, n, K, status);                                                                     \
+                           partial, partial_cnt, n, K, status);                                                        \
     else                                                                                                               \
         hipLaunchKernelGGL((xent_fwd_kernel<G, false>), dim3(blocks), dim3(kBlock), 0, stream, logits, labels, lse,    \
-                           partial, n, K, status)
+                           partial, partial_cnt, n, K, status)
     switch (xent_lanes(K)) {
         case 8: STG_XENT(8); break;
         case 32: STG_XENT(32); break;
         default: STG_XENT(64); break;
     }
 #undef STG_XENT
-    hipLaunchKernelGGL(xent_finish_kernel, dim3(1), dim3(kBlock), 0, stream, partial, blocks, 1.0f / (float)n, loss);
+    hipLaunchKernelGGL(xent_finish_kernel, dim3(1), dim3(kBlock), 0, stream, partial, partial_cnt, blocks, loss, n_counted);
     return check_launch("stg_xent_fwd");
 }
 
 extern "C" int stg_xent_bwd(const float *g_loss, const float *logits, const int64_t *labels, const float *lse,
-                            float *dlogits, int64_t n, int64_t n_total, int32_t K, void *stream_)
+                            const float *n_counted, float *dlogits, int64_t n, int64_t n_total, int32_t K, void *stream_)
 {
     using namespace stg;
     if (n <= 0 || K <= 0 || n_total < n) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd: bad shape");
-    if (!g_loss || !logits || !labels || !lse || !dlogits) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd: NULL pointer argument");
+    if (!g_loss || !logits || !labels || !lse || !n_counted || !dlogits) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd: NULL pointer argument");
     const int64_t total = n_total * (int64_t)K;
     const int blocks = (int)std::min<int64_t>((total + kBlock - 1) / kBlock, 256 * 16);
     hipLaunchKernelGGL(xent_bwd_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream_), g_loss, logits, labels,
-                       lse, dlogits, n, n_total, K, 1.0f / (float)n);
+                       lse, dlogits, n, n_total, K, n_counted);
     return check_launch("stg_xent_bwd");
 }

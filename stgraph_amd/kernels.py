@@ -1018,34 +1018,60 @@ def tgcn_head_bwd(g_loss, g_y, g_yout, h, y_out, target, W1, W2):
 _XENT_STATUS = {}
 
 
+def xent_status(device=None, clear: bool = True) -> int:
+    """Read (one device sync) and by default clear the sticky label-status word(s) of ``xent_fwd``: non-zero when
+    a label that is neither a class index nor ignore_index (-100) reached the kernel since the last clear (torch
+    would have raised a device assert).  ``device`` None: OR over every device used so far."""
+    word = 0
+    for dev, st in list(_XENT_STATUS.items()):
+        if device is None or torch.device(device) == dev:
+            word |= int(st.item())
+            if clear:
+                st.zero_()
+    return word
+
+
+def check_xent_status(device=None) -> None:
+    """Raise if ``xent_status`` is set (call it wherever a sync is affordable, e.g. once per epoch)."""
+    if xent_status(device):
+        raise _C.StgError(_C.STG_ERR_INVALID_ARGUMENT, "cross_entropy: a label outside [0, K) other than ignore_index = -100 was seen; "
+                          "its row was left out of the loss and received no gradient")
+
+
 def xent_fwd(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None):
     """Mean softmax cross-entropy over the first ``rows`` rows (default: all) (stg_xent_fwd).  Returns (loss [1],
-    lse [rows], status [1] int32: non-zero if a label was out of range in this or an earlier call on the device -- a
-    sticky word that is not read here: the caller decides whether to pay the sync)."""
+    lse [rows], n_counted [1] float: the rows that took part -- label -100 = ignore_index does not, as in torch,
+    status [1] int32: non-zero if another out-of-range label was seen in this or an earlier call on the device -- a
+    sticky word that is not read here: ``check_xent_status`` pays the sync when the caller wants it)."""
     n, K = logits.shape
     n = n if rows is None else int(rows)
     dev = logits.device
+    if not labels.is_cuda or labels.device != dev:
+        raise ValueError(f"xent_fwd: labels on {labels.device}, logits on {dev}")
     lse = torch.empty(n, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
+    n_counted = torch.empty(1, dtype=torch.float32, device=dev)
     status = _XENT_STATUS.get(dev)
     if status is None:                          # one sticky word per device, zeroed once (the kernel only ORs into it)
         status = _XENT_STATUS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
     ws_bytes = int(_C.lib.stg_xent_workspace_bytes(n, K))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev), _Timed("xent_fwd", 4 * n * (K + 3), 4 * n * K):
-        _C.check(_C.lib.stg_xent_fwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(loss), _ptr(status), n, K, _ptr(ws),
-                                     ws_bytes, _stream_ptr(dev)))
-    return loss, lse, status
+        _C.check(_C.lib.stg_xent_fwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(loss), _ptr(n_counted), _ptr(status),
+                                     n, K, _ptr(ws), ws_bytes, _stream_ptr(dev)))
+    return loss, lse, n_counted, status
 
 
-def xent_bwd(g_loss: torch.Tensor, logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor) -> torch.Tensor:
-    """Gradient of xent_fwd for the WHOLE logits matrix: rows beyond ``lse.shape[0]`` (not part of the loss) are zero."""
+def xent_bwd(g_loss: torch.Tensor, logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor,
+             n_counted: torch.Tensor) -> torch.Tensor:
+    """Gradient of xent_fwd for the WHOLE logits matrix: rows beyond ``lse.shape[0]`` (not part of the loss) and rows
+    the forward did not count are zero."""
     n_total, K = logits.shape
     n = int(lse.shape[0])
     d = torch.empty_like(logits)
     with torch.cuda.device(logits.device), _Timed("xent_bwd", 4 * n * (2 * K + 3) + 4 * (n_total - n) * K, 4 * n * K):
-        _C.check(_C.lib.stg_xent_bwd(_ptr(g_loss), _ptr(logits), _ptr(labels), _ptr(lse), _ptr(d), n, n_total, K,
-                                     _stream_ptr(logits.device)))
+        _C.check(_C.lib.stg_xent_bwd(_ptr(g_loss), _ptr(logits), _ptr(labels), _ptr(lse), _ptr(n_counted), _ptr(d), n,
+                                     n_total, K, _stream_ptr(logits.device)))
     return d
 
 

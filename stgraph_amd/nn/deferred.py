@@ -27,9 +27,16 @@ from .. import kernels
 
 # One backward pass at a time per process.  The autograd engine may run custom nodes on a device worker
 # thread and the end-of-pass callback on the thread that called backward(), so this is a plain global
-# guarded by a lock, not a thread-local.
+# guarded by a lock, not a thread-local.  The accumulator is tied to the engine's graph task: a backward()
+# that raised never runs its queued callbacks, so whatever it registered is dropped -- not flushed into, or
+# withheld from, the next pass -- as soon as a node of another task asks for the accumulator.
 _lock = threading.Lock()
 _active = None
+_active_task = None
+
+
+def _graph_task_id() -> int:
+    return int(torch._C._current_graph_task_id())
 
 
 class WeightGradAccumulator:
@@ -82,17 +89,28 @@ def add_to_grad(param: torch.Tensor, value: torch.Tensor) -> None:
 def current() -> WeightGradAccumulator:
     """The accumulator of the backward pass that is running on this thread (created on demand; its
     flush is queued to run when the autograd engine finishes the pass)."""
-    global _active
+    global _active, _active_task
+    task = _graph_task_id()
     with _lock:
         acc = _active
-        if acc is None:
+        if acc is None or _active_task != task:          # None, or left behind by a backward() that raised
             acc = _active = WeightGradAccumulator()
+            _active_task = task
 
-            def _finish():
-                global _active
+            def _finish(acc=acc):
+                global _active, _active_task
                 with _lock:
-                    _active = None
+                    if _active is acc:
+                        _active, _active_task = None, None
                 acc.flush()
 
             Variable._execution_engine.queue_callback(_finish)
     return acc
+
+
+def reset() -> None:
+    """Drop whatever an interrupted backward pass left registered (``current()`` does the same on its own when the
+    next pass starts; this frees the tensors right away)."""
+    global _active, _active_task
+    with _lock:
+        _active, _active_task = None, None

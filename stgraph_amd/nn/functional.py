@@ -171,23 +171,28 @@ class _CrossEntropy(torch.autograd.Function):
     def forward(ctx, logits, labels, rows=None):
         logits = logits.contiguous()
         labels = labels.contiguous()
-        loss, lse, _ = kernels.xent_fwd(logits, labels, rows)
-        ctx.save_for_backward(logits, labels, lse)
+        loss, lse, n_counted, _ = kernels.xent_fwd(logits, labels, rows)
+        ctx.save_for_backward(logits, labels, lse, n_counted)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        logits, labels, lse = ctx.saved_tensors
-        return kernels.xent_bwd(g.contiguous(), logits, labels, lse), None, None
+        logits, labels, lse, n_counted = ctx.saved_tensors
+        return kernels.xent_bwd(g.contiguous(), logits, labels, lse, n_counted), None, None
 
 
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None) -> torch.Tensor:
     """``nn.CrossEntropyLoss()(logits, labels)``: the fused launches for 2-D fp32 device logits and int64 class
-    labels, ``F.cross_entropy`` otherwise (same value and gradient up to fp32 rounding).  ``rows``: take the loss on
-    ``logits[:rows]`` / ``labels[:rows]`` (the train-mask prefix of the GCN scripts) without slicing -- the backward then
-    writes the whole gradient matrix (zero beyond ``rows``) in its one launch instead of autograd's fill + copy."""
+    labels on the same device, ``F.cross_entropy`` otherwise (same value and gradient up to fp32 rounding).  Rows
+    labelled ``ignore_index`` = -100 are left out of the sum, the mean's denominator and the gradient, as in torch;
+    any other label outside [0, K) -- a device assert in torch -- is left out the same way and recorded in a sticky
+    per-device word that ``kernels.check_xent_status()`` reads (one sync; call it where that is affordable).
+    ``rows``: take the loss on ``logits[:rows]`` / ``labels[:rows]`` (the train-mask prefix of the GCN scripts)
+    without slicing -- the backward then writes the whole gradient matrix (zero beyond ``rows``) in its one launch
+    instead of autograd's fill + copy."""
     n = logits.shape[0] if rows is None else int(rows)
     if (logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and labels.dtype == torch.int64
+            and labels.is_cuda and labels.device == logits.device
             and labels.dim() == 1 and labels.shape[0] >= n and 0 < n <= logits.shape[0]):
         return _CrossEntropy.apply(logits, labels, None if rows is None else n)
     return F.cross_entropy(logits[:n], labels[:n])

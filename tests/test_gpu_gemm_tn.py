@@ -59,3 +59,20 @@ def test_autograd_wrappers_match_torch(cuda):
                 assert (g - r).abs().max() <= 2e-5 * r.abs().max() + 1e-5, native
     finally:
         SF.set_native_weight_grad(True)
+
+
+def test_slices_stay_inside_32bit_addressing(cuda):
+    """A launch whose plan would give one wave K/4 rows of an 8192-float-wide operand (>= 2^31 bytes per slice:
+    buffer descriptor and scalar row offsets are 32-bit) is cut into more slices instead (integer data: exact)."""
+    from stgraph_amd import kernels
+    K, M, N, T = 262_144 + 48, 32, 8192, 8              # 64 tiles x 8 segments = 512 blocks: one slice per segment
+    a = (torch.arange(K * M, device=cuda) % 5 - 2).float().view(K, M)
+    b = (torch.arange(K * N, device=cuda) % 3 - 1).float().view(K, N)
+    want = torch.zeros(M, N, dtype=torch.float64, device=cuda)
+    for r in range(0, K, 65_536):                        # fp64 in row chunks (b.double() at once would be 17 GB)
+        want += a[r:r + 65_536].double().t() @ b[r:r + 65_536].double()
+    got, cs = kernels.gemm_tn_multi([a] * T, [b] * T, colsum=True)
+    assert torch.equal(got.double(), want * T)
+    assert torch.equal(cs.double(), a.double().sum(0) * T)
+    del a, b
+    torch.cuda.empty_cache()

@@ -54,12 +54,60 @@ def test_out_of_range_label_sets_the_status_word(cuda):
     from stgraph_amd import kernels
     logits = torch.randn(100, 5, device=cuda)
     labels = torch.randint(0, 5, (100,), device=cuda)
-    _, _, status = kernels.xent_fwd(logits, labels)
+    *_, status = kernels.xent_fwd(logits, labels)
     assert int(status.item()) == 0
     labels[17] = 5
-    _, _, status = kernels.xent_fwd(logits, labels)
+    *_, status = kernels.xent_fwd(logits, labels)
     assert int(status.item()) != 0
-    status.zero_()                              # the word is sticky: clear it for whoever comes next
+    with pytest.raises(kernels._C.StgError):
+        kernels.check_xent_status(cuda)         # reads AND clears the sticky word
+    assert kernels.xent_status(cuda) == 0
+
+
+def test_ignore_index_and_bad_labels_match_torch(cuda):
+    """ignore_index = -100 rows: no loss term, not in the denominator, zero gradient -- torch's semantics; another
+    out-of-range label is treated the same way (torch asserts) and reported."""
+    from stgraph_amd import kernels
+    from stgraph_amd.nn import functional as SF
+    g = torch.Generator(device=cuda).manual_seed(5)
+    for n, K in ((100, 5), (5000, 128), (3, 7)):
+        base = torch.randn(n, K, device=cuda, generator=g)
+        labels = torch.randint(0, K, (n,), device=cuda, generator=g)
+        labels[::3] = -100
+        a = base.clone().requires_grad_(True)
+        la = SF.cross_entropy(a, labels)
+        (la * 1.7).backward()
+        b = base.clone().requires_grad_(True)
+        lb = F.cross_entropy(b, labels)
+        (lb * 1.7).backward()
+        torch.testing.assert_close(la, lb, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-9)
+        assert not a.grad[::3].any()
+        assert kernels.xent_status(cuda) == 0
+        # a label that is neither a class nor ignore_index: same as ignored, but reported
+        bad = labels.clone()
+        bad[1] = K + 3
+        ref = labels.clone()
+        ref[1] = -100
+        c = base.clone().requires_grad_(True)
+        SF.cross_entropy(c, bad).backward()
+        d = base.clone().requires_grad_(True)
+        F.cross_entropy(d, ref).backward()
+        torch.testing.assert_close(c.grad, d.grad, rtol=1e-4, atol=1e-9)
+        assert kernels.xent_status(cuda) != 0 and kernels.xent_status(cuda) == 0
+    # all rows ignored: 0 / 0, as torch
+    x = torch.randn(4, 3, device=cuda)
+    assert torch.isnan(SF.cross_entropy(x, torch.full((4,), -100, device=cuda, dtype=torch.int64)))
+
+
+def test_labels_on_another_device_do_not_reach_the_kernel(cuda):
+    from stgraph_amd import kernels
+    from stgraph_amd.nn import functional as SF
+    x = torch.randn(6, 3, device=cuda)
+    with pytest.raises(ValueError):
+        kernels.xent_fwd(x, torch.zeros(6, dtype=torch.int64))
+    with pytest.raises(Exception):              # F.cross_entropy's own device check, not a GPU fault
+        SF.cross_entropy(x, torch.zeros(6, dtype=torch.int64))
 
 
 @pytest.mark.parametrize("n_total,rows,K", [(2708, 1624, 7), (100_000, 60_000, 128), (50, 50, 3), (10, 1, 5)])
