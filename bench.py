@@ -21,10 +21,19 @@ the epoch is fixed, ranks split its windows).
 A "dynamic" object carries BASELINE configs[4] (dynamic-temporal TGCN): epochs/s with the per-snapshot device
 CSR rebuild (its `value`) and on the dynamic edge store (PCSRGraph), windows sharded over the ranks.
 
+A "gat" object carries BASELINE configs[2] (GAT, 8 heads, |V| = 256K, |E| = 8M): one GATConv layer forward + backward
+with a per-kernel table, and the 2-layer model of benchmarking/gat/seastar/model.py as epochs/s (rank 0 only).
+
 "roofline": dominant kernel gcn_agg -- algorithmic bytes per launch over its
-mean launch time, measured with HIP events on the launch stream inside the timed region.
-"cpu_baseline": the C oracle (OpenMP port of the emitted kernel) timed on this host's cores
-on a bounded sample of the same workload (rank 0, N = 1 only).
+mean launch time, measured with HIP events on the launch stream inside the timed region; "traffic" = HBM bytes per
+launch from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate child runs of tools/pmc_gcn.py made by this
+script at N = 1, corrected as the microarchitecture guide prescribes; the committed passes under profiles/ if a child
+run fails).  "roofline.north_star" is the figure the north star's >= 60 % target is stated on: the fused GCN
+aggregation forward + backward at the Cora widths on 1024 replicas of the Cora-shaped graph.  Every config object
+("cora", "gat", "tgcn", "dynamic") carries its own "roofline" with a "frac" and the byte model it is taken against.
+"cpu_baseline": the same training epoch (forward, loss, backward, Adam) in plain torch on this host's cores --
+torch.sparse_csr_tensor(A_hat) @ dense, SURVEY.md 8(d) variant (i) -- on a bounded sample (rank 0, N = 1 only), with
+the C oracle's OpenMP aggregation (variant (ii)) beside it; "cora.cpu_baseline" is BASELINE configs[0]'s CPU path.
 """
 from __future__ import annotations
 
@@ -115,7 +124,7 @@ def gcn_setup(device, seed, n, e, feat):
         opt.step()
         return loss
 
-    return step, dict(n=n, e=e, feat=feat, agg_launches_per_step=4, graph=g, norm=norm, x=x)
+    return step, dict(n=n, e=e, feat=feat, agg_launches_per_step=4, graph=g, norm=norm, x=x, labels=labels)
 
 
 def cpu_baseline_gcn(meta, budget_s=20.0):
@@ -143,6 +152,77 @@ def cpu_baseline_gcn(meta, budget_s=20.0):
                       f"by oracle/stg_oracle.c, OpenMP over rows, {dt:.1f} s wall"}
 
 
+def torch_cpu_gcn_epochs(row_off, col, norm, x, labels, ntrain, widths, epochs, warmup, budget_s, seed=0, threads=None):
+    """SURVEY.md 8(d) CPU variant (i): the reference model's epoch in plain torch on the host -- A_hat as a
+    torch.sparse_csr_tensor (values norm[row] * norm[col]), each layer ``act(A_hat (h W) + b)``, cross-entropy on the
+    first ``ntrain`` rows, backward, Adam(1e-2, wd 5e-4).  Returns (mean seconds per epoch, epochs timed, threads)."""
+    threads = threads or os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    import warnings
+    row_off, col = row_off.cpu().long(), col.cpu().long()
+    nrm = norm.cpu().reshape(-1)
+    n = nrm.shape[0]
+    rows = torch.repeat_interleave(torch.arange(n), row_off[1:] - row_off[:-1])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        A = torch.sparse_csr_tensor(row_off, col, nrm[rows] * nrm[col], size=(n, n))
+    x, labels = x.cpu(), labels.cpu()
+    torch.manual_seed(seed)
+    Ws, bs = [], []
+    for fi, fo in zip(widths[:-1], widths[1:]):
+        w = torch.empty(fi, fo)
+        torch.nn.init.xavier_uniform_(w)
+        Ws.append(w.requires_grad_(True))
+        bs.append(torch.zeros(fo, requires_grad=True))
+    opt = torch.optim.Adam(Ws + bs, lr=1e-2, weight_decay=5e-4)
+    dur = []
+    t_start = time.time()
+    for ep in range(warmup + epochs):
+        t0 = time.perf_counter()
+        h = x
+        for li, (w, b) in enumerate(zip(Ws, bs)):
+            h = torch.sparse.mm(A, h @ w) + b
+            if li + 1 < len(Ws):
+                h = F.relu(h)
+        loss = F.cross_entropy(h[:ntrain], labels[:ntrain])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if ep >= warmup:
+            dur.append(time.perf_counter() - t0)
+        if time.time() - t_start > budget_s and len(dur) >= 1:
+            break
+    return float(np.mean(dur)), len(dur), threads
+
+
+def host_description():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "logical_cores": os.cpu_count(), "torch": torch.__version__}
+
+
+def cpu_baseline_epoch_gcn(meta, ntrain, labels, budget_s=20.0):
+    """The main line's workload (cfg2 training epoch) on the host in plain torch; bounded: at most 2 epochs /
+    ``budget_s`` (no warm-up epoch: one epoch takes ~20 s on a 256-thread host)."""
+    f = meta["graph"].csr("fwd")
+    sec, timed, threads = torch_cpu_gcn_epochs(f.row_offset, f.column_indices, meta["norm"], meta["x"], labels, ntrain,
+                                               [meta["feat"]] * 3, epochs=2, warmup=0, budget_s=budget_s)
+    return {"value": meta["agg_launches_per_step"] * meta["e"] * meta["feat"] / sec, "unit": "edges*feat/s",
+            "cores": threads, "kind": "port", "seconds_per_epoch": sec,
+            "sample": f"{timed} full training epoch(s) of the same model and graph (|V|={meta['n']}, |E|={meta['e']}, "
+                      f"{meta['feat']}->{meta['feat']}->{meta['feat']}) in plain torch on the host: "
+                      "torch.sparse_csr_tensor(A_hat) @ dense per layer, cross-entropy, backward, Adam "
+                      "(SURVEY.md 8(d) CPU variant (i); the reference has no CPU path of its own)",
+            "host": host_description()}
+
+
 # ------------------------------------------------------------------------- GCN-Cora (cfg 1)
 def cora_shaped(seed=0, n=2708, pairs=5278, max_deg=168):
     """Cora-SHAPED synthetic graph (the real dataset needs the network): Chung-Lu style power-law
@@ -162,7 +242,7 @@ def cora_shaped(seed=0, n=2708, pairs=5278, max_deg=168):
     return np.concatenate([und[:, 0], und[:, 1]]), np.concatenate([und[:, 1], und[:, 0]])
 
 
-def cora_run(device, epochs=200):
+def cora_run(device, epochs=200, cpu_baseline=False):
     """BASELINE configs[0] shape: 2-layer GCN 1433 -> 16 -> 7, Adam(1e-2, wd 5e-4), cross-entropy on
     the first 60 % (benchmarking/gcn/seastar/train.py:63-101).  Timing rule of the reference: wall
     clock between device syncs around each epoch, epochs 0-2 discarded.  Reported eagerly and with the
@@ -212,7 +292,39 @@ def cora_run(device, epochs=200):
                      "edges_feat_per_s": 2 * e * (16 + 7) / float(np.mean(dur)), "final_loss": float(loss)}
     out["metric"], out["value"] = "epochs/s", out["hip_graph"]["epochs_per_s"]
     out["roofline_x1024"] = cora_roofline(device, src, dst, n)
+    # the single 2708-vertex graph is launch-latency bound: its own fraction, for the record
+    per_epoch_bytes = 2 * (kernels_bytes(n, e, 16) + kernels_bytes(n, e, 7))
+    out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                       "bytes_model": "4 gcn_agg launches per epoch (F = 16 and F = 7, forward + backward), SURVEY.md 8(d) bytes",
+                       "achieved": per_epoch_bytes / (out["hip_graph"]["ms_per_epoch"] * 1e-3) / 1e9,
+                       "frac": per_epoch_bytes / (out["hip_graph"]["ms_per_epoch"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "note": "whole captured epoch (GEMMs, loss, Adam included) against the aggregation bytes only: "
+                               "launch bound; the bandwidth-bound variant of the same shape is roofline_x1024",
+                       "x1024_frac": out["roofline_x1024"]["frac"]}
+    if cpu_baseline:
+        f = g.csr("fwd")
+        # a 2708-vertex epoch is a few ms of work: with every logical core in the pool torch spends its time waking
+        # threads, so the pool size is part of the baseline -- both settings are timed, the faster one is the value
+        tried = {}
+        for th in sorted({min(16, os.cpu_count() or 1), os.cpu_count() or 1}):
+            sec, timed, _ = torch_cpu_gcn_epochs(f.row_offset, f.column_indices, g.get_ndata("norm"), x, labels, ntrain,
+                                                 [1433, 16, 7], epochs=100, warmup=3, budget_s=7.0, threads=th)
+            tried[th] = (sec, timed)
+        threads = min(tried, key=lambda k: tried[k][0])
+        sec, timed = tried[threads]
+        out["cpu_baseline"] = {"value": 1.0 / sec, "unit": "epochs/s", "cores": threads, "kind": "port",
+                               "edges_feat_per_s": 2 * e * (16 + 7) / sec, "ms_per_epoch": sec * 1e3,
+                               "ms_per_epoch_by_threads": {str(k): v[0] * 1e3 for k, v in tried.items()},
+                               "sample": f"{timed} epochs of the same model on the same graph in plain torch on the host "
+                                         "(torch.sparse_csr_tensor(A_hat) @ dense, cross-entropy, backward, Adam): BASELINE "
+                                         "configs[0] 'CPU PyTorch reference path'; baseline, not target",
+                               "host": host_description()}
     return out
+
+
+def kernels_bytes(n, e, f, ew=False):
+    from stgraph_amd import kernels
+    return kernels.gcn_agg_algorithmic_bytes(n, e, f, ew)
 
 
 def cora_roofline(device, src, dst, n, K=1024, iters=10):
@@ -227,6 +339,7 @@ def cora_roofline(device, src, dst, n, K=1024, iters=10):
     norm = torch.rand(N, 1, device=device) + 0.5
     res = {"workload": f"gcn_agg forward + backward launch on {K} disjoint replicas of the Cora-shaped graph "
                        f"(|V|={N}, |E|={E})"}
+    tot_b, tot_ms = 0, 0.0
     for F_ in (16, 7):
         x = torch.randn(N, F_, device=device)
         nbytes = kernels.gcn_agg_algorithmic_bytes(N, E, F_, False)
@@ -244,9 +357,126 @@ def cora_roofline(device, src, dst, n, K=1024, iters=10):
         gbps = 2 * nbytes / (sum(ms) * 1e-3) / 1e9
         res[f"F{F_}"] = {"fwd_ms": ms[0], "bwd_ms": ms[1], "algorithmic_bytes_per_launch": nbytes,
                          "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
+        tot_b += 2 * nbytes
+        tot_ms += sum(ms)
+    # the Cora model's four aggregation launches per epoch (F = 16 and F = 7, forward and backward) together
+    res["achieved"] = tot_b / (tot_ms * 1e-3) / 1e9
+    res["frac"] = res["achieved"] / HBM_PEAK_GBS
+    res["bound"], res["unit"], res["peak"] = "hbm", "GB/s", HBM_PEAK_GBS
     del g, x, norm
     torch.cuda.empty_cache()
     return res
+
+
+# ------------------------------------------------------------------------------ GAT (cfg 3)
+class GAT(nn.Module):
+    """benchmarking/gat/seastar/model.py:4-42 (hidden GATConv layers flattened over heads, output layer averaged)."""
+
+    def __init__(self, g, num_layers, in_dim, num_hidden, num_classes, heads, activation, feat_drop=0., attn_drop=0.,
+                 negative_slope=0.2):
+        super().__init__()
+        from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+        self.g = g
+        self.num_layers = num_layers
+        self.gat_layers = nn.ModuleList()
+        self.gat_layers.append(GATConv(in_dim, num_hidden, heads[0], feat_drop, attn_drop, negative_slope, activation))
+        for l in range(1, num_layers):
+            self.gat_layers.append(GATConv(num_hidden * heads[l - 1], num_hidden, heads[l], feat_drop, attn_drop,
+                                           negative_slope, activation))
+        self.gat_layers.append(GATConv(num_hidden * heads[-2], num_classes, heads[-1], feat_drop, attn_drop,
+                                       negative_slope, None))
+
+    def forward(self, inputs):
+        h = inputs
+        for l in range(self.num_layers):
+            h = self.gat_layers[l](self.g, h).flatten(1)
+        return self.gat_layers[-1](self.g, h).mean(1)
+
+
+def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer_iters=10, epochs=12):
+    """BASELINE configs[2]: (a) one GATConv(64 -> 8 x 64) forward + backward with per-kernel HIP-event times, each
+    against its SURVEY.md 8(d) byte model; (b) the 2-layer model of benchmarking/gat/seastar/model.py
+    (GATConv(64, 64, 8 heads, elu) -> GATConv(512, classes, 1 head), mean over heads), cross-entropy on the first 60 %,
+    Adam(5e-3, wd 5e-4) as gat/seastar/train.py runs it: epochs/s by the reference's timing rule."""
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    src, dst = synthetic_graph(n, e, 2, device)
+    g = StaticGraph((src, dst), None, n, device=device, sort_inplace=False)
+    gen = torch.Generator(device=device).manual_seed(2)
+    torch.manual_seed(2)
+    conv = GATConv(fin, D, H).to(device)
+    x = torch.randn(n, fin, device=device, generator=gen).requires_grad_(True)
+    R = torch.randn(n, H, D, device=device, generator=gen)
+    for _ in range(3):
+        (conv(g, x) * R).sum().backward()
+    rec = []
+    kernels.enable_launch_timing(rec)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(layer_iters):
+        conv.zero_grad()
+        x.grad = None
+        (conv(g, x) * R).sum().backward()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / layer_iters
+    kernels.enable_launch_timing(None)
+    tab = {}
+    for name, a, b, nbytes, _ in rec:
+        d = tab.setdefault(name, {"ms": [], "bytes": nbytes})
+        d["ms"].append(a.elapsed_time(b))
+    ktab = {k: {"launches_per_iter": len(v["ms"]) / layer_iters, "mean_ms": float(np.mean(v["ms"])),
+                "algorithmic_bytes": v["bytes"],
+                "frac_of_hbm_peak": v["bytes"] / float(np.mean(v["ms"])) / 1e6 / HBM_PEAK_GBS} for k, v in tab.items()}
+    if "gat_bwd" in ktab:   # the factored backward moves fewer bytes than the SURVEY model of the emitted unit
+        moved = 4 * e * H * D + 12 * e * H + 16 * n * H * D
+        ktab["gat_bwd"]["bytes_model"] = "SURVEY.md 8(d) model of the emitted K2 (two E*H*D gathers)"
+        ktab["gat_bwd"]["moved_bytes_factored_form"] = moved
+        ktab["gat_bwd"]["frac_of_hbm_peak_on_moved_bytes"] = moved / ktab["gat_bwd"]["mean_ms"] / 1e6 / HBM_PEAK_GBS
+    ab = kernels.gat_algorithmic_bytes(n, e, H, D)
+    unit_bytes = ab["gat_k0"] + ab["gat_k1"] + ab["gat_bwd"] + ab["gat_bwd_er"]
+    k1 = ktab.get("gat_k1", {})
+    layer = {"ms_per_fwd_bwd": dt * 1e3, "edges_feat_per_s": 2 * e * H * D / dt, "kernels": ktab}
+    del conv, x, R
+    torch.cuda.empty_cache()
+
+    # (b) 2-layer model, training epochs
+    torch.manual_seed(2)
+    feats = torch.randn(n, fin, device=device, generator=gen)
+    labels = torch.randint(0, classes, (n,), device=device, generator=gen)
+    ntrain = int(0.6 * n)
+    model = GAT(g, 1, fin, D, classes, [H, 1], F.elu).to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4)   # gat/seastar/train.py defaults
+    dur = []
+    for ep in range(epochs):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.train()
+        logits = model(feats)
+        loss = SF.cross_entropy(logits, labels, ntrain)        # = CrossEntropyLoss()(logits[train_mask], labels[train_mask])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        if ep >= 3:
+            dur.append(time.perf_counter() - t0)
+    sec = float(np.mean(dur))
+    ef_epoch = 2 * e * (H * D + classes)                        # K1 + K2 of both layers
+    return {"workload": f"GAT |V|={n} |E|={e} in={fin} heads={H} D={D} negative_slope=0.2 (BASELINE configs[2]); "
+                        f"layer = GATConv({fin}, {D}, {H}) forward + backward; model = GATConv({fin},{D},{H},elu) -> "
+                        f"GATConv({H * D},{classes},1), cross-entropy, Adam (benchmarking/gat/seastar)",
+            "metric": "epochs/s", "value": 1.0 / sec, "ms_per_epoch": sec * 1e3, "epochs_timed": len(dur),
+            "edges_feat_per_s": ef_epoch / sec, "final_loss": float(loss.detach()),
+            "layer": layer,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": "stg::gat_k1_kernel",
+                         "achieved": k1.get("algorithmic_bytes", 0) / k1["mean_ms"] / 1e6 if k1 else None,
+                         "frac": k1.get("frac_of_hbm_peak"),
+                         "algorithmic_bytes_per_launch": k1.get("algorithmic_bytes"),
+                         "mean_launch_ms": k1.get("mean_ms"),
+                         "layer_frac": unit_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                         "layer_bytes_model": "the four emitted units K0 + K1 + K2 + grad_er pass (SURVEY.md 8(d)) over the "
+                                              "WHOLE layer time (fc GEMM, projections and their gradients included)"}}
 
 
 # ----------------------------------------------------------------------------- TGCN (cfg 4)
@@ -295,6 +525,7 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
     for name, a, b, nbytes, _ in records:                        # per-kernel HIP-event times of the eager epoch
         d = ktab.setdefault(name, {"ms": [], "bytes": nbytes})
         d["ms"].append(a.elapsed_time(b))
+    native_bytes_epoch = float(sum(r[3] for r in records))       # byte models of this build's own kernels, one epoch
     ktab = {k: {"launches": len(v["ms"]), "mean_ms": float(np.mean(v["ms"])),
                 "algorithmic_GBps": v["bytes"] / float(np.mean(v["ms"])) / 1e6} for k, v in ktab.items()}
     records = [r for r in records if r[0] in ("gcn_agg", "gcn_agg_transform")]
@@ -323,7 +554,25 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
     fused = bool(model.temporal.fuse_gates)
     agg_per_step = 2 if fused else 6                             # (fwd + bwd) x (1 fused | 3 separate) gates
     width = (3 if fused else 1) * hidden                         # width of the layer's aggregation A_hat (X W)
+    steps_rank0 = sum(min(B, T - w * B) for _, w in temporal.windows_of_rank(T, B, rank, world) if w is not None)
+    sec_per_snapshot = dt / epochs / max(steps_rank0, 1)         # this rank's snapshots run back to back
+    # SURVEY.md 8(d) byte model of the reference's formulation: per snapshot three edge-weighted width-`hidden`
+    # aggregations forward + three backward (nn/pytorch/temporal/tgcn.py:21-43 through gcn_conv.py:169-182)
+    ref_bytes = 6 * kernels.gcn_agg_algorithmic_bytes(n, e, hidden, True)
+    roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "seconds_per_snapshot": sec_per_snapshot,
+            "bytes_model": "reference formulation: 6 edge-weighted gcn_agg launches of width hidden per snapshot "
+                           "(3 gates, forward + backward), SURVEY.md 8(d) bytes each; time = the WHOLE captured step "
+                           "(aggregation, GRU cell, head, loss, weight gradients, Adam)",
+            "algorithmic_bytes_per_snapshot": ref_bytes,
+            "achieved": ref_bytes / sec_per_snapshot / 1e9, "frac": ref_bytes / sec_per_snapshot / 1e9 / HBM_PEAK_GBS,
+            "own_kernels_bytes_per_snapshot": native_bytes_epoch / max(steps_rank0, 1),
+            "own_kernels_frac": native_bytes_epoch / max(steps_rank0, 1) / sec_per_snapshot / 1e9 / HBM_PEAK_GBS,
+            "own_kernels_note": "sum of the byte models of every native launch of one snapshot as THIS build runs it "
+                                "(one width-in aggregate-then-transform + fused cell + head forward; their backward; "
+                                "amortised weight gradients) over the same time"}
     return {
+        "roofline": roof,
         "workload": f"static-temporal TGCN |V|={n} |E|={e} T={T} feat={feat} hidden={hidden} backprop_every={B} "
                     f"(BASELINE configs[3]), windows sharded over {world} rank(s), Adam; "
                     f"{'fused 3-gate aggregation (one launch; aggregate-then-transform on the matrix cores)' if fused else 'three width-64 aggregations'} per snapshot, fused row-local GRU cell, "
@@ -399,11 +648,80 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
         if mode != "rebuild_per_snapshot":
             G.check()
         out[mode] = {"epochs_per_s": epochs / dt, "seconds_per_epoch": dt / epochs}
+        if mode == "rebuild_per_snapshot":
+            from stgraph_amd import kernels
+            steps_rank0 = sum(max(0, min(B, T - 1 - w * B)) for _, w in temporal.windows_of_rank(T, B, rank, world)
+                              if w is not None)
+            sps = dt / epochs / max(steps_rank0, 1)
+            ref_bytes = 6 * kernels.gcn_agg_algorithmic_bytes(n, e0, hidden, False) + 2 * 16 * e0
+            roofline = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "seconds_per_snapshot": sps,
+                        "bytes_model": "reference formulation per snapshot: 6 un-weighted gcn_agg launches of width hidden "
+                                       "(3 gates, forward + backward) + the CSR build's 16 B/edge per direction "
+                                       "(SURVEY.md 8(d)); time = the whole step incl. rebuild, cell, link head, Adam",
+                        "algorithmic_bytes_per_snapshot": ref_bytes, "achieved": ref_bytes / sps / 1e9,
+                        "frac": ref_bytes / sps / 1e9 / HBM_PEAK_GBS,
+                        "note": "|V| = 25K snapshots: launch- and host-bound, not bandwidth-bound"}
         del G, model, opt, bucket
     return {"workload": f"dynamic-temporal TGCN |V|={n} E0={e0} +-{churn} edges/step T={T} backprop_every={B} feat={feat} "
                         f"hidden={hidden} (BASELINE configs[4]), link-prediction loss, windows sharded over {world} rank(s)",
             "metric": "epochs/s", "value": out["rebuild_per_snapshot"]["epochs_per_s"], "scaling": "strong",
-            "n_gpus": world, "epochs": epochs, "windows_per_epoch": temporal.num_windows(T, B), **out}
+            "n_gpus": world, "epochs": epochs, "windows_per_epoch": temporal.num_windows(T, B), "roofline": roofline,
+            **out}
+
+
+def live_pmc_traffic(iters=2, timeout_s=170):
+    """HBM bytes per cfg2 gcn_agg launch measured NOW: two child runs of tools/pmc_gcn.py under
+    ``rocprofv3 --pmc`` (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, counters only, no trace domains), reduced as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: KiB units, WRITE_SIZE exact for 16-B-per-lane stores,
+    FETCH_SIZE of a wide coalesced read x2 on gfx950 -- the factor is re-measured on the script's calibration launch
+    (known bytes, same access shape) and both corrections are returned.  None if rocprofv3 is unavailable or a
+    pass fails (the caller then falls back to the committed passes under profiles/)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="stg_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    rows, meta = {}, None
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "pmc_gcn.py"), "--iters", str(iters)],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            meta = json.loads(r.stdout.strip().splitlines()[-1])
+            files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
+            if not files:
+                return None
+            sel = [x for x in csv.DictReader(open(files[0]))
+                   if "gcn_agg_kernel" in x["Kernel_Name"] and x["Counter_Name"] == counter]
+            sel.sort(key=lambda x: int(x["Dispatch_Id"]))
+            rows[counter] = [float(x["Counter_Value"]) * 1024 for x in sel]
+        seg = lambda v, k: float(np.mean(v[k * iters:(k + 1) * iters]))  # noqa: E731
+        if len(rows["FETCH_SIZE"]) < 3 * iters or len(rows["WRITE_SIZE"]) < 3 * iters:
+            return None
+        corr = meta["calibration"]["known_read_bytes"] / seg(rows["FETCH_SIZE"], 0)
+        per = {}
+        for k, name in ((1, "forward_csr"), (2, "backward_csr")):
+            fr, wr = seg(rows["FETCH_SIZE"], k), seg(rows["WRITE_SIZE"], k)
+            per[name] = {"FETCH_SIZE_bytes_raw": fr, "WRITE_SIZE_bytes": wr, "traffic_bytes": fr * corr + wr,
+                         "traffic_bytes_x2_rule": fr * 2 + wr}
+        return {"traffic": 0.5 * (per["forward_csr"]["traffic_bytes"] + per["backward_csr"]["traffic_bytes"]),
+                "traffic_guide_x2_rule": 0.5 * (per["forward_csr"]["traffic_bytes_x2_rule"] +
+                                                per["backward_csr"]["traffic_bytes_x2_rule"]),
+                "fetch_correction_measured": corr,
+                "write_calibration_ratio": seg(rows["WRITE_SIZE"], 0) / meta["calibration"]["known_write_bytes"],
+                "per_csr": per}
+    except Exception:                                            # noqa: BLE001  (a profiler hiccup must not cost the bench line)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -420,6 +738,8 @@ def main():
     ap.add_argument("--tgcn-timestamps", type=int, default=1000)
     ap.add_argument("--no-cora", action="store_true")
     ap.add_argument("--no-dynamic", action="store_true")
+    ap.add_argument("--no-gat", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed PMC passes")
     ap.add_argument("--dynamic-epochs", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device: exercise the multi-rank logic on a single GPU (testing only)")
@@ -510,18 +830,40 @@ def main():
             line["roofline"]["traffic_guide_x2_rule"] = 0.5 * (pmc["cfg2_forward_csr"]["traffic_bytes_x2_rule"] +
                                                                pmc["cfg2_backward_csr"]["traffic_bytes_x2_rule"])
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_gcn(meta)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if want_cpu:
+        cpu = cpu_baseline_epoch_gcn(meta, int(0.6 * meta["n"]), meta["labels"])
+        cpu["aggregation_kernel_openmp"] = cpu_baseline_gcn(meta, budget_s=8.0)
     line["cpu_baseline"] = cpu
     del step, meta
     torch.cuda.empty_cache()
     if rank == 0 and not args.no_cora:
-        line["cora"] = cora_run(device)
+        line["cora"] = cora_run(device, cpu_baseline=want_cpu)
+        x1024 = line["cora"]["roofline_x1024"]
+        line["roofline"]["north_star"] = {
+            "workload": "fused GCN aggregation forward + backward at the Cora model's widths (F = 16 and F = 7) on 1024 "
+                        "disjoint replicas of the Cora-shaped graph (SURVEY.md 8(d) 'Cora x K'); target >= 0.60",
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": x1024["achieved"], "frac": x1024["frac"],
+            "frac_F16": x1024["F16"]["frac_of_hbm_peak"], "frac_F7": x1024["F7"]["frac_of_hbm_peak"]}
+    if rank == 0 and not args.no_gat:
+        line["gat"] = gat_run(device)
+        torch.cuda.empty_cache()
     if not args.no_tgcn:
         line["tgcn"] = tgcn_run(device, rank, world, epochs=args.tgcn_epochs, warmup_epochs=1, n=50_000, e=500_000,
                                 T=args.tgcn_timestamps, feat=32, hidden=64, B=25)
     if not args.no_dynamic:
         line["dynamic"] = dynamic_run(device, rank, world, epochs=args.dynamic_epochs)
+    if rank == 0 and world == 1 and not args.no_live_pmc and line["roofline"].get("traffic") is not None:
+        torch.cuda.empty_cache()
+        live = live_pmc_traffic()
+        if live is not None:
+            line["roofline"]["traffic_committed_passes"] = line["roofline"]["traffic"]
+            line["roofline"]["traffic"] = live["traffic"]
+            line["roofline"]["traffic_guide_x2_rule"] = live["traffic_guide_x2_rule"]
+            line["roofline"]["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child "
+                                                  "passes over tools/pmc_gcn.py (same kernel, same shape)")
+            line["roofline"]["traffic_detail"] = {k: live[k] for k in ("fetch_correction_measured",
+                                                                       "write_calibration_ratio", "per_csr")}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
