@@ -426,6 +426,60 @@ int stg_tgcn_cell_fused_bwd_dx(const float *dHn, const float *Z, const float *H,
                                int64_t N, int32_t C, int32_t Fin, float lo, float hi, void *stream);
 
 
+/* ----------------------------------------------- one TGCN training step as one launch each way
+ * The per-snapshot body of the temporal harnesses: nn/pytorch/temporal/tgcn.py:21-55 (three GCNConv gates over the same
+ * graph and input, clamp to [lo, hi], gate Linears, GRU blend) under benchmarking/static-temporal-tgcn/seastar/model.py:6-18
+ * (relu -> Linear(C, Fh) -> Linear(Fh, 1)) and its loop's `cost += mean((y_out - y[t]) ** 2)`; the dynamic-temporal model
+ * (dynamic-temporal-tgcn/seastar/model.py:5-21) is the same step with head = 1.  Replaces, per snapshot, the three emitted
+ * GCN units forward + backward, ~100 torch launches and their autograd nodes.  See csrc/tgcn_step.hip.
+ * All pointers [dev], fp32 / int32, row-major contiguous; C = 64, Fin = Fh = 32 (stg_tgcn_step_supported).
+ *
+ * forward:  x [N,Fin] (NULL: a3 [N,3C] = A_hat (x Wcat) is given instead and no graph is read); forward CSR
+ *   (row_offsets, column_indices, norm_col_edge = norm[col[e]] and ew_edge = w[eid[e]] in CSR order as for
+ *   stg_gcn_agg_edge, ew_edge NULL = unweighted; node_ids NULL = rows in vertex order); norm [N]; H [N,C] (NULL = zeros);
+ *   WcatT [3C,Fin] = [Wz_conv | Wr_conv | Wh_conv]^T, b3 [3C]; Wz/Wr/Wh [C,2C] and bz/br/bh [C] (torch Linear layout);
+ *   head >= 1: W1 [Fh,C], b1 [Fh] -> y [N,Fh];  head == 2: W2 [Fh], b2 [1], target [N] -> y_out [N] and
+ *   loss_partial [stg_tgcn_step_loss_partials(N)] (per-tile sums of (y_out - target)^2: stg_tgcn_window_loss adds them).
+ *   outputs kept for the backward pass and the weight gradients: P [N,Fin] = A_hat x, x3 [N,3C] = P Wcat + b3 (before
+ *   the clamp), Z, R, Ht, Hn, HR = H*R [N,C].
+ * backward: backward CSR (rows = sources) with its per-edge arrays; zn [N,Fin] = the NEXT step's z (NULL: none);
+ *   g_y [N,Fh] = a gradient reaching y directly (NULL: none); dHn [N,C] = gradient reaching Hn from the next step (NULL: 0);
+ *   g_cost [1]; the forward's Z, R, Ht, H, Hn, x3, y_out, target; WzT/WrT/WhT [2C,C] (transposed gate weights),
+ *   Wcat [Fin,3C], W1T [C,Fh], W2 [Fh].  head == 2: dyo = 2 (y_out - target) / N * g_cost; dyt = A_hat^T zn + g_y + dyo W2;
+ *   dHn += (Hn > 0) (dyt W1).  outputs: dzl, drl, dhl [N,C] (pre-activation gradients of the gate Linears), da3 [N,3C]
+ *   (gradient of x3 after the clamp mask), dH [N,C] (to the previous step's Hn), z [N,Fin] = da3 Wcat^T (NULL: not
+ *   wanted) -- the gradient of this step's INPUT is A_hat^T z, taken by the previous step's backward launch (or by
+ *   stg_gcn_agg_edge) --, dyt [N,Fh], dyo [N]. */
+typedef struct stg_tgcn_step_fwd_args {
+    const int32_t *row_offsets, *column_indices, *node_ids;
+    const float *norm_col_edge, *ew_edge, *norm;
+    const float *x, *a3, *H, *target;
+    const float *WcatT, *b3, *Wz, *bz, *Wr, *br, *Wh, *bh, *W1, *b1, *W2, *b2;
+    float *P, *x3, *Z, *R, *Ht, *Hn, *HR, *y, *y_out, *loss_partial;
+    int64_t N;
+    int32_t C, Fin, Fh, head;
+    float lo, hi;
+} stg_tgcn_step_fwd_args;
+typedef struct stg_tgcn_step_bwd_args {
+    const int32_t *row_offsets, *column_indices, *node_ids;
+    const float *norm_col_edge, *ew_edge, *norm;
+    const float *zn, *g_y, *dHn, *g_cost;
+    const float *Z, *R, *Ht, *H, *Hn, *x3, *y_out, *target;
+    const float *WzT, *WrT, *WhT, *Wcat, *W1T, *W2;
+    float *dzl, *drl, *dhl, *da3, *dH, *z, *dyt, *dyo;
+    int64_t N;
+    int32_t C, Fin, Fh, head;
+    float lo, hi;
+} stg_tgcn_step_bwd_args;
+int    stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh);
+size_t stg_tgcn_step_loss_partials(int64_t N);
+int    stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *args, void *stream);
+int    stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *args, void *stream);
+/* cost[0] = sum over the window's `steps` steps, in order, of (sum of that step's partials) / N; step_loss [steps]
+ * (NULL: not wanted) gets the terms.  partials: `steps` rows of step_stride floats. */
+int    stg_tgcn_window_loss(const float *partials, int32_t steps, int64_t N, int64_t step_stride, float *step_loss,
+                            float *cost, void *stream);
+
 /* ----------------------------------------------- dense neighbour: softmax cross-entropy
  * `nn.CrossEntropyLoss()(logits, labels)` of the GCN training scripts (benchmarking/gcn/seastar/train.py:63-101),
  * mean over the n rows, one launch each way (+ a one-workgroup finish): see csrc/xent.hip.

@@ -43,7 +43,29 @@ EXPORTED_SYMBOLS = (
     "stg_link_head_supported", "stg_link_head_workspace_bytes", "stg_link_head_fwd", "stg_link_head_bwd",
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
+    "stg_tgcn_step_supported", "stg_tgcn_step_loss_partials", "stg_tgcn_step_fwd", "stg_tgcn_step_bwd",
+    "stg_tgcn_window_loss",
 )
+
+
+def _ptr_fields(names):
+    return [(n, ctypes.c_void_p) for n in names.split()]
+
+
+class TgcnStepFwdArgs(ctypes.Structure):
+    """stg_tgcn_step_fwd_args (include/stgraph_hip.h), field for field."""
+    _fields_ = (_ptr_fields("row_offsets column_indices node_ids norm_col_edge ew_edge norm x a3 H target "
+                            "WcatT b3 Wz bz Wr br Wh bh W1 b1 W2 b2 P x3 Z R Ht Hn HR y y_out loss_partial") +
+                [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
+                 ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)])
+
+
+class TgcnStepBwdArgs(ctypes.Structure):
+    """stg_tgcn_step_bwd_args (include/stgraph_hip.h), field for field."""
+    _fields_ = (_ptr_fields("row_offsets column_indices node_ids norm_col_edge ew_edge norm zn g_y dHn g_cost "
+                            "Z R Ht H Hn x3 y_out target WzT WrT WhT Wcat W1T W2 dzl drl dhl da3 dH z dyt dyo") +
+                [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
+                 ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)])
 
 
 class StgError(RuntimeError):
@@ -201,6 +223,16 @@ def _load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [vp] * nptr + tail
+    lib.stg_tgcn_step_supported.restype = ctypes.c_int
+    lib.stg_tgcn_step_supported.argtypes = [i32, i32, i32]
+    lib.stg_tgcn_step_loss_partials.restype = ctypes.c_size_t
+    lib.stg_tgcn_step_loss_partials.argtypes = [i64]
+    lib.stg_tgcn_step_fwd.restype = ctypes.c_int
+    lib.stg_tgcn_step_fwd.argtypes = [ctypes.POINTER(TgcnStepFwdArgs), vp]
+    lib.stg_tgcn_step_bwd.restype = ctypes.c_int
+    lib.stg_tgcn_step_bwd.argtypes = [ctypes.POINTER(TgcnStepBwdArgs), vp]
+    lib.stg_tgcn_window_loss.restype = ctypes.c_int
+    lib.stg_tgcn_window_loss.argtypes = [vp, i32, i64, i64, vp, vp, vp]
     if lib.stg_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.stg_abi_version()} != expected {ABI_VERSION}; rebuild")
     return lib

@@ -96,5 +96,10 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().gcn_xcd_tile = value;
         return 0;
     }
+    if (!std::strcmp(key, "step_waves")) {
+        if (value != 0 && value != 12 && value != 16) return fail(STG_ERR_INVALID_ARGUMENT, "step_waves must be 0, 12 or 16");
+        tuning().step_waves = value;
+        return 0;
+    }
     return fail(STG_ERR_INVALID_ARGUMENT, "stg_set_tuning: unknown key '%s'", key);
 }

@@ -31,6 +31,7 @@ struct Tuning {
     int gcn_block = 0;             // 0 = auto; 64 / 128 / 256 = threads per workgroup of the plain gcn_agg launch
     int gcn_addr32 = 0;            // 0 = auto (32-bit gather offsets when the matrix allows); 1 = always 64-bit
     int gcn_xcd_tile = 0;          // 0 = auto; 1 = workgroups round-robin over XCDs; T = runs of T workgroups per XCD
+    int step_waves = 0;            // one-launch TGCN step: 0 = auto, 12 / 16 waves per workgroup (168 / 128 registers)
 };
 Tuning &tuning();
 

@@ -1,0 +1,326 @@
+// Backward launch of the one-launch-per-step TGCN kernels: layout and design notes in tgcn_step.hpp.
+#include "tgcn_step.hpp"
+
+namespace stg {
+namespace {
+
+// ------------------------------------------------------------------------------------------------------ backward
+struct BwdArgs {
+    const int *row_offsets, *column_indices, *node_ids;        // BACKWARD CSR (rows = sources)
+    const float *nc_edge, *ew_edge, *norm;
+    const float *zn, *gy, *dHn, *g_cost;
+    const float *Z, *R, *Ht, *H, *Hn, *x3, *y_out, *target;
+    const float *WzT, *WrT, *WhT, *Wcat, *W1T, *W2;
+    float *dzl, *drl, *dhl, *da3, *dH, *z, *dyt, *dyo;
+    int64_t N;
+    float lo, hi, two_over_n;
+    int num_tiles;
+};
+
+template <int C, int FIN, int FH, int WAVES, bool GATHER, int HEAD>
+struct BwdShape {
+    static constexpr int K2 = 2 * C, LDB = C + 4, LDX = 3 * C + 4, LDT = FH + 4;
+    static constexpr int kGate = 3 * K2 * LDB;                // WzT | WrT | WhT, each [2C][LDB]
+    static constexpr int kCat = FIN * LDX;                    // Wcat [FIN][LDX]
+    static constexpr int kHead = HEAD ? C * LDT : 0;          // W1T [C][LDT]
+    static constexpr int kBias = FH + 4;                      // W2
+    static constexpr int kFloats = kGate + kCat + kHead + kBias;
+    static constexpr size_t kLds = sizeof(float) * (size_t)kFloats;
+    static_assert(kLds <= 160 * 1024, "the weights must fit one CU's LDS");
+};
+
+template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD>
+__global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdArgs a)
+{
+    using S = BwdShape<C, FIN, FH, WAVES, GATHER, HEAD>;
+    constexpr int NT = WAVES * kWave, PC = C / 16, PF = FIN / 16, PH = FH / 16;
+    constexpr int LDB = S::LDB, LDX = S::LDX, LDT = S::LDT;
+    static_assert(FIN == 32 && FH == FIN, "the head's output is the next step's input");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *WgT = lds;                                  // [3][2C][LDB]
+    float *Wc = WgT + S::kGate;                        // [FIN][LDX]
+    float *W1T = Wc + S::kCat;                         // [C][LDT]
+    float *bs = W1T + S::kHead;                        // W2 [FH]
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int n16 = lane & 15, kq = lane >> 4;
+
+    stage_rows<NT>(WgT, LDB, a.WzT, 2 * C, C);
+    stage_rows<NT>(WgT + 2 * C * LDB, LDB, a.WrT, 2 * C, C);
+    stage_rows<NT>(WgT + 4 * C * LDB, LDB, a.WhT, 2 * C, C);
+    const bool want_z = a.z != nullptr;                // block-uniform
+    if (want_z) stage_rows<NT>(Wc, LDX, a.Wcat, FIN, 3 * C);
+    if constexpr (HEAD != 0) stage_rows<NT>(W1T, LDT, a.W1T, C, FH);
+    if constexpr (HEAD == 2) {
+        for (int i = threadIdx.x; i < FH; i += NT) bs[i] = a.W2[i];
+    }
+    __syncthreads();
+
+    const int total = gridDim.x * WAVES;
+    const float lo = a.lo, hi = a.hi;
+    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < a.num_tiles; tile += total) {
+        const int64_t idx = (int64_t)tile * 16 + n16;
+        const bool rok = idx < a.N;
+        // Lanes past the last row read row N - 1 (valid memory, finite values) and never store: loads need no per-lane
+        // guard, hence no branch and no 64-bit address pair each.  Element offsets are 32-bit (N 3C < 2^30, checked on
+        // the host): one VGPR per row stride next to scalar base pointers.
+        unsigned row = (unsigned)(rok ? idx : a.N - 1);
+        if (a.node_ids) row = (unsigned)a.node_ids[row];
+        auto ldrow = [&](const float *p, int ld, int col) {            // p must not be NULL
+            return *reinterpret_cast<const float4 *>(p + (row * (unsigned)ld + (unsigned)col));
+        };
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        // ---- A_hat^T zn: the next step's input gradient, aggregated here (first: its gather loop is the register-hungry
+        //      part of the kernel and nothing else is live yet) ---------------------------------------------------------
+        float4 gp[PH];
+#pragma unroll
+        for (int j = 0; j < PH; ++j) gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (GATHER && HEAD != 0) {
+            if (a.zn) {                                              // block-uniform branch
+                const int q = lane & 3, grow = lane >> 2;
+                const int64_t gidx = (int64_t)tile * 16 + grow;
+                const bool gok = gidx < a.N;
+                int gr = (int)gidx;
+                if (gok && a.node_ids) gr = a.node_ids[gidx];
+                float p8[8];
+                gather_rows32<HAS_EW>(p8, a.zn, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, gok, q);
+                gather_to_pieces(p8, gp, n16, kq);
+            }
+        }
+        // clamp mask of the 3C columns of x3 as 48 bits (read now, used by three later phases: 2 registers instead of
+        // 12 loads in the middle of the MFMA chains)
+        unsigned mlo = 0u, mhi = 0u;
+        {
+            float4 v[3 * PC];
+#pragma unroll
+            for (int c = 0; c < 3 * PC; ++c) v[c] = ldrow(a.x3, 3 * C, 16 * c + 4 * kq);
+#pragma unroll
+            for (int c = 0; c < 3 * PC; ++c) {
+                const unsigned b = (v[c].x >= lo && v[c].x <= hi ? 1u : 0u) | (v[c].y >= lo && v[c].y <= hi ? 2u : 0u) |
+                                   (v[c].z >= lo && v[c].z <= hi ? 4u : 0u) | (v[c].w >= lo && v[c].w <= hi ? 8u : 0u);
+                if (4 * c < 32) mlo |= b << ((4 * c) & 31);
+                else mhi |= b << ((4 * c) & 31);
+            }
+        }
+        // ---- gradient reaching Hn: from the next step (dHn) and through the head --------------------------------
+        float4 dhn[PC];
+#pragma unroll
+        for (int j = 0; j < PC; ++j) dhn[j] = zero4;
+        if (a.dHn) {                                                 // wave-uniform: one branch for the group of loads
+#pragma unroll
+            for (int j = 0; j < PC; ++j) dhn[j] = ldrow(a.dHn, C, 16 * j + 4 * kq);
+        }
+        if constexpr (HEAD != 0) {
+            float4 gy[PH];
+#pragma unroll
+            for (int j = 0; j < PH; ++j) gy[j] = zero4;
+            if (a.gy) {
+#pragma unroll
+                for (int j = 0; j < PH; ++j) gy[j] = ldrow(a.gy, FH, 16 * j + 4 * kq);
+            }
+#pragma unroll
+            for (int j = 0; j < PH; ++j) gy[j] = make_float4(gy[j].x + gp[j].x, gy[j].y + gp[j].y, gy[j].z + gp[j].z, gy[j].w + gp[j].w);
+            if constexpr (HEAD == 2) {
+                float dyo = 0.f;
+                dyo = ((a.y_out[row] - a.target[row]) * a.two_over_n) * a.g_cost[0];
+                if (rok && kq == 0) a.dyo[row] = dyo;
+#pragma unroll
+                for (int j = 0; j < PH; ++j) {
+                    const float4 w2 = *reinterpret_cast<const float4 *>(bs + 16 * j + 4 * kq);
+                    gy[j] = make_float4(gy[j].x + dyo * w2.x, gy[j].y + dyo * w2.y, gy[j].z + dyo * w2.z, gy[j].w + dyo * w2.w);
+                }
+            }
+            if (rok) {
+#pragma unroll
+                for (int j = 0; j < PH; ++j) *reinterpret_cast<float4 *>(a.dyt + (row * FH + 16 * j + 4 * kq)) = gy[j];
+            }
+            f32x4 acc[PC];
+#pragma unroll
+            for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_pieces<PC, PH>(acc, W1T + n16 * LDT + 4 * kq, LDT, [&](int j) { return gy[j]; });
+#pragma unroll
+            for (int j = 0; j < PC; ++j) {
+                const float4 h = ldrow(a.Hn, C, 16 * j + 4 * kq);
+                dhn[j].x = dhn[j].x + (h.x > 0.f ? acc[j][0] : 0.f);
+                dhn[j].y = dhn[j].y + (h.y > 0.f ? acc[j][1] : 0.f);
+                dhn[j].z = dhn[j].z + (h.z > 0.f ? acc[j][2] : 0.f);
+                dhn[j].w = dhn[j].w + (h.w > 0.f ? acc[j][3] : 0.f);
+            }
+        }
+
+        // ---- GRU update backward ---------------------------------------------------------------------------------
+        // (dzl is stored here and re-read by the same lane -- an L2 hit -- when its products come up, instead of
+        // living through the first two: 16 registers)
+        float4 dhl[PC], dHa[PC];
+        float4 hh[PC];
+#pragma unroll
+        for (int j = 0; j < PC; ++j) hh[j] = zero4;
+        if (a.H) {
+#pragma unroll
+            for (int j = 0; j < PC; ++j) hh[j] = ldrow(a.H, C, 16 * j + 4 * kq);
+        }
+#pragma unroll
+        for (int j = 0; j < PC; ++j) {
+            float4 dzl[1];
+            const float4 g = dhn[j], z = ldrow(a.Z, C, 16 * j + 4 * kq), t = ldrow(a.Ht, C, 16 * j + 4 * kq);
+            const float4 h = hh[j];
+            dhl[j] = make_float4((g.x * (1.0f - z.x)) * (1.0f - t.x * t.x), (g.y * (1.0f - z.y)) * (1.0f - t.y * t.y),
+                                 (g.z * (1.0f - z.z)) * (1.0f - t.z * t.z), (g.w * (1.0f - z.w)) * (1.0f - t.w * t.w));
+            dzl[0] = make_float4((g.x * (h.x - t.x)) * (z.x * (1.0f - z.x)), (g.y * (h.y - t.y)) * (z.y * (1.0f - z.y)),
+                                 (g.z * (h.z - t.z)) * (z.z * (1.0f - z.z)), (g.w * (h.w - t.w)) * (z.w * (1.0f - z.w)));
+            dHa[j] = make_float4(g.x * z.x, g.y * z.y, g.z * z.z, g.w * z.w);
+            if (rok) {
+                *reinterpret_cast<float4 *>(a.dhl + (row * C + 16 * j + 4 * kq)) = dhl[j];
+                *reinterpret_cast<float4 *>(a.dzl + (row * C + 16 * j + 4 * kq)) = dzl[0];
+            }
+        }
+
+        f32x4 zacc[PF];
+#pragma unroll
+        for (int ft = 0; ft < PF; ++ft) zacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *wcrow = Wc + n16 * LDX + 4 * kq;
+        // out[blk] = (in (K = C) x W_g[:, half C + 16 blk ..]) as row pieces; W_g^T is [2C][LDB] in LDS
+        auto gemm = [&](const float4 (&in)[PC], int g, int half, f32x4 (&acc)[PC]) {
+            const float *w = WgT + (g * 2 * C + half * C + n16) * LDB + 4 * kq;
+#pragma unroll
+            for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_pieces<PC, PC>(acc, w, LDB, [&](int j) { return in[j]; });
+        };
+        // da3[:, g C + 16 blk ..] = clamp mask * piece; z += that piece x Wcat^T
+        auto emit_da3 = [&](int g, const f32x4 (&acc)[PC]) {
+#pragma unroll
+            for (int blk = 0; blk < PC; ++blk) {
+                const int c = g * C + 16 * blk + 4 * kq;
+                const int bit = 4 * (g * PC + blk);
+                const unsigned m = (bit < 32 ? mlo : mhi) >> (bit & 31);
+                float4 o;
+                o.x = (m & 1u) ? acc[blk][0] : 0.f;
+                o.y = (m & 2u) ? acc[blk][1] : 0.f;
+                o.z = (m & 4u) ? acc[blk][2] : 0.f;
+                o.w = (m & 8u) ? acc[blk][3] : 0.f;
+                if (rok) *reinterpret_cast<float4 *>(a.da3 + (row * (3 * C) + c)) = o;
+                if (want_z) {
+                    mfma_piece<PF>(zacc, wcrow, LDX, g * PC + blk, o);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+
+        f32x4 acc[PC];
+        // ---- dCH = dhl Wh: d(hh) -> da3[:, 2C..];  dHR -> drl, dH ---------------------------------------------------
+        gemm(dhl, 2, 0, acc);
+        emit_da3(2, acc);
+        float4 rr[PC], hb[PC];                                   // R and H for the dHR stage: in flight under the next product
+#pragma unroll
+        for (int j = 0; j < PC; ++j) rr[j] = ldrow(a.R, C, 16 * j + 4 * kq), hb[j] = zero4;
+        if (a.H) {
+#pragma unroll
+            for (int j = 0; j < PC; ++j) hb[j] = ldrow(a.H, C, 16 * j + 4 * kq);
+        }
+        gemm(dhl, 2, 1, acc);
+        float4 drl[PC], dzl[PC];
+#pragma unroll
+        for (int j = 0; j < PC; ++j) dzl[j] = ldrow(a.dzl, C, 16 * j + 4 * kq);      // this lane's own stores, above
+#pragma unroll
+        for (int blk = 0; blk < PC; ++blk) {
+            const float4 r = rr[blk], h = hb[blk];
+            const float4 d = to_f4(acc[blk]);
+            drl[blk] = make_float4((d.x * h.x) * (r.x * (1.0f - r.x)), (d.y * h.y) * (r.y * (1.0f - r.y)),
+                                   (d.z * h.z) * (r.z * (1.0f - r.z)), (d.w * h.w) * (r.w * (1.0f - r.w)));
+            dHa[blk] = make_float4(dHa[blk].x + d.x * r.x, dHa[blk].y + d.y * r.y, dHa[blk].z + d.z * r.z,
+                                   dHa[blk].w + d.w * r.w);
+            if (rok) *reinterpret_cast<float4 *>(a.drl + (row * C + 16 * blk + 4 * kq)) = drl[blk];
+        }
+        // ---- dCZ = dzl Wz,  dCR = drl Wr: d(hz), d(hr) -> da3;  second halves -> dH (dCZ's first, then dCR's) -------
+        gemm(dzl, 0, 0, acc);
+        emit_da3(0, acc);
+        gemm(dzl, 0, 1, acc);
+#pragma unroll
+        for (int blk = 0; blk < PC; ++blk)
+            dHa[blk] = make_float4(dHa[blk].x + acc[blk][0], dHa[blk].y + acc[blk][1], dHa[blk].z + acc[blk][2],
+                                   dHa[blk].w + acc[blk][3]);
+        gemm(drl, 1, 0, acc);
+        emit_da3(1, acc);
+        gemm(drl, 1, 1, acc);
+        if (rok) {
+#pragma unroll
+            for (int blk = 0; blk < PC; ++blk)
+                *reinterpret_cast<float4 *>(a.dH + (row * C + 16 * blk + 4 * kq)) =
+                    make_float4(dHa[blk].x + acc[blk][0], dHa[blk].y + acc[blk][1], dHa[blk].z + acc[blk][2],
+                                dHa[blk].w + acc[blk][3]);
+            if (want_z) {
+#pragma unroll
+                for (int ft = 0; ft < PF; ++ft) *reinterpret_cast<float4 *>(a.z + (row * FIN + 16 * ft + 4 * kq)) = to_f4(zacc[ft]);
+            }
+        }
+    }
+}
+
+template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD>
+int launch_step_bwd(const BwdArgs &a, hipStream_t stream)
+{
+    using S = BwdShape<C, FIN, FH, WAVES, GATHER, HEAD>;
+    auto kern = tgcn_step_bwd_kernel<C, FIN, FH, WAVES, GATHER, HAS_EW, HEAD>;
+    static PerDeviceOnce once;
+    bool *raised = once.slot();
+    if (S::kLds > 64 * 1024 && !*raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)S::kLds);
+        if (e != hipSuccess) return fail((int)e, "stg_tgcn_step_bwd: %s", hipGetErrorString(e));
+        *raised = true;
+    }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
+    const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)a.num_tiles + WAVES - 1) / WAVES, 256 * per_cu);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * kWave), S::kLds, stream, a);
+    return check_launch("stg_tgcn_step_bwd");
+}
+
+
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
+{
+    using namespace stg;
+    if (!p) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL argument block");
+    if (!stg_tgcn_step_supported(p->C, p->Fin, p->Fh))
+        return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_bwd: C=%d Fin=%d Fh=%d not supported (64 / 32 / 32)", p->C, p->Fin, p->Fh);
+    if (p->N < 0 || p->N > (int64_t)16 * 0x7ffffff0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: bad N");
+    if (p->head < 0 || p->head > 2) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: head must be 0, 1 or 2");
+    if (p->N == 0) return 0;
+    const bool gather = p->head != 0 && p->zn != nullptr;
+    if (gather && (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL graph pointer");
+    if ((int64_t)p->N * 3 * p->C >= ((int64_t)1 << 30)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_bwd: too many rows for 32-bit offsets");
+    if (!p->Z || !p->R || !p->Ht || !p->x3 || !p->WzT || !p->WrT || !p->WhT || !p->dzl || !p->drl || !p->dhl || !p->da3 || !p->dH)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL cell pointer");
+    if (p->z && !p->Wcat) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: z wanted but Wcat is NULL");
+    if (p->head >= 1 && (!p->W1T || !p->Hn || !p->dyt)) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL head pointer");
+    if (p->head == 2 && (!p->W2 || !p->y_out || !p->target || !p->g_cost || !p->dyo))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL loss pointer");
+    BwdArgs a{};
+    a.row_offsets = p->row_offsets; a.column_indices = p->column_indices; a.node_ids = p->node_ids;
+    a.nc_edge = p->norm_col_edge; a.ew_edge = p->ew_edge; a.norm = p->norm;
+    a.zn = p->zn; a.gy = p->g_y; a.dHn = p->dHn; a.g_cost = p->g_cost;
+    a.Z = p->Z; a.R = p->R; a.Ht = p->Ht; a.H = p->H; a.Hn = p->Hn; a.x3 = p->x3; a.y_out = p->y_out; a.target = p->target;
+    a.WzT = p->WzT; a.WrT = p->WrT; a.WhT = p->WhT; a.Wcat = p->Wcat; a.W1T = p->W1T; a.W2 = p->W2;
+    a.dzl = p->dzl; a.drl = p->drl; a.dhl = p->dhl; a.da3 = p->da3; a.dH = p->dH; a.z = p->z; a.dyt = p->dyt; a.dyo = p->dyo;
+    a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.two_over_n = 2.0f / (float)p->N; a.num_tiles = (int)((p->N + 15) / 16);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const bool w16 = tuning().step_waves == 16;
+#define STG_STEP_BWD(G_, EW_, HD_)                                                         \
+    return w16 ? launch_step_bwd<64, 32, 32, 16, G_, EW_, HD_>(a, st) : launch_step_bwd<64, 32, 32, 12, G_, EW_, HD_>(a, st)
+    if (p->head == 0) STG_STEP_BWD(false, false, 0);
+    if (gather) {
+        if (p->ew_edge) {
+            if (p->head == 1) STG_STEP_BWD(true, true, 1);
+            STG_STEP_BWD(true, true, 2);
+        }
+        if (p->head == 1) STG_STEP_BWD(true, false, 1);
+        STG_STEP_BWD(true, false, 2);
+    }
+    if (p->head == 1) STG_STEP_BWD(false, false, 1);
+    STG_STEP_BWD(false, false, 2);
+#undef STG_STEP_BWD
+}
+

@@ -1,0 +1,339 @@
+// Forward launch of the one-launch-per-step TGCN kernels: layout and design notes in tgcn_step.hpp.
+#include "tgcn_step.hpp"
+
+namespace stg {
+namespace {
+
+struct FwdArgs {
+    const int *row_offsets, *column_indices, *node_ids;
+    const float *nc_edge, *ew_edge, *norm;
+    const float *x, *a3, *H, *target;
+    const float *WcatT, *b3, *Wz, *bz, *Wr, *br, *Wh, *bh, *W1, *b1, *W2, *b2;
+    float *P, *x3, *Z, *R, *Ht, *Hn, *HR, *y, *y_out, *partial;
+    int64_t N;
+    float lo, hi;
+    int num_tiles;
+};
+
+template <int C, int FIN, int FH, int WAVES, bool GATHER, int HEAD>
+struct FwdShape {
+    static constexpr int K2 = 2 * C, LDW = K2 + 4, LDC = FIN + 4, LD1 = C + 4;
+    static constexpr int kGate = 3 * C * LDW;
+    static constexpr int kCat = GATHER ? 3 * C * LDC : 0;
+    static constexpr int kHead = HEAD ? FH * LD1 : 0;
+    static constexpr int kBias = 6 * C + 2 * FH + 4;          // b3 | bz br bh | b1 | W2 | b2
+    static constexpr int kFloats = kGate + kCat + kHead + kBias;
+    static constexpr size_t kLds = sizeof(float) * (size_t)kFloats;
+    static_assert(kLds <= 160 * 1024, "the weights must fit one CU's LDS");
+};
+
+template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD>
+__global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdArgs a)
+{
+    using S = FwdShape<C, FIN, FH, WAVES, GATHER, HEAD>;
+    constexpr int NT = WAVES * kWave, PC = C / 16, PF = FIN / 16, PH = FH / 16;
+    constexpr int LDW = S::LDW, LDC = S::LDC, LD1 = S::LD1;
+    static_assert(FIN == 32 && C % 16 == 0 && FH % 16 == 0, "shapes");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Wg = lds;                                   // Wz | Wr | Wh, each [C][LDW]
+    float *WcT = Wg + S::kGate;                        // [3C][LDC]
+    float *W1s = WcT + S::kCat;                        // [FH][LD1]
+    float *bs = W1s + S::kHead;                        // b3 [3C] | bz br bh [3C] | b1 [FH] | W2 [FH] | b2
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int n16 = lane & 15, kq = lane >> 4;
+
+    stage_rows<NT>(Wg, LDW, a.Wz, C, 2 * C);
+    stage_rows<NT>(Wg + C * LDW, LDW, a.Wr, C, 2 * C);
+    stage_rows<NT>(Wg + 2 * C * LDW, LDW, a.Wh, C, 2 * C);
+    if constexpr (GATHER) stage_rows<NT>(WcT, LDC, a.WcatT, 3 * C, FIN);
+    if constexpr (HEAD != 0) stage_rows<NT>(W1s, LD1, a.W1, FH, C);
+    for (int i = threadIdx.x; i < 3 * C; i += NT) bs[i] = a.b3[i];
+    for (int i = threadIdx.x; i < C; i += NT) {
+        bs[3 * C + i] = a.bz[i];
+        bs[4 * C + i] = a.br[i];
+        bs[5 * C + i] = a.bh[i];
+    }
+    if constexpr (HEAD != 0) {
+        for (int i = threadIdx.x; i < FH; i += NT) {
+            bs[6 * C + i] = a.b1[i];
+            if constexpr (HEAD == 2) bs[6 * C + FH + i] = a.W2[i];
+        }
+        if constexpr (HEAD == 2) {
+            if (threadIdx.x == 0) bs[6 * C + 2 * FH] = a.b2[0];
+        }
+    }
+    __syncthreads();
+
+    const int total = gridDim.x * WAVES;
+    const float lo = a.lo, hi = a.hi;
+    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < a.num_tiles; tile += total) {
+        const int64_t idx = (int64_t)tile * 16 + n16;
+        const bool rok = idx < a.N;
+        // Lanes past the last row read row N - 1 (valid memory, finite values) and never store: loads need no per-lane
+        // guard, hence no branch and no 64-bit address pair each.  Element offsets are 32-bit (N 3C < 2^30, checked on
+        // the host): one VGPR per row stride next to scalar base pointers.
+        unsigned row = (unsigned)(rok ? idx : a.N - 1);
+        if (a.node_ids) row = (unsigned)a.node_ids[row];
+
+        // ---- P = A_hat x (GATHER), handed from the gather layout to row pieces on the LDS crossbar ------------------------
+        float4 p[PF];
+        if constexpr (GATHER) {
+            {
+                const int q = lane & 3, grow = lane >> 2;
+                const int64_t gidx = (int64_t)tile * 16 + grow;
+                const bool gok = gidx < a.N;
+                int gr = (int)gidx;
+                if (gok && a.node_ids) gr = a.node_ids[gidx];
+                float p8[8];
+                gather_rows32<HAS_EW>(p8, a.x, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, gok, q);
+                const float4 lo4 = make_float4(p8[0], p8[1], p8[2], p8[3]), hi4 = make_float4(p8[4], p8[5], p8[6], p8[7]);
+                if (gok) {
+                    *reinterpret_cast<float4 *>(a.P + ((unsigned)gr * FIN + 8 * q)) = lo4;
+                    *reinterpret_cast<float4 *>(a.P + ((unsigned)gr * FIN + 8 * q + 4)) = hi4;
+                }
+                gather_to_pieces(p8, p, n16, kq);
+            }
+        }
+        // hg = clamp(x3[:, g C ..]) with x3 = P Wcat + b3 (or a3 + b3), one gate at a time (16 live registers instead
+        // of 48); x3 itself (before the clamp) is what the backward pass and the weight gradients read
+        auto gate_input = [&](int g, float4 (&hg)[PC]) {
+            if constexpr (GATHER) {
+                f32x4 acc[PC];
+#pragma unroll
+                for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_pieces<PC, PF>(acc, WcT + (g * C + n16) * LDC + 4 * kq, LDC, [&](int j) { return p[j]; });
+#pragma unroll
+                for (int ct = 0; ct < PC; ++ct) {
+                    const float4 b = *reinterpret_cast<const float4 *>(bs + g * C + 16 * ct + 4 * kq);
+                    hg[ct] = make_float4(acc[ct][0] + b.x, acc[ct][1] + b.y, acc[ct][2] + b.z, acc[ct][3] + b.w);
+                }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < PC; ++ct) {
+                    const float4 v = *reinterpret_cast<const float4 *>(a.a3 + (row * (3 * C) + g * C + 16 * ct + 4 * kq));
+                    const float4 b = *reinterpret_cast<const float4 *>(bs + g * C + 16 * ct + 4 * kq);
+                    hg[ct] = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < PC; ++ct) {
+                if (rok) *reinterpret_cast<float4 *>(a.x3 + (row * (3 * C) + g * C + 16 * ct + 4 * kq)) = hg[ct];
+                hg[ct].x = fminf(fmaxf(hg[ct].x, lo), hi);
+                hg[ct].y = fminf(fmaxf(hg[ct].y, lo), hi);
+                hg[ct].z = fminf(fmaxf(hg[ct].z, lo), hi);
+                hg[ct].w = fminf(fmaxf(hg[ct].w, lo), hi);
+            }
+        };
+        float4 hh[PC];
+#pragma unroll
+        for (int j = 0; j < PC; ++j) {
+            hh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.H) hh[j] = *reinterpret_cast<const float4 *>(a.H + (row * C + 16 * j + 4 * kq));
+        }
+        // acc = bias + [hg | second] W_g^T   (W_g [C][2C] in LDS, torch Linear layout)
+        auto gate = [&](int g, const float4 (&hg)[PC], const float4 (&second)[PC], f32x4 (&acc)[PC]) {
+#pragma unroll
+            for (int ct = 0; ct < PC; ++ct) acc[ct] = to_x4(*reinterpret_cast<const float4 *>(bs + (3 + g) * C + 16 * ct + 4 * kq));
+            gemm_pieces<PC, 2 * PC>(acc, Wg + (g * C + n16) * LDW + 4 * kq, LDW,
+                                    [&](int j) { return j < PC ? hg[j % PC] : second[j % PC]; });
+        };
+
+        // ---- Z = sigmoid([hz | H] Wz^T + bz),  R = sigmoid([hr | H] Wr^T + br) -----------------------------------
+        float4 zz[PC], hr[PC];
+        {
+            float4 hg[PC];
+            f32x4 acc[PC];
+            gate_input(0, hg);
+            gate(0, hg, hh, acc);
+#pragma unroll
+            for (int j = 0; j < PC; ++j) {
+                zz[j] = make_float4(sigmoid_(acc[j][0]), sigmoid_(acc[j][1]), sigmoid_(acc[j][2]), sigmoid_(acc[j][3]));
+                if (rok) *reinterpret_cast<float4 *>(a.Z + (row * C + 16 * j + 4 * kq)) = zz[j];
+            }
+            gate_input(1, hg);
+            gate(1, hg, hh, acc);
+#pragma unroll
+            for (int j = 0; j < PC; ++j) {
+                const float4 r = make_float4(sigmoid_(acc[j][0]), sigmoid_(acc[j][1]), sigmoid_(acc[j][2]), sigmoid_(acc[j][3]));
+                hr[j] = make_float4(hh[j].x * r.x, hh[j].y * r.y, hh[j].z * r.z, hh[j].w * r.w);
+                if (rok) {
+                    *reinterpret_cast<float4 *>(a.R + (row * C + 16 * j + 4 * kq)) = r;
+                    *reinterpret_cast<float4 *>(a.HR + (row * C + 16 * j + 4 * kq)) = hr[j];
+                }
+            }
+        }
+
+        // ---- Ht = tanh([hh | H*R] Wh^T + bh);  Hn = Z*H + (1 - Z)*Ht ----------------------------------------------
+        float4 hn[PC];
+        {
+            float4 hg[PC];
+            f32x4 acc[PC];
+            gate_input(2, hg);
+            gate(2, hg, hr, acc);
+#pragma unroll
+            for (int j = 0; j < PC; ++j) {
+                const float4 t = make_float4(tanh_(acc[j][0]), tanh_(acc[j][1]), tanh_(acc[j][2]), tanh_(acc[j][3]));
+                const float4 z = zz[j], h = hh[j];
+                hn[j] = make_float4(z.x * h.x + (1.0f - z.x) * t.x, z.y * h.y + (1.0f - z.y) * t.y,
+                                    z.z * h.z + (1.0f - z.z) * t.z, z.w * h.w + (1.0f - z.w) * t.w);
+                if (rok) {
+                    *reinterpret_cast<float4 *>(a.Ht + (row * C + 16 * j + 4 * kq)) = t;
+                    *reinterpret_cast<float4 *>(a.Hn + (row * C + 16 * j + 4 * kq)) = hn[j];
+                }
+            }
+        }
+
+        // ---- head: y = relu(Hn) W1^T + b1;  y_out = y W2^T + b2;  partial[tile] = sum (y_out - target)^2 ------------
+        if constexpr (HEAD != 0) {
+            f32x4 accy[PH];
+#pragma unroll
+            for (int ft = 0; ft < PH; ++ft) accy[ft] = to_x4(*reinterpret_cast<const float4 *>(bs + 6 * C + 16 * ft + 4 * kq));
+            gemm_pieces<PH, PC>(accy, W1s + n16 * LD1 + 4 * kq, LD1, [&](int j) {
+                return make_float4(hn[j].x < 0.f ? 0.f : hn[j].x, hn[j].y < 0.f ? 0.f : hn[j].y,
+                                   hn[j].z < 0.f ? 0.f : hn[j].z, hn[j].w < 0.f ? 0.f : hn[j].w);
+            });
+            if (rok) {
+#pragma unroll
+                for (int ft = 0; ft < PH; ++ft) *reinterpret_cast<float4 *>(a.y + (row * FH + 16 * ft + 4 * kq)) = to_f4(accy[ft]);
+            }
+            if constexpr (HEAD == 2) {
+                float s = 0.f;
+#pragma unroll
+                for (int ft = 0; ft < PH; ++ft) {
+                    const float4 w2 = *reinterpret_cast<const float4 *>(bs + 6 * C + FH + 16 * ft + 4 * kq);
+                    s = s + accy[ft][0] * w2.x;
+                    s = s + accy[ft][1] * w2.y;
+                    s = s + accy[ft][2] * w2.z;
+                    s = s + accy[ft][3] * w2.w;
+                }
+                s = s + __shfl_xor(s, 16, kWave);                   // the row's four kq lanes
+                s = s + __shfl_xor(s, 32, kWave);
+                const float yo = s + bs[6 * C + 2 * FH];
+                float sq = 0.f;
+                if (rok && kq == 0) {
+                    a.y_out[row] = yo;
+                    const float d = yo - a.target[row];
+                    sq = d * d;
+                }
+                sq = row16_sum(sq);                                 // lanes 0..15 (kq = 0): the tile's 16 rows, in lane order
+                if (lane == 15) a.partial[tile] = sq;
+            }
+        }
+    }
+}
+
+template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD>
+int launch_step_fwd(const FwdArgs &a, hipStream_t stream)
+{
+    using S = FwdShape<C, FIN, FH, WAVES, GATHER, HEAD>;
+    auto kern = tgcn_step_fwd_kernel<C, FIN, FH, WAVES, GATHER, HAS_EW, HEAD>;
+    static PerDeviceOnce once;
+    bool *raised = once.slot();
+    if (S::kLds > 64 * 1024 && !*raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)S::kLds);
+        if (e != hipSuccess) return fail((int)e, "stg_tgcn_step_fwd: %s", hipGetErrorString(e));
+        *raised = true;
+    }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
+    const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)a.num_tiles + WAVES - 1) / WAVES, 256 * per_cu);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * kWave), S::kLds, stream, a);
+    return check_launch("stg_tgcn_step_fwd");
+}
+
+
+// cost = sum_t mean_t, mean_t = (sum of step t's tile partials, in a fixed order) / N: one workgroup for the whole
+// window instead of one finish launch per step; the steps are added in order, as the loop's `cost = cost + loss`
+__global__ __launch_bounds__(kBlock) void window_loss_kernel(const float *__restrict__ partial, int steps, int num_tiles,
+                                                             int64_t stride, float inv_n, float *__restrict__ step_loss,
+                                                             float *__restrict__ cost)
+{
+    __shared__ float s[kBlock];
+    float total = 0.f;
+    for (int t = 0; t < steps; ++t) {
+        const float *p = partial + (int64_t)t * stride;
+        float v = 0.f;
+        for (int i = threadIdx.x; i < num_tiles; i += kBlock) v = v + p[i];
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = kBlock / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float l = s[0] * inv_n;
+            if (step_loss) step_loss[t] = l;
+            total = total + l;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cost[0] = total;
+}
+
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh)
+{
+    return C == 64 && Fin == 32 && Fh == 32;
+}
+
+extern "C" size_t stg_tgcn_step_loss_partials(int64_t N) { return N > 0 ? (size_t)((N + 15) / 16) : 0; }
+
+extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
+{
+    using namespace stg;
+    if (!p) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL argument block");
+    if (!stg_tgcn_step_supported(p->C, p->Fin, p->Fh))
+        return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_fwd: C=%d Fin=%d Fh=%d not supported (64 / 32 / 32)", p->C, p->Fin, p->Fh);
+    if (p->N < 0 || p->N > (int64_t)16 * 0x7ffffff0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: bad N");
+    if (p->head < 0 || p->head > 2) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: head must be 0, 1 or 2");
+    if (p->N == 0) return 0;
+    const bool gather = p->x != nullptr;
+    if (gather ? (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm || !p->WcatT || !p->P) : !p->a3)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL graph / input pointer");
+    if (!p->b3 || !p->Wz || !p->bz || !p->Wr || !p->br || !p->Wh || !p->bh || !p->x3 || !p->Z || !p->R || !p->Ht || !p->Hn || !p->HR)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL cell pointer");
+    if (p->head >= 1 && (!p->W1 || !p->b1 || !p->y)) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL head pointer");
+    if (p->head == 2 && (!p->W2 || !p->b2 || !p->y_out || !p->target || !p->loss_partial))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL loss pointer");
+    if ((int64_t)p->N * 3 * p->C >= ((int64_t)1 << 30)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_fwd: too many rows for 32-bit offsets");
+    FwdArgs a{};
+    a.row_offsets = p->row_offsets; a.column_indices = p->column_indices; a.node_ids = p->node_ids;
+    a.nc_edge = p->norm_col_edge; a.ew_edge = p->ew_edge; a.norm = p->norm;
+    a.x = p->x; a.a3 = p->a3; a.H = p->H; a.target = p->target;
+    a.WcatT = p->WcatT; a.b3 = p->b3; a.Wz = p->Wz; a.bz = p->bz; a.Wr = p->Wr; a.br = p->br; a.Wh = p->Wh; a.bh = p->bh;
+    a.W1 = p->W1; a.b1 = p->b1; a.W2 = p->W2; a.b2 = p->b2;
+    a.P = p->P; a.x3 = p->x3; a.Z = p->Z; a.R = p->R; a.Ht = p->Ht; a.Hn = p->Hn; a.HR = p->HR; a.y = p->y;
+    a.y_out = p->y_out; a.partial = p->loss_partial;
+    a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.num_tiles = (int)((p->N + 15) / 16);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const bool w16 = tuning().step_waves == 16;
+#define STG_STEP_FWD(G_, EW_, HD_)                                                         \
+    return w16 ? launch_step_fwd<64, 32, 32, 16, G_, EW_, HD_>(a, st) : launch_step_fwd<64, 32, 32, 12, G_, EW_, HD_>(a, st)
+#define STG_STEP_FWD_H(G_, EW_)                                                            \
+    switch (p->head) {                                                                     \
+        case 0: STG_STEP_FWD(G_, EW_, 0);                                                  \
+        case 1: STG_STEP_FWD(G_, EW_, 1);                                                  \
+        default: STG_STEP_FWD(G_, EW_, 2);                                                 \
+    }
+    if (gather) {
+        if (p->ew_edge) { STG_STEP_FWD_H(true, true) } else { STG_STEP_FWD_H(true, false) }
+    }
+    STG_STEP_FWD_H(false, false)
+#undef STG_STEP_FWD_H
+#undef STG_STEP_FWD
+}
+
+extern "C" int stg_tgcn_window_loss(const float *partials, int32_t steps, int64_t N, int64_t step_stride, float *step_loss,
+                                    float *cost, void *stream)
+{
+    using namespace stg;
+    if (steps <= 0 || N <= 0 || step_stride < (int64_t)stg_tgcn_step_loss_partials(N))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_window_loss: bad shape steps=%d N=%lld stride=%lld", steps,
+                    (long long)N, (long long)step_stride);
+    if (!partials || !cost) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_window_loss: NULL pointer argument");
+    hipLaunchKernelGGL(window_loss_kernel, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream), partials, steps,
+                       (int)stg_tgcn_step_loss_partials(N), step_stride, 1.0f / (float)N, step_loss, cost);
+    return check_launch("stg_tgcn_window_loss");
+}

@@ -977,6 +977,70 @@ def gemm_tn_multi(As, Bs, colsum: bool = False):
     return (c_tot, cs_tot) if colsum else c_tot
 
 
+# ------------------------------------------------------------- one TGCN step per launch (csrc/tgcn_step.hip)
+def tgcn_step_supported(C: int, Fin: int, Fh: int) -> bool:
+    return bool(_C.lib.stg_tgcn_step_supported(int(C), int(Fin), int(Fh)))
+
+
+def tgcn_step_loss_partials(N: int) -> int:
+    return int(_C.lib.stg_tgcn_step_loss_partials(int(N)))
+
+
+_STEP_INT_FIELDS = ("row_offsets", "column_indices", "node_ids")
+
+
+def _fill_step_args(args, what: str, dev: torch.device, tensors: dict) -> None:
+    """Check and store the device pointers of a stg_tgcn_step_*_args block (None -> NULL)."""
+    names = {f[0] for f in args._fields_}
+    for name, t in tensors.items():
+        if name not in names:
+            raise TypeError(f"{what}: unknown argument {name!r}")
+        if t is None:
+            continue
+        want = torch.int32 if name in _STEP_INT_FIELDS else torch.float32
+        if not torch.is_tensor(t) or t.dtype != want or not t.is_cuda or t.device != dev or not t.is_contiguous():
+            raise TypeError(f"{what}: {name} must be a contiguous {want} tensor on {dev}")
+        setattr(args, name, t.data_ptr())
+
+
+def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: float, device, **tensors) -> None:
+    """One TGCN step forward in one launch (stg_tgcn_step_fwd); ``tensors``: the pointer fields of
+    stg_tgcn_step_fwd_args by name (include/stgraph_hip.h).  Outputs are written in place."""
+    dev = torch.device(device)
+    a = _C.TgcnStepFwdArgs()
+    _fill_step_args(a, "tgcn_step_fwd", dev, tensors)
+    a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
+    # byte model: gathered input rows + index arrays + what the launch reads and writes per row
+    per_row = 4 * (Fin + 3 * C + 6 * C + (Fh + 2 if head else 0))
+    with torch.cuda.device(dev), _Timed("tgcn_step_fwd", N * per_row, 2 * N * (3 * C * Fin + 6 * C * C + (Fh * C if head else 0))):
+        _C.check(_C.lib.stg_tgcn_step_fwd(ctypes.byref(a), _stream_ptr(dev)))
+
+
+def tgcn_step_bwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: float, device, **tensors) -> None:
+    """One TGCN step backward in one launch (stg_tgcn_step_bwd); ``tensors``: the pointer fields of
+    stg_tgcn_step_bwd_args by name."""
+    dev = torch.device(device)
+    a = _C.TgcnStepBwdArgs()
+    _fill_step_args(a, "tgcn_step_bwd", dev, tensors)
+    a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
+    per_row = 4 * (6 * C + 3 * C + 3 * C + 3 * C + C + Fin + (2 * Fh + 3 if head else 0))
+    with torch.cuda.device(dev), _Timed("tgcn_step_bwd", N * per_row, 2 * N * (6 * C * C + 3 * C * Fin + (Fh * C if head else 0))):
+        _C.check(_C.lib.stg_tgcn_step_bwd(ctypes.byref(a), _stream_ptr(dev)))
+
+
+def tgcn_window_loss(partials: torch.Tensor, steps: int, N: int, step_loss: torch.Tensor | None = None) -> torch.Tensor:
+    """cost [1] = sum over ``steps`` rows of ``partials`` of (row sum) / N (stg_tgcn_window_loss)."""
+    partials = _f32(partials, "partials")
+    dev = partials.device
+    if partials.dim() != 2 or partials.shape[0] < steps:
+        raise ValueError("partials must be [steps, tiles]")
+    cost = torch.empty(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _C.check(_C.lib.stg_tgcn_window_loss(_ptr(partials), int(steps), int(N), int(partials.stride(0)), _ptr(step_loss),
+                                             _ptr(cost), _stream_ptr(dev)))
+    return cost
+
+
 def tgcn_head_supported(C: int, F: int, O: int) -> bool:
     return bool(_C.lib.stg_tgcn_head_supported(int(C), int(F), int(O)))
 

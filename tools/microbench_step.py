@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Device time of the one-launch TGCN step kernels (csrc/tgcn_step.hip) at the cfg4 shape, next to the launches they
+replace (aggregate-then-transform + fused cell + head forward; head + cell backward + backward aggregation)."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from bench import degree_norm, synthetic_graph
+from stgraph_amd import kernels
+from stgraph_amd.graph import StaticGraph
+
+C, FIN, FH = 64, 32, 32
+
+
+def timed(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=50_000)
+    ap.add_argument("--edges", type=int, default=500_000)
+    ap.add_argument("--waves", type=str, default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    n, e = args.nodes, args.edges
+    if args.waves:
+        from stgraph_amd import _C
+        _C.set_tuning("step_waves", int(args.waves))
+    src, dst = synthetic_graph(n, e, 3, dev)
+    g = StaticGraph((src, dst), None, n, device=dev, sort_inplace=False)
+    norm = degree_norm(g)
+    ew = torch.rand(e, 1, device=dev) + 0.5
+    f, b = g.csr("fwd"), g.csr("bwd")
+    r = lambda *s: torch.randn(*s, device=dev) * 0.2  # noqa: E731
+    p = dict(Wcat=r(FIN, 3 * C), b3=r(3 * C), Wz=r(C, 2 * C), bz=r(C), Wr=r(C, 2 * C), br=r(C), Wh=r(C, 2 * C), bh=r(C),
+             W1=r(FH, C), b1=r(FH), W2=r(FH), b2=r(1))
+    x, H, tgt = r(n, FIN), r(n, C), r(n)
+    new = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+    out = dict(P=new(n, FIN), x3=new(n, 3 * C), Z=new(n, C), R=new(n, C), Ht=new(n, C), Hn=new(n, C), HR=new(n, C),
+               y=new(n, FH), y_out=new(n), loss_partial=new(-(-n // 16)))
+    ncf, ewf = kernels._edge_gathered(f, "norm", norm, f.column_indices), kernels._edge_gathered(f, "ew", ew, f.eids)
+    ncb, ewb = kernels._edge_gathered(b, "norm", norm, b.column_indices), kernels._edge_gathered(b, "ew", ew, b.eids)
+    WcatT = p["Wcat"].t().contiguous()
+
+    def fwd():
+        kernels.tgcn_step_fwd(n, C, FIN, FH, 2, -1e6, 1e6, dev, row_offsets=f.row_offset, column_indices=f.column_indices,
+                              norm_col_edge=ncf, ew_edge=ewf, norm=norm.view(-1), x=x, H=H, target=tgt, WcatT=WcatT,
+                              b3=p["b3"], Wz=p["Wz"], bz=p["bz"], Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"],
+                              W1=p["W1"], b1=p["b1"], W2=p["W2"], b2=p["b2"], **out)
+    bo = dict(dzl=new(n, C), drl=new(n, C), dhl=new(n, C), da3=new(n, 3 * C), dH=new(n, C), dyt=new(n, FH), dyo=new(n), z=new(n, FIN))
+    zn, dHn, gc = r(n, FIN), r(n, C), torch.ones(1, device=dev)
+    T = {k: p[k].t().contiguous() for k in ("Wz", "Wr", "Wh", "W1")}
+
+    def bwd():
+        kernels.tgcn_step_bwd(n, C, FIN, FH, 2, -1e6, 1e6, dev, row_offsets=b.row_offset, column_indices=b.column_indices,
+                              norm_col_edge=ncb, ew_edge=ewb, norm=norm.view(-1), zn=zn, dHn=dHn, g_cost=gc, Z=out["Z"],
+                              R=out["R"], Ht=out["Ht"], H=H, Hn=out["Hn"], x3=out["x3"], y_out=out["y_out"], target=tgt,
+                              WzT=T["Wz"], WrT=T["Wr"], WhT=T["Wh"], Wcat=p["Wcat"], W1T=T["W1"], W2=p["W2"], **bo)
+    res = {"N": n, "E": e, "waves": args.waves or "auto", "step_fwd_us": timed(fwd), "step_bwd_us": timed(bwd)}
+
+    # the launches they replace
+    def old_fwd():
+        a3, P = kernels.gcn_agg_transform(x, p["Wcat"], norm, norm, f, ew=ew)
+        Hn, extra = kernels.tgcn_cell_fused_fwd(a3, p["b3"], H, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"], -1e6, 1e6)
+        kernels.tgcn_head_fwd(Hn, p["W1"], p["b1"], p["W2"].view(1, -1), p["b2"], tgt.view(-1, 1))
+        return a3, Hn, extra
+    res["old_fwd_us"] = timed(old_fwd)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
