@@ -396,6 +396,21 @@ int stg_gemm_tn_multi_f32(const float *const *A, const float *const *B, int32_t 
                           int64_t K, int32_t M, int32_t N, void *workspace, size_t workspace_bytes,
                           void *stream);
 
+/* The same contraction with operands taken where the one-launch TGCN step leaves them (csrc/tgcn_step.hpp):
+ * A_t [K, M] with row stride lda;  B_t [K, N] = [ op(b_t[:, 0:nsplit]) | b2_t[:, 0:N-nsplit] ] with row strides ldb /
+ * ldb2 (nsplit a multiple of 32, or N: then B2 / ldb2 are unused), op = b_op applied to the values of b_t as they
+ * are loaded: STG_GEMM_B_CLAMP: min(max(v, lo), hi), STG_GEMM_B_RELU: max(v, 0).  E.g. dWz = sum_t dzl_t^T
+ * [clamp(x3_t[:, 0:C]) | H_t] (reference: the autograd of nn.Linear inside nn/pytorch/temporal/tgcn.py:24-25).
+ * workspace: stg_gemm_tn_form_workspace_bytes(T, K, M, N, max(lda, ldb, ldb2)). */
+#define STG_GEMM_B_NONE  0
+#define STG_GEMM_B_CLAMP 1
+#define STG_GEMM_B_RELU  2
+size_t stg_gemm_tn_form_workspace_bytes(int32_t T, int64_t K, int32_t M, int32_t N, int32_t max_ld);
+int stg_gemm_tn_form_f32(const float *const *A, int32_t lda, const float *const *B, int32_t ldb, int32_t nsplit,
+                         const float *const *B2, int32_t ldb2, int32_t b_op, float lo, float hi, int32_t T, float *C,
+                         float *colsum_A, int64_t K, int32_t M, int32_t N, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
 /* The whole forward chain of the six stages below in ONE launch for C = 32 or 64 (hidden width): bias + clamp,
  * the three gate GEMMs on the fp32 matrix cores with the gate weights (torch Linear layout [C][2C]) resident in
  * LDS, sigmoid / tanh and the GRU blend -- one wave per 32-row tile, see csrc/tgcn_cell_fused.hip.  Outputs are

@@ -33,6 +33,18 @@ constexpr int kGemmMaxSeg = 32;
 struct GemmSegs {
     const float *a[kGemmMaxSeg];
     const float *b[kGemmMaxSeg];
+    const float *b2[kGemmMaxSeg];        // columns [nsplit, N) of B_t live in a second matrix (GemmForm::nsplit < N)
+};
+
+// Operand forms.  A_t is [K, M] with row stride lda.  B_t is [K, N] given as ONE or TWO row-major matrices side by
+// side: columns [0, nsplit) from b (row stride ldb), columns [nsplit, N) from b2 (row stride ldb2); nsplit is a multiple
+// of 32 or N.  b_op transforms the values of b as they are loaded (b2 is taken as is): the weight gradients of the
+// one-launch TGCN step contract dzl with [clamp(x3[:, gate]) | H] and dyt with relu(Hn) without those operands ever
+// being written out.
+struct GemmForm {
+    int lda, ldb, ldb2, nsplit;
+    int b_op;                            // STG_GEMM_B_NONE / _CLAMP / _RELU
+    float lo, hi;
 };
 
 // MT = 32-row M tiles per wave: every B dword a wave loads feeds MT MFMAs and every A dword NT of them.  With MT = 1
@@ -41,7 +53,7 @@ struct GemmSegs {
 // 1M x 128 x 128), and B is fetched once per M tile.  MT = 2: MT + NT loads for MT * NT MFMAs.
 template <int NT, int KU, bool CS, int MT>
 __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
-    const GemmSegs segs, float *__restrict__ slab, int64_t K, int M, int N, int64_t kslice_wave,
+    const GemmSegs segs, const GemmForm form, float *__restrict__ slab, int64_t K, int M, int N, int64_t kslice_wave,
     int m_groups, int n_groups, int s_per_seg)
 {
     extern __shared__ float lds[];                       // one wave's accumulators: (MT * NT) x 16 x 64 floats (+ 64 * MT)
@@ -55,6 +67,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     const int sl = s - seg * s_per_seg;
     const float *__restrict__ A = segs.a[seg];
     const float *__restrict__ B = segs.b[seg];
+    const float *__restrict__ B2 = segs.b2[seg];
+    const int lda = form.lda, nsplit = form.nsplit;
 
     const int64_t k0 = ((int64_t)sl * kWavesPerBlock + wave) * kslice_wave;     // wave-uniform, inside the segment
     const int64_t k1 = min(K, k0 + kslice_wave);
@@ -66,16 +80,20 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         m[i] = (mi * MT + i) * 32 + (lane & 31);
-        la[i] = (unsigned)(kh * M + min(m[i], M - 1));                          // lane offset into an A row pair
+        la[i] = (unsigned)(kh * lda + min(m[i], M - 1));                        // lane offset into an A row pair
     }
-    int n[NT];
+    int n[NT], ldj[NT];
     unsigned lb[NT];
-    bool nok[NT];
+    bool nok[NT], second[NT];            // second: the tile's 32 columns come from b2 (wave-uniform)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        n[j] = (nj * NT + j) * 32 + (lane & 31);
+        const int n0 = (nj * NT + j) * 32;
+        n[j] = n0 + (lane & 31);
         nok[j] = n[j] < N;
-        lb[j] = (unsigned)(kh * N + min(n[j], N - 1));
+        second[j] = n0 >= nsplit;
+        ldj[j] = second[j] ? form.ldb2 : form.ldb;
+        const int col = second[j] ? min(n[j], N - 1) - nsplit : min(n[j], nsplit - 1);
+        lb[j] = (unsigned)(kh * ldj[j] + col);
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -94,10 +112,19 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     // >= k1, which is exactly the zero padding the tail needs, and every load is
     // (descriptor in SGPRs) + (loop-invariant 32-bit lane offset) + (scalar row offset).
     const int64_t rows = k1 > k0 ? k1 - k0 : 0;
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + k0 * M), 0,
-                                                       (int)(rows * M * (int64_t)sizeof(float)), 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + k0 * N), 0,
-                                                       (int)(rows * N * (int64_t)sizeof(float)), 0x00020000);
+    // (records: the last row only as far as the columns in use, so that a column window of a wider matrix -- one gate
+    // of x3 -- never reaches past the tensor)
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + k0 * lda), 0,
+                                                       rows > 0 ? (int)(((rows - 1) * lda + M) * (int64_t)sizeof(float)) : 0,
+                                                       0x00020000);
+    const auto rsB1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(B + k0 * form.ldb), 0,
+        rows > 0 ? (int)(((rows - 1) * form.ldb + nsplit) * (int64_t)sizeof(float)) : 0, 0x00020000);
+    const auto rsB2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(B2 ? B2 + k0 * form.ldb2 : B), 0,
+        rows > 0 && B2 ? (int)(((rows - 1) * form.ldb2 + (N - nsplit)) * (int64_t)sizeof(float)) : 0, 0x00020000);
+    const int b_op = form.b_op;
+    const float blo = form.lo, bhi = form.hi;
     int voA[MT], voB[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) voA[i] = (int)(la[i] * sizeof(float));
@@ -107,15 +134,29 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
         const int r0 = (int)(k - k0);                                           // uniform
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
-            const int soA = (r0 + 2 * u) * M * (int)sizeof(float);
-            const int soB = (r0 + 2 * u) * N * (int)sizeof(float);
+            const int soA = (r0 + 2 * u) * lda * (int)sizeof(float);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
                 a[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voA[i], soA, 0));
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                b[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voB[j], soB, 0));
+            for (int j = 0; j < NT; ++j) {
+                const int soB = (r0 + 2 * u) * ldj[j] * (int)sizeof(float);
+                b[u][j] = second[j] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB2, voB[j], soB, 0))
+                                    : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB1, voB[j], soB, 0));
+            }
         }
+    };
+    // the transform of b's values, applied when a set is consumed (its loads have landed by then anyway)
+    auto transform = [&](float (&b)[KU][NT]) {
+        if (b_op == STG_GEMM_B_NONE) return;                                    // wave-uniform
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (second[j]) continue;
+                const float v = b[u][j];
+                b[u][j] = b_op == STG_GEMM_B_RELU ? (v < 0.f ? 0.f : v) : fminf(fmaxf(v, blo), bhi);
+            }
     };
     auto mfma_set = [&](const float (&a)[KU][MT], const float (&b)[KU][NT]) {
 #pragma unroll
@@ -137,9 +178,11 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     for (int64_t k = k0; k < k1; k += 2 * STEP) {
         const bool more1 = k + STEP < k1;
         if (more1) load_set(a1, b1, k + STEP);
+        transform(b0);
         mfma_set(a0, b0);
         if (more1) {
             if (k + 2 * STEP < k1) load_set(a0, b0, k + 2 * STEP);
+            transform(b1);
             mfma_set(a1, b1);
         }
     }
@@ -240,7 +283,7 @@ struct GemmPlan {
     int64_t kslice_wave;
 };
 
-GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1)
+GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1, int max_ld = 0)
 {
     GemmPlan p{};
     p.nt = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
@@ -257,7 +300,7 @@ GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1)
     per_wave = (per_wave + kGemmKStep - 1) / kGemmKStep * kGemmKStep;
     // a wave addresses its K slice through 32-bit buffer descriptors and scalar row offsets: rows * max(M, N) * 4
     // bytes must stay below 2^31 (more slices instead of longer ones; 0 = no slice length fits: unsupported)
-    const int64_t cap = ((int64_t)INT32_MAX / (4 * (int64_t)std::max(M, N))) / kGemmKStep * kGemmKStep;
+    const int64_t cap = ((int64_t)INT32_MAX / (4 * (int64_t)std::max(std::max(M, N), max_ld))) / kGemmKStep * kGemmKStep;
     if (cap < kGemmKStep) { p.S = 0; return p; }
     per_wave = std::min(per_wave, cap);
     p.kslice_wave = std::max<int64_t>(per_wave, kGemmKStep);
@@ -286,7 +329,8 @@ extern "C" size_t stg_gemm_tn_multi_workspace_bytes(int32_t T, int64_t K, int32_
 namespace stg {
 namespace {
 int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C, float *colsum, int64_t K,
-                int32_t M, int32_t N, void *workspace, size_t workspace_bytes, void *stream_, const char *what)
+                int32_t M, int32_t N, void *workspace, size_t workspace_bytes, void *stream_, const char *what,
+                const float *const *B2s = nullptr, const GemmForm *form_in = nullptr)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (K < 0 || M <= 0 || N <= 0 || T <= 0 || T > kGemmMaxSeg)
@@ -301,13 +345,23 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         return e == hipSuccess ? 0 : fail((int)e, "%s: %s", what, hipGetErrorString(e));
     }
     if (!As || !Bs || !workspace) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
+    GemmForm form{M, N, 0, N, STG_GEMM_B_NONE, 0.f, 0.f};
+    if (form_in) form = *form_in;
+    if (form.lda < M || form.nsplit < 0 || form.nsplit > N || (form.nsplit < N && form.nsplit % 32 != 0) ||
+        form.ldb < form.nsplit || (form.nsplit < N && (!B2s || form.ldb2 < N - form.nsplit)) ||
+        form.b_op < STG_GEMM_B_NONE || form.b_op > STG_GEMM_B_RELU)
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad operand form (lda=%d ldb=%d ldb2=%d nsplit=%d b_op=%d)", what,
+                    form.lda, form.ldb, form.ldb2, form.nsplit, form.b_op);
+    if (form.nsplit == 0) return fail(STG_ERR_INVALID_ARGUMENT, "%s: nsplit must be > 0 (pass the matrix as B)", what);
     GemmSegs segs{};
     for (int t = 0; t < T; ++t) {
-        if (!As[t] || !Bs[t]) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL operand in segment %d", what, t);
+        if (!As[t] || !Bs[t] || (form.nsplit < N && !B2s[t]))
+            return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL operand in segment %d", what, t);
         segs.a[t] = As[t];
         segs.b[t] = Bs[t];
+        segs.b2[t] = form.nsplit < N ? B2s[t] : nullptr;
     }
-    const GemmPlan p = plan_gemm_tn(K, M, N, T);
+    const GemmPlan p = plan_gemm_tn(K, M, N, T, std::max(form.lda, std::max(form.ldb, form.ldb2)));
     if (p.S < 1 || (int64_t)T * p.S > INT32_MAX / 2)
         return fail(STG_ERR_UNSUPPORTED, "%s: K=%lld x max(M, N)=%d is outside the 32-bit slice addressing", what,
                     (long long)K, std::max(M, N));
@@ -322,7 +376,7 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
     const size_t lds = ((size_t)p.mt * p.nt * 16 + p.mt) * kWave * sizeof(float);
 #define STG_GEMM_LAUNCH(NT_, KU_, CS_, MT_)                                                                       \
     hipLaunchKernelGGL((gemm_tn_partial_kernel<NT_, KU_, CS_, MT_>), dim3((unsigned)blocks), dim3(kBlock), lds,   \
-                       stream, segs, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S)
+                       stream, segs, form, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S)
 #define STG_GEMM_NT(CS_, MT_)                                                                                     \
     if (p.nt == 1) STG_GEMM_LAUNCH(1, 8, CS_, MT_); else if (p.nt == 2) STG_GEMM_LAUNCH(2, 8, CS_, MT_);         \
     else STG_GEMM_LAUNCH(4, 4, CS_, MT_)
@@ -360,4 +414,22 @@ extern "C" int stg_gemm_tn_multi_f32(const float *const *A, const float *const *
 {
     return stg::gemm_tn_run(A, B, T, C, colsum_A, K, M, N, workspace, workspace_bytes, stream,
                             "stg_gemm_tn_multi_f32");
+}
+
+extern "C" size_t stg_gemm_tn_form_workspace_bytes(int32_t T, int64_t K, int32_t M, int32_t N, int32_t max_ld)
+{
+    if (T <= 0 || T > stg::kGemmMaxSeg || K <= 0 || M <= 0 || N <= 0) return 0;
+    const stg::GemmPlan p = stg::plan_gemm_tn(K, M, N, T, max_ld);
+    if (p.S < 1) return 0;
+    return (size_t)T * (size_t)p.S * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+}
+
+extern "C" int stg_gemm_tn_form_f32(const float *const *A, int32_t lda, const float *const *B, int32_t ldb, int32_t nsplit,
+                                    const float *const *B2, int32_t ldb2, int32_t b_op, float lo, float hi, int32_t T,
+                                    float *C, float *colsum_A, int64_t K, int32_t M, int32_t N, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    const stg::GemmForm form{lda, ldb, ldb2, nsplit, b_op, lo, hi};
+    return stg::gemm_tn_run(A, B, T, C, colsum_A, K, M, N, workspace, workspace_bytes, stream, "stg_gemm_tn_form_f32", B2,
+                            &form);
 }

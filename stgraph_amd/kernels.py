@@ -977,6 +977,54 @@ def gemm_tn_multi(As, Bs, colsum: bool = False):
     return (c_tot, cs_tot) if colsum else c_tot
 
 
+GEMM_B_NONE, GEMM_B_CLAMP, GEMM_B_RELU = 0, 1, 2          # include/stgraph_hip.h STG_GEMM_B_*
+
+
+def gemm_tn_form(As, Bs, M: int, N: int, B2s=None, nsplit: int | None = None, b_op: int = GEMM_B_NONE, lo: float = 0.0,
+                 hi: float = 0.0, colsum: bool = False):
+    """``sum_t A_t.T @ [op(b_t[:, :nsplit]) | b2_t]`` with operands taken in place (stg_gemm_tn_form_f32): every
+    ``A_t`` is a 2-D fp32 view of M columns (unit column stride, any row stride), ``b_t`` one of ``nsplit`` columns
+    (default N) and ``b2_t`` one of ``N - nsplit``; all segments share strides.  ``op``: GEMM_B_CLAMP / GEMM_B_RELU
+    applied to ``b_t`` while loading.  With ``colsum`` also ``sum_t A_t.sum(0)``."""
+    if not As or len(As) != len(Bs) or (B2s is not None and len(B2s) != len(As)):
+        raise ValueError("gemm_tn_form needs equally long, non-empty operand lists")
+    nsplit = N if nsplit is None else int(nsplit)
+    dev = As[0].device
+    K = int(As[0].shape[0])
+
+    def check(ts, cols, name):
+        ld = None
+        for t in ts:
+            if (t.dtype != torch.float32 or not t.is_cuda or t.device != dev or t.dim() != 2 or t.shape[0] != K
+                    or t.shape[1] != cols or (cols > 1 and t.stride(1) != 1)):
+                raise ValueError(f"gemm_tn_form: {name} must be [K={K}, {cols}] fp32 views with unit column stride on {dev}")
+            ldt = int(t.stride(0)) if K > 1 else max(int(t.stride(0)), cols)
+            ld = ldt if ld is None else ld
+            if ldt != ld:
+                raise ValueError(f"gemm_tn_form: all {name} segments must share one row stride")
+        return max(ld, cols)
+    lda = check(As, M, "A")
+    ldb = check(Bs, nsplit, "B")
+    ldb2 = check(B2s, N - nsplit, "B2") if nsplit < N else 0
+    c_tot = cs_tot = None
+    for i in range(0, len(As), MAX_GEMM_SEGMENTS):
+        T = len(As[i:i + MAX_GEMM_SEGMENTS])
+        c = torch.empty(M, N, dtype=torch.float32, device=dev)
+        cs = torch.empty(M, dtype=torch.float32, device=dev) if colsum else None
+        ws_bytes = int(_C.lib.stg_gemm_tn_form_workspace_bytes(T, K, M, N, max(lda, ldb, ldb2)))
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        pa = (ctypes.c_void_p * T)(*[t.data_ptr() for t in As[i:i + T]])
+        pb = (ctypes.c_void_p * T)(*[t.data_ptr() for t in Bs[i:i + T]])
+        pb2 = (ctypes.c_void_p * T)(*[t.data_ptr() for t in B2s[i:i + T]]) if nsplit < N else None
+        with torch.cuda.device(dev), _Timed("gemm_tn_multi", 4 * T * K * (M + N) + 4 * M * N, 2 * T * K * M * N):
+            _C.check(_C.lib.stg_gemm_tn_form_f32(pa, lda, pb, ldb, nsplit, pb2, ldb2, int(b_op), float(lo), float(hi), T,
+                                                 _ptr(c), _ptr(cs), K, M, N, _ptr(ws), ws_bytes, _stream_ptr(dev)))
+        c_tot = c if c_tot is None else c_tot + c
+        if colsum:
+            cs_tot = cs if cs_tot is None else cs_tot + cs
+    return (c_tot, cs_tot) if colsum else c_tot
+
+
 # ------------------------------------------------------------- one TGCN step per launch (csrc/tgcn_step.hip)
 def tgcn_step_supported(C: int, Fin: int, Fh: int) -> bool:
     return bool(_C.lib.stg_tgcn_step_supported(int(C), int(Fin), int(Fh)))

@@ -27,6 +27,7 @@ from .nn.pytorch.temporal.tgcn import TGCN
 
 
 _FUSED_HEAD = True
+_FUSED_WINDOW = True
 
 
 def set_fused_head(enabled: bool) -> None:
@@ -35,6 +36,160 @@ def set_fused_head(enabled: bool) -> None:
     reference's script spells it."""
     global _FUSED_HEAD
     _FUSED_HEAD = bool(enabled)
+
+
+def set_fused_window(enabled: bool) -> None:
+    """True (default): where the shapes allow (``window_cost_usable``) the static-temporal loops run every snapshot of
+    a BPTT window as ONE launch forward and ONE backward (csrc/tgcn_step.hpp) inside a single autograd node, with the
+    weight gradients taken once per window; False: one autograd node per snapshot (``STGraphTGCN.step_loss``)."""
+    global _FUSED_WINDOW
+    _FUSED_WINDOW = bool(enabled)
+
+
+_ZEROS = {}
+
+
+def _zeros(n: int, c: int, device) -> torch.Tensor:
+    """A zero matrix kept per (shape, device): the first snapshot's hidden state as a weight-gradient operand."""
+    key = (n, c, str(device))
+    z = _ZEROS.get(key)
+    if z is None:
+        if len(_ZEROS) > 16:
+            _ZEROS.clear()
+        z = _ZEROS[key] = torch.zeros(n, c, device=device)
+    return z
+
+
+class _TGCNWindow(torch.autograd.Function):
+    """cost = sum_t mean((y_out_t - target_t)^2) over the snapshots of one BPTT window of the static-temporal loop
+    (benchmarking/static-temporal-tgcn/seastar/train.py:165-183 with model.py:6-18 and nn/pytorch/temporal/tgcn.py):
+    ``hidden = None``, ``y_hat = x0``, then ``y_out, y_hat, hidden = model(g, y_hat, w, hidden)`` per snapshot.
+    One launch per snapshot each way (kernels.tgcn_step_fwd / _bwd); the gradient of a snapshot's input is aggregated
+    by the previous snapshot's backward launch; six split-K launches per window give every weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x0, targets, norm, ew, fwd, bwd, use_nid, lo, hi,
+                Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2, b2):
+        from . import kernels
+        dev = x0.device
+        B, N = int(targets.shape[0]), int(x0.shape[0])
+        C, Fin, Fh = int(Wz.shape[0]), int(x0.shape[1]), int(W1.shape[0])
+        x0 = x0.contiguous()
+        targets = targets.reshape(B, N).contiguous()
+        normv = norm.reshape(-1).contiguous()
+        Wcat = torch.cat([Wcz, Wcr, Wch], dim=1)                 # [Fin, 3C]
+        WcatT = Wcat.t().contiguous()
+        b3 = torch.cat([bcz, bcr, bch], dim=0)
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        P, X3 = new(B, N, Fin), new(B, N, 3 * C)
+        Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
+        Y, Yout = new(B, N, Fh), new(B, N)
+        tiles = kernels.tgcn_step_loss_partials(N)
+        partial = new(B, tiles)
+        nid = fwd.node_ids_if_ready if use_nid else None
+        with torch.cuda.device(dev):
+            nc = kernels._edge_gathered(fwd, "norm", norm, fwd.column_indices)
+            ew_e = None if ew is None else kernels._edge_gathered(fwd, "ew", ew, fwd.eids)
+        W2v, weights = W2.reshape(-1).contiguous(), [t.contiguous() for t in (Wz, bz, Wr, br, Wh, bh, W1, b1, b2)]
+        Wz_, bz_, Wr_, br_, Wh_, bh_, W1_, b1_, b2_ = weights
+        for t in range(B):
+            kernels.tgcn_step_fwd(N, C, Fin, Fh, 2, lo, hi, dev, row_offsets=fwd.row_offset, column_indices=fwd.column_indices,
+                                  node_ids=nid, norm_col_edge=nc, ew_edge=ew_e, norm=normv,
+                                  x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1], target=targets[t],
+                                  WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
+                                  W2=W2v, b2=b2_, P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t],
+                                  y_out=Yout[t], loss_partial=partial[t])
+        step_loss = new(B)
+        cost = kernels.tgcn_window_loss(partial, B, N, step_loss)
+        ctx.save_for_backward(x0, targets, norm, normv, ew if ew is not None else norm.new_empty(0), Wcat, Wz_, Wr_, Wh_, W1_, W2v,
+                              P, X3, Z, R, Ht, Hn, HR, Y, Yout)
+        ctx.has_ew, ctx.csrs, ctx.use_nid, ctx.clamp = ew is not None, (fwd, bwd), use_nid, (float(lo), float(hi))
+        ctx.step_loss = step_loss
+        return cost.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_cost):
+        from . import kernels
+        (x0, targets, norm, normv, ew, Wcat, Wz, Wr, Wh, W1, W2v, P, X3, Z, R, Ht, Hn, HR, Y, Yout) = ctx.saved_tensors
+        ew = ew if ctx.has_ew else None
+        fwd, bwd = ctx.csrs
+        lo, hi = ctx.clamp
+        dev = x0.device
+        B, N, C = Z.shape
+        Fin, Fh = int(x0.shape[1]), int(Y.shape[2])
+        g = g_cost.reshape(1).contiguous().float()
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), new(B, N, 3 * C)
+        dyt, dyo = new(B, N, Fh), new(B, N)
+        dH, zbuf = new(2, N, C), new(2, N, Fin)
+        WzT, WrT, WhT, W1T = (w.t().contiguous() for w in (Wz, Wr, Wh, W1))
+        nid = bwd.node_ids_if_ready if ctx.use_nid else None
+        with torch.cuda.device(dev):
+            nc = kernels._edge_gathered(bwd, "norm", norm, bwd.column_indices)
+            ew_e = None if ew is None else kernels._edge_gathered(bwd, "ew", ew, bwd.eids)
+        want_dx0 = ctx.needs_input_grad[0]
+        for t in range(B - 1, -1, -1):
+            last = t == B - 1
+            kernels.tgcn_step_bwd(N, C, Fin, Fh, 2, lo, hi, dev, row_offsets=bwd.row_offset, column_indices=bwd.column_indices,
+                                  node_ids=nid, norm_col_edge=nc, ew_edge=ew_e, norm=normv,
+                                  zn=None if last else zbuf[(t + 1) & 1], g_y=None, dHn=None if last else dH[(t + 1) & 1],
+                                  g_cost=g, Z=Z[t], R=R[t], Ht=Ht[t], H=None if t == 0 else Hn[t - 1], Hn=Hn[t], x3=X3[t],
+                                  y_out=Yout[t], target=targets[t], WzT=WzT, WrT=WrT, WhT=WhT, Wcat=Wcat, W1T=W1T, W2=W2v,
+                                  dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=da3[t], dH=dH[t & 1],
+                                  z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], dyo=dyo[t])
+        dx0 = kernels.gcn_agg(zbuf[0], norm, norm, bwd, ew=ew, use_node_ids=ctx.use_nid) if want_dx0 else None
+        # weight gradients: one split-K launch per parameter over the window's snapshots
+        steps = range(B)
+        Hprev = [_zeros(N, C, dev)] + [Hn[t] for t in range(B - 1)]
+        gate = lambda d, k, second: kernels.gemm_tn_form(  # noqa: E731
+            [d[t] for t in steps], [X3[t][:, k * C:(k + 1) * C] for t in steps], C, 2 * C, B2s=second, nsplit=C,
+            b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True)
+        dWz, dbz = gate(dzl, 0, Hprev)
+        dWr, dbr = gate(drl, 1, Hprev)
+        dWh, dbh = gate(dhl, 2, [HR[t] for t in steps])
+        dWcT, db3 = kernels.gemm_tn_form([da3[t] for t in steps], [P[t] for t in steps], 3 * C, Fin, colsum=True)
+        dW1, db1 = kernels.gemm_tn_form([dyt[t] for t in steps], [Hn[t] for t in steps], Fh, C, b_op=kernels.GEMM_B_RELU,
+                                        colsum=True)
+        dW2, db2 = kernels.gemm_tn_form([dyo[t].view(N, 1) for t in steps], [Y[t] for t in steps], 1, Fh, colsum=True)
+        conv_w = [dWcT[k * C:(k + 1) * C].t() for k in range(3)]
+        conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
+        return (dx0, None, None, None, None, None, None, None, None, *conv_w, *conv_b, dWz, dbz, dWr, dbr, dWh, dbh,
+                dW1, db1, dW2.view(1, Fh), db2)
+
+
+def window_cost_usable(model, graph, x0, edge_weight, targets) -> bool:
+    """Shapes / types ``window_cost`` covers: the static-temporal harness model over TGCN(32 -> 64) on a static graph."""
+    from . import kernels
+    from .graph.dynamic.dynamic_graph import DynamicGraph
+    from .nn.pytorch.static.gcn_conv import GCNConv
+    if not (_FUSED_WINDOW and isinstance(model, STGraphTGCN) and type(model.temporal) is TGCN):
+        return False
+    tg = model.temporal
+    convs = (tg.conv_z, tg.conv_r, tg.conv_h)
+    return (x0.is_cuda and x0.dtype == torch.float32 and x0.dim() == 2 and hasattr(graph, "csr")
+            and not isinstance(graph, DynamicGraph) and not kernels.reference_compat() and kernels._EDGE_CACHE
+            and all(type(c) is GCNConv and c.bias is not None and c.activation is None for c in convs)
+            and model.linear2.out_features == 1 and model.linear.bias is not None and model.linear2.bias is not None
+            and targets.dtype == torch.float32 and targets.numel() == targets.shape[0] * x0.shape[0]
+            and graph.get_ndata("norm") is not None
+            and kernels.tgcn_step_supported(tg.out_channels, tg.in_channels, model.linear.out_features)
+            and model.linear.out_features == tg.in_channels
+            and x0.shape[0] * 3 * tg.out_channels < (1 << 30))
+
+
+def window_cost(model, graph, x0, edge_weight, targets) -> torch.Tensor:
+    """``sum_t mean((y_out_t - targets[t]) ** 2)`` of one BPTT window (``targets`` [B, N] or [B, N, 1]) starting from
+    ``hidden = None`` and input ``x0``: the reference loop's ``cost`` before its division by ``backprop_every + 1``."""
+    from . import kernels
+    from .nn.pytorch.static.gcn_conv import GCNConv
+    tg = model.temporal
+    GCNConv.check_norm(graph)
+    return _TGCNWindow.apply(
+        x0, targets, graph.get_ndata("norm"), edge_weight, graph.csr("fwd"), graph.csr("bwd"),
+        kernels.rows_by_node_ids(graph.graph_type()), -1e6, 1e6,
+        tg.conv_z.weight, tg.conv_r.weight, tg.conv_h.weight, tg.conv_z.bias, tg.conv_r.bias, tg.conv_h.bias,
+        tg.linear_z.weight, tg.linear_z.bias, tg.linear_r.weight, tg.linear_r.bias, tg.linear_h.weight, tg.linear_h.bias,
+        model.linear.weight, model.linear.bias, model.linear2.weight, model.linear2.bias)
 
 
 class STGraphTGCN(torch.nn.Module):
@@ -169,20 +324,25 @@ def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, 
     for _, w in windows_of_rank(total, backprop_every, rank, world):
         bucket.zero()
         if w is not None:
-            cost = 0
-            hidden = None
             y_hat = window_input(n, feat_size, epoch, w, targets.device, seed)
-            for k in range(backprop_every):
-                t = w * backprop_every + k
-                if t >= total:
-                    break
-                cost, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, targets[t], cost)
+            cost = window_cost_of(model, graph, y_hat, edge_weight, targets[w * backprop_every:(w + 1) * backprop_every])
             cost = cost / (backprop_every + 1)
             cost.backward()
             losses.append(cost.detach())
         bucket.all_reduce_mean(world, group, timed_comm)
         optimizer.step()
     return losses
+
+
+def window_cost_of(model, graph, x0, edge_weight, targets_window):
+    """The window's accumulated cost: one fused autograd node (``window_cost``) where usable, else the reference's
+    per-snapshot loop over ``model.step_loss``."""
+    if window_cost_usable(model, graph, x0, edge_weight, targets_window):
+        return window_cost(model, graph, x0, edge_weight, targets_window)
+    cost, hidden, y_hat = 0, None, x0
+    for t in range(targets_window.shape[0]):
+        cost, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, targets_window[t], cost)
+    return cost
 
 
 class DynamicSTGraphTGCN(torch.nn.Module):
@@ -282,11 +442,7 @@ class CapturedStaticWindow:
 
         def body():
             bucket.zero()
-            cost = 0
-            hidden = None
-            y_hat = self.static_y0
-            for k in range(self.B):
-                cost, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, self.static_targets[k], cost)
+            cost = window_cost_of(model, graph, self.static_y0, edge_weight, self.static_targets)
             cost = cost / (self.B + 1)
             cost.backward()
             return cost.detach()
@@ -330,11 +486,8 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
             continue
         bucket.zero()
         if w is not None:
-            cost = 0
-            hidden = None
             y_hat = window_input(n, feat_size, epoch, w, targets.device, seed)
-            for t in range(w * B, min((w + 1) * B, total)):
-                cost, y_hat, hidden = model.step_loss(graph, y_hat, edge_weight, hidden, targets[t], cost)
+            cost = window_cost_of(model, graph, y_hat, edge_weight, targets[w * B:min((w + 1) * B, total)])
             cost = cost / (B + 1)
             cost.backward()
             losses.append(cost.detach())

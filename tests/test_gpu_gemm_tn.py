@@ -76,3 +76,38 @@ def test_slices_stay_inside_32bit_addressing(cuda):
     assert torch.equal(cs.double(), a.double().sum(0) * T)
     del a, b
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("K,T", [(50_000, 3), (4099, 2), (64, 1)])
+def test_operand_forms_strides_split_and_transforms(cuda, K, T):
+    """stg_gemm_tn_form_f32: A and B as column windows of wider matrices, B split over two matrices, clamp / relu applied
+    to the first part while loading -- the forms the one-launch TGCN step's weight gradients use."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(K)
+    C = 64
+    x3 = [torch.randn(K, 3 * C, device=cuda, generator=gen) for _ in range(T)]
+    H = [torch.randn(K, C, device=cuda, generator=gen) for _ in range(T)]
+    d = [torch.randn(K, C, device=cuda, generator=gen) for _ in range(T)]
+    da3 = [torch.randn(K, 3 * C, device=cuda, generator=gen) for _ in range(T)]
+    lo, hi = -0.5, 0.8
+
+    def ref(As, Bs):
+        return sum(a.double().t() @ b.double() for a, b in zip(As, Bs))
+
+    def close(got, want):
+        assert (got.double() - want).abs().max() <= 3e-6 * want.abs().max() * max(1.0, K ** 0.5 / 50) + 1e-6
+    for gate in range(3):                        # dW_gate = sum_t d_t^T [clamp(x3_t[:, gate]) | H_t]
+        Bs = [x[:, gate * C:(gate + 1) * C] for x in x3]
+        got, cs = kernels.gemm_tn_form(d, Bs, C, 2 * C, B2s=H, nsplit=C, b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True)
+        close(got, ref(d, [torch.cat([b.clamp(lo, hi), h], 1) for b, h in zip(Bs, H)]))
+        close(cs, sum(a.double().sum(0) for a in d))
+    # relu on a plain operand, A a column window of a wider matrix (lda > M), N = 32
+    As = [x[:, 32:64] for x in da3]
+    got = kernels.gemm_tn_form(As, H, 32, C, b_op=kernels.GEMM_B_RELU)
+    close(got, ref(As, [h.relu() for h in H]))
+    # no transform, single operand, M = 192, N = 32 (the conv weight gradient da3^T P) and M = 1 (dyo^T y)
+    P = [h[:, :32].contiguous() for h in H]
+    close(kernels.gemm_tn_form(da3, P, 3 * C, 32), ref(da3, P))
+    one = [x[:, :1].contiguous() for x in d]
+    close(kernels.gemm_tn_form(one, P, 1, 32), ref(one, P))
+    assert torch.equal(kernels.gemm_tn_form(da3, P, 3 * C, 32), kernels.gemm_tn_multi(da3, P))      # same kernel, same order

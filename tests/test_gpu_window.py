@@ -1,0 +1,125 @@
+"""temporal.window_cost (one fused autograd node per BPTT window over the one-launch TGCN step kernels) against the
+per-snapshot formulation with every fusion switched off (the reference's loop spelled in torch + the aggregation
+kernels), at a small size with a ragged last window, and at the full BASELINE configs[3] size through the captured
+window (HIP graph) with Adam steps."""
+import contextlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def _unfused():
+    """One autograd node per torch op: no fused window, head, cell or gate aggregation, per-step weight gradients."""
+    from stgraph_amd import temporal
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.temporal import cell
+    from stgraph_amd.nn.pytorch.temporal.tgcn import TGCN
+    old = (TGCN.fuse_cell, TGCN.fuse_gates)
+    temporal.set_fused_window(False)
+    temporal.set_fused_head(False)
+    cell.set_fused_forward(False)
+    cell.set_fused_backward(False)
+    SF.set_deferred_weight_grads(False)
+    TGCN.fuse_cell = TGCN.fuse_gates = False
+    try:
+        yield
+    finally:
+        temporal.set_fused_window(True)
+        temporal.set_fused_head(True)
+        cell.set_fused_forward(True)
+        cell.set_fused_backward(True)
+        SF.set_deferred_weight_grads(True)
+        TGCN.fuse_cell, TGCN.fuse_gates = old
+
+
+def _setup(cuda, n, e, T, seed):
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import StaticGraph
+    from tests.util import random_graph
+    src, dst = random_graph(seed, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    g.set_ndata("norm", temporal.in_degree_norm(g))
+    gen = torch.Generator(device=cuda).manual_seed(seed)
+    ew = torch.rand(len(src), 1, device=cuda, generator=gen) + 0.5
+    targets = torch.randn(T, n, 1, device=cuda, generator=gen)
+    return g, ew, targets, gen
+
+
+@pytest.mark.parametrize("graph_type_ids", [False, True])
+def test_window_cost_matches_the_unfused_loop(cuda, graph_type_ids):
+    from stgraph_amd import temporal
+    n, e, B = 4321, 40000, 5
+    g, ew, targets, gen = _setup(cuda, n, e, B, 11)
+    x0 = torch.randn(n, 32, device=cuda, generator=gen).requires_grad_(True)
+    torch.manual_seed(3)
+    model = temporal.STGraphTGCN(32, 64, 1).to(cuda)
+    if graph_type_ids:
+        g.graph_type = lambda: "csr"               # rows through node_ids (reference tpl_fa_csr.jinja:13-18)
+    assert temporal.window_cost_usable(model, g, x0, ew, targets)
+    cost = temporal.window_cost_of(model, g, x0, ew, targets) / (B + 1)
+    cost.backward()
+    got = (cost.detach().clone(), x0.grad.clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    model.zero_grad()
+    x0.grad = None
+    with _unfused():
+        assert not temporal.window_cost_usable(model, g, x0, ew, targets)
+        ref = temporal.window_cost_of(model, g, x0, ew, targets) / (B + 1)
+        ref.backward()
+    torch.testing.assert_close(got[0], ref.detach(), rtol=1e-5, atol=1e-6)
+    scale = lambda t: float(t.abs().max()) + 1e-12  # noqa: E731
+    assert float((got[1] - x0.grad).abs().max()) <= 1e-4 * scale(x0.grad)
+    for k, p in model.named_parameters():
+        assert float((got[2][k] - p.grad).abs().max()) <= 1e-4 * scale(p.grad) + 1e-7, k
+
+
+def test_epoch_with_a_ragged_last_window_matches(cuda):
+    """T = 11, backprop_every = 4: windows of 4, 4, 3 snapshots; losses and parameters after two epochs of Adam."""
+    from stgraph_amd import temporal
+    n, e, T, B = 4100, 33000, 11, 4
+    res = []
+    for fused in (True, False):
+        g, ew, targets, gen = _setup(cuda, n, e, T, 5)
+        torch.manual_seed(1)
+        model = temporal.STGraphTGCN(32, 64, 1).to(cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        bucket = temporal.GradBucket(model.parameters())
+        ctx = contextlib.nullcontext() if fused else _unfused()
+        with ctx:
+            losses = []
+            for ep in range(2):
+                losses += temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, 32, epoch=ep)
+        res.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-4, atol=1e-6)
+    for a, b in zip(res[0][1], res[1][1]):
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5)       # after 6 Adam steps (sign-sensitive updates)
+
+
+def test_captured_window_at_full_cfg4_size_matches_the_unfused_eager_loop(cuda):
+    """BASELINE configs[3] shape (|V| = 50 K, |E| = 500 K, feat 32, hidden 64, backprop_every 25): two windows replayed
+    from the captured HIP graph with Adam steps == the same two windows run eagerly with every fusion off."""
+    from stgraph_amd import temporal
+    n, e, B = 50_000, 500_000, 25
+    T = 2 * B
+    res = []
+    for fused in (True, False):
+        g, ew, targets, gen = _setup(cuda, n, e, T, 3)
+        torch.manual_seed(3)
+        model = temporal.STGraphTGCN(32, 64, 1).to(cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        bucket = temporal.GradBucket(model.parameters())
+        if fused:
+            cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, 32)
+            losses = temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, 32, epoch=0)
+        else:
+            with _unfused():
+                losses = temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, 32, epoch=0)
+        res.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+        del model, opt, bucket, g
+        torch.cuda.empty_cache()
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-4, atol=1e-6)
+    for a, b in zip(res[0][1], res[1][1]):
+        # after two Adam steps of 1e-2: a gradient entry near zero moves its parameter by up to lr either way
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4)

@@ -71,6 +71,38 @@ def main():
                               WzT=T["Wz"], WrT=T["Wr"], WhT=T["Wh"], Wcat=p["Wcat"], W1T=T["W1"], W2=p["W2"], **bo)
     res = {"N": n, "E": e, "waves": args.waves or "auto", "step_fwd_us": timed(fwd), "step_bwd_us": timed(bwd)}
 
+    # ablations: which phase costs what
+    def fwd_variant(head, gather):
+        kw = dict(H=H, b3=p["b3"], Wz=p["Wz"], bz=p["bz"], Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"], x3=out["x3"],
+                  Z=out["Z"], R=out["R"], Ht=out["Ht"], Hn=out["Hn"], HR=out["HR"])
+        if gather:
+            kw.update(row_offsets=f.row_offset, column_indices=f.column_indices, norm_col_edge=ncf, ew_edge=ewf,
+                      norm=norm.view(-1), x=x, WcatT=WcatT, P=out["P"])
+        else:
+            kw.update(a3=a3c)
+        if head:
+            kw.update(W1=p["W1"], b1=p["b1"], W2=p["W2"], b2=p["b2"], target=tgt, y=out["y"], y_out=out["y_out"],
+                      loss_partial=out["loss_partial"])
+        return lambda: kernels.tgcn_step_fwd(n, C, FIN, FH, head, -1e6, 1e6, dev, **kw)
+    a3c = torch.randn(n, 3 * C, device=dev) * 0.2
+    res["fwd_cell_only_us"] = timed(fwd_variant(0, False))
+    res["fwd_cell_head_us"] = timed(fwd_variant(2, False))
+    res["fwd_gather_cell_us"] = timed(fwd_variant(0, True))
+
+    def bwd_variant(head, gather, want_z=True):
+        kw = dict(dHn=dHn, Z=out["Z"], R=out["R"], Ht=out["Ht"], H=H, x3=out["x3"], WzT=T["Wz"], WrT=T["Wr"], WhT=T["Wh"],
+                  Wcat=p["Wcat"], dzl=bo["dzl"], drl=bo["drl"], dhl=bo["dhl"], da3=bo["da3"], dH=bo["dH"],
+                  z=bo["z"] if want_z else None)
+        if head:
+            kw.update(Hn=out["Hn"], y_out=out["y_out"], target=tgt, g_cost=gc, W1T=T["W1"], W2=p["W2"], dyt=bo["dyt"], dyo=bo["dyo"])
+        if gather:
+            kw.update(row_offsets=b.row_offset, column_indices=b.column_indices, norm_col_edge=ncb, ew_edge=ewb,
+                      norm=norm.view(-1), zn=zn)
+        return lambda: kernels.tgcn_step_bwd(n, C, FIN, FH, head, -1e6, 1e6, dev, **kw)
+    res["bwd_cell_only_us"] = timed(bwd_variant(0, False))
+    res["bwd_cell_only_noz_us"] = timed(bwd_variant(0, False, False))
+    res["bwd_cell_head_us"] = timed(bwd_variant(2, False))
+
     # the launches they replace
     def old_fwd():
         a3, P = kernels.gcn_agg_transform(x, p["Wcat"], norm, norm, f, ew=ew)
