@@ -26,8 +26,9 @@ extern "C" {
 
 /* Bumped whenever an exported signature or contract changes (stgraph_amd/_C.py checks it at load):
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
- *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in. */
-#define STG_ABI_VERSION 3
+ *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
+ *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
+#define STG_ABI_VERSION 4
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -456,10 +457,12 @@ int stg_tgcn_cell_fused_bwd_dx(const float *dHn, const float *Z, const float *H,
  *   head >= 1: W1 [Fh,C], b1 [Fh] -> y [N,Fh];  head == 2: W2 [Fh], b2 [1], target [N] -> y_out [N] and
  *   loss_partial [stg_tgcn_step_loss_partials(N)] (per-tile sums of (y_out - target)^2: stg_tgcn_window_loss adds them).
  *   outputs kept for the backward pass and the weight gradients: P [N,Fin] = A_hat x, x3 [N,3C] = P Wcat + b3 (before
- *   the clamp), Z, R, Ht, Hn, HR = H*R [N,C].
+ *   the clamp), Z, R, Ht, Hn, HR = H*R [N,C]; clamp_mask [N, 12] uint32 (NULL: not wanted): one bit per column of x3,
+ *   set where lo <= x3 <= hi, in the kernels' own piece order (word 4 g + q: 16 bits for gate g, lane q of the row's
+ *   four lanes) -- the backward launch then reads 48 bytes per row instead of x3's 12C.
  * backward: backward CSR (rows = sources) with its per-edge arrays; zn [N,Fin] = the NEXT step's z (NULL: none);
  *   g_y [N,Fh] = a gradient reaching y directly (NULL: none); dHn [N,C] = gradient reaching Hn from the next step (NULL: 0);
- *   g_cost [1]; the forward's Z, R, Ht, H, Hn, x3, y_out, target; WzT/WrT/WhT [2C,C] (transposed gate weights),
+ *   g_cost [1]; the forward's Z, R, Ht, H, Hn, x3 (or clamp_mask, which is preferred when both are given), y_out, target; WzT/WrT/WhT [2C,C] (transposed gate weights),
  *   Wcat [Fin,3C], W1T [C,Fh], W2 [Fh].  head == 2: dyo = 2 (y_out - target) / N * g_cost; dyt = A_hat^T zn + g_y + dyo W2;
  *   dHn += (Hn > 0) (dyt W1).  outputs: dzl, drl, dhl [N,C] (pre-activation gradients of the gate Linears), da3 [N,3C]
  *   (gradient of x3 after the clamp mask), dH [N,C] (to the previous step's Hn), z [N,Fin] = da3 Wcat^T (NULL: not
@@ -471,6 +474,7 @@ typedef struct stg_tgcn_step_fwd_args {
     const float *x, *a3, *H, *target;
     const float *WcatT, *b3, *Wz, *bz, *Wr, *br, *Wh, *bh, *W1, *b1, *W2, *b2;
     float *P, *x3, *Z, *R, *Ht, *Hn, *HR, *y, *y_out, *loss_partial;
+    uint32_t *clamp_mask;
     int64_t N;
     int32_t C, Fin, Fh, head;
     float lo, hi;
@@ -482,6 +486,7 @@ typedef struct stg_tgcn_step_bwd_args {
     const float *Z, *R, *Ht, *H, *Hn, *x3, *y_out, *target;
     const float *WzT, *WrT, *WhT, *Wcat, *W1T, *W2;
     float *dzl, *drl, *dhl, *da3, *dH, *z, *dyt, *dyo;
+    const uint32_t *clamp_mask;
     int64_t N;
     int32_t C, Fin, Fh, head;
     float lo, hi;

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -55,7 +55,7 @@ def _ptr_fields(names):
 class TgcnStepFwdArgs(ctypes.Structure):
     """stg_tgcn_step_fwd_args (include/stgraph_hip.h), field for field."""
     _fields_ = (_ptr_fields("row_offsets column_indices node_ids norm_col_edge ew_edge norm x a3 H target "
-                            "WcatT b3 Wz bz Wr br Wh bh W1 b1 W2 b2 P x3 Z R Ht Hn HR y y_out loss_partial") +
+                            "WcatT b3 Wz bz Wr br Wh bh W1 b1 W2 b2 P x3 Z R Ht Hn HR y y_out loss_partial clamp_mask") +
                 [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
                  ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)])
 
@@ -63,7 +63,7 @@ class TgcnStepFwdArgs(ctypes.Structure):
 class TgcnStepBwdArgs(ctypes.Structure):
     """stg_tgcn_step_bwd_args (include/stgraph_hip.h), field for field."""
     _fields_ = (_ptr_fields("row_offsets column_indices node_ids norm_col_edge ew_edge norm zn g_y dHn g_cost "
-                            "Z R Ht H Hn x3 y_out target WzT WrT WhT Wcat W1T W2 dzl drl dhl da3 dH z dyt dyo") +
+                            "Z R Ht H Hn x3 y_out target WzT WrT WhT Wcat W1T W2 dzl drl dhl da3 dH z dyt dyo clamp_mask") +
                 [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
                  ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)])
 

@@ -12,6 +12,7 @@ struct BwdArgs {
     const float *Z, *R, *Ht, *H, *Hn, *x3, *y_out, *target;
     const float *WzT, *WrT, *WhT, *Wcat, *W1T, *W2;
     float *dzl, *drl, *dhl, *da3, *dH, *z, *dyt, *dyo;
+    const unsigned *mask;
     int64_t N;
     float lo, hi, two_over_n;
     int num_tiles;
@@ -90,7 +91,11 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         // clamp mask of the 3C columns of x3 as 48 bits (read now, used by three later phases: 2 registers instead of
         // 12 loads in the middle of the MFMA chains)
         unsigned mlo = 0u, mhi = 0u;
-        {
+        if (a.mask) {                                                // as the forward launch left it (wave-uniform branch)
+            // word 4 g + kq of the row: 16 bits for gate g; packed here as bit 16 g + 4 blk + i (gates 0, 1 in mlo, 2 in mhi)
+            const unsigned m0 = a.mask[row * 12u + kq], m1 = a.mask[row * 12u + 4 + kq], m2 = a.mask[row * 12u + 8 + kq];
+            mlo = (m0 & 0xffffu) | (m1 << 16), mhi = m2 & 0xffffu;
+        } else {
             float4 v[3 * PC];
 #pragma unroll
             for (int c = 0; c < 3 * PC; ++c) v[c] = ldrow(a.x3, 3 * C, 16 * c + 4 * kq);
@@ -292,7 +297,7 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     if (gather && (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL graph pointer");
     if ((int64_t)p->N * 3 * p->C >= ((int64_t)1 << 30)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_bwd: too many rows for 32-bit offsets");
-    if (!p->Z || !p->R || !p->Ht || !p->x3 || !p->WzT || !p->WrT || !p->WhT || !p->dzl || !p->drl || !p->dhl || !p->da3 || !p->dH)
+    if (!p->Z || !p->R || !p->Ht || (!p->x3 && !p->clamp_mask) || !p->WzT || !p->WrT || !p->WhT || !p->dzl || !p->drl || !p->dhl || !p->da3 || !p->dH)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL cell pointer");
     if (p->z && !p->Wcat) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: z wanted but Wcat is NULL");
     if (p->head >= 1 && (!p->W1T || !p->Hn || !p->dyt)) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL head pointer");
@@ -304,6 +309,7 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     a.zn = p->zn; a.gy = p->g_y; a.dHn = p->dHn; a.g_cost = p->g_cost;
     a.Z = p->Z; a.R = p->R; a.Ht = p->Ht; a.H = p->H; a.Hn = p->Hn; a.x3 = p->x3; a.y_out = p->y_out; a.target = p->target;
     a.WzT = p->WzT; a.WrT = p->WrT; a.WhT = p->WhT; a.Wcat = p->Wcat; a.W1T = p->W1T; a.W2 = p->W2;
+    a.mask = p->clamp_mask;
     a.dzl = p->dzl; a.drl = p->drl; a.dhl = p->dhl; a.da3 = p->da3; a.dH = p->dH; a.z = p->z; a.dyt = p->dyt; a.dyo = p->dyo;
     a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.two_over_n = 2.0f / (float)p->N; a.num_tiles = (int)((p->N + 15) / 16);
     hipStream_t st = static_cast<hipStream_t>(stream_);

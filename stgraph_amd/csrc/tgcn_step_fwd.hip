@@ -10,6 +10,7 @@ struct FwdArgs {
     const float *x, *a3, *H, *target;
     const float *WcatT, *b3, *Wz, *bz, *Wr, *br, *Wh, *bh, *W1, *b1, *W2, *b2;
     float *P, *x3, *Z, *R, *Ht, *Hn, *HR, *y, *y_out, *partial;
+    unsigned *mask;
     int64_t N;
     float lo, hi;
     int num_tiles;
@@ -115,14 +116,21 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
                     hg[ct] = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
                 }
             }
+            unsigned gm = 0u;             // clamp mask of this gate's columns: bit 4 ct + i <-> column 16 ct + 4 kq + i
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) {
                 if (rok) *reinterpret_cast<float4 *>(a.x3 + (row * (3 * C) + g * C + 16 * ct + 4 * kq)) = hg[ct];
+                {
+                    const float4 v = hg[ct];
+                    gm |= ((v.x >= lo && v.x <= hi ? 1u : 0u) | (v.y >= lo && v.y <= hi ? 2u : 0u) |
+                           (v.z >= lo && v.z <= hi ? 4u : 0u) | (v.w >= lo && v.w <= hi ? 8u : 0u)) << (4 * ct);
+                }
                 hg[ct].x = fminf(fmaxf(hg[ct].x, lo), hi);
                 hg[ct].y = fminf(fmaxf(hg[ct].y, lo), hi);
                 hg[ct].z = fminf(fmaxf(hg[ct].z, lo), hi);
                 hg[ct].w = fminf(fmaxf(hg[ct].w, lo), hi);
             }
+            if (a.mask && rok) a.mask[row * 12u + 4 * g + kq] = gm;
         };
         float4 hh[PC];
 #pragma unroll
@@ -305,7 +313,7 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
     a.WcatT = p->WcatT; a.b3 = p->b3; a.Wz = p->Wz; a.bz = p->bz; a.Wr = p->Wr; a.br = p->br; a.Wh = p->Wh; a.bh = p->bh;
     a.W1 = p->W1; a.b1 = p->b1; a.W2 = p->W2; a.b2 = p->b2;
     a.P = p->P; a.x3 = p->x3; a.Z = p->Z; a.R = p->R; a.Ht = p->Ht; a.Hn = p->Hn; a.HR = p->HR; a.y = p->y;
-    a.y_out = p->y_out; a.partial = p->loss_partial;
+    a.y_out = p->y_out; a.partial = p->loss_partial; a.mask = p->clamp_mask;
     a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.num_tiles = (int)((p->N + 15) / 16);
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const bool w16 = tuning().step_waves == 16;

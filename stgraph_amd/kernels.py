@@ -1045,7 +1045,7 @@ def _fill_step_args(args, what: str, dev: torch.device, tensors: dict) -> None:
             raise TypeError(f"{what}: unknown argument {name!r}")
         if t is None:
             continue
-        want = torch.int32 if name in _STEP_INT_FIELDS else torch.float32
+        want = torch.int32 if name in _STEP_INT_FIELDS or name == "clamp_mask" else torch.float32
         if not torch.is_tensor(t) or t.dtype != want or not t.is_cuda or t.device != dev or not t.is_contiguous():
             raise TypeError(f"{what}: {name} must be a contiguous {want} tensor on {dev}")
         setattr(args, name, t.data_ptr())

@@ -86,6 +86,7 @@ class _TGCNWindow(torch.autograd.Function):
         Y, Yout = new(B, N, Fh), new(B, N)
         tiles = kernels.tgcn_step_loss_partials(N)
         partial = new(B, tiles)
+        mask = torch.empty(B, N, 12, dtype=torch.int32, device=dev)              # clamp mask of x3, one bit per column
         nid = fwd.node_ids_if_ready if use_nid else None
         with torch.cuda.device(dev):
             nc = kernels._edge_gathered(fwd, "norm", norm, fwd.column_indices)
@@ -98,11 +99,11 @@ class _TGCNWindow(torch.autograd.Function):
                                   x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1], target=targets[t],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
                                   W2=W2v, b2=b2_, P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t],
-                                  y_out=Yout[t], loss_partial=partial[t])
+                                  y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t])
         step_loss = new(B)
         cost = kernels.tgcn_window_loss(partial, B, N, step_loss)
         ctx.save_for_backward(x0, targets, norm, normv, ew if ew is not None else norm.new_empty(0), Wcat, Wz_, Wr_, Wh_, W1_, W2v,
-                              P, X3, Z, R, Ht, Hn, HR, Y, Yout)
+                              P, X3, Z, R, Ht, Hn, HR, Y, Yout, mask)
         ctx.has_ew, ctx.csrs, ctx.use_nid, ctx.clamp = ew is not None, (fwd, bwd), use_nid, (float(lo), float(hi))
         ctx.step_loss = step_loss
         return cost.reshape(())
@@ -110,7 +111,7 @@ class _TGCNWindow(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_cost):
         from . import kernels
-        (x0, targets, norm, normv, ew, Wcat, Wz, Wr, Wh, W1, W2v, P, X3, Z, R, Ht, Hn, HR, Y, Yout) = ctx.saved_tensors
+        (x0, targets, norm, normv, ew, Wcat, Wz, Wr, Wh, W1, W2v, P, X3, Z, R, Ht, Hn, HR, Y, Yout, mask) = ctx.saved_tensors
         ew = ew if ctx.has_ew else None
         fwd, bwd = ctx.csrs
         lo, hi = ctx.clamp
@@ -133,7 +134,8 @@ class _TGCNWindow(torch.autograd.Function):
             kernels.tgcn_step_bwd(N, C, Fin, Fh, 2, lo, hi, dev, row_offsets=bwd.row_offset, column_indices=bwd.column_indices,
                                   node_ids=nid, norm_col_edge=nc, ew_edge=ew_e, norm=normv,
                                   zn=None if last else zbuf[(t + 1) & 1], g_y=None, dHn=None if last else dH[(t + 1) & 1],
-                                  g_cost=g, Z=Z[t], R=R[t], Ht=Ht[t], H=None if t == 0 else Hn[t - 1], Hn=Hn[t], x3=X3[t],
+                                  g_cost=g, Z=Z[t], R=R[t], Ht=Ht[t], H=None if t == 0 else Hn[t - 1], Hn=Hn[t], x3=None,
+                                  clamp_mask=mask[t],
                                   y_out=Yout[t], target=targets[t], WzT=WzT, WrT=WrT, WhT=WhT, Wcat=Wcat, W1T=W1T, W2=W2v,
                                   dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=da3[t], dH=dH[t & 1],
                                   z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], dyo=dyo[t])

@@ -74,7 +74,8 @@ def _ref_step(A, x, H, p, target, lo=LO, hi=HI):
 def _alloc(cuda, n):
     new = lambda *s: torch.full(s, float("nan"), device=cuda)  # noqa: E731
     return dict(P=new(n, FIN), x3=new(n, 3 * C), Z=new(n, C), R=new(n, C), Ht=new(n, C), Hn=new(n, C), HR=new(n, C),
-                y=new(n, FH), y_out=new(n), loss_partial=new(-(-n // 16)))
+                y=new(n, FH), y_out=new(n), loss_partial=new(-(-n // 16)),
+                clamp_mask=torch.zeros(n, 12, dtype=torch.int32, device=cuda))
 
 
 def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, hi=HI):
@@ -90,7 +91,8 @@ def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, h
     return out
 
 
-def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True, head=2, node_ids=False, lo=LO, hi=HI):
+def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True, head=2, node_ids=False, lo=LO, hi=HI,
+         use_mask=False):
     from stgraph_amd import kernels
     new = lambda *s: torch.full(s, float("nan"), device=cuda)  # noqa: E731
     out = dict(dzl=new(n, C), drl=new(n, C), dhl=new(n, C), da3=new(n, 3 * C), dH=new(n, C), dyt=new(n, FH), dyo=new(n),
@@ -100,7 +102,8 @@ def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True
     kernels.tgcn_step_bwd(n, C, FIN, FH, head, lo, hi, cuda, row_offsets=g.bwd.row_offset, column_indices=g.bwd.column_indices,
                           node_ids=g.bwd.node_ids if node_ids else None, norm_col_edge=nc, ew_edge=ew_e, norm=norm.view(-1),
                           zn=zn, g_y=None, dHn=dHn, g_cost=g_cost, Z=saved["Z"], R=saved["R"], Ht=saved["Ht"], H=H,
-                          Hn=saved["Hn"], x3=saved["x3"], y_out=saved["y_out"], target=target,
+                          Hn=saved["Hn"], x3=None if use_mask else saved["x3"],
+                          clamp_mask=saved["clamp_mask"] if use_mask else None, y_out=saved["y_out"], target=target,
                           WzT=p["Wz"].t().contiguous(), WrT=p["Wr"].t().contiguous(), WhT=p["Wh"].t().contiguous(),
                           Wcat=p["Wcat"], W1T=p["W1"].t().contiguous(), W2=p["W2"].view(-1).contiguous(), **out)
     return out
@@ -210,6 +213,9 @@ def test_clamp_is_honoured(cuda):
     H = torch.randn(n, C, device=cuda) * 0.3
     s0 = _fwd(cuda, g, norm, None, p, x0, H, t0, n, lo=lo, hi=hi)
     b0 = _bwd(cuda, g, norm, None, p, s0, H, t0, n, zn=None, dHn=None, g_cost=torch.ones(1, device=cuda), lo=lo, hi=hi)
+    bm = _bwd(cuda, g, norm, None, p, s0, H, t0, n, zn=None, dHn=None, g_cost=torch.ones(1, device=cuda), lo=lo, hi=hi,
+              use_mask=True)                     # the mask the forward launch left instead of x3: same gradients, bit for bit
+    assert all(torch.equal(b0[k], bm[k]) for k in ("da3", "dH", "dzl", "drl", "dhl", "z"))
     blocked = (s0["x3"] > hi) | (s0["x3"] < lo)
     assert 0.2 < blocked.float().mean() < 0.9            # the clamp really is active, x3 itself is kept unclamped
     assert not b0["da3"][blocked].any() and b0["da3"][~blocked].abs().sum() > 0
@@ -237,6 +243,6 @@ def test_cell_only_mode_matches_the_gather_mode(cuda):
     out = _alloc(cuda, n)
     kernels.tgcn_step_fwd(n, C, FIN, FH, 0, LO, HI, cuda, a3=a3.contiguous(), H=H, b3=p["b3"], Wz=p["Wz"], bz=p["bz"], Wr=p["Wr"],
                           br=p["br"], Wh=p["Wh"], bh=p["bh"], x3=out["x3"], Z=out["Z"], R=out["R"], Ht=out["Ht"], Hn=out["Hn"],
-                          HR=out["HR"])
+                          HR=out["HR"], clamp_mask=None)
     for k in ("x3", "Z", "R", "Ht", "Hn", "HR"):
         _close(out[k], full[k], k, 1e-5)
