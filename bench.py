@@ -491,7 +491,9 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
     targets = torch.randn(T, n, 1, device=device, generator=gen)
     torch.manual_seed(3)                                         # identical replicas
     model = temporal.STGraphTGCN(feat, hidden, 1).to(device)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    # capturable + fused: the update rule of the default Adam as ONE kernel that a HIP graph can hold (the captured
+    # windows replay it together with the gradient scaling; the eager epoch below uses the same optimizer object)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
     bucket = temporal.GradBucket(model.parameters())
 
     def barrier():
@@ -536,7 +538,7 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         comm = float(t.item())
     # (b) the same windows replayed from a captured HIP graph (one capture, 40/N replays per epoch)
-    cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, feat, world=world)
+    cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, feat, world=world, rank=rank)
     for ep in range(warmup_epochs):
         temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat, epoch=2 + ep, rank=rank,
                                              world=world)
@@ -550,6 +552,33 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
         t = torch.tensor([comm_g], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         comm_g = float(t.item())
+    calls_timed = bucket.comm_calls - calls0
+    # Per optimizer step: CPU time the rank spends issuing it (thread CPU time: a replay of a graph that is still in
+    # flight blocks in the runtime, which wall time would count) and device idle time between steps (epoch wall time
+    # minus the device time of the steps, from HIP events around each step)
+    steps_epoch = (temporal.num_windows(T, B) + world - 1) // world
+    ev = []
+    run_plain = cw.run
+
+    def run_timed(w, timed_comm=False):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = run_plain(w, timed_comm)
+        b.record()
+        ev.append((a, b))
+        return r
+    barrier()
+    tc0, tw0 = time.thread_time(), time.perf_counter()
+    temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat, epoch=98, rank=rank, world=world)
+    host_cpu_s = time.thread_time() - tc0
+    cw.run = run_timed
+    barrier()
+    tw0 = time.perf_counter()
+    temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat, epoch=99, rank=rank, world=world)
+    barrier()
+    wall_ev = time.perf_counter() - tw0
+    cw.run = run_plain
+    dev_busy_s = sum(a.elapsed_time(b) for a, b in ev) * 1e-3
     bucket.check_views()
     fused = bool(model.temporal.fuse_gates)
     agg_per_step = 2 if fused else 6                             # (fwd + bwd) x (1 fused | 3 separate) gates
@@ -583,11 +612,16 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
         "scaling": "strong", "n_gpus": world,
         "windows_per_epoch": temporal.num_windows(T, B),
         "optimizer_steps_per_epoch": (temporal.num_windows(T, B) + world - 1) // world,
+        "host_cpu_us_per_optimizer_step": host_cpu_s / max(steps_epoch, 1) * 1e6,
+        "device_idle_us_per_optimizer_step": max(0.0, wall_ev - dev_busy_s) / max(steps_epoch, 1) * 1e6,
+        "host_ops_per_optimizer_step": ("graph replay (window), all-reduce (eager, N > 1 only), graph replay (grad / N, "
+                                        "Adam, window index)") if cw.step_graph is not None else
+                                       "graph replay, all-reduce + div, eager optimizer step, window index add",
         "eager": {"seconds_per_epoch": dt_eager, "epochs_per_s": 1.0 / dt_eager,
                   "rank0_gcn_agg_kernel_seconds": agg_s, "rank0_gcn_agg_launches": agg_launches,
                   "rank0_gcn_agg_share": agg_s / dt_eager, "rank0_native_kernels": ktab,
                   "allreduce_seconds_max_rank": comm, "allreduce_share": comm / dt_eager},
-        "allreduce": {"bytes": bucket.nbytes, "calls_per_epoch": (bucket.comm_calls - calls0) / max(epochs, 1),
+        "allreduce": {"bytes": bucket.nbytes, "calls_per_epoch": calls_timed / max(epochs, 1),
                       "seconds_max_rank": comm_g, "share_of_epoch": comm_g / dt if dt else None,
                       "collective": "one all-reduce(sum)/N of the flattened gradient bucket per optimizer step"},
     }

@@ -262,14 +262,16 @@ class GradBucket:
                                    "(use bucket.zero(), not optimizer.zero_grad())")
             off += p.numel()
 
-    def all_reduce_mean(self, world: int, group=None, timed: bool = False) -> None:
+    def all_reduce_mean(self, world: int, group=None, timed: bool = False, divide: bool = True) -> None:
+        """``divide=False``: only the sum -- the caller divides (the captured optimizer step does, in its graph)."""
         if world <= 1:
             return
         if timed and self.flat.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.div_(world)
+        if divide:
+            self.flat.div_(world)
         self.comm_calls += 1
         if timed and self.flat.is_cuda:
             e1.record()
@@ -305,12 +307,48 @@ def windows_of_rank(total_timestamps: int, backprop_every: int, rank: int, world
     return out
 
 
+WINDOW_CHUNK = 64          # windows drawn by one randn call (fewer on very large graphs: chunk_windows)
+_GENERATORS = {}
+_LAST_CHUNK = {}
+
+
+def _generator(device) -> torch.Generator:
+    key = str(torch.device(device))
+    gen = _GENERATORS.get(key)
+    if gen is None:
+        gen = _GENERATORS[key] = torch.Generator(device=device)
+    return gen
+
+
+def chunk_windows(num_nodes: int, feat: int) -> int:
+    """Windows per draw: WINDOW_CHUNK, fewer when one draw would exceed 1 GiB (a function of the problem's shape only,
+    never of the number of ranks)."""
+    return max(1, min(WINDOW_CHUNK, (1 << 28) // max(1, num_nodes * feat)))
+
+
+def window_input_chunk(num_nodes: int, feat: int, epoch: int, chunk: int, device, seed: int = 0,
+                       out: torch.Tensor | None = None) -> torch.Tensor:
+    """The fresh ``torch.randn`` inputs of windows ``[chunk * CW, (chunk + 1) * CW)`` of an epoch (CW =
+    ``chunk_windows``) as one ``[CW, N, feat]`` draw whose stream is a function of (seed, epoch, chunk) only: a window's
+    input is the same for any number of ranks, and an epoch costs one generator call per chunk instead of one generator
+    object, one seeding and one launch per window."""
+    gen = _generator(device)
+    gen.manual_seed((seed * 1_000_003 + epoch) * 1_000_003 + chunk)
+    if out is None:
+        return torch.randn(chunk_windows(num_nodes, feat), num_nodes, feat, device=device, generator=gen)
+    return out.normal_(generator=gen)
+
+
 def window_input(num_nodes: int, feat: int, epoch: int, window: int, device, seed: int = 0) -> torch.Tensor:
-    """The fresh ``torch.randn`` input of a window, made a function of (seed, epoch, window) so
-    that a run is reproducible for any number of ranks."""
-    gen = torch.Generator(device=device)
-    gen.manual_seed((seed * 1_000_003 + epoch) * 1_000_003 + window)
-    return torch.randn(num_nodes, feat, device=device, generator=gen)
+    """Input of one window: row ``window % CW`` of its chunk (the last chunk drawn is kept, so a loop over
+    consecutive windows draws each chunk once)."""
+    cw = chunk_windows(num_nodes, feat)
+    key = (num_nodes, feat, epoch, window // cw, str(torch.device(device)), seed)
+    hit = _LAST_CHUNK.get("key")
+    if hit != key:
+        _LAST_CHUNK["chunk"] = window_input_chunk(num_nodes, feat, epoch, window // cw, device, seed)
+        _LAST_CHUNK["key"] = key
+    return _LAST_CHUNK["chunk"][window % cw]
 
 
 def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, optimizer,
@@ -420,34 +458,47 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
 
 
 class CapturedStaticWindow:
-    """The compute of one full BPTT window of the static-temporal loop -- bucket.zero,
-    ``backprop_every`` model steps, loss, backward through time -- captured ONCE into a HIP graph
-    and replayed per window; the gradient all-reduce and the optimizer step follow eagerly.
+    """The compute of one full BPTT window of the static-temporal loop -- bucket.zero, ``backprop_every`` model steps,
+    loss, backward through time -- captured ONCE into a HIP graph and replayed per window.
 
-    Eagerly the window issues ~6 000 small kernels (|V| = 50K: a few microseconds each) and is
-    bound by host launch overhead; the graph replays the identical kernel sequence (same kernels,
-    same order, same numerics) from device-side descriptors.  Inputs that change per window live
-    in static buffers overwritten before each replay: the window's ``randn`` input and its slice of
-    ``targets``.  The collective is deliberately NOT captured: one eager RCCL all-reduce and one
-    eager (foreach) Adam step per window cost microseconds next to the window itself, and it keeps
-    the N > 1 path free of stream-capture constraints on the communicator.
+    Eagerly the window issues thousands of small kernels and is bound by host launch overhead; the graph replays the
+    identical kernel sequence from device-side descriptors.  What changes per window is READ BY THE GRAPH from device
+    memory: a window index ``widx`` selects the window's ``randn`` input out of the epoch's pre-drawn chunk and its
+    slice of ``targets`` (captured gathers), and the cost lands in slot ``widx`` of a per-epoch buffer.  Per optimizer
+    step the host therefore issues: one graph replay, the all-reduce of the gradient bucket (eager: it keeps the
+    N > 1 path free of stream-capture constraints on the communicator; skipped at one rank), and a second small
+    graph holding ``grad /= world``, the optimizer step and ``widx += world`` when the optimizer is capturable
+    (``torch.optim.Adam(..., capturable=True)``); with another optimizer that tail runs eagerly as before.
     """
 
     def __init__(self, model, graph, edge_weight, targets, backprop_every: int, optimizer,
-                 bucket: GradBucket, feat_size: int, world: int = 1, group=None, warmup: int = 3):
-        self.B = backprop_every
+                 bucket: GradBucket, feat_size: int, world: int = 1, rank: int = 0, group=None, warmup: int = 3):
+        self.B = B = backprop_every
         n = graph.get_num_nodes()
         dev = targets.device
-        self.static_y0 = torch.zeros(n, feat_size, device=dev)
-        self.static_targets = torch.zeros((backprop_every,) + tuple(targets.shape[1:]), device=dev)
-        self.bucket, self.world, self.group, self.optimizer = bucket, world, group, optimizer
+        total = targets.shape[0]
+        self.full_windows = total // B                      # windows replayed from the graph; a ragged tail runs eagerly
+        self.bucket, self.world, self.rank, self.group, self.optimizer = bucket, world, rank, group, optimizer
+        self.n, self.feat, self.dev = n, feat_size, dev
+        self.num_windows = num_windows(total, B)
+        self.cw = chunk_windows(n, feat_size)
+        self.chunks = (self.num_windows + self.cw - 1) // self.cw
+        if self.chunks * self.cw * n * feat_size * 4 > (8 << 30):
+            raise ValueError("CapturedStaticWindow keeps an epoch's window inputs resident: more than 8 GiB here")
+        self.inputs = torch.zeros(self.chunks * self.cw, n, feat_size, device=dev)     # refilled in place every epoch
+        self.targets_w = targets[: self.full_windows * B].view(self.full_windows, B, *targets.shape[1:])
+        self.widx = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.costs = torch.zeros(max(self.num_windows, 1), device=dev)
+        self._epoch = None
 
         def body():
             bucket.zero()
-            cost = window_cost_of(model, graph, self.static_y0, edge_weight, self.static_targets)
-            cost = cost / (self.B + 1)
+            y0 = self.inputs.index_select(0, self.widx)[0]                            # captured gathers: no host copy
+            tw = self.targets_w.index_select(0, self.widx)[0]
+            cost = window_cost_of(model, graph, y0, edge_weight, tw)
+            cost = cost / (B + 1)
             cost.backward()
-            return cost.detach()
+            self.costs.index_copy_(0, self.widx, cost.detach().reshape(1))
 
         # Warm up on a side stream (allocator, lazily built per-edge caches, tracing).  The body
         # only writes gradients, so warming up and capturing leave the training state untouched.
@@ -460,42 +511,101 @@ class CapturedStaticWindow:
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.cost = body()
+            body()
         bucket.zero()
 
-    def run(self, y0: torch.Tensor, targets_window: torch.Tensor, timed_comm: bool = False) -> torch.Tensor:
-        self.static_y0.copy_(y0)
-        self.static_targets.copy_(targets_window)
+        # second graph: what follows the all-reduce
+        self.step_graph = None
+        if all(g.get("capturable", False) for g in optimizer.param_groups):
+            self._capture_step(dev)
+
+    def _capture_step(self, dev):
+        """``grad /= world`` + ``optimizer.step()`` + ``widx += world`` as one graph.  Capturing runs the optimizer
+        once, so its state and the parameters are snapshotted and restored around the capture (the first captured
+        step would otherwise count as a training step on zero gradients)."""
+        opt, bucket, world = self.optimizer, self.bucket, self.world
+        params = [p for g in opt.param_groups for p in g["params"]]
+
+        def tail():
+            if world > 1:
+                bucket.flat.div_(world)
+            opt.step()
+            self.widx.add_(world)
+        saved_p = [p.detach().clone() for p in params]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                tail()                                        # creates the optimizer state (device step counters)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            tail()
+        with torch.no_grad():
+            for p, q in zip(params, saved_p):
+                p.copy_(q)
+            for st in opt.state.values():                     # back to "no step taken yet"
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            self.widx.zero_()
+        bucket.zero()
+        self.step_graph = g
+
+    def begin_epoch(self, epoch: int, seed: int = 0) -> None:
+        """Draw the epoch's window inputs in place (one generator call) and point ``widx`` at this rank's first window."""
+        for c in range(self.chunks):
+            window_input_chunk(self.n, self.feat, epoch, c, self.dev, seed, out=self.inputs[c * self.cw:(c + 1) * self.cw])
+        self.widx.fill_(self.rank)
+        self._epoch = epoch
+
+    def run(self, window: int, timed_comm: bool = False) -> torch.Tensor:
+        """Replay the window ``widx`` points at (== ``window``: the caller's loop and the device counter advance
+        together), reduce, step.  Returns the slot of ``costs`` the window's cost is written to (a view: no copy)."""
         self.graph.replay()
-        self.bucket.all_reduce_mean(self.world, self.group, timed_comm)
-        self.optimizer.step()
-        return self.cost.clone()
+        if self.step_graph is not None:
+            self.bucket.all_reduce_mean(self.world, self.group, timed_comm, divide=False)
+            self.step_graph.replay()
+        else:
+            self.bucket.all_reduce_mean(self.world, self.group, timed_comm)
+            self.optimizer.step()
+            self.widx.add_(self.world)
+        return self.costs[window]
 
 
 def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_weight, targets, optimizer,
                                 bucket: GradBucket, feat_size: int, epoch: int = 0, rank: int = 0,
                                 world: int = 1, group=None, seed: int = 0, timed_comm: bool = False):
     """``train_epoch_static`` with full windows replayed from the captured graph; a trailing short
-    window or a padding step (more ranks than windows left) runs eagerly."""
+    window or a padding step (more ranks than windows left) runs eagerly.  Returns this rank's window costs as one
+    tensor (views into the captured window's per-epoch buffer, cloned once at the end)."""
     total = targets.shape[0]
     B = cw.B
     n = graph.get_num_nodes()
-    losses = []
+    cw.begin_epoch(epoch, seed)
+    slots, eager = [], {}
     for _, w in windows_of_rank(total, B, rank, world):
-        if w is not None and (w + 1) * B <= total:
-            y0 = window_input(n, feat_size, epoch, w, targets.device, seed)
-            losses.append(cw.run(y0, targets[w * B:(w + 1) * B], timed_comm))
+        if w is not None and w < cw.full_windows:
+            cw.run(w, timed_comm)
+            slots.append(w)
             continue
         bucket.zero()
         if w is not None:
-            y_hat = window_input(n, feat_size, epoch, w, targets.device, seed)
+            y_hat = cw.inputs[w]
             cost = window_cost_of(model, graph, y_hat, edge_weight, targets[w * B:min((w + 1) * B, total)])
             cost = cost / (B + 1)
             cost.backward()
-            losses.append(cost.detach())
+            eager[w] = cost.detach()
+            slots.append(w)
         bucket.all_reduce_mean(world, group)
         optimizer.step()
-    return losses
+        cw.widx.add_(world)
+    out = cw.costs[slots].clone() if slots else cw.costs[:0].clone()
+    for i, w in enumerate(slots):
+        if w in eager:
+            out[i] = eager[w]
+    return list(out.unbind(0))
 
 
 def in_degree_norm(graph) -> torch.Tensor:

@@ -123,3 +123,32 @@ def test_captured_window_at_full_cfg4_size_matches_the_unfused_eager_loop(cuda):
     for a, b in zip(res[0][1], res[1][1]):
         # after two Adam steps of 1e-2: a gradient entry near zero moves its parameter by up to lr either way
         torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4)
+
+
+def test_captured_optimizer_tail_matches_the_eager_tail(cuda):
+    """capturable Adam: the second graph (grad / world, optimizer step, window index) == the eager tail, over two epochs
+    with a ragged last window (T = 11, B = 4); the window inputs come from the epoch's pre-drawn chunk in both."""
+    from stgraph_amd import temporal
+    n, e, T, B = 4100, 33000, 11, 4
+    res = []
+    for mode in ("captured_tail", "eager_tail", "eager_loop"):
+        g, ew, targets, gen = _setup(cuda, n, e, T, 6)
+        torch.manual_seed(2)
+        model = temporal.STGraphTGCN(32, 64, 1).to(cuda)
+        opt = (torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True) if mode == "captured_tail"
+               else torch.optim.Adam(model.parameters(), lr=1e-2))
+        bucket = temporal.GradBucket(model.parameters())
+        losses = []
+        if mode != "eager_loop":
+            cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, 32)
+            assert (cw.step_graph is not None) == (mode == "captured_tail")
+        for ep in range(2):
+            if mode == "eager_loop":
+                losses += temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, 32, epoch=ep)
+            else:
+                losses += temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, 32, epoch=ep)
+        res.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+    for other in (1, 2):
+        torch.testing.assert_close(res[0][0], res[other][0], rtol=1e-4, atol=1e-6)
+        for a, b in zip(res[0][1], res[other][1]):
+            torch.testing.assert_close(a, b, rtol=2e-3, atol=1e-4)
