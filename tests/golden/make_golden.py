@@ -15,6 +15,14 @@ Fixture matrix follows SURVEY.md 8(c):
   tgcn.npz       TGCN, N=50 E=300 F_in=8 hidden=16 T=6, B in {3,6}: per-step hidden states, loss,
                  every parameter gradient; plus a 2-epoch Adam loop (per-window loss, param checksums)
   naive_tgcn.npz NaiveGraph with 4 snapshots (+-10 % churn): per-t CSRs and a TGCN BPTT pass
+  gcn_n200.npz   the GCN matrix again on N = 200, E = 1500 with an isolated vertex, self-loops and a hub of in-degree 90
+                 (rows longer than a wave, rows spanning several index rounds), all widths, StaticGraph
+  gcn_cora.npz   the Cora-SHAPED graph of the benchmark (N = 2708, E = 10556, mirrored pairs, max degree 168), widths
+                 {7, 16, 64, 300} x {no-ew, ew}: inputs are re-drawn from the stored seeds (torch CPU generator); of the
+                 outputs the file keeps 296 rows in full (the 40 highest-degree rows + 256 sampled) and the fp64 column
+                 sums over ALL rows, which pin every row of a bit-exact result
+  gat_cora.npz   GATConv on the same graph, (H,D) in {(8,8),(8,64)}: A, S, grad_el, grad_er in full, out / grad_feat on
+                 the sampled rows + fp64 column sums
 """
 from __future__ import annotations
 
@@ -247,6 +255,155 @@ def gen_gat():
     save("gat.npz", d)
 
 
+# ------------------------------------------------------------- larger graphs (round 2)
+def cora_shaped(seed=0, n=2708, pairs=5278, max_deg=168):
+    """The benchmark's Cora-shaped generator (bench.py::cora_shaped, restated so that this script stands alone)."""
+    rng = np.random.default_rng(seed)
+    w = (np.arange(1, n + 1, dtype=np.float64)) ** -0.6
+    w = np.minimum(w / w.sum() * 2 * pairs, max_deg)
+    p = w / w.sum()
+    got = set()
+    while len(got) < pairs:
+        a = rng.choice(n, size=2 * pairs, p=p)
+        b = rng.choice(n, size=2 * pairs, p=p)
+        for u, v in zip(a, b):
+            if u != v and (min(u, v), max(u, v)) not in got and len(got) < pairs:
+                got.add((min(u, v), max(u, v)))
+    und = np.array(sorted(got), np.int32)
+    return np.concatenate([und[:, 0], und[:, 1]]), np.concatenate([und[:, 1], und[:, 0]])
+
+
+def sample_rows(deg, count=256, top=40, seed=0):
+    rng = np.random.default_rng(seed)
+    hubs = np.argsort(-deg, kind="stable")[:top]
+    rest = rng.choice(len(deg), size=min(count, len(deg)), replace=False)
+    return np.unique(np.concatenate([hubs, rest])).astype(np.int64)
+
+
+def gen_gcn_n200():
+    n, e = 200, 1500
+    rng = np.random.default_rng(21)
+    el = random_edges(rng, n, e, self_loops=True, hub=17, isolated=(3, 199))
+    for v in (0, 5, 50):
+        if (v, v) not in el:
+            el.append((v, v))                                 # explicit self-loops
+    hubs = [(u, 17) for u in range(20, 111) if (u, 17) not in el]
+    el += hubs[: max(0, 90 - sum(1 for _, t in el if t == 17))]
+    e = len(el)
+    given = np.array(el, np.int32)
+    d = dict(num_nodes=n, src=given[:, 0], dst=given[:, 1])
+    g = StaticGraph(list(el), [1.0] * e, n)
+    w_eid = torch.from_numpy(rng.uniform(0.5, 1.5, (e, 1)).astype(np.float32))
+    d["edge_weight_by_eid"] = w_eid
+    norm = norm_of(g)
+    g.set_ndata("norm", norm)
+    d["norm"] = norm
+    d["in_degrees"] = g.in_degrees()
+    for side, csr in (("fwd", g._forward_graph), ("bwd", g._backward_graph)):
+        for k, v in csr_arrays(csr, n, e).items():
+            d[f"{side}_{k}"] = v
+    for F in (1, 4, 7, 16, 32, 64, 100, 128, 256, 300):
+        for use_ew in (False, True):
+            torch.manual_seed(3000 + F)
+            conv = GCNConv(F, F, bias=False)
+            with torch.no_grad():
+                conv.weight.copy_(torch.eye(F))
+            x = torch.randn(n, F, requires_grad=True)
+            R = torch.randn(n, F)
+            out = conv(g, x, edge_weight=w_eid if use_ew else None)
+            (out * R).sum().backward()
+            tag = f"F{F}_{'ew' if use_ew else 'now'}"
+            d[tag + "_x"], d[tag + "_R"] = x.detach(), R
+            d[tag + "_out"], d[tag + "_grad_x"] = out.detach(), x.grad.detach()
+    save("gcn_n200.npz", d)
+
+
+def gen_gcn_cora():
+    src, dst = cora_shaped()
+    n, e = 2708, len(src)
+    el = [(int(a), int(b)) for a, b in zip(src, dst)]
+    g = StaticGraph(list(el), [1.0] * e, n)
+    rng = np.random.default_rng(22)
+    w_eid = torch.from_numpy(rng.uniform(0.5, 1.5, (e, 1)).astype(np.float32))
+    norm = norm_of(g)
+    g.set_ndata("norm", norm)
+    deg = np.asarray(g.in_degrees())
+    rows = sample_rows(deg)
+    d = dict(num_nodes=n, src=src, dst=dst, edge_weight_by_eid=w_eid, norm=norm, in_degrees=deg, rows=rows,
+             max_in_degree=int(deg.max()))
+    for side, csr in (("fwd", g._forward_graph), ("bwd", g._backward_graph)):
+        for k, v in csr_arrays(csr, n, e).items():
+            d[f"{side}_{k}"] = v
+    for F in (7, 16, 64, 300):
+        for use_ew in (False, True):
+            seed = 4000 + F
+            conv = GCNConv(F, F, bias=False)
+            with torch.no_grad():
+                conv.weight.copy_(torch.eye(F))
+            xr = np.random.default_rng(seed)                   # numpy's PCG64 + ziggurat: the same bits on every host, so
+            x = torch.from_numpy(xr.standard_normal((n, F), dtype=np.float32)).requires_grad_(True)   # the tests re-draw
+            R = torch.from_numpy(xr.standard_normal((n, F), dtype=np.float32))                        # x, R from the seed
+            out = conv(g, x, edge_weight=w_eid if use_ew else None)
+            (out * R).sum().backward()
+            tag = f"F{F}_{'ew' if use_ew else 'now'}"
+            d[tag + "_seed"] = seed
+            d[tag + "_x_rows"], d[tag + "_R_rows"] = x.detach()[rows], R[rows]   # spot check of the re-drawn inputs
+            d[tag + "_out_rows"], d[tag + "_grad_x_rows"] = out.detach()[rows], x.grad.detach()[rows]
+            d[tag + "_out_colsum"] = out.detach().double().sum(0)
+            d[tag + "_grad_x_colsum"] = x.grad.detach().double().sum(0)
+            d[tag + "_out_abs_colsum"] = out.detach().double().abs().sum(0)
+            d[tag + "_grad_x_abs_colsum"] = x.grad.detach().double().abs().sum(0)
+    save("gcn_cora.npz", d)
+
+
+def gen_gat_cora():
+    src, dst = cora_shaped()
+    n, e = 2708, len(src)
+    el = [(int(a), int(b)) for a, b in zip(src, dst)]
+    g = StaticGraph(list(el), [1.0] * e, n)
+    deg = np.asarray(g.in_degrees())
+    rows = sample_rows(deg)
+    d = dict(num_nodes=n, src=src, dst=dst, rows=rows, in_degrees=deg)
+    fin = 6
+    for (H, D) in ((8, 8), (8, 64)):
+        seed = 5000 + H * 100 + D
+        torch.manual_seed(seed)
+        conv = GATConv(fin, D, H)
+        xr = np.random.default_rng(seed)
+        # x in multiples of 1/8, fc weight in multiples of 1/32: every partial sum of feat = fc(x) is exact in fp32, so
+        # the tests recompute feat with any BLAS and get the reference's bits; R re-drawn from the seed (numpy)
+        x = torch.from_numpy((xr.integers(-8, 9, (n, fin)) / 8.0).astype(np.float32)).requires_grad_(True)
+        with torch.no_grad():
+            conv.fc.weight.copy_(torch.from_numpy((xr.integers(-16, 17, (H * D, fin)) / 32.0).astype(np.float32)))
+        R = torch.from_numpy(xr.standard_normal((n, H, D), dtype=np.float32))
+        with Capture() as cap:
+            out = conv(g, x)
+            (out * R).sum().backward()
+        tag = f"H{H}_D{D}"
+        f0, b0 = cap.fwd[0], cap.bwd[0]
+        d[tag + "_seed"] = seed
+        d[tag + "_k_el"], d[tag + "_k_er"] = f0["args"]["Velinb"], f0["args"]["Vercen"]
+        feat = f0["args"]["Vfeat_srcinb"]
+        d[tag + "_x"] = x.detach()
+        d[tag + "_fc_weight"] = conv.fc.weight.detach()
+        d[tag + "_R_rows"] = R[rows]
+        d[tag + "_k_feat_rows"] = feat[rows]
+        for k, t in f0["saved"].items():
+            if t.dim() == 3 and t.shape[-1] == 1 and t.shape[0] == e and not k.endswith("inb") and not k.endswith("cen"):
+                d[tag + "_k_A"] = t
+            if t.dim() == 3 and t.shape[-1] == 1 and t.shape[0] == n and not k.endswith("inb") and not k.endswith("cen"):
+                d[tag + "_k_S"] = t
+        d[tag + "_out_rows"] = out.detach()[rows]
+        d[tag + "_out_colsum"] = out.detach().double().sum(0)
+        d[tag + "_k_grad_el"], d[tag + "_k_grad_er"] = b0["grads"]["Velinb"], b0["grads"]["Vercen"]
+        gf = b0["grads"]["Vfeat_srcinb"]
+        d[tag + "_k_grad_feat_rows"] = gf[rows]
+        d[tag + "_k_grad_feat_colsum"] = gf.double().sum(0)
+        d[tag + "_grad_attn_l"], d[tag + "_grad_attn_r"] = conv.attn_l.grad.detach(), conv.attn_r.grad.detach()
+        d[tag + "_attn_l"], d[tag + "_attn_r"] = conv.attn_l.detach(), conv.attn_r.detach()
+    save("gat_cora.npz", d)
+
+
 # ----------------------------------------------------------------------------- TGCN
 class RefTGCNModel(torch.nn.Module):
     """Model of tests/scripts/v1_1_0/temporal_tgcn_dataloaders (TGCN + ReLU + Linear head)."""
@@ -380,9 +537,9 @@ def gen_naive_tgcn():
 
 
 if __name__ == "__main__":
-    gen_csr()
-    gen_gcn()
-    gen_gat()
-    gen_tgcn()
-    gen_naive_tgcn()
+    only = set(sys.argv[1:])
+    for name, fn in (("csr", gen_csr), ("gcn", gen_gcn), ("gat", gen_gat), ("tgcn", gen_tgcn), ("naive_tgcn", gen_naive_tgcn),
+                     ("gcn_n200", gen_gcn_n200), ("gcn_cora", gen_gcn_cora), ("gat_cora", gen_gat_cora)):
+        if not only or name in only:
+            fn()
     print("emitted CUDA translation units compiled through the SIMT header:", len(rh.EMITTED_SOURCES))

@@ -149,3 +149,36 @@ def test_full_size_properties(cuda):
     a, b = gel.double().sum(0).view(-1), ger.double().sum(0).view(-1)
     assert torch.allclose(a, b, rtol=1e-6, atol=1e-3)
     assert bool(torch.isfinite(gel).all()) and bool(torch.isfinite(ger).all())
+
+
+@pytest.mark.parametrize("H,D", [(8, 8), (8, 64)])
+def test_golden_cora_shaped(cuda, H, D):
+    """Reference-generated vectors on the benchmark's Cora-shaped graph (hub of in-degree 159): A, S in full, out and
+    grad_feat on the sampled rows + fp64 column sums (bit-exact), grad_el / grad_er within 1e-4 (reference: atomics)."""
+    from stgraph_amd import kernels
+    d = golden("gat_cora.npz")
+    n = int(d["num_nodes"])
+    g = kernels.build_graph_csr(d["src"], d["dst"], n, cuda)
+    tag, rows = f"H{H}_D{D}", d["rows"]
+    feat = (d[tag + "_x"].astype(np.float64) @ d[tag + "_fc_weight"].astype(np.float64).T).astype(np.float32).reshape(n, H, D)
+    assert np.array_equal(feat[rows], d[tag + "_k_feat_rows"])
+    rng = np.random.default_rng(int(d[tag + "_seed"]))
+    rng.integers(-8, 9, (n, 6)), rng.integers(-16, 17, (H * D, 6))
+    R = rng.standard_normal((n, H, D), dtype=np.float32)
+    el, er = _t(d[tag + "_k_el"], cuda), _t(d[tag + "_k_er"], cuda)
+    out, A, S = kernels.gat_fwd(el, er, _t(feat, cuda), g.fwd, 0.2)
+    for factored in (True, False):
+        kernels.set_gat_factored_backward(factored)
+        try:
+            gf, gel, ger = kernels.gat_bwd(A, S, out, _t(R, cuda), el, er, _t(feat, cuda), g.fwd, g.bwd, 0.2)
+        finally:
+            kernels.set_gat_factored_backward(True)
+        gf = gf.cpu().numpy()
+        assert np.array_equal(gf[rows], d[tag + "_k_grad_feat_rows"])          # grad_feat: the reference's sums, both forms
+        assert np.array_equal(gf.astype(np.float64).sum(0), d[tag + "_k_grad_feat_colsum"])
+        np.testing.assert_allclose(gel.cpu().numpy(), d[tag + "_k_grad_el"], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(ger.cpu().numpy(), d[tag + "_k_grad_er"], rtol=TOL, atol=TOL)
+    assert np.array_equal(A.cpu().numpy(), d[tag + "_k_A"]) and np.array_equal(S.cpu().numpy(), d[tag + "_k_S"])
+    o = out.cpu().numpy()
+    assert np.array_equal(o[rows], d[tag + "_out_rows"])
+    assert np.array_equal(o.astype(np.float64).sum(0), d[tag + "_out_colsum"])

@@ -232,3 +232,52 @@ def test_full_size_properties(cuda):
         for c in col[ro[r]:ro[r + 1]]:
             acc = acc + nn_[c] * xn[c]
         assert np.array_equal(acc * nn_[r], Axn[i])
+
+
+@pytest.mark.parametrize("compat", [True, False])
+def test_golden_n200_hub_selfloops_isolated(cuda, compat):
+    """Reference-generated vectors on N = 200 with a hub of in-degree >= 90, self-loops, isolated vertices, all widths."""
+    from stgraph_amd import kernels
+    d = golden("gcn_n200.npz")
+    n = int(d["num_nodes"])
+    g = _dev_graph(d["src"], d["dst"], n, cuda)
+    og = orc.build_graph(d["src"], d["dst"], n)
+    norm = torch.from_numpy(d["norm"]).to(cuda)
+    for F in GCN_WIDTHS:
+        fa_ref = kernels.ref_active_columns(F)
+        fa = fa_ref if compat else F
+        for use_ew in (False, True):
+            tag = f"F{F}_{'ew' if use_ew else 'now'}"
+            ew = torch.from_numpy(d["edge_weight_by_eid"]).to(cuda) if use_ew else None
+            out = kernels.gcn_agg(torch.from_numpy(d[tag + "_x"]).to(cuda), norm, norm, g.fwd, ew=ew, f_active=fa).cpu().numpy()
+            gx = kernels.gcn_agg(torch.from_numpy(d[tag + "_R"]).to(cuda), norm, norm, g.bwd, ew=ew, f_active=fa).cpu().numpy()
+            assert np.array_equal(out[:, :fa_ref], d[tag + "_out"][:, :fa_ref]), tag
+            assert np.array_equal(gx[:, :fa_ref], d[tag + "_grad_x"][:, :fa_ref]), tag
+            if compat:
+                assert np.array_equal(out, d[tag + "_out"]) and np.array_equal(gx, d[tag + "_grad_x"]), tag
+            else:
+                w = d["edge_weight_by_eid"] if use_ew else None
+                assert np.array_equal(out, orc.gcn_agg(d[tag + "_x"], d["norm"], d["norm"], og.fwd, ew=w)), tag
+
+
+def test_golden_cora_shaped(cuda):
+    """Reference-generated vectors on the benchmark's Cora-shaped graph (N = 2708, E = 10556, hub of in-degree 159):
+    sampled rows in full and the fp64 column sums over all rows."""
+    from stgraph_amd import kernels
+    d = golden("gcn_cora.npz")
+    n = int(d["num_nodes"])
+    g = _dev_graph(d["src"], d["dst"], n, cuda)
+    norm, rows = torch.from_numpy(d["norm"]).to(cuda), d["rows"]
+    for F in (7, 16, 64, 300):
+        fa = kernels.ref_active_columns(F)
+        for use_ew in (False, True):
+            tag = f"F{F}_{'ew' if use_ew else 'now'}"
+            rng = np.random.default_rng(int(d[tag + "_seed"]))
+            x = rng.standard_normal((n, F), dtype=np.float32)
+            R = rng.standard_normal((n, F), dtype=np.float32)
+            ew = torch.from_numpy(d["edge_weight_by_eid"]).to(cuda) if use_ew else None
+            out = kernels.gcn_agg(torch.from_numpy(x).to(cuda), norm, norm, g.fwd, ew=ew, f_active=fa).cpu().numpy()
+            gx = kernels.gcn_agg(torch.from_numpy(R).to(cuda), norm, norm, g.bwd, ew=ew, f_active=fa).cpu().numpy()
+            assert np.array_equal(out[rows], d[tag + "_out_rows"]) and np.array_equal(gx[rows], d[tag + "_grad_x_rows"]), tag
+            assert np.array_equal(out.astype(np.float64).sum(0), d[tag + "_out_colsum"]), tag
+            assert np.array_equal(gx.astype(np.float64).sum(0), d[tag + "_grad_x_colsum"]), tag

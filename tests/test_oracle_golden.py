@@ -81,3 +81,80 @@ def test_gat_golden(H, D):
     # reference defect D2: attention is uniform, S equals the in-degree
     assert np.array_equal(S[:, 0, 0], g.in_degrees().astype(np.float32))
     assert S[7].sum() == 0 and not out[7].any()          # the in-degree-0 vertex
+
+
+# ------------------------------------------------------------------- larger reference-generated graphs (round 2)
+def cora_inputs(d, tag, n, shape_tail):
+    """x, R of a gcn_cora / gat_cora case re-drawn from the stored seed (numpy PCG64: the same bits on every host)."""
+    rng = np.random.default_rng(int(d[tag + "_seed"]))
+    return rng, rng.standard_normal((n,) + shape_tail, dtype=np.float32), None
+
+
+def test_gcn_golden_n200_hub_selfloops_isolated():
+    """N = 200 with a hub of in-degree >= 90 (a row longer than a wave), self-loops and isolated vertices, all widths."""
+    d = golden("gcn_n200.npz")
+    n = int(d["num_nodes"])
+    g = orc.build_graph(d["src"], d["dst"], n)
+    assert int(d["in_degrees"].max()) >= 90 and (d["in_degrees"] == 0).sum() >= 2 and (d["src"] == d["dst"]).sum() >= 3
+    for side, c in (("fwd", g.fwd), ("bwd", g.bwd)):
+        for k in CSR_KEYS:
+            assert np.array_equal(getattr(c, k), d[f"{side}_{k}"])
+    norm = d["norm"]
+    for F in GCN_WIDTHS:
+        fa = orc.ref_active_columns(F)
+        for use_ew in (False, True):
+            tag = f"F{F}_{'ew' if use_ew else 'now'}"
+            w = d["edge_weight_by_eid"] if use_ew else None
+            assert np.array_equal(orc.gcn_agg(d[tag + "_x"], norm, norm, g.fwd, ew=w, f_active=fa), d[tag + "_out"]), tag
+            assert np.array_equal(orc.gcn_agg(d[tag + "_R"], norm, norm, g.bwd, ew=w, f_active=fa), d[tag + "_grad_x"]), tag
+
+
+def test_gcn_golden_cora_shaped():
+    """The benchmark's Cora-shaped graph (N = 2708, E = 10556, max in-degree 168): sampled rows in full + fp64 column
+    sums over all rows (a bit-exact result reproduces them exactly)."""
+    d = golden("gcn_cora.npz")
+    n = int(d["num_nodes"])
+    g = orc.build_graph(d["src"], d["dst"], n)
+    assert int(d["max_in_degree"]) >= 150                 # the hub (expected degree capped at 168: 159 drawn)
+    for side, c in (("fwd", g.fwd), ("bwd", g.bwd)):
+        for k in CSR_KEYS:
+            assert np.array_equal(getattr(c, k), d[f"{side}_{k}"])
+    norm, rows = d["norm"], d["rows"]
+    for F in (7, 16, 64, 300):
+        fa = orc.ref_active_columns(F)
+        for use_ew in (False, True):
+            tag = f"F{F}_{'ew' if use_ew else 'now'}"
+            rng = np.random.default_rng(int(d[tag + "_seed"]))
+            x = rng.standard_normal((n, F), dtype=np.float32)
+            R = rng.standard_normal((n, F), dtype=np.float32)
+            assert np.array_equal(x[rows], d[tag + "_x_rows"]) and np.array_equal(R[rows], d[tag + "_R_rows"])
+            w = d["edge_weight_by_eid"] if use_ew else None
+            out = orc.gcn_agg(x, norm, norm, g.fwd, ew=w, f_active=fa)
+            gx = orc.gcn_agg(R, norm, norm, g.bwd, ew=w, f_active=fa)
+            assert np.array_equal(out[rows], d[tag + "_out_rows"]) and np.array_equal(gx[rows], d[tag + "_grad_x_rows"]), tag
+            assert np.array_equal(out.astype(np.float64).sum(0), d[tag + "_out_colsum"]), tag
+            assert np.array_equal(gx.astype(np.float64).sum(0), d[tag + "_grad_x_colsum"]), tag
+
+
+@pytest.mark.parametrize("H,D", [(8, 8), (8, 64)])
+def test_gat_golden_cora_shaped(H, D):
+    d = golden("gat_cora.npz")
+    n = int(d["num_nodes"])
+    g = orc.build_graph(d["src"], d["dst"], n)
+    tag, rows = f"H{H}_D{D}", d["rows"]
+    feat = (d[tag + "_x"].astype(np.float64) @ d[tag + "_fc_weight"].astype(np.float64).T).astype(np.float32).reshape(n, H, D)
+    assert np.array_equal(feat[rows], d[tag + "_k_feat_rows"])        # exact by construction (dyadic inputs)
+    rng = np.random.default_rng(int(d[tag + "_seed"]))
+    rng.integers(-8, 9, (n, 6)), rng.integers(-16, 17, (H * D, 6))     # the generator's draws before R
+    R = rng.standard_normal((n, H, D), dtype=np.float32)
+    assert np.array_equal(R[rows], d[tag + "_R_rows"])
+    el, er = d[tag + "_k_el"], d[tag + "_k_er"]
+    A, S = orc.gat_k0(el, er, g.fwd, g.num_edges)
+    out = orc.gat_k1(A, S, feat, g.fwd)
+    gf, gel, ger = orc.gat_bwd(A, S, out, R, el, er, feat, g.bwd)
+    assert np.array_equal(A, d[tag + "_k_A"]) and np.array_equal(S, d[tag + "_k_S"])
+    assert np.array_equal(out[rows], d[tag + "_out_rows"])
+    assert np.array_equal(out.astype(np.float64).sum(0), d[tag + "_out_colsum"])
+    assert np.array_equal(gf[rows], d[tag + "_k_grad_feat_rows"])
+    assert np.array_equal(gf.astype(np.float64).sum(0), d[tag + "_k_grad_feat_colsum"])
+    assert np.array_equal(gel, d[tag + "_k_grad_el"]) and np.array_equal(ger, d[tag + "_k_grad_er"])
