@@ -500,6 +500,24 @@ int    stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *args, void *stream);
 int    stg_tgcn_window_loss(const float *partials, int32_t steps, int64_t N, int64_t step_stride, float *step_loss,
                             float *cost, void *stream);
 
+/* cost[0] = sum over `steps` rows of `partials` (count values each, rows step_stride floats apart), in order, of
+ * (row sum, fixed order) * inv_n; step_loss [steps] (NULL: not wanted) gets the terms.  The general form of
+ * stg_tgcn_window_loss: the dynamic-temporal loop's `cost += BCEWithLogitsLoss()(...)` over a window. */
+int    stg_partial_sums_loss(const float *partials, int32_t steps, int32_t count, int64_t step_stride, float inv_n,
+                             float *step_loss, float *cost, void *stream);
+/* The link-prediction decoder and loss of benchmarking/dynamic-temporal-tgcn/seastar/model.py:19-21 + train loop on their
+ * own (stg_link_head_fwd / _bwd also run the relu -> Linear half, which the one-launch step does itself):
+ *   fwd: logits[e] = <y[src_e], y[dst_e]>, edge_index int64 [2, M] (sources then destinations);
+ *        partial[(M + 31) / 32] = per-workgroup sums of the stable BCE-with-logits terms;
+ *   bwd: dy [N, F] = sum over the label edges incident to each node, in the order of the incidence list
+ *        (row_ptr [N + 1], other, eid: see stg_link_head_bwd), of (sigmoid(logit) - target) * g_loss / M * y[other].
+ * F = 32. */
+int    stg_link_decode_fwd(const float *y, const int64_t *edge_index, const float *target, float *logits, float *partial,
+                           int64_t M, int32_t F, void *stream);
+int    stg_link_decode_bwd(const float *g_loss, const float *y, const float *logits, const float *target,
+                           const int32_t *row_ptr, const int32_t *other, const int32_t *eid, float *dy, int64_t N, int64_t M,
+                           int32_t F, void *stream);
+
 /* ----------------------------------------------- dense neighbour: softmax cross-entropy
  * `nn.CrossEntropyLoss()(logits, labels)` of the GCN training scripts (benchmarking/gcn/seastar/train.py:63-101),
  * mean over the n rows, one launch each way (+ a one-workgroup finish): see csrc/xent.hip.

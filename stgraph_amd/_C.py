@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
     "stg_tgcn_step_supported", "stg_tgcn_step_loss_partials", "stg_tgcn_step_fwd", "stg_tgcn_step_bwd",
-    "stg_tgcn_window_loss",
+    "stg_tgcn_window_loss", "stg_partial_sums_loss", "stg_link_decode_fwd", "stg_link_decode_bwd",
 )
 
 
@@ -238,6 +238,12 @@ def _load() -> ctypes.CDLL:
     lib.stg_tgcn_step_bwd.argtypes = [ctypes.POINTER(TgcnStepBwdArgs), vp]
     lib.stg_tgcn_window_loss.restype = ctypes.c_int
     lib.stg_tgcn_window_loss.argtypes = [vp, i32, i64, i64, vp, vp, vp]
+    lib.stg_partial_sums_loss.restype = ctypes.c_int
+    lib.stg_partial_sums_loss.argtypes = [vp, i32, i32, i64, f32, vp, vp, vp]
+    lib.stg_link_decode_fwd.restype = ctypes.c_int
+    lib.stg_link_decode_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
+    lib.stg_link_decode_bwd.restype = ctypes.c_int
+    lib.stg_link_decode_bwd.argtypes = [vp] * 8 + [i64, i64, i32, vp]
     if lib.stg_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.stg_abi_version()} != expected {ABI_VERSION}; rebuild")
     return lib

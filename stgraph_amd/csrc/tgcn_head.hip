@@ -624,3 +624,32 @@ extern "C" int stg_link_head_bwd(const float *g_loss, const float *g_y, const fl
 #undef STG_LINK_BWD
     return check_launch("stg_link_head_bwd");
 }
+
+// The decoder + loss and its node-side backward on their own (the relu -> Linear half of the link head runs inside the
+// one-launch TGCN step, csrc/tgcn_step.hpp, when a whole window is one autograd node).
+extern "C" int stg_link_decode_fwd(const float *y, const int64_t *edge_index, const float *target, float *logits,
+                                   float *partial, int64_t M, int32_t F, void *stream_)
+{
+    using namespace stg;
+    if (F != kHeadF) return fail(STG_ERR_UNSUPPORTED, "stg_link_decode_fwd: F=%d not supported (32)", F);
+    if (M <= 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_decode_fwd: bad M");
+    if (!y || !edge_index || !target || !logits || !partial) return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_decode_fwd: NULL pointer argument");
+    const int eblocks = (int)((M + 31) / 32);
+    hipLaunchKernelGGL(link_decode_bce_kernel, dim3(eblocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream_), y, edge_index,
+                       edge_index + M, target, logits, partial, M);
+    return check_launch("stg_link_decode_fwd");
+}
+
+extern "C" int stg_link_decode_bwd(const float *g_loss, const float *y, const float *logits, const float *target,
+                                   const int32_t *row_ptr, const int32_t *other, const int32_t *eid, float *dy, int64_t N,
+                                   int64_t M, int32_t F, void *stream_)
+{
+    using namespace stg;
+    if (F != kHeadF) return fail(STG_ERR_UNSUPPORTED, "stg_link_decode_bwd: F=%d not supported (32)", F);
+    if (N <= 0 || M <= 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_decode_bwd: bad N / M");
+    if (!g_loss || !y || !logits || !target || !row_ptr || !other || !eid || !dy)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_link_decode_bwd: NULL pointer argument");
+    hipLaunchKernelGGL(link_bwd_nodes_kernel, dim3((unsigned)((N + 31) / 32)), dim3(kBlock), 0, static_cast<hipStream_t>(stream_),
+                       g_loss, nullptr, y, logits, target, row_ptr, other, eid, dy, N, 1.0f / (float)M);
+    return check_launch("stg_link_decode_bwd");
+}

@@ -345,3 +345,16 @@ extern "C" int stg_tgcn_window_loss(const float *partials, int32_t steps, int64_
                        (int)stg_tgcn_step_loss_partials(N), step_stride, 1.0f / (float)N, step_loss, cost);
     return check_launch("stg_tgcn_window_loss");
 }
+
+extern "C" int stg_partial_sums_loss(const float *partials, int32_t steps, int32_t count, int64_t step_stride, float inv_n,
+                                     float *step_loss, float *cost, void *stream)
+{
+    using namespace stg;
+    if (steps <= 0 || count <= 0 || step_stride < count)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_partial_sums_loss: bad shape steps=%d count=%d stride=%lld", steps, count,
+                    (long long)step_stride);
+    if (!partials || !cost) return fail(STG_ERR_INVALID_ARGUMENT, "stg_partial_sums_loss: NULL pointer argument");
+    hipLaunchKernelGGL(window_loss_kernel, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream), partials, steps, count,
+                       step_stride, inv_n, step_loss, cost);
+    return check_launch("stg_partial_sums_loss");
+}

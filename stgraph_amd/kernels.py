@@ -1089,6 +1089,37 @@ def tgcn_window_loss(partials: torch.Tensor, steps: int, N: int, step_loss: torc
     return cost
 
 
+def partial_sums_loss(partials: torch.Tensor, steps: int, count: int, inv_n: float,
+                      step_loss: torch.Tensor | None = None) -> torch.Tensor:
+    """cost [1] = sum over the first ``steps`` rows of ``partials`` of (sum of the row's first ``count`` values) * inv_n."""
+    dev = partials.device
+    cost = torch.empty(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _C.check(_C.lib.stg_partial_sums_loss(_ptr(partials), int(steps), int(count), int(partials.stride(0)), float(inv_n),
+                                              _ptr(step_loss), _ptr(cost), _stream_ptr(dev)))
+    return cost
+
+
+def link_decode_fwd(y: torch.Tensor, edge_index: torch.Tensor, target: torch.Tensor, logits: torch.Tensor,
+                    partial: torch.Tensor) -> None:
+    """logits[e] = <y[src_e], y[dst_e]> and the per-workgroup sums of the BCE-with-logits terms (stg_link_decode_fwd)."""
+    M = int(edge_index.shape[1])
+    with torch.cuda.device(y.device):
+        _C.check(_C.lib.stg_link_decode_fwd(_ptr(y), _ptr(edge_index), _ptr(target), _ptr(logits), _ptr(partial), M,
+                                            int(y.shape[1]), _stream_ptr(y.device)))
+
+
+def link_decode_bwd(g_loss: torch.Tensor, y: torch.Tensor, logits: torch.Tensor, target: torch.Tensor, incidence,
+                    dy: torch.Tensor) -> None:
+    """dy [N, F]: gradient of the mean BCE loss with respect to y, per node over its incident label edges
+    (stg_link_decode_bwd; ``incidence`` from ``link_incidence``)."""
+    row_ptr, other, eid = incidence
+    with torch.cuda.device(y.device):
+        _C.check(_C.lib.stg_link_decode_bwd(_ptr(g_loss), _ptr(y), _ptr(logits), _ptr(target), _ptr(row_ptr), _ptr(other),
+                                            _ptr(eid), _ptr(dy), int(y.shape[0]), int(logits.shape[0]), int(y.shape[1]),
+                                            _stream_ptr(y.device)))
+
+
 def tgcn_head_supported(C: int, F: int, O: int) -> bool:
     return bool(_C.lib.stg_tgcn_head_supported(int(C), int(F), int(O)))
 

@@ -164,7 +164,7 @@ def window_cost_usable(model, graph, x0, edge_weight, targets) -> bool:
     from . import kernels
     from .graph.dynamic.dynamic_graph import DynamicGraph
     from .nn.pytorch.static.gcn_conv import GCNConv
-    if not (_FUSED_WINDOW and isinstance(model, STGraphTGCN) and type(model.temporal) is TGCN):
+    if not (_FUSED_WINDOW and _FUSED_HEAD and isinstance(model, STGraphTGCN) and type(model.temporal) is TGCN):
         return False
     tg = model.temporal
     convs = (tg.conv_z, tg.conv_r, tg.conv_h)
@@ -417,6 +417,131 @@ class DynamicSTGraphTGCN(torch.nn.Module):
         return (loss if not torch.is_tensor(cost) else cost + loss), y, h
 
 
+class _TGCNDynWindow(torch.autograd.Function):
+    """cost = sum_t BCEWithLogitsLoss()(decode(y_t, edges_t), targets_t) over the snapshots of one BPTT window of the
+    dynamic-temporal loop (benchmarking/dynamic-temporal-tgcn/seastar/train.py:179-231 with model.py:5-21): every
+    snapshot has its OWN graph (``steps[t]``: forward / backward CSR, norm), un-weighted GCN gates, link-prediction
+    head.  One step launch each way per snapshot plus the decoder; the input gradient of snapshot t + 1 is aggregated
+    over ITS backward CSR by snapshot t's backward launch."""
+
+    @staticmethod
+    def forward(ctx, x0, steps, use_nid, lo, hi, Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1):
+        from . import kernels
+        dev = x0.device
+        B, N = len(steps), int(x0.shape[0])
+        C, Fin, Fh = int(Wz.shape[0]), int(x0.shape[1]), int(W1.shape[0])
+        x0 = x0.contiguous()
+        Wcat = torch.cat([Wcz, Wcr, Wch], dim=1)
+        WcatT = Wcat.t().contiguous()
+        b3 = torch.cat([bcz, bcr, bch], dim=0)
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        P, X3 = new(B, N, Fin), new(B, N, 3 * C)
+        Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
+        Y = new(B, N, Fh)
+        mask = torch.empty(B, N, 12, dtype=torch.int32, device=dev)
+        M = int(steps[0]["edges"].shape[1])
+        if any(int(st["edges"].shape[1]) != M for st in steps):
+            raise ValueError("all snapshots of a window must carry the same number of label edges")
+        nparts = (M + 31) // 32
+        logits, partial = new(B, M), new(B, nparts)
+        Wz_, bz_, Wr_, br_, Wh_, bh_, W1_, b1_ = (t.contiguous() for t in (Wz, bz, Wr, br, Wh, bh, W1, b1))
+        with torch.cuda.device(dev):
+            for st in steps:
+                st["nc_f"] = kernels._edge_gathered(st["fwd"], "norm", st["norm"], st["fwd"].column_indices)
+                st["normv"] = st["norm"].reshape(-1)
+        for t, st in enumerate(steps):
+            f = st["fwd"]
+            kernels.tgcn_step_fwd(N, C, Fin, Fh, 1, lo, hi, dev, row_offsets=f.row_offset, column_indices=f.column_indices,
+                                  node_ids=f.node_ids_if_ready if use_nid else None, norm_col_edge=st["nc_f"], ew_edge=None,
+                                  norm=st["normv"], x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1],
+                                  WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
+                                  P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t], clamp_mask=mask[t])
+            kernels.link_decode_fwd(Y[t], st["edges"], st["targets"], logits[t], partial[t])
+        cost = kernels.partial_sums_loss(partial, B, nparts, 1.0 / M)
+        ctx.save_for_backward(x0, Wcat, Wz_, Wr_, Wh_, W1_, P, X3, Z, R, Ht, Hn, HR, Y, mask, logits)
+        ctx.steps, ctx.use_nid, ctx.clamp = steps, use_nid, (float(lo), float(hi))
+        return cost.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_cost):
+        from . import kernels
+        x0, Wcat, Wz, Wr, Wh, W1, P, X3, Z, R, Ht, Hn, HR, Y, mask, logits = ctx.saved_tensors
+        steps, lo, hi = ctx.steps, *ctx.clamp
+        dev = x0.device
+        B, N, C = Z.shape
+        Fin, Fh = int(x0.shape[1]), int(Y.shape[2])
+        g = g_cost.reshape(1).contiguous().float()
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), new(B, N, 3 * C)
+        dyt = new(B, N, Fh)
+        dH, zbuf, dy = new(2, N, C), new(2, N, Fin), new(N, Fh)
+        WzT, WrT, WhT, W1T = (w.t().contiguous() for w in (Wz, Wr, Wh, W1))
+        want_dx0 = ctx.needs_input_grad[0]
+        with torch.cuda.device(dev):
+            for st in steps:
+                st["nc_b"] = kernels._edge_gathered(st["bwd"], "norm", st["norm"], st["bwd"].column_indices)
+        for t in range(B - 1, -1, -1):
+            st, last = steps[t], t == B - 1
+            nxt = None if last else steps[t + 1]                 # the gather of z_{t+1} runs over snapshot t + 1's backward CSR
+            kernels.link_decode_bwd(g, Y[t], logits[t], st["targets"], st["incidence"], dy)
+            kw = {}
+            if nxt is not None:
+                b = nxt["bwd"]
+                kw = dict(row_offsets=b.row_offset, column_indices=b.column_indices,
+                          node_ids=b.node_ids_if_ready if ctx.use_nid else None, norm_col_edge=nxt["nc_b"], ew_edge=None,
+                          norm=nxt["normv"], zn=zbuf[(t + 1) & 1], dHn=dH[(t + 1) & 1])
+            kernels.tgcn_step_bwd(N, C, Fin, Fh, 1, lo, hi, dev, g_y=dy, Z=Z[t], R=R[t], Ht=Ht[t],
+                                  H=None if t == 0 else Hn[t - 1], Hn=Hn[t], clamp_mask=mask[t], WzT=WzT, WrT=WrT, WhT=WhT,
+                                  Wcat=Wcat, W1T=W1T, dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=da3[t], dH=dH[t & 1],
+                                  z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], **kw)
+        dx0 = None
+        if want_dx0:
+            s0 = steps[0]
+            dx0 = kernels.gcn_agg(zbuf[0], s0["norm"], s0["norm"], s0["bwd"], use_node_ids=ctx.use_nid)
+        rng = range(B)
+        Hprev = [_zeros(N, C, dev)] + [Hn[t] for t in range(B - 1)]
+        gate = lambda d, k, second: kernels.gemm_tn_form(  # noqa: E731
+            [d[t] for t in rng], [X3[t][:, k * C:(k + 1) * C] for t in rng], C, 2 * C, B2s=second, nsplit=C,
+            b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True)
+        dWz, dbz = gate(dzl, 0, Hprev)
+        dWr, dbr = gate(drl, 1, Hprev)
+        dWh, dbh = gate(dhl, 2, [HR[t] for t in rng])
+        dWcT, db3 = kernels.gemm_tn_form([da3[t] for t in rng], [P[t] for t in rng], 3 * C, Fin, colsum=True)
+        dW1, db1 = kernels.gemm_tn_form([dyt[t] for t in rng], [Hn[t] for t in rng], Fh, C, b_op=kernels.GEMM_B_RELU,
+                                        colsum=True)
+        conv_w = [dWcT[k * C:(k + 1) * C].t() for k in range(3)]
+        conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
+        ctx.steps = None
+        return (dx0, None, None, None, None, *conv_w, *conv_b, dWz, dbz, dWr, dbr, dWh, dbh, dW1, db1)
+
+
+def dyn_window_usable(model, graph, x0) -> bool:
+    from . import kernels
+    from .nn.pytorch.static.gcn_conv import GCNConv
+    if not (_FUSED_WINDOW and _FUSED_HEAD and isinstance(model, DynamicSTGraphTGCN) and type(model.temporal) is TGCN):
+        return False
+    tg = model.temporal
+    convs = (tg.conv_z, tg.conv_r, tg.conv_h)
+    return (x0.is_cuda and x0.dtype == torch.float32 and x0.dim() == 2 and hasattr(graph, "csr")
+            and not kernels.reference_compat() and kernels._EDGE_CACHE
+            and all(type(c) is GCNConv and c.bias is not None and c.activation is None for c in convs)
+            and model.linear.bias is not None
+            and kernels.tgcn_step_supported(tg.out_channels, tg.in_channels, model.linear.out_features)
+            and model.linear.out_features == tg.in_channels and x0.shape[0] * 3 * tg.out_channels < (1 << 30))
+
+
+def dyn_window_cost(model, graph, x0, steps) -> torch.Tensor:
+    """``sum_t BCEWithLogitsLoss()(decode(y_t), targets_t)`` over ``steps`` (dicts with fwd, bwd, norm, edges, targets,
+    incidence: one per snapshot, collected while the loop moved the graph forward)."""
+    from . import kernels
+    tg = model.temporal
+    return _TGCNDynWindow.apply(
+        x0, steps, kernels.rows_by_node_ids(graph.graph_type()), -1e6, 1e6,
+        tg.conv_z.weight, tg.conv_r.weight, tg.conv_h.weight, tg.conv_z.bias, tg.conv_r.bias, tg.conv_h.bias,
+        tg.linear_z.weight, tg.linear_z.bias, tg.linear_r.weight, tg.linear_r.bias, tg.linear_h.weight, tg.linear_h.bias,
+        model.linear.weight, model.linear.bias)
+
+
 def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_every: int, optimizer,
                         bucket: GradBucket, feat_size: int, epoch: int = 0, rank: int = 0, world: int = 1,
                         group=None, seed: int = 0, norm_fn=None, timed_comm: bool = False):
@@ -440,6 +565,13 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
             hidden = None
             y_hat = window_input(n, feat_size, epoch, w, dev, seed)
             graph.get_graph(w * backprop_every)
+            ts = range(w * backprop_every, min((w + 1) * backprop_every, total - 1))
+            fused = dyn_window_usable(model, graph, y_hat) and len(ts) > 0 and all(
+                pos_neg_edges[t].dtype == torch.int64 and pos_neg_edges[t].is_contiguous() and pos_neg_edges[t].dim() == 2
+                and pos_neg_edges[t].shape == pos_neg_edges[ts[0]].shape and pos_neg_edges[t].shape[1] > 0
+                and pos_neg_targets[t].dtype == torch.float32 and pos_neg_targets[t].is_contiguous()
+                and pos_neg_targets[t].numel() == pos_neg_edges[t].shape[1] for t in ts)
+            steps = []
             for k in range(backprop_every):
                 t = w * backprop_every + k
                 if t >= total - 1:
@@ -447,7 +579,14 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
                 graph.get_graph(t)
                 if graph.get_ndata("norm") is None:
                     graph.set_ndata("norm", norm_fn(graph))
-                cost, y_hat, hidden = model.step_loss(graph, y_hat, None, hidden, pos_neg_edges[t], pos_neg_targets[t], cost)
+                if fused:                                   # one autograd node for the window: collect the snapshots
+                    steps.append(dict(fwd=graph.csr("fwd"), bwd=graph.csr("bwd"), norm=graph.get_ndata("norm"),
+                                      edges=pos_neg_edges[t], targets=pos_neg_targets[t],
+                                      incidence=SF._incidence_of(pos_neg_edges[t], n)))
+                else:
+                    cost, y_hat, hidden = model.step_loss(graph, y_hat, None, hidden, pos_neg_edges[t], pos_neg_targets[t], cost)
+            if fused and steps:
+                cost = dyn_window_cost(model, graph, y_hat, steps)
             if not isinstance(cost, int):
                 cost = cost / (backprop_every + 1)
                 cost.backward()

@@ -152,3 +152,49 @@ def test_captured_optimizer_tail_matches_the_eager_tail(cuda):
         torch.testing.assert_close(res[0][0], res[other][0], rtol=1e-4, atol=1e-6)
         for a, b in zip(res[0][1], res[other][1]):
             torch.testing.assert_close(a, b, rtol=2e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["naive_resident", "naive_rebuild", "pcsr", "gpma"])
+def test_dynamic_window_matches_the_per_snapshot_loop(cuda, kind):
+    """temporal.dyn_window_cost (one autograd node per window of the dynamic-temporal loop, every snapshot its own
+    graph) == the per-snapshot loop, on every dynamic graph class: losses and parameters after two epochs of SGD."""
+    import numpy as np
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import GPMAGraph, NaiveGraph, PCSRGraph
+    n, e0, churn, T, B, feat, hid, m = 4000, 30000, 800, 10, 4, 32, 64, 1500
+    rng = np.random.default_rng(7)
+    stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
+    out = []
+    for fused in (True, False):
+        temporal.set_fused_window(fused)
+        try:
+            snaps, pn_edges, pn_targets = [], [], []
+            gen = torch.Generator(device=cuda).manual_seed(4)
+            for t in range(T):
+                keys = stream[t * churn: t * churn + e0]
+                s, d = (keys // n).astype(np.int32), (keys % n).astype(np.int32)
+                snaps.append((torch.from_numpy(s).to(cuda), torch.from_numpy(d).to(cuda)))
+                pos = torch.from_numpy(np.stack([s[:m], d[:m]]).astype(np.int64)).to(cuda)
+                neg = torch.randint(0, n, (2, m), device=cuda, generator=gen)
+                pn_edges.append(torch.cat([pos, neg], 1))
+                pn_targets.append(torch.cat([torch.ones(m, device=cuda), torch.zeros(m, device=cuda)]))
+            if kind.startswith("naive"):
+                G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False, resident=kind == "naive_resident", max_cached=B + 1)
+            else:
+                G = (PCSRGraph if kind == "pcsr" else GPMAGraph)(snaps, n, device=cuda)
+            torch.manual_seed(4)
+            model = temporal.DynamicSTGraphTGCN(feat, hid).to(cuda)
+            opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+            bucket = temporal.GradBucket(model.parameters())
+            losses = []
+            for ep in range(2):
+                if kind == "naive_rebuild":
+                    G._snapshots.clear()
+                G._ndata.clear()
+                losses += temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep)
+            out.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+        finally:
+            temporal.set_fused_window(True)
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=2e-4, atol=1e-6)
+    for a, b in zip(out[0][1], out[1][1]):
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4)
