@@ -500,6 +500,10 @@ int    stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *args, void *stream);
 int    stg_tgcn_window_loss(const float *partials, int32_t steps, int64_t N, int64_t step_stride, float *step_loss,
                             float *cost, void *stream);
 
+/* norm[i] = d_i^-0.5 (0 where d_i = 0), d_i = degrees[i] or row_offsets[i + 1] - row_offsets[i] (degrees NULL): the
+ * scripts' `norm = torch.pow(in_degrees, -0.5); norm[isinf(norm)] = 0` (benchmarking/gcn/seastar/train.py:53-57) in one
+ * launch; 1 / sqrt(d) correctly rounded. */
+int    stg_degree_norm_f32(const int32_t *degrees, const int32_t *row_offsets, float *norm, int64_t N, void *stream);
 /* cost[0] = sum over `steps` rows of `partials` (count values each, rows step_stride floats apart), in order, of
  * (row sum, fixed order) * inv_n; step_loss [steps] (NULL: not wanted) gets the terms.  The general form of
  * stg_tgcn_window_loss: the dynamic-temporal loop's `cost += BCEWithLogitsLoss()(...)` over a window. */

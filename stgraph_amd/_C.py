@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
     "stg_tgcn_step_supported", "stg_tgcn_step_loss_partials", "stg_tgcn_step_fwd", "stg_tgcn_step_bwd",
-    "stg_tgcn_window_loss", "stg_partial_sums_loss", "stg_link_decode_fwd", "stg_link_decode_bwd",
+    "stg_tgcn_window_loss", "stg_partial_sums_loss", "stg_link_decode_fwd", "stg_link_decode_bwd", "stg_degree_norm_f32",
 )
 
 
@@ -238,6 +238,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_tgcn_step_bwd.argtypes = [ctypes.POINTER(TgcnStepBwdArgs), vp]
     lib.stg_tgcn_window_loss.restype = ctypes.c_int
     lib.stg_tgcn_window_loss.argtypes = [vp, i32, i64, i64, vp, vp, vp]
+    lib.stg_degree_norm_f32.restype = ctypes.c_int
+    lib.stg_degree_norm_f32.argtypes = [vp, vp, vp, i64, vp]
     lib.stg_partial_sums_loss.restype = ctypes.c_int
     lib.stg_partial_sums_loss.argtypes = [vp, i32, i32, i64, f32, vp, vp, vp]
     lib.stg_link_decode_fwd.restype = ctypes.c_int

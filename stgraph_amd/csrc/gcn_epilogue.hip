@@ -174,3 +174,32 @@ extern "C" int stg_bias_act_bwd(const float *g, const float *out, float *g_act, 
         hipLaunchKernelGGL(colsum_finish_kernel, dim3((F + kFinCols - 1) / kFinCols), block, 0, stream, partial, colsum, s.grid, F);
     return check_launch("stg_bias_act_bwd");
 }
+
+// norm = in_deg^-0.5 with inf -> 0: the scripts' `torch.pow(deg, -0.5); norm[isinf(norm)] = 0`
+// (benchmarking/gcn/seastar/train.py:53-57; dynamic loop: once per snapshot) as one launch instead of five.
+// 1 / sqrt(d), both correctly rounded (torch's pow(x, -0.5) is an rsqrt approximation on the device and libm's pow on
+// the host: the three agree to 1 ulp).
+namespace stg {
+namespace {
+__global__ __launch_bounds__(kBlock) void degree_norm_kernel(const int *__restrict__ degrees, const int *__restrict__ row_offsets,
+                                                             float *__restrict__ norm, int64_t N)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+        const int d = degrees ? degrees[i] : row_offsets[i + 1] - row_offsets[i];
+        norm[i] = d > 0 ? __fdiv_rn(1.0f, __fsqrt_rn((float)d)) : 0.f;
+    }
+}
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_degree_norm_f32(const int32_t *degrees, const int32_t *row_offsets, float *norm, int64_t N, void *stream)
+{
+    using namespace stg;
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_degree_norm_f32: negative size");
+    if (N == 0) return 0;
+    if ((!degrees && !row_offsets) || !norm) return fail(STG_ERR_INVALID_ARGUMENT, "stg_degree_norm_f32: NULL pointer argument");
+    const int blocks = (int)std::min<int64_t>((N + kBlock - 1) / kBlock, 256 * 8);
+    hipLaunchKernelGGL(degree_norm_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), degrees, row_offsets,
+                       norm, N);
+    return check_launch("stg_degree_norm_f32");
+}

@@ -1089,6 +1089,20 @@ def tgcn_window_loss(partials: torch.Tensor, steps: int, N: int, step_loss: torc
     return cost
 
 
+def degree_norm(degrees: torch.Tensor | None = None, row_offsets: torch.Tensor | None = None) -> torch.Tensor:
+    """``deg ** -0.5`` with 0 for isolated vertices, [N, 1] (stg_degree_norm_f32): from int32 ``degrees`` or from the
+    differences of ``row_offsets``."""
+    src = degrees if degrees is not None else row_offsets
+    if src is None or src.dtype != torch.int32 or not src.is_cuda or not src.is_contiguous():
+        raise TypeError("degree_norm needs a contiguous int32 device tensor")
+    N = int(src.shape[0]) - (0 if degrees is not None else 1)
+    norm = torch.empty(N, 1, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _C.check(_C.lib.stg_degree_norm_f32(_ptr(degrees), _ptr(None if degrees is not None else row_offsets), _ptr(norm), N,
+                                            _stream_ptr(src.device)))
+    return norm
+
+
 def partial_sums_loss(partials: torch.Tensor, steps: int, count: int, inv_n: float,
                       step_loss: torch.Tensor | None = None) -> torch.Tensor:
     """cost [1] = sum over the first ``steps`` rows of ``partials`` of (sum of the row's first ``count`` values) * inv_n."""

@@ -748,12 +748,19 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
 
 
 def in_degree_norm(graph) -> torch.Tensor:
-    """norm = in_deg^-0.5, inf -> 0, computed on the device from the current snapshot."""
+    """norm = in_deg^-0.5, inf -> 0, computed on the device from the current snapshot (one launch: kernels.degree_norm;
+    the torch composition -- five launches -- for tensors that are not int32 on a GPU)."""
+    from . import kernels
     if hasattr(graph, "in_degrees_tensor"):
-        deg = graph.in_degrees_tensor().float()
+        deg = graph.in_degrees_tensor()
+        if deg.is_cuda and deg.dtype == torch.int32 and deg.is_contiguous():
+            return kernels.degree_norm(degrees=deg)
+        deg = deg.float()
     else:
-        f = graph.csr("fwd")
-        deg = (f.row_offset[1:] - f.row_offset[:-1]).float()
+        ro = graph.csr("fwd").row_offset
+        if ro.is_cuda and ro.dtype == torch.int32 and ro.is_contiguous():
+            return kernels.degree_norm(row_offsets=ro)
+        deg = (ro[1:] - ro[:-1]).float()
     norm = torch.pow(deg, -0.5)
     norm[torch.isinf(norm)] = 0
     return norm.unsqueeze(1)
