@@ -42,9 +42,15 @@ from .gir import Node, Program, ValType, infer_val_type
 _NODE_TYPES = (ValType.SRC, ValType.DEST)
 _BINARY = {"Mul": "*", "Add": "+", "Sub": "-", "TrueDiv": "/"}
 _UNARY = ("Exp", "LeakyRelu", "Relu", "BwdLeakyRelu")
+_AGGS = ("AggSum", "AggMax")
+_RESHAPES = ("Sum", "View")          # evaluated in their operand's own index space (nested block in the kernel)
 
 
 # ----------------------------------------------------------------------------------------- IR helpers
+def _kind(n: Node) -> str:
+    return "e" if n.val_type == ValType.EDGE else "p" if n.val_type == ValType.PARAM else "n"
+
+
 def _broadcast(a: tuple, b: tuple) -> tuple:
     return tuple(torch.broadcast_shapes(a, b))
 
@@ -70,6 +76,24 @@ class Builder:
     def agg(self, arg: Node, vt: ValType) -> Node:
         # over in-edges into a DEST value, over out-edges into a SRC value (the key keeps them apart)
         return self.prog.intern(Node("AggSum", vt, arg.shape, args=(arg,), params=(("to", vt.name),)))
+
+    def reshape(self, op: str, arg: Node, shape: tuple, params: tuple) -> Node:
+        """``Sum`` / ``View``: same row type as the operand, feature shape given."""
+        return self.prog.intern(Node(op, arg.val_type, tuple(shape), args=(arg,), params=params))
+
+    def sum_to(self, g: Node, shape: tuple) -> Node:
+        """``g`` (carried at a broadcast shape) reduced to ``shape`` -- torch's ``sum_to_size`` as a ``Sum`` node."""
+        gs = (1,) * (len(shape) - len(g.shape)) + tuple(g.shape)
+        if len(gs) > len(shape):
+            lead = len(gs) - len(shape)
+            g = self.reshape("Sum", g, gs[lead:], (("dims", tuple(range(lead))), ("keepdim", False)))
+            gs = gs[lead:]
+        elif tuple(g.shape) != gs:
+            g = self.reshape("View", g, gs, (("shape", gs),))
+        dims = tuple(i for i, (a, b) in enumerate(zip(gs, shape)) if b == 1 and a != 1)
+        if dims:
+            g = self.reshape("Sum", g, tuple(1 if i in dims else a for i, a in enumerate(gs)), (("dims", dims), ("keepdim", True)))
+        return g
 
 
 def topo(roots) -> list:
@@ -119,7 +143,7 @@ class Analysis:
         i = id(n)
         if n.op in ("Leaf", "Const"):
             self.inline[i], self.avail[i] = True, -1
-        elif n.op == "AggSum":
+        elif n.op in _AGGS:
             if n.val_type not in _NODE_TYPES:
                 raise NotImplementedError("aggregation into a non-vertex value")
             self.inline[i] = False
@@ -127,6 +151,8 @@ class Analysis:
         elif n.val_type in _NODE_TYPES and any(not self.inline[id(a)] for a in n.args):
             self.inline[i] = False
             self.stage[i] = max(self.stage[id(a)] for a in n.args if not self.inline[id(a)])
+            if n.op in _RESHAPES:
+                self.stage[i] += 1          # reads OTHER feature columns of a materialised value: a later kernel
         else:
             self.inline[i] = True
             self.avail[i] = max([self._ready(a) for a in n.args], default=-1)
@@ -157,6 +183,8 @@ def differentiate(fwd: Analysis, rets: list, builder: Builder):
             r = builder.leaf(f"__saved{len(saved_nodes)}", x.val_type, x.shape)
             saved[i] = r
             saved_nodes.append(x)
+        elif x.op in _RESHAPES:
+            r = builder.reshape(x.op, cut(x.args[0]), x.shape, x.params)
         else:
             r = builder.op(x.op, *[cut(a) for a in x.args], params=x.params)
         cut_memo[i] = r
@@ -174,10 +202,12 @@ def differentiate(fwd: Analysis, rets: list, builder: Builder):
         for p in parts[1:]:
             g = builder.op("Add", g, p)
         if n.op == "Leaf":
-            if n.val_type == ValType.PARAM:
-                raise NotImplementedError("gradient w.r.t. a module parameter used inside a vertex function")
-            grad_roots[id(n)] = (n, g)
+            if n.val_type == ValType.PARAM and g.val_type == ValType.PARAM:
+                raise NotImplementedError("gradient of a module parameter that meets no graph feature")
+            grad_roots[id(n)] = (n, g)                    # PARAM: per-row / per-edge contributions, summed by the plan
             continue
+        if n.op in _RESHAPES and tuple(g.shape) != tuple(n.shape):
+            g = builder.sum_to(g, n.shape)                # the adjoint arrives at a broadcast shape
         for pos, a in enumerate(n.args):
             if a.op == "Const" or not a.requires_grad:
                 continue
@@ -208,6 +238,17 @@ def _local_derivative(b: Builder, cut, n: Node, pos: int, g: Node) -> Node:
         return b.op("BwdRelu", cut(n.args[0]), g)
     if n.op == "AggSum":                                # registry.py:269-276
         return g
+    if n.op == "AggMax":                                # registry.py:295-306, 326-337: 1 where the edge attains the maximum
+        return b.op("Mul", g, b.op("BwdAMax", cut(n.args[0]), cut(n)))
+    if n.op == "Sum":                                   # broadcast back over the reduced dimensions
+        dims, keep = dict(n.params)["dims"], dict(n.params)["keepdim"]
+        if keep:
+            return g
+        ks = tuple(1 if i in dims else s_ for i, s_ in enumerate(n.args[0].shape))
+        return b.reshape("View", g, ks, (("shape", ks),))
+    if n.op == "View":
+        a = n.args[0]
+        return b.reshape("View", g, a.shape, (("shape", tuple(a.shape)),))
     raise NotImplementedError(f"no gradient rule for {n.op}")
 
 
@@ -226,17 +267,19 @@ def _numel(shape: tuple) -> int:
     return out
 
 
-def _index_expr(shape: tuple, full: tuple) -> str:
-    """Flat index of the element of an operand of ``shape`` that lane ``tx`` (flat index in ``full``) reads."""
+def _index_expr(shape: tuple, full: tuple, tx: str = "tx") -> str:
+    """Flat index of the element of an operand of ``shape`` that index ``tx`` (flat in ``full``) reads."""
     if _numel(shape) == 1:
         return "0"
     if tuple(shape) == tuple(full):
-        return "tx"
+        return tx
+    if len(shape) > len(full) or any(a not in (1, b) for a, b in zip((1,) * (len(full) - len(shape)) + tuple(shape), full)):
+        raise NotImplementedError(f"operand of shape {shape} in an index space of shape {full}")
     sh = (1,) * (len(full) - len(shape)) + tuple(shape)
     terms, stride_full, stride_op = [], 1, 1
     for j in range(len(full) - 1, -1, -1):
         if sh[j] != 1:
-            coord = f"((tx / {stride_full}) % {full[j]})" if stride_full > 1 else f"(tx % {full[j]})"
+            coord = f"(({tx} / {stride_full}) % {full[j]})" if stride_full > 1 else f"({tx} % {full[j]})"
             terms.append(coord if stride_op == 1 else f"{coord} * {stride_op}")
             stride_op *= sh[j]
         stride_full *= full[j]
@@ -306,6 +349,11 @@ class _Emitter:
         self.outputs: list = []
         self.uses_eids = False
         self.full: tuple = ()
+        self.ctx: list = []                    # nested index spaces: (full, tx variable, id) of Sum / View operands
+        self._nvar = 0
+
+    def space(self):
+        return self.ctx[-1] if self.ctx else (self.full, "tx", 0)
 
     def arg(self, key) -> str:
         if key not in self.tensors:
@@ -318,7 +366,8 @@ class _Emitter:
     # -- expression generation --------------------------------------------------------------------
     def _load(self, n: Node, level: str) -> str:
         """Read the tensor behind ``n`` (a leaf or a materialised node) at ``level`` ('row' | 'edge')."""
-        t, size, idx = self.arg(self.key_of(n)), _numel(n.shape), _index_expr(n.shape, self.full)
+        full, tx, _ = self.space()
+        t, size, idx = self.arg(self.key_of(n)), _numel(n.shape), _index_expr(n.shape, full, tx)
         if n.val_type == ValType.PARAM:
             return f"{t}[{idx}]"
         if n.val_type == ValType.EDGE:
@@ -337,21 +386,74 @@ class _Emitter:
     def expr(self, n: Node, level: str, lines: list, memo: dict, local: dict) -> str:
         """C expression (a variable name or literal) for ``n`` at ``level``; statements go to ``lines``."""
         i = id(n)
-        if i in local:                                   # a per-vertex statement of this unit, already computed
+        full, tx, cid = self.space()
+        if i in local and cid == 0:                      # a per-vertex statement of this unit, already computed
             return local[i]
-        if (i, level) in memo:
-            return memo[(i, level)]
+        if (i, level, cid) in memo:
+            return memo[(i, level, cid)]
         if n.op == "Const":
             return _lit(n.value)
+        self._nvar += 1
+        var = f"v{self._nvar}_{level[0]}"
         if self.an.is_tensor(n):
-            code = self._load(n, level)
+            lines.append(f"const float {var} = {self._load(n, level)};")
+        elif n.op in _RESHAPES:
+            self._reshape(n, var, level, lines, memo, local)
         else:
             a = [self.expr(x, level, lines, memo, local) for x in n.args]
-            code = _op_code(n, a)
-        var = f"v{len(memo)}_{level[0]}"
-        lines.append(f"const float {var} = {code};")
-        memo[(i, level)] = var
+            lines.append(f"const float {var} = {_op_code(n, a)};")
+        memo[(i, level, cid)] = var
         return var
+
+    def _reshape(self, n: Node, var: str, level: str, lines: list, memo: dict, local: dict) -> None:
+        """``Sum`` / ``View``: the operand lives in its own index space.  The lane's output element (flat index ``o`` in
+        n's shape) selects, for View, the operand element with the same flat index; for Sum, the operand elements
+        whose non-reduced coordinates are o's, visited in index order (one sequential fp32 sum)."""
+        full, tx, _ = self.space()
+        arg = n.args[0]
+        A = tuple(arg.shape)
+        self._nvar += 1
+        k = self._nvar
+        o = f"o{k}"
+        if n.op == "View":
+            lines.append(f"float {var};")
+            lines.append(f"{{ const int {o} = {_index_expr(n.shape, full, tx)};")
+            self.ctx.append((A, o, k))
+            inner: list = []
+            v = self.expr(arg, level, inner, memo, local)
+            self.ctx.pop()
+            lines += ["  " + ln for ln in inner] + [f"  {var} = {v}; }}"]
+            return
+        dims, keep = dict(n.params)["dims"], dict(n.params)["keepdim"]
+        K = tuple(1 if i in dims else s_ for i, s_ in enumerate(A))          # keepdim shape
+        out_shape = K if keep else tuple(s_ for i, s_ in enumerate(A) if i not in dims)
+        assert tuple(out_shape) == tuple(n.shape), (out_shape, n.shape)
+        R = 1
+        for d in dims:
+            R *= A[d]
+        # flat operand index from o (flat over the kept dims, in order) and r (flat over the reduced dims)
+        terms, astride, kstride, rstride = [], 1, 1, 1
+        for i in range(len(A) - 1, -1, -1):
+            if A[i] != 1:
+                if i in dims:
+                    coord = f"((r{k} / {rstride}) % {A[i]})" if rstride > 1 else f"(r{k} % {A[i]})"
+                else:
+                    coord = f"(({o} / {kstride}) % {A[i]})" if kstride > 1 else f"({o} % {A[i]})"
+                terms.append(coord if astride == 1 else f"{coord} * {astride}")
+            if i in dims:
+                rstride *= A[i]
+            else:
+                kstride *= A[i]
+            astride *= A[i]
+        lines.append(f"float {var} = 0.0f;")
+        lines.append(f"{{ const int {o} = {_index_expr(n.shape, full, tx)};")
+        lines.append(f"  for (int r{k} = 0; r{k} < {R}; ++r{k}) {{")
+        lines.append(f"    const int t{k} = {' + '.join(terms) if terms else '0'};")
+        self.ctx.append((A, f"t{k}", k))
+        inner = []
+        v = self.expr(arg, level, inner, memo, local)
+        self.ctx.pop()
+        lines += ["    " + ln for ln in inner] + [f"    {var} = {var} + {v};", "  } }"]
 
 
 def _op_code(n: Node, a: list) -> str:
@@ -368,6 +470,8 @@ def _op_code(n: Node, a: list) -> str:
         return f"{a[0]} > 0 ? 1 : {_lit(slope)}"
     if n.op == "BwdRelu":
         return f"{a[0]} > 0 ? {a[1]} : 0"
+    if n.op == "BwdAMax":
+        return f"{a[0]} == {a[1]} ? 1 : 0"
     raise NotImplementedError(f"no code for op {n.op}")
 
 
@@ -377,7 +481,7 @@ def _collect_shapes(an: Analysis, n: Node, em: _Emitter, seen: set) -> None:
         return
     seen.add(id(n))
     em.widen(n.shape)
-    if not an.is_tensor(n):
+    if not an.is_tensor(n) and n.op not in _RESHAPES:    # a Sum / View operand is enumerated by its own nested loop
         for a in n.args:
             _collect_shapes(an, a, em, seen)
 
@@ -388,20 +492,28 @@ def emit_unit(an: Analysis, key_of, name: str, row_type, stage: int, nodes: list
     seen: set = set()
     for n in nodes:
         em.widen(n.shape)
+        if n.op in _RESHAPES:
+            continue
         for a in n.args:
-            if n.op == "AggSum" or an.inline[id(a)]:
+            if n.op in _AGGS or an.inline[id(a)]:
                 _collect_shapes(an, a, em, seen)
-    aggs = [n for n in nodes if n.op == "AggSum"]
+    aggs = [n for n in nodes if n.op in _AGGS]
     edge_lines, memo = [], {}
     acc = {}
     for k, n in enumerate(aggs):
         v = em.expr(n.args[0], "edge", edge_lines, memo, {})
         acc[id(n)] = f"acc{k}"
-        edge_lines.append(f"acc{k} += {v};")
+        edge_lines.append(f"acc{k} += {v};" if n.op == "AggSum" else f"acc{k} = fmaxf({v}, acc{k});")
     post, local = [], {}
     for n in nodes:
-        if n.op == "AggSum":
+        if n.op in _AGGS:
             local[id(n)] = acc[id(n)]
+        elif n.op in _RESHAPES:
+            var = f"r{len(local)}"
+            tmp: list = []
+            em._reshape(n, var, "row", tmp, memo, local)
+            post += tmp
+            local[id(n)] = var
         else:
             a = [em.expr(x, "row", post, memo, local) for x in n.args]
             var = f"r{len(local)}"
@@ -414,7 +526,7 @@ def emit_unit(an: Analysis, key_of, name: str, row_type, stage: int, nodes: list
             size, idx, cond = _numel(n.shape), _index_expr(n.shape, em.full), _canonical_cond(n.shape, em.full)
             store = f"{t}[(long)row * {size} + {idx}] = {local[id(n)]};"
             post.append(f"if ({cond}) {store}" if cond else store)
-    return _finish(em, [f"float acc{k} = 0.0f;" for k in range(len(aggs))], edge_lines, post, has_loop=True)
+    return _finish(em, ["0.0f" if n.op == "AggSum" else "-__builtin_inff()" for n in aggs], edge_lines, post, has_loop=True)
 
 
 def emit_row_only(an: Analysis, key_of, name: str, row_type, roots: list) -> KernelSpec:
@@ -476,7 +588,7 @@ def _finish(em: _Emitter, init: list, edge_lines: list, post: list, has_loop: bo
     for k in range(naccs):
         body.append(ind1 + f"float acc{k}_[{V}];")
     if naccs:
-        body.append(ind1 + f"for (int q = 0; q < {V}; ++q) {{ " + " ".join(f"acc{k}_[q] = 0.0f;" for k in range(naccs)) + " }")
+        body.append(ind1 + f"for (int q = 0; q < {V}; ++q) {{ " + " ".join(f"acc{k}_[q] = {init[k]};" for k in range(naccs)) + " }")
     refs = [f"float &acc{k} = acc{k}_[q];" for k in range(naccs)]
     if has_loop:
         # unrolled so that the column / eid / gather loads of several edges are in flight together; the adds stay
@@ -502,6 +614,24 @@ def _finish(em: _Emitter, init: list, edge_lines: list, post: list, has_loop: bo
     body += ["    }", "}", ""]
     spec.source = "\n".join(body)
     return spec
+
+
+def _fit(g: torch.Tensor, shape: tuple) -> torch.Tensor:
+    """An adjoint carried at a broadcast shape brought to the leaf's shape: summed over the dimensions the leaf has
+    with size 1 (it was broadcast in the forward pass), expanded over those a ``Sum`` reduced away."""
+    shape = tuple(shape)
+    gs = tuple(g.shape)
+    if len(gs) < len(shape):
+        g = g.reshape((1,) * (len(shape) - len(gs)) + gs)
+        gs = tuple(g.shape)
+    lead = len(gs) - len(shape)
+    tgt = (1,) * lead + shape
+    inter = tuple(1 if t == 1 else a for a, t in zip(gs, tgt))
+    if inter != gs:
+        g = g.sum_to_size(inter)
+    if inter != tgt:
+        g = g.expand(tgt)
+    return g.reshape(shape).contiguous() if lead else g.contiguous()
 
 
 # ------------------------------------------------------------------------------------------- the plan
@@ -552,15 +682,16 @@ class GenericPlan:
                 raise NotImplementedError("a vertex function must return per-vertex or per-edge values")
         leaves = [n for n in topo(self.rets) if n.op == "Leaf"]
         self._inputs, seen = [], set()
+        self._params: dict = {}              # name -> the module's parameter / buffer read inside the vertex function
         for l in leaves:
+            k = (_kind(l), l.name)
             if l.val_type == ValType.PARAM:
-                raise NotImplementedError("module parameters inside a generated vertex function are not supported yet")
-            k = ("e" if l.val_type == ValType.EDGE else "n", l.name)
+                self._params[l.name] = l.value
             if k not in seen:
                 seen.add(k)
                 self._inputs.append(k)
-        self._diff = sorted({("e" if l.val_type == ValType.EDGE else "n", l.name) for l in leaves if l.requires_grad})
-        self._input_shape = {("e" if l.val_type == ValType.EDGE else "n", l.name): l.shape for l in leaves}
+        self._diff = sorted({(_kind(l), l.name) for l in leaves if l.requires_grad})
+        self._input_shape = {(_kind(l), l.name): l.shape for l in leaves}
 
         # forward placement, reverse mode, then forward placement again with the saved values as extra roots
         fwd0 = Analysis(self.rets)
@@ -577,15 +708,20 @@ class GenericPlan:
         if self.grad_roots:
             roots = [g for _, g in self.grad_roots]
             self.bwd = Analysis(roots)
-            self.bwd_kernels, self._bwd_out_key = self._build_pass(self.bwd, roots, [l.val_type for l, _ in self.grad_roots],
-                                                                   f"stg_b{self.uid}")
+            # a parameter's adjoint is built per row (or per edge) of whatever it was combined with, then summed
+            targets = [g.val_type if l.val_type == ValType.PARAM else l.val_type for l, g in self.grad_roots]
+            self.bwd_kernels, self._bwd_out_key = self._build_pass(self.bwd, roots, targets, f"stg_b{self.uid}")
         self.source = "\n".join(k.source for k in self.fwd_kernels + self.bwd_kernels)
         self.module = _Module(self.source, f"stg_generated_{self.uid}.hip")
 
     # -- construction -------------------------------------------------------------------------------
     @staticmethod
     def _leaf_key(n: Node):
-        return ("leaf", "e" if n.val_type == ValType.EDGE else "n", n.name)
+        return ("leaf", _kind(n), n.name)
+
+    def params(self) -> dict:
+        """{name: tensor} of the module parameters / buffers the vertex function reads (autograd inputs of the call)."""
+        return dict(self._params)
 
     def _build_pass(self, an: Analysis, roots: list, targets: list, prefix: str):
         """Kernels (in launch order) computing ``roots``; ``targets[i]`` is the kind of tensor root i has to
@@ -669,7 +805,7 @@ class GenericPlan:
     def _bind_inputs(self, n_feats: dict, e_feats: dict) -> dict:
         env = {}
         for kind, name in self._inputs:
-            t = (e_feats if kind == "e" else n_feats)[name]
+            t = self._params[name] if kind == "p" else (e_feats if kind == "e" else n_feats)[name]
             if not t.is_cuda:
                 raise RuntimeError("stgraph_amd has no CPU fallback: vertex-function inputs must be HIP tensors")
             env[("leaf", kind, name)] = t.detach().contiguous().float()
@@ -698,7 +834,7 @@ class GenericPlan:
             self._launch(spec, graph, env, N, E, device)
         result = {}
         for leaf, root in self.grad_roots:
-            key = ("e" if leaf.val_type == ValType.EDGE else "n", leaf.name)
+            key = (_kind(leaf), leaf.name)
             if id(root) in self._bwd_out_key:
                 g = env[self._bwd_out_key[id(root)]]
             elif root.op == "Leaf":
@@ -706,7 +842,12 @@ class GenericPlan:
             else:
                 raise RuntimeError("gradient root was not emitted")
             rows = g.shape[0]
-            g = g.sum_to_size((rows,) + tuple(self._input_shape[key]))
+            if leaf.val_type == ValType.PARAM:          # contributions of every row / edge, then down to the parameter's shape
+                shp = tuple(self._input_shape[key])
+                g = _fit(g.sum(0), shp) if shp else g.sum()
+                result[key] = g if key not in result else result[key] + g
+                continue
+            g = _fit(g, (rows,) + tuple(self._input_shape[key]))
             result[key] = g if key not in result else result[key] + g
         return result
 

@@ -68,6 +68,8 @@ class Context:
             self._executors[sig] = executor
         input_map = {("n", k): v for k, v in node_feats.items()}
         input_map.update({("e", k): v for k, v in edge_feats.items()})
+        if hasattr(executor.plan, "params"):          # module parameters read inside the vertex function: autograd inputs too
+            input_map.update({("p", k): v for k, v in executor.plan.params().items()})
         executor.restart(input_map, graph)
         self._executor_cache = executor
         self._entry_count += 1

@@ -111,11 +111,49 @@ class Val:
     def __floordiv__(self, other):
         raise NotImplementedError("__floordiv__ Op not supported")
 
-    def sum(self, *args, **kwargs):
-        raise NotImplementedError("Tensor.sum inside a vertex function is not supported by the MI355X kernels yet")
+    def sum(self, dim=None, keepdim: bool = False, **kwargs):
+        """``Tensor.sum`` over FEATURE dimensions (torch_val.py:172-197): ``dim`` counts the feature dimensions as the
+        traced value has them (the vertex / edge dimension is not one of them; negative values from the end), None =
+        all of them.  Recorded as a ``Sum`` statement; the generated kernels evaluate it in registers."""
+        if kwargs:
+            raise NotImplementedError(f"Tensor.sum({', '.join(kwargs)}=...) inside a vertex function")
+        shape = self.node.shape
+        nd = len(shape)
+        dims = tuple(range(nd)) if dim is None else tuple(sorted({(d + nd) % nd for d in ((dim,) if isinstance(dim, int) else dim)}))
+        if not dims and nd:
+            raise ValueError("empty dim list")
+        if any(d < 0 or d >= nd for d in dims):
+            raise IndexError(f"sum over dimension(s) {dim} of a value with feature shape {shape}")
+        out = tuple(1 if i in dims else s for i, s in enumerate(shape)) if keepdim else \
+            tuple(s for i, s in enumerate(shape) if i not in dims)
+        node = Node("Sum", self.node.val_type, out, args=(self.node,), params=(("dims", dims), ("keepdim", bool(keepdim))),
+                    requires_grad=self.node.requires_grad)
+        return Val(self.prog.intern(node), self.prog)
 
-    def view(self, *args, **kwargs):
-        raise NotImplementedError("Tensor.view inside a vertex function is not supported by the MI355X kernels yet")
+    def view(self, *shape):
+        """``Tensor.view`` of the FEATURE shape (torch_val.py:199-227: the run-time call is ``t.view(-1, *shape)``)."""
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        total = 1
+        for s_ in self.node.shape:
+            total *= int(s_)
+        shape = [int(x) for x in shape]
+        if shape.count(-1) > 1:
+            raise ValueError("only one dimension of a view can be inferred")
+        known = 1
+        for x in shape:
+            if x != -1:
+                known *= x
+        if -1 in shape:
+            if known == 0 or total % known:
+                raise ValueError(f"shape {tuple(shape)} is invalid for a value of feature shape {self.node.shape}")
+            shape[shape.index(-1)] = total // known
+            known = total
+        if known != total:
+            raise ValueError(f"shape {tuple(shape)} is invalid for a value of feature shape {self.node.shape}")
+        node = Node("View", self.node.val_type, tuple(shape), args=(self.node,), params=(("shape", tuple(shape)),),
+                    requires_grad=self.node.requires_grad)
+        return Val(self.prog.intern(node), self.prog)
 
     # -- torch.<fn>(val) and module(val) ----------------------------------------------------------
     @classmethod
@@ -146,3 +184,19 @@ class Val:
 
     def __repr__(self) -> str:
         return f"Val({self.node.key})"
+
+
+def agg_max(values) -> Val:
+    """``AggMax``: the maximum over a vertex's in-neighbours / in-edges of a per-neighbour or per-edge value
+    (reference registry.py:295-337; its front end never exposed it -- ``compiler/stgraph.py:6`` has the import commented
+    out -- and Python's builtin ``max`` over the one-element neighbour list is the identity).  Use inside
+    a vertex function as ``agg_max([nb.h for nb in v.innbs])``.  A vertex without in-edges gets -inf; ties share the
+    gradient (``BackwardAMax``: 1 for every edge attaining the maximum)."""
+    vals = list(values)
+    if len(vals) != 1 or not isinstance(vals[0], Val):
+        raise TypeError("agg_max takes the neighbour comprehension of a vertex function")
+    v = vals[0]
+    if v.val_type not in (ValType.SRC, ValType.EDGE):
+        raise TypeError("agg_max([...]) aggregates per-neighbour (SRC) or per-edge (EDGE) values")
+    node = Node("AggMax", ValType.DEST, v.node.shape, args=(v.node,), requires_grad=v.node.requires_grad)
+    return Val(v.prog.intern(node), v.prog)

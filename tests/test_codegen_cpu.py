@@ -91,14 +91,34 @@ def test_units_of_generated_plans():
 
 
 def test_unsupported_constructs_fail_loudly():
-    from stgraph_amd.compiler.dispatch import make_plan
-    w = torch.nn.Parameter(torch.ones(8))
     nf = {"h": torch.zeros(3, 8)}
-    rets, prog = trace_vertex_function(lambda v: sum([nb.h * w for nb in v.innbs]), nf, {})
-    with pytest.raises(NotImplementedError, match="module parameters"):
-        make_plan(rets, prog)
     with pytest.raises(NotImplementedError):
         trace_vertex_function(lambda v: sum([torch.tanh(nb.h) for nb in v.innbs]), nf, {})
+    with pytest.raises(TypeError):
+        trace_vertex_function(lambda v: sum([nb.h for nb in v.innbs]) * "x", nf, {})
+
+
+def test_parameters_sum_view_and_aggmax_generate_kernels():
+    """Module parameters read inside the function, Tensor.sum / .view over feature dimensions and agg_max: placement
+    and emitted source (hiprtc compiles without a GPU)."""
+    from stgraph_amd.compiler import agg_max
+    w = torch.nn.Parameter(torch.ones(8))
+    p = _plan(lambda v: sum([nb.h * w for nb in v.innbs]), {"h": (8,)}, {}, ["h"])
+    assert ("p", f"param{id(w):x}") in p.input_names() and ("p", f"param{id(w):x}") in p.differentiable()
+    assert len(p.fwd_kernels) == 1
+    p = _plan(lambda v: agg_max([nb.h for nb in v.innbs]), {"h": (8,)}, {}, ["h"])
+    assert "fmaxf" in p.fwd_kernels[0].source and "__builtin_inff" in p.fwd_kernels[0].source
+    assert "== " in p.source                              # BackwardAMax: 1 where the edge attains the maximum
+    # a sum over the features of an AGGREGATE needs the aggregate in memory: two forward kernels
+    p = _plan(lambda v: sum([nb.f for nb in v.innbs]).sum(-1, keepdim=True) * v.f, {"f": (4, 8)}, {}, ["f"])
+    assert len(p.fwd_kernels) == 2
+    # of leaves only: evaluated in registers inside the edge loop, one kernel
+    p = _plan(lambda v: sum([nb.f * nb.f.sum(-1, keepdim=True) for nb in v.innbs]), {"f": (4, 8)}, {}, ["f"])
+    assert len(p.fwd_kernels) == 1 and "for (int r" in p.fwd_kernels[0].source
+    p = _plan(lambda v: sum([nb.x.view(4, 8) * nb.a for nb in v.innbs]), {"x": (32,), "a": (4, 1)}, {}, ["x", "a"])
+    assert len(p.fwd_kernels) == 1
+    with pytest.raises(ValueError):
+        _plan(lambda v: sum([nb.x.view(5, 8) for nb in v.innbs]), {"x": (32,)}, {}, [])
 
 
 def test_jit_reports_compile_errors():

@@ -202,3 +202,82 @@ def test_forced_generation_of_gat_forward_matches_the_hand_written_units(cuda):
     torch.testing.assert_close(res[False][0], res[True][0], rtol=1e-5, atol=1e-5)
     assert float(res[True][1].abs().max()) == 0.0 and float(res[False][1].abs().max()) > 0.0
     assert torch.isfinite(res[True][2]).all()
+
+
+# ---------------------------------------------------------------- AggMax, Tensor.sum / .view, module parameters
+from stgraph_amd.compiler import agg_max  # noqa: E402
+
+EXTRA = {
+    # name: (vertex function factory(mod), node features, edge features, differentiable names)
+    "agg_max": (lambda mod: (lambda v: agg_max([nb.h for nb in v.innbs]) + v.h), {"h": (12,)}, {}, ["h"]),
+    "agg_max_edge": (lambda mod: (lambda v: agg_max([e.src.h * e.w for e in v.inedges]) * v.norm), {"h": (8,), "norm": (1,)},
+                     {"w": (8,)}, ["h", "w"]),
+    "row_sum_keep": (lambda mod: (lambda v: sum([nb.f * (nb.f.sum(-1, keepdim=True)) for nb in v.innbs])),
+                     {"f": (H, D)}, {}, ["f"]),
+    "attn_like": (lambda mod: (lambda v: sum([(e.src.f * e.dst.f).sum(-1, keepdim=True) * e.src.f for e in v.inedges])),
+                  {"f": (H, D)}, {}, ["f"]),
+    "sum_of_aggregate": (lambda mod: (lambda v: sum([nb.f for nb in v.innbs]).sum(-1, keepdim=True) * v.f), {"f": (H, D)}, {}, ["f"]),
+    "view_heads": (lambda mod: (lambda v: sum([nb.x.view(H, D) * nb.a for nb in v.innbs])), {"x": (H * D,), "a": (H, 1)}, {},
+                   ["x", "a"]),
+    "sum_nokeep": (lambda mod: (lambda v: sum([nb.f.sum(1) * nb.s for nb in v.innbs])), {"f": (H, D), "s": (H,)}, {}, ["f", "s"]),
+    "param_scale": (lambda mod: (lambda v: sum([nb.h * mod.scale for nb in v.innbs]) + mod.shift), {"h": (16,)}, {}, ["h"]),
+    "param_edge": (lambda mod: (lambda v: sum([torch.exp(e.src.h * mod.scale) * e.w for e in v.inedges])), {"h": (16,)},
+                   {"w": (1,)}, ["h", "w"]),
+}
+
+
+class _PMod(_Mod):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(11)
+        self.scale = torch.nn.Parameter(torch.rand(16, generator=g) + 0.5)
+        self.shift = torch.nn.Parameter(torch.randn(16, generator=g))
+
+
+@pytest.mark.parametrize("kind", ["static", "naive"])
+@pytest.mark.parametrize("name", sorted(EXTRA))
+def test_aggmax_sum_view_and_parameters_match_torch(cuda, name, kind):
+    """The ops of the reference's Python surface / registry that its own pipeline cannot reach (AggMax: front end
+    commented out, compiler/stgraph.py:6; Tensor.sum / .view: traced by torch_val.py:172-227 but without a code generator
+    entry; module parameters inside the function: stgraph.py:126-173) against torch in fp64, values and gradients --
+    including the gradients of the parameters."""
+    make, nshapes, eshapes, diff = EXTRA[name]
+    n, e = 400, 3000
+    g = _graph(cuda, kind, n, e, 3)
+    E = g.csr("fwd").column_indices.shape[0]
+    gen = torch.Generator().manual_seed(7)
+    mk = lambda rows, shape, key: (torch.rand((rows,) + shape, generator=gen) + 0.5 if key in ("deg", "norm")  # noqa: E731
+                                   else torch.randn((rows,) + shape, generator=gen) * 0.5).to(cuda)
+    nf = {k: mk(n, s, k).requires_grad_(k in diff) for k, s in nshapes.items()}
+    ef = {k: mk(E, s, k).requires_grad_(k in diff) for k, s in eshapes.items()}
+    mod = _PMod().to(cuda)
+    fn = make(mod)
+    fn_c = mod.stgraph.compile(gnn_module=mod)(fn)
+    outs = fn_c(g=g, n_feats=nf, e_feats=ef)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    assert fn_c._executor_cache.plan.name == "generated"
+    src, dst = edges_by_eid(g.csr("fwd"))
+    nf64 = {k: v.detach().double().requires_grad_(v.requires_grad) for k, v in nf.items()}
+    ef64 = {k: v.detach().double().requires_grad_(v.requires_grad) for k, v in ef.items()}
+    pf64 = {f"param{id(p):x}": p.detach().double().requires_grad_(True) for p in (mod.scale, mod.shift)}
+    ref = eval_vertex_function(fn, src, dst, n, nf64, ef64, pf64)
+    for o, r in zip(outs, ref):
+        assert o.shape == r.shape, (o.shape, r.shape)
+        fin = torch.isfinite(r)                        # agg_max: -inf on vertices without in-edges, on both sides
+        assert torch.equal(torch.isfinite(o), fin)
+        torch.testing.assert_close(o.double()[fin], r[fin], rtol=1e-4, atol=1e-4)
+    Rs = [torch.randn(o.shape, generator=gen).to(cuda) for o in outs]
+    fin = [torch.isfinite(r) for r in ref]
+    sum((torch.where(f, o, torch.zeros_like(o)) * R).sum() for o, R, f in zip(outs, Rs, fin)).backward()
+    sum((torch.where(f, r, torch.zeros_like(r)) * R.double()).sum() for r, R, f in zip(ref, Rs, fin)).backward()
+    for k in diff:
+        got = (nf.get(k) if k in nf else ef[k]).grad
+        want = (nf64.get(k) if k in nf64 else ef64[k]).grad
+        assert got is not None, k
+        torch.testing.assert_close(got.double(), want, rtol=1e-4, atol=1e-4, msg=lambda m: f"grad {k}: {m}")
+    if name.startswith("param"):
+        used = [(mod.scale, pf64[f"param{id(mod.scale):x}"])] + ([(mod.shift, pf64[f"param{id(mod.shift):x}"])] if name == "param_scale" else [])
+        for p, p64 in used:
+            assert p.grad is not None
+            torch.testing.assert_close(p.grad.double(), p64.grad, rtol=1e-4, atol=1e-3)
+    assert len(fn_c._executor_cache.ts.tensor_map_stack) == 0

@@ -70,7 +70,7 @@ def trace_vertex_function(fn, n_feats: dict, e_feats: dict):
     return [x.node for x in (r if isinstance(r, (tuple, list)) else [r])], prog
 
 
-def eval_vertex_function(fn, src_by_eid, dst_by_eid, num_nodes, n_feats: dict, e_feats: dict):
+def eval_vertex_function(fn, src_by_eid, dst_by_eid, num_nodes, n_feats: dict, e_feats: dict, p_feats: dict | None = None):
     """Plain-torch reference of a vertex function: every traced node is evaluated with torch ops on
     whole tensors (per-vertex values [N, ...], per-edge values [E, ...] in eid order, ``sum([...])`` =
     ``index_add_`` over the destination).  Differentiable through torch autograd; works in any dtype."""
@@ -89,11 +89,25 @@ def eval_vertex_function(fn, src_by_eid, dst_by_eid, num_nodes, n_feats: dict, e
             return memo[id(n)]
         if n.op == "Const":
             r = n.value
+        elif n.op == "Leaf" and n.val_type == ValType.PARAM:
+            r = (p_feats or {}).get(n.name, n.value)         # a module parameter read inside the vertex function
         elif n.op == "Leaf":
             r = (e_feats if n.val_type == ValType.EDGE else n_feats)[n.name]
         elif n.op == "AggSum":
             a = to_edge(n.args[0], ev(n.args[0]))
             r = torch.zeros((num_nodes,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device).index_add_(0, dst_by_eid, a)
+        elif n.op == "AggMax":
+            a = to_edge(n.args[0], ev(n.args[0]))
+            idx = dst_by_eid.view((-1,) + (1,) * (a.dim() - 1)).expand_as(a)
+            r = torch.full((num_nodes,) + tuple(a.shape[1:]), float("-inf"), dtype=a.dtype, device=a.device)
+            r = r.scatter_reduce(0, idx, a, reduce="amax", include_self=True)
+        elif n.op == "Sum":
+            v = ev(n.args[0])
+            pr = dict(n.params)
+            r = v.sum(dim=tuple(d + 1 for d in pr["dims"]), keepdim=pr["keepdim"])
+        elif n.op == "View":
+            v = ev(n.args[0])
+            r = v.reshape((v.shape[0],) + tuple(n.shape))
         else:
             vals = [ev(a) for a in n.args]
             if n.val_type == ValType.EDGE:
