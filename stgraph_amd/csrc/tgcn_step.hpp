@@ -101,6 +101,53 @@ __device__ __forceinline__ void stage_rows(float *dst, int ld, const float *__re
     }
 }
 
+// The same copy in two halves, so that the global loads are in flight while the wave does something else (its first
+// tile's gather): issue() fills PER float4 registers per thread from up to NSEG matrices, commit() writes them to LDS.
+struct StageSeg {
+    const float *src;
+    float *dst;
+    int rows, cols, ld;                    // rows = 0: unused
+};
+
+template <int NT, int NSEG, int PER>
+struct Stager {
+    float4 v[PER];
+
+    __device__ __forceinline__ void issue(const StageSeg (&segs)[NSEG])
+    {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * NT;
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int base = 0;
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s) {
+                const int cnt = segs[s].rows * (segs[s].cols >> 2);
+                if (i >= base && i < base + cnt) v[k] = *reinterpret_cast<const float4 *>(segs[s].src + (int64_t)(i - base) * 4);
+                base += cnt;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void commit(const StageSeg (&segs)[NSEG]) const
+    {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * NT;
+            int base = 0;
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s) {
+                const int c4 = segs[s].cols >> 2, cnt = segs[s].rows * c4;
+                if (i >= base && i < base + cnt) {
+                    const int r = (i - base) / c4, c = (i - base) - r * c4;
+                    *reinterpret_cast<float4 *>(segs[s].dst + r * segs[s].ld + 4 * c) = v[k];
+                }
+                base += cnt;
+            }
+        }
+    }
+};
+
 __device__ __forceinline__ f32x4 to_x4(const float4 &v) { return f32x4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ float4 to_f4(const f32x4 &v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
@@ -138,9 +185,21 @@ __device__ __forceinline__ void mfma_piece(f32x4 (&acc)[CT], const float *__rest
 // acc[ct] += sum_{j < J} W[16 ct + n16][16 j + 4 kq ..] x in(j): the weights of step j + 1 are read from LDS while the
 // MFMAs of step j issue, and no further ahead (left alone the scheduler hoists every LDS read of the unrolled chain
 // to the top and spills: 200+ registers).
-template <int CT, int J, typename InFn>
+template <int CT, int J, bool PREFETCH = true, typename InFn>
 __device__ __forceinline__ void gemm_pieces(f32x4 (&acc)[CT], const float *__restrict__ wrow, int ld, InFn in)
 {
+    if constexpr (!PREFETCH) {               // one weight buffer (16 registers less): the other waves of the SIMD cover the LDS latency
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float4 w[CT];
+            load_w<CT>(w, wrow, ld, j);
+            const float4 x = in(j);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_w<CT>(acc, w, x);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     float4 wn[CT];
     load_w<CT>(wn, wrow, ld, 0);
 #pragma unroll

@@ -45,20 +45,43 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int n16 = lane & 15, kq = lane >> 4;
 
-    stage_rows<NT>(WgT, LDB, a.WzT, 2 * C, C);
-    stage_rows<NT>(WgT + 2 * C * LDB, LDB, a.WrT, 2 * C, C);
-    stage_rows<NT>(WgT + 4 * C * LDB, LDB, a.WhT, 2 * C, C);
+    // weights: every global load of the staging in flight at once, then the LDS writes (see tgcn_step_fwd.hip)
     const bool want_z = a.z != nullptr;                // block-uniform
-    if (want_z) stage_rows<NT>(Wc, LDX, a.Wcat, FIN, 3 * C);
-    if constexpr (HEAD != 0) stage_rows<NT>(W1T, LDT, a.W1T, C, FH);
+    constexpr int kStage4 = (3 * 2 * C * C + FIN * 3 * C + (HEAD ? C * FH : 0)) / 4;
+    const StageSeg segs[5] = {{a.WzT, WgT, 2 * C, C, LDB}, {a.WrT, WgT + 2 * C * LDB, 2 * C, C, LDB},
+                              {a.WhT, WgT + 4 * C * LDB, 2 * C, C, LDB}, {a.Wcat, Wc, want_z ? FIN : 0, 3 * C, LDX},
+                              {a.W1T, W1T, HEAD ? C : 0, FH, LDT}};
+    Stager<NT, 5, (kStage4 + NT - 1) / NT> stager;
+    stager.issue(segs);
+    const int total = gridDim.x * WAVES;
+    int tile = wave * (int)gridDim.x + (int)blockIdx.x;
+    const bool do_gather = GATHER && HEAD != 0 && a.zn != nullptr;      // block-uniform
+    // A_hat^T zn of a tile's rows (the next step's input gradient, aggregated here), as row pieces
+    auto gather_tile = [&](int t, float4 (&pp)[PH]) {
+        const int q = lane & 3, grow = lane >> 2;
+        const int64_t gidx = (int64_t)t * 16 + grow;
+        const bool gok = gidx < a.N;
+        int gr = (int)gidx;
+        if (gok && a.node_ids) gr = a.node_ids[gidx];
+        float p8[8];
+        gather_rows32<HAS_EW>(p8, a.zn, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, gok, q);
+        gather_to_pieces(p8, pp, n16, kq);
+    };
+    stager.commit(segs);
     if constexpr (HEAD == 2) {
         for (int i = threadIdx.x; i < FH; i += NT) bs[i] = a.W2[i];
     }
     __syncthreads();
 
-    const int total = gridDim.x * WAVES;
     const float lo = a.lo, hi = a.hi;
-    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < a.num_tiles; tile += total) {
+    for (; tile < a.num_tiles; tile += total) {
+        // A_hat^T zn first: the gather loop is the register-hungry part of the kernel and nothing else is live yet
+        float4 gp[PH];
+#pragma unroll
+        for (int j = 0; j < PH; ++j) gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (GATHER && HEAD != 0) {
+            if (do_gather) gather_tile(tile, gp);
+        }
         const int64_t idx = (int64_t)tile * 16 + n16;
         const bool rok = idx < a.N;
         // Lanes past the last row read row N - 1 (valid memory, finite values) and never store: loads need no per-lane
@@ -71,23 +94,6 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         };
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-        // ---- A_hat^T zn: the next step's input gradient, aggregated here (first: its gather loop is the register-hungry
-        //      part of the kernel and nothing else is live yet) ---------------------------------------------------------
-        float4 gp[PH];
-#pragma unroll
-        for (int j = 0; j < PH; ++j) gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (GATHER && HEAD != 0) {
-            if (a.zn) {                                              // block-uniform branch
-                const int q = lane & 3, grow = lane >> 2;
-                const int64_t gidx = (int64_t)tile * 16 + grow;
-                const bool gok = gidx < a.N;
-                int gr = (int)gidx;
-                if (gok && a.node_ids) gr = a.node_ids[gidx];
-                float p8[8];
-                gather_rows32<HAS_EW>(p8, a.zn, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, gok, q);
-                gather_to_pieces(p8, gp, n16, kq);
-            }
-        }
         // clamp mask of the 3C columns of x3 as 48 bits (read now, used by three later phases: 2 registers instead of
         // 12 loads in the middle of the MFMA chains)
         unsigned mlo = 0u, mhi = 0u;
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
             f32x4 acc[PC];
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_pieces<PC, PH>(acc, W1T + n16 * LDT + 4 * kq, LDT, [&](int j) { return gy[j]; });
+            gemm_pieces<PC, PH, (WAVES <= 12)>(acc, W1T + n16 * LDT + 4 * kq, LDT, [&](int j) { return gy[j]; });
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
                 const float4 h = ldrow(a.Hn, C, 16 * j + 4 * kq);
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
             const float *w = WgT + (g * 2 * C + half * C + n16) * LDB + 4 * kq;
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_pieces<PC, PC>(acc, w, LDB, [&](int j) { return in[j]; });
+            gemm_pieces<PC, PC, (WAVES <= 12)>(acc, w, LDB, [&](int j) { return in[j]; });
         };
         // da3[:, g C + 16 blk ..] = clamp mask * piece; z += that piece x Wcat^T
         auto emit_da3 = [&](int g, const f32x4 (&acc)[PC]) {

@@ -43,11 +43,33 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int n16 = lane & 15, kq = lane >> 4;
 
-    stage_rows<NT>(Wg, LDW, a.Wz, C, 2 * C);
-    stage_rows<NT>(Wg + C * LDW, LDW, a.Wr, C, 2 * C);
-    stage_rows<NT>(Wg + 2 * C * LDW, LDW, a.Wh, C, 2 * C);
-    if constexpr (GATHER) stage_rows<NT>(WcT, LDC, a.WcatT, 3 * C, FIN);
-    if constexpr (HEAD != 0) stage_rows<NT>(W1s, LD1, a.W1, FH, C);
+    // weights: every global load of the staging in flight at once, then the LDS writes.  (Gathering the first tile
+    // between the two halves -- or a later tile's rows ahead of time -- measured SLOWER: the workgroup barrier then waits
+    // for the slowest wave's gather, and waves that start their products at different times overlap better.)
+    constexpr int kStage4 = (3 * C * 2 * C + (GATHER ? 3 * C * FIN : 0) + (HEAD ? FH * C : 0)) / 4;
+    const StageSeg segs[5] = {{a.Wz, Wg, C, 2 * C, LDW}, {a.Wr, Wg + C * LDW, C, 2 * C, LDW}, {a.Wh, Wg + 2 * C * LDW, C, 2 * C, LDW},
+                              {a.WcatT, WcT, GATHER ? 3 * C : 0, FIN, LDC}, {a.W1, W1s, HEAD ? FH : 0, C, LD1}};
+    Stager<NT, 5, (kStage4 + NT - 1) / NT> stager;
+    stager.issue(segs);
+    const int total = gridDim.x * WAVES;
+    int tile = wave * (int)gridDim.x + (int)blockIdx.x;
+    // P = A_hat x of a tile, handed from the gather layout to row pieces on the LDS crossbar (no LDS memory)
+    auto gather_tile = [&](int t, float4 (&pp)[PF]) {
+        const int q = lane & 3, grow = lane >> 2;
+        const int64_t gidx = (int64_t)t * 16 + grow;
+        const bool gok = gidx < a.N;
+        int gr = (int)gidx;
+        if (gok && a.node_ids) gr = a.node_ids[gidx];
+        float p8[8];
+        gather_rows32<HAS_EW>(p8, a.x, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, gok, q);
+        const float4 lo4 = make_float4(p8[0], p8[1], p8[2], p8[3]), hi4 = make_float4(p8[4], p8[5], p8[6], p8[7]);
+        if (gok) {
+            *reinterpret_cast<float4 *>(a.P + ((unsigned)gr * FIN + 8 * q)) = lo4;
+            *reinterpret_cast<float4 *>(a.P + ((unsigned)gr * FIN + 8 * q + 4)) = hi4;
+        }
+        gather_to_pieces(p8, pp, n16, kq);
+    };
+    stager.commit(segs);
     for (int i = threadIdx.x; i < 3 * C; i += NT) bs[i] = a.b3[i];
     for (int i = threadIdx.x; i < C; i += NT) {
         bs[3 * C + i] = a.bz[i];
@@ -65,9 +87,12 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     }
     __syncthreads();
 
-    const int total = gridDim.x * WAVES;
     const float lo = a.lo, hi = a.hi;
-    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < a.num_tiles; tile += total) {
+    for (; tile < a.num_tiles; tile += total) {
+        float4 p[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (GATHER) gather_tile(tile, p);
         const int64_t idx = (int64_t)tile * 16 + n16;
         const bool rok = idx < a.N;
         // Lanes past the last row read row N - 1 (valid memory, finite values) and never store: loads need no per-lane
@@ -75,26 +100,6 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
         // the host): one VGPR per row stride next to scalar base pointers.
         unsigned row = (unsigned)(rok ? idx : a.N - 1);
         if (a.node_ids) row = (unsigned)a.node_ids[row];
-
-        // ---- P = A_hat x (GATHER), handed from the gather layout to row pieces on the LDS crossbar ------------------------
-        float4 p[PF];
-        if constexpr (GATHER) {
-            {
-                const int q = lane & 3, grow = lane >> 2;
-                const int64_t gidx = (int64_t)tile * 16 + grow;
-                const bool gok = gidx < a.N;
-                int gr = (int)gidx;
-                if (gok && a.node_ids) gr = a.node_ids[gidx];
-                float p8[8];
-                gather_rows32<HAS_EW>(p8, a.x, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, gok, q);
-                const float4 lo4 = make_float4(p8[0], p8[1], p8[2], p8[3]), hi4 = make_float4(p8[4], p8[5], p8[6], p8[7]);
-                if (gok) {
-                    *reinterpret_cast<float4 *>(a.P + ((unsigned)gr * FIN + 8 * q)) = lo4;
-                    *reinterpret_cast<float4 *>(a.P + ((unsigned)gr * FIN + 8 * q + 4)) = hi4;
-                }
-                gather_to_pieces(p8, p, n16, kq);
-            }
-        }
         // hg = clamp(x3[:, g C ..]) with x3 = P Wcat + b3 (or a3 + b3), one gate at a time (16 live registers instead
         // of 48); x3 itself (before the clamp) is what the backward pass and the weight gradients read
         auto gate_input = [&](int g, float4 (&hg)[PC]) {
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
                 f32x4 acc[PC];
 #pragma unroll
                 for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_pieces<PC, PF>(acc, WcT + (g * C + n16) * LDC + 4 * kq, LDC, [&](int j) { return p[j]; });
+                gemm_pieces<PC, PF, (WAVES <= 12)>(acc, WcT + (g * C + n16) * LDC + 4 * kq, LDC, [&](int j) { return p[j]; });
 #pragma unroll
                 for (int ct = 0; ct < PC; ++ct) {
                     const float4 b = *reinterpret_cast<const float4 *>(bs + g * C + 16 * ct + 4 * kq);
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
         auto gate = [&](int g, const float4 (&hg)[PC], const float4 (&second)[PC], f32x4 (&acc)[PC]) {
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) acc[ct] = to_x4(*reinterpret_cast<const float4 *>(bs + (3 + g) * C + 16 * ct + 4 * kq));
-            gemm_pieces<PC, 2 * PC>(acc, Wg + (g * C + n16) * LDW + 4 * kq, LDW,
+            gemm_pieces<PC, 2 * PC, (WAVES <= 12)>(acc, Wg + (g * C + n16) * LDW + 4 * kq, LDW,
                                     [&](int j) { return j < PC ? hg[j % PC] : second[j % PC]; });
         };
 
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
             f32x4 accy[PH];
 #pragma unroll
             for (int ft = 0; ft < PH; ++ft) accy[ft] = to_x4(*reinterpret_cast<const float4 *>(bs + 6 * C + 16 * ft + 4 * kq));
-            gemm_pieces<PH, PC>(accy, W1s + n16 * LD1 + 4 * kq, LD1, [&](int j) {
+            gemm_pieces<PH, PC, (WAVES <= 12)>(accy, W1s + n16 * LD1 + 4 * kq, LD1, [&](int j) {
                 return make_float4(hn[j].x < 0.f ? 0.f : hn[j].x, hn[j].y < 0.f ? 0.f : hn[j].y,
                                    hn[j].z < 0.f ? 0.f : hn[j].z, hn[j].w < 0.f ? 0.f : hn[j].w);
             });
