@@ -496,7 +496,7 @@ size_t stg_tgcn_step_loss_partials(int64_t N);
 int    stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *args, void *stream);
 int    stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *args, void *stream);
 /* cost[0] = sum over the window's `steps` steps, in order, of (sum of that step's partials) / N; step_loss [steps]
- * (NULL: not wanted) gets the terms.  partials: `steps` rows of step_stride floats. */
+ * (required: the terms, and the scratch of the final sum).  partials: `steps` rows of step_stride floats. */
 int    stg_tgcn_window_loss(const float *partials, int32_t steps, int64_t N, int64_t step_stride, float *step_loss,
                             float *cost, void *stream);
 
@@ -505,7 +505,7 @@ int    stg_tgcn_window_loss(const float *partials, int32_t steps, int64_t N, int
  * launch; 1 / sqrt(d) correctly rounded. */
 int    stg_degree_norm_f32(const int32_t *degrees, const int32_t *row_offsets, float *norm, int64_t N, void *stream);
 /* cost[0] = sum over `steps` rows of `partials` (count values each, rows step_stride floats apart), in order, of
- * (row sum, fixed order) * inv_n; step_loss [steps] (NULL: not wanted) gets the terms.  The general form of
+ * (row sum, fixed order) * inv_n; step_loss [steps] (required) gets the terms.  The general form of
  * stg_tgcn_window_loss: the dynamic-temporal loop's `cost += BCEWithLogitsLoss()(...)` over a window. */
 int    stg_partial_sums_loss(const float *partials, int32_t steps, int32_t count, int64_t step_stride, float inv_n,
                              float *step_loss, float *cost, void *stream);

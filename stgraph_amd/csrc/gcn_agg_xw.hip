@@ -194,8 +194,10 @@ extern "C" int stg_gcn_agg_transform(const float *x, const float *norm_row, cons
     // measured (tools/microbench_xw.py): N = 1M / E = 16M: 456 -> 423 us with 32-row workgroups, N = 50 K: equal
     const int rows = tuning().xw_rows == 32 || (tuning().xw_rows == 0 && N >= 400000) ? 32 : 64;
     const size_t lds = sizeof(float) * ((size_t)rows * (Fin + 1) + (size_t)Fin * Fout);
-    if (lds > 64 * 1024)
-        return fail(STG_ERR_UNSUPPORTED, "stg_gcn_agg_transform: W (%d x %d) does not fit the 64 KB LDS budget", Fin, Fout);
+    // up to 64 KB without asking; larger weights (one workgroup per CU then: measured slower than GEMM + aggregation at
+    // 128 -> 128, profiles/r02_agg_transform_128.jsonl, so the layer never picks it) need the limit raised per kernel
+    if (lds > 150 * 1024)
+        return fail(STG_ERR_UNSUPPORTED, "stg_gcn_agg_transform: W (%d x %d) does not fit the LDS", Fin, Fout);
     if (N == 0) return 0;
     if (!x || !norm_row || !W || !out || !row_offsets)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg_transform: NULL pointer argument");
@@ -206,9 +208,19 @@ extern "C" int stg_gcn_agg_transform(const float *x, const float *norm_row, cons
     const int log2g = ilog2_ceil(lanes);
     const unsigned blocks = (unsigned)(((int64_t)N + rows - 1) / rows);
     hipStream_t st = static_cast<hipStream_t>(stream);
+#define STG_XW_RAISE(KERN)                                                                                     \
+    if (lds > 64 * 1024) {                                                                                     \
+        const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(KERN),                       \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        if (e_ != hipSuccess) return fail((int)e_, "stg_gcn_agg_transform: %s", hipGetErrorString(e_));        \
+    }
 #define STG_XW_(LG, WVS)                                                                                           \
     {                                                                                                          \
         constexpr int WV = WVS;                                                                                \
+        STG_XW_RAISE((gcn_agg_xw_kernel<LG, true, WV, 32>))                                                    \
+        STG_XW_RAISE((gcn_agg_xw_kernel<LG, false, WV, 32>))                                                   \
+        STG_XW_RAISE((gcn_agg_xw_kernel<LG, true, WV>))                                                        \
+        STG_XW_RAISE((gcn_agg_xw_kernel<LG, false, WV>))                                                       \
         if (rows == 32) {                                                                                      \
             if (ew_edge)                                                                                       \
                 hipLaunchKernelGGL((gcn_agg_xw_kernel<LG, true, WV, 32>), dim3(blocks), dim3(WV * kWave), lds, st, x, \
@@ -241,5 +253,6 @@ extern "C" int stg_gcn_agg_transform(const float *x, const float *norm_row, cons
     }
 #undef STG_XW
 #undef STG_XW_
+#undef STG_XW_RAISE
     return check_launch("stg_gcn_agg_transform");
 }

@@ -141,8 +141,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int soB = (r0 + 2 * u) * ldj[j] * (int)sizeof(float);
-                b[u][j] = second[j] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB2, voB[j], soB, 0))
-                                    : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB1, voB[j], soB, 0));
+                b[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(second[j] ? rsB2 : rsB1, voB[j], soB, 0));
             }
         }
     };

@@ -652,8 +652,9 @@ def bias_act_bwd(g: torch.Tensor, out: torch.Tensor | None, want_colsum: bool = 
     return (g_act if out is not None else g), colsum
 
 
-def agg_transform_supported(fin: int, fout: int) -> bool:
-    return fin % 4 == 0 and fin >= 16 and fout % 32 == 0 and 4 * (64 * (fin + 1) + fin * fout) <= 64 * 1024
+def agg_transform_supported(fin: int, fout: int, big_lds: bool = False) -> bool:
+    """``big_lds``: also shapes whose weight needs more than 64 KB of LDS (one workgroup per CU: only for measurements)."""
+    return fin % 4 == 0 and fin >= 16 and fout % 32 == 0 and 4 * (64 * (fin + 1) + fin * fout) <= (150 if big_lds else 64) * 1024
 
 
 def gcn_agg_transform(x: torch.Tensor, W: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor,
@@ -667,7 +668,7 @@ def gcn_agg_transform(x: torch.Tensor, W: torch.Tensor, norm_row: torch.Tensor, 
     if x.dim() != 2 or x.shape[0] != N or W.dim() != 2 or W.shape[0] != x.shape[1]:
         raise ValueError(f"gcn_agg_transform: x {tuple(x.shape)} / W {tuple(W.shape)} do not match the graph ({N} nodes)")
     fin, fout = int(W.shape[0]), int(W.shape[1])
-    if not agg_transform_supported(fin, fout):
+    if not agg_transform_supported(fin, fout, big_lds=True):
         raise ValueError(f"gcn_agg_transform does not cover {fin} -> {fout}")
     norm_row, norm_col = _f32(norm_row, "norm_row", dev), _f32(norm_col, "norm_col", dev)
     if norm_row.numel() != N or norm_col.numel() != N or csr.row_offset.device != dev:
@@ -1083,6 +1084,8 @@ def tgcn_window_loss(partials: torch.Tensor, steps: int, N: int, step_loss: torc
     if partials.dim() != 2 or partials.shape[0] < steps:
         raise ValueError("partials must be [steps, tiles]")
     cost = torch.empty(1, dtype=torch.float32, device=dev)
+    if step_loss is None:
+        step_loss = torch.empty(int(steps), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _C.check(_C.lib.stg_tgcn_window_loss(_ptr(partials), int(steps), int(N), int(partials.stride(0)), _ptr(step_loss),
                                              _ptr(cost), _stream_ptr(dev)))
@@ -1108,6 +1111,8 @@ def partial_sums_loss(partials: torch.Tensor, steps: int, count: int, inv_n: flo
     """cost [1] = sum over the first ``steps`` rows of ``partials`` of (sum of the row's first ``count`` values) * inv_n."""
     dev = partials.device
     cost = torch.empty(1, dtype=torch.float32, device=dev)
+    if step_loss is None:
+        step_loss = torch.empty(int(steps), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _C.check(_C.lib.stg_partial_sums_loss(_ptr(partials), int(steps), int(count), int(partials.stride(0)), float(inv_n),
                                               _ptr(step_loss), _ptr(cost), _stream_ptr(dev)))
