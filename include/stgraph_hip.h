@@ -46,6 +46,8 @@ const char *stg_last_error_string(void);
  * of T consecutive workgroups' rows, 1 = plain round robin), "gcn_addr32" (0 = auto, 1 = never use 32-bit gather
  * offsets), "gcn_block" (0 = auto; 64 / 128 / 256 threads per workgroup of the plain stg_gcn_agg* launch),
  * "gcn_tile" (edge-dealt kernel for rows of <= 32 floats: 0 = auto, 1 = never, 2 = whenever legal),
+ * "gcn_tile_rows" (its rows per workgroup: 0 = one per lane group, else 8 .. 256), "gcn_tile_pipe" (its
+ * persistent, software-pipelined form: 0 / 1 = off, 2 = whenever the tile kernel runs; measured equal),
  * "xw_waves" (0 = auto; 4 / 8 waves per workgroup of stg_gcn_agg_transform), "cell_rows" (0 = auto; 16 / 32 rows
  * per tile of stg_tgcn_cell_fused_fwd). */
 int stg_set_tuning(const char *key, int value);

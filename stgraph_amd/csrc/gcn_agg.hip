@@ -473,10 +473,10 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
     const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
     const float *__restrict__ ew_edge, float *__restrict__ out, const int *__restrict__ row_offsets,
     const int *__restrict__ column_indices, int N, int F, int F_active, const float *__restrict__ bias, int act,
-    int xcd_tile)
+    int xcd_tile, int rows)
 {
     constexpr int G = 1 << LOG2G, VEC = 4, W = G * VEC * VPL;
-    constexpr int RB = kBlock / G;                  // rows per workgroup = lane groups per workgroup
+    constexpr int RB = kBlock / G;                  // lane groups per workgroup; it owns `rows` <= RB rows (see launch)
     constexpr int U = STG_TILE_U;                   // 4: measured best (8: F = 7 0.53 -> 0.46)                           // edges per lane group and chunk
     constexpr int CAP = U * RB;                     // edges per chunk: a 16 KB (VPL = 1) / 32 KB tile
     __shared__ int offs[RB + 1];
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
         const int s = vb >> 3;
         vb = ((s / xcd_tile) * 8 + (vb & 7)) * xcd_tile + s % xcd_tile;
     }
-    const int r0 = vb * RB;
+    const int r0 = vb * rows;
     if (r0 >= N) return;                            // whole workgroup (grid padded to a multiple of 8 runs)
     const int group = threadIdx.x >> LOG2G, j = threadIdx.x & (G - 1);
     int foff[VPL], goff[VPL];
@@ -499,11 +499,12 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
         goff[p] = min(foff[p], F_active - VEC);     // ragged width: overlapping last window
     }
 
-    for (int i = threadIdx.x; i <= RB; i += kBlock) offs[i] = row_offsets[min(r0 + i, N)];
+    for (int i = threadIdx.x; i <= rows; i += kBlock) offs[i] = row_offsets[min(r0 + i, N)];
     __syncthreads();
-    const int e0 = offs[0], e1 = offs[RB];
-    const int row = r0 + group;
-    const int rb = offs[group], re = offs[group + 1];            // rows >= N: empty (both = row_offsets[N])
+    const int e0 = offs[0], e1 = offs[rows];
+    const bool has_row = group < rows;
+    const int row = has_row ? r0 + group : N;
+    const int rb = has_row ? offs[group] : 0, re = has_row ? offs[group + 1] : 0;   // rows >= N: empty (both = row_offsets[N])
 
     float acc[VPL][VEC];
 #pragma unroll
@@ -613,6 +614,203 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_tile_kernel(
     }
 }
 
+// ---- the same, software-pipelined over a workgroup's SEQUENCE of row blocks ------------------------------------------
+// A workgroup of the kernel above lives through three dependent memory round trips (row offsets -> index and
+// coefficients -> gathered rows) and two barriers for ~ 500 edges; on the Cora-shaped roofline graph the L2 request
+// rate is 14 % of its peak and the HBM rate 0.36 (r02_pmc_cora_l2.json): the time is those round trips, not bytes.  Here
+// the grid is what is resident at once and a workgroup walks row blocks s, s + S, ... of its XCD's list (the same
+// XCD-local runs of 64 blocks as above); while the gathers of one chunk of edges are in flight it already holds the
+// NEXT chunk's index and coefficients (issued one chunk ahead, of the same block or the first of the next) and the
+// row offsets of the block after next (an LDS ring of three), so that one gather round trip per chunk remains
+// exposed.  Products, the order of the additions and the epilogue are those of gcn_agg_tile_kernel: bit-identical.
+// MEASURED (Cora x 1024, round 2): F = 7 0.540 against 0.536 of the roofline, F = 4 0.562 / 0.563, F = 8 0.569 / 0.578
+// -- no gain, so the exposed round trips are not what bounds the narrow rows: kept behind `gcn_tile_pipe` = 2 (tested,
+// never taken by default).  What the counters show instead (profiles/r02_pmc_cora_l1.json): every 28-byte row costs
+// a 128-byte line through the CU's vector L1 (9.4 M L2 read requests = 1.2 GB per launch for 0.38 GB of rows, L1 hit
+// rate 51 %, L2 hit rate 74 %, L2 read latency 376 clk), and the L1's in-order pipe spends 56 % of its cycles stalled
+// on lines that are still in flight (TCP_PENDING_STALL_CYCLES / TCP_GATE_EN1).  Dealing each chunk's edges in column
+// order (a per-graph plan of sorted columns + tile slots, so that one gather instruction covers neighbouring lines)
+// was bit-identical and moved F = 7 from 0.493 to 0.508 and F = 4 from 0.56 to 0.63 -- not worth a second copy of
+// the index; dropped.
+constexpr int kTileRun = 64;
+
+template <int LOG2G, bool HAS_EW, bool EPI, bool A32>
+__global__ __launch_bounds__(kBlock) void gcn_agg_tile_pipe_kernel(
+    const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
+    const float *__restrict__ ew_edge, float *__restrict__ out, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, int N, int F, int F_active, const float *__restrict__ bias, int act,
+    int nblocks, int rows, int last_edge)
+{
+    constexpr int G = 1 << LOG2G, VEC = 4, W = G * VEC;
+    constexpr int RB = kBlock / G;                  // lane groups; a block is `rows` <= RB rows
+    constexpr int U = STG_TILE_U;
+    constexpr int CAP = U * RB;
+    __shared__ int offs[3][RB + 1];
+    __shared__ __attribute__((aligned(16))) float tile[CAP * W];
+
+    const int xcd = (int)blockIdx.x & 7, s = (int)blockIdx.x >> 3, S = (int)gridDim.x >> 3;
+    auto block_of = [&](int p) { return ((p / kTileRun) * 8 + xcd) * kTileRun + p % kTileRun; };
+    const int tid = (int)threadIdx.x;
+    const int group = tid >> LOG2G, j = tid & (G - 1);
+    const int foff = j * VEC;
+    const bool fok = foff < F_active;
+    const int goff = min(foff, F_active - VEC);     // ragged width: overlapping last window
+    const bool has_row = group < rows;
+
+    int p = s;
+    int b = block_of(p);
+    if (b >= nblocks) return;
+    // Every global load below is UNCONDITIONAL (clamped address, value dropped afterwards): loads under a branch make
+    // the compiler wait for all outstanding loads (s_waitcnt vmcnt(0)) at the join, which would serialise exactly the
+    // round trips this kernel overlaps.
+    // row offsets of a block: entry tid by every thread, entry RB (only when rows can be kBlock) by all, same address
+    auto offs_load = [&](int blk, int &o0, int &o1) {
+        const int r0 = min(blk, nblocks - 1) * rows;
+        o0 = row_offsets[min(r0 + tid, N)];
+        o1 = 0;
+        if constexpr (RB == kBlock) o1 = row_offsets[min(r0 + RB, N)];
+    };
+    auto offs_store = [&](int slot, int o0, int o1) {
+        if (tid <= RB) offs[slot][tid] = o0;
+        if (RB == kBlock && tid == 0) offs[slot][RB] = o1;
+    };
+    {
+        int o0, o1, q0, q1;
+        offs_load(b, o0, o1);
+        offs_load(block_of(p + S), q0, q1);
+        offs_store(0, o0, o1);
+        offs_store(1, q0, q1);
+    }
+    __syncthreads();
+
+    int cN[U];
+    float ncN[U], wN[U];
+    auto idx_load = [&](int cb, int cnt) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int el = group + u * RB;
+            const int at = min(cb + min(el, max(cnt - 1, 0)), last_edge);
+            const int cc = column_indices[at];
+            const float nn = nc_edge[at];
+            cN[u] = el < cnt ? cc : 0;
+            ncN[u] = el < cnt ? nn : 0.f;
+            wN[u] = 1.f;
+            if constexpr (HAS_EW) {
+                const float ww = ew_edge[at];
+                wN[u] = el < cnt ? ww : 1.f;
+            }
+        }
+    };
+    idx_load(offs[0][0], min(CAP, offs[0][rows] - offs[0][0]));
+    float bv[VEC] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI) {
+        if (bias) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) bv[q] = bias[goff + q];
+        }
+    }
+
+    for (int k = 0;; ++k, p += S) {
+        const int cur = k % 3, nxt = (k + 1) % 3, nn = (k + 2) % 3;
+        b = block_of(p);
+        const bool has1 = block_of(p + S) < nblocks;
+        const int b2 = block_of(p + 2 * S);
+        const bool has2 = b2 < nblocks;
+        int o0, o1;
+        offs_load(b2, o0, o1);
+        const int e0 = offs[cur][0], e1 = offs[cur][rows];
+        const int row = has_row ? b * rows + group : N;
+        const int rb = has_row ? offs[cur][group] : 0, re = has_row ? offs[cur][group + 1] : 0;
+        const float nr = norm_row[min(row, N - 1)];                 // early: its latency hides behind the chunk
+
+        float acc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+        int cb = e0;
+        do {
+            const int cnt = max(0, min(CAP, e1 - cb));
+            int c[U];
+            float nc[U], w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                c[u] = cN[u];
+                nc[u] = ncN[u];
+                w[u] = wN[u];
+            }
+            // ---- B: this chunk's gathers, then the next chunk's index and coefficients behind them
+            float v[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if constexpr (A32) {
+                    const uint32_t off = __umul24((uint32_t)c[u], (uint32_t)F * 4u) + (uint32_t)goff * 4u;
+                    vec_load_g<VEC>(v[u], reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + off));
+                } else {
+                    vec_load_g<VEC>(v[u], x + (int64_t)c[u] * F + goff);
+                }
+            }
+            {
+                int ncb = cb + CAP, ncnt = 0;
+                if (ncb < e1) ncnt = min(CAP, e1 - ncb);
+                else if (has1) {
+                    ncb = offs[nxt][0];
+                    ncnt = min(CAP, offs[nxt][rows] - ncb);
+                }
+                idx_load(ncb, ncnt);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int el = group + u * RB;
+                float t[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    t[q] = nc[u] * v[u][q];                         // Mul(norm_inb, h_inb)
+                    if constexpr (HAS_EW) t[q] = t[q] * w[u];       // Mul(., edge_weight)
+                }
+                if (el < cnt && fok) vec_store<VEC>(tile + el * W + foff, t);
+            }
+            __syncthreads();
+            // ---- C
+            {
+                const int lo = max(rb, cb) - cb, hi = min(re, cb + cnt) - cb;
+                for (int el = lo; el < hi; el += 4) {
+                    float t[4][VEC];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) vec_load<VEC>(t[u], tile + min(el + u, CAP - 1) * W + foff);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (el + u < hi) {
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) acc[q] = acc[q] + t[u][q];      // AggSum, CSR order
+                        }
+                    }
+                }
+            }
+            cb += CAP;
+            if (cb < e1) __syncthreads();           // the tile is rewritten by the next chunk
+        } while (cb < e1);
+        // ---- D
+        {
+            float o[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) o[q] = acc[q] * nr;       // Mul(., norm_cen)
+            if constexpr (EPI) {
+                if (bias) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o[q] = o[q] + bv[q];
+                }
+                if (act == STG_ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o[q] = o[q] < 0.f ? 0.f : o[q];
+                }
+            }
+            if (row < N && fok) vec_store_g<VEC>(out + (int64_t)row * F + goff, o);
+        }
+        if (!has1) break;
+        if (has2) offs_store(nn, o0, o1);
+        __syncthreads();                            // ring slot nn visible; tile free for the next block
+    }
+}
+
 // dst[i] = table[idx[i]]
 __global__ void edge_gather_kernel(float *__restrict__ dst, const float *__restrict__ table,
                                    const int *__restrict__ idx, int64_t n)
@@ -690,14 +888,48 @@ void launch(const GcnArgs &a)
         if (!a.node_ids && a.F_active >= 4 &&
             (tuning().gcn_tile == 2 || (tuning().gcn_tile == 0 && LOG2G <= 1 && !merged && blocks256 > 256 * 8))) {
             constexpr int TLG = LOG2G, VPL = 1;
-            constexpr int rb = kBlock >> TLG;
+            // Rows per workgroup: as many as its lane groups.  Fewer (`gcn_tile_rows`), so that a mean workgroup's edges
+            // fit ONE chunk of the tile (Cora-shaped, 4.9 edges per row with the self loops: 128 rows = 627 edges
+            // against 512 per chunk; the lane groups without a row still take their share of the edges), measured
+            // the same within noise (F = 7: 0.51-0.54 at 64 .. 128 rows): the second, short chunk is not the cost.
+            constexpr int lane_groups = kBlock >> TLG;
+            int rb = lane_groups;
+            if (tuning().gcn_tile_rows > 0) rb = std::min(tuning().gcn_tile_rows, lane_groups);
             int64_t tb = ((int64_t)a.N + rb - 1) / rb;
             int tt = tuning().gcn_xcd_tile > 0 ? tuning().gcn_xcd_tile : kXcdTile;
             if (tb < 16 * tt) tt = 1;
             if (tt > 1) tb = (tb + 8 * tt - 1) / (8 * tt) * (8 * tt);
+            if constexpr (VPL == 1) {
+                // more row blocks than are resident at once: the persistent, software-pipelined form
+                auto pipe = [&](auto kernel, int *cache) {
+                    int dev = 0;
+                    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
+                    if (cache[dev] == 0) {
+                        int per_cu = 0, cus = 0;
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess ||
+                            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev == 63 ? 0 : dev) !=
+                                hipSuccess)
+                            per_cu = 4, cus = 256;
+                        cache[dev] = std::max(per_cu * cus, 8);
+                    }
+                    const int64_t nb = ((int64_t)a.N + rb - 1) / rb;
+                    // (its unconditional loads need one valid edge: a.E is 0 when unknown or when there is none)
+                    if (a.E <= 0 || a.E > 0x7fffffffll || tuning().gcn_tile_pipe != 2) return false;
+                    const int64_t grid = (std::min<int64_t>(cache[dev], nb) + 7) / 8 * 8;
+                    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kBlock), 0, a.stream, a.x, a.norm_row,
+                                       a.norm_col, a.ew, a.out, a.row_offsets, a.column_indices, a.N, a.F,
+                                       a.F_active, a.bias, a.act, (int)nb, rb, (int)(a.E - 1));
+                    return true;
+                };
+                static int resident32[64] = {}, resident64[64] = {};
+
+                if (a32 ? pipe(gcn_agg_tile_pipe_kernel<TLG, HAS_EW, EPI, true>, resident32)
+                        : pipe(gcn_agg_tile_pipe_kernel<TLG, HAS_EW, EPI, false>, resident64))
+                    return;
+            }
             auto go = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3((unsigned)tb), dim3(kBlock), 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew,
-                                   a.out, a.row_offsets, a.column_indices, a.N, a.F, a.F_active, a.bias, a.act, tt);
+                                   a.out, a.row_offsets, a.column_indices, a.N, a.F, a.F_active, a.bias, a.act, tt, rb);
             };
             if (a32) go(gcn_agg_tile_kernel<TLG, VPL, HAS_EW, EPI, true>);
             else go(gcn_agg_tile_kernel<TLG, VPL, HAS_EW, EPI, false>);

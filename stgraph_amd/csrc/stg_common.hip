@@ -91,6 +91,17 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().gcn_addr32 = value;
         return 0;
     }
+    if (!std::strcmp(key, "gcn_tile_pipe")) {
+        if (value < 0 || value > 2) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_tile_pipe must be 0, 1 or 2");
+        tuning().gcn_tile_pipe = value;
+        return 0;
+    }
+    if (!std::strcmp(key, "gcn_tile_rows")) {
+        if (value < 0 || value > 256 || (value > 0 && value < 8))
+            return fail(STG_ERR_INVALID_ARGUMENT, "gcn_tile_rows must be 0 or in [8, 256]");
+        tuning().gcn_tile_rows = value;
+        return 0;
+    }
     if (!std::strcmp(key, "gcn_xcd_tile")) {
         if (value < 0 || value > 4096) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_xcd_tile must be in [0, 4096]");
         tuning().gcn_xcd_tile = value;

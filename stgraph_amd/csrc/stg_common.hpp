@@ -28,6 +28,8 @@ struct Tuning {
     int xw_waves = 0;              // gcn_agg_xw: 0 = auto, 4 / 8 waves per workgroup
     int cell_rows = 0;             // fused TGCN forward cell: 0 = auto (32-row tiles), 16 = 16-row tiles, 32
     int gcn_tile = 0;              // edge-dealt narrow-row kernel: 0 = auto (large grids), 1 = never, 2 = whenever legal
+    int gcn_tile_pipe = 0;         // its persistent software-pipelined form: 0 / 1 = off (measured: no gain), 2 = whenever the tile kernel runs
+    int gcn_tile_rows = 0;         // its rows per workgroup: 0 = as many as lane groups, else 8 .. lane groups
     int gcn_block = 0;             // 0 = auto; 64 / 128 / 256 = threads per workgroup of the plain gcn_agg launch
     int gcn_addr32 = 0;            // 0 = auto (32-bit gather offsets when the matrix allows); 1 = always 64-bit
     int gcn_xcd_tile = 0;          // 0 = auto; 1 = workgroups round-robin over XCDs; T = runs of T workgroups per XCD

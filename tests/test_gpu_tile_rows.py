@@ -1,7 +1,10 @@
 """The edge-dealt narrow-row kernel (gcn_agg_tile_kernel: a workgroup's rows = one contiguous edge range, edges dealt
 to lane groups, per-edge products staged in an LDS tile, per-row sums in CSR order): same additions in the same order,
 so bit-identical to the oracle's sequential loop and to the row-group kernel.  Forced (`gcn_tile` = 2) on small graphs
-for every supported width, and taken by itself (auto) on a graph larger than one resident grid."""
+for every supported width, and taken by itself (auto) on a graph larger than one resident grid.  Each case runs the
+one-block-per-workgroup form and the persistent, software-pipelined one (gcn_agg_tile_pipe_kernel, `gcn_tile_pipe` = 2:
+several row blocks per workgroup, index prefetch across chunk and block boundaries, the ring of row offsets), with
+the automatic and a small forced number of rows per block."""
 import numpy as np
 import pytest
 import torch
@@ -13,12 +16,17 @@ from tests.util import gcn_norm, random_graph
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def forced_tile():
+@pytest.fixture(params=[(1, 0), (2, 0), (2, 24)], ids=["block", "pipe", "pipe_rows24"])
+def forced_tile(request):
     from stgraph_amd import _C
+    pipe, rows = request.param
     _C.set_tuning("gcn_tile", 2)
+    _C.set_tuning("gcn_tile_pipe", pipe)
+    _C.set_tuning("gcn_tile_rows", rows)
     yield
     _C.set_tuning("gcn_tile", 0)
+    _C.set_tuning("gcn_tile_pipe", 0)
+    _C.set_tuning("gcn_tile_rows", 0)
 
 
 @pytest.mark.parametrize("F", [4, 5, 6, 7, 8, 9, 12, 13, 16, 20, 24, 31, 32])
@@ -98,6 +106,12 @@ def test_large_graph_takes_the_tile_kernel_by_itself(cuda, F):
     finally:
         _C.set_tuning("gcn_tile", 0)
     assert torch.equal(got, rows)
+    _C.set_tuning("gcn_tile_pipe", 1)
+    try:
+        block = kernels.gcn_agg(x, norm, norm, g.fwd)
+    finally:
+        _C.set_tuning("gcn_tile_pipe", 0)
+    assert torch.equal(got, block)
     # in-degree property: all-ones features, unit norms
     ones = torch.ones(n, 1, device=cuda)
     deg = kernels.gcn_agg(torch.ones(n, F, device=cuda), ones, ones, g.fwd)
