@@ -409,8 +409,10 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
     conv = GATConv(fin, D, H).to(device)
     x = torch.randn(n, fin, device=device, generator=gen).requires_grad_(True)
     R = torch.randn(n, H, D, device=device, generator=gen)
+    # forward + backward of the LAYER: the upstream gradient R is handed to backward() as it is (a `(out * R).sum()`
+    # loss costs three more passes over [N, H, D] each way that are not the layer's)
     for _ in range(3):
-        (conv(g, x) * R).sum().backward()
+        conv(g, x).backward(R)
     rec = []
     kernels.enable_launch_timing(rec)
     torch.cuda.synchronize()
@@ -418,7 +420,7 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
     for _ in range(layer_iters):
         conv.zero_grad()
         x.grad = None
-        (conv(g, x) * R).sum().backward()
+        conv(g, x).backward(R)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / layer_iters
     kernels.enable_launch_timing(None)

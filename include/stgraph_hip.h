@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 4
+#define STG_ABI_VERSION 5
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -332,7 +332,7 @@ int stg_gat_bwd(const float *A, const float *S, const float *out, const float *g
                 const int32_t *node_ids, int32_t N, int32_t H, int32_t D, int32_t HD_active,
                 float slope, void *stream);
 /* K2 with the target-only part hoisted: P[v,h] = sum_d (g/S)*out (one pass over the vertices,
- * P is an [N,H] scratch array) and per edge T = ((sum_d g*feat[u]) / S - P) * A * slope, so the
+ * P is a scratch array of 2 N H floats: P and 1/S, or, for H = 8, D = 64, S | P in 64 bytes per vertex) and per edge T = ((sum_d g*feat[u]) / S - P) * A * slope, so the
  * per-edge out[v] row gather (half of K2's traffic) disappears.  Same outputs as stg_gat_bwd
  * (grad_feat bit-identical; grad_el / T regrouped sums -- the reference forms them with atomicAdd
  * in an undefined order).  Computes all H*D columns (no *_active argument). */
@@ -361,6 +361,15 @@ int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t
  * gradient) from one extra MFMA per k-pair; colsum_A [dev, M floats]. */
 int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *colsum_A, int64_t K, int32_t M,
                            int32_t N, void *workspace, size_t workspace_bytes, void *stream);
+
+/* GATConv's input side as one launch: feat [N, H*D] = x [N, fin] W^T (W [H*D, fin], the layer's bias-free fc:
+ * reference nn/pytorch/static/gat_conv.py:43-48) and, from the accumulators, el / er [N, H] = sum_d feat[n,h,d] *
+ * attn_{l,r}[h,d] (what stg_gat_proj_fwd computes from feat).  MFMA fp32; results agree with x @ W^T followed by
+ * stg_gat_proj_fwd to fp32 rounding.  Supported: D = 64, even H, fin 32 or 64, H*64*(fin+4)*4 + 512 H <= 160 KB;
+ * else STG_ERR_UNSUPPORTED (callers run the GEMM and stg_gat_proj_fwd). */
+int stg_gat_fc_supported(int32_t fin, int32_t H, int32_t D);
+int stg_gat_fc_fwd(const float *x, const float *W, const float *attn_l, const float *attn_r, float *feat,
+                   float *el, float *er, int32_t N, int32_t fin, int32_t H, int32_t D, void *stream);
 
 /* GATConv's attention projections and their backward (nn/pytorch/static/gat_conv.py:43-45; torch ops in the
  * reference), one streaming pass each over feat [N,H,D]:

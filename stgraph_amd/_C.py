@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "stg_jit_compile", "stg_jit_free", "stg_jit_load", "stg_jit_get_function", "stg_jit_unload", "stg_jit_launch",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_layer_fwd", "stg_bias_act_bwd_workspace_bytes", "stg_bias_act_bwd",
     "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
-    "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
+    "stg_gat_fc_supported", "stg_gat_fc_fwd", "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
@@ -146,6 +146,10 @@ def _load() -> ctypes.CDLL:
     lib.stg_gcn_agg_transform.argtypes = [vp] * 10 + [i32, i32, i32, vp]
     lib.stg_edge_gather_f32.restype = ctypes.c_int
     lib.stg_edge_gather_f32.argtypes = [vp, vp, vp, i64, vp]
+    lib.stg_gat_fc_supported.restype = ctypes.c_int
+    lib.stg_gat_fc_supported.argtypes = [i32, i32, i32]
+    lib.stg_gat_fc_fwd.restype = ctypes.c_int
+    lib.stg_gat_fc_fwd.argtypes = [vp] * 7 + [i32, i32, i32, i32, vp]
     lib.stg_gat_fwd_k0.restype = ctypes.c_int
     lib.stg_gat_fwd_k0.argtypes = [vp] * 8 + [i32, i32, i32, f32, vp]
     lib.stg_gat_fwd_k1.restype = ctypes.c_int

@@ -326,11 +326,15 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_kernel(
 // 34.7 GB at |E| = 8M, H*D = 512) disappears.  The reference sums these terms with atomicAdd in an
 // undefined order, so the regrouping stays inside its own run-to-run spread (tested to 1e-4).
 // (z = s - s is 0 or NaN, so the LeakyReLU derivative `z > 0 ? 1 : slope` is always `slope`.)
+// The prepass also leaves 1.0f / S[v,h] behind P (P is [2][N][H]): the per-edge kernel's T term then loads the
+// quotient the emitted unit forms per edge (same value) -- an IEEE fp32 division is ~ 10 VALU instructions per wave,
+// per edge and 256-float chunk.  alpha = A / S stays a division: grad_feat remains bit-identical to the emitted unit.
 template <int VEC, int LOG2G, int CHUNKS, bool POW2>
 __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_kernel(
     const float *__restrict__ S, const float *__restrict__ outp, const float *__restrict__ g,
     float *__restrict__ P, int N, int H, int D)
 {
+    float *__restrict__ invS = P + (int64_t)N * H;
     constexpr int G = 1 << LOG2G;
     __shared__ float lds[POW2 ? 1 : kBlock];
     float *lds_wave = lds + (POW2 ? 0 : (threadIdx.x & ~(kWave - 1)));
@@ -357,12 +361,17 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_kernel(
                 for (int i = 0; i < VEC; ++i) p = p + (gv[i] / s) * ov[i];
             }
             const float tot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
-            if (fok && (foff % D) == 0) P[(int64_t)v * H + h] = tot;
+            if (fok && (foff % D) == 0) {
+                P[(int64_t)v * H + h] = tot;
+                invS[(int64_t)v * H + h] = 1.0f / S[(int64_t)v * H + h];
+            }
         }
     }
 }
 
-template <int VEC, int LOG2G, int CHUNKS, int UNROLL, bool POW2>
+// ROW16: a head is exactly one DPP row of 16 lanes (D = 16 * VEC, e.g. D = 64 at 16 B per lane): its per-edge dot
+// product is four DPP adds instead of four ds_bpermute_b32 + adds.
+template <int VEC, int LOG2G, int CHUNKS, int UNROLL, bool POW2, bool ROW16>
 __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
     const float *__restrict__ A, const float *__restrict__ S, const float *__restrict__ P,
     const float *__restrict__ g, const float *__restrict__ feat, float *__restrict__ grad_feat,
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
     const int HD = H * D;
     const int LH = D / VEC;
     const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+    const float *__restrict__ invS = P + (int64_t)N * H;
 
     for (int fbase = 0; fbase < HD; fbase += G * VEC * CHUNKS) {
         float a13[CHUNKS][VEC], fu[CHUNKS][VEC], gel[CHUNKS];
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
             }
             for (int k = 0; k < cnt_max; k += U) {
                 float gv[U][CHUNKS][VEC];
-                float av[U][CHUNKS], sv[U][CHUNKS], pv[U][CHUNKS];
+                float av[U][CHUNKS], sv[U][CHUNKS], iv[U][CHUNKS], pv[U][CHUNKS];
                 int ek[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -417,10 +427,11 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
                         if (kk < cnt && fok[ch]) {
                             av[u][ch] = A[(int64_t)ek[u] * H + hh[ch]];
                             sv[u][ch] = S[(int64_t)ck * H + hh[ch]];
+                            iv[u][ch] = invS[(int64_t)ck * H + hh[ch]];          // 1.0f / S
                             pv[u][ch] = P[(int64_t)ck * H + hh[ch]];
                             vec_load<VEC>(gv[u][ch], g + (int64_t)ck * HD + foff[ch]);
                         } else {
-                            av[u][ch] = 0.f; sv[u][ch] = 1.f; pv[u][ch] = 0.f;
+                            av[u][ch] = 0.f; sv[u][ch] = 1.f; iv[u][ch] = 1.f; pv[u][ch] = 0.f;
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) gv[u][ch][i] = 0.f;
                         }
@@ -437,12 +448,14 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) {
                                 a13[ch][i] = a13[ch][i] + gv[u][ch][i] * alpha;
-                                p = p + gv[u][ch][i] * fu[ch][i];
+                                p = __builtin_fmaf(gv[u][ch][i], fu[ch][i], p);     // (a regrouped sum either way)
                             }
                         }
-                        const float dot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
+                        float dot;
+                        if constexpr (ROW16) dot = row16_sum_lane0(p);
+                        else dot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
                         if (on && lead[ch]) {
-                            const float tv = ((dot * (1.0f / sv[u][ch]) - pv[u][ch]) * av[u][ch]) * slope;
+                            const float tv = ((dot * iv[u][ch] - pv[u][ch]) * av[u][ch]) * slope;
                             T[(int64_t)ek[u] * H + hh[ch]] = tv;
                             gel[ch] = gel[ch] + tv;
                         }
@@ -455,6 +468,130 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
             if (ri.valid && lead[ch]) grad_el[(int64_t)ri.r * H + hh[ch]] = gel[ch];
             if (ri.valid && fok[ch]) vec_store<VEC>(grad_feat + (int64_t)ri.r * HD + foff[ch], a13[ch]);
         }
+    }
+}
+
+// ----------------------------------------------- K2, factored form, H = 8 heads of D = 64 (BASELINE configs[2])
+// One wave per source row, 16 B per lane, two 256-float chunks = 4 heads each; a head is one DPP row of 16 lanes.
+// In the general kernel above every lane loads its head's A, S, 1/S and P per edge AND chunk: eight vector loads = eight
+// L1 misses per edge next to the eight 128-byte lines of the gathered g row (measured: 3.03 ms with them, 2.53 without;
+// K1, which needs none of them, runs the same gather in 2.33).  Here the target's 24 scalars sit in ONE 128-byte line
+// (pack[v] = S[8] | P[8], 64 bytes, written by the prepass) that lanes 0-15 load with one instruction, A[e, 0..7]
+// is one more (lanes 0-7), and alpha = A / S, 1.0f / S (the same divisions) and the T term are formed ONCE per edge on lanes 0-7
+// (lane = head); ds_bpermute_b32 hands alpha to the lanes of its head and brings the eight per-head dot products (DPP
+// row sums, valid in each row's lane 0) back.  T and grad_el leave as 32 contiguous bytes from lanes 0-7.
+__global__ __launch_bounds__(kBlock) void gat_bwd_prepass_h8d64_kernel(
+    const float *__restrict__ S, const float *__restrict__ outp, const float *__restrict__ g,
+    float *__restrict__ pack, int N)
+{
+    constexpr int H = 8, HD = 512;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int v = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (v >= N) return;                              // whole wave
+    float s = 1.f;
+    if (lane < H) s = S[(int64_t)v * H + lane];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        float gv[4], ov[4];
+        vec_load<4>(gv, g + (int64_t)v * HD + ch * 256 + lane * 4);
+        vec_load<4>(ov, outp + (int64_t)v * HD + ch * 256 + lane * 4);
+        // this lane's head: 4 ch + lane / 16; its S from lane (4 ch + lane / 16)
+        const float sh = __int_as_float(__builtin_amdgcn_ds_bpermute((4 * ch + (lane >> 4)) * 4, __float_as_int(s)));
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p = p + (gv[i] / sh) * ov[i];
+        const float tot = row16_sum_lane0(p);
+        if ((lane & 15) == 0) pack[(int64_t)v * 16 + 8 + 4 * ch + (lane >> 4)] = tot;
+    }
+    if (lane < H) pack[(int64_t)v * 16 + lane] = s;
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(kBlock) void gat_bwd_fact_h8d64_kernel(
+    const float *__restrict__ A, const float *__restrict__ pack, const float *__restrict__ g,
+    const float *__restrict__ feat, float *__restrict__ grad_feat, float *__restrict__ grad_el,
+    float *__restrict__ T, const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
+    const int *__restrict__ eids, const int *__restrict__ node_ids, int N, float slope)
+{
+    constexpr int H = 8, HD = 512, U = UNROLL;
+    const int lane = threadIdx.x & (kWave - 1);
+    const RowInfo ri = row_prologue<6>(row_offsets, node_ids, N);
+    float a13[2][4], fu[2][4];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a13[ch][i] = 0.f; fu[ch][i] = 0.f; }
+        if (ri.valid) vec_load<4>(fu[ch], feat + (int64_t)ri.r * HD + ch * 256 + lane * 4);
+    }
+    float gel = 0.f;                                  // lanes 0-7: head = lane
+    const int from_head0 = (lane >> 4) * 4, from_head1 = (4 + (lane >> 4)) * 4;   // bpermute byte addresses
+    const int from_lead = ((lane & 3) * 16) * 4;     // lanes 0-7: lane 0 of the row that holds head (lane & 3) of a chunk
+    const int from_p = ((lane & 7) + 8) * 4;
+    for (int base = 0; base < ri.max_deg; base += kWave) {
+        const int cnt = ri.deg - base;
+        const int cnt_max = min(kWave, ri.max_deg - base);
+        int c = 0, ev = 0;
+        if (lane < cnt) {
+            c = column_indices[ri.beg + base + lane];
+            ev = eids[ri.beg + base + lane];
+        }
+        for (int k = 0; k < cnt_max; k += U) {
+            float gv[U][2][4], X[U], Y[U];
+            int ek[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = k + u;
+                const int ck = __builtin_amdgcn_readlane(c, kk & (kWave - 1));
+                ek[u] = __builtin_amdgcn_readlane(ev, kk & (kWave - 1));
+                if (kk < cnt) {                       // wave-uniform: one row per wave
+                    X[u] = pack[(int64_t)ck * 16 + (lane & 15)];
+                    Y[u] = A[(int64_t)ek[u] * H + (lane & 7)];
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) vec_load<4>(gv[u][ch], g + (int64_t)ck * HD + ch * 256 + lane * 4);
+                } else {
+                    X[u] = 1.f;
+                    Y[u] = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gv[u][ch][i] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k + u < cnt) {
+                    const float alpha8 = Y[u] / X[u];                       // lanes 0-7: A / S
+                    float dot[2];
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const float alpha = __int_as_float(
+                            __builtin_amdgcn_ds_bpermute(ch ? from_head1 : from_head0, __float_as_int(alpha8)));
+                        float p = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a13[ch][i] = a13[ch][i] + gv[u][ch][i] * alpha;
+                            p = __builtin_fmaf(gv[u][ch][i], fu[ch][i], p);     // (a regrouped sum either way)
+                        }
+                        dot[ch] = row16_sum_lane0(p);
+                    }
+                    const float d0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from_lead, __float_as_int(dot[0])));
+                    const float d1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from_lead, __float_as_int(dot[1])));
+                    const float inv = 1.0f / X[u];                          // lanes 0-7
+                    const float pv = __int_as_float(__builtin_amdgcn_ds_bpermute(from_p, __float_as_int(X[u])));
+                    const float dt = (lane & 4) ? d1 : d0;
+                    const float tv = ((dt * inv - pv) * Y[u]) * slope;
+                    if (lane < H) {
+                        T[(int64_t)ek[u] * H + lane] = tv;
+                        gel = gel + tv;
+                    }
+                }
+            }
+        }
+    }
+    if (ri.valid) {
+        if (lane < H) grad_el[(int64_t)ri.r * H + lane] = gel;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) vec_store<4>(grad_feat + (int64_t)ri.r * HD + ch * 256 + lane * 4, a13[ch]);
     }
 }
 
@@ -654,14 +791,26 @@ extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float 
                     "stg_gat_bwd_factored: head width D=%d (H=%d) is outside the supported range "
                     "(D/vec <= 64; non power-of-two D/vec needs H*D/vec <= 64)", D, H);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (H == 8 && D == 64 && p.vec == 4) {
+        hipLaunchKernelGGL(gat_bwd_prepass_h8d64_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)),
+                           dim3(kBlock), 0, st, S, out, g, P, N);
+        hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, P, g, feat,
+                           grad_feat, grad_el, T, row_offsets, column_indices, eids, node_ids, N, slope);
+        return check_launch("stg_gat_bwd_factored");
+    }
 #define STG_K2F(VEC, CH, UN, P2)                                                                           \
     STG_SWITCH_LOG2G(p.chunks > 1 ? 6 : p.log2g, {                                                         \
         constexpr int LGE = (CH > 1 ? 6 : LG);                                                             \
         hipLaunchKernelGGL((gat_bwd_prepass_kernel<VEC, LGE, CH, P2>), dim3(grid_for(N, LGE)), dim3(kBlock), \
                            0, st, S, out, g, P, N, H, D);                                                  \
-        hipLaunchKernelGGL((gat_bwd_fact_kernel<VEC, LGE, CH, UN, P2>), dim3(grid_for(N, LGE)),            \
-                           dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,      \
-                           column_indices, eids, node_ids, N, H, D, slope);                                \
+        if (P2 && LH == 16 && LGE >= 4)                                                                    \
+            hipLaunchKernelGGL((gat_bwd_fact_kernel<VEC, LGE, CH, UN, P2, true>), dim3(grid_for(N, LGE)),  \
+                               dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,  \
+                               column_indices, eids, node_ids, N, H, D, slope);                            \
+        else                                                                                               \
+            hipLaunchKernelGGL((gat_bwd_fact_kernel<VEC, LGE, CH, UN, P2, false>), dim3(grid_for(N, LGE)), \
+                               dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,  \
+                               column_indices, eids, node_ids, N, H, D, slope);                            \
     })
     /* two-chunk rows (H*D = 512 at cfg3): unroll 2, not 4 -- 101 -> 80-odd VGPRs buys a fifth and sixth wave per   \
        SIMD, worth more than the deeper gather queue (measured 3.42 -> 2.90 ms; unroll 1: 3.1) */                  \

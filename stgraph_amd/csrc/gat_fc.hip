@@ -1,0 +1,129 @@
+// GATConv's input side as ONE launch: feat = x W^T (the layer's bias-free `fc`) and, in its epilogue, the attention
+// projections el[n,h] = sum_d feat[n,h,d] attn_l[h,d], er likewise.
+//
+// Reference: nn/pytorch/static/gat_conv.py:43-48 (`self.fc(h_src).view(-1, H, D)`, `(feat_src * self.attn_l).sum(-1)`,
+// `(feat_dst * self.attn_r).sum(-1)`): three torch passes there; here rowgemm_wide (0.28 ms at |V| = 256 K, 64 -> 8 x 64)
+// + stg_gat_proj_fwd (0.13 ms, re-reads all of feat) become one kernel that writes feat once.
+//
+// Layout: the "row pieces" scheme of tgcn_step.hpp -- v_mfma_f32_16x16x4_f32 with the WEIGHT as the A operand, so a
+// lane's four accumulator values are four consecutive output columns of its own row: 16-byte stores, and the head's
+// dot product with attn_l / attn_r is 16 multiply-adds per lane and two cross-lane adds (the four lanes that share
+// a row).  W [H*D, FIN] stays in LDS in its torch Linear layout (rows padded by 4 floats: ~ 140 KB at 512 x 64), one
+// workgroup of 16 waves per CU, 16-row tiles dealt wave-major; a tile is 128 output columns (two heads) at a time:
+// 8 accumulators, 128 MFMAs, then the epilogue.  MFMA-bound: 512 MFMAs x 32 cycles per tile and SIMD wave.
+// Results agree with rocBLAS / the unfused pair to fp32 rounding (k order (j, i, kq)); tests: 1e-5 relative.
+#include "tgcn_step.hpp"
+
+namespace stg {
+namespace {
+
+constexpr int kFcWaves = 16;
+constexpr int kFcCT = 8;             // column tiles (of 16) per pass = 128 columns = two heads of 64
+
+template <int FIN>
+__global__ __launch_bounds__(kFcWaves * 64) void gat_fc_kernel(
+    const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ attn_l,
+    const float *__restrict__ attn_r, float *__restrict__ feat, float *__restrict__ el, float *__restrict__ er,
+    int N, int H)
+{
+    constexpr int NT = kFcWaves * 64, LD = FIN + 4, J = FIN / 16, D = 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int HD = H * D;
+    float *Wl = lds, *al = Wl + HD * LD, *ar = al + HD;
+    stage_rows<NT>(Wl, LD, W, HD, FIN);
+    for (int i = threadIdx.x; i < HD; i += NT) {
+        al[i] = attn_l[i];
+        ar[i] = attn_r[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n16 = lane & 15, kq = lane >> 4;
+    const float *wrow = Wl + n16 * LD + 4 * kq;
+    const int ntiles = (N + 15) >> 4;
+    for (int tile = (int)blockIdx.x * kFcWaves + wave; tile < ntiles; tile += (int)gridDim.x * kFcWaves) {
+        const int row = tile * 16 + n16;
+        const bool ok = row < N;
+        const float *xr = x + (int64_t)min(row, N - 1) * FIN + 4 * kq;
+        float4 xin[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) xin[j] = *reinterpret_cast<const float4 *>(xr + 16 * j);
+        float *frow = feat + (int64_t)row * HD + 4 * kq;
+        for (int g = 0; g < HD / 128; ++g) {
+            f32x4 acc[kFcCT];
+#pragma unroll
+            for (int ct = 0; ct < kFcCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_pieces<kFcCT, J, false>(acc, wrow + g * 128 * LD, LD, [&](int j) { return xin[j]; });
+            float pl[2] = {0.f, 0.f}, pr[2] = {0.f, 0.f};
+#pragma unroll
+            for (int ct = 0; ct < kFcCT; ++ct) {
+                const int col = g * 128 + ct * 16;
+                if (ok) *reinterpret_cast<float4 *>(frow + col) = to_f4(acc[ct]);
+                const float4 a = *reinterpret_cast<const float4 *>(al + col + 4 * kq);
+                const float4 b = *reinterpret_cast<const float4 *>(ar + col + 4 * kq);
+                pl[ct >> 2] += acc[ct][0] * a.x + acc[ct][1] * a.y + acc[ct][2] * a.z + acc[ct][3] * a.w;
+                pr[ct >> 2] += acc[ct][0] * b.x + acc[ct][1] * b.y + acc[ct][2] * b.z + acc[ct][3] * b.w;
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                float l = pl[h2], r = pr[h2];
+                l = l + __shfl_xor(l, 16, 64);
+                r = r + __shfl_xor(r, 16, 64);
+                l = l + __shfl_xor(l, 32, 64);
+                r = r + __shfl_xor(r, 32, 64);
+                if (ok && kq == 0) {
+                    el[(int64_t)row * H + 2 * g + h2] = l;
+                    er[(int64_t)row * H + 2 * g + h2] = r;
+                }
+            }
+        }
+    }
+}
+
+inline size_t fc_lds_bytes(int fin, int H) { return ((size_t)H * 64 * (fin + 4) + 2 * (size_t)H * 64) * sizeof(float); }
+
+inline bool fc_shape_ok(int fin, int H, int D)
+{
+    return D == 64 && H >= 2 && H % 2 == 0 && (fin == 32 || fin == 64) && fc_lds_bytes(fin, H) <= 160 * 1024;
+}
+
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_gat_fc_supported(int32_t fin, int32_t H, int32_t D) { return stg::fc_shape_ok(fin, H, D) ? 1 : 0; }
+
+extern "C" int stg_gat_fc_fwd(const float *x, const float *W, const float *attn_l, const float *attn_r, float *feat,
+                              float *el, float *er, int32_t N, int32_t fin, int32_t H, int32_t D, void *stream)
+{
+    using namespace stg;
+    if (N < 0 || !fc_shape_ok(fin, H, D))
+        return fail(STG_ERR_UNSUPPORTED, "stg_gat_fc_fwd: unsupported shape N=%d fin=%d H=%d D=%d", N, fin, H, D);
+    if (N == 0) return 0;
+    if (!x || !W || !attn_l || !attn_r || !feat || !el || !er)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fc_fwd: NULL pointer argument");
+    if ((int64_t)N * H * D > 0x7fffffffll * 4)
+        return fail(STG_ERR_UNSUPPORTED, "stg_gat_fc_fwd: N * H * D too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = fc_lds_bytes(fin, H);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int ntiles = (N + 15) / 16;
+    const int grid = std::max(1, std::min(cus, (ntiles + kFcWaves - 1) / kFcWaves));
+    auto go = [&](auto kernel, PerDeviceOnce &once) {
+        bool *done = once.slot();
+        if (!*done) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return fail((int)e, "stg_gat_fc_fwd: %s", hipGetErrorString(e));
+            *done = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kFcWaves * 64), lds, st, x, W, attn_l, attn_r, feat, el,
+                           er, N, H);
+        return 0;
+    };
+    static PerDeviceOnce once32, once64;
+    const int rc = fin == 32 ? go(gat_fc_kernel<32>, once32) : go(gat_fc_kernel<64>, once64);
+    if (rc) return rc;
+    return check_launch("stg_gat_fc_fwd");
+}

@@ -169,6 +169,18 @@ inline int ilog2_ceil(int v)
 }
 
 
+// Sum over the 16 lanes of each DPP row (row_shl 1, 2, 4, 8; lanes shifted in from outside the row contribute 0):
+// the total is valid in lane 0 of the row.  Four VALU instructions, no LDS-pipe traffic (a __shfl_xor butterfly is four
+// ds_bpermute_b32).
+__device__ __forceinline__ float row16_sum_lane0(float v)
+{
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, false));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x102, 0xf, 0xf, false));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0xf, false));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x108, 0xf, 0xf, false));
+    return v;
+}
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per kernel AND per device: a launcher keeps one of these as a
 // function-local static and raises the limit the first time it launches on each device of the process.
 struct PerDeviceOnce {

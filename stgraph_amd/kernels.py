@@ -763,7 +763,7 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
         st = _stream_ptr(dev)
         with _Timed("gat_bwd", ab["gat_bwd"], E * H * D):
             if full and _GAT_FACTORED:
-                P = torch.empty((N, H), dtype=torch.float32, device=dev)
+                P = torch.empty((N, 2 * H), dtype=torch.float32, device=dev)    # scratch: P and 1 / S (or S)
                 _C.check(_C.lib.stg_gat_bwd_factored(
                     _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(feat), _ptr(grad_feat), _ptr(grad_el), _ptr(T),
                     _ptr(P), _ptr(bwd.row_offset), _ptr(bwd.column_indices), _ptr(bwd.eids),
@@ -785,6 +785,29 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
 # ------------------------------------------------------- dense neighbour: weight gradient
 def gat_proj_supported(H: int, D: int) -> bool:
     return bool(_C.lib.stg_gat_proj_supported(int(H), int(D)))
+
+
+def gat_fc_supported(fin: int, H: int, D: int) -> bool:
+    return bool(_C.lib.stg_gat_fc_supported(int(fin), int(H), int(D)))
+
+
+def gat_fc_fwd(x: torch.Tensor, W: torch.Tensor, attn_l: torch.Tensor, attn_r: torch.Tensor, H: int, D: int):
+    """(feat [N,H,D], el, er [N,H,1]): ``feat = x @ W.T`` and the attention projections from its accumulators, one
+    launch (stg_gat_fc_fwd)."""
+    x = _f32(x, "x")
+    dev = x.device
+    N, fin = x.shape
+    W = _f32(W, "fc.weight", dev)
+    al, ar = _f32(attn_l, "attn_l", dev), _f32(attn_r, "attn_r", dev)
+    if tuple(W.shape) != (H * D, fin) or al.numel() != H * D or ar.numel() != H * D:
+        raise ValueError("fc.weight must be [H*D, fin], attn_l / attn_r [H, D]")
+    feat = torch.empty(N, H, D, dtype=torch.float32, device=dev)
+    el = torch.empty(N, H, 1, dtype=torch.float32, device=dev)
+    er = torch.empty(N, H, 1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("gat_fc", 4 * N * (fin + H * D + 2 * H) + 4 * H * D * fin, 2 * N * fin * H * D):
+        _C.check(_C.lib.stg_gat_fc_fwd(_ptr(x), _ptr(W), _ptr(al), _ptr(ar), _ptr(feat), _ptr(el), _ptr(er),
+                                       N, fin, H, D, _stream_ptr(dev)))
+    return feat, el, er
 
 
 def gat_proj_fwd(feat: torch.Tensor, attn_l: torch.Tensor, attn_r: torch.Tensor):

@@ -392,6 +392,64 @@ class _GatLayer(torch.autograd.Function):
         return dfeat, dal.view_as(attn_l), dar.view_as(attn_r), None, None, None, None
 
 
+class _GatFcLayer(torch.autograd.Function):
+    """The whole GATConv from its INPUT on: ``feat = x @ fc.weight.T`` with the attention projections in the GEMM's
+    epilogue (stg_gat_fc_fwd: feat is written once and not re-read for el / er), then K0 / K1; backward as _GatLayer,
+    followed by the fc backward of _Linear (input gradient on rocBLAS, weight gradient on the split-K MFMA kernel or
+    deferred to the end of backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w, attn_l, attn_r, fwd_csr, bwd_csr, use_nid, slope, H, D):
+        feat, el, er = kernels.gat_fc_fwd(x, w, attn_l, attn_r, H, D)
+        out, A, S = kernels.gat_fwd(el, er, feat, fwd_csr, slope, use_nid)
+        ctx.save_for_backward(x, w, feat, attn_l, attn_r, el, er, A, S, out)
+        ctx.csrs, ctx.use_nid, ctx.slope, ctx.w = (fwd_csr, bwd_csr), use_nid, slope, w
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, feat, attn_l, attn_r, el, er, A, S, out = ctx.saved_tensors
+        fwd_csr, bwd_csr = ctx.csrs
+        gf, gel, ger = kernels.gat_bwd(A, S, out, g.contiguous(), el, er, feat, fwd_csr, bwd_csr, ctx.slope, ctx.use_nid)
+        dfeat, dal, dar = kernels.gat_proj_bwd(feat, attn_l, attn_r, gel, ger, gf, inplace=True)
+        g2 = dfeat.view(dfeat.shape[0], -1)
+        gx = kernels.matmul(g2, w) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            W = ctx.w
+            native = _use_native(x, x.shape[0], g2.shape[1], x.shape[1])
+            if native and deferred_weight_grads() and W.is_leaf:
+                deferred.current().add(("linear", id(W)), g2, x, sink=lambda d, W=W: deferred.add_to_grad(W, d),
+                                       colsum_sink=None)
+            else:
+                gw = kernels.gemm_tn(g2, x) if native else torch.mm(g2.t(), x)
+        return gx, gw, dal.view_as(attn_l), dar.view_as(attn_r), None, None, None, None, None, None
+
+
+def gat_fc_layer_usable(graph, x: torch.Tensor, fc, H: int, D: int) -> bool:
+    """``fc``: the layer's nn.Linear ([H*D, fin], no bias: reference nn/pytorch/static/gat_conv.py:27)."""
+    from ..compiler import dispatch
+    from ..graph.dynamic.dynamic_graph import DynamicGraph
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and fc.bias is None and hasattr(graph, "csr")
+            and not isinstance(graph, DynamicGraph) and not kernels.reference_compat()
+            and not dispatch._FORCE_GENERATED and _GAT_FC
+            and kernels.gat_fc_supported(x.shape[1], H, D) and kernels.gat_proj_supported(H, D))
+
+
+def gat_fc_layer(graph, x: torch.Tensor, fc, attn_l, attn_r, slope: float, H: int, D: int) -> torch.Tensor:
+    return _GatFcLayer.apply(x, fc.weight, attn_l, attn_r, graph.csr("fwd"), graph.csr("bwd"),
+                             kernels.rows_by_node_ids(graph.graph_type()), float(slope), int(H), int(D))
+
+
+_GAT_FC = True
+
+
+def set_gat_fc(on: bool) -> None:
+    """Tests: switch the fused input side of GATConv off (x @ W.T, then stg_gat_proj_fwd)."""
+    global _GAT_FC
+    _GAT_FC = bool(on)
+
+
 def gat_layer_usable(graph, feat3: torch.Tensor) -> bool:
     from ..compiler import dispatch
     from ..graph.dynamic.dynamic_graph import DynamicGraph

@@ -44,6 +44,12 @@ class GATConv(nn.Module):
 
     def forward(self, graph, feat):
         h_dst = h_src = self.feat_drop(feat)  # noqa: F841
+        if SF.gat_fc_layer_usable(graph, h_src, self.fc, self._num_heads, self._out_feats):
+            # the fc GEMM with the attention projections in its epilogue, the GAT units, and all of it backward, as
+            # one autograd node (stg_gat_fc_fwd)
+            rst = SF.gat_fc_layer(graph, h_src, self.fc, self.attn_l, self.attn_r, self.negative_slope,
+                                  self._num_heads, self._out_feats)
+            return self.activation(rst) if self.activation else rst
         # self.fc through functional.linear: same Linear, wide outputs in 128-column slices of the row GEMM (rocBLAS'
         # tile choice for [N, in] x [in, H*D] costs 3x its M = 128 launches), weight gradient on the split-K MFMA kernel
         feat_src = feat_dst = SF.linear(h_src, self.fc.weight, self.fc.bias).view(-1, self._num_heads, self._out_feats)

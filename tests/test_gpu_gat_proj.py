@@ -73,3 +73,52 @@ def test_gatconv_fused_layer_equals_compiled_path(cuda, H, D):
     assert torch.equal(res[0][0], res[1][0])                       # the output does not depend on el / er (D2)
     for a, b, name in zip(res[0][1:], res[1][1:], ("x", "attn_l", "attn_r", "fc.weight")):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max() + 1), msg=lambda m, n=name: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("fin,H", [(64, 8), (32, 8), (64, 2), (32, 4)])
+def test_gat_fc_kernel_against_gemm_and_projection(cuda, fin, H):
+    """stg_gat_fc_fwd (fc GEMM on MFMA with el / er from its accumulators) against x @ W.T in fp64 and the
+    projections of that; ragged last tile."""
+    from stgraph_amd import kernels
+    D, n = 64, 16 * 777 + 5
+    assert kernels.gat_fc_supported(fin, H, D) and not kernels.gat_fc_supported(fin, H, 32)
+    assert not kernels.gat_fc_supported(128, 8, D)
+    gen = torch.Generator(device=cuda).manual_seed(fin + H)
+    x = torch.randn(n, fin, device=cuda, generator=gen)
+    W = torch.randn(H * D, fin, device=cuda, generator=gen) / fin ** 0.5
+    al = torch.randn(H, D, device=cuda, generator=gen)
+    ar = torch.randn(H, D, device=cuda, generator=gen)
+    feat, el, er = kernels.gat_fc_fwd(x, W, al, ar, H, D)
+    want = (x.double() @ W.double().t()).view(n, H, D)
+    torch.testing.assert_close(feat.double(), want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(el.double(), (want * al.double()).sum(-1, keepdim=True), rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(er.double(), (want * ar.double()).sum(-1, keepdim=True), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("fin,H", [(64, 8), (32, 2)])
+def test_gatconv_with_fused_input_side_equals_the_unfused_layer(cuda, fin, H):
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    D, n, e = 64, 3001, 40000
+    src, dst = random_graph(H * D + fin, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    torch.manual_seed(3)
+    conv = GATConv(fin, D, H).to(cuda)
+    x0 = torch.randn(n, fin, device=cuda)
+    R = torch.randn(n, H, D, device=cuda)
+    res = []
+    for fused in (True, False):
+        SF.set_gat_fc(fused)
+        try:
+            assert SF.gat_fc_layer_usable(g, x0, conv.fc, H, D) == fused
+            conv.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            out = conv(g, x)
+            out.backward(R)
+        finally:
+            SF.set_gat_fc(True)
+        res.append((out.detach().clone(), x.grad.clone(), conv.attn_l.grad.clone(), conv.attn_r.grad.clone(),
+                    conv.fc.weight.grad.clone()))
+    for a, b, name in zip(res[0], res[1], ("out", "x", "attn_l", "attn_r", "fc.weight")):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max() + 1), msg=lambda m, n=name: f"{n}: {m}")
