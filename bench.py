@@ -632,7 +632,8 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
 def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, T=160, B=20, feat=32, hidden=64):
     """BASELINE.json configs[4]: dynamic-temporal TGCN (benchmarking/dynamic-temporal-tgcn/seastar/train.py loop:
     link prediction on a sliding window over an edge stream, un-weighted GCN gates), once with the per-snapshot
-    device CSR rebuild (NaiveGraph(resident=False)) and on the dynamic edge store behind both of the reference's
+    device CSR rebuild (NaiveGraph(resident=False)), with all snapshots resident as the reference's NaiveGraph keeps
+    them, and on the dynamic edge store behind both of the reference's
     delta-based graph classes (PCSRGraph, GPMAGraph: one resident graph + per-timestamp deltas).  BPTT windows are sharded over the ranks like the static configuration."""
     from stgraph_amd import temporal
     from stgraph_amd.graph import GPMAGraph, NaiveGraph, PCSRGraph
@@ -656,9 +657,13 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
         torch.cuda.synchronize()
 
     out = {}
-    for mode in ("rebuild_per_snapshot", "pcsr_store", "gpma_store"):
-        G = (NaiveGraph(snaps, n, device=device, sort_inplace=False, resident=False, max_cached=B + 1)
-             if mode == "rebuild_per_snapshot" else (PCSRGraph if mode == "pcsr_store" else GPMAGraph)(snaps, n, device=device))
+    for mode in ("resident_snapshots", "rebuild_per_snapshot", "pcsr_store", "gpma_store"):
+        if mode == "resident_snapshots":         # NaiveGraph as the reference defines it: all 2T CSRs built up front
+            G = NaiveGraph(snaps, n, device=device, sort_inplace=False)
+        elif mode == "rebuild_per_snapshot":
+            G = NaiveGraph(snaps, n, device=device, sort_inplace=False, resident=False, max_cached=B + 1)
+        else:
+            G = (PCSRGraph if mode == "pcsr_store" else GPMAGraph)(snaps, n, device=device)
         torch.manual_seed(4)
         model = temporal.DynamicSTGraphTGCN(feat, hidden).to(device)
         opt = torch.optim.Adam(model.parameters(), lr=1e-2)
@@ -681,7 +686,7 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        if mode != "rebuild_per_snapshot":
+        if mode in ("pcsr_store", "gpma_store"):
             G.check()
         out[mode] = {"epochs_per_s": epochs / dt, "seconds_per_epoch": dt / epochs}
         if mode == "rebuild_per_snapshot":
@@ -700,7 +705,12 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
         del G, model, opt, bucket
     return {"workload": f"dynamic-temporal TGCN |V|={n} E0={e0} +-{churn} edges/step T={T} backprop_every={B} feat={feat} "
                         f"hidden={hidden} (BASELINE configs[4]), link-prediction loss, windows sharded over {world} rank(s)",
-            "metric": "epochs/s", "value": out["rebuild_per_snapshot"]["epochs_per_s"], "scaling": "strong",
+            "metric": "epochs/s", "value": out["resident_snapshots"]["epochs_per_s"],
+            "value_is": "NaiveGraph with every snapshot's CSR pair resident, built once at construction -- the reference's "
+                        "NaiveGraph (graph/dynamic/naive/naive_graph.py: T forward + T backward CSRs up front; 1.6 GB "
+                        "here); rebuild_per_snapshot (a fresh device CSR build per snapshot and epoch, O(window) memory) and "
+                        "the two delta-based stores follow",
+            "scaling": "strong",
             "n_gpus": world, "epochs": epochs, "windows_per_epoch": temporal.num_windows(T, B), "roofline": roofline,
             **out}
 
