@@ -154,14 +154,17 @@ def test_captured_optimizer_tail_matches_the_eager_tail(cuda):
             torch.testing.assert_close(a, b, rtol=2e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("kind", ["naive_resident", "naive_rebuild", "pcsr", "gpma"])
-def test_dynamic_window_matches_the_per_snapshot_loop(cuda, kind):
+@pytest.mark.parametrize("kind,full", [("naive_resident", False), ("naive_rebuild", False), ("pcsr", False),
+                                       ("gpma", False), ("naive_resident", True), ("pcsr", True)])
+def test_dynamic_window_matches_the_per_snapshot_loop(cuda, kind, full):
     """temporal.dyn_window_cost (one autograd node per window of the dynamic-temporal loop, every snapshot its own
-    graph) == the per-snapshot loop, on every dynamic graph class: losses and parameters after two epochs of SGD."""
+    graph) == the per-snapshot loop, on every dynamic graph class: losses and parameters after two epochs of SGD.
+    ``full``: at BASELINE configs[4]'s sizes (|V| = 25 K, 250 K edges +- 6250 per step, windows of 20), two windows."""
     import numpy as np
     from stgraph_amd import temporal
     from stgraph_amd.graph import GPMAGraph, NaiveGraph, PCSRGraph
-    n, e0, churn, T, B, feat, hid, m = 4000, 30000, 800, 10, 4, 32, 64, 1500
+    n, e0, churn, T, B, feat, hid, m = ((25_000, 250_000, 6_250, 41, 20, 32, 64, 10_000) if full
+                                        else (4000, 30000, 800, 10, 4, 32, 64, 1500))
     rng = np.random.default_rng(7)
     stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
     out = []
