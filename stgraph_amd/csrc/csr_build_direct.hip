@@ -59,35 +59,52 @@ __global__ void direct_histogram(const int *__restrict__ src, const int *__restr
     }
 }
 
-// blockIdx.x = 0: forward (rows = dst, lengths = in_deg); 1: backward.  Exclusive scan of N lengths by one workgroup.
+// blockIdx.x = 0: forward (rows = dst, lengths = in_deg); 1: backward.  Exclusive scan of N lengths by one workgroup:
+// tiles of 4096 lengths, four consecutive ones per thread (coalesced), a shuffle scan inside each wave, the 16 wave
+// totals through LDS, a running carry between tiles (|V| = 25 K: 7 tiles, ~ 6 us; the first version gave every thread
+// one contiguous chunk -- strided loads and a 10-step Hillis-Steele over 1024 partials with 20 barriers: 31.6 us).
 __global__ __launch_bounds__(kScanThreads) void direct_scan(const int *__restrict__ in_deg, const int *__restrict__ out_deg,
                                                            int N, int *__restrict__ fwd_ro, int *__restrict__ bwd_ro,
                                                            int *__restrict__ status)
 {
-    __shared__ int part[kScanThreads];
+    constexpr int kWavesScan = kScanThreads / 64;
+    __shared__ int wsum[kWavesScan];
     const int *deg = blockIdx.x == 0 ? in_deg : out_deg;
     int *ro = blockIdx.x == 0 ? fwd_ro : bwd_ro;
-    const int chunk = (N + kScanThreads - 1) / kScanThreads;
-    const int beg = min(N, (int)threadIdx.x * chunk), end = min(N, beg + chunk);
-    int sum = 0, longest = 0;
-    for (int v = beg; v < end; ++v) {
-        sum += deg[v];
-        longest = max(longest, deg[v]);
-    }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < kScanThreads; off <<= 1) {              // inclusive Hillis-Steele over the 1024 partials
-        const int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0, longest = 0;
+    for (int base = 0; base < N; base += 4 * kScanThreads) {
+        const int v0 = base + 4 * tid;
+        int d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = v0 + i < N ? deg[v0 + i] : 0;
+        longest = max(max(longest, max(d[0], d[1])), max(d[2], d[3]));
+        const int tot = d[0] + d[1] + d[2] + d[3];
+        int x = tot;                                                  // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
         __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesScan; ++w) {
+            const int t = wsum[w];
+            before += w < wave ? t : 0;
+            all += t;
+        }
+        int run = carry + before + (x - tot);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (v0 + i < N) ro[v0 + i] = run;
+            run += d[i];
+        }
+        carry += all;
+        __syncthreads();                                              // wsum is rewritten by the next tile
     }
-    int run = part[threadIdx.x] - sum;                               // exclusive prefix of this thread's chunk
-    for (int v = beg; v < end; ++v) {
-        ro[v] = run;
-        run += deg[v];
-    }
-    if (threadIdx.x == kScanThreads - 1) ro[N] = part[kScanThreads - 1];
+    if (tid == 0) ro[N] = carry;
     if (longest > kDirectMaxRow) atomicOr(status, STG_BUILD_NEEDS_SORT);
 }
 
