@@ -6,7 +6,10 @@
 Main line, N = 1: BASELINE.json configs[1] -- 2-layer GCN 128->128->128 on a synthetic CSR
 with |V| = 1M, |E| = 16M (uniform, duplicate-free, seed 1).  One step = one training epoch
 (forward, cross-entropy on the train mask, backward, Adam), inputs resident in HBM.
-`value` = edges*feat/s = (aggregation launches per step x E x F) / wall time, whole job.
+`value` = edges*feat/s = (4 x E x F) / wall time of a step, whole job: 4 = the aggregations of one training step in the
+reference's formulation (2 layers, forward + backward).  The step itself executes 3: the first layer's input carries no
+gradient, so it aggregates before its weight product and its backward needs none (nn/functional._InputLayer); the same
+step in the reference's order is timed beside it (`reference_order`).
 N > 1: N independent replicas of that workload (a single-graph GCN does not shard:
 SURVEY.md 8(e) "replicas only"), `value` = sum over ranks.
 
@@ -836,6 +839,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same step with every layer in the reference's order (x W first): 4 aggregation launches
+    from stgraph_amd.nn import functional as SF
+    SF.set_input_layer_reorder(False)
+    try:
+        step()
+        barrier()
+        k_ref = max(2, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(k_ref):
+            step()
+        barrier()
+        dt_ref = (time.perf_counter() - t0) / k_ref
+    finally:
+        SF.set_input_layer_reorder(True)
+
     ef_per_step = meta["agg_launches_per_step"] * meta["e"] * meta["feat"]
     gemm_ms = [a.elapsed_time(b) for (name, a, b, _, _) in records if name == "gemm_tn"]
     records = [r for r in records if r[0] == "gcn_agg"]           # the dominant kernel
@@ -854,6 +872,9 @@ def main():
                                f"|E|={meta['e']} (BASELINE configs[1]); step = fwd + cross-entropy + bwd + Adam",
                    "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
                    "agg_launches_per_step": meta["agg_launches_per_step"],
+                   "agg_launches_per_step_is": "of the reference's formulation (2 layers x forward + backward); executed: "
+                                               "see aggregations_executed_per_step",
+                   "aggregations_executed_per_step": None,
                    "edges_feat_per_step": ef_per_step,
                    "reference_compat_D1": kernels.reference_compat()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -863,6 +884,13 @@ def main():
                      "gcn_agg_share_of_step": float(np.sum(ms)) * 1e-3 / dt,
                      "weight_grad_gemm_tn_mean_ms": float(np.mean(gemm_ms)) if gemm_ms else None},
     }
+    line["config"]["aggregations_executed_per_step"] = len(ms) / max(args.steps, 1)
+    line["reference_order"] = {
+        "ms_per_step": dt_ref * 1e3, "value": world * ef_per_step / dt_ref, "steps": k_ref,
+        "what": "the same training step with every GCNConv in the reference's order (x W, then aggregate: 4 aggregation "
+                "launches); the default runs the first layer aggregate-first because its input carries no gradient, which "
+                "leaves its backward without an aggregation (identical gradients up to fp32 rounding; "
+                "tests/test_gpu_input_layer.py)"}
     # HBM-side traffic per launch: PMC counters cannot be read inside this process, so the figure
     # comes from the committed rocprofv3 --pmc passes over the SAME kernel/shape (tools/pmc_gcn.py,
     # FETCH_SIZE corrected with the factor measured on a known-bytes launch, + WRITE_SIZE).

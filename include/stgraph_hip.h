@@ -275,6 +275,11 @@ int stg_gcn_layer_fwd(const float *x, const float *norm_row, const float *norm_c
                       const int32_t *node_ids, const int32_t *rows_by_degree,
                       int32_t N, int64_t E, int32_t F, void *stream);
 
+/* y[n,f] = act(y[n,f] + bias[f]) in place (bias may be NULL; act = STG_ACT_NONE / STG_ACT_RELU): the `h + self.bias`,
+ * `self.activation(h)` tail of GCNConv (reference nn/pytorch/static/gcn_conv.py:184-188) as one pass, for a layer
+ * whose aggregation ran before its weight product. */
+int stg_bias_act_fwd(float *y, const float *bias, int32_t act, int32_t N, int32_t F, void *stream);
+
 /* Backward of that tail in one pass over [N,F] (torch: threshold_backward + sum(0), two passes + a
  * single-block-per-column reduction):
  *   g_act[r,f] = out ? (out[r,f] > 0 ? g[r,f] : 0) : (not written)      -- ReLU mask, `out` = the layer output

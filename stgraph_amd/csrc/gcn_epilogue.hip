@@ -126,6 +126,46 @@ bool shape_for(int32_t N, int32_t F, Shape &s)
 }  // namespace
 }  // namespace stg
 
+// y = act(y + bias[f]) in place, one pass: the tail of a GCN layer whose aggregation ran BEFORE the weight product
+// (nn/functional._InputLayer).  16 B per thread when F % 4 == 0 and y is 16-byte aligned.
+namespace stg {
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void bias_act_fwd_kernel(float *__restrict__ y, const float *__restrict__ bias,
+                                                              int64_t total, int F, int act)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock * VEC;
+    for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC; i < total; i += stride) {
+        float v[VEC];
+        vec_load<VEC>(v, y + i);
+        const int f = (int)(i % F);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            if (bias) v[k] = v[k] + bias[f + k];
+            if (act == STG_ACT_RELU) v[k] = v[k] < 0.f ? 0.f : v[k];
+        }
+        vec_store<VEC>(y + i, v);
+    }
+}
+}  // namespace stg
+
+extern "C" int stg_bias_act_fwd(float *y, const float *bias, int32_t act, int32_t N, int32_t F, void *stream_)
+{
+    using namespace stg;
+    if (N < 0 || F <= 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_bias_act_fwd: bad shape N=%d F=%d", N, F);
+    if (act != STG_ACT_NONE && act != STG_ACT_RELU)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_bias_act_fwd: unknown activation %d", act);
+    if (N == 0 || (!bias && act == STG_ACT_NONE)) return 0;
+    if (!y) return fail(STG_ERR_INVALID_ARGUMENT, "stg_bias_act_fwd: NULL pointer argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t total = (int64_t)N * F;
+    const bool v4 = F % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+    const int64_t per = (int64_t)kBlock * (v4 ? 4 : 1);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + per - 1) / per, 256 * 32));
+    if (v4) hipLaunchKernelGGL(bias_act_fwd_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, y, bias, total, F, act);
+    else hipLaunchKernelGGL(bias_act_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, stream, y, bias, total, F, act);
+    return check_launch("stg_bias_act_fwd");
+}
+
 extern "C" size_t stg_bias_act_bwd_workspace_bytes(int32_t N, int32_t F)
 {
     stg::Shape s;

@@ -629,6 +629,20 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
     return out
 
 
+def bias_act_fwd_(y: torch.Tensor, bias: torch.Tensor | None, act: int) -> torch.Tensor:
+    """``y = act(y + bias)`` in place, one pass (stg_bias_act_fwd)."""
+    if y.dtype != torch.float32 or not y.is_cuda or not y.is_contiguous() or y.dim() != 2:
+        raise ValueError("y must be a contiguous 2-D fp32 device tensor")
+    dev = y.device
+    N, F = y.shape
+    b = None if bias is None else _f32(bias, "bias", dev)
+    if b is not None and b.numel() != F:
+        raise ValueError("bias must have one entry per column")
+    with torch.cuda.device(dev), _Timed("bias_act_fwd", 8 * N * F, N * F):
+        _C.check(_C.lib.stg_bias_act_fwd(_ptr(y), _ptr(b), int(act), N, F, _stream_ptr(dev)))
+    return y
+
+
 def bias_act_bwd(g: torch.Tensor, out: torch.Tensor | None, want_colsum: bool = True):
     """Backward of ``act(y + bias)`` in one pass (stg_bias_act_bwd): returns ``(g_act, colsum)`` with
     ``g_act = g * (out > 0)`` when ``out`` (the ReLU output) is given, else ``g`` itself, and ``colsum`` =

@@ -342,6 +342,61 @@ class _GcnLayerTail(torch.autograd.Function):
         return gh, gb, None, None, None, None, None, None
 
 
+class _InputLayer(torch.autograd.Function):
+    """A GCN layer whose INPUT needs no gradient (the first layer on the dataset's features), as
+    ``act((A_hat x) W + bias)`` instead of ``act(A_hat (x W) + bias)`` (reference nn/pytorch/static/gcn_conv.py:158-188;
+    equal by linearity, fp32 rounding apart).  The aggregate ``P = A_hat x`` is what the weight gradient needs
+    (``dW = P^T g`` = ``x^T (A_hat^T g)``), so the layer's backward has NO aggregation: the reference order spends
+    one there only to reach a gradient with respect to ``x W`` that then feeds ``dW`` alone.  Used when the
+    aggregation is not wider this way round (in <= out)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, norm, ew, fwd_csr, use_nid, act):
+        P = kernels.gcn_agg(x, norm, norm, fwd_csr, ew=ew, use_node_ids=use_nid)
+        out = torch.mm(P, w)
+        kernels.bias_act_fwd_(out, bias, act)
+        ctx.save_for_backward(P, out if act != kernels.ACT_NONE else norm.new_empty(0))
+        ctx.act, ctx.has_bias, ctx.w = act, bias is not None, w
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        P, out = ctx.saved_tensors
+        g = g.contiguous()
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        gb = gw = None
+        if ctx.act != kernels.ACT_NONE or want_b:
+            g, gb = kernels.bias_act_bwd(g, out if ctx.act != kernels.ACT_NONE else None, want_colsum=want_b)
+        if ctx.needs_input_grad[1]:
+            W = ctx.w
+            native = _use_native(P, P.shape[0], P.shape[1], g.shape[1])
+            if native and deferred_weight_grads() and W.is_leaf:
+                deferred.current().add(("mm", id(W)), P, g, sink=lambda d, W=W: deferred.add_to_grad(W, d))
+            else:
+                gw = kernels.gemm_tn(P, g) if native else torch.mm(P.t(), g)
+        return None, gw, gb, None, None, None, None, None
+
+
+_INPUT_LAYER = True
+
+
+def set_input_layer_reorder(on: bool) -> None:
+    """False: every GCNConv runs in the reference's order (x W first), whatever its input."""
+    global _INPUT_LAYER
+    _INPUT_LAYER = bool(on)
+
+
+def input_layer_usable(graph, x: torch.Tensor, weight: torch.Tensor, activation) -> bool:
+    return (_INPUT_LAYER and not x.requires_grad and weight.shape[0] <= weight.shape[1]
+            and gcn_layer_tail_usable(graph, x, activation) and kernels._EDGE_CACHE and not kernels.reference_compat())
+
+
+def input_layer(graph, x: torch.Tensor, weight, bias, activation, edge_weight=None) -> torch.Tensor:
+    norm = graph.get_ndata("norm")
+    return _InputLayer.apply(x, weight, bias, norm, edge_weight, graph.csr("fwd"),
+                             kernels.rows_by_node_ids(graph.graph_type()), activation_code(activation))
+
+
 def activation_code(activation):
     """STG_ACT_* of a GCNConv ``activation`` argument, or None if it is not one the epilogue implements."""
     if activation is None:

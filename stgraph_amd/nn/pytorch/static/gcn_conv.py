@@ -72,6 +72,10 @@ class GCNConv(nn.Module):
 
     def forward(self, graph, h, edge_weight=None):
         self.check_norm(graph)
+        if SF.input_layer_usable(graph, h, self.weight, self.activation):
+            # an input that carries no gradient (the dataset's features): aggregate first, so that the backward pass
+            # of this layer needs no aggregation at all (functional._InputLayer)
+            return SF.input_layer(graph, h, self.weight, self.bias, self.activation, edge_weight)
         h = SF.mm(h, self.weight)            # torch.mm forward; weight gradient on the fp32 matrix cores
         if (self.bias is not None or self.activation is not None) and SF.gcn_layer_tail_usable(graph, h, self.activation):
             # same aggregation kernel as the compiled vertex function below, with `+ bias` and the
