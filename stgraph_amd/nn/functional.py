@@ -53,6 +53,8 @@ def _mm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         key = (w.shape[1], x.device)
         z = _ZERO_BIAS.get(key)
         if z is None:
+            if torch.cuda.is_current_stream_capturing():      # not from a graph's private pool
+                return torch.mm(x, w)
             z = _ZERO_BIAS[key] = torch.zeros(w.shape[1], dtype=torch.float32, device=x.device)
         return torch.addmm(z, x, w)
     return torch.mm(x, w)
