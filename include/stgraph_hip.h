@@ -370,7 +370,7 @@ int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *cols
 /* GATConv's input side as one launch: feat [N, H*D] = x [N, fin] W^T (W [H*D, fin], the layer's bias-free fc:
  * reference nn/pytorch/static/gat_conv.py:43-48) and, from the accumulators, el / er [N, H] = sum_d feat[n,h,d] *
  * attn_{l,r}[h,d] (what stg_gat_proj_fwd computes from feat).  MFMA fp32; results agree with x @ W^T followed by
- * stg_gat_proj_fwd to fp32 rounding.  Supported: D = 64, even H, fin 32 or 64, H*64*(fin+4)*4 + 512 H <= 160 KB;
+ * stg_gat_proj_fwd to fp32 rounding.  Supported: D = 64, even H, fin 32 or 64, H*64*(fin+8)*4 + 512 H <= 160 KB;
  * else STG_ERR_UNSUPPORTED (callers run the GEMM and stg_gat_proj_fwd). */
 int stg_gat_fc_supported(int32_t fin, int32_t H, int32_t D);
 int stg_gat_fc_fwd(const float *x, const float *W, const float *attn_l, const float *attn_r, float *feat,

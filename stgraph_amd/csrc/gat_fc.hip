@@ -8,7 +8,7 @@
 // Layout: the "row pieces" scheme of tgcn_step.hpp -- v_mfma_f32_16x16x4_f32 with the WEIGHT as the A operand, so a
 // lane's four accumulator values are four consecutive output columns of its own row: 16-byte stores, and the head's
 // dot product with attn_l / attn_r is 16 multiply-adds per lane and two cross-lane adds (the four lanes that share
-// a row).  W [H*D, FIN] stays in LDS in its torch Linear layout (rows padded by 4 floats: ~ 140 KB at 512 x 64), one
+// a row).  W [H*D, FIN] stays in LDS in its torch Linear layout (rows padded by 8 floats: ~ 148 KB at 512 x 64), one
 // workgroup of 16 waves per CU, 16-row tiles dealt wave-major; a tile is 128 output columns (two heads) at a time:
 // 8 accumulators, 128 MFMAs, then the epilogue.  MFMA-bound: 512 MFMAs x 32 cycles per tile and SIMD wave.
 // Results agree with rocBLAS / the unfused pair to fp32 rounding (k order (j, i, kq)); tests: 1e-5 relative.
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kFcWaves * 64) void gat_fc_kernel(
     const float *__restrict__ attn_r, float *__restrict__ feat, float *__restrict__ el, float *__restrict__ er,
     int N, int H)
 {
-    constexpr int NT = kFcWaves * 64, LD = FIN + 4, J = FIN / 16, D = 64;
+    constexpr int NT = kFcWaves * 64, LD = FIN + 8, J = FIN / 16, D = 64;     // 8 mod 16 dwords: conflict-free ds_read_b128 (tgcn_step.hpp)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int HD = H * D;
     float *Wl = lds, *al = Wl + HD * LD, *ar = al + HD;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kFcWaves * 64) void gat_fc_kernel(
     }
 }
 
-inline size_t fc_lds_bytes(int fin, int H) { return ((size_t)H * 64 * (fin + 4) + 2 * (size_t)H * 64) * sizeof(float); }
+inline size_t fc_lds_bytes(int fin, int H) { return ((size_t)H * 64 * (fin + 8) + 2 * (size_t)H * 64) * sizeof(float); }
 
 inline bool fc_shape_ok(int fin, int H, int D)
 {

@@ -20,7 +20,7 @@ struct BwdArgs {
 
 template <int C, int FIN, int FH, int WAVES, bool GATHER, int HEAD>
 struct BwdShape {
-    static constexpr int K2 = 2 * C, LDB = C + 4, LDX = 3 * C + 4, LDT = FH + 4;
+    static constexpr int K2 = 2 * C, LDB = C + 8, LDX = 3 * C + 8, LDT = FH + 8;   // row strides = 8 mod 16 dwords: see tgcn_step.hpp
     static constexpr int kGate = 3 * K2 * LDB;                // WzT | WrT | WhT, each [2C][LDB]
     static constexpr int kCat = FIN * LDX;                    // Wcat [FIN][LDX]
     static constexpr int kHead = HEAD ? C * LDT : 0;          // W1T [C][LDT]

@@ -18,7 +18,7 @@ struct FwdArgs {
 
 template <int C, int FIN, int FH, int WAVES, bool GATHER, int HEAD>
 struct FwdShape {
-    static constexpr int K2 = 2 * C, LDW = K2 + 4, LDC = FIN + 4, LD1 = C + 4;
+    static constexpr int K2 = 2 * C, LDW = K2 + 8, LDC = FIN + 8, LD1 = C + 8;   // row strides = 8 mod 16 dwords: see tgcn_step.hpp
     static constexpr int kGate = 3 * C * LDW;
     static constexpr int kCat = GATHER ? 3 * C * LDC : 0;
     static constexpr int kHead = HEAD ? FH * LD1 : 0;
