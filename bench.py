@@ -451,28 +451,48 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
     feats = torch.randn(n, fin, device=device, generator=gen)
     labels = torch.randint(0, classes, (n,), device=device, generator=gen)
     ntrain = int(0.6 * n)
-    model = GAT(g, 1, fin, D, classes, [H, 1], F.elu).to(device)
-    opt = torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4)   # gat/seastar/train.py defaults
-    dur = []
-    for ep in range(epochs):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        model.train()
-        logits = model(feats)
-        loss = SF.cross_entropy(logits, labels, ntrain)        # = CrossEntropyLoss()(logits[train_mask], labels[train_mask])
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        torch.cuda.synchronize()
-        if ep >= 3:
-            dur.append(time.perf_counter() - t0)
-    sec = float(np.mean(dur))
+    from stgraph_amd.capture import CapturedTrainStep
+    modes = {}
+    for mode in ("eager", "hip_graph"):
+        torch.manual_seed(2)
+        model = GAT(g, 1, fin, D, classes, [H, 1], F.elu).to(device)
+        # gat/seastar/train.py defaults; captured mode: the same rule as torch's single-kernel capturable Adam
+        opt = (torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4, capturable=True, fused=True)
+               if mode == "hip_graph" else torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4))
+
+        def step():
+            model.train()
+            logits = model(feats)
+            loss = SF.cross_entropy(logits, labels, ntrain)    # = CrossEntropyLoss()(logits[train_mask], labels[train_mask])
+            opt.zero_grad(set_to_none=False)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+
+        run = step if mode == "eager" else CapturedTrainStep(step, opt, list(model.parameters()))
+        dur = []
+        for ep in range(epochs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = run()
+            torch.cuda.synchronize()
+            if ep >= 3:
+                dur.append(time.perf_counter() - t0)
+        modes[mode] = {"epochs_per_s": 1.0 / float(np.mean(dur)), "ms_per_epoch": float(np.mean(dur)) * 1e3,
+                       "final_loss": float(loss)}
+        del model, opt, run
+        torch.cuda.empty_cache()
+    sec = modes["hip_graph"]["ms_per_epoch"] * 1e-3
     ef_epoch = 2 * e * (H * D + classes)                        # K1 + K2 of both layers
     return {"workload": f"GAT |V|={n} |E|={e} in={fin} heads={H} D={D} negative_slope=0.2 (BASELINE configs[2]); "
                         f"layer = GATConv({fin}, {D}, {H}) forward + backward; model = GATConv({fin},{D},{H},elu) -> "
                         f"GATConv({H * D},{classes},1), cross-entropy, Adam (benchmarking/gat/seastar)",
             "metric": "epochs/s", "value": 1.0 / sec, "ms_per_epoch": sec * 1e3, "epochs_timed": len(dur),
-            "edges_feat_per_s": ef_epoch / sec, "final_loss": float(loss.detach()),
+            "value_is": "the whole epoch (forward + loss + backward + Adam) replayed from one HIP graph, as for the Cora "
+                        "configuration; the eager loop of the reference script beside it (its ~ 60 launches per epoch "
+                        "leave the device idle 5-15 % depending on the host)",
+            "eager": modes["eager"], "hip_graph": modes["hip_graph"],
+            "edges_feat_per_s": ef_epoch / sec, "final_loss": modes["hip_graph"]["final_loss"],
             "layer": layer,
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": "stg::gat_k1_kernel",
                          "achieved": k1.get("algorithmic_bytes", 0) / k1["mean_ms"] / 1e6 if k1 else None,
@@ -669,20 +689,34 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
             G = (PCSRGraph if mode == "pcsr_store" else GPMAGraph)(snaps, n, device=device)
         torch.manual_seed(4)
         model = temporal.DynamicSTGraphTGCN(feat, hidden).to(device)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        # capturable + fused: the default Adam's update rule as one kernel that a HIP graph can hold
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
         bucket = temporal.GradBucket(model.parameters())
+        # snapshot-per-timestamp graphs: every window replayed from its own HIP graph after one eager epoch (in rebuild
+        # mode the graph contains the snapshot builds, which so still run every epoch); the delta stores stay eager
+        captured = mode in ("resident_snapshots", "rebuild_per_snapshot")
+        cd = None
 
         def epoch(ep):
+            nonlocal cd
             if mode == "rebuild_per_snapshot":
                 G._snapshots.clear()                 # every epoch rebuilds every snapshot it touches
             G._ndata.clear()
-            temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep, rank=rank,
-                                         world=world)
+            if captured and ep >= 1:
+                if cd is None:
+                    cd = temporal.CapturedDynamicWindows(model, G, pn_edges, pn_targets, B, opt, bucket, feat, world=world,
+                                                         rank=rank)
+                temporal.train_epoch_dynamic_captured(cd, epoch=ep)
+            else:
+                temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep, rank=rank,
+                                             world=world)
         epoch(0)
+        if captured:
+            epoch(1)                                 # captures
         barrier()
         t0 = time.perf_counter()
         for ep in range(epochs):
-            epoch(1 + ep)
+            epoch(2 + ep)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -705,7 +739,9 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
                         "algorithmic_bytes_per_snapshot": ref_bytes, "achieved": ref_bytes / sps / 1e9,
                         "frac": ref_bytes / sps / 1e9 / HBM_PEAK_GBS,
                         "note": "|V| = 25K snapshots: launch- and host-bound, not bandwidth-bound"}
-        del G, model, opt, bucket
+        out[mode]["hip_graph_per_window"] = captured
+        del G, model, opt, bucket, cd
+        torch.cuda.empty_cache()
     return {"workload": f"dynamic-temporal TGCN |V|={n} E0={e0} +-{churn} edges/step T={T} backprop_every={B} feat={feat} "
                         f"hidden={hidden} (BASELINE configs[4]), link-prediction loss, windows sharded over {world} rank(s)",
             "metric": "epochs/s", "value": out["rebuild_per_snapshot"]["epochs_per_s"],

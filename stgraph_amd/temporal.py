@@ -747,6 +747,134 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
     return list(out.unbind(0))
 
 
+class CapturedDynamicWindows:
+    """The dynamic-temporal loop with ONE HIP graph per BPTT window.
+
+    A window of the dynamic loop differs from the next in its graphs, not in its shapes, so -- unlike the static
+    case -- there is one captured graph per window rather than one for all: window ``w``'s graph holds bucket.zero, the
+    move through its snapshots (for ``NaiveGraph(resident=False)`` the device CSR builds themselves, which therefore
+    still run every epoch; for a resident NaiveGraph only pointer swaps, which cost nothing at replay), the in-degree
+    norms, ``dyn_window_cost`` and the backward pass.  It is captured the first time the window is met -- AFTER at least
+    one eager epoch (lazy initialisations, the label edges' incidence lists) -- and replayed from then on; per
+    optimizer step the host issues one input copy, one replay, the all-reduce and the captured optimizer tail.
+    Eagerly the window is ~ 60 launches per snapshot from Python and leaves the device idle 20-30 % of the time.
+
+    Only snapshot-per-timestamp graphs (NaiveGraph) qualify: the delta-based stores move through host-side protocol
+    code with synchronisation points.  Memory: a window's activations and (rebuild mode) CSRs live in its graph's pool
+    (~ 2 GB per window of 20 snapshots at |V| = 25 K)."""
+
+    def __init__(self, model, graph, pos_neg_edges, pos_neg_targets, backprop_every: int, optimizer,
+                 bucket: GradBucket, feat_size: int, world: int = 1, rank: int = 0, group=None, norm_fn=None):
+        from .graph.dynamic.naive.naive_graph import NaiveGraph
+        if not isinstance(graph, NaiveGraph):
+            raise TypeError("CapturedDynamicWindows needs a NaiveGraph (one CSR pair per timestamp)")
+        self.model, self.graph, self.edges, self.targets = model, graph, pos_neg_edges, pos_neg_targets
+        self.total = len(pos_neg_edges)
+        self.B = backprop_every or self.total
+        self.optimizer, self.bucket, self.feat = optimizer, bucket, feat_size
+        self.world, self.rank, self.group = world, rank, group
+        self.norm_fn = norm_fn or in_degree_norm
+        self.n = graph.get_num_nodes()
+        self.dev = pos_neg_targets[0].device
+        self.graphs, self.inputs, self.costs = {}, {}, {}
+        self.step_graph = None
+        self._tail_ready = False
+
+    def timestamps(self, w: int):
+        return range(w * self.B, min((w + 1) * self.B, self.total - 1))
+
+    def usable(self, w: int) -> bool:
+        ts = self.timestamps(w)
+        if len(ts) == 0:
+            return False
+        e, t0 = self.edges, ts[0]
+        probe = torch.empty(self.n, self.feat, device=self.dev)
+        return dyn_window_usable(self.model, self.graph, probe) and all(
+            e[t].dtype == torch.int64 and e[t].is_contiguous() and e[t].dim() == 2 and e[t].shape == e[t0].shape
+            and e[t].shape[1] > 0 and self.targets[t].dtype == torch.float32 and self.targets[t].is_contiguous()
+            and self.targets[t].numel() == e[t].shape[1] for t in ts)
+
+    def _body(self, w: int) -> torch.Tensor:
+        from .nn import functional as SF
+        g = self.graph
+        self.bucket.zero()
+        steps = []
+        for t in self.timestamps(w):
+            g.get_graph(t)
+            steps.append(dict(fwd=g.csr("fwd"), bwd=g.csr("bwd"), norm=self.norm_fn(g), edges=self.edges[t],
+                              targets=self.targets[t], incidence=SF._incidence_of(self.edges[t], self.n)))
+        cost = dyn_window_cost(self.model, g, self.inputs[w], steps) / (self.B + 1)
+        cost.backward()
+        return cost.detach()
+
+    def _capture(self, w: int) -> None:
+        g = self.graph
+        self.inputs[w] = torch.zeros(self.n, self.feat, device=self.dev)
+        if not g._resident:
+            for t in self.timestamps(w):         # the builds must be IN the graph: forget snapshots an eager epoch left
+                g._snapshots.pop(t, None)
+        torch.cuda.synchronize(self.dev)
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            self.costs[w] = self._body(w)
+        if not g._resident:
+            for t in self.timestamps(w):         # tensors of the graph's private pool: not for eager readers
+                g._snapshots.pop(t, None)
+        self.graphs[w] = cg
+        self.bucket.zero()
+
+    def _capture_tail(self) -> None:
+        """``grad /= world`` + ``optimizer.step()`` as one graph (capturable optimizers; the optimizer has taken real
+        steps in the eager epoch before, so its state exists and capturing does not run it)."""
+        self._tail_ready = True
+        opt, bucket, world = self.optimizer, self.bucket, self.world
+        if not all(g.get("capturable", False) for g in opt.param_groups) or not opt.state:
+            return
+
+        def tail():
+            if world > 1:
+                bucket.flat.div_(world)
+            opt.step()
+        torch.cuda.synchronize(self.dev)
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            tail()
+        self.step_graph = cg
+
+    def run(self, w: int, epoch: int, seed: int = 0, timed_comm: bool = False) -> torch.Tensor:
+        if not self._tail_ready:
+            self._capture_tail()
+        if w not in self.graphs:
+            self._capture(w)
+        self.inputs[w].copy_(window_input(self.n, self.feat, epoch, w, self.dev, seed))
+        self.graphs[w].replay()
+        if self.step_graph is not None:
+            self.bucket.all_reduce_mean(self.world, self.group, timed_comm, divide=False)
+            self.step_graph.replay()
+        else:
+            self.bucket.all_reduce_mean(self.world, self.group, timed_comm)
+            self.optimizer.step()
+        return self.costs[w]
+
+
+def train_epoch_dynamic_captured(cd: CapturedDynamicWindows, epoch: int = 0, seed: int = 0, timed_comm: bool = False):
+    """``train_epoch_dynamic`` with every usable window replayed from its own HIP graph (call after at least one eager
+    epoch on the same objects).  Returns this rank's window costs (views of the graphs' output buffers: valid until
+    the window is replayed again)."""
+    losses = []
+    cd.graph.reset_graph()
+    for _, w in windows_of_rank(cd.total, cd.B, cd.rank, cd.world):
+        if w is not None and cd.usable(w):
+            losses.append(cd.run(w, epoch, seed, timed_comm))
+            continue
+        cd.bucket.zero()
+        if w is not None and len(cd.timestamps(w)) > 0:
+            raise RuntimeError("CapturedDynamicWindows: window %d is not covered by the fused window path" % w)
+        cd.bucket.all_reduce_mean(cd.world, cd.group, timed_comm)
+        cd.optimizer.step()
+    return losses
+
+
 def in_degree_norm(graph) -> torch.Tensor:
     """norm = in_deg^-0.5, inf -> 0, computed on the device from the current snapshot (one launch: kernels.degree_norm;
     the torch composition -- five launches -- for tensors that are not int32 on a GPU)."""

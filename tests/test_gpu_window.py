@@ -201,3 +201,51 @@ def test_dynamic_window_matches_the_per_snapshot_loop(cuda, kind, full):
     torch.testing.assert_close(out[0][0], out[1][0], rtol=2e-4, atol=1e-6)
     for a, b in zip(out[0][1], out[1][1]):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("kind,optim", [("naive_resident", "adam"), ("naive_rebuild", "adam"), ("naive_resident", "sgd")])
+def test_captured_dynamic_windows_match_the_eager_loop(cuda, kind, optim):
+    """temporal.CapturedDynamicWindows (one HIP graph per window: snapshot moves / builds, norms, window cost, backward;
+    captured optimizer tail when the optimizer is capturable) == train_epoch_dynamic on the same objects: per-window
+    costs and parameters after one eager + three replayed epochs (the first of them captures)."""
+    import numpy as np
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import NaiveGraph
+    n, e0, churn, T, B, feat, hid, m = 4000, 30000, 800, 13, 4, 32, 64, 1500
+    rng = np.random.default_rng(11)
+    stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
+    snaps, pn_edges, pn_targets = [], [], []
+    gen = torch.Generator(device=cuda).manual_seed(4)
+    for t in range(T):
+        keys = stream[t * churn: t * churn + e0]
+        s, d = (keys // n).astype(np.int32), (keys % n).astype(np.int32)
+        snaps.append((torch.from_numpy(s).to(cuda), torch.from_numpy(d).to(cuda)))
+        pos = torch.from_numpy(np.stack([s[:m], d[:m]]).astype(np.int64)).to(cuda)
+        neg = torch.randint(0, n, (2, m), device=cuda, generator=gen)
+        pn_edges.append(torch.cat([pos, neg], 1))
+        pn_targets.append(torch.cat([torch.ones(m, device=cuda), torch.zeros(m, device=cuda)]))
+    out = []
+    for captured in (True, False):
+        G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False, resident=kind == "naive_resident", max_cached=B + 1)
+        torch.manual_seed(4)
+        model = temporal.DynamicSTGraphTGCN(feat, hid).to(cuda)
+        opt = (torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True) if optim == "adam"
+               else torch.optim.SGD(model.parameters(), lr=1e-2))
+        bucket = temporal.GradBucket(model.parameters())
+        cd, losses = None, []
+        for ep in range(4):
+            if kind == "naive_rebuild":
+                G._snapshots.clear()
+            G._ndata.clear()
+            if captured and ep >= 1:
+                cd = cd or temporal.CapturedDynamicWindows(model, G, pn_edges, pn_targets, B, opt, bucket, feat)
+                ls = temporal.train_epoch_dynamic_captured(cd, epoch=ep)
+                losses += [x.clone() for x in ls]
+            else:
+                losses += temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep)
+        if captured:
+            assert cd is not None and len(cd.graphs) == 3 and (cd.step_graph is not None) == (optim == "adam")   # window 3 = {t = 12}: no target
+        out.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-7)
+    for a, b in zip(out[0][1], out[1][1]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
