@@ -22,10 +22,13 @@ bucket per optimizer step -- the path the north star scales to 8 GPUs ("scaling"
 the epoch is fixed, ranks split its windows).
 
 A "dynamic" object carries BASELINE configs[4] (dynamic-temporal TGCN): epochs/s with the per-snapshot device
-CSR rebuild (its `value`) and on the dynamic edge store (PCSRGraph), windows sharded over the ranks.
+CSR rebuild (its `value`), with every snapshot's CSR resident as the reference's NaiveGraph keeps them (both replayed
+from one HIP graph per BPTT window after an eager epoch) and on the dynamic edge store (PCSRGraph, GPMAGraph; eager),
+windows sharded over the ranks; `csr_build_share` = 1 - resident / rebuild.
 
-A "gat" object carries BASELINE configs[2] (GAT, 8 heads, |V| = 256K, |E| = 8M): one GATConv layer forward + backward
-with a per-kernel table, and the 2-layer model of benchmarking/gat/seastar/model.py as epochs/s (rank 0 only).
+A "gat" object carries BASELINE configs[2] (GAT, 8 heads, |V| = 256K, |E| = 8M): one GATConv layer forward +
+backward(R) with a per-kernel table, and the 2-layer model of benchmarking/gat/seastar/model.py as epochs/s, eagerly and
+with the whole epoch replayed from a HIP graph (its `value`; rank 0 only).
 
 "roofline": dominant kernel gcn_agg -- algorithmic bytes per launch over its
 mean launch time, measured with HIP events on the launch stream inside the timed region; "traffic" = HBM bytes per
