@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 5
+#define STG_ABI_VERSION 6
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -412,6 +412,14 @@ size_t stg_gemm_tn_multi_workspace_bytes(int32_t T, int64_t K, int32_t M, int32_
 int stg_gemm_tn_multi_f32(const float *const *A, const float *const *B, int32_t T, float *C, float *colsum_A,
                           int64_t K, int32_t M, int32_t N, void *workspace, size_t workspace_bytes,
                           void *stream);
+
+/* C [M,N] = (A * [mask > 0])^T B and, if colsum_A, its column sums sum_k (A * [mask > 0])[k][m]: the weight and bias
+ * gradients of `act(X W + b)` with a ReLU (A = upstream gradient [K,M], mask = the layer's output [K,M], B = the layer's
+ * input [K,N]) in one launch -- the masked gradient is formed in the operand registers and never written
+ * (replaces stg_bias_act_bwd + stg_gemm_tn_colsum_f32 where nothing else needs the masked gradient).  All contiguous;
+ * workspace as stg_gemm_tn_workspace_bytes(K, M, N). */
+int stg_gemm_tn_relu_mask_f32(const float *A, const float *mask, const float *B, float *C, float *colsum_A,
+                              int64_t K, int32_t M, int32_t N, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same contraction with operands taken where the one-launch TGCN step leaves them (csrc/tgcn_step.hpp):
  * A_t [K, M] with row stride lda;  B_t [K, N] = [ op(b_t[:, 0:nsplit]) | b2_t[:, 0:N-nsplit] ] with row strides ldb /

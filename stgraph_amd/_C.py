@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_layer_fwd", "stg_bias_act_fwd", "stg_bias_act_bwd_workspace_bytes", "stg_bias_act_bwd",
     "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gat_fc_supported", "stg_gat_fc_fwd", "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
-    "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32",
+    "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32", "stg_gemm_tn_relu_mask_f32",
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
@@ -186,6 +186,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_rowgemm_strided_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, ctypes.c_int, vp]
     lib.stg_gemm_tn_colsum_f32.restype = ctypes.c_int
     lib.stg_gemm_tn_colsum_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, ctypes.c_size_t, vp]
+    lib.stg_gemm_tn_relu_mask_f32.restype = ctypes.c_int
+    lib.stg_gemm_tn_relu_mask_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, ctypes.c_size_t, vp]
     lib.stg_tgcn_cell_fused_supported.restype = ctypes.c_int
     lib.stg_tgcn_cell_fused_supported.argtypes = [i32]
     lib.stg_tgcn_cell_fused_fwd.restype = ctypes.c_int

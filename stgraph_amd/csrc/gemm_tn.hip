@@ -34,6 +34,7 @@ struct GemmSegs {
     const float *a[kGemmMaxSeg];
     const float *b[kGemmMaxSeg];
     const float *b2[kGemmMaxSeg];        // columns [nsplit, N) of B_t live in a second matrix (GemmForm::nsplit < N)
+    const float *am[kGemmMaxSeg];        // GemmForm::a_mask: A_t[k][m] counts only where am_t[k][m] > 0 (same shape and stride)
 };
 
 // Operand forms.  A_t is [K, M] with row stride lda.  B_t is [K, N] given as ONE or TWO row-major matrices side by
@@ -45,13 +46,16 @@ struct GemmForm {
     int lda, ldb, ldb2, nsplit;
     int b_op;                            // STG_GEMM_B_NONE / _CLAMP / _RELU
     float lo, hi;
+    int a_mask;                          // 1: A is taken as A * [am > 0] -- the backward of a ReLU applied while loading:
+                                         // dW = (g * [out > 0])^T X and its column sums (the bias gradient) in one launch,
+                                         // the masked gradient never written
 };
 
 // MT = 32-row M tiles per wave: every B dword a wave loads feeds MT MFMAs and every A dword NT of them.  With MT = 1
 // a k-pair costs 1 + NT dword loads for NT MFMAs; the kernel then runs at the rate the texture addresser issues
 // those loads (16 cycles per wave instruction, 8 waves per CU: 262 us of address cycles against 210 us of MFMA at
 // 1M x 128 x 128), and B is fetched once per M tile.  MT = 2: MT + NT loads for MT * NT MFMAs.
-template <int NT, int KU, bool CS, int MT>
+template <int NT, int KU, bool CS, int MT, bool AMASK = false>
 __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     const GemmSegs segs, const GemmForm form, float *__restrict__ slab, int64_t K, int M, int N, int64_t kslice_wave,
     int m_groups, int n_groups, int s_per_seg)
@@ -68,6 +72,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     const float *__restrict__ A = segs.a[seg];
     const float *__restrict__ B = segs.b[seg];
     const float *__restrict__ B2 = segs.b2[seg];
+    const float *__restrict__ AM = segs.am[seg];
+    constexpr bool a_mask = AMASK;      // (a template parameter: the mask registers must not cost the plain forms their occupancy)
     const int lda = form.lda, nsplit = form.nsplit;
 
     const int64_t k0 = ((int64_t)sl * kWavesPerBlock + wave) * kslice_wave;     // wave-uniform, inside the segment
@@ -117,6 +123,9 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + k0 * lda), 0,
                                                        rows > 0 ? (int)(((rows - 1) * lda + M) * (int64_t)sizeof(float)) : 0,
                                                        0x00020000);
+    const auto rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a_mask ? AM + k0 * lda : A + k0 * lda), 0,
+                                                       rows > 0 ? (int)(((rows - 1) * lda + M) * (int64_t)sizeof(float)) : 0,
+                                                       0x00020000);
     const auto rsB1 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(B + k0 * form.ldb), 0,
         rows > 0 ? (int)(((rows - 1) * form.ldb + nsplit) * (int64_t)sizeof(float)) : 0, 0x00020000);
@@ -130,14 +139,16 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     for (int i = 0; i < MT; ++i) voA[i] = (int)(la[i] * sizeof(float));
 #pragma unroll
     for (int j = 0; j < NT; ++j) voB[j] = (int)(lb[j] * sizeof(float));
-    auto load_set = [&](float (&a)[KU][MT], float (&b)[KU][NT], int64_t k) {
+    auto load_set = [&](float (&a)[KU][MT], float (&b)[KU][NT], float (&am)[a_mask ? KU : 1][a_mask ? MT : 1], int64_t k) {
         const int r0 = (int)(k - k0);                                           // uniform
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int soA = (r0 + 2 * u) * lda * (int)sizeof(float);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) {
                 a[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voA[i], soA, 0));
+                if constexpr (a_mask) am[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, voA[i], soA, 0));
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int soB = (r0 + 2 * u) * ldj[j] * (int)sizeof(float);
@@ -159,6 +170,14 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
                 b[u][j] = b_op == STG_GEMM_B_RELU ? (v < 0.f ? 0.f : v) : __builtin_amdgcn_fmed3f(v, blo, bhi);
             }
     };
+    auto mask_a = [&](float (&a)[KU][MT], const float (&am)[a_mask ? KU : 1][a_mask ? MT : 1]) {
+        if constexpr (a_mask) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[u][i] = am[u][i] > 0.f ? a[u][i] : 0.f;
+        }
+    };
     auto mfma_set = [&](const float (&a)[KU][MT], const float (&b)[KU][NT]) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
@@ -174,16 +193,18 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
 
     // two operand sets: the loads of the next STEP rows are in flight while the matrix pipe
     // consumes the current set (fp32 MFMA: 64 cycles each, KU*MT*NT of them per set)
-    float a0[KU][MT], b0[KU][NT], a1[KU][MT], b1[KU][NT];
-    if (k0 < k1) load_set(a0, b0, k0);
+    float a0[KU][MT], b0[KU][NT], a1[KU][MT], b1[KU][NT], m0[a_mask ? KU : 1][a_mask ? MT : 1], m1[a_mask ? KU : 1][a_mask ? MT : 1];
+    if (k0 < k1) load_set(a0, b0, m0, k0);
     for (int64_t k = k0; k < k1; k += 2 * STEP) {
         const bool more1 = k + STEP < k1;
-        if (more1) load_set(a1, b1, k + STEP);
+        if (more1) load_set(a1, b1, m1, k + STEP);
         transform(b0);
+        mask_a(a0, m0);
         mfma_set(a0, b0);
         if (more1) {
-            if (k + 2 * STEP < k1) load_set(a0, b0, k + 2 * STEP);
+            if (k + 2 * STEP < k1) load_set(a0, b0, m0, k + 2 * STEP);
             transform(b1);
+            mask_a(a1, m1);
             mfma_set(a1, b1);
         }
     }
@@ -331,7 +352,7 @@ namespace stg {
 namespace {
 int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C, float *colsum, int64_t K,
                 int32_t M, int32_t N, void *workspace, size_t workspace_bytes, void *stream_, const char *what,
-                const float *const *B2s = nullptr, const GemmForm *form_in = nullptr)
+                const float *const *B2s = nullptr, const GemmForm *form_in = nullptr, const float *const *AMs = nullptr)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (K < 0 || M <= 0 || N <= 0 || T <= 0 || T > kGemmMaxSeg)
@@ -346,8 +367,9 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         return e == hipSuccess ? 0 : fail((int)e, "%s: %s", what, hipGetErrorString(e));
     }
     if (!As || !Bs || !workspace) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
-    GemmForm form{M, N, 0, N, STG_GEMM_B_NONE, 0.f, 0.f};
+    GemmForm form{M, N, 0, N, STG_GEMM_B_NONE, 0.f, 0.f, 0};
     if (form_in) form = *form_in;
+    if (form.a_mask && !AMs) return fail(STG_ERR_INVALID_ARGUMENT, "%s: a_mask without mask operands", what);
     if (form.lda < M || form.nsplit < 0 || form.nsplit > N || (form.nsplit < N && form.nsplit % 32 != 0) ||
         form.ldb < form.nsplit || (form.nsplit < N && (!B2s || form.ldb2 < N - form.nsplit)) ||
         form.b_op < STG_GEMM_B_NONE || form.b_op > STG_GEMM_B_RELU)
@@ -361,6 +383,8 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         segs.a[t] = As[t];
         segs.b[t] = Bs[t];
         segs.b2[t] = form.nsplit < N ? B2s[t] : nullptr;
+        segs.am[t] = form.a_mask ? AMs[t] : nullptr;
+        if (form.a_mask && !AMs[t]) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL mask in segment %d", what, t);
     }
     const GemmPlan p = plan_gemm_tn(K, M, N, T, std::max(form.lda, std::max(form.ldb, form.ldb2)));
     if (p.S < 1 || (int64_t)T * p.S > INT32_MAX / 2)
@@ -376,8 +400,15 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
     const int64_t blocks = (int64_t)S_total * p.m_tiles * p.n_groups;
     const size_t lds = ((size_t)p.mt * p.nt * 16 + p.mt) * kWave * sizeof(float);
 #define STG_GEMM_LAUNCH(NT_, KU_, CS_, MT_)                                                                       \
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<NT_, KU_, CS_, MT_>), dim3((unsigned)blocks), dim3(kBlock), lds,   \
-                       stream, segs, form, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S)
+    do {                                                                                                          \
+        if (form.a_mask)                                                                                          \
+            hipLaunchKernelGGL((gemm_tn_partial_kernel<NT_, KU_, CS_, MT_, true>), dim3((unsigned)blocks),        \
+                               dim3(kBlock), lds, stream, segs, form, slab, K, M, N, p.kslice_wave, p.m_tiles,    \
+                               p.n_groups, p.S);                                                                  \
+        else                                                                                                      \
+            hipLaunchKernelGGL((gemm_tn_partial_kernel<NT_, KU_, CS_, MT_>), dim3((unsigned)blocks), dim3(kBlock), \
+                               lds, stream, segs, form, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S); \
+    } while (0)
 #define STG_GEMM_NT(CS_, MT_)                                                                                     \
     if (p.nt == 1) STG_GEMM_LAUNCH(1, 8, CS_, MT_); else if (p.nt == 2) STG_GEMM_LAUNCH(2, 8, CS_, MT_);         \
     else STG_GEMM_LAUNCH(4, 4, CS_, MT_)
@@ -430,7 +461,17 @@ extern "C" int stg_gemm_tn_form_f32(const float *const *A, int32_t lda, const fl
                                     float *C, float *colsum_A, int64_t K, int32_t M, int32_t N, void *workspace,
                                     size_t workspace_bytes, void *stream)
 {
-    const stg::GemmForm form{lda, ldb, ldb2, nsplit, b_op, lo, hi};
+    const stg::GemmForm form{lda, ldb, ldb2, nsplit, b_op, lo, hi, 0};
     return stg::gemm_tn_run(A, B, T, C, colsum_A, K, M, N, workspace, workspace_bytes, stream, "stg_gemm_tn_form_f32", B2,
                             &form);
+}
+
+extern "C" int stg_gemm_tn_relu_mask_f32(const float *A, const float *mask, const float *B, float *C, float *colsum_A,
+                                         int64_t K, int32_t M, int32_t N, void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    if (!mask) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_relu_mask_f32: NULL mask");
+    const stg::GemmForm form{M, N, 0, N, STG_GEMM_B_NONE, 0.f, 0.f, 1};
+    return stg::gemm_tn_run(&A, &B, 1, C, colsum_A, K, M, N, workspace, workspace_bytes, stream,
+                            "stg_gemm_tn_relu_mask_f32", nullptr, &form, &mask);
 }

@@ -888,6 +888,25 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, colsum: bool = False):
     return (c, cs) if colsum else c
 
 
+def gemm_tn_relu_mask(g: torch.Tensor, out: torch.Tensor, x: torch.Tensor, colsum: bool = True):
+    """``(g * (out > 0)).T @ x`` and, with ``colsum``, ``(g * (out > 0)).sum(0)`` -- the weight ([M, N], i.e. torch
+    Linear layout [out, in]) and bias gradients of ``relu(x W + b)`` -- in one launch, the masked gradient never
+    written (stg_gemm_tn_relu_mask_f32)."""
+    g, out, x = _f32(g, "g"), _f32(out, "out", g.device), _f32(x, "x", g.device)
+    if g.dim() != 2 or out.shape != g.shape or x.dim() != 2 or x.shape[0] != g.shape[0]:
+        raise ValueError("gemm_tn_relu_mask expects g, out [K, M] and x [K, N]")
+    K, M = g.shape
+    N = x.shape[1]
+    c = torch.empty(M, N, dtype=torch.float32, device=g.device)
+    cs = torch.empty(M, dtype=torch.float32, device=g.device) if colsum else None
+    ws_bytes = int(_C.lib.stg_gemm_tn_workspace_bytes(K, M, N))
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=g.device)
+    with torch.cuda.device(g.device), _Timed("gemm_tn", 4 * K * (2 * M + N) + 4 * M * N, 2 * K * M * N):
+        _C.check(_C.lib.stg_gemm_tn_relu_mask_f32(_ptr(g), _ptr(out), _ptr(x), _ptr(c), _ptr(cs), K, M, N, _ptr(ws),
+                                                  ws_bytes, _stream_ptr(g.device)))
+    return (c, cs) if colsum else c
+
+
 _WIDE_LINEAR = True
 _ROWGEMM_MODE = os.environ.get("STGRAPH_AMD_ROWGEMM", "0")     # "0" | "1" | "auto" (only where measured faster)
 _ROWGEMM = _ROWGEMM_MODE != "0"

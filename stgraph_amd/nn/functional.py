@@ -388,12 +388,18 @@ class _InputLayer(torch.autograd.Function):
         P, out = ctx.saved_tensors
         g = g.contiguous()
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        want_w = ctx.needs_input_grad[1]
         gb = gw = None
+        native = _use_native(P, P.shape[0], P.shape[1], g.shape[1])
+        if ctx.act == kernels.ACT_RELU and want_w and native and (int(P.shape[0]) * max(P.shape[1], g.shape[1]) < (1 << 29)):
+            # nothing but dW and db needs the masked gradient (the input carries none): one launch forms
+            # (g * [out > 0])^T P and its column sums, g * [out > 0] is never written
+            gwt, gb = kernels.gemm_tn_relu_mask(g, out, P, colsum=True)
+            return None, gwt.t().contiguous(), (gb if want_b else None), None, None, None, None, None
         if ctx.act != kernels.ACT_NONE or want_b:
             g, gb = kernels.bias_act_bwd(g, out if ctx.act != kernels.ACT_NONE else None, want_colsum=want_b)
-        if ctx.needs_input_grad[1]:
+        if want_w:
             W = ctx.w
-            native = _use_native(P, P.shape[0], P.shape[1], g.shape[1])
             if native and deferred_weight_grads() and W.is_leaf:
                 deferred.current().add(("mm", id(W)), P, g, sink=lambda d, W=W: deferred.add_to_grad(W, d))
             else:

@@ -111,3 +111,22 @@ def test_operand_forms_strides_split_and_transforms(cuda, K, T):
     one = [x[:, :1].contiguous() for x in d]
     close(kernels.gemm_tn_form(one, P, 1, 32), ref(one, P))
     assert torch.equal(kernels.gemm_tn_form(da3, P, 3 * C, 32), kernels.gemm_tn_multi(da3, P))      # same kernel, same order
+
+
+@pytest.mark.parametrize("K,M,N", [(100_003, 128, 128), (50_000, 64, 32), (4097, 16, 7), (20_000, 96, 200)])
+def test_relu_mask_on_load(cuda, K, M, N):
+    """stg_gemm_tn_relu_mask_f32: (g * [out > 0])^T x and its column sums without materialising the masked gradient."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(K + M)
+    g = torch.randn(K, M, device=cuda, generator=gen)
+    out = torch.relu(torch.randn(K, M, device=cuda, generator=gen))
+    x = torch.randn(K, N, device=cuda, generator=gen)
+    c, cs = kernels.gemm_tn_relu_mask(g, out, x, colsum=True)
+    gm = (g * (out > 0)).double()
+    want, want_cs = gm.t() @ x.double(), gm.sum(0)
+    scale = float(want.abs().max()) + 1
+    torch.testing.assert_close(c.double(), want, rtol=1e-5, atol=1e-6 * scale)
+    torch.testing.assert_close(cs.double(), want_cs, rtol=1e-5, atol=1e-6 * (float(want_cs.abs().max()) + 1))
+    # identical to the two-launch form (same kernel arithmetic on the same operand values)
+    two, two_cs = kernels.gemm_tn((g * (out > 0)), x, colsum=True)
+    assert torch.equal(c, two) and torch.equal(cs, two_cs)
