@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=50_000)
     ap.add_argument("--edges", type=int, default=500_000)
     ap.add_argument("--waves", type=str, default="")
+    ap.add_argument("--nid", action="store_true", help="visit rows in degree order (node_ids), as the layers do on a StaticGraph")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     n, e = args.nodes, args.edges
@@ -57,6 +58,7 @@ def main():
 
     def fwd():
         kernels.tgcn_step_fwd(n, C, FIN, FH, 2, -1e6, 1e6, dev, row_offsets=f.row_offset, column_indices=f.column_indices,
+                              node_ids=f.node_ids if args.nid else None,
                               norm_col_edge=ncf, ew_edge=ewf, norm=norm.view(-1), x=x, H=H, target=tgt, WcatT=WcatT,
                               b3=p["b3"], Wz=p["Wz"], bz=p["bz"], Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"],
                               W1=p["W1"], b1=p["b1"], W2=p["W2"], b2=p["b2"], **out)
@@ -66,6 +68,7 @@ def main():
 
     def bwd():
         kernels.tgcn_step_bwd(n, C, FIN, FH, 2, -1e6, 1e6, dev, row_offsets=b.row_offset, column_indices=b.column_indices,
+                              node_ids=b.node_ids if args.nid else None,
                               norm_col_edge=ncb, ew_edge=ewb, norm=norm.view(-1), zn=zn, dHn=dHn, g_cost=gc, Z=out["Z"],
                               R=out["R"], Ht=out["Ht"], H=H, Hn=out["Hn"], x3=out["x3"], y_out=out["y_out"], target=tgt,
                               WzT=T["Wz"], WrT=T["Wr"], WhT=T["Wh"], Wcat=p["Wcat"], W1T=T["W1"], W2=p["W2"], **bo)
