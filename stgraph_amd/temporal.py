@@ -784,6 +784,7 @@ class CapturedDynamicWindows:
         self.graphs, self.inputs, self.costs = {}, {}, {}
         self.step_graph = None
         self._tail_ready = False
+        self._probe = None
 
     def timestamps(self, w: int):
         return range(w * self.B, min((w + 1) * self.B, self.total - 1))
@@ -793,8 +794,9 @@ class CapturedDynamicWindows:
         if len(ts) == 0:
             return False
         e, t0 = self.edges, ts[0]
-        probe = torch.empty(self.n, self.feat, device=self.dev)
-        return dyn_window_usable(self.model, self.graph, probe) and all(
+        if self._probe is None:
+            self._probe = torch.empty(self.n, self.feat, device=self.dev)      # shape / dtype / device stand-in for a window input
+        return dyn_window_usable(self.model, self.graph, self._probe) and all(
             e[t].dtype == torch.int64 and e[t].is_contiguous() and e[t].dim() == 2 and e[t].shape == e[t0].shape
             and e[t].shape[1] > 0 and self.targets[t].dtype == torch.float32 and self.targets[t].is_contiguous()
             and self.targets[t].numel() == e[t].shape[1] for t in ts)
