@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 6
+#define STG_ABI_VERSION 7
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -340,11 +340,14 @@ int stg_gat_bwd(const float *A, const float *S, const float *out, const float *g
  * P is a scratch array of 2 N H floats: P and 1/S, or, for H = 8, D = 64, S | P in 64 bytes per vertex) and per edge T = ((sum_d g*feat[u]) / S - P) * A * slope, so the
  * per-edge out[v] row gather (half of K2's traffic) disappears.  Same outputs as stg_gat_bwd
  * (grad_feat bit-identical; grad_el / T regrouped sums -- the reference forms them with atomicAdd
- * in an undefined order).  Computes all H*D columns (no *_active argument). */
+ * in an undefined order).  Computes all H*D columns (no *_active argument).  grad_er (optional, [N,H]): the sum of
+ * T over every vertex's in-edges, regrouped into the per-vertex pass as slope * (g . out - P * S) -- what stg_gat_bwd_er
+ * computes from T (rounding noise around 0 in either form); with it T may be NULL and is then neither written nor
+ * needed. */
 int stg_gat_bwd_factored(const float *A, const float *S, const float *out, const float *g,
                          const float *feat, float *grad_feat, float *grad_el, float *T, float *P,
                          const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
-                         const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope,
+                         const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope, float *grad_er,
                          void *stream);
 int stg_gat_bwd_er(const float *T, float *grad_er,
                    const int32_t *row_offsets, const int32_t *eids, const int32_t *node_ids,

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -159,7 +159,7 @@ def _load() -> ctypes.CDLL:
     lib.stg_gat_bwd.restype = ctypes.c_int
     lib.stg_gat_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, f32, vp]
     lib.stg_gat_bwd_factored.restype = ctypes.c_int
-    lib.stg_gat_bwd_factored.argtypes = [vp] * 13 + [i32, i32, i32, f32, vp]
+    lib.stg_gat_bwd_factored.argtypes = [vp] * 13 + [i32, i32, i32, f32, vp, vp]
     lib.stg_gat_bwd_er.restype = ctypes.c_int
     lib.stg_gat_bwd_er.argtypes = [vp] * 5 + [i32, i32, i32, vp]
     lib.stg_gat_proj_supported.restype = ctypes.c_int

@@ -326,13 +326,19 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_kernel(
 // 34.7 GB at |E| = 8M, H*D = 512) disappears.  The reference sums these terms with atomicAdd in an
 // undefined order, so the regrouping stays inside its own run-to-run spread (tested to 1e-4).
 // (z = s - s is 0 or NaN, so the LeakyReLU derivative `z > 0 ? 1 : slope` is always `slope`.)
+// The same regrouping over a TARGET's in-edges gives grad_er without T:  sum_{e in in(v)} T[e,h]
+//     = slope * ( (1/S) * sum_e A_e (g . f_e)  -  P * sum_e A_e )  =  slope * ( g . out  -  P * S )      per (v, h),
+// because sum_e A_e f_e = S out (K1) and sum_e A_e = S (K0): a per-vertex quantity the prepass has in its registers.  In
+// exact arithmetic it is 0 (the softmax gradient sums to zero under a constant LeakyReLU slope); the reference's
+// atomicAdd sums leave rounding noise there (goldens: max |grad_er| 4.5e-7 next to grad_el of 4.7), and so does this
+// form.  With `grad_er` given, T is not needed (pass NULL): the E*H scattered stores and the dst-major pass over T go.
 // The prepass also leaves 1.0f / S[v,h] behind P (P is [2][N][H]): the per-edge kernel's T term then loads the
 // quotient the emitted unit forms per edge (same value) -- an IEEE fp32 division is ~ 10 VALU instructions per wave,
 // per edge and 256-float chunk.  alpha = A / S stays a division: grad_feat remains bit-identical to the emitted unit.
 template <int VEC, int LOG2G, int CHUNKS, bool POW2>
 __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_kernel(
     const float *__restrict__ S, const float *__restrict__ outp, const float *__restrict__ g,
-    float *__restrict__ P, int N, int H, int D)
+    float *__restrict__ P, int N, int H, int D, float *__restrict__ grad_er, float slope)
 {
     float *__restrict__ invS = P + (int64_t)N * H;
     constexpr int G = 1 << LOG2G;
@@ -351,19 +357,27 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_kernel(
             const int foff = fbase + (ch * G + j) * VEC;
             const bool fok = valid && foff < HD;
             const int h = foff < HD ? foff / D : 0;
-            float p = 0.f;
+            float p = 0.f, q = 0.f;
             if (fok) {
                 float gv[VEC], ov[VEC];
                 vec_load<VEC>(gv, g + (int64_t)v * HD + foff);
                 vec_load<VEC>(ov, outp + (int64_t)v * HD + foff);
                 const float s = S[(int64_t)v * H + h];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) p = p + (gv[i] / s) * ov[i];
+                for (int i = 0; i < VEC; ++i) {
+                    p = p + (gv[i] / s) * ov[i];
+                    q = q + gv[i] * ov[i];
+                }
             }
             const float tot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
+            float go = 0.f;
+            if (grad_er) go = head_sum<POW2>(q, LH, lds_wave, lane, j, G);          // kernel-uniform
             if (fok && (foff % D) == 0) {
+                const float s = S[(int64_t)v * H + h];
                 P[(int64_t)v * H + h] = tot;
-                invS[(int64_t)v * H + h] = 1.0f / S[(int64_t)v * H + h];
+                invS[(int64_t)v * H + h] = 1.0f / s;
+                // = sum over v's in-edges of T (see below); S = 0 <=> no in-edge (A = exp(0) or NaN): an empty sum
+                if (grad_er) grad_er[(int64_t)v * H + h] = s == 0.f ? 0.f : slope * (go - tot * s);
             }
         }
     }
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
                         else dot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
                         if (on && lead[ch]) {
                             const float tv = ((dot * iv[u][ch] - pv[u][ch]) * av[u][ch]) * slope;
-                            T[(int64_t)ek[u] * H + hh[ch]] = tv;
+                            if (T) T[(int64_t)ek[u] * H + hh[ch]] = tv;
                             gel[ch] = gel[ch] + tv;
                         }
                     }
@@ -482,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
 // row sums, valid in each row's lane 0) back.  T and grad_el leave as 32 contiguous bytes from lanes 0-7.
 __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_h8d64_kernel(
     const float *__restrict__ S, const float *__restrict__ outp, const float *__restrict__ g,
-    float *__restrict__ pack, int N)
+    float *__restrict__ pack, int N, float *__restrict__ grad_er, float slope)
 {
     constexpr int H = 8, HD = 512;
     const int lane = threadIdx.x & (kWave - 1);
@@ -497,11 +511,18 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_h8d64_kernel(
         vec_load<4>(ov, outp + (int64_t)v * HD + ch * 256 + lane * 4);
         // this lane's head: 4 ch + lane / 16; its S from lane (4 ch + lane / 16)
         const float sh = __int_as_float(__builtin_amdgcn_ds_bpermute((4 * ch + (lane >> 4)) * 4, __float_as_int(s)));
-        float p = 0.f;
+        float p = 0.f, q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p = p + (gv[i] / sh) * ov[i];
+        for (int i = 0; i < 4; ++i) {
+            p = p + (gv[i] / sh) * ov[i];
+            q = q + gv[i] * ov[i];
+        }
         const float tot = row16_sum_lane0(p);
-        if ((lane & 15) == 0) pack[(int64_t)v * 16 + 8 + 4 * ch + (lane >> 4)] = tot;
+        const float go = row16_sum_lane0(q);
+        if ((lane & 15) == 0) {
+            pack[(int64_t)v * 16 + 8 + 4 * ch + (lane >> 4)] = tot;
+            if (grad_er) grad_er[(int64_t)v * H + 4 * ch + (lane >> 4)] = sh == 0.f ? 0.f : slope * (go - tot * sh);   // S = 0: no in-edge
+        }
     }
     if (lane < H) pack[(int64_t)v * 16 + lane] = s;
 }
@@ -581,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_h8d64_kernel(
                     const float dt = (lane & 4) ? d1 : d0;
                     const float tv = ((dt * inv - pv) * Y[u]) * slope;
                     if (lane < H) {
-                        T[(int64_t)ek[u] * H + lane] = tv;
+                        if (T) T[(int64_t)ek[u] * H + lane] = tv;
                         gel = gel + tv;
                     }
                 }
@@ -773,14 +794,14 @@ extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float 
                                     float *P, const int32_t *row_offsets,
                                     const int32_t *column_indices, const int32_t *eids,
                                     const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope,
-                                    void *stream)
+                                    float *grad_er, void *stream)
 {
     using namespace stg;
     if (N < 0 || H <= 0 || D <= 0)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_factored: bad shape N=%d H=%d D=%d", N, H, D);
     if (N == 0) return 0;
-    if (!S || !out || !g || !feat || !grad_feat || !grad_el || !P || !row_offsets)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_factored: NULL pointer argument");
+    if (!S || !out || !g || !feat || !grad_feat || !grad_el || !P || !row_offsets || (!T && !grad_er))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_factored: NULL pointer argument (T or grad_er must be given)");
     const uintptr_t align = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
                             reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(grad_feat);
     const FeatPlan p = plan_features(H * D, D, H * D, align, true);
@@ -793,7 +814,7 @@ extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (H == 8 && D == 64 && p.vec == 4) {
         hipLaunchKernelGGL(gat_bwd_prepass_h8d64_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)),
-                           dim3(kBlock), 0, st, S, out, g, P, N);
+                           dim3(kBlock), 0, st, S, out, g, P, N, grad_er, slope);
         hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, P, g, feat,
                            grad_feat, grad_el, T, row_offsets, column_indices, eids, node_ids, N, slope);
         return check_launch("stg_gat_bwd_factored");
@@ -802,7 +823,7 @@ extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float 
     STG_SWITCH_LOG2G(p.chunks > 1 ? 6 : p.log2g, {                                                         \
         constexpr int LGE = (CH > 1 ? 6 : LG);                                                             \
         hipLaunchKernelGGL((gat_bwd_prepass_kernel<VEC, LGE, CH, P2>), dim3(grid_for(N, LGE)), dim3(kBlock), \
-                           0, st, S, out, g, P, N, H, D);                                                  \
+                           0, st, S, out, g, P, N, H, D, grad_er, slope);                                  \
         if (P2 && LH == 16 && LGE >= 4)                                                                    \
             hipLaunchKernelGGL((gat_bwd_fact_kernel<VEC, LGE, CH, UN, P2, true>), dim3(grid_for(N, LGE)),  \
                                dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,  \

@@ -752,6 +752,16 @@ def set_gat_factored_backward(enabled: bool) -> None:
     _GAT_FACTORED = bool(enabled)
 
 
+_GAT_REGROUPED_ER = True
+
+
+def set_gat_regrouped_er(on: bool) -> None:
+    """False: the factored backward writes the per-edge terms T and grad_er is summed from them by stg_gat_bwd_er (as
+    the emitted units do); True (default): grad_er from the per-vertex pass, slope * (g . out - P * S), T never formed."""
+    global _GAT_REGROUPED_ER
+    _GAT_REGROUPED_ER = bool(on)
+
+
 def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: float,
             use_node_ids: bool = False):
     """Backward unit K2 (+ the dst-major grad_er pass).  Returns (grad_feat, grad_el, grad_er)."""
@@ -771,7 +781,8 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
     grad_feat = alloc((N, H, D), dtype=torch.float32, device=dev)
     grad_el = alloc((N, H, 1), dtype=torch.float32, device=dev)
     grad_er = alloc((N, H, 1), dtype=torch.float32, device=dev)
-    T = alloc((E, H), dtype=torch.float32, device=dev)
+    regrouped = full and _GAT_FACTORED and _GAT_REGROUPED_ER
+    T = None if regrouped else alloc((E, H), dtype=torch.float32, device=dev)
     ab = gat_algorithmic_bytes(N, E, H, D)
     with torch.cuda.device(dev):
         st = _stream_ptr(dev)
@@ -781,7 +792,10 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
                 _C.check(_C.lib.stg_gat_bwd_factored(
                     _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(feat), _ptr(grad_feat), _ptr(grad_el), _ptr(T),
                     _ptr(P), _ptr(bwd.row_offset), _ptr(bwd.column_indices), _ptr(bwd.eids),
-                    _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, H, D, float(slope), st))
+                    _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, H, D, float(slope),
+                    _ptr(grad_er if regrouped else None), st))
+                if regrouped:       # grad_er came out of the per-vertex pass (sum of T over in-edges, regrouped): no T, no
+                    return grad_feat, grad_el, grad_er                            # dst-major pass over it
             else:
                 _C.check(_C.lib.stg_gat_bwd(
                     _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(el), _ptr(er), _ptr(feat),

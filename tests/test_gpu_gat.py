@@ -91,6 +91,17 @@ def test_oracle_random_graph(cuda, H, D, nid):
     assert np.array_equal(gfl.cpu().numpy(), gf0)
     np.testing.assert_allclose(gell.cpu().numpy(), gel0, rtol=TOL, atol=TOL * scale)
     np.testing.assert_allclose(gerl.cpu().numpy(), ger0, rtol=TOL, atol=TOL * scale)
+    # grad_er summed from the per-edge terms T (stg_gat_bwd_er) against the default, regrouped per-vertex form: both are
+    # rounding noise around zero (the softmax gradient sums to zero over a target's in-edges); grad_feat / grad_el same bits
+    kernels.set_gat_regrouped_er(False)
+    try:
+        gft, gelt, gert = kernels.gat_bwd(A, S, out, _t(R, cuda), _t(el, cuda), _t(er, cuda), _t(feat, cuda),
+                                          g.fwd, g.bwd, 0.2, nid)
+    finally:
+        kernels.set_gat_regrouped_er(True)
+    assert torch.equal(gft, gf) and torch.equal(gelt, gel)
+    np.testing.assert_allclose(gert.cpu().numpy(), ger0, rtol=TOL, atol=TOL * scale)
+    assert float(ger.abs().max()) <= 1e-5 * scale and float(gert.abs().max()) <= 1e-5 * scale
     # determinism: no atomics anywhere
     gf2, gel2, ger2 = kernels.gat_bwd(A, S, out, _t(R, cuda), _t(el, cuda), _t(er, cuda), _t(feat, cuda),
                                       g.fwd, g.bwd, 0.2, nid)
