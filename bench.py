@@ -437,6 +437,13 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
     ktab = {k: {"launches_per_iter": len(v["ms"]) / layer_iters, "mean_ms": float(np.mean(v["ms"])),
                 "algorithmic_bytes": v["bytes"],
                 "frac_of_hbm_peak": v["bytes"] / float(np.mean(v["ms"])) / 1e6 / HBM_PEAK_GBS} for k, v in tab.items()}
+    if "gat_k0" in ktab and ktab["gat_k0"]["frac_of_hbm_peak"] > 1.0:
+        # finite scores: A == 1.0f, S == in-degree (the literal `emb - max([emb])` of the vertex function is +0), so K0
+        # writes S from the row offsets and visits no edge; its SURVEY byte model no longer describes what runs
+        moved = 4 * n * H + 8 * n
+        ktab["gat_k0"].update({"bytes_model": "SURVEY.md 8(d) model of the emitted K0 (E*H scores read and written)",
+                               "shortcut": "all scores finite (device flag): S = min(deg, 2^24), A neither written nor read",
+                               "moved_bytes": moved, "frac_of_hbm_peak": None})
     if "gat_bwd" in ktab:   # the factored backward moves fewer bytes than the SURVEY model of the emitted unit
         moved = 4 * e * H * D + 12 * e * H + 16 * n * H * D
         ktab["gat_bwd"]["bytes_model"] = "SURVEY.md 8(d) model of the emitted K2 (two E*H*D gathers)"

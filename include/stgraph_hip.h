@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 7
+#define STG_ABI_VERSION 8
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -306,6 +306,14 @@ int stg_gcn_agg_transform(const float *x, const float *norm_row, const float *no
 /* dst[i] = table[idx[i]], i < n.  All [dev]. */
 int stg_edge_gather_f32(float *dst, const float *table, const int32_t *idx, int64_t n, void *stream);
 
+/* ones_flag (optional device word, NULL = not known) of the GAT entry points below: when *ones_flag == 0 every
+ * attention score el[u] + er[v] is finite, so the vertex function's `emb - max([emb])` (reference
+ * nn/pytorch/static/gat_conv.py:50) is +0, A[e,h] = exp(leaky(0)) = 1.0f exactly and S[v,h] = min(in-degree, 2^24);
+ * stg_gat_fwd_k0 then writes S without visiting an edge (A is left untouched) and the other units take A as 1.0f
+ * instead of loading it -- bit-identical to the general path.  stg_gat_score_flag sets it: 1 iff some |el| or |er| is
+ * not below 1e38 (inf and NaN included). */
+int stg_gat_score_flag(const float *el, const float *er, int64_t n, int32_t *flag, void *stream);
+
 /* ----------------------------------------------------------------- fused GAT
  * Replace the emitted units K0, K1 (forward) and K2 (backward) of GATConv
  * (tracer nn/pytorch/static/gat_conv.py:48-56; listing SURVEY.md Appendix B.3).
@@ -325,17 +333,17 @@ int stg_edge_gather_f32(float *dst, const float *table, const int32_t *idx, int6
 int stg_gat_fwd_k0(const float *el, const float *er, float *A, float *S,
                    const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
                    const int32_t *node_ids, int32_t N, int32_t H, int32_t H_active, float slope,
-                   void *stream);
+                   const int32_t *ones_flag, void *stream);
 int stg_gat_fwd_k1(const float *A, const float *S, const float *feat, float *out,
                    const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
                    const int32_t *node_ids, int32_t N, int32_t H, int32_t D, int32_t HD_active,
-                   void *stream);
+                   const int32_t *ones_flag, void *stream);
 int stg_gat_bwd(const float *A, const float *S, const float *out, const float *g,
                 const float *el, const float *er, const float *feat,
                 float *grad_feat, float *grad_el, float *T,
                 const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
                 const int32_t *node_ids, int32_t N, int32_t H, int32_t D, int32_t HD_active,
-                float slope, void *stream);
+                float slope, const int32_t *ones_flag, void *stream);
 /* K2 with the target-only part hoisted: P[v,h] = sum_d (g/S)*out (one pass over the vertices,
  * P is a scratch array of 2 N H floats: P and 1/S, or, for H = 8, D = 64, S | P in 64 bytes per vertex) and per edge T = ((sum_d g*feat[u]) / S - P) * A * slope, so the
  * per-edge out[v] row gather (half of K2's traffic) disappears.  Same outputs as stg_gat_bwd
@@ -348,7 +356,7 @@ int stg_gat_bwd_factored(const float *A, const float *S, const float *out, const
                          const float *feat, float *grad_feat, float *grad_el, float *T, float *P,
                          const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
                          const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope, float *grad_er,
-                         void *stream);
+                         const int32_t *ones_flag, void *stream);
 int stg_gat_bwd_er(const float *T, float *grad_er,
                    const int32_t *row_offsets, const int32_t *eids, const int32_t *node_ids,
                    int32_t N, int32_t H, int32_t H_active, void *stream);

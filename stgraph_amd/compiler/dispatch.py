@@ -98,7 +98,7 @@ class GatPlan:
     def forward(self, graph, n_feats, e_feats):
         el, er, feat = n_feats[self.el], n_feats[self.er], n_feats[self.feat]
         use_nid = kernels.rows_by_node_ids(graph.graph_type())
-        out, A, S = kernels.gat_fwd(el, er, feat, graph.csr("fwd"), self.slope, use_nid)
+        out, A, S = kernels.gat_fwd(el, er, feat, graph.csr("fwd"), self.slope, use_nid, ones_shortcut=True)
         return (out,), {"A": A, "S": S, "out": out, "el": el, "er": er, "feat": feat}
 
     def backward(self, graph, saved, grads):

@@ -50,18 +50,45 @@ __device__ __forceinline__ RowInfo row_prologue(const int *__restrict__ row_offs
     return ri;
 }
 
+// ------------------------------------------------------------------------------ "all ones" flag
+// The vertex function's `emb - max([emb])` (reference gat_conv.py:50) is s - s with s = el[u] + er[v]:
+// +0 for every finite s, hence A[e,h] = exp(leaky(0)) = 1.0f EXACTLY and S[v,h] = the in-degree, unless some score is
+// inf / NaN.  *flag (zeroed by the caller) is set when any |el| or |er| is not below 1e38 -- then, and only then, can a
+// sum be non-finite.  With the flag clear K0 writes S = min(deg, 2^24) (what the sequential fp32 sum of ones gives)
+// without visiting an edge, and K1 / K2 take A as the constant 1.0f instead of loading E*H of them (in K2 through a
+// scattered edge id): the same bits as the emitted units in every case, 0.3 ms of the cfg3 layer.
+__global__ __launch_bounds__(kBlock) void gat_score_flag_kernel(const float *__restrict__ el, const float *__restrict__ er,
+                                                                int64_t n, int *__restrict__ flag)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        bad |= !(fabsf(el[i]) < 1e38f) || !(fabsf(er[i]) < 1e38f);
+    if (bad) atomicOr(flag, 1);
+}
+
+__device__ __forceinline__ bool all_ones(const int *__restrict__ flag)
+{
+    return flag != nullptr && __builtin_amdgcn_readfirstlane(*flag) == 0;
+}
+
 // ------------------------------------------------------------------------------ K0
 template <int LOG2G>
 __global__ __launch_bounds__(kBlock) void gat_k0_kernel(
     const float *__restrict__ el, const float *__restrict__ er, float *__restrict__ A,
     float *__restrict__ S, const int *__restrict__ row_offsets,
     const int *__restrict__ column_indices, const int *__restrict__ eids,
-    const int *__restrict__ node_ids, int N, int H, int H_active, float slope)
+    const int *__restrict__ node_ids, int N, int H, int H_active, float slope, const int *__restrict__ flag)
 {
     constexpr int G = 1 << LOG2G;
     constexpr int U = G < 4 ? G : 4;
     const int j = threadIdx.x & (G - 1);
     const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+    if (all_ones(flag)) {                                   // kernel-uniform
+        const float s = (float)min(ri.deg, 1 << 24);
+        for (int h = j; h < H_active; h += G)
+            if (ri.valid) S[(int64_t)ri.r * H + h] = s;
+        return;
+    }
 
     for (int hbase = 0; hbase < H_active; hbase += G) {
         const int h = hbase + j;
@@ -109,13 +136,14 @@ __global__ __launch_bounds__(kBlock) void gat_k1_kernel(
     const float *__restrict__ A, const float *__restrict__ S, const float *__restrict__ feat,
     float *__restrict__ out, const int *__restrict__ row_offsets,
     const int *__restrict__ column_indices, const int *__restrict__ eids,
-    const int *__restrict__ node_ids, int N, int H, int D, int HD_active)
+    const int *__restrict__ node_ids, int N, int H, int D, int HD_active, const int *__restrict__ flag)
 {
     constexpr int G = 1 << LOG2G;
     constexpr int U = UNROLL < G ? UNROLL : G;
     const int j = threadIdx.x & (G - 1);
     const int HD = H * D;
     const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+    const bool ones = all_ones(flag);
 
     for (int fbase = 0; fbase < HD_active; fbase += G * VEC * CHUNKS) {
         float acc[CHUNKS][VEC];
@@ -151,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void gat_k1_kernel(
 #pragma unroll
                     for (int ch = 0; ch < CHUNKS; ++ch) {
                         if (kk < cnt && fok[ch]) {
-                            a[u][ch] = A[(int64_t)ek * H + hh[ch]];
+                            a[u][ch] = ones ? 1.0f : A[(int64_t)ek * H + hh[ch]];
                             vec_load<VEC>(v[u][ch], row + foff[ch]);
                         } else {
                             a[u][ch] = 0.f;
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_kernel(
     const float *__restrict__ feat, float *__restrict__ grad_feat, float *__restrict__ grad_el,
     float *__restrict__ T, const int *__restrict__ row_offsets,
     const int *__restrict__ column_indices, const int *__restrict__ eids,
-    const int *__restrict__ node_ids, int N, int H, int D, int HD_active, float slope)
+    const int *__restrict__ node_ids, int N, int H, int D, int HD_active, float slope, const int *__restrict__ flag)
 {
     constexpr int G = 1 << LOG2G;
     constexpr int U = UNROLL < G ? UNROLL : G;
@@ -224,6 +252,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_kernel(
     const int HD = H * D;
     const int LH = D / VEC;                       // lanes per head (host guarantees D % VEC == 0)
     const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+    const bool ones = all_ones(flag);
 
     for (int fbase = 0; fbase < HD_active; fbase += G * VEC * CHUNKS) {
         float a13[CHUNKS][VEC], a29[CHUNKS][VEC], fu[CHUNKS][VEC];
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_kernel(
 #pragma unroll
                     for (int ch = 0; ch < CHUNKS; ++ch) {
                         if (kk < cnt && fok[ch]) {
-                            av[u][ch] = A[(int64_t)ek[u] * H + hh[ch]];
+                            av[u][ch] = ones ? 1.0f : A[(int64_t)ek[u] * H + hh[ch]];
                             sv[u][ch] = S[(int64_t)ck * H + hh[ch]];
                             erv[u][ch] = er[(int64_t)ck * H + hh[ch]];
                             vec_load<VEC>(gv[u][ch], g + (int64_t)ck * HD + foff[ch]);
@@ -391,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
     const float *__restrict__ g, const float *__restrict__ feat, float *__restrict__ grad_feat,
     float *__restrict__ grad_el, float *__restrict__ T, const int *__restrict__ row_offsets,
     const int *__restrict__ column_indices, const int *__restrict__ eids,
-    const int *__restrict__ node_ids, int N, int H, int D, float slope)
+    const int *__restrict__ node_ids, int N, int H, int D, float slope, const int *__restrict__ flag)
 {
     constexpr int G = 1 << LOG2G;
     constexpr int U = UNROLL < G ? UNROLL : G;
@@ -402,6 +431,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
     const int HD = H * D;
     const int LH = D / VEC;
     const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+    const bool ones = all_ones(flag);
     const float *__restrict__ invS = P + (int64_t)N * H;
 
     for (int fbase = 0; fbase < HD; fbase += G * VEC * CHUNKS) {
@@ -439,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
 #pragma unroll
                     for (int ch = 0; ch < CHUNKS; ++ch) {
                         if (kk < cnt && fok[ch]) {
-                            av[u][ch] = A[(int64_t)ek[u] * H + hh[ch]];
+                            av[u][ch] = ones ? 1.0f : A[(int64_t)ek[u] * H + hh[ch]];
                             sv[u][ch] = S[(int64_t)ck * H + hh[ch]];
                             iv[u][ch] = invS[(int64_t)ck * H + hh[ch]];          // 1.0f / S
                             pv[u][ch] = P[(int64_t)ck * H + hh[ch]];
@@ -532,11 +562,12 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_h8d64_kernel(
     const float *__restrict__ A, const float *__restrict__ pack, const float *__restrict__ g,
     const float *__restrict__ feat, float *__restrict__ grad_feat, float *__restrict__ grad_el,
     float *__restrict__ T, const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
-    const int *__restrict__ eids, const int *__restrict__ node_ids, int N, float slope)
+    const int *__restrict__ eids, const int *__restrict__ node_ids, int N, float slope, const int *__restrict__ flag)
 {
     constexpr int H = 8, HD = 512, U = UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const RowInfo ri = row_prologue<6>(row_offsets, node_ids, N);
+    const bool ones = all_ones(flag);
     float a13[2][4], fu[2][4];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
@@ -566,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_h8d64_kernel(
                 ek[u] = __builtin_amdgcn_readlane(ev, kk & (kWave - 1));
                 if (kk < cnt) {                       // wave-uniform: one row per wave
                     X[u] = pack[(int64_t)ck * 16 + (lane & 15)];
-                    Y[u] = A[(int64_t)ek[u] * H + (lane & 7)];
+                    Y[u] = ones ? 1.0f : A[(int64_t)ek[u] * H + (lane & 7)];
 #pragma unroll
                     for (int ch = 0; ch < 2; ++ch) vec_load<4>(gv[u][ch], g + (int64_t)ck * HD + ch * 256 + lane * 4);
                 } else {
@@ -698,7 +729,7 @@ FeatPlan plan_features(int HD, int D, int active, uintptr_t align, bool need_hea
 extern "C" int stg_gat_fwd_k0(const float *el, const float *er, float *A, float *S,
                               const int32_t *row_offsets, const int32_t *column_indices,
                               const int32_t *eids, const int32_t *node_ids, int32_t N, int32_t H,
-                              int32_t H_active, float slope, void *stream)
+                              int32_t H_active, float slope, const int32_t *ones_flag, void *stream)
 {
     using namespace stg;
     if (N < 0 || H <= 0 || H_active < 0 || H_active > H)
@@ -710,14 +741,14 @@ extern "C" int stg_gat_fwd_k0(const float *el, const float *er, float *A, float 
     hipStream_t st = static_cast<hipStream_t>(stream);
     STG_SWITCH_LOG2G(log2g, hipLaunchKernelGGL((gat_k0_kernel<LG>), dim3(grid_for(N, LG)), dim3(kBlock), 0, st,
                                                el, er, A, S, row_offsets, column_indices, eids, node_ids,
-                                               N, H, H_active, slope));
+                                               N, H, H_active, slope, ones_flag));
     return check_launch("stg_gat_fwd_k0");
 }
 
 extern "C" int stg_gat_fwd_k1(const float *A, const float *S, const float *feat, float *out,
                               const int32_t *row_offsets, const int32_t *column_indices,
                               const int32_t *eids, const int32_t *node_ids, int32_t N, int32_t H,
-                              int32_t D, int32_t HD_active, void *stream)
+                              int32_t D, int32_t HD_active, const int32_t *ones_flag, void *stream)
 {
     using namespace stg;
     if (N < 0 || H <= 0 || D <= 0 || HD_active < 0 || (int64_t)HD_active > (int64_t)H * D)
@@ -733,7 +764,7 @@ extern "C" int stg_gat_fwd_k1(const float *A, const float *S, const float *feat,
                      hipLaunchKernelGGL((gat_k1_kernel<VEC, (CH > 1 ? 6 : LG), CH, UN>),                 \
                                         dim3(grid_for(N, (CH > 1 ? 6 : LG))), dim3(kBlock), 0, st, A, S, \
                                         feat, out, row_offsets, column_indices, eids, node_ids, N, H, D, \
-                                        HD_active))
+                                        HD_active, ones_flag))
 #define STG_K1_VEC(VEC)                          \
     if (p.chunks == 4) { STG_K1(VEC, 4, 2); }    \
     else if (p.chunks == 2) { STG_K1(VEC, 2, 4); } \
@@ -749,7 +780,7 @@ extern "C" int stg_gat_bwd(const float *A, const float *S, const float *out, con
                            float *grad_el, float *T, const int32_t *row_offsets,
                            const int32_t *column_indices, const int32_t *eids,
                            const int32_t *node_ids, int32_t N, int32_t H, int32_t D,
-                           int32_t HD_active, float slope, void *stream)
+                           int32_t HD_active, float slope, const int32_t *ones_flag, void *stream)
 {
     using namespace stg;
     if (N < 0 || H <= 0 || D <= 0 || HD_active < 0 || (int64_t)HD_active > (int64_t)H * D)
@@ -774,7 +805,7 @@ extern "C" int stg_gat_bwd(const float *A, const float *S, const float *out, con
                      hipLaunchKernelGGL((gat_bwd_kernel<VEC, (CH > 1 ? 6 : LG), CH, UN, P2>),            \
                                         dim3(grid_for(N, (CH > 1 ? 6 : LG))), dim3(kBlock), 0, st, A, S, \
                                         out, g, el, er, feat, grad_feat, grad_el, T, row_offsets,        \
-                                        column_indices, eids, node_ids, N, H, D, HD_active, slope))
+                                        column_indices, eids, node_ids, N, H, D, HD_active, slope, ones_flag))
 #define STG_K2_VEC(VEC, P2)                          \
     if (p.chunks == 4) { STG_K2(VEC, 4, 2, P2); }    \
     else if (p.chunks == 2) { STG_K2(VEC, 2, 2, P2); } \
@@ -794,7 +825,7 @@ extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float 
                                     float *P, const int32_t *row_offsets,
                                     const int32_t *column_indices, const int32_t *eids,
                                     const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope,
-                                    float *grad_er, void *stream)
+                                    float *grad_er, const int32_t *ones_flag, void *stream)
 {
     using namespace stg;
     if (N < 0 || H <= 0 || D <= 0)
@@ -816,7 +847,7 @@ extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float 
         hipLaunchKernelGGL(gat_bwd_prepass_h8d64_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)),
                            dim3(kBlock), 0, st, S, out, g, P, N, grad_er, slope);
         hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, P, g, feat,
-                           grad_feat, grad_el, T, row_offsets, column_indices, eids, node_ids, N, slope);
+                           grad_feat, grad_el, T, row_offsets, column_indices, eids, node_ids, N, slope, ones_flag);
         return check_launch("stg_gat_bwd_factored");
     }
 #define STG_K2F(VEC, CH, UN, P2)                                                                           \
@@ -827,11 +858,11 @@ extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float 
         if (P2 && LH == 16 && LGE >= 4)                                                                    \
             hipLaunchKernelGGL((gat_bwd_fact_kernel<VEC, LGE, CH, UN, P2, true>), dim3(grid_for(N, LGE)),  \
                                dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,  \
-                               column_indices, eids, node_ids, N, H, D, slope);                            \
+                               column_indices, eids, node_ids, N, H, D, slope, ones_flag);                 \
         else                                                                                               \
             hipLaunchKernelGGL((gat_bwd_fact_kernel<VEC, LGE, CH, UN, P2, false>), dim3(grid_for(N, LGE)), \
                                dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,  \
-                               column_indices, eids, node_ids, N, H, D, slope);                            \
+                               column_indices, eids, node_ids, N, H, D, slope, ones_flag);                 \
     })
     /* two-chunk rows (H*D = 512 at cfg3): unroll 2, not 4 -- 101 -> 80-odd VGPRs buys a fifth and sixth wave per   \
        SIMD, worth more than the deeper gather queue (measured 3.42 -> 2.90 ms; unroll 1: 3.1) */                  \
@@ -864,4 +895,18 @@ extern "C" int stg_gat_bwd_er(const float *T, float *grad_er, const int32_t *row
     STG_SWITCH_LOG2G(log2g, hipLaunchKernelGGL((gat_bwd_er_kernel<LG>), dim3(grid_for(N, LG)), dim3(kBlock), 0, st,
                                                T, grad_er, row_offsets, eids, node_ids, N, H, H_active));
     return check_launch("stg_gat_bwd_er");
+}
+
+extern "C" int stg_gat_score_flag(const float *el, const float *er, int64_t n, int32_t *flag, void *stream)
+{
+    using namespace stg;
+    if (n < 0 || !flag) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_score_flag: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return fail((int)e, "stg_gat_score_flag: %s", hipGetErrorString(e));
+    if (n == 0) return 0;
+    if (!el || !er) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_score_flag: NULL pointer argument");
+    const unsigned grid = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 256 * 8);
+    hipLaunchKernelGGL(gat_score_flag_kernel, dim3(grid), dim3(kBlock), 0, st, el, er, n, flag);
+    return check_launch("stg_gat_score_flag");
 }

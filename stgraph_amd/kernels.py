@@ -707,9 +707,23 @@ def gcn_agg_transform(x: torch.Tensor, W: torch.Tensor, norm_row: torch.Tensor, 
 
 
 # ------------------------------------------------------------------------------- GAT
+_GAT_ONES = True
+
+
+def set_gat_ones_shortcut(on: bool) -> None:
+    """False: the layers' GAT units always materialise and read the per-edge scores A (tests)."""
+    global _GAT_ONES
+    _GAT_ONES = bool(on)
+
+
 def gat_fwd(el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor, csr: DeviceCSR,
-            slope: float, use_node_ids: bool = False):
-    """Forward units K0 + K1.  Returns (out[N,H,D], A[E,H,1], S[N,H,1])."""
+            slope: float, use_node_ids: bool = False, ones_shortcut: bool = False):
+    """Forward units K0 + K1.  Returns (out[N,H,D], A[E,H,1], S[N,H,1]).
+
+    ``ones_shortcut`` (what the layers pass): a device flag says whether every score is finite (stg_gat_score_flag); if
+    so A is the constant 1.0f (``emb - max([emb])`` is +0: SURVEY.md D2) and is neither written by K0 nor read by K1 /
+    K2 -- same bits.  The returned ``A`` then carries the flag (``A._stg_ones``) for ``gat_bwd`` and its CONTENT IS ONLY
+    VALID WHEN THE FLAG IS SET (some non-finite score); callers that read A themselves leave the shortcut off."""
     feat = _f32(feat, "feat_src")
     dev = feat.device
     if feat.dim() != 3:
@@ -729,15 +743,22 @@ def gat_fwd(el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor, csr: DeviceC
     out = alloc((N, H, D), dtype=torch.float32, device=dev)
     nid = _ptr(csr.node_ids_if_ready if use_node_ids else None)
     ab = gat_algorithmic_bytes(N, E, H, D)
+    flag = None
     with torch.cuda.device(dev):
         st = _stream_ptr(dev)
+        if ones_shortcut and _GAT_ONES and full and not reference_compat():
+            flag = torch.empty(1, dtype=torch.int32, device=dev)
+            _C.check(_C.lib.stg_gat_score_flag(_ptr(el), _ptr(er), N * H, _ptr(flag), st))
         with _Timed("gat_k0", ab["gat_k0"], E * H):
             _C.check(_C.lib.stg_gat_fwd_k0(_ptr(el), _ptr(er), _ptr(A), _ptr(S), _ptr(csr.row_offset),
                                            _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, h_act,
-                                           float(slope), st))
+                                           float(slope), _ptr(flag), st))
         with _Timed("gat_k1", ab["gat_k1"], E * H * D):
             _C.check(_C.lib.stg_gat_fwd_k1(_ptr(A), _ptr(S), _ptr(feat), _ptr(out), _ptr(csr.row_offset),
-                                           _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, D, hd_act, st))
+                                           _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, D, hd_act,
+                                           _ptr(flag), st))
+    if flag is not None:
+        A._stg_ones = flag
     return out, A, S
 
 
@@ -783,6 +804,7 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
     grad_er = alloc((N, H, 1), dtype=torch.float32, device=dev)
     regrouped = full and _GAT_FACTORED and _GAT_REGROUPED_ER
     T = None if regrouped else alloc((E, H), dtype=torch.float32, device=dev)
+    flag = getattr(A, "_stg_ones", None)               # set by gat_fwd(ones_shortcut=True): A is 1.0f unless *flag
     ab = gat_algorithmic_bytes(N, E, H, D)
     with torch.cuda.device(dev):
         st = _stream_ptr(dev)
@@ -793,7 +815,7 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
                     _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(feat), _ptr(grad_feat), _ptr(grad_el), _ptr(T),
                     _ptr(P), _ptr(bwd.row_offset), _ptr(bwd.column_indices), _ptr(bwd.eids),
                     _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, H, D, float(slope),
-                    _ptr(grad_er if regrouped else None), st))
+                    _ptr(grad_er if regrouped else None), _ptr(flag), st))
                 if regrouped:       # grad_er came out of the per-vertex pass (sum of T over in-edges, regrouped): no T, no
                     return grad_feat, grad_el, grad_er                            # dst-major pass over it
             else:
@@ -801,7 +823,7 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
                     _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(el), _ptr(er), _ptr(feat),
                     _ptr(grad_feat), _ptr(grad_el), _ptr(T), _ptr(bwd.row_offset), _ptr(bwd.column_indices),
                     _ptr(bwd.eids), _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, H, D, hd_act,
-                    float(slope), st))
+                    float(slope), _ptr(flag), st))
         # heads the backward unit touched: those with at least one active feature column
         h_touched = H if full else min(H, (hd_act + D - 1) // D)
         with _Timed("gat_bwd_er", ab["gat_bwd_er"], E * H):

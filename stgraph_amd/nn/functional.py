@@ -463,7 +463,7 @@ class _GatLayer(torch.autograd.Function):
     def forward(ctx, feat, attn_l, attn_r, fwd_csr, bwd_csr, use_nid, slope):
         feat = feat.contiguous()
         el, er = kernels.gat_proj_fwd(feat, attn_l, attn_r)
-        out, A, S = kernels.gat_fwd(el, er, feat, fwd_csr, slope, use_nid)
+        out, A, S = kernels.gat_fwd(el, er, feat, fwd_csr, slope, use_nid, ones_shortcut=True)
         ctx.save_for_backward(feat, attn_l, attn_r, el, er, A, S, out)
         ctx.csrs, ctx.use_nid, ctx.slope = (fwd_csr, bwd_csr), use_nid, slope
         return out
@@ -486,7 +486,7 @@ class _GatFcLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, attn_l, attn_r, fwd_csr, bwd_csr, use_nid, slope, H, D):
         feat, el, er = kernels.gat_fc_fwd(x, w, attn_l, attn_r, H, D)
-        out, A, S = kernels.gat_fwd(el, er, feat, fwd_csr, slope, use_nid)
+        out, A, S = kernels.gat_fwd(el, er, feat, fwd_csr, slope, use_nid, ones_shortcut=True)
         ctx.save_for_backward(x, w, feat, attn_l, attn_r, el, er, A, S, out)
         ctx.csrs, ctx.use_nid, ctx.slope, ctx.w = (fwd_csr, bwd_csr), use_nid, slope, w
         return out

@@ -193,3 +193,48 @@ def test_golden_cora_shaped(cuda, H, D):
     o = out.cpu().numpy()
     assert np.array_equal(o[rows], d[tag + "_out_rows"])
     assert np.array_equal(o.astype(np.float64).sum(0), d[tag + "_out_colsum"])
+
+
+@pytest.mark.parametrize("H,D", [(8, 64), (2, 16), (8, 8)])
+@pytest.mark.parametrize("poison", [False, True])
+def test_all_ones_shortcut_is_bit_identical(cuda, H, D, poison, monkeypatch):
+    """Finite scores: A == 1.0f and S == in-degree, so the layers skip writing / reading A (device flag from
+    stg_gat_score_flag); one inf score: the flag is set and every unit takes the general path.  Same bits either way,
+    forward and backward, through the autograd node the layers use."""
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    if not kernels.gat_proj_supported(H, D):
+        pytest.skip("the one-node GAT layer does not cover this head shape")
+    n, e = 3000, 40000
+    src, dst = random_graph(H * D + 1, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    gen = torch.Generator(device=cuda).manual_seed(H + D)
+    feat0 = torch.randn(n, H, D, device=cuda, generator=gen)
+    al = torch.randn(H, D, device=cuda, generator=gen)
+    ar = torch.randn(H, D, device=cuda, generator=gen)
+    if poison:
+        feat0[17, 0, 0] = float("inf")                     # el[17, 0] = er[17, 0] = +-inf
+    R = torch.randn(n, H, D, device=cuda, generator=gen)
+    seen = []
+    real_bwd = kernels.gat_bwd
+    monkeypatch.setattr(kernels, "gat_bwd", lambda A, *a, **k: (seen.append(getattr(A, "_stg_ones", None)), real_bwd(A, *a, **k))[1])
+    res = []
+    for on in (True, False):
+        kernels.set_gat_ones_shortcut(on)
+        try:
+            feat = feat0.clone().requires_grad_(True)
+            a1, a2 = al.clone().requires_grad_(True), ar.clone().requires_grad_(True)
+            out = SF._GatLayer.apply(feat, a1, a2, g.csr("fwd"), g.csr("bwd"), False, 0.2)
+            out.backward(R)
+        finally:
+            kernels.set_gat_ones_shortcut(True)
+        res.append((out.detach(), feat.grad, a1.grad, a2.grad))
+    assert seen[0] is not None and int(seen[0].item()) == int(poison) and seen[1] is None
+    for a, b in zip(*res):
+        assert torch.equal(torch.nan_to_num(a, nan=7.0, posinf=8.0, neginf=9.0), torch.nan_to_num(b, nan=7.0, posinf=8.0, neginf=9.0))
+    if not poison:
+        deg = g.csr("fwd").row_offset[1:] - g.csr("fwd").row_offset[:-1]
+        el, er = kernels.gat_proj_fwd(feat0, al, ar)
+        _, A, S = kernels.gat_fwd(el, er, feat0, g.csr("fwd"), 0.2)
+        assert bool((A == 1).all()) and torch.equal(S.view(n, H), deg.float().view(n, 1).expand(n, H))
