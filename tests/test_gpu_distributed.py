@@ -1,0 +1,205 @@
+"""The N > 1 path on the device: 2 ranks (gloo, both on cuda:0 -- a one-GPU box) run the window-sharded static-temporal
+loop through the CAPTURED window (HIP graph per window body + captured `grad / world`, Adam, window index) and the
+dynamic loop through one HIP graph per window; each must equal a single process that consumes the same `world` windows
+per optimizer step eagerly and averages their gradients.  (RCCL itself needs two GPUs: the driver's scaling run.)"""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+N, E, FEAT, HID, T, B, EPOCHS, SEED = 3000, 20000, 32, 64, 11, 2, 3, 5
+
+
+def _static_problem(dev):
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import StaticGraph
+    from tests.util import gcn_norm, random_graph
+    src, dst = random_graph(21, N, E)
+    g = StaticGraph((src, dst), None, N, device=dev, sort_inplace=False)
+    g.set_ndata("norm", torch.from_numpy(gcn_norm(np.bincount(dst, minlength=N))).to(dev))
+    rng = np.random.default_rng(3)
+    ew = torch.from_numpy(rng.uniform(0.5, 1.5, (len(src), 1)).astype(np.float32)).to(dev)
+    targets = torch.from_numpy(rng.standard_normal((T, N, 1)).astype(np.float32)).to(dev)
+    torch.manual_seed(SEED)
+    model = temporal.STGraphTGCN(FEAT, HID, 1).to(dev)
+    return g, ew, targets, model
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stgraph_amd import temporal
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        g, ew, targets, model = _static_problem(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
+        bucket = temporal.GradBucket(model.parameters())
+        cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, FEAT, world=world, rank=rank)
+        assert cw.step_graph is not None
+        losses = []
+        for ep in range(EPOCHS):
+            losses += temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, FEAT, epoch=ep,
+                                                           rank=rank, world=world, seed=SEED)
+        torch.cuda.synchronize()
+        torch.save({"params": [p.detach().cpu() for p in model.parameters()], "losses": torch.stack(losses).cpu(),
+                    "calls": bucket.comm_calls}, os.path.join(outdir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _single_process_equivalent(world, dev):
+    from stgraph_amd import temporal
+    g, ew, targets, model = _static_problem(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    nwin = temporal.num_windows(T, B)
+    losses = {r: [] for r in range(world)}
+    for ep in range(EPOCHS):
+        for s in range((nwin + world - 1) // world):
+            grads = [torch.zeros_like(p) for p in model.parameters()]
+            for r in range(world):
+                w = s * world + r
+                if w >= nwin:
+                    continue
+                model.zero_grad()
+                y_hat = temporal.window_input(N, FEAT, ep, w, dev, SEED)
+                cost = temporal.window_cost_of(model, g, y_hat, ew, targets[w * B:min((w + 1) * B, T)]) / (B + 1)
+                cost.backward()
+                losses[r].append(cost.detach().cpu())
+                for acc, p in zip(grads, model.parameters()):
+                    if p.grad is not None:
+                        acc += p.grad
+            for acc, p in zip(grads, model.parameters()):
+                p.grad = acc / world
+            opt.step()
+    return [p.detach().cpu() for p in model.parameters()], losses
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_captured_static_windows_equal_single_process(cuda):
+    from stgraph_amd import temporal
+    world = 2
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_worker, args=(world, _free_port(), outdir), nprocs=world, join=True)
+        res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
+    want_params, want_losses = _single_process_equivalent(world, cuda)
+    steps = (temporal.num_windows(T, B) + world - 1) // world * EPOCHS
+    for r in range(world):
+        assert res[r]["calls"] == steps                    # ONE all-reduce per optimizer step
+        np.testing.assert_allclose(res[r]["losses"].numpy(), torch.stack(want_losses[r]).numpy(), rtol=2e-4, atol=1e-6)
+        for got, want in zip(res[r]["params"], want_params):
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3, atol=2e-5)
+    for a, b in zip(res[0]["params"], res[1]["params"]):   # replicas stay in lock step
+        assert torch.equal(a, b)
+
+
+DN, DE0, DCHURN, DT, DB, DM = 3000, 25000, 600, 11, 3, 1200
+
+
+def _dynamic_problem(dev, resident):
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import NaiveGraph
+    rng = np.random.default_rng(11)
+    stream = rng.choice(DN * DN, size=DE0 + DCHURN * DT, replace=False)
+    snaps, pn_edges, pn_targets = [], [], []
+    gen = torch.Generator(device=dev).manual_seed(4)
+    for t in range(DT):
+        keys = stream[t * DCHURN: t * DCHURN + DE0]
+        s, d = (keys // DN).astype(np.int32), (keys % DN).astype(np.int32)
+        snaps.append((torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)))
+        pos = torch.from_numpy(np.stack([s[:DM], d[:DM]]).astype(np.int64)).to(dev)
+        neg = torch.randint(0, DN, (2, DM), device=dev, generator=gen)
+        pn_edges.append(torch.cat([pos, neg], 1))
+        pn_targets.append(torch.cat([torch.ones(DM, device=dev), torch.zeros(DM, device=dev)]))
+    G = NaiveGraph(snaps, DN, device=dev, sort_inplace=False, resident=resident, max_cached=DB + 1)
+    torch.manual_seed(SEED)
+    model = temporal.DynamicSTGraphTGCN(FEAT, HID).to(dev)
+    return G, pn_edges, pn_targets, model
+
+
+def _dyn_worker(rank, world, port, outdir, resident):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stgraph_amd import temporal
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        G, pn_edges, pn_targets, model = _dynamic_problem(dev, resident)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
+        bucket = temporal.GradBucket(model.parameters())
+        losses = temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, DB, opt, bucket, FEAT, epoch=0, rank=rank,
+                                              world=world, seed=SEED)
+        cd = temporal.CapturedDynamicWindows(model, G, pn_edges, pn_targets, DB, opt, bucket, FEAT, world=world, rank=rank)
+        for ep in range(1, EPOCHS):
+            G._ndata.clear()
+            losses += [x.clone() for x in temporal.train_epoch_dynamic_captured(cd, epoch=ep, seed=SEED)]
+        torch.cuda.synchronize()
+        assert cd.step_graph is not None and len(cd.graphs) >= 1
+        torch.save({"params": [p.detach().cpu() for p in model.parameters()], "losses": torch.stack(losses).cpu()},
+                   os.path.join(outdir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _dyn_single_process_equivalent(world, dev, resident):
+    from stgraph_amd import temporal
+    from stgraph_amd.nn import functional as SF
+    G, pn_edges, pn_targets, model = _dynamic_problem(dev, resident)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    nwin = temporal.num_windows(DT, DB)
+    losses = {r: [] for r in range(world)}
+    for ep in range(EPOCHS):
+        G.reset_graph()
+        for s in range((nwin + world - 1) // world):
+            grads = [torch.zeros_like(p) for p in model.parameters()]
+            for r in range(world):
+                w = s * world + r
+                ts = range(w * DB, min((w + 1) * DB, DT - 1)) if w < nwin else range(0)
+                if len(ts) == 0:
+                    continue
+                model.zero_grad()
+                steps = []
+                for t in ts:
+                    G.get_graph(t)
+                    steps.append(dict(fwd=G.csr("fwd"), bwd=G.csr("bwd"), norm=temporal.in_degree_norm(G), edges=pn_edges[t],
+                                      targets=pn_targets[t], incidence=SF._incidence_of(pn_edges[t], DN)))
+                y_hat = temporal.window_input(DN, FEAT, ep, w, dev, SEED)
+                cost = temporal.dyn_window_cost(model, G, y_hat, steps) / (DB + 1)
+                cost.backward()
+                losses[r].append(cost.detach().cpu())
+                for acc, p in zip(grads, model.parameters()):
+                    if p.grad is not None:
+                        acc += p.grad
+            for acc, p in zip(grads, model.parameters()):
+                p.grad = acc / world
+            opt.step()
+    return [p.detach().cpu() for p in model.parameters()], losses
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("resident", [True, False])
+def test_two_ranks_captured_dynamic_windows_equal_single_process(cuda, resident):
+    world = 2
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_dyn_worker, args=(world, _free_port(), outdir, resident), nprocs=world, join=True)
+        res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
+    want_params, want_losses = _dyn_single_process_equivalent(world, cuda, resident)
+    for r in range(world):
+        np.testing.assert_allclose(res[r]["losses"].numpy(), torch.stack(want_losses[r]).numpy(), rtol=2e-4, atol=1e-6)
+        for got, want in zip(res[r]["params"], want_params):
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3, atol=2e-5)
+    for a, b in zip(res[0]["params"], res[1]["params"]):
+        assert torch.equal(a, b)
