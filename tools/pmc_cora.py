@@ -19,8 +19,12 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--K", type=int, default=1024)
     ap.add_argument("--feats", default="16,7")
+    ap.add_argument("--pipe", action="store_true", help="narrow rows on the persistent software-pipelined tile kernel")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if args.pipe:
+        from stgraph_amd import _C
+        _C.set_tuning("gcn_tile_pipe", 2)
     src, dst = cora_shaped()
     n, K = 2708, args.K
     big_src = np.concatenate([src + k * n for k in range(K)]).astype(np.int32)
