@@ -372,10 +372,11 @@ class _InputLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, norm, ew, fwd_csr, use_nid, act):
         P = kernels.gcn_agg(x, norm, norm, fwd_csr, ew=ew, use_node_ids=use_nid)
-        if bias is not None and w.is_contiguous():
+        fused_relu = getattr(torch, "_addmm_activation", None)
+        if bias is not None and w.is_contiguous() and (act == kernels.ACT_NONE or fused_relu is not None):
             # bias (+ ReLU) in the library GEMM's epilogue (hipBLASLt): 0.36 ms at [1M, 128] x [128, 128] against
             # 0.42 + 0.17 for rocBLAS + one more pass
-            out = torch._addmm_activation(bias, P, w) if act == kernels.ACT_RELU else torch.addmm(bias, P, w)
+            out = fused_relu(bias, P, w) if act == kernels.ACT_RELU else torch.addmm(bias, P, w)
         else:
             out = _mm(P, w)
             kernels.bias_act_fwd_(out, bias, act)
