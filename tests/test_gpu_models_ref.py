@@ -1,0 +1,393 @@
+"""The paths the benchmark TIMES -- reference-compat OFF, every shortcut ON -- against vectors recorded from the REFERENCE
+models and training loops (tests/golden/make_golden_models.py; benchmarking/*/seastar/model.py run unmodified on the
+reference's compiler stack):
+
+  * ``temporal.window_cost`` (one launch per snapshot each way, csrc/tgcn_step_*.hip) and ``CapturedStaticWindow`` vs
+    the static-temporal loop at the native widths 32 -> 64           (tgcn_native.npz; nn/pytorch/temporal/tgcn.py:21-55)
+  * ``temporal.dyn_window_cost`` / ``CapturedDynamicWindows`` vs the dynamic-temporal loop      (dyn_tgcn.npz)
+  * ``functional._InputLayer`` (aggregate first) + ``_GcnLayerTail`` vs the 2-layer GCN model, eagerly and replayed from
+    a HIP graph (``CapturedTrainStep``)                              (gcn_model.npz; nn/pytorch/static/gcn_conv.py:158-188)
+  * ``functional._GatFcLayer`` / ``_GatLayer`` vs GATConv and the 2-layer GAT model             (gat.npz, gat_model.npz;
+    nn/pytorch/static/gat_conv.py:41-58)
+
+All widths are powers of two, so reference defect D1 cannot trigger and compat OFF == compat ON
+in exact arithmetic.  Tolerance: north_star's 1e-4 (activations and gradients; absolute on values of magnitude <= 1,
+relative above)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import stgraph_amd
+from tests.util import golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _close(got, want, name, tol=TOL):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol, err_msg=name)
+
+
+def _colsum_close(t, d, key, name):
+    """fp64 column sums over ALL rows: |sum - want| <= 1e-4 * sum|x| (+ tiny)."""
+    got = t.detach().double().sum(-2).cpu().numpy()
+    bound = TOL * d[key + "_abs_colsum"] + 1e-6
+    assert np.all(np.abs(got - d[key + "_colsum"]) <= bound), name
+
+
+@pytest.fixture(autouse=True)
+def _defaults():
+    stgraph_amd.set_reference_compat(False)
+    yield
+    stgraph_amd.set_reference_compat(False)
+
+
+def _load(model, d, prefix, dev):
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(_t(d[prefix + k], dev))
+
+
+def _x0(seed, n, feat, dev):
+    return _t(np.random.default_rng(int(seed)).standard_normal((n, feat), dtype=np.float32), dev)
+
+
+# ------------------------------------------------------------------------------------------ static-temporal TGCN
+def _static_setup(d, cuda, use_ew):
+    from stgraph_amd.graph import StaticGraph
+    n = int(d["num_nodes"])
+    el = [(int(a), int(b)) for a, b in zip(d["src"], d["dst"])]
+    g = StaticGraph(el, d["edge_weight_by_eid"].reshape(-1).tolist(), n, device=cuda)
+    g.set_ndata("norm", _t(d["norm"], cuda))
+    T = int(d["T"])
+    targets = _t(np.random.default_rng(int(d["targets_seed"])).standard_normal((T, n, 1), dtype=np.float32), cuda)
+    ew = _t(d["edge_weight_by_eid"], cuda) if use_ew else None
+    return g, targets, ew, n, T
+
+
+@pytest.mark.parametrize("use_ew", [False, True])
+@pytest.mark.parametrize("B", [3, 6])
+def test_window_cost_matches_the_reference_loop_at_native_widths(cuda, B, use_ew):
+    from stgraph_amd import temporal
+    d = golden("tgcn_native.npz")
+    g, targets, ew, n, T = _static_setup(d, cuda, use_ew)
+    feat, hid, rows = int(d["feat"]), int(d["hidden"]), d["rows"]
+    tag = f"{'ew' if use_ew else 'now'}_B{B}"
+    model = temporal.STGraphTGCN(feat, hid, 1).to(cuda)
+    _load(model, d, f"{tag}_param_", cuda)
+    hs, ys, youts = [], [], []
+    for index in range(T // B):
+        model.zero_grad()
+        x0 = _x0(int(d["x0_seed_base"]) + index, n, feat, cuda)
+        tw = targets[index * B:(index + 1) * B]
+        assert temporal.window_cost_usable(model, g, x0, ew, tw), "the fused window path must be the one under test"
+        cost = temporal.window_cost_of(model, g, x0, ew, tw)
+        assert type(cost.grad_fn).__name__.startswith("_TGCNWindow")
+        saved = cost.grad_fn.saved_tensors            # (..., P, X3, Z, R, Ht, Hn, HR, Y, Yout, mask): see _TGCNWindow.forward
+        hs.append(saved[16].clone()), ys.append(saved[18].clone()), youts.append(saved[19].clone())
+        cost = cost / (B + 1)
+        cost.backward()
+        _close(cost, d[f"{tag}_cost"][index], "cost", 1e-5)
+        for k, p in model.named_parameters():
+            _close(p.grad, d[f"{tag}_w{index}_grad_{k}"], f"{tag} window {index} grad {k}")
+    H, Y, Yo = torch.cat(hs), torch.cat(ys), torch.cat(youts).unsqueeze(-1)
+    for key, t in (("hidden", H), ("y", Y), ("yout", Yo)):
+        _close(t[:, rows], d[f"{tag}_{key}_rows"], key)
+        _colsum_close(t, d, f"{tag}_{key}", key)
+
+
+@pytest.mark.parametrize("captured", [False, True])
+def test_static_training_loop_matches_the_reference_adam_run(cuda, captured, monkeypatch):
+    """2 epochs x 2 windows (B = 3, edge weights, Adam lr 1e-2) through train_epoch_static / its HIP-graph form."""
+    from stgraph_amd import temporal
+    d = golden("tgcn_native.npz")
+    g, targets, ew, n, T = _static_setup(d, cuda, True)
+    feat, hid, B = int(d["feat"]), int(d["hidden"]), 3
+    model = temporal.STGraphTGCN(feat, hid, 1).to(cuda)
+    _load(model, d, "train_param0_", cuda)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=captured)
+    bucket = temporal.GradBucket(model.parameters())
+    base = int(d["train_x0_seed_base"])
+    state = {"epoch": 0}
+
+    def chunk(num_nodes, f, epoch, c, device, seed=0, out=None):          # the reference loop's torch.randn draws
+        cw = temporal.chunk_windows(num_nodes, f)
+        buf = out if out is not None else torch.zeros(cw, num_nodes, f, device=device)
+        for w in range(min(cw, T // B)):
+            buf[w].copy_(_x0(base + epoch * 10 + c * cw + w, num_nodes, f, device))
+        return buf
+    monkeypatch.setattr(temporal, "window_input_chunk", chunk)
+    temporal._LAST_CHUNK.clear()
+    costs = []
+    cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, feat) if captured else None
+    for epoch in range(2):
+        state["epoch"] = epoch
+        if captured:
+            costs += temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat, epoch=epoch)
+        else:
+            costs += temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, feat, epoch=epoch)
+    _close(torch.stack([c.reshape(()) for c in costs]), d["train_costs"], "window costs", 1e-4)
+    for k, p in model.named_parameters():
+        _close(p, d["train_paramT_" + k], "parameter after 4 Adam steps: " + k, 2e-4)   # Adam: sign-like first steps amplify 1e-7
+
+
+# ------------------------------------------------------------------------------------------ dynamic-temporal TGCN
+@pytest.mark.parametrize("B", [3, 6])
+@pytest.mark.parametrize("resident", [True, False])
+def test_dyn_window_cost_matches_the_reference_loop(cuda, B, resident):
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import NaiveGraph
+    d = golden("dyn_tgcn.npz")
+    n, T, feat, hid, M = (int(d[k]) for k in ("num_nodes", "T", "feat", "hidden", "M"))
+    snaps = [[(int(a), int(b)) for a, b in zip(d[f"t{t}_src"], d[f"t{t}_dst"])] for t in range(T)]
+    G = NaiveGraph(snaps, n, device=cuda, resident=resident)
+    edges = [_t(d[f"t{t}_label_edges"], cuda) for t in range(T - 1)]
+    edges.append(edges[-1])
+    targets = [torch.cat([torch.ones(M), torch.zeros(M)]).to(cuda) for _ in range(T)]
+    model = temporal.DynamicSTGraphTGCN(feat, hid).to(cuda)
+    _load(model, d, f"B{B}_param_", cuda)
+    rows = d["rows"]
+    hs = []
+    G.reset_graph()
+    for index in range((T + B - 1) // B):
+        ts = range(index * B, min((index + 1) * B, T - 1))
+        if len(ts) == 0:
+            break
+        model.zero_grad()
+        x0 = _x0(int(d["x0_seed_base"]) + index, n, feat, cuda)
+        G.get_graph(index * B)
+        assert temporal.dyn_window_usable(model, G, x0)
+        steps = []
+        for t in ts:
+            G.get_graph(t)
+            if G.get_ndata("norm") is None:
+                G.set_ndata("norm", temporal.in_degree_norm(G))
+            steps.append(dict(fwd=G.csr("fwd"), bwd=G.csr("bwd"), norm=G.get_ndata("norm"), edges=edges[t],
+                              targets=targets[t], incidence=temporal.SF._incidence_of(edges[t], n)))
+        cost = temporal.dyn_window_cost(model, G, x0, steps)
+        hs.append(cost.grad_fn.saved_tensors[11].clone())          # Hn: see _TGCNDynWindow.forward
+        cost = cost / (B + 1)
+        cost.backward()
+        _close(cost, d[f"B{B}_cost"][index], "cost", 1e-5)
+        for k, p in model.named_parameters():
+            _close(p.grad, d[f"B{B}_w{index}_grad_{k}"], f"B{B} window {index} grad {k}")
+    H = torch.cat(hs)
+    _close(H[:, rows], d[f"B{B}_hidden_rows"], "hidden")
+    _colsum_close(H, d, f"B{B}_hidden", "hidden")
+
+
+# ------------------------------------------------------------------------------------------ GCN model
+def _gcn_setup(d, cuda, tag):
+    from stgraph_amd.graph import StaticGraph
+    n = int(d["num_nodes"])
+    g = StaticGraph((d["src"].copy(), d["dst"].copy()), None, n, device=cuda, sort_inplace=False)
+    g.set_ndata("norm", _t(d["norm"], cuda))
+    fin, hid, out = (int(v) for v in tag[1:].split("_"))
+    rng = np.random.default_rng(int(d[tag + "_seed"]))
+    if fin == 1433:
+        x = _t((rng.random((n, fin)) < 0.0127).astype(np.float32), cuda)
+    else:
+        x = _t(rng.standard_normal((n, fin), dtype=np.float32), cuda)
+    labels = _t(rng.integers(0, out, n).astype(np.int64), cuda)
+    return g, x, labels, (fin, hid, out)
+
+
+@pytest.mark.parametrize("mode", ["eager", "eager_native_wgrad", "hip_graph"])
+@pytest.mark.parametrize("tag", ["w128_128_128", "w1433_16_8"])
+def test_gcn_model_training_step_matches_the_reference(cuda, tag, mode, monkeypatch):
+    """logits / loss / every gradient of step 0, the losses of steps 0..3 and the parameters after 3 Adam steps.
+    ``eager_native_wgrad``: the split-K MFMA weight-gradient kernels (and the ReLU-masked form of the input layer) forced on
+    at this |V| (their production threshold is |V| >= 4096)."""
+    from bench import GCN
+    from stgraph_amd.capture import CapturedTrainStep
+    from stgraph_amd.nn import functional as SF
+    d = golden("gcn_model.npz")
+    g, x, labels, (fin, hid, out) = _gcn_setup(d, cuda, tag)
+    ntrain, rows = int(d["ntrain"]), d["rows"]
+    if mode == "eager_native_wgrad":
+        monkeypatch.setattr(SF, "MIN_K", 1024)
+    model = GCN(fin, hid, out, 1, F.relu).to(cuda)
+    _load(model, d, f"{tag}_param0_", cuda)
+    if fin <= hid:
+        assert SF.input_layer_usable(g, x, model.layers[0].weight, model.layers[0].activation), "aggregate-first must be under test"
+    assert SF.gcn_layer_tail_usable(g, x, model.layers[1].activation)
+    captured = mode == "hip_graph"
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4, **(dict(capturable=True, fused=True) if captured else {}))
+    keep = {}
+
+    def step():
+        logits = model(g, x)
+        loss = SF.cross_entropy(logits, labels, ntrain)
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        keep["logits"] = logits.detach()
+        opt.step()
+        return loss.detach()
+
+    if not captured:
+        # step 0 by hand: gradients before the optimizer moves
+        logits = model(g, x)
+        loss = SF.cross_entropy(logits, labels, ntrain)
+        loss.backward()
+        _close(logits[rows], d[tag + "_logits_rows"], "logits")
+        got, want, bound = (logits.detach().double().sum(0).cpu().numpy(), d[tag + "_logits_colsum"],
+                            TOL * d[tag + "_logits_abs_colsum"] + 1e-6)
+        assert np.all(np.abs(got - want) <= bound)
+        _close(loss, d[tag + "_losses"][0], "loss", 1e-5)
+        for k, p in model.named_parameters():
+            # gradients of a mean over 1624 rows are O(1e-4): relative to the largest entry of each tensor
+            w = d[f"{tag}_grad0_{k}"]
+            err = np.abs(p.grad.cpu().numpy() - w).max() / (np.abs(w).max() + 1e-30)
+            assert err <= TOL, (k, err)
+        model.zero_grad(set_to_none=False)
+    run = CapturedTrainStep(step, opt, list(model.parameters())) if captured else step
+    losses = [float(run()) for _ in range(3)]
+    logits = model(g, x)
+    losses.append(float(SF.cross_entropy(logits, labels, ntrain)))
+    np.testing.assert_allclose(losses, d[tag + "_losses"], rtol=1e-4, atol=1e-5)
+    for k, p in model.named_parameters():
+        _close(p, d[f"{tag}_param3_{k}"], "parameter after 3 Adam steps: " + k, 2e-4)
+
+
+def test_captured_train_step_equals_eager(cuda):
+    """CapturedTrainStep replays the kernels of the eager step: same losses and parameters to 1e-6 over 20 steps
+    (cfg1 shape 1433 -> 16 -> 7; torch's fused single-kernel Adam in both, so only the capture differs)."""
+    from bench import GCN
+    from stgraph_amd.capture import CapturedTrainStep
+    from stgraph_amd.nn import functional as SF
+    d = golden("gcn_model.npz")
+    g, x, labels, (fin, hid, out) = _gcn_setup(d, cuda, "w1433_16_7")
+    ntrain = int(d["ntrain"])
+    res = []
+    for captured in (False, True):
+        model = GCN(fin, hid, out, 1, F.relu).to(cuda)
+        _load(model, d, "w1433_16_7_param0_", cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4, capturable=True, fused=True)
+
+        def step():
+            logits = model(g, x)
+            loss = SF.cross_entropy(logits, labels, ntrain)
+            opt.zero_grad(set_to_none=False)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        run = CapturedTrainStep(step, opt, list(model.parameters())) if captured else step
+        losses = torch.stack([run().clone() for _ in range(20)])
+        res.append((losses, [p.detach().clone() for p in model.parameters()]))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=1e-6)
+    for a, b in zip(res[0][1], res[1][1]):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+
+
+def test_gcn_model_with_reference_defect_d1_in_compat_mode(cuda):
+    """1433 -> 16 -> 7 as the reference computes it (columns 4..6 of the 7-wide aggregation stay zero)."""
+    from bench import GCN
+    from stgraph_amd.nn import functional as SF
+    d = golden("gcn_model.npz")
+    tag = "w1433_16_7"
+    g, x, labels, (fin, hid, out) = _gcn_setup(d, cuda, tag)
+    stgraph_amd.set_reference_compat(True)
+    model = GCN(fin, hid, out, 1, F.relu).to(cuda)
+    _load(model, d, f"{tag}_param0_", cuda)
+    logits = model(g, x)
+    loss = SF.cross_entropy(logits, labels, int(d["ntrain"]))
+    loss.backward()
+    _close(logits[d["rows"]], d[tag + "_logits_rows"], "logits")
+    _close(loss, d[tag + "_losses"][0], "loss", 1e-5)
+    for k, p in model.named_parameters():
+        w = d[f"{tag}_grad0_{k}"]
+        assert np.abs(p.grad.cpu().numpy() - w).max() / (np.abs(w).max() + 1e-30) <= TOL, k
+
+
+# ------------------------------------------------------------------------------------------ GAT
+@pytest.mark.parametrize("H,D", [(2, 4), (8, 8), (8, 64)])
+@pytest.mark.parametrize("fc_fused", [True, False])
+def test_gatconv_fused_layers_match_the_reference_layer(cuda, H, D, fc_fused):
+    """_GatFcLayer (fc + projections in one GEMM epilogue) and _GatLayer against the reference GATConv, compat OFF."""
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    d = golden("gat.npz")
+    n = int(d["num_nodes"])
+    el = [(int(a), int(b)) for a, b in zip(d["src"], d["dst"])]
+    g = StaticGraph(el, [1.0] * len(el), n, device=cuda)
+    tag = f"H{H}_D{D}"
+    conv = GATConv(d[tag + "_x"].shape[1], D, H).to(cuda)
+    with torch.no_grad():
+        conv.fc.weight.copy_(_t(d[tag + "_fc_weight"], cuda))
+        conv.attn_l.copy_(_t(d[tag + "_attn_l"], cuda))
+        conv.attn_r.copy_(_t(d[tag + "_attn_r"], cuda))
+    x = _t(d[tag + "_x"], cuda).requires_grad_(True)
+    SF.set_gat_fc(fc_fused)
+    try:
+        fused_in = SF.gat_fc_layer_usable(g, x, conv.fc, H, D)
+        assert fused_in == (fc_fused and SF.kernels.gat_fc_supported(x.shape[1], H, D))
+        assert SF.gat_layer_usable(g, torch.empty(n, H, D, device=cuda))
+        out = conv(g, x)
+        names = []
+        node = out.grad_fn
+        while node is not None and len(names) < 6:
+            names.append(type(node).__name__)
+            node = node.next_functions[0][0] if node.next_functions else None
+        assert any(nm.startswith("_GatFcLayer" if fused_in else "_GatLayer") for nm in names), names
+        (out * _t(d[tag + "_R"], cuda)).sum().backward()
+    finally:
+        SF.set_gat_fc(True)
+    _close(out, d[tag + "_out"], "out")
+    for name, got in (("grad_x", x.grad), ("grad_fc_weight", conv.fc.weight.grad),
+                      ("grad_attn_l", conv.attn_l.grad), ("grad_attn_r", conv.attn_r.grad)):
+        _close(got, d[f"{tag}_{name}"], name)
+
+
+@pytest.mark.parametrize("mode", ["eager", "hip_graph"])
+@pytest.mark.parametrize("tag", ["in32_H8_D8", "in64_H8_D64"])
+def test_gat_model_training_step_matches_the_reference(cuda, tag, mode):
+    from bench import GAT
+    from stgraph_amd.capture import CapturedTrainStep
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    d = golden("gat_model.npz")
+    n, ntrain, rows = int(d["num_nodes"]), int(d["ntrain"]), d["rows"]
+    g = StaticGraph((d["src"].copy(), d["dst"].copy()), None, n, device=cuda, sort_inplace=False)
+    parts = tag.split("_")
+    fin, H, D = int(parts[0][2:]), int(parts[1][1:]), int(parts[2][1:])
+    classes = 16
+    rng = np.random.default_rng(int(d[tag + "_seed"]))
+    x = _t(rng.standard_normal((n, fin), dtype=np.float32), cuda)
+    labels = _t(rng.integers(0, classes, n).astype(np.int64), cuda)
+    model = GAT(g, 1, fin, D, classes, [H, 1], F.elu).to(cuda)
+    _load(model, d, f"{tag}_param0_", cuda)
+    captured = mode == "hip_graph"
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4, **(dict(capturable=True, fused=True) if captured else {}))
+
+    def step():
+        logits = model(x)
+        loss = SF.cross_entropy(logits, labels, ntrain)
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    if not captured:
+        logits = model(x)
+        loss = SF.cross_entropy(logits, labels, ntrain)
+        loss.backward()
+        _close(logits[rows], d[tag + "_logits_rows"], "logits")
+        _close(loss, d[tag + "_losses"][0], "loss", 1e-5)
+        for k, p in model.named_parameters():
+            w = d[f"{tag}_grad0_{k}"]
+            err = np.abs(p.grad.cpu().numpy() - w).max() / (np.abs(w).max() + 1e-30)
+            assert err <= TOL, (k, err)
+        model.zero_grad(set_to_none=False)
+    run = CapturedTrainStep(step, opt, list(model.parameters())) if captured else step
+    losses = [float(run()) for _ in range(3)]
+    losses.append(float(SF.cross_entropy(model(x), labels, ntrain)))
+    np.testing.assert_allclose(losses, d[tag + "_losses"], rtol=1e-4, atol=1e-5)
+    for k, p in model.named_parameters():
+        _close(p, d[f"{tag}_param3_{k}"], "parameter after 3 Adam steps: " + k, 2e-4)
