@@ -34,6 +34,14 @@ def _close(got, want, name, tol=TOL):
     np.testing.assert_allclose(got, want, rtol=tol, atol=tol, err_msg=name)
 
 
+def _grad_close(got, want, name, tol=TOL):
+    """Gradients of a mean loss over thousands of rows are O(1e-5): an absolute 1e-4 would be vacuous, so the error is
+    taken relative to the largest entry of the tensor."""
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    err = np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+    assert err <= tol, (name, float(err))
+
+
 def _colsum_close(t, d, key, name):
     """fp64 column sums over ALL rows: |sum - want| <= 1e-4 * sum|x| (+ tiny)."""
     got = t.detach().double().sum(-2).cpu().numpy()
@@ -84,7 +92,7 @@ def test_window_cost_matches_the_reference_loop_at_native_widths(cuda, B, use_ew
     hs, ys, youts = [], [], []
     for index in range(T // B):
         model.zero_grad()
-        x0 = _x0(int(d["x0_seed_base"]) + index, n, feat, cuda)
+        x0 = _x0(int(d[f"{tag}_x0_seeds"][index]), n, feat, cuda)
         tw = targets[index * B:(index + 1) * B]
         assert temporal.window_cost_usable(model, g, x0, ew, tw), "the fused window path must be the one under test"
         cost = temporal.window_cost_of(model, g, x0, ew, tw)
@@ -95,46 +103,59 @@ def test_window_cost_matches_the_reference_loop_at_native_widths(cuda, B, use_ew
         cost.backward()
         _close(cost, d[f"{tag}_cost"][index], "cost", 1e-5)
         for k, p in model.named_parameters():
-            _close(p.grad, d[f"{tag}_w{index}_grad_{k}"], f"{tag} window {index} grad {k}")
+            _grad_close(p.grad, d[f"{tag}_w{index}_grad_{k}"], f"{tag} window {index} grad {k}")
     H, Y, Yo = torch.cat(hs), torch.cat(ys), torch.cat(youts).unsqueeze(-1)
     for key, t in (("hidden", H), ("y", Y), ("yout", Yo)):
         _close(t[:, rows], d[f"{tag}_{key}_rows"], key)
         _colsum_close(t, d, f"{tag}_{key}", key)
 
 
-@pytest.mark.parametrize("captured", [False, True])
-def test_static_training_loop_matches_the_reference_adam_run(cuda, captured, monkeypatch):
-    """2 epochs x 2 windows (B = 3, edge weights, Adam lr 1e-2) through train_epoch_static / its HIP-graph form."""
+@pytest.mark.parametrize("mode", ["eager", "hip_graph", "hip_graph_capturable_adam"])
+def test_static_training_loop_matches_the_reference_adam_run(cuda, mode, monkeypatch):
+    """2 epochs x 2 windows (B = 3, edge weights, Adam lr 1e-2) through train_epoch_static / its HIP-graph form.
+
+    ``eager`` and ``hip_graph`` (window replayed from the graph, torch's default Adam stepping eagerly) follow the
+    reference run to 2e-5 on every parameter.  With torch's ``capturable=True`` Adam (optimizer inside the second graph)
+    one step differs from the default Adam by 7e-8 (measured, same gradients); entries whose gradient is below Adam's
+    eps = 1e-8 (the gradients here peak at 2.5e-5 and reach down to 3e-11) move by lr * dg / (|g| + eps), so that
+    difference grows to ~1e-3 on a fraction of a percent of the entries after 4 steps -- a property of the update rule,
+    not of this package (the captured window's gradients are bit-identical to the eager ones): costs are checked
+    strictly, parameters in the bulk."""
     from stgraph_amd import temporal
     d = golden("tgcn_native.npz")
     g, targets, ew, n, T = _static_setup(d, cuda, True)
     feat, hid, B = int(d["feat"]), int(d["hidden"]), 3
     model = temporal.STGraphTGCN(feat, hid, 1).to(cuda)
     _load(model, d, "train_param0_", cuda)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=captured)
+    captured = mode != "eager"
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=mode == "hip_graph_capturable_adam")
     bucket = temporal.GradBucket(model.parameters())
     base = int(d["train_x0_seed_base"])
-    state = {"epoch": 0}
 
     def chunk(num_nodes, f, epoch, c, device, seed=0, out=None):          # the reference loop's torch.randn draws
         cw = temporal.chunk_windows(num_nodes, f)
         buf = out if out is not None else torch.zeros(cw, num_nodes, f, device=device)
         for w in range(min(cw, T // B)):
-            buf[w].copy_(_x0(base + epoch * 10 + c * cw + w, num_nodes, f, device))
+            buf[w].copy_(_x0(base + epoch * 2 + c * cw + w, num_nodes, f, device))
         return buf
     monkeypatch.setattr(temporal, "window_input_chunk", chunk)
     temporal._LAST_CHUNK.clear()
     costs = []
     cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, feat) if captured else None
+    assert cw is None or (cw.step_graph is not None) == (mode == "hip_graph_capturable_adam")
     for epoch in range(2):
-        state["epoch"] = epoch
         if captured:
             costs += temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat, epoch=epoch)
         else:
             costs += temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, feat, epoch=epoch)
-    _close(torch.stack([c.reshape(()) for c in costs]), d["train_costs"], "window costs", 1e-4)
+    _close(torch.stack([c.reshape(()) for c in costs]), d["train_costs"], "window costs", 1e-5)
     for k, p in model.named_parameters():
-        _close(p, d["train_paramT_" + k], "parameter after 4 Adam steps: " + k, 2e-4)   # Adam: sign-like first steps amplify 1e-7
+        want = d["train_paramT_" + k]
+        err = np.abs(p.detach().cpu().numpy() - want)
+        if mode == "hip_graph_capturable_adam":
+            assert (err > 2e-4).mean() < 0.01 and err.max() < 5e-3, (k, float(err.max()), float((err > 2e-4).mean()))
+        else:
+            assert err.max() <= 2e-5, (k, float(err.max()))
 
 
 # ------------------------------------------------------------------------------------------ dynamic-temporal TGCN
@@ -160,7 +181,7 @@ def test_dyn_window_cost_matches_the_reference_loop(cuda, B, resident):
         if len(ts) == 0:
             break
         model.zero_grad()
-        x0 = _x0(int(d["x0_seed_base"]) + index, n, feat, cuda)
+        x0 = _x0(int(d[f"B{B}_x0_seeds"][index]), n, feat, cuda)
         G.get_graph(index * B)
         assert temporal.dyn_window_usable(model, G, x0)
         steps = []
@@ -176,7 +197,7 @@ def test_dyn_window_cost_matches_the_reference_loop(cuda, B, resident):
         cost.backward()
         _close(cost, d[f"B{B}_cost"][index], "cost", 1e-5)
         for k, p in model.named_parameters():
-            _close(p.grad, d[f"B{B}_w{index}_grad_{k}"], f"B{B} window {index} grad {k}")
+            _grad_close(p.grad, d[f"B{B}_w{index}_grad_{k}"], f"B{B} window {index} grad {k}")
     H = torch.cat(hs)
     _close(H[:, rows], d[f"B{B}_hidden_rows"], "hidden")
     _colsum_close(H, d, f"B{B}_hidden", "hidden")
@@ -248,8 +269,8 @@ def test_gcn_model_training_step_matches_the_reference(cuda, tag, mode, monkeypa
         model.zero_grad(set_to_none=False)
     run = CapturedTrainStep(step, opt, list(model.parameters())) if captured else step
     losses = [float(run()) for _ in range(3)]
-    logits = model(g, x)
-    losses.append(float(SF.cross_entropy(logits, labels, ntrain)))
+    with torch.no_grad():
+        losses.append(float(SF.cross_entropy(model(g, x), labels, ntrain)))
     np.testing.assert_allclose(losses, d[tag + "_losses"], rtol=1e-4, atol=1e-5)
     for k, p in model.named_parameters():
         _close(p, d[f"{tag}_param3_{k}"], "parameter after 3 Adam steps: " + k, 2e-4)
@@ -381,13 +402,18 @@ def test_gat_model_training_step_matches_the_reference(cuda, tag, mode):
         _close(logits[rows], d[tag + "_logits_rows"], "logits")
         _close(loss, d[tag + "_losses"][0], "loss", 1e-5)
         for k, p in model.named_parameters():
-            w = d[f"{tag}_grad0_{k}"]
-            err = np.abs(p.grad.cpu().numpy() - w).max() / (np.abs(w).max() + 1e-30)
+            # attn_r's gradient is zero in exact arithmetic (sum_e alpha_e (g.feat_u) - g.out_v = 0 per destination:
+            # K2's grad_er) -- the reference's own value is 2e-10 of rounding noise against
+            # 4e-3 for attn_l -- so it is held to the scale of its layer's attn_l gradient
+            w, scale = d[f"{tag}_grad0_{k}"], d[f"{tag}_grad0_{k.replace('attn_r', 'attn_l')}"]
+            err = np.abs(p.grad.cpu().numpy() - w).max() / (np.abs(scale).max() + 1e-30)
             assert err <= TOL, (k, err)
         model.zero_grad(set_to_none=False)
     run = CapturedTrainStep(step, opt, list(model.parameters())) if captured else step
     losses = [float(run()) for _ in range(3)]
-    losses.append(float(SF.cross_entropy(model(x), labels, ntrain)))
+    with torch.no_grad():
+        losses.append(float(SF.cross_entropy(model(x), labels, ntrain)))
     np.testing.assert_allclose(losses, d[tag + "_losses"], rtol=1e-4, atol=1e-5)
     for k, p in model.named_parameters():
-        _close(p, d[f"{tag}_param3_{k}"], "parameter after 3 Adam steps: " + k, 2e-4)
+        # attn_r: Adam turns a 2e-10 noise gradient into steps of lr * g / (|g| + eps) ~ 1e-4 of either sign
+        _close(p, d[f"{tag}_param3_{k}"], "parameter after 3 Adam steps: " + k, 6e-4 if k.endswith("attn_r") else 2e-4)
