@@ -6,10 +6,11 @@
 Main line, N = 1: BASELINE.json configs[1] -- 2-layer GCN 128->128->128 on a synthetic CSR
 with |V| = 1M, |E| = 16M (uniform, duplicate-free, seed 1).  One step = one training epoch
 (forward, cross-entropy on the train mask, backward, Adam), inputs resident in HBM.
-`value` = edges*feat/s = (4 x E x F) / wall time of a step, whole job: 4 = the aggregations of one training step in the
-reference's formulation (2 layers, forward + backward).  The step itself executes 3: the first layer's input carries no
-gradient, so it aggregates before its weight product and its backward needs none (nn/functional._InputLayer); the same
-step in the reference's order is timed beside it (`reference_order`).
+`value` = edges*feat/s = sum of E x F over the aggregation launches executed in the timed region / wall time, whole job
+(SURVEY.md 8(d)).  The step executes 3 aggregations: the first layer's input carries no gradient, so it aggregates before
+its weight product and its backward needs none (nn/functional._InputLayer); `value_reference_formulation` counts the 4
+the same step has in the reference's order (2 layers, forward + backward), and that step is timed beside it
+(`reference_order`: 4 executed).
 N > 1: N independent replicas of that workload (a single-graph GCN does not shard:
 SURVEY.md 8(e) "replicas only"), `value` = sum over ranks.
 
@@ -907,9 +908,15 @@ def main():
     bytes_alg = records[0][3]
     mean_ms = float(np.mean(ms))
     achieved = bytes_alg / (mean_ms * 1e-3) / 1e9
+    # edges*feat/s = sum over the aggregation launches IN THE TIMED REGION of E * F_launch / wall time
+    executed = len(ms) / max(args.steps, 1)
+    ef_executed = executed * meta["e"] * meta["feat"]
     line = {
         "metric": "edges*feat/s (2-layer GCN training epoch, BASELINE configs[1])",
-        "value": world * args.steps * ef_per_step / dt, "unit": "edges*feat/s",
+        "value": world * args.steps * ef_executed / dt, "unit": "edges*feat/s",
+        "value_is": "sum of E x F over the aggregation launches executed in the timed region / wall time (SURVEY.md 8(d)); "
+                    "value_reference_formulation counts the 4 aggregations the same step has in the reference's order",
+        "value_reference_formulation": world * args.steps * ef_per_step / dt,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -921,7 +928,8 @@ def main():
                    "agg_launches_per_step_is": "of the reference's formulation (2 layers x forward + backward); executed: "
                                                "see aggregations_executed_per_step",
                    "aggregations_executed_per_step": None,
-                   "edges_feat_per_step": ef_per_step,
+                   "edges_feat_per_step": ef_executed,
+                   "edges_feat_per_step_reference_formulation": ef_per_step,
                    "reference_compat_D1": kernels.reference_compat()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "stg::gcn_agg_kernel",
@@ -930,9 +938,9 @@ def main():
                      "gcn_agg_share_of_step": float(np.sum(ms)) * 1e-3 / dt,
                      "weight_grad_gemm_tn_mean_ms": float(np.mean(gemm_ms)) if gemm_ms else None},
     }
-    line["config"]["aggregations_executed_per_step"] = len(ms) / max(args.steps, 1)
+    line["config"]["aggregations_executed_per_step"] = executed
     line["reference_order"] = {
-        "ms_per_step": dt_ref * 1e3, "value": world * ef_per_step / dt_ref, "steps": k_ref,
+        "ms_per_step": dt_ref * 1e3, "value": world * ef_per_step / dt_ref, "steps": k_ref, "aggregations_executed_per_step": 4,
         "what": "the same training step with every GCNConv in the reference's order (x W, then aggregate: 4 aggregation "
                 "launches); the default runs the first layer aggregate-first because its input carries no gradient, which "
                 "leaves its backward without an aggregation (identical gradients up to fp32 rounding; "
@@ -950,7 +958,7 @@ def main():
             line["roofline"]["traffic_source"] = os.path.relpath(pmc_files[-1], ROOT)
             # the same counters under the microarch guide's flat rule (FETCH_SIZE x 2 for wide coalesced reads);
             # `traffic` uses the factor measured on a known-bytes launch of this kernel's own access shape
-            # (8 B per lane: 1.65), see DESIGN.md section 3
+            # (tools/pmc_gcn.py), see DESIGN.md section 3
             line["roofline"]["traffic_guide_x2_rule"] = 0.5 * (pmc["cfg2_forward_csr"]["traffic_bytes_x2_rule"] +
                                                                pmc["cfg2_backward_csr"]["traffic_bytes_x2_rule"])
     cpu = None
