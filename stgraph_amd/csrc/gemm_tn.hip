@@ -266,6 +266,234 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     }
 }
 
+// ---- wide form (round 3) ---------------------------------------------------------------------------------------------
+// The kernel above feeds v_mfma_f32_32x32x2_f32 from one dword per lane per operand tile: MT + NT buffer_load_dword per
+// k-pair, i.e. 12 load instructions of 256 B per 4 rows of a 64 x 128 product.  This form loads 16 BYTES per lane: lane
+// (n16, kq) of a wave reads columns 4 n16 .. 4 n16 + 3 of row k + kq, so ONE buffer_load_dwordx4 brings 4 rows x 64 columns
+// (1 KiB, contiguous for a dense operand), and its four components are the operands of four v_mfma_f32_16x16x4_f32 whose
+// tile index i = n16 stands for column 4 i + r -- the M (and N) dimension is visited in a PERMUTED order that costs nothing:
+// the accumulator of tile (r_a, r_b) holds C[64 ca + 16 kq + 4 v + r_a][64 cb + 4 n16 + r_b], so a lane's r_b = 0..3
+// values are again 16 contiguous bytes of an output row.  3 load instructions per 32 MFMAs instead of 12 per 16, same MFMA
+// cycles (32 x 32 = 16 x 64), same exact-f32 k-ordered sums per K slice (a different, still fixed, split of K than the
+// narrow form's: results differ from it by fp32 rounding of the slice sums only).  W = 2 / 1 (dwordx2 / dword) serve
+// operands 32 / 16 columns wide.  D operand sets are in flight per wave (D - 1 sets ahead of the MFMAs).
+template <int W>
+__device__ __forceinline__ void load_vec(float (&dst)[W], __amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    // (element by element through scalars: __builtin_bit_cast(float, v[i]) on a vector ELEMENT reads the vector's first
+    // dword for every i with this clang -- all four values came back equal)
+    if constexpr (W == 4) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+        const unsigned u0 = v[0], u1 = v[1], u2 = v[2], u3 = v[3];
+        dst[0] = __uint_as_float(u0);
+        dst[1] = __uint_as_float(u1);
+        dst[2] = __uint_as_float(u2);
+        dst[3] = __uint_as_float(u3);
+    } else if constexpr (W == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        const unsigned u0 = v[0], u1 = v[1];
+        dst[0] = __uint_as_float(u0);
+        dst[1] = __uint_as_float(u1);
+    } else {
+        dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    }
+}
+
+using f32x4w = __attribute__((ext_vector_type(4))) float;
+constexpr int kWideDepth = 4;
+
+// WA / WB: floats per lane of an A / B chunk (chunk = 16 WA / 16 WB columns); CA / CB: chunks per wave.
+// CYC (experiment): the block's four waves take the 4-row groups of the block's K range in turn (wave w: groups w, w + 4,
+// ...) instead of a contiguous quarter each, so the block reads 16 consecutive rows per step.
+template <int WA, int CA, int WB, int CB, bool CS, bool AMASK, int D = kWideDepth, int MINW = 2>
+__global__ __launch_bounds__(kBlock, MINW) void gemm_tn_wide_kernel(
+    const GemmSegs segs, const GemmForm form, float *__restrict__ slab, int64_t K, int M, int N, int64_t kslice_wave,
+    int m_groups, int n_groups, int s_per_seg, int cyclic)
+{
+    constexpr int TA = WA * CA, TB = WB * CB;
+    static_assert(TA * TB <= 32, "accumulator tiles per wave");
+    extern __shared__ float lds[];                       // one wave's accumulators: TA x TB x 4 x 64 floats (+ TA x 64)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int mi = blockIdx.x % m_groups;
+    const int t = blockIdx.x / m_groups;
+    const int nj = t % n_groups;
+    const int s = t / n_groups;                          // slab index = segment * s_per_seg + slice
+    const int seg = s / s_per_seg;
+    const int sl = s - seg * s_per_seg;
+    const float *__restrict__ A = segs.a[seg];
+    const float *__restrict__ B = segs.b[seg];
+    const float *__restrict__ B2 = segs.b2[seg];
+    const float *__restrict__ AM = segs.am[seg];
+    const int lda = form.lda, nsplit = form.nsplit;
+    // contiguous: wave-uniform K slice [k0, k1) of kslice_wave rows.  cyclic: the block's range starts at kb, this wave's
+    // first group at kb + 4 wave, groups 16 rows apart.
+    const int64_t kb = (int64_t)sl * kWavesPerBlock * kslice_wave;
+    const int64_t k0 = cyclic ? kb + 4 * wave : kb + (int64_t)wave * kslice_wave;
+    const int64_t kend = cyclic ? min(K, kb + kWavesPerBlock * kslice_wave) : min(K, k0 + kslice_wave);
+    const int64_t rows = kend > k0 ? kend - k0 : 0;      // rows from this wave's first row to the end of its range
+    const int gstride = cyclic ? 16 : 4;                 // rows between this wave's consecutive groups
+    // rows >= kend read as zero through the descriptors' range check (see the narrow kernel)
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + k0 * lda), 0,
+                                                       rows > 0 ? (int)(((rows - 1) * lda + M) * (int64_t)sizeof(float)) : 0,
+                                                       0x00020000);
+    const auto rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(AMASK ? AM + k0 * lda : A + k0 * lda), 0,
+                                                       rows > 0 ? (int)(((rows - 1) * lda + M) * (int64_t)sizeof(float)) : 0,
+                                                       0x00020000);
+    const auto rsB1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(B + k0 * form.ldb), 0,
+        rows > 0 ? (int)(((rows - 1) * form.ldb + nsplit) * (int64_t)sizeof(float)) : 0, 0x00020000);
+    const auto rsB2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(B2 ? B2 + k0 * form.ldb2 : B), 0,
+        rows > 0 && B2 ? (int)(((rows - 1) * form.ldb2 + (N - nsplit)) * (int64_t)sizeof(float)) : 0, 0x00020000);
+    int voA[CA], voB[CB], ldj[CB];
+    bool second[CB];
+#pragma unroll
+    for (int ca = 0; ca < CA; ++ca) voA[ca] = (kq * lda + (mi * CA + ca) * 16 * WA + WA * n16) * (int)sizeof(float);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int col0 = (nj * CB + cb) * 16 * WB;
+        second[cb] = col0 >= nsplit;                                             // wave-uniform
+        ldj[cb] = second[cb] ? form.ldb2 : form.ldb;
+        voB[cb] = (kq * ldj[cb] + (second[cb] ? col0 - nsplit : col0) + WB * n16) * (int)sizeof(float);
+    }
+    const int b_op = form.b_op;
+    const float blo = form.lo, bhi = form.hi;
+
+    f32x4w acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    float cs[TA];
+#pragma unroll
+    for (int i = 0; i < TA; ++i) cs[i] = 0.f;
+
+    float a[D][CA][WA], b[D][CB][WB], am[AMASK ? D : 1][AMASK ? CA : 1][AMASK ? WA : 1];
+    auto load_set = [&](int d, int step) {
+        const int r0 = gstride * step;                                          // uniform
+        const int soA = r0 * lda * (int)sizeof(float);
+#pragma unroll
+        for (int ca = 0; ca < CA; ++ca) {
+            load_vec<WA>(a[d][ca], rsA, voA[ca], soA);
+            if constexpr (AMASK) load_vec<WA>(am[d][ca], rsM, voA[ca], soA);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) load_vec<WB>(b[d][cb], second[cb] ? rsB2 : rsB1, voB[cb], r0 * ldj[cb] * (int)sizeof(float));
+    };
+    auto consume = [&](int d) {
+        if (b_op != STG_GEMM_B_NONE) {                                          // wave-uniform
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                if (second[cb]) continue;
+#pragma unroll
+                for (int r = 0; r < WB; ++r) {
+                    const float v = b[d][cb][r];
+                    b[d][cb][r] = b_op == STG_GEMM_B_RELU ? (v < 0.f ? 0.f : v) : __builtin_amdgcn_fmed3f(v, blo, bhi);
+                }
+            }
+        }
+        if constexpr (AMASK) {
+#pragma unroll
+            for (int ca = 0; ca < CA; ++ca)
+#pragma unroll
+                for (int r = 0; r < WA; ++r) a[d][ca][r] = am[d][ca][r] > 0.f ? a[d][ca][r] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TA; ++i) {
+            const float av = a[d][i / WA][i % WA];
+#pragma unroll
+            for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[d][j / WB][j % WB], acc[i][j], 0, 0, 0);
+            if constexpr (CS) cs[i] += av;
+        }
+    };
+
+    const int nsteps = (int)((rows + gstride - 1) / gstride);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (d < nsteps) load_set(d, d);
+    int i = 0;
+    for (; i + 2 * D - 1 <= nsteps; i += D) {               // steady state: straight-line, D - 1 sets ahead of the MFMAs
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            load_set((d + D - 1) % D, i + d + D - 1);
+            consume(d);
+        }
+    }
+    for (; i < nsteps; i += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (i + d < nsteps) {
+                if (i + d + D - 1 < nsteps) load_set((d + D - 1) % D, i + d + D - 1);
+                consume(d);
+            }
+        }
+    }
+
+    // the block's 4 K sub-slices, added in wave order through one wave-sized LDS buffer (as in the narrow kernel)
+    constexpr int kAccFloats = TA * TB * 4 * kWave;
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+        if (wave == w) {
+            float *dst = lds + lane;
+#pragma unroll
+            for (int ii = 0; ii < TA; ++ii)
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((ii * TB + j) * 4 + r) * kWave] = acc[ii][j][r];
+            if constexpr (CS) {
+#pragma unroll
+                for (int ii = 0; ii < TA; ++ii) lds[kAccFloats + ii * kWave + lane] = cs[ii];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float *src = lds + lane;
+#pragma unroll
+            for (int ii = 0; ii < TA; ++ii)
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[ii][j][r] += src[((ii * TB + j) * 4 + r) * kWave];
+            if constexpr (CS) {
+#pragma unroll
+                for (int ii = 0; ii < TA; ++ii) cs[ii] += lds[kAccFloats + ii * kWave + lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        // acc[ca WA + ra][cb WB + rb][v] = C[chunk_a(ca) + WA (4 kq + v) + ra][chunk_b(cb) + WB n16 + rb]
+        const int64_t slab_stride = (int64_t)M * N + (CS ? M : 0);
+        float *out = slab + (int64_t)s * slab_stride;
+#pragma unroll
+        for (int ii = 0; ii < TA; ++ii) {
+            const int ca = ii / WA, ra = ii % WA;
+            if constexpr (CS) {
+                float tot = cs[ii] + __shfl_xor(cs[ii], 16, kWave);             // the four kq lanes hold rows k = kq mod 4
+                tot = tot + __shfl_xor(tot, 32, kWave);
+                if (nj == 0 && kq == 0) out[(int64_t)M * N + (mi * CA + ca) * 16 * WA + WA * n16 + ra] = tot;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int m = (mi * CA + ca) * 16 * WA + WA * (4 * kq + v) + ra;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    float *o = out + (int64_t)m * N + (nj * CB + cb) * 16 * WB + WB * n16;
+                    if constexpr (WB == 4)
+                        *reinterpret_cast<float4 *>(o) = make_float4(acc[ii][cb * WB][v], acc[ii][cb * WB + 1][v], acc[ii][cb * WB + 2][v],
+                                                                     acc[ii][cb * WB + 3][v]);
+                    else if constexpr (WB == 2)
+                        *reinterpret_cast<float2 *>(o) = make_float2(acc[ii][cb * WB][v], acc[ii][cb * WB + 1][v]);
+                    else
+                        o[0] = acc[ii][cb * WB][v];
+                }
+            }
+        }
+    }
+}
+
 // C[o] = sum_s slab[s][o]: 64 outputs per block, the 4 waves take s = w, w+4, ... (8 loads in
 // flight each) and are combined in wave order through LDS -- fixed order, deterministic.
 __global__ __launch_bounds__(kBlock) void gemm_tn_reduce_kernel(const float *__restrict__ slab,
@@ -305,13 +533,45 @@ struct GemmPlan {
     int64_t kslice_wave;
 };
 
-GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1, int max_ld = 0)
+// The wide kernel's tile of one wave for (M, N), or wa = 0 where the narrow kernel serves (other widths).
+struct WideShape {
+    int wa, ca, wb, cb;
+};
+
+WideShape wide_shape(int M, int N, int nsplit)
+{
+    WideShape w{0, 0, 0, 0};
+    if (M % 64 == 0) {
+        w.wa = 4;
+        if (N % 64 == 0) {
+            w.wb = 4;
+            if (N % 128 == 0) { w.ca = 1; w.cb = 2; }
+            else if (M % 128 == 0) { w.ca = 2; w.cb = 1; }
+            else { w.ca = 1; w.cb = 1; }
+        } else if (N == 32) {
+            w.wb = 2; w.cb = 1;
+            w.ca = M % 192 == 0 ? 3 : (M % 128 == 0 ? 2 : 1);
+        } else {
+            w.wa = 0;
+        }
+    } else if (M == 32 && N % 64 == 0) {
+        w.wa = 2; w.ca = 1; w.wb = 4; w.cb = N % 128 == 0 ? 2 : 1;
+    }
+    if (w.wa && nsplit < N && nsplit % (16 * w.wb) != 0) w.wa = 0;            // B's two matrices must meet on a chunk boundary
+    return w;
+}
+
+GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1, int max_ld = 0, const WideShape *wide = nullptr)
 {
     GemmPlan p{};
     p.nt = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
     p.mt = M > 32 ? 2 : 1;
     p.m_tiles = (M + 32 * p.mt - 1) / (32 * p.mt);
     p.n_groups = (N + 32 * p.nt - 1) / (32 * p.nt);
+    if (wide && wide->wa) {
+        p.m_tiles = M / (16 * wide->wa * wide->ca);
+        p.n_groups = N / (16 * wide->wb * wide->cb);
+    }
     const int64_t tiles = (int64_t)p.m_tiles * p.n_groups;
     // at most 512 blocks = ONE resident round (2 per CU): a 550-block grid (T = 25, 2 tiles: S rounded up to 11)
     // ran a second round for its last 38 blocks, i.e. at half speed; never slice below 64 rows per wave
@@ -331,21 +591,30 @@ GemmPlan plan_gemm_tn(int64_t K, int M, int N, int T = 1, int max_ld = 0)
     return p;
 }
 
+// bytes of slab space that covers whichever form the launch picks (the wide form may cut K into more slices)
+size_t workspace_need(int T, int64_t K, int M, int N, int max_ld)
+{
+    const GemmPlan p = plan_gemm_tn(K, M, N, T, max_ld);
+    int S = p.S;
+    const WideShape w = wide_shape(M, N, N);
+    if (w.wa) S = std::max(S, plan_gemm_tn(K, M, N, T, max_ld, &w).S);
+    if (S < 1) return 0;
+    return (size_t)T * (size_t)S * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+}
+
 }  // namespace
 }  // namespace stg
 
 extern "C" size_t stg_gemm_tn_workspace_bytes(int64_t K, int32_t M, int32_t N)
 {
     if (K <= 0 || M <= 0 || N <= 0) return 0;
-    const stg::GemmPlan p = stg::plan_gemm_tn(K, M, N);
-    return (size_t)p.S * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+    return stg::workspace_need(1, K, M, N, 0);
 }
 
 extern "C" size_t stg_gemm_tn_multi_workspace_bytes(int32_t T, int64_t K, int32_t M, int32_t N)
 {
     if (T <= 0 || T > stg::kGemmMaxSeg || K <= 0 || M <= 0 || N <= 0) return 0;
-    const stg::GemmPlan p = stg::plan_gemm_tn(K, M, N, T);
-    return (size_t)T * (size_t)p.S * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+    return stg::workspace_need(T, K, M, N, 0);
 }
 
 namespace stg {
@@ -386,7 +655,14 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         segs.am[t] = form.a_mask ? AMs[t] : nullptr;
         if (form.a_mask && !AMs[t]) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL mask in segment %d", what, t);
     }
-    const GemmPlan p = plan_gemm_tn(K, M, N, T, std::max(form.lda, std::max(form.ldb, form.ldb2)));
+    WideShape wide = wide_shape(M, N, form.nsplit);
+    if (tuning().gemm_wide == 1 || form.lda % 4 != 0 || form.ldb % 4 != 0 || (form.nsplit < N && form.ldb2 % 4 != 0)) wide.wa = 0;
+    for (int t = 0; t < T && wide.wa; ++t) {                      // 16-byte lane loads: every operand base on a 16-byte boundary
+        const uintptr_t bits = reinterpret_cast<uintptr_t>(segs.a[t]) | reinterpret_cast<uintptr_t>(segs.b[t]) |
+                               reinterpret_cast<uintptr_t>(segs.b2[t]) | reinterpret_cast<uintptr_t>(segs.am[t]);
+        if (bits & 15) wide.wa = 0;
+    }
+    const GemmPlan p = plan_gemm_tn(K, M, N, T, std::max(form.lda, std::max(form.ldb, form.ldb2)), wide.wa ? &wide : nullptr);
     if (p.S < 1 || (int64_t)T * p.S > INT32_MAX / 2)
         return fail(STG_ERR_UNSUPPORTED, "%s: K=%lld x max(M, N)=%d is outside the 32-bit slice addressing", what,
                     (long long)K, std::max(M, N));
@@ -398,6 +674,29 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         return fail(STG_ERR_WORKSPACE, "%s: workspace %zu < required %zu", what, workspace_bytes, need);
     float *slab = static_cast<float *>(workspace);
     const int64_t blocks = (int64_t)S_total * p.m_tiles * p.n_groups;
+    if (wide.wa) {
+        const size_t wlds = ((size_t)wide.wa * wide.ca * wide.wb * wide.cb * 4 + (size_t)wide.wa * wide.ca) * kWave * sizeof(float);
+        const int cyclic = tuning().gemm_cyclic;
+#define STG_WIDE_L(WA_, CA_, WB_, CB_, CS_, AM_)                                                                   \
+    hipLaunchKernelGGL((gemm_tn_wide_kernel<WA_, CA_, WB_, CB_, CS_, AM_>), dim3((unsigned)blocks), dim3(kBlock), wlds, stream, segs, \
+                       form, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S, cyclic)
+#define STG_WIDE(WA_, CA_, WB_, CB_)                                                                               \
+    if (wide.wa == WA_ && wide.ca == CA_ && wide.wb == WB_ && wide.cb == CB_) {                                    \
+        if (form.a_mask) {                                                                                         \
+            if (cs) STG_WIDE_L(WA_, CA_, WB_, CB_, true, true); else STG_WIDE_L(WA_, CA_, WB_, CB_, false, true);   \
+        } else {                                                                                                   \
+            if (cs) STG_WIDE_L(WA_, CA_, WB_, CB_, true, false); else STG_WIDE_L(WA_, CA_, WB_, CB_, false, false); \
+        }                                                                                                          \
+    }
+        STG_WIDE(4, 1, 4, 2) else STG_WIDE(4, 2, 4, 1) else STG_WIDE(4, 1, 4, 1) else STG_WIDE(4, 3, 2, 1) else STG_WIDE(4, 2, 2, 1)
+        else STG_WIDE(4, 1, 2, 1) else STG_WIDE(2, 1, 4, 2) else STG_WIDE(2, 1, 4, 1)
+        else return fail(STG_ERR_UNSUPPORTED, "%s: no wide instantiation for this tile", what);
+#undef STG_WIDE
+#undef STG_WIDE_L
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MNc + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
+                           slab, C, colsum, MNc, MN, S_total);
+        return check_launch(what);
+    }
     const size_t lds = ((size_t)p.mt * p.nt * 16 + p.mt) * kWave * sizeof(float);
 #define STG_GEMM_LAUNCH(NT_, KU_, CS_, MT_)                                                                       \
     do {                                                                                                          \
@@ -451,9 +750,7 @@ extern "C" int stg_gemm_tn_multi_f32(const float *const *A, const float *const *
 extern "C" size_t stg_gemm_tn_form_workspace_bytes(int32_t T, int64_t K, int32_t M, int32_t N, int32_t max_ld)
 {
     if (T <= 0 || T > stg::kGemmMaxSeg || K <= 0 || M <= 0 || N <= 0) return 0;
-    const stg::GemmPlan p = stg::plan_gemm_tn(K, M, N, T, max_ld);
-    if (p.S < 1) return 0;
-    return (size_t)T * (size_t)p.S * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+    return stg::workspace_need(T, K, M, N, max_ld);
 }
 
 extern "C" int stg_gemm_tn_form_f32(const float *const *A, int32_t lda, const float *const *B, int32_t ldb, int32_t nsplit,

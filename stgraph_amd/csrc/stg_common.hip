@@ -112,5 +112,15 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().step_waves = value;
         return 0;
     }
+    if (!std::strcmp(key, "gemm_wide")) {
+        if (value != 0 && value != 1) return fail(STG_ERR_INVALID_ARGUMENT, "gemm_wide must be 0 (auto) or 1 (never)");
+        tuning().gemm_wide = value;
+        return 0;
+    }
+    if (!std::strcmp(key, "gemm_cyclic")) {
+        if (value != 0 && value != 1) return fail(STG_ERR_INVALID_ARGUMENT, "gemm_cyclic must be 0 or 1");
+        tuning().gemm_cyclic = value;
+        return 0;
+    }
     return fail(STG_ERR_INVALID_ARGUMENT, "stg_set_tuning: unknown key '%s'", key);
 }
