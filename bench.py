@@ -667,106 +667,115 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
     """BASELINE.json configs[4]: dynamic-temporal TGCN (benchmarking/dynamic-temporal-tgcn/seastar/train.py loop:
     link prediction on a sliding window over an edge stream, un-weighted GCN gates), once with the per-snapshot
     device CSR rebuild (NaiveGraph(resident=False)), with all snapshots resident as the reference's NaiveGraph keeps
-    them, and on the dynamic edge store behind both of the reference's
-    delta-based graph classes (PCSRGraph, GPMAGraph: one resident graph + per-timestamp deltas).  BPTT windows are sharded over the ranks like the static configuration."""
-    from stgraph_amd import temporal
+    them, and on the dynamic edge store behind both of the reference's delta-based graph classes (PCSRGraph,
+    GPMAGraph: one resident graph + per-timestamp deltas).  Every mode replays one HIP graph per BPTT window after an
+    eager epoch; BPTT windows are sharded over the ranks like the static configuration.  T = 160 is the sharded
+    workload (8 windows); at one rank the same modes are also timed at BASELINE.md's own T = 40 ("T40")."""
+    from stgraph_amd import kernels, temporal
     from stgraph_amd.graph import GPMAGraph, NaiveGraph, PCSRGraph
-    rng = np.random.default_rng(4)
-    stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
-    snaps, pn_edges, pn_targets = [], [], []
-    gen = torch.Generator(device=device).manual_seed(4)
-    m = 10_000
-    for t in range(T):
-        keys = stream[t * churn: t * churn + e0]
-        s, d = (keys // n).astype(np.int32), (keys % n).astype(np.int32)
-        snaps.append((torch.from_numpy(s).to(device), torch.from_numpy(d).to(device)))
-        pos = torch.from_numpy(np.stack([s[:m], d[:m]]).astype(np.int64)).to(device)
-        neg = torch.randint(0, n, (2, m), device=device, generator=gen)
-        pn_edges.append(torch.cat([pos, neg], 1))
-        pn_targets.append(torch.cat([torch.ones(m, device=device), torch.zeros(m, device=device)]))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    out = {}
-    for mode in ("resident_snapshots", "rebuild_per_snapshot", "pcsr_store", "gpma_store"):
-        if mode == "resident_snapshots":         # NaiveGraph as the reference defines it: all 2T CSRs built up front
-            G = NaiveGraph(snaps, n, device=device, sort_inplace=False)
-        elif mode == "rebuild_per_snapshot":
-            G = NaiveGraph(snaps, n, device=device, sort_inplace=False, resident=False, max_cached=B + 1)
-        else:
-            G = (PCSRGraph if mode == "pcsr_store" else GPMAGraph)(snaps, n, device=device)
-        torch.manual_seed(4)
-        model = temporal.DynamicSTGraphTGCN(feat, hidden).to(device)
-        # capturable + fused: the default Adam's update rule as one kernel that a HIP graph can hold
-        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
-        bucket = temporal.GradBucket(model.parameters())
-        # snapshot-per-timestamp graphs: every window replayed from its own HIP graph after one eager epoch (in rebuild
-        # mode the graph contains the snapshot builds, which so still run every epoch); the delta stores stay eager
-        captured = mode in ("resident_snapshots", "rebuild_per_snapshot")
-        cd = None
-
-        def epoch(ep):
-            nonlocal cd
-            if mode == "rebuild_per_snapshot":
-                G._snapshots.clear()                 # every epoch rebuilds every snapshot it touches
-            G._ndata.clear()
-            if captured and ep >= 1:
-                if cd is None:
-                    cd = temporal.CapturedDynamicWindows(model, G, pn_edges, pn_targets, B, opt, bucket, feat, world=world,
-                                                         rank=rank)
-                temporal.train_epoch_dynamic_captured(cd, epoch=ep)
+    def run_modes(T, modes, epochs):
+        rng = np.random.default_rng(4)
+        stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
+        snaps, pn_edges, pn_targets = [], [], []
+        gen = torch.Generator(device=device).manual_seed(4)
+        m = 10_000
+        for t in range(T):
+            keys = stream[t * churn: t * churn + e0]
+            s, d = (keys // n).astype(np.int32), (keys % n).astype(np.int32)
+            snaps.append((torch.from_numpy(s).to(device), torch.from_numpy(d).to(device)))
+            pos = torch.from_numpy(np.stack([s[:m], d[:m]]).astype(np.int64)).to(device)
+            neg = torch.randint(0, n, (2, m), device=device, generator=gen)
+            pn_edges.append(torch.cat([pos, neg], 1))
+            pn_targets.append(torch.cat([torch.ones(m, device=device), torch.zeros(m, device=device)]))
+        out = {}
+        for mode in modes:
+            if mode == "resident_snapshots":         # NaiveGraph as the reference defines it: all 2T CSRs built up front
+                G = NaiveGraph(snaps, n, device=device, sort_inplace=False)
+            elif mode == "rebuild_per_snapshot":
+                G = NaiveGraph(snaps, n, device=device, sort_inplace=False, resident=False, max_cached=B + 1)
             else:
-                temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep, rank=rank,
-                                             world=world)
-        epoch(0)
-        if captured:
-            epoch(1)                                 # captures
-        barrier()
-        t0 = time.perf_counter()
-        for ep in range(epochs):
-            epoch(2 + ep)
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        if mode in ("pcsr_store", "gpma_store"):
-            G.check()
-        out[mode] = {"epochs_per_s": epochs / dt, "seconds_per_epoch": dt / epochs}
-        if mode == "rebuild_per_snapshot":
-            from stgraph_amd import kernels
-            steps_rank0 = sum(max(0, min(B, T - 1 - w * B)) for _, w in temporal.windows_of_rank(T, B, rank, world)
-                              if w is not None)
-            sps = dt / epochs / max(steps_rank0, 1)
-            ref_bytes = 6 * kernels.gcn_agg_algorithmic_bytes(n, e0, hidden, False) + 2 * 16 * e0
-            roofline = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "seconds_per_snapshot": sps,
-                        "bytes_model": "reference formulation per snapshot: 6 un-weighted gcn_agg launches of width hidden "
-                                       "(3 gates, forward + backward) + the CSR build's 16 B/edge per direction "
-                                       "(SURVEY.md 8(d)); time = the whole step incl. rebuild, cell, link head, Adam",
-                        "algorithmic_bytes_per_snapshot": ref_bytes, "achieved": ref_bytes / sps / 1e9,
-                        "frac": ref_bytes / sps / 1e9 / HBM_PEAK_GBS,
-                        "note": "|V| = 25K snapshots: launch- and host-bound, not bandwidth-bound"}
-        out[mode]["hip_graph_per_window"] = captured
-        del G, model, opt, bucket, cd
-        torch.cuda.empty_cache()
-    return {"workload": f"dynamic-temporal TGCN |V|={n} E0={e0} +-{churn} edges/step T={T} backprop_every={B} feat={feat} "
-                        f"hidden={hidden} (BASELINE configs[4]), link-prediction loss, windows sharded over {world} rank(s)",
-            "metric": "epochs/s", "value": out["rebuild_per_snapshot"]["epochs_per_s"],
-            "value_is": "rebuild_per_snapshot -- the configuration BASELINE.md names (a fresh device CSR build per snapshot "
-                        "and epoch, O(window) memory).  resident_snapshots is NaiveGraph as the reference keeps it (T forward "
-                        "+ T backward CSRs built once at construction, graph/dynamic/naive/naive_graph.py; 1.6 GB here); the two "
-                        "delta-based stores follow.  T = 160 instead of BASELINE.md's 40: 40 snapshots are 2 windows of 20, "
-                        "which 8 ranks cannot share",
-            "csr_build_share": 1.0 - out["resident_snapshots"]["seconds_per_epoch"] / out["rebuild_per_snapshot"]["seconds_per_epoch"],
-            "csr_build_share_is": "1 - seconds_per_epoch(resident_snapshots) / seconds_per_epoch(rebuild_per_snapshot): what the "
-                                  "per-snapshot builds (and the per-edge coefficient gathers that follow a new CSR) cost of the epoch",
-            "scaling": "strong",
-            "n_gpus": world, "epochs": epochs, "windows_per_epoch": temporal.num_windows(T, B), "roofline": roofline,
-            **out}
+                G = (PCSRGraph if mode == "pcsr_store" else GPMAGraph)(snaps, n, device=device)
+            torch.manual_seed(4)
+            model = temporal.DynamicSTGraphTGCN(feat, hidden).to(device)
+            # capturable + fused: the default Adam's update rule as one kernel that a HIP graph can hold
+            opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
+            bucket = temporal.GradBucket(model.parameters())
+            # every window replayed from its own HIP graph after one eager epoch: in rebuild mode the graph contains the
+            # snapshot builds, on the stores the merges and CSR emissions of get_graph(t) -- both still run every epoch
+            cd = None
+
+            def epoch(ep):
+                nonlocal cd
+                if mode == "rebuild_per_snapshot":
+                    G._snapshots.clear()                 # every epoch rebuilds every snapshot it touches
+                G._ndata.clear()
+                if ep >= 1:
+                    if cd is None:
+                        cd = temporal.CapturedDynamicWindows(model, G, pn_edges, pn_targets, B, opt, bucket, feat, world=world,
+                                                             rank=rank)
+                    temporal.train_epoch_dynamic_captured(cd, epoch=ep)
+                else:
+                    temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep, rank=rank,
+                                                 world=world)
+            epoch(0)
+            epoch(1)                                     # captures
+            epoch(2)                                     # first pure replay (warm-up; epochs 0-2 discarded as the reference does)
+            barrier()
+            t0 = time.perf_counter()
+            for ep in range(epochs):
+                epoch(3 + ep)
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            if mode in ("pcsr_store", "gpma_store"):
+                G.check()
+            out[mode] = {"epochs_per_s": epochs / dt, "seconds_per_epoch": dt / epochs, "hip_graph_per_window": True,
+                         "epochs_timed": epochs, "epochs_discarded": 3}
+            del G, model, opt, bucket, cd
+            torch.cuda.empty_cache()
+        return out
+
+    all_modes = ("resident_snapshots", "rebuild_per_snapshot", "pcsr_store", "gpma_store")
+    out = run_modes(T, all_modes, epochs)
+    dt_e = out["rebuild_per_snapshot"]["seconds_per_epoch"]
+    steps_rank0 = sum(max(0, min(B, T - 1 - w * B)) for _, w in temporal.windows_of_rank(T, B, rank, world) if w is not None)
+    sps = dt_e / max(steps_rank0, 1)
+    ref_bytes = 6 * kernels.gcn_agg_algorithmic_bytes(n, e0, hidden, False) + 2 * 16 * e0
+    roofline = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "seconds_per_snapshot": sps,
+                "bytes_model": "reference formulation per snapshot: 6 un-weighted gcn_agg launches of width hidden "
+                               "(3 gates, forward + backward) + the CSR build's 16 B/edge per direction "
+                               "(SURVEY.md 8(d)); time = the whole step incl. rebuild, cell, link head, Adam",
+                "algorithmic_bytes_per_snapshot": ref_bytes, "achieved": ref_bytes / sps / 1e9,
+                "frac": ref_bytes / sps / 1e9 / HBM_PEAK_GBS,
+                "note": "|V| = 25K snapshots: launch- and latency-bound, not bandwidth-bound"}
+    res = {"workload": f"dynamic-temporal TGCN |V|={n} E0={e0} +-{churn} edges/step T={T} backprop_every={B} feat={feat} "
+                       f"hidden={hidden} (BASELINE configs[4]), link-prediction loss, windows sharded over {world} rank(s)",
+           "metric": "epochs/s", "value": out["rebuild_per_snapshot"]["epochs_per_s"],
+           "value_is": "rebuild_per_snapshot -- the configuration BASELINE.md names (a fresh device CSR build per snapshot "
+                       "and epoch, O(window) memory).  resident_snapshots is NaiveGraph as the reference keeps it (T forward "
+                       "+ T backward CSRs built once at construction, graph/dynamic/naive/naive_graph.py; 1.6 GB here); the two "
+                       "delta-based stores follow.  T = 160 instead of BASELINE.md's 40: 40 snapshots are 2 windows of 20, "
+                       "which 8 ranks cannot share; the T = 40 figures are in 'T40' (one rank)",
+           "csr_build_share": 1.0 - out["resident_snapshots"]["seconds_per_epoch"] / out["rebuild_per_snapshot"]["seconds_per_epoch"],
+           "csr_build_share_is": "1 - seconds_per_epoch(resident_snapshots) / seconds_per_epoch(rebuild_per_snapshot): what the "
+                                 "per-snapshot builds (and the per-edge coefficient gathers that follow a new CSR) cost of the epoch",
+           "scaling": "strong",
+           "n_gpus": world, "epochs": epochs, "windows_per_epoch": temporal.num_windows(T, B), "roofline": roofline,
+           **out}
+    if world == 1 and T != 40:
+        t40 = run_modes(40, all_modes, max(epochs, 20))          # the reference's rule: >= 20 epochs, the first three discarded
+        res["T40"] = {"workload": "the same stream cut at T = 40 (BASELINE.md cfg5 exactly: 2 BPTT windows of 20 per epoch)",
+                      "metric": "epochs/s", "value": t40["rebuild_per_snapshot"]["epochs_per_s"], **t40}
+    return res
 
 
 def live_pmc_traffic(iters=2, timeout_s=170):

@@ -676,7 +676,10 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
     const int64_t blocks = (int64_t)S_total * p.m_tiles * p.n_groups;
     if (wide.wa) {
         const size_t wlds = ((size_t)wide.wa * wide.ca * wide.wb * wide.cb * 4 + (size_t)wide.wa * wide.ca) * kWave * sizeof(float);
-        const int cyclic = tuning().gemm_cyclic;
+        // (cyclic: a wave's descriptor spans the whole block range, 4 x kslice_wave rows: only while that stays inside the
+        // 32-bit addressing the plan sized for one slice)
+        const int64_t max_ld_ = std::max(form.lda, std::max(form.ldb, form.ldb2));
+        const int cyclic = tuning().gemm_cyclic && 4 * p.kslice_wave * max_ld_ * 4 < (int64_t)INT32_MAX;
 #define STG_WIDE_L(WA_, CA_, WB_, CB_, CS_, AM_)                                                                   \
     hipLaunchKernelGGL((gemm_tn_wide_kernel<WA_, CA_, WB_, CB_, CS_, AM_>), dim3((unsigned)blocks), dim3(kBlock), wlds, stream, segs, \
                        form, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S, cyclic)

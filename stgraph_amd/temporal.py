@@ -764,15 +764,24 @@ class CapturedDynamicWindows:
     optimizer step the host issues one input copy, one replay, the all-reduce and the captured optimizer tail.
     Eagerly the window is ~ 60 launches per snapshot from Python and leaves the device idle 20-30 % of the time.
 
-    Only snapshot-per-timestamp graphs (NaiveGraph) qualify: the delta-based stores move through host-side protocol
-    code with synchronisation points.  Memory: a window's activations and (rebuild mode) CSRs live in its graph's pool
-    (~ 2 GB per window of 20 snapshots at |V| = 25 K)."""
+    The delta-based stores (PCSRGraph, GPMAGraph) qualify too (round 3): their update batches are packed and sorted at
+    construction, every step of the graph protocol (merge, CSR emission in both orientations, degrees) is a device launch
+    with shapes known on the host, and nothing synchronises -- so ``get_graph(t)`` itself is captured.  A window's graph
+    then starts from the edge set the PREVIOUS window of this rank left (tensors of that window's pool, rewritten by its
+    replay) or from the persistent base set after ``reset_graph()``; the host half of the protocol (current timestamp,
+    which store object is current) is restored after every replay from what the capture recorded.  Windows must be
+    replayed in increasing order within an epoch, as ``train_epoch_dynamic_captured`` does.
+    Memory: a window's activations and (rebuild mode, stores) CSRs live in its graph's pool (~ 2 GB per window of 20
+    snapshots at |V| = 25 K)."""
 
     def __init__(self, model, graph, pos_neg_edges, pos_neg_targets, backprop_every: int, optimizer,
                  bucket: GradBucket, feat_size: int, world: int = 1, rank: int = 0, group=None, norm_fn=None):
+        from .graph.dynamic.dynamic_graph import DynamicGraph
         from .graph.dynamic.naive.naive_graph import NaiveGraph
-        if not isinstance(graph, NaiveGraph):
-            raise TypeError("CapturedDynamicWindows needs a NaiveGraph (one CSR pair per timestamp)")
+        if not (isinstance(graph, DynamicGraph) and hasattr(graph, "csr")):
+            raise TypeError("CapturedDynamicWindows needs a dynamic graph that hands out device CSRs (NaiveGraph, PCSRGraph, GPMAGraph)")
+        self._store = not isinstance(graph, NaiveGraph)
+        self._end_state = {}
         self.model, self.graph, self.edges, self.targets = model, graph, pos_neg_edges, pos_neg_targets
         self.total = len(pos_neg_edges)
         self.B = backprop_every or self.total
@@ -815,18 +824,24 @@ class CapturedDynamicWindows:
         return cost.detach()
 
     def _capture(self, w: int) -> None:
+        import copy
         g = self.graph
         self.inputs[w] = torch.zeros(self.n, self.feat, device=self.dev)
-        if not g._resident:
+        rebuild = not self._store and not g._resident
+        if rebuild:
             for t in self.timestamps(w):         # the builds must be IN the graph: forget snapshots an eager epoch left
                 g._snapshots.pop(t, None)
+        if self._store:
+            g._ndata.clear()                     # per-timestamp norms of an eager epoch: recomputed inside the graph
         torch.cuda.synchronize(self.dev)
         cg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(cg):
             self.costs[w] = self._body(w)
-        if not g._resident:
+        if rebuild:
             for t in self.timestamps(w):         # tensors of the graph's private pool: not for eager readers
                 g._snapshots.pop(t, None)
+        if self._store:                          # where the walk ended: restored on the host after every replay
+            self._end_state[w] = (copy.copy(g._forward_graph), g.current_timestamp)
         self.graphs[w] = cg
         self.bucket.zero()
 
@@ -855,6 +870,12 @@ class CapturedDynamicWindows:
             self._capture(w)
         self.inputs[w].copy_(window_input(self.n, self.feat, epoch, w, self.dev, seed))
         self.graphs[w].replay()
+        if self._store:
+            import copy
+            fg, ts = self._end_state[w]
+            g = self.graph
+            g._forward_graph, g.current_timestamp, g._is_backprop_state = copy.copy(fg), ts, False
+            g._get_graph_csr_ptrs()
         if self.step_graph is not None:
             self.bucket.all_reduce_mean(self.world, self.group, timed_comm, divide=False)
             self.step_graph.replay()

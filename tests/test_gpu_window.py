@@ -203,14 +203,15 @@ def test_dynamic_window_matches_the_per_snapshot_loop(cuda, kind, full):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4)
 
 
-@pytest.mark.parametrize("kind,optim", [("naive_resident", "adam"), ("naive_rebuild", "adam"), ("naive_resident", "sgd")])
+@pytest.mark.parametrize("kind,optim", [("naive_resident", "adam"), ("naive_rebuild", "adam"), ("naive_resident", "sgd"),
+                                        ("pcsr", "adam"), ("gpma", "adam"), ("pcsr", "sgd")])
 def test_captured_dynamic_windows_match_the_eager_loop(cuda, kind, optim):
     """temporal.CapturedDynamicWindows (one HIP graph per window: snapshot moves / builds, norms, window cost, backward;
     captured optimizer tail when the optimizer is capturable) == train_epoch_dynamic on the same objects: per-window
     costs and parameters after one eager + three replayed epochs (the first of them captures)."""
     import numpy as np
     from stgraph_amd import temporal
-    from stgraph_amd.graph import NaiveGraph
+    from stgraph_amd.graph import GPMAGraph, NaiveGraph, PCSRGraph
     n, e0, churn, T, B, feat, hid, m = 4000, 30000, 800, 13, 4, 32, 64, 1500
     rng = np.random.default_rng(11)
     stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
@@ -226,7 +227,10 @@ def test_captured_dynamic_windows_match_the_eager_loop(cuda, kind, optim):
         pn_targets.append(torch.cat([torch.ones(m, device=cuda), torch.zeros(m, device=cuda)]))
     out = []
     for captured in (True, False):
-        G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False, resident=kind == "naive_resident", max_cached=B + 1)
+        if kind.startswith("naive"):
+            G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False, resident=kind == "naive_resident", max_cached=B + 1)
+        else:                                   # the delta stores: get_graph(t) itself (merge + CSR emission) is in the graph
+            G = (PCSRGraph if kind == "pcsr" else GPMAGraph)(snaps, n, device=cuda)
         torch.manual_seed(4)
         model = temporal.DynamicSTGraphTGCN(feat, hid).to(cuda)
         opt = (torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True) if optim == "adam"
@@ -245,6 +249,9 @@ def test_captured_dynamic_windows_match_the_eager_loop(cuda, kind, optim):
                 losses += temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep)
         if captured:
             assert cd is not None and len(cd.graphs) == 3 and (cd.step_graph is not None) == (optim == "adam")   # window 3 = {t = 12}: no target
+            if not kind.startswith("naive"):
+                G.check()                       # the store's stream contract held through the replays
+                assert G.current_timestamp == 11
         out.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
     torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-7)
     for a, b in zip(out[0][1], out[1][1]):

@@ -16,7 +16,11 @@ def med(fn, iters=12):
         a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     return float(np.median(ts)) * 1e3
 fn = lambda: kernels.gemm_tn_form(d, xs, C, 2 * C, B2s=H, nsplit=C, b_op=kernels.GEMM_B_CLAMP, lo=-1e6, hi=1e6, colsum=True)
-for depth in (4, 12):
-    for skew in (0, 100, 101):
-        _C.set_tuning("gemm_depth", depth); _C.set_tuning("gemm_skew", skew)
-        print("depth", depth or 3, "skew", skew, "us", round(med(fn), 1), flush=True)
+ref = None
+for rep in range(2):
+  for wide, cyc in ((1, 0), (0, 0), (0, 1)):
+    _C.set_tuning("gemm_wide", wide); _C.set_tuning("gemm_cyclic", cyc)
+    out = fn()
+    if ref is None: ref = out
+    err = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(out, ref))
+    print("narrow" if wide else "wide", "cyclic" if cyc else "contig", "us", round(med(fn), 1), "relerr vs narrow", err, flush=True)
