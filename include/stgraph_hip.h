@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 8
+#define STG_ABI_VERSION 9
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -128,6 +128,21 @@ int stg_graph_build_direct_device(const int32_t *src, const int32_t *dst, int64_
                                   int32_t *status, void *workspace, size_t workspace_bytes,
                                   void *stream);
 
+/* The same build (same arrays, same bits) for a snapshot that is REBUILT -- NaiveGraph(resident=False), reference
+ * graph/dynamic/naive/naive_graph.py:45-74 built once per snapshot; here once per snapshot and epoch -- in five launches
+ * with one atomic pass, together with what the training loop derives from every new CSR
+ * (dynamic-temporal-tgcn/seastar/train.py:213-218): norm [N] = in_deg^-1/2 (nullable) and norm gathered through the
+ * forward / backward columns [E] (nullable; need norm).  zero_counters: 2 N ints owned by the caller, all zero on
+ * entry and all zero again on exit.  sticky_status is OR-ed into, never cleared (codes as above): for edge lists an
+ * earlier stg_graph_build_direct_device call has validated. */
+int stg_graph_build_direct2_device(const int32_t *src, const int32_t *dst, int64_t E, int32_t N, int64_t *perm_fwd,
+                                   int32_t *fwd_row_offset, int32_t *fwd_column_indices, int32_t *fwd_eids,
+                                   int32_t *fwd_node_ids, int32_t *bwd_row_offset, int32_t *bwd_column_indices,
+                                   int32_t *bwd_eids, int32_t *bwd_node_ids, int32_t *in_degrees, int32_t *out_degrees,
+                                   float *norm, float *norm_col_fwd, float *norm_col_bwd, int32_t *zero_counters,
+                                   int32_t *sticky_status, void *workspace, size_t workspace_bytes, void *stream);
+
+
 /* ------------------------------------------------------- dynamic edge store (PCSR, GPMA)
  * Replaces the reference's PCSR class: graph/dynamic/pcsr/pcsr.cu:273-939
  * (PCSR::edge_update_list :759-779, label_edges :745-757, build_csr :829-879,
@@ -184,6 +199,20 @@ int stg_edgeset_update_host(const uint64_t *keys_fwd_in, const uint64_t *keys_bw
 int stg_edgeset_merge_device(const uint64_t *keys_in, int64_t E, const uint64_t *add_sorted, int64_t n_add,
                              const uint64_t *del_sorted, int64_t n_del, uint64_t *keys_out,
                              int32_t *status, void *stream);
+
+/* One timestamp of a delta store (PCSRGraph / GPMAGraph._update_graph_forward / _backward: reference
+ * graph/dynamic/pcsr/pcsr_graph.py:121-166 = edge_update_list x 2 + label_edges + build_csr / build_reverse_csr, and the
+ * norm the training loop derives from the new in-degrees, dynamic-temporal-tgcn/seastar/train.py:213-218) as THREE
+ * launches: (old \ del) U add in both orientations from batches packed + sorted up front, both CSRs (row offsets +
+ * columns: rows back to front, or ascending with STG_EMIT_KEY_ORDER), in_degrees [N] (nullable), norm [N] = in_deg^-1/2
+ * (0 for isolated rows; nullable) and norm gathered through either CSR's columns [E_out] (nullable; need norm).
+ * status is OR-ed into, never cleared (codes as stg_edgeset_update_device): one word may serve a whole store. */
+int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E, const uint64_t *add_fwd,
+                            const uint64_t *add_bwd, int64_t n_add, const uint64_t *del_fwd, const uint64_t *del_bwd,
+                            int64_t n_del, int32_t N, int flags, uint64_t *keys_fwd_out, uint64_t *keys_bwd_out,
+                            int32_t *fwd_row_offset, int32_t *fwd_column_indices, int32_t *bwd_row_offset,
+                            int32_t *bwd_column_indices, int32_t *in_degrees, float *norm, float *norm_col_fwd,
+                            float *norm_col_bwd, int32_t *status, void *stream);
 #define STG_EMIT_REVERSE   1   /* rows = src (build_reverse_csr / build_backward_csr) */
 #define STG_EMIT_KEY_ORDER 2   /* GPMA view: rows and columns in key order; default = PCSR's back-to-front rows */
 size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N);

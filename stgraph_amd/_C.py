@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -26,9 +26,9 @@ EXPORTED_SYMBOLS = (
     "stg_abi_version", "stg_last_error_string", "stg_set_tuning",
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
-    "stg_graph_build_direct_workspace_bytes", "stg_graph_build_direct_device",
+    "stg_graph_build_direct_workspace_bytes", "stg_graph_build_direct_device", "stg_graph_build_direct2_device",
     "stg_rows_by_degree_workspace_bytes", "stg_rows_by_degree_device",
-    "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host", "stg_edgeset_merge_device",
+    "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host", "stg_edgeset_merge_device", "stg_edgeset_step_device",
     "stg_edgeset_emit_csr_workspace_bytes", "stg_edgeset_emit_csr_device", "stg_edgeset_emit_csr_host",
     "stg_jit_compile", "stg_jit_free", "stg_jit_load", "stg_jit_get_function", "stg_jit_unload", "stg_jit_launch",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_layer_fwd", "stg_bias_act_fwd", "stg_bias_act_bwd_workspace_bytes", "stg_bias_act_bwd",
@@ -101,6 +101,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_graph_build_direct_workspace_bytes.argtypes = [i64, i32]
     lib.stg_graph_build_direct_device.restype = ctypes.c_int
     lib.stg_graph_build_direct_device.argtypes = [vp, vp, i64, i32] + [vp] * 11 + [vp, vp, ctypes.c_size_t, vp]
+    lib.stg_graph_build_direct2_device.restype = ctypes.c_int
+    lib.stg_graph_build_direct2_device.argtypes = [vp, vp, i64, i32] + [vp] * 16 + [vp, ctypes.c_size_t, vp]
     lib.stg_rows_by_degree_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_rows_by_degree_workspace_bytes.argtypes = [i32]
     lib.stg_rows_by_degree_device.restype = ctypes.c_int
@@ -113,6 +115,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_edgeset_update_host.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp]
     lib.stg_edgeset_merge_device.restype = ctypes.c_int
     lib.stg_edgeset_merge_device.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, vp]
+    lib.stg_edgeset_step_device.restype = ctypes.c_int
+    lib.stg_edgeset_step_device.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, ctypes.c_int] + [vp] * 12
     lib.stg_edgeset_emit_csr_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_edgeset_emit_csr_workspace_bytes.argtypes = [i32]
     lib.stg_edgeset_emit_csr_device.restype = ctypes.c_int

@@ -177,8 +177,156 @@ __global__ void direct_sort_keys(const int *__restrict__ deg, int N, unsigned *_
     iota[v] = v;
 }
 
+// ---- the same build in FIVE launches with ONE atomic pass (round 3) -------------------------------------------------------
+// A snapshot rebuilt every epoch (NaiveGraph(resident=False)) pays the six launches above plus what follows every new CSR
+// in the training loop: the in-degree norm and its per-edge gathers (3 more launches) -- 88 + 14 us at |E| = 250 K, of
+// which the three random-address atomic passes (histogram, two scatter cursors) are 60.  Here the histogram pass RETURNS
+// each edge's arrival index inside its two rows, so placing needs no cursor; the scan also writes norm = in_deg^-1/2; the
+// two ranking passes also write norm gathered through their columns; the last pass leaves the counters zero again for the
+// next build (they live in a caller-owned buffer that is zero between builds: no init launch).
+__global__ __launch_bounds__(kBlock) void direct2_count(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int N,
+                                                       int *__restrict__ cnt, int *__restrict__ pos_f, int *__restrict__ pos_b,
+                                                       int *__restrict__ status)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+        const int s = src[i], d = dst[i];
+        if ((unsigned)s >= (unsigned)N || (unsigned)d >= (unsigned)N) {
+            atomicOr(status, 1);
+            pos_f[i] = -1;
+            continue;
+        }
+        pos_f[i] = atomicAdd(cnt + d, 1);
+        pos_b[i] = atomicAdd(cnt + N + s, 1);
+    }
+}
+
+// blockIdx.x = 0: forward rows (lengths cnt[0 .. N)), 1: backward rows (cnt[N .. 2N)).  One pass: every thread owns a
+// contiguous chunk of rows, a shuffle scan over the wave's chunk totals, the 16 wave totals through LDS.
+constexpr int kScan2Chunk = 64;                  // rows per thread per pass (|V| <= 65536 is one pass)
+__global__ __launch_bounds__(kScanThreads) void direct2_scan(const int *__restrict__ cnt, int N, int *__restrict__ fwd_ro,
+                                                            int *__restrict__ bwd_ro, int *__restrict__ in_deg,
+                                                            int *__restrict__ out_deg, float *__restrict__ norm,
+                                                            int *__restrict__ status)
+{
+    constexpr int kWavesScan = kScanThreads / 64;
+    __shared__ int wsum[kWavesScan];
+    const int side = blockIdx.x;
+    const int *deg = cnt + (side ? N : 0);
+    int *ro = side ? bwd_ro : fwd_ro;
+    int *dout = side ? out_deg : in_deg;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0, longest = 0;
+    for (int base = 0; base < N; base += kScanThreads * kScan2Chunk) {
+        const int span = min(N - base, kScanThreads * kScan2Chunk);
+        const int chunk = (span + kScanThreads - 1) / kScanThreads;          // <= kScan2Chunk
+        const int v0 = base + tid * chunk;
+        int d[kScan2Chunk];
+        int tot = 0;
+#pragma unroll
+        for (int i = 0; i < kScan2Chunk; ++i) {
+            d[i] = (i < chunk && v0 + i < base + span) ? deg[v0 + i] : 0;
+            tot += d[i];
+            longest = max(longest, d[i]);
+        }
+        int x = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesScan; ++w) {
+            const int t = wsum[w];
+            before += w < wave ? t : 0;
+            all += t;
+        }
+        int run = carry + before + (x - tot);
+#pragma unroll
+        for (int i = 0; i < kScan2Chunk; ++i) {
+            if (i < chunk && v0 + i < base + span) {
+                ro[v0 + i] = run;
+                dout[v0 + i] = d[i];
+                if (side == 0 && norm) norm[v0 + i] = d[i] > 0 ? __fdiv_rn(1.0f, __fsqrt_rn((float)d[i])) : 0.f;   // = degree_norm_kernel
+                run += d[i];
+            }
+        }
+        carry += all;
+        __syncthreads();
+    }
+    if (tid == 0) ro[N] = carry;
+    if (longest > kDirectMaxRow) atomicOr(status, STG_BUILD_NEEDS_SORT);
+}
+
+__global__ __launch_bounds__(kBlock) void direct2_place(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
+                                                       const int *__restrict__ fwd_ro, const int *__restrict__ pos_f,
+                                                       uint64_t *__restrict__ key, int *__restrict__ row,
+                                                       const int *__restrict__ status)
+{
+    if (*status) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+        const int d = dst[i];
+        const int slot = fwd_ro[d] + pos_f[i];
+        key[slot] = ((uint64_t)(unsigned)src[i] << 32) | (uint64_t)(unsigned)i;
+        row[slot] = d;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const uint64_t *__restrict__ key, const int *__restrict__ row, int64_t E,
+                                                          const int *__restrict__ fwd_ro, const int *__restrict__ bwd_ro,
+                                                          const int *__restrict__ pos_b, int *__restrict__ fwd_col,
+                                                          int *__restrict__ fwd_eid, int64_t *__restrict__ perm_fwd,
+                                                          uint64_t *__restrict__ key_b, int *__restrict__ row_b,
+                                                          const float *__restrict__ norm, float *__restrict__ nc_fwd,
+                                                          const int *__restrict__ status)
+{
+    if (*status) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < E; t += stride) {
+        const uint64_t mine = key[t];
+        const int d = row[t];
+        const int beg = fwd_ro[d];
+        const int e = beg + rank_in_row(key, beg, fwd_ro[d + 1], mine);   // = eid
+        const int s = (int)(mine >> 32);
+        const unsigned i = (unsigned)mine;                                // caller position
+        fwd_col[e] = s;
+        fwd_eid[e] = e;
+        perm_fwd[e] = (int64_t)i;
+        if (nc_fwd) nc_fwd[e] = norm[s];
+        const int slot = bwd_ro[s] + pos_b[i];
+        key_b[slot] = ((uint64_t)(unsigned)e << 32) | (uint64_t)(unsigned)d;
+        row_b[slot] = s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void direct2_rank_bwd(const uint64_t *__restrict__ key_b, const int *__restrict__ row_b, int64_t E,
+                                                          const int *__restrict__ bwd_ro, int *__restrict__ bwd_col,
+                                                          int *__restrict__ bwd_eid, const float *__restrict__ norm,
+                                                          float *__restrict__ nc_bwd, int *__restrict__ cnt, int N,
+                                                          const int *__restrict__ status)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t v = first; v < 2 * (int64_t)N; v += stride) cnt[v] = 0;     // nobody reads the counters any more
+    if (*status) return;
+    for (int64_t t = first; t < E; t += stride) {
+        const uint64_t mine = key_b[t];
+        const int s = row_b[t];
+        const int beg = bwd_ro[s];
+        const int o = beg + rank_in_row(key_b, beg, bwd_ro[s + 1], mine);
+        const int d = (int)(unsigned)mine;
+        bwd_eid[o] = (int)(mine >> 32);
+        bwd_col[o] = d;
+        if (nc_bwd) nc_bwd[o] = norm[d];
+    }
+}
+
 struct DirectLayout {
-    size_t key_f, row_f, key_b, row_b, cursors, deg_key_a, deg_key_b, iota, sort_tmp, total, sort_tmp_bytes;
+    size_t key_f, row_f, key_b, row_b, cursors, pos_f, pos_b, deg_key_a, deg_key_b, iota, sort_tmp, total, sort_tmp_bytes;
 };
 
 DirectLayout direct_layout(int64_t E, int32_t N)
@@ -196,6 +344,8 @@ DirectLayout direct_layout(int64_t E, int32_t N)
     L.key_b = take(e * 8);
     L.row_b = take(e * 4);
     L.cursors = take(2 * n * 4);
+    L.pos_f = take(e * 4);
+    L.pos_b = take(e * 4);
     L.deg_key_a = take(n * 4);
     L.deg_key_b = take(n * 4);
     L.iota = take(n * 4);
@@ -271,6 +421,66 @@ extern "C" int stg_graph_build_direct_device(const int32_t *src, const int32_t *
         }
     }
     return check_launch("stg_graph_build_direct_device");
+}
+
+extern "C" int stg_graph_build_direct2_device(const int32_t *src, const int32_t *dst, int64_t E, int32_t N,
+                                              int64_t *perm_fwd, int32_t *fwd_row_offset, int32_t *fwd_column_indices,
+                                              int32_t *fwd_eids, int32_t *fwd_node_ids, int32_t *bwd_row_offset,
+                                              int32_t *bwd_column_indices, int32_t *bwd_eids, int32_t *bwd_node_ids,
+                                              int32_t *in_degrees, int32_t *out_degrees, float *norm, float *norm_col_fwd,
+                                              float *norm_col_bwd, int32_t *zero_counters, int32_t *sticky_status,
+                                              void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (E < 0 || N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_graph_build_direct2_device: negative size");
+    if (E >= (int64_t(1) << 31))
+        return fail(STG_ERR_UNSUPPORTED, "stg_graph_build_direct2_device: E=%lld does not fit int32 edge ids", (long long)E);
+    if ((E > 0 && (!src || !dst || !perm_fwd || !fwd_column_indices || !fwd_eids || !bwd_column_indices || !bwd_eids)) ||
+        !fwd_row_offset || !bwd_row_offset || !sticky_status || !workspace || (N > 0 && (!in_degrees || !out_degrees || !zero_counters)) ||
+        (!fwd_node_ids != !bwd_node_ids) || ((norm_col_fwd || norm_col_bwd) && !norm))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_graph_build_direct2_device: NULL pointer argument");
+    const DirectLayout L = direct_layout(E, N);
+    if (workspace_bytes < L.total)
+        return fail(STG_ERR_WORKSPACE, "stg_graph_build_direct2_device: workspace %zu < required %zu", workspace_bytes, L.total);
+    char *ws = static_cast<char *>(workspace);
+    auto *key_f = reinterpret_cast<uint64_t *>(ws + L.key_f);
+    auto *row_f = reinterpret_cast<int *>(ws + L.row_f);
+    auto *key_b = reinterpret_cast<uint64_t *>(ws + L.key_b);
+    auto *row_b = reinterpret_cast<int *>(ws + L.row_b);
+    auto *pos_f = reinterpret_cast<int *>(ws + L.pos_f);
+    auto *pos_b = reinterpret_cast<int *>(ws + L.pos_b);
+    const int eblocks = (int)std::max<int64_t>(1, std::min<int64_t>((E + kBlock - 1) / kBlock, 256 * 16));
+    if (E > 0)
+        hipLaunchKernelGGL(direct2_count, dim3(eblocks), dim3(kBlock), 0, stream, src, dst, E, N, zero_counters, pos_f, pos_b,
+                           sticky_status);
+    hipLaunchKernelGGL(direct2_scan, dim3(2), dim3(kScanThreads), 0, stream, zero_counters, N, fwd_row_offset, bwd_row_offset,
+                       in_degrees, out_degrees, norm, sticky_status);
+    if (E > 0) {
+        hipLaunchKernelGGL(direct2_place, dim3(eblocks), dim3(kBlock), 0, stream, src, dst, E, fwd_row_offset, pos_f, key_f, row_f,
+                           sticky_status);
+        hipLaunchKernelGGL(direct2_rank_fwd, dim3(eblocks), dim3(kBlock), 0, stream, key_f, row_f, E, fwd_row_offset, bwd_row_offset,
+                           pos_b, fwd_column_indices, fwd_eids, perm_fwd, key_b, row_b, norm, norm_col_fwd, sticky_status);
+    }
+    // (also re-zeroes the counters: launched even for E = 0)
+    hipLaunchKernelGGL(direct2_rank_bwd, dim3(std::max(eblocks, (2 * std::max(N, 1) + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       key_b, row_b, E, bwd_row_offset, bwd_column_indices, bwd_eids, norm, norm_col_bwd, zero_counters, N,
+                       sticky_status);
+    if (N > 0 && fwd_node_ids) {
+        auto *ka = reinterpret_cast<unsigned *>(ws + L.deg_key_a);
+        auto *kb = reinterpret_cast<unsigned *>(ws + L.deg_key_b);
+        auto *iota = reinterpret_cast<int *>(ws + L.iota);
+        const int vblocks = (N + kBlock - 1) / kBlock;
+        const int *degs[2] = {in_degrees, out_degrees};
+        int32_t *outs[2] = {fwd_node_ids, bwd_node_ids};
+        for (int side = 0; side < 2; ++side) {
+            hipLaunchKernelGGL(direct_sort_keys, dim3(vblocks), dim3(kBlock), 0, stream, degs[side], N, ka, iota);
+            size_t tmp = L.sort_tmp_bytes;
+            const hipError_t e = rocprim::radix_sort_pairs_desc(ws + L.sort_tmp, tmp, ka, kb, iota, outs[side], (size_t)N, 0, 32, stream);
+            if (e != hipSuccess) return fail((int)e, "stg_graph_build_direct2_device: node_ids sort: %s", hipGetErrorString(e));
+        }
+    }
+    return check_launch("stg_graph_build_direct2_device");
 }
 
 extern "C" size_t stg_rows_by_degree_workspace_bytes(int32_t N)

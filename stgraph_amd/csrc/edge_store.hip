@@ -82,14 +82,14 @@ __device__ __forceinline__ int64_t upper_bound_dev(const uint64_t *__restrict__ 
     return lo;
 }
 
-__global__ __launch_bounds__(kBlock) void scatter_old(const uint64_t *__restrict__ old, int64_t E,
-                                                      const uint64_t *__restrict__ add, int64_t na,
-                                                      const uint64_t *__restrict__ del, int64_t nd,
-                                                      uint64_t *__restrict__ out, int64_t E_out,
-                                                      int *__restrict__ status)
+__device__ __forceinline__ void scatter_old_tile(const uint64_t *__restrict__ old, int64_t E,
+                                                 const uint64_t *__restrict__ add, int64_t na,
+                                                 const uint64_t *__restrict__ del, int64_t nd,
+                                                 uint64_t *__restrict__ out, int64_t E_out,
+                                                 int *__restrict__ status, int64_t tile)
 {
     __shared__ int64_t bounds[4];
-    const int64_t base = (int64_t)blockIdx.x * (kBlock * kMergeItems);
+    const int64_t base = tile * (kBlock * kMergeItems);
     const int64_t last = min(base + (int64_t)kBlock * kMergeItems, E) - 1;
     if (threadIdx.x < 4) {
         const bool hi = threadIdx.x & 1, use_del = threadIdx.x & 2;
@@ -133,14 +133,24 @@ __global__ __launch_bounds__(kBlock) void scatter_old(const uint64_t *__restrict
     else place(add + a0, del + d0);
 }
 
-// Added keys: slot = j + #(old keys below) - #(deleted keys below); deleted keys: must exist.
-__global__ void scatter_add_check_del(const uint64_t *__restrict__ old, int64_t E,
-                                      const uint64_t *__restrict__ add, int64_t na,
-                                      const uint64_t *__restrict__ del, int64_t nd,
-                                      uint64_t *__restrict__ out, int64_t E_out, int *__restrict__ status)
+__global__ __launch_bounds__(kBlock) void scatter_old(const uint64_t *__restrict__ old, int64_t E,
+                                                      const uint64_t *__restrict__ add, int64_t na,
+                                                      const uint64_t *__restrict__ del, int64_t nd,
+                                                      uint64_t *__restrict__ out, int64_t E_out,
+                                                      int *__restrict__ status)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < na + nd; j += stride) {
+    scatter_old_tile(old, E, add, na, del, nd, out, E_out, status, (int64_t)blockIdx.x);
+}
+
+// Added keys: slot = j + #(old keys below) - #(deleted keys below); deleted keys: must exist.
+__device__ __forceinline__ void scatter_add_range(const uint64_t *__restrict__ old, int64_t E,
+                                                  const uint64_t *__restrict__ add, int64_t na,
+                                                  const uint64_t *__restrict__ del, int64_t nd,
+                                                  uint64_t *__restrict__ out, int64_t E_out, int *__restrict__ status,
+                                                  int64_t block, int64_t nblocks)
+{
+    const int64_t stride = nblocks * blockDim.x;
+    for (int64_t j = block * blockDim.x + threadIdx.x; j < na + nd; j += stride) {
         if (j < na) {
             const uint64_t k = add[j];
             if (j > 0 && add[j - 1] >= k) { atomicOr(status, add[j - 1] == k ? 2 : 16); continue; }   // duplicate / unsorted
@@ -156,6 +166,85 @@ __global__ void scatter_add_check_del(const uint64_t *__restrict__ old, int64_t 
             if (q > 0 && del[q - 1] > k) atomicOr(status, 16);                              // batch not sorted
             if (o >= E || old[o] != k || (q > 0 && del[q - 1] == k)) atomicOr(status, 4);   // deleting an absent edge
         }
+    }
+}
+
+__global__ void scatter_add_check_del(const uint64_t *__restrict__ old, int64_t E,
+                                      const uint64_t *__restrict__ add, int64_t na,
+                                      const uint64_t *__restrict__ del, int64_t nd,
+                                      uint64_t *__restrict__ out, int64_t E_out, int *__restrict__ status)
+{
+    scatter_add_range(old, E, add, na, del, nd, out, E_out, status, (int64_t)blockIdx.x, (int64_t)gridDim.x);
+}
+
+// ---- one timestamp of a delta store as THREE launches (round 3) ---------------------------------------------------------
+// What a training step of the dynamic loop needs from the store after an update: the new key arrays, both CSRs (row
+// offsets + columns; labels stay lazy), the in-degrees, norm = in_deg^-1/2 and norm gathered per edge of either CSR.
+// Issued piecewise that is two scatter launches per orientation, two row-offset searches, two emissions, a degree
+// difference, the norm and two gathers -- ~14 launches of 4-20 us at |E| = 250 K, 100 us in all.  Here: (1) both
+// orientations' merges in one grid, (2) both row-offset arrays + degrees + norm, (3) both emissions + per-edge norm.
+struct StepArgs {
+    const uint64_t *old[2], *add[2], *del[2];
+    uint64_t *out[2];
+    int *ro[2], *col[2];
+    float *nc[2];
+    int *in_deg;
+    float *norm;
+    int *status;
+    int64_t E, na, nd, E_out;
+    int N, nb_old, nb_add;
+};
+
+__global__ __launch_bounds__(kBlock) void step_merge_kernel(const StepArgs a)
+{
+    const int per = a.nb_old + a.nb_add;
+    const int side = (int)blockIdx.x / per, r = (int)blockIdx.x - side * per;       // block-uniform
+    if (r < a.nb_old)
+        scatter_old_tile(a.old[side], a.E, a.add[side], a.na, a.del[side], a.nd, a.out[side], a.E_out, a.status, r);
+    else
+        scatter_add_range(a.old[side], a.E, a.add[side], a.na, a.del[side], a.nd, a.out[side], a.E_out, a.status,
+                          r - a.nb_old, a.nb_add);
+}
+
+__device__ __forceinline__ int row_begin(const uint64_t *__restrict__ keys, int64_t E, int v)
+{
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(keys[mid] >> kStoreBits) < (int64_t)v) lo = mid + 1;
+        else hi = mid;
+    }
+    return (int)lo;
+}
+
+__global__ __launch_bounds__(kBlock) void step_rows_kernel(const StepArgs a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int side = idx > a.N ? 1 : 0;
+    const int v = (int)(idx - (side ? a.N + 1 : 0));
+    if (v > a.N) return;
+    const int lo = row_begin(a.out[side], a.E_out, v);
+    a.ro[side][v] = lo;
+    if (side == 0 && v < a.N && (a.in_deg || a.norm)) {
+        const int d = row_begin(a.out[0], a.E_out, v + 1) - lo;
+        if (a.in_deg) a.in_deg[v] = d;
+        if (a.norm) a.norm[v] = d > 0 ? __fdiv_rn(1.0f, __fsqrt_rn((float)d)) : 0.f;     // = degree_norm_kernel
+    }
+}
+
+template <bool KEY_ORDER>
+__global__ __launch_bounds__(kBlock) void step_emit_kernel(const StepArgs a)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < 2 * a.E_out; t += stride) {
+        const int side = t >= a.E_out ? 1 : 0;
+        const int64_t i = t - (side ? a.E_out : 0);
+        const uint64_t k = a.out[side][i];
+        const unsigned row = (unsigned)(k >> kStoreBits), c = (unsigned)k;
+        const int *ro = a.ro[side];
+        const int64_t o = KEY_ORDER ? i : (int64_t)ro[row] + ((int64_t)ro[row + 1] - 1 - i);
+        a.col[side][o] = (int)c;
+        if (a.nc[side]) a.nc[side][o] = a.norm[c];
     }
 }
 
@@ -416,6 +505,49 @@ extern "C" int stg_edgeset_merge_device(const uint64_t *keys_in, int64_t E, cons
     launch_merge(keys_in, E, add_sorted, n_add, del_sorted, n_del, keys_out, E_out, status,
                  static_cast<hipStream_t>(stream_));
     return check_launch("stg_edgeset_merge_device");
+}
+
+extern "C" int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E,
+                                       const uint64_t *add_fwd, const uint64_t *add_bwd, int64_t n_add,
+                                       const uint64_t *del_fwd, const uint64_t *del_bwd, int64_t n_del, int32_t N, int flags,
+                                       uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *fwd_row_offset,
+                                       int32_t *fwd_column_indices, int32_t *bwd_row_offset, int32_t *bwd_column_indices,
+                                       int32_t *in_degrees, float *norm, float *norm_col_fwd, float *norm_col_bwd,
+                                       int32_t *status, void *stream_)
+{
+    using namespace stg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (E < 0 || n_add < 0 || n_del < 0 || N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: negative size");
+    const int64_t E_out = E + n_add - n_del;
+    if (E_out < 0 || E + n_add >= (int64_t(1) << 30))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: edge count %lld out of range", (long long)E_out);
+    if (flags & ~STG_EMIT_KEY_ORDER) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: unknown flag");
+    if (!status || !fwd_row_offset || !bwd_row_offset || (E > 0 && (!keys_fwd_in || !keys_bwd_in)) ||
+        (E_out > 0 && (!keys_fwd_out || !keys_bwd_out || !fwd_column_indices || !bwd_column_indices)) ||
+        (n_add > 0 && (!add_fwd || !add_bwd)) || (n_del > 0 && (!del_fwd || !del_bwd)) ||
+        ((norm_col_fwd || norm_col_bwd) && !norm))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: NULL pointer argument");
+    if (keys_fwd_out == keys_fwd_in || keys_bwd_out == keys_bwd_in)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: the update is out of place");
+    StepArgs a{};
+    a.old[0] = keys_fwd_in; a.old[1] = keys_bwd_in; a.add[0] = add_fwd; a.add[1] = add_bwd; a.del[0] = del_fwd; a.del[1] = del_bwd;
+    a.out[0] = keys_fwd_out; a.out[1] = keys_bwd_out; a.ro[0] = fwd_row_offset; a.ro[1] = bwd_row_offset;
+    a.col[0] = fwd_column_indices; a.col[1] = bwd_column_indices; a.nc[0] = norm_col_fwd; a.nc[1] = norm_col_bwd;
+    a.in_deg = in_degrees; a.norm = norm; a.status = status;
+    a.E = E; a.na = n_add; a.nd = n_del; a.E_out = E_out; a.N = N;
+    const int64_t tile = (int64_t)kBlock * kMergeItems;
+    a.nb_old = (int)((E + tile - 1) / tile);
+    a.nb_add = n_add + n_del > 0 ? grid_for(n_add + n_del) : 0;
+    if (a.nb_old + a.nb_add > 0)
+        hipLaunchKernelGGL(step_merge_kernel, dim3(2u * (unsigned)(a.nb_old + a.nb_add)), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(step_rows_kernel, dim3((unsigned)((2 * ((int64_t)N + 1) + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, a);
+    if (E_out > 0) {
+        if (flags & STG_EMIT_KEY_ORDER)
+            hipLaunchKernelGGL((step_emit_kernel<true>), dim3(grid_for(2 * E_out)), dim3(kBlock), 0, stream, a);
+        else
+            hipLaunchKernelGGL((step_emit_kernel<false>), dim3(grid_for(2 * E_out)), dim3(kBlock), 0, stream, a);
+    }
+    return check_launch("stg_edgeset_step_device");
 }
 
 extern "C" size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N)

@@ -69,8 +69,8 @@ class NaiveGraph(DynamicGraph):
             g = kernels.build_graph_csr(s, d, self.max_num_nodes, self._device, lazy_node_ids=not self._resident,
                                         known_path=self._built_by.get(t))       # validated once: no status sync on rebuilds
             self._built_by[t] = g.built_by
-            if g.unchecked_status is not None:
-                self._pending_status.append(g.unchecked_status)
+            if g.unchecked_status is not None and not any(g.unchecked_status is p for p in self._pending_status[-1:]):
+                self._pending_status.append(g.unchecked_status)      # (the fused rebuild's word is one per device: once)
                 if len(self._pending_status) >= 4096:
                     self.verify_builds()
             self.build_count += 1
@@ -130,6 +130,10 @@ class NaiveGraph(DynamicGraph):
     def in_degrees_tensor(self) -> torch.Tensor:
         """Device-resident in-degrees of the current snapshot (avoids the D2H copy of ``in_degrees``)."""
         return self._snapshot(self.current_timestamp).in_degrees
+
+    def in_degree_norm_tensor(self):
+        """``in_deg ** -0.5`` [N, 1] of the current snapshot if its build already produced it (fused rebuild), else None."""
+        return getattr(self._snapshot(self.current_timestamp), "norm_in", None)
 
     def _get_graph_csr_ptrs(self, timestamp: int) -> None:
         """Remember which snapshot the ``fwd_*/bwd_*_ptr`` attributes refer to; the addresses (and with them a

@@ -37,6 +37,9 @@ def _pairs(edge_list, device):
     return to(a), to(b)
 
 
+FUSED_STEP = True       # merge_sorted as ONE fused device step (kernels.edgeset_step); False: merge, then emit on demand
+
+
 class PCSR:
     _key_order = False      # emission layout: PCSR rows come out back to front (the GPMA subclass sets True)
 
@@ -48,6 +51,9 @@ class PCSR:
         self._pending = {"add": [], "delete": []}       # (store src, store dst) tensor pairs, not yet merged
         self._emitted = {}                              # reverse(bool) -> kernels.StoreCSR of self._set
         self._published = None                          # the arrays the last build_* call handed out
+        # sticky status word of the fused steps, shared by every copy of this store (made here, outside any HIP-graph capture)
+        self._status = torch.zeros(1, dtype=torch.int32, device=self._device) if self._device.type == "cuda" else None
+        self._norm_in = None                            # in_deg ** -0.5 [N, 1] of the current set, when a fused step made it
         self.update_count = 0                           # merge passes issued (two orientations each)
 
     # -- copies share everything immutable (the reference's copies share the device arrays too) --------
@@ -86,6 +92,7 @@ class PCSR:
         self._set = kernels.edgeset_update(self._set, a_dst, a_src, d_dst, d_src)
         self._pending = {"add": [], "delete": []}
         self._emitted = {}
+        self._norm_in = None
         self.update_count += 1
 
     def merge_sorted(self, add_keys, del_keys) -> None:
@@ -94,8 +101,16 @@ class PCSR:
         self._flush()
         if add_keys[0].numel() == 0 and del_keys[0].numel() == 0:
             return
-        self._set = kernels.edgeset_merge(self._set, add_keys, del_keys)
-        self._emitted = {}
+        if FUSED_STEP and self._device.type == "cuda":
+            # merge + both CSRs + in-degree norm (+ its per-edge gathers) in three launches: what every consumer of a
+            # timestamp asks for next anyway (build_csr / build_reverse_csr, the loop's norm)
+            self._set, fwd, bwd, self._norm_in = kernels.edgeset_step(self._set, add_keys, del_keys, self._key_order,
+                                                                      self._status)
+            self._emitted = {False: fwd, True: bwd}
+        else:
+            self._set = kernels.edgeset_merge(self._set, add_keys, del_keys)
+            self._emitted = {}
+            self._norm_in = None
         self.update_count += 1
 
     def label_edges(self) -> None:

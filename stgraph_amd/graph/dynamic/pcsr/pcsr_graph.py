@@ -115,6 +115,10 @@ class PCSRGraph(DynamicGraph):
     def in_degrees_tensor(self) -> torch.Tensor:
         return self._forward_graph.row_lengths(False)
 
+    def in_degree_norm_tensor(self):
+        """``in_deg ** -0.5`` [N, 1] of the current timestamp if the store's fused step already produced it (else None)."""
+        return self._forward_graph._norm_in
+
     def _get_graph_csr_ptrs(self, *_):
         """Remember which build the eight ``fwd_*/bwd_*_ptr`` attributes refer to; the addresses themselves
         (and with them the 1-based label array) are produced when an attribute is read."""

@@ -194,6 +194,7 @@ class GraphCSR:
     perm_fwd: torch.Tensor         # int64 [E]: caller position of the edge that became eid j
     built_by: str = ""             # 'direct' | 'sort' | 'host': which builder produced (and validated) it
     unchecked_status: "torch.Tensor | None" = None    # the build's status word when its read was skipped (known_path)
+    norm_in: "torch.Tensor | None" = None             # in_deg ** -0.5 [N, 1] when the (fused re-)build produced it
 
     @property
     def num_edges(self) -> int:
@@ -240,6 +241,9 @@ def check_build_statuses(statuses) -> None:
     codes = torch.stack([s.reshape(()) for s in statuses]).cpu().tolist()
     bad = [c for c in codes if c != 0]
     if bad:
+        for s_, c in zip(statuses, codes):
+            if c != 0:
+                s_.zero_()                 # a sticky word (fused rebuild) is shared by later builds: reported once, then clean
         raise ValueError(f"{len(bad)} per-snapshot CSR build(s) whose validation was deferred failed "
                          f"(libstgraph_hip status {bad[0]}): the edge list changed after it was first built")
 
@@ -249,6 +253,23 @@ def set_direct_build(enabled: bool) -> None:
     sort-based builder when a row is longer than 2048 entries.  False: always the sort-based builder."""
     global _DIRECT_BUILD
     _DIRECT_BUILD = bool(enabled)
+
+
+FUSED_REBUILD = True     # re-builds of a validated edge list go through stg_graph_build_direct2_device
+_BUILD_COUNTERS = {}
+
+
+def _build_counters(device, N: int):
+    """(2 N zeroed counters, sticky status word) of ``device`` for stg_graph_build_direct2_device: the counters are zero
+    between builds by that function's contract, so one buffer per (device, N) serves every rebuild on a stream."""
+    key = (str(device), int(N))
+    hit = _BUILD_COUNTERS.get(key)
+    if hit is None:
+        if len(_BUILD_COUNTERS) > 64:
+            _BUILD_COUNTERS.clear()
+        hit = _BUILD_COUNTERS[key] = (torch.zeros(2 * max(N, 1), dtype=torch.int32, device=device),
+                                      torch.zeros(1, dtype=torch.int32, device=device))
+    return hit
 
 
 def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_node_ids: bool = False,
@@ -286,9 +307,30 @@ def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_n
         status = torch.empty(1, **i32)
         code = BUILD_NEEDS_SORT
         built_by = "sort"
-        if known_path == "direct" and lazy == bool(lazy_node_ids) and _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES:
+        direct_ok = _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES
+        if direct_ok and not torch.cuda.is_current_stream_capturing():
+            _build_counters(device, N)             # made outside any capture: a later captured rebuild finds them
+        if known_path == "direct" and lazy == bool(lazy_node_ids) and direct_ok:
             ws_bytes = int(_C.lib.stg_graph_build_direct_workspace_bytes(E, N))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            if FUSED_REBUILD and N > 0 and E > 0:
+                # five launches, one atomic pass; norm = in_deg ** -0.5 and its per-edge gathers ride along (what the
+                # dynamic loop computes from every new snapshot); status: the device's sticky word
+                counters, sticky = _build_counters(device, N)
+                norm = torch.empty(N, 1, dtype=torch.float32, device=device)
+                nc_f = torch.empty(E, dtype=torch.float32, device=device)
+                nc_b = torch.empty(E, dtype=torch.float32, device=device)
+                with torch.cuda.device(device):
+                    _C.check(_C.lib.stg_graph_build_direct2_device(
+                        _ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays], _ptr(norm), _ptr(nc_f), _ptr(nc_b),
+                        _ptr(counters), _ptr(sticky), _ptr(ws), ws_bytes, _stream_ptr(device)))
+                g = GraphCSR(N, fwd, bwd, indeg, outdeg, perm)
+                g.built_by = "direct"
+                g.unchecked_status = sticky
+                g.norm_in = norm
+                fwd.__dict__["_edge_cache"] = {"norm": (norm, norm._version, nc_f)}
+                bwd.__dict__["_edge_cache"] = {"norm": (norm, norm._version, nc_b)}
+                return g
             with torch.cuda.device(device):
                 _C.check(_C.lib.stg_graph_build_direct_device(
                     _ptr(s), _ptr(d), E, N, *[_ptr(a) for a in arrays],
@@ -439,6 +481,43 @@ def edgeset_merge(es: EdgeSet, add_keys, del_keys) -> EdgeSet:
         _C.check(_C.lib.stg_edgeset_merge_device(_ptr(es.keys_bwd), E, _ptr(add_keys[1]), na, _ptr(del_keys[1]), nd,
                                                  _ptr(kb), _ptr(status), st))
     return EdgeSet(N, kf, kb, status)
+
+
+def edgeset_step(es: EdgeSet, add_keys, del_keys, key_order: bool, status: torch.Tensor | None = None):
+    """One timestamp of a delta store in three launches (stg_edgeset_step_device): returns ``(new set, forward StoreCSR,
+    backward StoreCSR, norm [N, 1])`` -- the merge of :func:`edgeset_merge`, both emissions of :func:`edgeset_emit_csr`, the
+    in-degrees, ``norm = in_deg ** -0.5`` (:func:`degree_norm`'s values) and ``norm`` gathered per edge of either CSR,
+    already filed in the CSRs' per-edge caches under the returned ``norm`` tensor.  ``status``: the store's sticky status
+    word (OR-ed into; a fresh zero word if None)."""
+    device, N, E = es.device, es.num_nodes, es.num_edges
+    if device.type != "cuda":
+        raise ValueError("edgeset_step is the device fast path")
+    na, nd = int(add_keys[0].shape[0]), int(del_keys[0].shape[0])
+    E_out = E + na - nd
+    if E_out < 0:
+        raise ValueError("more deletions than edges")
+    i32 = dict(dtype=torch.int32, device=device)
+    kf = torch.empty(E_out, dtype=torch.int64, device=device)
+    kb = torch.empty(E_out, dtype=torch.int64, device=device)
+    if status is None:
+        status = torch.zeros(1, **i32)
+    ro_f, ro_b = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
+    col_f, col_b = torch.empty(E_out, **i32), torch.empty(E_out, **i32)
+    deg = torch.empty(N, **i32)
+    norm = torch.empty(N, 1, dtype=torch.float32, device=device)
+    nc_f = torch.empty(E_out, dtype=torch.float32, device=device)
+    nc_b = torch.empty(E_out, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _C.check(_C.lib.stg_edgeset_step_device(
+            _ptr(es.keys_fwd), _ptr(es.keys_bwd), E, _ptr(add_keys[0]), _ptr(add_keys[1]), na, _ptr(del_keys[0]),
+            _ptr(del_keys[1]), nd, N, EMIT_KEY_ORDER if key_order else 0, _ptr(kf), _ptr(kb), _ptr(ro_f), _ptr(col_f),
+            _ptr(ro_b), _ptr(col_b), _ptr(deg), _ptr(norm), _ptr(nc_f), _ptr(nc_b), _ptr(status), _stream_ptr(device)))
+    new = EdgeSet(N, kf, kb, status)
+    fwd = StoreCSR(new, False, ro_f, col_f, None, deg, key_order)
+    bwd = StoreCSR(new, True, ro_b, col_b, None, None, key_order)
+    fwd.__dict__["_edge_cache"] = {"norm": (norm, norm._version, nc_f)}
+    bwd.__dict__["_edge_cache"] = {"norm": (norm, norm._version, nc_b)}
+    return new, fwd, bwd, norm
 
 
 def edgeset_check(es: EdgeSet) -> None:

@@ -907,6 +907,10 @@ def in_degree_norm(graph) -> torch.Tensor:
     """norm = in_deg^-0.5, inf -> 0, computed on the device from the current snapshot (one launch: kernels.degree_norm;
     the torch composition -- five launches -- for tensors that are not int32 on a GPU)."""
     from . import kernels
+    if hasattr(graph, "in_degree_norm_tensor"):
+        pre = graph.in_degree_norm_tensor()          # made by the graph step itself (delta stores, fused rebuild)
+        if pre is not None:
+            return pre
     if hasattr(graph, "in_degrees_tensor"):
         deg = graph.in_degrees_tensor()
         if deg.is_cuda and deg.dtype == torch.int32 and deg.is_contiguous():
