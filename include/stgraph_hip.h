@@ -132,8 +132,8 @@ int stg_graph_build_direct_device(const int32_t *src, const int32_t *dst, int64_
  * graph/dynamic/naive/naive_graph.py:45-74 built once per snapshot; here once per snapshot and epoch -- in five launches
  * with one atomic pass, together with what the training loop derives from every new CSR
  * (dynamic-temporal-tgcn/seastar/train.py:213-218): norm [N] = in_deg^-1/2 (nullable) and norm gathered through the
- * forward / backward columns [E] (nullable; need norm).  zero_counters: 2 N ints owned by the caller, all zero on
- * entry and all zero again on exit.  sticky_status is OR-ed into, never cleared (codes as above): for edge lists an
+ * forward / backward columns [E] (nullable; need norm).  zero_counters: 2 * ((N + 3) & ~3) ints owned by the caller, all
+ * zero on entry and all zero again on exit; the per-vertex arrays 16-byte aligned.  sticky_status is OR-ed into, never cleared (codes as above): for edge lists an
  * earlier stg_graph_build_direct_device call has validated. */
 int stg_graph_build_direct2_device(const int32_t *src, const int32_t *dst, int64_t E, int32_t N, int64_t *perm_fwd,
                                    int32_t *fwd_row_offset, int32_t *fwd_column_indices, int32_t *fwd_eids,

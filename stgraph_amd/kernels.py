@@ -267,7 +267,7 @@ def _build_counters(device, N: int):
     if hit is None:
         if len(_BUILD_COUNTERS) > 64:
             _BUILD_COUNTERS.clear()
-        hit = _BUILD_COUNTERS[key] = (torch.zeros(2 * max(N, 1), dtype=torch.int32, device=device),
+        hit = _BUILD_COUNTERS[key] = (torch.zeros(2 * ((max(N, 1) + 3) & ~3), dtype=torch.int32, device=device),
                                       torch.zeros(1, dtype=torch.int32, device=device))
     return hit
 
