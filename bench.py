@@ -400,7 +400,7 @@ class GAT(nn.Module):
         return self.gat_layers[-1](self.g, h).mean(1)
 
 
-def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer_iters=10, epochs=12):
+def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer_iters=10, epochs=23):
     """BASELINE configs[2]: (a) one GATConv(64 -> 8 x 64) forward + backward with per-kernel HIP-event times, each
     against its SURVEY.md 8(d) byte model; (b) the 2-layer model of benchmarking/gat/seastar/model.py
     (GATConv(64, 64, 8 heads, elu) -> GATConv(512, classes, 1 head), mean over heads), cross-entropy on the first 60 %,
@@ -516,7 +516,25 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
 
 
 # ----------------------------------------------------------------------------- TGCN (cfg 4)
-def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, B):
+def process_group_info(device, rank, world):
+    """What the process group actually consists of (for auditing a SCALE record): backend, size, and per rank the
+    device it computes on."""
+    info = {"world_size": world, "backend": None, "ranks": [{"rank": rank, "device": str(device),
+                                                              "name": torch.cuda.get_device_name(device)}]}
+    if world > 1:
+        info["backend"] = dist.get_backend()
+        info["world_size"] = dist.get_world_size()
+        mine = {"rank": rank, "device": str(device), "name": torch.cuda.get_device_name(device),
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
+                "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", ""))}
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        info["ranks"] = got
+        info["distinct_devices"] = len({(r["uuid"] or r["device"]) for r in got})
+    return info
+
+
+def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, B, allreduce_in_graph=False):
     from stgraph_amd import kernels, temporal
     from stgraph_amd.graph import StaticGraph
     src, dst = synthetic_graph(n, e, 3, device)                 # same graph on every rank
@@ -574,7 +592,8 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         comm = float(t.item())
     # (b) the same windows replayed from a captured HIP graph (one capture, 40/N replays per epoch)
-    cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, feat, world=world, rank=rank)
+    cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, feat, world=world, rank=rank,
+                                       allreduce_in_graph=allreduce_in_graph)
     for ep in range(warmup_epochs):
         temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat, epoch=2 + ep, rank=rank,
                                              world=world)
@@ -657,8 +676,10 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
                   "rank0_gcn_agg_kernel_seconds": agg_s, "rank0_gcn_agg_launches": agg_launches,
                   "rank0_gcn_agg_share": agg_s / dt_eager, "rank0_native_kernels": ktab,
                   "allreduce_seconds_max_rank": comm, "allreduce_share": comm / dt_eager},
+        "process_group": process_group_info(device, rank, world),
         "allreduce": {"bytes": bucket.nbytes, "calls_per_epoch": calls_timed / max(epochs, 1),
                       "seconds_max_rank": comm_g, "share_of_epoch": comm_g / dt if dt else None,
+                      "in_graph": bool(cw.allreduce_in_graph),
                       "collective": "one all-reduce(sum)/N of the flattened gradient bucket per optimizer step"},
     }
 
@@ -843,16 +864,18 @@ def main():
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--edges", type=int, default=16_000_000)
     ap.add_argument("--feat", type=int, default=128)
-    ap.add_argument("--tgcn-epochs", type=int, default=4)
+    ap.add_argument("--tgcn-epochs", type=int, default=20, help="timed epochs (the reference: >= 20, the first three discarded)")
     ap.add_argument("--tgcn-timestamps", type=int, default=1000)
     ap.add_argument("--no-cora", action="store_true")
     ap.add_argument("--no-dynamic", action="store_true")
     ap.add_argument("--no-gat", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed PMC passes")
-    ap.add_argument("--dynamic-epochs", type=int, default=3)
+    ap.add_argument("--dynamic-epochs", type=int, default=20)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device: exercise the multi-rank logic on a single GPU (testing only)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (testing only)")
+    ap.add_argument("--allreduce-in-graph", action="store_true",
+                    help="N > 1: capture the gradient all-reduce into the optimizer-tail HIP graph (default: eager between the replays)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -990,8 +1013,8 @@ def main():
         line["gat"] = gat_run(device)
         torch.cuda.empty_cache()
     if not args.no_tgcn:
-        line["tgcn"] = tgcn_run(device, rank, world, epochs=args.tgcn_epochs, warmup_epochs=1, n=50_000, e=500_000,
-                                T=args.tgcn_timestamps, feat=32, hidden=64, B=25)
+        line["tgcn"] = tgcn_run(device, rank, world, epochs=args.tgcn_epochs, warmup_epochs=3, n=50_000, e=500_000,
+                                T=args.tgcn_timestamps, feat=32, hidden=64, B=25, allreduce_in_graph=args.allreduce_in_graph)
     if not args.no_dynamic:
         line["dynamic"] = dynamic_run(device, rank, world, epochs=args.dynamic_epochs)
     if rank == 0 and world == 1 and not args.no_live_pmc and line["roofline"].get("traffic") is not None:

@@ -60,14 +60,15 @@ class NaiveGraph(DynamicGraph):
             self._get_graph_csr_ptrs(0)
 
     # -- snapshot store -------------------------------------------------------------------------
-    def _snapshot(self, t: int) -> kernels.GraphCSR:
+    def _snapshot(self, t: int, counters_slot: int = 0) -> kernels.GraphCSR:
         g = self._snapshots.get(t)
         if g is None:
             t0 = time.time()
             s, d = self._edges[t]
             # snapshots built on demand live for one training step: their degree sorts (node_ids) wait for a reader
             g = kernels.build_graph_csr(s, d, self.max_num_nodes, self._device, lazy_node_ids=not self._resident,
-                                        known_path=self._built_by.get(t))       # validated once: no status sync on rebuilds
+                                        known_path=self._built_by.get(t),       # validated once: no status sync on rebuilds
+                                        counters_slot=counters_slot)
             self._built_by[t] = g.built_by
             if g.unchecked_status is not None and not any(g.unchecked_status is p for p in self._pending_status[-1:]):
                 self._pending_status.append(g.unchecked_status)      # (the fused rebuild's word is one per device: once)

@@ -256,13 +256,15 @@ def set_direct_build(enabled: bool) -> None:
 
 
 FUSED_REBUILD = True     # re-builds of a validated edge list go through stg_graph_build_direct2_device
+BUILD_SLOTS = 4          # counter buffers per (device, |V|): that many rebuilds may be in flight on different streams
 _BUILD_COUNTERS = {}
 
 
-def _build_counters(device, N: int):
+def _build_counters(device, N: int, slot: int = 0):
     """(2 N zeroed counters, sticky status word) of ``device`` for stg_graph_build_direct2_device: the counters are zero
-    between builds by that function's contract, so one buffer per (device, N) serves every rebuild on a stream."""
-    key = (str(device), int(N))
+    between builds by that function's contract, so one buffer per (device, N) serves every rebuild on a stream; builds
+    issued on CONCURRENT streams take different ``slot``s."""
+    key = (str(device), int(N), int(slot))
     hit = _BUILD_COUNTERS.get(key)
     if hit is None:
         if len(_BUILD_COUNTERS) > 64:
@@ -273,7 +275,7 @@ def _build_counters(device, N: int):
 
 
 def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_node_ids: bool = False,
-                    known_path: str | None = None) -> GraphCSR:
+                    known_path: str | None = None, counters_slot: int = 0) -> GraphCSR:
     """Build both CSRs of a graph from (src, dst) arrays (static_graph.py:40-78).
 
     ``device`` cuda -> the direct (counting) build for small graphs, the sort-based build otherwise or when a
@@ -309,14 +311,15 @@ def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_n
         built_by = "sort"
         direct_ok = _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES
         if direct_ok and not torch.cuda.is_current_stream_capturing():
-            _build_counters(device, N)             # made outside any capture: a later captured rebuild finds them
+            for slot in range(BUILD_SLOTS):        # made outside any capture: a later captured rebuild finds them
+                _build_counters(device, N, slot)
         if known_path == "direct" and lazy == bool(lazy_node_ids) and direct_ok:
             ws_bytes = int(_C.lib.stg_graph_build_direct_workspace_bytes(E, N))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
             if FUSED_REBUILD and N > 0 and E > 0:
                 # five launches, one atomic pass; norm = in_deg ** -0.5 and its per-edge gathers ride along (what the
                 # dynamic loop computes from every new snapshot); status: the device's sticky word
-                counters, sticky = _build_counters(device, N)
+                counters, sticky = _build_counters(device, N, counters_slot)
                 norm = torch.empty(N, 1, dtype=torch.float32, device=device)
                 nc_f = torch.empty(E, dtype=torch.float32, device=device)
                 nc_b = torch.empty(E, dtype=torch.float32, device=device)

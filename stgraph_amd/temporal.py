@@ -312,9 +312,7 @@ def windows_of_rank(total_timestamps: int, backprop_every: int, rank: int, world
     return out
 
 
-WINDOW_CHUNK = 64          # windows drawn by one randn call (fewer on very large graphs: chunk_windows)
 _GENERATORS = {}
-_LAST_CHUNK = {}
 
 
 def _generator(device) -> torch.Generator:
@@ -325,35 +323,18 @@ def _generator(device) -> torch.Generator:
     return gen
 
 
-def chunk_windows(num_nodes: int, feat: int) -> int:
-    """Windows per draw: WINDOW_CHUNK, fewer when one draw would exceed 1 GiB (a function of the problem's shape only,
-    never of the number of ranks)."""
-    return max(1, min(WINDOW_CHUNK, (1 << 28) // max(1, num_nodes * feat)))
-
-
-def window_input_chunk(num_nodes: int, feat: int, epoch: int, chunk: int, device, seed: int = 0,
-                       out: torch.Tensor | None = None) -> torch.Tensor:
-    """The fresh ``torch.randn`` inputs of windows ``[chunk * CW, (chunk + 1) * CW)`` of an epoch (CW =
-    ``chunk_windows``) as one ``[CW, N, feat]`` draw whose stream is a function of (seed, epoch, chunk) only: a window's
-    input is the same for any number of ranks, and an epoch costs one generator call per chunk instead of one generator
-    object, one seeding and one launch per window."""
+def window_input(num_nodes: int, feat: int, epoch: int, window: int, device, seed: int = 0,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
+    """The fresh ``torch.randn`` input of one BPTT window (static-temporal-tgcn/seastar/train.py:165-168), as a stream that
+    is a function of (seed, epoch, window) ONLY: a window's input is the same whichever rank runs it and however many ranks
+    there are, and a rank draws just the windows it owns (round 2 drew every window of the epoch on every rank in 64-window
+    chunks: one launch, but a serial 256 MB term per rank at cfg4 that did not shrink with the number of ranks).
+    ``out``: filled in place (a captured window's resident input slot)."""
     gen = _generator(device)
-    gen.manual_seed((seed * 1_000_003 + epoch) * 1_000_003 + chunk)
+    gen.manual_seed((seed * 1_000_003 + epoch) * 1_000_003 + window)
     if out is None:
-        return torch.randn(chunk_windows(num_nodes, feat), num_nodes, feat, device=device, generator=gen)
+        return torch.randn(num_nodes, feat, device=device, generator=gen)
     return out.normal_(generator=gen)
-
-
-def window_input(num_nodes: int, feat: int, epoch: int, window: int, device, seed: int = 0) -> torch.Tensor:
-    """Input of one window: row ``window % CW`` of its chunk (the last chunk drawn is kept, so a loop over
-    consecutive windows draws each chunk once)."""
-    cw = chunk_windows(num_nodes, feat)
-    key = (num_nodes, feat, epoch, window // cw, str(torch.device(device)), seed)
-    hit = _LAST_CHUNK.get("key")
-    if hit != key:
-        _LAST_CHUNK["chunk"] = window_input_chunk(num_nodes, feat, epoch, window // cw, device, seed)
-        _LAST_CHUNK["key"] = key
-    return _LAST_CHUNK["chunk"][window % cw]
 
 
 def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, optimizer,
@@ -616,8 +597,14 @@ class CapturedStaticWindow:
     """
 
     def __init__(self, model, graph, edge_weight, targets, backprop_every: int, optimizer,
-                 bucket: GradBucket, feat_size: int, world: int = 1, rank: int = 0, group=None, warmup: int = 3):
+                 bucket: GradBucket, feat_size: int, world: int = 1, rank: int = 0, group=None, warmup: int = 3,
+                 allreduce_in_graph: bool = False):
+        """``allreduce_in_graph`` (N > 1, RCCL only; default off): capture the gradient all-reduce INTO the second graph
+        (all-reduce, / N, Adam, window index) instead of issuing it eagerly between the two replays -- one host operation
+        fewer per optimizer step.  Falls back to the eager all-reduce if the communicator refuses stream capture."""
         self.B = B = backprop_every
+        self.allreduce_in_graph = False
+        self._want_allreduce_in_graph = bool(allreduce_in_graph) and world > 1
         n = graph.get_num_nodes()
         dev = targets.device
         total = targets.shape[0]
@@ -625,19 +612,20 @@ class CapturedStaticWindow:
         self.bucket, self.world, self.rank, self.group, self.optimizer = bucket, world, rank, group, optimizer
         self.n, self.feat, self.dev = n, feat_size, dev
         self.num_windows = num_windows(total, B)
-        self.cw = chunk_windows(n, feat_size)
-        self.chunks = (self.num_windows + self.cw - 1) // self.cw
-        if self.chunks * self.cw * n * feat_size * 4 > (8 << 30):
-            raise ValueError("CapturedStaticWindow keeps an epoch's window inputs resident: more than 8 GiB here")
-        self.inputs = torch.zeros(self.chunks * self.cw, n, feat_size, device=dev)     # refilled in place every epoch
+        self.my_windows = list(range(rank, self.num_windows, world))                   # window w runs on rank w mod R
+        if len(self.my_windows) * n * feat_size * 4 > (8 << 30):
+            raise ValueError("CapturedStaticWindow keeps its rank's window inputs of an epoch resident: more than 8 GiB here")
+        # one resident slot per window of THIS rank (slot = w // world), refilled in place every epoch
+        self.inputs = torch.zeros(max(len(self.my_windows), 1), n, feat_size, device=dev)
         self.targets_w = targets[: self.full_windows * B].view(self.full_windows, B, *targets.shape[1:])
-        self.widx = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.widx = torch.zeros(1, dtype=torch.int64, device=dev)         # the window the next replay runs (global index)
+        self.slot = torch.zeros(1, dtype=torch.int64, device=dev)         # its input slot = widx // world
         self.costs = torch.zeros(max(self.num_windows, 1), device=dev)
         self._epoch = None
 
         def body():
             bucket.zero()
-            y0 = self.inputs.index_select(0, self.widx)[0]                            # captured gathers: no host copy
+            y0 = self.inputs.index_select(0, self.slot)[0]                            # captured gathers: no host copy
             tw = self.targets_w.index_select(0, self.widx)[0]
             cost = window_cost_of(model, graph, y0, edge_weight, tw)
             cost = cost / (B + 1)
@@ -670,11 +658,16 @@ class CapturedStaticWindow:
         opt, bucket, world = self.optimizer, self.bucket, self.world
         params = [p for g in opt.param_groups for p in g["params"]]
 
+        in_graph = [self._want_allreduce_in_graph]
+
         def tail():
             if world > 1:
+                if in_graph[0]:
+                    dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
                 bucket.flat.div_(world)
             opt.step()
             self.widx.add_(world)
+            self.slot.add_(1)
         saved_p = [p.detach().clone() for p in params]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -684,8 +677,18 @@ class CapturedStaticWindow:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            tail()
+        try:
+            with torch.cuda.graph(g):
+                tail()
+        except RuntimeError:
+            if not in_graph[0]:
+                raise
+            in_graph[0] = False                               # the communicator does not capture: keep the collective eager
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                tail()
+        self.allreduce_in_graph = in_graph[0]
         with torch.no_grad():
             for p, q in zip(params, saved_p):
                 p.copy_(q)
@@ -694,14 +697,16 @@ class CapturedStaticWindow:
                     if torch.is_tensor(v):
                         v.zero_()
             self.widx.zero_()
+            self.slot.zero_()
         bucket.zero()
         self.step_graph = g
 
     def begin_epoch(self, epoch: int, seed: int = 0) -> None:
-        """Draw the epoch's window inputs in place (one generator call) and point ``widx`` at this rank's first window."""
-        for c in range(self.chunks):
-            window_input_chunk(self.n, self.feat, epoch, c, self.dev, seed, out=self.inputs[c * self.cw:(c + 1) * self.cw])
+        """Draw THIS RANK's window inputs of the epoch in place and point ``widx`` / ``slot`` at its first window."""
+        for i, w in enumerate(self.my_windows):
+            window_input(self.n, self.feat, epoch, w, self.dev, seed, out=self.inputs[i])
         self.widx.fill_(self.rank)
+        self.slot.zero_()
         self._epoch = epoch
 
     def run(self, window: int, timed_comm: bool = False) -> torch.Tensor:
@@ -709,12 +714,14 @@ class CapturedStaticWindow:
         together), reduce, step.  Returns the slot of ``costs`` the window's cost is written to (a view: no copy)."""
         self.graph.replay()
         if self.step_graph is not None:
-            self.bucket.all_reduce_mean(self.world, self.group, timed_comm, divide=False)
+            if not self.allreduce_in_graph:
+                self.bucket.all_reduce_mean(self.world, self.group, timed_comm, divide=False)
             self.step_graph.replay()
         else:
             self.bucket.all_reduce_mean(self.world, self.group, timed_comm)
             self.optimizer.step()
             self.widx.add_(self.world)
+            self.slot.add_(1)
         return self.costs[window]
 
 
@@ -736,7 +743,7 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
             continue
         bucket.zero()
         if w is not None:
-            y_hat = cw.inputs[w]
+            y_hat = cw.inputs[w // world]
             cost = window_cost_of(model, graph, y_hat, edge_weight, targets[w * B:min((w + 1) * B, total)])
             cost = cost / (B + 1)
             cost.backward()
@@ -745,6 +752,7 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
         bucket.all_reduce_mean(world, group)
         optimizer.step()
         cw.widx.add_(world)
+        cw.slot.add_(1)
     out = cw.costs[slots].clone() if slots else cw.costs[:0].clone()
     for i, w in enumerate(slots):
         if w in eager:
@@ -782,6 +790,10 @@ class CapturedDynamicWindows:
             raise TypeError("CapturedDynamicWindows needs a dynamic graph that hands out device CSRs (NaiveGraph, PCSRGraph, GPMAGraph)")
         self._store = not isinstance(graph, NaiveGraph)
         self._end_state = {}
+        self._side = None
+        # rebuild mode: snapshot builds on parallel branches of the window's graph.  Off: measured 30.2 against 31.7 epochs/s
+        # at cfg5 (profiles/r03 notes in DESIGN.md) -- hipGraphLaunch did not overlap the branches' 5-launch chains
+        self.parallel_builds = False
         self.model, self.graph, self.edges, self.targets = model, graph, pos_neg_edges, pos_neg_targets
         self.total = len(pos_neg_edges)
         self.B = backprop_every or self.total
@@ -810,10 +822,36 @@ class CapturedDynamicWindows:
             and e[t].shape[1] > 0 and self.targets[t].dtype == torch.float32 and self.targets[t].is_contiguous()
             and self.targets[t].numel() == e[t].shape[1] for t in ts)
 
+    def _prebuild(self, w: int) -> None:
+        """Rebuild mode: the window's snapshot builds are independent of each other and of the model, and each is a
+        chain of five small launches that leaves most of the chip idle -- so they are issued round-robin on
+        ``kernels.BUILD_SLOTS`` side streams (parallel branches of the window's HIP graph, one counter buffer each) and
+        joined before the first step.  Bit-identical CSRs; ~ 4 builds in flight instead of 1."""
+        from . import kernels
+        g = self.graph
+        cur = torch.cuda.current_stream(self.dev)
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(kernels.BUILD_SLOTS)]
+        used = []
+        for i, t in enumerate(self.timestamps(w)):
+            if t in g._snapshots or g._built_by.get(t) != "direct":
+                continue
+            k = i % len(self._side)
+            st = self._side[k]
+            if st not in used:
+                st.wait_stream(cur)
+                used.append(st)
+            with torch.cuda.stream(st):
+                g._snapshot(t, counters_slot=k)
+        for st in used:
+            cur.wait_stream(st)
+
     def _body(self, w: int) -> torch.Tensor:
         from .nn import functional as SF
         g = self.graph
         self.bucket.zero()
+        if not self._store and not g._resident and self.parallel_builds:
+            self._prebuild(w)
         steps = []
         for t in self.timestamps(w):
             g.get_graph(t)

@@ -132,14 +132,10 @@ def test_static_training_loop_matches_the_reference_adam_run(cuda, mode, monkeyp
     bucket = temporal.GradBucket(model.parameters())
     base = int(d["train_x0_seed_base"])
 
-    def chunk(num_nodes, f, epoch, c, device, seed=0, out=None):          # the reference loop's torch.randn draws
-        cw = temporal.chunk_windows(num_nodes, f)
-        buf = out if out is not None else torch.zeros(cw, num_nodes, f, device=device)
-        for w in range(min(cw, T // B)):
-            buf[w].copy_(_x0(base + epoch * 2 + c * cw + w, num_nodes, f, device))
-        return buf
-    monkeypatch.setattr(temporal, "window_input_chunk", chunk)
-    temporal._LAST_CHUNK.clear()
+    def draw(num_nodes, f, epoch, w, device, seed=0, out=None):           # the reference loop's torch.randn draws
+        x = _x0(base + epoch * 2 + w, num_nodes, f, device)
+        return x if out is None else out.copy_(x)
+    monkeypatch.setattr(temporal, "window_input", draw)
     costs = []
     cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, feat) if captured else None
     assert cw is None or (cw.step_graph is not None) == (mode == "hip_graph_capturable_adam")
