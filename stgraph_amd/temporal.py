@@ -604,7 +604,8 @@ class CapturedStaticWindow:
         fewer per optimizer step.  Falls back to the eager all-reduce if the communicator refuses stream capture."""
         self.B = B = backprop_every
         self.allreduce_in_graph = False
-        self._want_allreduce_in_graph = bool(allreduce_in_graph) and world > 1
+        # (a one-rank RCCL group passed explicitly also takes the captured collective: how the single-GPU test drives it)
+        self._want_allreduce_in_graph = bool(allreduce_in_graph) and (world > 1 or group is not None)
         n = graph.get_num_nodes()
         dev = targets.device
         total = targets.shape[0]
@@ -661,9 +662,9 @@ class CapturedStaticWindow:
         in_graph = [self._want_allreduce_in_graph]
 
         def tail():
+            if in_graph[0]:
+                dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
             if world > 1:
-                if in_graph[0]:
-                    dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
                 bucket.flat.div_(world)
             opt.step()
             self.widx.add_(world)
