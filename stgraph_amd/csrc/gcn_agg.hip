@@ -251,6 +251,121 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_long_kernel(
         threshold);
 }
 
+// ---- long rows WIDER than half a wave (F >= 128; round 3) ------------------------------------------------------------------
+// gcn_agg_long_rows gives a long row ONE wave (rows up to 32 lanes wide).  At F = 128 the main kernel walks a row 4-8
+// edges per index round trip with one wave, so a hub of 10^5 in-edges is ~2 x 10^4 dependent round trips: tens of ms
+// behind a 1.1 ms launch.  Here a hub gets WORKGROUPS, and more than one: the order-preserving part of the work is one
+// dependent fp32 add per edge and FEATURE, so the features of a long row are cut into `fs` slices (1, 4 or 16 by row
+// length) and each slice is summed by its own workgroup:
+//   gather  all 256 threads fetch 16-byte pieces of the slice for a batch of up to 512 edges (one 32-byte sector per
+//           edge at 8 floats per slice; up to 8 pieces in flight per thread) and write the PRODUCTS nc * x (* w), formed
+//           exactly as in the main kernel, into an LDS tile [edge][slice width];
+//   sum     thread f of the slice adds its column of the tile in CSR order: one accumulator per (row, feature), the same
+//           sequence of fp32 additions as every other path -- bit-identical output; the next batch's gathers are in flight
+//           meanwhile.
+// Workgroups walk `rows_by_degree` (longest first) and stop at the first row of <= `threshold` edges.
+constexpr int kWideTileFloats = 8192;           // 32 KB
+constexpr int kWideMaxRounds = 8;
+
+template <bool HAS_EW, bool EPI>
+__global__ __launch_bounds__(kBlock) void gcn_agg_wide_long_kernel(
+    const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
+    const float *__restrict__ ew_edge, float *__restrict__ out, const int *__restrict__ row_offsets,
+    const int *__restrict__ column_indices, const int *__restrict__ rows_by_degree, int N, int F, int F_active,
+    const float *__restrict__ bias, int act, int threshold, int fs_max)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kWideTileFloats];
+    const int t = (int)threadIdx.x;
+    const int slots = (int)gridDim.x / fs_max, slot = (int)blockIdx.x / fs_max, slice = (int)blockIdx.x % fs_max;
+    const int PT = F_active >> 2;                                   // 16-byte pieces per row (F_active % 4 == 0: host)
+    for (int i = slot; i < N; i += slots) {
+        const int r = rows_by_degree[i];
+        const int beg = row_offsets[r];
+        const int deg = row_offsets[r + 1] - beg;                   // block-uniform
+        if (deg <= threshold) break;
+        int fs = deg >= 8192 ? 16 : (deg >= 2048 ? 4 : 1);
+        fs = min(fs, fs_max);
+        while (fs > 1 && PT / fs < 2) fs >>= 1;                     // a slice is at least one 32-byte sector wide
+        if (slice >= fs) continue;
+        const int pp = (PT + fs - 1) / fs;
+        const int p0 = slice * pp, P = min(pp, PT - p0);            // this slice: pieces [p0, p0 + P), P <= 64 (host)
+        if (P <= 0) continue;
+        const int Wc = 4 * P, f0 = 4 * p0;
+        const int ER = kBlock / P;                                  // edges per gather round
+        int rounds = min(kWideMaxRounds, min(512, kWideTileFloats / Wc) / ER);
+        if (rounds < 1) rounds = 1;
+        const int B = rounds * ER;                                  // edges per batch (B * Wc <= tile)
+        const int piece = t % P, e_in = t / P;
+        const bool gthread = t < ER * P;
+
+        // (Two batches of gathers in flight and a hand-pipelined add loop were tried: 5.3 ms against 3.7 ms for this simple
+        // form on tools/bench_powerlaw.py's graph -- the extra registers and branches cost more than the latency they hide.)
+        float4 v[kWideMaxRounds];
+        float nc[kWideMaxRounds], w[kWideMaxRounds];
+        auto prefetch = [&](int base) {
+#pragma unroll
+            for (int rr = 0; rr < kWideMaxRounds; ++rr) {
+                v[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+                nc[rr] = 0.f;
+                w[rr] = 1.f;
+                const int k = base + rr * ER + e_in;
+                if (rr < rounds && gthread && k < deg) {
+                    const int e = beg + k;
+                    const int c = column_indices[e];
+                    nc[rr] = nc_edge[e];
+                    if constexpr (HAS_EW) w[rr] = ew_edge[e];
+                    v[rr] = *reinterpret_cast<const float4 *>(x + (int64_t)c * F + f0 + 4 * piece);
+                }
+            }
+        };
+        float acc = 0.f;
+        prefetch(0);
+        for (int base = 0; base < deg; base += B) {
+            const int cnt = min(B, deg - base);
+#pragma unroll
+            for (int rr = 0; rr < kWideMaxRounds; ++rr) {
+                const int el = rr * ER + e_in;
+                if (rr < rounds && gthread && el < cnt) {
+                    float4 p;
+                    p.x = nc[rr] * v[rr].x;                          // Mul(norm_inb, h_inb)
+                    p.y = nc[rr] * v[rr].y;
+                    p.z = nc[rr] * v[rr].z;
+                    p.w = nc[rr] * v[rr].w;
+                    if constexpr (HAS_EW) {                          // Mul(., edge_weight)
+                        p.x = p.x * w[rr];
+                        p.y = p.y * w[rr];
+                        p.z = p.z * w[rr];
+                        p.w = p.w * w[rr];
+                    }
+                    *reinterpret_cast<float4 *>(tile + el * Wc + 4 * piece) = p;
+                }
+            }
+            __syncthreads();
+            if (base + B < deg) prefetch(base + B);                  // in flight during the sums
+            if (t < Wc) {
+                constexpr int kRead = 16;
+                for (int k = 0; k < cnt; k += kRead) {
+                    float tv[kRead];
+#pragma unroll
+                    for (int u = 0; u < kRead; ++u) tv[u] = tile[min(k + u, B - 1) * Wc + t];
+#pragma unroll
+                    for (int u = 0; u < kRead; ++u)
+                        if (k + u < cnt) acc = acc + tv[u];          // AggSum, CSR order
+                }
+            }
+            __syncthreads();
+        }
+        if (t < Wc) {
+            float o = acc * norm_row[r];                             // Mul(., norm_cen)
+            if constexpr (EPI) {
+                if (bias) o = o + bias[f0 + t];
+                if (act == STG_ACT_RELU) o = o < 0.f ? 0.f : o;
+            }
+            out[(int64_t)r * F + f0 + t] = o;
+        }
+    }
+}
+
 template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false, bool LONG = false,
           bool A32 = false>
 __global__ __launch_bounds__(kBlock) void gcn_agg_kernel(
@@ -958,6 +1073,23 @@ void launch(const GcnArgs &a)
             hipLaunchKernelGGL((gcn_agg_long_kernel<VEC, LOG2G, HAS_EW, EPI>), dim3((unsigned)std::min(long_blocks, 512)),
                                dim3(kBlock), 0, a.stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets,
                                a.column_indices, a.rows_by_degree, a.N, a.F, a.F_active, a.bias, a.act, threshold);
+            return;
+        }
+    }
+    if constexpr (PRE && LOG2G == 6) {
+        // rows of a whole wave and wider: hubs above 1024 edges go to feature-sliced workgroups (gcn_agg_wide_long_kernel)
+        if (a.rows_by_degree && tuning().gcn_wide_long != 1 && a.F_active % 4 == 0 && a.F % 4 == 0 && a.F_active <= 256 && a.N >= 1) {
+            const int forced = tuning().gcn_long_threshold;
+            const int threshold = forced > 0 ? forced : kGiantRowThreshold;
+            // (Forking the hubs' launch onto a side stream so that it runs BESIDE the main kernel was measured and dropped: its
+            // few latency-bound workgroups slow down under the main kernel's traffic -- 4.9 ms against 3.7 ms in sequence on
+            // the power-law graph of tools/bench_powerlaw.py -- and the fork / join costs a uniform graph 1 %.)
+            const int fs_max = 16;
+            const int slots = (int)std::max<int64_t>(1, std::min<int64_t>(a.N, 256));
+            main_kernel(std::false_type{}, blocks, a.rows_by_degree, 0, threshold);
+            hipLaunchKernelGGL((gcn_agg_wide_long_kernel<HAS_EW, EPI>), dim3((unsigned)(slots * fs_max)), dim3(kBlock), 0, a.stream,
+                               a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets, a.column_indices, a.rows_by_degree, a.N,
+                               a.F, a.F_active, a.bias, a.act, threshold, fs_max);
             return;
         }
     }

@@ -132,3 +132,49 @@ def test_hand_built_csr_keeps_every_row_on_the_row_group_path(cuda):
     x = torch.randn(n, 16, device=cuda)
     norm = torch.rand(n, 1, device=cuda) + 0.5
     assert torch.equal(kernels.gcn_agg(x, norm, norm, mine, use_node_ids=True), kernels.gcn_agg(x, norm, norm, f))
+
+
+def hub_graph(seed, n, hub_degrees, bulk_edges):
+    """Hubs of the given in-degrees (destinations 0, 1, ...) and the same hubs as sources, over a random low-degree bulk."""
+    rng = np.random.default_rng(seed)
+    src, dst = [], []
+    for h, deg in enumerate(hub_degrees):
+        others = rng.choice(np.arange(len(hub_degrees), n), size=deg, replace=False).astype(np.int64)
+        src += [others, np.full(deg, h, np.int64)]
+        dst += [np.full(deg, h, np.int64), others]
+    bs, bd = rng.integers(len(hub_degrees), n, bulk_edges), rng.integers(len(hub_degrees), n, bulk_edges)
+    keys = np.unique(np.concatenate([np.concatenate(src) * n + np.concatenate(dst), bs * n + bd]))
+    rng.shuffle(keys)
+    return (keys // n).astype(np.int32), (keys % n).astype(np.int32)
+
+
+@pytest.mark.parametrize("F,use_ew,epilogue", [(128, False, False), (128, True, False), (128, False, True), (256, True, False),
+                                               (64, False, False), (200, False, False)])
+def test_wide_hub_rows_bit_exact(cuda, F, use_ew, epilogue):
+    """Rows of a whole wave and wider (F >= 128) with hubs of 50 000 / 20 000 / 5 000 / 1 500 / 1 025 / 1 024 in-edges:
+    the feature-sliced long-row workgroups (gcn_agg_wide_long_kernel: 16 / 4 / 1 slices by row length) give the oracle's
+    sequential sums bit for bit, forward and backward CSR, with edge weights and with the layer epilogue; F = 64 (the
+    one-wave long-row path) and F = 200 (the main kernel: 200 / 4 pieces fit, 200 <= 256) ride along."""
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    n = 60_000
+    src, dst = hub_graph(F, n, [50_000, 20_000, 5_000, 1_500, 1_025, 1_024], 150_000)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    og = orc.build_graph(src, dst, n)
+    norm_np = gcn_norm(og.in_degrees())
+    norm = torch.from_numpy(norm_np).to(cuda)
+    rng = np.random.default_rng(2)
+    x_np = rng.standard_normal((n, F)).astype(np.float32)
+    w_np = (rng.random(len(src)) + 0.5).astype(np.float32)
+    b_np = rng.standard_normal(F).astype(np.float32)
+    x = torch.from_numpy(x_np).to(cuda)
+    w = torch.from_numpy(w_np).to(cuda) if use_ew else None
+    assert g.csr("fwd").degree_sorted and int(g.csr("fwd").node_ids[0]) == 0
+    for side, ocsr in (("fwd", og.fwd), ("bwd", og.bwd)):
+        want = orc.gcn_agg(x_np, norm_np, norm_np, ocsr, ew=w_np if use_ew else None, omp=True)
+        if epilogue:
+            want = np.maximum(want + b_np, np.float32(0))
+            got = kernels.gcn_agg(x, norm, norm, g.csr(side), ew=w, bias=torch.from_numpy(b_np).to(cuda), act=kernels.ACT_RELU)
+        else:
+            got = kernels.gcn_agg(x, norm, norm, g.csr(side), ew=w)
+        assert np.array_equal(got.cpu().numpy(), want), side
