@@ -329,11 +329,14 @@ __global__ __launch_bounds__(kBlock, MINW) void gemm_tn_wide_kernel(
     const int lda = form.lda, nsplit = form.nsplit;
     // contiguous: wave-uniform K slice [k0, k1) of kslice_wave rows.  cyclic: the block's range starts at kb, this wave's
     // first group at kb + 4 wave, groups 16 rows apart.
+    // cyclic == 2: ALL waves of a segment take its 4-row groups in turn (wave (sl, w): groups sl * 4 + w, + 4 S, ...), so the
+    // chip reads each operand of a segment as ONE moving window instead of 4 S private streams.
     const int64_t kb = (int64_t)sl * kWavesPerBlock * kslice_wave;
-    const int64_t k0 = cyclic ? kb + 4 * wave : kb + (int64_t)wave * kslice_wave;
-    const int64_t kend = cyclic ? min(K, kb + kWavesPerBlock * kslice_wave) : min(K, k0 + kslice_wave);
+    const int64_t k0 = cyclic == 2 ? (int64_t)(sl * kWavesPerBlock + wave) * 4
+                                   : (cyclic ? kb + 4 * wave : kb + (int64_t)wave * kslice_wave);
+    const int64_t kend = cyclic == 2 ? K : (cyclic ? min(K, kb + kWavesPerBlock * kslice_wave) : min(K, k0 + kslice_wave));
     const int64_t rows = kend > k0 ? kend - k0 : 0;      // rows from this wave's first row to the end of its range
-    const int gstride = cyclic ? 16 : 4;                 // rows between this wave's consecutive groups
+    const int gstride = cyclic == 2 ? 16 * s_per_seg : (cyclic ? 16 : 4);   // rows between this wave's consecutive groups
     // rows >= kend read as zero through the descriptors' range check (see the narrow kernel)
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + k0 * lda), 0,
                                                        rows > 0 ? (int)(((rows - 1) * lda + M) * (int64_t)sizeof(float)) : 0,
@@ -679,7 +682,9 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         // (cyclic: a wave's descriptor spans the whole block range, 4 x kslice_wave rows: only while that stays inside the
         // 32-bit addressing the plan sized for one slice)
         const int64_t max_ld_ = std::max(form.lda, std::max(form.ldb, form.ldb2));
-        const int cyclic = tuning().gemm_cyclic && 4 * p.kslice_wave * max_ld_ * 4 < (int64_t)INT32_MAX;
+        int cyclic = tuning().gemm_cyclic;
+        if (cyclic == 1 && 4 * p.kslice_wave * max_ld_ * 4 >= (int64_t)INT32_MAX) cyclic = 0;
+        if (cyclic == 2 && K * max_ld_ * 4 >= (int64_t)INT32_MAX) cyclic = 0;
 #define STG_WIDE_L(WA_, CA_, WB_, CB_, CS_, AM_)                                                                   \
     hipLaunchKernelGGL((gemm_tn_wide_kernel<WA_, CA_, WB_, CB_, CS_, AM_>), dim3((unsigned)blocks), dim3(kBlock), wlds, stream, segs, \
                        form, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S, cyclic)

@@ -123,7 +123,7 @@ extern "C" int stg_set_tuning(const char *key, int value)
         return 0;
     }
     if (!std::strcmp(key, "gemm_cyclic")) {
-        if (value != 0 && value != 1) return fail(STG_ERR_INVALID_ARGUMENT, "gemm_cyclic must be 0 or 1");
+        if (value < 0 || value > 2) return fail(STG_ERR_INVALID_ARGUMENT, "gemm_cyclic must be 0, 1 or 2");
         tuning().gemm_cyclic = value;
         return 0;
     }

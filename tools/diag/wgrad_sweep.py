@@ -18,9 +18,9 @@ def med(fn, iters=12):
 fn = lambda: kernels.gemm_tn_form(d, xs, C, 2 * C, B2s=H, nsplit=C, b_op=kernels.GEMM_B_CLAMP, lo=-1e6, hi=1e6, colsum=True)
 ref = None
 for rep in range(2):
-  for wide, cyc in ((1, 0), (0, 0), (0, 1)):
+  for wide, cyc in ((1, 0), (0, 0), (0, 1), (0, 2)):
     _C.set_tuning("gemm_wide", wide); _C.set_tuning("gemm_cyclic", cyc)
     out = fn()
     if ref is None: ref = out
     err = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(out, ref))
-    print("narrow" if wide else "wide", "cyclic" if cyc else "contig", "us", round(med(fn), 1), "relerr vs narrow", err, flush=True)
+    print("narrow" if wide else "wide", "cyclic%d" % cyc, "us", round(med(fn), 1), "relerr vs narrow", err, flush=True)
