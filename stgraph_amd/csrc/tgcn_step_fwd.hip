@@ -249,7 +249,12 @@ int launch_step_fwd(const FwdArgs &a, hipStream_t stream)
         *raised = true;
     }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (S::kLds + 512), 32 / WAVES));
-    const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)a.num_tiles + WAVES - 1) / WAVES, 256 * per_cu);
+    // Tiles are dealt wave-major over the grid (tile = wave * grid + block), so a grid of one workgroup per CU spreads FEWER
+    // tiles than wave slots over all CUs (|V| = 25 K: 6 tiles on each of 256 CUs instead of 12 on 131): the launch lasts as long
+    // as one SIMD's share of the matrix work.  `step_spread` = 1 restores the packed grid.
+    const int64_t packed = ((int64_t)a.num_tiles + WAVES - 1) / WAVES;
+    const int64_t spread = tuning().step_spread == 1 ? packed : std::min<int64_t>(a.num_tiles, 256 * per_cu);
+    const unsigned blocks = (unsigned)std::min<int64_t>(std::max(packed, spread), 256 * per_cu);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * kWave), S::kLds, stream, a);
     return check_launch("stg_tgcn_step_fwd");
 }

@@ -33,13 +33,16 @@ def main():
     ap.add_argument("--nodes", type=int, default=50_000)
     ap.add_argument("--edges", type=int, default=500_000)
     ap.add_argument("--waves", type=str, default="")
+    ap.add_argument("--packed-grid", action="store_true", help="step_spread = 1: fill CUs with 12 tiles each instead of one workgroup per CU")
     ap.add_argument("--nid", action="store_true", help="visit rows in degree order (node_ids), as the layers do on a StaticGraph")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     n, e = args.nodes, args.edges
+    from stgraph_amd import _C
     if args.waves:
-        from stgraph_amd import _C
         _C.set_tuning("step_waves", int(args.waves))
+    if args.packed_grid:
+        _C.set_tuning("step_spread", 1)
     src, dst = synthetic_graph(n, e, 3, dev)
     g = StaticGraph((src, dst), None, n, device=dev, sort_inplace=False)
     norm = degree_norm(g)
