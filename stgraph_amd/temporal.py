@@ -588,11 +588,12 @@ class CapturedStaticWindow:
 
     Eagerly the window issues thousands of small kernels and is bound by host launch overhead; the graph replays the
     identical kernel sequence from device-side descriptors.  What changes per window is READ BY THE GRAPH from device
-    memory: a window index ``widx`` selects the window's ``randn`` input out of the epoch's pre-drawn chunk and its
-    slice of ``targets`` (captured gathers), and the cost lands in slot ``widx`` of a per-epoch buffer.  Per optimizer
-    step the host therefore issues: one graph replay, the all-reduce of the gradient bucket (eager: it keeps the
-    N > 1 path free of stream-capture constraints on the communicator; skipped at one rank), and a second small
-    graph holding ``grad /= world``, the optimizer step and ``widx += world`` when the optimizer is capturable
+    memory: a window index ``widx`` selects the window's slice of ``targets`` and ``slot`` (= widx // world) its ``randn``
+    input among this rank's pre-drawn inputs of the epoch (captured gathers), and the cost lands in slot ``widx`` of a
+    per-epoch buffer.  Per optimizer step the host therefore issues: one graph replay, the all-reduce of the gradient
+    bucket (eager by default: it keeps the N > 1 path free of stream-capture constraints on the communicator; skipped at
+    one rank; ``allreduce_in_graph`` moves it into the second graph), and a second small graph holding ``grad /= world``,
+    the optimizer step, ``widx += world`` and ``slot += 1`` when the optimizer is capturable
     (``torch.optim.Adam(..., capturable=True)``); with another optimizer that tail runs eagerly as before.
     """
 
