@@ -110,8 +110,9 @@ DN, DE0, DCHURN, DT, DB, DM = 3000, 25000, 600, 11, 3, 1200
 
 
 def _dynamic_problem(dev, resident):
+    """``resident``: True / False = NaiveGraph with resident / rebuilt snapshots; "pcsr" / "gpma" = the delta stores."""
     from stgraph_amd import temporal
-    from stgraph_amd.graph import NaiveGraph
+    from stgraph_amd.graph import GPMAGraph, NaiveGraph, PCSRGraph
     rng = np.random.default_rng(11)
     stream = rng.choice(DN * DN, size=DE0 + DCHURN * DT, replace=False)
     snaps, pn_edges, pn_targets = [], [], []
@@ -124,7 +125,10 @@ def _dynamic_problem(dev, resident):
         neg = torch.randint(0, DN, (2, DM), device=dev, generator=gen)
         pn_edges.append(torch.cat([pos, neg], 1))
         pn_targets.append(torch.cat([torch.ones(DM, device=dev), torch.zeros(DM, device=dev)]))
-    G = NaiveGraph(snaps, DN, device=dev, sort_inplace=False, resident=resident, max_cached=DB + 1)
+    if resident in ("pcsr", "gpma"):
+        G = (PCSRGraph if resident == "pcsr" else GPMAGraph)(snaps, DN, device=dev)
+    else:
+        G = NaiveGraph(snaps, DN, device=dev, sort_inplace=False, resident=resident, max_cached=DB + 1)
     torch.manual_seed(SEED)
     model = temporal.DynamicSTGraphTGCN(FEAT, HID).to(dev)
     return G, pn_edges, pn_targets, model
@@ -190,7 +194,7 @@ def _dyn_single_process_equivalent(world, dev, resident):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("resident", [True, False])
+@pytest.mark.parametrize("resident", [True, False, "pcsr", "gpma"])
 def test_two_ranks_captured_dynamic_windows_equal_single_process(cuda, resident):
     world = 2
     with tempfile.TemporaryDirectory() as outdir:
