@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 9
+#define STG_ABI_VERSION 10
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -303,6 +303,19 @@ int stg_gcn_layer_fwd(const float *x, const float *norm_row, const float *norm_c
                       const int32_t *row_offsets, const int32_t *column_indices,
                       const int32_t *node_ids, const int32_t *rows_by_degree,
                       int32_t N, int64_t E, int32_t F, void *stream);
+
+/* stg_gcn_agg_edge and stg_gcn_layer_fwd in one signature (bias NULL + STG_ACT_NONE = the bare aggregation; with an epilogue
+ * F_active must equal F), plus the caller's HUB PLAN for rows of a whole wave and wider (F >= 128, F % 4 == 0, F <= 256): of
+ * the first rows of rows_by_degree, hub_rows_16 have >= 8192 edges, the next hub_rows_4 have 2048 .. 8191 and the next
+ * hub_rows_1 have hub_threshold + 1 .. 2047 (counted once per graph on the host).  Those rows are skipped by the main launch
+ * (every row above hub_threshold is) and summed by feature-sliced workgroups in CSR order -- bit-identical to the main path --
+ * in a second launch of exactly 16 hub_rows_16 + 4 hub_rows_4 + hub_rows_1 workgroups.  All three 0: one launch, no skip.
+ * The reference treats every row alike (compiler/execution_unit.py:92-100: one block per vertex). */
+int stg_gcn_agg_edge2(const float *x, const float *norm_row, const float *norm_col_edge, const float *ew_edge,
+                      const float *bias, int32_t act, float *out, const int32_t *row_offsets,
+                      const int32_t *column_indices, const int32_t *node_ids, const int32_t *rows_by_degree, int32_t N,
+                      int64_t E, int32_t F, int32_t F_active, int32_t hub_threshold, int32_t hub_rows_16, int32_t hub_rows_4,
+                      int32_t hub_rows_1, void *stream);
 
 /* y[n,f] = act(y[n,f] + bias[f]) in place (bias may be NULL; act = STG_ACT_NONE / STG_ACT_RELU): the `h + self.bias`,
  * `self.activation(h)` tail of GCNConv (reference nn/pytorch/static/gcn_conv.py:184-188) as one pass, for a layer

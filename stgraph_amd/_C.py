@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host", "stg_edgeset_merge_device", "stg_edgeset_step_device",
     "stg_edgeset_emit_csr_workspace_bytes", "stg_edgeset_emit_csr_device", "stg_edgeset_emit_csr_host",
     "stg_jit_compile", "stg_jit_free", "stg_jit_load", "stg_jit_get_function", "stg_jit_unload", "stg_jit_launch",
-    "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_layer_fwd", "stg_bias_act_fwd", "stg_bias_act_bwd_workspace_bytes", "stg_bias_act_bwd",
+    "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_layer_fwd", "stg_gcn_agg_edge2", "stg_bias_act_fwd", "stg_bias_act_bwd_workspace_bytes", "stg_bias_act_bwd",
     "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_score_flag", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gat_fc_supported", "stg_gat_fc_fwd", "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32", "stg_gemm_tn_relu_mask_f32",
@@ -138,6 +138,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_jit_launch.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, i32, vp, i32, vp]
     lib.stg_gcn_agg.restype = ctypes.c_int
     lib.stg_gcn_agg.argtypes = [vp] * 9 + [i32, i32, i32, vp]
+    lib.stg_gcn_agg_edge2.restype = ctypes.c_int
+    lib.stg_gcn_agg_edge2.argtypes = [vp] * 5 + [i32] + [vp] * 5 + [i32, i64, i32, i32, i32, i32, i32, i32, vp]
     lib.stg_gcn_agg_edge.restype = ctypes.c_int
     lib.stg_gcn_agg_edge.argtypes = [vp] * 9 + [i32, i64, i32, i32, vp]
     lib.stg_gcn_layer_fwd.restype = ctypes.c_int

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "stg_common.hpp"
+#include <cstdlib>
 
 namespace stg {
 
@@ -257,14 +258,17 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_long_kernel(
 // behind a 1.1 ms launch.  Here a hub gets WORKGROUPS, and more than one: the order-preserving part of the work is one
 // dependent fp32 add per edge and FEATURE, so the features of a long row are cut into `fs` slices (1, 4 or 16 by row
 // length) and each slice is summed by its own workgroup:
-//   gather  all 256 threads fetch 16-byte pieces of the slice for a batch of up to 512 edges (one 32-byte sector per
+//   gather  all 256 threads fetch 16-byte pieces of the slice for a batch of up to 1024 edges (one 32-byte sector per
 //           edge at 8 floats per slice; up to 8 pieces in flight per thread) and write the PRODUCTS nc * x (* w), formed
 //           exactly as in the main kernel, into an LDS tile [edge][slice width];
 //   sum     thread f of the slice adds its column of the tile in CSR order: one accumulator per (row, feature), the same
 //           sequence of fp32 additions as every other path -- bit-identical output; the next batch's gathers are in flight
 //           meanwhile.
-// Workgroups walk `rows_by_degree` (longest first) and stop at the first row of <= `threshold` edges.
-constexpr int kWideTileFloats = 8192;           // 32 KB
+// The host knows how many rows fall in each class (counted once per graph: the caller's plan), so the grid is exactly the
+// work items, longest rows first.  (Launching 1024 x 16 workgroups that find their work -- or none -- on the device cost the
+// hubs' launch 0.6 ms of dispatch and a uniform graph 19 us per aggregation.)
+constexpr int kWideTileFloats = 8192;           // products per batch (32 KB) ...
+constexpr int kWideTileAlloc = kWideTileFloats + 4 * 256;   // ... in rows of B + 4 floats (one per feature of the slice)
 constexpr int kWideMaxRounds = 8;
 
 template <bool HAS_EW, bool EPI>
@@ -272,19 +276,26 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_wide_long_kernel(
     const float *__restrict__ x, const float *__restrict__ norm_row, const float *__restrict__ nc_edge,
     const float *__restrict__ ew_edge, float *__restrict__ out, const int *__restrict__ row_offsets,
     const int *__restrict__ column_indices, const int *__restrict__ rows_by_degree, int N, int F, int F_active,
-    const float *__restrict__ bias, int act, int threshold, int fs_max)
+    const float *__restrict__ bias, int act, int n16, int n4, int n1)
 {
-    __shared__ __attribute__((aligned(16))) float tile[kWideTileFloats];
+    __shared__ __attribute__((aligned(16))) float tile[kWideTileAlloc];
     const int t = (int)threadIdx.x;
-    const int slots = (int)gridDim.x / fs_max, slot = (int)blockIdx.x / fs_max, slice = (int)blockIdx.x % fs_max;
     const int PT = F_active >> 2;                                   // 16-byte pieces per row (F_active % 4 == 0: host)
-    for (int i = slot; i < N; i += slots) {
+    // work items = (row, slice), longest rows first: rows_by_degree[0 .. n16) in 16 slices, the next n4 in 4, the next n1 whole
+    for (int item = (int)blockIdx.x; item < 16 * n16 + 4 * n4 + n1; item += (int)gridDim.x) {
+        int i, slice, fs;
+        if (item < 16 * n16) {
+            i = item >> 4, slice = item & 15, fs = 16;
+        } else if (item < 16 * n16 + 4 * n4) {
+            const int j = item - 16 * n16;
+            i = n16 + (j >> 2), slice = j & 3, fs = 4;
+        } else {
+            i = n16 + n4 + (item - 16 * n16 - 4 * n4), slice = 0, fs = 1;
+        }
         const int r = rows_by_degree[i];
         const int beg = row_offsets[r];
         const int deg = row_offsets[r + 1] - beg;                   // block-uniform
-        if (deg <= threshold) break;
-        int fs = deg >= 8192 ? 16 : (deg >= 2048 ? 4 : 1);
-        fs = min(fs, fs_max);
+        if (deg <= 0) continue;
         while (fs > 1 && PT / fs < 2) fs >>= 1;                     // a slice is at least one 32-byte sector wide
         if (slice >= fs) continue;
         const int pp = (PT + fs - 1) / fs;
@@ -292,9 +303,10 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_wide_long_kernel(
         if (P <= 0) continue;
         const int Wc = 4 * P, f0 = 4 * p0;
         const int ER = kBlock / P;                                  // edges per gather round
-        int rounds = min(kWideMaxRounds, min(512, kWideTileFloats / Wc) / ER);
+        int rounds = min(kWideMaxRounds, min(1024, kWideTileFloats / Wc) / ER);
         if (rounds < 1) rounds = 1;
-        const int B = rounds * ER;                                  // edges per batch (B * Wc <= tile)
+        const int B = rounds * ER;                                  // edges per batch (B * Wc <= kWideTileFloats)
+        const int LDB = B + 4;                                      // tile row (one feature): + 4 floats against bank conflicts
         const int piece = t % P, e_in = t / P;
         const bool gthread = t < ER * P;
 
@@ -302,24 +314,39 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_wide_long_kernel(
         // form on tools/bench_powerlaw.py's graph -- the extra registers and branches cost more than the latency they hide.)
         float4 v[kWideMaxRounds];
         float nc[kWideMaxRounds], w[kWideMaxRounds];
-        auto prefetch = [&](int base) {
+        // Index and row-piece loads are separate steps, no per-lane branches (slots past the row's end are clamped to its last
+        // edge and never staged): the indices of batch k + 2 and the row pieces of batch k + 1 are issued while batch k is summed,
+        // so neither of the two dependent round trips sits on the critical path.  (As one guarded block per round the compiler
+        // could not move a load across the guards: 2 x rounds DEPENDENT round trips per batch, 34 us per 64-edge batch at F = 128.)
+        int cn[kWideMaxRounds];
+        float ncn[kWideMaxRounds], wn[kWideMaxRounds];
+        auto load_idx = [&](int base) {
 #pragma unroll
             for (int rr = 0; rr < kWideMaxRounds; ++rr) {
-                v[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-                nc[rr] = 0.f;
-                w[rr] = 1.f;
-                const int k = base + rr * ER + e_in;
-                if (rr < rounds && gthread && k < deg) {
-                    const int e = beg + k;
-                    const int c = column_indices[e];
-                    nc[rr] = nc_edge[e];
-                    if constexpr (HAS_EW) w[rr] = ew_edge[e];
-                    v[rr] = *reinterpret_cast<const float4 *>(x + (int64_t)c * F + f0 + 4 * piece);
+                cn[rr] = 0;
+                ncn[rr] = 0.f;
+                wn[rr] = 1.f;
+                if (rr < rounds) {                                   // block-uniform
+                    const int e = beg + min(base + rr * ER + e_in, deg - 1);
+                    cn[rr] = column_indices[e];
+                    ncn[rr] = nc_edge[e];
+                    if constexpr (HAS_EW) wn[rr] = ew_edge[e];
                 }
             }
         };
+        auto load_x = [&]() {                                        // rows named by cn[]; takes over ncn / wn as the batch's
+#pragma unroll
+            for (int rr = 0; rr < kWideMaxRounds; ++rr) {
+                v[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+                nc[rr] = ncn[rr];
+                w[rr] = wn[rr];
+                if (rr < rounds) v[rr] = *reinterpret_cast<const float4 *>(x + (int64_t)cn[rr] * F + f0 + 4 * min(piece, P - 1));
+            }
+        };
         float acc = 0.f;
-        prefetch(0);
+        load_idx(0);
+        load_x();
+        if (B < deg) load_idx(B);
         for (int base = 0; base < deg; base += B) {
             const int cnt = min(B, deg - base);
 #pragma unroll
@@ -337,21 +364,41 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_wide_long_kernel(
                         p.z = p.z * w[rr];
                         p.w = p.w * w[rr];
                     }
-                    *reinterpret_cast<float4 *>(tile + el * Wc + 4 * piece) = p;
+                    // the tile is FEATURE-major, [slice feature][edge] with rows of B + 4 floats: the summing thread of a
+                    // feature then reads four consecutive edges per ds_read_b128 and spends ~1.25 instructions per edge (edge-major,
+                    // one ds_read_b32 + index arithmetic + a guard per edge, was ~10 instructions = 50 cycles per edge for the one
+                    // wave that sums: 2.2 ms for a row of 9.1e4 edges)
+                    float *dstp = tile + (4 * piece) * LDB + el;
+                    dstp[0] = p.x;
+                    dstp[LDB] = p.y;
+                    dstp[2 * LDB] = p.z;
+                    dstp[3 * LDB] = p.w;
                 }
             }
             __syncthreads();
-            if (base + B < deg) prefetch(base + B);                  // in flight during the sums
+            if (base + B < deg) {                                    // in flight during the sums
+                load_x();
+                if (base + 2 * B < deg) load_idx(base + 2 * B);
+            }
             if (t < Wc) {
-                constexpr int kRead = 16;
-                for (int k = 0; k < cnt; k += kRead) {
-                    float tv[kRead];
-#pragma unroll
-                    for (int u = 0; u < kRead; ++u) tv[u] = tile[min(k + u, B - 1) * Wc + t];
-#pragma unroll
-                    for (int u = 0; u < kRead; ++u)
-                        if (k + u < cnt) acc = acc + tv[u];          // AggSum, CSR order
+                const float *colp = tile + t * LDB;
+                int k = 0;
+                if (cnt >= 16) {
+                    // the next 16 edges' LDS reads are in flight while the current 16 are added (one dependent v_add per edge)
+                    float4 a0 = *reinterpret_cast<const float4 *>(colp), a1 = *reinterpret_cast<const float4 *>(colp + 4);
+                    float4 a2 = *reinterpret_cast<const float4 *>(colp + 8), a3 = *reinterpret_cast<const float4 *>(colp + 12);
+                    for (; k + 16 <= cnt; k += 16) {
+                        const int kn = min(k + 16, B - 12);          // (past the last full group: a valid address, values unused)
+                        const float4 b0 = *reinterpret_cast<const float4 *>(colp + kn), b1 = *reinterpret_cast<const float4 *>(colp + kn + 4);
+                        const float4 b2 = *reinterpret_cast<const float4 *>(colp + kn + 8), b3 = *reinterpret_cast<const float4 *>(colp + kn + 12);
+                        acc = acc + a0.x; acc = acc + a0.y; acc = acc + a0.z; acc = acc + a0.w;      // AggSum, CSR order
+                        acc = acc + a1.x; acc = acc + a1.y; acc = acc + a1.z; acc = acc + a1.w;
+                        acc = acc + a2.x; acc = acc + a2.y; acc = acc + a2.z; acc = acc + a2.w;
+                        acc = acc + a3.x; acc = acc + a3.y; acc = acc + a3.z; acc = acc + a3.w;
+                        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+                    }
                 }
+                for (; k < cnt; ++k) acc = acc + colp[k];
             }
             __syncthreads();
         }
@@ -948,6 +995,9 @@ struct GcnArgs {
     const float *bias = nullptr;   // layer epilogue: out = act(out + bias)
     int act = STG_ACT_NONE;
     const int *rows_by_degree = nullptr;   // rows by non-increasing degree: enables the long-row launch
+    // rows of a wave and wider (F >= 128): how many of the first rows of rows_by_degree have >= 8192 / 2048..8191 /
+    // hub_threshold + 1 .. 2047 edges (counted by the caller, once per graph); 0 rows: no hub launch
+    int hub_threshold = 0, hub_n16 = 0, hub_n4 = 0, hub_n1 = 0;
 };
 
 constexpr int kLongRowThreshold = 16;      // edges; rows above it go to gcn_agg_long_kernel (G < 64 only)
@@ -957,6 +1007,28 @@ constexpr int kXcdTile = 64;
 constexpr int kPlainBlock = 64;
 
 inline bool long_rows_enabled(const GcnArgs &a, int log2g) { return a.pre && a.rows_by_degree && log2g < 6; }
+
+// one helper stream + two events per device, created on first use (never destroyed: process lifetime)
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false, tried = false;
+};
+
+inline SideStream *side_stream()
+{
+    static SideStream per_device[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    SideStream &s = per_device[dev];
+    if (!s.tried) {
+        s.tried = true;
+        s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+    }
+    return s.ok ? &s : nullptr;
+}
 
 template <int VEC, int LOG2G, int CHUNKS, bool HAS_EW, bool PRE, int UNROLL, bool EPI = false>
 void launch(const GcnArgs &a)
@@ -1078,18 +1150,23 @@ void launch(const GcnArgs &a)
     }
     if constexpr (PRE && LOG2G == 6) {
         // rows of a whole wave and wider: hubs above 1024 edges go to feature-sliced workgroups (gcn_agg_wide_long_kernel)
-        if (a.rows_by_degree && tuning().gcn_wide_long != 1 && a.F_active % 4 == 0 && a.F % 4 == 0 && a.F_active <= 256 && a.N >= 1) {
-            const int forced = tuning().gcn_long_threshold;
-            const int threshold = forced > 0 ? forced : kGiantRowThreshold;
-            // (Forking the hubs' launch onto a side stream so that it runs BESIDE the main kernel was measured and dropped: its
-            // few latency-bound workgroups slow down under the main kernel's traffic -- 4.9 ms against 3.7 ms in sequence on
-            // the power-law graph of tools/bench_powerlaw.py -- and the fork / join costs a uniform graph 1 %.)
-            const int fs_max = 16;
-            const int slots = (int)std::max<int64_t>(1, std::min<int64_t>(a.N, 256));
-            main_kernel(std::false_type{}, blocks, a.rows_by_degree, 0, threshold);
-            hipLaunchKernelGGL((gcn_agg_wide_long_kernel<HAS_EW, EPI>), dim3((unsigned)(slots * fs_max)), dim3(kBlock), 0, a.stream,
-                               a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets, a.column_indices, a.rows_by_degree, a.N,
-                               a.F, a.F_active, a.bias, a.act, threshold, fs_max);
+        const int64_t items = 16 * (int64_t)a.hub_n16 + 4 * (int64_t)a.hub_n4 + a.hub_n1;
+        if (a.rows_by_degree && items > 0 && a.hub_threshold > 0 && tuning().gcn_wide_long != 1 && a.F_active % 4 == 0 &&
+            a.F % 4 == 0 && a.F_active <= 256) {
+            // The hubs' workgroups run BESIDE the main kernel when a helper stream is available: forked and joined through two
+            // events (a stream capture records them as graph edges).  Only graphs WITH hubs pay the fork.
+            SideStream *ss = tuning().gcn_wide_long == 2 ? nullptr : side_stream();
+            hipStream_t wide_stream = a.stream;
+            if (ss && hipEventRecord(ss->fork, a.stream) == hipSuccess && hipStreamWaitEvent(ss->stream, ss->fork, 0) == hipSuccess)
+                wide_stream = ss->stream;
+            hipLaunchKernelGGL((gcn_agg_wide_long_kernel<HAS_EW, EPI>), dim3((unsigned)std::min<int64_t>(items, 1 << 20)), dim3(kBlock), 0,
+                               wide_stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets, a.column_indices, a.rows_by_degree,
+                               a.N, a.F, a.F_active, a.bias, a.act, a.hub_n16, a.hub_n4, a.hub_n1);
+            main_kernel(std::false_type{}, blocks, a.rows_by_degree, 0, a.hub_threshold);
+            if (wide_stream != a.stream) {
+                (void)hipEventRecord(ss->join, ss->stream);
+                (void)hipStreamWaitEvent(a.stream, ss->join, 0);
+            }
             return;
         }
     }
@@ -1220,6 +1297,24 @@ extern "C" int stg_gcn_layer_fwd(const float *x, const float *norm_row, const fl
     a.bias = bias;
     a.act = act;
     return stg::gcn_agg_dispatch(a, "stg_gcn_layer_fwd");
+}
+
+extern "C" int stg_gcn_agg_edge2(const float *x, const float *norm_row, const float *norm_col_edge, const float *ew_edge,
+                                 const float *bias, int32_t act, float *out, const int32_t *row_offsets,
+                                 const int32_t *column_indices, const int32_t *node_ids, const int32_t *rows_by_degree,
+                                 int32_t N, int64_t E, int32_t F, int32_t F_active, int32_t hub_threshold, int32_t hub_rows_16,
+                                 int32_t hub_rows_4, int32_t hub_rows_1, void *stream)
+{
+    if (hub_threshold < 0 || hub_rows_16 < 0 || hub_rows_4 < 0 || hub_rows_1 < 0 ||
+        (int64_t)hub_rows_16 + hub_rows_4 + hub_rows_1 > N)
+        return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gcn_agg_edge2: bad hub plan");
+    stg::GcnArgs a{x, norm_row, norm_col_edge, ew_edge, out, row_offsets, column_indices, nullptr,
+                   node_ids, N, F, F_active, true, static_cast<hipStream_t>(stream), E};
+    a.rows_by_degree = rows_by_degree;
+    a.bias = bias;
+    a.act = act;
+    a.hub_threshold = hub_threshold; a.hub_n16 = hub_rows_16; a.hub_n4 = hub_rows_4; a.hub_n1 = hub_rows_1;
+    return stg::gcn_agg_dispatch(a, "stg_gcn_agg_edge2");
 }
 
 extern "C" int stg_edge_gather_f32(float *dst, const float *table, const int32_t *idx, int64_t n,

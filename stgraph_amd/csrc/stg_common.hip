@@ -113,7 +113,7 @@ extern "C" int stg_set_tuning(const char *key, int value)
         return 0;
     }
     if (!std::strcmp(key, "gcn_wide_long")) {
-        if (value != 0 && value != 1) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_wide_long must be 0 (auto) or 1 (never)");
+        if (value < 0 || value > 2) return fail(STG_ERR_INVALID_ARGUMENT, "gcn_wide_long must be 0 (auto), 1 (never) or 2 (behind the main launch, same stream)");
         tuning().gcn_wide_long = value;
         return 0;
     }

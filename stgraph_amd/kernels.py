@@ -655,6 +655,24 @@ def layer_epilogue_usable() -> bool:
     return _EDGE_CACHE and not reference_compat()
 
 
+HUB_THRESHOLD = 1024       # rows above it are "hubs" at F >= WIDE_ROW_MIN_F (stg_gcn_agg_edge2's hub plan)
+WIDE_ROW_MIN_F = 128       # the narrowest row the kernels map to a whole wave (narrower rows have their own long-row path)
+
+
+def _hub_plan(csr: "DeviceCSR"):
+    """(rows with >= 8192, 2048 .. 8191, HUB_THRESHOLD + 1 .. 2047 edges) of ``csr``, counted once per CSR object (one host
+    sync; (0, 0, 0) while a stream capture is running and the count is not known yet: the main launch then takes every row)."""
+    plan = csr.__dict__.get("_hub_plan")
+    if plan is None:
+        if torch.cuda.is_current_stream_capturing():
+            return (0, 0, 0)
+        deg = csr.row_offset[1:] - csr.row_offset[:-1]
+        counts = torch.stack([(deg >= 8192).sum(), ((deg >= 2048) & (deg < 8192)).sum(),
+                              ((deg > HUB_THRESHOLD) & (deg < 2048)).sum()]).tolist()
+        plan = csr.__dict__["_hub_plan"] = tuple(int(c) for c in counts)
+    return plan
+
+
 def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr: DeviceCSR,
             ew: torch.Tensor | None = None, use_node_ids: bool = False,
             f_active: int | None = None, bias: torch.Tensor | None = None, act: int = ACT_NONE) -> torch.Tensor:
@@ -693,16 +711,17 @@ def gcn_agg(x: torch.Tensor, norm_row: torch.Tensor, norm_col: torch.Tensor, csr
             nc_e = _edge_gathered(csr, "norm", norm_col, csr.column_indices)
             ew_e = None if ew is None else _edge_gathered(csr, "ew", ew, csr.eids)
         with _Timed("gcn_agg", gcn_agg_algorithmic_bytes(N, csr.num_edges, fa, ew is not None), csr.num_edges * fa):
-            if epilogue:
-                _C.check(_C.lib.stg_gcn_layer_fwd(
-                    _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(bias), int(act), _ptr(out),
-                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids_if_ready if (_LONG_ROWS and csr.degree_sorted) else None),
-                    N, csr.num_edges, F, _stream_ptr(dev)))
-            elif _EDGE_CACHE:
-                _C.check(_C.lib.stg_gcn_agg_edge(
-                    _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(out),
-                    _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(csr.node_ids_if_ready if (_LONG_ROWS and csr.degree_sorted) else None),
-                    N, csr.num_edges, F, fa, _stream_ptr(dev)))
+            if _EDGE_CACHE:
+                rbd = csr.node_ids_if_ready if (_LONG_ROWS and csr.degree_sorted) else None
+                plan = (0, 0, 0)
+                if rbd is not None and fa >= WIDE_ROW_MIN_F:
+                    # rows of a wave and wider: the hubs' workgroups are launched from a per-graph count of the long rows
+                    # (one sync per CSR object, never inside a capture); without it, or without hubs, one launch for all
+                    plan = _hub_plan(csr)
+                _C.check(_C.lib.stg_gcn_agg_edge2(
+                    _ptr(x), _ptr(norm_row), _ptr(nc_e), _ptr(ew_e), _ptr(bias) if epilogue else None, int(act) if epilogue else ACT_NONE,
+                    _ptr(out), _ptr(csr.row_offset), _ptr(csr.column_indices), nid, _ptr(rbd), N, csr.num_edges, F, fa,
+                    HUB_THRESHOLD, plan[0], plan[1], plan[2], _stream_ptr(dev)))
             else:
                 _C.check(_C.lib.stg_gcn_agg(
                     _ptr(x), _ptr(norm_row), _ptr(norm_col), _ptr(ew), _ptr(out),

@@ -178,3 +178,33 @@ def test_wide_hub_rows_bit_exact(cuda, F, use_ew, epilogue):
         else:
             got = kernels.gcn_agg(x, norm, norm, g.csr(side), ew=w)
         assert np.array_equal(got.cpu().numpy(), want), side
+
+
+def test_wide_hub_rows_replayed_from_a_hip_graph(cuda):
+    """The hubs' launch runs on a helper stream beside the main launch (fork / join through two events); captured in a HIP
+    graph those become graph edges: the replay gives the eager bits."""
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    n, F = 30_000, 128
+    src, dst = hub_graph(5, n, [20_000, 3_000, 1_100], 60_000)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    deg = np.bincount(dst, minlength=n)
+    norm = torch.from_numpy(gcn_norm(deg)).to(cuda)
+    x = torch.randn(n, F, device=cuda)
+    csr = g.csr("fwd")
+    eager = kernels.gcn_agg(x, norm, norm, csr)
+    assert kernels._hub_plan(csr) == (1, 1, 1)
+    side = torch.cuda.Stream(device=cuda)
+    side.wait_stream(torch.cuda.current_stream(cuda))
+    with torch.cuda.stream(side):
+        kernels.gcn_agg(x, norm, norm, csr)
+    torch.cuda.current_stream(cuda).wait_stream(side)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        out = kernels.gcn_agg(x, norm, norm, csr)
+    for _ in range(3):
+        out.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
