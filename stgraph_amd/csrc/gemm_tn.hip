@@ -276,7 +276,9 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
 // values are again 16 contiguous bytes of an output row.  3 load instructions per 32 MFMAs instead of 12 per 16, same MFMA
 // cycles (32 x 32 = 16 x 64), same exact-f32 k-ordered sums per K slice (a different, still fixed, split of K than the
 // narrow form's: results differ from it by fp32 rounding of the slice sums only).  W = 2 / 1 (dwordx2 / dword) serve
-// operands 32 / 16 columns wide.  D operand sets are in flight per wave (D - 1 sets ahead of the MFMAs).
+// operands 32 / 16 columns wide.  D = 4 operand sets are in flight per wave (D - 1 sets ahead of the MFMAs).  The ReLU-masked
+// form (a third operand stream) stays on the narrow kernel: here it spills 22 registers at D = 4 (390 us at cfg2's 1M x 128 x 128)
+// and starves at D = 3 (454 us) against 331 us there.
 template <int W>
 __device__ __forceinline__ void load_vec(float (&dst)[W], __amdgpu_buffer_rsrc_t rs, int voff, int soff)
 {
@@ -659,7 +661,7 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         if (form.a_mask && !AMs[t]) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL mask in segment %d", what, t);
     }
     WideShape wide = wide_shape(M, N, form.nsplit);
-    if (tuning().gemm_wide == 1 || form.lda % 4 != 0 || form.ldb % 4 != 0 || (form.nsplit < N && form.ldb2 % 4 != 0)) wide.wa = 0;
+    if (tuning().gemm_wide == 1 || form.a_mask || form.lda % 4 != 0 || form.ldb % 4 != 0 || (form.nsplit < N && form.ldb2 % 4 != 0)) wide.wa = 0;
     for (int t = 0; t < T && wide.wa; ++t) {                      // 16-byte lane loads: every operand base on a 16-byte boundary
         const uintptr_t bits = reinterpret_cast<uintptr_t>(segs.a[t]) | reinterpret_cast<uintptr_t>(segs.b[t]) |
                                reinterpret_cast<uintptr_t>(segs.b2[t]) | reinterpret_cast<uintptr_t>(segs.am[t]);
