@@ -127,6 +127,12 @@ def test_relu_mask_on_load(cuda, K, M, N):
     scale = float(want.abs().max()) + 1
     torch.testing.assert_close(c.double(), want, rtol=1e-5, atol=1e-6 * scale)
     torch.testing.assert_close(cs.double(), want_cs, rtol=1e-5, atol=1e-6 * (float(want_cs.abs().max()) + 1))
-    # identical to the two-launch form (same kernel arithmetic on the same operand values)
-    two, two_cs = kernels.gemm_tn((g * (out > 0)), x, colsum=True)
+    # identical to the two-launch form on the same kernel: the masked form runs on the dword-per-lane kernel, so the plain form is
+    # pinned to it here (its 16-byte-per-lane kernel splits K differently and agrees to fp32 rounding, as checked above)
+    from stgraph_amd import _C
+    _C.set_tuning("gemm_wide", 1)
+    try:
+        two, two_cs = kernels.gemm_tn((g * (out > 0)), x, colsum=True)
+    finally:
+        _C.set_tuning("gemm_wide", 0)
     assert torch.equal(c, two) and torch.equal(cs, two_cs)
