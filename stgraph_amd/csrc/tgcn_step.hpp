@@ -43,8 +43,13 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__device__ __forceinline__ float sigmoid_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+// v_rcp_f32 (1 ulp) instead of the correctly rounded reciprocal: `__frcp_rn` is a 10-instruction division sequence, 48 of them per
+// tile were 40 % of the forward launch's vector instructions, all issued beside the MFMAs (MI355X_MICROARCH.md: every vector
+// instruction of every wave shares the SIMD's issue port with them).  The gates move by at most one ulp (6e-8 relative).
+__device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+// clamp(x, lo, hi) of a finite x with lo <= hi as ONE instruction (v_med3_f32; fminf(fmaxf()) is three: a canonicalising max, max, min)
+__device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_quad(int v)
@@ -147,6 +152,49 @@ struct Stager {
         }
     }
 };
+
+// base (uniform: SGPR pair) + 32-bit BYTE offset (one VGPR) + immediate: the saddr form of global_load / global_store.  An
+// element index scaled by the compiler (`p + idx`) becomes a 64-bit multiply-add and a VGPR PAIR per array instead.
+__device__ __forceinline__ float4 ld_f4(const float *base, unsigned off_bytes, int imm_bytes)
+{
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + (size_t)off_bytes + imm_bytes);
+}
+__device__ __forceinline__ void st_f4(float *base, unsigned off_bytes, int imm_bytes, const float4 &v)
+{
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + (size_t)off_bytes + imm_bytes) = v;
+}
+__device__ __forceinline__ float ld_f1(const float *base, unsigned off_bytes)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)off_bytes);
+}
+__device__ __forceinline__ void st_f1(float *base, unsigned off_bytes, float v)
+{
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (size_t)off_bytes) = v;
+}
+
+// A per-lane LDS offset the compiler must keep as ONE register: left alone it folds the offset into a separate address
+// VGPR per matrix / gate / bias block (a dozen loop invariants), spills them under the gather and reloads each right before
+// its ds_read behind an s_waitcnt vmcnt(0).  Uses of `pinned(x) + constant` become ds_read immediates instead.
+__device__ __forceinline__ unsigned pinned(unsigned v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// Phase timestamps of every wave (tools/diag/step_trace.py builds a second library with -DSTG_STEP_TRACE; the product build has
+// none of this): slot [global wave][k] of a host-provided buffer gets the 100 MHz wall clock, slots 14 / 15 the shader clock.
+#ifdef STG_STEP_TRACE
+#define STG_TRACE_SLOTS 16
+__device__ unsigned long long *g_step_trace = nullptr;
+#define STG_TRACE_MARK(k)                                                                                                  \
+    do {                                                                                                                   \
+        if (g_step_trace && (threadIdx.x & 63) == 0)                                                                       \
+            g_step_trace[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * STG_TRACE_SLOTS + (k)] =           \
+                (k) >= 14 ? (unsigned long long)clock64() : (unsigned long long)wall_clock64();                            \
+    } while (0)
+#else
+#define STG_TRACE_MARK(k) ((void)0)
+#endif
 
 __device__ __forceinline__ f32x4 to_x4(const float4 &v) { return f32x4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ float4 to_f4(const f32x4 &v) { return make_float4(v[0], v[1], v[2], v[3]); }
@@ -270,9 +318,9 @@ __device__ __forceinline__ void gather_rows32(float (&out)[8], const float *__re
                     ws[u] = 1.f;
                     if constexpr (HAS_EW) ws[u] = quad_bcast_f(w[el], src);
                     if (kk < cnt) {
-                        const float *p = x + ((unsigned)ck * FIN + 8 * q);
-                        v[u][0] = *reinterpret_cast<const float4 *>(p);
-                        v[u][1] = *reinterpret_cast<const float4 *>(p + 4);
+                        const unsigned off = (unsigned)ck * (FIN * 4u) + 32u * q;
+                        v[u][0] = ld_f4(x, off, 0);
+                        v[u][1] = ld_f4(x, off, 16);
                     } else {
                         v[u][0] = v[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }

@@ -51,20 +51,24 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
     const StageSeg segs[5] = {{a.WzT, WgT, 2 * C, C, LDB}, {a.WrT, WgT + 2 * C * LDB, 2 * C, C, LDB},
                               {a.WhT, WgT + 4 * C * LDB, 2 * C, C, LDB}, {a.Wcat, Wc, want_z ? FIN : 0, 3 * C, LDX},
                               {a.W1T, W1T, HEAD ? C : 0, FH, LDT}};
+    STG_TRACE_MARK(0);
+    STG_TRACE_MARK(14);
     Stager<NT, 5, (kStage4 + NT - 1) / NT> stager;
     stager.issue(segs);
     const int total = gridDim.x * WAVES;
     int tile = wave * (int)gridDim.x + (int)blockIdx.x;
     const bool do_gather = GATHER && HEAD != 0 && a.zn != nullptr;      // block-uniform
-    // A_hat^T zn of a tile's rows (the next step's input gradient, aggregated here), as row pieces
+    // A_hat^T zn of a tile's rows (the next step's input gradient, aggregated here), as row pieces.  Lanes past the last row
+    // MIRROR row N - 1 (gather, loads, arithmetic, stores): they recompute and rewrite that row's values bit for bit, so no
+    // load or store of the tile body sits behind a per-lane guard -- a guarded store is a basic block of its own, and the
+    // loads of the next phase could not be scheduled above it (round 2's form exposed ~12 memory round trips per tile).
     auto gather_tile = [&](int t, float4 (&pp)[PH]) {
         const int q = lane & 3, grow = lane >> 2;
-        const int64_t gidx = (int64_t)t * 16 + grow;
-        const bool gok = gidx < a.N;
+        const int64_t gidx = std::min<int64_t>((int64_t)t * 16 + grow, a.N - 1);
         int gr = (int)gidx;
-        if (gok && a.node_ids) gr = a.node_ids[gidx];
+        if (a.node_ids) gr = a.node_ids[gidx];
         float p8[8];
-        gather_rows32<HAS_EW>(p8, a.zn, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, gok, q);
+        gather_rows32<HAS_EW>(p8, a.zn, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, true, q);
         gather_to_pieces(p8, pp, n16, kq);
     };
     stager.commit(segs);
@@ -72,39 +76,37 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         for (int i = threadIdx.x; i < FH; i += NT) bs[i] = a.W2[i];
     }
     __syncthreads();
+    STG_TRACE_MARK(1);
 
     const float lo = a.lo, hi = a.hi;
+    // this lane's row / piece inside each LDS matrix (tgcn_step.hpp: pinned)
+    const float *const wg_l = WgT + pinned((unsigned)(n16 * LDB + 4 * kq)), *const wcrow = Wc + pinned((unsigned)(n16 * LDX + 4 * kq));
+    const float *const w1_l = W1T + pinned((unsigned)(n16 * LDT + 4 * kq)), *const bs_l = bs + pinned((unsigned)(4 * kq));
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (; tile < a.num_tiles; tile += total) {
         // A_hat^T zn first: the gather loop is the register-hungry part of the kernel and nothing else is live yet
         float4 gp[PH];
 #pragma unroll
-        for (int j = 0; j < PH; ++j) gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < PH; ++j) gp[j] = zero4;
         if constexpr (GATHER && HEAD != 0) {
             if (do_gather) gather_tile(tile, gp);
         }
-        const int64_t idx = (int64_t)tile * 16 + n16;
-        const bool rok = idx < a.N;
-        // Lanes past the last row read row N - 1 (valid memory, finite values) and never store: loads need no per-lane
-        // guard, hence no branch and no 64-bit address pair each.  Element offsets are 32-bit (N 3C < 2^30, checked on
-        // the host): one VGPR per row stride next to scalar base pointers.
-        unsigned row = (unsigned)(rok ? idx : a.N - 1);
+        STG_TRACE_MARK(2);
+        // Element offsets are 32-bit (N 3C < 2^30, checked on the host): one VGPR per row stride next to scalar base pointers.
+        unsigned row = (unsigned)std::min<int64_t>((int64_t)tile * 16 + n16, a.N - 1);
         if (a.node_ids) row = (unsigned)a.node_ids[row];
-        auto ldrow = [&](const float *p, int ld, int col) {            // p must not be NULL
-            return *reinterpret_cast<const float4 *>(p + (row * (unsigned)ld + (unsigned)col));
-        };
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // byte offsets of this lane's first piece in a row of C, 3C and FH floats (one VGPR each; columns are immediates)
+        const unsigned oC = (row * C + 4u * kq) * 4u, o3 = (row * (3u * C) + 4u * kq) * 4u, oF = (row * FH + 4u * kq) * 4u;
+        auto ldC = [&](const float *p, int j) { return ld_f4(p, oC, 64 * j); };          // p must not be NULL
+        auto stC = [&](float *p, int j, const float4 &v) { st_f4(p, oC, 64 * j, v); };
 
-        // clamp mask of the 3C columns of x3 as 48 bits (read now, used by three later phases: 2 registers instead of
-        // 12 loads in the middle of the MFMA chains)
+        // clamp mask of the 3C columns of x3 as 48 bits (used by three later phases: 2 registers)
         unsigned mlo = 0u, mhi = 0u;
-        if (a.mask) {                                                // as the forward launch left it (wave-uniform branch)
-            // word 4 g + kq of the row: 16 bits for gate g; packed here as bit 16 g + 4 blk + i (gates 0, 1 in mlo, 2 in mhi)
-            const unsigned m0 = a.mask[row * 12u + kq], m1 = a.mask[row * 12u + 4 + kq], m2 = a.mask[row * 12u + 8 + kq];
-            mlo = (m0 & 0xffffu) | (m1 << 16), mhi = m2 & 0xffffu;
-        } else {
+        unsigned m0 = 0u, m1 = 0u, m2 = 0u;
+        if (!a.mask) {                                               // wave-uniform; the test-only form (no mask from the forward launch)
             float4 v[3 * PC];
 #pragma unroll
-            for (int c = 0; c < 3 * PC; ++c) v[c] = ldrow(a.x3, 3 * C, 16 * c + 4 * kq);
+            for (int c = 0; c < 3 * PC; ++c) v[c] = ld_f4(a.x3, o3, 64 * c);
 #pragma unroll
             for (int c = 0; c < 3 * PC; ++c) {
                 const unsigned b = (v[c].x >= lo && v[c].x <= hi ? 1u : 0u) | (v[c].y >= lo && v[c].y <= hi ? 2u : 0u) |
@@ -113,45 +115,64 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
                 else mhi |= b << ((4 * c) & 31);
             }
         }
-        // ---- gradient reaching Hn: from the next step (dHn) and through the head --------------------------------
-        float4 dhn[PC];
-#pragma unroll
-        for (int j = 0; j < PC; ++j) dhn[j] = zero4;
-        if (a.dHn) {                                                 // wave-uniform: one branch for the group of loads
-#pragma unroll
-            for (int j = 0; j < PC; ++j) dhn[j] = ldrow(a.dHn, C, 16 * j + 4 * kq);
+        // ---- every operand the tile reads before its first gate product, in flight at once (ONE round trip) -------------
+        float4 dhn[PC], gy[PH], hn[PC], hh[PC], zz[PC], tt[PC];
+        float yo = 0.f, tg = 0.f, gc = 0.f;
+        {
+            // word 4 g + kq of the row: 16 bits for gate g; packed below as bit 16 g + 4 blk + i (gates 0, 1 in mlo, 2 in mhi).
+            // Loaded without a branch (from Z's rows, discarded, when there is no mask) so that the unpacking stays below the batch.
+            const unsigned *mbase = a.mask ? a.mask : reinterpret_cast<const unsigned *>(a.Z);
+            const unsigned *mp = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(mbase) + (size_t)((row * 12u + kq) * 4u));
+            m0 = mp[0], m1 = mp[4], m2 = mp[8];
         }
-        if constexpr (HEAD != 0) {
-            float4 gy[PH];
 #pragma unroll
-            for (int j = 0; j < PH; ++j) gy[j] = zero4;
+        for (int j = 0; j < PC; ++j) dhn[j] = hh[j] = hn[j] = zero4;
+#pragma unroll
+        for (int j = 0; j < PH; ++j) gy[j] = zero4;
+        if constexpr (HEAD != 0) {
             if (a.gy) {
 #pragma unroll
-                for (int j = 0; j < PH; ++j) gy[j] = ldrow(a.gy, FH, 16 * j + 4 * kq);
+                for (int j = 0; j < PH; ++j) gy[j] = ld_f4(a.gy, oF, 64 * j);
             }
+            if constexpr (HEAD == 2) yo = ld_f1(a.y_out, row * 4u), tg = ld_f1(a.target, row * 4u), gc = a.g_cost[0];
+#pragma unroll
+            for (int j = 0; j < PC; ++j) hn[j] = ldC(a.Hn, j);
+        }
+        if (a.dHn) {                                                 // wave-uniform: one branch for the group of loads
+#pragma unroll
+            for (int j = 0; j < PC; ++j) dhn[j] = ldC(a.dHn, j);
+        }
+        if (a.H) {
+#pragma unroll
+            for (int j = 0; j < PC; ++j) hh[j] = ldC(a.H, j);
+        }
+#pragma unroll
+        for (int j = 0; j < PC; ++j) zz[j] = ldC(a.Z, j), tt[j] = ldC(a.Ht, j);
+        __builtin_amdgcn_sched_barrier(0);
+        if (a.mask) mlo = (m0 & 0xffffu) | (m1 << 16), mhi = m2 & 0xffffu;
+
+        // ---- gradient reaching Hn: from the next step (dHn) and through the head --------------------------------
+        if constexpr (HEAD != 0) {
 #pragma unroll
             for (int j = 0; j < PH; ++j) gy[j] = make_float4(gy[j].x + gp[j].x, gy[j].y + gp[j].y, gy[j].z + gp[j].z, gy[j].w + gp[j].w);
             if constexpr (HEAD == 2) {
-                float dyo = 0.f;
-                dyo = ((a.y_out[row] - a.target[row]) * a.two_over_n) * a.g_cost[0];
-                if (rok && kq == 0) a.dyo[row] = dyo;
+                const float dyo = ((yo - tg) * a.two_over_n) * gc;
+                if (kq == 0) st_f1(a.dyo, row * 4u, dyo);
 #pragma unroll
                 for (int j = 0; j < PH; ++j) {
-                    const float4 w2 = *reinterpret_cast<const float4 *>(bs + 16 * j + 4 * kq);
+                    const float4 w2 = *reinterpret_cast<const float4 *>(bs_l + 16 * j);
                     gy[j] = make_float4(gy[j].x + dyo * w2.x, gy[j].y + dyo * w2.y, gy[j].z + dyo * w2.z, gy[j].w + dyo * w2.w);
                 }
             }
-            if (rok) {
 #pragma unroll
-                for (int j = 0; j < PH; ++j) *reinterpret_cast<float4 *>(a.dyt + (row * FH + 16 * j + 4 * kq)) = gy[j];
-            }
+            for (int j = 0; j < PH; ++j) st_f4(a.dyt, oF, 64 * j, gy[j]);
             f32x4 acc[PC];
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_pieces<PC, PH, (WAVES <= 12)>(acc, W1T + n16 * LDT + 4 * kq, LDT, [&](int j) { return gy[j]; });
+            gemm_pieces<PC, PH, false>(acc, w1_l, LDT, [&](int j) { return gy[j]; });
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
-                const float4 h = ldrow(a.Hn, C, 16 * j + 4 * kq);
+                const float4 h = hn[j];
                 dhn[j].x = dhn[j].x + (h.x > 0.f ? acc[j][0] : 0.f);
                 dhn[j].y = dhn[j].y + (h.y > 0.f ? acc[j][1] : 0.f);
                 dhn[j].z = dhn[j].z + (h.z > 0.f ? acc[j][2] : 0.f);
@@ -159,40 +180,33 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
             }
         }
 
+        STG_TRACE_MARK(3);
         // ---- GRU update backward ---------------------------------------------------------------------------------
-        // (dzl is stored here and re-read by the same lane -- an L2 hit -- when its products come up, instead of
-        // living through the first two: 16 registers)
+        // (dzl is stored here and read back by the same lane -- an L2 hit, issued a whole product ahead of its use -- instead of
+        // living through the first two products, and H likewise: 32 registers)
         float4 dhl[PC], dHa[PC];
-        float4 hh[PC];
-#pragma unroll
-        for (int j = 0; j < PC; ++j) hh[j] = zero4;
-        if (a.H) {
-#pragma unroll
-            for (int j = 0; j < PC; ++j) hh[j] = ldrow(a.H, C, 16 * j + 4 * kq);
-        }
 #pragma unroll
         for (int j = 0; j < PC; ++j) {
-            float4 dzl[1];
-            const float4 g = dhn[j], z = ldrow(a.Z, C, 16 * j + 4 * kq), t = ldrow(a.Ht, C, 16 * j + 4 * kq);
-            const float4 h = hh[j];
+            const float4 g = dhn[j], z = zz[j], t = tt[j], h = hh[j];
             dhl[j] = make_float4((g.x * (1.0f - z.x)) * (1.0f - t.x * t.x), (g.y * (1.0f - z.y)) * (1.0f - t.y * t.y),
                                  (g.z * (1.0f - z.z)) * (1.0f - t.z * t.z), (g.w * (1.0f - z.w)) * (1.0f - t.w * t.w));
-            dzl[0] = make_float4((g.x * (h.x - t.x)) * (z.x * (1.0f - z.x)), (g.y * (h.y - t.y)) * (z.y * (1.0f - z.y)),
-                                 (g.z * (h.z - t.z)) * (z.z * (1.0f - z.z)), (g.w * (h.w - t.w)) * (z.w * (1.0f - z.w)));
+            const float4 dz = make_float4((g.x * (h.x - t.x)) * (z.x * (1.0f - z.x)), (g.y * (h.y - t.y)) * (z.y * (1.0f - z.y)),
+                                          (g.z * (h.z - t.z)) * (z.z * (1.0f - z.z)), (g.w * (h.w - t.w)) * (z.w * (1.0f - z.w)));
             dHa[j] = make_float4(g.x * z.x, g.y * z.y, g.z * z.z, g.w * z.w);
-            if (rok) {
-                *reinterpret_cast<float4 *>(a.dhl + (row * C + 16 * j + 4 * kq)) = dhl[j];
-                *reinterpret_cast<float4 *>(a.dzl + (row * C + 16 * j + 4 * kq)) = dzl[0];
-            }
+            stC(a.dhl, j, dhl[j]);
+            stC(a.dzl, j, dz);
         }
+        // R for the dHR stage: in flight under the first gate product
+        float4 rr[PC];
+#pragma unroll
+        for (int j = 0; j < PC; ++j) rr[j] = ldC(a.R, j);
 
         f32x4 zacc[PF];
 #pragma unroll
         for (int ft = 0; ft < PF; ++ft) zacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float *wcrow = Wc + n16 * LDX + 4 * kq;
         // out[blk] = (in (K = C) x W_g[:, half C + 16 blk ..]) as row pieces; W_g^T is [2C][LDB] in LDS
         auto gemm = [&](const float4 (&in)[PC], int g, int half, f32x4 (&acc)[PC]) {
-            const float *w = WgT + (g * 2 * C + half * C + n16) * LDB + 4 * kq;
+            const float *w = wg_l + (g * 2 * C + half * C) * LDB;
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             gemm_pieces<PC, PC, (WAVES <= 12)>(acc, w, LDB, [&](int j) { return in[j]; });
@@ -201,7 +215,6 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         auto emit_da3 = [&](int g, const f32x4 (&acc)[PC]) {
 #pragma unroll
             for (int blk = 0; blk < PC; ++blk) {
-                const int c = g * C + 16 * blk + 4 * kq;
                 const int bit = 4 * (g * PC + blk);
                 const unsigned m = (bit < 32 ? mlo : mhi) >> (bit & 31);
                 float4 o;
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
                 o.y = (m & 2u) ? acc[blk][1] : 0.f;
                 o.z = (m & 4u) ? acc[blk][2] : 0.f;
                 o.w = (m & 8u) ? acc[blk][3] : 0.f;
-                if (rok) *reinterpret_cast<float4 *>(a.da3 + (row * (3 * C) + c)) = o;
+                st_f4(a.da3, o3, 4 * (g * C + 16 * blk), o);
                 if (want_z) {
                     mfma_piece<PF>(zacc, wcrow, LDX, g * PC + blk, o);
                     __builtin_amdgcn_sched_barrier(0);
@@ -221,17 +234,16 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         // ---- dCH = dhl Wh: d(hh) -> da3[:, 2C..];  dHR -> drl, dH ---------------------------------------------------
         gemm(dhl, 2, 0, acc);
         emit_da3(2, acc);
-        float4 rr[PC], hb[PC];                                   // R and H for the dHR stage: in flight under the next product
+        STG_TRACE_MARK(4);
+        float4 hb[PC], dzl[PC];
 #pragma unroll
-        for (int j = 0; j < PC; ++j) rr[j] = ldrow(a.R, C, 16 * j + 4 * kq), hb[j] = zero4;
+        for (int j = 0; j < PC; ++j) hb[j] = zero4, dzl[j] = ldC(a.dzl, j);      // this lane's own stores, above
         if (a.H) {
 #pragma unroll
-            for (int j = 0; j < PC; ++j) hb[j] = ldrow(a.H, C, 16 * j + 4 * kq);
+            for (int j = 0; j < PC; ++j) hb[j] = ldC(a.H, j);
         }
         gemm(dhl, 2, 1, acc);
-        float4 drl[PC], dzl[PC];
-#pragma unroll
-        for (int j = 0; j < PC; ++j) dzl[j] = ldrow(a.dzl, C, 16 * j + 4 * kq);      // this lane's own stores, above
+        float4 drl[PC];
 #pragma unroll
         for (int blk = 0; blk < PC; ++blk) {
             const float4 r = rr[blk], h = hb[blk];
@@ -240,9 +252,10 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
                                    (d.z * h.z) * (r.z * (1.0f - r.z)), (d.w * h.w) * (r.w * (1.0f - r.w)));
             dHa[blk] = make_float4(dHa[blk].x + d.x * r.x, dHa[blk].y + d.y * r.y, dHa[blk].z + d.z * r.z,
                                    dHa[blk].w + d.w * r.w);
-            if (rok) *reinterpret_cast<float4 *>(a.drl + (row * C + 16 * blk + 4 * kq)) = drl[blk];
+            stC(a.drl, blk, drl[blk]);
         }
         // ---- dCZ = dzl Wz,  dCR = drl Wr: d(hz), d(hr) -> da3;  second halves -> dH (dCZ's first, then dCR's) -------
+        STG_TRACE_MARK(5);
         gemm(dzl, 0, 0, acc);
         emit_da3(0, acc);
         gemm(dzl, 0, 1, acc);
@@ -250,20 +263,20 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         for (int blk = 0; blk < PC; ++blk)
             dHa[blk] = make_float4(dHa[blk].x + acc[blk][0], dHa[blk].y + acc[blk][1], dHa[blk].z + acc[blk][2],
                                    dHa[blk].w + acc[blk][3]);
+        STG_TRACE_MARK(6);
         gemm(drl, 1, 0, acc);
         emit_da3(1, acc);
         gemm(drl, 1, 1, acc);
-        if (rok) {
 #pragma unroll
-            for (int blk = 0; blk < PC; ++blk)
-                *reinterpret_cast<float4 *>(a.dH + (row * C + 16 * blk + 4 * kq)) =
-                    make_float4(dHa[blk].x + acc[blk][0], dHa[blk].y + acc[blk][1], dHa[blk].z + acc[blk][2],
-                                dHa[blk].w + acc[blk][3]);
-            if (want_z) {
+        for (int blk = 0; blk < PC; ++blk)
+            stC(a.dH, blk, make_float4(dHa[blk].x + acc[blk][0], dHa[blk].y + acc[blk][1], dHa[blk].z + acc[blk][2],
+                                       dHa[blk].w + acc[blk][3]));
+        if (want_z) {
 #pragma unroll
-                for (int ft = 0; ft < PF; ++ft) *reinterpret_cast<float4 *>(a.z + (row * FIN + 16 * ft + 4 * kq)) = to_f4(zacc[ft]);
-            }
+            for (int ft = 0; ft < PF; ++ft) st_f4(a.z, oF, 64 * ft, to_f4(zacc[ft]));
         }
+        STG_TRACE_MARK(7);
+        STG_TRACE_MARK(15);
     }
 }
 
@@ -294,6 +307,13 @@ int launch_step_bwd(const BwdArgs &a, hipStream_t stream)
 
 }  // namespace
 }  // namespace stg
+
+#ifdef STG_STEP_TRACE
+extern "C" int stg_debug_set_step_trace_bwd(void *buf)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(stg::g_step_trace), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
 {

@@ -49,24 +49,25 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     constexpr int kStage4 = (3 * C * 2 * C + (GATHER ? 3 * C * FIN : 0) + (HEAD ? FH * C : 0)) / 4;
     const StageSeg segs[5] = {{a.Wz, Wg, C, 2 * C, LDW}, {a.Wr, Wg + C * LDW, C, 2 * C, LDW}, {a.Wh, Wg + 2 * C * LDW, C, 2 * C, LDW},
                               {a.WcatT, WcT, GATHER ? 3 * C : 0, FIN, LDC}, {a.W1, W1s, HEAD ? FH : 0, C, LD1}};
+    STG_TRACE_MARK(0);
+    STG_TRACE_MARK(14);
     Stager<NT, 5, (kStage4 + NT - 1) / NT> stager;
     stager.issue(segs);
     const int total = gridDim.x * WAVES;
     int tile = wave * (int)gridDim.x + (int)blockIdx.x;
-    // P = A_hat x of a tile, handed from the gather layout to row pieces on the LDS crossbar (no LDS memory)
+    // P = A_hat x of a tile, handed from the gather layout to row pieces on the LDS crossbar (no LDS memory).  Lanes past the
+    // last row MIRROR row N - 1 (they recompute and rewrite its values bit for bit): no load or store of the tile body sits
+    // behind a per-lane guard, so the scheduler sees straight-line code between the products (tgcn_step_bwd.hip).
     auto gather_tile = [&](int t, float4 (&pp)[PF]) {
         const int q = lane & 3, grow = lane >> 2;
-        const int64_t gidx = (int64_t)t * 16 + grow;
-        const bool gok = gidx < a.N;
+        const int64_t gidx = std::min<int64_t>((int64_t)t * 16 + grow, a.N - 1);
         int gr = (int)gidx;
-        if (gok && a.node_ids) gr = a.node_ids[gidx];
+        if (a.node_ids) gr = a.node_ids[gidx];
         float p8[8];
-        gather_rows32<HAS_EW>(p8, a.x, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, gok, q);
-        const float4 lo4 = make_float4(p8[0], p8[1], p8[2], p8[3]), hi4 = make_float4(p8[4], p8[5], p8[6], p8[7]);
-        if (gok) {
-            *reinterpret_cast<float4 *>(a.P + ((unsigned)gr * FIN + 8 * q)) = lo4;
-            *reinterpret_cast<float4 *>(a.P + ((unsigned)gr * FIN + 8 * q + 4)) = hi4;
-        }
+        gather_rows32<HAS_EW>(p8, a.x, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, true, q);
+        const unsigned off = (unsigned)gr * (FIN * 4u) + 32u * q;
+        st_f4(a.P, off, 0, make_float4(p8[0], p8[1], p8[2], p8[3]));
+        st_f4(a.P, off, 16, make_float4(p8[4], p8[5], p8[6], p8[7]));
         gather_to_pieces(p8, pp, n16, kq);
     };
     stager.commit(segs);
@@ -86,20 +87,33 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
         }
     }
     __syncthreads();
+    STG_TRACE_MARK(1);
 
     const float lo = a.lo, hi = a.hi;
+    // this lane's row / piece inside each LDS matrix (tgcn_step.hpp: pinned)
+    const float *const wg_l = Wg + pinned((unsigned)(n16 * LDW + 4 * kq)), *const wc_l = WcT + pinned((unsigned)(n16 * LDC + 4 * kq));
+    const float *const w1_l = W1s + pinned((unsigned)(n16 * LD1 + 4 * kq)), *const bs_l = bs + pinned((unsigned)(4 * kq));
     for (; tile < a.num_tiles; tile += total) {
         float4 p[PF];
 #pragma unroll
         for (int j = 0; j < PF; ++j) p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (GATHER) gather_tile(tile, p);
+        STG_TRACE_MARK(2);
         const int64_t idx = (int64_t)tile * 16 + n16;
-        const bool rok = idx < a.N;
-        // Lanes past the last row read row N - 1 (valid memory, finite values) and never store: loads need no per-lane
-        // guard, hence no branch and no 64-bit address pair each.  Element offsets are 32-bit (N 3C < 2^30, checked on
-        // the host): one VGPR per row stride next to scalar base pointers.
-        unsigned row = (unsigned)(rok ? idx : a.N - 1);
+        const bool rok = idx < a.N;                               // only the loss partial looks at it
+        // Element offsets are 32-bit (N 3C < 2^30, checked on the host); byte offsets of this lane's first piece in a row of
+        // C, 3C and FH floats: one VGPR each next to scalar base pointers, the column is an immediate.
+        unsigned row = (unsigned)std::min<int64_t>(idx, a.N - 1);
         if (a.node_ids) row = (unsigned)a.node_ids[row];
+        const unsigned oC = (row * C + 4u * kq) * 4u, o3 = (row * (3u * C) + 4u * kq) * 4u, oF = (row * FH + 4u * kq) * 4u;
+        float4 hh[PC];
+        float tg = 0.f;
+#pragma unroll
+        for (int j = 0; j < PC; ++j) {
+            hh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.H) hh[j] = ld_f4(a.H, oC, 64 * j);
+        }
+        if constexpr (HEAD == 2) tg = ld_f1(a.target, row * 4u);
         // hg = clamp(x3[:, g C ..]) with x3 = P Wcat + b3 (or a3 + b3), one gate at a time (16 live registers instead
         // of 48); x3 itself (before the clamp) is what the backward pass and the weight gradients read
         auto gate_input = [&](int g, float4 (&hg)[PC]) {
@@ -107,47 +121,36 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
                 f32x4 acc[PC];
 #pragma unroll
                 for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_pieces<PC, PF, (WAVES <= 12)>(acc, WcT + (g * C + n16) * LDC + 4 * kq, LDC, [&](int j) { return p[j]; });
+                gemm_pieces<PC, PF, (WAVES <= 12)>(acc, wc_l + g * C * LDC, LDC, [&](int j) { return p[j]; });
 #pragma unroll
                 for (int ct = 0; ct < PC; ++ct) {
-                    const float4 b = *reinterpret_cast<const float4 *>(bs + g * C + 16 * ct + 4 * kq);
+                    const float4 b = *reinterpret_cast<const float4 *>(bs_l + g * C + 16 * ct);
                     hg[ct] = make_float4(acc[ct][0] + b.x, acc[ct][1] + b.y, acc[ct][2] + b.z, acc[ct][3] + b.w);
                 }
             } else {
 #pragma unroll
                 for (int ct = 0; ct < PC; ++ct) {
-                    const float4 v = *reinterpret_cast<const float4 *>(a.a3 + (row * (3 * C) + g * C + 16 * ct + 4 * kq));
-                    const float4 b = *reinterpret_cast<const float4 *>(bs + g * C + 16 * ct + 4 * kq);
+                    const float4 v = ld_f4(a.a3, o3, 4 * (g * C + 16 * ct));
+                    const float4 b = *reinterpret_cast<const float4 *>(bs_l + g * C + 16 * ct);
                     hg[ct] = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
                 }
             }
             unsigned gm = 0u;             // clamp mask of this gate's columns: bit 4 ct + i <-> column 16 ct + 4 kq + i
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) {
-                if (rok) *reinterpret_cast<float4 *>(a.x3 + (row * (3 * C) + g * C + 16 * ct + 4 * kq)) = hg[ct];
-                {
-                    const float4 v = hg[ct];
-                    gm |= ((v.x >= lo && v.x <= hi ? 1u : 0u) | (v.y >= lo && v.y <= hi ? 2u : 0u) |
-                           (v.z >= lo && v.z <= hi ? 4u : 0u) | (v.w >= lo && v.w <= hi ? 8u : 0u)) << (4 * ct);
-                }
-                hg[ct].x = fminf(fmaxf(hg[ct].x, lo), hi);
-                hg[ct].y = fminf(fmaxf(hg[ct].y, lo), hi);
-                hg[ct].z = fminf(fmaxf(hg[ct].z, lo), hi);
-                hg[ct].w = fminf(fmaxf(hg[ct].w, lo), hi);
+                st_f4(a.x3, o3, 4 * (g * C + 16 * ct), hg[ct]);
+                const float4 v = hg[ct];
+                hg[ct] = make_float4(clamp3(v.x, lo, hi), clamp3(v.y, lo, hi), clamp3(v.z, lo, hi), clamp3(v.w, lo, hi));
+                // inside [lo, hi]  <=>  the clamp left the value alone
+                gm |= ((hg[ct].x == v.x ? 1u : 0u) | (hg[ct].y == v.y ? 2u : 0u) | (hg[ct].z == v.z ? 4u : 0u) | (hg[ct].w == v.w ? 8u : 0u)) << (4 * ct);
             }
-            if (a.mask && rok) a.mask[row * 12u + 4 * g + kq] = gm;
+            if (a.mask) a.mask[row * 12u + 4 * g + kq] = gm;
         };
-        float4 hh[PC];
-#pragma unroll
-        for (int j = 0; j < PC; ++j) {
-            hh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.H) hh[j] = *reinterpret_cast<const float4 *>(a.H + (row * C + 16 * j + 4 * kq));
-        }
         // acc = bias + [hg | second] W_g^T   (W_g [C][2C] in LDS, torch Linear layout)
         auto gate = [&](int g, const float4 (&hg)[PC], const float4 (&second)[PC], f32x4 (&acc)[PC]) {
 #pragma unroll
-            for (int ct = 0; ct < PC; ++ct) acc[ct] = to_x4(*reinterpret_cast<const float4 *>(bs + (3 + g) * C + 16 * ct + 4 * kq));
-            gemm_pieces<PC, 2 * PC, (WAVES <= 12)>(acc, Wg + (g * C + n16) * LDW + 4 * kq, LDW,
+            for (int ct = 0; ct < PC; ++ct) acc[ct] = to_x4(*reinterpret_cast<const float4 *>(bs_l + (3 + g) * C + 16 * ct));
+            gemm_pieces<PC, 2 * PC, (WAVES <= 12)>(acc, wg_l + g * C * LDW, LDW,
                                     [&](int j) { return j < PC ? hg[j % PC] : second[j % PC]; });
         };
 
@@ -161,21 +164,21 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
                 zz[j] = make_float4(sigmoid_(acc[j][0]), sigmoid_(acc[j][1]), sigmoid_(acc[j][2]), sigmoid_(acc[j][3]));
-                if (rok) *reinterpret_cast<float4 *>(a.Z + (row * C + 16 * j + 4 * kq)) = zz[j];
+                st_f4(a.Z, oC, 64 * j, zz[j]);
             }
+            STG_TRACE_MARK(3);
             gate_input(1, hg);
             gate(1, hg, hh, acc);
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
                 const float4 r = make_float4(sigmoid_(acc[j][0]), sigmoid_(acc[j][1]), sigmoid_(acc[j][2]), sigmoid_(acc[j][3]));
                 hr[j] = make_float4(hh[j].x * r.x, hh[j].y * r.y, hh[j].z * r.z, hh[j].w * r.w);
-                if (rok) {
-                    *reinterpret_cast<float4 *>(a.R + (row * C + 16 * j + 4 * kq)) = r;
-                    *reinterpret_cast<float4 *>(a.HR + (row * C + 16 * j + 4 * kq)) = hr[j];
-                }
+                st_f4(a.R, oC, 64 * j, r);
+                st_f4(a.HR, oC, 64 * j, hr[j]);
             }
         }
 
+        STG_TRACE_MARK(4);
         // ---- Ht = tanh([hh | H*R] Wh^T + bh);  Hn = Z*H + (1 - Z)*Ht ----------------------------------------------
         float4 hn[PC];
         {
@@ -189,31 +192,28 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
                 const float4 z = zz[j], h = hh[j];
                 hn[j] = make_float4(z.x * h.x + (1.0f - z.x) * t.x, z.y * h.y + (1.0f - z.y) * t.y,
                                     z.z * h.z + (1.0f - z.z) * t.z, z.w * h.w + (1.0f - z.w) * t.w);
-                if (rok) {
-                    *reinterpret_cast<float4 *>(a.Ht + (row * C + 16 * j + 4 * kq)) = t;
-                    *reinterpret_cast<float4 *>(a.Hn + (row * C + 16 * j + 4 * kq)) = hn[j];
-                }
+                st_f4(a.Ht, oC, 64 * j, t);
+                st_f4(a.Hn, oC, 64 * j, hn[j]);
             }
         }
 
+        STG_TRACE_MARK(5);
         // ---- head: y = relu(Hn) W1^T + b1;  y_out = y W2^T + b2;  partial[tile] = sum (y_out - target)^2 ------------
         if constexpr (HEAD != 0) {
             f32x4 accy[PH];
 #pragma unroll
-            for (int ft = 0; ft < PH; ++ft) accy[ft] = to_x4(*reinterpret_cast<const float4 *>(bs + 6 * C + 16 * ft + 4 * kq));
-            gemm_pieces<PH, PC, (WAVES <= 12)>(accy, W1s + n16 * LD1 + 4 * kq, LD1, [&](int j) {
+            for (int ft = 0; ft < PH; ++ft) accy[ft] = to_x4(*reinterpret_cast<const float4 *>(bs_l + 6 * C + 16 * ft));
+            gemm_pieces<PH, PC, (WAVES <= 12)>(accy, w1_l, LD1, [&](int j) {
                 return make_float4(hn[j].x < 0.f ? 0.f : hn[j].x, hn[j].y < 0.f ? 0.f : hn[j].y,
                                    hn[j].z < 0.f ? 0.f : hn[j].z, hn[j].w < 0.f ? 0.f : hn[j].w);
             });
-            if (rok) {
 #pragma unroll
-                for (int ft = 0; ft < PH; ++ft) *reinterpret_cast<float4 *>(a.y + (row * FH + 16 * ft + 4 * kq)) = to_f4(accy[ft]);
-            }
+            for (int ft = 0; ft < PH; ++ft) st_f4(a.y, oF, 64 * ft, to_f4(accy[ft]));
             if constexpr (HEAD == 2) {
                 float s = 0.f;
 #pragma unroll
                 for (int ft = 0; ft < PH; ++ft) {
-                    const float4 w2 = *reinterpret_cast<const float4 *>(bs + 6 * C + FH + 16 * ft + 4 * kq);
+                    const float4 w2 = *reinterpret_cast<const float4 *>(bs_l + 6 * C + FH + 16 * ft);
                     s = s + accy[ft][0] * w2.x;
                     s = s + accy[ft][1] * w2.y;
                     s = s + accy[ft][2] * w2.z;
@@ -222,16 +222,15 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
                 s = s + __shfl_xor(s, 16, kWave);                   // the row's four kq lanes
                 s = s + __shfl_xor(s, 32, kWave);
                 const float yo = s + bs[6 * C + 2 * FH];
-                float sq = 0.f;
-                if (rok && kq == 0) {
-                    a.y_out[row] = yo;
-                    const float d = yo - a.target[row];
-                    sq = d * d;
-                }
+                if (kq == 0) st_f1(a.y_out, row * 4u, yo);
+                const float d = yo - tg;
+                float sq = (rok && kq == 0) ? d * d : 0.f;
                 sq = row16_sum(sq);                                 // lanes 0..15 (kq = 0): the tile's 16 rows, in lane order
                 if (lane == 15) a.partial[tile] = sq;
             }
         }
+        STG_TRACE_MARK(6);
+        STG_TRACE_MARK(15);
     }
 }
 
@@ -299,6 +298,13 @@ int window_loss_launch(const float *partials, int steps, int count, int64_t stri
 
 }  // namespace
 }  // namespace stg
+
+#ifdef STG_STEP_TRACE
+extern "C" int stg_debug_set_step_trace_fwd(void *buf)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(stg::g_step_trace), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" int stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh)
 {

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Second library with per-wave phase timestamps in the TGCN step kernels (-DSTG_STEP_TRACE): build/trace/libstgraph_hip.so.
+# Run in the build container after `make -C stgraph_amd/csrc`; tools/diag/step_trace.py uses it on the GPU box.
+set -e
+cd "$(dirname "$0")/../../stgraph_amd/csrc"
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 -DSTG_STEP_TRACE"
+mkdir -p ../../build/trace
+for f in tgcn_step_fwd tgcn_step_bwd; do /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o ../../build/trace/$f.o; done
+OBJS=$(ls ../../build/obj/*.o | grep -v tgcn_step_)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/trace/libstgraph_hip.so $OBJS ../../build/trace/tgcn_step_fwd.o ../../build/trace/tgcn_step_bwd.o -lhiprtc
+ls -la ../../build/trace/libstgraph_hip.so

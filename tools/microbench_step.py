@@ -54,7 +54,8 @@ def main():
     x, H, tgt = r(n, FIN), r(n, C), r(n)
     new = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
     out = dict(P=new(n, FIN), x3=new(n, 3 * C), Z=new(n, C), R=new(n, C), Ht=new(n, C), Hn=new(n, C), HR=new(n, C),
-               y=new(n, FH), y_out=new(n), loss_partial=new(-(-n // 16)))
+               y=new(n, FH), y_out=new(n), loss_partial=new(-(-n // 16)),
+               clamp_mask=torch.empty(n, 12, dtype=torch.int32, device=dev))     # as temporal.window_cost passes it
     ncf, ewf = kernels._edge_gathered(f, "norm", norm, f.column_indices), kernels._edge_gathered(f, "ew", ew, f.eids)
     ncb, ewb = kernels._edge_gathered(b, "norm", norm, b.column_indices), kernels._edge_gathered(b, "ew", ew, b.eids)
     WcatT = p["Wcat"].t().contiguous()
@@ -73,7 +74,7 @@ def main():
         kernels.tgcn_step_bwd(n, C, FIN, FH, 2, -1e6, 1e6, dev, row_offsets=b.row_offset, column_indices=b.column_indices,
                               node_ids=b.node_ids if args.nid else None,
                               norm_col_edge=ncb, ew_edge=ewb, norm=norm.view(-1), zn=zn, dHn=dHn, g_cost=gc, Z=out["Z"],
-                              R=out["R"], Ht=out["Ht"], H=H, Hn=out["Hn"], x3=out["x3"], y_out=out["y_out"], target=tgt,
+                              R=out["R"], Ht=out["Ht"], H=H, Hn=out["Hn"], x3=None, clamp_mask=out["clamp_mask"], y_out=out["y_out"], target=tgt,
                               WzT=T["Wz"], WrT=T["Wr"], WhT=T["Wh"], Wcat=p["Wcat"], W1T=T["W1"], W2=p["W2"], **bo)
     res = {"N": n, "E": e, "waves": args.waves or "auto", "step_fwd_us": timed(fwd), "step_bwd_us": timed(bwd)}
 
