@@ -196,6 +196,13 @@ __device__ unsigned long long *g_step_trace = nullptr;
 #define STG_TRACE_MARK(k) ((void)0)
 #endif
 
+// "This value exists NOW": an IR-level sink otherwise moves its computation to the block that uses it, products later, and
+// keeps the (larger) operands alive in its place.
+__device__ __forceinline__ void materialize(float4 &v)
+{
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+
 __device__ __forceinline__ f32x4 to_x4(const float4 &v) { return f32x4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ float4 to_f4(const f32x4 &v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
@@ -269,32 +276,30 @@ __device__ __forceinline__ void gemm_pieces(f32x4 (&acc)[CT], const float *__res
 }
 
 // ---- gather: out8 = norm[r] * sum_e (nc[e] * x[col[e], 8 q .. 8 q + 7]) * w[e], rows of FIN = 32 floats ------------
-// lane = (grow = lane >> 2, q = lane & 3); arithmetic and order of gcn_agg_xw_kernel (bit-identical P)
+// lane = (grow = lane >> 2, q = lane & 3); arithmetic and order of gcn_agg_xw_kernel (bit-identical P).
+// In three calls, one per dependent round of loads: begin() = the row's extent and norm, indices() = the column indices / per-edge
+// scalars of its first kR edges, run() = the neighbour rows (and further index rounds for longer rows).
 template <bool HAS_EW>
-__device__ __forceinline__ void gather_rows32(float (&out)[8], const float *__restrict__ x, const int *__restrict__ row_offsets,
-                                              const int *__restrict__ column_indices, const float *__restrict__ nc_edge,
-                                              const float *__restrict__ ew_edge, const float *__restrict__ norm, int r,
-                                              bool valid, int q)
-{
-    constexpr int FIN = 32, R = 16, I = 4, U = 8;
-    int beg = 0, deg = 0;
-    float nr = 0.f;
-    if (valid) {
+struct RowGather32 {
+    static constexpr int FIN = 32, kR = 16, kI = kR / 4, kU = 8;
+    int beg, deg;
+    float nr;
+    int c[kI];
+    float nc[kI], w[kI];
+
+    __device__ __forceinline__ void begin(const int *__restrict__ row_offsets, const float *__restrict__ norm, int r)
+    {
         beg = row_offsets[r];
         deg = row_offsets[r + 1] - beg;
         nr = norm[r];
     }
-    const int max_deg = wave_max_nonneg(deg);
-    float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int base = 0; base < max_deg; base += R) {
+
+    __device__ __forceinline__ void indices(const int *__restrict__ column_indices, const float *__restrict__ nc_edge,
+                                            const float *__restrict__ ew_edge, int base, int q)
+    {
         const int cnt = deg - base;
-        const int cnt_max = min(R, max_deg - base);
-        int c[I];
-        float nc[I], w[I];
 #pragma unroll
-        for (int i = 0; i < I; ++i) {
+        for (int i = 0; i < kI; ++i) {
             c[i] = 0;
             nc[i] = 0.f;
             w[i] = 1.f;
@@ -305,45 +310,60 @@ __device__ __forceinline__ void gather_rows32(float (&out)[8], const float *__re
                 if constexpr (HAS_EW) w[i] = ew_edge[e];
             }
         }
+    }
+
+    // indices(.., 0, q) must have been called
+    __device__ __forceinline__ void run(float (&out)[8], const float *__restrict__ x, const int *__restrict__ column_indices,
+                                        const float *__restrict__ nc_edge, const float *__restrict__ ew_edge, int q)
+    {
+        const int max_deg = wave_max_nonneg(deg);
+        float acc[8];
 #pragma unroll
-        for (int k = 0; k < R; k += U) {
-            if (k < cnt_max) {
-                float4 v[U][2];
-                float ncs[U], ws[U];
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int base = 0; base < max_deg; base += kR) {
+            if (base > 0) indices(column_indices, nc_edge, ew_edge, base, q);
+            const int cnt = deg - base;
+            const int cnt_max = min(kR, max_deg - base);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int kk = k + u, el = kk >> 2, src = kk & 3;
-                    const int ck = quad_bcast_i(c[el], src);
-                    ncs[u] = quad_bcast_f(nc[el], src);
-                    ws[u] = 1.f;
-                    if constexpr (HAS_EW) ws[u] = quad_bcast_f(w[el], src);
-                    if (kk < cnt) {
-                        const unsigned off = (unsigned)ck * (FIN * 4u) + 32u * q;
-                        v[u][0] = ld_f4(x, off, 0);
-                        v[u][1] = ld_f4(x, off, 16);
-                    } else {
-                        v[u][0] = v[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < kR; k += kU) {
+                if (k < cnt_max) {
+                    float4 v[kU][2];
+                    float ncs[kU], ws[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int kk = k + u, el = kk >> 2, src = kk & 3;
+                        const int ck = quad_bcast_i(c[el], src);
+                        ncs[u] = quad_bcast_f(nc[el], src);
+                        ws[u] = 1.f;
+                        if constexpr (HAS_EW) ws[u] = quad_bcast_f(w[el], src);
+                        if (kk < cnt) {
+                            const unsigned off = (unsigned)ck * (FIN * 4u) + 32u * q;
+                            v[u][0] = ld_f4(x, off, 0);
+                            v[u][1] = ld_f4(x, off, 16);
+                        } else {
+                            v[u][0] = v[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (k + u < cnt) {
-                        const float vv[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w,
-                                             v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+                    for (int u = 0; u < kU; ++u) {
+                        if (k + u < cnt) {
+                            const float vv[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w,
+                                                 v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            float t = ncs[u] * vv[i];
-                            if constexpr (HAS_EW) t = t * ws[u];
-                            acc[i] = acc[i] + t;
+                            for (int i = 0; i < 8; ++i) {
+                                float t = ncs[u] * vv[i];
+                                if constexpr (HAS_EW) t = t * ws[u];
+                                acc[i] = acc[i] + t;
+                            }
                         }
                     }
                 }
             }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = acc[i] * nr;
-}
+        for (int i = 0; i < 8; ++i) out[i] = acc[i] * nr;
+    }
+};
 
 // From the gather layout (lane 4 g + q holds columns 8 q .. 8 q + 7 of row g) to row pieces (lane (n16, kq) holds
 // columns 16 j + 4 kq .. + 3 of row n16, j = 0, 1) on the LDS crossbar (ds_bpermute: no LDS memory, no fence):

@@ -45,32 +45,28 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int n16 = lane & 15, kq = lane >> 4;
 
-    // weights: every global load of the staging in flight at once, then the LDS writes (see tgcn_step_fwd.hip)
+    // tile hand-out and staging: see tgcn_step_fwd.hip
+    int *const next_w = reinterpret_cast<int *>(bs + FH);
+    STG_TRACE_MARK(0);
+    STG_TRACE_MARK(14);
+    if (threadIdx.x == 0) *next_w = WAVES;
+    int tile = wave * (int)gridDim.x + (int)blockIdx.x;
     const bool want_z = a.z != nullptr;                // block-uniform
     constexpr int kStage4 = (3 * 2 * C * C + FIN * 3 * C + (HEAD ? C * FH : 0)) / 4;
     const StageSeg segs[5] = {{a.WzT, WgT, 2 * C, C, LDB}, {a.WrT, WgT + 2 * C * LDB, 2 * C, C, LDB},
                               {a.WhT, WgT + 4 * C * LDB, 2 * C, C, LDB}, {a.Wcat, Wc, want_z ? FIN : 0, 3 * C, LDX},
                               {a.W1T, W1T, HEAD ? C : 0, FH, LDT}};
-    STG_TRACE_MARK(0);
-    STG_TRACE_MARK(14);
     Stager<NT, 5, (kStage4 + NT - 1) / NT> stager;
-    stager.issue(segs);
-    const int total = gridDim.x * WAVES;
-    int tile = wave * (int)gridDim.x + (int)blockIdx.x;
     const bool do_gather = GATHER && HEAD != 0 && a.zn != nullptr;      // block-uniform
-    // A_hat^T zn of a tile's rows (the next step's input gradient, aggregated here), as row pieces.  Lanes past the last row
-    // MIRROR row N - 1 (gather, loads, arithmetic, stores): they recompute and rewrite that row's values bit for bit, so no
-    // load or store of the tile body sits behind a per-lane guard -- a guarded store is a basic block of its own, and the
-    // loads of the next phase could not be scheduled above it (round 2's form exposed ~12 memory round trips per tile).
-    auto gather_tile = [&](int t, float4 (&pp)[PH]) {
-        const int q = lane & 3, grow = lane >> 2;
+    const int q = lane & 3, grow = lane >> 2;
+    // Lanes past the last row MIRROR row N - 1 (gather, loads, arithmetic, stores): they recompute and rewrite that row's values
+    // bit for bit, so no load or store of the tile body sits behind a per-lane guard -- a guarded store is a basic block of its
+    // own, and the loads of the next phase could not be scheduled above it (round 2's form exposed ~12 round trips per tile).
+    auto gather_row = [&](int t) {
         const int64_t gidx = std::min<int64_t>((int64_t)t * 16 + grow, a.N - 1);
-        int gr = (int)gidx;
-        if (a.node_ids) gr = a.node_ids[gidx];
-        float p8[8];
-        gather_rows32<HAS_EW>(p8, a.zn, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, true, q);
-        gather_to_pieces(p8, pp, n16, kq);
+        return a.node_ids ? a.node_ids[gidx] : (int)gidx;
     };
+    stager.issue(segs);
     stager.commit(segs);
     if constexpr (HEAD == 2) {
         for (int i = threadIdx.x; i < FH; i += NT) bs[i] = a.W2[i];
@@ -83,13 +79,21 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
     const float *const wg_l = WgT + pinned((unsigned)(n16 * LDB + 4 * kq)), *const wcrow = Wc + pinned((unsigned)(n16 * LDX + 4 * kq));
     const float *const w1_l = W1T + pinned((unsigned)(n16 * LDT + 4 * kq)), *const bs_l = bs + pinned((unsigned)(4 * kq));
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (; tile < a.num_tiles; tile += total) {
-        // A_hat^T zn first: the gather loop is the register-hungry part of the kernel and nothing else is live yet
+    while (tile < a.num_tiles) {
+        // A_hat^T zn of the tile's rows (the next step's input gradient, aggregated here) as row pieces.  First: the gather loop
+        // is the register-hungry part of the kernel and nothing else is live yet.
         float4 gp[PH];
 #pragma unroll
         for (int j = 0; j < PH; ++j) gp[j] = zero4;
         if constexpr (GATHER && HEAD != 0) {
-            if (do_gather) gather_tile(tile, gp);
+            if (do_gather) {
+                RowGather32<HAS_EW> rg;
+                rg.begin(a.row_offsets, a.norm, gather_row(tile));
+                rg.indices(a.column_indices, a.nc_edge, a.ew_edge, 0, q);
+                float p8[8];
+                rg.run(p8, a.zn, a.column_indices, a.nc_edge, a.ew_edge, q);
+                gather_to_pieces(p8, gp, n16, kq);
+            }
         }
         STG_TRACE_MARK(2);
         // Element offsets are 32-bit (N 3C < 2^30, checked on the host): one VGPR per row stride next to scalar base pointers.
@@ -196,11 +200,9 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
             stC(a.dhl, j, dhl[j]);
             stC(a.dzl, j, dz);
         }
-        // R for the dHR stage: in flight under the first gate product
-        float4 rr[PC];
+        // (left free, `g * z` is sunk to the dHR stage, keeping g and z -- 32 registers, 12 of them spilled -- instead of dHa)
 #pragma unroll
-        for (int j = 0; j < PC; ++j) rr[j] = ldC(a.R, j);
-
+        for (int j = 0; j < PC; ++j) materialize(dHa[j]);
         f32x4 zacc[PF];
 #pragma unroll
         for (int ft = 0; ft < PF; ++ft) zacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -235,7 +237,9 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         gemm(dhl, 2, 0, acc);
         emit_da3(2, acc);
         STG_TRACE_MARK(4);
-        float4 hb[PC], dzl[PC];
+        float4 rr[PC], hb[PC], dzl[PC];                          // for the dHR stage: in flight under the next product
+#pragma unroll
+        for (int j = 0; j < PC; ++j) rr[j] = ldC(a.R, j);
 #pragma unroll
         for (int j = 0; j < PC; ++j) hb[j] = zero4, dzl[j] = ldC(a.dzl, j);      // this lane's own stores, above
         if (a.H) {
@@ -277,6 +281,9 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         }
         STG_TRACE_MARK(7);
         STG_TRACE_MARK(15);
+        int w = 0;
+        if (lane == 0) w = atomicAdd(next_w, 1);
+        tile = __builtin_amdgcn_readfirstlane(w) * (int)gridDim.x + (int)blockIdx.x;
     }
 }
 

@@ -43,33 +43,32 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int n16 = lane & 15, kq = lane >> 4;
 
-    // weights: every global load of the staging in flight at once, then the LDS writes.  (Gathering the first tile
-    // between the two halves -- or a later tile's rows ahead of time -- measured SLOWER: the workgroup barrier then waits
-    // for the slowest wave's gather, and waves that start their products at different times overlap better.)
+    // Tiles of a workgroup: (w * grid + block), w = 0, 1, ...  Wave w starts on tile w; whichever wave finishes FIRST takes the
+    // workgroup's next one off a counter in LDS (|V| = 50 K is 12 tiles on every CU and a 13th on 53 of them: taken by the
+    // earliest finisher it runs beside the other waves' last phases instead of alone after wave 0's own tile).
+    int *const next_w = reinterpret_cast<int *>(bs + (6 * C + 2 * FH + 1));
+    STG_TRACE_MARK(0);
+    STG_TRACE_MARK(14);
+    if (threadIdx.x == 0) *next_w = WAVES;
+    int tile = wave * (int)gridDim.x + (int)blockIdx.x;
+
+    // Weights and biases: every global load of the staging in flight at once, then the LDS writes.  Measured and dropped, both
+    // SLOWER: gathering the first tile between the two halves (the workgroup barrier then waits for the slowest wave's gather,
+    // and waves that start their products at different times overlap better), and -- round 3 -- no barrier at all (a count in LDS
+    // each wave bumps after its share, looked at after the wave's first gather, with that gather's extent and index loads
+    // issued around the staging loads: the gather ends 1.4 us earlier, the staging 0.5-1.4 us later, the launch +1 us).
     constexpr int kStage4 = (3 * C * 2 * C + (GATHER ? 3 * C * FIN : 0) + (HEAD ? FH * C : 0)) / 4;
     const StageSeg segs[5] = {{a.Wz, Wg, C, 2 * C, LDW}, {a.Wr, Wg + C * LDW, C, 2 * C, LDW}, {a.Wh, Wg + 2 * C * LDW, C, 2 * C, LDW},
                               {a.WcatT, WcT, GATHER ? 3 * C : 0, FIN, LDC}, {a.W1, W1s, HEAD ? FH : 0, C, LD1}};
-    STG_TRACE_MARK(0);
-    STG_TRACE_MARK(14);
     Stager<NT, 5, (kStage4 + NT - 1) / NT> stager;
-    stager.issue(segs);
-    const int total = gridDim.x * WAVES;
-    int tile = wave * (int)gridDim.x + (int)blockIdx.x;
-    // P = A_hat x of a tile, handed from the gather layout to row pieces on the LDS crossbar (no LDS memory).  Lanes past the
-    // last row MIRROR row N - 1 (they recompute and rewrite its values bit for bit): no load or store of the tile body sits
-    // behind a per-lane guard, so the scheduler sees straight-line code between the products (tgcn_step_bwd.hip).
-    auto gather_tile = [&](int t, float4 (&pp)[PF]) {
-        const int q = lane & 3, grow = lane >> 2;
+    const int q = lane & 3, grow = lane >> 2;
+    // Lanes past the last row MIRROR row N - 1 (they recompute and rewrite its values bit for bit): no load or store of the tile
+    // body sits behind a per-lane guard, so the scheduler sees straight-line code between the products (tgcn_step_bwd.hip).
+    auto gather_row = [&](int t) {
         const int64_t gidx = std::min<int64_t>((int64_t)t * 16 + grow, a.N - 1);
-        int gr = (int)gidx;
-        if (a.node_ids) gr = a.node_ids[gidx];
-        float p8[8];
-        gather_rows32<HAS_EW>(p8, a.x, a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, gr, true, q);
-        const unsigned off = (unsigned)gr * (FIN * 4u) + 32u * q;
-        st_f4(a.P, off, 0, make_float4(p8[0], p8[1], p8[2], p8[3]));
-        st_f4(a.P, off, 16, make_float4(p8[4], p8[5], p8[6], p8[7]));
-        gather_to_pieces(p8, pp, n16, kq);
+        return a.node_ids ? a.node_ids[gidx] : (int)gidx;
     };
+    stager.issue(segs);
     stager.commit(segs);
     for (int i = threadIdx.x; i < 3 * C; i += NT) bs[i] = a.b3[i];
     for (int i = threadIdx.x; i < C; i += NT) {
@@ -93,11 +92,23 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     // this lane's row / piece inside each LDS matrix (tgcn_step.hpp: pinned)
     const float *const wg_l = Wg + pinned((unsigned)(n16 * LDW + 4 * kq)), *const wc_l = WcT + pinned((unsigned)(n16 * LDC + 4 * kq));
     const float *const w1_l = W1s + pinned((unsigned)(n16 * LD1 + 4 * kq)), *const bs_l = bs + pinned((unsigned)(4 * kq));
-    for (; tile < a.num_tiles; tile += total) {
+    while (tile < a.num_tiles) {
+        // P = A_hat x of the tile, handed from the gather layout to row pieces on the LDS crossbar (no LDS memory)
         float4 p[PF];
 #pragma unroll
         for (int j = 0; j < PF; ++j) p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (GATHER) gather_tile(tile, p);
+        if constexpr (GATHER) {
+            const int gr = gather_row(tile);
+            RowGather32<HAS_EW> rg;
+            rg.begin(a.row_offsets, a.norm, gr);
+            rg.indices(a.column_indices, a.nc_edge, a.ew_edge, 0, q);
+            float p8[8];
+            rg.run(p8, a.x, a.column_indices, a.nc_edge, a.ew_edge, q);
+            const unsigned off = (unsigned)gr * (FIN * 4u) + 32u * q;
+            st_f4(a.P, off, 0, make_float4(p8[0], p8[1], p8[2], p8[3]));
+            st_f4(a.P, off, 16, make_float4(p8[4], p8[5], p8[6], p8[7]));
+            gather_to_pieces(p8, p, n16, kq);
+        }
         STG_TRACE_MARK(2);
         const int64_t idx = (int64_t)tile * 16 + n16;
         const bool rok = idx < a.N;                               // only the loss partial looks at it
@@ -231,6 +242,9 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
         }
         STG_TRACE_MARK(6);
         STG_TRACE_MARK(15);
+        int w = 0;
+        if (lane == 0) w = atomicAdd(next_w, 1);
+        tile = __builtin_amdgcn_readfirstlane(w) * (int)gridDim.x + (int)blockIdx.x;
     }
 }
 
