@@ -161,6 +161,9 @@ __device__ __forceinline__ float4 ld_f4(const float *base, unsigned off_bytes, i
 }
 __device__ __forceinline__ void st_f4(float *base, unsigned off_bytes, int imm_bytes, const float4 &v)
 {
+#ifdef STG_ABLATE_STORES        // diagnosis builds only (tools/diag/build_step_trace.sh): what the row-piece stores cost
+    if (v.x == 123456.75f)
+#endif
     *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + (size_t)off_bytes + imm_bytes) = v;
 }
 __device__ __forceinline__ float ld_f1(const float *base, unsigned off_bytes)
@@ -215,6 +218,11 @@ __device__ __forceinline__ float4 to_f4(const f32x4 &v) { return make_float4(v[0
 template <int CT>
 __device__ __forceinline__ void load_w(float4 (&w)[CT], const float *__restrict__ wrow, int ld, int j)
 {
+#ifdef STG_ABLATE_LDS           // diagnosis builds only: what the weight reads from LDS cost (one fragment reused for every step)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) w[ct] = *reinterpret_cast<const float4 *>(wrow);
+    return;
+#endif
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) w[ct] = *reinterpret_cast<const float4 *>(wrow + ct * 16 * ld + 16 * j);
 }
@@ -268,6 +276,31 @@ __device__ __forceinline__ void gemm_pieces(f32x4 (&acc)[CT], const float *__res
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) w[ct] = wn[ct];
         if (j + 1 < J) load_w<CT>(wn, wrow, ld, j + 1);
+        const float4 x = in(j);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_w<CT>(acc, w, x);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// gemm_pieces with the step-0 weights handed in (`w0`: the caller read them from LDS a phase ahead -- load_w<CT>(w0, wrow, ld, 0) --
+// so the product does not start by waiting for LDS) and `tail()` run where the last step has nothing of its own to prefetch:
+// the caller reads the NEXT product's step-0 weights there.  With twelve waves on the CU's one LDS a read that an MFMA waits on
+// costs several hundred cycles; the backward launch had 19 of them per tile (diagnosis build with the reads removed: -10 us).
+template <int CT, int J, typename InFn, typename TailFn>
+__device__ __forceinline__ void gemm_chain(f32x4 (&acc)[CT], const float *__restrict__ wrow, int ld, InFn in, const float4 (&w0)[CT],
+                                           TailFn tail)
+{
+    float4 wn[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) wn[ct] = w0[ct];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        float4 w[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w[ct] = wn[ct];
+        if (j + 1 < J) load_w<CT>(wn, wrow, ld, j + 1);
+        else tail();
         const float4 x = in(j);
         __builtin_amdgcn_sched_barrier(0);
         mfma_w<CT>(acc, w, x);

@@ -127,18 +127,24 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
         if constexpr (HEAD == 2) tg = ld_f1(a.target, row * 4u);
         // hg = clamp(x3[:, g C ..]) with x3 = P Wcat + b3 (or a3 + b3), one gate at a time (16 live registers instead
         // of 48); x3 itself (before the clamp) is what the backward pass and the weight gradients read
-        auto gate_input = [&](int g, float4 (&hg)[PC]) {
+        // (wq: the step-0 weights of the next product, read from LDS one phase ahead -- tgcn_step.hpp, gemm_chain)
+        auto gate_input = [&](int g, float4 (&hg)[PC], float4 (&wq)[PC]) {
             if constexpr (GATHER) {
                 f32x4 acc[PC];
 #pragma unroll
                 for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_pieces<PC, PF, (WAVES <= 12)>(acc, wc_l + g * C * LDC, LDC, [&](int j) { return p[j]; });
+                float4 w0[PC];
+#pragma unroll
+                for (int ct = 0; ct < PC; ++ct) w0[ct] = wq[ct];
+                gemm_chain<PC, PF>(acc, wc_l + g * C * LDC, LDC, [&](int j) { return p[j]; }, w0,
+                                   [&]() { load_w<PC>(wq, wg_l + g * C * LDW, LDW, 0); });
 #pragma unroll
                 for (int ct = 0; ct < PC; ++ct) {
                     const float4 b = *reinterpret_cast<const float4 *>(bs_l + g * C + 16 * ct);
                     hg[ct] = make_float4(acc[ct][0] + b.x, acc[ct][1] + b.y, acc[ct][2] + b.z, acc[ct][3] + b.w);
                 }
             } else {
+                load_w<PC>(wq, wg_l + g * C * LDW, LDW, 0);
 #pragma unroll
                 for (int ct = 0; ct < PC; ++ct) {
                     const float4 v = ld_f4(a.a3, o3, 4 * (g * C + 16 * ct));
@@ -158,28 +164,44 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
             if (a.mask) a.mask[row * 12u + 4 * g + kq] = gm;
         };
         // acc = bias + [hg | second] W_g^T   (W_g [C][2C] in LDS, torch Linear layout)
-        auto gate = [&](int g, const float4 (&hg)[PC], const float4 (&second)[PC], f32x4 (&acc)[PC]) {
+        // on return wq holds the step-0 weights of what follows: the next gate's x3 product, or the head (in wq[0 .. PH))
+        auto gate = [&](int g, const float4 (&hg)[PC], const float4 (&second)[PC], f32x4 (&acc)[PC], float4 (&wq)[PC]) {
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) acc[ct] = to_x4(*reinterpret_cast<const float4 *>(bs_l + (3 + g) * C + 16 * ct));
-            gemm_pieces<PC, 2 * PC, (WAVES <= 12)>(acc, wg_l + g * C * LDW, LDW,
-                                    [&](int j) { return j < PC ? hg[j % PC] : second[j % PC]; });
+            float4 w0[PC];
+#pragma unroll
+            for (int ct = 0; ct < PC; ++ct) w0[ct] = wq[ct];
+            gemm_chain<PC, 2 * PC>(acc, wg_l + g * C * LDW, LDW, [&](int j) { return j < PC ? hg[j % PC] : second[j % PC]; }, w0, [&]() {
+                if (g < 2) {
+                    if constexpr (GATHER) load_w<PC>(wq, wc_l + (g + 1) * C * LDC, LDC, 0);
+                } else if constexpr (HEAD != 0) {
+                    float4 wh[PH];
+                    load_w<PH>(wh, w1_l, LD1, 0);
+#pragma unroll
+                    for (int ft = 0; ft < PH; ++ft) wq[ft] = wh[ft];
+                }
+            });
         };
 
+        float4 wq[PC];
+        if constexpr (GATHER) load_w<PC>(wq, wc_l, LDC, 0);
         // ---- Z = sigmoid([hz | H] Wz^T + bz),  R = sigmoid([hr | H] Wr^T + br) -----------------------------------
         float4 zz[PC], hr[PC];
         {
             float4 hg[PC];
             f32x4 acc[PC];
-            gate_input(0, hg);
-            gate(0, hg, hh, acc);
+            gate_input(0, hg, wq);
+            STG_TRACE_MARK(8);                              // (trace build only) the x3 product, its stores, clamp and mask
+            gate(0, hg, hh, acc, wq);
+            STG_TRACE_MARK(9);                              // the gate product
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
                 zz[j] = make_float4(sigmoid_(acc[j][0]), sigmoid_(acc[j][1]), sigmoid_(acc[j][2]), sigmoid_(acc[j][3]));
                 st_f4(a.Z, oC, 64 * j, zz[j]);
             }
             STG_TRACE_MARK(3);
-            gate_input(1, hg);
-            gate(1, hg, hh, acc);
+            gate_input(1, hg, wq);
+            gate(1, hg, hh, acc, wq);
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
                 const float4 r = make_float4(sigmoid_(acc[j][0]), sigmoid_(acc[j][1]), sigmoid_(acc[j][2]), sigmoid_(acc[j][3]));
@@ -195,8 +217,8 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
         {
             float4 hg[PC];
             f32x4 acc[PC];
-            gate_input(2, hg);
-            gate(2, hg, hr, acc);
+            gate_input(2, hg, wq);
+            gate(2, hg, hr, acc, wq);
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
                 const float4 t = make_float4(tanh_(acc[j][0]), tanh_(acc[j][1]), tanh_(acc[j][2]), tanh_(acc[j][3]));
@@ -214,10 +236,13 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
             f32x4 accy[PH];
 #pragma unroll
             for (int ft = 0; ft < PH; ++ft) accy[ft] = to_x4(*reinterpret_cast<const float4 *>(bs_l + 6 * C + 16 * ft));
-            gemm_pieces<PH, PC, (WAVES <= 12)>(accy, w1_l, LD1, [&](int j) {
+            float4 wh[PH];
+#pragma unroll
+            for (int ft = 0; ft < PH; ++ft) wh[ft] = wq[ft];
+            gemm_chain<PH, PC>(accy, w1_l, LD1, [&](int j) {
                 return make_float4(hn[j].x < 0.f ? 0.f : hn[j].x, hn[j].y < 0.f ? 0.f : hn[j].y,
                                    hn[j].z < 0.f ? 0.f : hn[j].z, hn[j].w < 0.f ? 0.f : hn[j].w);
-            });
+            }, wh, []() {});
 #pragma unroll
             for (int ft = 0; ft < PH; ++ft) st_f4(a.y, oF, 64 * ft, to_f4(accy[ft]));
             if constexpr (HEAD == 2) {

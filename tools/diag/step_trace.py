@@ -97,6 +97,13 @@ def main():
         rows["simd_end"] = [round(float(v), 2) for v in np.percentile(simd_end, [0, 10, 50, 90, 100])]
         rows["phase_us_per_wave_p10_p50_p90"] = {f"{k}->{k + 1}": [round(float(v), 2) for v in np.percentile((t[one, k + 1] - t[one, k]) / 100.0, [10, 50, 90])]
                                                  for k in range(last)}
+        cls = (wave_id % waves) // 4
+        rows["phase_us_median_by_wave_class"] = {f"waves {4 * c}-{4 * c + 3}": {f"{k}->{k + 1}": round(float(np.median((t[one & (cls == c), k + 1] - t[one & (cls == c), k]) / 100.0)), 2)
+                                                                                for k in range(last)} for c in range(3)}
+        if name == "fwd":
+            rows["fwd_gate0_us_p10_p50_p90"] = {k: [round(float(v), 2) for v in np.percentile((t[one, b] - t[one, a]) / 100.0, [10, 50, 90])]
+                                                for k, (a, b) in {"x3 product + stores + clamp (32 MFMA)": (2, 8), "gate product (128 MFMA)": (8, 9),
+                                                                  "sigmoid + Z stores": (9, 3)}.items()}
         rows["shader_clock_GHz_median"] = round(float(np.median(clk)), 3)
         rows["waves_one_two"] = [int(one.sum()), int(two.sum())]
         res[name] = rows
