@@ -125,7 +125,10 @@ def _close(got, want, what, tol=2e-5):
 
 
 @pytest.mark.parametrize("n,e,use_ew,node_ids", [(300, 2400, True, False), (3001, 30000, True, True), (1000, 9000, False, False),
-                                                 (17, 60, True, False), (50_000, 500_000, True, False)])
+                                                 (17, 60, True, False), (50_000, 500_000, True, False),
+                                                 # 7501 tiles on 3072 wave slots, one row in the last tile: every wave takes
+                                                 # further tiles off the workgroup's counter
+                                                 (120_001, 1_000_000, False, False)])
 def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids):
     from stgraph_amd import kernels
     g, e = _graph(cuda, n, e, seed=n)
