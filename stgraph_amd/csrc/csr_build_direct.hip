@@ -201,6 +201,69 @@ __global__ __launch_bounds__(kBlock) void direct2_count(const int *__restrict__ 
     }
 }
 
+// The same pass with the histograms in LDS (|V| <= kLdsCountMaxN): the 2 E returning atomics of direct2_count go to random
+// addresses of a 200 KB table in L2 and take 23.6 us at |E| = 250 K -- the chip's scattered-atomic rate.  Here workgroup
+// (chunk c, side) counts ITS kLdsChunks-th of the edges into a private histogram of |V| ints in LDS (side 0: by destination,
+// side 1: by source), leaves every edge's arrival index inside (chunk, row) in pos_f / pos_b and the histogram in
+// part[side][c][.]; direct3_combine turns the chunks' counts of a row into exclusive bases (in place) and the row's total
+// (cnt, as direct2_count leaves it); placing adds base[chunk of the edge][row] to the arrival index.
+constexpr int kLdsChunks = 16;
+constexpr int kLdsCountMaxN = 40 * 1024;                        // 160 KB of LDS
+__global__ __launch_bounds__(kScanThreads) void direct3_count(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int N,
+                                                             int64_t chunk_len, int *__restrict__ part, int npad,
+                                                             int *__restrict__ pos_f, int *__restrict__ pos_b, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) int hist[];  // npad = |V| rounded up to 4 ints (also the row stride of part)
+    const int c = (int)blockIdx.x, side = (int)blockIdx.y;
+    for (int v = 4 * threadIdx.x; v < npad; v += 4 * kScanThreads) *reinterpret_cast<int4 *>(hist + v) = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    const int64_t lo = c * chunk_len, hi = std::min<int64_t>(E, lo + chunk_len);
+    int *pos = side ? pos_b : pos_f;
+    constexpr int U = 16;                                  // edges per thread in flight (|E| = 250 K: a chunk in ONE round): the loop is a chain of load -> atomic -> store
+    for (int64_t base = lo + threadIdx.x; base < hi; base += (int64_t)U * kScanThreads) {
+        int s[U], d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * kScanThreads;
+            s[u] = i < hi ? src[i] : 0;
+            d[u] = i < hi ? dst[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * kScanThreads;
+            if (i >= hi) continue;
+            if ((unsigned)s[u] >= (unsigned)N || (unsigned)d[u] >= (unsigned)N) {
+                if (side == 0) {
+                    atomicOr(status, 1);
+                    pos_f[i] = -1;
+                }
+                continue;
+            }
+            pos[i] = atomicAdd(hist + (side ? s[u] : d[u]), 1);
+        }
+    }
+    __syncthreads();
+    int *out = part + ((int64_t)side * kLdsChunks + c) * npad;
+    for (int v = 4 * threadIdx.x; v < npad; v += 4 * kScanThreads) *reinterpret_cast<int4 *>(out + v) = *reinterpret_cast<const int4 *>(hist + v);
+}
+
+__global__ __launch_bounds__(kBlock) void direct3_combine(int *__restrict__ part, int npad, int *__restrict__ cnt)
+{
+    const int v = 4 * (blockIdx.x * blockDim.x + threadIdx.x), side = (int)blockIdx.y;      // four rows per thread
+    if (v >= npad) return;
+    int *p = part + (int64_t)side * kLdsChunks * npad + v;
+    int4 x[kLdsChunks];
+#pragma unroll
+    for (int c = 0; c < kLdsChunks; ++c) x[c] = *reinterpret_cast<const int4 *>(p + (int64_t)c * npad);     // all loads first
+    int4 run = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < kLdsChunks; ++c) {
+        *reinterpret_cast<int4 *>(p + (int64_t)c * npad) = run;
+        run = make_int4(run.x + x[c].x, run.y + x[c].y, run.z + x[c].z, run.w + x[c].w);
+    }
+    *reinterpret_cast<int4 *>(cnt + side * npad + v) = run;          // (rows past |V| inside the padding: zero, as the scan expects)
+}
+
 // blockIdx.x = 0: forward rows (lengths cnt[0 .. N)), 1: backward rows (cnt[npad .. npad + N)), npad = N rounded up to 4.
 // Up to 16 tiles of 4096 lengths are held in registers at once (|V| <= 65536: one pass): every tile is loaded with one
 // coalesced int4 per thread, the 16 tiles' wave scans run interleaved on the shuffle network, ONE barrier publishes the
@@ -302,16 +365,19 @@ __global__ __launch_bounds__(kScanThreads) void direct2_scan(const int *__restri
     if (longest > kDirectMaxRow) atomicOr(status, STG_BUILD_NEEDS_SORT);
 }
 
+// (base != NULL: pos_f / pos_b count inside (chunk, row) -- direct3_count -- and base[chunk][row] is added; npad = its row stride)
 __global__ __launch_bounds__(kBlock) void direct2_place(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
                                                        const int *__restrict__ fwd_ro, const int *__restrict__ pos_f,
                                                        uint64_t *__restrict__ key, int *__restrict__ row,
-                                                       const int *__restrict__ status)
+                                                       const int *__restrict__ status, const int *__restrict__ base_f, int npad,
+                                                       int64_t chunk_len)
 {
     if (*status) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
         const int d = dst[i];
-        const int slot = fwd_ro[d] + pos_f[i];
+        int slot = fwd_ro[d] + pos_f[i];
+        if (base_f) slot += base_f[(i / chunk_len) * npad + d];
         key[slot] = ((uint64_t)(unsigned)src[i] << 32) | (uint64_t)(unsigned)i;
         row[slot] = d;
     }
@@ -323,7 +389,8 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const uint64_t *__res
                                                           int *__restrict__ fwd_eid, int64_t *__restrict__ perm_fwd,
                                                           uint64_t *__restrict__ key_b, int *__restrict__ row_b,
                                                           const float *__restrict__ norm, float *__restrict__ nc_fwd,
-                                                          const int *__restrict__ status)
+                                                          const int *__restrict__ status, const int *__restrict__ base_b, int npad,
+                                                          int64_t chunk_len)
 {
     if (*status) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -338,7 +405,8 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const uint64_t *__res
         fwd_eid[e] = e;
         perm_fwd[e] = (int64_t)i;
         if (nc_fwd) nc_fwd[e] = norm[s];
-        const int slot = bwd_ro[s] + pos_b[i];
+        int slot = bwd_ro[s] + pos_b[i];
+        if (base_b) slot += base_b[((int64_t)i / chunk_len) * npad + s];
         key_b[slot] = ((uint64_t)(unsigned)e << 32) | (uint64_t)(unsigned)d;
         row_b[slot] = s;
     }
@@ -367,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_bwd(const uint64_t *__res
 }
 
 struct DirectLayout {
-    size_t key_f, row_f, key_b, row_b, cursors, pos_f, pos_b, deg_key_a, deg_key_b, iota, sort_tmp, total, sort_tmp_bytes;
+    size_t key_f, row_f, key_b, row_b, cursors, pos_f, pos_b, deg_key_a, deg_key_b, iota, sort_tmp, part, total, sort_tmp_bytes;
 };
 
 DirectLayout direct_layout(int64_t E, int32_t N)
@@ -391,6 +459,7 @@ DirectLayout direct_layout(int64_t E, int32_t N)
     L.deg_key_b = take(n * 4);
     L.iota = take(n * 4);
     L.sort_tmp = take(t);
+    L.part = take(N <= kLdsCountMaxN ? (size_t)2 * kLdsChunks * ((n + 3) & ~(size_t)3) * 4 : 0);      // direct3_count's per-chunk histograms
     L.total = off;
     return L;
 }
@@ -496,16 +565,37 @@ extern "C" int stg_graph_build_direct2_device(const int32_t *src, const int32_t 
     if (((uintptr_t)zero_counters | (uintptr_t)fwd_row_offset | (uintptr_t)bwd_row_offset | (uintptr_t)in_degrees |
          (uintptr_t)out_degrees | (uintptr_t)norm) & 15)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_graph_build_direct2_device: the per-vertex arrays must be 16-byte aligned");
-    if (E > 0)
+    // histograms in LDS when |V| fits it and there are enough edges per vertex to pay for writing and combining 2 x 16 x |V| counts
+    const int mode = tuning().build_lds_count;
+    const bool lds_count = E > 0 && N <= kLdsCountMaxN && mode != 2 && (mode == 1 || (E >= 2 * (int64_t)N && E >= 32768));
+    const int64_t chunk_len = lds_count ? (E + kLdsChunks - 1) / kLdsChunks : 1;
+    int *part = reinterpret_cast<int *>(ws + L.part);
+    const int *base_f = lds_count ? part : nullptr, *base_b = lds_count ? part + (size_t)kLdsChunks * npad : nullptr;
+    if (lds_count) {
+        const size_t lds = (size_t)npad * sizeof(int);
+        static PerDeviceOnce once;
+        bool *raised = once.slot();
+        if (lds > 64 * 1024 && !*raised) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(direct3_count), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     kLdsCountMaxN * (int)sizeof(int));
+            if (e != hipSuccess) return fail((int)e, "stg_graph_build_direct2_device: %s", hipGetErrorString(e));
+            *raised = true;
+        }
+        hipLaunchKernelGGL(direct3_count, dim3(kLdsChunks, 2), dim3(kScanThreads), lds, stream, src, dst, E, N, chunk_len, part, npad,
+                           pos_f, pos_b, sticky_status);
+        hipLaunchKernelGGL(direct3_combine, dim3((npad / 4 + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stream, part, npad, zero_counters);
+    } else if (E > 0) {
         hipLaunchKernelGGL(direct2_count, dim3(eblocks), dim3(kBlock), 0, stream, src, dst, E, N, zero_counters, npad, pos_f, pos_b,
                            sticky_status);
+    }
     hipLaunchKernelGGL(direct2_scan, dim3(2), dim3(kScanThreads), 0, stream, zero_counters, npad, N, fwd_row_offset, bwd_row_offset,
                        in_degrees, out_degrees, norm, sticky_status);
     if (E > 0) {
         hipLaunchKernelGGL(direct2_place, dim3(eblocks), dim3(kBlock), 0, stream, src, dst, E, fwd_row_offset, pos_f, key_f, row_f,
-                           sticky_status);
+                           sticky_status, base_f, npad, chunk_len);
         hipLaunchKernelGGL(direct2_rank_fwd, dim3(eblocks), dim3(kBlock), 0, stream, key_f, row_f, E, fwd_row_offset, bwd_row_offset,
-                           pos_b, fwd_column_indices, fwd_eids, perm_fwd, key_b, row_b, norm, norm_col_fwd, sticky_status);
+                           pos_b, fwd_column_indices, fwd_eids, perm_fwd, key_b, row_b, norm, norm_col_fwd, sticky_status, base_b, npad,
+                           chunk_len);
     }
     // (also re-zeroes the counters: launched even for E = 0)
     hipLaunchKernelGGL(direct2_rank_bwd, dim3(std::max(eblocks, (2 * npad + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,

@@ -156,17 +156,27 @@ def test_rebuilt_snapshots_are_verified_in_bulk(cuda):
     G.reset_graph()
 
 
-@pytest.mark.parametrize("n,e", [(1, 1), (64, 400), (2708, 10556), (25_000, 250_000), (70_000, 300_000)])
-def test_fused_rebuild_equals_the_first_build(cuda, n, e):
-    """stg_graph_build_direct2_device (five launches, one atomic pass, norm + per-edge norm on the side; what a
+@pytest.mark.parametrize("lds_count", [0, 1, 2])
+@pytest.mark.parametrize("n,e", [(1, 1), (64, 400), (2708, 10556), (25_000, 250_000), (40_960, 300_000), (70_000, 300_000)])
+def test_fused_rebuild_equals_the_first_build(cuda, n, e, lds_count):
+    """(``lds_count``: the histogram pass with its counters in LDS -- 0 as the library chooses, 1 wherever |V| fits, 2 never.)
+    stg_graph_build_direct2_device (five launches, one atomic pass, norm + per-edge norm on the side; what a
     NaiveGraph(resident=False) re-runs per snapshot and epoch) against stg_graph_build_direct_device on the same edges: every
     CSR array bit for bit, norm == degree_norm, the per-edge gathers == norm[col]; the shared counters are zero afterwards,
     so the build can be repeated (also from a HIP graph)."""
-    from stgraph_amd import kernels
+    from stgraph_amd import _C, kernels
     src, dst = random_graph(n + e, n, e, hub=e < 16000)        # (a hub of e / 8 edges: rows past 2048 go to the sort-based build)
     s, d = torch.from_numpy(src).to(cuda), torch.from_numpy(dst).to(cuda)
     first = kernels.build_graph_csr(s, d, n, cuda, lazy_node_ids=True)
     assert first.built_by == "direct"
+    _C.set_tuning("build_lds_count", lds_count)
+    try:
+        _fused_rebuild_checks(cuda, kernels, first, s, d, n)
+    finally:
+        _C.set_tuning("build_lds_count", 0)
+
+
+def _fused_rebuild_checks(cuda, kernels, first, s, d, n):
     for rep in range(3):
         again = kernels.build_graph_csr(s, d, n, cuda, lazy_node_ids=True, known_path="direct")
         assert again.norm_in is not None
