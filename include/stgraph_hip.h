@@ -49,7 +49,12 @@ const char *stg_last_error_string(void);
  * "gcn_tile_rows" (its rows per workgroup: 0 = one per lane group, else 8 .. 256), "gcn_tile_pipe" (its
  * persistent, software-pipelined form: 0 / 1 = off, 2 = whenever the tile kernel runs; measured equal),
  * "xw_waves" (0 = auto; 4 / 8 waves per workgroup of stg_gcn_agg_transform), "cell_rows" (0 = auto; 16 / 32 rows
- * per tile of stg_tgcn_cell_fused_fwd). */
+ * per tile of stg_tgcn_cell_fused_fwd), "step_waves" (stg_tgcn_step_*: 0 = auto, 12 / 16 waves per workgroup), "step_spread"
+ * (0 = one workgroup per CU when there are fewer tiles than wave slots, 1 = packed grid), "gemm_wide" (tall-skinny weight
+ * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_cyclic" (its row-group hand-out: 0 .. 2),
+ * "gcn_wide_long" (rows of >= 1024 edges at F >= 128: 0 = feature-sliced workgroups beside the main launch, 1 = never, 2 = behind
+ * it on the same stream), "build_lds_count" (stg_graph_build_direct2_device: 0 = histograms in LDS when |V| <= 40 K and the graph
+ * is dense enough, 1 = whenever |V| fits, 2 = never). */
 int stg_set_tuning(const char *key, int value);
 
 /* ---------------------------------------------------------------- CSR, host
