@@ -370,14 +370,14 @@ __global__ __launch_bounds__(kBlock) void direct2_place(const int *__restrict__ 
                                                        const int *__restrict__ fwd_ro, const int *__restrict__ pos_f,
                                                        uint64_t *__restrict__ key, int *__restrict__ row,
                                                        const int *__restrict__ status, const int *__restrict__ base_f, int npad,
-                                                       int64_t chunk_len)
+                                                       int chunk_shift)
 {
     if (*status) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
         const int d = dst[i];
         int slot = fwd_ro[d] + pos_f[i];
-        if (base_f) slot += base_f[(i / chunk_len) * npad + d];
+        if (base_f) slot += base_f[(i >> chunk_shift) * npad + d];
         key[slot] = ((uint64_t)(unsigned)src[i] << 32) | (uint64_t)(unsigned)i;
         row[slot] = d;
     }
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const uint64_t *__res
                                                           uint64_t *__restrict__ key_b, int *__restrict__ row_b,
                                                           const float *__restrict__ norm, float *__restrict__ nc_fwd,
                                                           const int *__restrict__ status, const int *__restrict__ base_b, int npad,
-                                                          int64_t chunk_len)
+                                                          int chunk_shift)
 {
     if (*status) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const uint64_t *__res
         perm_fwd[e] = (int64_t)i;
         if (nc_fwd) nc_fwd[e] = norm[s];
         int slot = bwd_ro[s] + pos_b[i];
-        if (base_b) slot += base_b[((int64_t)i / chunk_len) * npad + s];
+        if (base_b) slot += base_b[(i >> chunk_shift) * npad + s];
         key_b[slot] = ((uint64_t)(unsigned)e << 32) | (uint64_t)(unsigned)d;
         row_b[slot] = s;
     }
@@ -568,7 +568,9 @@ extern "C" int stg_graph_build_direct2_device(const int32_t *src, const int32_t 
     // histograms in LDS when |V| fits it and there are enough edges per vertex to pay for writing and combining 2 x 16 x |V| counts
     const int mode = tuning().build_lds_count;
     const bool lds_count = E > 0 && N <= kLdsCountMaxN && mode != 2 && (mode == 1 || (E >= 2 * (int64_t)N && E >= 32768));
-    const int64_t chunk_len = lds_count ? (E + kLdsChunks - 1) / kLdsChunks : 1;
+    int chunk_shift = 0;                                   // chunks of 2^shift edges (the chunk of an edge is a shift in the placing passes)
+    while (((int64_t)kLdsChunks << chunk_shift) < E) ++chunk_shift;
+    const int64_t chunk_len = (int64_t)1 << chunk_shift;
     int *part = reinterpret_cast<int *>(ws + L.part);
     const int *base_f = lds_count ? part : nullptr, *base_b = lds_count ? part + (size_t)kLdsChunks * npad : nullptr;
     if (lds_count) {
@@ -592,10 +594,10 @@ extern "C" int stg_graph_build_direct2_device(const int32_t *src, const int32_t 
                        in_degrees, out_degrees, norm, sticky_status);
     if (E > 0) {
         hipLaunchKernelGGL(direct2_place, dim3(eblocks), dim3(kBlock), 0, stream, src, dst, E, fwd_row_offset, pos_f, key_f, row_f,
-                           sticky_status, base_f, npad, chunk_len);
+                           sticky_status, base_f, npad, chunk_shift);
         hipLaunchKernelGGL(direct2_rank_fwd, dim3(eblocks), dim3(kBlock), 0, stream, key_f, row_f, E, fwd_row_offset, bwd_row_offset,
                            pos_b, fwd_column_indices, fwd_eids, perm_fwd, key_b, row_b, norm, norm_col_fwd, sticky_status, base_b, npad,
-                           chunk_len);
+                           chunk_shift);
     }
     // (also re-zeroes the counters: launched even for E = 0)
     hipLaunchKernelGGL(direct2_rank_bwd, dim3(std::max(eblocks, (2 * npad + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
