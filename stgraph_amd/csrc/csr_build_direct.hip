@@ -126,7 +126,15 @@ __global__ void direct_scatter_fwd(const int *__restrict__ src, const int *__res
 __device__ __forceinline__ int rank_in_row(const uint64_t *__restrict__ key, int beg, int end, uint64_t mine)
 {
     int r = 0;
-    for (int t = beg; t < end; ++t) r += key[t] < mine ? 1 : 0;
+    int t = beg;
+    for (; t + 8 <= end; t += 8) {                     // eight independent loads in flight: the loop is latency, not bandwidth
+        uint64_t k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k[u] = key[t + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r += k[u] < mine ? 1 : 0;
+    }
+    for (; t < end; ++t) r += key[t] < mine ? 1 : 0;
     return r;
 }
 
