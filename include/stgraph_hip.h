@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 10
+#define STG_ABI_VERSION 11
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -211,13 +211,16 @@ int stg_edgeset_merge_device(const uint64_t *keys_in, int64_t E, const uint64_t 
  * launches: (old \ del) U add in both orientations from batches packed + sorted up front, both CSRs (row offsets +
  * columns: rows back to front, or ascending with STG_EMIT_KEY_ORDER), in_degrees [N] (nullable), norm [N] = in_deg^-1/2
  * (0 for isolated rows; nullable) and norm gathered through either CSR's columns [E_out] (nullable; need norm).
+ * fwd_row_offset_in / bwd_row_offset_in (both or neither; nullable): the row offsets [N + 1] of keys_fwd_in / keys_bwd_in, as a
+ * previous step emitted them -- search hints only (a batch key is then placed inside its own row of the old set), never results.
  * status is OR-ed into, never cleared (codes as stg_edgeset_update_device): one word may serve a whole store. */
 int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E, const uint64_t *add_fwd,
                             const uint64_t *add_bwd, int64_t n_add, const uint64_t *del_fwd, const uint64_t *del_bwd,
                             int64_t n_del, int32_t N, int flags, uint64_t *keys_fwd_out, uint64_t *keys_bwd_out,
                             int32_t *fwd_row_offset, int32_t *fwd_column_indices, int32_t *bwd_row_offset,
                             int32_t *bwd_column_indices, int32_t *in_degrees, float *norm, float *norm_col_fwd,
-                            float *norm_col_bwd, int32_t *status, void *stream);
+                            float *norm_col_bwd, const int32_t *fwd_row_offset_in, const int32_t *bwd_row_offset_in,
+                            int32_t *status, void *stream);
 #define STG_EMIT_REVERSE   1   /* rows = src (build_reverse_csr / build_backward_csr) */
 #define STG_EMIT_KEY_ORDER 2   /* GPMA view: rows and columns in key order; default = PCSR's back-to-front rows */
 size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N);

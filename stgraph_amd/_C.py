@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -116,7 +116,7 @@ def _load() -> ctypes.CDLL:
     lib.stg_edgeset_merge_device.restype = ctypes.c_int
     lib.stg_edgeset_merge_device.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, vp]
     lib.stg_edgeset_step_device.restype = ctypes.c_int
-    lib.stg_edgeset_step_device.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, ctypes.c_int] + [vp] * 12
+    lib.stg_edgeset_step_device.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, ctypes.c_int] + [vp] * 14
     lib.stg_edgeset_emit_csr_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_edgeset_emit_csr_workspace_bytes.argtypes = [i32]
     lib.stg_edgeset_emit_csr_device.restype = ctypes.c_int

@@ -51,6 +51,29 @@ __device__ __forceinline__ int64_t lower_bound_dev(const uint64_t *__restrict__ 
     return lo;
 }
 
+// Two independent lower bounds in ONE loop: a binary search is a chain of dependent loads (18 of them over 250 K keys, each an
+// L2 round trip), and two searches written one after the other are a chain of both lengths added.
+__device__ __forceinline__ void lower_bound2_dev(const uint64_t *__restrict__ a, int64_t na, uint64_t ka, const uint64_t *__restrict__ b,
+                                                 int64_t nb, uint64_t kb, int64_t &ra, int64_t &rb)
+{
+    int64_t alo = 0, ahi = na, blo = 0, bhi = nb;
+    while (alo < ahi || blo < bhi) {
+        const int64_t am = (alo + ahi) >> 1, bm = (blo + bhi) >> 1;
+        const bool ago = alo < ahi, bgo = blo < bhi;
+        const uint64_t av = ago ? a[am] : 0, bv = bgo ? b[bm] : 0;
+        if (ago) {
+            if (av < ka) alo = am + 1;
+            else ahi = am;
+        }
+        if (bgo) {
+            if (bv < kb) blo = bm + 1;
+            else bhi = bm;
+        }
+    }
+    ra = alo;
+    rb = blo;
+}
+
 // Pack an update batch in both orientations.
 __global__ void pack_batch(const int *__restrict__ src, const int *__restrict__ dst, int64_t n, int N,
                            uint64_t *__restrict__ kf, uint64_t *__restrict__ kb, int *__restrict__ status)
@@ -82,6 +105,28 @@ __device__ __forceinline__ int64_t upper_bound_dev(const uint64_t *__restrict__ 
     return lo;
 }
 
+// lower (UPPER = false) / upper bound of k in a[0 .. n) by one WAVE: every round the 64 lanes probe the last entries of 64 equal
+// chunks and a ballot keeps one chunk -- three dependent loads for the 6 K entries of a batch where a lane's binary search has 13.
+template <bool UPPER>
+__device__ __forceinline__ int64_t wave_bound_dev(const uint64_t *__restrict__ a, int64_t n, uint64_t k)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    int64_t lo = 0, hi = n;                                // the answer is in [lo, hi]
+    while (hi - lo > kWave) {
+        const int64_t chunk = (hi - lo + kWave - 1) / kWave;
+        const int64_t last = std::min<int64_t>(hi, lo + (lane + 1) * chunk) - 1;   // last entry of this lane's chunk
+        const bool have = lo + lane * chunk < hi;
+        const uint64_t v = have ? a[last] : ~0ull;
+        const bool below = have && (UPPER ? v <= k : v < k);      // the whole chunk is below the bound
+        const int c = __popcll(__ballot(below));                  // chunks entirely below: they form a prefix (a is sorted)
+        lo = std::min<int64_t>(hi, lo + c * chunk);
+        hi = std::min<int64_t>(hi, lo + chunk);
+    }
+    const bool have = lo + lane < hi;
+    const uint64_t v = have ? a[lo + lane] : ~0ull;
+    return lo + __popcll(__ballot(have && (UPPER ? v <= k : v < k)));
+}
+
 __device__ __forceinline__ void scatter_old_tile(const uint64_t *__restrict__ old, int64_t E,
                                                  const uint64_t *__restrict__ add, int64_t na,
                                                  const uint64_t *__restrict__ del, int64_t nd,
@@ -91,11 +136,13 @@ __device__ __forceinline__ void scatter_old_tile(const uint64_t *__restrict__ ol
     __shared__ int64_t bounds[4];
     const int64_t base = tile * (kBlock * kMergeItems);
     const int64_t last = min(base + (int64_t)kBlock * kMergeItems, E) - 1;
-    if (threadIdx.x < 4) {
-        const bool hi = threadIdx.x & 1, use_del = threadIdx.x & 2;
+    {                                                      // wave w of the four: bracket w, searched by the whole wave
+        const int w = threadIdx.x / kWave;
+        const bool hi = w & 1, use_del = w & 2;
         const uint64_t *arr = use_del ? del : add;
         const int64_t n = use_del ? nd : na;
-        bounds[threadIdx.x] = hi ? upper_bound_dev(arr, n, old[last]) : lower_bound_dev(arr, n, old[base]);
+        const int64_t r = hi ? wave_bound_dev<true>(arr, n, old[last]) : wave_bound_dev<false>(arr, n, old[base]);
+        if ((threadIdx.x & (kWave - 1)) == 0) bounds[w] = r;
     }
     __syncthreads();
     const int64_t a0 = bounds[0], a1 = bounds[1], d0 = bounds[2], d1 = bounds[3];
@@ -147,22 +194,34 @@ __device__ __forceinline__ void scatter_add_range(const uint64_t *__restrict__ o
                                                   const uint64_t *__restrict__ add, int64_t na,
                                                   const uint64_t *__restrict__ del, int64_t nd,
                                                   uint64_t *__restrict__ out, int64_t E_out, int *__restrict__ status,
-                                                  int64_t block, int64_t nblocks)
+                                                  int64_t block, int64_t nblocks, const int *__restrict__ ro_old = nullptr, int n_rows = 0)
 {
+    // ro_old (nullable): the row offsets of `old` -- a key's place among the old keys is then searched inside its own row
+    // (two loads + ~4 steps instead of 18 dependent steps over the whole array)
     const int64_t stride = nblocks * blockDim.x;
     for (int64_t j = block * blockDim.x + threadIdx.x; j < na + nd; j += stride) {
+        const uint64_t kk = j < na ? add[j] : del[j - na];
+        int64_t rlo = 0, rn = E;
+        if (ro_old) {
+            const int64_t row = (int64_t)(kk >> kStoreBits);
+            if (row < n_rows) {                                // (a key past the last row: searched over the whole array, reported as before)
+                rlo = ro_old[row];
+                rn = (int64_t)ro_old[row + 1] - rlo;
+            }
+        }
         if (j < na) {
-            const uint64_t k = add[j];
+            const uint64_t k = kk;
             if (j > 0 && add[j - 1] >= k) { atomicOr(status, add[j - 1] == k ? 2 : 16); continue; }   // duplicate / unsorted
-            const int64_t o_lt = lower_bound_dev(old, E, k);
-            const int64_t d_lt = lower_bound_dev(del, nd, k);
+            int64_t o_lt, d_lt;
+            lower_bound2_dev(old + rlo, rn, k, del, nd, k, o_lt, d_lt);
+            o_lt += rlo;
             if (d_lt < nd && del[d_lt] == k) atomicOr(status, 8);                  // added and deleted at once
             const int64_t o = j + o_lt - d_lt;
             if (o >= 0 && o < E_out) out[o] = k;
         } else {
             const int64_t q = j - na;
-            const uint64_t k = del[q];
-            const int64_t o = lower_bound_dev(old, E, k);
+            const uint64_t k = kk;
+            const int64_t o = rlo + lower_bound_dev(old + rlo, rn, k);
             if (q > 0 && del[q - 1] > k) atomicOr(status, 16);                              // batch not sorted
             if (o >= E || old[o] != k || (q > 0 && del[q - 1] == k)) atomicOr(status, 4);   // deleting an absent edge
         }
@@ -187,6 +246,7 @@ struct StepArgs {
     const uint64_t *old[2], *add[2], *del[2];
     uint64_t *out[2];
     int *ro[2], *col[2];
+    const int *ro_old[2];                                  // row offsets of old[side] (nullable): search hints
     float *nc[2];
     int *in_deg;
     float *norm;
@@ -203,18 +263,7 @@ __global__ __launch_bounds__(kBlock) void step_merge_kernel(const StepArgs a)
         scatter_old_tile(a.old[side], a.E, a.add[side], a.na, a.del[side], a.nd, a.out[side], a.E_out, a.status, r);
     else
         scatter_add_range(a.old[side], a.E, a.add[side], a.na, a.del[side], a.nd, a.out[side], a.E_out, a.status,
-                          r - a.nb_old, a.nb_add);
-}
-
-__device__ __forceinline__ int row_begin(const uint64_t *__restrict__ keys, int64_t E, int v)
-{
-    int64_t lo = 0, hi = E;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)(keys[mid] >> kStoreBits) < (int64_t)v) lo = mid + 1;
-        else hi = mid;
-    }
-    return (int)lo;
+                          r - a.nb_old, a.nb_add, a.ro_old[side], a.N);
 }
 
 __global__ __launch_bounds__(kBlock) void step_rows_kernel(const StepArgs a)
@@ -223,10 +272,15 @@ __global__ __launch_bounds__(kBlock) void step_rows_kernel(const StepArgs a)
     const int side = idx > a.N ? 1 : 0;
     const int v = (int)(idx - (side ? a.N + 1 : 0));
     if (v > a.N) return;
-    const int lo = row_begin(a.out[side], a.E_out, v);
+    // first key of row v and (forward side: the degree) of row v + 1, searched together (lower_bound2_dev)
+    const uint64_t kv = (uint64_t)(unsigned)v << kStoreBits, kn = (uint64_t)((unsigned)v + 1u) << kStoreBits;
+    const bool want_deg = side == 0 && v < a.N && (a.in_deg || a.norm);
+    int64_t lo64, nx64;
+    lower_bound2_dev(a.out[side], a.E_out, kv, a.out[side], want_deg ? a.E_out : 0, kn, lo64, nx64);
+    const int lo = (int)lo64;
     a.ro[side][v] = lo;
-    if (side == 0 && v < a.N && (a.in_deg || a.norm)) {
-        const int d = row_begin(a.out[0], a.E_out, v + 1) - lo;
+    if (want_deg) {
+        const int d = (int)nx64 - lo;
         if (a.in_deg) a.in_deg[v] = d;
         if (a.norm) a.norm[v] = d > 0 ? __fdiv_rn(1.0f, __fsqrt_rn((float)d)) : 0.f;     // = degree_norm_kernel
     }
@@ -513,7 +567,8 @@ extern "C" int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64
                                        uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *fwd_row_offset,
                                        int32_t *fwd_column_indices, int32_t *bwd_row_offset, int32_t *bwd_column_indices,
                                        int32_t *in_degrees, float *norm, float *norm_col_fwd, float *norm_col_bwd,
-                                       int32_t *status, void *stream_)
+                                       const int32_t *fwd_row_offset_in, const int32_t *bwd_row_offset_in, int32_t *status,
+                                       void *stream_)
 {
     using namespace stg;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -534,6 +589,8 @@ extern "C" int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64
     a.out[0] = keys_fwd_out; a.out[1] = keys_bwd_out; a.ro[0] = fwd_row_offset; a.ro[1] = bwd_row_offset;
     a.col[0] = fwd_column_indices; a.col[1] = bwd_column_indices; a.nc[0] = norm_col_fwd; a.nc[1] = norm_col_bwd;
     a.in_deg = in_degrees; a.norm = norm; a.status = status;
+    const bool hints = fwd_row_offset_in && bwd_row_offset_in;
+    a.ro_old[0] = hints ? fwd_row_offset_in : nullptr; a.ro_old[1] = hints ? bwd_row_offset_in : nullptr;
     a.E = E; a.na = n_add; a.nd = n_del; a.E_out = E_out; a.N = N;
     const int64_t tile = (int64_t)kBlock * kMergeItems;
     a.nb_old = (int)((E + tile - 1) / tile);

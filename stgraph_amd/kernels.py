@@ -486,12 +486,13 @@ def edgeset_merge(es: EdgeSet, add_keys, del_keys) -> EdgeSet:
     return EdgeSet(N, kf, kb, status)
 
 
-def edgeset_step(es: EdgeSet, add_keys, del_keys, key_order: bool, status: torch.Tensor | None = None):
+def edgeset_step(es: EdgeSet, add_keys, del_keys, key_order: bool, status: torch.Tensor | None = None, old_row_offsets=None):
     """One timestamp of a delta store in three launches (stg_edgeset_step_device): returns ``(new set, forward StoreCSR,
     backward StoreCSR, norm [N, 1])`` -- the merge of :func:`edgeset_merge`, both emissions of :func:`edgeset_emit_csr`, the
     in-degrees, ``norm = in_deg ** -0.5`` (:func:`degree_norm`'s values) and ``norm`` gathered per edge of either CSR,
     already filed in the CSRs' per-edge caches under the returned ``norm`` tensor.  ``status``: the store's sticky status
-    word (OR-ed into; a fresh zero word if None)."""
+    word (OR-ed into; a fresh zero word if None).  ``old_row_offsets``: ``(forward, backward)`` row offsets of ``es`` as an earlier
+    step emitted them -- search hints (a batch key is placed inside its own row of the old set), or None."""
     device, N, E = es.device, es.num_nodes, es.num_edges
     if device.type != "cuda":
         raise ValueError("edgeset_step is the device fast path")
@@ -514,7 +515,9 @@ def edgeset_step(es: EdgeSet, add_keys, del_keys, key_order: bool, status: torch
         _C.check(_C.lib.stg_edgeset_step_device(
             _ptr(es.keys_fwd), _ptr(es.keys_bwd), E, _ptr(add_keys[0]), _ptr(add_keys[1]), na, _ptr(del_keys[0]),
             _ptr(del_keys[1]), nd, N, EMIT_KEY_ORDER if key_order else 0, _ptr(kf), _ptr(kb), _ptr(ro_f), _ptr(col_f),
-            _ptr(ro_b), _ptr(col_b), _ptr(deg), _ptr(norm), _ptr(nc_f), _ptr(nc_b), _ptr(status), _stream_ptr(device)))
+            _ptr(ro_b), _ptr(col_b), _ptr(deg), _ptr(norm), _ptr(nc_f), _ptr(nc_b),
+            _ptr(old_row_offsets[0]) if old_row_offsets else None, _ptr(old_row_offsets[1]) if old_row_offsets else None,
+            _ptr(status), _stream_ptr(device)))
     new = EdgeSet(N, kf, kb, status)
     fwd = StoreCSR(new, False, ro_f, col_f, None, deg, key_order)
     bwd = StoreCSR(new, True, ro_b, col_b, None, None, key_order)
