@@ -115,7 +115,9 @@ def gcn_setup(device, seed, n, e, feat):
     ntrain = int(0.6 * n)                                      # train mask = first 60 % (gcn/seastar/utils.py:25-27)
     torch.manual_seed(seed)
     model = GCN(feat, feat, feat, 1, F.relu).to(device)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4)
+    # torch.optim.Adam as the reference script constructs it (benchmarking/gcn/seastar/train.py:63-66), in torch's single-launch
+    # implementation on the GPU (fused=True: the same update rule; the default foreach form is eight multi-tensor launches a step)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4, fused=device.type == "cuda")
     # Same loss as the reference's nn.CrossEntropyLoss() on logits[train_mask] (mean over the masked rows).
     # Written as a slice (the mask is a prefix: a view, no gather/scatter); the loss itself is the library's fused
     # softmax cross-entropy (csrc/xent.hip; torch's fused 'mean' reduction runs single-block nll_loss kernels on

@@ -15,7 +15,7 @@ namespace {
 
 constexpr int kMaxSlots = 4;
 constexpr int kMaxGrid = 2048;     // partial rows; 8 workgroups per CU with kRowUnroll rows in flight each
-constexpr int kRowUnroll = 4;
+constexpr int kRowUnroll = 8;
 constexpr int kFinCols = 8, kFinGroups = kBlock / kFinCols;
 
 template <int VEC, bool MASK>
