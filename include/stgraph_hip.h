@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 11
+#define STG_ABI_VERSION 12
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -464,6 +464,13 @@ int stg_rowgemm_f32(const float *X, const float *W, const float *bias, float *Y,
  * so an output wider than one launch covers (M > 192) is produced in column slices of W / bias. */
 int stg_rowgemm_strided_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K,
                             int32_t M, int32_t ldy, int trans_w, void *stream);
+
+/* Y = act(X op(W) + bias) for K, M in {64, 128} (stg_rowgemm_act_supported) and many rows: the dense layer of the GCN / GAT
+ * configs (gcn_conv.py:158-188: `torch.mm(h, self.weight)`, `+ self.bias`, activation) as ONE launch in the 16-row row-piece
+ * layout of the step kernels; act = STG_ACT_NONE / STG_ACT_RELU.  X, W, Y 16-byte aligned, Y contiguous [N, M]. */
+int stg_rowgemm_act_supported(int32_t K, int32_t M);
+int stg_rowgemm_act_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K, int32_t M,
+                        int trans_w, int act, void *stream);
 
 /* C = sum_{t < T} A_t^T B_t (and colsum_A = sum_t colsum(A_t), nullable) in ONE launch: A, B are HOST
  * arrays of T <= 32 device pointers, every A_t [K,M], B_t [K,N].  The pointers travel by value in

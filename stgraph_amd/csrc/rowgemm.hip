@@ -5,11 +5,123 @@
 // for [50K,128] x [128,64]^T, whose 38 MB of traffic take 7 us; profiles/r01).
 #include <algorithm>
 
-#include "stg_common.hpp"
+#include "tgcn_step.hpp"
 
 namespace stg {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ---- the same product in the step kernels' row-piece layout (tgcn_step.hpp) for many rows x (K, M <= 128, multiples of 16) ----
+// cfg2's three dense products per step are [1M, 128] x [128, 128]: 32.8 GFLOP = 209 us of fp32 MFMA, 1 GB = 170 us of HBM;
+// hipBLASLt's 128x128x16 macro tile takes 360 us and the 32x32x2 kernel below 443.  Here a wave owns 16 rows: lane (n16, kq)
+// holds the row pieces X[row n16][16 j + 4 kq ..] (K / 16 float4s, loaded one tile ahead), the weight is the A operand of
+// v_mfma_f32_16x16x4_f32 read from LDS in its [out][in] layout (one ds_read_b128 per four k steps, rows padded by 8 floats:
+// conflict-free), so a lane's four accumulator values are four consecutive columns of its own row: 16-byte stores, no
+// transposes.  The output columns are taken in two halves (16 accumulator registers live instead of 32).  One workgroup of
+// 12 waves per CU, tiles dealt wave-major.
+template <int K, int M, bool TRANS_W, bool RELU>
+__global__ __launch_bounds__(12 * kWave) void rowgemm16_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                              const float *__restrict__ bias, float *__restrict__ Y, int64_t N,
+                                                              int num_tiles, int ldy)
+{
+    constexpr int WAVES = 12, NT = WAVES * kWave, PK = K / 16, PM = M / 16, LD = K + 8;
+    constexpr int HALF = PM >= 2 && PM % 2 == 0 ? PM / 2 : PM, NH = PM / HALF;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Ws = lds;                                   // [M][LD]: W as [out][in]
+    float *bs = Ws + M * LD;                           // [M] (zeros without a bias)
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int total = gridDim.x * WAVES;
+    int tile = wave * (int)gridDim.x + (int)blockIdx.x;
+
+    auto row_off = [&](int t) {                        // lanes past the last row mirror row N - 1 (they rewrite its values)
+        const int64_t r = std::min<int64_t>((int64_t)t * 16 + n16, N - 1);
+        return r;
+    };
+    float4 xn[PK];
+    auto load_x = [&](int t) {
+        const float *src = X + row_off(t) * K + 4 * kq;
+#pragma unroll
+        for (int j = 0; j < PK; ++j) xn[j] = *reinterpret_cast<const float4 *>(src + 16 * j);
+    };
+    if (tile < num_tiles) load_x(tile);
+
+    if constexpr (TRANS_W) {                           // W is [M][K] already: rows copied with the padded stride
+        for (int i = threadIdx.x; i < M * K / 4; i += NT) {
+            const int m = (i * 4) / K, k = (i * 4) - m * K;
+            *reinterpret_cast<float4 *>(Ws + m * LD + k) = *reinterpret_cast<const float4 *>(W + (int64_t)i * 4);
+        }
+    } else {                                           // W is [K][M]: transposed on the way (coalesced reads, strided LDS writes, once)
+        for (int i = threadIdx.x; i < K * M / 4; i += NT) {
+            const int k = (i * 4) / M, m = (i * 4) - k * M;
+            const float4 v = *reinterpret_cast<const float4 *>(W + (int64_t)i * 4);
+            Ws[(m + 0) * LD + k] = v.x;
+            Ws[(m + 1) * LD + k] = v.y;
+            Ws[(m + 2) * LD + k] = v.z;
+            Ws[(m + 3) * LD + k] = v.w;
+        }
+    }
+    for (int i = threadIdx.x; i < M; i += NT) bs[i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+
+    const float *const w_l = Ws + pinned((unsigned)(n16 * LD + 4 * kq)), *const b_l = bs + pinned((unsigned)(4 * kq));
+    float4 wq[HALF];
+    load_w<HALF>(wq, w_l, LD, 0);
+    for (; tile < num_tiles; tile += total) {
+        float4 x[PK];
+#pragma unroll
+        for (int j = 0; j < PK; ++j) x[j] = xn[j];
+        const int64_t r = row_off(tile);
+        if (tile + total < num_tiles) load_x(tile + total);          // the next tile's rows: in flight under this tile's products
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 acc[HALF];
+#pragma unroll
+            for (int ct = 0; ct < HALF; ++ct) acc[ct] = to_x4(*reinterpret_cast<const float4 *>(b_l + 16 * (h * HALF + ct)));
+            float4 w0[HALF];
+#pragma unroll
+            for (int ct = 0; ct < HALF; ++ct) w0[ct] = wq[ct];
+            gemm_chain<HALF, PK>(acc, w_l + h * HALF * 16 * LD, LD, [&](int j) { return x[j]; }, w0,
+                                 [&]() { load_w<HALF>(wq, w_l + ((h + 1) % NH) * HALF * 16 * LD, LD, 0); });
+            float *dst = Y + r * ldy + 16 * h * HALF + 4 * kq;
+#pragma unroll
+            for (int ct = 0; ct < HALF; ++ct) {
+                float4 o = to_f4(acc[ct]);
+                if constexpr (RELU) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+                *reinterpret_cast<float4 *>(dst + 16 * ct) = o;
+            }
+        }
+    }
+}
+
+template <int K, int M, bool TW, bool RELU>
+int rowgemm16_launch2(const float *X, const float *W, const float *bias, float *Y, int64_t N, hipStream_t st, int ldy)
+{
+    constexpr size_t lds = sizeof(float) * ((size_t)M * (K + 8) + M);
+    const int64_t tiles = (N + 15) / 16;
+    if (tiles > INT32_MAX) return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: too many rows");
+    static PerDeviceOnce once;
+    bool *raised = once.slot();
+    if (lds > 64 * 1024 && !*raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm16_kernel<K, M, TW, RELU>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail((int)e, "stg_rowgemm_f32: %s", hipGetErrorString(e));
+        *raised = true;
+    }
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + 11) / 12, 256);
+    hipLaunchKernelGGL((rowgemm16_kernel<K, M, TW, RELU>), dim3(blocks), dim3(12 * kWave), lds, st, X, W, bias, Y, N, (int)tiles, ldy);
+    return check_launch("stg_rowgemm_f32");
+}
+
+template <int K, int M>
+int rowgemm16_launch(const float *X, const float *W, const float *bias, float *Y, int64_t N, bool trans_w, bool relu, hipStream_t st, int ldy)
+{
+    if (trans_w) return relu ? rowgemm16_launch2<K, M, true, true>(X, W, bias, Y, N, st, ldy) : rowgemm16_launch2<K, M, true, false>(X, W, bias, Y, N, st, ldy);
+    return relu ? rowgemm16_launch2<K, M, false, true>(X, W, bias, Y, N, st, ldy) : rowgemm16_launch2<K, M, false, false>(X, W, bias, Y, N, st, ldy);
+}
+
+// shapes the row-piece kernel is instantiated for (the dense layers of the GCN / GAT configs)
+inline bool rowgemm16_shape(int K, int M) { return (K == 128 && M == 128) || (K == 64 && M == 128) || (K == 128 && M == 64) || (K == 64 && M == 64); }
 
 // One WAVE owns a 32-row tile of X and ALL M output columns (M / 32 accumulators of v_mfma_f32_32x32x2_f32):
 //   * its A operands come straight from global memory into registers in MFMA layout -- lane (row, kh) loads the
@@ -184,6 +296,27 @@ extern "C" int stg_rowgemm_supported(int32_t K, int32_t M)
 extern "C" int stg_rowgemm_strided_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N,
                                        int32_t K, int32_t M, int32_t ldy, int trans_w, void *stream);
 
+extern "C" int stg_rowgemm_act_supported(int32_t K, int32_t M) { return stg::rowgemm16_shape(K, M) ? 1 : 0; }
+
+extern "C" int stg_rowgemm_act_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K, int32_t M,
+                                   int trans_w, int act, void *stream)
+{
+    using namespace stg;
+    if (act != STG_ACT_NONE && act != STG_ACT_RELU) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_f32: unknown activation %d", act);
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_f32: negative N");
+    if (!rowgemm16_shape(K, M)) return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_act_f32: K, M must be 64 or 128 (got %d, %d)", K, M);
+    if (N == 0) return 0;
+    if (!X || !W || !Y) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_f32: NULL pointer argument");
+    if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Y)) % 16 != 0)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_f32: X, W and Y must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool tw = trans_w != 0, relu = act == STG_ACT_RELU;
+    if (K == 128 && M == 128) return rowgemm16_launch<128, 128>(X, W, bias, Y, N, tw, relu, st, M);
+    if (K == 64 && M == 128) return rowgemm16_launch<64, 128>(X, W, bias, Y, N, tw, relu, st, M);
+    if (K == 128 && M == 64) return rowgemm16_launch<128, 64>(X, W, bias, Y, N, tw, relu, st, M);
+    return rowgemm16_launch<64, 64>(X, W, bias, Y, N, tw, relu, st, M);
+}
+
 extern "C" int stg_rowgemm_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K,
                                int32_t M, int trans_w, void *stream)
 {
@@ -206,6 +339,13 @@ extern "C" int stg_rowgemm_strided_f32(const float *X, const float *W, const flo
     if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) % 16 != 0)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_f32: X and W must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (rowgemm16_shape(K, M) && N >= 4096 && ldy % 4 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 && tuning().rowgemm16 != 1) {
+        const bool tw = trans_w != 0;
+        if (K == 128 && M == 128) return rowgemm16_launch<128, 128>(X, W, bias, Y, N, tw, false, st, ldy);
+        if (K == 64 && M == 128) return rowgemm16_launch<64, 128>(X, W, bias, Y, N, tw, false, st, ldy);
+        if (K == 128 && M == 64) return rowgemm16_launch<128, 64>(X, W, bias, Y, N, tw, false, st, ldy);
+        return rowgemm16_launch<64, 64>(X, W, bias, Y, N, tw, false, st, ldy);
+    }
     switch (s.kbmax) {
         case 4: return rowgemm_mt<4>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st, ldy);
         case 8: return rowgemm_mt<8>(s.mt, X, W, bias, Y, N, K, M, trans_w != 0, s.lds, st, ldy);

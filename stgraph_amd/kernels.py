@@ -1060,6 +1060,39 @@ def set_native_rowgemm(enabled: bool) -> None:
     _ROWGEMM, _ROWGEMM_MODE = bool(enabled), ("1" if enabled else "0")
 
 
+ROWGEMM16_MIN_ROWS = 65536
+
+
+def rowgemm16_usable(x: torch.Tensor, K: int, M: int) -> bool:
+    """Tall fp32 products with K, M in {64, 128} (the dense layers of the GCN / GAT configs): the 16-row row-piece kernel
+    of stg_rowgemm_f32 -- 1.14x (128 x 128) to 1.4x (64 -> 128) hipBLASLt's time at 256 K - 1 M rows."""
+    return (_ROWGEMM16 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+            and x.shape[0] >= ROWGEMM16_MIN_ROWS and K in (64, 128) and M in (64, 128) and x.data_ptr() % 16 == 0)
+
+
+_ROWGEMM16 = os.environ.get("STGRAPH_AMD_ROWGEMM16", "1") != "0"
+
+
+def rowgemm_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, trans_w: bool, act: int = ACT_NONE) -> torch.Tensor:
+    """``act(x @ op(w) + bias)`` in one launch (stg_rowgemm_act_f32; shapes: :func:`rowgemm16_usable`)."""
+    x = _f32(x, "x")
+    dev = x.device
+    w = _f32(w, "w", dev)
+    N, K = x.shape
+    M = int(w.shape[0] if trans_w else w.shape[1])
+    if int(w.shape[1] if trans_w else w.shape[0]) != K:
+        raise ValueError(f"rowgemm_act: x {tuple(x.shape)} and w {tuple(w.shape)} (trans_w={trans_w}) do not match")
+    if bias is not None:
+        bias = _f32(bias, "bias", dev)
+        if bias.numel() != M:
+            raise ValueError("rowgemm_act: bias length != output width")
+    y = torch.empty(N, M, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("rowgemm", 4 * N * (K + M) + 4 * K * M, 2 * N * K * M):
+        _C.check(_C.lib.stg_rowgemm_act_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), N, K, M, int(bool(trans_w)), int(act),
+                                            _stream_ptr(dev)))
+    return y
+
+
 def rowgemm_usable(x: torch.Tensor, K: int, M: int, trans_w: bool = False) -> bool:
     # "auto": in situ (TGCN, |V| = 50K) the kernel beats rocBLAS's 64x32 macro tile on x @ W with W [K, M] wider
     # than deep (19.9 vs 29.7 us for [50K,64] x [64,128]) and loses on the transposed forward shapes (24.4 vs 17.5 us)

@@ -49,6 +49,8 @@ def _mm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """``x @ w`` from the BLAS library.  Tall fp32 products go through ``addmm`` with a (cached, zero) 1-D bias: that
     form is dispatched to hipBLASLt, whose kernel for [1M, 128] x [128, 128] takes 0.37 ms against rocBLAS' 0.42
     (``torch.mm``); below ~ 500 K rows the two are equal.  Same values (tested)."""
+    if w.dim() == 2 and w.is_contiguous() and kernels.rowgemm16_usable(x, w.shape[0], w.shape[1]) and w.data_ptr() % 16 == 0:
+        return kernels.rowgemm(x, w, None, trans_w=False)
     if x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= LT_MIN_ROWS and w.is_contiguous():
         key = (w.shape[1], x.device)
         z = _ZERO_BIAS.get(key)
@@ -74,7 +76,10 @@ class _MM(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _mm(g, w.t().contiguous()) if g.shape[0] >= LT_MIN_ROWS else torch.mm(g, w.t())
+            if w.is_contiguous() and kernels.rowgemm16_usable(g, w.shape[1], w.shape[0]) and w.data_ptr() % 16 == 0:
+                gx = kernels.rowgemm(g, w, None, trans_w=True)               # g @ w.T with w read in place ([in][out] = [M][K])
+            else:
+                gx = _mm(g, w.t().contiguous()) if g.shape[0] >= LT_MIN_ROWS else torch.mm(g, w.t())
         if ctx.needs_input_grad[1]:
             native = _use_native(x, x.shape[0], x.shape[1], g.shape[1])
             if native and deferred_weight_grads() and ctx.w.is_leaf:
@@ -373,7 +378,10 @@ class _InputLayer(torch.autograd.Function):
     def forward(ctx, x, w, bias, norm, ew, fwd_csr, use_nid, act):
         P = kernels.gcn_agg(x, norm, norm, fwd_csr, ew=ew, use_node_ids=use_nid)
         fused_relu = getattr(torch, "_addmm_activation", None)
-        if bias is not None and w.is_contiguous() and (act == kernels.ACT_NONE or fused_relu is not None):
+        if (w.is_contiguous() and act in (kernels.ACT_NONE, kernels.ACT_RELU) and kernels.rowgemm16_usable(P, w.shape[0], w.shape[1])
+                and w.data_ptr() % 16 == 0):
+            out = kernels.rowgemm_act(P, w, bias, False, act)     # product, bias and activation in one launch (csrc/rowgemm.hip)
+        elif bias is not None and w.is_contiguous() and (act == kernels.ACT_NONE or fused_relu is not None):
             # bias (+ ReLU) in the library GEMM's epilogue (hipBLASLt): 0.36 ms at [1M, 128] x [128, 128] against
             # 0.42 + 0.17 for rocBLAS + one more pass
             out = fused_relu(bias, P, w) if act == kernels.ACT_RELU else torch.addmm(bias, P, w)

@@ -55,3 +55,27 @@ def test_wide_linear_in_column_slices(cuda):
         scale = x.double().abs() @ w.double().abs().t() + 1
         assert ((got.double() - want).abs() <= 2e-6 * scale).all()
     assert not kernels.wide_linear_usable(x[:1000], w) and not kernels.wide_linear_usable(x, w[:200])
+
+
+@pytest.mark.parametrize("N", [1, 17, 4096, 70_001])
+@pytest.mark.parametrize("K,M", [(128, 128), (64, 128), (128, 64), (64, 64)])
+@pytest.mark.parametrize("trans_w,use_bias,relu", [(False, True, True), (True, False, False), (False, False, True), (True, True, False)])
+def test_row_piece_kernel_with_its_epilogue(cuda, N, K, M, trans_w, use_bias, relu):
+    """stg_rowgemm_act_f32 (16-row tiles in the step kernels' row-piece layout; bias and ReLU in the epilogue): the dense
+    layer of the GCN / GAT configs.  The last tile is partial at every N here but 4096; integer data is exact."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(N + K + 2 * M)
+    x = torch.randn(N, K, device=cuda, generator=gen)
+    w = torch.randn((M, K) if trans_w else (K, M), device=cuda, generator=gen)
+    b = torch.randn(M, device=cuda, generator=gen) if use_bias else None
+    got = kernels.rowgemm_act(x, w, b, trans_w, kernels.ACT_RELU if relu else kernels.ACT_NONE)
+    wd = w.double().t() if trans_w else w.double()
+    want = x.double() @ wd + (b.double() if use_bias else 0)
+    scale = x.double().abs() @ wd.abs() + 1
+    if relu:
+        want = want.relu()
+    assert ((got.double() - want).abs() <= 2e-6 * scale).all()
+    xi = (torch.arange(N * K, device=cuda) % 7 - 3).float().view(N, K)
+    wi = (torch.arange(K * M, device=cuda) % 5 - 2).float().view(w.shape)
+    wid = wi.double().t() if trans_w else wi.double()
+    assert torch.equal(kernels.rowgemm_act(xi, wi, None, trans_w), (xi.double() @ wid).float())
