@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 12
+#define STG_ABI_VERSION 13
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -632,6 +632,13 @@ int stg_xent_fwd(const float *logits, const int64_t *labels, float *lse, float *
                  int64_t n, int32_t K, void *workspace, size_t workspace_bytes, void *stream);
 int stg_xent_bwd(const float *g_loss, const float *logits, const int64_t *labels, const float *lse,
                  const float *n_counted, float *dlogits, int64_t n, int64_t n_total, int32_t K, void *stream);
+/* The same gradient together with its column sums colsum [K] = dlogits.sum(0) -- the bias gradient of the layer that produced the
+ * logits (gcn_conv.py:186 `h + self.bias`), which otherwise re-reads the whole gradient for them.  K % 4 == 0 and K <= 8 x the
+ * kernel's lanes per row (stg_xent_bwd_colsum_workspace_bytes returns 0 for a shape that is not covered); deterministic. */
+size_t stg_xent_bwd_colsum_workspace_bytes(int64_t n_total, int32_t K);
+int stg_xent_bwd_colsum(const float *g_loss, const float *logits, const int64_t *labels, const float *lse,
+                        const float *n_counted, float *dlogits, float *colsum, int64_t n, int64_t n_total, int32_t K,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ----------------------------------------------- dense neighbour: the TGCN harness head
  * The model head and loss of the static-temporal TGCN training step

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
-    "stg_xent_workspace_bytes", "stg_xent_fwd", "stg_xent_bwd",
+    "stg_xent_workspace_bytes", "stg_xent_fwd", "stg_xent_bwd", "stg_xent_bwd_colsum_workspace_bytes", "stg_xent_bwd_colsum",
     "stg_link_head_supported", "stg_link_head_workspace_bytes", "stg_link_head_fwd", "stg_link_head_bwd",
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
@@ -226,6 +226,10 @@ def _load() -> ctypes.CDLL:
     lib.stg_xent_fwd.argtypes = [vp] * 6 + [i64, i32, vp, ctypes.c_size_t, vp]
     lib.stg_xent_bwd.restype = ctypes.c_int
     lib.stg_xent_bwd.argtypes = [vp] * 6 + [i64, i64, i32, vp]
+    lib.stg_xent_bwd_colsum_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_xent_bwd_colsum_workspace_bytes.argtypes = [i64, i32]
+    lib.stg_xent_bwd_colsum.restype = ctypes.c_int
+    lib.stg_xent_bwd_colsum.argtypes = [vp] * 7 + [i64, i64, i32, vp, ctypes.c_size_t, vp]
     lib.stg_link_head_supported.restype = ctypes.c_int
     lib.stg_link_head_supported.argtypes = [i32, i32]
     lib.stg_link_head_workspace_bytes.restype = ctypes.c_size_t

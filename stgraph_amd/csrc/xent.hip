@@ -214,13 +214,18 @@ __global__ __launch_bounds__(kBlock) void xent_bwd_kernel(const float *__restric
 // The same gradient by rows (K % 4 == 0): G lanes per row, 16-byte loads and stores, the row's label and lse read once per row,
 // two rows in flight.  The element form above spends a 64-bit division and two scalar gathers per ELEMENT: 270 us for
 // [1 M, 128] (600 K live rows), whose 0.82 GB take ~140 us.
-template <int G>
+// COLSUM: also partial[block][K] = the column sums of the rows this workgroup wrote (K <= 8 G), added up by
+// xent_colsum_finish_kernel: the gradient's column sums are the bias gradient of the layer that produced the logits, which
+// otherwise re-reads the whole matrix for them (120-150 us at [1 M, 128]).
+template <int G, bool COLSUM>
 __global__ __launch_bounds__(kBlock) void xent_bwd_rows_kernel(const float *__restrict__ g_loss, const float *__restrict__ logits,
                                                                const int64_t *__restrict__ labels, const float *__restrict__ lse,
                                                                float *__restrict__ dlogits, int64_t n, int64_t n_total, int K,
-                                                               const float *__restrict__ n_counted)
+                                                               const float *__restrict__ n_counted, float *__restrict__ partial)
 {
     constexpr int ROWS = kBlock / G, R = 2;
+    __shared__ float4 red[COLSUM ? kBlock * 2 : 1];
+    float4 cs[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     const int g = threadIdx.x / G, j = threadIdx.x % G;
     const float scale = g_loss[0] / n_counted[0];
     const int64_t stride = (int64_t)gridDim.x * ROWS;
@@ -256,8 +261,51 @@ __global__ __launch_bounds__(kBlock) void xent_bwd_rows_kernel(const float *__re
                     o.w = (expf(x[r].w - l[r]) - (tc == 3 ? 1.f : 0.f)) * scale;
                 }
                 *reinterpret_cast<float4 *>(dlogits + row * K + col) = o;
+                if constexpr (COLSUM) {
+                    float4 &c = cs[col >= G * 4 ? 1 : 0];
+                    c = make_float4(c.x + o.x, c.y + o.y, c.z + o.z, c.w + o.w);
+                }
             }
         }
+    }
+    if constexpr (COLSUM) {
+        red[threadIdx.x] = cs[0];
+        red[kBlock + threadIdx.x] = cs[1];
+        __syncthreads();
+        // thread (chunk, j) of the first 2 G: the ROWS lane groups' sums of column piece 4 j + 4 G chunk, in group order
+        if ((int)threadIdx.x < 2 * G) {
+            const int chunk = threadIdx.x / G, jj = threadIdx.x % G, col = (jj + chunk * G) * 4;
+            if (col < K) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < ROWS; ++q) {
+                    const float4 v = red[chunk * kBlock + q * G + jj];
+                    t = make_float4(t.x + v.x, t.y + v.y, t.z + v.z, t.w + v.w);
+                }
+                *reinterpret_cast<float4 *>(partial + (int64_t)blockIdx.x * K + col) = t;
+            }
+        }
+    }
+}
+
+// colsum[f] = sum_b partial[b][f] in a fixed order: 8 columns per workgroup, the partial rows dealt to 32 thread groups
+__global__ __launch_bounds__(kBlock) void xent_colsum_finish_kernel(const float *__restrict__ partial, float *__restrict__ colsum,
+                                                                   int blocks, int K)
+{
+    constexpr int kCols = 8, kGroups = kBlock / kCols;
+    __shared__ float red[kGroups][kCols];
+    const int c = threadIdx.x % kCols, grp = threadIdx.x / kCols;
+    const int f = blockIdx.x * kCols + c;
+    float s = 0.f;
+    if (f < K) {
+#pragma unroll 4
+        for (int b = grp; b < blocks; b += kGroups) s += partial[(int64_t)b * K + f];
+    }
+    red[grp][c] = s;
+    __syncthreads();
+    if (grp == 0 && f < K) {
+        float t = 0.f;
+        for (int q = 0; q < kGroups; ++q) t += red[q][c];
+        colsum[f] = t;
     }
 }
 
@@ -323,26 +371,76 @@ extern "C" int stg_xent_fwd(const float *logits, const int64_t *labels, float *l
     return check_launch("stg_xent_fwd");
 }
 
+namespace stg {
+namespace {
+inline int xent_bwd_row_blocks(int64_t n_total, int K)
+{
+    const int rows = kBlock / xent_lanes(K);
+    return (int)std::min<int64_t>((n_total + rows - 1) / rows, 256 * 16);
+}
+
+int xent_bwd_launch(const float *g_loss, const float *logits, const int64_t *labels, const float *lse, const float *n_counted,
+                    float *dlogits, float *colsum, float *partial, int64_t n, int64_t n_total, int32_t K, hipStream_t st)
+{
+    const bool rows_ok = K % 4 == 0 && reinterpret_cast<uintptr_t>(logits) % 16 == 0 && reinterpret_cast<uintptr_t>(dlogits) % 16 == 0;
+    if (rows_ok) {
+        const int G = xent_lanes(K), rblocks = xent_bwd_row_blocks(n_total, K);
+#define STG_XBWD(G_)                                                                                                          \
+    if (colsum)                                                                                                               \
+        hipLaunchKernelGGL((xent_bwd_rows_kernel<G_, true>), dim3(rblocks), dim3(kBlock), 0, st, g_loss, logits, labels, lse,  \
+                           dlogits, n, n_total, K, n_counted, partial);                                                        \
+    else                                                                                                                      \
+        hipLaunchKernelGGL((xent_bwd_rows_kernel<G_, false>), dim3(rblocks), dim3(kBlock), 0, st, g_loss, logits, labels, lse, \
+                           dlogits, n, n_total, K, n_counted, nullptr)
+        switch (G) {
+            case 8: STG_XBWD(8); break;
+            case 32: STG_XBWD(32); break;
+            default: STG_XBWD(64); break;
+        }
+#undef STG_XBWD
+        if (colsum)
+            hipLaunchKernelGGL(xent_colsum_finish_kernel, dim3((K + 7) / 8), dim3(kBlock), 0, st, partial, colsum, rblocks, K);
+        return 0;
+    }
+    const int64_t total = n_total * (int64_t)K;
+    const int blocks = (int)std::min<int64_t>((total + kBlock - 1) / kBlock, 256 * 16);
+    hipLaunchKernelGGL(xent_bwd_kernel, dim3(blocks), dim3(kBlock), 0, st, g_loss, logits, labels, lse, dlogits, n, n_total, K,
+                       n_counted);
+    return 0;
+}
+}  // namespace
+}  // namespace stg
+
 extern "C" int stg_xent_bwd(const float *g_loss, const float *logits, const int64_t *labels, const float *lse,
                             const float *n_counted, float *dlogits, int64_t n, int64_t n_total, int32_t K, void *stream_)
 {
     using namespace stg;
     if (n <= 0 || K <= 0 || n_total < n) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd: bad shape");
     if (!g_loss || !logits || !labels || !lse || !n_counted || !dlogits) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd: NULL pointer argument");
-    const int64_t total = n_total * (int64_t)K;
-    if (K % 4 == 0 && reinterpret_cast<uintptr_t>(logits) % 16 == 0 && reinterpret_cast<uintptr_t>(dlogits) % 16 == 0) {
-        const int G = xent_lanes(K), rows = kBlock / G;
-        const int rblocks = (int)std::min<int64_t>((n_total + rows - 1) / rows, 256 * 16);
-        hipStream_t st = static_cast<hipStream_t>(stream_);
-        switch (G) {
-            case 8: hipLaunchKernelGGL((xent_bwd_rows_kernel<8>), dim3(rblocks), dim3(kBlock), 0, st, g_loss, logits, labels, lse, dlogits, n, n_total, K, n_counted); break;
-            case 32: hipLaunchKernelGGL((xent_bwd_rows_kernel<32>), dim3(rblocks), dim3(kBlock), 0, st, g_loss, logits, labels, lse, dlogits, n, n_total, K, n_counted); break;
-            default: hipLaunchKernelGGL((xent_bwd_rows_kernel<64>), dim3(rblocks), dim3(kBlock), 0, st, g_loss, logits, labels, lse, dlogits, n, n_total, K, n_counted); break;
-        }
-        return check_launch("stg_xent_bwd");
-    }
-    const int blocks = (int)std::min<int64_t>((total + kBlock - 1) / kBlock, 256 * 16);
-    hipLaunchKernelGGL(xent_bwd_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream_), g_loss, logits, labels,
-                       lse, dlogits, n, n_total, K, n_counted);
+    xent_bwd_launch(g_loss, logits, labels, lse, n_counted, dlogits, nullptr, nullptr, n, n_total, K, static_cast<hipStream_t>(stream_));
     return check_launch("stg_xent_bwd");
+}
+
+extern "C" size_t stg_xent_bwd_colsum_workspace_bytes(int64_t n_total, int32_t K)
+{
+    if (n_total <= 0 || K <= 0 || K % 4 != 0 || K > 8 * stg::xent_lanes(K)) return 0;          // 0: shape not covered
+    return sizeof(float) * (size_t)stg::xent_bwd_row_blocks(n_total, K) * (size_t)K;
+}
+
+extern "C" int stg_xent_bwd_colsum(const float *g_loss, const float *logits, const int64_t *labels, const float *lse,
+                                   const float *n_counted, float *dlogits, float *colsum, int64_t n, int64_t n_total, int32_t K,
+                                   void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    if (n <= 0 || K <= 0 || n_total < n) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd_colsum: bad shape");
+    if (!g_loss || !logits || !labels || !lse || !n_counted || !dlogits || !colsum || !workspace)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_bwd_colsum: NULL pointer argument");
+    const size_t need = stg_xent_bwd_colsum_workspace_bytes(n_total, K);
+    if (need == 0 || reinterpret_cast<uintptr_t>(logits) % 16 != 0 || reinterpret_cast<uintptr_t>(dlogits) % 16 != 0 ||
+        reinterpret_cast<uintptr_t>(workspace) % 16 != 0)
+        return fail(STG_ERR_UNSUPPORTED, "stg_xent_bwd_colsum: needs K %% 4 == 0, K <= 8 lanes-per-row and 16-byte aligned matrices (K=%d)", K);
+    if (workspace_bytes < need) return fail(STG_ERR_WORKSPACE, "stg_xent_bwd_colsum: workspace %zu < required %zu", workspace_bytes, need);
+    xent_bwd_launch(g_loss, logits, labels, lse, n_counted, dlogits, colsum, static_cast<float *>(workspace), n, n_total, K,
+                    static_cast<hipStream_t>(stream_));
+    return check_launch("stg_xent_bwd_colsum");
 }

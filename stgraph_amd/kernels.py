@@ -1454,12 +1454,23 @@ def xent_fwd(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None
 
 
 def xent_bwd(g_loss: torch.Tensor, logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor,
-             n_counted: torch.Tensor) -> torch.Tensor:
+             n_counted: torch.Tensor, want_colsum: bool = False):
     """Gradient of xent_fwd for the WHOLE logits matrix: rows beyond ``lse.shape[0]`` (not part of the loss) and rows
-    the forward did not count are zero."""
+    the forward did not count are zero.  ``want_colsum``: returns ``(gradient, gradient.sum(0))`` from the same launch
+    (stg_xent_bwd_colsum) -- the column sums are None for a shape that entry point does not cover."""
     n_total, K = logits.shape
     n = int(lse.shape[0])
     d = torch.empty_like(logits)
+    if want_colsum:
+        ws_bytes = int(_C.lib.stg_xent_bwd_colsum_workspace_bytes(n_total, K))
+        if ws_bytes == 0 or logits.data_ptr() % 16 or d.data_ptr() % 16:
+            return xent_bwd(g_loss, logits, labels, lse, n_counted), None
+        cs = torch.empty(K, dtype=torch.float32, device=logits.device)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
+        with torch.cuda.device(logits.device), _Timed("xent_bwd", 4 * n * (2 * K + 3) + 4 * (n_total - n) * K, 4 * n * K):
+            _C.check(_C.lib.stg_xent_bwd_colsum(_ptr(g_loss), _ptr(logits), _ptr(labels), _ptr(lse), _ptr(n_counted), _ptr(d),
+                                                _ptr(cs), n, n_total, K, _ptr(ws), ws_bytes, _stream_ptr(logits.device)))
+        return d, cs
     with torch.cuda.device(logits.device), _Timed("xent_bwd", 4 * n * (2 * K + 3) + 4 * (n_total - n) * K, 4 * n * K):
         _C.check(_C.lib.stg_xent_bwd(_ptr(g_loss), _ptr(logits), _ptr(labels), _ptr(lse), _ptr(n_counted), _ptr(d), n,
                                      n_total, K, _stream_ptr(logits.device)))

@@ -202,7 +202,12 @@ class _CrossEntropy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         logits, labels, lse, n_counted = ctx.saved_tensors
-        return kernels.xent_bwd(g.contiguous(), logits, labels, lse, n_counted), None, None
+        d, colsum = kernels.xent_bwd(g.contiguous(), logits, labels, lse, n_counted, want_colsum=True)
+        if colsum is not None:
+            # the gradient's column sums ride along on the tensor object: a bias layer right below the loss (GCNConv's
+            # `h + self.bias`) takes them as its bias gradient instead of re-reading the matrix (_GcnLayerTail.backward)
+            d._stg_colsum = colsum
+        return d, None, None
 
 
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None) -> torch.Tensor:
@@ -355,10 +360,13 @@ class _GcnLayerTail(torch.autograd.Function):
     def backward(ctx, g):
         out, norm, ew = ctx.saved_tensors
         ew = ew if ctx.has_ew else None
+        known = getattr(g, "_stg_colsum", None)          # column sums of THIS tensor object, left by the loss's backward
         g = g.contiguous()
         want_b = ctx.has_bias and ctx.needs_input_grad[1]
         gb = None
-        if ctx.act != kernels.ACT_NONE or want_b:
+        if ctx.act == kernels.ACT_NONE and want_b and known is not None and known.numel() == g.shape[-1] and g.dim() == 2:
+            gb = known
+        elif ctx.act != kernels.ACT_NONE or want_b:
             g, gb = kernels.bias_act_bwd(g, out if ctx.act != kernels.ACT_NONE else None, want_colsum=want_b)
         gh = None
         if ctx.needs_input_grad[0]:

@@ -126,3 +126,60 @@ def test_row_prefix_without_slicing(cuda, n_total, rows, K):
     torch.testing.assert_close(la, lb, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-9)
     assert not a.grad[rows:].any()
+
+
+@pytest.mark.parametrize("n_total,n,K", [(1000, 600, 128), (70_001, 70_001, 128), (5000, 4999, 8), (3000, 100, 256), (2708, 1624, 16)])
+def test_backward_with_column_sums(cuda, n_total, n, K):
+    """stg_xent_bwd_colsum: the same gradient as stg_xent_bwd bit for bit, and its column sums (the bias gradient of a layer
+    right below the loss) to fp32 rounding of a 64-bit sum; twice the same result (fixed summation order)."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(n_total + K)
+    logits = torch.randn(n_total, K, device=cuda, generator=gen)
+    labels = torch.randint(0, K, (n_total,), device=cuda, generator=gen)
+    labels[::7] = -100
+    loss, lse, n_counted, _ = kernels.xent_fwd(logits, labels, n)
+    g = torch.tensor([0.7], device=cuda)
+    plain = kernels.xent_bwd(g, logits, labels, lse, n_counted)
+    d, cs = kernels.xent_bwd(g, logits, labels, lse, n_counted, want_colsum=True)
+    assert cs is not None and torch.equal(d, plain)
+    want = plain.double().sum(0)
+    assert ((cs.double() - want).abs() <= 1e-5 * plain.double().abs().sum(0) + 1e-12).all()
+    d2, cs2 = kernels.xent_bwd(g, logits, labels, lse, n_counted, want_colsum=True)
+    assert torch.equal(cs, cs2)
+
+
+def test_bias_gradient_of_the_layer_below_the_loss_comes_from_the_loss_backward(cuda):
+    """A GCNConv (bias, no activation) right below SF.cross_entropy: its bias gradient is the column sums the loss's backward
+    left on the gradient tensor, and equals the separate pass over the matrix."""
+    import numpy as np
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gcn_conv import GCNConv
+    from tests.util import gcn_norm, random_graph
+    n, e, fin, K = 3000, 30000, 32, 16
+    src, dst = random_graph(5, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    g.set_ndata("norm", torch.from_numpy(gcn_norm(np.bincount(dst, minlength=n))).to(cuda))
+    torch.manual_seed(0)
+    conv = GCNConv(fin, K).to(cuda)
+    x = torch.randn(n, fin, device=cuda)
+    labels = torch.randint(0, K, (n,), device=cuda)
+    calls = []
+    real = kernels.bias_act_bwd
+
+    def counting(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    kernels.bias_act_bwd = counting
+    try:
+        SF.cross_entropy(conv(g, x), labels, 1800).backward()
+        fused = conv.bias.grad.clone()
+        assert not calls                                       # no separate pass for the bias gradient
+        conv.zero_grad()
+        logits = conv(g, x)
+        torch.nn.functional.cross_entropy(logits[:1800], labels[:1800]).backward()
+        assert calls
+    finally:
+        kernels.bias_act_bwd = real
+    torch.testing.assert_close(fused, conv.bias.grad, rtol=1e-4, atol=1e-7)
