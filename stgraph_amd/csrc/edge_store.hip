@@ -94,17 +94,6 @@ __global__ void pack_batch(const int *__restrict__ src, const int *__restrict__ 
 constexpr int kMergeItems = 8;
 constexpr int kMergeSlice = 1024;        // batch entries per tile kept in LDS (2 x 8 KiB)
 
-__device__ __forceinline__ int64_t upper_bound_dev(const uint64_t *__restrict__ a, int64_t n, uint64_t k)
-{
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (a[mid] <= k) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
-
 // lower (UPPER = false) / upper bound of k in a[0 .. n) by one WAVE: every round the 64 lanes probe the last entries of 64 equal
 // chunks and a ballot keeps one chunk -- three dependent loads for the 6 K entries of a batch where a lane's binary search has 13.
 template <bool UPPER>
