@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 13
+#define STG_ABI_VERSION 14
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -582,6 +582,13 @@ typedef struct stg_tgcn_step_bwd_args {
     int64_t N;
     int32_t C, Fin, Fh, head;
     float lo, hi;
+    /* head == 1, optional (link_row_ptr NULL: not used): the node side of the link-prediction loss's backward taken in this
+     * launch instead of stg_link_decode_bwd before it -- g_y[v] += sum over the label edges incident to v, in the order of
+     * the node-sorted incidence list (link_row_ptr [N + 1], link_other, link_eid: stg_link_head_bwd's), of
+     * (sigmoid(link_logits[e]) - link_target[e]) * g_cost[0] * link_inv_m * link_y[other end] (link_y = this step's y [N,Fh]). */
+    const int32_t *link_row_ptr, *link_other, *link_eid;
+    const float *link_y, *link_logits, *link_target;
+    float link_inv_m;
 } stg_tgcn_step_bwd_args;
 int    stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh);
 size_t stg_tgcn_step_loss_partials(int64_t N);

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -65,7 +65,8 @@ class TgcnStepBwdArgs(ctypes.Structure):
     _fields_ = (_ptr_fields("row_offsets column_indices node_ids norm_col_edge ew_edge norm zn g_y dHn g_cost "
                             "Z R Ht H Hn x3 y_out target WzT WrT WhT Wcat W1T W2 dzl drl dhl da3 dH z dyt dyo clamp_mask") +
                 [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
-                 ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)])
+                 ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)] +
+                _ptr_fields("link_row_ptr link_other link_eid link_y link_logits link_target") + [("link_inv_m", ctypes.c_float)])
 
 
 class StgError(RuntimeError):

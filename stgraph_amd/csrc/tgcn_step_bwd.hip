@@ -13,6 +13,9 @@ struct BwdArgs {
     const float *WzT, *WrT, *WhT, *Wcat, *W1T, *W2;
     float *dzl, *drl, *dhl, *da3, *dH, *z, *dyt, *dyo;
     const unsigned *mask;
+    const int *link_row_ptr, *link_other, *link_eid;           // node side of the link loss's backward (head == 1; NULL: not here)
+    const float *link_y, *link_logits, *link_target;
+    float link_inv_m;
     int64_t N;
     float lo, hi, two_over_n;
     int num_tiles;
@@ -156,6 +159,44 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         if (a.mask) mlo = (m0 & 0xffffu) | (m1 << 16), mhi = m2 & 0xffffu;
 
         // ---- gradient reaching Hn: from the next step (dHn) and through the head --------------------------------
+        if constexpr (HEAD == 1) {
+            // The node side of the link-prediction loss (stg_link_decode_bwd's sum, term for term and in its order): the label
+            // edges incident to this lane's row, four at a time -- indices first, then logits / targets / the other ends' rows of y.
+            if (a.link_row_ptr) {                                    // block-uniform
+                const int kb = a.link_row_ptr[row], ke = a.link_row_ptr[row + 1];
+                const float scale = a.g_cost[0] * a.link_inv_m;
+                const int kmax = wave_max_nonneg(ke - kb);
+                for (int k0 = 0; k0 < kmax; k0 += 4) {
+                    int e[4], o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = kb + k0 + u < ke;
+                        e[u] = ok ? a.link_eid[kb + k0 + u] : 0;
+                        o[u] = ok ? a.link_other[kb + k0 + u] : 0;
+                    }
+                    float x[4], t[4];
+                    float4 yo[4][PH];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        x[u] = a.link_logits[e[u]];
+                        t[u] = a.link_target[e[u]];
+#pragma unroll
+                        for (int j = 0; j < PH; ++j) yo[u][j] = ld_f4(a.link_y, ((unsigned)o[u] * FH + 4u * kq) * 4u, 64 * j);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (kb + k0 + u < ke) {
+                            const float sig = 1.0f / (1.0f + __expf(-x[u]));
+                            const float coef = (sig - t[u]) * scale;
+#pragma unroll
+                            for (int j = 0; j < PH; ++j)
+                                gy[j] = make_float4(gy[j].x + coef * yo[u][j].x, gy[j].y + coef * yo[u][j].y,
+                                                    gy[j].z + coef * yo[u][j].z, gy[j].w + coef * yo[u][j].w);
+                        }
+                    }
+                }
+            }
+        }
         if constexpr (HEAD != 0) {
 #pragma unroll
             for (int j = 0; j < PH; ++j) gy[j] = make_float4(gy[j].x + gp[j].x, gy[j].y + gp[j].y, gy[j].z + gp[j].z, gy[j].w + gp[j].w);
@@ -348,6 +389,13 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     a.Z = p->Z; a.R = p->R; a.Ht = p->Ht; a.H = p->H; a.Hn = p->Hn; a.x3 = p->x3; a.y_out = p->y_out; a.target = p->target;
     a.WzT = p->WzT; a.WrT = p->WrT; a.WhT = p->WhT; a.Wcat = p->Wcat; a.W1T = p->W1T; a.W2 = p->W2;
     a.mask = p->clamp_mask;
+    if (p->link_row_ptr) {
+        if (p->head != 1 || !p->link_other || !p->link_eid || !p->link_y || !p->link_logits || !p->link_target || !p->g_cost ||
+            !(p->link_inv_m > 0.f))
+            return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: the link-loss arguments need head == 1, g_cost and every link_* field");
+        a.link_row_ptr = p->link_row_ptr; a.link_other = p->link_other; a.link_eid = p->link_eid;
+        a.link_y = p->link_y; a.link_logits = p->link_logits; a.link_target = p->link_target; a.link_inv_m = p->link_inv_m;
+    }
     a.dzl = p->dzl; a.drl = p->drl; a.dhl = p->dhl; a.da3 = p->da3; a.dH = p->dH; a.z = p->z; a.dyt = p->dyt; a.dyo = p->dyo;
     a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.two_over_n = 2.0f / (float)p->N; a.num_tiles = (int)((p->N + 15) / 16);
     hipStream_t st = static_cast<hipStream_t>(stream_);

@@ -1264,7 +1264,7 @@ def tgcn_step_loss_partials(N: int) -> int:
     return int(_C.lib.stg_tgcn_step_loss_partials(int(N)))
 
 
-_STEP_INT_FIELDS = ("row_offsets", "column_indices", "node_ids")
+_STEP_INT_FIELDS = ("row_offsets", "column_indices", "node_ids", "link_row_ptr", "link_other", "link_eid")
 
 
 def _fill_step_args(args, what: str, dev: torch.device, tensors: dict) -> None:
@@ -1294,13 +1294,16 @@ def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
         _C.check(_C.lib.stg_tgcn_step_fwd(ctypes.byref(a), _stream_ptr(dev)))
 
 
-def tgcn_step_bwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: float, device, **tensors) -> None:
+def tgcn_step_bwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: float, device, link_edges: int = 0,
+                  **tensors) -> None:
     """One TGCN step backward in one launch (stg_tgcn_step_bwd); ``tensors``: the pointer fields of
-    stg_tgcn_step_bwd_args by name."""
+    stg_tgcn_step_bwd_args by name.  With ``link_row_ptr / link_other / link_eid / link_y / link_logits / link_target`` (and
+    ``link_edges`` = the number of label edges) the node side of the link loss's backward runs inside the launch."""
     dev = torch.device(device)
     a = _C.TgcnStepBwdArgs()
     _fill_step_args(a, "tgcn_step_bwd", dev, tensors)
     a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
+    a.link_inv_m = 1.0 / float(link_edges) if link_edges else 0.0
     per_row = 4 * (6 * C + 3 * C + 3 * C + 3 * C + C + Fin + (2 * Fh + 3 if head else 0))
     with torch.cuda.device(dev), _Timed("tgcn_step_bwd", N * per_row, 2 * N * (6 * C * C + 3 * C * Fin + (Fh * C if head else 0))):
         _C.check(_C.lib.stg_tgcn_step_bwd(ctypes.byref(a), _stream_ptr(dev)))

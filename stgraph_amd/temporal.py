@@ -460,7 +460,7 @@ class _TGCNDynWindow(torch.autograd.Function):
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), new(B, N, 3 * C)
         dyt = new(B, N, Fh)
-        dH, zbuf, dy = new(2, N, C), new(2, N, Fin), new(N, Fh)
+        dH, zbuf = new(2, N, C), new(2, N, Fin)
         WzT, WrT, WhT, W1T = (w.t().contiguous() for w in (Wz, Wr, Wh, W1))
         want_dx0 = ctx.needs_input_grad[0]
         with torch.cuda.device(dev):
@@ -469,14 +469,17 @@ class _TGCNDynWindow(torch.autograd.Function):
         for t in range(B - 1, -1, -1):
             st, last = steps[t], t == B - 1
             nxt = None if last else steps[t + 1]                 # the gather of z_{t+1} runs over snapshot t + 1's backward CSR
-            kernels.link_decode_bwd(g, Y[t], logits[t], st["targets"], st["incidence"], dy)
+            # the node side of the link loss's backward runs inside the step launch (stg_tgcn_step_bwd's link_* fields)
+            row_ptr, other, eid = st["incidence"]
             kw = {}
             if nxt is not None:
                 b = nxt["bwd"]
                 kw = dict(row_offsets=b.row_offset, column_indices=b.column_indices,
                           node_ids=None, norm_col_edge=nxt["nc_b"], ew_edge=None,
                           norm=nxt["normv"], zn=zbuf[(t + 1) & 1], dHn=dH[(t + 1) & 1])
-            kernels.tgcn_step_bwd(N, C, Fin, Fh, 1, lo, hi, dev, g_y=dy, Z=Z[t], R=R[t], Ht=Ht[t],
+            kernels.tgcn_step_bwd(N, C, Fin, Fh, 1, lo, hi, dev, link_edges=int(logits[t].shape[0]), g_cost=g, link_row_ptr=row_ptr,
+                                  link_other=other, link_eid=eid, link_y=Y[t], link_logits=logits[t], link_target=st["targets"],
+                                  Z=Z[t], R=R[t], Ht=Ht[t],
                                   H=None if t == 0 else Hn[t - 1], Hn=Hn[t], clamp_mask=mask[t], WzT=WzT, WrT=WrT, WhT=WhT,
                                   Wcat=Wcat, W1T=W1T, dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=da3[t], dH=dH[t & 1],
                                   z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], **kw)

@@ -257,3 +257,43 @@ def test_cell_only_mode_matches_the_gather_mode(cuda):
                           HR=out["HR"], clamp_mask=None)
     for k in ("x3", "Z", "R", "Ht", "Hn", "HR"):
         _close(out[k], full[k], k, 1e-5)
+
+
+@pytest.mark.parametrize("n,e,m", [(3001, 30000, 5000), (17, 60, 40), (25_000, 250_000, 12_500)])
+def test_link_loss_backward_inside_the_step_launch(cuda, n, e, m):
+    """head == 1 with the link_* fields: the node side of the link-prediction loss's backward (stg_link_decode_bwd) taken inside
+    the backward step launch -- every output bit for bit what the two launches produce (same terms, same order)."""
+    from stgraph_amd import kernels
+    g, e = _graph(cuda, n, e, seed=n + 3)
+    gen = torch.Generator(device=cuda).manual_seed(n + 4)
+    deg = (g.fwd.row_offset[1:] - g.fwd.row_offset[:-1]).float()
+    norm = torch.where(deg > 0, deg.clamp(min=1) ** -0.5, torch.zeros_like(deg)).view(-1, 1)
+    p = _params(cuda, n + 5)
+    x0 = torch.randn(n, FIN, device=cuda, generator=gen)
+    H = torch.randn(n, C, device=cuda, generator=gen) * 0.3
+    s = _fwd(cuda, g, norm, None, p, x0, H, torch.zeros(n, device=cuda), n, head=1)
+    edge_index = torch.randint(0, n, (2, m), device=cuda, generator=gen)
+    target = (torch.rand(m, device=cuda, generator=gen) < 0.5).float()
+    y = s["y"]
+    logits = (y[edge_index[0]] * y[edge_index[1]]).sum(1).contiguous()
+    inc = kernels.link_incidence(edge_index, n)
+    g_cost = torch.tensor([0.61], device=cuda)
+    zn = torch.randn(n, FIN, device=cuda, generator=gen)
+    dHn = torch.randn(n, C, device=cuda, generator=gen)
+    nc = kernels._edge_gathered(g.bwd, "norm", norm, g.bwd.column_indices)
+
+    def run(**kw):
+        new = lambda *sh: torch.full(sh, float("nan"), device=cuda)  # noqa: E731
+        out = dict(dzl=new(n, C), drl=new(n, C), dhl=new(n, C), da3=new(n, 3 * C), dH=new(n, C), dyt=new(n, FH), z=new(n, FIN))
+        kernels.tgcn_step_bwd(n, C, FIN, FH, 1, LO, HI, cuda, row_offsets=g.bwd.row_offset, column_indices=g.bwd.column_indices,
+                              norm_col_edge=nc, norm=norm.view(-1), zn=zn, dHn=dHn, Z=s["Z"], R=s["R"], Ht=s["Ht"], H=H,
+                              Hn=s["Hn"], clamp_mask=s["clamp_mask"], WzT=p["Wz"].t().contiguous(), WrT=p["Wr"].t().contiguous(),
+                              WhT=p["Wh"].t().contiguous(), Wcat=p["Wcat"], W1T=p["W1"].t().contiguous(), **out, **kw)
+        return out
+    dy = torch.empty(n, FH, device=cuda)
+    kernels.link_decode_bwd(g_cost, y, logits, target, inc, dy)
+    two = run(g_y=dy)
+    one = run(link_edges=m, g_cost=g_cost, link_row_ptr=inc[0], link_other=inc[1], link_eid=inc[2], link_y=y, link_logits=logits,
+              link_target=target)
+    for k in two:
+        assert torch.equal(one[k], two[k]), k
