@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 14
+#define STG_ABI_VERSION 15
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -503,6 +503,16 @@ int stg_gemm_tn_form_f32(const float *const *A, int32_t lda, const float *const 
                          const float *const *B2, int32_t ldb2, int32_t b_op, float lo, float hi, int32_t T, float *C,
                          float *colsum_A, int64_t K, int32_t M, int32_t N, void *workspace, size_t workspace_bytes,
                          void *stream);
+/* The same contraction WITHOUT its final reduction: the split-K slabs stay in `workspace` (size as stg_gemm_tn_form_workspace_bytes)
+ * and their count is written to *slabs; stg_gemm_tn_reduce_multi_f32 then sums the slabs of up to 8 products in ONE launch into
+ * C[i] [M[i], N[i]] and colsum[i] [M[i]] (NULL where the product was run with want_colsum = 0) -- same arithmetic and order as the
+ * one-product form.  A BPTT window's six weight gradients take one reduction launch instead of six. */
+int stg_gemm_tn_form_partial_f32(const float *const *A, int32_t lda, const float *const *B, int32_t ldb, int32_t nsplit,
+                                 const float *const *B2, int32_t ldb2, int32_t b_op, float lo, float hi, int32_t T,
+                                 int32_t want_colsum, int64_t K, int32_t M, int32_t N, void *workspace, size_t workspace_bytes,
+                                 int32_t *slabs, void *stream);
+int stg_gemm_tn_reduce_multi_f32(int32_t count, const float *const *slabs, float *const *C, float *const *colsum,
+                                 const int32_t *M, const int32_t *N, const int32_t *S, void *stream);
 
 /* The whole forward chain of the six stages below in ONE launch for C = 32 or 64 (hidden width): bias + clamp,
  * the three gate GEMMs on the fp32 matrix cores with the gate weights (torch Linear layout [C][2C]) resident in

@@ -531,6 +531,47 @@ __global__ __launch_bounds__(kBlock) void gemm_tn_reduce_kernel(const float *__r
     }
 }
 
+// The same reduction for up to kReduceJobs products in ONE launch (blockIdx.y = job): a BPTT window's six weight-gradient
+// contractions leave their slabs and are summed together (six 9 us launches otherwise, at the launch floor).
+constexpr int kReduceJobs = 8;
+struct ReduceJobs {
+    const float *slab[kReduceJobs];
+    float *C[kReduceJobs], *CS[kReduceJobs];
+    int64_t MNc[kReduceJobs], MN[kReduceJobs];
+    int S[kReduceJobs];
+};
+__global__ __launch_bounds__(kBlock) void gemm_tn_reduce_multi_kernel(const ReduceJobs jobs)
+{
+    __shared__ float part[kWavesPerBlock][kWave];
+    const int job = blockIdx.y;
+    const float *__restrict__ slab = jobs.slab[job];
+    const int64_t MNc = jobs.MNc[job], MN = jobs.MN[job];
+    const int S = jobs.S[job];
+    if ((int64_t)blockIdx.x * kWave >= MNc) return;              // block-uniform: this job has fewer outputs than the widest
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x >> 6;
+    const int64_t o = (int64_t)blockIdx.x * kWave + lane;
+    float acc = 0.f;
+    if (o < MNc) {                                               // (arithmetic and order of gemm_tn_reduce_kernel)
+        int s = w;
+        for (; s + 7 * kWavesPerBlock < S; s += 8 * kWavesPerBlock) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(s + u * kWavesPerBlock) * MNc + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; s < S; s += kWavesPerBlock) acc += slab[(int64_t)s * MNc + o];
+    }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && o < MNc) {
+        const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        if (o < MN) jobs.C[job][o] = tot;
+        else jobs.CS[job][o - MN] = tot;
+    }
+}
+
 namespace {
 
 struct GemmPlan {
@@ -626,8 +667,11 @@ namespace stg {
 namespace {
 int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C, float *colsum, int64_t K,
                 int32_t M, int32_t N, void *workspace, size_t workspace_bytes, void *stream_, const char *what,
-                const float *const *B2s = nullptr, const GemmForm *form_in = nullptr, const float *const *AMs = nullptr)
+                const float *const *B2s = nullptr, const GemmForm *form_in = nullptr, const float *const *AMs = nullptr,
+                int *defer_slabs = nullptr)
 {
+    // defer_slabs (non-NULL): leave the slabs in the workspace, write their count there and skip the reduction
+    // (stg_gemm_tn_reduce_multi_f32 sums several products' slabs in one launch); C / colsum then only say what is wanted.
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (K < 0 || M <= 0 || N <= 0 || T <= 0 || T > kGemmMaxSeg)
         return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad shape T=%d K=%lld M=%d N=%d (T <= %d)", what, T,
@@ -635,6 +679,7 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
     if ((int64_t)2 * M * N > INT32_MAX || (int64_t)2 * M > INT32_MAX / 2)
         return fail(STG_ERR_UNSUPPORTED, "%s: output %d x %d too large for the tall-skinny kernel", what, M, N);
     if (!C) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL output", what);
+    if (K == 0 && defer_slabs) return fail(STG_ERR_INVALID_ARGUMENT, "%s: K = 0 has no slabs to defer", what);
     if (K == 0) {
         hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, stream);
         if (e == hipSuccess && colsum) e = hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)M, stream);
@@ -703,6 +748,10 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         else return fail(STG_ERR_UNSUPPORTED, "%s: no wide instantiation for this tile", what);
 #undef STG_WIDE
 #undef STG_WIDE_L
+        if (defer_slabs) {
+            *defer_slabs = S_total;
+            return check_launch(what);
+        }
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MNc + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
                            slab, C, colsum, MNc, MN, S_total);
         return check_launch(what);
@@ -728,6 +777,10 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
     }
 #undef STG_GEMM_NT
 #undef STG_GEMM_LAUNCH
+    if (defer_slabs) {
+        *defer_slabs = S_total;
+        return check_launch(what);
+    }
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MNc + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
                        slab, C, colsum, MNc, MN, S_total);
     return check_launch(what);
@@ -771,6 +824,46 @@ extern "C" int stg_gemm_tn_form_f32(const float *const *A, int32_t lda, const fl
     const stg::GemmForm form{lda, ldb, ldb2, nsplit, b_op, lo, hi, 0};
     return stg::gemm_tn_run(A, B, T, C, colsum_A, K, M, N, workspace, workspace_bytes, stream, "stg_gemm_tn_form_f32", B2,
                             &form);
+}
+
+extern "C" int stg_gemm_tn_form_partial_f32(const float *const *A, int32_t lda, const float *const *B, int32_t ldb, int32_t nsplit,
+                                            const float *const *B2, int32_t ldb2, int32_t b_op, float lo, float hi, int32_t T,
+                                            int32_t want_colsum, int64_t K, int32_t M, int32_t N, void *workspace,
+                                            size_t workspace_bytes, int32_t *slabs, void *stream)
+{
+    if (!slabs) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_form_partial_f32: NULL slab count");
+    if (K <= 0) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_form_partial_f32: K must be positive");
+    const stg::GemmForm form{lda, ldb, ldb2, nsplit, b_op, lo, hi, 0};
+    float dummy = 0.f;                                      // gemm_tn_run only looks at which outputs are wanted here
+    int S = 0;
+    const int rc = stg::gemm_tn_run(A, B, T, &dummy, want_colsum ? &dummy : nullptr, K, M, N, workspace, workspace_bytes, stream,
+                                    "stg_gemm_tn_form_partial_f32", B2, &form, nullptr, &S);
+    *slabs = S;
+    return rc;
+}
+
+extern "C" int stg_gemm_tn_reduce_multi_f32(int32_t count, const float *const *slabs, float *const *C, float *const *colsum,
+                                            const int32_t *M, const int32_t *N, const int32_t *S, void *stream)
+{
+    using namespace stg;
+    if (count <= 0 || count > kReduceJobs) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_reduce_multi_f32: 1 .. %d products per call", kReduceJobs);
+    if (!slabs || !C || !colsum || !M || !N || !S) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_reduce_multi_f32: NULL pointer argument");
+    ReduceJobs jobs{};
+    int64_t widest = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!slabs[i] || !C[i] || M[i] <= 0 || N[i] <= 0 || S[i] <= 0)
+            return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_reduce_multi_f32: bad product %d", i);
+        jobs.slab[i] = slabs[i];
+        jobs.C[i] = C[i];
+        jobs.CS[i] = colsum[i];
+        jobs.MN[i] = (int64_t)M[i] * N[i];
+        jobs.MNc[i] = jobs.MN[i] + (colsum[i] ? M[i] : 0);
+        jobs.S[i] = S[i];
+        widest = std::max(widest, jobs.MNc[i]);
+    }
+    hipLaunchKernelGGL(gemm_tn_reduce_multi_kernel, dim3((unsigned)((widest + kWave - 1) / kWave), (unsigned)count), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), jobs);
+    return check_launch("stg_gemm_tn_reduce_multi_f32");
 }
 
 extern "C" int stg_gemm_tn_relu_mask_f32(const float *A, const float *mask, const float *B, float *C, float *colsum_A,

@@ -1255,6 +1255,57 @@ def gemm_tn_form(As, Bs, M: int, N: int, B2s=None, nsplit: int | None = None, b_
     return (c_tot, cs_tot) if colsum else c_tot
 
 
+GEMM_REDUCE_JOBS = 8
+
+
+def gemm_tn_form_batch(calls):
+    """Several :func:`gemm_tn_form` contractions whose final reductions run as ONE launch (stg_gemm_tn_form_partial_f32 per
+    product, then stg_gemm_tn_reduce_multi_f32): ``calls`` is a list of keyword dicts for ``gemm_tn_form``; returns the list of
+    its results, same values bit for bit.  Products with more than 32 segments, or more than 8 of them, go one by one."""
+    if len(calls) > GEMM_REDUCE_JOBS or any(len(c["As"]) > MAX_GEMM_SEGMENTS for c in calls) or len(calls) < 2:
+        return [gemm_tn_form(**c) for c in calls]
+    dev = calls[0]["As"][0].device
+    outs, keep = [], []
+    slabs_p, c_p, cs_p = [], [], []
+    Ms, Ns, Ss = [], [], []
+    with torch.cuda.device(dev):
+        for c in calls:
+            As, Bs, M, N = c["As"], c["Bs"], int(c["M"]), int(c["N"])
+            B2s, nsplit = c.get("B2s"), c.get("nsplit")
+            nsplit = N if nsplit is None else int(nsplit)
+            colsum = bool(c.get("colsum", False))
+            K, T = int(As[0].shape[0]), len(As)
+            lda = max(int(As[0].stride(0)), M)
+            ldb = max(int(Bs[0].stride(0)), nsplit)
+            ldb2 = max(int(B2s[0].stride(0)), N - nsplit) if nsplit < N else 0
+            for ts, cols, ld in ((As, M, lda), (Bs, nsplit, ldb)) + (((B2s, N - nsplit, ldb2),) if nsplit < N else ()):
+                for t in ts:
+                    if (t.dtype != torch.float32 or t.device != dev or t.dim() != 2 or t.shape != (K, cols) or
+                            (cols > 1 and t.stride(1) != 1) or (K > 1 and max(int(t.stride(0)), cols) != ld)):
+                        raise ValueError("gemm_tn_form_batch: operands must be [K, cols] fp32 views sharing one row stride")
+            ws_bytes = int(_C.lib.stg_gemm_tn_form_workspace_bytes(T, K, M, N, max(lda, ldb, ldb2)))
+            ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+            pa = (ctypes.c_void_p * T)(*[t.data_ptr() for t in As])
+            pb = (ctypes.c_void_p * T)(*[t.data_ptr() for t in Bs])
+            pb2 = (ctypes.c_void_p * T)(*[t.data_ptr() for t in B2s]) if nsplit < N else None
+            S = ctypes.c_int32(0)
+            _C.check(_C.lib.stg_gemm_tn_form_partial_f32(pa, lda, pb, ldb, nsplit, pb2, ldb2, int(c.get("b_op", GEMM_B_NONE)),
+                                                         float(c.get("lo", 0.0)), float(c.get("hi", 0.0)), T, int(colsum), K, M, N,
+                                                         _ptr(ws), ws_bytes, ctypes.byref(S), _stream_ptr(dev)))
+            out = torch.empty(M, N, dtype=torch.float32, device=dev)
+            cs = torch.empty(M, dtype=torch.float32, device=dev) if colsum else None
+            keep.append(ws)
+            outs.append((out, cs) if colsum else out)
+            slabs_p.append(ws.data_ptr()); c_p.append(out.data_ptr()); cs_p.append(cs.data_ptr() if colsum else None)
+            Ms.append(M); Ns.append(N); Ss.append(int(S.value))
+        n = len(calls)
+        arr = lambda vals: (ctypes.c_void_p * n)(*vals)  # noqa: E731
+        i32s = lambda vals: (ctypes.c_int32 * n)(*vals)  # noqa: E731
+        _C.check(_C.lib.stg_gemm_tn_reduce_multi_f32(n, arr(slabs_p), arr(c_p), arr(cs_p), i32s(Ms), i32s(Ns), i32s(Ss),
+                                                     _stream_ptr(dev)))
+    return outs
+
+
 # ------------------------------------------------------------- one TGCN step per launch (csrc/tgcn_step.hip)
 def tgcn_step_supported(C: int, Fin: int, Fh: int) -> bool:
     return bool(_C.lib.stg_tgcn_step_supported(int(C), int(Fin), int(Fh)))

@@ -148,16 +148,15 @@ class _TGCNWindow(torch.autograd.Function):
         # weight gradients: one split-K launch per parameter over the window's snapshots
         steps = range(B)
         Hprev = [_zeros(N, C, dev)] + [Hn[t] for t in range(B - 1)]
-        gate = lambda d, k, second: kernels.gemm_tn_form(  # noqa: E731
-            [d[t] for t in steps], [X3[t][:, k * C:(k + 1) * C] for t in steps], C, 2 * C, B2s=second, nsplit=C,
+        gate = lambda d, k, second: dict(  # noqa: E731
+            As=[d[t] for t in steps], Bs=[X3[t][:, k * C:(k + 1) * C] for t in steps], M=C, N=2 * C, B2s=second, nsplit=C,
             b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True)
-        dWz, dbz = gate(dzl, 0, Hprev)
-        dWr, dbr = gate(drl, 1, Hprev)
-        dWh, dbh = gate(dhl, 2, [HR[t] for t in steps])
-        dWcT, db3 = kernels.gemm_tn_form([da3[t] for t in steps], [P[t] for t in steps], 3 * C, Fin, colsum=True)
-        dW1, db1 = kernels.gemm_tn_form([dyt[t] for t in steps], [Hn[t] for t in steps], Fh, C, b_op=kernels.GEMM_B_RELU,
-                                        colsum=True)
-        dW2, db2 = kernels.gemm_tn_form([dyo[t].view(N, 1) for t in steps], [Y[t] for t in steps], 1, Fh, colsum=True)
+        # six split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch)
+        (dWz, dbz), (dWr, dbr), (dWh, dbh), (dWcT, db3), (dW1, db1), (dW2, db2) = kernels.gemm_tn_form_batch([
+            gate(dzl, 0, Hprev), gate(drl, 1, Hprev), gate(dhl, 2, [HR[t] for t in steps]),
+            dict(As=[da3[t] for t in steps], Bs=[P[t] for t in steps], M=3 * C, N=Fin, colsum=True),
+            dict(As=[dyt[t] for t in steps], Bs=[Hn[t] for t in steps], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True),
+            dict(As=[dyo[t].view(N, 1) for t in steps], Bs=[Y[t] for t in steps], M=1, N=Fh, colsum=True)])
         conv_w = [dWcT[k * C:(k + 1) * C].t() for k in range(3)]
         conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
         return (dx0, None, None, None, None, None, None, None, None, *conv_w, *conv_b, dWz, dbz, dWr, dbr, dWh, dbh,
@@ -489,15 +488,14 @@ class _TGCNDynWindow(torch.autograd.Function):
             dx0 = kernels.gcn_agg(zbuf[0], s0["norm"], s0["norm"], s0["bwd"], use_node_ids=ctx.use_nid)
         rng = range(B)
         Hprev = [_zeros(N, C, dev)] + [Hn[t] for t in range(B - 1)]
-        gate = lambda d, k, second: kernels.gemm_tn_form(  # noqa: E731
-            [d[t] for t in rng], [X3[t][:, k * C:(k + 1) * C] for t in rng], C, 2 * C, B2s=second, nsplit=C,
+        gate = lambda d, k, second: dict(  # noqa: E731
+            As=[d[t] for t in rng], Bs=[X3[t][:, k * C:(k + 1) * C] for t in rng], M=C, N=2 * C, B2s=second, nsplit=C,
             b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True)
-        dWz, dbz = gate(dzl, 0, Hprev)
-        dWr, dbr = gate(drl, 1, Hprev)
-        dWh, dbh = gate(dhl, 2, [HR[t] for t in rng])
-        dWcT, db3 = kernels.gemm_tn_form([da3[t] for t in rng], [P[t] for t in rng], 3 * C, Fin, colsum=True)
-        dW1, db1 = kernels.gemm_tn_form([dyt[t] for t in rng], [Hn[t] for t in rng], Fh, C, b_op=kernels.GEMM_B_RELU,
-                                        colsum=True)
+        # five split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch)
+        (dWz, dbz), (dWr, dbr), (dWh, dbh), (dWcT, db3), (dW1, db1) = kernels.gemm_tn_form_batch([
+            gate(dzl, 0, Hprev), gate(drl, 1, Hprev), gate(dhl, 2, [HR[t] for t in rng]),
+            dict(As=[da3[t] for t in rng], Bs=[P[t] for t in rng], M=3 * C, N=Fin, colsum=True),
+            dict(As=[dyt[t] for t in rng], Bs=[Hn[t] for t in rng], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True)])
         conv_w = [dWcT[k * C:(k + 1) * C].t() for k in range(3)]
         conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
         ctx.steps = None

@@ -136,3 +136,31 @@ def test_relu_mask_on_load(cuda, K, M, N):
     finally:
         _C.set_tuning("gemm_wide", 0)
     assert torch.equal(c, two) and torch.equal(cs, two_cs)
+
+
+def test_batched_reduction_equals_the_one_product_form(cuda):
+    """kernels.gemm_tn_form_batch (stg_gemm_tn_form_partial_f32 per product + ONE stg_gemm_tn_reduce_multi_f32): a BPTT window's
+    weight-gradient contractions -- different widths, operand transforms, with and without column sums -- bit for bit what
+    gemm_tn_form returns for each alone."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(7)
+    K, C, T = 20_001, 64, 3
+    r = lambda *s: torch.randn(*s, device=cuda, generator=gen)  # noqa: E731
+    d = [r(K, C) for _ in range(T)]
+    x3 = [r(K, 3 * C) for _ in range(T)]
+    H = [r(K, C) for _ in range(T)]
+    da3 = [r(K, 3 * C) for _ in range(T)]
+    P = [r(K, 32) for _ in range(T)]
+    one = [r(K) for _ in range(T)]
+    calls = [dict(As=d, Bs=[x[:, C:2 * C] for x in x3], M=C, N=2 * C, B2s=H, nsplit=C, b_op=kernels.GEMM_B_CLAMP, lo=-0.5, hi=0.7,
+                  colsum=True),
+             dict(As=da3, Bs=P, M=3 * C, N=32, colsum=True),
+             dict(As=[p[:, :32].contiguous() for p in H], Bs=d, M=32, N=C, b_op=kernels.GEMM_B_RELU),
+             dict(As=[o.view(K, 1) for o in one], Bs=P, M=1, N=32, colsum=True)]
+    got = kernels.gemm_tn_form_batch(calls)
+    for c, g in zip(calls, got):
+        want = kernels.gemm_tn_form(**c)
+        if c.get("colsum"):
+            assert torch.equal(g[0], want[0]) and torch.equal(g[1], want[1])
+        else:
+            assert torch.equal(g, want)
