@@ -1261,9 +1261,22 @@ GEMM_REDUCE_JOBS = 8
 def gemm_tn_form_batch(calls):
     """Several :func:`gemm_tn_form` contractions whose final reductions run as ONE launch (stg_gemm_tn_form_partial_f32 per
     product, then stg_gemm_tn_reduce_multi_f32): ``calls`` is a list of keyword dicts for ``gemm_tn_form``; returns the list of
-    its results, same values bit for bit.  Products with more than 32 segments, or more than 8 of them, go one by one."""
+    its results, same values bit for bit.  Optional keys ``out`` [M, N] / ``colsum_out`` [M]: contiguous fp32 tensors the results
+    are written to (a parameter's ``.grad`` view, say).  Products with more than 32 segments, or more than 8 of them, go one by one."""
     if len(calls) > GEMM_REDUCE_JOBS or any(len(c["As"]) > MAX_GEMM_SEGMENTS for c in calls) or len(calls) < 2:
-        return [gemm_tn_form(**c) for c in calls]
+        res = []
+        for c in calls:
+            c = dict(c)
+            out, cs_out = c.pop("out", None), c.pop("colsum_out", None)
+            r = gemm_tn_form(**c)
+            if out is not None:                              # (``out`` / ``colsum_out``: results written where the caller wants them)
+                out.copy_(r[0] if c.get("colsum") else r)
+                r = (out, r[1]) if c.get("colsum") else out
+            if cs_out is not None and c.get("colsum"):
+                cs_out.copy_(r[1])
+                r = (r[0], cs_out)
+            res.append(r)
+        return res
     dev = calls[0]["As"][0].device
     outs, keep = [], []
     slabs_p, c_p, cs_p = [], [], []
@@ -1292,8 +1305,14 @@ def gemm_tn_form_batch(calls):
             _C.check(_C.lib.stg_gemm_tn_form_partial_f32(pa, lda, pb, ldb, nsplit, pb2, ldb2, int(c.get("b_op", GEMM_B_NONE)),
                                                          float(c.get("lo", 0.0)), float(c.get("hi", 0.0)), T, int(colsum), K, M, N,
                                                          _ptr(ws), ws_bytes, ctypes.byref(S), _stream_ptr(dev)))
-            out = torch.empty(M, N, dtype=torch.float32, device=dev)
-            cs = torch.empty(M, dtype=torch.float32, device=dev) if colsum else None
+            out, cs = c.get("out"), c.get("colsum_out") if colsum else None
+            for t, shape, name in ((out, (M, N), "out"), (cs, (M,), "colsum_out")):
+                if t is not None and (t.dtype != torch.float32 or t.device != dev or tuple(t.shape) != shape or not t.is_contiguous()):
+                    raise ValueError(f"gemm_tn_form_batch: {name} must be a contiguous fp32 {shape} tensor on {dev}")
+            if out is None:
+                out = torch.empty(M, N, dtype=torch.float32, device=dev)
+            if colsum and cs is None:
+                cs = torch.empty(M, dtype=torch.float32, device=dev)
             keep.append(ws)
             outs.append((out, cs) if colsum else out)
             slabs_p.append(ws.data_ptr()); c_p.append(out.data_ptr()); cs_p.append(cs.data_ptr() if colsum else None)

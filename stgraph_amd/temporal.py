@@ -60,6 +60,35 @@ def _zeros(n: int, c: int, device) -> torch.Tensor:
     return z
 
 
+# Inside the captured window bodies (CapturedStaticWindow / CapturedDynamicWindows) the window's autograd node writes every
+# parameter gradient straight into the parameter's ``.grad`` -- a view of the gradient bucket, zeroed at the top of the body -- and
+# returns None for it: autograd's AccumulateGrad would otherwise add each of the 16 gradients into its (zero) view with a launch
+# of its own, 13-16 launches of ~4.6 us per window.  Opt-in per backward pass; everywhere else the gradients are returned.
+_DIRECT_GRADS = [False]
+
+
+class direct_param_grads:
+    def __enter__(self):
+        self.prev, _DIRECT_GRADS[0] = _DIRECT_GRADS[0], True
+
+    def __exit__(self, *exc):
+        _DIRECT_GRADS[0] = self.prev
+
+
+def _grad_sinks(params):
+    """The ``.grad`` tensors of ``params`` if the window node may write them directly (opted in, every one a contiguous fp32
+    tensor of the parameter's shape on its device), else None."""
+    if not _DIRECT_GRADS[0]:
+        return None
+    sinks = []
+    for p in params:
+        g = getattr(p, "grad", None)
+        if g is None or g.shape != p.shape or g.dtype != torch.float32 or g.device != p.device or not g.is_contiguous():
+            return None
+        sinks.append(g)
+    return sinks
+
+
 class _TGCNWindow(torch.autograd.Function):
     """cost = sum_t mean((y_out_t - target_t)^2) over the snapshots of one BPTT window of the static-temporal loop
     (benchmarking/static-temporal-tgcn/seastar/train.py:165-183 with model.py:6-18 and nn/pytorch/temporal/tgcn.py):
@@ -110,6 +139,7 @@ class _TGCNWindow(torch.autograd.Function):
         ctx.save_for_backward(x0, targets, norm, normv, ew if ew is not None else norm.new_empty(0), Wcat, Wz_, Wr_, Wh_, W1_, W2v,
                               P, X3, Z, R, Ht, Hn, HR, Y, Yout, mask)
         ctx.has_ew, ctx.csrs, ctx.use_nid, ctx.clamp = ew is not None, (fwd, bwd), use_nid, (float(lo), float(hi))
+        ctx.params = (Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2, b2)
         ctx.step_loss = step_loss
         return cost.reshape(())
 
@@ -148,17 +178,24 @@ class _TGCNWindow(torch.autograd.Function):
         # weight gradients: one split-K launch per parameter over the window's snapshots
         steps = range(B)
         Hprev = [_zeros(N, C, dev)] + [Hn[t] for t in range(B - 1)]
-        gate = lambda d, k, second: dict(  # noqa: E731
+        sinks = _grad_sinks(ctx.params)                    # .grad of (Wcz Wcr Wch bcz bcr bch Wz bz Wr br Wh bh W1 b1 W2 b2), or None
+        dst = (lambda i, j: dict(out=sinks[i], colsum_out=sinks[j])) if sinks else (lambda i, j: {})  # noqa: E731
+        gate = lambda d, k, second, i: dict(  # noqa: E731
             As=[d[t] for t in steps], Bs=[X3[t][:, k * C:(k + 1) * C] for t in steps], M=C, N=2 * C, B2s=second, nsplit=C,
-            b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True)
+            b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True, **dst(i, i + 1))
         # six split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch)
         (dWz, dbz), (dWr, dbr), (dWh, dbh), (dWcT, db3), (dW1, db1), (dW2, db2) = kernels.gemm_tn_form_batch([
-            gate(dzl, 0, Hprev), gate(drl, 1, Hprev), gate(dhl, 2, [HR[t] for t in steps]),
+            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in steps], 10),
             dict(As=[da3[t] for t in steps], Bs=[P[t] for t in steps], M=3 * C, N=Fin, colsum=True),
-            dict(As=[dyt[t] for t in steps], Bs=[Hn[t] for t in steps], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True),
-            dict(As=[dyo[t].view(N, 1) for t in steps], Bs=[Y[t] for t in steps], M=1, N=Fh, colsum=True)])
+            dict(As=[dyt[t] for t in steps], Bs=[Hn[t] for t in steps], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13)),
+            dict(As=[dyo[t].view(N, 1) for t in steps], Bs=[Y[t] for t in steps], M=1, N=Fh, colsum=True, **dst(14, 15))])
         conv_w = [dWcT[k * C:(k + 1) * C].t() for k in range(3)]
         conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
+        if sinks:                                          # the conv weights arrive transposed / as slices: six small copies
+            for k in range(3):
+                sinks[k].copy_(conv_w[k])
+                sinks[3 + k].copy_(conv_b[k])
+            return (dx0,) + (None,) * 24
         return (dx0, None, None, None, None, None, None, None, None, *conv_w, *conv_b, dWz, dbz, dWr, dbr, dWh, dbh,
                 dW1, db1, dW2.view(1, Fh), db2)
 
@@ -413,6 +450,7 @@ class _TGCNDynWindow(torch.autograd.Function):
     def forward(ctx, x0, steps, use_nid, lo, hi, Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1):
         from . import kernels
         dev = x0.device
+        ctx.params = (Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)
         B, N = len(steps), int(x0.shape[0])
         C, Fin, Fh = int(Wz.shape[0]), int(x0.shape[1]), int(W1.shape[0])
         x0 = x0.contiguous()
@@ -488,17 +526,24 @@ class _TGCNDynWindow(torch.autograd.Function):
             dx0 = kernels.gcn_agg(zbuf[0], s0["norm"], s0["norm"], s0["bwd"], use_node_ids=ctx.use_nid)
         rng = range(B)
         Hprev = [_zeros(N, C, dev)] + [Hn[t] for t in range(B - 1)]
-        gate = lambda d, k, second: dict(  # noqa: E731
+        sinks = _grad_sinks(ctx.params)                    # see _TGCNWindow.backward
+        dst = (lambda i, j: dict(out=sinks[i], colsum_out=sinks[j])) if sinks else (lambda i, j: {})  # noqa: E731
+        gate = lambda d, k, second, i: dict(  # noqa: E731
             As=[d[t] for t in rng], Bs=[X3[t][:, k * C:(k + 1) * C] for t in rng], M=C, N=2 * C, B2s=second, nsplit=C,
-            b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True)
+            b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True, **dst(i, i + 1))
         # five split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch)
         (dWz, dbz), (dWr, dbr), (dWh, dbh), (dWcT, db3), (dW1, db1) = kernels.gemm_tn_form_batch([
-            gate(dzl, 0, Hprev), gate(drl, 1, Hprev), gate(dhl, 2, [HR[t] for t in rng]),
+            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in rng], 10),
             dict(As=[da3[t] for t in rng], Bs=[P[t] for t in rng], M=3 * C, N=Fin, colsum=True),
-            dict(As=[dyt[t] for t in rng], Bs=[Hn[t] for t in rng], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True)])
+            dict(As=[dyt[t] for t in rng], Bs=[Hn[t] for t in rng], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13))])
         conv_w = [dWcT[k * C:(k + 1) * C].t() for k in range(3)]
         conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
         ctx.steps = None
+        if sinks:
+            for k in range(3):
+                sinks[k].copy_(conv_w[k])
+                sinks[3 + k].copy_(conv_b[k])
+            return (dx0,) + (None,) * 18
         return (dx0, None, None, None, None, *conv_w, *conv_b, dWz, dbz, dWr, dbr, dWh, dbh, dW1, db1)
 
 
@@ -632,7 +677,8 @@ class CapturedStaticWindow:
             tw = self.targets_w.index_select(0, self.widx)[0]
             cost = window_cost_of(model, graph, y0, edge_weight, tw)
             cost = cost / (B + 1)
-            cost.backward()
+            with direct_param_grads():                       # the bucket was zeroed above: written, not accumulated
+                cost.backward()
             self.costs.index_copy_(0, self.widx, cost.detach().reshape(1))
 
         # Warm up on a side stream (allocator, lazily built per-edge caches, tracing).  The body
@@ -861,7 +907,8 @@ class CapturedDynamicWindows:
             steps.append(dict(fwd=g.csr("fwd"), bwd=g.csr("bwd"), norm=self.norm_fn(g), edges=self.edges[t],
                               targets=self.targets[t], incidence=SF._incidence_of(self.edges[t], self.n)))
         cost = dyn_window_cost(self.model, g, self.inputs[w], steps) / (self.B + 1)
-        cost.backward()
+        with direct_param_grads():                           # the bucket was zeroed above: written, not accumulated
+            cost.backward()
         return cost.detach()
 
     def _capture(self, w: int) -> None:
