@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 15
+#define STG_ABI_VERSION 16
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -603,6 +603,13 @@ typedef struct stg_tgcn_step_bwd_args {
 int    stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh);
 size_t stg_tgcn_step_loss_partials(int64_t N);
 int    stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *args, void *stream);
+/* The weight layouts the two step launches take, from the modules' parameters, in one launch per window: Wcat [Fin,3C] =
+ * [Wcz | Wcr | Wch] (GCNConv weights [Fin,C]), WcatT [3C,Fin], b3 [3C] = [bcz | bcr | bch], WzT / WrT / WhT [2C,C] (transposed gate
+ * Linear weights [C,2C]), W1T [C,Fh] (transposed head weight [Fh,C]). */
+int    stg_tgcn_pack_weights(const float *Wcz, const float *Wcr, const float *Wch, const float *bcz, const float *bcr,
+                             const float *bch, const float *Wz, const float *Wr, const float *Wh, const float *W1, float *Wcat,
+                             float *WcatT, float *b3, float *WzT, float *WrT, float *WhT, float *W1T, int32_t C, int32_t Fin,
+                             int32_t Fh, void *stream);
 int    stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *args, void *stream);
 /* cost[0] = sum over the window's `steps` steps, in order, of (sum of that step's partials) / N; step_loss [steps]
  * (required: the terms, and the scratch of the final sum).  partials: `steps` rows of step_stride floats. */

@@ -420,3 +420,63 @@ extern "C" int stg_partial_sums_loss(const float *partials, int32_t steps, int32
     return window_loss_launch(partials, steps, count, step_stride, inv_n, step_loss, cost, static_cast<hipStream_t>(stream),
                               "stg_partial_sums_loss");
 }
+
+// The layouts the two step launches want of a window's weights, made in ONE launch (the window loop made them with two
+// torch.cat, one transpose for the forward pass and four for the backward pass: seven launches of ~4.6 us per window):
+//   Wcat [Fin, 3C] = [Wcz | Wcr | Wch], WcatT [3C, Fin], b3 [3C] = [bcz | bcr | bch], WzT / WrT / WhT [2C, C], W1T [C, Fh].
+namespace stg {
+namespace {
+struct PackArgs {
+    const float *Wc[3], *bc[3], *Wg[3], *W1;
+    float *Wcat, *WcatT, *b3, *WgT[3], *W1T;
+    int C, Fin, Fh;
+};
+__global__ __launch_bounds__(kBlock) void tgcn_pack_weights_kernel(const PackArgs a)
+{
+    const int C = a.C, Fin = a.Fin, Fh = a.Fh;
+    const int n_cat = Fin * 3 * C, n_b = 3 * C, n_g = 2 * C * C, n_1 = C * Fh;
+    const int total = n_cat + n_b + 3 * n_g + n_1;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        int j = i;
+        if (j < n_cat) {                                   // (f, c) of Wcat: gate c / C
+            const int f = j / (3 * C), c = j - f * 3 * C, g = c / C;
+            const float v = a.Wc[g][f * C + (c - g * C)];
+            a.Wcat[j] = v;
+            a.WcatT[c * Fin + f] = v;
+            continue;
+        }
+        j -= n_cat;
+        if (j < n_b) {
+            a.b3[j] = a.bc[j / C][j % C];
+            continue;
+        }
+        j -= n_b;
+        if (j < 3 * n_g) {                                 // gate Linear weights [C][2C] -> [2C][C]
+            const int g = j / n_g, r = j - g * n_g, o = r / (2 * C), k = r - o * 2 * C;
+            a.WgT[g][k * C + o] = a.Wg[g][r];
+            continue;
+        }
+        j -= 3 * n_g;
+        const int o = j / C, k = j - o * C;                // W1 [Fh][C] -> [C][Fh]
+        a.W1T[k * Fh + o] = a.W1[j];
+    }
+}
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_tgcn_pack_weights(const float *Wcz, const float *Wcr, const float *Wch, const float *bcz, const float *bcr,
+                                     const float *bch, const float *Wz, const float *Wr, const float *Wh, const float *W1,
+                                     float *Wcat, float *WcatT, float *b3, float *WzT, float *WrT, float *WhT, float *W1T,
+                                     int32_t C, int32_t Fin, int32_t Fh, void *stream)
+{
+    using namespace stg;
+    if (C <= 0 || Fin <= 0 || Fh <= 0 || (int64_t)C * (Fin * 3 + 6 * C + Fh + 3) > (1 << 28))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_pack_weights: bad shape C=%d Fin=%d Fh=%d", C, Fin, Fh);
+    if (!Wcz || !Wcr || !Wch || !bcz || !bcr || !bch || !Wz || !Wr || !Wh || !W1 || !Wcat || !WcatT || !b3 || !WzT || !WrT || !WhT || !W1T)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_pack_weights: NULL pointer argument");
+    PackArgs a{{Wcz, Wcr, Wch}, {bcz, bcr, bch}, {Wz, Wr, Wh}, W1, Wcat, WcatT, b3, {WzT, WrT, WhT}, W1T, C, Fin, Fh};
+    const int total = Fin * 3 * C + 3 * C + 3 * 2 * C * C + C * Fh;
+    hipLaunchKernelGGL(tgcn_pack_weights_kernel, dim3((unsigned)std::min((total + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return check_launch("stg_tgcn_pack_weights");
+}

@@ -1351,6 +1351,23 @@ def _fill_step_args(args, what: str, dev: torch.device, tensors: dict) -> None:
         setattr(args, name, t.data_ptr())
 
 
+def tgcn_pack_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1):
+    """``(Wcat, WcatT, b3, WzT, WrT, WhT, W1T)``: the layouts tgcn_step_fwd / _bwd take, from the modules' parameters, in one
+    launch (stg_tgcn_pack_weights)."""
+    src = [_f32(t, "weight") for t in (Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1)]
+    dev = src[0].device
+    Fin, C = (int(v) for v in src[0].shape)
+    Fh = int(src[9].shape[0])
+    if (any(t.device != dev for t in src) or any(tuple(t.shape) != (Fin, C) for t in src[:3]) or any(tuple(t.shape) != (C,) for t in src[3:6])
+            or any(tuple(t.shape) != (C, 2 * C) for t in src[6:9]) or tuple(src[9].shape) != (Fh, C)):
+        raise ValueError("tgcn_pack_weights: conv weights [Fin, C], conv biases [C], gate weights [C, 2C], head weight [Fh, C]")
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    out = (new(Fin, 3 * C), new(3 * C, Fin), new(3 * C), new(2 * C, C), new(2 * C, C), new(2 * C, C), new(C, Fh))
+    with torch.cuda.device(dev):
+        _C.check(_C.lib.stg_tgcn_pack_weights(*[_ptr(t) for t in src], *[_ptr(t) for t in out], C, Fin, Fh, _stream_ptr(dev)))
+    return out
+
+
 def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: float, device, **tensors) -> None:
     """One TGCN step forward in one launch (stg_tgcn_step_fwd); ``tensors``: the pointer fields of
     stg_tgcn_step_fwd_args by name (include/stgraph_hip.h).  Outputs are written in place."""

@@ -106,9 +106,9 @@ class _TGCNWindow(torch.autograd.Function):
         x0 = x0.contiguous()
         targets = targets.reshape(B, N).contiguous()
         normv = norm.reshape(-1).contiguous()
-        Wcat = torch.cat([Wcz, Wcr, Wch], dim=1)                 # [Fin, 3C]
-        WcatT = Wcat.t().contiguous()
-        b3 = torch.cat([bcz, bcr, bch], dim=0)
+        # Wcat [Fin, 3C], its transpose, b3 and the transposed gate / head weights of the backward pass: one launch
+        Wcat, WcatT, b3, WzT, WrT, WhT, W1T = kernels.tgcn_pack_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1)
+        ctx.packed_T = (WzT, WrT, WhT, W1T)
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         P, X3 = new(B, N, Fin), new(B, N, 3 * C)
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
@@ -158,7 +158,7 @@ class _TGCNWindow(torch.autograd.Function):
         dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), new(B, N, 3 * C)
         dyt, dyo = new(B, N, Fh), new(B, N)
         dH, zbuf = new(2, N, C), new(2, N, Fin)
-        WzT, WrT, WhT, W1T = (w.t().contiguous() for w in (Wz, Wr, Wh, W1))
+        WzT, WrT, WhT, W1T = ctx.packed_T
         nid = None                                  # vertex order: see forward
         with torch.cuda.device(dev):
             nc = kernels._edge_gathered(bwd, "norm", norm, bwd.column_indices)
@@ -454,9 +454,8 @@ class _TGCNDynWindow(torch.autograd.Function):
         B, N = len(steps), int(x0.shape[0])
         C, Fin, Fh = int(Wz.shape[0]), int(x0.shape[1]), int(W1.shape[0])
         x0 = x0.contiguous()
-        Wcat = torch.cat([Wcz, Wcr, Wch], dim=1)
-        WcatT = Wcat.t().contiguous()
-        b3 = torch.cat([bcz, bcr, bch], dim=0)
+        Wcat, WcatT, b3, WzT, WrT, WhT, W1T = kernels.tgcn_pack_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1)
+        ctx.packed_T = (WzT, WrT, WhT, W1T)
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         P, X3 = new(B, N, Fin), new(B, N, 3 * C)
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
@@ -498,7 +497,7 @@ class _TGCNDynWindow(torch.autograd.Function):
         dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), new(B, N, 3 * C)
         dyt = new(B, N, Fh)
         dH, zbuf = new(2, N, C), new(2, N, Fin)
-        WzT, WrT, WhT, W1T = (w.t().contiguous() for w in (Wz, Wr, Wh, W1))
+        WzT, WrT, WhT, W1T = ctx.packed_T
         want_dx0 = ctx.needs_input_grad[0]
         with torch.cuda.device(dev):
             for st in steps:

@@ -297,3 +297,15 @@ def test_link_loss_backward_inside_the_step_launch(cuda, n, e, m):
               link_target=target)
     for k in two:
         assert torch.equal(one[k], two[k]), k
+
+
+def test_pack_weights(cuda):
+    """stg_tgcn_pack_weights: the cat / transposes of a window's weights in one launch, element for element."""
+    from stgraph_amd import kernels
+    p = _params(cuda, 3)
+    Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
+    bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
+    Wcat, WcatT, b3, WzT, WrT, WhT, W1T = kernels.tgcn_pack_weights(*Wc, *bc, p["Wz"], p["Wr"], p["Wh"], p["W1"])
+    assert torch.equal(Wcat, p["Wcat"]) and torch.equal(WcatT, p["Wcat"].t().contiguous()) and torch.equal(b3, p["b3"])
+    for got, w in ((WzT, p["Wz"]), (WrT, p["Wr"]), (WhT, p["Wh"]), (W1T, p["W1"])):
+        assert torch.equal(got, w.t().contiguous())
