@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 16
+#define STG_ABI_VERSION 17
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -634,6 +634,10 @@ int    stg_partial_sums_loss(const float *partials, int32_t steps, int32_t count
  * F = 32. */
 int    stg_link_decode_fwd(const float *y, const int64_t *edge_index, const float *target, float *logits, float *partial,
                            int64_t M, int32_t F, void *stream);
+/* The same for up to 32 snapshots of a BPTT window in one launch (host arrays of per-snapshot device pointers, passed by value:
+ * capturable): every snapshot has M label edges; partial[t] has (M + 31) / 32 entries. */
+int    stg_link_decode_fwd_multi(int32_t count, const float *const *y, const int64_t *const *edge_index, const float *const *target,
+                                 float *const *logits, float *const *partial, int64_t M, int32_t F, void *stream);
 int    stg_link_decode_bwd(const float *g_loss, const float *y, const float *logits, const float *target,
                            const int32_t *row_ptr, const int32_t *other, const int32_t *eid, float *dy, int64_t N, int64_t M,
                            int32_t F, void *stream);

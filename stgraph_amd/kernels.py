@@ -1447,6 +1447,26 @@ def link_decode_fwd(y: torch.Tensor, edge_index: torch.Tensor, target: torch.Ten
                                             int(y.shape[1]), _stream_ptr(y.device)))
 
 
+LINK_DECODE_JOBS = 32
+
+
+def link_decode_fwd_window(ys, edge_indices, targets, logits, partials) -> None:
+    """:func:`link_decode_fwd` for every snapshot of a window in one launch per 32 snapshots (stg_link_decode_fwd_multi):
+    lists of per-snapshot tensors, every ``edge_index`` [2, M] with the same M."""
+    n = len(ys)
+    M = int(edge_indices[0].shape[1])
+    dev = ys[0].device
+    for e in edge_indices:
+        if e.dtype != torch.int64 or tuple(e.shape) != (2, M) or not e.is_contiguous() or e.device != dev:
+            raise ValueError("link_decode_fwd_window: every edge_index must be a contiguous int64 [2, M] tensor on one device")
+    with torch.cuda.device(dev):
+        for i in range(0, n, LINK_DECODE_JOBS):
+            k = min(LINK_DECODE_JOBS, n - i)
+            arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts[i:i + k]])  # noqa: E731
+            _C.check(_C.lib.stg_link_decode_fwd_multi(k, arr(ys), arr(edge_indices), arr(targets), arr(logits), arr(partials), M,
+                                                      int(ys[0].shape[1]), _stream_ptr(dev)))
+
+
 def link_decode_bwd(g_loss: torch.Tensor, y: torch.Tensor, logits: torch.Tensor, target: torch.Tensor, incidence,
                     dy: torch.Tensor) -> None:
     """dy [N, F]: gradient of the mean BCE loss with respect to y, per node over its incident label edges

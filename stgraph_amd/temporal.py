@@ -478,7 +478,9 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   norm=st["normv"], x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
                                   P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t], clamp_mask=mask[t])
-            kernels.link_decode_fwd(Y[t], st["edges"], st["targets"], logits[t], partial[t])
+        # the decoder + loss of every snapshot behind the last step, in one launch: a snapshot's loss feeds nothing in the next one
+        kernels.link_decode_fwd_window([Y[t] for t in range(B)], [st["edges"] for st in steps], [st["targets"] for st in steps],
+                                       [logits[t] for t in range(B)], [partial[t] for t in range(B)])
         cost = kernels.partial_sums_loss(partial, B, nparts, 1.0 / M)
         ctx.save_for_backward(x0, Wcat, Wz_, Wr_, Wh_, W1_, P, X3, Z, R, Ht, Hn, HR, Y, mask, logits)
         ctx.steps, ctx.use_nid, ctx.clamp = steps, use_nid, (float(lo), float(hi))

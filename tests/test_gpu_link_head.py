@@ -143,3 +143,22 @@ def test_dynamic_training_epochs_same_with_and_without_the_fused_head(cuda):
     torch.testing.assert_close(out[0][0], out[1][0], rtol=2e-4, atol=1e-6)
     for a, b in zip(out[0][1], out[1][1]):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4)
+
+
+def test_decoder_of_a_whole_window_in_one_launch(cuda):
+    """stg_link_decode_fwd_multi: logits and loss partials of every snapshot of a window, bit for bit what stg_link_decode_fwd
+    gives snapshot by snapshot (36 snapshots: two launches of 32 and 4)."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(11)
+    B, N, M = 36, 5000, 3001
+    ys = [torch.randn(N, 32, device=cuda, generator=gen) for _ in range(B)]
+    edges = [torch.randint(0, N, (2, M), device=cuda, generator=gen) for _ in range(B)]
+    targets = [(torch.rand(M, device=cuda, generator=gen) < 0.5).float() for _ in range(B)]
+    parts = (M + 31) // 32
+    lo = [torch.empty(M, device=cuda) for _ in range(B)]
+    pa = [torch.empty(parts, device=cuda) for _ in range(B)]
+    kernels.link_decode_fwd_window(ys, edges, targets, lo, pa)
+    for t in range(B):
+        l1, p1 = torch.empty(M, device=cuda), torch.empty(parts, device=cuda)
+        kernels.link_decode_fwd(ys[t], edges[t], targets[t], l1, p1)
+        assert torch.equal(lo[t], l1) and torch.equal(pa[t], p1), t
