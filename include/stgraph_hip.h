@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 17
+#define STG_ABI_VERSION 18
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -147,6 +147,25 @@ int stg_graph_build_direct2_device(const int32_t *src, const int32_t *dst, int64
                                    float *norm, float *norm_col_fwd, float *norm_col_bwd, int32_t *zero_counters,
                                    int32_t *sticky_status, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The snapshots of one BPTT window (dynamic-temporal-tgcn/seastar/train.py:205-232 walks them one get_graph() at a time) are
+ * independent builds over the same |V|: up to STG_BUILD_BATCH_MAX of them in the SAME six launches (blockIdx.z = snapshot),
+ * every output bit-identical to n_jobs calls of stg_graph_build_direct2_device without node_ids.  Each job brings its own
+ * zero_counters and its own workspace (>= stg_graph_build_direct_workspace_bytes(E, N)); N > 0 is common to the batch. */
+#define STG_BUILD_BATCH_MAX 16
+typedef struct stg_build_job {
+    const int32_t *src, *dst;
+    int64_t E;
+    int64_t *perm_fwd;
+    int32_t *fwd_row_offset, *fwd_column_indices, *fwd_eids;
+    int32_t *bwd_row_offset, *bwd_column_indices, *bwd_eids;
+    int32_t *in_degrees, *out_degrees;
+    float *norm, *norm_col_fwd, *norm_col_bwd;       /* nullable, as above */
+    int32_t *zero_counters;
+    void *workspace;
+    size_t workspace_bytes;
+} stg_build_job;
+int stg_graph_build_direct2_batch_device(const stg_build_job *jobs, int32_t n_jobs, int32_t N, int32_t *sticky_status,
+                                         void *stream);
 
 /* ------------------------------------------------------- dynamic edge store (PCSR, GPMA)
  * Replaces the reference's PCSR class: graph/dynamic/pcsr/pcsr.cu:273-939

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = (
     "stg_csr_ctor_host", "stg_graph_build_host",
     "stg_graph_build_device_workspace_bytes", "stg_graph_build_device",
     "stg_graph_build_direct_workspace_bytes", "stg_graph_build_direct_device", "stg_graph_build_direct2_device",
+    "stg_graph_build_direct2_batch_device",
     "stg_rows_by_degree_workspace_bytes", "stg_rows_by_degree_device",
     "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host", "stg_edgeset_merge_device", "stg_edgeset_step_device",
     "stg_edgeset_emit_csr_workspace_bytes", "stg_edgeset_emit_csr_device", "stg_edgeset_emit_csr_host",
@@ -50,6 +51,18 @@ EXPORTED_SYMBOLS = (
 
 def _ptr_fields(names):
     return [(n, ctypes.c_void_p) for n in names.split()]
+
+
+BUILD_BATCH_MAX = 16
+
+
+class BuildJob(ctypes.Structure):
+    """stg_build_job (include/stgraph_hip.h)."""
+    _fields_ = ([("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("E", ctypes.c_int64)] +
+                [(k, ctypes.c_void_p) for k in ("perm_fwd", "fwd_row_offset", "fwd_column_indices", "fwd_eids", "bwd_row_offset",
+                                                "bwd_column_indices", "bwd_eids", "in_degrees", "out_degrees", "norm",
+                                                "norm_col_fwd", "norm_col_bwd", "zero_counters", "workspace")] +
+                [("workspace_bytes", ctypes.c_size_t)])
 
 
 class TgcnStepFwdArgs(ctypes.Structure):
@@ -104,6 +117,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_graph_build_direct_device.argtypes = [vp, vp, i64, i32] + [vp] * 11 + [vp, vp, ctypes.c_size_t, vp]
     lib.stg_graph_build_direct2_device.restype = ctypes.c_int
     lib.stg_graph_build_direct2_device.argtypes = [vp, vp, i64, i32] + [vp] * 16 + [vp, ctypes.c_size_t, vp]
+    lib.stg_graph_build_direct2_batch_device.restype = ctypes.c_int
+    lib.stg_graph_build_direct2_batch_device.argtypes = [ctypes.POINTER(BuildJob), i32, i32, vp, vp]
     lib.stg_rows_by_degree_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_rows_by_degree_workspace_bytes.argtypes = [i32]
     lib.stg_rows_by_degree_device.restype = ctypes.c_int

@@ -192,10 +192,37 @@ __global__ void direct_sort_keys(const int *__restrict__ deg, int N, unsigned *_
 // each edge's arrival index inside its two rows, so placing needs no cursor; the scan also writes norm = in_deg^-1/2; the
 // two ranking passes also write norm gathered through their columns; the last pass leaves the counters zero again for the
 // next build (they live in a caller-owned buffer that is zero between builds: no init launch).
-__global__ __launch_bounds__(kBlock) void direct2_count(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int N,
-                                                       int *__restrict__ cnt, int npad, int *__restrict__ pos_f,
-                                                       int *__restrict__ pos_b, int *__restrict__ status)
+//
+// Every kernel of this build takes its operands as jobs.j[blockIdx.z]: ONE build is a batch of one (CAP = 1), and the
+// snapshots of a whole BPTT window -- independent builds over the same |V| -- go through the SAME launches as up to
+// kBuildBatchMax jobs (stg_graph_build_direct2_batch_device): a 250 K-edge build is six launches that each fill a fraction of
+// the chip for 5-10 us, so eight of them side by side cost little more than one.
+struct BJob {
+    const int *src, *dst;
+    int64_t E;
+    int64_t *perm;
+    int *fwd_ro, *fwd_col, *fwd_eid, *bwd_ro, *bwd_col, *bwd_eid, *in_deg, *out_deg;
+    float *norm, *nc_f, *nc_b;
+    int *cnt;                               // 2 npad counters, zero between builds
+    uint64_t *key_f, *key_b;
+    int *row_f, *row_b, *pos_f, *pos_b, *part;
+    int chunk_shift, lds;                   // lds != 0: counted by direct3_count (per-chunk histograms in LDS) and combined
+};
+constexpr int kBuildBatchMax = STG_BUILD_BATCH_MAX;
+template <int CAP>
+struct BuildJobs {
+    BJob j[CAP];
+};
+static_assert(sizeof(BuildJobs<kBuildBatchMax>) <= 3584, "the batch travels as a kernel argument");
+
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void direct2_count(const BuildJobs<CAP> jobs, int N, int npad, int *__restrict__ status)
 {
+    const BJob &J = jobs.j[blockIdx.z];
+    if (J.lds) return;
+    const int *__restrict__ src = J.src, *__restrict__ dst = J.dst;
+    int *__restrict__ cnt = J.cnt, *__restrict__ pos_f = J.pos_f, *__restrict__ pos_b = J.pos_b;
+    const int64_t E = J.E;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
         const int s = src[i], d = dst[i];
@@ -217,11 +244,15 @@ __global__ __launch_bounds__(kBlock) void direct2_count(const int *__restrict__ 
 // (cnt, as direct2_count leaves it); placing adds base[chunk of the edge][row] to the arrival index.
 constexpr int kLdsChunks = 16;
 constexpr int kLdsCountMaxN = 40 * 1024;                        // 160 KB of LDS
-__global__ __launch_bounds__(kScanThreads) void direct3_count(const int *__restrict__ src, const int *__restrict__ dst, int64_t E, int N,
-                                                             int64_t chunk_len, int *__restrict__ part, int npad,
-                                                             int *__restrict__ pos_f, int *__restrict__ pos_b, int *__restrict__ status)
+template <int CAP>
+__global__ __launch_bounds__(kScanThreads) void direct3_count(const BuildJobs<CAP> jobs, int N, int npad, int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) int hist[];  // npad = |V| rounded up to 4 ints (also the row stride of part)
+    const BJob &J = jobs.j[blockIdx.z];
+    if (!J.lds) return;
+    const int *__restrict__ src = J.src, *__restrict__ dst = J.dst;
+    int *__restrict__ part = J.part, *__restrict__ pos_f = J.pos_f, *__restrict__ pos_b = J.pos_b;
+    const int64_t E = J.E, chunk_len = (int64_t)1 << J.chunk_shift;
     const int c = (int)blockIdx.x, side = (int)blockIdx.y;
     for (int v = 4 * threadIdx.x; v < npad; v += 4 * kScanThreads) *reinterpret_cast<int4 *>(hist + v) = make_int4(0, 0, 0, 0);
     __syncthreads();
@@ -255,8 +286,12 @@ __global__ __launch_bounds__(kScanThreads) void direct3_count(const int *__restr
     for (int v = 4 * threadIdx.x; v < npad; v += 4 * kScanThreads) *reinterpret_cast<int4 *>(out + v) = *reinterpret_cast<const int4 *>(hist + v);
 }
 
-__global__ __launch_bounds__(kBlock) void direct3_combine(int *__restrict__ part, int npad, int *__restrict__ cnt)
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void direct3_combine(const BuildJobs<CAP> jobs, int npad)
 {
+    const BJob &J = jobs.j[blockIdx.z];
+    if (!J.lds) return;
+    int *__restrict__ part = J.part, *__restrict__ cnt = J.cnt;
     const int v = 4 * (blockIdx.x * blockDim.x + threadIdx.x), side = (int)blockIdx.y;      // four rows per thread
     if (v >= npad) return;
     int *p = part + (int64_t)side * kLdsChunks * npad + v;
@@ -278,11 +313,13 @@ __global__ __launch_bounds__(kBlock) void direct3_combine(int *__restrict__ part
 // wave totals, and offsets / degrees / norm leave as coalesced 16-byte stores.  (A contiguous chunk of rows per thread --
 // strided 4-byte loads and stores -- took 47 us at |V| = 25 K; the seven-tile sequential loop of direct_scan 16.)
 constexpr int kScan2Tiles = 16;
-__global__ __launch_bounds__(kScanThreads) void direct2_scan(const int *__restrict__ cnt, int npad, int N, int *__restrict__ fwd_ro,
-                                                            int *__restrict__ bwd_ro, int *__restrict__ in_deg,
-                                                            int *__restrict__ out_deg, float *__restrict__ norm,
-                                                            int *__restrict__ status)
+template <int CAP>
+__global__ __launch_bounds__(kScanThreads) void direct2_scan(const BuildJobs<CAP> jobs, int npad, int N, int *__restrict__ status)
 {
+    const BJob &J = jobs.j[blockIdx.z];
+    const int *__restrict__ cnt = J.cnt;
+    int *__restrict__ fwd_ro = J.fwd_ro, *__restrict__ bwd_ro = J.bwd_ro, *__restrict__ in_deg = J.in_deg, *__restrict__ out_deg = J.out_deg;
+    float *__restrict__ norm = J.norm;
     constexpr int kWavesScan = kScanThreads / 64;                 // 16
     constexpr int kFlat = kScan2Tiles * kWavesScan;               // 256 (tile, wave) totals = 4 waves of entries
     __shared__ int wsum[kFlat];                                   // [tile * 16 + wave]: totals, then exclusive bases
@@ -374,13 +411,17 @@ __global__ __launch_bounds__(kScanThreads) void direct2_scan(const int *__restri
 }
 
 // (base != NULL: pos_f / pos_b count inside (chunk, row) -- direct3_count -- and base[chunk][row] is added; npad = its row stride)
-__global__ __launch_bounds__(kBlock) void direct2_place(const int *__restrict__ src, const int *__restrict__ dst, int64_t E,
-                                                       const int *__restrict__ fwd_ro, const int *__restrict__ pos_f,
-                                                       uint64_t *__restrict__ key, int *__restrict__ row,
-                                                       const int *__restrict__ status, const int *__restrict__ base_f, int npad,
-                                                       int chunk_shift)
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void direct2_place(const BuildJobs<CAP> jobs, int npad, const int *__restrict__ status)
 {
     if (*status) return;
+    const BJob &J = jobs.j[blockIdx.z];
+    const int *__restrict__ src = J.src, *__restrict__ dst = J.dst, *__restrict__ fwd_ro = J.fwd_ro, *__restrict__ pos_f = J.pos_f;
+    uint64_t *__restrict__ key = J.key_f;
+    int *__restrict__ row = J.row_f;
+    const int *__restrict__ base_f = J.lds ? J.part : nullptr;
+    const int chunk_shift = J.chunk_shift;
+    const int64_t E = J.E;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
         const int d = dst[i];
@@ -391,16 +432,21 @@ __global__ __launch_bounds__(kBlock) void direct2_place(const int *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const uint64_t *__restrict__ key, const int *__restrict__ row, int64_t E,
-                                                          const int *__restrict__ fwd_ro, const int *__restrict__ bwd_ro,
-                                                          const int *__restrict__ pos_b, int *__restrict__ fwd_col,
-                                                          int *__restrict__ fwd_eid, int64_t *__restrict__ perm_fwd,
-                                                          uint64_t *__restrict__ key_b, int *__restrict__ row_b,
-                                                          const float *__restrict__ norm, float *__restrict__ nc_fwd,
-                                                          const int *__restrict__ status, const int *__restrict__ base_b, int npad,
-                                                          int chunk_shift)
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const BuildJobs<CAP> jobs, int npad, const int *__restrict__ status)
 {
     if (*status) return;
+    const BJob &J = jobs.j[blockIdx.z];
+    const uint64_t *__restrict__ key = J.key_f;
+    const int *__restrict__ row = J.row_f, *__restrict__ fwd_ro = J.fwd_ro, *__restrict__ bwd_ro = J.bwd_ro, *__restrict__ pos_b = J.pos_b;
+    int *__restrict__ fwd_col = J.fwd_col, *__restrict__ fwd_eid = J.fwd_eid, *__restrict__ row_b = J.row_b;
+    int64_t *__restrict__ perm_fwd = J.perm;
+    uint64_t *__restrict__ key_b = J.key_b;
+    const float *__restrict__ norm = J.norm;
+    float *__restrict__ nc_fwd = J.nc_f;
+    const int *__restrict__ base_b = J.lds ? J.part + (size_t)kLdsChunks * npad : nullptr;
+    const int chunk_shift = J.chunk_shift;
+    const int64_t E = J.E;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < E; t += stride) {
         const uint64_t mine = key[t];
@@ -420,12 +466,16 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const uint64_t *__res
     }
 }
 
-__global__ __launch_bounds__(kBlock) void direct2_rank_bwd(const uint64_t *__restrict__ key_b, const int *__restrict__ row_b, int64_t E,
-                                                          const int *__restrict__ bwd_ro, int *__restrict__ bwd_col,
-                                                          int *__restrict__ bwd_eid, const float *__restrict__ norm,
-                                                          float *__restrict__ nc_bwd, int *__restrict__ cnt, int npad,
-                                                          const int *__restrict__ status)
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void direct2_rank_bwd(const BuildJobs<CAP> jobs, int npad, const int *__restrict__ status)
 {
+    const BJob &J = jobs.j[blockIdx.z];
+    const uint64_t *__restrict__ key_b = J.key_b;
+    const int *__restrict__ row_b = J.row_b, *__restrict__ bwd_ro = J.bwd_ro;
+    int *__restrict__ bwd_col = J.bwd_col, *__restrict__ bwd_eid = J.bwd_eid, *__restrict__ cnt = J.cnt;
+    const float *__restrict__ norm = J.norm;
+    float *__restrict__ nc_bwd = J.nc_b;
+    const int64_t E = J.E;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t v = first; v < 2 * (int64_t)npad; v += stride) cnt[v] = 0;  // nobody reads the counters any more
@@ -470,6 +520,66 @@ DirectLayout direct_layout(int64_t E, int32_t N)
     L.part = take(N <= kLdsCountMaxN ? (size_t)2 * kLdsChunks * ((n + 3) & ~(size_t)3) * 4 : 0);      // direct3_count's per-chunk histograms
     L.total = off;
     return L;
+}
+
+
+BJob make_job(const DirectLayout &L, char *ws, const int32_t *src, const int32_t *dst, int64_t E, int32_t N, int64_t *perm_fwd,
+              int32_t *fwd_ro, int32_t *fwd_col, int32_t *fwd_eid, int32_t *bwd_ro, int32_t *bwd_col, int32_t *bwd_eid,
+              int32_t *in_deg, int32_t *out_deg, float *norm, float *nc_f, float *nc_b, int32_t *counters)
+{
+    BJob j{};
+    j.src = src, j.dst = dst, j.E = E, j.perm = perm_fwd;
+    j.fwd_ro = fwd_ro, j.fwd_col = fwd_col, j.fwd_eid = fwd_eid, j.bwd_ro = bwd_ro, j.bwd_col = bwd_col, j.bwd_eid = bwd_eid;
+    j.in_deg = in_deg, j.out_deg = out_deg, j.norm = norm, j.nc_f = nc_f, j.nc_b = nc_b, j.cnt = counters;
+    j.key_f = reinterpret_cast<uint64_t *>(ws + L.key_f), j.key_b = reinterpret_cast<uint64_t *>(ws + L.key_b);
+    j.row_f = reinterpret_cast<int *>(ws + L.row_f), j.row_b = reinterpret_cast<int *>(ws + L.row_b);
+    j.pos_f = reinterpret_cast<int *>(ws + L.pos_f), j.pos_b = reinterpret_cast<int *>(ws + L.pos_b);
+    j.part = reinterpret_cast<int *>(ws + L.part);
+    // histograms in LDS when |V| fits it and there are enough edges per vertex to pay for writing and combining 2 x 16 x |V| counts
+    const int mode = tuning().build_lds_count;
+    j.lds = E > 0 && N <= kLdsCountMaxN && mode != 2 && (mode == 1 || (E >= 2 * (int64_t)N && E >= 32768));
+    j.chunk_shift = 0;                                     // chunks of 2^shift edges (the chunk of an edge is a shift in the placing passes)
+    while (((int64_t)kLdsChunks << j.chunk_shift) < E) ++j.chunk_shift;
+    return j;
+}
+
+// The six launches over jobs.j[0 .. n): blockIdx.z = job; a job with E = 0 still gets its row offsets, degrees and norm.
+template <int CAP>
+int run_direct2(const BuildJobs<CAP> &jobs, int n, int32_t N, int32_t *sticky_status, hipStream_t stream, const char *who)
+{
+    const int npad = (std::max(N, 1) + 3) & ~3;
+    int64_t emax = 0;
+    bool any_lds = false, any_flat = false;
+    for (int i = 0; i < n; ++i) {
+        emax = std::max(emax, jobs.j[i].E);
+        if (jobs.j[i].lds) any_lds = true;
+        else if (jobs.j[i].E > 0) any_flat = true;
+    }
+    const int eblocks = (int)std::max<int64_t>(1, std::min<int64_t>((emax + kBlock - 1) / kBlock, 256 * 16));
+    if (any_lds) {
+        const size_t lds = (size_t)npad * sizeof(int);
+        static PerDeviceOnce once;
+        bool *raised = once.slot();
+        if (lds > 64 * 1024 && !*raised) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(direct3_count<CAP>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCountMaxN * (int)sizeof(int));
+            if (e != hipSuccess) return fail((int)e, "%s: %s", who, hipGetErrorString(e));
+            *raised = true;
+        }
+        hipLaunchKernelGGL(direct3_count<CAP>, dim3(kLdsChunks, 2, n), dim3(kScanThreads), lds, stream, jobs, N, npad, sticky_status);
+        hipLaunchKernelGGL(direct3_combine<CAP>, dim3((npad / 4 + kBlock - 1) / kBlock, 2, n), dim3(kBlock), 0, stream, jobs, npad);
+    }
+    if (any_flat)
+        hipLaunchKernelGGL(direct2_count<CAP>, dim3(eblocks, 1, n), dim3(kBlock), 0, stream, jobs, N, npad, sticky_status);
+    hipLaunchKernelGGL(direct2_scan<CAP>, dim3(2, 1, n), dim3(kScanThreads), 0, stream, jobs, npad, N, sticky_status);
+    if (emax > 0) {
+        hipLaunchKernelGGL(direct2_place<CAP>, dim3(eblocks, 1, n), dim3(kBlock), 0, stream, jobs, npad, sticky_status);
+        hipLaunchKernelGGL(direct2_rank_fwd<CAP>, dim3(eblocks, 1, n), dim3(kBlock), 0, stream, jobs, npad, sticky_status);
+    }
+    // (also re-zeroes the counters: launched even for E = 0)
+    hipLaunchKernelGGL(direct2_rank_bwd<CAP>, dim3(std::max(eblocks, (2 * npad + kBlock - 1) / kBlock), 1, n), dim3(kBlock), 0, stream,
+                       jobs, npad, sticky_status);
+    return 0;
 }
 
 }  // namespace
@@ -558,59 +668,17 @@ extern "C" int stg_graph_build_direct2_device(const int32_t *src, const int32_t 
         !fwd_row_offset || !bwd_row_offset || !sticky_status || !workspace || (N > 0 && (!in_degrees || !out_degrees || !zero_counters)) ||
         (!fwd_node_ids != !bwd_node_ids) || ((norm_col_fwd || norm_col_bwd) && !norm))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_graph_build_direct2_device: NULL pointer argument");
+    if (((uintptr_t)zero_counters | (uintptr_t)fwd_row_offset | (uintptr_t)bwd_row_offset | (uintptr_t)in_degrees |
+         (uintptr_t)out_degrees | (uintptr_t)norm) & 15)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_graph_build_direct2_device: the per-vertex arrays must be 16-byte aligned");
     const DirectLayout L = direct_layout(E, N);
     if (workspace_bytes < L.total)
         return fail(STG_ERR_WORKSPACE, "stg_graph_build_direct2_device: workspace %zu < required %zu", workspace_bytes, L.total);
     char *ws = static_cast<char *>(workspace);
-    auto *key_f = reinterpret_cast<uint64_t *>(ws + L.key_f);
-    auto *row_f = reinterpret_cast<int *>(ws + L.row_f);
-    auto *key_b = reinterpret_cast<uint64_t *>(ws + L.key_b);
-    auto *row_b = reinterpret_cast<int *>(ws + L.row_b);
-    auto *pos_f = reinterpret_cast<int *>(ws + L.pos_f);
-    auto *pos_b = reinterpret_cast<int *>(ws + L.pos_b);
-    const int eblocks = (int)std::max<int64_t>(1, std::min<int64_t>((E + kBlock - 1) / kBlock, 256 * 16));
-    const int npad = (std::max(N, 1) + 3) & ~3;
-    if (((uintptr_t)zero_counters | (uintptr_t)fwd_row_offset | (uintptr_t)bwd_row_offset | (uintptr_t)in_degrees |
-         (uintptr_t)out_degrees | (uintptr_t)norm) & 15)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_graph_build_direct2_device: the per-vertex arrays must be 16-byte aligned");
-    // histograms in LDS when |V| fits it and there are enough edges per vertex to pay for writing and combining 2 x 16 x |V| counts
-    const int mode = tuning().build_lds_count;
-    const bool lds_count = E > 0 && N <= kLdsCountMaxN && mode != 2 && (mode == 1 || (E >= 2 * (int64_t)N && E >= 32768));
-    int chunk_shift = 0;                                   // chunks of 2^shift edges (the chunk of an edge is a shift in the placing passes)
-    while (((int64_t)kLdsChunks << chunk_shift) < E) ++chunk_shift;
-    const int64_t chunk_len = (int64_t)1 << chunk_shift;
-    int *part = reinterpret_cast<int *>(ws + L.part);
-    const int *base_f = lds_count ? part : nullptr, *base_b = lds_count ? part + (size_t)kLdsChunks * npad : nullptr;
-    if (lds_count) {
-        const size_t lds = (size_t)npad * sizeof(int);
-        static PerDeviceOnce once;
-        bool *raised = once.slot();
-        if (lds > 64 * 1024 && !*raised) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(direct3_count), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     kLdsCountMaxN * (int)sizeof(int));
-            if (e != hipSuccess) return fail((int)e, "stg_graph_build_direct2_device: %s", hipGetErrorString(e));
-            *raised = true;
-        }
-        hipLaunchKernelGGL(direct3_count, dim3(kLdsChunks, 2), dim3(kScanThreads), lds, stream, src, dst, E, N, chunk_len, part, npad,
-                           pos_f, pos_b, sticky_status);
-        hipLaunchKernelGGL(direct3_combine, dim3((npad / 4 + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stream, part, npad, zero_counters);
-    } else if (E > 0) {
-        hipLaunchKernelGGL(direct2_count, dim3(eblocks), dim3(kBlock), 0, stream, src, dst, E, N, zero_counters, npad, pos_f, pos_b,
-                           sticky_status);
-    }
-    hipLaunchKernelGGL(direct2_scan, dim3(2), dim3(kScanThreads), 0, stream, zero_counters, npad, N, fwd_row_offset, bwd_row_offset,
-                       in_degrees, out_degrees, norm, sticky_status);
-    if (E > 0) {
-        hipLaunchKernelGGL(direct2_place, dim3(eblocks), dim3(kBlock), 0, stream, src, dst, E, fwd_row_offset, pos_f, key_f, row_f,
-                           sticky_status, base_f, npad, chunk_shift);
-        hipLaunchKernelGGL(direct2_rank_fwd, dim3(eblocks), dim3(kBlock), 0, stream, key_f, row_f, E, fwd_row_offset, bwd_row_offset,
-                           pos_b, fwd_column_indices, fwd_eids, perm_fwd, key_b, row_b, norm, norm_col_fwd, sticky_status, base_b, npad,
-                           chunk_shift);
-    }
-    // (also re-zeroes the counters: launched even for E = 0)
-    hipLaunchKernelGGL(direct2_rank_bwd, dim3(std::max(eblocks, (2 * npad + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                       key_b, row_b, E, bwd_row_offset, bwd_column_indices, bwd_eids, norm, norm_col_bwd, zero_counters, npad,
-                       sticky_status);
+    BuildJobs<1> jobs;
+    jobs.j[0] = make_job(L, ws, src, dst, E, N, perm_fwd, fwd_row_offset, fwd_column_indices, fwd_eids, bwd_row_offset,
+                         bwd_column_indices, bwd_eids, in_degrees, out_degrees, norm, norm_col_fwd, norm_col_bwd, zero_counters);
+    if (const int rc = run_direct2(jobs, 1, N, sticky_status, stream, "stg_graph_build_direct2_device")) return rc;
     if (N > 0 && fwd_node_ids) {
         auto *ka = reinterpret_cast<unsigned *>(ws + L.deg_key_a);
         auto *kb = reinterpret_cast<unsigned *>(ws + L.deg_key_b);
@@ -626,6 +694,42 @@ extern "C" int stg_graph_build_direct2_device(const int32_t *src, const int32_t 
         }
     }
     return check_launch("stg_graph_build_direct2_device");
+}
+
+extern "C" int stg_graph_build_direct2_batch_device(const stg_build_job *jobs_in, int32_t n_jobs, int32_t N, int32_t *sticky_status,
+                                                    void *stream_)
+{
+    using namespace stg;
+    const char *who = "stg_graph_build_direct2_batch_device";
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_jobs < 0 || N <= 0 || (n_jobs > 0 && !jobs_in) || !sticky_status)
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad argument (n_jobs=%d, N=%d)", who, n_jobs, N);
+    if (n_jobs > kBuildBatchMax) return fail(STG_ERR_UNSUPPORTED, "%s: %d jobs > STG_BUILD_BATCH_MAX = %d", who, n_jobs, kBuildBatchMax);
+    if (n_jobs == 0) return 0;
+    BuildJobs<kBuildBatchMax> jobs{};
+    for (int i = 0; i < n_jobs; ++i) {
+        const stg_build_job &q = jobs_in[i];
+        if (q.E < 0) return fail(STG_ERR_INVALID_ARGUMENT, "%s: job %d: negative size", who, i);
+        if (q.E >= (int64_t(1) << 31)) return fail(STG_ERR_UNSUPPORTED, "%s: job %d: E=%lld does not fit int32 edge ids", who, i, (long long)q.E);
+        if ((q.E > 0 && (!q.src || !q.dst || !q.perm_fwd || !q.fwd_column_indices || !q.fwd_eids || !q.bwd_column_indices || !q.bwd_eids)) ||
+            !q.fwd_row_offset || !q.bwd_row_offset || !q.workspace || !q.in_degrees || !q.out_degrees || !q.zero_counters ||
+            ((q.norm_col_fwd || q.norm_col_bwd) && !q.norm))
+            return fail(STG_ERR_INVALID_ARGUMENT, "%s: job %d: NULL pointer argument", who, i);
+        if (((uintptr_t)q.zero_counters | (uintptr_t)q.fwd_row_offset | (uintptr_t)q.bwd_row_offset | (uintptr_t)q.in_degrees |
+             (uintptr_t)q.out_degrees | (uintptr_t)q.norm) & 15)
+            return fail(STG_ERR_INVALID_ARGUMENT, "%s: job %d: the per-vertex arrays must be 16-byte aligned", who, i);
+        for (int k = 0; k < i; ++k)
+            if (jobs_in[k].zero_counters == q.zero_counters || jobs_in[k].workspace == q.workspace)
+                return fail(STG_ERR_INVALID_ARGUMENT, "%s: jobs %d and %d share counters or workspace", who, k, i);
+        const DirectLayout L = direct_layout(q.E, N);
+        if (q.workspace_bytes < L.total)
+            return fail(STG_ERR_WORKSPACE, "%s: job %d: workspace %zu < required %zu", who, i, q.workspace_bytes, L.total);
+        jobs.j[i] = make_job(L, static_cast<char *>(q.workspace), q.src, q.dst, q.E, N, q.perm_fwd, q.fwd_row_offset, q.fwd_column_indices,
+                             q.fwd_eids, q.bwd_row_offset, q.bwd_column_indices, q.bwd_eids, q.in_degrees, q.out_degrees, q.norm,
+                             q.norm_col_fwd, q.norm_col_bwd, q.zero_counters);
+    }
+    if (const int rc = run_direct2(jobs, n_jobs, N, sticky_status, stream, who)) return rc;
+    return check_launch(who);
 }
 
 extern "C" size_t stg_rows_by_degree_workspace_bytes(int32_t N)

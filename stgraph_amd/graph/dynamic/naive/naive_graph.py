@@ -90,6 +90,28 @@ class NaiveGraph(DynamicGraph):
             self._snapshots.move_to_end(t)
         return g
 
+    def prebuild(self, timestamps) -> int:
+        """Rebuild the not-yet-cached snapshots among ``timestamps`` (each validated by an earlier build on the counting
+        path, non-empty) as one batched device build -- the launches of ONE snapshot's rebuild, bit-identical CSRs.  What
+        does not qualify is left to ``_snapshot``.  Returns the number of snapshots built."""
+        cap = kernels._C.BUILD_BATCH_MAX
+        if not self._resident and self._max_cached is not None:          # never more snapshots alive than the cache allows
+            cap = min(cap, max(1, self._max_cached) - len(self._snapshots))
+        ts = [t for t in timestamps if t not in self._snapshots and self._built_by.get(t) == "direct"
+              and t in self._distinct_edges and self._edges[t][0].numel() > 0][:max(cap, 0)]
+        if (len(ts) < 2 or self._device.type != "cuda" or not kernels.FUSED_REBUILD or not kernels._DIRECT_BUILD
+                or self.max_num_nodes <= 0 or any(self._edges[t][0].numel() > kernels.DIRECT_BUILD_MAX_EDGES for t in ts)):
+            return 0
+        t0 = time.time()
+        built = kernels.build_graph_csr_batch([self._edges[t] for t in ts], self.max_num_nodes, self._device)
+        for t, g in zip(ts, built):
+            self._snapshots[t] = g
+        if not any(built[0].unchecked_status is p for p in self._pending_status[-1:]):
+            self._pending_status.append(built[0].unchecked_status)
+        self.build_count += len(ts)
+        self.build_time += time.time() - t0
+        return len(ts)
+
     def verify_builds(self) -> None:
         """One host sync for all rebuilds since the last call whose per-build status read was skipped (a snapshot that
         was validated when first built).  ``reset_graph`` -- the start of every epoch of the reference's loops -- calls it."""

@@ -256,7 +256,7 @@ def set_direct_build(enabled: bool) -> None:
 
 
 FUSED_REBUILD = True     # re-builds of a validated edge list go through stg_graph_build_direct2_device
-BUILD_SLOTS = 4          # counter buffers per (device, |V|): that many rebuilds may be in flight on different streams
+BUILD_SLOTS = 16         # counter buffers per (device, |V|): that many rebuilds may be in flight on different streams
 _BUILD_COUNTERS = {}
 
 
@@ -272,6 +272,57 @@ def _build_counters(device, N: int, slot: int = 0):
         hit = _BUILD_COUNTERS[key] = (torch.zeros(2 * ((max(N, 1) + 3) & ~3), dtype=torch.int32, device=device),
                                       torch.zeros(1, dtype=torch.int32, device=device))
     return hit
+
+
+def build_graph_csr_batch(edge_lists, num_nodes: int, device: torch.device | str) -> list:
+    """The re-builds of SEVERAL validated edge lists over the same vertex set -- the snapshots of a BPTT window -- in the
+    launches of one (stg_graph_build_direct2_batch_device; <= _C.BUILD_BATCH_MAX lists).  Every GraphCSR is bit-identical
+    to ``build_graph_csr(s, d, N, device, lazy_node_ids=True, known_path='direct')`` of its list."""
+    device = torch.device(device)
+    N = int(num_nodes)
+    n = len(edge_lists)
+    if not 0 < n <= _C.BUILD_BATCH_MAX or N <= 0 or device.type != "cuda":
+        raise ValueError("build_graph_csr_batch: 1 .. %d edge lists over N > 0 vertices on a GPU" % _C.BUILD_BATCH_MAX)
+    i32 = dict(dtype=torch.int32, device=device)
+    jobs = (_C.BuildJob * n)()
+    out, keep = [], []
+    sticky = _build_counters(device, N, 0)[1]
+    for k, (src, dst) in enumerate(edge_lists):
+        s, d = _as_i32(src, device), _as_i32(dst, device)
+        if s.dim() != 1 or s.shape != d.shape:
+            raise ValueError("src and dst must be 1-D arrays of equal length")
+        E = int(s.shape[0])
+        if E == 0 or E > DIRECT_BUILD_MAX_EDGES:
+            raise ValueError("build_graph_csr_batch: every list needs 1 .. DIRECT_BUILD_MAX_EDGES edges")
+        perm = torch.empty(E, dtype=torch.int64, device=device)
+        indeg, outdeg = torch.empty(N, **i32), torch.empty(N, **i32)
+        fwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), None, False, indeg)
+        bwd = DeviceCSR(torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32), None, False, outdeg)
+        norm = torch.empty(N, 1, dtype=torch.float32, device=device)
+        nc_f = torch.empty(E, dtype=torch.float32, device=device)
+        nc_b = torch.empty(E, dtype=torch.float32, device=device)
+        ws_bytes = int(_C.lib.stg_graph_build_direct_workspace_bytes(E, N))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        counters = _build_counters(device, N, k)[0]
+        j = jobs[k]
+        j.src, j.dst, j.E = _ptr(s), _ptr(d), E
+        j.perm_fwd = _ptr(perm)
+        j.fwd_row_offset, j.fwd_column_indices, j.fwd_eids = _ptr(fwd.row_offset), _ptr(fwd.column_indices), _ptr(fwd.eids)
+        j.bwd_row_offset, j.bwd_column_indices, j.bwd_eids = _ptr(bwd.row_offset), _ptr(bwd.column_indices), _ptr(bwd.eids)
+        j.in_degrees, j.out_degrees = _ptr(indeg), _ptr(outdeg)
+        j.norm, j.norm_col_fwd, j.norm_col_bwd = _ptr(norm), _ptr(nc_f), _ptr(nc_b)
+        j.zero_counters, j.workspace, j.workspace_bytes = _ptr(counters), _ptr(ws), ws_bytes
+        keep.append((s, d, ws))
+        g = GraphCSR(N, fwd, bwd, indeg, outdeg, perm)
+        g.built_by = "direct"
+        g.unchecked_status = sticky
+        g.norm_in = norm
+        fwd.__dict__["_edge_cache"] = {"norm": (norm, norm._version, nc_f)}
+        bwd.__dict__["_edge_cache"] = {"norm": (norm, norm._version, nc_b)}
+        out.append(g)
+    with torch.cuda.device(device):
+        _C.check(_C.lib.stg_graph_build_direct2_batch_device(jobs, n, N, _ptr(sticky), _stream_ptr(device)))
+    return out
 
 
 def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_node_ids: bool = False,

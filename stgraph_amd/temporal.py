@@ -844,6 +844,8 @@ class CapturedDynamicWindows:
         # rebuild mode: snapshot builds on parallel branches of the window's graph.  Off: measured 30.2 against 31.7 epochs/s
         # at cfg5 (profiles/r03 notes in DESIGN.md) -- hipGraphLaunch did not overlap the branches' 5-launch chains
         self.parallel_builds = False
+        # rebuild mode: the window's snapshots as ONE batched build (stg_graph_build_direct2_batch_device)
+        self.batched_builds = True
         self.model, self.graph, self.edges, self.targets = model, graph, pos_neg_edges, pos_neg_targets
         self.total = len(pos_neg_edges)
         self.B = backprop_every or self.total
@@ -881,7 +883,7 @@ class CapturedDynamicWindows:
         g = self.graph
         cur = torch.cuda.current_stream(self.dev)
         if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(kernels.BUILD_SLOTS)]
+            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(min(4, kernels.BUILD_SLOTS))]
         used = []
         for i, t in enumerate(self.timestamps(w)):
             if t in g._snapshots or g._built_by.get(t) != "direct":
@@ -900,8 +902,12 @@ class CapturedDynamicWindows:
         from .nn import functional as SF
         g = self.graph
         self.bucket.zero()
-        if not self._store and not g._resident and self.parallel_builds:
-            self._prebuild(w)
+        if not self._store and not g._resident:
+            if self.parallel_builds:
+                self._prebuild(w)
+            elif self.batched_builds:
+                while g.prebuild(self.timestamps(w)):        # the window's snapshots in the launches of one build
+                    pass                                     # (a window longer than STG_BUILD_BATCH_MAX: of two, ...)
         steps = []
         for t in self.timestamps(w):
             g.get_graph(t)

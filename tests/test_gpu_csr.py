@@ -206,3 +206,105 @@ def _fused_rebuild_checks(cuda, kernels, first, s, d, n):
     torch.cuda.synchronize()
     assert torch.equal(cap.fwd.column_indices, first.fwd.column_indices) and torch.equal(cap.bwd.eids, first.bwd.eids)
     assert int(kernels._build_counters(cuda, n)[0].abs().sum()) == 0
+
+
+def _same_graph(a, b, tag):
+    for side in ("fwd", "bwd"):
+        x, y = getattr(a, side), getattr(b, side)
+        for k in ("row_offset", "column_indices", "eids"):
+            assert torch.equal(getattr(x, k), getattr(y, k)), (tag, side, k)
+        assert torch.equal(x._edge_cache["norm"][2], y._edge_cache["norm"][2]), (tag, side, "norm_col")
+    assert torch.equal(a.in_degrees, b.in_degrees) and torch.equal(a.out_degrees, b.out_degrees), tag
+    assert torch.equal(a.perm_fwd, b.perm_fwd) and torch.equal(a.norm_in, b.norm_in), tag
+
+
+@pytest.mark.parametrize("lds_count", [0, 1, 2])
+@pytest.mark.parametrize("n,sizes", [(64, [400, 1, 90]), (2708, [10556, 9000, 12000, 300]),
+                                     (25_000, [250_000, 240_000, 40_000, 260_000, 250_001, 249_999, 8, 250_000]),
+                                     (40_960, [300_000] * 2 + [90_000]), (70_000, [300_000, 280_000]),
+                                     (5_000, [60_000 + 17 * i for i in range(16)])])
+def test_a_window_of_rebuilds_in_the_launches_of_one(cuda, n, sizes, lds_count):
+    """stg_graph_build_direct2_batch_device: the snapshots of a window (different |E|, some counted in LDS and some not in
+    the same batch) against one stg_graph_build_direct2_device call each -- every array bit for bit; counters of every
+    slot zero afterwards; replayable from a HIP graph."""
+    from stgraph_amd import _C, kernels
+    lists = []
+    for i, e in enumerate(sizes):
+        src, dst = random_graph(n + e + i, n, e, hub=False)
+        lists.append((torch.from_numpy(src).to(cuda), torch.from_numpy(dst).to(cuda)))
+        assert kernels.build_graph_csr(*lists[-1], n, cuda, lazy_node_ids=True).built_by == "direct"      # validated
+    _C.set_tuning("build_lds_count", lds_count)
+    try:
+        singles = [kernels.build_graph_csr(s, d, n, cuda, lazy_node_ids=True, known_path="direct") for s, d in lists]
+        for rep in range(2):
+            batch = kernels.build_graph_csr_batch(lists, n, cuda)
+            assert len(batch) == len(lists)
+            for i, (a, b) in enumerate(zip(singles, batch)):
+                _same_graph(a, b, (rep, i))
+            for slot in range(len(lists)):
+                counters, sticky = kernels._build_counters(cuda, n, slot)
+                assert int(counters.abs().sum()) == 0 and int(sticky) == 0
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cap = kernels.build_graph_csr_batch(lists, n, cuda)
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(singles, cap)):
+            _same_graph(a, b, ("graph", i))
+    finally:
+        _C.set_tuning("build_lds_count", 0)
+
+
+def test_batched_rebuild_argument_checks(cuda):
+    from stgraph_amd import _C, kernels
+    n = 100
+    src, dst = random_graph(3, n, 500, hub=False)
+    s, d = torch.from_numpy(src).to(cuda), torch.from_numpy(dst).to(cuda)
+    with pytest.raises(ValueError):
+        kernels.build_graph_csr_batch([(s, d)] * (_C.BUILD_BATCH_MAX + 1), n, cuda)
+    with pytest.raises(ValueError):
+        kernels.build_graph_csr_batch([], n, cuda)
+    with pytest.raises(ValueError):
+        kernels.build_graph_csr_batch([(s, d), (s[:0], d[:0])], n, cuda)
+    sticky = torch.zeros(1, dtype=torch.int32, device=cuda)
+    jobs = (_C.BuildJob * 2)()
+    assert _C.lib.stg_graph_build_direct2_batch_device(jobs, _C.BUILD_BATCH_MAX + 1, n, sticky.data_ptr(), None) == _C.STG_ERR_UNSUPPORTED
+    assert _C.lib.stg_graph_build_direct2_batch_device(jobs, 2, n, sticky.data_ptr(), None) == _C.STG_ERR_INVALID_ARGUMENT    # NULL arrays
+    assert _C.lib.stg_graph_build_direct2_batch_device(jobs, 0, n, sticky.data_ptr(), None) == 0
+    # a corrupted list inside a batch reports through the sticky word, as a single rebuild does
+    good = kernels.build_graph_csr(s, d, n, cuda, lazy_node_ids=True)
+    bad = s.clone()
+    bad[5] = n + 1
+    kernels.build_graph_csr_batch([(s, d), (bad, d)], n, cuda)
+    word = kernels._build_counters(cuda, n, 0)[1]
+    assert int(word) != 0
+    word.zero_()
+    for slot in range(2):
+        kernels._build_counters(cuda, n, slot)[0].zero_()
+    again = kernels.build_graph_csr_batch([(s, d), (s, d)], n, cuda)
+    _same_graph(kernels.build_graph_csr(s, d, n, cuda, lazy_node_ids=True, known_path="direct"), again[1], "after")
+    assert torch.equal(good.fwd.column_indices, again[0].fwd.column_indices)
+
+
+def test_naive_graph_prebuilds_a_window(cuda):
+    from stgraph_amd.graph import NaiveGraph
+    n = 3000
+    rng = np.random.default_rng(1)
+    snaps = []
+    for t in range(6):
+        keys = rng.choice(n * n, size=20_000 + 100 * t, replace=False)
+        snaps.append((torch.from_numpy((keys // n).astype(np.int32)).to(cuda), torch.from_numpy((keys % n).astype(np.int32)).to(cuda)))
+    G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False, resident=False, max_cached=5)
+    first = [(G.csr("fwd", t).column_indices.clone(), G.csr("bwd", t).eids.clone()) for t in range(6)]
+    G._snapshots.clear()
+    builds = G.build_count
+    assert G.prebuild(range(0, 4)) == 4 and G.build_count == builds + 4
+    assert G.prebuild(range(0, 4)) == 0                                  # all cached
+    for t in range(4):
+        assert torch.equal(G.csr("fwd", t).column_indices, first[t][0]) and torch.equal(G.csr("bwd", t).eids, first[t][1])
+    assert G.build_count == builds + 4                                   # served from the batch
+    G._snapshots.clear()
+    assert G.prebuild(range(0, 6)) == 5                                  # max_cached bounds a batch
+    G.reset_graph()                                                      # deferred status words: clean
