@@ -98,7 +98,9 @@ class NaiveGraph(DynamicGraph):
         if not self._resident and self._max_cached is not None:          # never more snapshots alive than the cache allows
             cap = min(cap, max(1, self._max_cached) - len(self._snapshots))
         ts = [t for t in timestamps if t not in self._snapshots and self._built_by.get(t) == "direct"
-              and t in self._distinct_edges and self._edges[t][0].numel() > 0][:max(cap, 0)]
+              and t in self._distinct_edges and self._edges[t][0].numel() > 0]
+        batches = -(-len(ts) // kernels._C.BUILD_BATCH_MAX)              # a window of 20: two batches of 10, not 16 + 4
+        ts = ts[:max(min(cap, -(-len(ts) // max(batches, 1))), 0)]
         if (len(ts) < 2 or self._device.type != "cuda" or not kernels.FUSED_REBUILD or not kernels._DIRECT_BUILD
                 or self.max_num_nodes <= 0 or any(self._edges[t][0].numel() > kernels.DIRECT_BUILD_MAX_EDGES for t in ts)):
             return 0
