@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 18
+#define STG_ABI_VERSION 19
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -54,7 +54,9 @@ const char *stg_last_error_string(void);
  * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_cyclic" (its row-group hand-out: 0 .. 2),
  * "gcn_wide_long" (rows of >= 1024 edges at F >= 128: 0 = feature-sliced workgroups beside the main launch, 1 = never, 2 = behind
  * it on the same stream), "build_lds_count" (stg_graph_build_direct2_device: 0 = histograms in LDS when |V| <= 40 K and the graph
- * is dense enough, 1 = whenever |V| fits, 2 = never). */
+ * is dense enough, 1 = whenever |V| fits, 2 = never), "store_rows" (stg_edgeset_step_device given the old set's row offsets: 0 = the
+ * new row offsets are derived from them inside the merge launch -- two launches per step --, 1 = searched in the merged keys by a
+ * launch of their own, as without the offsets). */
 int stg_set_tuning(const char *key, int value);
 
 /* ---------------------------------------------------------------- CSR, host
@@ -230,8 +232,11 @@ int stg_edgeset_merge_device(const uint64_t *keys_in, int64_t E, const uint64_t 
  * launches: (old \ del) U add in both orientations from batches packed + sorted up front, both CSRs (row offsets +
  * columns: rows back to front, or ascending with STG_EMIT_KEY_ORDER), in_degrees [N] (nullable), norm [N] = in_deg^-1/2
  * (0 for isolated rows; nullable) and norm gathered through either CSR's columns [E_out] (nullable; need norm).
- * fwd_row_offset_in / bwd_row_offset_in (both or neither; nullable): the row offsets [N + 1] of keys_fwd_in / keys_bwd_in, as a
- * previous step emitted them -- search hints only (a batch key is then placed inside its own row of the old set), never results.
+ * fwd_row_offset_in / bwd_row_offset_in (both or neither; nullable): EXACTLY the row offsets [N + 1] of keys_fwd_in / keys_bwd_in, as
+ * a previous step emitted them.  With them a batch key is placed inside its own row of the old set, and the new row offsets, degrees
+ * and norm are derived from them and the batches (old offset + additions below the row - deletions below it; exact for every step that
+ * leaves status clean) by blocks of the merge launch: TWO launches per step.  Offsets that are not those of the input set give
+ * undefined outputs.
  * status is OR-ed into, never cleared (codes as stg_edgeset_update_device): one word may serve a whole store. */
 int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E, const uint64_t *add_fwd,
                             const uint64_t *add_bwd, int64_t n_add, const uint64_t *del_fwd, const uint64_t *del_bwd,

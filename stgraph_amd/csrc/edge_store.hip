@@ -242,12 +242,46 @@ struct StepArgs {
     int *status;
     int64_t E, na, nd, E_out;
     int N, nb_old, nb_add;
+    int nb_rows;                                           // > 0: the row offsets are derived from ro_old by that many extra blocks per side of the merge launch
 };
+
+// Row offsets, in-degrees and norm of the NEW set without reading it: ro_new[v] = ro_old[v] + #(added keys below row v) - #(deleted
+// keys below row v) -- exact whenever the step is valid (every deletion present, no addition present: anything else raises a status
+// bit in the merge blocks).  Two 13-step searches over the L2-resident batches instead of an 18-step one over the merged keys, and
+// -- the point -- no dependence on the merge: these blocks ride in ITS launch and the step is two launches, not three.
+// Block b of a side takes rows [255 b, 255 b + 255]; the last thread's row is only the next row of its neighbour's degree.
+__device__ __forceinline__ void step_rows_from_old(const StepArgs &a, int side, int b)
+{
+    __shared__ int first[kBlock];
+    const int t = (int)threadIdx.x;
+    const int64_t v = (int64_t)b * (kBlock - 1) + t;
+    int r = 0;
+    if (v <= a.N) {
+        const uint64_t kv = (uint64_t)(unsigned)v << kStoreBits;
+        int64_t al, dl;
+        lower_bound2_dev(a.add[side], a.na, kv, a.del[side], a.nd, kv, al, dl);
+        r = a.ro_old[side][v] + (int)al - (int)dl;
+    }
+    first[t] = r;
+    __syncthreads();
+    if (t == kBlock - 1 || v > a.N) return;
+    a.ro[side][v] = r;
+    if (side == 0 && v < a.N && (a.in_deg || a.norm)) {
+        const int d = first[t + 1] - r;
+        if (a.in_deg) a.in_deg[v] = d;
+        if (a.norm) a.norm[v] = d > 0 ? __fdiv_rn(1.0f, __fsqrt_rn((float)d)) : 0.f;     // = degree_norm_kernel
+    }
+}
 
 __global__ __launch_bounds__(kBlock) void step_merge_kernel(const StepArgs a)
 {
     const int per = a.nb_old + a.nb_add;
-    const int side = (int)blockIdx.x / per, r = (int)blockIdx.x - side * per;       // block-uniform
+    if ((int)blockIdx.x >= 2 * per) {                                               // (block-uniform, as everything below)
+        const int rb = (int)blockIdx.x - 2 * per;
+        step_rows_from_old(a, rb / a.nb_rows, rb % a.nb_rows);
+        return;
+    }
+    const int side = (int)blockIdx.x / per, r = (int)blockIdx.x - side * per;
     if (r < a.nb_old)
         scatter_old_tile(a.old[side], a.E, a.add[side], a.na, a.del[side], a.nd, a.out[side], a.E_out, a.status, r);
     else
@@ -584,9 +618,14 @@ extern "C" int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64
     const int64_t tile = (int64_t)kBlock * kMergeItems;
     a.nb_old = (int)((E + tile - 1) / tile);
     a.nb_add = n_add + n_del > 0 ? grid_for(n_add + n_del) : 0;
+    // with the old set's row offsets at hand the new ones do not wait for the merge: their blocks join its launch
+    const bool rows_in_merge = hints && a.nb_old + a.nb_add > 0 && tuning().store_rows != 1 && fwd_row_offset_in != fwd_row_offset &&
+                               bwd_row_offset_in != bwd_row_offset;
+    a.nb_rows = rows_in_merge ? (int)(((int64_t)N + 1 + kBlock - 2) / (kBlock - 1)) : 0;
     if (a.nb_old + a.nb_add > 0)
-        hipLaunchKernelGGL(step_merge_kernel, dim3(2u * (unsigned)(a.nb_old + a.nb_add)), dim3(kBlock), 0, stream, a);
-    hipLaunchKernelGGL(step_rows_kernel, dim3((unsigned)((2 * ((int64_t)N + 1) + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL(step_merge_kernel, dim3(2u * (unsigned)(a.nb_old + a.nb_add + a.nb_rows)), dim3(kBlock), 0, stream, a);
+    if (!rows_in_merge)
+        hipLaunchKernelGGL(step_rows_kernel, dim3((unsigned)((2 * ((int64_t)N + 1) + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, a);
     if (E_out > 0) {
         if (flags & STG_EMIT_KEY_ORDER)
             hipLaunchKernelGGL((step_emit_kernel<true>), dim3(grid_for(2 * E_out)), dim3(kBlock), 0, stream, a);

@@ -123,6 +123,7 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().build_lds_count = value;
         return 0;
     }
+    if (!std::strcmp(key, "store_rows")) { tuning().store_rows = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "rowgemm16")) { tuning().rowgemm16 = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "gemm_wide")) {
         if (value != 0 && value != 1) return fail(STG_ERR_INVALID_ARGUMENT, "gemm_wide must be 0 (auto) or 1 (never)");

@@ -146,3 +146,54 @@ def test_invalid_updates_are_flagged_on_device(cuda):
         q = dele or (e, e)
         with pytest.raises(ValueError):
             kernels.edgeset_check(kernels.edgeset_update(base, a[0], a[1], q[0], q[1]))
+
+
+@pytest.mark.parametrize("key_order", [False, True])
+@pytest.mark.parametrize("n,e,k", [(1, 1, 1), (254, 3000, 200), (255, 3000, 200), (256, 3000, 0), (509, 9000, 700), (510, 9000, 700),
+                                   (25_000, 250_000, 6_250)])
+def test_step_with_row_offsets_of_the_old_set_is_two_launches_and_the_same_bits(cuda, n, e, k, key_order):
+    """stg_edgeset_step_device given the row offsets of its input set derives the new row offsets, in-degrees and norm from
+    them and the batches inside the merge launch (no pass over the merged keys): a chain of steps against the same chain
+    without the offsets and with the derivation switched off (tuning 'store_rows' = 1) -- every output bit for bit, also
+    with an empty addition or deletion batch and with |V| + 1 on either side of a multiple of the 255 rows a block takes."""
+    from stgraph_amd import _C, kernels
+    src, dst = random_graph(5 + n, n, e, hub=False)
+    keys = np.unique(src.astype(np.int64) * n + dst)                  # distinct edges
+    rng = np.random.default_rng(3)
+    rng.shuffle(keys)
+    src, dst = torch.from_numpy((keys // n).astype(np.int32)).to(cuda), torch.from_numpy((keys % n).astype(np.int32)).to(cuda)
+    e = len(keys)
+    k = min(k, e // 4)
+    base = kernels.edgeset_update(kernels.edgeset_empty(n, cuda), src[2 * k:], dst[2 * k:])
+    pack = lambda lo, hi: kernels.edgeset_pack_sorted(src[lo:hi], dst[lo:hi], cuda)      # noqa: E731
+    none = pack(0, 0)
+    batches = [(pack(0, k), pack(e - k, e)), (pack(k, 2 * k), none), (none, pack(0, k)), (pack(e - k, e), pack(k, 2 * k))]
+    if k == 0:
+        batches = [(pack(0, 0), pack(0, 0))]
+
+    def chain(hints_on, rows_mode):
+        _C.set_tuning("store_rows", rows_mode)
+        try:
+            es, hints, outs = base, None, []
+            first = kernels.edgeset_step(base, none, none, key_order)                  # the CSRs of the base set: first hints
+            hints = (first[1].row_offset, first[2].row_offset)
+            for add, dele in batches:
+                es, fwd, bwd, norm = kernels.edgeset_step(es, add, dele, key_order, None, hints if hints_on else None)
+                kernels.edgeset_check(es)
+                hints = (fwd.row_offset, bwd.row_offset)
+                outs.append((es.keys_fwd, es.keys_bwd, fwd.row_offset, bwd.row_offset, fwd.column_indices, bwd.column_indices,
+                             fwd.degrees, norm, fwd._edge_cache["norm"][2], bwd._edge_cache["norm"][2]))
+            return outs
+        finally:
+            _C.set_tuning("store_rows", 0)
+
+    ref = chain(False, 0)
+    for hints_on, mode in ((True, 0), (True, 1)):
+        got = chain(hints_on, mode)
+        for step, (a, b) in enumerate(zip(ref, got)):
+            for i, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x, y), (hints_on, mode, step, i)
+    # and against the rows of the set itself
+    last = ref[-1]
+    rows = (last[0] >> 32).to(torch.int64)
+    assert torch.equal(last[2].long(), torch.searchsorted(rows, torch.arange(n + 1, device=cuda)))
