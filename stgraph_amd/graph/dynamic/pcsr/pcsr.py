@@ -102,9 +102,9 @@ class PCSR:
         if add_keys[0].numel() == 0 and del_keys[0].numel() == 0:
             return
         if FUSED_STEP and self._device.type == "cuda":
-            # merge + both CSRs + in-degree norm (+ its per-edge gathers) in three launches: what every consumer of a
+            # merge + both CSRs + in-degree norm (+ its per-edge gathers) in two launches: what every consumer of a
             # timestamp asks for next anyway (build_csr / build_reverse_csr, the loop's norm)
-            # (the row offsets the previous step emitted for the current set: search hints for the merge)
+            # (the row offsets the previous step emitted for the current set: the new ones are derived from them)
             f0, b0 = self._emitted.get(False), self._emitted.get(True)
             hints = (f0.row_offset, b0.row_offset) if f0 is not None and b0 is not None else None
             self._set, fwd, bwd, self._norm_in = kernels.edgeset_step(self._set, add_keys, del_keys, self._key_order,

@@ -538,12 +538,12 @@ def edgeset_merge(es: EdgeSet, add_keys, del_keys) -> EdgeSet:
 
 
 def edgeset_step(es: EdgeSet, add_keys, del_keys, key_order: bool, status: torch.Tensor | None = None, old_row_offsets=None):
-    """One timestamp of a delta store in three launches (stg_edgeset_step_device): returns ``(new set, forward StoreCSR,
+    """One timestamp of a delta store in two launches (three without ``old_row_offsets``; stg_edgeset_step_device): returns ``(new set, forward StoreCSR,
     backward StoreCSR, norm [N, 1])`` -- the merge of :func:`edgeset_merge`, both emissions of :func:`edgeset_emit_csr`, the
     in-degrees, ``norm = in_deg ** -0.5`` (:func:`degree_norm`'s values) and ``norm`` gathered per edge of either CSR,
     already filed in the CSRs' per-edge caches under the returned ``norm`` tensor.  ``status``: the store's sticky status
     word (OR-ed into; a fresh zero word if None).  ``old_row_offsets``: ``(forward, backward)`` row offsets of ``es`` as an earlier
-    step emitted them -- search hints (a batch key is placed inside its own row of the old set), or None."""
+    step emitted them (EXACTLY those of ``es``: the new row offsets, degrees and norm are derived from them and the batches), or None."""
     device, N, E = es.device, es.num_nodes, es.num_edges
     if device.type != "cuda":
         raise ValueError("edgeset_step is the device fast path")
