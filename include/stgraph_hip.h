@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 19
+#define STG_ABI_VERSION 20
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -245,6 +245,31 @@ int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bw
                             int32_t *bwd_column_indices, int32_t *in_degrees, float *norm, float *norm_col_fwd,
                             float *norm_col_bwd, const int32_t *fwd_row_offset_in, const int32_t *bwd_row_offset_in,
                             int32_t *status, void *stream);
+
+/* Several steps issued back to back -- the graph updates of a BPTT window, which the training loop performs before the window's
+ * first model step -- need not pay a launch for each emission: a step's emission (columns + per-edge norm of both CSRs) depends
+ * only on ITS merge launch, and the next step's merge does not depend on it.  stg_edgeset_step_deferred_device is
+ * stg_edgeset_step_device except that (i) it describes its own emission in *pending_out instead of launching it and (ii) it
+ * carries `carry` (nullable: an earlier step's pending emission) as extra blocks of its merge launch: ONE launch per step.  The
+ * last pending emission is issued by stg_edgeset_emit_pending_device.  Outputs bit-identical to the undeferred calls; the
+ * column / norm_col arrays of a step hold nothing until its emission has run. */
+typedef struct stg_store_emission {
+    const uint64_t *keys_fwd, *keys_bwd;
+    int64_t E;
+    const int32_t *fwd_row_offset, *bwd_row_offset;
+    int32_t *fwd_column_indices, *bwd_column_indices;
+    const float *norm;
+    float *norm_col_fwd, *norm_col_bwd;
+    int flags;
+} stg_store_emission;
+int stg_edgeset_step_deferred_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E, const uint64_t *add_fwd,
+                                     const uint64_t *add_bwd, int64_t n_add, const uint64_t *del_fwd, const uint64_t *del_bwd,
+                                     int64_t n_del, int32_t N, int flags, uint64_t *keys_fwd_out, uint64_t *keys_bwd_out,
+                                     int32_t *fwd_row_offset, int32_t *fwd_column_indices, int32_t *bwd_row_offset,
+                                     int32_t *bwd_column_indices, int32_t *in_degrees, float *norm, float *norm_col_fwd,
+                                     float *norm_col_bwd, const int32_t *fwd_row_offset_in, const int32_t *bwd_row_offset_in,
+                                     const stg_store_emission *carry, stg_store_emission *pending_out, int32_t *status, void *stream);
+int stg_edgeset_emit_pending_device(const stg_store_emission *pending, void *stream);
 #define STG_EMIT_REVERSE   1   /* rows = src (build_reverse_csr / build_backward_csr) */
 #define STG_EMIT_KEY_ORDER 2   /* GPMA view: rows and columns in key order; default = PCSR's back-to-front rows */
 size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N);

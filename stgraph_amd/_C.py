@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "stg_graph_build_direct2_batch_device",
     "stg_rows_by_degree_workspace_bytes", "stg_rows_by_degree_device",
     "stg_edgeset_update_workspace_bytes", "stg_edgeset_update_device", "stg_edgeset_update_host", "stg_edgeset_merge_device", "stg_edgeset_step_device",
+    "stg_edgeset_step_deferred_device", "stg_edgeset_emit_pending_device",
     "stg_edgeset_emit_csr_workspace_bytes", "stg_edgeset_emit_csr_device", "stg_edgeset_emit_csr_host",
     "stg_jit_compile", "stg_jit_free", "stg_jit_load", "stg_jit_get_function", "stg_jit_unload", "stg_jit_launch",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_layer_fwd", "stg_gcn_agg_edge2", "stg_bias_act_fwd", "stg_bias_act_bwd_workspace_bytes", "stg_bias_act_bwd",
@@ -54,6 +55,14 @@ def _ptr_fields(names):
 
 
 BUILD_BATCH_MAX = 16
+
+
+class StoreEmission(ctypes.Structure):
+    """stg_store_emission (include/stgraph_hip.h)."""
+    _fields_ = [("keys_fwd", ctypes.c_void_p), ("keys_bwd", ctypes.c_void_p), ("E", ctypes.c_int64),
+                ("fwd_row_offset", ctypes.c_void_p), ("bwd_row_offset", ctypes.c_void_p), ("fwd_column_indices", ctypes.c_void_p),
+                ("bwd_column_indices", ctypes.c_void_p), ("norm", ctypes.c_void_p), ("norm_col_fwd", ctypes.c_void_p),
+                ("norm_col_bwd", ctypes.c_void_p), ("flags", ctypes.c_int)]
 
 
 class BuildJob(ctypes.Structure):
@@ -133,6 +142,11 @@ def _load() -> ctypes.CDLL:
     lib.stg_edgeset_merge_device.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, vp]
     lib.stg_edgeset_step_device.restype = ctypes.c_int
     lib.stg_edgeset_step_device.argtypes = [vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, ctypes.c_int] + [vp] * 14
+    lib.stg_edgeset_step_deferred_device.restype = ctypes.c_int
+    lib.stg_edgeset_step_deferred_device.argtypes = ([vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, ctypes.c_int] + [vp] * 12 +
+                                                     [ctypes.POINTER(StoreEmission), ctypes.POINTER(StoreEmission), vp, vp])
+    lib.stg_edgeset_emit_pending_device.restype = ctypes.c_int
+    lib.stg_edgeset_emit_pending_device.argtypes = [ctypes.POINTER(StoreEmission), vp]
     lib.stg_edgeset_emit_csr_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_edgeset_emit_csr_workspace_bytes.argtypes = [i32]
     lib.stg_edgeset_emit_csr_device.restype = ctypes.c_int

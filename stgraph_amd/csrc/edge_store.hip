@@ -245,6 +245,42 @@ struct StepArgs {
     int nb_rows;                                           // > 0: the row offsets are derived from ro_old by that many extra blocks per side of the merge launch
 };
 
+// The emission of a step (columns + per-edge norm of both CSRs from its merged keys, row offsets and norm) as its own argument
+// block: it depends on that step's merge launch only, and the NEXT step's merge does not depend on it -- so a caller that issues
+// several steps back to back (a BPTT window's graph updates) may leave it pending and hand it to the next step, whose merge launch
+// then carries it as extra blocks (nb > 0): ONE launch per step.
+struct EmitArgs {
+    const uint64_t *keys[2];
+    const int *ro[2];
+    int *col[2];
+    float *nc[2];
+    const float *norm;
+    int64_t E;
+    int key_order, nb;
+};
+
+template <bool KEY_ORDER>
+__device__ __forceinline__ void step_emit_blocks(const EmitArgs &a, int64_t block, int64_t nblocks)
+{
+    const int64_t stride = nblocks * kBlock;
+    for (int64_t t = block * kBlock + threadIdx.x; t < 2 * a.E; t += stride) {
+        const int side = t >= a.E ? 1 : 0;
+        const int64_t i = t - (side ? a.E : 0);
+        const uint64_t k = a.keys[side][i];
+        const unsigned row = (unsigned)(k >> kStoreBits), c = (unsigned)k;
+        const int *ro = a.ro[side];
+        const int64_t o = KEY_ORDER ? i : (int64_t)ro[row] + ((int64_t)ro[row + 1] - 1 - i);
+        a.col[side][o] = (int)c;
+        if (a.nc[side]) a.nc[side][o] = a.norm[c];
+    }
+}
+
+template <bool KEY_ORDER>
+__global__ __launch_bounds__(kBlock) void step_emit_kernel(const EmitArgs a)
+{
+    step_emit_blocks<KEY_ORDER>(a, (int64_t)blockIdx.x, (int64_t)gridDim.x);
+}
+
 // Row offsets, in-degrees and norm of the NEW set without reading it: ro_new[v] = ro_old[v] + #(added keys below row v) - #(deleted
 // keys below row v) -- exact whenever the step is valid (every deletion present, no addition present: anything else raises a status
 // bit in the merge blocks).  Two 13-step searches over the L2-resident batches instead of an 18-step one over the merged keys, and
@@ -273,10 +309,16 @@ __device__ __forceinline__ void step_rows_from_old(const StepArgs &a, int side, 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void step_merge_kernel(const StepArgs a)
+__global__ __launch_bounds__(kBlock) void step_merge_kernel(const StepArgs a, const EmitArgs prev)
 {
     const int per = a.nb_old + a.nb_add;
-    if ((int)blockIdx.x >= 2 * per) {                                               // (block-uniform, as everything below)
+    if ((int)blockIdx.x >= 2 * (per + a.nb_rows)) {                                 // (block-uniform, as everything below)
+        const int64_t eb = (int64_t)blockIdx.x - 2 * (per + a.nb_rows);            // an earlier step's pending emission
+        if (prev.key_order) step_emit_blocks<true>(prev, eb, prev.nb);
+        else step_emit_blocks<false>(prev, eb, prev.nb);
+        return;
+    }
+    if ((int)blockIdx.x >= 2 * per) {
         const int rb = (int)blockIdx.x - 2 * per;
         step_rows_from_old(a, rb / a.nb_rows, rb % a.nb_rows);
         return;
@@ -306,22 +348,6 @@ __global__ __launch_bounds__(kBlock) void step_rows_kernel(const StepArgs a)
         const int d = (int)nx64 - lo;
         if (a.in_deg) a.in_deg[v] = d;
         if (a.norm) a.norm[v] = d > 0 ? __fdiv_rn(1.0f, __fsqrt_rn((float)d)) : 0.f;     // = degree_norm_kernel
-    }
-}
-
-template <bool KEY_ORDER>
-__global__ __launch_bounds__(kBlock) void step_emit_kernel(const StepArgs a)
-{
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < 2 * a.E_out; t += stride) {
-        const int side = t >= a.E_out ? 1 : 0;
-        const int64_t i = t - (side ? a.E_out : 0);
-        const uint64_t k = a.out[side][i];
-        const unsigned row = (unsigned)(k >> kStoreBits), c = (unsigned)k;
-        const int *ro = a.ro[side];
-        const int64_t o = KEY_ORDER ? i : (int64_t)ro[row] + ((int64_t)ro[row + 1] - 1 - i);
-        a.col[side][o] = (int)c;
-        if (a.nc[side]) a.nc[side][o] = a.norm[c];
     }
 }
 
@@ -584,29 +610,62 @@ extern "C" int stg_edgeset_merge_device(const uint64_t *keys_in, int64_t E, cons
     return check_launch("stg_edgeset_merge_device");
 }
 
-extern "C" int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E,
-                                       const uint64_t *add_fwd, const uint64_t *add_bwd, int64_t n_add,
-                                       const uint64_t *del_fwd, const uint64_t *del_bwd, int64_t n_del, int32_t N, int flags,
-                                       uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *fwd_row_offset,
-                                       int32_t *fwd_column_indices, int32_t *bwd_row_offset, int32_t *bwd_column_indices,
-                                       int32_t *in_degrees, float *norm, float *norm_col_fwd, float *norm_col_bwd,
-                                       const int32_t *fwd_row_offset_in, const int32_t *bwd_row_offset_in, int32_t *status,
-                                       void *stream_)
+namespace stg {
+namespace {
+
+EmitArgs emit_args(const stg_store_emission &e)
 {
-    using namespace stg;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (E < 0 || n_add < 0 || n_del < 0 || N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: negative size");
+    EmitArgs p{};
+    p.keys[0] = e.keys_fwd; p.keys[1] = e.keys_bwd; p.ro[0] = e.fwd_row_offset; p.ro[1] = e.bwd_row_offset;
+    p.col[0] = e.fwd_column_indices; p.col[1] = e.bwd_column_indices; p.nc[0] = e.norm_col_fwd; p.nc[1] = e.norm_col_bwd;
+    p.norm = e.norm; p.E = e.E; p.key_order = (e.flags & STG_EMIT_KEY_ORDER) ? 1 : 0;
+    p.nb = e.E > 0 ? grid_for(2 * e.E) : 0;
+    return p;
+}
+
+int emission_ok(const stg_store_emission &e, const char *who)
+{
+    if (e.E < 0 || e.E >= (int64_t(1) << 30) || (e.flags & ~STG_EMIT_KEY_ORDER))
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad pending emission (E=%lld, flags=%d)", who, (long long)e.E, e.flags);
+    if (e.E > 0 && (!e.keys_fwd || !e.keys_bwd || !e.fwd_row_offset || !e.bwd_row_offset || !e.fwd_column_indices ||
+                    !e.bwd_column_indices || ((e.norm_col_fwd || e.norm_col_bwd) && !e.norm)))
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer in a pending emission", who);
+    return 0;
+}
+
+void launch_emission(const EmitArgs &p, hipStream_t stream)
+{
+    if (p.nb == 0) return;
+    if (p.key_order) hipLaunchKernelGGL((step_emit_kernel<true>), dim3(p.nb), dim3(kBlock), 0, stream, p);
+    else hipLaunchKernelGGL((step_emit_kernel<false>), dim3(p.nb), dim3(kBlock), 0, stream, p);
+}
+
+// carry (nullable): an earlier step's emission, issued with this step's merge; pending_out (nullable): NULL = this step's
+// emission is launched here, else it is described there and left to the caller.
+int edgeset_step_run(const char *who, const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E, const uint64_t *add_fwd,
+                     const uint64_t *add_bwd, int64_t n_add, const uint64_t *del_fwd, const uint64_t *del_bwd, int64_t n_del, int32_t N,
+                     int flags, uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *fwd_row_offset, int32_t *fwd_column_indices,
+                     int32_t *bwd_row_offset, int32_t *bwd_column_indices, int32_t *in_degrees, float *norm, float *norm_col_fwd,
+                     float *norm_col_bwd, const int32_t *fwd_row_offset_in, const int32_t *bwd_row_offset_in,
+                     const stg_store_emission *carry, stg_store_emission *pending_out, int32_t *status, hipStream_t stream)
+{
+    if (E < 0 || n_add < 0 || n_del < 0 || N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "%s: negative size", who);
     const int64_t E_out = E + n_add - n_del;
     if (E_out < 0 || E + n_add >= (int64_t(1) << 30))
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: edge count %lld out of range", (long long)E_out);
-    if (flags & ~STG_EMIT_KEY_ORDER) return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: unknown flag");
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: edge count %lld out of range", who, (long long)E_out);
+    if (flags & ~STG_EMIT_KEY_ORDER) return fail(STG_ERR_INVALID_ARGUMENT, "%s: unknown flag", who);
     if (!status || !fwd_row_offset || !bwd_row_offset || (E > 0 && (!keys_fwd_in || !keys_bwd_in)) ||
         (E_out > 0 && (!keys_fwd_out || !keys_bwd_out || !fwd_column_indices || !bwd_column_indices)) ||
         (n_add > 0 && (!add_fwd || !add_bwd)) || (n_del > 0 && (!del_fwd || !del_bwd)) ||
         ((norm_col_fwd || norm_col_bwd) && !norm))
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: NULL pointer argument");
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", who);
     if (keys_fwd_out == keys_fwd_in || keys_bwd_out == keys_bwd_in)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_device: the update is out of place");
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: the update is out of place", who);
+    EmitArgs prev{};
+    if (carry) {
+        if (const int rc = emission_ok(*carry, who)) return rc;
+        prev = emit_args(*carry);
+    }
     StepArgs a{};
     a.old[0] = keys_fwd_in; a.old[1] = keys_bwd_in; a.add[0] = add_fwd; a.add[1] = add_bwd; a.del[0] = del_fwd; a.del[1] = del_bwd;
     a.out[0] = keys_fwd_out; a.out[1] = keys_bwd_out; a.ro[0] = fwd_row_offset; a.ro[1] = bwd_row_offset;
@@ -623,16 +682,62 @@ extern "C" int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64
                                bwd_row_offset_in != bwd_row_offset;
     a.nb_rows = rows_in_merge ? (int)(((int64_t)N + 1 + kBlock - 2) / (kBlock - 1)) : 0;
     if (a.nb_old + a.nb_add > 0)
-        hipLaunchKernelGGL(step_merge_kernel, dim3(2u * (unsigned)(a.nb_old + a.nb_add + a.nb_rows)), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL(step_merge_kernel, dim3(2u * (unsigned)(a.nb_old + a.nb_add + a.nb_rows) + (unsigned)prev.nb), dim3(kBlock), 0,
+                           stream, a, prev);
+    else
+        launch_emission(prev, stream);
     if (!rows_in_merge)
         hipLaunchKernelGGL(step_rows_kernel, dim3((unsigned)((2 * ((int64_t)N + 1) + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, a);
-    if (E_out > 0) {
-        if (flags & STG_EMIT_KEY_ORDER)
-            hipLaunchKernelGGL((step_emit_kernel<true>), dim3(grid_for(2 * E_out)), dim3(kBlock), 0, stream, a);
-        else
-            hipLaunchKernelGGL((step_emit_kernel<false>), dim3(grid_for(2 * E_out)), dim3(kBlock), 0, stream, a);
-    }
-    return check_launch("stg_edgeset_step_device");
+    stg_store_emission mine{};
+    mine.keys_fwd = keys_fwd_out; mine.keys_bwd = keys_bwd_out; mine.E = E_out; mine.fwd_row_offset = fwd_row_offset;
+    mine.bwd_row_offset = bwd_row_offset; mine.fwd_column_indices = fwd_column_indices; mine.bwd_column_indices = bwd_column_indices;
+    mine.norm = norm; mine.norm_col_fwd = norm_col_fwd; mine.norm_col_bwd = norm_col_bwd; mine.flags = flags;
+    if (pending_out) *pending_out = mine;
+    else launch_emission(emit_args(mine), stream);
+    return check_launch(who);
+}
+
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_edgeset_step_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E,
+                                       const uint64_t *add_fwd, const uint64_t *add_bwd, int64_t n_add,
+                                       const uint64_t *del_fwd, const uint64_t *del_bwd, int64_t n_del, int32_t N, int flags,
+                                       uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *fwd_row_offset,
+                                       int32_t *fwd_column_indices, int32_t *bwd_row_offset, int32_t *bwd_column_indices,
+                                       int32_t *in_degrees, float *norm, float *norm_col_fwd, float *norm_col_bwd,
+                                       const int32_t *fwd_row_offset_in, const int32_t *bwd_row_offset_in, int32_t *status,
+                                       void *stream_)
+{
+    return stg::edgeset_step_run("stg_edgeset_step_device", keys_fwd_in, keys_bwd_in, E, add_fwd, add_bwd, n_add, del_fwd, del_bwd, n_del,
+                                 N, flags, keys_fwd_out, keys_bwd_out, fwd_row_offset, fwd_column_indices, bwd_row_offset,
+                                 bwd_column_indices, in_degrees, norm, norm_col_fwd, norm_col_bwd, fwd_row_offset_in, bwd_row_offset_in,
+                                 nullptr, nullptr, status, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int stg_edgeset_step_deferred_device(const uint64_t *keys_fwd_in, const uint64_t *keys_bwd_in, int64_t E,
+                                                const uint64_t *add_fwd, const uint64_t *add_bwd, int64_t n_add,
+                                                const uint64_t *del_fwd, const uint64_t *del_bwd, int64_t n_del, int32_t N, int flags,
+                                                uint64_t *keys_fwd_out, uint64_t *keys_bwd_out, int32_t *fwd_row_offset,
+                                                int32_t *fwd_column_indices, int32_t *bwd_row_offset, int32_t *bwd_column_indices,
+                                                int32_t *in_degrees, float *norm, float *norm_col_fwd, float *norm_col_bwd,
+                                                const int32_t *fwd_row_offset_in, const int32_t *bwd_row_offset_in,
+                                                const stg_store_emission *carry, stg_store_emission *pending_out, int32_t *status,
+                                                void *stream_)
+{
+    if (!pending_out) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_step_deferred_device: NULL pending_out");
+    return stg::edgeset_step_run("stg_edgeset_step_deferred_device", keys_fwd_in, keys_bwd_in, E, add_fwd, add_bwd, n_add, del_fwd, del_bwd,
+                                 n_del, N, flags, keys_fwd_out, keys_bwd_out, fwd_row_offset, fwd_column_indices, bwd_row_offset,
+                                 bwd_column_indices, in_degrees, norm, norm_col_fwd, norm_col_bwd, fwd_row_offset_in, bwd_row_offset_in,
+                                 carry, pending_out, status, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int stg_edgeset_emit_pending_device(const stg_store_emission *pending, void *stream_)
+{
+    if (!pending) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_edgeset_emit_pending_device: NULL argument");
+    if (const int rc = stg::emission_ok(*pending, "stg_edgeset_emit_pending_device")) return rc;
+    stg::launch_emission(stg::emit_args(*pending), static_cast<hipStream_t>(stream_));
+    return stg::check_launch("stg_edgeset_emit_pending_device");
 }
 
 extern "C" size_t stg_edgeset_emit_csr_workspace_bytes(int32_t N)

@@ -50,6 +50,7 @@ class PCSR:
         self._set = kernels.edgeset_empty(self._n, self._device)
         self._pending = {"add": [], "delete": []}       # (store src, store dst) tensor pairs, not yet merged
         self._emitted = {}                              # reverse(bool) -> kernels.StoreCSR of self._set
+        self._emission = kernels.EmissionQueue()        # shared by the copies of this store (deferred_emission)
         self._published = None                          # the arrays the last build_* call handed out
         # sticky status word of the fused steps, shared by every copy of this store (made here, outside any HIP-graph capture)
         self._status = torch.zeros(1, dtype=torch.int32, device=self._device) if self._device.type == "cuda" else None
@@ -108,7 +109,7 @@ class PCSR:
             f0, b0 = self._emitted.get(False), self._emitted.get(True)
             hints = (f0.row_offset, b0.row_offset) if f0 is not None and b0 is not None else None
             self._set, fwd, bwd, self._norm_in = kernels.edgeset_step(self._set, add_keys, del_keys, self._key_order,
-                                                                      self._status, hints)
+                                                                      self._status, hints, self._emission)
             self._emitted = {False: fwd, True: bwd}
         else:
             self._set = kernels.edgeset_merge(self._set, add_keys, del_keys)

@@ -12,6 +12,7 @@ the direction of correctness (defects D13-D15):
 """
 from __future__ import annotations
 
+import contextlib
 import copy
 import time
 
@@ -178,6 +179,21 @@ class PCSRGraph(DynamicGraph):
 
     def check(self) -> None:
         self._forward_graph.check()
+
+    @contextlib.contextmanager
+    def deferred_emission(self):
+        """For a caller that moves the graph through several timestamps BEFORE anything reads the CSRs' columns (a captured
+        BPTT window collects all its snapshots' CSR handles first): inside the block a step's emission -- columns + per-edge
+        norm of both CSRs -- is not launched on its own but rides in the NEXT step's merge launch
+        (stg_edgeset_step_deferred_device: one launch per timestamp instead of two); the last one is issued on leaving the
+        block.  Row offsets, degrees and norm are complete after every step; column arrays only after the block."""
+        q = self._forward_graph._emission
+        q.defer = True
+        try:
+            yield self
+        finally:
+            q.defer = False
+            q.flush()
 
 
 def _ptr_property(side: str, index: int):

@@ -537,7 +537,24 @@ def edgeset_merge(es: EdgeSet, add_keys, del_keys) -> EdgeSet:
     return EdgeSet(N, kf, kb, status)
 
 
-def edgeset_step(es: EdgeSet, add_keys, del_keys, key_order: bool, status: torch.Tensor | None = None, old_row_offsets=None):
+class EmissionQueue:
+    """At most one store-step emission left pending (stg_store_emission + the tensors it points into), shared by the copies of
+    a store.  While ``defer`` is set :func:`edgeset_step` leaves its emission here and carries the one it finds in its merge
+    launch -- one launch per step; whoever set ``defer`` calls :meth:`flush` before anything reads the emitted columns."""
+
+    def __init__(self):
+        self.defer = False
+        self.pending = None             # (StoreEmission, device, tensors kept alive)
+
+    def flush(self) -> None:
+        p, self.pending = self.pending, None
+        if p is not None:
+            with torch.cuda.device(p[1]):
+                _C.check(_C.lib.stg_edgeset_emit_pending_device(ctypes.byref(p[0]), _stream_ptr(p[1])))
+
+
+def edgeset_step(es: EdgeSet, add_keys, del_keys, key_order: bool, status: torch.Tensor | None = None, old_row_offsets=None,
+                 queue: "EmissionQueue | None" = None):
     """One timestamp of a delta store in two launches (three without ``old_row_offsets``; stg_edgeset_step_device): returns ``(new set, forward StoreCSR,
     backward StoreCSR, norm [N, 1])`` -- the merge of :func:`edgeset_merge`, both emissions of :func:`edgeset_emit_csr`, the
     in-degrees, ``norm = in_deg ** -0.5`` (:func:`degree_norm`'s values) and ``norm`` gathered per edge of either CSR,
@@ -562,13 +579,24 @@ def edgeset_step(es: EdgeSet, add_keys, del_keys, key_order: bool, status: torch
     norm = torch.empty(N, 1, dtype=torch.float32, device=device)
     nc_f = torch.empty(E_out, dtype=torch.float32, device=device)
     nc_b = torch.empty(E_out, dtype=torch.float32, device=device)
-    with torch.cuda.device(device):
-        _C.check(_C.lib.stg_edgeset_step_device(
-            _ptr(es.keys_fwd), _ptr(es.keys_bwd), E, _ptr(add_keys[0]), _ptr(add_keys[1]), na, _ptr(del_keys[0]),
+    args = (_ptr(es.keys_fwd), _ptr(es.keys_bwd), E, _ptr(add_keys[0]), _ptr(add_keys[1]), na, _ptr(del_keys[0]),
             _ptr(del_keys[1]), nd, N, EMIT_KEY_ORDER if key_order else 0, _ptr(kf), _ptr(kb), _ptr(ro_f), _ptr(col_f),
             _ptr(ro_b), _ptr(col_b), _ptr(deg), _ptr(norm), _ptr(nc_f), _ptr(nc_b),
-            _ptr(old_row_offsets[0]) if old_row_offsets else None, _ptr(old_row_offsets[1]) if old_row_offsets else None,
-            _ptr(status), _stream_ptr(device)))
+            _ptr(old_row_offsets[0]) if old_row_offsets else None, _ptr(old_row_offsets[1]) if old_row_offsets else None)
+    with torch.cuda.device(device):
+        if queue is not None and queue.defer:
+            # this step's emission stays pending (queue); the one found there rides in this step's merge launch
+            carry, mine = queue.pending, _C.StoreEmission()
+            if carry is not None and carry[1] != device:
+                queue.flush()
+                carry = None
+            _C.check(_C.lib.stg_edgeset_step_deferred_device(*args, ctypes.byref(carry[0]) if carry is not None else None,
+                                                             ctypes.byref(mine), _ptr(status), _stream_ptr(device)))
+            queue.pending = (mine, device, (kf, kb, ro_f, ro_b, col_f, col_b, norm, nc_f, nc_b))
+        else:
+            if queue is not None:
+                queue.flush()
+            _C.check(_C.lib.stg_edgeset_step_device(*args, _ptr(status), _stream_ptr(device)))
     new = EdgeSet(N, kf, kb, status)
     fwd = StoreCSR(new, False, ro_f, col_f, None, deg, key_order)
     bwd = StoreCSR(new, True, ro_b, col_b, None, None, key_order)

@@ -846,6 +846,7 @@ class CapturedDynamicWindows:
         self.parallel_builds = False
         # rebuild mode: the window's snapshots as ONE batched build (stg_graph_build_direct2_batch_device)
         self.batched_builds = True
+        self.deferred_emission = True
         self.model, self.graph, self.edges, self.targets = model, graph, pos_neg_edges, pos_neg_targets
         self.total = len(pos_neg_edges)
         self.B = backprop_every or self.total
@@ -909,10 +910,15 @@ class CapturedDynamicWindows:
                 while g.prebuild(self.timestamps(w)):        # the window's snapshots in the launches of one build
                     pass                                     # (a window longer than STG_BUILD_BATCH_MAX: of two, ...)
         steps = []
-        for t in self.timestamps(w):
-            g.get_graph(t)
-            steps.append(dict(fwd=g.csr("fwd"), bwd=g.csr("bwd"), norm=self.norm_fn(g), edges=self.edges[t],
-                              targets=self.targets[t], incidence=SF._incidence_of(self.edges[t], self.n)))
+        import contextlib
+        # delta stores: nothing reads a snapshot's columns before the window's first model step, so the emissions ride in the
+        # next timestamp's merge launch (one launch per timestamp)
+        defer = g.deferred_emission() if self._store and self.deferred_emission and hasattr(g, "deferred_emission") else contextlib.nullcontext()
+        with defer:
+            for t in self.timestamps(w):
+                g.get_graph(t)
+                steps.append(dict(fwd=g.csr("fwd"), bwd=g.csr("bwd"), norm=self.norm_fn(g), edges=self.edges[t],
+                                  targets=self.targets[t], incidence=SF._incidence_of(self.edges[t], self.n)))
         cost = dyn_window_cost(self.model, g, self.inputs[w], steps) / (self.B + 1)
         with direct_param_grads():                           # the bucket was zeroed above: written, not accumulated
             cost.backward()

@@ -197,3 +197,81 @@ def test_step_with_row_offsets_of_the_old_set_is_two_launches_and_the_same_bits(
     last = ref[-1]
     rows = (last[0] >> 32).to(torch.int64)
     assert torch.equal(last[2].long(), torch.searchsorted(rows, torch.arange(n + 1, device=cuda)))
+
+
+@pytest.mark.parametrize("key_order", [False, True])
+def test_deferred_emissions_ride_in_the_next_merge_launch(cuda, key_order):
+    """stg_edgeset_step_deferred_device / stg_edgeset_emit_pending_device: a chain of steps whose emissions are carried by the
+    following step's merge launch (kernels.EmissionQueue) writes the same bits as the undeferred chain -- with and without
+    the old set's row offsets; nothing is pending after the flush; a step with empty batches carries too."""
+    from stgraph_amd import kernels
+    n, e, k = 3000, 40_000, 1500
+    src, dst = random_graph(9, n, e, hub=False)
+    keys = np.unique(src.astype(np.int64) * n + dst)
+    np.random.default_rng(4).shuffle(keys)
+    src, dst = torch.from_numpy((keys // n).astype(np.int32)).to(cuda), torch.from_numpy((keys % n).astype(np.int32)).to(cuda)
+    e = len(keys)
+    base = kernels.edgeset_update(kernels.edgeset_empty(n, cuda), src[2 * k:], dst[2 * k:])
+    pack = lambda lo, hi: kernels.edgeset_pack_sorted(src[lo:hi], dst[lo:hi], cuda)      # noqa: E731
+    none = pack(0, 0)
+    batches = [(none, none), (pack(0, k), pack(e - k, e)), (pack(k, 2 * k), none), (none, none), (none, pack(0, k)),
+               (pack(e - k, e), pack(k, 2 * k))]
+
+    def chain(queue, hints_on):
+        es, hints, outs = base, None, []
+        for add, dele in batches:
+            es, fwd, bwd, norm = kernels.edgeset_step(es, add, dele, key_order, None, hints if hints_on else None, queue)
+            hints = (fwd.row_offset, bwd.row_offset)
+            outs.append((es.keys_fwd, fwd.row_offset, bwd.row_offset, fwd.column_indices, bwd.column_indices, fwd.degrees, norm,
+                         fwd._edge_cache["norm"][2], bwd._edge_cache["norm"][2]))
+            kernels.edgeset_check(es)
+        return outs
+
+    for hints_on in (False, True):
+        ref = chain(None, hints_on)
+        q = kernels.EmissionQueue()
+        q.defer = True
+        got = chain(q, hints_on)
+        assert q.pending is not None
+        q.defer = False
+        q.flush()
+        assert q.pending is None
+        for step, (a, b) in enumerate(zip(ref, got)):
+            for i, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x, y), (hints_on, step, i)
+        # an undeferred step issues what it finds pending before its own
+        q.defer = True
+        first = kernels.edgeset_step(base, *batches[1], key_order, None, None, q)
+        q.defer = False
+        second = kernels.edgeset_step(first[0], *batches[2], key_order, None, (first[1].row_offset, first[2].row_offset), q)
+        assert q.pending is None
+        assert torch.equal(first[1].column_indices, ref[1][3]) and torch.equal(second[2].column_indices, ref[2][4])
+
+
+@pytest.mark.parametrize("cls_name", ["PCSRGraph", "GPMAGraph"])
+def test_graph_walk_with_deferred_emission(cuda, cls_name):
+    import stgraph_amd.graph as SG
+    n, T = 800, 6
+    rng = np.random.default_rng(7)
+    snaps = []
+    for t in range(T):
+        keys = rng.choice(n * n, size=6000 + 50 * t, replace=False)
+        snaps.append((torch.from_numpy((keys // n).astype(np.int32)), torch.from_numpy((keys % n).astype(np.int32))))
+
+    def walk(deferred):
+        import contextlib
+        G = getattr(SG, cls_name)([(s.numpy(), d.numpy()) for s, d in snaps], n, device=cuda)
+        got = []
+        with (G.deferred_emission() if deferred else contextlib.nullcontext()):
+            for t in range(T):
+                G.get_graph(t)
+                f, b = G.csr("fwd"), G.csr("bwd")
+                got.append((f, b, G.in_degree_norm_tensor()))
+        G.check()
+        return [(f.row_offset, f.column_indices, b.row_offset, b.column_indices) + ((nrm, f._edge_cache["norm"][2]) if nrm is not None else ())
+                for f, b, nrm in got]
+
+    for a, b in zip(walk(False), walk(True)):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
