@@ -102,7 +102,7 @@ class NaiveGraph(DynamicGraph):
         batches = -(-len(ts) // kernels._C.BUILD_BATCH_MAX)              # a window of 20: two batches of 10, not 16 + 4
         ts = ts[:max(min(cap, -(-len(ts) // max(batches, 1))), 0)]
         if (len(ts) < 2 or self._device.type != "cuda" or not kernels.FUSED_REBUILD or not kernels._DIRECT_BUILD
-                or self.max_num_nodes <= 0 or any(self._edges[t][0].numel() > kernels.DIRECT_BUILD_MAX_EDGES for t in ts)):
+                or not 0 < self.max_num_nodes <= kernels.BUILD_BATCH_MAX_NODES or any(self._edges[t][0].numel() > kernels.DIRECT_BUILD_MAX_EDGES for t in ts)):
             return 0
         t0 = time.time()
         built = kernels.build_graph_csr_batch([self._edges[t] for t in ts], self.max_num_nodes, self._device)

@@ -256,7 +256,8 @@ def set_direct_build(enabled: bool) -> None:
 
 
 FUSED_REBUILD = True     # re-builds of a validated edge list go through stg_graph_build_direct2_device
-BUILD_SLOTS = 16         # counter buffers per (device, |V|): that many rebuilds may be in flight on different streams
+BUILD_SLOTS = 16         # counter buffers per (device, |V|): that many rebuilds may be in flight (side streams, or the jobs of a batch)
+BUILD_BATCH_MAX_NODES = 1 << 18     # batched rebuilds (and their 16 counter buffers of 8 |V| bytes) are for small snapshots; above: 4 slots
 _BUILD_COUNTERS = {}
 
 
@@ -267,7 +268,7 @@ def _build_counters(device, N: int, slot: int = 0):
     key = (str(device), int(N), int(slot))
     hit = _BUILD_COUNTERS.get(key)
     if hit is None:
-        if len(_BUILD_COUNTERS) > 64:
+        if len(_BUILD_COUNTERS) > 512:              # (captured graphs hold raw pointers into these: evict rarely)
             _BUILD_COUNTERS.clear()
         hit = _BUILD_COUNTERS[key] = (torch.zeros(2 * ((max(N, 1) + 3) & ~3), dtype=torch.int32, device=device),
                                       torch.zeros(1, dtype=torch.int32, device=device))
@@ -281,8 +282,8 @@ def build_graph_csr_batch(edge_lists, num_nodes: int, device: torch.device | str
     device = torch.device(device)
     N = int(num_nodes)
     n = len(edge_lists)
-    if not 0 < n <= _C.BUILD_BATCH_MAX or N <= 0 or device.type != "cuda":
-        raise ValueError("build_graph_csr_batch: 1 .. %d edge lists over N > 0 vertices on a GPU" % _C.BUILD_BATCH_MAX)
+    if not 0 < n <= _C.BUILD_BATCH_MAX or not 0 < N <= BUILD_BATCH_MAX_NODES or device.type != "cuda":
+        raise ValueError("build_graph_csr_batch: 1 .. %d edge lists over 1 .. %d vertices on a GPU" % (_C.BUILD_BATCH_MAX, BUILD_BATCH_MAX_NODES))
     i32 = dict(dtype=torch.int32, device=device)
     jobs = (_C.BuildJob * n)()
     out, keep = [], []
@@ -362,7 +363,7 @@ def build_graph_csr(src, dst, num_nodes: int, device: torch.device | str, lazy_n
         built_by = "sort"
         direct_ok = _DIRECT_BUILD and E <= DIRECT_BUILD_MAX_EDGES
         if direct_ok and not torch.cuda.is_current_stream_capturing():
-            for slot in range(BUILD_SLOTS):        # made outside any capture: a later captured rebuild finds them
+            for slot in range(BUILD_SLOTS if N <= BUILD_BATCH_MAX_NODES else 4):     # made outside any capture: a later captured rebuild finds them
                 _build_counters(device, N, slot)
         if known_path == "direct" and lazy == bool(lazy_node_ids) and direct_ok:
             ws_bytes = int(_C.lib.stg_graph_build_direct_workspace_bytes(E, N))
