@@ -24,7 +24,8 @@ the epoch is fixed, ranks split its windows).
 
 A "dynamic" object carries BASELINE configs[4] (dynamic-temporal TGCN): epochs/s with the per-snapshot device
 CSR rebuild (its `value`), with every snapshot's CSR resident as the reference's NaiveGraph keeps them (both replayed
-from one HIP graph per BPTT window after an eager epoch) and on the dynamic edge store (PCSRGraph, GPMAGraph; eager),
+from one HIP graph per BPTT window after an eager epoch; the rebuilds of a window's snapshots share the launches of one build)
+and on the dynamic edge stores (PCSRGraph, GPMAGraph: one merge launch per timestamp inside the same per-window HIP graphs),
 windows sharded over the ranks; `csr_build_share` = 1 - resident / rebuild.
 
 A "gat" object carries BASELINE configs[2] (GAT, 8 heads, |V| = 256K, |E| = 8M): one GATConv layer forward +
