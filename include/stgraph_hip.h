@@ -28,7 +28,7 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 20
+#define STG_ABI_VERSION 21
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -562,6 +562,15 @@ int stg_gemm_tn_form_partial_f32(const float *const *A, int32_t lda, const float
                                  int32_t *slabs, void *stream);
 int stg_gemm_tn_reduce_multi_f32(int32_t count, const float *const *slabs, float *const *C, float *const *colsum,
                                  const int32_t *M, const int32_t *N, const int32_t *S, void *stream);
+/* The same reduction with a product's C [M, N] leaving as M / block_rows[i] row blocks, each TRANSPOSED into its own contiguous
+ * [N, block_rows[i]] array C_blocks[i * STG_GEMM_REDUCE_BLOCKS + b] (and its slice of the column sums into colsum_blocks[...]; all NULL
+ * = no column sums; the product must then have been formed without them): three GCNConv layers' weight gradients computed as ONE
+ * stacked product (dynamic-temporal TGCN: conv_z / conv_r / conv_h share their input) land in the layout of their parameters'
+ * .grad without a transposing copy each.  block_rows[i] = 0 (or block_rows NULL): C[i] / colsum[i] as above.  Same sums, bit for bit. */
+#define STG_GEMM_REDUCE_BLOCKS 4
+int stg_gemm_tn_reduce_multi_blocks_f32(int32_t count, const float *const *slabs, float *const *C, float *const *colsum,
+                                        const int32_t *M, const int32_t *N, const int32_t *S, const int32_t *block_rows,
+                                        float *const *C_blocks, float *const *colsum_blocks, void *stream);
 
 /* The whole forward chain of the six stages below in ONE launch for C = 32 or 64 (hidden width): bias + clamp,
  * the three gate GEMMs on the fp32 matrix cores with the gate weights (torch Linear layout [C][2C]) resident in

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = (
     "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_score_flag", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gat_fc_supported", "stg_gat_fc_fwd", "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32", "stg_gemm_tn_relu_mask_f32",
-    "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_tgcn_pack_weights", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
+    "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
@@ -55,6 +55,7 @@ def _ptr_fields(names):
 
 
 BUILD_BATCH_MAX = 16
+GEMM_REDUCE_BLOCKS = 4
 
 
 class StoreEmission(ctypes.Structure):
@@ -287,6 +288,8 @@ def _load() -> ctypes.CDLL:
                                                  ctypes.c_size_t, vp, vp]
     lib.stg_gemm_tn_reduce_multi_f32.restype = ctypes.c_int
     lib.stg_gemm_tn_reduce_multi_f32.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.stg_gemm_tn_reduce_multi_blocks_f32.restype = ctypes.c_int
+    lib.stg_gemm_tn_reduce_multi_blocks_f32.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.stg_link_decode_fwd_multi.restype = ctypes.c_int
     lib.stg_link_decode_fwd_multi.argtypes = [i32, vp, vp, vp, vp, vp, i64, i32, vp]
     lib.stg_tgcn_pack_weights.restype = ctypes.c_int

@@ -534,11 +534,16 @@ __global__ __launch_bounds__(kBlock) void gemm_tn_reduce_kernel(const float *__r
 // The same reduction for up to kReduceJobs products in ONE launch (blockIdx.y = job): a BPTT window's six weight-gradient
 // contractions leave their slabs and are summed together (six 9 us launches otherwise, at the launch floor).
 constexpr int kReduceJobs = 8;
+constexpr int kReduceBlocks = STG_GEMM_REDUCE_BLOCKS;
 struct ReduceJobs {
     const float *slab[kReduceJobs];
     float *C[kReduceJobs], *CS[kReduceJobs];
     int64_t MNc[kReduceJobs], MN[kReduceJobs];
     int S[kReduceJobs];
+    // rows > 0: C [M, N] leaves as M / rows blocks, each TRANSPOSED into its own [N, rows] array Cb[.][b] (and its colsum slice
+    // into CSb[.][b]) -- three layers' weight gradients computed as one stacked product land in their parameters' layout
+    int rows[kReduceJobs], N[kReduceJobs];
+    float *Cb[kReduceJobs][kReduceBlocks], *CSb[kReduceJobs][kReduceBlocks];
 };
 __global__ __launch_bounds__(kBlock) void gemm_tn_reduce_multi_kernel(const ReduceJobs jobs)
 {
@@ -567,8 +572,18 @@ __global__ __launch_bounds__(kBlock) void gemm_tn_reduce_multi_kernel(const Redu
     __syncthreads();
     if (w == 0 && o < MNc) {
         const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-        if (o < MN) jobs.C[job][o] = tot;
-        else jobs.CS[job][o - MN] = tot;
+        const int rows = jobs.rows[job];
+        if (rows == 0) {
+            if (o < MN) jobs.C[job][o] = tot;
+            else jobs.CS[job][o - MN] = tot;
+        } else if (o < MN) {
+            const int N = jobs.N[job];
+            const int m = (int)(o / N), n = (int)(o - (int64_t)m * N), b = m / rows;
+            jobs.Cb[job][b][(int64_t)n * rows + (m - b * rows)] = tot;
+        } else {
+            const int m = (int)(o - MN), b = m / rows;
+            jobs.CSb[job][b][m - b * rows] = tot;
+        }
     }
 }
 
@@ -845,25 +860,49 @@ extern "C" int stg_gemm_tn_form_partial_f32(const float *const *A, int32_t lda, 
 extern "C" int stg_gemm_tn_reduce_multi_f32(int32_t count, const float *const *slabs, float *const *C, float *const *colsum,
                                             const int32_t *M, const int32_t *N, const int32_t *S, void *stream)
 {
+    return stg_gemm_tn_reduce_multi_blocks_f32(count, slabs, C, colsum, M, N, S, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int stg_gemm_tn_reduce_multi_blocks_f32(int32_t count, const float *const *slabs, float *const *C, float *const *colsum,
+                                                   const int32_t *M, const int32_t *N, const int32_t *S, const int32_t *block_rows,
+                                                   float *const *C_blocks, float *const *colsum_blocks, void *stream)
+{
     using namespace stg;
-    if (count <= 0 || count > kReduceJobs) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_reduce_multi_f32: 1 .. %d products per call", kReduceJobs);
-    if (!slabs || !C || !colsum || !M || !N || !S) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_reduce_multi_f32: NULL pointer argument");
+    const char *who = "stg_gemm_tn_reduce_multi_blocks_f32";
+    if (count <= 0 || count > kReduceJobs) return fail(STG_ERR_INVALID_ARGUMENT, "%s: 1 .. %d products per call", who, kReduceJobs);
+    if (!slabs || !C || !colsum || !M || !N || !S) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", who);
     ReduceJobs jobs{};
     int64_t widest = 0;
     for (int i = 0; i < count; ++i) {
-        if (!slabs[i] || !C[i] || M[i] <= 0 || N[i] <= 0 || S[i] <= 0)
-            return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_reduce_multi_f32: bad product %d", i);
+        const int rows = block_rows ? block_rows[i] : 0;
+        if (!slabs[i] || M[i] <= 0 || N[i] <= 0 || S[i] <= 0 || rows < 0 || (rows == 0 && !C[i]))
+            return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad product %d", who, i);
+        bool want_cs = colsum[i] != nullptr;
+        if (rows > 0) {
+            const int nb = M[i] / rows;
+            if (M[i] % rows || nb > kReduceBlocks || !C_blocks || !colsum_blocks)
+                return fail(STG_ERR_INVALID_ARGUMENT, "%s: product %d: M = %d is not 1 .. %d blocks of %d rows", who, i, M[i], kReduceBlocks, rows);
+            want_cs = colsum_blocks[i * STG_GEMM_REDUCE_BLOCKS] != nullptr;
+            for (int b = 0; b < nb; ++b) {
+                jobs.Cb[i][b] = C_blocks[i * STG_GEMM_REDUCE_BLOCKS + b];
+                jobs.CSb[i][b] = colsum_blocks[i * STG_GEMM_REDUCE_BLOCKS + b];
+                if (!jobs.Cb[i][b] || (want_cs && !jobs.CSb[i][b]))
+                    return fail(STG_ERR_INVALID_ARGUMENT, "%s: product %d: NULL block %d", who, i, b);
+            }
+        }
+        jobs.rows[i] = rows;
+        jobs.N[i] = N[i];
         jobs.slab[i] = slabs[i];
         jobs.C[i] = C[i];
         jobs.CS[i] = colsum[i];
         jobs.MN[i] = (int64_t)M[i] * N[i];
-        jobs.MNc[i] = jobs.MN[i] + (colsum[i] ? M[i] : 0);
+        jobs.MNc[i] = jobs.MN[i] + (want_cs ? M[i] : 0);
         jobs.S[i] = S[i];
         widest = std::max(widest, jobs.MNc[i]);
     }
     hipLaunchKernelGGL(gemm_tn_reduce_multi_kernel, dim3((unsigned)((widest + kWave - 1) / kWave), (unsigned)count), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), jobs);
-    return check_launch("stg_gemm_tn_reduce_multi_f32");
+    return check_launch(who);
 }
 
 extern "C" int stg_gemm_tn_relu_mask_f32(const float *A, const float *mask, const float *B, float *C, float *colsum_A,

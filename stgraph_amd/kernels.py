@@ -1342,13 +1342,26 @@ def gemm_tn_form_batch(calls):
     """Several :func:`gemm_tn_form` contractions whose final reductions run as ONE launch (stg_gemm_tn_form_partial_f32 per
     product, then stg_gemm_tn_reduce_multi_f32): ``calls`` is a list of keyword dicts for ``gemm_tn_form``; returns the list of
     its results, same values bit for bit.  Optional keys ``out`` [M, N] / ``colsum_out`` [M]: contiguous fp32 tensors the results
-    are written to (a parameter's ``.grad`` view, say).  Products with more than 32 segments, or more than 8 of them, go one by one."""
+    are written to (a parameter's ``.grad`` view, say).  Or ``out_blocks_t``: a list of M / rows contiguous [N, rows] tensors -- the
+    result's row blocks, each transposed (stacked layers' weight gradients in their parameters' layout) -- with ``colsum_blocks``:
+    as many [rows] tensors (iff ``colsum``); the product's entry in the returned list is then None.
+    Products with more than 32 segments, or more than 8 of them, go one by one."""
     if len(calls) > GEMM_REDUCE_JOBS or any(len(c["As"]) > MAX_GEMM_SEGMENTS for c in calls) or len(calls) < 2:
         res = []
         for c in calls:
             c = dict(c)
             out, cs_out = c.pop("out", None), c.pop("colsum_out", None)
+            blocks, cs_blocks = c.pop("out_blocks_t", None), c.pop("colsum_blocks", None)
             r = gemm_tn_form(**c)
+            if blocks is not None:
+                rows = int(c["M"]) // len(blocks)
+                full, cs = (r if c.get("colsum") else (r, None))
+                for b, t in enumerate(blocks):
+                    t.copy_(full[b * rows:(b + 1) * rows].t())
+                    if cs is not None:
+                        cs_blocks[b].copy_(cs[b * rows:(b + 1) * rows])
+                res.append(None)
+                continue
             if out is not None:                              # (``out`` / ``colsum_out``: results written where the caller wants them)
                 out.copy_(r[0] if c.get("colsum") else r)
                 r = (out, r[1]) if c.get("colsum") else out
@@ -1360,7 +1373,9 @@ def gemm_tn_form_batch(calls):
     dev = calls[0]["As"][0].device
     outs, keep = [], []
     slabs_p, c_p, cs_p = [], [], []
-    Ms, Ns, Ss = [], [], []
+    Ms, Ns, Ss, rows_l = [], [], [], []
+    nb_max = _C.GEMM_REDUCE_BLOCKS
+    blk_p, csblk_p = [], []
     with torch.cuda.device(dev):
         for c in calls:
             As, Bs, M, N = c["As"], c["Bs"], int(c["M"]), int(c["N"])
@@ -1385,6 +1400,25 @@ def gemm_tn_form_batch(calls):
             _C.check(_C.lib.stg_gemm_tn_form_partial_f32(pa, lda, pb, ldb, nsplit, pb2, ldb2, int(c.get("b_op", GEMM_B_NONE)),
                                                          float(c.get("lo", 0.0)), float(c.get("hi", 0.0)), T, int(colsum), K, M, N,
                                                          _ptr(ws), ws_bytes, ctypes.byref(S), _stream_ptr(dev)))
+            blocks, cs_blocks = c.get("out_blocks_t"), c.get("colsum_blocks")
+            if blocks is not None:
+                nb = len(blocks)
+                rows = M // max(nb, 1)
+                if (not 0 < nb <= nb_max or rows * nb != M or (colsum and (cs_blocks is None or len(cs_blocks) != nb)) or
+                        any(t.dtype != torch.float32 or t.device != dev or tuple(t.shape) != (N, rows) or not t.is_contiguous() for t in blocks) or
+                        (colsum and any(t.dtype != torch.float32 or t.device != dev or tuple(t.shape) != (rows,) or not t.is_contiguous()
+                                        for t in cs_blocks))):
+                    raise ValueError(f"gemm_tn_form_batch: out_blocks_t must be 1 .. {nb_max} contiguous fp32 [N, M / blocks] tensors (+ colsum_blocks)")
+                keep.append(ws)
+                outs.append(None)
+                slabs_p.append(ws.data_ptr()); c_p.append(None); cs_p.append(None)
+                Ms.append(M); Ns.append(N); Ss.append(int(S.value)); rows_l.append(rows)
+                blk_p += [t.data_ptr() for t in blocks] + [None] * (nb_max - nb)
+                csblk_p += ([t.data_ptr() for t in cs_blocks] if colsum else [None] * nb) + [None] * (nb_max - nb)
+                continue
+            rows_l.append(0)
+            blk_p += [None] * nb_max
+            csblk_p += [None] * nb_max
             out, cs = c.get("out"), c.get("colsum_out") if colsum else None
             for t, shape, name in ((out, (M, N), "out"), (cs, (M,), "colsum_out")):
                 if t is not None and (t.dtype != torch.float32 or t.device != dev or tuple(t.shape) != shape or not t.is_contiguous()):
@@ -1400,8 +1434,13 @@ def gemm_tn_form_batch(calls):
         n = len(calls)
         arr = lambda vals: (ctypes.c_void_p * n)(*vals)  # noqa: E731
         i32s = lambda vals: (ctypes.c_int32 * n)(*vals)  # noqa: E731
-        _C.check(_C.lib.stg_gemm_tn_reduce_multi_f32(n, arr(slabs_p), arr(c_p), arr(cs_p), i32s(Ms), i32s(Ns), i32s(Ss),
-                                                     _stream_ptr(dev)))
+        if any(rows_l):
+            ptrs = lambda vals: (ctypes.c_void_p * len(vals))(*vals)  # noqa: E731
+            _C.check(_C.lib.stg_gemm_tn_reduce_multi_blocks_f32(n, arr(slabs_p), arr(c_p), arr(cs_p), i32s(Ms), i32s(Ns), i32s(Ss),
+                                                                i32s(rows_l), ptrs(blk_p), ptrs(csblk_p), _stream_ptr(dev)))
+        else:
+            _C.check(_C.lib.stg_gemm_tn_reduce_multi_f32(n, arr(slabs_p), arr(c_p), arr(cs_p), i32s(Ms), i32s(Ns), i32s(Ss),
+                                                         _stream_ptr(dev)))
     return outs
 
 

@@ -183,19 +183,20 @@ class _TGCNWindow(torch.autograd.Function):
         gate = lambda d, k, second, i: dict(  # noqa: E731
             As=[d[t] for t in steps], Bs=[X3[t][:, k * C:(k + 1) * C] for t in steps], M=C, N=2 * C, B2s=second, nsplit=C,
             b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True, **dst(i, i + 1))
-        # six split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch)
-        (dWz, dbz), (dWr, dbr), (dWh, dbh), (dWcT, db3), (dW1, db1), (dW2, db2) = kernels.gemm_tn_form_batch([
-            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in steps], 10),
-            dict(As=[da3[t] for t in steps], Bs=[P[t] for t in steps], M=3 * C, N=Fin, colsum=True),
+        # six split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch); the three conv layers' gradients are one
+        # stacked product whose row blocks the reduction transposes straight into the parameters' .grad (sinks 0-2, biases 3-5)
+        conv = dict(As=[da3[t] for t in steps], Bs=[P[t] for t in steps], M=3 * C, N=Fin, colsum=True)
+        if sinks:
+            conv.update(out_blocks_t=list(sinks[0:3]), colsum_blocks=list(sinks[3:6]))
+        res = kernels.gemm_tn_form_batch([
+            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in steps], 10), conv,
             dict(As=[dyt[t] for t in steps], Bs=[Hn[t] for t in steps], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13)),
             dict(As=[dyo[t].view(N, 1) for t in steps], Bs=[Y[t] for t in steps], M=1, N=Fh, colsum=True, **dst(14, 15))])
+        if sinks:
+            return (dx0,) + (None,) * 24
+        (dWz, dbz), (dWr, dbr), (dWh, dbh), (dWcT, db3), (dW1, db1), (dW2, db2) = res
         conv_w = [dWcT[k * C:(k + 1) * C].t() for k in range(3)]
         conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
-        if sinks:                                          # the conv weights arrive transposed / as slices: six small copies
-            for k in range(3):
-                sinks[k].copy_(conv_w[k])
-                sinks[3 + k].copy_(conv_b[k])
-            return (dx0,) + (None,) * 24
         return (dx0, None, None, None, None, None, None, None, None, *conv_w, *conv_b, dWz, dbz, dWr, dbr, dWh, dbh,
                 dW1, db1, dW2.view(1, Fh), db2)
 
@@ -532,19 +533,19 @@ class _TGCNDynWindow(torch.autograd.Function):
         gate = lambda d, k, second, i: dict(  # noqa: E731
             As=[d[t] for t in rng], Bs=[X3[t][:, k * C:(k + 1) * C] for t in rng], M=C, N=2 * C, B2s=second, nsplit=C,
             b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True, **dst(i, i + 1))
-        # five split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch)
-        (dWz, dbz), (dWr, dbr), (dWh, dbh), (dWcT, db3), (dW1, db1) = kernels.gemm_tn_form_batch([
-            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in rng], 10),
-            dict(As=[da3[t] for t in rng], Bs=[P[t] for t in rng], M=3 * C, N=Fin, colsum=True),
+        # five split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch); conv gradients as in _TGCNWindow.backward
+        conv = dict(As=[da3[t] for t in rng], Bs=[P[t] for t in rng], M=3 * C, N=Fin, colsum=True)
+        if sinks:
+            conv.update(out_blocks_t=list(sinks[0:3]), colsum_blocks=list(sinks[3:6]))
+        res = kernels.gemm_tn_form_batch([
+            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in rng], 10), conv,
             dict(As=[dyt[t] for t in rng], Bs=[Hn[t] for t in rng], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13))])
-        conv_w = [dWcT[k * C:(k + 1) * C].t() for k in range(3)]
-        conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
         ctx.steps = None
         if sinks:
-            for k in range(3):
-                sinks[k].copy_(conv_w[k])
-                sinks[3 + k].copy_(conv_b[k])
             return (dx0,) + (None,) * 18
+        (dWz, dbz), (dWr, dbr), (dWh, dbh), (dWcT, db3), (dW1, db1) = res
+        conv_w = [dWcT[k * C:(k + 1) * C].t() for k in range(3)]
+        conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
         return (dx0, None, None, None, None, *conv_w, *conv_b, dWz, dbz, dWr, dbr, dWh, dbh, dW1, db1)
 
 

@@ -164,3 +164,35 @@ def test_batched_reduction_equals_the_one_product_form(cuda):
             assert torch.equal(g[0], want[0]) and torch.equal(g[1], want[1])
         else:
             assert torch.equal(g, want)
+
+
+@pytest.mark.parametrize("colsum", [True, False])
+def test_batched_reduction_into_transposed_row_blocks(cuda, colsum):
+    """``out_blocks_t`` / ``colsum_blocks`` of kernels.gemm_tn_form_batch (stg_gemm_tn_reduce_multi_blocks_f32): the stacked product
+    of three layers' weight gradients leaves the reduction as three transposed [N, C] blocks and three bias slices -- the same
+    floats as slicing and transposing the plain result; also through the one-by-one path (a single product)."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(11)
+    K, C, T, Fin = 20_001, 64, 3, 32
+    r = lambda *s: torch.randn(*s, device=cuda, generator=gen)  # noqa: E731
+    da3, P, d = [r(K, 3 * C) for _ in range(T)], [r(K, Fin) for _ in range(T)], [r(K, C) for _ in range(T)]
+    want = kernels.gemm_tn_form(As=da3, Bs=P, M=3 * C, N=Fin, colsum=True)
+    other = dict(As=d, Bs=P, M=C, N=Fin, colsum=True)
+    for blocks_n in (3, 1, 4):
+        rows = 3 * C // blocks_n
+        for alone in (False, True):
+            blocks = [torch.full((Fin, rows), float("nan"), device=cuda) for _ in range(blocks_n)]
+            cs = [torch.full((rows,), float("nan"), device=cuda) for _ in range(blocks_n)] if colsum else None
+            call = dict(As=da3, Bs=P, M=3 * C, N=Fin, colsum=colsum, out_blocks_t=blocks, colsum_blocks=cs)
+            res = kernels.gemm_tn_form_batch([call] if alone else [other, call])
+            assert res[-1] is None
+            if not alone:
+                w2 = kernels.gemm_tn_form(**other)
+                assert torch.equal(res[0][0], w2[0]) and torch.equal(res[0][1], w2[1])
+            for b in range(blocks_n):
+                assert torch.equal(blocks[b], want[0][b * rows:(b + 1) * rows].t()), (blocks_n, alone, b)
+                if colsum:
+                    assert torch.equal(cs[b], want[1][b * rows:(b + 1) * rows]), (blocks_n, alone, b)
+    with pytest.raises(ValueError):
+        kernels.gemm_tn_form_batch([other, dict(As=da3, Bs=P, M=3 * C, N=Fin, colsum=False,
+                                                out_blocks_t=[torch.empty(Fin, 3 * C // 5, device=cuda)] * 5)])
