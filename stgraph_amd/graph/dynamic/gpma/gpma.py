@@ -53,9 +53,9 @@ class GPMA(PCSR):
 def init_gpma(gpma: GPMA, num_nodes: int) -> None:
     """gpma.cu:947-980: an empty graph with ``num_nodes`` rows."""
     gpma.row_num = gpma._n = int(num_nodes)
-    gpma._set = kernels.edgeset_empty(gpma._n, gpma._device)
     gpma._pending = {"add": [], "delete": []}
-    gpma._emitted, gpma._published, gpma._backward = {}, None, None
+    gpma._replace_set(kernels.edgeset_empty(gpma._n, gpma._device))      # drops the emitted CSRs, the cached norm, a pending emission
+    gpma._published, gpma._backward = None, None
 
 
 def init_graph_updates(gpma: GPMA, updates, reverse_edges: bool = False) -> None:

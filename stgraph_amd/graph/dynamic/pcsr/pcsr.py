@@ -57,6 +57,15 @@ class PCSR:
         self._norm_in = None                            # in_deg ** -0.5 [N, 1] of the current set, when a fused step made it
         self.update_count = 0                           # merge passes issued (two orientations each)
 
+    def _replace_set(self, new_set) -> None:
+        """Every replacement of the edge set goes through here: what was derived from the old set -- the emitted CSRs, the
+        cached ``norm``, an emission still pending in the queue (written now: someone may hold its arrays) -- goes with it."""
+        if self._emission.pending is not None:
+            self._emission.flush()
+        self._set = new_set
+        self._emitted = {}
+        self._norm_in = None
+
     # -- copies share everything immutable (the reference's copies share the device arrays too) --------
     def __copy__(self) -> "PCSR":
         self._flush()
@@ -90,10 +99,8 @@ class PCSR:
         a_src, a_dst = (cat(add, 0), cat(add, 1)) if add else (empty, empty)
         d_src, d_dst = (cat(dele, 0), cat(dele, 1)) if dele else (empty, empty)
         # EdgeSet speaks graph orientation (forward rows = graph dst = store src)
-        self._set = kernels.edgeset_update(self._set, a_dst, a_src, d_dst, d_src)
+        self._replace_set(kernels.edgeset_update(self._set, a_dst, a_src, d_dst, d_src))
         self._pending = {"add": [], "delete": []}
-        self._emitted = {}
-        self._norm_in = None
         self.update_count += 1
 
     def merge_sorted(self, add_keys, del_keys) -> None:
@@ -112,9 +119,7 @@ class PCSR:
                                                                       self._status, hints, self._emission)
             self._emitted = {False: fwd, True: bwd}
         else:
-            self._set = kernels.edgeset_merge(self._set, add_keys, del_keys)
-            self._emitted = {}
-            self._norm_in = None
+            self._replace_set(kernels.edgeset_merge(self._set, add_keys, del_keys))
         self.update_count += 1
 
     def label_edges(self) -> None:

@@ -235,7 +235,12 @@ def check_build_statuses(statuses) -> None:
     """Verify, with ONE host sync, the status words of builds whose read was skipped (``known_path``): a snapshot
     whose edge list changed since it was validated (an endpoint out of range, a row too long for the counting
     build) is reported here instead of never."""
-    statuses = [s for s in statuses if s is not None]
+    seen, uniq = set(), []
+    for s in statuses:                     # the fused rebuilds of a device share ONE sticky word: read and report it once
+        if s is not None and s.data_ptr() not in seen:
+            seen.add(s.data_ptr())
+            uniq.append(s)
+    statuses = uniq
     if not statuses:
         return
     codes = torch.stack([s.reshape(()) for s in statuses]).cpu().tolist()
@@ -268,11 +273,25 @@ def _build_counters(device, N: int, slot: int = 0):
     key = (str(device), int(N), int(slot))
     hit = _BUILD_COUNTERS.get(key)
     if hit is None:
-        if len(_BUILD_COUNTERS) > 512:              # (captured graphs hold raw pointers into these: evict rarely)
-            _BUILD_COUNTERS.clear()
+        # Kept for the life of the process, never evicted: captured HIP graphs (CapturedDynamicWindows in rebuild mode, the
+        # batched builds) hold raw pointers into these buffers and into the sticky status word, and a replay adds into them
+        # assuming they are zero -- memory handed back to the caching allocator could by then belong to a live tensor.  The
+        # slots of a (device, N) are made one at a time, on first use (8 N bytes each).
         hit = _BUILD_COUNTERS[key] = (torch.zeros(2 * ((max(N, 1) + 3) & ~3), dtype=torch.int32, device=device),
-                                      torch.zeros(1, dtype=torch.int32, device=device))
+                                      _build_status_word(device))
     return hit
+
+
+_BUILD_STATUS = {}
+
+
+def _build_status_word(device) -> torch.Tensor:
+    """ONE sticky status word per device for every direct build (whatever |V| or slot): `check_build_status` reads it."""
+    key = str(device)
+    w = _BUILD_STATUS.get(key)
+    if w is None:
+        w = _BUILD_STATUS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
 
 
 def build_graph_csr_batch(edge_lists, num_nodes: int, device: torch.device | str) -> list:

@@ -188,6 +188,19 @@ def tgcn_head(h, W1, b1, W2, b2, target, cost=None):
     return y, y_out, loss if cost is None else cost + loss
 
 
+def _known_colsum(g: torch.Tensor):
+    """The column sums `_CrossEntropy.backward` left on the gradient tensor ``g``, or None when ``g`` is not that tensor any
+    more: another tensor object (autograd summed two gradients out of place), or the same object modified since (summed in
+    place: the version counter moved)."""
+    tag = getattr(g, "_stg_colsum", None)
+    if tag is None:
+        return None
+    colsum, version, ptr = tag
+    if g._version != version or g.data_ptr() != ptr:
+        return None
+    return colsum
+
+
 class _CrossEntropy(torch.autograd.Function):
     """``F.cross_entropy(logits, labels)`` (mean) as one launch each way (csrc/xent.hip)."""
 
@@ -205,8 +218,11 @@ class _CrossEntropy(torch.autograd.Function):
         d, colsum = kernels.xent_bwd(g.contiguous(), logits, labels, lse, n_counted, want_colsum=True)
         if colsum is not None:
             # the gradient's column sums ride along on the tensor object: a bias layer right below the loss (GCNConv's
-            # `h + self.bias`) takes them as its bias gradient instead of re-reading the matrix (_GcnLayerTail.backward)
-            d._stg_colsum = colsum
+            # `h + self.bias`) takes them as its bias gradient instead of re-reading the matrix (_GcnLayerTail.backward).
+            # They describe the tensor AS WRITTEN HERE: the version counter and the storage address go with them, so a consumer
+            # can tell when autograd has since accumulated another consumer's gradient into the same tensor in place (logits
+            # with a second loss term) and must re-read the matrix.
+            d._stg_colsum = (colsum, d._version, d.data_ptr())
         return d, None, None
 
 
@@ -360,7 +376,7 @@ class _GcnLayerTail(torch.autograd.Function):
     def backward(ctx, g):
         out, norm, ew = ctx.saved_tensors
         ew = ew if ctx.has_ew else None
-        known = getattr(g, "_stg_colsum", None)          # column sums of THIS tensor object, left by the loss's backward
+        known = _known_colsum(g)                         # column sums of THIS tensor object, left by the loss's backward
         g = g.contiguous()
         want_b = ctx.has_bias and ctx.needs_input_grad[1]
         gb = None

@@ -75,15 +75,23 @@ class direct_param_grads:
         _DIRECT_GRADS[0] = self.prev
 
 
-def _grad_sinks(params):
-    """The ``.grad`` tensors of ``params`` if the window node may write them directly (opted in, every one a contiguous fp32
-    tensor of the parameter's shape on its device), else None."""
+def _grad_sinks(params, needs):
+    """The ``.grad`` tensors of ``params`` if the window node may write them directly, else None (the gradients are then
+    returned to autograd).  Direct writes OVERWRITE ``.grad`` and bypass AccumulateGrad (no accumulation with another node's
+    contribution, no post-accumulate hooks), so they are taken only when: the caller opted in (``direct_param_grads``: the
+    captured window bodies, which zero the bucket first and use every parameter in this one node); autograd asks for every
+    one of these gradients (``needs``: ctx.needs_input_grad of the parameters) and each parameter requires grad -- a frozen
+    parameter with a stale ``.grad`` is never written; each ``.grad`` is a contiguous fp32 tensor of the parameter's shape on
+    its device; and no two parameters are the same tensor (a parameter used twice would receive two writes)."""
     if not _DIRECT_GRADS[0]:
+        return None
+    if len(needs) != len(params) or not all(needs) or len({id(p) for p in params}) != len(params):
         return None
     sinks = []
     for p in params:
         g = getattr(p, "grad", None)
-        if g is None or g.shape != p.shape or g.dtype != torch.float32 or g.device != p.device or not g.is_contiguous():
+        if (not p.requires_grad or g is None or g.shape != p.shape or g.dtype != torch.float32 or g.device != p.device
+                or not g.is_contiguous()):
             return None
         sinks.append(g)
     return sinks
@@ -178,7 +186,8 @@ class _TGCNWindow(torch.autograd.Function):
         # weight gradients: one split-K launch per parameter over the window's snapshots
         steps = range(B)
         Hprev = [_zeros(N, C, dev)] + [Hn[t] for t in range(B - 1)]
-        sinks = _grad_sinks(ctx.params)                    # .grad of (Wcz Wcr Wch bcz bcr bch Wz bz Wr br Wh bh W1 b1 W2 b2), or None
+        # .grad of (Wcz Wcr Wch bcz bcr bch Wz bz Wr br Wh bh W1 b1 W2 b2), or None
+        sinks = _grad_sinks(ctx.params, ctx.needs_input_grad[9:25])
         dst = (lambda i, j: dict(out=sinks[i], colsum_out=sinks[j])) if sinks else (lambda i, j: {})  # noqa: E731
         gate = lambda d, k, second, i: dict(  # noqa: E731
             As=[d[t] for t in steps], Bs=[X3[t][:, k * C:(k + 1) * C] for t in steps], M=C, N=2 * C, B2s=second, nsplit=C,
@@ -528,7 +537,7 @@ class _TGCNDynWindow(torch.autograd.Function):
             dx0 = kernels.gcn_agg(zbuf[0], s0["norm"], s0["norm"], s0["bwd"], use_node_ids=ctx.use_nid)
         rng = range(B)
         Hprev = [_zeros(N, C, dev)] + [Hn[t] for t in range(B - 1)]
-        sinks = _grad_sinks(ctx.params)                    # see _TGCNWindow.backward
+        sinks = _grad_sinks(ctx.params, ctx.needs_input_grad[5:19])          # see _TGCNWindow.backward
         dst = (lambda i, j: dict(out=sinks[i], colsum_out=sinks[j])) if sinks else (lambda i, j: {})  # noqa: E731
         gate = lambda d, k, second, i: dict(  # noqa: E731
             As=[d[t] for t in rng], Bs=[X3[t][:, k * C:(k + 1) * C] for t in rng], M=C, N=2 * C, B2s=second, nsplit=C,
@@ -630,6 +639,35 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
     return losses
 
 
+def _capture_tail_graph(tail, in_graph, dev, bucket, group, what: str):
+    """Capture ``tail()`` into a HIP graph.  ``in_graph[0]``: the tail contains the gradient all-reduce; if the communicator
+    refuses stream capture the failure is LOGGED (warnings), ``in_graph[0]`` is cleared, the communicator and the stream are
+    checked with one eager all-reduce of the bucket (it must come back: a broken communicator raises here, not steps later), and
+    the tail is captured again without the collective."""
+    import warnings
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(g):
+            tail()
+    except RuntimeError as err:
+        if not in_graph[0]:
+            raise
+        warnings.warn(f"{what}: the process group refused to capture the gradient all-reduce into the optimizer-tail graph "
+                      f"({type(err).__name__}: {str(err).splitlines()[0][:200]}); keeping the collective eager between the replays")
+        in_graph[0] = False
+        torch.cuda.synchronize(dev)
+        probe = bucket.flat.clone()
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=group)            # health check of communicator + stream
+        torch.cuda.synchronize(dev)
+        if not bool(torch.isfinite(probe).all()):
+            raise RuntimeError(f"{what}: the eager all-reduce after the failed capture returned non-finite values") from err
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            tail()
+    return g
+
+
 class CapturedStaticWindow:
     """The compute of one full BPTT window of the static-temporal loop -- bucket.zero, ``backprop_every`` model steps,
     loss, backward through time -- captured ONCE into a HIP graph and replayed per window.
@@ -667,7 +705,18 @@ class CapturedStaticWindow:
             raise ValueError("CapturedStaticWindow keeps its rank's window inputs of an epoch resident: more than 8 GiB here")
         # one resident slot per window of THIS rank (slot = w // world), refilled in place every epoch
         self.inputs = torch.zeros(max(len(self.my_windows), 1), n, feat_size, device=dev)
-        self.targets_w = targets[: self.full_windows * B].view(self.full_windows, B, *targets.shape[1:])
+        # targets are sharded by owning rank: this object keeps the snapshots of ITS windows only -- slot
+        # i = the i-th window of this rank, like the inputs -- so the caller may drop the full [T, N] tensor afterwards
+        self.total = int(total)
+        mine_full = [w for w in self.my_windows if w < self.full_windows]
+        if world == 1:
+            self.targets_w = targets[: self.full_windows * B].view(self.full_windows, B, *targets.shape[1:])   # a view: no copy
+        else:
+            self.targets_w = (torch.stack([targets[w * B:(w + 1) * B] for w in mine_full]) if mine_full
+                              else targets.new_zeros((1, B) + tuple(targets.shape[1:])))
+        tail_w = self.num_windows - 1
+        self.targets_tail = (targets[tail_w * B:total].clone()
+                             if self.num_windows > self.full_windows and tail_w in self.my_windows else None)
         self.widx = torch.zeros(1, dtype=torch.int64, device=dev)         # the window the next replay runs (global index)
         self.slot = torch.zeros(1, dtype=torch.int64, device=dev)         # its input slot = widx // world
         self.costs = torch.zeros(max(self.num_windows, 1), device=dev)
@@ -676,7 +725,7 @@ class CapturedStaticWindow:
         def body():
             bucket.zero()
             y0 = self.inputs.index_select(0, self.slot)[0]                            # captured gathers: no host copy
-            tw = self.targets_w.index_select(0, self.widx)[0]
+            tw = self.targets_w.index_select(0, self.slot)[0]             # slot == widx at one rank
             cost = window_cost_of(model, graph, y0, edge_weight, tw)
             cost = cost / (B + 1)
             with direct_param_grads():                       # the bucket was zeroed above: written, not accumulated
@@ -726,19 +775,7 @@ class CapturedStaticWindow:
             for _ in range(2):
                 tail()                                        # creates the optimizer state (device step counters)
         torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
-        try:
-            with torch.cuda.graph(g):
-                tail()
-        except RuntimeError:
-            if not in_graph[0]:
-                raise
-            in_graph[0] = False                               # the communicator does not capture: keep the collective eager
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                tail()
+        g = _capture_tail_graph(tail, in_graph, dev, bucket, self.group, "CapturedStaticWindow")
         self.allreduce_in_graph = in_graph[0]
         with torch.no_grad():
             for p, q in zip(params, saved_p):
@@ -782,9 +819,8 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
     """``train_epoch_static`` with full windows replayed from the captured graph; a trailing short
     window or a padding step (more ranks than windows left) runs eagerly.  Returns this rank's window costs as one
     tensor (views into the captured window's per-epoch buffer, cloned once at the end)."""
-    total = targets.shape[0]
+    total = cw.total                                     # (``targets`` may be None: the window object holds this rank's share)
     B = cw.B
-    n = graph.get_num_nodes()
     cw.begin_epoch(epoch, seed)
     slots, eager = [], {}
     for _, w in windows_of_rank(total, B, rank, world):
@@ -795,7 +831,8 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
         bucket.zero()
         if w is not None:
             y_hat = cw.inputs[w // world]
-            cost = window_cost_of(model, graph, y_hat, edge_weight, targets[w * B:min((w + 1) * B, total)])
+            tw = cw.targets_tail if cw.targets_tail is not None else targets[w * B:min((w + 1) * B, total)]
+            cost = window_cost_of(model, graph, y_hat, edge_weight, tw)
             cost = cost / (B + 1)
             cost.backward()
             eager[w] = cost.detach()
@@ -834,7 +871,10 @@ class CapturedDynamicWindows:
     snapshots at |V| = 25 K)."""
 
     def __init__(self, model, graph, pos_neg_edges, pos_neg_targets, backprop_every: int, optimizer,
-                 bucket: GradBucket, feat_size: int, world: int = 1, rank: int = 0, group=None, norm_fn=None):
+                 bucket: GradBucket, feat_size: int, world: int = 1, rank: int = 0, group=None, norm_fn=None,
+                 allreduce_in_graph: bool = False):
+        """``allreduce_in_graph``: as for :class:`CapturedStaticWindow` -- the gradient all-reduce captured into the
+        optimizer-tail graph (N > 1, or an explicit one-rank RCCL group); logged fallback to the eager collective."""
         from .graph.dynamic.dynamic_graph import DynamicGraph
         from .graph.dynamic.naive.naive_graph import NaiveGraph
         if not (isinstance(graph, DynamicGraph) and hasattr(graph, "csr")):
@@ -860,6 +900,8 @@ class CapturedDynamicWindows:
         self.step_graph = None
         self._tail_ready = False
         self._probe = None
+        self.allreduce_in_graph = False
+        self._want_allreduce_in_graph = bool(allreduce_in_graph) and (world > 1 or group is not None)
 
     def timestamps(self, w: int):
         return range(w * self.B, min((w + 1) * self.B, self.total - 1))
@@ -955,15 +997,19 @@ class CapturedDynamicWindows:
         if not all(g.get("capturable", False) for g in opt.param_groups) or not opt.state:
             return
 
+        in_graph = [self._want_allreduce_in_graph]
+
         def tail():
+            if in_graph[0]:
+                dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
             if world > 1:
                 bucket.flat.div_(world)
             opt.step()
-        torch.cuda.synchronize(self.dev)
-        cg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cg):
-            tail()
-        self.step_graph = cg
+        # capturing RUNS nothing, but a refused collective capture falls back to an eager health check: keep the gradients
+        saved = bucket.flat.clone()
+        self.step_graph = _capture_tail_graph(tail, in_graph, self.dev, bucket, self.group, "CapturedDynamicWindows")
+        bucket.flat.copy_(saved)
+        self.allreduce_in_graph = in_graph[0]
 
     def run(self, w: int, epoch: int, seed: int = 0, timed_comm: bool = False) -> torch.Tensor:
         if not self._tail_ready:
@@ -979,7 +1025,8 @@ class CapturedDynamicWindows:
             g._forward_graph, g.current_timestamp, g._is_backprop_state = copy.copy(fg), ts, False
             g._get_graph_csr_ptrs()
         if self.step_graph is not None:
-            self.bucket.all_reduce_mean(self.world, self.group, timed_comm, divide=False)
+            if not self.allreduce_in_graph:
+                self.bucket.all_reduce_mean(self.world, self.group, timed_comm, divide=False)
             self.step_graph.replay()
         else:
             self.bucket.all_reduce_mean(self.world, self.group, timed_comm)

@@ -44,15 +44,35 @@ def _worker(rank, world, port, outdir):
         bucket = temporal.GradBucket(model.parameters())
         cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, FEAT, world=world, rank=rank)
         assert cw.step_graph is not None
+        # the window object keeps this rank's share of the targets: the full tensor is not needed any more
+        assert cw.targets_w.shape[0] == max(1, len([w for w in cw.my_windows if w < cw.full_windows]))
+        del targets
+        grads, run_plain = [], cw.run
+
+        def run_recording(w, timed_comm=False):            # the averaged gradient every optimizer step consumed
+            r = run_plain(w, timed_comm)
+            if len(grads) < 3:
+                grads.append(bucket.flat.detach().clone().cpu())
+            return r
+        cw.run = run_recording
         losses = []
         for ep in range(EPOCHS):
-            losses += temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, FEAT, epoch=ep,
+            losses += temporal.train_epoch_static_captured(cw, model, g, ew, None, opt, bucket, FEAT, epoch=ep,
                                                            rank=rank, world=world, seed=SEED)
         torch.cuda.synchronize()
         torch.save({"params": [p.detach().cpu() for p in model.parameters()], "losses": torch.stack(losses).cpu(),
-                    "calls": bucket.comm_calls}, os.path.join(outdir, f"rank{rank}.pt"))
+                    "calls": bucket.comm_calls, "grads": grads}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
+
+
+def _grads_close(got, want, step):
+    """The averaged gradient bucket an optimizer step consumed: strict.  At step 0 both sides hold the same parameters, so the
+    gradients agree to fp32 rounding (1e-3 relative, 2e-5 of the bucket's largest entry); the parameters of later steps have
+    been through Adam (see ``_params_close``), so steps 1 and 2 get five times the absolute slack, nothing more."""
+    got, want = got.numpy(), want.numpy()
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=(2e-5 if step == 0 else 1e-4) * scale)
 
 
 def _params_close(got, want):
@@ -77,6 +97,7 @@ def _single_process_equivalent(world, dev):
     opt = torch.optim.Adam(model.parameters(), lr=1e-2)
     nwin = temporal.num_windows(T, B)
     losses = {r: [] for r in range(world)}
+    step_grads = []
     for ep in range(EPOCHS):
         for s in range((nwin + world - 1) // world):
             grads = [torch.zeros_like(p) for p in model.parameters()]
@@ -94,8 +115,10 @@ def _single_process_equivalent(world, dev):
                         acc += p.grad
             for acc, p in zip(grads, model.parameters()):
                 p.grad = acc / world
+            if len(step_grads) < 3:
+                step_grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu())
             opt.step()
-    return [p.detach().cpu() for p in model.parameters()], losses
+    return [p.detach().cpu() for p in model.parameters()], losses, step_grads
 
 
 @pytest.mark.timeout(600)
@@ -105,10 +128,13 @@ def test_two_ranks_captured_static_windows_equal_single_process(cuda):
     with tempfile.TemporaryDirectory() as outdir:
         mp.spawn(_worker, args=(world, _free_port(), outdir), nprocs=world, join=True)
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
-    want_params, want_losses = _single_process_equivalent(world, cuda)
+    want_params, want_losses, want_grads = _single_process_equivalent(world, cuda)
     steps = (temporal.num_windows(T, B) + world - 1) // world * EPOCHS
     for r in range(world):
         assert res[r]["calls"] == steps                    # ONE all-reduce per optimizer step
+        assert len(res[r]["grads"]) == len(want_grads) == 3
+        for k, (got, want) in enumerate(zip(res[r]["grads"], want_grads)):
+            _grads_close(got, want, k)                     # the gradients themselves: strict (the bucket's flat order = parameters())
         np.testing.assert_allclose(res[r]["losses"].numpy(), torch.stack(want_losses[r]).numpy(), rtol=2e-4, atol=1e-6)
         for got, want in zip(res[r]["params"], want_params):
             _params_close(got.numpy(), want.numpy())
@@ -154,16 +180,24 @@ def _dyn_worker(rank, world, port, outdir, resident):
         G, pn_edges, pn_targets, model = _dynamic_problem(dev, resident)
         opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
         bucket = temporal.GradBucket(model.parameters())
+        grads, step_plain = [], opt.step
+
+        def step_recording(*a, **k):                       # the averaged gradient each eager optimizer step consumes
+            if len(grads) < 2:
+                grads.append(bucket.flat.detach().clone().cpu())
+            return step_plain(*a, **k)
+        opt.step = step_recording
         losses = temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, DB, opt, bucket, FEAT, epoch=0, rank=rank,
                                               world=world, seed=SEED)
+        opt.step = step_plain
         cd = temporal.CapturedDynamicWindows(model, G, pn_edges, pn_targets, DB, opt, bucket, FEAT, world=world, rank=rank)
         for ep in range(1, EPOCHS):
             G._ndata.clear()
             losses += [x.clone() for x in temporal.train_epoch_dynamic_captured(cd, epoch=ep, seed=SEED)]
         torch.cuda.synchronize()
         assert cd.step_graph is not None and len(cd.graphs) >= 1
-        torch.save({"params": [p.detach().cpu() for p in model.parameters()], "losses": torch.stack(losses).cpu()},
-                   os.path.join(outdir, f"rank{rank}.pt"))
+        torch.save({"params": [p.detach().cpu() for p in model.parameters()], "losses": torch.stack(losses).cpu(),
+                    "grads": grads}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -175,6 +209,7 @@ def _dyn_single_process_equivalent(world, dev, resident):
     opt = torch.optim.Adam(model.parameters(), lr=1e-2)
     nwin = temporal.num_windows(DT, DB)
     losses = {r: [] for r in range(world)}
+    step_grads = []
     for ep in range(EPOCHS):
         G.reset_graph()
         for s in range((nwin + world - 1) // world):
@@ -199,8 +234,10 @@ def _dyn_single_process_equivalent(world, dev, resident):
                         acc += p.grad
             for acc, p in zip(grads, model.parameters()):
                 p.grad = acc / world
+            if len(step_grads) < 3:
+                step_grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu())
             opt.step()
-    return [p.detach().cpu() for p in model.parameters()], losses
+    return [p.detach().cpu() for p in model.parameters()], losses, step_grads
 
 
 @pytest.mark.timeout(600)
@@ -210,8 +247,11 @@ def test_two_ranks_captured_dynamic_windows_equal_single_process(cuda, resident)
     with tempfile.TemporaryDirectory() as outdir:
         mp.spawn(_dyn_worker, args=(world, _free_port(), outdir, resident), nprocs=world, join=True)
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
-    want_params, want_losses = _dyn_single_process_equivalent(world, cuda, resident)
+    want_params, want_losses, want_grads = _dyn_single_process_equivalent(world, cuda, resident)
     for r in range(world):
+        assert len(res[r]["grads"]) == 2 and len(want_grads) >= 2          # the eager epoch's two optimizer steps
+        for k, (got, want) in enumerate(zip(res[r]["grads"], want_grads)):
+            _grads_close(got, want, k)
         np.testing.assert_allclose(res[r]["losses"].numpy(), torch.stack(want_losses[r]).numpy(), rtol=2e-4, atol=1e-6)
         for got, want in zip(res[r]["params"], want_params):
             _params_close(got.numpy(), want.numpy())

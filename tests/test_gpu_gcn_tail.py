@@ -113,3 +113,41 @@ def test_tail_at_bench_scale_properties(cuda):
     ga, cs = kernels.bias_act_bwd(gr, fused)
     assert torch.equal(ga, gr * (fused > 0))
     torch.testing.assert_close(cs.double(), ga.double().sum(0), rtol=1e-5, atol=1e-2)
+
+
+@pytest.mark.parametrize("second_first", [False, True])
+def test_bias_gradient_with_a_second_consumer_of_the_logits(cuda, second_first):
+    """The cross-entropy backward leaves the gradient's column sums on the gradient tensor for the bias layer below it
+    (nn/functional.py: `_stg_colsum`).  When the logits have a SECOND consumer (a regulariser here) autograd adds the two
+    gradients -- in place or into a new tensor -- and the sums no longer describe what the layer receives: the layer must
+    notice (version counter / storage address) and re-read the matrix.  Checked against the torch composition of the same
+    loss, with the regulariser's node created before and after the loss's (both accumulation orders)."""
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gcn_conv import GCNConv
+    n, e, Fi, K = 1500, 20000, 24, 7
+    g, og, norm = _graph(cuda, n, e, 9)
+    torch.manual_seed(3)
+    conv = GCNConv(Fi, K, activation=None).to(cuda)
+    x = torch.randn(n, Fi, device=cuda)
+    labels = torch.randint(0, K, (n,), device=cuda)
+    res = []
+    for fused in (True, False):
+        conv.zero_grad()
+        logits = conv(g, x)
+        if second_first:
+            reg = 0.3 * logits.pow(2).mean()
+            loss = (SF.cross_entropy(logits, labels) if fused else F.cross_entropy(logits, labels)) + reg
+        else:
+            loss = (SF.cross_entropy(logits, labels) if fused else F.cross_entropy(logits, labels)) + 0.3 * logits.pow(2).mean()
+        loss.backward()
+        res.append((conv.bias.grad.clone(), conv.weight.grad.clone()))
+    (gb1, gw1), (gb2, gw2) = res
+    torch.testing.assert_close(gb1, gb2, rtol=1e-4, atol=1e-5 * float(gb2.abs().max()))
+    torch.testing.assert_close(gw1, gw2, rtol=1e-4, atol=1e-5 * float(gw2.abs().max()))
+    # and alone (the fast path still taken): the loss's own column sums are the bias gradient
+    conv.zero_grad()
+    SF.cross_entropy(conv(g, x), labels).backward()
+    gb_alone = conv.bias.grad.clone()
+    conv.zero_grad()
+    F.cross_entropy(conv(g, x), labels).backward()
+    torch.testing.assert_close(gb_alone, conv.bias.grad, rtol=1e-4, atol=1e-5 * float(conv.bias.grad.abs().max()))
