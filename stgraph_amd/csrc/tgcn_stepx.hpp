@@ -1,0 +1,192 @@
+// The one-launch TGCN step on the MATRIX cores of gfx950: every product as a 3-term bf16 split with fp32 accumulation.
+//
+// Why (profiles/r04_coexec_f32mfma.jsonl, tools/diag/coexec.hip): v_mfma_f32_16x16x4_f32 runs ON the vector ALU's fp32 lanes --
+// 32 cycles per instruction, every vector instruction of the wave adds its full 4 cycles on top (57.8 cycles for one MFMA + 4
+// v_fma), for one, two or three waves per SIMD alike -- so the fp32 form of the step (tgcn_step_fwd.hip) is priced at
+// 512 x 32 + ~740 x 4 cycles per 16-row tile whatever the schedule.  The bf16 matrix instruction v_mfma_f32_16x16x32_bf16 covers
+// eight times the K in half the cycles on a pipe of its own (vector instructions issue in its shadow).  An fp32 value is the
+// exact sum of three bf16 values (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 3 x 8 significant bits), and a product
+// x w is taken as the six terms h h + h m + m h + h l + l h + m m accumulated in fp32 -- what is dropped (m l, l m, l l) is below
+// 2^-23 |x w|, the size of ONE fp32 rounding; each bf16 x bf16 product is exact in fp32.  Six 16-cycle instructions replace
+// eight 32-cycle ones: 2.7 x less matrix time, off the vector lanes.
+//
+// Layout.  Three bf16 terms of the weights are 6 bytes per weight: 196 KB, more than a CU's LDS -- but the four SIMDs of a CU
+// hold 512 KB of registers.  So the OUTPUT COLUMNS of every product are cut over the waves: wave (team, ct) owns columns
+// 16 ct .. 16 ct + 15 of each gate (ct = 0 .. 3), keeps ITS rows of the three gate Linears in registers for the whole launch as
+// MFMA A operands (36 fragments = 144 registers, split once per window by stg_tgcn_pack_weights_x3), and the activations -- the
+// B operands, needed by all four waves -- travel through LDS as ready-made bf16 fragments: each wave splits the four values per
+// lane it produced and drops them into the fragment image.  The small weights (Wcat, the head's W1: 48 KB as fragments) sit in LDS.
+// A workgroup is two TEAMS of four waves (one wave of each team per SIMD) working on different tiles two phases apart, so that one
+// team's matrix phase runs beside the other's gather / elementwise / store phase; a phase boundary is one workgroup barrier.
+//
+// Fragment conventions (v_mfma_f32_16x16x32_bf16: lane l holds A[row l & 15][k = 8 (l >> 4) + i], B[k][col l & 15], i = 0 .. 7;
+// D[row 4 (l >> 4) + r][col l & 15]).  Weights are A (row = output column inside the wave's 16), activations are B (col = row
+// n16 of the tile), so lane (n16 = l & 15, kq = l >> 4) receives output columns 16 ct + 4 kq .. + 3 of ITS row: a 16-byte row
+// piece, as in tgcn_step.hpp.  The k index of K-block b is mapped to input column  c(b, kq, i) = 32 b + 16 (i >> 2) + 4 kq + (i & 3):
+// a lane's eight k values are the row pieces j = 2 b and j = 2 b + 1 of the input, so the piece a wave PRODUCES (j = its ct) is
+// half (ct & 1) of the fragment of K-block ct >> 1: one 8-byte LDS store per term.
+#pragma once
+#include "tgcn_step.hpp"
+
+namespace stg {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kXC = 64, kXFin = 32, kXFh = 32;          // the shapes the split form is built for (stg_tgcn_step_supported)
+constexpr int kXTerms = 3;
+constexpr int kFragBytes = 64 * 16;                     // one fragment of one term: 16 bytes per lane
+
+// ---- weight image (stg_tgcn_pack_weights_x3) -----------------------------------------------------------------------------
+// forward:  [gate section: ct 0..3][g 0..2][b 0..3][t 0..2] | [Wcat section: ct][g][t] | [W1 section: ct' 0..1][b 0..1][t]
+//           then fp32: b3 [3C] | bz br bh [3C] | b1 [Fh] | W2 [Fh] | b2 [1] (+ 3 pad)
+// backward: [gate section: ct][g][half 0..1][b 0..1][t] | [W1T section: ct][t] | [Wcat section: ct' 0..1][b 0..5][t]
+//           then fp32: W2 [Fh]
+constexpr int kFwdGateFrags = 3 * 4 * kXTerms;          // per ct: 36
+constexpr int kFwdCatFrags = 3 * kXTerms;               // per ct: 9
+constexpr int kFwdHeadFrags = 2 * kXTerms;              // per ct': 6
+constexpr int kFwdImgGate = 0;
+constexpr int kFwdImgCat = kFwdImgGate + 4 * kFwdGateFrags * kFragBytes;
+constexpr int kFwdImgHead = kFwdImgCat + 4 * kFwdCatFrags * kFragBytes;
+constexpr int kFwdImgBias = kFwdImgHead + 2 * kFwdHeadFrags * kFragBytes;
+constexpr int kFwdBiasFloats = 6 * kXC + 2 * kXFh + 4;
+constexpr int kFwdImgBytes = kFwdImgBias + 4 * kFwdBiasFloats;
+
+constexpr int kBwdGateFrags = 3 * 2 * 2 * kXTerms;      // per ct: 36
+constexpr int kBwdHeadFrags = kXTerms;                  // per ct: 3  (W1T: K = Fh = 32 is one K-block)
+constexpr int kBwdCatFrags = 6 * kXTerms;               // per ct': 18 (K = 3C = 192 is six K-blocks)
+constexpr int kBwdImgGate = 0;
+constexpr int kBwdImgHead = kBwdImgGate + 4 * kBwdGateFrags * kFragBytes;
+constexpr int kBwdImgCat = kBwdImgHead + 4 * kBwdHeadFrags * kFragBytes;
+constexpr int kBwdImgBias = kBwdImgCat + 2 * kBwdCatFrags * kFragBytes;
+constexpr int kBwdBiasFloats = kXFh;
+constexpr int kBwdImgBytes = kBwdImgBias + 4 * kBwdBiasFloats;
+
+// input column of element i of lane group kq in K-block b
+__host__ __device__ constexpr int xcol(int b, int kq, int i) { return 32 * b + 16 * (i >> 2) + 4 * kq + (i & 3); }
+
+// ---- the split ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pk_bf16(float a, float b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));      // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+
+// four fp32 values -> three terms of four bf16 each (8 bytes per term): v = h + m + l to within 2^-25 |v|
+struct Split4 {
+    uint2 t[kXTerms];
+};
+__device__ __forceinline__ Split4 split4(const float4 &v)
+{
+    Split4 s;
+    float a = v.x, b = v.y, c = v.z, d = v.w;
+#pragma unroll
+    for (int k = 0; k < kXTerms; ++k) {
+        const unsigned p0 = pk_bf16(a, b), p1 = pk_bf16(c, d);
+        s.t[k] = make_uint2(p0, p1);
+        if (k + 1 < kXTerms) {
+            a = a - bf16_lo(p0), b = b - bf16_hi(p0), c = c - bf16_lo(p1), d = d - bf16_hi(p1);      // exact in fp32
+        }
+    }
+    return s;
+}
+
+// the fragment (eight k values of this lane) of each term from two split row pieces: elements 0..3 = piece 2 b, 4..7 = piece 2 b + 1
+struct Frag3 {
+    bf16x8 t[kXTerms];
+};
+__device__ __forceinline__ Frag3 frag_of(const Split4 &lo, const Split4 &hi)
+{
+    Frag3 f;
+#pragma unroll
+    for (int k = 0; k < kXTerms; ++k) f.t[k] = __builtin_bit_cast(bf16x8, make_uint4(lo.t[k].x, lo.t[k].y, hi.t[k].x, hi.t[k].y));
+    return f;
+}
+
+// acc += W x X over one K-block: the six kept terms, small ones first
+__device__ __forceinline__ void mfma6(f32x4 &acc, const Frag3 &w, const Frag3 &x)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[0], x.t[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[2], x.t[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[1], x.t[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[0], x.t[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[1], x.t[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[0], x.t[0], acc, 0, 0, 0);
+}
+
+// ---- fragment images in LDS ----------------------------------------------------------------------------------------------------
+// An activation image of KB K-blocks: [b][t][lane] 16 bytes.  The producer of row piece j writes half (j & 1) of K-block j >> 1.
+__device__ __forceinline__ void frag_store_piece(char *img, int j, int lane, const Split4 &s)
+{
+    char *p = img + ((j >> 1) * kXTerms * kFragBytes) + lane * 16 + (j & 1) * 8;
+#pragma unroll
+    for (int k = 0; k < kXTerms; ++k) *reinterpret_cast<uint2 *>(p + k * kFragBytes) = s.t[k];
+}
+__device__ __forceinline__ Frag3 frag_load(const char *img, int b, int lane)
+{
+    Frag3 f;
+    const char *p = img + (b * kXTerms * kFragBytes) + lane * 16;
+#pragma unroll
+    for (int k = 0; k < kXTerms; ++k) f.t[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(p + k * kFragBytes));
+    return f;
+}
+// a weight fragment triple out of an image section laid out [.. frag index ..][lane]
+__device__ __forceinline__ Frag3 wfrag_load(const char *sec, int first_frag, int lane)
+{
+    Frag3 f;
+    const char *p = sec + (size_t)first_frag * kFragBytes + lane * 16;
+#pragma unroll
+    for (int k = 0; k < kXTerms; ++k) f.t[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(p + k * kFragBytes));
+    return f;
+}
+
+// ---- gather: four rows per wave, sixteen lanes x two floats per row -----------------------------------------------------------
+// P[r, :] = norm[r] * sum_e (nc[e] * x[col[e], :]) * w[e] in CSR order: the arithmetic (and order) of gcn_agg_kernel, bit-identical P.
+// lane = (rl = lane >> 4: row 4 slot + rl of the tile, c2 = lane & 15: columns 2 c2, 2 c2 + 1).  The 16 lanes of a row load the same
+// index / scalar words (one transaction) instead of broadcasting them.
+template <bool HAS_EW>
+__device__ __forceinline__ float2 gather_row2(const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
+                                              const float *__restrict__ nc_edge, const float *__restrict__ ew_edge,
+                                              const float *__restrict__ norm, const float *__restrict__ x, int row, int c2)
+{
+    constexpr int U = 8;
+    const int beg = row_offsets[row], deg = row_offsets[row + 1] - beg;
+    const float nr = norm[row];
+    const int max_deg = wave_max_nonneg(deg);
+    float a0 = 0.f, a1 = 0.f;
+    for (int base = 0; base < max_deg; base += U) {
+        int c[U];
+        float nc[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = base + u < deg;
+            const int e = beg + (ok ? base + u : 0);
+            c[u] = ok ? column_indices[e] : 0;
+            nc[u] = ok ? nc_edge[e] : 0.f;
+            w[u] = 1.f;
+            if constexpr (HAS_EW) w[u] = ok ? ew_edge[e] : 0.f;
+        }
+        float2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned off = (unsigned)c[u] * (kXFin * 4u) + 8u * c2;
+            v[u] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(x) + (size_t)off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + u < deg) {
+                float t0 = nc[u] * v[u].x, t1 = nc[u] * v[u].y;
+                if constexpr (HAS_EW) t0 = t0 * w[u], t1 = t1 * w[u];
+                a0 = a0 + t0;
+                a1 = a1 + t1;
+            }
+        }
+    }
+    return make_float2(a0 * nr, a1 * nr);
+}
+
+}  // namespace
+}  // namespace stg

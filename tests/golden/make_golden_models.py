@@ -16,10 +16,11 @@ loops restate benchmarking/*/seastar/train.py (whose imports do not resolve in t
                    (N = 2708, E = 10556), loop of gcn/seastar/train.py:63-101 (CrossEntropyLoss on the first 60 % rows,
                    Adam lr 1e-2 wd 5e-4): widths 128-128-128 (the cfg2 model), 1433-16-8 and 1433-16-7 (cfg1; the last
                    one carries reference defect D1): logits, loss and every gradient at step 0, loss of steps 0..3,
-                   parameters after 3 steps.
+                   parameters after 3 steps; (round 4) the parameters and gradients of steps 1 and 2.
   gat_model.npz    benchmarking/gat/seastar/model.py GAT (1 hidden layer, heads [8, 1], ELU) on the same graph, loop of
                    gat/seastar/train.py:95-125: shapes in 32 -> 8 x 8 -> 16 and in 64 -> 8 x 64 -> 16 (the cfg3 layer
-                   widths): logits, loss, every gradient at step 0, losses of steps 0..3, parameters after 3 steps.
+                   widths): logits, loss, every gradient at step 0, losses of steps 0..3, parameters after 3 steps;
+                   (round 4) the parameters and gradients of steps 1 and 2.
   dyn_tgcn.npz     dynamic-temporal loop (dynamic-temporal-tgcn/seastar/train.py:179-231, model.py:5-21) on a
                    NaiveGraph: N = 4096, E_t = 32768 with 5 % churn per step, T = 7, B in {3, 6}, feat 32 -> hidden 64,
                    link-prediction head on 2048 positive + 2048 negative label edges per snapshot: window costs, every
@@ -191,7 +192,7 @@ def gen_tgcn_native():
         torch.manual_seed(7500)
         model = STGraphTGCN(feat, hid, 1)
         opt = torch.optim.Adam(model.parameters(), lr=1e-2)
-        costs, margin = [], 1.0
+        costs, margin, step_grads = [], 1.0, {}
         for epoch in range(2):
             for index in range(T // B):
                 opt.zero_grad()
@@ -203,12 +204,16 @@ def gen_tgcn_native():
                     margin = min(margin, float(hidden.detach().abs().min()))
                 cost = cost / (B + 1)
                 cost.backward()
+                # round 4: the gradient every optimizer step consumed (the GPU test names the entries whose gradient is
+                # rounding noise -- where Adam's g / (|g| + eps) is ill-conditioned -- by THESE values)
+                step_grads.update({f"train_grad{len(costs)}_{k}": p.grad.detach().clone() for k, p in model.named_parameters()})
                 opt.step()
                 costs.append(cost.detach().clone())
         print("train loop base", base, "min|h|", margin, flush=True)
         if margin >= TIE_MARGIN:
             break
     d["train_min_abs_hidden"] = margin
+    d.update(step_grads)
     d["train_costs"] = torch.stack(costs)
     d.update({f"train_paramT_{k}": p.detach().clone() for k, p in model.named_parameters()})
     save("tgcn_native.npz", d)
@@ -254,6 +259,12 @@ def gen_gcn_model():
                 d[tag + "_logits_colsum"] = logits.detach().double().sum(0)
                 d[tag + "_logits_abs_colsum"] = logits.detach().double().abs().sum(0)
                 d.update({f"{tag}_grad0_{k}": p.grad.detach().clone() for k, p in model.named_parameters()})
+            elif step < 3:
+                # round 4: the parameters every later step starts from and the gradients it produces, so that the GPU test
+                # checks GRADIENTS at the reference's own parameters step by step instead of parameters after 3 Adam steps
+                # (whose entries with a rounding-noise gradient move by lr in either direction)
+                d.update({f"{tag}_param{step}_{k}": p.detach().clone() for k, p in model.named_parameters()})
+                d.update({f"{tag}_grad{step}_{k}": p.grad.detach().clone() for k, p in model.named_parameters()})
             losses.append(loss.detach().clone())
             if step < 3:
                 opt.step()
@@ -298,6 +309,12 @@ def gen_gat_model():
                 d[tag + "_logits_colsum"] = logits.detach().double().sum(0)
                 d[tag + "_logits_abs_colsum"] = logits.detach().double().abs().sum(0)
                 d.update({f"{tag}_grad0_{k}": p.grad.detach().clone() for k, p in model.named_parameters()})
+            elif step < 3:
+                # round 4: the parameters every later step starts from and the gradients it produces, so that the GPU test
+                # checks GRADIENTS at the reference's own parameters step by step instead of parameters after 3 Adam steps
+                # (whose entries with a rounding-noise gradient move by lr in either direction)
+                d.update({f"{tag}_param{step}_{k}": p.detach().clone() for k, p in model.named_parameters()})
+                d.update({f"{tag}_grad{step}_{k}": p.grad.detach().clone() for k, p in model.named_parameters()})
             losses.append(loss.detach().clone())
             if step < 3:
                 opt.step()

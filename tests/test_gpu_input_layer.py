@@ -17,13 +17,15 @@ def _model(fin, hid, out, seed, cuda):
     return torch.nn.ModuleList([GCNConv(fin, hid, torch.relu), GCNConv(hid, out, None)]).to(cuda)
 
 
-@pytest.mark.parametrize("bias0", [30.0, 0.0])
+@pytest.mark.parametrize("bias0", ["positive", "kink_free"])
 @pytest.mark.parametrize("fin,hid,out,use_ew", [(128, 128, 128, False), (24, 64, 7, True), (16, 16, 5, False)])
 def test_reordered_input_layer_matches_the_reference_order(cuda, fin, hid, out, use_ew, bias0):
-    """``bias0`` = 30: every pre-activation of the first layer is positive, so the two orders must agree to fp32 rounding
-    everywhere.  ``bias0`` = 0: a pre-activation within rounding of zero may land on either side of the ReLU (as it
-    may between any two fp32 evaluations, the reference's FMA build and its no-FMA emulation included), which moves a
-    whole column of the weight gradient by one row's contribution: outputs strictly, gradients in norm."""
+    """Both orders on the same GPU, outputs and every gradient to 1e-4 of the tensor's largest entry.  ``positive``: a first-layer
+    bias of 30 keeps every pre-activation positive (no ReLU decision at all).  ``kink_free``: a per-column bias that leaves
+    no pre-activation within 2e-5 of zero (``_kink_free_bias``), so the ReLU mask is a real mix of zeros and ones but cannot
+    depend on the order of an fp32 sum.  (With pre-activations ON the kink two correct fp32 evaluations flip individual
+    ReLUs -- measured at the full cfg2 shape: 4.4e-4 of a gradient's size, 8.2e-4 for the reference order itself,
+    profiles/r03_input_layer_error.json; that is a property of the inputs, not a tolerance of this test.)"""
     from stgraph_amd import kernels
     from stgraph_amd.graph import StaticGraph
     from stgraph_amd.nn import functional as SF
@@ -38,12 +40,20 @@ def test_reordered_input_layer_matches_the_reference_order(cuda, fin, hid, out, 
     ew = torch.from_numpy((rng.random((e, 1)) + 0.5).astype(np.float32)).to(cuda) if use_ew else None
     R = torch.from_numpy(rng.standard_normal((n, out)).astype(np.float32)).to(cuda)
     res, aggs = [], []
+    if bias0 == "kink_free":
+        probe = _model(fin, hid, out, 5, cuda)
+        with torch.no_grad():
+            pre = kernels.gcn_agg(x @ probe[0].weight, g.get_ndata("norm"), g.get_ndata("norm"), g.csr("fwd"), ew=ew)
+        bias_np = _kink_free_bias(pre.cpu().numpy())
     for reorder in (True, False):
         SF.set_input_layer_reorder(reorder)
         try:
             layers = _model(fin, hid, out, 5, cuda)
             with torch.no_grad():
-                layers[0].bias.fill_(bias0)
+                if bias0 == "positive":
+                    layers[0].bias.fill_(30.0)
+                else:
+                    layers[0].bias.copy_(torch.from_numpy(bias_np).to(cuda))
             assert SF.input_layer_usable(g, x, layers[0].weight, layers[0].activation) == reorder
             rec = []
             kernels.enable_launch_timing(rec)
@@ -60,11 +70,8 @@ def test_reordered_input_layer_matches_the_reference_order(cuda, fin, hid, out, 
     assert aggs == [3, 4], (aggs, [r[0] for r in rec])    # one aggregation fewer per training step
     names = ["out"] + [n for n, _ in layers.named_parameters()]
     for name, a, b in zip(names, res[0], res[1]):
-        if bias0 or name == "out":
-            torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max() + 1),
-                                       msg=lambda m, name=name: f"{name}: {m}")
-        else:
-            assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-3, name
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        assert err <= 1e-4, (name, err)
 
 
 def test_an_input_that_needs_a_gradient_keeps_the_reference_order(cuda):

@@ -49,6 +49,23 @@ def _colsum_close(t, d, key, name):
     assert np.all(np.abs(got - d[key + "_colsum"]) <= bound), name
 
 
+def _params_close_where_adam_is_well_conditioned(model, d, tag, lr):
+    """Parameters after the 3 recorded Adam steps.  Adam moves an entry by lr * m / (sqrt(v) + eps): where a step's gradient
+    is within rounding noise of zero (|g| below NOISE = 1e-4 of that gradient tensor's largest entry, or below 100 eps in
+    absolute terms) the update is ill-conditioned -- two correct fp32 evaluations of the same gradient move the entry by up to
+    lr in either direction -- so those entries are EXCLUDED, by name of this rule, using the REFERENCE's recorded gradients
+    of steps 0..2; every other entry is held to 1e-4 (absolute; the parameters are O(0.1)).  The gradients themselves are
+    checked entry by entry, unconditionally, at every step (the per-step fixtures)."""
+    for k, p in model.named_parameters():
+        keep = np.ones(tuple(p.shape), dtype=bool)
+        for s_ in range(3):
+            gref = np.abs(d[f"{tag}_grad{s_}_{k}"])
+            keep &= gref >= max(1e-4 * float(gref.max()), 1e-6)
+        err = np.abs(p.detach().cpu().numpy() - d[f"{tag}_param3_{k}"])
+        assert not keep.any() or err[keep].max() <= TOL, (k, float(err[keep].max()), float(keep.mean()))
+        assert err.max() <= 3.5 * lr, (k, float(err.max()))        # nothing moves further than three steps of lr
+
+
 @pytest.fixture(autouse=True)
 def _defaults():
     stgraph_amd.set_reference_compat(False)
@@ -110,17 +127,19 @@ def test_window_cost_matches_the_reference_loop_at_native_widths(cuda, B, use_ew
         _colsum_close(t, d, f"{tag}_{key}", key)
 
 
-@pytest.mark.parametrize("mode", ["eager", "hip_graph", "hip_graph_capturable_adam"])
+@pytest.mark.parametrize("mode", ["eager", "hip_graph", "hip_graph_capturable_adam", "hip_graph_capturable_fused_adam"])
 def test_static_training_loop_matches_the_reference_adam_run(cuda, mode, monkeypatch):
     """2 epochs x 2 windows (B = 3, edge weights, Adam lr 1e-2) through train_epoch_static / its HIP-graph form.
 
     ``eager`` and ``hip_graph`` (window replayed from the graph, torch's default Adam stepping eagerly) follow the
-    reference run to 2e-5 on every parameter.  With torch's ``capturable=True`` Adam (optimizer inside the second graph)
-    one step differs from the default Adam by 7e-8 (measured, same gradients); entries whose gradient is below Adam's
-    eps = 1e-8 (the gradients here peak at 2.5e-5 and reach down to 3e-11) move by lr * dg / (|g| + eps), so that
-    difference grows to ~1e-3 on a fraction of a percent of the entries after 4 steps -- a property of the update rule,
-    not of this package (the captured window's gradients are bit-identical to the eager ones): costs are checked
-    strictly, parameters in the bulk."""
+    reference run to 2e-5 on every parameter.  ``hip_graph_capturable_fused_adam`` is the optimizer ``bench.py`` times
+    (``Adam(capturable=True, fused=True)``: the update inside the second graph as one kernel), ``hip_graph_capturable_adam``
+    the same without ``fused``.  The capturable forms evaluate the same update rule in another order (one step differs from
+    the default Adam by 7e-8, measured on equal gradients), and Adam's lr * m / (sqrt(v) + eps) amplifies that where a
+    step's gradient is rounding noise: the gradients of this run peak at 6e-6 and reach down to 9e-10, eps is 1e-8.  So
+    the rule is explicit: an entry is EXCLUDED when its reference gradient (recorded per optimizer step in the fixture,
+    ``train_grad<k>_*``) is below 1e-6 of that tensor's largest entry at any of the four steps; every other entry is held to
+    2e-5 like the eager mode, and every entry, excluded or not, to four steps of lr.  Costs are checked strictly."""
     from stgraph_amd import temporal
     d = golden("tgcn_native.npz")
     g, targets, ew, n, T = _static_setup(d, cuda, True)
@@ -128,7 +147,8 @@ def test_static_training_loop_matches_the_reference_adam_run(cuda, mode, monkeyp
     model = temporal.STGraphTGCN(feat, hid, 1).to(cuda)
     _load(model, d, "train_param0_", cuda)
     captured = mode != "eager"
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=mode == "hip_graph_capturable_adam")
+    capturable = mode.startswith("hip_graph_capturable")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=capturable, fused=True if mode.endswith("fused_adam") else None)
     bucket = temporal.GradBucket(model.parameters())
     base = int(d["train_x0_seed_base"])
 
@@ -138,7 +158,7 @@ def test_static_training_loop_matches_the_reference_adam_run(cuda, mode, monkeyp
     monkeypatch.setattr(temporal, "window_input", draw)
     costs = []
     cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, feat) if captured else None
-    assert cw is None or (cw.step_graph is not None) == (mode == "hip_graph_capturable_adam")
+    assert cw is None or (cw.step_graph is not None) == capturable
     for epoch in range(2):
         if captured:
             costs += temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, feat, epoch=epoch)
@@ -148,8 +168,14 @@ def test_static_training_loop_matches_the_reference_adam_run(cuda, mode, monkeyp
     for k, p in model.named_parameters():
         want = d["train_paramT_" + k]
         err = np.abs(p.detach().cpu().numpy() - want)
-        if mode == "hip_graph_capturable_adam":
-            assert (err > 2e-4).mean() < 0.01 and err.max() < 5e-3, (k, float(err.max()), float((err > 2e-4).mean()))
+        if capturable:
+            keep = np.ones(want.shape, dtype=bool)
+            for s_ in range(4):
+                gref = np.abs(d[f"train_grad{s_}_{k}"])
+                keep &= gref >= 1e-6 * float(gref.max())
+            assert keep.mean() > 0.9, (k, float(keep.mean()))             # the rule names a small minority
+            assert err[keep].max() <= 2e-5, (k, float(err[keep].max()), float(keep.mean()))
+            assert err.max() <= 4.5e-2, (k, float(err.max()))
         else:
             assert err.max() <= 2e-5, (k, float(err.max()))
 
@@ -268,8 +294,16 @@ def test_gcn_model_training_step_matches_the_reference(cuda, tag, mode, monkeypa
     with torch.no_grad():
         losses.append(float(SF.cross_entropy(model(g, x), labels, ntrain)))
     np.testing.assert_allclose(losses, d[tag + "_losses"], rtol=1e-4, atol=1e-5)
-    for k, p in model.named_parameters():
-        _close(p, d[f"{tag}_param3_{k}"], "parameter after 3 Adam steps: " + k, 2e-4)
+    _params_close_where_adam_is_well_conditioned(model, d, tag, 1e-2)
+    # steps 1 and 2 at the REFERENCE's own parameters of those steps (recorded per step, round 4): loss and every gradient
+    for s_ in (1, 2):
+        _load(model, d, f"{tag}_param{s_}_", cuda)
+        model.zero_grad(set_to_none=False)
+        loss = SF.cross_entropy(model(g, x), labels, ntrain)
+        loss.backward()
+        _close(loss, d[tag + "_losses"][s_], f"loss of step {s_}", 1e-5)
+        for k, p in model.named_parameters():
+            _grad_close(p.grad, d[f"{tag}_grad{s_}_{k}"], f"gradient of step {s_}: {k}")
 
 
 def test_captured_train_step_equals_eager(cuda):
@@ -410,6 +444,15 @@ def test_gat_model_training_step_matches_the_reference(cuda, tag, mode):
     with torch.no_grad():
         losses.append(float(SF.cross_entropy(model(x), labels, ntrain)))
     np.testing.assert_allclose(losses, d[tag + "_losses"], rtol=1e-4, atol=1e-5)
-    for k, p in model.named_parameters():
-        # attn_r: Adam turns a 2e-10 noise gradient into steps of lr * g / (|g| + eps) ~ 1e-4 of either sign
-        _close(p, d[f"{tag}_param3_{k}"], "parameter after 3 Adam steps: " + k, 6e-4 if k.endswith("attn_r") else 2e-4)
+    # (attn_r's gradient is 2e-10 of rounding noise in the reference itself: every entry of it falls under the rule's exclusion)
+    _params_close_where_adam_is_well_conditioned(model, d, tag, 5e-3)
+    for s_ in (1, 2):                                   # steps 1 and 2 at the reference's own parameters of those steps
+        _load(model, d, f"{tag}_param{s_}_", cuda)
+        model.zero_grad(set_to_none=False)
+        loss = SF.cross_entropy(model(x), labels, ntrain)
+        loss.backward()
+        _close(loss, d[tag + "_losses"][s_], f"loss of step {s_}", 1e-5)
+        for k, p in model.named_parameters():
+            w, scale = d[f"{tag}_grad{s_}_{k}"], d[f"{tag}_grad{s_}_{k.replace('attn_r', 'attn_l')}"]
+            err = np.abs(p.grad.cpu().numpy() - w).max() / (np.abs(scale).max() + 1e-30)
+            assert err <= TOL, (k, s_, err)
