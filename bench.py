@@ -167,7 +167,7 @@ def torch_cpu_gcn_epochs(row_off, col, norm, x, labels, ntrain, widths, epochs, 
     """SURVEY.md 8(d) CPU variant (i): the reference model's epoch in plain torch on the host -- A_hat as a
     torch.sparse_csr_tensor (values norm[row] * norm[col]), each layer ``act(A_hat (h W) + b)``, cross-entropy on the
     first ``ntrain`` rows, backward, Adam(1e-2, wd 5e-4).  Returns (mean seconds per epoch, epochs timed, threads)."""
-    threads = threads or os.cpu_count() or 1
+    threads = threads or cpu_threads()
     torch.set_num_threads(threads)
     import warnings
     row_off, col = row_off.cpu().long(), col.cpu().long()
@@ -257,6 +257,21 @@ def cpu_baseline_epoch_gcn(meta, ntrain, labels, executed_per_step, budget_s=20.
             "host": host_description()}
 
 
+def progress(msg):
+    """One line on stderr per section: a long run must keep writing (the GPU box kills a command that is silent for minutes)."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_threads(cap=None):
+    """Threads for a CPU baseline: the logical CPUs this process may run on (affinity mask), optionally capped -- the temporal
+    baselines are thousands of SMALL ops, where more threads than ~32 only add fork/join cost."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(n, cap) if cap else n)
+
+
 def _cpu_sparse(row_off, col, values, n):
     import warnings
     with warnings.catch_warnings():
@@ -292,82 +307,82 @@ def _cpu_tgcn_cell(A, x, H, p):
     return Z * H + (1 - Z) * Ht
 
 
-def cpu_baseline_tgcn(g, ew, targets, n, e, T, feat, hidden, B, budget_s=15.0, max_windows=2):
+def _cpu_window_sample(run_window, B, budget_s):
+    """Time ``run_window(steps)`` (forward, loss, backward, Adam over ``steps`` snapshots) within ``budget_s``: a 2-snapshot
+    probe first, then ONE window of as many snapshots (<= B) as the budget allows.  Returns (seconds per snapshot, snapshots timed)."""
+    t0 = time.perf_counter()
+    run_window(2)
+    probe = (time.perf_counter() - t0) / 2
+    steps = int(max(2, min(B, budget_s / max(probe, 1e-6))))
+    t0 = time.perf_counter()
+    run_window(steps)
+    return (time.perf_counter() - t0) / steps, steps
+
+
+def cpu_baseline_tgcn(g, ew, targets, n, e, T, feat, hidden, B, budget_s=12.0):
     """cfg4's training loop (static-temporal-tgcn/seastar/train.py:160-187) in plain torch on the host: A_hat as ONE
-    torch.sparse_csr_tensor with values norm[row] * w[eid] * norm[col]; per window hidden = None, y_hat = randn, B
-    snapshots of cell + relu + two Linears + MSE, cost / (B + 1), backward through time, Adam.  Bounded sample:
-    ``max_windows`` windows (or ``budget_s``); epochs/s = 1 / (mean seconds per window x windows per epoch)."""
-    from stgraph_amd import temporal
-    threads = os.cpu_count() or 1
+    torch.sparse_csr_tensor with values norm[row] * w[eid] * norm[col]; per window hidden = None, y_hat = randn, the
+    snapshots of cell + relu + two Linears + MSE, cost / (B + 1), backward through time, Adam.  Bounded sample (see
+    ``_cpu_window_sample``); epochs/s = 1 / (seconds per snapshot x T)."""
+    threads = cpu_threads(32)
     torch.set_num_threads(threads)
     f = g.csr("fwd")
     nrm = g.get_ndata("norm").detach().cpu().reshape(-1)
     rows, col = _cpu_rows(f.row_offset, n), f.column_indices.cpu().long()
     w = ew.detach().cpu().reshape(-1)[f.eids.cpu().long()]
     A = _cpu_sparse(f.row_offset, f.column_indices, nrm[rows] * w * nrm[col], n)
-    tg = targets.detach().cpu().reshape(T, n, 1)
+    tg = targets.detach()[:B].cpu().reshape(B, n, 1)
     p, flat = _cpu_tgcn_params(feat, hidden, 1, seed=3)
     opt = torch.optim.Adam(flat, lr=1e-2)
-    dur, t_start = [], time.time()
-    for wdx in range(max_windows):
-        t0 = time.perf_counter()
+
+    def run_window(steps):
         opt.zero_grad()
         cost, H, y = 0, torch.zeros(n, hidden), torch.randn(n, feat)
-        for k in range(B):
+        for k in range(steps):
             H = _cpu_tgcn_cell(A, y, H, p)
             y = torch.relu(H) @ p["W1"].t() + p["b1"]
             y_out = y @ p["W2"].t() + p["b2"]
-            cost = cost + torch.mean((y_out - tg[wdx * B + k]) ** 2)
+            cost = cost + torch.mean((y_out - tg[k]) ** 2)
         cost = cost / (B + 1)
         cost.backward()
         opt.step()
-        dur.append(time.perf_counter() - t0)
-        if time.time() - t_start > budget_s:
-            break
-    sec_w = float(np.mean(dur))
-    windows = temporal.num_windows(T, B)
-    return {"value": 1.0 / (sec_w * windows), "unit": "epochs/s", "cores": threads, "kind": "port",
-            "seconds_per_window": sec_w, "seconds_per_snapshot": sec_w / B,
-            "sample": f"{len(dur)} of the epoch's {windows} BPTT windows ({B} snapshots each: forward, loss, backward through "
-                      f"time, Adam) of the same graph (|V|={n}, |E|={e}, edge weights) and model shape in plain torch on the "
-                      "host: torch.sparse_csr_tensor(A_hat) @ dense for the three gate convolutions of every snapshot; "
-                      "epochs/s extrapolated from the mean window (the reference has no CPU path of its own)",
+    sps, steps = _cpu_window_sample(run_window, B, budget_s)
+    return {"value": 1.0 / (sps * T), "unit": "epochs/s", "cores": threads, "kind": "port",
+            "seconds_per_snapshot": sps,
+            "sample": f"one BPTT window of {steps} snapshot(s) (of the epoch's {T}: forward, loss, backward through time, Adam) "
+                      f"on the same graph (|V|={n}, |E|={e}, edge weights) and model shape in plain torch on the host: "
+                      "torch.sparse_csr_tensor(A_hat) @ dense for the three gate convolutions of every snapshot; epochs/s = "
+                      "1 / (seconds per snapshot x T) (the reference has no CPU path of its own)",
             "host": host_description()}
 
 
-def cpu_baseline_dynamic(snaps, pn_edges, pn_targets, n, T, feat, hidden, B, budget_s=15.0, max_windows=2):
+def cpu_baseline_dynamic(snaps, pn_edges, pn_targets, n, T, feat, hidden, B, budget_s=12.0):
     """cfg5's loop (dynamic-temporal-tgcn/seastar/train.py:192-254) in plain torch on the host: one un-weighted A_hat per
     snapshot (built up front, outside the timed region, as the reference's NaiveGraph builds its CSRs at construction),
     TGCN cell, relu + Linear, dot-product decoder on the label edges, BCE-with-logits, cost / (B + 1), backward, Adam."""
-    from stgraph_amd import temporal
-    threads = os.cpu_count() or 1
+    threads = cpu_threads(32)
     torch.set_num_threads(threads)
-    windows = temporal.num_windows(T, B)
-    use = min(max_windows, windows)
-    As = {}
-    for t in range(min(use * B, T - 1)):
-        s, d = snaps[t][0].cpu().long(), snaps[t][1].cpu().long()
-        order = torch.argsort(d * n + s)
-        s, d = s[order], d[order]
-        deg = torch.bincount(d, minlength=n)
+    use = min(B, T - 1)
+    As = []
+    for t in range(use):
+        s_, d_ = snaps[t][0].cpu().long(), snaps[t][1].cpu().long()
+        order = torch.argsort(d_ * n + s_)
+        s_, d_ = s_[order], d_[order]
+        deg = torch.bincount(d_, minlength=n)
         ro = torch.zeros(n + 1, dtype=torch.long)
         ro[1:] = torch.cumsum(deg, 0)
         nrm = deg.float().pow(-0.5)
         nrm[torch.isinf(nrm)] = 0
-        As[t] = _cpu_sparse(ro, s, nrm[d] * nrm[s], n)
+        As.append(_cpu_sparse(ro, s_, nrm[d_] * nrm[s_], n))
     p, flat = _cpu_tgcn_params(feat, hidden, 0, seed=4)
     opt = torch.optim.Adam(flat, lr=1e-2)
-    edges = [x.cpu() for x in pn_edges[:use * B]]
-    tgts = [x.cpu() for x in pn_targets[:use * B]]
-    dur, t_start = [], time.time()
-    for wdx in range(use):
-        t0 = time.perf_counter()
+    edges = [x.cpu() for x in pn_edges[:use]]
+    tgts = [x.cpu() for x in pn_targets[:use]]
+
+    def run_window(steps):
         opt.zero_grad()
         cost, H, y = 0, torch.zeros(n, hidden), torch.randn(n, feat)
-        for k in range(B):
-            t = wdx * B + k
-            if t >= T - 1:
-                break
+        for t in range(min(steps, use)):
             H = _cpu_tgcn_cell(As[t], y, H, p)
             y = torch.relu(H) @ p["W1"].t() + p["b1"]
             logits = (y[edges[t][0]] * y[edges[t][1]]).sum(-1)
@@ -375,25 +390,21 @@ def cpu_baseline_dynamic(snaps, pn_edges, pn_targets, n, T, feat, hidden, B, bud
         cost = cost / (B + 1)
         cost.backward()
         opt.step()
-        dur.append(time.perf_counter() - t0)
-        if time.time() - t_start > budget_s:
-            break
-    sec_w = float(np.mean(dur))
-    return {"value": 1.0 / (sec_w * windows), "unit": "epochs/s", "cores": threads, "kind": "port",
-            "seconds_per_window": sec_w,
-            "sample": f"{len(dur)} of the epoch's {windows} BPTT windows of the T = {T} stream (|V|={n}, {B} snapshots each, "
-                      "one un-weighted A_hat per snapshot built outside the timed region) in plain torch on the host: "
-                      "sparse_csr @ dense TGCN cell, link head (dot-product decoder + BCE-with-logits), backward, Adam; "
-                      "epochs/s extrapolated from the mean window",
+    sps, steps = _cpu_window_sample(run_window, use, budget_s)
+    return {"value": 1.0 / (sps * (T - 1)), "unit": "epochs/s", "cores": threads, "kind": "port",
+            "seconds_per_snapshot": sps,
+            "sample": f"one BPTT window of {steps} snapshot(s) of the T = {T} stream (|V|={n}; one un-weighted A_hat per snapshot, "
+                      "built outside the timed region) in plain torch on the host: sparse_csr @ dense TGCN cell, link head "
+                      "(dot-product decoder + BCE-with-logits), backward, Adam; epochs/s = 1 / (seconds per snapshot x (T - 1))",
             "host": host_description()}
 
 
-def cpu_baseline_gat(g, feats, labels, ntrain, n, e, fin, H, D, classes, budget_s=20.0, max_epochs=2):
+def cpu_baseline_gat(g, feats, labels, ntrain, n, e, fin, H, D, classes, budget_s=15.0, max_epochs=2):
     """cfg3's model epoch (benchmarking/gat/seastar/model.py:4-42, train.py) in plain torch on the host.  The vertex
     function's `emb - max([emb])` is +0, so each layer is fc -> uniform mean over the in-neighbours
     (one sparse_csr @ dense with values 1 / in-degree) with el / er still formed; ELU between the layers, mean over the
     output heads, cross-entropy on the first 60 %, Adam(5e-3, wd 5e-4)."""
-    threads = os.cpu_count() or 1
+    threads = cpu_threads()
     torch.set_num_threads(threads)
     f = g.csr("fwd")
     rows = _cpu_rows(f.row_offset, n)
@@ -711,6 +722,8 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
         torch.cuda.empty_cache()
     sec = modes["hip_graph"]["ms_per_epoch"] * 1e-3
     ef_epoch = 2 * e * (H * D + classes)                        # K1 + K2 of both layers
+    if cpu_baseline:
+        progress("cfg3: CPU baseline")
     cpu = cpu_baseline_gat(g, feats, labels, ntrain, n, e, fin, H, D, classes) if cpu_baseline else None
     return {"cpu_baseline": cpu,
             "workload": f"GAT |V|={n} |E|={e} in={fin} heads={H} D={D} negative_slope=0.2 (BASELINE configs[2]); "
@@ -888,6 +901,8 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
                 "bytes_per_snapshot": ref_bytes,
                 "equivalent_GBps": ref_bytes / sec_per_snapshot / 1e9,
                 "equivalent_frac_of_hbm_peak": ref_bytes / sec_per_snapshot / 1e9 / HBM_PEAK_GBS}}
+    if cpu_baseline:
+        progress("cfg4: CPU baseline")
     cpu = cpu_baseline_tgcn(g, ew, targets, n, e, T, feat, hidden, B) if cpu_baseline else None
     idle_us = max(0.0, wall_ev - dev_busy_s) / max(steps_epoch, 1) * 1e6
     per_rank = [{"rank": rank, "windows_run_per_epoch": len(cw.my_windows), "targets_resident_windows": int(cw.targets_w.shape[0]),
@@ -964,8 +979,11 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
             pn_targets.append(torch.cat([torch.ones(m, device=device), torch.zeros(m, device=device)]))
         out = {}
         if cpu:
+            progress(f"cfg5 T={T}: CPU baseline")
             out["cpu_baseline"] = cpu_baseline_dynamic(snaps, pn_edges, pn_targets, n, T, feat, hidden, B)
         for mode in modes:
+            if rank == 0:
+                progress(f"cfg5 T={T}: {mode}")
             if mode == "resident_snapshots":         # NaiveGraph as the reference defines it: all 2T CSRs built up front
                 G = NaiveGraph(snaps, n, device=device, sort_inplace=False)
             elif mode == "rebuild_per_snapshot":
@@ -1171,6 +1189,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        progress("cfg2: building the graph and the model")
     step, meta = gcn_setup(device, seed=1 + rank, n=args.nodes, e=args.edges, feat=args.feat)
     for _ in range(args.warmup):
         step()
@@ -1273,12 +1293,14 @@ def main():
     cpu = None
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if want_cpu:
+        progress("cfg2: CPU baseline (torch epoch, then the OpenMP aggregation)")
         cpu = cpu_baseline_epoch_gcn(meta, int(0.6 * meta["n"]), meta["labels"], executed)
         cpu["aggregation_kernel_openmp"] = cpu_baseline_gcn(meta, budget_s=8.0)
     line["cpu_baseline"] = cpu
     del step, meta
     torch.cuda.empty_cache()
     if rank == 0 and not args.no_cora:
+        progress("cfg1: Cora-shaped GCN")
         line["cora"] = cora_run(device, cpu_baseline=want_cpu)
         x1024 = line["cora"]["roofline_x1024"]
         line["roofline"]["north_star"] = {
@@ -1287,16 +1309,22 @@ def main():
             "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": x1024["achieved"], "frac": x1024["frac"],
             "frac_F16": x1024["F16"]["frac_of_hbm_peak"], "frac_F7": x1024["F7"]["frac_of_hbm_peak"]}
     if rank == 0 and not args.no_gat:
+        progress("cfg3: GAT")
         line["gat"] = gat_run(device, cpu_baseline=want_cpu)
         torch.cuda.empty_cache()
     if not args.no_tgcn:
+        if rank == 0:
+            progress("cfg4: static-temporal TGCN")
         line["tgcn"] = tgcn_run(device, rank, world, epochs=args.tgcn_epochs, warmup_epochs=3, n=50_000, e=500_000,
                                 T=args.tgcn_timestamps, feat=32, hidden=64, B=25, allreduce_in_graph=args.allreduce_in_graph,
                                 cpu_baseline=want_cpu, share_device=args.share_device)
     if not args.no_dynamic:
+        if rank == 0:
+            progress("cfg5: dynamic-temporal TGCN")
         line["dynamic"] = dynamic_run(device, rank, world, epochs=args.dynamic_epochs, cpu_baseline=want_cpu)
     if rank == 0 and world == 1 and not args.no_live_pmc and line["roofline"].get("traffic") is not None:
         torch.cuda.empty_cache()
+        progress("cfg2: rocprofv3 --pmc child passes (HBM traffic of gcn_agg)")
         live = live_pmc_traffic()
         if live is not None:
             line["roofline"]["traffic_committed_passes"] = line["roofline"]["traffic"]

@@ -27,8 +27,9 @@ extern "C" {
 /* Bumped whenever an exported signature or contract changes (stgraph_amd/_C.py checks it at load):
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
- *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added. */
-#define STG_ABI_VERSION 21
+ *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added.
+ *  22: stg_tgcn_step_*_args gain `w_image` (last field); stg_tgcn_pack_weights_x3, stg_tgcn_step_image_bytes; knob "step_impl". */
+#define STG_ABI_VERSION 22
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -49,7 +50,9 @@ const char *stg_last_error_string(void);
  * "gcn_tile_rows" (its rows per workgroup: 0 = one per lane group, else 8 .. 256), "gcn_tile_pipe" (its
  * persistent, software-pipelined form: 0 / 1 = off, 2 = whenever the tile kernel runs; measured equal),
  * "xw_waves" (0 = auto; 4 / 8 waves per workgroup of stg_gcn_agg_transform), "cell_rows" (0 = auto; 16 / 32 rows
- * per tile of stg_tgcn_cell_fused_fwd), "step_waves" (stg_tgcn_step_*: 0 = auto, 12 / 16 waves per workgroup), "step_spread"
+ * per tile of stg_tgcn_cell_fused_fwd), "step_waves" (stg_tgcn_step_*: 0 = auto, 12 / 16 waves per workgroup), "step_impl" (stg_tgcn_step_* given a
+ * weight image: 0 = the matrix-core form, 1 = always the fp32 form; the one knob that selects between two ARITHMETICS -- both
+ * within 1e-5 of fp64), "step_spread"
  * (0 = one workgroup per CU when there are fewer tiles than wave slots, 1 = packed grid), "gemm_wide" (tall-skinny weight
  * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_cyclic" (its row-group hand-out: 0 .. 2),
  * "gcn_wide_long" (rows of >= 1024 edges at F >= 128: 0 = feature-sliced workgroups beside the main launch, 1 = never, 2 = behind
@@ -638,6 +641,11 @@ typedef struct stg_tgcn_step_fwd_args {
     int64_t N;
     int32_t C, Fin, Fh, head;
     float lo, hi;
+    /* Optional (NULL: not used).  The forward weight image of stg_tgcn_pack_weights_x3: with it, x != NULL, node_ids == NULL and
+     * head >= 1 the launch takes the MATRIX-CORE form (csrc/tgcn_stepx_fwd.hip: every product as a 3-term bf16 split with fp32
+     * accumulation -- fp32-class results, 1e-5 of the fp32 form; P bit-identical) unless the knob "step_impl" is 1.  clamp_mask is
+     * then written in that form's layout (one byte per row piece) and must be consumed by a backward launch given the backward image. */
+    const void *w_image;
 } stg_tgcn_step_fwd_args;
 typedef struct stg_tgcn_step_bwd_args {
     const int32_t *row_offsets, *column_indices, *node_ids;
@@ -657,6 +665,9 @@ typedef struct stg_tgcn_step_bwd_args {
     const int32_t *link_row_ptr, *link_other, *link_eid;
     const float *link_y, *link_logits, *link_target;
     float link_inv_m;
+    /* Optional (NULL: not used): the backward weight image of stg_tgcn_pack_weights_x3 -- the matrix-core form of the backward
+     * launch (csrc/tgcn_stepx_bwd.hip), for a clamp_mask written by the matrix-core forward launch. */
+    const void *w_image;
 } stg_tgcn_step_bwd_args;
 int    stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh);
 size_t stg_tgcn_step_loss_partials(int64_t N);
@@ -669,6 +680,15 @@ int    stg_tgcn_pack_weights(const float *Wcz, const float *Wcr, const float *Wc
                              float *WcatT, float *b3, float *WzT, float *WrT, float *WhT, float *W1T, int32_t C, int32_t Fin,
                              int32_t Fh, void *stream);
 int    stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *args, void *stream);
+/* The weights of a window as bf16 fragment images for the matrix-core form of the two step launches (one launch per window):
+ * every weight as three bf16 terms (w = h + m + l to 2^-25 |w|), laid out as the MFMA A operands of the wave that owns them
+ * (csrc/tgcn_stepx.hpp), followed by the fp32 biases.  fwd_image / bwd_image: stg_tgcn_step_image_bytes(0 / 1) bytes, 16-byte
+ * aligned.  W2 / b2 may be NULL (dynamic-temporal model: no second Linear).  C = 64, Fin = Fh = 32. */
+size_t stg_tgcn_step_image_bytes(int32_t backward);
+int    stg_tgcn_pack_weights_x3(const float *Wcz, const float *Wcr, const float *Wch, const float *bcz, const float *bcr,
+                                const float *bch, const float *Wz, const float *bz, const float *Wr, const float *br,
+                                const float *Wh, const float *bh, const float *W1, const float *b1, const float *W2,
+                                const float *b2, void *fwd_image, void *bwd_image, int32_t C, int32_t Fin, int32_t Fh, void *stream);
 /* cost[0] = sum over the window's `steps` steps, in order, of (sum of that step's partials) / N; step_loss [steps]
  * (required: the terms, and the scratch of the final sum).  partials: `steps` rows of step_stride floats. */
 int    stg_tgcn_window_loss(const float *partials, int32_t steps, int64_t N, int64_t step_stride, float *step_loss,

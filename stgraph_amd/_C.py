@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = (
     "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_score_flag", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
     "stg_gat_fc_supported", "stg_gat_fc_fwd", "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32", "stg_gemm_tn_relu_mask_f32",
-    "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
+    "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_tgcn_pack_weights_x3", "stg_tgcn_step_image_bytes", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
@@ -80,7 +80,7 @@ class TgcnStepFwdArgs(ctypes.Structure):
     _fields_ = (_ptr_fields("row_offsets column_indices node_ids norm_col_edge ew_edge norm x a3 H target "
                             "WcatT b3 Wz bz Wr br Wh bh W1 b1 W2 b2 P x3 Z R Ht Hn HR y y_out loss_partial clamp_mask") +
                 [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
-                 ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)])
+                 ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("w_image", ctypes.c_void_p)])
 
 
 class TgcnStepBwdArgs(ctypes.Structure):
@@ -89,7 +89,8 @@ class TgcnStepBwdArgs(ctypes.Structure):
                             "Z R Ht H Hn x3 y_out target WzT WrT WhT Wcat W1T W2 dzl drl dhl da3 dH z dyt dyo clamp_mask") +
                 [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
                  ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)] +
-                _ptr_fields("link_row_ptr link_other link_eid link_y link_logits link_target") + [("link_inv_m", ctypes.c_float)])
+                _ptr_fields("link_row_ptr link_other link_eid link_y link_logits link_target") + [("link_inv_m", ctypes.c_float),
+                                                                                                    ("w_image", ctypes.c_void_p)])
 
 
 class StgError(RuntimeError):
@@ -294,6 +295,10 @@ def _load() -> ctypes.CDLL:
     lib.stg_link_decode_fwd_multi.argtypes = [i32, vp, vp, vp, vp, vp, i64, i32, vp]
     lib.stg_tgcn_pack_weights.restype = ctypes.c_int
     lib.stg_tgcn_pack_weights.argtypes = [vp] * 17 + [i32, i32, i32, vp]
+    lib.stg_tgcn_pack_weights_x3.restype = ctypes.c_int
+    lib.stg_tgcn_pack_weights_x3.argtypes = [vp] * 18 + [i32, i32, i32, vp]
+    lib.stg_tgcn_step_image_bytes.restype = ctypes.c_size_t
+    lib.stg_tgcn_step_image_bytes.argtypes = [i32]
     lib.stg_tgcn_step_supported.restype = ctypes.c_int
     lib.stg_tgcn_step_supported.argtypes = [i32, i32, i32]
     lib.stg_tgcn_step_loss_partials.restype = ctypes.c_size_t

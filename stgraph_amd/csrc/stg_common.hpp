@@ -35,6 +35,7 @@ struct Tuning {
     int gcn_xcd_tile = 0;          // 0 = auto; 1 = workgroups round-robin over XCDs; T = runs of T workgroups per XCD
     int step_waves = 0;            // one-launch TGCN step: 0 = auto, 12 / 16 waves per workgroup (168 / 128 registers)
     int gcn_wide_long = 0;         // hubs of rows >= 64 lanes wide: 0 = feature-sliced workgroups (F % 4 == 0, F <= 256), 1 = never
+    int step_impl = 0;             // one-launch TGCN step given a weight image: 0 = matrix-core (3-term bf16 split) form, 1 = fp32 form
     int step_spread = 0;           // one-launch TGCN step with fewer tiles than wave slots: 0 = one workgroup per CU, 1 = packed grid
     int store_rows = 0;            // stg_edgeset_step_device with row-offset hints: 0 = new row offsets derived from them inside the merge launch, 1 = searched in their own launch
     int build_lds_count = 0;       // per-snapshot CSR build: 0 = auto (histograms in LDS when |V| fits and the graph is dense enough), 1 = always when |V| fits, 2 = never

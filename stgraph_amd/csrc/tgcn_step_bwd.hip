@@ -363,6 +363,8 @@ extern "C" int stg_debug_set_step_trace_bwd(void *buf)
 }
 #endif
 
+int stg_tgcn_stepx_bwd_launch(const stg_tgcn_step_bwd_args *p, void *stream_);      // tgcn_stepx_bwd.hip
+
 extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
 {
     using namespace stg;
@@ -382,6 +384,13 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     if (p->head >= 1 && (!p->W1T || !p->Hn || !p->dyt)) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL head pointer");
     if (p->head == 2 && (!p->W2 || !p->y_out || !p->target || !p->g_cost || !p->dyo))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL loss pointer");
+    if (p->link_row_ptr && (p->head != 1 || !p->link_other || !p->link_eid || !p->link_y || !p->link_logits || !p->link_target || !p->g_cost ||
+                            !(p->link_inv_m > 0.f)))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: the link-loss arguments need head == 1, g_cost and every link_* field");
+    if (p->w_image && !p->node_ids && p->head >= 1 && p->clamp_mask && tuning().step_impl == 0) {
+        if (reinterpret_cast<uintptr_t>(p->w_image) & 15) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: w_image must be 16-byte aligned");
+        return stg_tgcn_stepx_bwd_launch(p, stream_);
+    }
     BwdArgs a{};
     a.row_offsets = p->row_offsets; a.column_indices = p->column_indices; a.node_ids = p->node_ids;
     a.nc_edge = p->norm_col_edge; a.ew_edge = p->ew_edge; a.norm = p->norm;

@@ -352,6 +352,8 @@ extern "C" int stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh)
 
 extern "C" size_t stg_tgcn_step_loss_partials(int64_t N) { return N > 0 ? (size_t)((N + 15) / 16) : 0; }
 
+int stg_tgcn_stepx_fwd_launch(const stg_tgcn_step_fwd_args *p, void *stream_);      // tgcn_stepx_fwd.hip
+
 extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
 {
     using namespace stg;
@@ -370,6 +372,10 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
     if (p->head == 2 && (!p->W2 || !p->b2 || !p->y_out || !p->target || !p->loss_partial))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL loss pointer");
     if ((int64_t)p->N * 3 * p->C >= ((int64_t)1 << 30)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_fwd: too many rows for 32-bit offsets");
+    if (p->w_image && gather && !p->node_ids && p->head >= 1 && tuning().step_impl == 0) {
+        if (reinterpret_cast<uintptr_t>(p->w_image) & 15) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: w_image must be 16-byte aligned");
+        return stg_tgcn_stepx_fwd_launch(p, stream_);
+    }
     FwdArgs a{};
     a.row_offsets = p->row_offsets; a.column_indices = p->column_indices; a.node_ids = p->node_ids;
     a.nc_edge = p->norm_col_edge; a.ew_edge = p->ew_edge; a.norm = p->norm;

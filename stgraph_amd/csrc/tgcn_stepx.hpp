@@ -98,11 +98,19 @@ __device__ __forceinline__ Split4 split4(const float4 &v)
 struct Frag3 {
     bf16x8 t[kXTerms];
 };
-__device__ __forceinline__ Frag3 frag_of(const Split4 &lo, const Split4 &hi)
+__device__ __forceinline__ Frag3 frag_of(const float4 &lo, const float4 &hi)
 {
     Frag3 f;
+    float a = lo.x, b = lo.y, c = lo.z, d = lo.w, e = hi.x, g = hi.y, h = hi.z, i = hi.w;
 #pragma unroll
-    for (int k = 0; k < kXTerms; ++k) f.t[k] = __builtin_bit_cast(bf16x8, make_uint4(lo.t[k].x, lo.t[k].y, hi.t[k].x, hi.t[k].y));
+    for (int k = 0; k < kXTerms; ++k) {
+        const unsigned p0 = pk_bf16(a, b), p1 = pk_bf16(c, d), p2 = pk_bf16(e, g), p3 = pk_bf16(h, i);
+        f.t[k] = __builtin_bit_cast(bf16x8, make_uint4(p0, p1, p2, p3));
+        if (k + 1 < kXTerms) {
+            a = a - bf16_lo(p0), b = b - bf16_hi(p0), c = c - bf16_lo(p1), d = d - bf16_hi(p1);
+            e = e - bf16_lo(p2), g = g - bf16_hi(p2), h = h - bf16_lo(p3), i = i - bf16_hi(p3);
+        }
+    }
     return f;
 }
 

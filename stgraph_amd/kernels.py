@@ -1464,6 +1464,17 @@ def gemm_tn_form_batch(calls):
 
 
 # ------------------------------------------------------------- one TGCN step per launch (csrc/tgcn_step.hip)
+# True (default): the window nodes of stgraph_amd.temporal hand the step launches bf16 fragment images of the weights
+# (tgcn_pack_weights_x3) and so take their matrix-core form (csrc/tgcn_stepx_*.hip: every product as a 3-term bf16 split with
+# fp32 accumulation, fp32-class results); False: the fp32-instruction form (csrc/tgcn_step_*.hip).
+STEP_MATRIX_CORE = True
+
+
+def set_step_matrix_core(enabled: bool) -> None:
+    global STEP_MATRIX_CORE
+    STEP_MATRIX_CORE = bool(enabled)
+
+
 def tgcn_step_supported(C: int, Fin: int, Fh: int) -> bool:
     return bool(_C.lib.stg_tgcn_step_supported(int(C), int(Fin), int(Fh)))
 
@@ -1482,6 +1493,11 @@ def _fill_step_args(args, what: str, dev: torch.device, tensors: dict) -> None:
         if name not in names:
             raise TypeError(f"{what}: unknown argument {name!r}")
         if t is None:
+            continue
+        if name == "w_image":
+            if not torch.is_tensor(t) or t.dtype != torch.uint8 or t.device != dev or not t.is_contiguous() or t.data_ptr() % 16:
+                raise TypeError(f"{what}: w_image must be the uint8 image of tgcn_pack_weights_x3 on {dev}")
+            setattr(args, name, t.data_ptr())
             continue
         want = torch.int32 if name in _STEP_INT_FIELDS or name == "clamp_mask" else torch.float32
         if not torch.is_tensor(t) or t.dtype != want or not t.is_cuda or t.device != dev or not t.is_contiguous():
@@ -1504,6 +1520,30 @@ def tgcn_pack_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1):
     with torch.cuda.device(dev):
         _C.check(_C.lib.stg_tgcn_pack_weights(*[_ptr(t) for t in src], *[_ptr(t) for t in out], C, Fin, Fh, _stream_ptr(dev)))
     return out
+
+
+def tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2=None, b2=None):
+    """``(forward image, backward image)``: the weights of a window as bf16 fragment images (every weight = three bf16 terms,
+    laid out as the MFMA operands of the wave that owns them) for the matrix-core form of tgcn_step_fwd / _bwd
+    (stg_tgcn_pack_weights_x3; csrc/tgcn_stepx.hpp).  One launch per window.  ``W2`` / ``b2``: the second head Linear of the
+    static-temporal model ([1, Fh] or [Fh], [1]); None for the dynamic-temporal model."""
+    src = [_f32(t, "weight") for t in (Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)]
+    dev = src[0].device
+    Fin, C = (int(v) for v in src[0].shape)
+    Fh = int(src[12].shape[0])
+    opt = [None if t is None else _f32(t, "weight").reshape(-1) for t in (W2, b2)]
+    if (any(t.device != dev for t in src) or any(tuple(t.shape) != (Fin, C) for t in src[:3]) or any(tuple(t.shape) != (C,) for t in src[3:6])
+            or any(tuple(src[i].shape) != (C, 2 * C) for i in (6, 8, 10)) or any(tuple(src[i].shape) != (C,) for i in (7, 9, 11))
+            or tuple(src[12].shape) != (Fh, C) or tuple(src[13].shape) != (Fh,)
+            or (opt[0] is not None and (opt[0].numel() != Fh or opt[1] is None or opt[1].numel() != 1))):
+        raise ValueError("tgcn_pack_weights_x3: conv weights [Fin, C], conv biases [C], gate weights [C, 2C] + biases [C], head [Fh, C] + [Fh], W2 [Fh], b2 [1]")
+    fwd = torch.empty(int(_C.lib.stg_tgcn_step_image_bytes(0)), dtype=torch.uint8, device=dev)
+    bwd = torch.empty(int(_C.lib.stg_tgcn_step_image_bytes(1)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _C.check(_C.lib.stg_tgcn_pack_weights_x3(*[_ptr(t) for t in src], _ptr(opt[0]) if opt[0] is not None else None,
+                                                 _ptr(opt[1]) if opt[1] is not None else None, _ptr(fwd), _ptr(bwd), C, Fin, Fh,
+                                                 _stream_ptr(dev)))
+    return fwd, bwd
 
 
 def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: float, device, **tensors) -> None:

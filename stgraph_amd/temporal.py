@@ -117,6 +117,9 @@ class _TGCNWindow(torch.autograd.Function):
         # Wcat [Fin, 3C], its transpose, b3 and the transposed gate / head weights of the backward pass: one launch
         Wcat, WcatT, b3, WzT, WrT, WhT, W1T = kernels.tgcn_pack_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1)
         ctx.packed_T = (WzT, WrT, WhT, W1T)
+        # the same weights as bf16 fragment images: with them the step launches take their matrix-core form (csrc/tgcn_stepx.hpp)
+        img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2, b2)
+                            if kernels.STEP_MATRIX_CORE else (None, None))
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         P, X3 = new(B, N, Fin), new(B, N, 3 * C)
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
@@ -141,7 +144,7 @@ class _TGCNWindow(torch.autograd.Function):
                                   x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1], target=targets[t],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
                                   W2=W2v, b2=b2_, P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t],
-                                  y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t])
+                                  y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t], w_image=img_f)
         step_loss = new(B)
         cost = kernels.tgcn_window_loss(partial, B, N, step_loss)
         ctx.save_for_backward(x0, targets, norm, normv, ew if ew is not None else norm.new_empty(0), Wcat, Wz_, Wr_, Wh_, W1_, W2v,
@@ -181,7 +184,7 @@ class _TGCNWindow(torch.autograd.Function):
                                   clamp_mask=mask[t],
                                   y_out=Yout[t], target=targets[t], WzT=WzT, WrT=WrT, WhT=WhT, Wcat=Wcat, W1T=W1T, W2=W2v,
                                   dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=da3[t], dH=dH[t & 1],
-                                  z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], dyo=dyo[t])
+                                  z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], dyo=dyo[t], w_image=ctx.img_b)
         dx0 = kernels.gcn_agg(zbuf[0], norm, norm, bwd, ew=ew, use_node_ids=ctx.use_nid) if want_dx0 else None
         # weight gradients: one split-K launch per parameter over the window's snapshots
         steps = range(B)
@@ -466,6 +469,8 @@ class _TGCNDynWindow(torch.autograd.Function):
         x0 = x0.contiguous()
         Wcat, WcatT, b3, WzT, WrT, WhT, W1T = kernels.tgcn_pack_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1)
         ctx.packed_T = (WzT, WrT, WhT, W1T)
+        img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)
+                            if kernels.STEP_MATRIX_CORE else (None, None))          # matrix-core form: see _TGCNWindow.forward
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         P, X3 = new(B, N, Fin), new(B, N, 3 * C)
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
@@ -487,7 +492,8 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   node_ids=None, norm_col_edge=st["nc_f"], ew_edge=None,        # vertex order: see _TGCNWindow
                                   norm=st["normv"], x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
-                                  P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t], clamp_mask=mask[t])
+                                  P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t], clamp_mask=mask[t],
+                                  w_image=img_f)
         # the decoder + loss of every snapshot behind the last step, in one launch: a snapshot's loss feeds nothing in the next one
         kernels.link_decode_fwd_window([Y[t] for t in range(B)], [st["edges"] for st in steps], [st["targets"] for st in steps],
                                        [logits[t] for t in range(B)], [partial[t] for t in range(B)])
@@ -530,7 +536,7 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   Z=Z[t], R=R[t], Ht=Ht[t],
                                   H=None if t == 0 else Hn[t - 1], Hn=Hn[t], clamp_mask=mask[t], WzT=WzT, WrT=WrT, WhT=WhT,
                                   Wcat=Wcat, W1T=W1T, dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=da3[t], dH=dH[t & 1],
-                                  z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], **kw)
+                                  z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], w_image=ctx.img_b, **kw)
         dx0 = None
         if want_dx0:
             s0 = steps[0]

@@ -23,6 +23,7 @@ from tests.util import golden
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+ADAM_EPS = 1e-8
 
 
 def _t(a, dev):
@@ -136,10 +137,11 @@ def test_static_training_loop_matches_the_reference_adam_run(cuda, mode, monkeyp
     (``Adam(capturable=True, fused=True)``: the update inside the second graph as one kernel), ``hip_graph_capturable_adam``
     the same without ``fused``.  The capturable forms evaluate the same update rule in another order (one step differs from
     the default Adam by 7e-8, measured on equal gradients), and Adam's lr * m / (sqrt(v) + eps) amplifies that where a
-    step's gradient is rounding noise: the gradients of this run peak at 6e-6 and reach down to 9e-10, eps is 1e-8.  So
-    the rule is explicit: an entry is EXCLUDED when its reference gradient (recorded per optimizer step in the fixture,
-    ``train_grad<k>_*``) is below 1e-6 of that tensor's largest entry at any of the four steps; every other entry is held to
-    2e-5 like the eager mode, and every entry, excluded or not, to four steps of lr.  Costs are checked strictly."""
+    step's gradient is comparable to eps = 1e-8: d(update) / dg = lr eps / (|g| + eps)^2, i.e. 1e6 at |g| << eps and 1e2 at
+    |g| = 100 eps -- and the gradients of this run (a mean loss over 4096 rows) peak at 6e-6 and reach down to 9e-10.  The
+    rule, stated on the reference's own per-step gradients (``train_grad<k>_*`` in the fixture): EVERY entry is held to the
+    north star's 1e-4; the entries whose reference gradient is at least 100 eps at all four steps (where Adam is
+    well-conditioned) are held to 2e-5 like the eager modes.  Costs are checked strictly in every mode."""
     from stgraph_amd import temporal
     d = golden("tgcn_native.npz")
     g, targets, ew, n, T = _static_setup(d, cuda, True)
@@ -165,19 +167,17 @@ def test_static_training_loop_matches_the_reference_adam_run(cuda, mode, monkeyp
         else:
             costs += temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, feat, epoch=epoch)
     _close(torch.stack([c.reshape(()) for c in costs]), d["train_costs"], "window costs", 1e-5)
+    report = {}
     for k, p in model.named_parameters():
         want = d["train_paramT_" + k]
         err = np.abs(p.detach().cpu().numpy() - want)
-        if capturable:
-            keep = np.ones(want.shape, dtype=bool)
-            for s_ in range(4):
-                gref = np.abs(d[f"train_grad{s_}_{k}"])
-                keep &= gref >= 1e-6 * float(gref.max())
-            assert keep.mean() > 0.9, (k, float(keep.mean()))             # the rule names a small minority
-            assert err[keep].max() <= 2e-5, (k, float(err[keep].max()), float(keep.mean()))
-            assert err.max() <= 4.5e-2, (k, float(err.max()))
-        else:
-            assert err.max() <= 2e-5, (k, float(err.max()))
+        keep = np.ones(want.shape, dtype=bool)
+        for s_ in range(4):
+            gref = np.abs(d[f"train_grad{s_}_{k}"])
+            keep &= gref >= 100 * ADAM_EPS
+        report[k] = (float(err.max()), float(err[keep].max()) if keep.any() else 0.0, float(keep.mean()))
+    bad = {k: v for k, v in report.items() if v[0] > (TOL if capturable else 2e-5) or (capturable and v[1] > 2e-5)}
+    assert not bad, (mode, bad, report)
 
 
 # ------------------------------------------------------------------------------------------ dynamic-temporal TGCN

@@ -86,9 +86,20 @@ def _alloc(cuda, n):
                 clamp_mask=torch.zeros(n, 12, dtype=torch.int32, device=cuda))
 
 
-def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, hi=HI):
+def _images(p):
+    """The bf16 fragment images of ``_params`` (matrix-core form of the step launches)."""
+    from stgraph_amd import kernels
+    Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
+    bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
+    return kernels.tgcn_pack_weights_x3(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"], p["W1"], p["b1"],
+                                        p["W2"], p["b2"])
+
+
+def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, hi=HI, x3form=False):
     from stgraph_amd import kernels
     out = _alloc(cuda, n)
+    if x3form:
+        out["w_image"] = _images(p)[0]
     nc = kernels._edge_gathered(g.fwd, "norm", norm, g.fwd.column_indices)
     ew_e = None if ew is None else kernels._edge_gathered(g.fwd, "ew", ew, g.fwd.eids)
     kernels.tgcn_step_fwd(n, C, FIN, FH, head, lo, hi, cuda, row_offsets=g.fwd.row_offset, column_indices=g.fwd.column_indices,
@@ -96,15 +107,18 @@ def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, h
                           x=x, H=H, target=target, WcatT=p["Wcat"].t().contiguous(), b3=p["b3"], Wz=p["Wz"], bz=p["bz"],
                           Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"], W1=p["W1"], b1=p["b1"],
                           W2=p["W2"].view(-1).contiguous(), b2=p["b2"], **out)
+    out.pop("w_image", None)
     return out
 
 
 def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True, head=2, node_ids=False, lo=LO, hi=HI,
-         use_mask=False):
+         use_mask=False, x3form=False):
     from stgraph_amd import kernels
     new = lambda *s: torch.full(s, float("nan"), device=cuda)  # noqa: E731
     out = dict(dzl=new(n, C), drl=new(n, C), dhl=new(n, C), da3=new(n, 3 * C), dH=new(n, C), dyt=new(n, FH), dyo=new(n),
                z=new(n, FIN) if want_z else None)
+    if x3form:                                   # the matrix-core form reads the mask its forward twin wrote
+        out["w_image"], use_mask = _images(p)[1], True
     nc = kernels._edge_gathered(g.bwd, "norm", norm, g.bwd.column_indices)
     ew_e = None if ew is None else kernels._edge_gathered(g.bwd, "ew", ew, g.bwd.eids)
     kernels.tgcn_step_bwd(n, C, FIN, FH, head, lo, hi, cuda, row_offsets=g.bwd.row_offset, column_indices=g.bwd.column_indices,
@@ -114,6 +128,7 @@ def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True
                           clamp_mask=saved["clamp_mask"] if use_mask else None, y_out=saved["y_out"], target=target,
                           WzT=p["Wz"].t().contiguous(), WrT=p["Wr"].t().contiguous(), WhT=p["Wh"].t().contiguous(),
                           Wcat=p["Wcat"], W1T=p["W1"].t().contiguous(), W2=p["W2"].view(-1).contiguous(), **out)
+    out.pop("w_image", None)
     return out
 
 
@@ -129,8 +144,13 @@ def _close(got, want, what, tol=2e-5):
                                                  # 7501 tiles on 3072 wave slots, one row in the last tile: every wave takes
                                                  # further tiles off the workgroup's counter
                                                  (120_001, 1_000_000, False, False)])
-def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids):
+@pytest.mark.parametrize("x3form", [False, True])
+def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3form):
+    """``x3form``: the matrix-core form of both launches (a weight image in the argument block; csrc/tgcn_stepx_*.hip) -- the SAME
+    fp64 reference and the SAME tolerances as the fp32 form."""
     from stgraph_amd import kernels
+    if x3form and node_ids:
+        pytest.skip("the matrix-core form visits rows in vertex order (as the window nodes do); node_ids takes the fp32 form")
     g, e = _graph(cuda, n, e, seed=n)
     gen = torch.Generator(device=cuda).manual_seed(n + 1)
     deg = (g.fwd.row_offset[1:] - g.fwd.row_offset[:-1]).float()
@@ -141,14 +161,14 @@ def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids):
     t0, t1 = torch.randn(n, device=cuda, generator=gen), torch.randn(n, device=cuda, generator=gen)
     g_cost = torch.tensor([0.37], device=cuda)
 
-    s0 = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, node_ids=node_ids)          # H = None: zeros
-    s1 = _fwd(cuda, g, norm, ew, p, s0["y"], s0["Hn"], t1, n, node_ids=node_ids)
+    s0 = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, node_ids=node_ids, x3form=x3form)          # H = None: zeros
+    s1 = _fwd(cuda, g, norm, ew, p, s0["y"], s0["Hn"], t1, n, node_ids=node_ids, x3form=x3form)
     # P is the aggregation kernel's own arithmetic, bit for bit
     assert torch.equal(s0["P"], kernels.gcn_agg(x0, norm, norm, g.fwd, ew=ew))
     assert torch.equal(s1["P"], kernels.gcn_agg(s0["y"], norm, norm, g.fwd, ew=ew))
 
-    b1 = _bwd(cuda, g, norm, ew, p, s1, s0["Hn"], t1, n, zn=None, dHn=None, g_cost=g_cost, node_ids=node_ids)
-    b0 = _bwd(cuda, g, norm, ew, p, s0, None, t0, n, zn=b1["z"], dHn=b1["dH"], g_cost=g_cost, node_ids=node_ids)
+    b1 = _bwd(cuda, g, norm, ew, p, s1, s0["Hn"], t1, n, zn=None, dHn=None, g_cost=g_cost, node_ids=node_ids, x3form=x3form)
+    b0 = _bwd(cuda, g, norm, ew, p, s0, None, t0, n, zn=b1["z"], dHn=b1["dH"], g_cost=g_cost, node_ids=node_ids, x3form=x3form)
 
     if n > 20_000:
         A = None                                   # dense A_hat would be 20 GB: aggregate with the (tested) kernel in fp32
@@ -211,7 +231,8 @@ def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids):
     _close((b0["dyo"].double() @ s0["y"].double() + b1["dyo"].double() @ s1["y"].double()).view(1, -1), pd["W2"].grad, "dW2", btol)
 
 
-def test_clamp_is_honoured(cuda):
+@pytest.mark.parametrize("x3form", [False, True])
+def test_clamp_is_honoured(cuda, x3form):
     """A clamp that bites ([-0.25, 0.4] instead of the layer's +-1e6): forward clamps, x3 is kept unclamped, backward
     blocks the gradient exactly where x3 is outside [lo, hi]."""
     n, lo, hi = 200, -0.25, 0.4
@@ -222,10 +243,10 @@ def test_clamp_is_honoured(cuda):
     x0 = torch.randn(n, FIN, device=cuda)
     t0 = torch.randn(n, device=cuda)
     H = torch.randn(n, C, device=cuda) * 0.3
-    s0 = _fwd(cuda, g, norm, None, p, x0, H, t0, n, lo=lo, hi=hi)
-    b0 = _bwd(cuda, g, norm, None, p, s0, H, t0, n, zn=None, dHn=None, g_cost=torch.ones(1, device=cuda), lo=lo, hi=hi)
+    s0 = _fwd(cuda, g, norm, None, p, x0, H, t0, n, lo=lo, hi=hi, x3form=x3form)
+    b0 = _bwd(cuda, g, norm, None, p, s0, H, t0, n, zn=None, dHn=None, g_cost=torch.ones(1, device=cuda), lo=lo, hi=hi, x3form=x3form)
     bm = _bwd(cuda, g, norm, None, p, s0, H, t0, n, zn=None, dHn=None, g_cost=torch.ones(1, device=cuda), lo=lo, hi=hi,
-              use_mask=True)                     # the mask the forward launch left instead of x3: same gradients, bit for bit
+              use_mask=True, x3form=x3form)      # the mask the forward launch left instead of x3: same gradients, bit for bit
     assert all(torch.equal(b0[k], bm[k]) for k in ("da3", "dH", "dzl", "drl", "dhl", "z"))
     blocked = (s0["x3"] > hi) | (s0["x3"] < lo)
     assert 0.2 < blocked.float().mean() < 0.9            # the clamp really is active, x3 itself is kept unclamped
@@ -259,8 +280,9 @@ def test_cell_only_mode_matches_the_gather_mode(cuda):
         _close(out[k], full[k], k, 1e-5)
 
 
+@pytest.mark.parametrize("x3form", [False, True])
 @pytest.mark.parametrize("n,e,m", [(3001, 30000, 5000), (17, 60, 40), (25_000, 250_000, 12_500)])
-def test_link_loss_backward_inside_the_step_launch(cuda, n, e, m):
+def test_link_loss_backward_inside_the_step_launch(cuda, n, e, m, x3form):
     """head == 1 with the link_* fields: the node side of the link-prediction loss's backward (stg_link_decode_bwd) taken inside
     the backward step launch -- every output bit for bit what the two launches produce (same terms, same order)."""
     from stgraph_amd import kernels
@@ -271,7 +293,8 @@ def test_link_loss_backward_inside_the_step_launch(cuda, n, e, m):
     p = _params(cuda, n + 5)
     x0 = torch.randn(n, FIN, device=cuda, generator=gen)
     H = torch.randn(n, C, device=cuda, generator=gen) * 0.3
-    s = _fwd(cuda, g, norm, None, p, x0, H, torch.zeros(n, device=cuda), n, head=1)
+    s = _fwd(cuda, g, norm, None, p, x0, H, torch.zeros(n, device=cuda), n, head=1, x3form=x3form)
+    img = _images(p)[1] if x3form else None
     edge_index = torch.randint(0, n, (2, m), device=cuda, generator=gen)
     target = (torch.rand(m, device=cuda, generator=gen) < 0.5).float()
     y = s["y"]
@@ -288,7 +311,7 @@ def test_link_loss_backward_inside_the_step_launch(cuda, n, e, m):
         kernels.tgcn_step_bwd(n, C, FIN, FH, 1, LO, HI, cuda, row_offsets=g.bwd.row_offset, column_indices=g.bwd.column_indices,
                               norm_col_edge=nc, norm=norm.view(-1), zn=zn, dHn=dHn, Z=s["Z"], R=s["R"], Ht=s["Ht"], H=H,
                               Hn=s["Hn"], clamp_mask=s["clamp_mask"], WzT=p["Wz"].t().contiguous(), WrT=p["Wr"].t().contiguous(),
-                              WhT=p["Wh"].t().contiguous(), Wcat=p["Wcat"], W1T=p["W1"].t().contiguous(), **out, **kw)
+                              WhT=p["Wh"].t().contiguous(), Wcat=p["Wcat"], W1T=p["W1"].t().contiguous(), w_image=img, **out, **kw)
         return out
     dy = torch.empty(n, FH, device=cuda)
     kernels.link_decode_bwd(g_cost, y, logits, target, inc, dy)
@@ -309,3 +332,97 @@ def test_pack_weights(cuda):
     assert torch.equal(Wcat, p["Wcat"]) and torch.equal(WcatT, p["Wcat"].t().contiguous()) and torch.equal(b3, p["b3"])
     for got, w in ((WzT, p["Wz"]), (WrT, p["Wr"]), (WhT, p["Wh"]), (W1T, p["W1"])):
         assert torch.equal(got, w.t().contiguous())
+
+
+def _bf16_terms_to_f64(words):
+    """[..., 3 terms, 8] uint16 bf16 bit patterns -> the fp64 sum of the three terms."""
+    u = words.astype(np.uint32) << 16
+    return u.view(np.float32).astype(np.float64).sum(-2)
+
+
+def test_pack_weights_x3_images(cuda):
+    """stg_tgcn_pack_weights_x3: every weight of the images is the sum of its three bf16 terms to 2^-24 relative, and sits where
+    csrc/tgcn_stepx.hpp says (lane (m16, kq), element i of K-block b <-> input column 32 b + 16 (i >> 2) + 4 kq + (i & 3))."""
+    p = _params(cuda, 11)
+    fwd, bwd = _images(p)
+    W = {k: v.cpu().numpy().astype(np.float64) for k, v in p.items()}
+    xcol = lambda b, kq, i: 32 * b + 16 * (i >> 2) + 4 * kq + (i & 3)  # noqa: E731
+    m16, kq, i8 = np.arange(64) % 16, np.arange(64) // 16, np.arange(8)
+    cols = lambda b: xcol(b, kq[:, None], i8[None, :])  # noqa: E731  [lane, 8]
+
+    def section(img, offset, nfrag):                      # -> [nfrag / 3, lane, 3 terms, 8] fp64 sums [.., lane, 8]
+        raw = img[offset:offset + nfrag * 1024].cpu().numpy().view(np.uint16).reshape(nfrag // 3, 3, 64, 8)
+        return _bf16_terms_to_f64(raw.transpose(0, 2, 1, 3))
+
+    def check(got, want, what):
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err <= 2.0 ** -23, (what, err)
+
+    gates = [W["Wz"], W["Wr"], W["Wh"]]
+    f_gate = section(fwd, 0, 4 * 36).reshape(4, 3, 4, 64, 8)
+    for ct in range(4):
+        for g in range(3):
+            for b in range(4):
+                check(f_gate[ct, g, b], gates[g][(16 * ct + m16)[:, None], cols(b)], f"fwd gate {ct} {g} {b}")
+    f_cat = section(fwd, 4 * 36 * 1024, 4 * 9).reshape(4, 3, 64, 8)
+    for ct in range(4):
+        for g in range(3):
+            check(f_cat[ct, g], W["Wcat"][cols(0), (g * C + 16 * ct + m16)[:, None]], f"fwd cat {ct} {g}")
+    f_head = section(fwd, (4 * 36 + 4 * 9) * 1024, 2 * 6).reshape(2, 2, 64, 8)
+    for ft in range(2):
+        for b in range(2):
+            check(f_head[ft, b], W["W1"][(16 * ft + m16)[:, None], cols(b)], f"fwd head {ft} {b}")
+    tail = fwd[(4 * 36 + 4 * 9 + 2 * 6) * 1024:].cpu().numpy().view(np.float32)
+    want = np.concatenate([p[k].cpu().numpy().reshape(-1) for k in ("b3", "bz", "br", "bh", "b1", "W2", "b2")])
+    assert np.array_equal(tail[:want.size], want)
+    b_gate = section(bwd, 0, 4 * 36).reshape(4, 3, 2, 2, 64, 8)
+    for ct in range(4):
+        for g in range(3):
+            for half in range(2):
+                for b in range(2):
+                    check(b_gate[ct, g, half, b], gates[g][cols(b), (half * C + 16 * ct + m16)[:, None]], f"bwd gate {ct} {g} {half} {b}")
+    b_head = section(bwd, 4 * 36 * 1024, 4 * 3).reshape(4, 64, 8)
+    for ct in range(4):
+        check(b_head[ct], W["W1"][cols(0), (16 * ct + m16)[:, None]], f"bwd head {ct}")
+    b_cat = section(bwd, (4 * 36 + 4 * 3) * 1024, 2 * 18).reshape(2, 6, 64, 8)
+    for ft in range(2):
+        for b in range(6):
+            check(b_cat[ft, b], W["Wcat"][(16 * ft + m16)[:, None], cols(b)], f"bwd cat {ft} {b}")
+
+
+@pytest.mark.parametrize("n,e,use_ew,head", [(300, 2400, True, 2), (3001, 30000, False, 2), (17, 60, True, 2), (1, 1, False, 2),
+                                              (50_000, 500_000, True, 2), (25_000, 250_000, False, 1), (120_001, 1_000_000, False, 2)])
+def test_matrix_core_forward_matches_the_fp32_form(cuda, n, e, use_ew, head):
+    """stg_tgcn_step_fwd given a weight image (csrc/tgcn_stepx_fwd.hip: 3-term bf16 split on the matrix cores) against the fp32
+    form of the same launch on the same inputs: P bit for bit (same gather arithmetic), every other output to 1e-5 of its largest
+    entry -- fp32-class: the fp32 form itself stands 2e-5 from fp64 (test_two_chained_steps_match_fp64_autograd) --, two
+    chained steps so that H != 0 is exercised."""
+    from stgraph_amd import _C
+    g, e = _graph(cuda, n, e, seed=n + 7) if n > 1 else _graph(cuda, 2, 1, seed=1)
+    n = max(n, 2)
+    gen = torch.Generator(device=cuda).manual_seed(n + 1)
+    deg = (g.fwd.row_offset[1:] - g.fwd.row_offset[:-1]).float()
+    norm = torch.where(deg > 0, deg.clamp(min=1) ** -0.5, torch.zeros_like(deg)).view(-1, 1)
+    ew = (torch.rand(e, 1, device=cuda, generator=gen) + 0.5) if use_ew else None
+    p = _params(cuda, n + 2)
+    x0 = torch.randn(n, FIN, device=cuda, generator=gen)
+    t0, t1 = torch.randn(n, device=cuda, generator=gen), torch.randn(n, device=cuda, generator=gen)
+    res = []
+    for x3form in (False, True):
+        s0 = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, head=head, x3form=x3form)
+        s1 = _fwd(cuda, g, norm, ew, p, s0["y"], s0["Hn"], t1, n, head=head, x3form=x3form)
+        res.append((s0, s1))
+    keys = ["x3", "Z", "R", "Ht", "Hn", "HR", "y"] + (["y_out", "loss_partial"] if head == 2 else [])
+    for k_step in range(2):
+        a, b = res[0][k_step], res[1][k_step]
+        if k_step == 0:
+            assert torch.equal(a["P"], b["P"])
+        for k in keys:
+            _close(b[k], a[k], f"step {k_step} {k}", 1e-5)
+    # the knob forces the fp32 form even with an image: bit-identical to the launch without one
+    _C.set_tuning("step_impl", 1)
+    try:
+        s0 = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, head=head, x3form=True)
+    finally:
+        _C.set_tuning("step_impl", 0)
+    assert all(torch.equal(s0[k], res[0][0][k]) for k in keys + ["P"])
