@@ -153,47 +153,119 @@ __device__ __forceinline__ Frag3 wfrag_load(const char *sec, int first_frag, int
 
 // ---- gather: four rows per wave, sixteen lanes x two floats per row -----------------------------------------------------------
 // P[r, :] = norm[r] * sum_e (nc[e] * x[col[e], :]) * w[e] in CSR order: the arithmetic (and order) of gcn_agg_kernel, bit-identical P.
-// lane = (rl = lane >> 4: row 4 slot + rl of the tile, c2 = lane & 15: columns 2 c2, 2 c2 + 1).  The 16 lanes of a row load the same
-// index / scalar words (one transaction) instead of broadcasting them.
+// lane = (rl = lane >> 4: row 4 ct + rl of the tile, c2 = lane & 15: columns 2 c2, 2 c2 + 1).
+//
+// A gather is three dependent memory round trips (row extent -> edge records -> neighbour rows).  The step kernels spread the
+// NEXT tile's gather over the phases of the current one, each round trip issued a phase ahead of its use:
+//   extent()  : the row's extent and norm                                      -> 3 registers
+//   indices() : (col, nc, w) of the row's first 32 edges, two edges per lane   -> 6 registers
+//   stash()   : those records into the wave's own rows of an LDS table [16 rows][32 edges] x 16 bytes
+//   run()     : the neighbour rows; edge records come from the table (all 16 lanes of a row read one address: a broadcast),
+//               beyond 32 edges from global memory.
+// No load sits behind a per-lane guard (a guarded load is a branch and a wait of its own -- the first version of this gather had
+// 24 serialised round trips per batch): lanes past the end of their row re-read its last edge and drop the term (|E| >= 1).
+#ifndef STGX_GATHER_U
+#define STGX_GATHER_U 4                                  // neighbour rows in flight per lane: 4 keeps the step kernels free of spills
+#endif
+constexpr int kGatherTableEdges = 32;
+constexpr int kGatherTableBytes = 16 * kGatherTableEdges * 16;         // per team
+
 template <bool HAS_EW>
-__device__ __forceinline__ float2 gather_row2(const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
-                                              const float *__restrict__ nc_edge, const float *__restrict__ ew_edge,
-                                              const float *__restrict__ norm, const float *__restrict__ x, int row, int c2)
-{
-    constexpr int U = 8;
-    const int beg = row_offsets[row], deg = row_offsets[row + 1] - beg;
-    const float nr = norm[row];
-    const int max_deg = wave_max_nonneg(deg);
-    float a0 = 0.f, a1 = 0.f;
-    for (int base = 0; base < max_deg; base += U) {
-        int c[U];
-        float nc[U], w[U];
+struct RowGatherX {
+    int beg, end;
+    float nr;
+    int c0, c1;
+    float n0, n1, w0, w1;
+
+    __device__ __forceinline__ void extent(const int *__restrict__ row_offsets, const float *__restrict__ norm, int row)
+    {
+        beg = row_offsets[row];
+        end = row_offsets[row + 1];
+        nr = norm[row];
+    }
+    __device__ __forceinline__ void indices(const int *__restrict__ column_indices, const float *__restrict__ nc_edge,
+                                            const float *__restrict__ ew_edge, int c2)
+    {
+        const int last = max(end - 1, 0);
+        const int e0 = min(beg + c2, last), e1 = min(beg + 16 + c2, last);
+        c0 = column_indices[e0], c1 = column_indices[e1];
+        n0 = nc_edge[e0], n1 = nc_edge[e1];
+        w0 = w1 = 1.f;
+        if constexpr (HAS_EW) w0 = ew_edge[e0], w1 = ew_edge[e1];
+    }
+    // `table_row`: the 32 records of THIS lane's row (the 16 lanes of a row share it)
+    __device__ __forceinline__ void stash(uint4 *table_row, int c2) const
+    {
+        table_row[c2] = make_uint4((unsigned)c0, __float_as_uint(n0), __float_as_uint(w0), 0u);
+        table_row[16 + c2] = make_uint4((unsigned)c1, __float_as_uint(n1), __float_as_uint(w1), 0u);
+    }
+    __device__ __forceinline__ float2 run(const uint4 *table_row, const float *__restrict__ x, const int *__restrict__ column_indices,
+                                          const float *__restrict__ nc_edge, const float *__restrict__ ew_edge, int c2) const
+    {
+        constexpr int U = STGX_GATHER_U;
+        const int deg = end - beg, last = max(end - 1, 0);
+        const int max_deg = wave_max_nonneg(deg);
+        float a0 = 0.f, a1 = 0.f;
+        for (int base = 0; base < max_deg; base += U) {
+            int c[U];
+            float nc[U], w[U];
+            if (base < kGatherTableEdges) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool ok = base + u < deg;
-            const int e = beg + (ok ? base + u : 0);
-            c[u] = ok ? column_indices[e] : 0;
-            nc[u] = ok ? nc_edge[e] : 0.f;
-            w[u] = 1.f;
-            if constexpr (HAS_EW) w[u] = ok ? ew_edge[e] : 0.f;
-        }
-        float2 v[U];
+                for (int u = 0; u < U; ++u) {
+                    const uint4 t = table_row[base + u];
+                    c[u] = (int)t.x, nc[u] = __uint_as_float(t.y), w[u] = __uint_as_float(t.z);
+                }
+            } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned off = (unsigned)c[u] * (kXFin * 4u) + 8u * c2;
-            v[u] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(x) + (size_t)off);
-        }
+                for (int u = 0; u < U; ++u) {
+                    const int e = min(beg + base + u, last);
+                    c[u] = column_indices[e];
+                    nc[u] = nc_edge[e];
+                    w[u] = 1.f;
+                    if constexpr (HAS_EW) w[u] = ew_edge[e];
+                }
+            }
+            float2 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (base + u < deg) {
+            for (int u = 0; u < U; ++u) {
+                const unsigned off = (unsigned)c[u] * (kXFin * 4u) + 8u * c2;
+                v[u] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(x) + (size_t)off);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = base + u < deg;
                 float t0 = nc[u] * v[u].x, t1 = nc[u] * v[u].y;
                 if constexpr (HAS_EW) t0 = t0 * w[u], t1 = t1 * w[u];
-                a0 = a0 + t0;
-                a1 = a1 + t1;
+                a0 = ok ? a0 + t0 : a0;
+                a1 = ok ? a1 + t1 : a1;
             }
         }
+        return make_float2(a0 * nr, a1 * nr);
     }
-    return make_float2(a0 * nr, a1 * nr);
+};
+
+// Interval timestamps of every wave (tools/diag/stepx_trace.py builds a second library with -DSTG_STEPX_TRACE; the product build
+// has none of this): slot [global wave][2 it] = the 100 MHz wall clock when the wave enters interval `it`, [2 it + 1] when it
+// reaches the interval's barrier.
+#ifdef STG_STEPX_TRACE
+#define STGX_TRACE_SLOTS 128
+__device__ unsigned long long *g_stepx_trace = nullptr;
+#define STGX_MARK(k)                                                                                                        \
+    do {                                                                                                                   \
+        if (g_stepx_trace && (threadIdx.x & 63) == 0 && (k) < STGX_TRACE_SLOTS)                                             \
+            g_stepx_trace[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * STGX_TRACE_SLOTS + (k)] =          \
+                (unsigned long long)wall_clock64();                                                                        \
+    } while (0)
+#else
+#define STGX_MARK(k) ((void)0)
+#endif
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global store of the wave (its fence
+// drains vmcnt): the step kernels store ~15 row pieces per tile that nothing in the launch reads back, and eight waves waiting
+// for those acknowledgements at every phase boundary is most of a phase.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 }  // namespace

@@ -32,7 +32,7 @@ struct BwdXArgs {
 
 constexpr int kBPLd = 36;
 constexpr int kBActImg = 2 * kXTerms * kFragBytes;                      // a 64-column operand as fragments
-constexpr int kBTeamBytes = 16 * kBPLd * 4 + 3 * kBActImg + 3 * kBActImg;   // Gbuf | dhl dzl drl | da3 (z, r, h thirds)
+constexpr int kBTeamBytes = 16 * kBPLd * 4 + 3 * kBActImg + 3 * kBActImg + kGatherTableBytes;   // Gbuf | dhl dzl drl | da3 (z, r, h thirds) | edge records
 constexpr int kBwdLdsHead = 0;                                          // W1^T fragments [ct][t]
 constexpr int kBwdLdsCat = kBwdLdsHead + 4 * kBwdHeadFrags * kFragBytes;    // Wcat fragments [ct'][b][t]
 constexpr int kBwdLdsBias = kBwdLdsCat + 2 * kBwdCatFrags * kFragBytes;     // W2 [Fh]
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512) void tgcn_stepx_bwd_kernel(const BwdXArgs a)
     float *const Gbuf = reinterpret_cast<float *>(tm);
     char *const sFdh = tm + 16 * kBPLd * 4, *const sFdz = sFdh + kBActImg, *const sFdr = sFdz + kBActImg;
     char *const sFda = sFdr + kBActImg;                                      // da3: gate g at sFda + g * kBActImg
+    uint4 *const trow = reinterpret_cast<uint4 *>(sFda + 3 * kBActImg) + (4 * ct + (lane >> 4)) * kGatherTableEdges;
 
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.img + kBwdImgHead);
@@ -89,17 +90,18 @@ __global__ __launch_bounds__(512) void tgcn_stepx_bwd_kernel(const BwdXArgs a)
     // carried across the intervals of a tile: the own pieces the tile reads, dHa, the clamp-mask nibbles
     float4 p_dhn = zero4, p_hn = zero4, p_z = zero4, p_t = zero4, p_h = zero4, p_r = zero4, dHa = zero4;
     unsigned mz = 0u, mr = 0u, mh = 0u;
+    float p_yo = 0.f, p_tg = 0.f;                                            // HEAD == 2: the row's y_out and target
 
-    // gather A_hat^T z_next of tile `t` into Gbuf; this lane's pieces of the tile's saved tensors into registers
-    auto stage_tile = [&](int t, float4 &o_dhn, float4 &o_hn, float4 &o_z, float4 &o_t, float4 &o_h, unsigned &o_mz,
-                          unsigned &o_mr, unsigned &o_mh) {
-        {
-            const int rl = lane >> 4, c2 = lane & 15;
-            const int row = (int)min((int64_t)t * 16 + 4 * ct + rl, a.N - 1);
-            float2 p = make_float2(0.f, 0.f);
-            if (do_gather) p = gather_row2<HAS_EW>(a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, a.zn, row, c2);
-            *reinterpret_cast<float2 *>(Gbuf + (4 * ct + rl) * kBPLd + 2 * c2) = p;
-        }
+    // The gather of A_hat^T z_next for a tile's rows in its steps (RowGatherX); `gather_finish` ends it (Gbuf) and puts this
+    // lane's pieces of the tile's saved tensors in flight.
+    RowGatherX<HAS_EW> rg;
+    const int c2 = lane & 15;
+    auto grow = [&](int t) { return (int)min((int64_t)t * 16 + 4 * ct + (lane >> 4), a.N - 1); };
+    auto gather_finish = [&](int t, float4 &o_dhn, float4 &o_hn, float4 &o_z, float4 &o_t, float4 &o_h, unsigned &o_mz, unsigned &o_mr,
+                             unsigned &o_mh, float &o_yo, float &o_tg) {
+        float2 p = make_float2(0.f, 0.f);
+        if (do_gather) p = rg.run(trow, a.zn, a.column_indices, a.nc_edge, a.ew_edge, c2);
+        *reinterpret_cast<float2 *>(Gbuf + (4 * ct + (lane >> 4)) * kBPLd + 2 * c2) = p;
         const unsigned row = (unsigned)min((int64_t)t * 16 + n16, a.N - 1);
         const unsigned oC = (row * C + 16u * ct + 4u * kq) * 4u;
         o_dhn = a.dHn ? ld_f4(a.dHn, oC, 0) : zero4;
@@ -109,146 +111,192 @@ __global__ __launch_bounds__(512) void tgcn_stepx_bwd_kernel(const BwdXArgs a)
         o_t = ld_f4(a.Ht, oC, 0);
         const unsigned char *mp = a.mask + (size_t)row * 48u + 4u * kq + ct;
         o_mz = mp[0], o_mr = mp[16], o_mh = mp[32];
+        if constexpr (HEAD == 2) o_yo = ld_f1(a.y_out, row * 4u), o_tg = ld_f1(a.target, row * 4u);
     };
     auto masked = [](const f32x4 &v, unsigned m) {
         return make_float4((m & 1u) ? v[0] : 0.f, (m & 2u) ? v[1] : 0.f, (m & 4u) ? v[2] : 0.f, (m & 8u) ? v[3] : 0.f);
     };
 
+    // one wait for the weight fragments here, none in the intervals (tgcn_stepx_fwd.hip)
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int k = 0; k < kXTerms; ++k) asm volatile("" ::"v"(Wg[g][h][b].t[k]));
     __syncthreads();
-    for (int it = 0; it < total; ++it) {
-        const int s = it - 2 * team;
-        if (s == 0 && n_mine > 0) {
-            stage_tile(first, p_dhn, p_hn, p_z, p_t, p_h, mz, mr, mh);
-        } else if (s > 0 && (s - 1) / 4 < n_mine) {
-            const int j = (s - 1) >> 2, ph = (s - 1) & 3;
-            const int tile = first + j * 2 * G;
-            const unsigned row = (unsigned)min((int64_t)tile * 16 + n16, a.N - 1);
-            const unsigned oC = (row * C + 16u * ct + 4u * kq) * 4u;
-            const unsigned o3 = (row * (3u * C) + 16u * ct + 4u * kq) * 4u;
-            if (ph == 0) {
-                // ---- dyt (this lane's two row pieces of its row), dHn through the head, GRU backward ------------------------
-                const unsigned oF = (row * FHW + 4u * kq) * 4u;
-                float4 gy[2] = {zero4, zero4};
-                if (a.gy) gy[0] = ld_f4(a.gy, oF, 0), gy[1] = ld_f4(a.gy, oF, 64);
-                if constexpr (HEAD == 1) {
-                    // node side of the link-prediction loss (stg_link_decode_bwd's sum, term for term and in its order)
-                    if (a.link_row_ptr) {
-                        const int kb = a.link_row_ptr[row], ke = a.link_row_ptr[row + 1];
-                        const float scale = a.g_cost[0] * a.link_inv_m;
-                        const int kmax = wave_max_nonneg(ke - kb);
-                        for (int k0 = 0; k0 < kmax; k0 += 4) {
-                            int e[4], o[4];
+    // Straight-line intervals per tile (no phase switch inside the loop): see tgcn_stepx_fwd.hip.
+    int itc = 0;
+    auto interval_end = [&]() {
+        STGX_MARK(2 * itc + 1);
+        lds_barrier();
+        ++itc;
+        STGX_MARK(2 * itc);
+    };
+    STGX_MARK(0);
+    for (int k = 0; k < 2 * team; ++k) interval_end();
+    if (n_mine > 0) {
+        if (do_gather) {                                                     // the first tile's gather: its steps back to back
+            rg.extent(a.row_offsets, a.norm, grow(first));
+            rg.indices(a.column_indices, a.nc_edge, a.ew_edge, c2);
+            rg.stash(trow, c2);
+            wave_lds_fence();
+        }
+        gather_finish(first, p_dhn, p_hn, p_z, p_t, p_h, mz, mr, mh, p_yo, p_tg);
+    }
+    interval_end();
+    for (int j = 0; j < n_mine; ++j) {
+        const int tile = first + j * 2 * G;
+        const unsigned row = (unsigned)min((int64_t)tile * 16 + n16, a.N - 1);
+        const unsigned oC = (row * C + 16u * ct + 4u * kq) * 4u;
+        const unsigned o3 = (row * (3u * C) + 16u * ct + 4u * kq) * 4u;
+        const bool more = j + 1 < n_mine, pre = more && do_gather;           // uniform per team
+        {
+            // ---- dyt (this lane's two row pieces of its row), dHn through the head, GRU backward ------------------------
+            const unsigned oF = (row * FHW + 4u * kq) * 4u;
+            float4 gy[2] = {zero4, zero4};
+            if (a.gy) gy[0] = ld_f4(a.gy, oF, 0), gy[1] = ld_f4(a.gy, oF, 64);
+            if constexpr (HEAD == 1) {
+                // node side of the link-prediction loss (stg_link_decode_bwd's sum, term for term and in its order)
+                if (a.link_row_ptr) {
+                    const int kb = a.link_row_ptr[row], ke = a.link_row_ptr[row + 1];
+                    const float scale = a.g_cost[0] * a.link_inv_m;
+                    const int kmax = wave_max_nonneg(ke - kb);
+                    const int klast = max(ke - 1, 0);             // no guarded loads: lanes past their list re-read its last entry
+                    for (int k0 = 0; k0 < kmax; k0 += 4) {
+                        int e[4], o[4];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const bool ok = kb + k0 + u < ke;
-                                e[u] = ok ? a.link_eid[kb + k0 + u] : 0;
-                                o[u] = ok ? a.link_other[kb + k0 + u] : 0;
-                            }
-                            float x[4], tg[4];
-                            float4 yo[4][2];
+                        for (int u = 0; u < 4; ++u) {
+                            const int k = min(kb + k0 + u, klast);
+                            e[u] = a.link_eid[k];
+                            o[u] = a.link_other[k];
+                        }
+                        float x[4], tg[4];
+                        float4 yo[4][2];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                x[u] = a.link_logits[e[u]];
-                                tg[u] = a.link_target[e[u]];
+                        for (int u = 0; u < 4; ++u) {
+                            x[u] = a.link_logits[e[u]];
+                            tg[u] = a.link_target[e[u]];
 #pragma unroll
-                                for (int q = 0; q < 2; ++q) yo[u][q] = ld_f4(a.link_y, ((unsigned)o[u] * FHW + 4u * kq) * 4u, 64 * q);
-                            }
+                            for (int q = 0; q < 2; ++q) yo[u][q] = ld_f4(a.link_y, ((unsigned)o[u] * FHW + 4u * kq) * 4u, 64 * q);
+                        }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                if (kb + k0 + u < ke) {
-                                    const float sig = 1.0f / (1.0f + __expf(-x[u]));
-                                    const float coef = (sig - tg[u]) * scale;
+                        for (int u = 0; u < 4; ++u) {
+                            const bool ok = kb + k0 + u < ke;
+                            const float sig = 1.0f / (1.0f + __expf(-x[u]));
+                            const float coef = (sig - tg[u]) * scale;
 #pragma unroll
-                                    for (int q = 0; q < 2; ++q)
-                                        gy[q] = make_float4(gy[q].x + coef * yo[u][q].x, gy[q].y + coef * yo[u][q].y,
-                                                            gy[q].z + coef * yo[u][q].z, gy[q].w + coef * yo[u][q].w);
-                                }
-                            }
+                            for (int q = 0; q < 2; ++q)
+                                gy[q] = make_float4(ok ? gy[q].x + coef * yo[u][q].x : gy[q].x, ok ? gy[q].y + coef * yo[u][q].y : gy[q].y,
+                                                    ok ? gy[q].z + coef * yo[u][q].z : gy[q].z, ok ? gy[q].w + coef * yo[u][q].w : gy[q].w);
                         }
                     }
                 }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 gp = *reinterpret_cast<const float4 *>(Gbuf + n16 * kBPLd + 16 * q + 4 * kq);
+                gy[q] = make_float4(gy[q].x + gp.x, gy[q].y + gp.y, gy[q].z + gp.z, gy[q].w + gp.w);
+            }
+            float dyo = 0.f;
+            if constexpr (HEAD == 2) {
+                dyo = ((p_yo - p_tg) * a.two_over_n) * a.g_cost[0];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const float4 gp = *reinterpret_cast<const float4 *>(Gbuf + n16 * kBPLd + 16 * q + 4 * kq);
-                    gy[q] = make_float4(gy[q].x + gp.x, gy[q].y + gp.y, gy[q].z + gp.z, gy[q].w + gp.w);
+                    const float4 w2 = *reinterpret_cast<const float4 *>(sW2 + 16 * q + 4 * kq);
+                    gy[q] = make_float4(gy[q].x + dyo * w2.x, gy[q].y + dyo * w2.y, gy[q].z + dyo * w2.z, gy[q].w + dyo * w2.w);
                 }
-                if constexpr (HEAD == 2) {
-                    const float dyo = ((ld_f1(a.y_out, row * 4u) - ld_f1(a.target, row * 4u)) * a.two_over_n) * a.g_cost[0];
-                    if (ct == 0 && kq == 0) st_f1(a.dyo, row * 4u, dyo);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float4 w2 = *reinterpret_cast<const float4 *>(sW2 + 16 * q + 4 * kq);
-                        gy[q] = make_float4(gy[q].x + dyo * w2.x, gy[q].y + dyo * w2.y, gy[q].z + dyo * w2.z, gy[q].w + dyo * w2.w);
-                    }
-                }
-                if (ct < 2) st_f4(a.dyt, oF, 64 * ct, ct == 0 ? gy[0] : gy[1]);       // waves 0 and 1 store one piece each
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                mfma6(acc, wfrag_load(sHead, ct * kXTerms, lane), frag_of(gy[0], gy[1]));
-                const float4 g = make_float4(p_dhn.x + (p_hn.x > 0.f ? acc[0] : 0.f), p_dhn.y + (p_hn.y > 0.f ? acc[1] : 0.f),
-                                             p_dhn.z + (p_hn.z > 0.f ? acc[2] : 0.f), p_dhn.w + (p_hn.w > 0.f ? acc[3] : 0.f));
-                const float4 z = p_z, t = p_t, h = p_h;
-                const float4 dhl = make_float4((g.x * (1.0f - z.x)) * (1.0f - t.x * t.x), (g.y * (1.0f - z.y)) * (1.0f - t.y * t.y),
-                                               (g.z * (1.0f - z.z)) * (1.0f - t.z * t.z), (g.w * (1.0f - z.w)) * (1.0f - t.w * t.w));
-                const float4 dz = make_float4((g.x * (h.x - t.x)) * (z.x * (1.0f - z.x)), (g.y * (h.y - t.y)) * (z.y * (1.0f - z.y)),
-                                              (g.z * (h.z - t.z)) * (z.z * (1.0f - z.z)), (g.w * (h.w - t.w)) * (z.w * (1.0f - z.w)));
-                dHa = make_float4(g.x * z.x, g.y * z.y, g.z * z.z, g.w * z.w);
-                st_f4(a.dhl, oC, 0, dhl);
-                st_f4(a.dzl, oC, 0, dz);
-                frag_store_piece(sFdh, ct, lane, split4(dhl));
-                frag_store_piece(sFdz, ct, lane, split4(dz));
-                p_r = ld_f4(a.R, oC, 0);                                     // for the next interval: in flight across the barrier
-            } else if (ph == 1) {
-                // ---- dCH = dhl Wh: d(hh) -> da3[:, 2C + own];  dHR -> drl, dHa ------------------------------------------------
-                f32x4 aa = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const Frag3 f = frag_load(sFdh, b, lane);
-                    mfma6(aa, Wg[2][0][b], f);
-                    mfma6(ab, Wg[2][1][b], f);
-                }
-                const float4 d3 = masked(aa, mh);
-                st_f4(a.da3, o3, 4 * (2 * C), d3);
-                frag_store_piece(sFda + 2 * kBActImg, ct, lane, split4(d3));
-                const float4 r = p_r, h = p_h;
-                const float4 drl = make_float4((ab[0] * h.x) * (r.x * (1.0f - r.x)), (ab[1] * h.y) * (r.y * (1.0f - r.y)),
-                                               (ab[2] * h.z) * (r.z * (1.0f - r.z)), (ab[3] * h.w) * (r.w * (1.0f - r.w)));
-                dHa = make_float4(dHa.x + ab[0] * r.x, dHa.y + ab[1] * r.y, dHa.z + ab[2] * r.z, dHa.w + ab[3] * r.w);
-                st_f4(a.drl, oC, 0, drl);
-                frag_store_piece(sFdr, ct, lane, split4(drl));
-            } else if (ph == 2) {
-                // ---- dCZ = dzl Wz, dCR = drl Wr: first halves -> da3, second halves -> dH (dCZ's first, then dCR's) -----------
-                f32x4 za = {0.f, 0.f, 0.f, 0.f}, zb = za, ra = za, rb = za;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const Frag3 fz = frag_load(sFdz, b, lane);
-                    mfma6(za, Wg[0][0][b], fz);
-                    mfma6(zb, Wg[0][1][b], fz);
-                    const Frag3 fr = frag_load(sFdr, b, lane);
-                    mfma6(ra, Wg[1][0][b], fr);
-                    mfma6(rb, Wg[1][1][b], fr);
-                }
-                const float4 dzc = masked(za, mz), drc = masked(ra, mr);
-                st_f4(a.da3, o3, 0, dzc);
-                st_f4(a.da3, o3, 4 * C, drc);
-                frag_store_piece(sFda, ct, lane, split4(dzc));
-                frag_store_piece(sFda + kBActImg, ct, lane, split4(drc));
-                const float4 d1 = make_float4(dHa.x + zb[0], dHa.y + zb[1], dHa.z + zb[2], dHa.w + zb[3]);
-                st_f4(a.dH, oC, 0, make_float4(d1.x + rb[0], d1.y + rb[1], d1.z + rb[2], d1.w + rb[3]));
-            } else {
-                // ---- z = da3 Wcat^T (two waves of the team, 16 output columns each, in turn), then the next tile ---------------
-                if (want_z && (ct >> 1) == (j & 1)) {
-                    const int ft = ct & 1;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int b = 0; b < 6; ++b)
-                        mfma6(acc, wfrag_load(sCat, (ft * 6 + b) * kXTerms, lane), frag_load(sFda + (b >> 1) * kBActImg, b & 1, lane));
-                    st_f4(a.z, (row * FIN + 4u * kq) * 4u, 64 * ft, to_f4(acc));
-                }
-                if (j + 1 < n_mine) stage_tile(tile + 2 * G, p_dhn, p_hn, p_z, p_t, p_h, mz, mr, mh);
             }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            mfma6(acc, wfrag_load(sHead, ct * kXTerms, lane), frag_of(gy[0], gy[1]));
+            const float4 g = make_float4(p_dhn.x + (p_hn.x > 0.f ? acc[0] : 0.f), p_dhn.y + (p_hn.y > 0.f ? acc[1] : 0.f),
+                                         p_dhn.z + (p_hn.z > 0.f ? acc[2] : 0.f), p_dhn.w + (p_hn.w > 0.f ? acc[3] : 0.f));
+            const float4 z = p_z, t = p_t, h = p_h;
+            const float4 dhl = make_float4((g.x * (1.0f - z.x)) * (1.0f - t.x * t.x), (g.y * (1.0f - z.y)) * (1.0f - t.y * t.y),
+                                           (g.z * (1.0f - z.z)) * (1.0f - t.z * t.z), (g.w * (1.0f - z.w)) * (1.0f - t.w * t.w));
+            const float4 dz = make_float4((g.x * (h.x - t.x)) * (z.x * (1.0f - z.x)), (g.y * (h.y - t.y)) * (z.y * (1.0f - z.y)),
+                                          (g.z * (h.z - t.z)) * (z.z * (1.0f - z.z)), (g.w * (h.w - t.w)) * (z.w * (1.0f - z.w)));
+            dHa = make_float4(g.x * z.x, g.y * z.y, g.z * z.z, g.w * z.w);
+            frag_store_piece(sFdh, ct, lane, split4(dhl));
+            frag_store_piece(sFdz, ct, lane, split4(dz));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HEAD == 2) {
+                if (ct == 0 && kq == 0) st_f1(a.dyo, row * 4u, dyo);
+            }
+            if (ct < 2) st_f4(a.dyt, oF, 64 * ct, ct == 0 ? gy[0] : gy[1]);       // waves 0 and 1 store one piece each
+            st_f4(a.dhl, oC, 0, dhl);
+            st_f4(a.dzl, oC, 0, dz);
+            p_r = ld_f4(a.R, oC, 0);                                     // for the next interval: in flight across the barrier
+            if (pre) rg.extent(a.row_offsets, a.norm, grow(tile + 2 * G));        // next tile's gather, first round trip
         }
-        __syncthreads();
+        interval_end();
+        {
+            // ---- dCH = dhl Wh: d(hh) -> da3[:, 2C + own];  dHR -> drl, dHa ------------------------------------------------
+            f32x4 aa = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const Frag3 f = frag_load(sFdh, b, lane);
+                mfma6(aa, Wg[2][0][b], f);
+                mfma6(ab, Wg[2][1][b], f);
+            }
+            const float4 d3 = masked(aa, mh);
+            frag_store_piece(sFda + 2 * kBActImg, ct, lane, split4(d3));
+            const float4 r = p_r, h = p_h;
+            const float4 drl = make_float4((ab[0] * h.x) * (r.x * (1.0f - r.x)), (ab[1] * h.y) * (r.y * (1.0f - r.y)),
+                                           (ab[2] * h.z) * (r.z * (1.0f - r.z)), (ab[3] * h.w) * (r.w * (1.0f - r.w)));
+            dHa = make_float4(dHa.x + ab[0] * r.x, dHa.y + ab[1] * r.y, dHa.z + ab[2] * r.z, dHa.w + ab[3] * r.w);
+            frag_store_piece(sFdr, ct, lane, split4(drl));
+            __builtin_amdgcn_sched_barrier(0);
+            st_f4(a.da3, o3, 4 * (2 * C), d3);
+            st_f4(a.drl, oC, 0, drl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pre) rg.indices(a.column_indices, a.nc_edge, a.ew_edge, c2);        // second round trip (needs the extent: an interval old)
+        }
+        interval_end();
+        {
+            // ---- dCZ = dzl Wz, dCR = drl Wr: first halves -> da3, second halves -> dH (dCZ's first, then dCR's) -----------
+            f32x4 za = {0.f, 0.f, 0.f, 0.f}, zb = za, ra = za, rb = za;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const Frag3 fz = frag_load(sFdz, b, lane);
+                mfma6(za, Wg[0][0][b], fz);
+                mfma6(zb, Wg[0][1][b], fz);
+                const Frag3 fr = frag_load(sFdr, b, lane);
+                mfma6(ra, Wg[1][0][b], fr);
+                mfma6(rb, Wg[1][1][b], fr);
+            }
+            const float4 dzc = masked(za, mz), drc = masked(ra, mr);
+            frag_store_piece(sFda, ct, lane, split4(dzc));
+            frag_store_piece(sFda + kBActImg, ct, lane, split4(drc));
+            const float4 d1 = make_float4(dHa.x + zb[0], dHa.y + zb[1], dHa.z + zb[2], dHa.w + zb[3]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pre) rg.stash(trow, c2);                                           // the edge records (an interval old) into the table
+            __builtin_amdgcn_sched_barrier(0);
+            st_f4(a.da3, o3, 0, dzc);
+            st_f4(a.da3, o3, 4 * C, drc);
+            st_f4(a.dH, oC, 0, make_float4(d1.x + rb[0], d1.y + rb[1], d1.z + rb[2], d1.w + rb[3]));
+        }
+        interval_end();
+        {
+            // ---- z = da3 Wcat^T (two waves of the team, 16 output columns each, in turn), then the next tile ---------------
+            const bool z_wave = want_z && (ct >> 1) == (j & 1);
+            const int ft = ct & 1;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (z_wave) {
+#pragma unroll
+                for (int b = 0; b < 6; ++b)
+                    mfma6(acc, wfrag_load(sCat, (ft * 6 + b) * kXTerms, lane), frag_load(sFda + (b >> 1) * kBActImg, b & 1, lane));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) gather_finish(tile + 2 * G, p_dhn, p_hn, p_z, p_t, p_h, mz, mr, mh, p_yo, p_tg);
+            __builtin_amdgcn_sched_barrier(0);
+            if (z_wave) st_f4(a.z, (row * FIN + 4u * kq) * 4u, 64 * ft, to_f4(acc));
+        }
+        interval_end();
     }
+    while (itc < total) interval_end();
 }
 
 template <bool HAS_EW, int HEAD>
@@ -269,6 +317,10 @@ int launch_stepx_bwd(const BwdXArgs &a, hipStream_t stream)
 
 }  // namespace
 }  // namespace stg
+
+#ifdef STG_STEPX_TRACE
+extern "C" int stg_debug_set_stepx_trace_bwd(void *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(stg::g_stepx_trace), &buf, sizeof(buf)); }
+#endif
 
 // dispatch target of stg_tgcn_step_bwd (tgcn_step_bwd.hip) when the argument block carries a weight image
 int stg_tgcn_stepx_bwd_launch(const stg_tgcn_step_bwd_args *p, void *stream_)

@@ -21,7 +21,7 @@ struct FwdXArgs {
 
 constexpr int kPLd = 36;                                               // Pbuf row stride in floats
 constexpr int kActImg = 2 * kXTerms * kFragBytes;                      // a 64-column activation as fragments: 2 K-blocks = 6144 B
-constexpr int kTeamBytes = 16 * kPLd * 4 + 3 * kActImg + 3 * kActImg;  // Pbuf | hz hr hh | H, HR, relu(Hn)
+constexpr int kTeamBytes = 16 * kPLd * 4 + 3 * kActImg + 3 * kActImg + kGatherTableBytes;  // Pbuf | hz hr hh | H, HR, relu(Hn) | edge records
 constexpr int kFwdLdsCat = 0;
 constexpr int kFwdLdsHead = kFwdLdsCat + 4 * kFwdCatFrags * kFragBytes;
 constexpr int kFwdLdsBias = kFwdLdsHead + 2 * kFwdHeadFrags * kFragBytes;
@@ -43,6 +43,8 @@ __global__ __launch_bounds__(512) void tgcn_stepx_fwd_kernel(const FwdXArgs a)
     float *const Pbuf = reinterpret_cast<float *>(tm);
     char *const sFhg = tm + 16 * kPLd * 4;                                  // hz | hr | hh, kActImg each
     char *const sFH = sFhg + 3 * kActImg, *const sFHR = sFH + kActImg, *const sFHn = sFHR + kActImg;
+    // the 32 edge records of this lane's gather row (row 4 ct + rl of the tile; the 16 lanes of a row share them)
+    uint4 *const trow = reinterpret_cast<uint4 *>(sFHn + kActImg) + (4 * ct + (lane >> 4)) * kGatherTableEdges;
 
     // ---- the small weights and the biases into LDS; this wave's rows of the gate Linears into registers -------------------
     {
@@ -77,126 +79,186 @@ __global__ __launch_bounds__(512) void tgcn_stepx_fwd_kernel(const FwdXArgs a)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 h4 = zero4, z4 = zero4;                                          // own pieces of H and Z, carried across intervals
 
-    // gather of tile `t` into Pbuf (+ global P), and this wave's piece of H as fragments
-    auto stage_tile = [&](int t) -> float4 {
-        {
-            const int rl = lane >> 4, c2 = lane & 15;
-            const int row = (int)min((int64_t)t * 16 + 4 * ct + rl, a.N - 1);
-            const float2 p = gather_row2<HAS_EW>(a.row_offsets, a.column_indices, a.nc_edge, a.ew_edge, a.norm, a.x, row, c2);
-            *reinterpret_cast<float2 *>(reinterpret_cast<char *>(a.P) + ((size_t)(unsigned)row * (FIN * 4u) + 8u * c2)) = p;
-            *reinterpret_cast<float2 *>(Pbuf + (4 * ct + rl) * kPLd + 2 * c2) = p;
-        }
-        const unsigned row = (unsigned)min((int64_t)t * 16 + n16, a.N - 1);
-        const float4 h = a.H ? ld_f4(a.H, (row * C + 16u * ct + 4u * kq) * 4u, 0) : zero4;
-        frag_store_piece(sFH, ct, lane, split4(h));
-        return h;
+    // The gather of a tile's P rows (four rows per wave) in its steps: see RowGatherX.  `gather_finish` ends it: P to global
+    // memory and to Pbuf, and this lane's piece of the tile's H (split into fragments by the tile's first phase).
+    RowGatherX<HAS_EW> rg;
+    const int c2 = lane & 15;
+    auto grow = [&](int t) { return (int)min((int64_t)t * 16 + 4 * ct + (lane >> 4), a.N - 1); };
+    auto gather_finish = [&](int t) -> float4 {
+        const int row = grow(t);
+        const float2 p = rg.run(trow, a.x, a.column_indices, a.nc_edge, a.ew_edge, c2);
+        *reinterpret_cast<float2 *>(reinterpret_cast<char *>(a.P) + ((size_t)(unsigned)row * (FIN * 4u) + 8u * c2)) = p;
+        *reinterpret_cast<float2 *>(Pbuf + (4 * ct + (lane >> 4)) * kPLd + 2 * c2) = p;
+        const unsigned hrow = (unsigned)min((int64_t)t * 16 + n16, a.N - 1);
+        return a.H ? ld_f4(a.H, (hrow * C + 16u * ct + 4u * kq) * 4u, 0) : zero4;
     };
 
+    // The weight fragments are used in every interval: one wait for them HERE (an asm use the compiler must honour), so that no
+    // interval starts by waiting for "maybe still pending" loads with vmcnt(0).
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int k = 0; k < kXTerms; ++k) asm volatile("" ::"v"(Wg[g][b].t[k]));
     __syncthreads();
-    for (int it = 0; it < total; ++it) {
-        const int s = it - 2 * team;
-        if (s == 0 && n_mine > 0) {
-            h4 = stage_tile(first);
-        } else if (s > 0 && (s - 1) / 4 < n_mine) {
-            const int j = (s - 1) >> 2, ph = (s - 1) & 3;
-            const int tile = first + j * 2 * G;
-            const int64_t idx = (int64_t)tile * 16 + n16;
-            const unsigned row = (unsigned)min(idx, a.N - 1);
-            const unsigned oC = (row * C + 16u * ct + 4u * kq) * 4u;              // this lane's piece in a row of C floats
-            if (ph == 0) {
-                // ---- x3 = P Wcat + b3 (this wave's 16 columns of each gate), clamp, mask; hg as fragments -------------
-                const float *pb = Pbuf + n16 * kPLd + 4 * kq;
-                const Frag3 fp = frag_of(*reinterpret_cast<const float4 *>(pb), *reinterpret_cast<const float4 *>(pb + 16));
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    mfma6(acc, wfrag_load(sCat, (ct * 3 + g) * kXTerms, lane), fp);
-                    const float4 b = *reinterpret_cast<const float4 *>(sBias + g * C + 16 * ct + 4 * kq);
-                    const float4 v = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
-                    st_f4(a.x3, (row * (3u * C) + 4u * kq) * 4u, 4 * (g * C + 16 * ct), v);
-                    const float4 hg = make_float4(clamp3(v.x, lo, hi), clamp3(v.y, lo, hi), clamp3(v.z, lo, hi), clamp3(v.w, lo, hi));
-                    if (a.mask) {
-                        const unsigned m = (hg.x == v.x ? 1u : 0u) | (hg.y == v.y ? 2u : 0u) | (hg.z == v.z ? 4u : 0u) | (hg.w == v.w ? 8u : 0u);
-                        a.mask[(size_t)row * 48u + (4u * g + kq) * 4u + ct] = (unsigned char)m;
-                    }
-                    frag_store_piece(sFhg + g * kActImg, ct, lane, split4(hg));
-                }
-            } else if (ph == 1) {
-                // ---- Z = sigmoid([hz | H] Wz^T + bz),  R = sigmoid([hr | H] Wr^T + br) ------------------------------------
-                f32x4 az = to_x4(*reinterpret_cast<const float4 *>(sBias + 3 * C + 16 * ct + 4 * kq));
-                f32x4 ar = to_x4(*reinterpret_cast<const float4 *>(sBias + 4 * C + 16 * ct + 4 * kq));
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    mfma6(az, Wg[0][b], frag_load(sFhg, b, lane));
-                    mfma6(ar, Wg[1][b], frag_load(sFhg + kActImg, b, lane));
-                }
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const Frag3 fh = frag_load(sFH, b, lane);
-                    mfma6(az, Wg[0][2 + b], fh);
-                    mfma6(ar, Wg[1][2 + b], fh);
-                }
-                z4 = make_float4(sigmoid_(az[0]), sigmoid_(az[1]), sigmoid_(az[2]), sigmoid_(az[3]));
-                const float4 r = make_float4(sigmoid_(ar[0]), sigmoid_(ar[1]), sigmoid_(ar[2]), sigmoid_(ar[3]));
-                const float4 hr = make_float4(h4.x * r.x, h4.y * r.y, h4.z * r.z, h4.w * r.w);
-                st_f4(a.Z, oC, 0, z4);
-                st_f4(a.R, oC, 0, r);
-                st_f4(a.HR, oC, 0, hr);
-                frag_store_piece(sFHR, ct, lane, split4(hr));
-            } else if (ph == 2) {
-                // ---- Ht = tanh([hh | H*R] Wh^T + bh);  Hn = Z*H + (1 - Z)*Ht -----------------------------------------------
-                f32x4 ah = to_x4(*reinterpret_cast<const float4 *>(sBias + 5 * C + 16 * ct + 4 * kq));
-#pragma unroll
-                for (int b = 0; b < 2; ++b) mfma6(ah, Wg[2][b], frag_load(sFhg + 2 * kActImg, b, lane));
-#pragma unroll
-                for (int b = 0; b < 2; ++b) mfma6(ah, Wg[2][2 + b], frag_load(sFHR, b, lane));
-                const float4 t = make_float4(tanh_(ah[0]), tanh_(ah[1]), tanh_(ah[2]), tanh_(ah[3]));
-                const float4 hn = make_float4(z4.x * h4.x + (1.0f - z4.x) * t.x, z4.y * h4.y + (1.0f - z4.y) * t.y,
-                                              z4.z * h4.z + (1.0f - z4.z) * t.z, z4.w * h4.w + (1.0f - z4.w) * t.w);
-                st_f4(a.Ht, oC, 0, t);
-                st_f4(a.Hn, oC, 0, hn);
-                frag_store_piece(sFHn, ct, lane, split4(make_float4(hn.x < 0.f ? 0.f : hn.x, hn.y < 0.f ? 0.f : hn.y,
-                                                                   hn.z < 0.f ? 0.f : hn.z, hn.w < 0.f ? 0.f : hn.w)));
-            } else {
-                // ---- head of this tile (one wave of the team, in turn), then the next tile's gather and H ----------------------
-                if (HEAD != 0 && ct == (j & 3)) {
-                    f32x4 ay[2];
-#pragma unroll
-                    for (int ft = 0; ft < 2; ++ft) ay[ft] = to_x4(*reinterpret_cast<const float4 *>(sBias + 6 * C + 16 * ft + 4 * kq));
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const Frag3 f = frag_load(sFHn, b, lane);
-#pragma unroll
-                        for (int ft = 0; ft < 2; ++ft) mfma6(ay[ft], wfrag_load(sHead, (ft * 2 + b) * kXTerms, lane), f);
-                    }
-                    const unsigned oF = (row * FH + 4u * kq) * 4u;
-#pragma unroll
-                    for (int ft = 0; ft < 2; ++ft) st_f4(a.y, oF, 64 * ft, to_f4(ay[ft]));
-                    if constexpr (HEAD == 2) {
-                        float sdot = 0.f;
-#pragma unroll
-                        for (int ft = 0; ft < 2; ++ft) {
-                            const float4 w2 = *reinterpret_cast<const float4 *>(sBias + 6 * C + FH + 16 * ft + 4 * kq);
-                            sdot = sdot + ay[ft][0] * w2.x;
-                            sdot = sdot + ay[ft][1] * w2.y;
-                            sdot = sdot + ay[ft][2] * w2.z;
-                            sdot = sdot + ay[ft][3] * w2.w;
-                        }
-                        sdot = sdot + __shfl_xor(sdot, 16, kWave);               // the row's four kq lanes
-                        sdot = sdot + __shfl_xor(sdot, 32, kWave);
-                        const float yo = sdot + sBias[6 * C + 2 * FH];
-                        if (kq == 0) st_f1(a.y_out, row * 4u, yo);
-                        const float dlt = yo - ld_f1(a.target, row * 4u);
-                        float sq = (idx < a.N && kq == 0) ? dlt * dlt : 0.f;
-                        sq = row16_sum(sq);                                   // lanes 0..15: the tile's 16 rows, in lane order
-                        if (lane == 15) a.partial[tile] = sq;
-                    }
-                }
-                if (j + 1 < n_mine) h4 = stage_tile(tile + 2 * G);
-            }
-        }
-        __syncthreads();
+    // The intervals of a team in program order -- [first gather] then per tile [x3] [gates z, r] [gate h] [head + next gather] --
+    // as STRAIGHT-LINE code per tile (no phase switch inside the loop): the compiler's s_waitcnt insertion counts exactly inside an
+    // iteration, while a wait that has to look across a loop back edge becomes vmcnt(0) -- a full drain of every load and store in
+    // flight at the head of every phase (measured: 2 - 3 us per interval).  Team 1 runs two intervals behind team 0, so that one
+    // team's matrix phase sits beside the other's gather / store phase; every wave of the workgroup passes `total` barriers.
+    int itc = 0;                                                                // barriers passed (= trace interval)
+    auto interval_end = [&]() {
+        STGX_MARK(2 * itc + 1);
+        lds_barrier();
+        ++itc;
+        STGX_MARK(2 * itc);
+    };
+    STGX_MARK(0);
+    for (int k = 0; k < 2 * team; ++k) interval_end();
+    if (n_mine > 0) {
+        rg.extent(a.row_offsets, a.norm, grow(first));                       // the first tile's gather: its steps back to back
+        rg.indices(a.column_indices, a.nc_edge, a.ew_edge, c2);
+        rg.stash(trow, c2);
+        wave_lds_fence();                                                    // the table rows are this wave's own
+        h4 = gather_finish(first);
     }
+    interval_end();
+    for (int j = 0; j < n_mine; ++j) {
+        const int tile = first + j * 2 * G;
+        const int64_t idx = (int64_t)tile * 16 + n16;
+        const unsigned row = (unsigned)min(idx, a.N - 1);
+        const unsigned oC = (row * C + 16u * ct + 4u * kq) * 4u;              // this lane's piece in a row of C floats
+        const bool more = j + 1 < n_mine;                                   // uniform per team
+        // Order inside an interval: the matrix work, then whatever consumes an earlier interval's loads, the interval's own global
+        // stores, and the loads for later intervals last.  sched_barrier pins the sections.
+        {
+            // ---- x3 = P Wcat + b3 (this wave's 16 columns of each gate), clamp, mask; hg as fragments -------------
+            const float *pb = Pbuf + n16 * kPLd + 4 * kq;
+            const Frag3 fp = frag_of(*reinterpret_cast<const float4 *>(pb), *reinterpret_cast<const float4 *>(pb + 16));
+            float4 x3v[3];
+            unsigned mk[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                mfma6(acc, wfrag_load(sCat, (ct * 3 + g) * kXTerms, lane), fp);
+                const float4 b = *reinterpret_cast<const float4 *>(sBias + g * C + 16 * ct + 4 * kq);
+                const float4 v = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
+                const float4 hg = make_float4(clamp3(v.x, lo, hi), clamp3(v.y, lo, hi), clamp3(v.z, lo, hi), clamp3(v.w, lo, hi));
+                mk[g] = (hg.x == v.x ? 1u : 0u) | (hg.y == v.y ? 2u : 0u) | (hg.z == v.z ? 4u : 0u) | (hg.w == v.w ? 8u : 0u);
+                x3v[g] = v;
+                frag_store_piece(sFhg + g * kActImg, ct, lane, split4(hg));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            frag_store_piece(sFH, ct, lane, split4(h4));                    // this tile's H piece (loaded an interval ago)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) st_f4(a.x3, (row * (3u * C) + 4u * kq) * 4u, 4 * (g * C + 16 * ct), x3v[g]);
+            if (a.mask) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) a.mask[(size_t)row * 48u + (4u * g + kq) * 4u + ct] = (unsigned char)mk[g];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) rg.extent(a.row_offsets, a.norm, grow(tile + 2 * G));    // next tile's gather, first round trip: issued LAST
+        }
+        interval_end();
+        {
+            // ---- Z = sigmoid([hz | H] Wz^T + bz),  R = sigmoid([hr | H] Wr^T + br) ------------------------------------
+            f32x4 az = to_x4(*reinterpret_cast<const float4 *>(sBias + 3 * C + 16 * ct + 4 * kq));
+            f32x4 ar = to_x4(*reinterpret_cast<const float4 *>(sBias + 4 * C + 16 * ct + 4 * kq));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                mfma6(az, Wg[0][b], frag_load(sFhg, b, lane));
+                mfma6(ar, Wg[1][b], frag_load(sFhg + kActImg, b, lane));
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const Frag3 fh = frag_load(sFH, b, lane);
+                mfma6(az, Wg[0][2 + b], fh);
+                mfma6(ar, Wg[1][2 + b], fh);
+            }
+            z4 = make_float4(sigmoid_(az[0]), sigmoid_(az[1]), sigmoid_(az[2]), sigmoid_(az[3]));
+            const float4 r = make_float4(sigmoid_(ar[0]), sigmoid_(ar[1]), sigmoid_(ar[2]), sigmoid_(ar[3]));
+            const float4 hr = make_float4(h4.x * r.x, h4.y * r.y, h4.z * r.z, h4.w * r.w);
+            frag_store_piece(sFHR, ct, lane, split4(hr));
+            __builtin_amdgcn_sched_barrier(0);
+            st_f4(a.Z, oC, 0, z4);
+            st_f4(a.R, oC, 0, r);
+            st_f4(a.HR, oC, 0, hr);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) rg.indices(a.column_indices, a.nc_edge, a.ew_edge, c2);   // second round trip (needs the extent: an interval old), LAST
+        }
+        interval_end();
+        {
+            // ---- Ht = tanh([hh | H*R] Wh^T + bh);  Hn = Z*H + (1 - Z)*Ht -----------------------------------------------
+            f32x4 ah = to_x4(*reinterpret_cast<const float4 *>(sBias + 5 * C + 16 * ct + 4 * kq));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) mfma6(ah, Wg[2][b], frag_load(sFhg + 2 * kActImg, b, lane));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) mfma6(ah, Wg[2][2 + b], frag_load(sFHR, b, lane));
+            const float4 t = make_float4(tanh_(ah[0]), tanh_(ah[1]), tanh_(ah[2]), tanh_(ah[3]));
+            const float4 hn = make_float4(z4.x * h4.x + (1.0f - z4.x) * t.x, z4.y * h4.y + (1.0f - z4.y) * t.y,
+                                          z4.z * h4.z + (1.0f - z4.z) * t.z, z4.w * h4.w + (1.0f - z4.w) * t.w);
+            frag_store_piece(sFHn, ct, lane, split4(make_float4(hn.x < 0.f ? 0.f : hn.x, hn.y < 0.f ? 0.f : hn.y,
+                                                               hn.z < 0.f ? 0.f : hn.z, hn.w < 0.f ? 0.f : hn.w)));
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) rg.stash(trow, c2);                                       // the edge records (an interval old) into the table
+            __builtin_amdgcn_sched_barrier(0);
+            st_f4(a.Ht, oC, 0, t);
+            st_f4(a.Hn, oC, 0, hn);
+        }
+        interval_end();
+        {
+            // ---- head of this tile (one wave of the team, in turn), the next tile's gather, then the stores and the H load ----
+            const bool head_wave = HEAD != 0 && ct == (j & 3);
+            f32x4 ay[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            float yo = 0.f, tg = 0.f;
+            if (head_wave) {
+                if constexpr (HEAD == 2) tg = ld_f1(a.target, row * 4u);       // consumed after the gather
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) ay[ft] = to_x4(*reinterpret_cast<const float4 *>(sBias + 6 * C + 16 * ft + 4 * kq));
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const Frag3 f = frag_load(sFHn, b, lane);
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) mfma6(ay[ft], wfrag_load(sHead, (ft * 2 + b) * kXTerms, lane), f);
+                }
+                if constexpr (HEAD == 2) {
+                    float sdot = 0.f;
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) {
+                        const float4 w2 = *reinterpret_cast<const float4 *>(sBias + 6 * C + FH + 16 * ft + 4 * kq);
+                        sdot = sdot + ay[ft][0] * w2.x;
+                        sdot = sdot + ay[ft][1] * w2.y;
+                        sdot = sdot + ay[ft][2] * w2.z;
+                        sdot = sdot + ay[ft][3] * w2.w;
+                    }
+                    sdot = sdot + __shfl_xor(sdot, 16, kWave);               // the row's four kq lanes
+                    sdot = sdot + __shfl_xor(sdot, 32, kWave);
+                    yo = sdot + sBias[6 * C + 2 * FH];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float4 hnext = zero4;
+            if (more) hnext = gather_finish(tile + 2 * G);                   // third round trip: the neighbour rows; P; the H load
+            __builtin_amdgcn_sched_barrier(0);
+            if (head_wave) {
+                const unsigned oF = (row * FH + 4u * kq) * 4u;
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) st_f4(a.y, oF, 64 * ft, to_f4(ay[ft]));
+                if constexpr (HEAD == 2) {
+                    if (kq == 0) st_f1(a.y_out, row * 4u, yo);
+                    const float dlt = yo - tg;
+                    float sq = (idx < a.N && kq == 0) ? dlt * dlt : 0.f;
+                    sq = row16_sum(sq);                                   // lanes 0..15: the tile's 16 rows, in lane order
+                    if (lane == 15) a.partial[tile] = sq;
+                }
+            }
+            if (more) h4 = hnext;
+        }
+        interval_end();
+    }
+    while (itc < total) interval_end();
 }
 
 template <bool HAS_EW, int HEAD>
@@ -333,6 +395,10 @@ extern "C" int stg_tgcn_pack_weights_x3(const float *Wcz, const float *Wcr, cons
                        static_cast<hipStream_t>(stream), a);
     return check_launch("stg_tgcn_pack_weights_x3");
 }
+
+#ifdef STG_STEPX_TRACE
+extern "C" int stg_debug_set_stepx_trace_fwd(void *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(stg::g_stepx_trace), &buf, sizeof(buf)); }
+#endif
 
 // dispatch target of stg_tgcn_step_fwd (tgcn_step_fwd.hip) when the argument block carries a weight image
 int stg_tgcn_stepx_fwd_launch(const stg_tgcn_step_fwd_args *p, void *stream_)

@@ -1464,10 +1464,12 @@ def gemm_tn_form_batch(calls):
 
 
 # ------------------------------------------------------------- one TGCN step per launch (csrc/tgcn_step.hip)
-# True (default): the window nodes of stgraph_amd.temporal hand the step launches bf16 fragment images of the weights
+# True: the window nodes of stgraph_amd.temporal hand the step launches bf16 fragment images of the weights
 # (tgcn_pack_weights_x3) and so take their matrix-core form (csrc/tgcn_stepx_*.hip: every product as a 3-term bf16 split with
-# fp32 accumulation, fp32-class results); False: the fp32-instruction form (csrc/tgcn_step_*.hip).
-STEP_MATRIX_CORE = True
+# fp32 accumulation, fp32-class results, same tests and tolerances); False (default): the fp32-instruction form
+# (csrc/tgcn_step_*.hip).  The default is the MEASURED faster one: 56 + 59 us per snapshot at cfg4 against 77 + 87 us
+# (profiles/r04_stepx_*.json; DESIGN.md section 0 has the anatomy of why the column-split form is latency-bound).
+STEP_MATRIX_CORE = False
 
 
 def set_step_matrix_core(enabled: bool) -> None:
@@ -1551,6 +1553,8 @@ def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     stg_tgcn_step_fwd_args by name (include/stgraph_hip.h).  Outputs are written in place."""
     dev = torch.device(device)
     a = _C.TgcnStepFwdArgs()
+    if tensors.get("column_indices") is not None and tensors["column_indices"].numel() == 0:
+        tensors = dict(tensors, w_image=None)               # the matrix-core form assumes |E| >= 1 (its gather has no guarded loads)
     _fill_step_args(a, "tgcn_step_fwd", dev, tensors)
     a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
     # byte model: gathered input rows + index arrays + what the launch reads and writes per row
@@ -1566,6 +1570,8 @@ def tgcn_step_bwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     ``link_edges`` = the number of label edges) the node side of the link loss's backward runs inside the launch."""
     dev = torch.device(device)
     a = _C.TgcnStepBwdArgs()
+    if tensors.get("column_indices") is not None and tensors["column_indices"].numel() == 0:
+        tensors = dict(tensors, w_image=None)
     _fill_step_args(a, "tgcn_step_bwd", dev, tensors)
     a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
     a.link_inv_m = 1.0 / float(link_edges) if link_edges else 0.0

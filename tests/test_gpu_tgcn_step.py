@@ -169,6 +169,8 @@ def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3f
 
     b1 = _bwd(cuda, g, norm, ew, p, s1, s0["Hn"], t1, n, zn=None, dHn=None, g_cost=g_cost, node_ids=node_ids, x3form=x3form)
     b0 = _bwd(cuda, g, norm, ew, p, s0, None, t0, n, zn=b1["z"], dHn=b1["dH"], g_cost=g_cost, node_ids=node_ids, x3form=x3form)
+    b0_again = _bwd(cuda, g, norm, ew, p, s0, None, t0, n, zn=b1["z"], dHn=b1["dH"], g_cost=g_cost, node_ids=node_ids, x3form=x3form)
+    assert all(torch.equal(b0[k], b0_again[k]) for k in b0)            # deterministic: no atomics, fixed orders
 
     if n > 20_000:
         A = None                                   # dense A_hat would be 20 GB: aggregate with the (tested) kernel in fp32
@@ -419,6 +421,9 @@ def test_matrix_core_forward_matches_the_fp32_form(cuda, n, e, use_ew, head):
             assert torch.equal(a["P"], b["P"])
         for k in keys:
             _close(b[k], a[k], f"step {k_step} {k}", 1e-5)
+    # the matrix-core form is deterministic: a second launch gives the same bits
+    again = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, head=head, x3form=True)
+    assert all(torch.equal(again[k], res[1][0][k]) for k in keys + ["P", "clamp_mask"])
     # the knob forces the fp32 form even with an image: bit-identical to the launch without one
     _C.set_tuning("step_impl", 1)
     try:

@@ -151,7 +151,43 @@ def test_captured_optimizer_tail_matches_the_eager_tail(cuda):
     for other in (1, 2):
         torch.testing.assert_close(res[0][0], res[other][0], rtol=1e-4, atol=1e-6)
         for a, b in zip(res[0][1], res[other][1]):
-            torch.testing.assert_close(a, b, rtol=2e-3, atol=1e-4)
+            # six Adam steps with the gradients recomputed from the parameters: where a gradient entry is within rounding of
+            # zero the fused capturable kernel and the default Adam move it by up to lr in either direction (both correct), so
+            # the bulk of every tensor is held to (2e-3, 1e-4) and every entry to a few steps of lr; the tails themselves are
+            # compared on FIXED gradients, strictly, in test_captured_tail_equals_the_eager_tail_on_fixed_gradients
+            bad = (a - b).abs() > 1e-4 + 2e-3 * b.abs()
+            assert bad.float().mean() <= 0.01 and float((a - b).abs().max()) <= 3e-2, (float(bad.float().mean()), float((a - b).abs().max()))
+
+
+def test_captured_tail_equals_the_eager_tail_on_fixed_gradients(cuda):
+    """The second graph of CapturedStaticWindow (grad / world, fused capturable Adam, window index) against the default Adam
+    stepping eagerly, both fed the SAME sequence of well-conditioned gradients (|g| in [1e-3, 1], nothing near Adam's eps):
+    parameters agree to 1e-6 after five steps -- the tails are the same update rule."""
+    from stgraph_amd import temporal
+    n, e, T, B = 2000, 16000, 8, 4
+    g, ew, targets, gen = _setup(cuda, n, e, T, 6)
+    res = []
+    for captured in (True, False):
+        torch.manual_seed(2)
+        model = temporal.STGraphTGCN(32, 64, 1).to(cuda)
+        opt = (torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True) if captured
+               else torch.optim.Adam(model.parameters(), lr=1e-2))
+        bucket = temporal.GradBucket(model.parameters())
+        if captured:
+            cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, 32)
+            assert cw.step_graph is not None
+        gg = torch.Generator(device=cuda).manual_seed(11)
+        for step in range(5):
+            mag = torch.rand(bucket.flat.shape, device=cuda, generator=gg) * (1 - 1e-3) + 1e-3
+            sign = torch.where(torch.rand(bucket.flat.shape, device=cuda, generator=gg) < 0.5, -1.0, 1.0)
+            bucket.flat.copy_(mag * sign)
+            if captured:
+                cw.step_graph.replay()
+            else:
+                opt.step()
+        res.append([p.detach().clone() for p in model.parameters()])
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=0, atol=1e-6)
 
 
 @pytest.mark.parametrize("kind,full", [("naive_resident", False), ("naive_rebuild", False), ("pcsr", False),

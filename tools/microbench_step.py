@@ -77,6 +77,18 @@ def main():
                               R=out["R"], Ht=out["Ht"], H=H, Hn=out["Hn"], x3=None, clamp_mask=out["clamp_mask"], y_out=out["y_out"], target=tgt,
                               WzT=T["Wz"], WrT=T["Wr"], WhT=T["Wh"], Wcat=p["Wcat"], W1T=T["W1"], W2=p["W2"], **bo)
     res = {"N": n, "E": e, "waves": args.waves or "auto", "step_fwd_us": timed(fwd), "step_bwd_us": timed(bwd)}
+    # the matrix-core form of the same two launches (csrc/tgcn_stepx_*.hip): a weight image in the argument block
+    Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
+    bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
+    img_f, img_b = kernels.tgcn_pack_weights_x3(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"], p["W1"], p["b1"],
+                                                p["W2"], p["b2"])
+    res["pack_weights_x3_us"] = timed(lambda: kernels.tgcn_pack_weights_x3(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"],
+                                                                           p["bh"], p["W1"], p["b1"], p["W2"], p["b2"]))
+    out["w_image"], bo["w_image"] = img_f, img_b
+    fwd()                                                          # the mask in the matrix-core layout for its backward twin
+    res["stepx_fwd_us"], res["stepx_bwd_us"] = timed(fwd), timed(bwd)
+    del out["w_image"], bo["w_image"]
+    fwd()
 
     # ablations: which phase costs what
     def fwd_variant(head, gather):
