@@ -872,7 +872,7 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
     temporal.train_epoch_static_captured(cw, model, g, ew, targets_c, opt, bucket, feat, epoch=99, rank=rank, world=world)
     barrier()
     wall_ev = time.perf_counter() - tw0
-    cw.run = run_plain
+    del cw.run                  # back to the class's method (an instance attribute holding the object's own bound method is a cycle)
     dev_busy_s = sum(a.elapsed_time(b) for a, b in ev) * 1e-3
     bucket.check_views()
     fused = bool(model.temporal.fuse_gates)

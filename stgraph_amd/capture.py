@@ -11,7 +11,29 @@ and nothing inside synchronises (the C ABI never does; see include/stgraph_hip.h
 """
 from __future__ import annotations
 
+import contextlib
+import gc
+
 import torch
+
+
+@contextlib.contextmanager
+def capture(graph: "torch.cuda.CUDAGraph", **kw):
+    """``torch.cuda.graph(graph)`` with Python's cyclic garbage collector kept out of the capture.  A dead reference cycle that
+    holds another ``CUDAGraph`` (an object that stored its own bound method, a closure that names its owner ...) is freed
+    whenever the collector happens to run -- and destroying a HIP graph while a stream of the process is capturing is an error
+    the runtime reports from a destructor: the process aborts (torch 2.10 no longer collects before a capture).  So: collect
+    once before, no collection during."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
 
 
 class CapturedTrainStep:
@@ -34,7 +56,7 @@ class CapturedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with capture(self.graph):
             self.loss = step_fn()
         with torch.no_grad():
             for p, s in zip(params, saved):

@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from .capture import capture as _graph_capture
 from .nn import functional as SF
 from .nn.pytorch.temporal.tgcn import TGCN
 
@@ -654,7 +655,7 @@ def _capture_tail_graph(tail, in_graph, dev, bucket, group, what: str):
     torch.cuda.synchronize(dev)
     g = torch.cuda.CUDAGraph()
     try:
-        with torch.cuda.graph(g):
+        with _graph_capture(g):
             tail()
     except RuntimeError as err:
         if not in_graph[0]:
@@ -669,7 +670,7 @@ def _capture_tail_graph(tail, in_graph, dev, bucket, group, what: str):
         if not bool(torch.isfinite(probe).all()):
             raise RuntimeError(f"{what}: the eager all-reduce after the failed capture returned non-finite values") from err
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with _graph_capture(g):
             tail()
     return g
 
@@ -748,7 +749,7 @@ class CapturedStaticWindow:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with _graph_capture(self.graph):
             body()
         bucket.zero()
 
@@ -985,7 +986,7 @@ class CapturedDynamicWindows:
             g._ndata.clear()                     # per-timestamp norms of an eager epoch: recomputed inside the graph
         torch.cuda.synchronize(self.dev)
         cg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cg):
+        with _graph_capture(cg):
             self.costs[w] = self._body(w)
         if rebuild:
             for t in self.timestamps(w):         # tensors of the graph's private pool: not for eager readers

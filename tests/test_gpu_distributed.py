@@ -51,7 +51,7 @@ def _worker(rank, world, port, outdir):
 
         def run_recording(w, timed_comm=False):            # the averaged gradient every optimizer step consumed
             r = run_plain(w, timed_comm)
-            if len(grads) < 3:
+            if len(grads) < 2:                             # (the third step of an epoch holds the ragged window: it runs eagerly)
                 grads.append(bucket.flat.detach().clone().cpu())
             return r
         cw.run = run_recording
@@ -132,7 +132,7 @@ def test_two_ranks_captured_static_windows_equal_single_process(cuda):
     steps = (temporal.num_windows(T, B) + world - 1) // world * EPOCHS
     for r in range(world):
         assert res[r]["calls"] == steps                    # ONE all-reduce per optimizer step
-        assert len(res[r]["grads"]) == len(want_grads) == 3
+        assert len(res[r]["grads"]) == 2 and len(want_grads) >= 2
         for k, (got, want) in enumerate(zip(res[r]["grads"], want_grads)):
             _grads_close(got, want, k)                     # the gradients themselves: strict (the bucket's flat order = parameters())
         np.testing.assert_allclose(res[r]["losses"].numpy(), torch.stack(want_losses[r]).numpy(), rtol=2e-4, atol=1e-6)
