@@ -280,9 +280,17 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_wide_long_kernel(
 {
     __shared__ __attribute__((aligned(16))) float tile[kWideTileAlloc];
     const int t = (int)threadIdx.x;
-    const int PT = F_active >> 2;                                   // 16-byte pieces per row (F_active % 4 == 0: host)
-    // work items = (row, slice), longest rows first: rows_by_degree[0 .. n16) in 16 slices, the next n4 in 4, the next n1 whole
-    for (int item = (int)blockIdx.x; item < 16 * n16 + 4 * n4 + n1; item += (int)gridDim.x) {
+    // Columns in super-blocks of at most 256 floats (any F_active >= 4): nsb of them, equal widths that are multiples of 4 except the
+    // last.  A super-block of Ws floats is PT = ceil(Ws / 4) 16-byte pieces; when Ws % 4 != 0 the LAST piece is the window that
+    // starts at Ws - 4 (gfx950 loads 16 bytes at any dword address), so up to three features are formed twice -- the same sums,
+    // the same stores.
+    const int nsb = (F_active + 255) / 256;
+    const int sbw = 4 * ((F_active + 4 * nsb - 1) / (4 * nsb));
+    // work items = (row, slice, super-block), longest rows first: rows_by_degree[0 .. n16) in 16 slices, the next n4 in 4, the next n1 whole
+    for (int item0 = (int)blockIdx.x; item0 < (16 * n16 + 4 * n4 + n1) * nsb; item0 += (int)gridDim.x) {
+        const int sb = item0 % nsb, item = item0 / nsb;
+        const int c0 = sb * sbw, Ws = min(sbw, F_active - c0);
+        const int PT = (Ws + 3) >> 2;
         int i, slice, fs;
         if (item < 16 * n16) {
             i = item >> 4, slice = item & 15, fs = 16;
@@ -295,13 +303,15 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_wide_long_kernel(
         const int r = rows_by_degree[i];
         const int beg = row_offsets[r];
         const int deg = row_offsets[r + 1] - beg;                   // block-uniform
-        if (deg <= 0) continue;
+        if (deg <= 0 || Ws < 4) continue;
         while (fs > 1 && PT / fs < 2) fs >>= 1;                     // a slice is at least one 32-byte sector wide
         if (slice >= fs) continue;
         const int pp = (PT + fs - 1) / fs;
-        const int p0 = slice * pp, P = min(pp, PT - p0);            // this slice: pieces [p0, p0 + P), P <= 64 (host)
+        const int p0 = slice * pp, P = min(pp, PT - p0);            // this slice: pieces [p0, p0 + P), P <= 64
         if (P <= 0) continue;
-        const int Wc = 4 * P, f0 = 4 * p0;
+        const int Wc = 4 * P;
+        // first float (inside the super-block) of piece q of this slice: the super-block's last piece may be the overlapping window
+        auto piece_f = [&](int q) { return (p0 + q == PT - 1 && (Ws & 3)) ? Ws - 4 : 4 * (p0 + q); };
         const int ER = kBlock / P;                                  // edges per gather round
         int rounds = min(kWideMaxRounds, min(1024, kWideTileFloats / Wc) / ER);
         if (rounds < 1) rounds = 1;
@@ -340,7 +350,10 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_wide_long_kernel(
                 v[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
                 nc[rr] = ncn[rr];
                 w[rr] = wn[rr];
-                if (rr < rounds) v[rr] = *reinterpret_cast<const float4 *>(x + (int64_t)cn[rr] * F + f0 + 4 * min(piece, P - 1));
+                if (rr < rounds) {
+                    const stg_f4u u4 = *reinterpret_cast<const stg_f4u *>(x + (int64_t)cn[rr] * F + c0 + piece_f(min(piece, P - 1)));
+                    v[rr] = make_float4(u4.x, u4.y, u4.z, u4.w);
+                }
             }
         };
         float acc = 0.f;
@@ -403,12 +416,13 @@ __global__ __launch_bounds__(kBlock) void gcn_agg_wide_long_kernel(
             __syncthreads();
         }
         if (t < Wc) {
+            const int f = c0 + piece_f(t >> 2) + (t & 3);            // the feature this tile row holds
             float o = acc * norm_row[r];                             // Mul(., norm_cen)
             if constexpr (EPI) {
-                if (bias) o = o + bias[f0 + t];
+                if (bias) o = o + bias[f];
                 if (act == STG_ACT_RELU) o = o < 0.f ? 0.f : o;
             }
-            out[(int64_t)r * F + f0 + t] = o;
+            out[(int64_t)r * F + f] = o;
         }
     }
 }
@@ -1151,15 +1165,15 @@ void launch(const GcnArgs &a)
     if constexpr (PRE && LOG2G == 6) {
         // rows of a whole wave and wider: hubs above 1024 edges go to feature-sliced workgroups (gcn_agg_wide_long_kernel)
         const int64_t items = 16 * (int64_t)a.hub_n16 + 4 * (int64_t)a.hub_n4 + a.hub_n1;
-        if (a.rows_by_degree && items > 0 && a.hub_threshold > 0 && tuning().gcn_wide_long != 1 && a.F_active % 4 == 0 &&
-            a.F % 4 == 0 && a.F_active <= 256) {
+        if (a.rows_by_degree && items > 0 && a.hub_threshold > 0 && tuning().gcn_wide_long != 1 && a.F_active >= 4) {
             // The hubs' workgroups run BESIDE the main kernel when a helper stream is available: forked and joined through two
             // events (a stream capture records them as graph edges).  Only graphs WITH hubs pay the fork.
             SideStream *ss = tuning().gcn_wide_long == 2 ? nullptr : side_stream();
             hipStream_t wide_stream = a.stream;
             if (ss && hipEventRecord(ss->fork, a.stream) == hipSuccess && hipStreamWaitEvent(ss->stream, ss->fork, 0) == hipSuccess)
                 wide_stream = ss->stream;
-            hipLaunchKernelGGL((gcn_agg_wide_long_kernel<HAS_EW, EPI>), dim3((unsigned)std::min<int64_t>(items, 1 << 20)), dim3(kBlock), 0,
+            const int64_t witems = items * ((a.F_active + 255) / 256);            // x column super-blocks of <= 256 floats
+            hipLaunchKernelGGL((gcn_agg_wide_long_kernel<HAS_EW, EPI>), dim3((unsigned)std::min<int64_t>(witems, 1 << 20)), dim3(kBlock), 0,
                                wide_stream, a.x, a.norm_row, a.norm_col, a.ew, a.out, a.row_offsets, a.column_indices, a.rows_by_degree,
                                a.N, a.F, a.F_active, a.bias, a.act, a.hub_n16, a.hub_n4, a.hub_n1);
             main_kernel(std::false_type{}, blocks, a.rows_by_degree, 0, a.hub_threshold);

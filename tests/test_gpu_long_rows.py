@@ -149,12 +149,15 @@ def hub_graph(seed, n, hub_degrees, bulk_edges):
 
 
 @pytest.mark.parametrize("F,use_ew,epilogue", [(128, False, False), (128, True, False), (128, False, True), (256, True, False),
-                                               (64, False, False), (200, False, False)])
+                                               (64, False, False), (200, False, False), (100, False, False), (300, False, False),
+                                               (300, True, True), (131, False, False), (257, True, False), (1030, False, True)])
 def test_wide_hub_rows_bit_exact(cuda, F, use_ew, epilogue):
     """Rows of a whole wave and wider (F >= 128) with hubs of 50 000 / 20 000 / 5 000 / 1 500 / 1 025 / 1 024 in-edges:
-    the feature-sliced long-row workgroups (gcn_agg_wide_long_kernel: 16 / 4 / 1 slices by row length) give the oracle's
-    sequential sums bit for bit, forward and backward CSR, with edge weights and with the layer epilogue; F = 64 (the
-    one-wave long-row path) and F = 200 (the main kernel: 200 / 4 pieces fit, 200 <= 256) ride along."""
+    the feature-sliced long-row workgroups (gcn_agg_wide_long_kernel: 16 / 4 / 1 slices by row length, columns in super-blocks
+    of <= 256 floats, a width that is not a multiple of 4 closed by an overlapping 16-byte window) give the oracle's sequential
+    sums bit for bit, forward and backward CSR, with edge weights and with the layer epilogue -- for EVERY width: 300 and
+    1030 (several super-blocks), 131 / 257 (not multiples of 4; 257 leaves a 125-float second super-block); F = 64 and 100
+    (the one-wave long-row path of narrower rows) ride along."""
     from stgraph_amd import kernels
     from stgraph_amd.graph import StaticGraph
     n = 60_000

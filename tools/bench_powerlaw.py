@@ -41,7 +41,7 @@ def timed(fn, iters=10):
 
 def main():
     dev = torch.device("cuda", 0)
-    n, e, F = 1_000_000, 16_000_000, 128
+    n, e, F = 1_000_000, 16_000_000, int(sys.argv[1]) if len(sys.argv) > 1 else 128       # width: any (round 4: 300, 131 ...)
     out = {"N": n, "F": F}
     x = torch.randn(n, F, device=dev)
     for name in ("uniform", "power_law"):
