@@ -649,7 +649,7 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
     # every kernel against the roofline that bounds it: the dense ones (fc + projection epilogue, the split-K weight
     # gradients, row GEMMs) against the fp32 matrix rate (157.3 TFLOP/s: v_mfma_f32_*_f32, the guide's F32 row), the
     # gather / elementwise ones against HBM on the bytes they actually MOVE
-    dense = ("gat_fc", "gemm_tn", "gemm_tn_multi", "rowgemm", "rowgemm_wide")
+    dense = ("gat_fc", "gat_fc_out", "gemm_tn", "gemm_tn_multi", "rowgemm", "rowgemm_wide")
     ktab = {}
     for k, v in tab.items():
         ms = float(np.mean(v["ms"]))
@@ -677,9 +677,23 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
                                 "frac": moved / ktab["gat_bwd"]["mean_ms"] / 1e6 / HBM_PEAK_GBS,
                                 "bytes_are": "moved by the factored form (one E*H*D gather)",
                                 "emitted_unit_bytes_SURVEY_8d": emitted})
-    ab = kernels.gat_algorithmic_bytes(n, e, H, D)
+    if "gat_k1_scored" in ktab:
+        ktab["gat_k1_scored"].update({"note": "the full-width K1 that replaces the result when some score is inf / NaN: the "
+                                              "device flag says none is, the launch returns at once (bytes: the flag)"})
+    if "gat_k1_uniform" in ktab:
+        ktab["gat_k1_uniform"].update({
+            "bytes_are": "moved: K1 at the input width (all scores finite: out = (mean of x over in-neighbours) W^T, the "
+                         "product is gat_fc_out)",
+            "emitted_unit_bytes_SURVEY_8d": kernels.gat_algorithmic_bytes(n, e, H, D)["gat_k1"],
+            "emitted_unit_equivalent_GBps": kernels.gat_algorithmic_bytes(n, e, H, D)["gat_k1"] / 1e6 / (
+                ktab["gat_k1_uniform"]["mean_ms"] + ktab.get("gat_fc_out", {}).get("mean_ms", 0.0))})
     moved_layer = sum(v["bytes"] * v["launches_per_iter"] for v in ktab.values())
-    k1 = ktab.get("gat_k1", {})
+    hbm_kernels = {k: v for k, v in ktab.items() if v["bound"] == "hbm"}
+    dom_name = max(hbm_kernels, key=lambda k: hbm_kernels[k]["mean_ms"] * hbm_kernels[k]["launches_per_iter"])
+    k1 = ktab[dom_name]
+    dom_symbol = {"gat_k1": "stg::gat_k1_kernel", "gat_k1_uniform": "stg::gat_k1_kernel",
+                  "gat_bwd": "stg::gat_bwd_fact_h8d64_kernel (+ its per-vertex prepass stg::gat_bwd_prepass_h8d64_kernel, "
+                             "one C-ABI call: stg_gat_bwd_factored)"}.get(dom_name, dom_name)
     layer = {"ms_per_fwd_bwd": dt * 1e3, "edges_feat_per_s": 2 * e * H * D / dt, "kernels": ktab}
     del conv, x, R
     torch.cuda.empty_cache()
@@ -736,7 +750,8 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
             "eager": modes["eager"], "hip_graph": modes["hip_graph"],
             "edges_feat_per_s": ef_epoch / sec, "final_loss": modes["hip_graph"]["final_loss"],
             "layer": layer,
-            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": "stg::gat_k1_kernel",
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": dom_symbol,
+                         "kernel_is": "the layer's dominant launch by time (layer.kernels has every one)",
                          "achieved": k1.get("achieved_GBps"),
                          "frac": k1.get("frac"),
                          "algorithmic_bytes_per_launch": k1.get("bytes"),

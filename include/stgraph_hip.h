@@ -29,7 +29,7 @@ extern "C" {
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added.
  *  22: stg_tgcn_step_*_args gain `w_image` (last field); stg_tgcn_pack_weights_x3, stg_tgcn_step_image_bytes; knob "step_impl". */
-#define STG_ABI_VERSION 22
+#define STG_ABI_VERSION 23
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -462,6 +462,37 @@ int stg_gat_bwd_factored(const float *A, const float *S, const float *out, const
 int stg_gat_bwd_er(const float *T, float *grad_er,
                    const int32_t *row_offsets, const int32_t *eids, const int32_t *node_ids,
                    int32_t N, int32_t H, int32_t H_active, void *stream);
+
+/* The uniform-attention form of the layer (ABI 23).  The vertex function's `emb - max([emb])` is emb - emb (reference
+ * nn/pytorch/static/gat_conv.py:50): with every score finite (*ones_flag == 0, stg_gat_score_flag) each
+ * A is 1.0f and K1 is out[v] = sum_u (1.0f / S[v]) * feat[u] with feat = x W^T -- linear in x, so the gather can run
+ * at the INPUT width:
+ *   stg_gat_fwd_k1_uniform : xm[v, 0..F) = sum_{u in in(v)} (1.0f / S[v*H]) * x[u, 0..F)  (K1's own loop, one "head" of F
+ *                            columns; S [N,H] from K0, all H equal).  Runs only if *ones_flag == 0, else returns at once.
+ *   stg_gat_fc_out         : out = xm W^T (the kernel of stg_gat_fc_fwd without the projections; same shape support),
+ *                            and, when act_out != NULL, act_out = elu(out) beside it (torch's elu, alpha 1: x <= 0 ?
+ *                            exp(x) - 1 : x) -- the layer's `activation`.
+ *   stg_gat_fwd_k1_scored  : the full-width K1 (stg_gat_fwd_k1 over all H*D columns) that OVERWRITES out (and act_out,
+ *                            nullable) when *ones_flag != 0 -- some score is inf / NaN -- and returns at once otherwise.
+ * Launched in this order the three leave exactly K1's result for non-finite scores and sum-then-product instead of
+ * product-then-sum (fp32 rounding, ~1e-7 relative) for finite ones, at 1/8 of the gather bytes for 64 -> 8 x 64.
+ * stg_gat_bwd_factored_elu: stg_gat_bwd_factored for a layer whose output went through that elu: g_act is the gradient
+ * of elu(out); the per-vertex pass forms g_pre = g_act * (out <= 0 ? exp(out) : 1) (torch's elu_backward), stores it in
+ * g_pre [N, H*D] and everything downstream uses it. */
+int stg_gat_fwd_k1_uniform(const float *S, int32_t H, const float *x, float *xm, const int32_t *row_offsets,
+                           const int32_t *column_indices, const int32_t *node_ids, int32_t N, int32_t F,
+                           const int32_t *ones_flag, void *stream);
+int stg_gat_fc_out(const float *xm, const float *W, float *out, float *act_out, int32_t N, int32_t fin, int32_t H,
+                   int32_t D, void *stream);
+int stg_gat_fwd_k1_scored(const float *A, const float *S, const float *feat, float *out, float *act_out,
+                          const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
+                          const int32_t *node_ids, int32_t N, int32_t H, int32_t D, const int32_t *ones_flag,
+                          void *stream);
+int stg_gat_bwd_factored_elu(const float *A, const float *S, const float *out, const float *g_act, float *g_pre,
+                             const float *feat, float *grad_feat, float *grad_el, float *T, float *P,
+                             const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
+                             const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope, float *grad_er,
+                             const int32_t *ones_flag, void *stream);
 
 /* ------------------------------------------------- dense neighbour: weight gradient
  * C[M,N] = A[K,M]^T * B[K,N], all fp32 row-major [dev]; K = number of vertices (large), M, N =

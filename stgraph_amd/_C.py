@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "stg_jit_compile", "stg_jit_free", "stg_jit_load", "stg_jit_get_function", "stg_jit_unload", "stg_jit_launch",
     "stg_gcn_agg", "stg_gcn_agg_edge", "stg_gcn_layer_fwd", "stg_gcn_agg_edge2", "stg_bias_act_fwd", "stg_bias_act_bwd_workspace_bytes", "stg_bias_act_bwd",
     "stg_gcn_agg_transform", "stg_edge_gather_f32", "stg_gat_score_flag", "stg_gat_fwd_k0", "stg_gat_fwd_k1", "stg_gat_bwd", "stg_gat_bwd_factored", "stg_gat_bwd_er",
+    "stg_gat_fwd_k1_uniform", "stg_gat_fc_out", "stg_gat_fwd_k1_scored", "stg_gat_bwd_factored_elu",
     "stg_gat_fc_supported", "stg_gat_fc_fwd", "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32", "stg_gemm_tn_relu_mask_f32",
     "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_tgcn_pack_weights_x3", "stg_tgcn_step_image_bytes", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
@@ -200,6 +201,14 @@ def _load() -> ctypes.CDLL:
     lib.stg_gat_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, f32, vp, vp]
     lib.stg_gat_bwd_factored.restype = ctypes.c_int
     lib.stg_gat_bwd_factored.argtypes = [vp] * 13 + [i32, i32, i32, f32, vp, vp, vp]
+    lib.stg_gat_bwd_factored_elu.restype = ctypes.c_int
+    lib.stg_gat_bwd_factored_elu.argtypes = [vp] * 14 + [i32, i32, i32, f32, vp, vp, vp]
+    lib.stg_gat_fwd_k1_uniform.restype = ctypes.c_int
+    lib.stg_gat_fwd_k1_uniform.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.stg_gat_fc_out.restype = ctypes.c_int
+    lib.stg_gat_fc_out.argtypes = [vp] * 4 + [i32] * 4 + [vp]
+    lib.stg_gat_fwd_k1_scored.restype = ctypes.c_int
+    lib.stg_gat_fwd_k1_scored.argtypes = [vp] * 9 + [i32, i32, i32, vp, vp]
     lib.stg_gat_bwd_er.restype = ctypes.c_int
     lib.stg_gat_bwd_er.argtypes = [vp] * 5 + [i32, i32, i32, vp]
     lib.stg_gat_proj_supported.restype = ctypes.c_int

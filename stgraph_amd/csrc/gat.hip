@@ -131,19 +131,30 @@ __global__ __launch_bounds__(kBlock) void gat_k0_kernel(
 }
 
 // ------------------------------------------------------------------------------ K1
+enum { kK1Always = 0, kK1IfUniform = 1, kK1UnlessUniform = 2 };
+
+// torch's elu (alpha = 1) as its device kernel forms it: x <= 0 ? exp(x) - 1 : x
+__device__ __forceinline__ float elu1(float x) { return x <= 0.f ? expf(x) - 1.0f : x; }
+// ... and its elu_backward from the pre-activation value: g * (x <= 0 ? exp(x) : 1)
+__device__ __forceinline__ float elu1_bwd(float g, float x) { return x <= 0.f ? g * expf(x) : g; }
+
 template <int VEC, int LOG2G, int CHUNKS, int UNROLL>
 __global__ __launch_bounds__(kBlock) void gat_k1_kernel(
     const float *__restrict__ A, const float *__restrict__ S, const float *__restrict__ feat,
     float *__restrict__ out, const int *__restrict__ row_offsets,
     const int *__restrict__ column_indices, const int *__restrict__ eids,
-    const int *__restrict__ node_ids, int N, int H, int D, int HD_active, const int *__restrict__ flag)
+    const int *__restrict__ node_ids, int N, int H, int D, int HD_active, const int *__restrict__ flag,
+    int s_stride, int when, float *__restrict__ act_out)
 {
     constexpr int G = 1 << LOG2G;
     constexpr int U = UNROLL < G ? UNROLL : G;
     const int j = threadIdx.x & (G - 1);
     const int HD = H * D;
-    const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
     const bool ones = all_ones(flag);
+    // when: kK1Always | kK1IfUniform (the narrow-width pass of the uniform-attention form: only meaningful when every
+    // A is 1.0f) | kK1UnlessUniform (the full-width pass that replaces its result otherwise): kernel-uniform exits
+    if ((when == kK1IfUniform && !ones) || (when == kK1UnlessUniform && ones)) return;
+    const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
 
     for (int fbase = 0; fbase < HD_active; fbase += G * VEC * CHUNKS) {
         float acc[CHUNKS][VEC];
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void gat_k1_kernel(
             foff[ch] = fbase + (ch * G + j) * VEC;
             fok[ch] = foff[ch] < HD_active;
             hh[ch] = fok[ch] ? foff[ch] / D : 0;
-            sv[ch] = (ri.valid && fok[ch]) ? S[(int64_t)ri.r * H + hh[ch]] : 1.f;
+            sv[ch] = (ri.valid && fok[ch]) ? S[(int64_t)ri.r * s_stride + hh[ch]] : 1.f;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[ch][i] = 0.f;
         }
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void gat_k1_kernel(
             int c = 0, ev = 0;
             if (j < cnt) {
                 c = column_indices[ri.beg + base + j];
-                ev = eids[ri.beg + base + j];
+                if (!ones) ev = eids[ri.beg + base + j];
             }
             for (int k = 0; k < cnt_max; k += U) {
                 float v[U][CHUNKS][VEC];
@@ -209,6 +220,17 @@ __global__ __launch_bounds__(kBlock) void gat_k1_kernel(
 #pragma unroll
             for (int ch = 0; ch < CHUNKS; ++ch)
                 if (fok[ch]) vec_store<VEC>(orow + foff[ch], acc[ch]);
+            if (act_out) {                                   // kernel-uniform: the layer's ELU beside the pre-activation rows
+                float *arow = act_out + (int64_t)ri.r * HD;
+#pragma unroll
+                for (int ch = 0; ch < CHUNKS; ++ch) {
+                    if (!fok[ch]) continue;
+                    float y[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) y[i] = elu1(acc[ch][i]);
+                    vec_store<VEC>(arow + foff[ch], y);
+                }
+            }
         }
     }
 }
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_kernel(
 template <int VEC, int LOG2G, int CHUNKS, bool POW2>
 __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_kernel(
     const float *__restrict__ S, const float *__restrict__ outp, const float *__restrict__ g,
-    float *__restrict__ P, int N, int H, int D, float *__restrict__ grad_er, float slope)
+    float *__restrict__ P, int N, int H, int D, float *__restrict__ grad_er, float slope, float *__restrict__ g_pre)
 {
     float *__restrict__ invS = P + (int64_t)N * H;
     constexpr int G = 1 << LOG2G;
@@ -391,6 +413,11 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_kernel(
                 float gv[VEC], ov[VEC];
                 vec_load<VEC>(gv, g + (int64_t)v * HD + foff);
                 vec_load<VEC>(ov, outp + (int64_t)v * HD + foff);
+                if (g_pre) {                          // kernel-uniform: g is the gradient of elu(out); see elu1_bwd
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gv[i] = elu1_bwd(gv[i], ov[i]);
+                    vec_store<VEC>(g_pre + (int64_t)v * HD + foff, gv);
+                }
                 const float s = S[(int64_t)v * H + h];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -526,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
 // row sums, valid in each row's lane 0) back.  T and grad_el leave as 32 contiguous bytes from lanes 0-7.
 __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_h8d64_kernel(
     const float *__restrict__ S, const float *__restrict__ outp, const float *__restrict__ g,
-    float *__restrict__ pack, int N, float *__restrict__ grad_er, float slope)
+    float *__restrict__ pack, int N, float *__restrict__ grad_er, float slope, float *__restrict__ g_pre)
 {
     constexpr int H = 8, HD = 512;
     const int lane = threadIdx.x & (kWave - 1);
@@ -539,6 +566,11 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_prepass_h8d64_kernel(
         float gv[4], ov[4];
         vec_load<4>(gv, g + (int64_t)v * HD + ch * 256 + lane * 4);
         vec_load<4>(ov, outp + (int64_t)v * HD + ch * 256 + lane * 4);
+        if (g_pre) {                                  // kernel-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gv[i] = elu1_bwd(gv[i], ov[i]);
+            vec_store<4>(g_pre + (int64_t)v * HD + ch * 256 + lane * 4, gv);
+        }
         // this lane's head: 4 ch + lane / 16; its S from lane (4 ch + lane / 16)
         const float sh = __int_as_float(__builtin_amdgcn_ds_bpermute((4 * ch + (lane >> 4)) * 4, __float_as_int(s)));
         float p = 0.f, q = 0.f;
@@ -745,18 +777,20 @@ extern "C" int stg_gat_fwd_k0(const float *el, const float *er, float *A, float 
     return check_launch("stg_gat_fwd_k0");
 }
 
-extern "C" int stg_gat_fwd_k1(const float *A, const float *S, const float *feat, float *out,
-                              const int32_t *row_offsets, const int32_t *column_indices,
-                              const int32_t *eids, const int32_t *node_ids, int32_t N, int32_t H,
-                              int32_t D, int32_t HD_active, const int32_t *ones_flag, void *stream)
+namespace stg {
+namespace {
+// One K1 launch: out[N, H*D] = sum_e (A / S[row * s_stride + head]) * feat[u]; `when` and `act_out` as in the kernel.
+int launch_k1(const char *what, const float *A, const float *S, int s_stride, const float *feat, float *out, float *act_out,
+              const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids, const int32_t *node_ids,
+              int32_t N, int32_t H, int32_t D, int32_t HD_active, const int32_t *ones_flag, int when, void *stream)
 {
-    using namespace stg;
     if (N < 0 || H <= 0 || D <= 0 || HD_active < 0 || (int64_t)HD_active > (int64_t)H * D)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k1: bad shape N=%d H=%d D=%d HD_active=%d", N, H, D, HD_active);
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad shape N=%d H=%d D=%d HD_active=%d", what, N, H, D, HD_active);
     if (N == 0 || HD_active == 0) return 0;
-    if (!S || !feat || !out || !row_offsets)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k1: NULL pointer argument");
-    const uintptr_t align = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out);
+    if (!S || !feat || !out || !row_offsets || (when != kK1Always && !ones_flag))
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
+    const uintptr_t align = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
+                            reinterpret_cast<uintptr_t>(act_out);
     const FeatPlan p = plan_features(H * D, D, HD_active, align, false);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define STG_K1(VEC, CH, UN)                                                                              \
@@ -764,7 +798,7 @@ extern "C" int stg_gat_fwd_k1(const float *A, const float *S, const float *feat,
                      hipLaunchKernelGGL((gat_k1_kernel<VEC, (CH > 1 ? 6 : LG), CH, UN>),                 \
                                         dim3(grid_for(N, (CH > 1 ? 6 : LG))), dim3(kBlock), 0, st, A, S, \
                                         feat, out, row_offsets, column_indices, eids, node_ids, N, H, D, \
-                                        HD_active, ones_flag))
+                                        HD_active, ones_flag, s_stride, when, act_out))
 #define STG_K1_VEC(VEC)                          \
     if (p.chunks == 4) { STG_K1(VEC, 4, 2); }    \
     else if (p.chunks == 2) { STG_K1(VEC, 2, 4); } \
@@ -772,7 +806,38 @@ extern "C" int stg_gat_fwd_k1(const float *A, const float *S, const float *feat,
     if (p.vec == 4) { STG_K1_VEC(4) } else if (p.vec == 2) { STG_K1_VEC(2) } else { STG_K1_VEC(1) }
 #undef STG_K1_VEC
 #undef STG_K1
-    return check_launch("stg_gat_fwd_k1");
+    return check_launch(what);
+}
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_gat_fwd_k1(const float *A, const float *S, const float *feat, float *out,
+                              const int32_t *row_offsets, const int32_t *column_indices,
+                              const int32_t *eids, const int32_t *node_ids, int32_t N, int32_t H,
+                              int32_t D, int32_t HD_active, const int32_t *ones_flag, void *stream)
+{
+    return stg::launch_k1("stg_gat_fwd_k1", A, S, H, feat, out, nullptr, row_offsets, column_indices, eids, node_ids, N,
+                          H, D, HD_active, ones_flag, stg::kK1Always, stream);
+}
+
+extern "C" int stg_gat_fwd_k1_uniform(const float *S, int32_t H, const float *x, float *xm, const int32_t *row_offsets,
+                                      const int32_t *column_indices, const int32_t *node_ids, int32_t N, int32_t F,
+                                      const int32_t *ones_flag, void *stream)
+{
+    if (H <= 0) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k1_uniform: bad H=%d", H);
+    // one "head" of F columns whose S is head 0's of the H real ones (all equal: the in-degree)
+    return stg::launch_k1("stg_gat_fwd_k1_uniform", nullptr, S, H, x, xm, nullptr, row_offsets, column_indices, nullptr,
+                          node_ids, N, 1, F, F, ones_flag, stg::kK1IfUniform, stream);
+}
+
+extern "C" int stg_gat_fwd_k1_scored(const float *A, const float *S, const float *feat, float *out, float *act_out,
+                                     const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
+                                     const int32_t *node_ids, int32_t N, int32_t H, int32_t D,
+                                     const int32_t *ones_flag, void *stream)
+{
+    if (!A || !eids) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fwd_k1_scored: NULL pointer argument");
+    return stg::launch_k1("stg_gat_fwd_k1_scored", A, S, H, feat, out, act_out, row_offsets, column_indices, eids, node_ids,
+                          N, H, D, H * D, ones_flag, stg::kK1UnlessUniform, stream);
 }
 
 extern "C" int stg_gat_bwd(const float *A, const float *S, const float *out, const float *g,
@@ -820,48 +885,51 @@ extern "C" int stg_gat_bwd(const float *A, const float *S, const float *out, con
     return check_launch("stg_gat_bwd");
 }
 
-extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float *out, const float *g,
-                                    const float *feat, float *grad_feat, float *grad_el, float *T,
-                                    float *P, const int32_t *row_offsets,
-                                    const int32_t *column_indices, const int32_t *eids,
-                                    const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope,
-                                    float *grad_er, const int32_t *ones_flag, void *stream)
+namespace stg {
+namespace {
+// g_pre == nullptr: g is the gradient of `out`.  Otherwise g is the gradient of elu(out): the per-vertex pass turns it
+// into the gradient of `out` on the way (it reads g and out anyway), leaves that in g_pre, and the edge pass gathers g_pre.
+int bwd_factored(const char *what, const float *A, const float *S, const float *out, const float *g, float *g_pre,
+                 const float *feat, float *grad_feat, float *grad_el, float *T, float *P, const int32_t *row_offsets,
+                 const int32_t *column_indices, const int32_t *eids, const int32_t *node_ids, int32_t N, int32_t H,
+                 int32_t D, float slope, float *grad_er, const int32_t *ones_flag, void *stream)
 {
-    using namespace stg;
     if (N < 0 || H <= 0 || D <= 0)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_factored: bad shape N=%d H=%d D=%d", N, H, D);
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: bad shape N=%d H=%d D=%d", what, N, H, D);
     if (N == 0) return 0;
     if (!S || !out || !g || !feat || !grad_feat || !grad_el || !P || !row_offsets || (!T && !grad_er))
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_factored: NULL pointer argument (T or grad_er must be given)");
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument (T or grad_er must be given)", what);
     const uintptr_t align = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
-                            reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(grad_feat);
+                            reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(grad_feat) |
+                            reinterpret_cast<uintptr_t>(g_pre);
     const FeatPlan p = plan_features(H * D, D, H * D, align, true);
     const int LH = D / p.vec;
     const bool pow2 = (LH & (LH - 1)) == 0 && LH <= (1 << p.log2g);
     if (LH > kWave || (!pow2 && (H * D + p.vec - 1) / p.vec > kWave))
         return fail(STG_ERR_UNSUPPORTED,
-                    "stg_gat_bwd_factored: head width D=%d (H=%d) is outside the supported range "
-                    "(D/vec <= 64; non power-of-two D/vec needs H*D/vec <= 64)", D, H);
+                    "%s: head width D=%d (H=%d) is outside the supported range "
+                    "(D/vec <= 64; non power-of-two D/vec needs H*D/vec <= 64)", what, D, H);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *gq = g_pre ? g_pre : g;               // what the edge pass gathers
     if (H == 8 && D == 64 && p.vec == 4) {
         hipLaunchKernelGGL(gat_bwd_prepass_h8d64_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)),
-                           dim3(kBlock), 0, st, S, out, g, P, N, grad_er, slope);
-        hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, P, g, feat,
+                           dim3(kBlock), 0, st, S, out, g, P, N, grad_er, slope, g_pre);
+        hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, P, gq, feat,
                            grad_feat, grad_el, T, row_offsets, column_indices, eids, node_ids, N, slope, ones_flag);
-        return check_launch("stg_gat_bwd_factored");
+        return check_launch(what);
     }
 #define STG_K2F(VEC, CH, UN, P2)                                                                           \
     STG_SWITCH_LOG2G(p.chunks > 1 ? 6 : p.log2g, {                                                         \
         constexpr int LGE = (CH > 1 ? 6 : LG);                                                             \
         hipLaunchKernelGGL((gat_bwd_prepass_kernel<VEC, LGE, CH, P2>), dim3(grid_for(N, LGE)), dim3(kBlock), \
-                           0, st, S, out, g, P, N, H, D, grad_er, slope);                                  \
+                           0, st, S, out, g, P, N, H, D, grad_er, slope, g_pre);                                  \
         if (P2 && LH == 16 && LGE >= 4)                                                                    \
             hipLaunchKernelGGL((gat_bwd_fact_kernel<VEC, LGE, CH, UN, P2, true>), dim3(grid_for(N, LGE)),  \
-                               dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,  \
+                               dim3(kBlock), 0, st, A, S, P, gq, feat, grad_feat, grad_el, T, row_offsets,  \
                                column_indices, eids, node_ids, N, H, D, slope, ones_flag);                 \
         else                                                                                               \
             hipLaunchKernelGGL((gat_bwd_fact_kernel<VEC, LGE, CH, UN, P2, false>), dim3(grid_for(N, LGE)), \
-                               dim3(kBlock), 0, st, A, S, P, g, feat, grad_feat, grad_el, T, row_offsets,  \
+                               dim3(kBlock), 0, st, A, S, P, gq, feat, grad_feat, grad_el, T, row_offsets,  \
                                column_indices, eids, node_ids, N, H, D, slope, ones_flag);                 \
     })
     /* two-chunk rows (H*D = 512 at cfg3): unroll 2, not 4 -- 101 -> 80-odd VGPRs buys a fifth and sixth wave per   \
@@ -877,7 +945,33 @@ extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float 
     }
 #undef STG_K2F_VEC
 #undef STG_K2F
-    return check_launch("stg_gat_bwd_factored");
+    return check_launch(what);
+}
+
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_gat_bwd_factored(const float *A, const float *S, const float *out, const float *g,
+                                    const float *feat, float *grad_feat, float *grad_el, float *T,
+                                    float *P, const int32_t *row_offsets,
+                                    const int32_t *column_indices, const int32_t *eids,
+                                    const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope,
+                                    float *grad_er, const int32_t *ones_flag, void *stream)
+{
+    return stg::bwd_factored("stg_gat_bwd_factored", A, S, out, g, nullptr, feat, grad_feat, grad_el, T, P, row_offsets,
+                             column_indices, eids, node_ids, N, H, D, slope, grad_er, ones_flag, stream);
+}
+
+extern "C" int stg_gat_bwd_factored_elu(const float *A, const float *S, const float *out, const float *g_act, float *g_pre,
+                                        const float *feat, float *grad_feat, float *grad_el, float *T,
+                                        float *P, const int32_t *row_offsets,
+                                        const int32_t *column_indices, const int32_t *eids,
+                                        const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope,
+                                        float *grad_er, const int32_t *ones_flag, void *stream)
+{
+    if (!g_pre) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_factored_elu: NULL g_pre");
+    return stg::bwd_factored("stg_gat_bwd_factored_elu", A, S, out, g_act, g_pre, feat, grad_feat, grad_el, T, P,
+                             row_offsets, column_indices, eids, node_ids, N, H, D, slope, grad_er, ones_flag, stream);
 }
 
 extern "C" int stg_gat_bwd_er(const float *T, float *grad_er, const int32_t *row_offsets,

@@ -20,20 +20,24 @@ namespace {
 constexpr int kFcWaves = 16;
 constexpr int kFcCT = 8;             // column tiles (of 16) per pass = 128 columns = two heads of 64
 
-template <int FIN>
+// PROJ: the attention projections in the epilogue (the layer's input side).  !PROJ: the plain product, optionally with
+// elu(product) written beside it (act_out; the layer's OUTPUT side in its uniform-attention form, see stg_gat_fc_out).
+template <int FIN, bool PROJ>
 __global__ __launch_bounds__(kFcWaves * 64) void gat_fc_kernel(
     const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ attn_l,
     const float *__restrict__ attn_r, float *__restrict__ feat, float *__restrict__ el, float *__restrict__ er,
-    int N, int H)
+    int N, int H, float *__restrict__ act_out)
 {
     constexpr int NT = kFcWaves * 64, LD = FIN + 8, J = FIN / 16, D = 64;     // 8 mod 16 dwords: conflict-free ds_read_b128 (tgcn_step.hpp)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int HD = H * D;
     float *Wl = lds, *al = Wl + HD * LD, *ar = al + HD;
     stage_rows<NT>(Wl, LD, W, HD, FIN);
-    for (int i = threadIdx.x; i < HD; i += NT) {
-        al[i] = attn_l[i];
-        ar[i] = attn_r[i];
+    if constexpr (PROJ) {
+        for (int i = threadIdx.x; i < HD; i += NT) {
+            al[i] = attn_l[i];
+            ar[i] = attn_r[i];
+        }
     }
     __syncthreads();
 
@@ -59,11 +63,23 @@ __global__ __launch_bounds__(kFcWaves * 64) void gat_fc_kernel(
             for (int ct = 0; ct < kFcCT; ++ct) {
                 const int col = g * 128 + ct * 16;
                 if (ok) *reinterpret_cast<float4 *>(frow + col) = to_f4(acc[ct]);
+                if constexpr (!PROJ) {
+                    if (ok && act_out) {                      // kernel-uniform; torch's elu: x <= 0 ? exp(x) - 1 : x
+                        float4 y;
+                        y.x = acc[ct][0] <= 0.f ? expf(acc[ct][0]) - 1.0f : acc[ct][0];
+                        y.y = acc[ct][1] <= 0.f ? expf(acc[ct][1]) - 1.0f : acc[ct][1];
+                        y.z = acc[ct][2] <= 0.f ? expf(acc[ct][2]) - 1.0f : acc[ct][2];
+                        y.w = acc[ct][3] <= 0.f ? expf(acc[ct][3]) - 1.0f : acc[ct][3];
+                        *reinterpret_cast<float4 *>(act_out + (int64_t)row * HD + 4 * kq + col) = y;
+                    }
+                    continue;
+                }
                 const float4 a = *reinterpret_cast<const float4 *>(al + col + 4 * kq);
                 const float4 b = *reinterpret_cast<const float4 *>(ar + col + 4 * kq);
                 pl[ct >> 2] += acc[ct][0] * a.x + acc[ct][1] * a.y + acc[ct][2] * a.z + acc[ct][3] * a.w;
                 pr[ct >> 2] += acc[ct][0] * b.x + acc[ct][1] * b.y + acc[ct][2] * b.z + acc[ct][3] * b.w;
             }
+            if constexpr (!PROJ) continue;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 float l = pl[h2], r = pr[h2];
@@ -92,17 +108,18 @@ inline bool fc_shape_ok(int fin, int H, int D)
 
 extern "C" int stg_gat_fc_supported(int32_t fin, int32_t H, int32_t D) { return stg::fc_shape_ok(fin, H, D) ? 1 : 0; }
 
-extern "C" int stg_gat_fc_fwd(const float *x, const float *W, const float *attn_l, const float *attn_r, float *feat,
-                              float *el, float *er, int32_t N, int32_t fin, int32_t H, int32_t D, void *stream)
+namespace stg {
+namespace {
+int fc_launch(const char *what, bool proj, const float *x, const float *W, const float *attn_l, const float *attn_r,
+              float *feat, float *el, float *er, float *act_out, int32_t N, int32_t fin, int32_t H, int32_t D, void *stream)
 {
-    using namespace stg;
     if (N < 0 || !fc_shape_ok(fin, H, D))
-        return fail(STG_ERR_UNSUPPORTED, "stg_gat_fc_fwd: unsupported shape N=%d fin=%d H=%d D=%d", N, fin, H, D);
+        return fail(STG_ERR_UNSUPPORTED, "%s: unsupported shape N=%d fin=%d H=%d D=%d", what, N, fin, H, D);
     if (N == 0) return 0;
-    if (!x || !W || !attn_l || !attn_r || !feat || !el || !er)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fc_fwd: NULL pointer argument");
+    if (!x || !W || !feat || (proj && (!attn_l || !attn_r || !el || !er)))
+        return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
     if ((int64_t)N * H * D > 0x7fffffffll * 4)
-        return fail(STG_ERR_UNSUPPORTED, "stg_gat_fc_fwd: N * H * D too large");
+        return fail(STG_ERR_UNSUPPORTED, "%s: N * H * D too large", what);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = fc_lds_bytes(fin, H);
     int dev = 0, cus = 256;
@@ -115,15 +132,31 @@ extern "C" int stg_gat_fc_fwd(const float *x, const float *W, const float *attn_
         if (!*done) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return fail((int)e, "stg_gat_fc_fwd: %s", hipGetErrorString(e));
+            if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
             *done = true;
         }
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kFcWaves * 64), lds, st, x, W, attn_l, attn_r, feat, el,
-                           er, N, H);
+                           er, N, H, act_out);
         return 0;
     };
-    static PerDeviceOnce once32, once64;
-    const int rc = fin == 32 ? go(gat_fc_kernel<32>, once32) : go(gat_fc_kernel<64>, once64);
+    static PerDeviceOnce once32p, once64p, once32, once64;
+    const int rc = proj ? (fin == 32 ? go(gat_fc_kernel<32, true>, once32p) : go(gat_fc_kernel<64, true>, once64p))
+                        : (fin == 32 ? go(gat_fc_kernel<32, false>, once32) : go(gat_fc_kernel<64, false>, once64));
     if (rc) return rc;
-    return check_launch("stg_gat_fc_fwd");
+    return check_launch(what);
+}
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_gat_fc_fwd(const float *x, const float *W, const float *attn_l, const float *attn_r, float *feat,
+                              float *el, float *er, int32_t N, int32_t fin, int32_t H, int32_t D, void *stream)
+{
+    return stg::fc_launch("stg_gat_fc_fwd", true, x, W, attn_l, attn_r, feat, el, er, nullptr, N, fin, H, D, stream);
+}
+
+extern "C" int stg_gat_fc_out(const float *xm, const float *W, float *out, float *act_out, int32_t N, int32_t fin,
+                              int32_t H, int32_t D, void *stream)
+{
+    return stg::fc_launch("stg_gat_fc_out", false, xm, W, nullptr, nullptr, out, nullptr, nullptr, act_out, N, fin, H, D,
+                          stream);
 }

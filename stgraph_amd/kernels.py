@@ -965,6 +965,70 @@ def gat_fwd(el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor, csr: DeviceC
     return out, A, S
 
 
+_GAT_UNIFORM = True
+
+
+def set_gat_uniform_form(on: bool) -> None:
+    """True (default): a fused GATConv whose input is narrower than its H*D output runs K1 in the uniform-attention form
+    (:func:`gat_fwd_uniform`); False: K1 at full width always (tests compare the two)."""
+    global _GAT_UNIFORM
+    _GAT_UNIFORM = bool(on)
+
+
+def gat_uniform_usable(x: torch.Tensor, H: int, D: int) -> bool:
+    fin = int(x.shape[1])
+    return (_GAT_UNIFORM and _GAT_ONES and not reference_compat() and fin < H * D and gat_fc_supported(fin, H, D)
+            and active_columns(H) == H and active_columns(H * D) == H * D and x.data_ptr() % 16 == 0)
+
+
+def gat_fwd_uniform(x: torch.Tensor, W: torch.Tensor, el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor,
+                    csr: DeviceCSR, slope: float, use_node_ids: bool = False, elu: bool = False):
+    """K0 + K1 of a layer whose ``feat = x @ W.T`` ([N, fin] -> [N, H, D], fin < H*D), in the uniform-attention form
+    (stgraph_hip.h, ABI 23).  ``emb - max([emb])`` is +0 for every finite score (reference gat_conv.py:50, SURVEY.md
+    D2), every A is then 1.0f and K1 is the in-neighbour mean of ``feat`` -- linear in x: the gather runs over x at
+    width fin (stg_gat_fwd_k1_uniform, K1's own loop) and the product with W follows (stg_gat_fc_out, which also writes
+    ``elu(out)`` when asked).  A device flag decides: with any non-finite score the narrow pass returns at once and the
+    full-width K1 (stg_gat_fwd_k1_scored) overwrites the result -- the emitted unit's bits.  Returns (out, act, A, S);
+    ``act`` is None unless ``elu``.  A's content is only valid when the flag is set (see :func:`gat_fwd`)."""
+    x = _f32(x, "x")
+    dev = x.device
+    N, fin = x.shape
+    feat = _f32(feat, "feat_src", dev)
+    _, H, D = feat.shape
+    W = _f32(W, "fc.weight", dev)
+    el, er = _f32(el, "el", dev), _f32(er, "er", dev)
+    if N != csr.num_nodes or feat.shape[0] != N or tuple(W.shape) != (H * D, fin) or el.numel() != N * H or er.numel() != N * H:
+        raise ValueError("gat_fwd_uniform: x [N, fin], W [H*D, fin], feat [N, H, D], el / er [N, H, 1] must match the graph")
+    if csr.row_offset.device != dev:
+        raise RuntimeError(f"graph arrays are on {csr.row_offset.device}, features on {dev}")
+    E = csr.num_edges
+    A = torch.empty((E, H, 1), dtype=torch.float32, device=dev)
+    S = torch.empty((N, H, 1), dtype=torch.float32, device=dev)
+    xm = torch.empty((N, fin), dtype=torch.float32, device=dev)
+    out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
+    act = torch.empty((N, H, D), dtype=torch.float32, device=dev) if elu else None
+    nid = _ptr(csr.node_ids_if_ready if use_node_ids else None)
+    ab = gat_algorithmic_bytes(N, E, H, D)
+    idx = 4 * (N + 1) + 4 * E
+    with torch.cuda.device(dev):
+        st = _stream_ptr(dev)
+        flag = torch.empty(1, dtype=torch.int32, device=dev)
+        _C.check(_C.lib.stg_gat_score_flag(_ptr(el), _ptr(er), N * H, _ptr(flag), st))
+        with _Timed("gat_k0", ab["gat_k0"], E * H):
+            _C.check(_C.lib.stg_gat_fwd_k0(_ptr(el), _ptr(er), _ptr(A), _ptr(S), _ptr(csr.row_offset),
+                                           _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, H, float(slope), _ptr(flag), st))
+        with _Timed("gat_k1_uniform", 4 * E * fin + 8 * N * fin + 4 * N + idx, E * fin):
+            _C.check(_C.lib.stg_gat_fwd_k1_uniform(_ptr(S), H, _ptr(x), _ptr(xm), _ptr(csr.row_offset),
+                                                   _ptr(csr.column_indices), nid, N, fin, _ptr(flag), st))
+        with _Timed("gat_fc_out", 4 * N * (fin + (2 if elu else 1) * H * D) + 4 * H * D * fin, 2 * N * fin * H * D):
+            _C.check(_C.lib.stg_gat_fc_out(_ptr(xm), _ptr(W), _ptr(out), _ptr(act), N, fin, H, D, st))
+        with _Timed("gat_k1_scored", 4, 0):
+            _C.check(_C.lib.stg_gat_fwd_k1_scored(_ptr(A), _ptr(S), _ptr(feat), _ptr(out), _ptr(act), _ptr(csr.row_offset),
+                                                  _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, D, _ptr(flag), st))
+    A._stg_ones = flag
+    return out, act, A, S
+
+
 _GAT_FACTORED = True
 
 
@@ -987,8 +1051,12 @@ def set_gat_regrouped_er(on: bool) -> None:
 
 
 def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: float,
-            use_node_ids: bool = False):
-    """Backward unit K2 (+ the dst-major grad_er pass).  Returns (grad_feat, grad_el, grad_er)."""
+            use_node_ids: bool = False, elu: bool = False):
+    """Backward unit K2 (+ the dst-major grad_er pass).  Returns (grad_feat, grad_el, grad_er).
+
+    ``elu``: ``g`` is the gradient of ``elu(out)`` (a layer whose activation was fused, :func:`gat_fwd_uniform`): the
+    factored form turns it into the gradient of ``out`` inside its per-vertex pass (stg_gat_bwd_factored_elu); the
+    literal form gets it from torch's elu_backward first."""
     feat = _f32(feat, "feat_src")
     dev = feat.device
     N, H, D = feat.shape
@@ -1014,14 +1082,21 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
         with _Timed("gat_bwd", ab["gat_bwd"], E * H * D):
             if full and _GAT_FACTORED:
                 P = torch.empty((N, 2 * H), dtype=torch.float32, device=dev)    # scratch: P and 1 / S (or S)
-                _C.check(_C.lib.stg_gat_bwd_factored(
-                    _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(feat), _ptr(grad_feat), _ptr(grad_el), _ptr(T),
-                    _ptr(P), _ptr(bwd.row_offset), _ptr(bwd.column_indices), _ptr(bwd.eids),
-                    _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, H, D, float(slope),
-                    _ptr(grad_er if regrouped else None), _ptr(flag), st))
+                tail = (_ptr(P), _ptr(bwd.row_offset), _ptr(bwd.column_indices), _ptr(bwd.eids),
+                        _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, H, D, float(slope),
+                        _ptr(grad_er if regrouped else None), _ptr(flag), st)
+                if elu:
+                    g_pre = torch.empty_like(g)
+                    _C.check(_C.lib.stg_gat_bwd_factored_elu(_ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(g_pre), _ptr(feat),
+                                                             _ptr(grad_feat), _ptr(grad_el), _ptr(T), *tail))
+                else:
+                    _C.check(_C.lib.stg_gat_bwd_factored(_ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(feat), _ptr(grad_feat),
+                                                         _ptr(grad_el), _ptr(T), *tail))
                 if regrouped:       # grad_er came out of the per-vertex pass (sum of T over in-edges, regrouped): no T, no
                     return grad_feat, grad_el, grad_er                            # dst-major pass over it
             else:
+                if elu:
+                    g = torch.ops.aten.elu_backward(g, 1.0, 1.0, 1.0, False, out)
                 _C.check(_C.lib.stg_gat_bwd(
                     _ptr(A), _ptr(S), _ptr(out), _ptr(g), _ptr(el), _ptr(er), _ptr(feat),
                     _ptr(grad_feat), _ptr(grad_el), _ptr(T), _ptr(bwd.row_offset), _ptr(bwd.column_indices),

@@ -517,18 +517,24 @@ class _GatFcLayer(torch.autograd.Function):
     deferred to the end of backward)."""
 
     @staticmethod
-    def forward(ctx, x, w, attn_l, attn_r, fwd_csr, bwd_csr, use_nid, slope, H, D):
+    def forward(ctx, x, w, attn_l, attn_r, fwd_csr, bwd_csr, use_nid, slope, H, D, elu):
         feat, el, er = kernels.gat_fc_fwd(x, w, attn_l, attn_r, H, D)
-        out, A, S = kernels.gat_fwd(el, er, feat, fwd_csr, slope, use_nid, ones_shortcut=True)
-        ctx.save_for_backward(x, w, feat, attn_l, attn_r, el, er, A, S, out)
-        ctx.csrs, ctx.use_nid, ctx.slope, ctx.w = (fwd_csr, bwd_csr), use_nid, slope, w
-        return out
+        if kernels.gat_uniform_usable(x, H, D):
+            # K1 at the input width, then the product with W (and the layer's elu in its epilogue)
+            out, act, A, S = kernels.gat_fwd_uniform(x, w, el, er, feat, fwd_csr, slope, use_nid, elu)
+        else:
+            out, A, S = kernels.gat_fwd(el, er, feat, fwd_csr, slope, use_nid, ones_shortcut=True)
+            act = F.elu(out) if elu else None
+        ctx.save_for_backward(x, w, feat, attn_l, attn_r, el, er, A, S, out)     # `out`: the pre-activation rows
+        ctx.csrs, ctx.use_nid, ctx.slope, ctx.w, ctx.elu = (fwd_csr, bwd_csr), use_nid, slope, w, bool(elu)
+        return act if elu else out
 
     @staticmethod
     def backward(ctx, g):
         x, w, feat, attn_l, attn_r, el, er, A, S, out = ctx.saved_tensors
         fwd_csr, bwd_csr = ctx.csrs
-        gf, gel, ger = kernels.gat_bwd(A, S, out, g.contiguous(), el, er, feat, fwd_csr, bwd_csr, ctx.slope, ctx.use_nid)
+        gf, gel, ger = kernels.gat_bwd(A, S, out, g.contiguous(), el, er, feat, fwd_csr, bwd_csr, ctx.slope, ctx.use_nid,
+                                       elu=ctx.elu)
         dfeat, dal, dar = kernels.gat_proj_bwd(feat, attn_l, attn_r, gel, ger, gf, inplace=True)
         g2 = dfeat.view(dfeat.shape[0], -1)
         gx = kernels.matmul(g2, w) if ctx.needs_input_grad[0] else None
@@ -541,7 +547,7 @@ class _GatFcLayer(torch.autograd.Function):
                                        colsum_sink=None)
             else:
                 gw = kernels.gemm_tn(g2, x) if native else torch.mm(g2.t(), x)
-        return gx, gw, dal.view_as(attn_l), dar.view_as(attn_r), None, None, None, None, None, None
+        return gx, gw, dal.view_as(attn_l), dar.view_as(attn_r), None, None, None, None, None, None, None
 
 
 def gat_fc_layer_usable(graph, x: torch.Tensor, fc, H: int, D: int) -> bool:
@@ -554,9 +560,18 @@ def gat_fc_layer_usable(graph, x: torch.Tensor, fc, H: int, D: int) -> bool:
             and kernels.gat_fc_supported(x.shape[1], H, D) and kernels.gat_proj_supported(H, D))
 
 
-def gat_fc_layer(graph, x: torch.Tensor, fc, attn_l, attn_r, slope: float, H: int, D: int) -> torch.Tensor:
+def gat_fc_layer(graph, x: torch.Tensor, fc, attn_l, attn_r, slope: float, H: int, D: int, elu: bool = False) -> torch.Tensor:
+    """``elu``: return ``F.elu`` of the layer's result (the caller's ``activation``, see :func:`is_elu`), formed in the
+    epilogue of the producing kernel and differentiated inside the backward unit's per-vertex pass."""
     return _GatFcLayer.apply(x, fc.weight, attn_l, attn_r, graph.csr("fwd"), graph.csr("bwd"),
-                             kernels.rows_by_node_ids(graph.graph_type()), float(slope), int(H), int(D))
+                             kernels.rows_by_node_ids(graph.graph_type()), float(slope), int(H), int(D), bool(elu))
+
+
+def is_elu(activation) -> bool:
+    """A GATConv ``activation`` that is exactly ``F.elu`` with its defaults (alpha = 1, out of place)."""
+    if activation is F.elu or activation is torch.nn.functional.elu:
+        return True
+    return isinstance(activation, torch.nn.ELU) and activation.alpha == 1.0 and not activation.inplace
 
 
 _GAT_FC = True

@@ -47,9 +47,10 @@ class GATConv(nn.Module):
         if SF.gat_fc_layer_usable(graph, h_src, self.fc, self._num_heads, self._out_feats):
             # the fc GEMM with the attention projections in its epilogue, the GAT units, and all of it backward, as
             # one autograd node (stg_gat_fc_fwd)
+            elu = SF.is_elu(self.activation)        # ... and F.elu in the same node (stg_gat_fc_out / the backward prepass)
             rst = SF.gat_fc_layer(graph, h_src, self.fc, self.attn_l, self.attn_r, self.negative_slope,
-                                  self._num_heads, self._out_feats)
-            return self.activation(rst) if self.activation else rst
+                                  self._num_heads, self._out_feats, elu)
+            return self.activation(rst) if self.activation and not elu else rst
         # self.fc through functional.linear: same Linear, wide outputs in 128-column slices of the row GEMM (rocBLAS'
         # tile choice for [N, in] x [in, H*D] costs 3x its M = 128 launches), weight gradient on the split-K MFMA kernel
         feat_src = feat_dst = SF.linear(h_src, self.fc.weight, self.fc.bias).view(-1, self._num_heads, self._out_feats)

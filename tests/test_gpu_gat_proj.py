@@ -122,3 +122,104 @@ def test_gatconv_with_fused_input_side_equals_the_unfused_layer(cuda, fin, H):
                     conv.fc.weight.grad.clone()))
     for a, b, name in zip(res[0], res[1], ("out", "x", "attn_l", "attn_r", "fc.weight")):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max() + 1), msg=lambda m, n=name: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("fin,H", [(64, 8), (32, 4)])
+@pytest.mark.parametrize("act", ["elu", "none", "elu_module", "tanh"])
+def test_uniform_attention_form_equals_the_full_width_layer(cuda, fin, H, act):
+    """The layer with K1 at the input width + product (+ fused elu, and its backward inside the per-vertex pass) against
+    the same layer with K1 at full width and torch's elu around it: forward and every gradient."""
+    import torch.nn.functional as F
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    D, n, e = 64, 5003, 60000
+    src, dst = random_graph(7 * H + fin, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    torch.manual_seed(5)
+    activation = {"elu": F.elu, "none": None, "elu_module": torch.nn.ELU(), "tanh": torch.tanh}[act]   # smooth ones: a kink would flip on rounding
+    assert SF.is_elu(activation) == act.startswith("elu") and not SF.is_elu(torch.nn.ELU(alpha=0.5))
+    conv = GATConv(fin, D, H, activation=activation).to(cuda)
+    x0 = torch.randn(n, fin, device=cuda)
+    R = torch.randn(n, H, D, device=cuda)
+    res = []
+    for uniform in (True, False):
+        kernels.set_gat_uniform_form(uniform)
+        try:
+            assert kernels.gat_uniform_usable(x0, H, D) == uniform
+            rec = []
+            kernels.enable_launch_timing(rec)
+            conv.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            out = conv(g, x)
+            out.backward(R)
+        finally:
+            kernels.enable_launch_timing(None)
+            kernels.set_gat_uniform_form(True)
+        names = {r[0] for r in rec}
+        assert ("gat_k1_uniform" in names) == uniform and ("gat_k1" in names) == (not uniform), names
+        res.append((out.detach().clone(), x.grad.clone(), conv.attn_l.grad.clone(), conv.attn_r.grad.clone(),
+                    conv.fc.weight.grad.clone()))
+    for a, b, name in zip(res[0], res[1], ("out", "x", "attn_l", "attn_r", "fc.weight")):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max() + 1), msg=lambda m, n=name: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("elu", [True, False])
+def test_uniform_form_with_a_non_finite_score_is_the_emitted_unit_bit_for_bit(cuda, elu):
+    """One inf in el: the device flag is set, the narrow pass returns at once and the full-width K1 overwrites out (and
+    its elu) -- exactly gat_fwd's result; with finite scores the narrow pass's mean of x is K1's own sum at width fin."""
+    import torch.nn.functional as F
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    fin, H, D, n, e = 64, 8, 64, 4099, 50000
+    src, dst = random_graph(11, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    csr = g.csr("fwd")
+    gen = torch.Generator(device=cuda).manual_seed(9)
+    x = torch.randn(n, fin, device=cuda, generator=gen)
+    W = torch.randn(H * D, fin, device=cuda, generator=gen) / 8
+    al, ar = torch.randn(H, D, device=cuda, generator=gen), torch.randn(H, D, device=cuda, generator=gen)
+    feat, el, er = kernels.gat_fc_fwd(x, W, al, ar, H, D)
+    for bad in (True, False):
+        el2 = el.clone()
+        if bad:
+            el2[int(src[0]), 3, 0] = float("inf")
+        want, A0, S0 = kernels.gat_fwd(el2, er, feat, csr, 0.2, False, ones_shortcut=True)
+        out, act, A, S = kernels.gat_fwd_uniform(x, W, el2, er, feat, csr, 0.2, False, elu)
+        assert int(A._stg_ones.item()) == int(bad)
+        torch.testing.assert_close(S, S0, rtol=0, atol=0)
+        if bad:
+            assert not torch.isfinite(want).all()
+            torch.testing.assert_close(out, want, rtol=0, atol=0, equal_nan=True)
+            torch.testing.assert_close(A, A0, rtol=0, atol=0, equal_nan=True)
+        else:
+            torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+            deg = S[:, 0, 0]
+            xm = torch.zeros(n, fin, device=cuda, dtype=torch.float64).index_add_(
+                0, torch.as_tensor(dst, device=cuda).long(), x.double()[torch.as_tensor(src, device=cuda).long()])
+            xm = xm / deg.double().clamp(min=1).unsqueeze(1)
+            torch.testing.assert_close(out.double().view(n, -1), xm @ W.double().t(), rtol=1e-5, atol=1e-5)
+        if elu:
+            torch.testing.assert_close(act, F.elu(out), rtol=1e-6, atol=1e-7, equal_nan=True)
+        else:
+            assert act is None
+
+
+def test_factored_backward_with_fused_elu_equals_elu_backward_then_the_unit(cuda):
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    for H, D in ((8, 64), (4, 16)):
+        n, e = 3001, 30000
+        src, dst = random_graph(13 + H, n, e)
+        g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+        gen = torch.Generator(device=cuda).manual_seed(H)
+        feat = torch.randn(n, H, D, device=cuda, generator=gen)
+        el, er = torch.randn(n, H, 1, device=cuda, generator=gen), torch.randn(n, H, 1, device=cuda, generator=gen)
+        out, A, S = kernels.gat_fwd(el, er, feat, g.csr("fwd"), 0.2, False, ones_shortcut=True)
+        gy = torch.randn(n, H, D, device=cuda, generator=gen)
+        got = kernels.gat_bwd(A, S, out, gy, el, er, feat, g.csr("fwd"), g.csr("bwd"), 0.2, False, elu=True)
+        gpre = torch.ops.aten.elu_backward(gy, 1.0, 1.0, 1.0, False, out)
+        want = kernels.gat_bwd(A, S, out, gpre, el, er, feat, g.csr("fwd"), g.csr("bwd"), 0.2, False)
+        for a, b, name in zip(got, want, ("grad_feat", "grad_el", "grad_er")):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max() + 1), msg=lambda m, n=name: f"{n}: {m}")
