@@ -120,6 +120,12 @@ int rowgemm16_launch(const float *X, const float *W, const float *bias, float *Y
     return relu ? rowgemm16_launch2<K, M, false, true>(X, W, bias, Y, N, st, ldy) : rowgemm16_launch2<K, M, false, false>(X, W, bias, Y, N, st, ldy);
 }
 
+// the 3-term bf16 split on the matrix cores (rowgemm_x3.hip) pays once the launch is long enough to be matrix-bound
+inline bool rowgemm_x3_wanted(int64_t N, int K)
+{
+    return N * K < ((int64_t)1 << 30) && (tuning().rowgemm_x3 >= 2 || (tuning().rowgemm_x3 == 0 && N >= 65536));
+}
+
 // shapes the row-piece kernel is instantiated for (the dense layers of the GCN / GAT configs)
 inline bool rowgemm16_shape(int K, int M) { return (K == 128 && M == 128) || (K == 64 && M == 128) || (K == 128 && M == 64) || (K == 64 && M == 64); }
 
@@ -311,6 +317,7 @@ extern "C" int stg_rowgemm_act_f32(const float *X, const float *W, const float *
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_f32: X, W and Y must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool tw = trans_w != 0, relu = act == STG_ACT_RELU;
+    if (rowgemm_x3_wanted(N, K)) return rowgemm_x3_launch(K, M, X, W, bias, Y, N, tw, relu, stream, M);
     if (K == 128 && M == 128) return rowgemm16_launch<128, 128>(X, W, bias, Y, N, tw, relu, st, M);
     if (K == 64 && M == 128) return rowgemm16_launch<64, 128>(X, W, bias, Y, N, tw, relu, st, M);
     if (K == 128 && M == 64) return rowgemm16_launch<128, 64>(X, W, bias, Y, N, tw, relu, st, M);
@@ -341,6 +348,7 @@ extern "C" int stg_rowgemm_strided_f32(const float *X, const float *W, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (rowgemm16_shape(K, M) && N >= 4096 && ldy % 4 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 && tuning().rowgemm16 != 1) {
         const bool tw = trans_w != 0;
+        if (rowgemm_x3_wanted(N, K)) return rowgemm_x3_launch(K, M, X, W, bias, Y, N, tw, false, stream, ldy);
         if (K == 128 && M == 128) return rowgemm16_launch<128, 128>(X, W, bias, Y, N, tw, false, st, ldy);
         if (K == 64 && M == 128) return rowgemm16_launch<64, 128>(X, W, bias, Y, N, tw, false, st, ldy);
         if (K == 128 && M == 64) return rowgemm16_launch<128, 64>(X, W, bias, Y, N, tw, false, st, ldy);

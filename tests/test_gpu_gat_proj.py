@@ -162,7 +162,10 @@ def test_uniform_attention_form_equals_the_full_width_layer(cuda, fin, H, act):
         res.append((out.detach().clone(), x.grad.clone(), conv.attn_l.grad.clone(), conv.attn_r.grad.clone(),
                     conv.fc.weight.grad.clone()))
     for a, b, name in zip(res[0], res[1], ("out", "x", "attn_l", "attn_r", "fc.weight")):
-        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max() + 1), msg=lambda m, n=name: f"{n}: {m}")
+        # attn_r's gradient is slope * (g . out - P S) summed over the vertices: exactly 0 in real arithmetic, rounding noise
+        # of n terms of size |g . out| in either form -- compared on that scale
+        atol = 5e-5 if name == "attn_r" else 1e-5 * float(b.abs().max() + 1)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=atol, msg=lambda m, n=name: f"{n}: {m}")
 
 
 @pytest.mark.parametrize("elu", [True, False])
@@ -188,7 +191,7 @@ def test_uniform_form_with_a_non_finite_score_is_the_emitted_unit_bit_for_bit(cu
         want, A0, S0 = kernels.gat_fwd(el2, er, feat, csr, 0.2, False, ones_shortcut=True)
         out, act, A, S = kernels.gat_fwd_uniform(x, W, el2, er, feat, csr, 0.2, False, elu)
         assert int(A._stg_ones.item()) == int(bad)
-        torch.testing.assert_close(S, S0, rtol=0, atol=0)
+        torch.testing.assert_close(S, S0, rtol=0, atol=0, equal_nan=True)
         if bad:
             assert not torch.isfinite(want).all()
             torch.testing.assert_close(out, want, rtol=0, atol=0, equal_nan=True)

@@ -79,3 +79,37 @@ def test_row_piece_kernel_with_its_epilogue(cuda, N, K, M, trans_w, use_bias, re
     wi = (torch.arange(K * M, device=cuda) % 5 - 2).float().view(w.shape)
     wid = wi.double().t() if trans_w else wi.double()
     assert torch.equal(kernels.rowgemm_act(xi, wi, None, trans_w), (xi.double() @ wid).float())
+
+
+@pytest.mark.parametrize("N", [1, 31, 4096, 70_001])
+@pytest.mark.parametrize("K,M", [(128, 128), (64, 128), (128, 64), (64, 64)])
+@pytest.mark.parametrize("trans_w,use_bias,relu", [(False, True, True), (True, False, False), (True, True, False)])
+def test_split_form_on_the_matrix_cores(cuda, N, K, M, trans_w, use_bias, relu):
+    """The same products as three-term bf16 splits on v_mfma_f32_16x16x32_bf16 (rowgemm_x3.hip; the default from 64 K rows,
+    forced here at every N): the fp32 kernel's error bound against fp64, integers exact, and the plain (strided) entry."""
+    from stgraph_amd import _C, kernels
+    gen = torch.Generator(device=cuda).manual_seed(N + K + 2 * M)
+    x = torch.randn(N, K, device=cuda, generator=gen) * torch.exp(3 * torch.randn(N, 1, device=cuda, generator=gen))
+    w = torch.randn((M, K) if trans_w else (K, M), device=cuda, generator=gen)
+    b = torch.randn(M, device=cuda, generator=gen) if use_bias else None
+    wd = w.double().t() if trans_w else w.double()
+    want = x.double() @ wd + (b.double() if use_bias else 0)
+    scale = x.double().abs() @ wd.abs() + 1
+    xi = (torch.arange(N * K, device=cuda) % 7 - 3).float().view(N, K)
+    wi = (torch.arange(K * M, device=cuda) % 5 - 2).float().view(w.shape)
+    wid = wi.double().t() if trans_w else wi.double()
+    _C.set_tuning("rowgemm_x3", 2)
+    try:
+        got = kernels.rowgemm_act(x, w, b, trans_w, kernels.ACT_RELU if relu else kernels.ACT_NONE)
+        goti = kernels.rowgemm_act(xi, wi, None, trans_w)
+        y = torch.full((N, M + 8), 7.0, device=cuda)
+        if N >= 4096:
+            _C.check(_C.lib.stg_rowgemm_strided_f32(x.data_ptr(), w.data_ptr(), b.data_ptr() if use_bias else None, y.data_ptr(),
+                                                    N, K, M, M + 8, int(trans_w), None))
+            torch.cuda.synchronize()
+    finally:
+        _C.set_tuning("rowgemm_x3", 0)
+    assert ((got.double() - (want.relu() if relu else want)).abs() <= 2e-6 * scale).all()
+    assert torch.equal(goti, (xi.double() @ wid).float())
+    if N >= 4096:
+        assert ((y[:, :M].double() - want).abs() <= 2e-6 * scale).all() and bool((y[:, M:] == 7.0).all())

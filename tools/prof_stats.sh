@@ -14,6 +14,6 @@ import csv
 rows=list(csv.DictReader(open("gpurun_out/prof_$tag/kernel_stats.csv")))
 tot=sum(float(r["TotalDurationNs"]) for r in rows); n=sum(int(r["Calls"]) for r in rows)
 print("total kernel ms %.1f calls %d" % (tot/1e6, n))
-for r in rows[:22]:
+for r in rows[:40]:
     print(r["Name"][:90].ljust(90), r["Calls"].rjust(7), ("%.1f"%(float(r["AverageNs"])/1e3)).rjust(9), r["Percentage"])
 PY
