@@ -113,3 +113,46 @@ def test_split_form_on_the_matrix_cores(cuda, N, K, M, trans_w, use_bias, relu):
     assert torch.equal(goti, (xi.double() @ wid).float())
     if N >= 4096:
         assert ((y[:, :M].double() - want).abs() <= 2e-6 * scale).all() and bool((y[:, M:] == 7.0).all())
+
+
+def test_gcn_training_step_with_the_split_products_matches_the_fp32_products(cuda):
+    """A 2-layer GCN (128 -> 128 -> 128, the cfg2 widths) on 70 K vertices -- where the row products take the split form by
+    default -- against the same step with them on the fp32 matrix instruction: loss and every gradient.  A first-layer bias
+    of 30 keeps every pre-activation positive: no ReLU decision hangs on an fp32 rounding (tests/test_gpu_input_layer.py)."""
+    import numpy as np
+    from stgraph_amd import _C, kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gcn_conv import GCNConv
+    from tests.util import gcn_norm, random_graph
+    n, f = 70_001, 128
+    src, dst = random_graph(3, n, 600_000)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    g.set_ndata("norm", torch.from_numpy(gcn_norm(np.bincount(dst, minlength=n))).to(cuda))
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    x = torch.randn(n, f, device=cuda, generator=gen)
+    labels = torch.randint(0, f, (n,), device=cuda, generator=gen)
+    res = []
+    for knob in (0, 1):
+        _C.set_tuning("rowgemm_x3", knob)
+        try:
+            torch.manual_seed(4)
+            layers = torch.nn.ModuleList([GCNConv(f, f, torch.relu), GCNConv(f, f, None)]).to(cuda)
+            with torch.no_grad():
+                layers[0].bias.fill_(30.0)
+            rec = []
+            kernels.enable_launch_timing(rec)
+            h = x
+            for layer in layers:
+                h = layer(g, h)
+            loss = SF.cross_entropy(h, labels, n)
+            loss.backward()
+            kernels.enable_launch_timing(None)
+        finally:
+            kernels.enable_launch_timing(None)
+            _C.set_tuning("rowgemm_x3", 0)
+        assert any(r[0] == "rowgemm" for r in rec), {r[0] for r in rec}
+        res.append((loss.detach().clone(), [p.grad.clone() for p in layers.parameters()]))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=0)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (float((a - b).abs().max()), float(b.abs().max()))
