@@ -28,7 +28,8 @@ extern "C" {
  *   3: stg_xent_fwd / stg_xent_bwd count the rows (ignore_index = -100, n_counted); round-1 changes to
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added.
- *  22: stg_tgcn_step_*_args gain `w_image` (last field); stg_tgcn_pack_weights_x3, stg_tgcn_step_image_bytes; knob "step_impl". */
+ *  22: stg_tgcn_step_*_args gain `w_image` (last field); stg_tgcn_pack_weights_x3, stg_tgcn_step_image_bytes; knob "step_impl".
+ *  23: stg_gat_fwd_k1_uniform, stg_gat_fc_out, stg_gat_fwd_k1_scored, stg_gat_bwd_factored_elu; knob "rowgemm_x3". */
 #define STG_ABI_VERSION 23
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -52,7 +53,10 @@ const char *stg_last_error_string(void);
  * "xw_waves" (0 = auto; 4 / 8 waves per workgroup of stg_gcn_agg_transform), "cell_rows" (0 = auto; 16 / 32 rows
  * per tile of stg_tgcn_cell_fused_fwd), "step_waves" (stg_tgcn_step_*: 0 = auto, 12 / 16 waves per workgroup), "step_impl" (stg_tgcn_step_* given a
  * weight image: 0 = the matrix-core form, 1 = always the fp32 form; the one knob that selects between two ARITHMETICS -- both
- * within 1e-5 of fp64), "step_spread"
+ * within 1e-5 of fp64), "rowgemm_x3" (stg_rowgemm_f32 / _strided_f32 / _act_f32 at K, M in {64, 128} and N K < 2^30: 0 = from 64 K rows
+ * every product as a 3-term bf16 split on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, 1 = always v_mfma_f32_16x16x4_f32, 2 = the
+ * split form at every N, 3 = its lane-owns-row-pieces load / store variant (diagnosis); the second such knob: both forms inside the
+ * fp32 kernel's error bound against fp64, integer data exact in both), "step_spread"
  * (0 = one workgroup per CU when there are fewer tiles than wave slots, 1 = packed grid), "gemm_wide" (tall-skinny weight
  * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_cyclic" (its row-group hand-out: 0 .. 2),
  * "gcn_wide_long" (rows of >= 1024 edges at F >= 128: 0 = feature-sliced workgroups beside the main launch, 1 = never, 2 = behind

@@ -12,6 +12,10 @@
 // workgroup of 16 waves per CU, 16-row tiles dealt wave-major; a tile is 128 output columns (two heads) at a time:
 // 8 accumulators, 128 MFMAs, then the epilogue.  MFMA-bound: 512 MFMAs x 32 cycles per tile and SIMD wave.
 // Results agree with rocBLAS / the unfused pair to fp32 rounding (k order (j, i, kq)); tests: 1e-5 relative.
+//
+// The same kernel without the projections (PROJ = false) is the layer's OUTPUT side in its uniform-attention form
+// (stg_gat_fc_out, ABI 23): out = xm W^T with xm the in-neighbour mean of x (stg_gat_fwd_k1_uniform in gat.hip), and the
+// layer's elu written beside it from the same accumulators.
 #include "tgcn_step.hpp"
 
 namespace stg {

@@ -25,7 +25,8 @@ What is substituted, and why:
      C++ classes inside those .so files through oracle/_ref/libref_shim.so
      (oracle/ref_shim.cpp) and hand out HOST addresses instead of device ones; only
      the pybind glue is replaced.  (Without the shim -- it needs /root/reference --
-     ``CSR`` falls back to oracle.orc_csr_ctor, which tests/test_oracle_ref_shim.py
+     ``CSR`` falls back to oracle.orc_csr_ctor, which
+     tests/test_oracle_pcsr.py::test_csr_oracle_equals_reference_binary
      shows to be identical.)
   3. the nvcc -> PTX -> cuModuleLoad step (code_gen/compiler.py:36-44): the
      CUDA source the reference EMITS is compiled verbatim with g++ behind a
