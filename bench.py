@@ -26,11 +26,12 @@ A "dynamic" object carries BASELINE configs[4] (dynamic-temporal TGCN): epochs/s
 CSR rebuild (its `value`), with every snapshot's CSR resident as the reference's NaiveGraph keeps them (both replayed
 from one HIP graph per BPTT window after an eager epoch; the rebuilds of a window's snapshots share the launches of one build)
 and on the dynamic edge stores (PCSRGraph, GPMAGraph: one merge launch per timestamp inside the same per-window HIP graphs),
-windows sharded over the ranks; `csr_build_share` = 1 - resident / rebuild.
+windows sharded over the ranks; `csr_build_share` = 1 - resident / rebuild.  At N = 1 its `value` is quoted at BASELINE.md's own
+T = 40; the T = 160 stream the multi-rank runs shard is the `T160` sub-object (and the `value` at N > 1).
 
 A "gat" object carries BASELINE configs[2] (GAT, 8 heads, |V| = 256K, |E| = 8M): one GATConv layer forward +
 backward(R) with a per-kernel table, and the 2-layer model of benchmarking/gat/seastar/model.py as epochs/s, eagerly and
-with the whole epoch replayed from a HIP graph (its `value`; rank 0 only).
+with the whole epoch replayed from a HIP graph (its `value`; rank 0 only); its "roofline" names the layer's dominant launch by time.
 
 "roofline": dominant kernel gcn_agg -- algorithmic bytes per launch over its
 mean launch time, measured with HIP events on the launch stream inside the timed region; "traffic" = HBM bytes per
@@ -38,7 +39,9 @@ launch from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate child runs 
 script at N = 1, corrected as the microarchitecture guide prescribes; the committed passes under profiles/ if a child
 run fails).  "roofline.north_star" is the figure the north star's >= 60 % target is stated on: the fused GCN
 aggregation forward + backward at the Cora widths on 1024 replicas of the Cora-shaped graph.  Every config object
-("cora", "gat", "tgcn", "dynamic") carries its own "roofline" with a "frac" and the byte model it is taken against.
+("cora", "gat", "tgcn", "dynamic") carries its own "roofline" whose "frac" is ACHIEVED -- the bytes this build moves over the measured
+time over the peak -- next to the byte model of the reference's formulation, and its own "cpu_baseline" (a bounded sample of the same
+workload in plain torch on the host, with the host's sockets / physical / logical cores).
 "cpu_baseline": the same training epoch (forward, loss, backward, Adam) in plain torch on this host's cores --
 torch.sparse_csr_tensor(A_hat) @ dense, SURVEY.md 8(d) variant (i) -- on a bounded sample (rank 0, N = 1 only), with
 the C oracle's OpenMP aggregation (variant (ii)) beside it; "cora.cpu_baseline" is BASELINE configs[0]'s CPU path.
