@@ -29,8 +29,9 @@ extern "C" {
  *      stg_link_head_fwd (loss_in), stg_tgcn_head_fwd_acc and the xent status contract folded in.
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added.
  *  22: stg_tgcn_step_*_args gain `w_image` (last field); stg_tgcn_pack_weights_x3, stg_tgcn_step_image_bytes; knob "step_impl".
- *  23: stg_gat_fwd_k1_uniform, stg_gat_fc_out, stg_gat_fwd_k1_scored, stg_gat_bwd_factored_elu; knob "rowgemm_x3". */
-#define STG_ABI_VERSION 23
+ *  23: stg_gat_fwd_k1_uniform, stg_gat_fc_out, stg_gat_fwd_k1_scored, stg_gat_bwd_factored_elu; knob "rowgemm_x3".
+ *  24: stg_tgcn_step_fwd_args gains w_fold, b_fold, fold_status (last fields): the folded form of the forward step launch. */
+#define STG_ABI_VERSION 24
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -681,6 +682,16 @@ typedef struct stg_tgcn_step_fwd_args {
      * accumulation -- fp32-class results, 1e-5 of the fp32 form; P bit-identical) unless the knob "step_impl" is 1.  clamp_mask is
      * then written in that form's layout (one byte per row piece) and must be consumed by a backward launch given the backward image. */
     const void *w_image;
+    /* Optional (NULL: not used; ABI 24).  The FOLDED form of the forward launch (csrc/tgcn_stepf_fwd.hip): w_fold [3C][Fin + C], rows
+     * g C + c = [ (Wc_g Wg[:, :C]^T)^T | Wg[:, C:] ] and b_fold [3C] = bc_g Wg[:, :C]^T + bg -- the conv output folded into the gate
+     * Linears, formed once per window by the caller.  With them, x != NULL, node_ids == NULL, head >= 1 and the knob "step_impl"
+     * != 1 every product runs as a 3-term bf16 split on the matrix cores with all weights in LDS.  Same outputs and saved tensors
+     * (x3 and the clamp mask in the fp32 form's layout included: any backward launch may follow); results fp32-class (1e-5 of the
+     * fp32 form).  The fold is only valid while no element of x3 is clamped: if one is, *fold_status |= 1 (sticky, never cleared by
+     * the library) and THAT launch's Z / R / Ht / Hn / HR / y are wrong -- the caller must check it and redo the work without
+     * w_fold.  The three go together. */
+    const float *w_fold, *b_fold;
+    int32_t *fold_status;
 } stg_tgcn_step_fwd_args;
 typedef struct stg_tgcn_step_bwd_args {
     const int32_t *row_offsets, *column_indices, *node_ids;

@@ -11,9 +11,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstgraph_hip.so")
+# STGRAPH_AMD_LIB: a diagnosis build of the same library (tools/diag/build_*_trace.sh); the product never sets it
+LIB_PATH = os.environ.get("STGRAPH_AMD_LIB") or os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -81,7 +82,8 @@ class TgcnStepFwdArgs(ctypes.Structure):
     _fields_ = (_ptr_fields("row_offsets column_indices node_ids norm_col_edge ew_edge norm x a3 H target "
                             "WcatT b3 Wz bz Wr br Wh bh W1 b1 W2 b2 P x3 Z R Ht Hn HR y y_out loss_partial clamp_mask") +
                 [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
-                 ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("w_image", ctypes.c_void_p)])
+                 ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("w_image", ctypes.c_void_p),
+                 ("w_fold", ctypes.c_void_p), ("b_fold", ctypes.c_void_p), ("fold_status", ctypes.c_void_p)])
 
 
 class TgcnStepBwdArgs(ctypes.Structure):

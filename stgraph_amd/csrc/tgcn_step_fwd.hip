@@ -353,6 +353,7 @@ extern "C" int stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh)
 extern "C" size_t stg_tgcn_step_loss_partials(int64_t N) { return N > 0 ? (size_t)((N + 15) / 16) : 0; }
 
 int stg_tgcn_stepx_fwd_launch(const stg_tgcn_step_fwd_args *p, void *stream_);      // tgcn_stepx_fwd.hip
+int stg_tgcn_stepf_fwd_launch(const stg_tgcn_step_fwd_args *p, void *stream_);      // tgcn_stepf_fwd.hip
 
 extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
 {
@@ -364,6 +365,8 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
     if (p->head < 0 || p->head > 2) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: head must be 0, 1 or 2");
     if (p->N == 0) return 0;
     const bool gather = p->x != nullptr;
+    if (p->w_fold && (gather || (!p->a3 && p->P && p->WcatT)) && !p->node_ids && p->head >= 1 && tuning().step_impl == 0)
+        return stg_tgcn_stepf_fwd_launch(p, stream_);
     if (gather ? (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm || !p->WcatT || !p->P) : !p->a3)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL graph / input pointer");
     if (!p->b3 || !p->Wz || !p->bz || !p->Wr || !p->br || !p->Wh || !p->bh || !p->x3 || !p->Z || !p->R || !p->Ht || !p->Hn || !p->HR)
@@ -372,6 +375,7 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
     if (p->head == 2 && (!p->W2 || !p->b2 || !p->y_out || !p->target || !p->loss_partial))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL loss pointer");
     if ((int64_t)p->N * 3 * p->C >= ((int64_t)1 << 30)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_fwd: too many rows for 32-bit offsets");
+
     if (p->w_image && gather && !p->node_ids && p->head >= 1 && tuning().step_impl == 0) {
         if (reinterpret_cast<uintptr_t>(p->w_image) & 15) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: w_image must be 16-byte aligned");
         return stg_tgcn_stepx_fwd_launch(p, stream_);

@@ -1552,6 +1552,61 @@ def set_step_matrix_core(enabled: bool) -> None:
     STEP_MATRIX_CORE = bool(enabled)
 
 
+# True: the window nodes hand the FORWARD step launch the gate Linears with the conv folded in (tgcn_fold_weights) and it runs in its
+# folded form (csrc/tgcn_stepf_fwd.hip: every product a 3-term bf16 split on the matrix cores, all weights in LDS, one wave per
+# 16-row tile).  The fold is exact only while no conv output is clamped (|.| <= 1e6 always holds on sane data): the launch raises a
+# sticky per-device status word otherwise, which check_step_fold_status() turns into an error.  False (default): measured 51 us
+# against the fp32 form's 56 at cfg4 (profiles/r04_stepf_*.json) -- not enough to make a form with a validity condition the default.
+STEP_FOLDED = False
+
+
+def set_step_folded(enabled: bool) -> None:
+    global STEP_FOLDED
+    STEP_FOLDED = bool(enabled)
+
+
+_FOLD_STATUS = {}
+
+
+def step_fold_status_word(device) -> torch.Tensor:
+    """The device's sticky int32 word the folded step launches OR a 1 into when the fold was not valid."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _FOLD_STATUS.get(key)
+    if t is None:
+        t = _FOLD_STATUS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
+def check_step_fold_status(device=None, clear: bool = True) -> None:
+    """Raise if a folded step launch since the last check met a clamped conv output (its results are then wrong).  Synchronises."""
+    for key, t in list(_FOLD_STATUS.items()):
+        if device is not None:
+            dev = torch.device(device)
+            if key != (dev.type, dev.index if dev.index is not None else torch.cuda.current_device()):
+                continue
+        if int(t.item()) != 0:
+            if clear:
+                t.zero_()
+            raise RuntimeError("a TGCN conv output left [-1e6, 1e6]: the folded step form (reference nn/pytorch/temporal/tgcn.py:23 clamps "
+                               "there) is not valid for this data; results since the last check are wrong -- "
+                               "rerun with stgraph_amd.kernels.set_step_folded(False)")
+
+
+def tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh):
+    """``(w_fold [3C, Fin + C], b_fold [3C])`` for the folded forward step launch: row ``g C + c`` of w_fold is
+    ``[(Wc_g @ Wg[:, :C].T).T[c] | Wg[c, C:]]`` and ``b_fold[g C + c] = (bc_g @ Wg[:, :C].T + bg)[c]`` -- the gate pre-activation
+    ``[P Wc_g + bc_g | H] Wg^T + bg`` as one product of ``[P | H]`` (reference nn/pytorch/temporal/tgcn.py:21-41 without its clamp).
+    A few small torch launches per window."""
+    C = int(Wz.shape[0])
+    rows, bias = [], []
+    for Wc, bc, Wg, bg in ((Wcz, bcz, Wz, bz), (Wcr, bcr, Wr, br), (Wch, bch, Wh, bh)):
+        top = Wg[:, :C]                                         # [C out, C in]
+        rows.append(torch.cat([torch.mm(top, Wc.t()), Wg[:, C:]], dim=1))      # [C, Fin + C]
+        bias.append(torch.addmv(bg, top, bc))
+    return torch.cat(rows, dim=0).contiguous(), torch.cat(bias).contiguous()
+
+
 def tgcn_step_supported(C: int, Fin: int, Fh: int) -> bool:
     return bool(_C.lib.stg_tgcn_step_supported(int(C), int(Fin), int(Fh)))
 
@@ -1576,7 +1631,7 @@ def _fill_step_args(args, what: str, dev: torch.device, tensors: dict) -> None:
                 raise TypeError(f"{what}: w_image must be the uint8 image of tgcn_pack_weights_x3 on {dev}")
             setattr(args, name, t.data_ptr())
             continue
-        want = torch.int32 if name in _STEP_INT_FIELDS or name == "clamp_mask" else torch.float32
+        want = torch.int32 if name in _STEP_INT_FIELDS or name in ("clamp_mask", "fold_status") else torch.float32
         if not torch.is_tensor(t) or t.dtype != want or not t.is_cuda or t.device != dev or not t.is_contiguous():
             raise TypeError(f"{what}: {name} must be a contiguous {want} tensor on {dev}")
         setattr(args, name, t.data_ptr())
@@ -1629,7 +1684,9 @@ def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     dev = torch.device(device)
     a = _C.TgcnStepFwdArgs()
     if tensors.get("column_indices") is not None and tensors["column_indices"].numel() == 0:
-        tensors = dict(tensors, w_image=None)               # the matrix-core form assumes |E| >= 1 (its gather has no guarded loads)
+        tensors = dict(tensors, w_image=None, w_fold=None, b_fold=None)   # the matrix-core forms assume |E| >= 1 (their gathers have no guarded loads)
+    if tensors.get("w_fold") is not None and tensors.get("fold_status") is None:
+        tensors = dict(tensors, fold_status=step_fold_status_word(dev))
     _fill_step_args(a, "tgcn_step_fwd", dev, tensors)
     a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
     # byte model: gathered input rows + index arrays + what the launch reads and writes per row

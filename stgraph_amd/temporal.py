@@ -121,6 +121,9 @@ class _TGCNWindow(torch.autograd.Function):
         # the same weights as bf16 fragment images: with them the step launches take their matrix-core form (csrc/tgcn_stepx.hpp)
         img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2, b2)
                             if kernels.STEP_MATRIX_CORE else (None, None))
+        # the gate Linears with the conv folded in: the forward launch's folded form (csrc/tgcn_stepf_fwd.hip)
+        w_fold, b_fold = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh)
+                          if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None))
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         P, X3 = new(B, N, Fin), new(B, N, 3 * C)
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
@@ -145,7 +148,8 @@ class _TGCNWindow(torch.autograd.Function):
                                   x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1], target=targets[t],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
                                   W2=W2v, b2=b2_, P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t],
-                                  y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t], w_image=img_f)
+                                  y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t], w_image=img_f, w_fold=w_fold,
+                                  b_fold=b_fold)
         step_loss = new(B)
         cost = kernels.tgcn_window_loss(partial, B, N, step_loss)
         ctx.save_for_backward(x0, targets, norm, normv, ew if ew is not None else norm.new_empty(0), Wcat, Wz_, Wr_, Wh_, W1_, W2v,
@@ -472,6 +476,8 @@ class _TGCNDynWindow(torch.autograd.Function):
         ctx.packed_T = (WzT, WrT, WhT, W1T)
         img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)
                             if kernels.STEP_MATRIX_CORE else (None, None))          # matrix-core form: see _TGCNWindow.forward
+        w_fold, b_fold = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh)
+                          if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None))      # folded form: likewise
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         P, X3 = new(B, N, Fin), new(B, N, 3 * C)
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
@@ -494,7 +500,7 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   norm=st["normv"], x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
                                   P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t], clamp_mask=mask[t],
-                                  w_image=img_f)
+                                  w_image=img_f, w_fold=w_fold, b_fold=b_fold)
         # the decoder + loss of every snapshot behind the last step, in one launch: a snapshot's loss feeds nothing in the next one
         kernels.link_decode_fwd_window([Y[t] for t in range(B)], [st["edges"] for st in steps], [st["targets"] for st in steps],
                                        [logits[t] for t in range(B)], [partial[t] for t in range(B)])

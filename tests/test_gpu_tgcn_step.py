@@ -98,7 +98,12 @@ def _images(p):
 def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, hi=HI, x3form=False):
     from stgraph_amd import kernels
     out = _alloc(cuda, n)
-    if x3form:
+    if x3form == "folded":                    # csrc/tgcn_stepf_fwd.hip: the conv folded into the gate Linears
+        Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
+        bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
+        out["w_fold"], out["b_fold"] = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"])
+        assert out["w_fold"].shape == (3 * C, FIN + C) and out["b_fold"].shape == (3 * C,)
+    elif x3form:
         out["w_image"] = _images(p)[0]
     nc = kernels._edge_gathered(g.fwd, "norm", norm, g.fwd.column_indices)
     ew_e = None if ew is None else kernels._edge_gathered(g.fwd, "ew", ew, g.fwd.eids)
@@ -107,7 +112,8 @@ def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, h
                           x=x, H=H, target=target, WcatT=p["Wcat"].t().contiguous(), b3=p["b3"], Wz=p["Wz"], bz=p["bz"],
                           Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"], W1=p["W1"], b1=p["b1"],
                           W2=p["W2"].view(-1).contiguous(), b2=p["b2"], **out)
-    out.pop("w_image", None)
+    for k in ("w_image", "w_fold", "b_fold"):
+        out.pop(k, None)
     return out
 
 
@@ -117,7 +123,9 @@ def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True
     new = lambda *s: torch.full(s, float("nan"), device=cuda)  # noqa: E731
     out = dict(dzl=new(n, C), drl=new(n, C), dhl=new(n, C), da3=new(n, 3 * C), dH=new(n, C), dyt=new(n, FH), dyo=new(n),
                z=new(n, FIN) if want_z else None)
-    if x3form:                                   # the matrix-core form reads the mask its forward twin wrote
+    if x3form == "folded":                       # the folded forward leaves the fp32 form's saved tensors: the fp32 backward follows it
+        use_mask = True
+    elif x3form:                                 # the matrix-core form reads the mask its forward twin wrote
         out["w_image"], use_mask = _images(p)[1], True
     nc = kernels._edge_gathered(g.bwd, "norm", norm, g.bwd.column_indices)
     ew_e = None if ew is None else kernels._edge_gathered(g.bwd, "ew", ew, g.bwd.eids)
@@ -144,11 +152,13 @@ def _close(got, want, what, tol=2e-5):
                                                  # 7501 tiles on 3072 wave slots, one row in the last tile: every wave takes
                                                  # further tiles off the workgroup's counter
                                                  (120_001, 1_000_000, False, False)])
-@pytest.mark.parametrize("x3form", [False, True])
+@pytest.mark.parametrize("x3form", [False, True, "folded"])
 def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3form):
     """``x3form``: the matrix-core form of both launches (a weight image in the argument block; csrc/tgcn_stepx_*.hip) -- the SAME
-    fp64 reference and the SAME tolerances as the fp32 form."""
+    fp64 reference and the SAME tolerances as the fp32 form.  ``"folded"``: the folded forward launch (csrc/tgcn_stepf_fwd.hip)
+    followed by the fp32 backward launch, likewise; its status word stays clear."""
     from stgraph_amd import kernels
+    kernels.step_fold_status_word(cuda).zero_()
     if x3form and node_ids:
         pytest.skip("the matrix-core form visits rows in vertex order (as the window nodes do); node_ids takes the fp32 form")
     g, e = _graph(cuda, n, e, seed=n)
@@ -171,6 +181,11 @@ def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3f
     b0 = _bwd(cuda, g, norm, ew, p, s0, None, t0, n, zn=b1["z"], dHn=b1["dH"], g_cost=g_cost, node_ids=node_ids, x3form=x3form)
     b0_again = _bwd(cuda, g, norm, ew, p, s0, None, t0, n, zn=b1["z"], dHn=b1["dH"], g_cost=g_cost, node_ids=node_ids, x3form=x3form)
     assert all(torch.equal(b0[k], b0_again[k]) for k in b0)            # deterministic: no atomics, fixed orders
+    assert int(kernels.step_fold_status_word(cuda).item()) == 0
+    if x3form == "folded":
+        s0_again = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, node_ids=node_ids, x3form=x3form)
+        assert all(torch.equal(s0[k], s0_again[k]) for k in s0)
+        assert bool((s0["clamp_mask"] == 0xffff).all())
 
     if n > 20_000:
         A = None                                   # dense A_hat would be 20 GB: aggregate with the (tested) kernel in fp32
@@ -231,6 +246,36 @@ def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3f
     _close(b0["dyt"].double().t() @ s0["Hn"].double().relu() + b1["dyt"].double().t() @ s1["Hn"].double().relu(),
            pd["W1"].grad, "dW1", btol)
     _close((b0["dyo"].double() @ s0["y"].double() + b1["dyo"].double() @ s1["y"].double()).view(1, -1), pd["W2"].grad, "dW2", btol)
+
+
+def test_folded_form_reports_a_clamp_that_bites(cuda):
+    """With a clamp range the conv output leaves, the folded forward launch still writes the exact x3 and clamp mask (the fp32
+    form's, bit for bit in the mask) and raises the sticky status word that makes check_step_fold_status() refuse the results."""
+    from stgraph_amd import kernels
+    n, lo, hi = 200, -0.25, 0.4
+    g, e = _graph(cuda, n, 1500, seed=5)
+    deg = (g.fwd.row_offset[1:] - g.fwd.row_offset[:-1]).float()
+    norm = torch.where(deg > 0, deg.clamp(min=1) ** -0.5, torch.zeros_like(deg)).view(-1, 1)
+    p = _params(cuda, 9)
+    x0, t0, H = torch.randn(n, FIN, device=cuda), torch.randn(n, device=cuda), torch.randn(n, C, device=cuda) * 0.3
+    kernels.step_fold_status_word(cuda).zero_()
+    kernels.check_step_fold_status(cuda)
+    sf = _fwd(cuda, g, norm, None, p, x0, H, t0, n, lo=lo, hi=hi, x3form="folded")
+    s0 = _fwd(cuda, g, norm, None, p, x0, H, t0, n, lo=lo, hi=hi)
+    _close(sf["x3"], s0["x3"], "x3", 1e-5)
+    far = ((s0["x3"] - lo).abs() > 1e-4) & ((s0["x3"] - hi).abs() > 1e-4)          # bits of elements not within rounding of a bound
+    def bits(m):
+        # mask word [row][gate][kq], bit 4 ct + i <-> column 16 ct + 4 kq + i
+        out = torch.zeros(n, 3, C, dtype=torch.bool, device=cuda)
+        for ct in range(4):
+            for kq in range(4):
+                for i in range(4):
+                    out[:, :, 16 * ct + 4 * kq + i] = ((m.view(n, 3, 4)[:, :, kq] >> (4 * ct + i)) & 1).bool()
+        return out.view(n, 3 * C)
+    assert torch.equal(bits(sf["clamp_mask"])[far], bits(s0["clamp_mask"])[far])
+    with pytest.raises(RuntimeError, match="folded step form"):
+        kernels.check_step_fold_status(cuda)
+    kernels.check_step_fold_status(cuda)             # cleared by the failed check
 
 
 @pytest.mark.parametrize("x3form", [False, True])

@@ -88,6 +88,23 @@ def main():
     fwd()                                                          # the mask in the matrix-core layout for its backward twin
     res["stepx_fwd_us"], res["stepx_bwd_us"] = timed(fwd), timed(bwd)
     del out["w_image"], bo["w_image"]
+    # the folded form of the forward launch (csrc/tgcn_stepf_fwd.hip): the conv folded into the gate Linears
+    w_fold, b_fold = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"])
+    res["fold_weights_us"] = timed(lambda: kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"]))
+    ref = {k: v.clone() for k, v in out.items()}
+    out["w_fold"], out["b_fold"] = w_fold, b_fold
+    fwd()
+    res["stepf_fwd_us"] = timed(fwd)
+    res["stepf_status"] = int(kernels.step_fold_status_word(dev).item())
+    res["stepf_max_err_vs_fp32_form"] = {k: float((out[k] - ref[k]).abs().max()) for k in ("x3", "Z", "R", "Ht", "Hn", "HR", "y", "y_out")}
+    # ... and the same launch given P (no gather inside), next to the aggregation launch that would produce it
+    def fwd_noagg():
+        kernels.tgcn_step_fwd(n, C, FIN, FH, 2, -1e6, 1e6, dev, norm=norm.view(-1), H=H, target=tgt, WcatT=WcatT,
+                              b3=p["b3"], Wz=p["Wz"], bz=p["bz"], Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"],
+                              W1=p["W1"], b1=p["b1"], W2=p["W2"], b2=p["b2"], **out)
+    res["stepf_fwd_given_P_us"] = timed(fwd_noagg)
+    res["gcn_agg_F32_us"] = timed(lambda: kernels.gcn_agg(x, norm, norm, f, ew=ew))
+    del out["w_fold"], out["b_fold"]
     fwd()
 
     # ablations: which phase costs what
