@@ -689,7 +689,9 @@ typedef struct stg_tgcn_step_fwd_args {
      * (x3 and the clamp mask in the fp32 form's layout included: any backward launch may follow); results fp32-class (1e-5 of the
      * fp32 form).  The fold is only valid while no element of x3 is clamped: if one is, *fold_status |= 1 (sticky, never cleared by
      * the library) and THAT launch's Z / R / Ht / Hn / HR / y are wrong -- the caller must check it and redo the work without
-     * w_fold.  The three go together. */
+     * w_fold.  The three go together -- except that fold_status alone may be given to the fp32 form, which then ORs a 1 into it
+     * when an element of x3 is clamped (callers that form the weight gradients from P^T d_g instead of x3 and da3 -- both then
+     * optional: x3 may be NULL when clamp_mask is given, stg_tgcn_step_bwd_args::da3 may be NULL when z is wanted -- need to know). */
     const float *w_fold, *b_fold;
     int32_t *fold_status;
 } stg_tgcn_step_fwd_args;

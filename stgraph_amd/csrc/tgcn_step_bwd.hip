@@ -265,7 +265,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
                 o.y = (m & 2u) ? acc[blk][1] : 0.f;
                 o.z = (m & 4u) ? acc[blk][2] : 0.f;
                 o.w = (m & 8u) ? acc[blk][3] : 0.f;
-                st_f4(a.da3, o3, 4 * (g * C + 16 * blk), o);
+                if (a.da3) st_f4(a.da3, o3, 4 * (g * C + 16 * blk), o);           // kernel-uniform (optional: the conv gradients can come from P^T d_g)
                 if (want_z) {
                     mfma_piece<PF>(zacc, wcrow, LDX, g * PC + blk, o);
                     __builtin_amdgcn_sched_barrier(0);
@@ -378,7 +378,7 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     if (gather && (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL graph pointer");
     if ((int64_t)p->N * 3 * p->C >= ((int64_t)1 << 30)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_bwd: too many rows for 32-bit offsets");
-    if (!p->Z || !p->R || !p->Ht || (!p->x3 && !p->clamp_mask) || !p->WzT || !p->WrT || !p->WhT || !p->dzl || !p->drl || !p->dhl || !p->da3 || !p->dH)
+    if (!p->Z || !p->R || !p->Ht || (!p->x3 && !p->clamp_mask) || !p->WzT || !p->WrT || !p->WhT || !p->dzl || !p->drl || !p->dhl || (!p->da3 && !p->z) || !p->dH)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL cell pointer");
     if (p->z && !p->Wcat) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: z wanted but Wcat is NULL");
     if (p->head >= 1 && (!p->W1T || !p->Hn || !p->dyt)) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL head pointer");

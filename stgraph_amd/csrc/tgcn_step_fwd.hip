@@ -11,6 +11,7 @@ struct FwdArgs {
     const float *WcatT, *b3, *Wz, *bz, *Wr, *br, *Wh, *bh, *W1, *b1, *W2, *b2;
     float *P, *x3, *Z, *R, *Ht, *Hn, *HR, *y, *y_out, *partial;
     unsigned *mask;
+    int *status;                                       // optional: |= 1 when an element of x3 is clamped (stg_tgcn_step_fwd_args::fold_status)
     int64_t N;
     float lo, hi;
     int num_tiles;
@@ -155,13 +156,14 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
             unsigned gm = 0u;             // clamp mask of this gate's columns: bit 4 ct + i <-> column 16 ct + 4 kq + i
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) {
-                st_f4(a.x3, o3, 4 * (g * C + 16 * ct), hg[ct]);
+                if (a.x3) st_f4(a.x3, o3, 4 * (g * C + 16 * ct), hg[ct]);     // kernel-uniform (x3 is optional when the mask is taken)
                 const float4 v = hg[ct];
                 hg[ct] = make_float4(clamp3(v.x, lo, hi), clamp3(v.y, lo, hi), clamp3(v.z, lo, hi), clamp3(v.w, lo, hi));
                 // inside [lo, hi]  <=>  the clamp left the value alone
                 gm |= ((hg[ct].x == v.x ? 1u : 0u) | (hg[ct].y == v.y ? 2u : 0u) | (hg[ct].z == v.z ? 4u : 0u) | (hg[ct].w == v.w ? 8u : 0u)) << (4 * ct);
             }
             if (a.mask) a.mask[row * 12u + 4 * g + kq] = gm;
+            if (a.status && gm != (PC == 4 ? 0xffffu : (1u << (4 * PC)) - 1u)) atomicOr(a.status, 1);
         };
         // acc = bias + [hg | second] W_g^T   (W_g [C][2C] in LDS, torch Linear layout)
         // on return wq holds the step-0 weights of what follows: the next gate's x3 product, or the head (in wq[0 .. PH))
@@ -369,7 +371,7 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
         return stg_tgcn_stepf_fwd_launch(p, stream_);
     if (gather ? (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm || !p->WcatT || !p->P) : !p->a3)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL graph / input pointer");
-    if (!p->b3 || !p->Wz || !p->bz || !p->Wr || !p->br || !p->Wh || !p->bh || !p->x3 || !p->Z || !p->R || !p->Ht || !p->Hn || !p->HR)
+    if (!p->b3 || !p->Wz || !p->bz || !p->Wr || !p->br || !p->Wh || !p->bh || (!p->x3 && !p->clamp_mask) || !p->Z || !p->R || !p->Ht || !p->Hn || !p->HR)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL cell pointer");
     if (p->head >= 1 && (!p->W1 || !p->b1 || !p->y)) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL head pointer");
     if (p->head == 2 && (!p->W2 || !p->b2 || !p->y_out || !p->target || !p->loss_partial))
@@ -387,7 +389,7 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
     a.WcatT = p->WcatT; a.b3 = p->b3; a.Wz = p->Wz; a.bz = p->bz; a.Wr = p->Wr; a.br = p->br; a.Wh = p->Wh; a.bh = p->bh;
     a.W1 = p->W1; a.b1 = p->b1; a.W2 = p->W2; a.b2 = p->b2;
     a.P = p->P; a.x3 = p->x3; a.Z = p->Z; a.R = p->R; a.Ht = p->Ht; a.Hn = p->Hn; a.HR = p->HR; a.y = p->y;
-    a.y_out = p->y_out; a.partial = p->loss_partial; a.mask = p->clamp_mask;
+    a.y_out = p->y_out; a.partial = p->loss_partial; a.mask = p->clamp_mask; a.status = p->fold_status;
     a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.num_tiles = (int)((p->N + 15) / 16);
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const bool w16 = tuning().step_waves == 16;

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kFWaves * 64) void tgcn_stepf_fwd_kernel(const FwdF
                 const float4 hg = make_float4(clamp3(v.x, lo_c, hi_c), clamp3(v.y, lo_c, hi_c), clamp3(v.z, lo_c, hi_c), clamp3(v.w, lo_c, hi_c));
                 const unsigned m4 = (hg.x == v.x ? 1u : 0u) | (hg.y == v.y ? 2u : 0u) | (hg.z == v.z ? 4u : 0u) | (hg.w == v.w ? 8u : 0u);
                 gm[g] |= m4 << (4 * (cp + sidx));
-                st_f4(a.x3, oX, 4 * (g * C + 16 * (cp + sidx)), v);
+                if (a.x3) st_f4(a.x3, oX, 4 * (g * C + 16 * (cp + sidx)), v);       // kernel-uniform: x3 is optional
             }
         };
         auto gidx = [](int g, int ct, int kb) { return kFSecGate + (g * 4 + ct) * kFKg + kb; };

@@ -1565,6 +1565,18 @@ def set_step_folded(enabled: bool) -> None:
     STEP_FOLDED = bool(enabled)
 
 
+# True (default): the window nodes form the gate / conv weight gradients from P^T d_g and H^T d_g (temporal._unfold_gate_grads)
+# instead of x3^T d_g and P^T da3: the forward launch then stores no x3 and the backward launch no da3 (38 MB each per snapshot
+# at |V| = 50 K), and the gate contractions read [P | H] instead of [x3_g | H].  Exact for an inactive clamp (the fp32 forward
+# launch raises the same sticky status word as the folded form when an element of x3 is clamped).
+STEP_WGRAD_FROM_P = True
+
+
+def set_step_wgrad_from_p(enabled: bool) -> None:
+    global STEP_WGRAD_FROM_P
+    STEP_WGRAD_FROM_P = bool(enabled)
+
+
 _FOLD_STATUS = {}
 
 
@@ -1588,9 +1600,9 @@ def check_step_fold_status(device=None, clear: bool = True) -> None:
         if int(t.item()) != 0:
             if clear:
                 t.zero_()
-            raise RuntimeError("a TGCN conv output left [-1e6, 1e6]: the folded step form (reference nn/pytorch/temporal/tgcn.py:23 clamps "
-                               "there) is not valid for this data; results since the last check are wrong -- "
-                               "rerun with stgraph_amd.kernels.set_step_folded(False)")
+            raise RuntimeError("a TGCN conv output left [-1e6, 1e6] (reference nn/pytorch/temporal/tgcn.py:23 clamps there): the folded step form "
+                               "and the weight gradients formed from P are not valid for this data; results since the last check are "
+                               "wrong -- rerun with stgraph_amd.kernels.set_step_folded(False) and set_step_wgrad_from_p(False)")
 
 
 def tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh):

@@ -98,6 +98,17 @@ def _grad_sinks(params, needs):
     return sinks
 
 
+def _unfold_gate_grads(MgT, cs, dWbot, Wc, bc, Wg):
+    """Gate + conv parameter gradients of one gate from the contractions over the window's rows that do not need x3 or da3:
+    ``MgT = d_g^T P`` [C, Fin], ``cs`` = column sums of d_g [C], ``dWbot = d_g^T Hx`` [C, C] (d_g: gradient of the gate's
+    pre-activation; x3_g = P Wc + bc, unclamped).  Returns (dWg [C, 2C], dbg [C], dWc [Fin, C], dbc [C]):
+    ``dWg[:, :C] = d_g^T x3_g = MgT Wc + cs bc^T``; ``dWc = P^T (d_g Wg[:, :C]) = MgT^T Wg[:, :C]``; ``dbc = cs Wg[:, :C]``."""
+    C = Wg.shape[0]
+    top = Wg[:, :C]
+    dWg = torch.cat([torch.addmm(torch.outer(cs, bc), MgT, Wc), dWbot], dim=1)
+    return dWg, cs, torch.mm(MgT.t(), top), torch.mv(top.t(), cs)
+
+
 class _TGCNWindow(torch.autograd.Function):
     """cost = sum_t mean((y_out_t - target_t)^2) over the snapshots of one BPTT window of the static-temporal loop
     (benchmarking/static-temporal-tgcn/seastar/train.py:165-183 with model.py:6-18 and nn/pytorch/temporal/tgcn.py):
@@ -125,7 +136,9 @@ class _TGCNWindow(torch.autograd.Function):
         w_fold, b_fold = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh)
                           if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None))
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
-        P, X3 = new(B, N, Fin), new(B, N, 3 * C)
+        from_p = kernels.STEP_WGRAD_FROM_P and not kernels.STEP_MATRIX_CORE       # weight gradients from P: no x3, no da3
+        P, X3 = new(B, N, Fin), (None if from_p else new(B, N, 3 * C))
+        fold_status = kernels.step_fold_status_word(dev) if (from_p or w_fold is not None) else None
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
         Y, Yout = new(B, N, Fh), new(B, N)
         tiles = kernels.tgcn_step_loss_partials(N)
@@ -147,9 +160,9 @@ class _TGCNWindow(torch.autograd.Function):
                                   node_ids=nid, norm_col_edge=nc, ew_edge=ew_e, norm=normv,
                                   x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1], target=targets[t],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
-                                  W2=W2v, b2=b2_, P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t],
-                                  y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t], w_image=img_f, w_fold=w_fold,
-                                  b_fold=b_fold)
+                                  W2=W2v, b2=b2_, P=P[t], x3=None if from_p else X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t],
+                                  HR=HR[t], y=Y[t], y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t], w_image=img_f,
+                                  w_fold=w_fold, b_fold=b_fold, fold_status=fold_status)
         step_loss = new(B)
         cost = kernels.tgcn_window_loss(partial, B, N, step_loss)
         ctx.save_for_backward(x0, targets, norm, normv, ew if ew is not None else norm.new_empty(0), Wcat, Wz_, Wr_, Wh_, W1_, W2v,
@@ -171,7 +184,8 @@ class _TGCNWindow(torch.autograd.Function):
         Fin, Fh = int(x0.shape[1]), int(Y.shape[2])
         g = g_cost.reshape(1).contiguous().float()
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
-        dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), new(B, N, 3 * C)
+        from_p = X3 is None                                     # weight gradients from P (kernels.STEP_WGRAD_FROM_P): no x3, no da3
+        dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), (None if from_p else new(B, N, 3 * C))
         dyt, dyo = new(B, N, Fh), new(B, N)
         dH, zbuf = new(2, N, C), new(2, N, Fin)
         WzT, WrT, WhT, W1T = ctx.packed_T
@@ -188,8 +202,9 @@ class _TGCNWindow(torch.autograd.Function):
                                   g_cost=g, Z=Z[t], R=R[t], Ht=Ht[t], H=None if t == 0 else Hn[t - 1], Hn=Hn[t], x3=None,
                                   clamp_mask=mask[t],
                                   y_out=Yout[t], target=targets[t], WzT=WzT, WrT=WrT, WhT=WhT, Wcat=Wcat, W1T=W1T, W2=W2v,
-                                  dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=da3[t], dH=dH[t & 1],
-                                  z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], dyo=dyo[t], w_image=ctx.img_b)
+                                  dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=None if from_p else da3[t], dH=dH[t & 1],
+                                  z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t], dyo=dyo[t],
+                                  w_image=ctx.img_b)
         dx0 = kernels.gcn_agg(zbuf[0], norm, norm, bwd, ew=ew, use_node_ids=ctx.use_nid) if want_dx0 else None
         # weight gradients: one split-K launch per parameter over the window's snapshots
         steps = range(B)
@@ -202,13 +217,35 @@ class _TGCNWindow(torch.autograd.Function):
             b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True, **dst(i, i + 1))
         # six split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch); the three conv layers' gradients are one
         # stacked product whose row blocks the reduction transposes straight into the parameters' .grad (sinks 0-2, biases 3-5)
+        head_calls = [
+            dict(As=[dyt[t] for t in steps], Bs=[Hn[t] for t in steps], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13)),
+            dict(As=[dyo[t].view(N, 1) for t in steps], Bs=[Y[t] for t in steps], M=1, N=Fh, colsum=True, **dst(14, 15))]
+        if from_p:
+            # per gate d_g^T Hx [C, C] (+ column sums) and d_g^T P [C, Fin]: eight contractions, one reduction launch; the gate and conv
+            # parameters' gradients follow from them in a few small products (_unfold_gate_grads)
+            Wcz, Wcr, Wch, bcz, bcr, bch, Wz_p, _, Wr_p, _, Wh_p, _ = ctx.params[:12]
+            seconds = (Hprev, Hprev, [HR[t] for t in steps])
+            ds = (dzl, drl, dhl)
+            res = kernels.gemm_tn_form_batch(
+                [dict(As=[d[t] for t in steps], Bs=sec, M=C, N=C, colsum=True) for d, sec in zip(ds, seconds)]
+                + [dict(As=[d[t] for t in steps], Bs=[P[t] for t in steps], M=C, N=Fin) for d in ds] + head_calls)
+            gates = [_unfold_gate_grads(res[3 + k], res[k][1], res[k][0], Wc, bc, Wg)
+                     for k, (Wc, bc, Wg) in enumerate(((Wcz, bcz, Wz_p), (Wcr, bcr, Wr_p), (Wch, bch, Wh_p)))]
+            if sinks:
+                for k, (dWg, dbg, dWc, dbc) in enumerate(gates):
+                    sinks[6 + 2 * k].copy_(dWg)
+                    sinks[7 + 2 * k].copy_(dbg)
+                    sinks[k].copy_(dWc)
+                    sinks[3 + k].copy_(dbc)
+                return (dx0,) + (None,) * 24
+            (dW1, db1), (dW2, db2) = res[6], res[7]
+            return (dx0, None, None, None, None, None, None, None, None, *[g[2] for g in gates], *[g[3] for g in gates],
+                    gates[0][0], gates[0][1], gates[1][0], gates[1][1], gates[2][0], gates[2][1], dW1, db1, dW2.view(1, Fh), db2)
         conv = dict(As=[da3[t] for t in steps], Bs=[P[t] for t in steps], M=3 * C, N=Fin, colsum=True)
         if sinks:
             conv.update(out_blocks_t=list(sinks[0:3]), colsum_blocks=list(sinks[3:6]))
         res = kernels.gemm_tn_form_batch([
-            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in steps], 10), conv,
-            dict(As=[dyt[t] for t in steps], Bs=[Hn[t] for t in steps], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13)),
-            dict(As=[dyo[t].view(N, 1) for t in steps], Bs=[Y[t] for t in steps], M=1, N=Fh, colsum=True, **dst(14, 15))])
+            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in steps], 10), conv] + head_calls)
         if sinks:
             return (dx0,) + (None,) * 24
         (dWz, dbz), (dWr, dbr), (dWh, dbh), (dWcT, db3), (dW1, db1), (dW2, db2) = res
@@ -479,7 +516,9 @@ class _TGCNDynWindow(torch.autograd.Function):
         w_fold, b_fold = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh)
                           if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None))      # folded form: likewise
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
-        P, X3 = new(B, N, Fin), new(B, N, 3 * C)
+        from_p = kernels.STEP_WGRAD_FROM_P and not kernels.STEP_MATRIX_CORE       # weight gradients from P: no x3, no da3 (_TGCNWindow)
+        P, X3 = new(B, N, Fin), (None if from_p else new(B, N, 3 * C))
+        fold_status = kernels.step_fold_status_word(dev) if (from_p or w_fold is not None) else None
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
         Y = new(B, N, Fh)
         mask = torch.empty(B, N, 12, dtype=torch.int32, device=dev)
@@ -499,8 +538,8 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   node_ids=None, norm_col_edge=st["nc_f"], ew_edge=None,        # vertex order: see _TGCNWindow
                                   norm=st["normv"], x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
-                                  P=P[t], x3=X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t], clamp_mask=mask[t],
-                                  w_image=img_f, w_fold=w_fold, b_fold=b_fold)
+                                  P=P[t], x3=None if from_p else X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t],
+                                  clamp_mask=mask[t], w_image=img_f, w_fold=w_fold, b_fold=b_fold, fold_status=fold_status)
         # the decoder + loss of every snapshot behind the last step, in one launch: a snapshot's loss feeds nothing in the next one
         kernels.link_decode_fwd_window([Y[t] for t in range(B)], [st["edges"] for st in steps], [st["targets"] for st in steps],
                                        [logits[t] for t in range(B)], [partial[t] for t in range(B)])
@@ -519,7 +558,8 @@ class _TGCNDynWindow(torch.autograd.Function):
         Fin, Fh = int(x0.shape[1]), int(Y.shape[2])
         g = g_cost.reshape(1).contiguous().float()
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
-        dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), new(B, N, 3 * C)
+        from_p = X3 is None
+        dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), (None if from_p else new(B, N, 3 * C))
         dyt = new(B, N, Fh)
         dH, zbuf = new(2, N, C), new(2, N, Fin)
         WzT, WrT, WhT, W1T = ctx.packed_T
@@ -542,8 +582,8 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   link_other=other, link_eid=eid, link_y=Y[t], link_logits=logits[t], link_target=st["targets"],
                                   Z=Z[t], R=R[t], Ht=Ht[t],
                                   H=None if t == 0 else Hn[t - 1], Hn=Hn[t], clamp_mask=mask[t], WzT=WzT, WrT=WrT, WhT=WhT,
-                                  Wcat=Wcat, W1T=W1T, dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=da3[t], dH=dH[t & 1],
-                                  z=zbuf[t & 1] if (t > 0 or want_dx0) else None, dyt=dyt[t], w_image=ctx.img_b, **kw)
+                                  Wcat=Wcat, W1T=W1T, dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=None if from_p else da3[t], dH=dH[t & 1],
+                                  z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t], w_image=ctx.img_b, **kw)
         dx0 = None
         if want_dx0:
             s0 = steps[0]
@@ -556,12 +596,31 @@ class _TGCNDynWindow(torch.autograd.Function):
             As=[d[t] for t in rng], Bs=[X3[t][:, k * C:(k + 1) * C] for t in rng], M=C, N=2 * C, B2s=second, nsplit=C,
             b_op=kernels.GEMM_B_CLAMP, lo=lo, hi=hi, colsum=True, **dst(i, i + 1))
         # five split-K contractions, ONE reduction launch (kernels.gemm_tn_form_batch); conv gradients as in _TGCNWindow.backward
+        head_call = dict(As=[dyt[t] for t in rng], Bs=[Hn[t] for t in rng], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13))
+        if from_p:                                               # as in _TGCNWindow.backward
+            Wcz, Wcr, Wch, bcz, bcr, bch, Wz_p, _, Wr_p, _, Wh_p, _ = ctx.params[:12]
+            ds, seconds = (dzl, drl, dhl), (Hprev, Hprev, [HR[t] for t in rng])
+            res = kernels.gemm_tn_form_batch(
+                [dict(As=[d[t] for t in rng], Bs=sec, M=C, N=C, colsum=True) for d, sec in zip(ds, seconds)]
+                + [dict(As=[d[t] for t in rng], Bs=[P[t] for t in rng], M=C, N=Fin) for d in ds] + [head_call])
+            gates = [_unfold_gate_grads(res[3 + k], res[k][1], res[k][0], Wc, bc, Wg)
+                     for k, (Wc, bc, Wg) in enumerate(((Wcz, bcz, Wz_p), (Wcr, bcr, Wr_p), (Wch, bch, Wh_p)))]
+            ctx.steps = None
+            if sinks:
+                for k, (dWg, dbg, dWc, dbc) in enumerate(gates):
+                    sinks[6 + 2 * k].copy_(dWg)
+                    sinks[7 + 2 * k].copy_(dbg)
+                    sinks[k].copy_(dWc)
+                    sinks[3 + k].copy_(dbc)
+                return (dx0,) + (None,) * 18
+            dW1, db1 = res[6]
+            return (dx0, None, None, None, None, *[g[2] for g in gates], *[g[3] for g in gates],
+                    gates[0][0], gates[0][1], gates[1][0], gates[1][1], gates[2][0], gates[2][1], dW1, db1)
         conv = dict(As=[da3[t] for t in rng], Bs=[P[t] for t in rng], M=3 * C, N=Fin, colsum=True)
         if sinks:
             conv.update(out_blocks_t=list(sinks[0:3]), colsum_blocks=list(sinks[3:6]))
         res = kernels.gemm_tn_form_batch([
-            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in rng], 10), conv,
-            dict(As=[dyt[t] for t in rng], Bs=[Hn[t] for t in rng], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13))])
+            gate(dzl, 0, Hprev, 6), gate(drl, 1, Hprev, 8), gate(dhl, 2, [HR[t] for t in rng], 10), conv, head_call])
         ctx.steps = None
         if sinks:
             return (dx0,) + (None,) * 18

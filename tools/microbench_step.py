@@ -77,6 +77,11 @@ def main():
                               R=out["R"], Ht=out["Ht"], H=H, Hn=out["Hn"], x3=None, clamp_mask=out["clamp_mask"], y_out=out["y_out"], target=tgt,
                               WzT=T["Wz"], WrT=T["Wr"], WhT=T["Wh"], Wcat=p["Wcat"], W1T=T["W1"], W2=p["W2"], **bo)
     res = {"N": n, "E": e, "waves": args.waves or "auto", "step_fwd_us": timed(fwd), "step_bwd_us": timed(bwd)}
+    # the same two launches without the x3 / da3 stores (both optional: the weight gradients can be formed from P^T d_g)
+    keep = out["x3"], bo["da3"]
+    out["x3"], bo["da3"] = None, None
+    res["step_fwd_no_x3_us"], res["step_bwd_no_da3_us"] = timed(fwd), timed(bwd)
+    out["x3"], bo["da3"] = keep
     # the matrix-core form of the same two launches (csrc/tgcn_stepx_*.hip): a weight image in the argument block
     Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
     bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
