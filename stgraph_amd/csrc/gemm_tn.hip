@@ -612,6 +612,8 @@ WideShape wide_shape(int M, int N, int nsplit)
         } else if (N == 32) {
             w.wb = 2; w.cb = 1;
             w.ca = M % 192 == 0 ? 3 : (M % 128 == 0 ? 2 : 1);
+        } else if (N == 96) {                                   // d_g^T [Hx | P] of a TGCN gate (C = 64, Fin = 32): 4 x 6 tiles per wave
+            w.wb = 2; w.cb = 3; w.ca = 1;
         } else {
             w.wa = 0;
         }
@@ -759,7 +761,7 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         }                                                                                                          \
     }
         STG_WIDE(4, 1, 4, 2) else STG_WIDE(4, 2, 4, 1) else STG_WIDE(4, 1, 4, 1) else STG_WIDE(4, 3, 2, 1) else STG_WIDE(4, 2, 2, 1)
-        else STG_WIDE(4, 1, 2, 1) else STG_WIDE(2, 1, 4, 2) else STG_WIDE(2, 1, 4, 1)
+        else STG_WIDE(4, 1, 2, 1) else STG_WIDE(4, 1, 2, 3) else STG_WIDE(2, 1, 4, 2) else STG_WIDE(2, 1, 4, 1)
         else return fail(STG_ERR_UNSUPPORTED, "%s: no wide instantiation for this tile", what);
 #undef STG_WIDE
 #undef STG_WIDE_L

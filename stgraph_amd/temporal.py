@@ -221,15 +221,16 @@ class _TGCNWindow(torch.autograd.Function):
             dict(As=[dyt[t] for t in steps], Bs=[Hn[t] for t in steps], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13)),
             dict(As=[dyo[t].view(N, 1) for t in steps], Bs=[Y[t] for t in steps], M=1, N=Fh, colsum=True, **dst(14, 15))]
         if from_p:
-            # per gate d_g^T Hx [C, C] (+ column sums) and d_g^T P [C, Fin]: eight contractions, one reduction launch; the gate and conv
-            # parameters' gradients follow from them in a few small products (_unfold_gate_grads)
+            # per gate d_g^T Hx [C, C] (+ column sums) and d_g^T P [C, Fin]; the gate and conv parameters' gradients follow from them in
+            # a few small products (_unfold_gate_grads)
             Wcz, Wcr, Wch, bcz, bcr, bch, Wz_p, _, Wr_p, _, Wh_p, _ = ctx.params[:12]
             seconds = (Hprev, Hprev, [HR[t] for t in steps])
             ds = (dzl, drl, dhl)
+            # one contraction per gate: d_g^T [Hx | P] -> [C, C + Fin] (+ column sums): d_g is read once
             res = kernels.gemm_tn_form_batch(
-                [dict(As=[d[t] for t in steps], Bs=sec, M=C, N=C, colsum=True) for d, sec in zip(ds, seconds)]
-                + [dict(As=[d[t] for t in steps], Bs=[P[t] for t in steps], M=C, N=Fin) for d in ds] + head_calls)
-            gates = [_unfold_gate_grads(res[3 + k], res[k][1], res[k][0], Wc, bc, Wg)
+                [dict(As=[d[t] for t in steps], Bs=sec, B2s=[P[t] for t in steps], M=C, N=C + Fin, nsplit=C, colsum=True)
+                 for d, sec in zip(ds, seconds)] + head_calls)
+            gates = [_unfold_gate_grads(res[k][0][:, C:], res[k][1], res[k][0][:, :C], Wc, bc, Wg)
                      for k, (Wc, bc, Wg) in enumerate(((Wcz, bcz, Wz_p), (Wcr, bcr, Wr_p), (Wch, bch, Wh_p)))]
             if sinks:
                 for k, (dWg, dbg, dWc, dbc) in enumerate(gates):
@@ -238,7 +239,7 @@ class _TGCNWindow(torch.autograd.Function):
                     sinks[k].copy_(dWc)
                     sinks[3 + k].copy_(dbc)
                 return (dx0,) + (None,) * 24
-            (dW1, db1), (dW2, db2) = res[6], res[7]
+            (dW1, db1), (dW2, db2) = res[3], res[4]
             return (dx0, None, None, None, None, None, None, None, None, *[g[2] for g in gates], *[g[3] for g in gates],
                     gates[0][0], gates[0][1], gates[1][0], gates[1][1], gates[2][0], gates[2][1], dW1, db1, dW2.view(1, Fh), db2)
         conv = dict(As=[da3[t] for t in steps], Bs=[P[t] for t in steps], M=3 * C, N=Fin, colsum=True)
@@ -601,9 +602,9 @@ class _TGCNDynWindow(torch.autograd.Function):
             Wcz, Wcr, Wch, bcz, bcr, bch, Wz_p, _, Wr_p, _, Wh_p, _ = ctx.params[:12]
             ds, seconds = (dzl, drl, dhl), (Hprev, Hprev, [HR[t] for t in rng])
             res = kernels.gemm_tn_form_batch(
-                [dict(As=[d[t] for t in rng], Bs=sec, M=C, N=C, colsum=True) for d, sec in zip(ds, seconds)]
-                + [dict(As=[d[t] for t in rng], Bs=[P[t] for t in rng], M=C, N=Fin) for d in ds] + [head_call])
-            gates = [_unfold_gate_grads(res[3 + k], res[k][1], res[k][0], Wc, bc, Wg)
+                [dict(As=[d[t] for t in rng], Bs=sec, B2s=[P[t] for t in rng], M=C, N=C + Fin, nsplit=C, colsum=True)
+                 for d, sec in zip(ds, seconds)] + [head_call])
+            gates = [_unfold_gate_grads(res[k][0][:, C:], res[k][1], res[k][0][:, :C], Wc, bc, Wg)
                      for k, (Wc, bc, Wg) in enumerate(((Wcz, bcz, Wz_p), (Wcr, bcr, Wr_p), (Wch, bch, Wh_p)))]
             ctx.steps = None
             if sinks:
@@ -613,7 +614,7 @@ class _TGCNDynWindow(torch.autograd.Function):
                     sinks[k].copy_(dWc)
                     sinks[3 + k].copy_(dbc)
                 return (dx0,) + (None,) * 18
-            dW1, db1 = res[6]
+            dW1, db1 = res[3]
             return (dx0, None, None, None, None, *[g[2] for g in gates], *[g[3] for g in gates],
                     gates[0][0], gates[0][1], gates[1][0], gates[1][1], gates[2][0], gates[2][1], dW1, db1)
         conv = dict(As=[da3[t] for t in rng], Bs=[P[t] for t in rng], M=3 * C, N=Fin, colsum=True)
