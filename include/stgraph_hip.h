@@ -30,7 +30,8 @@ extern "C" {
  *   4: stg_tgcn_step_fwd / _bwd, stg_tgcn_window_loss, stg_gemm_tn_form_f32 added.
  *  22: stg_tgcn_step_*_args gain `w_image` (last field); stg_tgcn_pack_weights_x3, stg_tgcn_step_image_bytes; knob "step_impl".
  *  23: stg_gat_fwd_k1_uniform, stg_gat_fc_out, stg_gat_fwd_k1_scored, stg_gat_bwd_factored_elu; knob "rowgemm_x3".
- *  24: stg_tgcn_step_fwd_args gains w_fold, b_fold, fold_status (last fields): the folded form of the forward step launch. */
+ *  24: stg_tgcn_step_fwd_args gains w_fold, b_fold, fold_status (last fields): the folded form of the forward step launch; x3 / da3 of
+ *      the step launches optional; stg_tgcn_unfold_gate_grads. */
 #define STG_ABI_VERSION 24
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -737,6 +738,15 @@ int    stg_tgcn_pack_weights_x3(const float *Wcz, const float *Wcr, const float 
                                 const float *bch, const float *Wz, const float *bz, const float *Wr, const float *br,
                                 const float *Wh, const float *bh, const float *W1, const float *b1, const float *W2,
                                 const float *b2, void *fwd_image, void *bwd_image, int32_t C, int32_t Fin, int32_t Fh, void *stream);
+/* The gate and conv parameter gradients of a window from contractions that need neither x3 nor da3 (ABI 24).  Tables of three
+ * device pointers, one per gate (z, r, h).  Inputs: R_g [C, C + Fin] = d_g^T [Hx | P] and cs_g [C] = column sums of d_g (d_g: gradient
+ * of the gate's pre-activation over the window's rows -- stg_gemm_tn_form_f32 with the column sums), the conv weight Wc_g [Fin, C]
+ * and bias bc_g [C], the gate Linear's weight Wg [C, 2C].  Outputs (fully overwritten): dWg [C, 2C] = [R_g[:, C:] Wc_g + cs_g bc_g^T
+ * | R_g[:, :C]], dbg [C] = cs_g, dWc_g [Fin, C] = R_g[:, C:]^T Wg[:, :C], dbc_g [C] = cs_g Wg[:, :C] -- exact when no element of x3 was
+ * clamped (stg_tgcn_step_fwd_args::fold_status tells).  One launch, sums in index order. */
+int    stg_tgcn_unfold_gate_grads(const float *const *R, const float *const *cs, const float *const *Wc, const float *const *bc,
+                                  const float *const *Wg, float *const *dWg, float *const *dbg, float *const *dWc,
+                                  float *const *dbc, int32_t C, int32_t Fin, void *stream);
 /* cost[0] = sum over the window's `steps` steps, in order, of (sum of that step's partials) / N; step_loss [steps]
  * (required: the terms, and the scratch of the final sum).  partials: `steps` rows of step_stride floats. */
 int    stg_tgcn_window_loss(const float *partials, int32_t steps, int64_t N, int64_t step_stride, float *step_loss,

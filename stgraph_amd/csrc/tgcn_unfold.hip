@@ -1,0 +1,83 @@
+// The gate and conv parameter gradients of a TGCN window from the three contractions that need neither x3 nor da3
+// (stgraph_amd/temporal.py::_unfold_gate_grads, one launch for the three gates instead of ~25 small torch launches per window).
+//
+// Per gate g (reference nn/pytorch/temporal/tgcn.py:21-41; x3_g = P Wc_g + bc_g unclamped, pre_g = [x3_g | Hx] Wg^T + bg,
+// d_g = d cost / d pre_g), given R_g = d_g^T [Hx | P]  [C, C + Fin]  and  cs_g = column sums of d_g  [C]:
+//   dWg[:, :C]  = d_g^T x3_g       = MgT Wc_g + cs_g bc_g^T          (MgT = R_g[:, C:],  [C, Fin])
+//   dWg[:, C:]  = d_g^T Hx         = R_g[:, :C]
+//   dbg         = cs_g
+//   dWc_g       = P^T (d_g Wg[:, :C]) = MgT^T Wg[:, :C]              [Fin, C]
+//   dbc_g       = cs_g Wg[:, :C]                                     [C]
+// One thread per output, sums of at most C terms in index order: deterministic.
+#include "stg_common.hpp"
+
+#include "../../include/stgraph_hip.h"
+
+namespace stg {
+namespace {
+
+struct UnfoldArgs {
+    const float *R[3], *cs[3], *Wc[3], *bc[3], *Wg[3];
+    float *dWg[3], *dbg[3], *dWc[3], *dbc[3];
+    int C, Fin;
+};
+
+__global__ __launch_bounds__(kBlock) void tgcn_unfold_kernel(const UnfoldArgs a)
+{
+    const int C = a.C, Fin = a.Fin, ldr = C + Fin;
+    const int per_gate = C * 2 * C + C + Fin * C + C;
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= 3 * per_gate) return;
+    const int g = gid / per_gate;
+    int i = gid - g * per_gate;
+    const float *R = a.R[g], *cs = a.cs[g], *Wc = a.Wc[g], *bc = a.bc[g], *Wg = a.Wg[g];
+    if (i < C * 2 * C) {
+        const int o = i / (2 * C), col = i - o * 2 * C;
+        float v;
+        if (col < C) {
+            v = cs[o] * bc[col];                                  // torch.addmm(outer(cs, bc), MgT, Wc): the outer product first
+            for (int f = 0; f < Fin; ++f) v = v + R[o * ldr + C + f] * Wc[f * C + col];
+        } else {
+            v = R[o * ldr + (col - C)];
+        }
+        a.dWg[g][i] = v;
+    } else if ((i -= C * 2 * C) < C) {
+        a.dbg[g][i] = cs[i];
+    } else if ((i -= C) < Fin * C) {
+        const int f = i / C, col = i - f * C;
+        float v = 0.f;
+        for (int o = 0; o < C; ++o) v = v + R[o * ldr + C + f] * Wg[o * 2 * C + col];
+        a.dWc[g][i] = v;
+    } else {
+        i -= Fin * C;
+        float v = 0.f;
+        for (int o = 0; o < C; ++o) v = v + cs[o] * Wg[o * 2 * C + i];
+        a.dbc[g][i] = v;
+    }
+}
+
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_tgcn_unfold_gate_grads(const float *const *R, const float *const *cs, const float *const *Wc,
+                                          const float *const *bc, const float *const *Wg, float *const *dWg, float *const *dbg,
+                                          float *const *dWc, float *const *dbc, int32_t C, int32_t Fin, void *stream)
+{
+    using namespace stg;
+    if (C <= 0 || Fin <= 0 || C > 1024 || Fin > 1024)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_unfold_gate_grads: bad shape C=%d Fin=%d", C, Fin);
+    if (!R || !cs || !Wc || !bc || !Wg || !dWg || !dbg || !dWc || !dbc)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_unfold_gate_grads: NULL pointer table");
+    UnfoldArgs a{};
+    for (int g = 0; g < 3; ++g) {
+        if (!R[g] || !cs[g] || !Wc[g] || !bc[g] || !Wg[g] || !dWg[g] || !dbg[g] || !dWc[g] || !dbc[g])
+            return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_unfold_gate_grads: NULL pointer for gate %d", g);
+        a.R[g] = R[g]; a.cs[g] = cs[g]; a.Wc[g] = Wc[g]; a.bc[g] = bc[g]; a.Wg[g] = Wg[g];
+        a.dWg[g] = dWg[g]; a.dbg[g] = dbg[g]; a.dWc[g] = dWc[g]; a.dbc[g] = dbc[g];
+    }
+    a.C = C; a.Fin = Fin;
+    const int total = 3 * (C * 2 * C + C + Fin * C + C);
+    hipLaunchKernelGGL(tgcn_unfold_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return check_launch("stg_tgcn_unfold_gate_grads");
+}

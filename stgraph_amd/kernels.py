@@ -1605,6 +1605,32 @@ def check_step_fold_status(device=None, clear: bool = True) -> None:
                                "wrong -- rerun with stgraph_amd.kernels.set_step_folded(False) and set_step_wgrad_from_p(False)")
 
 
+def tgcn_unfold_gate_grads(Rs, css, Wcs, bcs, Wgs, outs=None):
+    """Gate + conv parameter gradients of the three gates from ``R_g = d_g^T [Hx | P]`` [C, C + Fin] and ``cs_g`` (one launch:
+    stg_tgcn_unfold_gate_grads; see stgraph_hip.h).  ``outs``: None, or per gate (dWg, dbg, dWc, dbc) tensors to fill (the
+    parameters' ``.grad``s).  Returns the list of those four per gate."""
+    dev = Rs[0].device
+    C, Fin = int(Wgs[0].shape[0]), int(Wcs[0].shape[0])
+    srcs = [[_f32(t, "input", dev).contiguous() for t in ts] for ts in (Rs, css, Wcs, bcs, Wgs)]
+    for g in range(3):
+        if (tuple(srcs[0][g].shape) != (C, C + Fin) or srcs[1][g].numel() != C or tuple(srcs[2][g].shape) != (Fin, C)
+                or srcs[3][g].numel() != C or tuple(srcs[4][g].shape) != (C, 2 * C)):
+            raise ValueError("tgcn_unfold_gate_grads: R [C, C + Fin], cs [C], Wc [Fin, C], bc [C], Wg [C, 2C] per gate")
+    if outs is None:
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        outs = [(new(C, 2 * C), new(C), new(Fin, C), new(C)) for _ in range(3)]
+    else:
+        for g in range(3):
+            for t, shape in zip(outs[g], ((C, 2 * C), (C,), (Fin, C), (C,))):
+                if t.dtype != torch.float32 or t.device != dev or not t.is_contiguous() or tuple(t.shape) != shape:
+                    raise TypeError("tgcn_unfold_gate_grads: outputs must be contiguous fp32 (dWg [C, 2C], dbg [C], dWc [Fin, C], dbc [C])")
+    tab = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
+    with torch.cuda.device(dev):
+        _C.check(_C.lib.stg_tgcn_unfold_gate_grads(*[tab(ts) for ts in srcs], *[tab([outs[g][k] for g in range(3)]) for k in range(4)],
+                                                   C, Fin, _stream_ptr(dev)))
+    return outs
+
+
 def tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh):
     """``(w_fold [3C, Fin + C], b_fold [3C])`` for the folded forward step launch: row ``g C + c`` of w_fold is
     ``[(Wc_g @ Wg[:, :C].T).T[c] | Wg[c, C:]]`` and ``b_fold[g C + c] = (bc_g @ Wg[:, :C].T + bg)[c]`` -- the gate pre-activation

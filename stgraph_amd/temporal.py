@@ -230,14 +230,10 @@ class _TGCNWindow(torch.autograd.Function):
             res = kernels.gemm_tn_form_batch(
                 [dict(As=[d[t] for t in steps], Bs=sec, B2s=[P[t] for t in steps], M=C, N=C + Fin, nsplit=C, colsum=True)
                  for d, sec in zip(ds, seconds)] + head_calls)
-            gates = [_unfold_gate_grads(res[k][0][:, C:], res[k][1], res[k][0][:, :C], Wc, bc, Wg)
-                     for k, (Wc, bc, Wg) in enumerate(((Wcz, bcz, Wz_p), (Wcr, bcr, Wr_p), (Wch, bch, Wh_p)))]
+            gates = kernels.tgcn_unfold_gate_grads(
+                [res[k][0] for k in range(3)], [res[k][1] for k in range(3)], (Wcz, Wcr, Wch), (bcz, bcr, bch), (Wz_p, Wr_p, Wh_p),
+                outs=[(sinks[6 + 2 * k], sinks[7 + 2 * k], sinks[k], sinks[3 + k]) for k in range(3)] if sinks else None)
             if sinks:
-                for k, (dWg, dbg, dWc, dbc) in enumerate(gates):
-                    sinks[6 + 2 * k].copy_(dWg)
-                    sinks[7 + 2 * k].copy_(dbg)
-                    sinks[k].copy_(dWc)
-                    sinks[3 + k].copy_(dbc)
                 return (dx0,) + (None,) * 24
             (dW1, db1), (dW2, db2) = res[3], res[4]
             return (dx0, None, None, None, None, None, None, None, None, *[g[2] for g in gates], *[g[3] for g in gates],
@@ -604,15 +600,11 @@ class _TGCNDynWindow(torch.autograd.Function):
             res = kernels.gemm_tn_form_batch(
                 [dict(As=[d[t] for t in rng], Bs=sec, B2s=[P[t] for t in rng], M=C, N=C + Fin, nsplit=C, colsum=True)
                  for d, sec in zip(ds, seconds)] + [head_call])
-            gates = [_unfold_gate_grads(res[k][0][:, C:], res[k][1], res[k][0][:, :C], Wc, bc, Wg)
-                     for k, (Wc, bc, Wg) in enumerate(((Wcz, bcz, Wz_p), (Wcr, bcr, Wr_p), (Wch, bch, Wh_p)))]
+            gates = kernels.tgcn_unfold_gate_grads(
+                [res[k][0] for k in range(3)], [res[k][1] for k in range(3)], (Wcz, Wcr, Wch), (bcz, bcr, bch), (Wz_p, Wr_p, Wh_p),
+                outs=[(sinks[6 + 2 * k], sinks[7 + 2 * k], sinks[k], sinks[3 + k]) for k in range(3)] if sinks else None)
             ctx.steps = None
             if sinks:
-                for k, (dWg, dbg, dWc, dbc) in enumerate(gates):
-                    sinks[6 + 2 * k].copy_(dWg)
-                    sinks[7 + 2 * k].copy_(dbg)
-                    sinks[k].copy_(dWc)
-                    sinks[3 + k].copy_(dbc)
                 return (dx0,) + (None,) * 18
             dW1, db1 = res[3]
             return (dx0, None, None, None, None, *[g[2] for g in gates], *[g[3] for g in gates],

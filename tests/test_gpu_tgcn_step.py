@@ -476,3 +476,34 @@ def test_matrix_core_forward_matches_the_fp32_form(cuda, n, e, use_ew, head):
     finally:
         _C.set_tuning("step_impl", 0)
     assert all(torch.equal(s0[k], res[0][0][k]) for k in keys + ["P"])
+
+
+def test_unfold_gate_grads_kernel_against_its_torch_statement(cuda):
+    """stg_tgcn_unfold_gate_grads (the window nodes' gate / conv parameter gradients from d_g^T [Hx | P] and the column sums of d_g)
+    against temporal._unfold_gate_grads in fp64, and that statement against the direct products d_g^T [x3_g | Hx], P^T (d_g Wg[:, :C])
+    on random rows."""
+    from stgraph_amd import kernels, temporal
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    n = 700
+    r = lambda *s: torch.randn(*s, device=cuda, generator=gen)  # noqa: E731
+    Rs, css, Wcs, bcs, Wgs, want = [], [], [], [], [], []
+    for g in range(3):
+        d, Hx, P = r(n, C), r(n, C), r(n, FIN)
+        Wc, bc, Wg = r(FIN, C) * 0.3, r(C) * 0.3, r(C, 2 * C) * 0.3
+        Rs.append((d.double().t() @ torch.cat([Hx, P], 1).double()).float())
+        css.append(d.double().sum(0).float())
+        Wcs.append(Wc), bcs.append(bc), Wgs.append(Wg)
+        x3 = P.double() @ Wc.double() + bc.double()
+        direct = (d.double().t() @ torch.cat([x3, Hx.double()], 1), d.double().sum(0),
+                  P.double().t() @ (d.double() @ Wg.double()[:, :C]), (d.double() @ Wg.double()[:, :C]).sum(0))
+        stated = temporal._unfold_gate_grads(Rs[g][:, C:].double(), css[g].double(), Rs[g][:, :C].double(), Wc.double(), bc.double(), Wg.double())
+        for a, b in zip(stated, direct):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+        want.append(stated)
+    got = kernels.tgcn_unfold_gate_grads(Rs, css, Wcs, bcs, Wgs)
+    outs = [tuple(torch.full_like(t, float("nan")) for t in got[g]) for g in range(3)]
+    assert kernels.tgcn_unfold_gate_grads(Rs, css, Wcs, bcs, Wgs, outs=outs) is outs
+    for g in range(3):
+        for a, o, b in zip(got[g], outs[g], want[g]):
+            torch.testing.assert_close(a.double(), b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+            assert torch.equal(a, o)
