@@ -1491,9 +1491,10 @@ def gemm_tn_form_batch(calls):
             pb = (ctypes.c_void_p * T)(*[t.data_ptr() for t in Bs])
             pb2 = (ctypes.c_void_p * T)(*[t.data_ptr() for t in B2s]) if nsplit < N else None
             S = ctypes.c_int32(0)
-            _C.check(_C.lib.stg_gemm_tn_form_partial_f32(pa, lda, pb, ldb, nsplit, pb2, ldb2, int(c.get("b_op", GEMM_B_NONE)),
-                                                         float(c.get("lo", 0.0)), float(c.get("hi", 0.0)), T, int(colsum), K, M, N,
-                                                         _ptr(ws), ws_bytes, ctypes.byref(S), _stream_ptr(dev)))
+            with _Timed("gemm_tn_form", 4 * T * K * (M + N) + 4 * M * N, 2 * T * K * M * N):
+                _C.check(_C.lib.stg_gemm_tn_form_partial_f32(pa, lda, pb, ldb, nsplit, pb2, ldb2, int(c.get("b_op", GEMM_B_NONE)),
+                                                             float(c.get("lo", 0.0)), float(c.get("hi", 0.0)), T, int(colsum), K, M, N,
+                                                             _ptr(ws), ws_bytes, ctypes.byref(S), _stream_ptr(dev)))
             blocks, cs_blocks = c.get("out_blocks_t"), c.get("colsum_blocks")
             if blocks is not None:
                 nb = len(blocks)
@@ -1728,7 +1729,7 @@ def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     _fill_step_args(a, "tgcn_step_fwd", dev, tensors)
     a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
     # byte model: gathered input rows + index arrays + what the launch reads and writes per row
-    per_row = 4 * (Fin + 3 * C + 6 * C + (Fh + 2 if head else 0))
+    per_row = 4 * (Fin + (3 * C if tensors.get("x3") is not None else 0) + 6 * C + (Fh + 2 if head else 0))
     with torch.cuda.device(dev), _Timed("tgcn_step_fwd", N * per_row, 2 * N * (3 * C * Fin + 6 * C * C + (Fh * C if head else 0))):
         _C.check(_C.lib.stg_tgcn_step_fwd(ctypes.byref(a), _stream_ptr(dev)))
 
@@ -1745,7 +1746,7 @@ def tgcn_step_bwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     _fill_step_args(a, "tgcn_step_bwd", dev, tensors)
     a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
     a.link_inv_m = 1.0 / float(link_edges) if link_edges else 0.0
-    per_row = 4 * (6 * C + 3 * C + 3 * C + 3 * C + C + Fin + (2 * Fh + 3 if head else 0))
+    per_row = 4 * (6 * C + 3 * C + 3 * C + (3 * C if tensors.get("da3") is not None else 0) + C + Fin + (2 * Fh + 3 if head else 0))
     with torch.cuda.device(dev), _Timed("tgcn_step_bwd", N * per_row, 2 * N * (6 * C * C + 3 * C * Fin + (Fh * C if head else 0))):
         _C.check(_C.lib.stg_tgcn_step_bwd(ctypes.byref(a), _stream_ptr(dev)))
 

@@ -98,6 +98,14 @@ def _grad_sinks(params, needs):
     return sinks
 
 
+def _check_step_fold(device) -> None:
+    """End of an epoch: refuse its results if a step launch met a clamped conv output while a form that assumes none was in use
+    (kernels.STEP_WGRAD_FROM_P / STEP_FOLDED; one 4-byte read-back per epoch)."""
+    from . import kernels
+    if kernels.STEP_WGRAD_FROM_P or kernels.STEP_FOLDED:
+        kernels.check_step_fold_status(device)
+
+
 def _unfold_gate_grads(MgT, cs, dWbot, Wc, bc, Wg):
     """Gate + conv parameter gradients of one gate from the contractions over the window's rows that do not need x3 or da3:
     ``MgT = d_g^T P`` [C, Fin], ``cs`` = column sums of d_g [C], ``dWbot = d_g^T Hx`` [C, C] (d_g: gradient of the gate's
@@ -445,6 +453,7 @@ def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, 
             losses.append(cost.detach())
         bucket.all_reduce_mean(world, group, timed_comm)
         optimizer.step()
+    _check_step_fold(targets.device)
     return losses
 
 
@@ -701,6 +710,7 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
                 losses.append(cost.detach())
         bucket.all_reduce_mean(world, group, timed_comm)
         optimizer.step()
+    _check_step_fold(next(model.parameters()).device)
     return losses
 
 
@@ -910,6 +920,7 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
     for i, w in enumerate(slots):
         if w in eager:
             out[i] = eager[w]
+    _check_step_fold(out.device)
     return list(out.unbind(0))
 
 
@@ -1114,6 +1125,7 @@ def train_epoch_dynamic_captured(cd: CapturedDynamicWindows, epoch: int = 0, see
             raise RuntimeError("CapturedDynamicWindows: window %d is not covered by the fused window path" % w)
         cd.bucket.all_reduce_mean(cd.world, cd.group, timed_comm)
         cd.optimizer.step()
+    _check_step_fold(next(cd.model.parameters()).device)
     return losses
 
 
