@@ -695,6 +695,12 @@ typedef struct stg_tgcn_step_fwd_args {
      * optional: x3 may be NULL when clamp_mask is given, stg_tgcn_step_bwd_args::da3 may be NULL when z is wanted -- need to know). */
     const float *w_fold, *b_fold;
     int32_t *fold_status;
+    /* With fold_bound ({max |Wcat|, max |b3|}, two floats: stg_tgcn_fold_weights writes them) and x3 == NULL the folded launch runs
+     * on the fp32 matrix instruction instead (knob "step_fold" 0, the default; 1 = always the matrix-core folded form): the gate
+     * products straight from P on the folded weights -- 320 matrix instructions per tile instead of 512, no x3 formed.  The clamp
+     * cannot be looked at then, so the launch bounds it: |P[r, :]|_1 max |Wcat| + max |b3| outside [lo, hi] sets *fold_status.
+     * clamp_mask is not written (an inactive clamp's mask is all ones: 0xffff in every word). */
+    const float *fold_bound;
 } stg_tgcn_step_fwd_args;
 typedef struct stg_tgcn_step_bwd_args {
     const int32_t *row_offsets, *column_indices, *node_ids;
@@ -744,6 +750,12 @@ int    stg_tgcn_pack_weights_x3(const float *Wcz, const float *Wcr, const float 
  * and bias bc_g [C], the gate Linear's weight Wg [C, 2C].  Outputs (fully overwritten): dWg [C, 2C] = [R_g[:, C:] Wc_g + cs_g bc_g^T
  * | R_g[:, :C]], dbg [C] = cs_g, dWc_g [Fin, C] = R_g[:, C:]^T Wg[:, :C], dbc_g [C] = cs_g Wg[:, :C] -- exact when no element of x3 was
  * clamped (stg_tgcn_step_fwd_args::fold_status tells).  One launch, sums in index order. */
+/* ... and the gate Linears with the conv folded in, once per window, for the folded forms of the forward step launch
+ * (stg_tgcn_step_fwd_args::w_fold): w_fold [3C][Fin + C], rows g C + c = [ Wg[c, :C] . Wc_g[f, :] (f < Fin) | Wg[c, C:] ];
+ * b_fold [3C] = Wg[:, :C] bc_g + bg;  bound [2] = {max |Wc_g|, max |bc_g|} over the gates (stg_tgcn_step_fwd_args::fold_bound).
+ * Tables of three device pointers (gates z, r, h): Wc_g [Fin, C], bc_g [C], Wg [C, 2C], bg [C]. */
+int    stg_tgcn_fold_weights(const float *const *Wc, const float *const *bc, const float *const *Wg, const float *const *bg,
+                             float *w_fold, float *b_fold, float *bound, int32_t C, int32_t Fin, void *stream);
 int    stg_tgcn_unfold_gate_grads(const float *const *R, const float *const *cs, const float *const *Wc, const float *const *bc,
                                   const float *const *Wg, float *const *dWg, float *const *dbg, float *const *dWc,
                                   float *const *dbc, int32_t C, int32_t Fin, void *stream);

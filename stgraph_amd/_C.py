@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "stg_gat_fwd_k1_uniform", "stg_gat_fc_out", "stg_gat_fwd_k1_scored", "stg_gat_bwd_factored_elu",
     "stg_gat_fc_supported", "stg_gat_fc_fwd", "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32", "stg_gemm_tn_relu_mask_f32",
-    "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_tgcn_pack_weights_x3", "stg_tgcn_unfold_gate_grads", "stg_tgcn_step_image_bytes", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
+    "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_tgcn_pack_weights_x3", "stg_tgcn_unfold_gate_grads", "stg_tgcn_fold_weights", "stg_tgcn_step_image_bytes", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
@@ -83,7 +83,8 @@ class TgcnStepFwdArgs(ctypes.Structure):
                             "WcatT b3 Wz bz Wr br Wh bh W1 b1 W2 b2 P x3 Z R Ht Hn HR y y_out loss_partial clamp_mask") +
                 [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
                  ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("w_image", ctypes.c_void_p),
-                 ("w_fold", ctypes.c_void_p), ("b_fold", ctypes.c_void_p), ("fold_status", ctypes.c_void_p)])
+                 ("w_fold", ctypes.c_void_p), ("b_fold", ctypes.c_void_p), ("fold_status", ctypes.c_void_p),
+                 ("fold_bound", ctypes.c_void_p)])
 
 
 class TgcnStepBwdArgs(ctypes.Structure):
@@ -205,6 +206,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_gat_bwd_factored.argtypes = [vp] * 13 + [i32, i32, i32, f32, vp, vp, vp]
     lib.stg_gat_bwd_factored_elu.restype = ctypes.c_int
     lib.stg_gat_bwd_factored_elu.argtypes = [vp] * 14 + [i32, i32, i32, f32, vp, vp, vp]
+    lib.stg_tgcn_fold_weights.restype = ctypes.c_int
+    lib.stg_tgcn_fold_weights.argtypes = [vp] * 7 + [i32, i32, vp]
     lib.stg_tgcn_unfold_gate_grads.restype = ctypes.c_int
     lib.stg_tgcn_unfold_gate_grads.argtypes = [vp] * 9 + [i32, i32, vp]
     lib.stg_gat_fwd_k1_uniform.restype = ctypes.c_int

@@ -130,6 +130,7 @@ extern "C" int stg_set_tuning(const char *key, int value)
     }
     if (!std::strcmp(key, "store_rows")) { tuning().store_rows = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "rowgemm16")) { tuning().rowgemm16 = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "step_fold")) { tuning().step_fold = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "rowgemm_x3")) {
         if (value < 0 || value > 3) return fail(STG_ERR_INVALID_ARGUMENT, "rowgemm_x3 must be 0 .. 3");
         tuning().rowgemm_x3 = value;

@@ -9,6 +9,7 @@ struct FwdArgs {
     const float *nc_edge, *ew_edge, *norm;
     const float *x, *a3, *H, *target;
     const float *WcatT, *b3, *Wz, *bz, *Wr, *br, *Wh, *bh, *W1, *b1, *W2, *b2;
+    const float *Ag, *bgf, *bound;                     // FOLD: gate Linears with the conv folded in [3C][Fin + C], their biases [3C], {max |Wcat|, max |b3|}
     float *P, *x3, *Z, *R, *Ht, *Hn, *HR, *y, *y_out, *partial;
     unsigned *mask;
     int *status;                                       // optional: |= 1 when an element of x3 is clamped (stg_tgcn_step_fwd_args::fold_status)
@@ -17,11 +18,15 @@ struct FwdArgs {
     int num_tiles;
 };
 
-template <int C, int FIN, int FH, int WAVES, bool GATHER, int HEAD>
+// FOLD (GATHER only): the conv output enters the gates only through their Linears, so the gate products run on
+// Ag = [(Wc_g Wg[:, :C]^T)^T | Wg[:, C:]] (K = Fin + C = 96 instead of 2 C = 128, stg_tgcn_fold_weights) straight from P: no x3 product
+// (96 of the tile's 512 matrix instructions), no Wcat in LDS.  Valid while no element of x3 WOULD be clamped; x3 is not formed,
+// so the launch checks a bound instead: |x3[r, :]| <= |P[r, :]|_1 max |Wcat| + max |b3| must stay inside [lo, hi], else *status |= 1.
+template <int C, int FIN, int FH, int WAVES, bool GATHER, int HEAD, bool FOLD = false>
 struct FwdShape {
-    static constexpr int K2 = 2 * C, LDW = K2 + 8, LDC = FIN + 8, LD1 = C + 8;   // row strides = 8 mod 16 dwords: see tgcn_step.hpp
+    static constexpr int K2 = FOLD ? FIN + C : 2 * C, LDW = K2 + 8, LDC = FIN + 8, LD1 = C + 8;   // row strides = 8 mod 16 dwords: see tgcn_step.hpp
     static constexpr int kGate = 3 * C * LDW;
-    static constexpr int kCat = GATHER ? 3 * C * LDC : 0;
+    static constexpr int kCat = (GATHER && !FOLD) ? 3 * C * LDC : 0;
     static constexpr int kHead = HEAD ? FH * LD1 : 0;
     static constexpr int kBias = 6 * C + 2 * FH + 4;          // b3 | bz br bh | b1 | W2 | b2
     static constexpr int kFloats = kGate + kCat + kHead + kBias;
@@ -29,10 +34,11 @@ struct FwdShape {
     static_assert(kLds <= 160 * 1024, "the weights must fit one CU's LDS");
 };
 
-template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD>
+template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD, bool FOLD = false>
 __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdArgs a)
 {
-    using S = FwdShape<C, FIN, FH, WAVES, GATHER, HEAD>;
+    static_assert(!FOLD || GATHER, "the folded form gathers P itself");
+    using S = FwdShape<C, FIN, FH, WAVES, GATHER, HEAD, FOLD>;
     constexpr int NT = WAVES * kWave, PC = C / 16, PF = FIN / 16, PH = FH / 16;
     constexpr int LDW = S::LDW, LDC = S::LDC, LD1 = S::LD1;
     static_assert(FIN == 32 && C % 16 == 0 && FH % 16 == 0, "shapes");
@@ -58,9 +64,11 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     // and waves that start their products at different times overlap better), and -- round 3 -- no barrier at all (a count in LDS
     // each wave bumps after its share, looked at after the wave's first gather, with that gather's extent and index loads
     // issued around the staging loads: the gather ends 1.4 us earlier, the staging 0.5-1.4 us later, the launch +1 us).
-    constexpr int kStage4 = (3 * C * 2 * C + (GATHER ? 3 * C * FIN : 0) + (HEAD ? FH * C : 0)) / 4;
-    const StageSeg segs[5] = {{a.Wz, Wg, C, 2 * C, LDW}, {a.Wr, Wg + C * LDW, C, 2 * C, LDW}, {a.Wh, Wg + 2 * C * LDW, C, 2 * C, LDW},
-                              {a.WcatT, WcT, GATHER ? 3 * C : 0, FIN, LDC}, {a.W1, W1s, HEAD ? FH : 0, C, LD1}};
+    constexpr int kStage4 = (3 * C * S::K2 + ((GATHER && !FOLD) ? 3 * C * FIN : 0) + (HEAD ? FH * C : 0)) / 4;
+    const StageSeg segs[5] = {{FOLD ? a.Ag : a.Wz, Wg, C, S::K2, LDW},
+                              {FOLD ? a.Ag + C * S::K2 : a.Wr, Wg + C * LDW, C, S::K2, LDW},
+                              {FOLD ? a.Ag + 2 * C * S::K2 : a.Wh, Wg + 2 * C * LDW, C, S::K2, LDW},
+                              {a.WcatT, WcT, (GATHER && !FOLD) ? 3 * C : 0, FIN, LDC}, {a.W1, W1s, HEAD ? FH : 0, C, LD1}};
     Stager<NT, 5, (kStage4 + NT - 1) / NT> stager;
     const int q = lane & 3, grow = lane >> 2;
     // Lanes past the last row MIRROR row N - 1 (they recompute and rewrite its values bit for bit): no load or store of the tile
@@ -71,11 +79,15 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     };
     stager.issue(segs);
     stager.commit(segs);
-    for (int i = threadIdx.x; i < 3 * C; i += NT) bs[i] = a.b3[i];
-    for (int i = threadIdx.x; i < C; i += NT) {
-        bs[3 * C + i] = a.bz[i];
-        bs[4 * C + i] = a.br[i];
-        bs[5 * C + i] = a.bh[i];
+    if constexpr (FOLD) {
+        for (int i = threadIdx.x; i < 3 * C; i += NT) bs[3 * C + i] = a.bgf[i];
+    } else {
+        for (int i = threadIdx.x; i < 3 * C; i += NT) bs[i] = a.b3[i];
+        for (int i = threadIdx.x; i < C; i += NT) {
+            bs[3 * C + i] = a.bz[i];
+            bs[4 * C + i] = a.br[i];
+            bs[5 * C + i] = a.bh[i];
+        }
     }
     if constexpr (HEAD != 0) {
         for (int i = threadIdx.x; i < FH; i += NT) {
@@ -111,6 +123,16 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
             gather_to_pieces(p8, p, n16, kq);
         }
         STG_TRACE_MARK(2);
+        if constexpr (FOLD) {
+            // the fold assumes an inactive clamp: bound this row's |x3| (pieces of the row sit in its four kq lanes)
+            float s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < PF; ++j) s1 = s1 + ((fabsf(p[j].x) + fabsf(p[j].y)) + (fabsf(p[j].z) + fabsf(p[j].w)));
+            s1 = s1 + __shfl_xor(s1, 16, kWave);
+            s1 = s1 + __shfl_xor(s1, 32, kWave);
+            const float bnd = s1 * a.bound[0] + a.bound[1];
+            if (!(bnd <= a.hi && -bnd >= a.lo)) atomicOr(a.status, 1);          // (also catches NaN)
+        }
         const int64_t idx = (int64_t)tile * 16 + n16;
         const bool rok = idx < a.N;                               // only the loss partial looks at it
         // Element offsets are 32-bit (N 3C < 2^30, checked on the host); byte offsets of this lane's first piece in a row of
@@ -185,16 +207,40 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
             });
         };
 
+        // FOLD: acc = bg'_g + [P | second] Ag_g^T   (Ag_g [C][Fin + C] in LDS); wq as above (the next gate's, or the head's, step 0)
+        auto gate_f = [&](int g, const float4 (&second)[PC], f32x4 (&acc)[PC], float4 (&wq)[PC]) {
+#pragma unroll
+            for (int ct = 0; ct < PC; ++ct) acc[ct] = to_x4(*reinterpret_cast<const float4 *>(bs_l + (3 + g) * C + 16 * ct));
+            float4 w0[PC];
+#pragma unroll
+            for (int ct = 0; ct < PC; ++ct) w0[ct] = wq[ct];
+            gemm_chain<PC, PF + PC>(acc, wg_l + g * C * LDW, LDW, [&](int j) { return j < PF ? p[j % PF] : second[(j - PF) % PC]; }, w0, [&]() {
+                if (g < 2) {
+                    load_w<PC>(wq, wg_l + (g + 1) * C * LDW, LDW, 0);
+                } else if constexpr (HEAD != 0) {
+                    float4 wh[PH];
+                    load_w<PH>(wh, w1_l, LD1, 0);
+#pragma unroll
+                    for (int ft = 0; ft < PH; ++ft) wq[ft] = wh[ft];
+                }
+            });
+        };
+
         float4 wq[PC];
-        if constexpr (GATHER) load_w<PC>(wq, wc_l, LDC, 0);
+        if constexpr (FOLD) load_w<PC>(wq, wg_l, LDW, 0);
+        else if constexpr (GATHER) load_w<PC>(wq, wc_l, LDC, 0);
         // ---- Z = sigmoid([hz | H] Wz^T + bz),  R = sigmoid([hr | H] Wr^T + br) -----------------------------------
         float4 zz[PC], hr[PC];
         {
             float4 hg[PC];
             f32x4 acc[PC];
-            gate_input(0, hg, wq);
-            STG_TRACE_MARK(8);                              // (trace build only) the x3 product, its stores, clamp and mask
-            gate(0, hg, hh, acc, wq);
+            if constexpr (FOLD) {
+                gate_f(0, hh, acc, wq);
+            } else {
+                gate_input(0, hg, wq);
+                STG_TRACE_MARK(8);                          // (trace build only) the x3 product, its stores, clamp and mask
+                gate(0, hg, hh, acc, wq);
+            }
             STG_TRACE_MARK(9);                              // the gate product
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
@@ -202,8 +248,12 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
                 st_f4(a.Z, oC, 64 * j, zz[j]);
             }
             STG_TRACE_MARK(3);
-            gate_input(1, hg, wq);
-            gate(1, hg, hh, acc, wq);
+            if constexpr (FOLD) {
+                gate_f(1, hh, acc, wq);
+            } else {
+                gate_input(1, hg, wq);
+                gate(1, hg, hh, acc, wq);
+            }
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
                 const float4 r = make_float4(sigmoid_(acc[j][0]), sigmoid_(acc[j][1]), sigmoid_(acc[j][2]), sigmoid_(acc[j][3]));
@@ -219,8 +269,12 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
         {
             float4 hg[PC];
             f32x4 acc[PC];
-            gate_input(2, hg, wq);
-            gate(2, hg, hr, acc, wq);
+            if constexpr (FOLD) {
+                gate_f(2, hr, acc, wq);
+            } else {
+                gate_input(2, hg, wq);
+                gate(2, hg, hr, acc, wq);
+            }
 #pragma unroll
             for (int j = 0; j < PC; ++j) {
                 const float4 t = make_float4(tanh_(acc[j][0]), tanh_(acc[j][1]), tanh_(acc[j][2]), tanh_(acc[j][3]));
@@ -275,11 +329,11 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     }
 }
 
-template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD>
+template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD, bool FOLD = false>
 int launch_step_fwd(const FwdArgs &a, hipStream_t stream)
 {
-    using S = FwdShape<C, FIN, FH, WAVES, GATHER, HEAD>;
-    auto kern = tgcn_step_fwd_kernel<C, FIN, FH, WAVES, GATHER, HAS_EW, HEAD>;
+    using S = FwdShape<C, FIN, FH, WAVES, GATHER, HEAD, FOLD>;
+    auto kern = tgcn_step_fwd_kernel<C, FIN, FH, WAVES, GATHER, HAS_EW, HEAD, FOLD>;
     static PerDeviceOnce once;
     bool *raised = once.slot();
     if (S::kLds > 64 * 1024 && !*raised) {
@@ -367,11 +421,16 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
     if (p->head < 0 || p->head > 2) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: head must be 0, 1 or 2");
     if (p->N == 0) return 0;
     const bool gather = p->x != nullptr;
-    if (p->w_fold && (gather || (!p->a3 && p->P && p->WcatT)) && !p->node_ids && p->head >= 1 && tuning().step_impl == 0)
+    // folded gate weights: knob "step_fold" 0 = the fp32-instruction folded form below (x3 is then not formed: it must not be asked
+    // for), 1 = the matrix-core folded form (tgcn_stepf_fwd.hip)
+    const bool fold32 = p->w_fold && gather && p->head >= 1 && !p->x3 && p->fold_bound && tuning().step_impl == 0 && tuning().step_fold == 0;
+    if (p->w_fold && !fold32 && (gather || (!p->a3 && p->P && p->WcatT)) && !p->node_ids && p->head >= 1 && tuning().step_impl == 0)
         return stg_tgcn_stepf_fwd_launch(p, stream_);
+    if (fold32 && (!p->b_fold || !p->fold_status))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: w_fold, b_fold, fold_bound and fold_status go together");
     if (gather ? (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm || !p->WcatT || !p->P) : !p->a3)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL graph / input pointer");
-    if (!p->b3 || !p->Wz || !p->bz || !p->Wr || !p->br || !p->Wh || !p->bh || (!p->x3 && !p->clamp_mask) || !p->Z || !p->R || !p->Ht || !p->Hn || !p->HR)
+    if (!p->b3 || !p->Wz || !p->bz || !p->Wr || !p->br || !p->Wh || !p->bh || (!p->x3 && !p->clamp_mask && !fold32) || !p->Z || !p->R || !p->Ht || !p->Hn || !p->HR)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL cell pointer");
     if (p->head >= 1 && (!p->W1 || !p->b1 || !p->y)) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL head pointer");
     if (p->head == 2 && (!p->W2 || !p->b2 || !p->y_out || !p->target || !p->loss_partial))
@@ -388,6 +447,7 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
     a.x = p->x; a.a3 = p->a3; a.H = p->H; a.target = p->target;
     a.WcatT = p->WcatT; a.b3 = p->b3; a.Wz = p->Wz; a.bz = p->bz; a.Wr = p->Wr; a.br = p->br; a.Wh = p->Wh; a.bh = p->bh;
     a.W1 = p->W1; a.b1 = p->b1; a.W2 = p->W2; a.b2 = p->b2;
+    a.Ag = p->w_fold; a.bgf = p->b_fold; a.bound = p->fold_bound;
     a.P = p->P; a.x3 = p->x3; a.Z = p->Z; a.R = p->R; a.Ht = p->Ht; a.Hn = p->Hn; a.HR = p->HR; a.y = p->y;
     a.y_out = p->y_out; a.partial = p->loss_partial; a.mask = p->clamp_mask; a.status = p->fold_status;
     a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.num_tiles = (int)((p->N + 15) / 16);
@@ -400,6 +460,12 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
         case 0: STG_STEP_FWD(G_, EW_, 0);                                                  \
         case 1: STG_STEP_FWD(G_, EW_, 1);                                                  \
         default: STG_STEP_FWD(G_, EW_, 2);                                                 \
+    }
+    if (fold32) {
+#define STG_STEP_FWD_F(EW_, HD_) return launch_step_fwd<64, 32, 32, 12, true, EW_, HD_, true>(a, st)
+        if (p->ew_edge) { if (p->head == 1) STG_STEP_FWD_F(true, 1); else STG_STEP_FWD_F(true, 2); }
+        if (p->head == 1) STG_STEP_FWD_F(false, 1); else STG_STEP_FWD_F(false, 2);
+#undef STG_STEP_FWD_F
     }
     if (gather) {
         if (p->ew_edge) { STG_STEP_FWD_H(true, true) } else { STG_STEP_FWD_H(true, false) }

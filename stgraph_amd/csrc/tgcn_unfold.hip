@@ -61,8 +61,89 @@ __global__ __launch_bounds__(kBlock) void tgcn_unfold_kernel(const UnfoldArgs a)
     }
 }
 
+// ---- the other direction, once per window: the gate Linears with the conv folded in (stg_tgcn_fold_weights) ----------------------
+//   w_fold[g C + c][f]       = sum_k Wg[c][k] Wc_g[f][k]   (f < Fin: the P part of [P | Hx] Ag^T)
+//   w_fold[g C + c][Fin + j] = Wg[c][C + j]
+//   b_fold[g C + c]          = sum_k Wg[c][k] bc_g[k] + bg[c]
+//   bound = {max |Wc_g|, max |bc_g|} over the three gates (what a step launch that does not form x3 bounds it with)
+struct FoldArgs {
+    const float *Wc[3], *bc[3], *Wg[3], *bg[3];
+    float *w_fold, *b_fold, *bound;
+    int C, Fin;
+};
+
+__global__ __launch_bounds__(kBlock) void tgcn_fold_kernel(const FoldArgs a)
+{
+    const int C = a.C, Fin = a.Fin, K = Fin + C;
+    const int total = 3 * C * K + 3 * C;
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid < 3 * C * K) {
+        const int row = gid / K, col = gid - row * K, g = row / C, c = row - g * C;
+        const float *__restrict__ Wg = a.Wg[g] + c * 2 * C;
+        float v;
+        if (col < Fin) {
+            const float *__restrict__ Wc = a.Wc[g] + col * C;
+            v = 0.f;
+            for (int k = 0; k < C; k += 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(Wg + k), y = *reinterpret_cast<const float4 *>(Wc + k);
+                v = v + x.x * y.x;
+                v = v + x.y * y.y;
+                v = v + x.z * y.z;
+                v = v + x.w * y.w;
+            }
+        } else {
+            v = Wg[C + (col - Fin)];
+        }
+        a.w_fold[gid] = v;
+    } else if (gid < total) {
+        const int row = gid - 3 * C * K, g = row / C, c = row - g * C;
+        const float *__restrict__ Wg = a.Wg[g] + c * 2 * C, *__restrict__ bc = a.bc[g];
+        float v = a.bg[g][c];
+        for (int k = 0; k < C; ++k) v = v + Wg[k] * bc[k];
+        a.b_fold[row] = v;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < kWave) {             // the last block's first wave: the two maxima
+        float mw = 0.f, mb = 0.f;
+        for (int g = 0; g < 3; ++g) {
+            for (int i = threadIdx.x; i < Fin * C; i += kWave) mw = fmaxf(mw, fabsf(a.Wc[g][i]));
+            for (int i = threadIdx.x; i < C; i += kWave) mb = fmaxf(mb, fabsf(a.bc[g][i]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mw = fmaxf(mw, __shfl_xor(mw, o, kWave));
+            mb = fmaxf(mb, __shfl_xor(mb, o, kWave));
+        }
+        if (threadIdx.x == 0) {
+            a.bound[0] = mw;
+            a.bound[1] = mb;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace stg
+
+extern "C" int stg_tgcn_fold_weights(const float *const *Wc, const float *const *bc, const float *const *Wg, const float *const *bg,
+                                     float *w_fold, float *b_fold, float *bound, int32_t C, int32_t Fin, void *stream)
+{
+    using namespace stg;
+    if (C <= 0 || Fin <= 0 || C % 4 != 0 || C > 1024 || Fin > 1024)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_fold_weights: bad shape C=%d Fin=%d (C %% 4 == 0)", C, Fin);
+    if (!Wc || !bc || !Wg || !bg || !w_fold || !b_fold || !bound)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_fold_weights: NULL pointer argument");
+    FoldArgs a{};
+    for (int g = 0; g < 3; ++g) {
+        if (!Wc[g] || !bc[g] || !Wg[g] || !bg[g]) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_fold_weights: NULL pointer for gate %d", g);
+        if ((reinterpret_cast<uintptr_t>(Wc[g]) | reinterpret_cast<uintptr_t>(Wg[g])) & 15)
+            return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_fold_weights: weights must be 16-byte aligned");
+        a.Wc[g] = Wc[g]; a.bc[g] = bc[g]; a.Wg[g] = Wg[g]; a.bg[g] = bg[g];
+    }
+    a.w_fold = w_fold; a.b_fold = b_fold; a.bound = bound; a.C = C; a.Fin = Fin;
+    const int total = 3 * C * (Fin + C) + 3 * C;
+    hipLaunchKernelGGL(tgcn_fold_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return check_launch("stg_tgcn_fold_weights");
+}
 
 extern "C" int stg_tgcn_unfold_gate_grads(const float *const *R, const float *const *cs, const float *const *Wc,
                                           const float *const *bc, const float *const *Wg, float *const *dWg, float *const *dbg,

@@ -1556,9 +1556,10 @@ def set_step_matrix_core(enabled: bool) -> None:
 # True: the window nodes hand the FORWARD step launch the gate Linears with the conv folded in (tgcn_fold_weights) and it runs in its
 # folded form (csrc/tgcn_stepf_fwd.hip: every product a 3-term bf16 split on the matrix cores, all weights in LDS, one wave per
 # 16-row tile).  The fold is exact only while no conv output is clamped (|.| <= 1e6 always holds on sane data): the launch raises a
-# sticky per-device status word otherwise, which check_step_fold_status() turns into an error.  False (default): measured 51 us
-# against the fp32 form's 56 at cfg4 (profiles/r04_stepf_*.json) -- not enough to make a form with a validity condition the default.
-STEP_FOLDED = False
+# sticky per-device status word otherwise, which check_step_fold_status() turns into an error.  With STEP_WGRAD_FROM_P (nobody reads
+# x3 then) the launch takes the fp32-instruction folded form of csrc/tgcn_step_fwd.hip instead (knob "step_fold" 0): the gate products
+# straight from P, 320 matrix instructions per tile instead of 512, the clamp BOUNDED instead of looked at.  True (default).
+STEP_FOLDED = os.environ.get("STGRAPH_AMD_STEP_FOLDED", "1") != "0"
 
 
 def set_step_folded(enabled: bool) -> None:
@@ -1570,7 +1571,7 @@ def set_step_folded(enabled: bool) -> None:
 # instead of x3^T d_g and P^T da3: the forward launch then stores no x3 and the backward launch no da3 (38 MB each per snapshot
 # at |V| = 50 K), and the gate contractions read [P | H] instead of [x3_g | H].  Exact for an inactive clamp (the fp32 forward
 # launch raises the same sticky status word as the folded form when an element of x3 is clamped).
-STEP_WGRAD_FROM_P = True
+STEP_WGRAD_FROM_P = os.environ.get("STGRAPH_AMD_STEP_WGRAD_FROM_P", "1") != "0"
 
 
 def set_step_wgrad_from_p(enabled: bool) -> None:
@@ -1579,6 +1580,13 @@ def set_step_wgrad_from_p(enabled: bool) -> None:
 
 
 _FOLD_STATUS = {}
+
+
+def step_ones_mask(N: int, device) -> torch.Tensor:
+    """The clamp mask of an inactive clamp ([N, 12] int32 words 0xffff: the fp32 backward launch's layout) -- what a backward launch
+    reads after a folded forward launch that did not form x3.  A fresh tensor per call (one small fill): a window captured into a
+    HIP graph must own every buffer its launches read."""
+    return torch.full((int(N), 12), 0xffff, dtype=torch.int32, device=torch.device(device))
 
 
 def step_fold_status_word(device) -> torch.Tensor:
@@ -1632,18 +1640,27 @@ def tgcn_unfold_gate_grads(Rs, css, Wcs, bcs, Wgs, outs=None):
     return outs
 
 
-def tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh):
-    """``(w_fold [3C, Fin + C], b_fold [3C])`` for the folded forward step launch: row ``g C + c`` of w_fold is
-    ``[(Wc_g @ Wg[:, :C].T).T[c] | Wg[c, C:]]`` and ``b_fold[g C + c] = (bc_g @ Wg[:, :C].T + bg)[c]`` -- the gate pre-activation
-    ``[P Wc_g + bc_g | H] Wg^T + bg`` as one product of ``[P | H]`` (reference nn/pytorch/temporal/tgcn.py:21-41 without its clamp).
-    A few small torch launches per window."""
-    C = int(Wz.shape[0])
-    rows, bias = [], []
-    for Wc, bc, Wg, bg in ((Wcz, bcz, Wz, bz), (Wcr, bcr, Wr, br), (Wch, bch, Wh, bh)):
-        top = Wg[:, :C]                                         # [C out, C in]
-        rows.append(torch.cat([torch.mm(top, Wc.t()), Wg[:, C:]], dim=1))      # [C, Fin + C]
-        bias.append(torch.addmv(bg, top, bc))
-    return torch.cat(rows, dim=0).contiguous(), torch.cat(bias).contiguous()
+def tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound: bool = False):
+    """``(w_fold [3C, Fin + C], b_fold [3C])`` (+ ``bound`` [2] with ``with_bound``) for the folded forward step launch: row
+    ``g C + c`` of w_fold is ``[(Wc_g @ Wg[:, :C].T).T[c] | Wg[c, C:]]`` and ``b_fold[g C + c] = (bc_g @ Wg[:, :C].T + bg)[c]`` -- the
+    gate pre-activation ``[P Wc_g + bc_g | H] Wg^T + bg`` as one product of ``[P | H]`` (reference nn/pytorch/temporal/tgcn.py:21-41
+    without its clamp); ``bound = (max |Wc|, max |bc|)``.  One launch (stg_tgcn_fold_weights)."""
+    Wc = [_f32(t, "conv weight").contiguous() for t in (Wcz, Wcr, Wch)]
+    dev = Wc[0].device
+    bc = [_f32(t, "conv bias", dev).contiguous() for t in (bcz, bcr, bch)]
+    Wg = [_f32(t, "gate weight", dev).contiguous() for t in (Wz, Wr, Wh)]
+    bg = [_f32(t, "gate bias", dev).contiguous() for t in (bz, br, bh)]
+    Fin, C = (int(v) for v in Wc[0].shape)
+    if (any(tuple(t.shape) != (Fin, C) for t in Wc) or any(t.numel() != C for t in bc + bg) or any(tuple(t.shape) != (C, 2 * C) for t in Wg)):
+        raise ValueError("tgcn_fold_weights: conv weights [Fin, C], conv / gate biases [C], gate weights [C, 2C]")
+    w_fold = torch.empty(3 * C, Fin + C, dtype=torch.float32, device=dev)
+    b_fold = torch.empty(3 * C, dtype=torch.float32, device=dev)
+    bound = torch.empty(2, dtype=torch.float32, device=dev)
+    tab = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
+    with torch.cuda.device(dev):
+        _C.check(_C.lib.stg_tgcn_fold_weights(tab(Wc), tab(bc), tab(Wg), tab(bg), _ptr(w_fold), _ptr(b_fold), _ptr(bound), C, Fin,
+                                              _stream_ptr(dev)))
+    return (w_fold, b_fold, bound) if with_bound else (w_fold, b_fold)
 
 
 def tgcn_step_supported(C: int, Fin: int, Fh: int) -> bool:
@@ -1723,7 +1740,9 @@ def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     dev = torch.device(device)
     a = _C.TgcnStepFwdArgs()
     if tensors.get("column_indices") is not None and tensors["column_indices"].numel() == 0:
-        tensors = dict(tensors, w_image=None, w_fold=None, b_fold=None)   # the matrix-core forms assume |E| >= 1 (their gathers have no guarded loads)
+        tensors = dict(tensors, w_image=None, w_fold=None, b_fold=None, fold_bound=None)   # the matrix-core forms assume |E| >= 1 (their gathers have no guarded loads)
+    if tensors.get("w_fold") is None:
+        tensors = dict(tensors, b_fold=None, fold_bound=None)
     if tensors.get("w_fold") is not None and tensors.get("fold_status") is None:
         tensors = dict(tensors, fold_status=step_fold_status_word(dev))
     _fill_step_args(a, "tgcn_step_fwd", dev, tensors)

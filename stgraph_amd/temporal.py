@@ -141,8 +141,8 @@ class _TGCNWindow(torch.autograd.Function):
         img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2, b2)
                             if kernels.STEP_MATRIX_CORE else (None, None))
         # the gate Linears with the conv folded in: the forward launch's folded form (csrc/tgcn_stepf_fwd.hip)
-        w_fold, b_fold = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh)
-                          if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None))
+        w_fold, b_fold, f_bound = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound=True)
+                                   if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None, None))
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         from_p = kernels.STEP_WGRAD_FROM_P and not kernels.STEP_MATRIX_CORE       # weight gradients from P: no x3, no da3
         P, X3 = new(B, N, Fin), (None if from_p else new(B, N, 3 * C))
@@ -151,7 +151,9 @@ class _TGCNWindow(torch.autograd.Function):
         Y, Yout = new(B, N, Fh), new(B, N)
         tiles = kernels.tgcn_step_loss_partials(N)
         partial = new(B, tiles)
-        mask = torch.empty(B, N, 12, dtype=torch.int32, device=dev)              # clamp mask of x3, one bit per column
+        # clamp mask of x3, one bit per column; the folded forward launch does not form x3 (it bounds it): the all-ones mask then
+        mask = (kernels.step_ones_mask(N, dev).unsqueeze(0).expand(B, N, 12) if (from_p and w_fold is not None)
+                else torch.empty(B, N, 12, dtype=torch.int32, device=dev))
         # The step kernels visit rows in vertex order whatever the graph type's node_ids say: every row is computed
         # independently of the order (the reference's degree-sorted visiting order is a scheduling detail of its
         # one-thread-per-row kernels), and a 16-row tile of consecutive rows loads and stores contiguous memory where a
@@ -170,7 +172,7 @@ class _TGCNWindow(torch.autograd.Function):
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
                                   W2=W2v, b2=b2_, P=P[t], x3=None if from_p else X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t],
                                   HR=HR[t], y=Y[t], y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t], w_image=img_f,
-                                  w_fold=w_fold, b_fold=b_fold, fold_status=fold_status)
+                                  w_fold=w_fold, b_fold=b_fold, fold_bound=f_bound if from_p else None, fold_status=fold_status)
         step_loss = new(B)
         cost = kernels.tgcn_window_loss(partial, B, N, step_loss)
         ctx.save_for_backward(x0, targets, norm, normv, ew if ew is not None else norm.new_empty(0), Wcat, Wz_, Wr_, Wh_, W1_, W2v,
@@ -519,15 +521,16 @@ class _TGCNDynWindow(torch.autograd.Function):
         ctx.packed_T = (WzT, WrT, WhT, W1T)
         img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)
                             if kernels.STEP_MATRIX_CORE else (None, None))          # matrix-core form: see _TGCNWindow.forward
-        w_fold, b_fold = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh)
-                          if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None))      # folded form: likewise
+        w_fold, b_fold, f_bound = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound=True)
+                                   if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None, None))      # folded form: likewise
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         from_p = kernels.STEP_WGRAD_FROM_P and not kernels.STEP_MATRIX_CORE       # weight gradients from P: no x3, no da3 (_TGCNWindow)
         P, X3 = new(B, N, Fin), (None if from_p else new(B, N, 3 * C))
         fold_status = kernels.step_fold_status_word(dev) if (from_p or w_fold is not None) else None
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
         Y = new(B, N, Fh)
-        mask = torch.empty(B, N, 12, dtype=torch.int32, device=dev)
+        mask = (kernels.step_ones_mask(N, dev).unsqueeze(0).expand(B, N, 12) if (from_p and w_fold is not None)
+                else torch.empty(B, N, 12, dtype=torch.int32, device=dev))                        # as in _TGCNWindow.forward
         M = int(steps[0]["edges"].shape[1])
         if any(int(st["edges"].shape[1]) != M for st in steps):
             raise ValueError("all snapshots of a window must carry the same number of label edges")
@@ -545,7 +548,8 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   norm=st["normv"], x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
                                   P=P[t], x3=None if from_p else X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t],
-                                  clamp_mask=mask[t], w_image=img_f, w_fold=w_fold, b_fold=b_fold, fold_status=fold_status)
+                                  clamp_mask=mask[t], w_image=img_f, w_fold=w_fold, b_fold=b_fold,
+                                  fold_bound=f_bound if from_p else None, fold_status=fold_status)
         # the decoder + loss of every snapshot behind the last step, in one launch: a snapshot's loss feeds nothing in the next one
         kernels.link_decode_fwd_window([Y[t] for t in range(B)], [st["edges"] for st in steps], [st["targets"] for st in steps],
                                        [logits[t] for t in range(B)], [partial[t] for t in range(B)])

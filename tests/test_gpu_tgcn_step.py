@@ -98,11 +98,16 @@ def _images(p):
 def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, hi=HI, x3form=False):
     from stgraph_amd import kernels
     out = _alloc(cuda, n)
-    if x3form == "folded":                    # csrc/tgcn_stepf_fwd.hip: the conv folded into the gate Linears
-        Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
+    if x3form in ("folded", "folded32"):      # the conv folded into the gate Linears: csrc/tgcn_stepf_fwd.hip (matrix cores) /
+        Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]      # the FOLD form of csrc/tgcn_step_fwd.hip (fp32 instruction)
         bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
-        out["w_fold"], out["b_fold"] = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"])
+        out["w_fold"], out["b_fold"], bound = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"],
+                                                                        with_bound=True)
         assert out["w_fold"].shape == (3 * C, FIN + C) and out["b_fold"].shape == (3 * C,)
+        assert float(bound[0]) == float(p["Wcat"].abs().max()) and float(bound[1]) == float(p["b3"].abs().max())
+        if x3form == "folded32":               # x3 is not formed (nor asked for), the clamp is bounded instead of looked at
+            out["fold_bound"], out["x3"] = bound, None
+            out["clamp_mask"] = kernels.step_ones_mask(n, cuda)
     elif x3form:
         out["w_image"] = _images(p)[0]
     nc = kernels._edge_gathered(g.fwd, "norm", norm, g.fwd.column_indices)
@@ -112,8 +117,10 @@ def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, h
                           x=x, H=H, target=target, WcatT=p["Wcat"].t().contiguous(), b3=p["b3"], Wz=p["Wz"], bz=p["bz"],
                           Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"], W1=p["W1"], b1=p["b1"],
                           W2=p["W2"].view(-1).contiguous(), b2=p["b2"], **out)
-    for k in ("w_image", "w_fold", "b_fold"):
+    for k in ("w_image", "w_fold", "b_fold", "fold_bound"):
         out.pop(k, None)
+    if x3form == "folded32":                   # the launch formed no x3: what the checks downstream read is P Wcat + b3
+        out["x3"] = out["P"] @ p["Wcat"] + p["b3"]
     return out
 
 
@@ -123,7 +130,7 @@ def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True
     new = lambda *s: torch.full(s, float("nan"), device=cuda)  # noqa: E731
     out = dict(dzl=new(n, C), drl=new(n, C), dhl=new(n, C), da3=new(n, 3 * C), dH=new(n, C), dyt=new(n, FH), dyo=new(n),
                z=new(n, FIN) if want_z else None)
-    if x3form == "folded":                       # the folded forward leaves the fp32 form's saved tensors: the fp32 backward follows it
+    if x3form in ("folded", "folded32"):         # the folded forwards leave the fp32 form's saved tensors: the fp32 backward follows them
         use_mask = True
     elif x3form:                                 # the matrix-core form reads the mask its forward twin wrote
         out["w_image"], use_mask = _images(p)[1], True
@@ -152,7 +159,7 @@ def _close(got, want, what, tol=2e-5):
                                                  # 7501 tiles on 3072 wave slots, one row in the last tile: every wave takes
                                                  # further tiles off the workgroup's counter
                                                  (120_001, 1_000_000, False, False)])
-@pytest.mark.parametrize("x3form", [False, True, "folded"])
+@pytest.mark.parametrize("x3form", [False, True, "folded", "folded32"])
 def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3form):
     """``x3form``: the matrix-core form of both launches (a weight image in the argument block; csrc/tgcn_stepx_*.hip) -- the SAME
     fp64 reference and the SAME tolerances as the fp32 form.  ``"folded"``: the folded forward launch (csrc/tgcn_stepf_fwd.hip)
@@ -182,7 +189,7 @@ def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3f
     b0_again = _bwd(cuda, g, norm, ew, p, s0, None, t0, n, zn=b1["z"], dHn=b1["dH"], g_cost=g_cost, node_ids=node_ids, x3form=x3form)
     assert all(torch.equal(b0[k], b0_again[k]) for k in b0)            # deterministic: no atomics, fixed orders
     assert int(kernels.step_fold_status_word(cuda).item()) == 0
-    if x3form == "folded":
+    if x3form in ("folded", "folded32"):
         s0_again = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, node_ids=node_ids, x3form=x3form)
         assert all(torch.equal(s0[k], s0_again[k]) for k in s0)
         assert bool((s0["clamp_mask"] == 0xffff).all())
