@@ -723,6 +723,11 @@ typedef struct stg_tgcn_step_bwd_args {
     /* Optional (NULL: not used): the backward weight image of stg_tgcn_pack_weights_x3 -- the matrix-core form of the backward
      * launch (csrc/tgcn_stepx_bwd.hip), for a clamp_mask written by the matrix-core forward launch. */
     const void *w_image;
+    /* Optional (NULL: not used; ABI 24): [3 Fin][C], rows g Fin + f = the folded gate weights' P part transposed (stg_tgcn_fold_weights'
+     * w_fold_t).  With it, da3 == NULL and head >= 1 the launch takes its FOLDED form: z = sum_g d_g w_fold_t_g^T instead of da3 Wcat^T
+     * with da3_g = d_g Wg[:, :C] (320 matrix instructions per tile instead of 512), da3 is not formed and neither x3 nor clamp_mask
+     * read -- exact for an inactive clamp (stg_tgcn_step_fwd_args::fold_status tells).  Wcat may then be NULL. */
+    const float *w_fold_t;
 } stg_tgcn_step_bwd_args;
 int    stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh);
 size_t stg_tgcn_step_loss_partials(int64_t N);
@@ -752,10 +757,11 @@ int    stg_tgcn_pack_weights_x3(const float *Wcz, const float *Wcr, const float 
  * clamped (stg_tgcn_step_fwd_args::fold_status tells).  One launch, sums in index order. */
 /* ... and the gate Linears with the conv folded in, once per window, for the folded forms of the forward step launch
  * (stg_tgcn_step_fwd_args::w_fold): w_fold [3C][Fin + C], rows g C + c = [ Wg[c, :C] . Wc_g[f, :] (f < Fin) | Wg[c, C:] ];
- * b_fold [3C] = Wg[:, :C] bc_g + bg;  bound [2] = {max |Wc_g|, max |bc_g|} over the gates (stg_tgcn_step_fwd_args::fold_bound).
+ * b_fold [3C] = Wg[:, :C] bc_g + bg;  bound [2] = {max |Wc_g|, max |bc_g|} over the gates (stg_tgcn_step_fwd_args::fold_bound);
+ * w_fold_t [3 Fin][C] (nullable), rows g Fin + f = w_fold[g C + :, f] (stg_tgcn_step_bwd_args::w_fold_t).
  * Tables of three device pointers (gates z, r, h): Wc_g [Fin, C], bc_g [C], Wg [C, 2C], bg [C]. */
 int    stg_tgcn_fold_weights(const float *const *Wc, const float *const *bc, const float *const *Wg, const float *const *bg,
-                             float *w_fold, float *b_fold, float *bound, int32_t C, int32_t Fin, void *stream);
+                             float *w_fold, float *b_fold, float *bound, float *w_fold_t, int32_t C, int32_t Fin, void *stream);
 int    stg_tgcn_unfold_gate_grads(const float *const *R, const float *const *cs, const float *const *Wc, const float *const *bc,
                                   const float *const *Wg, float *const *dWg, float *const *dbg, float *const *dWc,
                                   float *const *dbc, int32_t C, int32_t Fin, void *stream);

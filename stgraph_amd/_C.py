@@ -94,7 +94,8 @@ class TgcnStepBwdArgs(ctypes.Structure):
                 [("N", ctypes.c_int64), ("C", ctypes.c_int32), ("Fin", ctypes.c_int32), ("Fh", ctypes.c_int32),
                  ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)] +
                 _ptr_fields("link_row_ptr link_other link_eid link_y link_logits link_target") + [("link_inv_m", ctypes.c_float),
-                                                                                                    ("w_image", ctypes.c_void_p)])
+                                                                                                    ("w_image", ctypes.c_void_p),
+                                                                                                    ("w_fold_t", ctypes.c_void_p)])
 
 
 class StgError(RuntimeError):
@@ -207,7 +208,7 @@ def _load() -> ctypes.CDLL:
     lib.stg_gat_bwd_factored_elu.restype = ctypes.c_int
     lib.stg_gat_bwd_factored_elu.argtypes = [vp] * 14 + [i32, i32, i32, f32, vp, vp, vp]
     lib.stg_tgcn_fold_weights.restype = ctypes.c_int
-    lib.stg_tgcn_fold_weights.argtypes = [vp] * 7 + [i32, i32, vp]
+    lib.stg_tgcn_fold_weights.argtypes = [vp] * 8 + [i32, i32, vp]
     lib.stg_tgcn_unfold_gate_grads.restype = ctypes.c_int
     lib.stg_tgcn_unfold_gate_grads.argtypes = [vp] * 9 + [i32, i32, vp]
     lib.stg_gat_fwd_k1_uniform.restype = ctypes.c_int

@@ -11,6 +11,7 @@ struct BwdArgs {
     const float *zn, *gy, *dHn, *g_cost;
     const float *Z, *R, *Ht, *H, *Hn, *x3, *y_out, *target;
     const float *WzT, *WrT, *WhT, *Wcat, *W1T, *W2;
+    const float *At;                                           // FOLD: [3 Fin][C], rows g Fin + f = the folded gate weights' P part, transposed
     float *dzl, *drl, *dhl, *da3, *dH, *z, *dyt, *dyo;
     const unsigned *mask;
     const int *link_row_ptr, *link_other, *link_eid;           // node side of the link loss's backward (head == 1; NULL: not here)
@@ -21,11 +22,15 @@ struct BwdArgs {
     int num_tiles;
 };
 
-template <int C, int FIN, int FH, int WAVES, bool GATHER, int HEAD>
+// FOLD: the input gradient z = da3 Wcat^T with da3_g = d_g Wg[:, :C] is  sum_g d_g At_g^T  with At_g [Fin][C] = (the folded gate
+// weights' P part)^T (stg_tgcn_fold_weights): three products of K = C onto Fin columns (96 matrix instructions per tile) instead of
+// three onto C columns + da3 Wcat^T (288); da3 is not formed and the clamp mask not read (an inactive clamp is the fold's premise:
+// the forward launch raises the status word otherwise).  LDS holds the gate Linears' H halves only.
+template <int C, int FIN, int FH, int WAVES, bool GATHER, int HEAD, bool FOLD = false>
 struct BwdShape {
     static constexpr int K2 = 2 * C, LDB = C + 8, LDX = 3 * C + 8, LDT = FH + 8;   // row strides = 8 mod 16 dwords: see tgcn_step.hpp
-    static constexpr int kGate = 3 * K2 * LDB;                // WzT | WrT | WhT, each [2C][LDB]
-    static constexpr int kCat = FIN * LDX;                    // Wcat [FIN][LDX]
+    static constexpr int kGate = FOLD ? 3 * C * LDB : 3 * K2 * LDB;   // WzT | WrT | WhT, each [2C][LDB] (FOLD: rows C .. 2C - 1 of each)
+    static constexpr int kCat = FOLD ? 3 * FIN * LDB : FIN * LDX;     // Wcat [FIN][LDX] (FOLD: At [3 FIN][LDB])
     static constexpr int kHead = HEAD ? C * LDT : 0;          // W1T [C][LDT]
     static constexpr int kBias = FH + 4;                      // W2
     static constexpr int kFloats = kGate + kCat + kHead + kBias;
@@ -33,10 +38,10 @@ struct BwdShape {
     static_assert(kLds <= 160 * 1024, "the weights must fit one CU's LDS");
 };
 
-template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD>
+template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD, bool FOLD = false>
 __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdArgs a)
 {
-    using S = BwdShape<C, FIN, FH, WAVES, GATHER, HEAD>;
+    using S = BwdShape<C, FIN, FH, WAVES, GATHER, HEAD, FOLD>;
     constexpr int NT = WAVES * kWave, PC = C / 16, PF = FIN / 16, PH = FH / 16;
     constexpr int LDB = S::LDB, LDX = S::LDX, LDT = S::LDT;
     static_assert(FIN == 32 && FH == FIN, "the head's output is the next step's input");
@@ -55,9 +60,11 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
     if (threadIdx.x == 0) *next_w = WAVES;
     int tile = wave * (int)gridDim.x + (int)blockIdx.x;
     const bool want_z = a.z != nullptr;                // block-uniform
-    constexpr int kStage4 = (3 * 2 * C * C + FIN * 3 * C + (HEAD ? C * FH : 0)) / 4;
-    const StageSeg segs[5] = {{a.WzT, WgT, 2 * C, C, LDB}, {a.WrT, WgT + 2 * C * LDB, 2 * C, C, LDB},
-                              {a.WhT, WgT + 4 * C * LDB, 2 * C, C, LDB}, {a.Wcat, Wc, want_z ? FIN : 0, 3 * C, LDX},
+    constexpr int kStage4 = ((FOLD ? 3 * C * C : 3 * 2 * C * C) + FIN * 3 * C + (HEAD ? C * FH : 0)) / 4;
+    constexpr int GR = FOLD ? C : 2 * C;                // rows of a gate's block in LDS (FOLD: its H half, rows C .. 2C - 1 of W_g^T)
+    const StageSeg segs[5] = {{FOLD ? a.WzT + C * C : a.WzT, WgT, GR, C, LDB}, {FOLD ? a.WrT + C * C : a.WrT, WgT + GR * LDB, GR, C, LDB},
+                              {FOLD ? a.WhT + C * C : a.WhT, WgT + 2 * GR * LDB, GR, C, LDB},
+                              {FOLD ? a.At : a.Wcat, Wc, want_z ? (FOLD ? 3 * FIN : FIN) : 0, FOLD ? C : 3 * C, FOLD ? LDB : LDX},
                               {a.W1T, W1T, HEAD ? C : 0, FH, LDT}};
     Stager<NT, 5, (kStage4 + NT - 1) / NT> stager;
     const bool do_gather = GATHER && HEAD != 0 && a.zn != nullptr;      // block-uniform
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
 
     const float lo = a.lo, hi = a.hi;
     // this lane's row / piece inside each LDS matrix (tgcn_step.hpp: pinned)
-    const float *const wg_l = WgT + pinned((unsigned)(n16 * LDB + 4 * kq)), *const wcrow = Wc + pinned((unsigned)(n16 * LDX + 4 * kq));
+    const float *const wg_l = WgT + pinned((unsigned)(n16 * LDB + 4 * kq)), *const wcrow = Wc + pinned((unsigned)(n16 * (FOLD ? LDB : LDX) + 4 * kq));
     const float *const w1_l = W1T + pinned((unsigned)(n16 * LDT + 4 * kq)), *const bs_l = bs + pinned((unsigned)(4 * kq));
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     while (tile < a.num_tiles) {
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         // clamp mask of the 3C columns of x3 as 48 bits (used by three later phases: 2 registers)
         unsigned mlo = 0u, mhi = 0u;
         unsigned m0 = 0u, m1 = 0u, m2 = 0u;
-        if (!a.mask) {                                               // wave-uniform; the test-only form (no mask from the forward launch)
+        if (!FOLD && !a.mask) {                                      // wave-uniform; the test-only form (no mask from the forward launch)
             float4 v[3 * PC];
 #pragma unroll
             for (int c = 0; c < 3 * PC; ++c) v[c] = ld_f4(a.x3, o3, 64 * c);
@@ -128,9 +135,11 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         {
             // word 4 g + kq of the row: 16 bits for gate g; packed below as bit 16 g + 4 blk + i (gates 0, 1 in mlo, 2 in mhi).
             // Loaded without a branch (from Z's rows, discarded, when there is no mask) so that the unpacking stays below the batch.
-            const unsigned *mbase = a.mask ? a.mask : reinterpret_cast<const unsigned *>(a.Z);
-            const unsigned *mp = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(mbase) + (size_t)((row * 12u + kq) * 4u));
-            m0 = mp[0], m1 = mp[4], m2 = mp[8];
+            if constexpr (!FOLD) {
+                const unsigned *mbase = a.mask ? a.mask : reinterpret_cast<const unsigned *>(a.Z);
+                const unsigned *mp = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(mbase) + (size_t)((row * 12u + kq) * 4u));
+                m0 = mp[0], m1 = mp[4], m2 = mp[8];
+            }
         }
 #pragma unroll
         for (int j = 0; j < PC; ++j) dhn[j] = hh[j] = hn[j] = zero4;
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         for (int ft = 0; ft < PF; ++ft) zacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
         // out[blk] = (in (K = C) x W_g[:, half C + 16 blk ..]) as row pieces; W_g^T is [2C][LDB] in LDS
         auto gemm = [&](const float4 (&in)[PC], int g, int half, f32x4 (&acc)[PC]) {
-            const float *w = wg_l + (g * 2 * C + half * C) * LDB;
+            const float *w = wg_l + (FOLD ? g * C : g * 2 * C + half * C) * LDB;      // FOLD keeps the H halves only (half == 1)
 #pragma unroll
             for (int ct = 0; ct < PC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             gemm_pieces<PC, PC, (WAVES <= 12)>(acc, w, LDB, [&](int j) { return in[j]; });
@@ -273,10 +282,18 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
             }
         };
 
+        // FOLD: z += d_g At_g^T (At_g [FIN][C] in LDS at wcrow + g FIN LDB): the gate's whole contribution to the input gradient
+        auto emit_z = [&](int g, const float4 (&d)[PC]) {
+            if (want_z) gemm_pieces<PF, PC, (WAVES <= 12)>(zacc, wcrow + g * FIN * LDB, LDB, [&](int j) { return d[j]; });
+        };
         f32x4 acc[PC];
         // ---- dCH = dhl Wh: d(hh) -> da3[:, 2C..];  dHR -> drl, dH ---------------------------------------------------
-        gemm(dhl, 2, 0, acc);
-        emit_da3(2, acc);
+        if constexpr (FOLD) {
+            emit_z(2, dhl);
+        } else {
+            gemm(dhl, 2, 0, acc);
+            emit_da3(2, acc);
+        }
         STG_TRACE_MARK(4);
         float4 rr[PC], hb[PC], dzl[PC];                          // for the dHR stage: in flight under the next product
 #pragma unroll
@@ -301,16 +318,24 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         }
         // ---- dCZ = dzl Wz,  dCR = drl Wr: d(hz), d(hr) -> da3;  second halves -> dH (dCZ's first, then dCR's) -------
         STG_TRACE_MARK(5);
-        gemm(dzl, 0, 0, acc);
-        emit_da3(0, acc);
+        if constexpr (FOLD) {
+            emit_z(0, dzl);
+        } else {
+            gemm(dzl, 0, 0, acc);
+            emit_da3(0, acc);
+        }
         gemm(dzl, 0, 1, acc);
 #pragma unroll
         for (int blk = 0; blk < PC; ++blk)
             dHa[blk] = make_float4(dHa[blk].x + acc[blk][0], dHa[blk].y + acc[blk][1], dHa[blk].z + acc[blk][2],
                                    dHa[blk].w + acc[blk][3]);
         STG_TRACE_MARK(6);
-        gemm(drl, 1, 0, acc);
-        emit_da3(1, acc);
+        if constexpr (FOLD) {
+            emit_z(1, drl);
+        } else {
+            gemm(drl, 1, 0, acc);
+            emit_da3(1, acc);
+        }
         gemm(drl, 1, 1, acc);
 #pragma unroll
         for (int blk = 0; blk < PC; ++blk)
@@ -328,11 +353,11 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
     }
 }
 
-template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD>
+template <int C, int FIN, int FH, int WAVES, bool GATHER, bool HAS_EW, int HEAD, bool FOLD = false>
 int launch_step_bwd(const BwdArgs &a, hipStream_t stream)
 {
-    using S = BwdShape<C, FIN, FH, WAVES, GATHER, HEAD>;
-    auto kern = tgcn_step_bwd_kernel<C, FIN, FH, WAVES, GATHER, HAS_EW, HEAD>;
+    using S = BwdShape<C, FIN, FH, WAVES, GATHER, HEAD, FOLD>;
+    auto kern = tgcn_step_bwd_kernel<C, FIN, FH, WAVES, GATHER, HAS_EW, HEAD, FOLD>;
     static PerDeviceOnce once;
     bool *raised = once.slot();
     if (S::kLds > 64 * 1024 && !*raised) {
@@ -378,9 +403,11 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     if (gather && (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL graph pointer");
     if ((int64_t)p->N * 3 * p->C >= ((int64_t)1 << 30)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_bwd: too many rows for 32-bit offsets");
-    if (!p->Z || !p->R || !p->Ht || (!p->x3 && !p->clamp_mask) || !p->WzT || !p->WrT || !p->WhT || !p->dzl || !p->drl || !p->dhl || (!p->da3 && !p->z) || !p->dH)
+    // folded form: w_fold_t given, no da3 asked for, head >= 1 (knob "step_impl" 1 never takes it)
+    const bool fold = p->w_fold_t && !p->da3 && p->head >= 1 && tuning().step_impl == 0;
+    if (!p->Z || !p->R || !p->Ht || (!p->x3 && !p->clamp_mask && !fold) || !p->WzT || !p->WrT || !p->WhT || !p->dzl || !p->drl || !p->dhl || (!p->da3 && !p->z) || !p->dH)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL cell pointer");
-    if (p->z && !p->Wcat) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: z wanted but Wcat is NULL");
+    if (p->z && !p->Wcat && !fold) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: z wanted but Wcat is NULL");
     if (p->head >= 1 && (!p->W1T || !p->Hn || !p->dyt)) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL head pointer");
     if (p->head == 2 && (!p->W2 || !p->y_out || !p->target || !p->g_cost || !p->dyo))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL loss pointer");
@@ -397,6 +424,7 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     a.zn = p->zn; a.gy = p->g_y; a.dHn = p->dHn; a.g_cost = p->g_cost;
     a.Z = p->Z; a.R = p->R; a.Ht = p->Ht; a.H = p->H; a.Hn = p->Hn; a.x3 = p->x3; a.y_out = p->y_out; a.target = p->target;
     a.WzT = p->WzT; a.WrT = p->WrT; a.WhT = p->WhT; a.Wcat = p->Wcat; a.W1T = p->W1T; a.W2 = p->W2;
+    a.At = p->w_fold_t;
     a.mask = p->clamp_mask;
     if (p->link_row_ptr) {
         if (p->head != 1 || !p->link_other || !p->link_eid || !p->link_y || !p->link_logits || !p->link_target || !p->g_cost ||
@@ -411,6 +439,15 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     const bool w16 = tuning().step_waves == 16;
 #define STG_STEP_BWD(G_, EW_, HD_)                                                         \
     return w16 ? launch_step_bwd<64, 32, 32, 16, G_, EW_, HD_>(a, st) : launch_step_bwd<64, 32, 32, 12, G_, EW_, HD_>(a, st)
+    if (fold) {
+#define STG_STEP_BWD_F(G_, EW_, HD_) return launch_step_bwd<64, 32, 32, 12, G_, EW_, HD_, true>(a, st)
+        if (gather) {
+            if (p->ew_edge) { if (p->head == 1) STG_STEP_BWD_F(true, true, 1); else STG_STEP_BWD_F(true, true, 2); }
+            if (p->head == 1) STG_STEP_BWD_F(true, false, 1); else STG_STEP_BWD_F(true, false, 2);
+        }
+        if (p->head == 1) STG_STEP_BWD_F(false, false, 1); else STG_STEP_BWD_F(false, false, 2);
+#undef STG_STEP_BWD_F
+    }
     if (p->head == 0) STG_STEP_BWD(false, false, 0);
     if (gather) {
         if (p->ew_edge) {

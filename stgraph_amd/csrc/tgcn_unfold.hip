@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void tgcn_unfold_kernel(const UnfoldArgs a)
 //   bound = {max |Wc_g|, max |bc_g|} over the three gates (what a step launch that does not form x3 bounds it with)
 struct FoldArgs {
     const float *Wc[3], *bc[3], *Wg[3], *bg[3];
-    float *w_fold, *b_fold, *bound;
+    float *w_fold, *b_fold, *bound, *w_fold_t;
     int C, Fin;
 };
 
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(kBlock) void tgcn_fold_kernel(const FoldArgs a)
                 v = v + x.z * y.z;
                 v = v + x.w * y.w;
             }
+            if (a.w_fold_t) a.w_fold_t[(g * Fin + col) * C + c] = v;
         } else {
             v = Wg[C + (col - Fin)];
         }
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void tgcn_fold_kernel(const FoldArgs a)
 }  // namespace stg
 
 extern "C" int stg_tgcn_fold_weights(const float *const *Wc, const float *const *bc, const float *const *Wg, const float *const *bg,
-                                     float *w_fold, float *b_fold, float *bound, int32_t C, int32_t Fin, void *stream)
+                                     float *w_fold, float *b_fold, float *bound, float *w_fold_t, int32_t C, int32_t Fin, void *stream)
 {
     using namespace stg;
     if (C <= 0 || Fin <= 0 || C % 4 != 0 || C > 1024 || Fin > 1024)
@@ -138,7 +139,7 @@ extern "C" int stg_tgcn_fold_weights(const float *const *Wc, const float *const 
             return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_fold_weights: weights must be 16-byte aligned");
         a.Wc[g] = Wc[g]; a.bc[g] = bc[g]; a.Wg[g] = Wg[g]; a.bg[g] = bg[g];
     }
-    a.w_fold = w_fold; a.b_fold = b_fold; a.bound = bound; a.C = C; a.Fin = Fin;
+    a.w_fold = w_fold; a.b_fold = b_fold; a.bound = bound; a.w_fold_t = w_fold_t; a.C = C; a.Fin = Fin;
     const int total = 3 * C * (Fin + C) + 3 * C;
     hipLaunchKernelGGL(tgcn_fold_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), a);

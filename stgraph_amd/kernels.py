@@ -1641,7 +1641,8 @@ def tgcn_unfold_gate_grads(Rs, css, Wcs, bcs, Wgs, outs=None):
 
 
 def tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound: bool = False):
-    """``(w_fold [3C, Fin + C], b_fold [3C])`` (+ ``bound`` [2] with ``with_bound``) for the folded forward step launch: row
+    """``(w_fold [3C, Fin + C], b_fold [3C])`` (+ ``bound`` [2] and ``w_fold_t`` [3 Fin, C], the folded backward launch's operand,
+    with ``with_bound``) for the folded forward step launch: row
     ``g C + c`` of w_fold is ``[(Wc_g @ Wg[:, :C].T).T[c] | Wg[c, C:]]`` and ``b_fold[g C + c] = (bc_g @ Wg[:, :C].T + bg)[c]`` -- the
     gate pre-activation ``[P Wc_g + bc_g | H] Wg^T + bg`` as one product of ``[P | H]`` (reference nn/pytorch/temporal/tgcn.py:21-41
     without its clamp); ``bound = (max |Wc|, max |bc|)``.  One launch (stg_tgcn_fold_weights)."""
@@ -1656,11 +1657,12 @@ def tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with
     w_fold = torch.empty(3 * C, Fin + C, dtype=torch.float32, device=dev)
     b_fold = torch.empty(3 * C, dtype=torch.float32, device=dev)
     bound = torch.empty(2, dtype=torch.float32, device=dev)
+    w_fold_t = torch.empty(3 * Fin, C, dtype=torch.float32, device=dev) if with_bound else None     # the backward launch's operand
     tab = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
     with torch.cuda.device(dev):
-        _C.check(_C.lib.stg_tgcn_fold_weights(tab(Wc), tab(bc), tab(Wg), tab(bg), _ptr(w_fold), _ptr(b_fold), _ptr(bound), C, Fin,
-                                              _stream_ptr(dev)))
-    return (w_fold, b_fold, bound) if with_bound else (w_fold, b_fold)
+        _C.check(_C.lib.stg_tgcn_fold_weights(tab(Wc), tab(bc), tab(Wg), tab(bg), _ptr(w_fold), _ptr(b_fold), _ptr(bound), _ptr(w_fold_t),
+                                              C, Fin, _stream_ptr(dev)))
+    return (w_fold, b_fold, bound, w_fold_t) if with_bound else (w_fold, b_fold)
 
 
 def tgcn_step_supported(C: int, Fin: int, Fh: int) -> bool:

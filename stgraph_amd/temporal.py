@@ -141,8 +141,8 @@ class _TGCNWindow(torch.autograd.Function):
         img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2, b2)
                             if kernels.STEP_MATRIX_CORE else (None, None))
         # the gate Linears with the conv folded in: the forward launch's folded form (csrc/tgcn_stepf_fwd.hip)
-        w_fold, b_fold, f_bound = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound=True)
-                                   if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None, None))
+        w_fold, b_fold, f_bound, ctx.w_fold_t = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound=True)
+                                   if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None, None, None))
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         from_p = kernels.STEP_WGRAD_FROM_P and not kernels.STEP_MATRIX_CORE       # weight gradients from P: no x3, no da3
         P, X3 = new(B, N, Fin), (None if from_p else new(B, N, 3 * C))
@@ -214,7 +214,7 @@ class _TGCNWindow(torch.autograd.Function):
                                   y_out=Yout[t], target=targets[t], WzT=WzT, WrT=WrT, WhT=WhT, Wcat=Wcat, W1T=W1T, W2=W2v,
                                   dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=None if from_p else da3[t], dH=dH[t & 1],
                                   z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t], dyo=dyo[t],
-                                  w_image=ctx.img_b)
+                                  w_image=ctx.img_b, w_fold_t=ctx.w_fold_t if from_p else None)
         dx0 = kernels.gcn_agg(zbuf[0], norm, norm, bwd, ew=ew, use_node_ids=ctx.use_nid) if want_dx0 else None
         # weight gradients: one split-K launch per parameter over the window's snapshots
         steps = range(B)
@@ -521,8 +521,8 @@ class _TGCNDynWindow(torch.autograd.Function):
         ctx.packed_T = (WzT, WrT, WhT, W1T)
         img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)
                             if kernels.STEP_MATRIX_CORE else (None, None))          # matrix-core form: see _TGCNWindow.forward
-        w_fold, b_fold, f_bound = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound=True)
-                                   if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None, None))      # folded form: likewise
+        w_fold, b_fold, f_bound, ctx.w_fold_t = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound=True)
+                                   if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None, None, None))      # folded form: likewise
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         from_p = kernels.STEP_WGRAD_FROM_P and not kernels.STEP_MATRIX_CORE       # weight gradients from P: no x3, no da3 (_TGCNWindow)
         P, X3 = new(B, N, Fin), (None if from_p else new(B, N, 3 * C))
@@ -593,7 +593,8 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   Z=Z[t], R=R[t], Ht=Ht[t],
                                   H=None if t == 0 else Hn[t - 1], Hn=Hn[t], clamp_mask=mask[t], WzT=WzT, WrT=WrT, WhT=WhT,
                                   Wcat=Wcat, W1T=W1T, dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=None if from_p else da3[t], dH=dH[t & 1],
-                                  z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t], w_image=ctx.img_b, **kw)
+                                  z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t], w_image=ctx.img_b,
+                                  w_fold_t=ctx.w_fold_t if from_p else None, **kw)
         dx0 = None
         if want_dx0:
             s0 = steps[0]

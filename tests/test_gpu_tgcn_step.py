@@ -101,8 +101,9 @@ def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, h
     if x3form in ("folded", "folded32"):      # the conv folded into the gate Linears: csrc/tgcn_stepf_fwd.hip (matrix cores) /
         Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]      # the FOLD form of csrc/tgcn_step_fwd.hip (fp32 instruction)
         bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
-        out["w_fold"], out["b_fold"], bound = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"],
-                                                                        with_bound=True)
+        out["w_fold"], out["b_fold"], bound, w_fold_t = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"],
+                                                                                  p["bh"], with_bound=True)
+        assert torch.equal(w_fold_t.view(3, FIN, C), out["w_fold"].view(3, C, FIN + C)[:, :, :FIN].transpose(1, 2))
         assert out["w_fold"].shape == (3 * C, FIN + C) and out["b_fold"].shape == (3 * C,)
         assert float(bound[0]) == float(p["Wcat"].abs().max()) and float(bound[1]) == float(p["b3"].abs().max())
         if x3form == "folded32":               # x3 is not formed (nor asked for), the clamp is bounded instead of looked at
@@ -130,7 +131,14 @@ def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True
     new = lambda *s: torch.full(s, float("nan"), device=cuda)  # noqa: E731
     out = dict(dzl=new(n, C), drl=new(n, C), dhl=new(n, C), da3=new(n, 3 * C), dH=new(n, C), dyt=new(n, FH), dyo=new(n),
                z=new(n, FIN) if want_z else None)
-    if x3form in ("folded", "folded32"):         # the folded forwards leave the fp32 form's saved tensors: the fp32 backward follows them
+    if x3form == "folded32":                     # the folded backward launch: z from d_g and the folded weights, no da3, no mask read
+        Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
+        bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
+        out["w_fold_t"] = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"], with_bound=True)[3]
+        out["da3"], use_mask = None, True
+        if not want_z:
+            out["z"] = new(n, FIN)
+    elif x3form == "folded":                     # the matrix-core folded forward leaves the fp32 form's saved tensors: the fp32 backward follows
         use_mask = True
     elif x3form:                                 # the matrix-core form reads the mask its forward twin wrote
         out["w_image"], use_mask = _images(p)[1], True
@@ -144,6 +152,10 @@ def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True
                           WzT=p["Wz"].t().contiguous(), WrT=p["Wr"].t().contiguous(), WhT=p["Wh"].t().contiguous(),
                           Wcat=p["Wcat"], W1T=p["W1"].t().contiguous(), W2=p["W2"].view(-1).contiguous(), **out)
     out.pop("w_image", None)
+    if out.pop("w_fold_t", None) is not None:    # the launch formed no da3: what the checks downstream read is d_g Wg[:, :C]
+        out["da3"] = torch.cat([out["dzl"] @ p["Wz"][:, :C], out["drl"] @ p["Wr"][:, :C], out["dhl"] @ p["Wh"][:, :C]], 1)
+        if not want_z:
+            out["z"] = None
     return out
 
 
