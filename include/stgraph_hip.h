@@ -55,7 +55,8 @@ const char *stg_last_error_string(void);
  * "xw_waves" (0 = auto; 4 / 8 waves per workgroup of stg_gcn_agg_transform), "cell_rows" (0 = auto; 16 / 32 rows
  * per tile of stg_tgcn_cell_fused_fwd), "step_waves" (stg_tgcn_step_*: 0 = auto, 12 / 16 waves per workgroup), "step_impl" (stg_tgcn_step_* given a
  * weight image: 0 = the matrix-core form, 1 = always the fp32 form; the one knob that selects between two ARITHMETICS -- both
- * within 1e-5 of fp64), "rowgemm_x3" (stg_rowgemm_f32 / _strided_f32 / _act_f32 at K, M in {64, 128} and N K < 2^30: 0 = from 64 K rows
+ * within 1e-5 of fp64), "step_fold" (stg_tgcn_step_fwd given w_fold: 0 = the folded form on the fp32 instruction when fold_bound is
+ * given and x3 is not asked for, 1 = always the matrix-core folded form), "rowgemm_x3" (stg_rowgemm_f32 / _strided_f32 / _act_f32 at K, M in {64, 128} and N K < 2^30: 0 = from 64 K rows
  * every product as a 3-term bf16 split on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, 1 = always v_mfma_f32_16x16x4_f32, 2 = the
  * split form at every N, 3 = its lane-owns-row-pieces load / store variant (diagnosis); the second such knob: both forms inside the
  * fp32 kernel's error bound against fp64, integer data exact in both), "step_spread"
