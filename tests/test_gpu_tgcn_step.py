@@ -295,6 +295,14 @@ def test_folded_form_reports_a_clamp_that_bites(cuda):
     with pytest.raises(RuntimeError, match="folded step form"):
         kernels.check_step_fold_status(cuda)
     kernels.check_step_fold_status(cuda)             # cleared by the failed check
+    # the fp32-instruction folded form does not form x3: it refuses on its BOUND |P_r|_1 max |Wcat| + max |b3| (conservative: here
+    # it exceeds the range for every row) ...
+    _fwd(cuda, g, norm, None, p, x0, H, t0, n, lo=lo, hi=hi, x3form="folded32")
+    with pytest.raises(RuntimeError, match="folded step form"):
+        kernels.check_step_fold_status(cuda)
+    # ... and stays silent where the bound holds (the layer's own +-1e6), as does the fp32 form given the status word alone
+    _fwd(cuda, g, norm, None, p, x0, H, t0, n, x3form="folded32")
+    kernels.check_step_fold_status(cuda)
 
 
 @pytest.mark.parametrize("x3form", [False, True])
