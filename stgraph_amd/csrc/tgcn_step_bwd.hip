@@ -440,7 +440,8 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
 #define STG_STEP_BWD(G_, EW_, HD_)                                                         \
     return w16 ? launch_step_bwd<64, 32, 32, 16, G_, EW_, HD_>(a, st) : launch_step_bwd<64, 32, 32, 12, G_, EW_, HD_>(a, st)
     if (fold) {
-#define STG_STEP_BWD_F(G_, EW_, HD_) return launch_step_bwd<64, 32, 32, 12, G_, EW_, HD_, true>(a, st)
+#define STG_STEP_BWD_F(G_, EW_, HD_)                                                                                 \
+    return w16 ? launch_step_bwd<64, 32, 32, 16, G_, EW_, HD_, true>(a, st) : launch_step_bwd<64, 32, 32, 12, G_, EW_, HD_, true>(a, st)
         if (gather) {
             if (p->ew_edge) { if (p->head == 1) STG_STEP_BWD_F(true, true, 1); else STG_STEP_BWD_F(true, true, 2); }
             if (p->head == 1) STG_STEP_BWD_F(true, false, 1); else STG_STEP_BWD_F(true, false, 2);

@@ -462,7 +462,8 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
         default: STG_STEP_FWD(G_, EW_, 2);                                                 \
     }
     if (fold32) {
-#define STG_STEP_FWD_F(EW_, HD_) return launch_step_fwd<64, 32, 32, 12, true, EW_, HD_, true>(a, st)
+#define STG_STEP_FWD_F(EW_, HD_)                                                                                     \
+    return w16 ? launch_step_fwd<64, 32, 32, 16, true, EW_, HD_, true>(a, st) : launch_step_fwd<64, 32, 32, 12, true, EW_, HD_, true>(a, st)
         if (p->ew_edge) { if (p->head == 1) STG_STEP_FWD_F(true, 1); else STG_STEP_FWD_F(true, 2); }
         if (p->head == 1) STG_STEP_FWD_F(false, 1); else STG_STEP_FWD_F(false, 2);
 #undef STG_STEP_FWD_F

@@ -103,20 +103,20 @@ __global__ __launch_bounds__(kBlock) void tgcn_fold_kernel(const FoldArgs a)
         for (int k = 0; k < C; ++k) v = v + Wg[k] * bc[k];
         a.b_fold[row] = v;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < kWave) {             // the last block's first wave: the two maxima
+    // the two maxima: every thread brings one element (|.| >= 0: the float's bits order like unsigned integers), a wave its maximum
+    // with one atomic (bound was zeroed by the launcher)
+    {
         float mw = 0.f, mb = 0.f;
-        for (int g = 0; g < 3; ++g) {
-            for (int i = threadIdx.x; i < Fin * C; i += kWave) mw = fmaxf(mw, fabsf(a.Wc[g][i]));
-            for (int i = threadIdx.x; i < C; i += kWave) mb = fmaxf(mb, fabsf(a.bc[g][i]));
-        }
+        if (gid < 3 * Fin * C) mw = fabsf(a.Wc[gid / (Fin * C)][gid % (Fin * C)]);
+        if (gid < 3 * C) mb = fabsf(a.bc[gid / C][gid % C]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             mw = fmaxf(mw, __shfl_xor(mw, o, kWave));
             mb = fmaxf(mb, __shfl_xor(mb, o, kWave));
         }
-        if (threadIdx.x == 0) {
-            a.bound[0] = mw;
-            a.bound[1] = mb;
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            if (mw > 0.f) atomicMax(reinterpret_cast<unsigned *>(a.bound), __float_as_uint(mw));
+            if (mb > 0.f) atomicMax(reinterpret_cast<unsigned *>(a.bound) + 1, __float_as_uint(mb));
         }
     }
 }
@@ -141,6 +141,8 @@ extern "C" int stg_tgcn_fold_weights(const float *const *Wc, const float *const 
     }
     a.w_fold = w_fold; a.b_fold = b_fold; a.bound = bound; a.w_fold_t = w_fold_t; a.C = C; a.Fin = Fin;
     const int total = 3 * C * (Fin + C) + 3 * C;
+    const hipError_t e = hipMemsetAsync(bound, 0, 2 * sizeof(float), static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail((int)e, "stg_tgcn_fold_weights: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(tgcn_fold_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), a);
     return check_launch("stg_tgcn_fold_weights");

@@ -8,7 +8,10 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 args = dict(zip(sys.argv[1::2], sys.argv[2::2]))
 kernels.set_step_wgrad_from_p(bool(int(args.get("--from-p", 1))))
-kernels.set_step_folded(bool(int(args.get("--folded", 0))))
+kernels.set_step_folded(bool(int(args.get("--folded", 1))))
+if "--waves" in args:
+    from stgraph_amd import _C
+    _C.set_tuning("step_waves", int(args["--waves"]))
 t = bench.tgcn_run(dev, 0, 1, epochs=8, warmup_epochs=3, n=50_000, e=500_000, T=1000, feat=32, hidden=64, B=25, cpu_baseline=False)
 d = bench.dynamic_run(dev, 0, 1, epochs=8, cpu_baseline=False)
 kernels.check_step_fold_status(dev)

@@ -102,6 +102,19 @@ def main():
     res["stepf_fwd_us"] = timed(fwd)
     res["stepf_status"] = int(kernels.step_fold_status_word(dev).item())
     res["stepf_max_err_vs_fp32_form"] = {k: float((out[k] - ref[k]).abs().max()) for k in ("x3", "Z", "R", "Ht", "Hn", "HR", "y", "y_out")}
+    # the folded form on the fp32 instruction (the default of the window nodes): forward from P on the folded weights, no x3;
+    # backward with z from d_g and the folded weights' transposed P part, no da3
+    w_fold2, b_fold2, bound, w_fold_t = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"],
+                                                                 with_bound=True)
+    res["fold_weights_with_bound_us"] = timed(lambda: kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"],
+                                                                                p["bh"], with_bound=True))
+    keep2 = out["x3"], bo["da3"]
+    out["fold_bound"], out["x3"], bo["w_fold_t"], bo["da3"] = bound, None, w_fold_t, None
+    fwd()
+    res["step_fwd_folded_fp32_us"], res["step_bwd_folded_fp32_us"] = timed(fwd), timed(bwd)
+    res["step_folded_fp32_max_err_vs_fp32_form"] = {k: float((out[k] - ref[k]).abs().max()) for k in ("Z", "R", "Ht", "Hn", "HR", "y", "y_out")}
+    del out["fold_bound"], bo["w_fold_t"]
+    out["x3"], bo["da3"] = keep2
     # ... and the same launch given P (no gather inside), next to the aggregation launch that would produce it
     def fwd_noagg():
         kernels.tgcn_step_fwd(n, C, FIN, FH, 2, -1e6, 1e6, dev, norm=norm.view(-1), H=H, target=tgt, WcatT=WcatT,
