@@ -38,13 +38,23 @@ def main():
     ncf, ewf = kernels._edge_gathered(f, "norm", norm, f.column_indices), kernels._edge_gathered(f, "ew", ew, f.eids)
     ncb, ewb = kernels._edge_gathered(b, "norm", norm, b.column_indices), kernels._edge_gathered(b, "ew", ew, b.eids)
     WcatT = p["Wcat"].t().contiguous()
+    folded = "--folded" in sys.argv            # the folded form (the window nodes' default): forward from P, backward without da3
+    bo_extra = {}
+    if folded:
+        Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
+        bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
+        w_fold, b_fold, bound, w_fold_t = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"],
+                                                                    with_bound=True)
+        out.update(w_fold=w_fold, b_fold=b_fold, fold_bound=bound, x3=None)
+        bo_extra = dict(w_fold_t=w_fold_t)
 
     def fwd():
         kernels.tgcn_step_fwd(n, C, FIN, FH, 2, -1e6, 1e6, dev, row_offsets=f.row_offset, column_indices=f.column_indices,
                               node_ids=None, norm_col_edge=ncf, ew_edge=ewf, norm=norm.view(-1), x=x, H=H, target=tgt, WcatT=WcatT,
                               b3=p["b3"], Wz=p["Wz"], bz=p["bz"], Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"],
                               W1=p["W1"], b1=p["b1"], W2=p["W2"], b2=p["b2"], **out)
-    bo = dict(dzl=new(n, C), drl=new(n, C), dhl=new(n, C), da3=new(n, 3 * C), dH=new(n, C), dyt=new(n, FH), dyo=new(n), z=new(n, FIN))
+    bo = dict(dzl=new(n, C), drl=new(n, C), dhl=new(n, C), da3=None if folded else new(n, 3 * C), dH=new(n, C), dyt=new(n, FH), dyo=new(n),
+              z=new(n, FIN), **bo_extra)
     zn, dHn, gc = r(n, FIN), r(n, C), torch.ones(1, device=dev)
     T = {k: p[k].t().contiguous() for k in ("Wz", "Wr", "Wh", "W1")}
 
