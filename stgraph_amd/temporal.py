@@ -106,6 +106,26 @@ def _check_step_fold(device) -> None:
         kernels.check_step_fold_status(device)
 
 
+def _fold_refused(fold_status) -> bool:
+    """After the forward step launches of a window node, OUTSIDE a stream capture: did one of them refuse the folded formulation
+    (a conv output that may leave the clamp range)?  Then the formulation is switched off for the process, with a warning, and the
+    caller recomputes the window in the reference formulation -- a drop-in must not fail on data the reference handles.  Inside a
+    capture nothing can be read back: the epoch functions check the word once per epoch (``_check_step_fold``) and raise."""
+    if fold_status is None or torch.cuda.is_current_stream_capturing():
+        return False
+    if int(fold_status.item()) == 0:
+        return False
+    from . import kernels
+    import warnings
+    fold_status.zero_()
+    kernels.set_step_folded(False)
+    kernels.set_step_wgrad_from_p(False)
+    warnings.warn("stgraph_amd: a TGCN conv output may leave [-1e6, 1e6] on this data (reference nn/pytorch/temporal/tgcn.py:23 clamps there): "
+                  "the folded step formulation is switched off for this process (kernels.set_step_folded / set_step_wgrad_from_p) and "
+                  "the window recomputed in the reference formulation", RuntimeWarning, stacklevel=3)
+    return True
+
+
 def _unfold_gate_grads(MgT, cs, dWbot, Wc, bc, Wg):
     """Gate + conv parameter gradients of one gate from the contractions over the window's rows that do not need x3 or da3:
     ``MgT = d_g^T P`` [C, Fin], ``cs`` = column sums of d_g [C], ``dWbot = d_g^T Hx`` [C, C] (d_g: gradient of the gate's
@@ -173,6 +193,9 @@ class _TGCNWindow(torch.autograd.Function):
                                   W2=W2v, b2=b2_, P=P[t], x3=None if from_p else X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t],
                                   HR=HR[t], y=Y[t], y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t], w_image=img_f,
                                   w_fold=w_fold, b_fold=b_fold, fold_bound=f_bound if from_p else None, fold_status=fold_status)
+        if _fold_refused(fold_status):
+            return _TGCNWindow.forward(ctx, x0, targets, norm, ew, fwd, bwd, use_nid, lo, hi,
+                                       Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2, b2)
         step_loss = new(B)
         cost = kernels.tgcn_window_loss(partial, B, N, step_loss)
         ctx.save_for_backward(x0, targets, norm, normv, ew if ew is not None else norm.new_empty(0), Wcat, Wz_, Wr_, Wh_, W1_, W2v,
@@ -550,6 +573,8 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   P=P[t], x3=None if from_p else X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t],
                                   clamp_mask=mask[t], w_image=img_f, w_fold=w_fold, b_fold=b_fold,
                                   fold_bound=f_bound if from_p else None, fold_status=fold_status)
+        if _fold_refused(fold_status):
+            return _TGCNDynWindow.forward(ctx, x0, steps, use_nid, lo, hi, Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)
         # the decoder + loss of every snapshot behind the last step, in one launch: a snapshot's loss feeds nothing in the next one
         kernels.link_decode_fwd_window([Y[t] for t in range(B)], [st["edges"] for st in steps], [st["targets"] for st in steps],
                                        [logits[t] for t in range(B)], [partial[t] for t in range(B)])

@@ -292,3 +292,39 @@ def test_captured_dynamic_windows_match_the_eager_loop(cuda, kind, optim):
     torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-7)
     for a, b in zip(out[0][1], out[1][1]):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_window_on_data_the_fold_refuses_falls_back_to_the_reference_formulation(cuda):
+    """Inputs of size 3e5: the folded step's BOUND on the conv output leaves the clamp range (the conv output itself need not).  The
+    eager window node notices (one read-back per window outside a capture), switches the folded formulation off for the process with
+    a warning and recomputes the window in the reference formulation: bit for bit what the node gives with the folded formulation off
+    from the start, no exception."""
+    import warnings
+    from stgraph_amd import kernels, temporal
+    n, e, B = 2000, 16000, 3
+    g, ew, targets, gen = _setup(cuda, n, e, B, 5)
+    x0 = (torch.randn(n, 32, device=cuda, generator=gen) * 3e5).requires_grad_(True)
+    torch.manual_seed(3)
+    model = temporal.STGraphTGCN(32, 64, 1).to(cuda)
+    was = kernels.STEP_FOLDED, kernels.STEP_WGRAD_FROM_P
+    kernels.set_step_folded(True), kernels.set_step_wgrad_from_p(True)
+    kernels.step_fold_status_word(cuda).zero_()
+    try:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            cost = temporal.window_cost_of(model, g, x0, ew, targets) / (B + 1)
+        assert any("folded step formulation is switched off" in str(w.message) for w in rec)
+        assert not kernels.STEP_FOLDED and not kernels.STEP_WGRAD_FROM_P
+        assert int(kernels.step_fold_status_word(cuda).item()) == 0
+        cost.backward()
+        got = (cost.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+        model.zero_grad()
+        x0.grad = None
+        ref = temporal.window_cost_of(model, g, x0, ew, targets) / (B + 1)     # the reference formulation from the start: the same launches
+        ref.backward()
+        assert torch.equal(got[0], ref.detach())
+        for k, p in model.named_parameters():
+            assert torch.equal(got[1][k], p.grad), k
+    finally:
+        kernels.set_step_folded(was[0]), kernels.set_step_wgrad_from_p(was[1])
+        kernels.step_fold_status_word(cuda).zero_()
