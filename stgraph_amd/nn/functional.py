@@ -535,9 +535,32 @@ class _GatFcLayer(torch.autograd.Function):
         fwd_csr, bwd_csr = ctx.csrs
         gf, gel, ger = kernels.gat_bwd(A, S, out, g.contiguous(), el, er, feat, fwd_csr, bwd_csr, ctx.slope, ctx.use_nid,
                                        elu=ctx.elu)
-        dfeat, dal, dar = kernels.gat_proj_bwd(feat, attn_l, attn_r, gel, ger, gf, inplace=True)
-        g2 = dfeat.view(dfeat.shape[0], -1)
-        gx = kernels.matmul(g2, w) if ctx.needs_input_grad[0] else None
+        small = None
+        if _GAT_PROJ_FOLD:
+            # feat = x W^T, so everything the attention projections add to the backward pass -- dfeat = gf + gel (x) attn_l + ger (x)
+            # attn_r, its products with W and x, and the attn gradients sum_u gel[u, h] feat[u, h, :] -- follows at width H from
+            # G = [gel | ger]^T x  [2H, fin] and A = [W_h^T attn_l[h] ; W_h^T attn_r[h]]  [2H, fin]:
+            #   gx = gf W + [gel | ger] A,   gw = gf^T x + attn (x) G,   d attn_l[h] = W_h G_l[h]
+            # -- dfeat [N, H, D] is never formed (stg_gat_proj_bwd: a read of feat and gf and a write of dfeat, 1.6 GB at cfg3).
+            N, fin = x.shape
+            H, D = feat.shape[1], feat.shape[2]
+            ge = torch.cat([gel.view(N, H), ger.view(N, H)], 1)
+            native16 = _use_native(x, N, 2 * H, fin)
+            G = kernels.gemm_tn(ge, x) if native16 else torch.mm(ge.t(), x)
+            Wh = w.view(H, D, fin)
+            al, ar = attn_l.reshape(H, D), attn_r.reshape(H, D)
+            dal, dar = torch.einsum("hdf,hf->hd", Wh, G[:H]), torch.einsum("hdf,hf->hd", Wh, G[H:])
+            g2 = gf.view(N, H * D)
+            gx = None
+            if ctx.needs_input_grad[0]:
+                Aw = torch.cat([torch.einsum("hdf,hd->hf", Wh, al), torch.einsum("hdf,hd->hf", Wh, ar)], 0)
+                gx = torch.addmm(kernels.matmul(g2, w), ge, Aw)
+            if ctx.needs_input_grad[1]:
+                small = (al.unsqueeze(2) * G[:H].unsqueeze(1) + ar.unsqueeze(2) * G[H:].unsqueeze(1)).reshape(H * D, fin)
+        else:
+            dfeat, dal, dar = kernels.gat_proj_bwd(feat, attn_l, attn_r, gel, ger, gf, inplace=True)
+            g2 = dfeat.view(dfeat.shape[0], -1)
+            gx = kernels.matmul(g2, w) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
             W = ctx.w
@@ -545,8 +568,12 @@ class _GatFcLayer(torch.autograd.Function):
             if native and deferred_weight_grads() and W.is_leaf:
                 deferred.current().add(("linear", id(W)), g2, x, sink=lambda d, W=W: deferred.add_to_grad(W, d),
                                        colsum_sink=None)
+                if small is not None:
+                    deferred.add_to_grad(W, small)
             else:
                 gw = kernels.gemm_tn(g2, x) if native else torch.mm(g2.t(), x)
+                if small is not None:
+                    gw = gw + small
         return gx, gw, dal.view_as(attn_l), dar.view_as(attn_r), None, None, None, None, None, None, None
 
 
@@ -575,6 +602,15 @@ def is_elu(activation) -> bool:
 
 
 _GAT_FC = True
+_GAT_PROJ_FOLD = True
+
+
+def set_gat_proj_fold(on: bool) -> None:
+    """False: the fused GATConv's backward forms dfeat and its attention-projection terms at full width (stg_gat_proj_bwd), as the
+    un-fused layer does; True (default): at width H from [gel | ger]^T x (see _GatFcLayer.backward)."""
+    global _GAT_PROJ_FOLD
+    _GAT_PROJ_FOLD = bool(on)
+
 
 
 def set_gat_fc(on: bool) -> None:

@@ -226,3 +226,38 @@ def test_factored_backward_with_fused_elu_equals_elu_backward_then_the_unit(cuda
         want = kernels.gat_bwd(A, S, out, gpre, el, er, feat, g.csr("fwd"), g.csr("bwd"), 0.2, False)
         for a, b, name in zip(got, want, ("grad_feat", "grad_el", "grad_er")):
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max() + 1), msg=lambda m, n=name: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("fin,H,act", [(64, 8, "elu"), (32, 4, "none")])
+def test_projection_backward_at_width_H_equals_the_full_width_one(cuda, fin, H, act):
+    """_GatFcLayer.backward with the attention projections' terms formed from [gel | ger]^T x (no dfeat, no stg_gat_proj_bwd)
+    against the same layer with stg_gat_proj_bwd: every gradient."""
+    import torch.nn.functional as F
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    D, n, e = 64, 70_003, 700_000                       # >= 64 K rows: the native weight-gradient path
+    src, dst = random_graph(17 + H, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    torch.manual_seed(6)
+    conv = GATConv(fin, D, H, activation=F.elu if act == "elu" else None).to(cuda)
+    x0 = torch.randn(n, fin, device=cuda)
+    R = torch.randn(n, H, D, device=cuda)
+    res = []
+    for fold in (True, False):
+        SF.set_gat_proj_fold(fold)
+        try:
+            rec = []
+            kernels.enable_launch_timing(rec)
+            conv.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            conv(g, x).backward(R)
+        finally:
+            kernels.enable_launch_timing(None)
+            SF.set_gat_proj_fold(True)
+        assert ("gat_proj_bwd" in {r[0] for r in rec}) == (not fold)
+        res.append((x.grad.clone(), conv.attn_l.grad.clone(), conv.attn_r.grad.clone(), conv.fc.weight.grad.clone()))
+    for a, b, name in zip(res[0], res[1], ("x", "attn_l", "attn_r", "fc.weight")):
+        atol = 5e-5 if name == "attn_r" else 1e-5 * float(b.abs().max() + 1)      # attn_r: rounding noise around 0 (see above)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=atol, msg=lambda m, nm=name: f"{nm}: {m}")
