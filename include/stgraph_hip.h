@@ -31,8 +31,9 @@ extern "C" {
  *  22: stg_tgcn_step_*_args gain `w_image` (last field); stg_tgcn_pack_weights_x3, stg_tgcn_step_image_bytes; knob "step_impl".
  *  23: stg_gat_fwd_k1_uniform, stg_gat_fc_out, stg_gat_fwd_k1_scored, stg_gat_bwd_factored_elu; knob "rowgemm_x3".
  *  24: stg_tgcn_step_fwd_args gains w_fold, b_fold, fold_status (last fields): the folded form of the forward step launch; x3 / da3 of
- *      the step launches optional; stg_tgcn_unfold_gate_grads. */
-#define STG_ABI_VERSION 24
+ *      the step launches optional; stg_tgcn_unfold_gate_grads.
+ *  25: stg_rowgemm_act_bits_f32, stg_rowgemm_bits_words, stg_rowgemm_bits_supported: a ReLU layer's sign pattern as bits. */
+#define STG_ABI_VERSION 25
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -561,6 +562,21 @@ int stg_rowgemm_strided_f32(const float *X, const float *W, const float *bias, f
 int stg_rowgemm_act_supported(int32_t K, int32_t M);
 int stg_rowgemm_act_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K, int32_t M,
                         int trans_w, int act, void *stream);
+
+/* The same product with the ReLU's sign pattern as ONE BIT per output element, so that the backward pass never re-reads the layer's
+ * output for it (gcn_conv.py:186-188 `h = self.activation(h)`; autograd's threshold_backward reads [N, M] floats, 0.5 GB at cfg2):
+ *   forward  (trans_w = 0, act = STG_ACT_RELU, bits_out given): Y = relu(X W + bias) and bits_out = [Y > 0];
+ *   backward (trans_w = 1, act = STG_ACT_NONE, bits_in given): Y = (X W^T) * pattern -- the gradient with respect to the ReLU
+ *   layer's pre-activation, formed in the launch of the layer ABOVE that computes its input gradient g W^T (M = the ReLU
+ *   layer's width in both calls, same N).
+ * bits: stg_rowgemm_bits_words(N) uint32 words (16 bytes per row, rounded up to 32 rows).  Element (row, col) is bit
+ * 8 (col >> 5) + 4 ((row >> 3) & 1) + (col & 3) of word 64 (row >> 4) + (row & 7) + 8 ((col >> 4) & 1) + 16 ((col >> 2) & 3) -- the
+ * arrangement in which a lane of the kernel holds its 32 outputs of a 16-row tile.  Always the 3-term bf16 split on the matrix
+ * cores; stg_rowgemm_bits_supported: K, M in {64, 128}, N K and N M < 2^30, knob "rowgemm_x3" neither 1 nor 3. */
+size_t stg_rowgemm_bits_words(int64_t N);
+int stg_rowgemm_bits_supported(int64_t N, int32_t K, int32_t M);
+int stg_rowgemm_act_bits_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K, int32_t M,
+                             int trans_w, int act, const uint32_t *bits_in, uint32_t *bits_out, void *stream);
 
 /* C = sum_{t < T} A_t^T B_t (and colsum_A = sum_t colsum(A_t), nullable) in ONE launch: A, B are HOST
  * arrays of T <= 32 device pointers, every A_t [K,M], B_t [K,N].  The pointers travel by value in

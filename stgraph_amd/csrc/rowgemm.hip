@@ -324,6 +324,37 @@ extern "C" int stg_rowgemm_act_f32(const float *X, const float *W, const float *
     return rowgemm16_launch<64, 64>(X, W, bias, Y, N, tw, relu, st, M);
 }
 
+// ---- the ReLU sign pattern as bits (rowgemm_x3.hip) --------------------------------------------------------------------------
+extern "C" size_t stg_rowgemm_bits_words(int64_t N) { return N > 0 ? (size_t)((N + 31) / 32) * 128 : 0; }
+
+extern "C" int stg_rowgemm_bits_supported(int64_t N, int32_t K, int32_t M)
+{
+    using namespace stg;
+    const int mode = tuning().rowgemm_x3;
+    return rowgemm16_shape(K, M) && N > 0 && N * K < ((int64_t)1 << 30) && N * M < ((int64_t)1 << 30) && mode != 1 && mode != 3 ? 1 : 0;
+}
+
+extern "C" int stg_rowgemm_act_bits_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K, int32_t M,
+                                        int trans_w, int act, const uint32_t *bits_in, uint32_t *bits_out, void *stream)
+{
+    using namespace stg;
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_bits_f32: negative N");
+    if (N == 0) return 0;
+    if (!stg_rowgemm_bits_supported(N, K, M))
+        return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_act_bits_f32: K, M must be 64 or 128 and N K, N M < 2^30 (got N=%lld K=%d M=%d), "
+                    "knob rowgemm_x3 neither 1 nor 3", (long long)N, K, M);
+    if ((bits_in != nullptr) == (bits_out != nullptr))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_bits_f32: exactly one of bits_in / bits_out");
+    if (bits_out && !(trans_w == 0 && act == STG_ACT_RELU))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_bits_f32: bits_out goes with trans_w = 0 and act = STG_ACT_RELU");
+    if (bits_in && !(trans_w != 0 && act == STG_ACT_NONE))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_bits_f32: bits_in goes with trans_w = 1 and act = STG_ACT_NONE");
+    if (!X || !W || !Y) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_bits_f32: NULL pointer argument");
+    if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Y)) % 16 != 0)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_act_bits_f32: X, W and Y must be 16-byte aligned");
+    return rowgemm_x3_bits_launch(K, M, X, W, bias, Y, N, bits_in, bits_out, stream);
+}
+
 extern "C" int stg_rowgemm_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K,
                                int32_t M, int trans_w, void *stream)
 {

@@ -61,11 +61,17 @@ __device__ __forceinline__ void mfma6x4(f32x4 &a0, f32x4 &a1, f32x4 &b0, f32x4 &
 #undef STG_X3_ROUND
 }
 
-template <int K, int M, bool TRANS_W, bool RELU, bool LINES>
+// BITS (whole-line form only): the sign pattern of a ReLU layer's output as one bit per element, in the lanes' own arrangement
+// of the output -- element (row, col) is bit 8 (col >> 5) + 4 ((row >> 3) & 1) + (col & 3) of word
+// 64 (row >> 4) + (row & 7) + 8 ((col >> 4) & 1) + 16 ((col >> 2) & 3): a lane's 32 outputs of a 16-row tile are ONE word, written
+// and read back with no exchange between lanes.  1: leave [y > 0] in `bits` (with RELU); 2: multiply the product by the pattern in
+// `bits` before it is stored -- the ReLU backward of the layer below, dX = (g W^T) * [out > 0], in the launch that forms g W^T.
+template <int K, int M, bool TRANS_W, bool RELU, bool LINES, int BITS = 0>
 __global__ __launch_bounds__(kX3Waves * kWave, 1) void rowgemm_x3_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                                         const float *__restrict__ bias, float *__restrict__ Y,
-                                                                        int64_t N, int num_pairs, int ldy)
+                                                                        int64_t N, int num_pairs, int ldy, uint32_t *__restrict__ bits)
 {
+    static_assert(BITS == 0 || LINES, "the bit pattern follows the whole-line arrangement");
     constexpr int KB = K / 32, CT = M / 16, AHEAD = 2;
     static_assert(KB >= AHEAD && KB % AHEAD == 0, "the prefetch ring is two K-blocks deep");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -165,8 +171,16 @@ __global__ __launch_bounds__(kX3Waves * kWave, 1) void rowgemm_x3_kernel(const f
     for (int i = threadIdx.x; i < M; i += kX3Waves * kWave) bs[i] = bias ? bias[i] : 0.f;
     __syncthreads();
 
+    const auto rsBits = __builtin_amdgcn_make_buffer_rsrc(BITS ? bits : reinterpret_cast<uint32_t *>(Y), 0,
+                                                          BITS ? (int)((int64_t)num_pairs * 2 * kWave * sizeof(uint32_t)) : 0, 0x00020000);
     for (; pair < num_pairs; pair += total) {
         const int next = std::min(pair + total, num_pairs - 1);
+        unsigned pattern[2] = {0u, 0u};
+        if constexpr (BITS == 2) {                                     // (ahead of the ring's loads: long since here at the stores)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                pattern[t] = __builtin_amdgcn_raw_buffer_load_b32(rsBits, ((pair * 2 + t) * kWave + lane) * (int)sizeof(uint32_t), 0, 0);
+        }
         f32x4 acc[2][CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -229,10 +243,20 @@ __global__ __launch_bounds__(kX3Waves * kWave, 1) void rowgemm_x3_kernel(const f
                     one(a.y, bq.y, s1.y, s2.y);
                     one(a.z, bq.z, s1.z, s2.z);
                     one(a.w, bq.w, s1.w, s2.w);
+                    if constexpr (BITS == 1) {
+                        pattern[t] |= ((s1.x > 0.f ? 1u : 0u) | (s1.y > 0.f ? 2u : 0u) | (s1.z > 0.f ? 4u : 0u) | (s1.w > 0.f ? 8u : 0u) |
+                                       (s2.x > 0.f ? 16u : 0u) | (s2.y > 0.f ? 32u : 0u) | (s2.z > 0.f ? 64u : 0u) | (s2.w > 0.f ? 128u : 0u))
+                                      << (8 * c);
+                    } else if constexpr (BITS == 2) {
+                        const unsigned pb = pattern[t] >> (8 * c);
+                        s1 = make_float4(pb & 1u ? s1.x : 0.f, pb & 2u ? s1.y : 0.f, pb & 4u ? s1.z : 0.f, pb & 8u ? s1.w : 0.f);
+                        s2 = make_float4(pb & 16u ? s2.x : 0.f, pb & 32u ? s2.y : 0.f, pb & 64u ? s2.z : 0.f, pb & 128u ? s2.w : 0.f);
+                    }
                     if ((STG_X3_ABLATE & 1) && s1.x != 1.2345e33f) continue;
                     *reinterpret_cast<float4 *>(d1 + 32 * c) = s1;
                     *reinterpret_cast<float4 *>(d2 + 32 * c) = s2;
                 }
+                if constexpr (BITS == 1) bits[((int64_t)pair * 2 + t) * kWave + lane] = pattern[t];
             } else {
                 float *dst = Y + row_of(pair, t) * ldy + 4 * kq;
 #pragma unroll
@@ -246,8 +270,8 @@ __global__ __launch_bounds__(kX3Waves * kWave, 1) void rowgemm_x3_kernel(const f
     }
 }
 
-template <int K, int M, bool TW, bool RELU, bool LINES>
-int rowgemm_x3_launch3(const float *X, const float *W, const float *bias, float *Y, int64_t N, hipStream_t st, int ldy)
+template <int K, int M, bool TW, bool RELU, bool LINES, int BITS = 0>
+int rowgemm_x3_launch3(const float *X, const float *W, const float *bias, float *Y, int64_t N, hipStream_t st, int ldy, uint32_t *bits = nullptr)
 {
     constexpr size_t lds = (size_t)(M / 16) * (K / 32) * kXTerms * kFragBytes + sizeof(float) * M;
     const int64_t pairs = (N + 31) / 32;
@@ -255,7 +279,7 @@ int rowgemm_x3_launch3(const float *X, const float *W, const float *bias, float 
     static PerDeviceOnce once;
     bool *raised = once.slot();
     if (lds > 64 * 1024 && !*raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_x3_kernel<K, M, TW, RELU, LINES>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_x3_kernel<K, M, TW, RELU, LINES, BITS>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail((int)e, "stg_rowgemm_f32: %s", hipGetErrorString(e));
         *raised = true;
@@ -264,8 +288,8 @@ int rowgemm_x3_launch3(const float *X, const float *W, const float *bias, float 
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const unsigned blocks = (unsigned)std::min<int64_t>((pairs + kX3Waves - 1) / kX3Waves, cus);
-    hipLaunchKernelGGL((rowgemm_x3_kernel<K, M, TW, RELU, LINES>), dim3(blocks), dim3(kX3Waves * kWave), lds, st, X, W, bias, Y, N, (int)pairs,
-                       ldy);
+    hipLaunchKernelGGL((rowgemm_x3_kernel<K, M, TW, RELU, LINES, BITS>), dim3(blocks), dim3(kX3Waves * kWave), lds, st, X, W, bias, Y, N,
+                       (int)pairs, ldy, bits);
     return check_launch("stg_rowgemm_f32");
 }
 
@@ -280,6 +304,24 @@ int rowgemm_x3_launch2(const float *X, const float *W, const float *bias, float 
 }  // namespace
 
 // (declared in stg_common.hpp; rowgemm.hip dispatches here)
+int rowgemm_x3_bits_launch(int K, int M, const float *X, const float *W, const float *bias, float *Y, int64_t N, const uint32_t *bits_in,
+                           uint32_t *bits_out, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the two uses: the ReLU layer forward (W [K][M], pattern out) and the input gradient of the layer above it (W [M][K] read in
+    // place, pattern in)
+#define STG_X3(K_, M_)                                                                                                          \
+    if (K == K_ && M == M_)                                                                                                     \
+        return bits_out ? rowgemm_x3_launch3<K_, M_, false, true, true, 1>(X, W, bias, Y, N, st, M, bits_out)                    \
+                        : rowgemm_x3_launch3<K_, M_, true, false, true, 2>(X, W, bias, Y, N, st, M, const_cast<uint32_t *>(bits_in));
+    STG_X3(128, 128)
+    STG_X3(64, 128)
+    STG_X3(128, 64)
+    STG_X3(64, 64)
+#undef STG_X3
+    return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_act_bits_f32: the split form covers K, M in {64, 128} (got %d, %d)", K, M);
+}
+
 int rowgemm_x3_launch(int K, int M, const float *X, const float *W, const float *bias, float *Y, int64_t N, bool tw, bool relu,
                       void *stream, int ldy)
 {

@@ -1267,6 +1267,62 @@ def rowgemm_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, tra
     return y
 
 
+def rowgemm_bits_usable(x: torch.Tensor, K: int, M: int) -> bool:
+    """The ReLU sign pattern as bits (stg_rowgemm_act_bits_f32): where the split-form row product serves (:func:`rowgemm16_usable`,
+    K, M in {64, 128})."""
+    return (_RELU_BITS and rowgemm16_usable(x, K, M) and bool(_C.lib.stg_rowgemm_bits_supported(int(x.shape[0]), int(K), int(M))))
+
+
+_RELU_BITS = os.environ.get("STGRAPH_AMD_RELU_BITS", "1") != "0"
+
+
+def set_relu_bits(on: bool) -> None:
+    """False: the ReLU backward of the GCN input layer re-reads the layer's output (the form before the bit pattern)."""
+    global _RELU_BITS
+    _RELU_BITS = bool(on)
+
+
+def rowgemm_relu_bits(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None):
+    """``relu(x @ w + bias)`` and the bit pattern ``[out > 0]`` (opaque int32 words, include/stgraph_hip.h) for
+    :func:`rowgemm_masked_t`."""
+    x = _f32(x, "x")
+    dev = x.device
+    w = _f32(w, "w", dev)
+    N, K = x.shape
+    M = int(w.shape[1])
+    if int(w.shape[0]) != K:
+        raise ValueError(f"rowgemm_relu_bits: x {tuple(x.shape)} and w {tuple(w.shape)} do not match")
+    if bias is not None:
+        bias = _f32(bias, "bias", dev)
+        if bias.numel() != M:
+            raise ValueError("rowgemm_relu_bits: bias length != output width")
+    y = torch.empty(N, M, dtype=torch.float32, device=dev)
+    bits = torch.empty(int(_C.lib.stg_rowgemm_bits_words(N)), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev), _Timed("rowgemm", 4 * N * (K + M) + 4 * K * M + N * M // 8, 2 * N * K * M):
+        _C.check(_C.lib.stg_rowgemm_act_bits_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), N, K, M, 0, int(ACT_RELU), None, _ptr(bits),
+                                                 _stream_ptr(dev)))
+    return y, bits
+
+
+def rowgemm_masked_t(g: torch.Tensor, w: torch.Tensor, bits: torch.Tensor) -> torch.Tensor:
+    """``(g @ w.T) * pattern`` with ``w`` [M, K] read in place and ``pattern`` the bits :func:`rowgemm_relu_bits` left for a
+    ReLU output of shape [N, M]: the gradient with respect to that ReLU's pre-activation, from the launch that forms ``g w^T``."""
+    g = _f32(g, "g")
+    dev = g.device
+    w = _f32(w, "w", dev)
+    N, K = g.shape
+    M = int(w.shape[0])
+    if int(w.shape[1]) != K:
+        raise ValueError(f"rowgemm_masked_t: g {tuple(g.shape)} and w {tuple(w.shape)} do not match")
+    if bits.dtype != torch.int32 or bits.device != dev or bits.numel() != int(_C.lib.stg_rowgemm_bits_words(N)):
+        raise ValueError("rowgemm_masked_t: bits is not the pattern of an [N, M] output on this device")
+    y = torch.empty(N, M, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("rowgemm", 4 * N * (K + M) + 4 * K * M + N * M // 8, 2 * N * K * M):
+        _C.check(_C.lib.stg_rowgemm_act_bits_f32(_ptr(g), _ptr(w), None, _ptr(y), N, K, M, 1, int(ACT_NONE), _ptr(bits), None,
+                                                 _stream_ptr(dev)))
+    return y
+
+
 def rowgemm_usable(x: torch.Tensor, K: int, M: int, trans_w: bool = False) -> bool:
     # "auto": in situ (TGCN, |V| = 50K) the kernel beats rocBLAS's 64x32 macro tile on x @ W with W [K, M] wider
     # than deep (19.9 vs 29.7 us for [50K,64] x [64,128]) and loses on the transposed forward shapes (24.4 vs 17.5 us)

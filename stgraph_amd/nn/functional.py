@@ -69,6 +69,8 @@ class _MM(torch.autograd.Function):
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
         ctx.w = w
+        # x = relu(...) of _InputLayer with its sign pattern as bits: the backward multiplies g w^T by it in the same launch
+        ctx.relu_bits = _tagged(x, "_stg_relu_bits")
         return _mm(x, w)
 
     @staticmethod
@@ -77,7 +79,15 @@ class _MM(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             if w.is_contiguous() and kernels.rowgemm16_usable(g, w.shape[1], w.shape[0]) and w.data_ptr() % 16 == 0:
-                gx = kernels.rowgemm(g, w, None, trans_w=True)               # g @ w.T with w read in place ([in][out] = [M][K])
+                g = g.contiguous()
+                bits = ctx.relu_bits
+                if bits is not None and kernels.rowgemm_bits_usable(g, w.shape[1], w.shape[0]):
+                    # the ReLU below masks this gradient anyway (and again whatever autograd adds to it: masking twice is
+                    # masking once); done here it costs 16 bytes per row instead of a pass over the ReLU's output
+                    gx = kernels.rowgemm_masked_t(g, w, bits)
+                    _tag(gx, "_stg_relu_masked", bits)
+                else:
+                    gx = kernels.rowgemm(g, w, None, trans_w=True)           # g @ w.T with w read in place ([in][out] = [M][K])
             else:
                 gx = _mm(g, w.t().contiguous()) if g.shape[0] >= LT_MIN_ROWS else torch.mm(g, w.t())
         if ctx.needs_input_grad[1]:
@@ -199,6 +209,22 @@ def _known_colsum(g: torch.Tensor):
     if g._version != version or g.data_ptr() != ptr:
         return None
     return colsum
+
+
+def _tagged(t: torch.Tensor, name: str):
+    """The object a producer left on tensor ``t`` under ``name`` (with the tensor's version and address at that time), or None
+    when ``t`` has been written since or is another tensor."""
+    tag = getattr(t, name, None)
+    if tag is None:
+        return None
+    what, version, ptr = tag
+    if t._version != version or t.data_ptr() != ptr:
+        return None
+    return what
+
+
+def _tag(t: torch.Tensor, name: str, what) -> None:
+    setattr(t, name, (what, t._version, t.data_ptr()))
 
 
 class _CrossEntropy(torch.autograd.Function):
@@ -401,10 +427,14 @@ class _InputLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, norm, ew, fwd_csr, use_nid, act):
         P = kernels.gcn_agg(x, norm, norm, fwd_csr, ew=ew, use_node_ids=use_nid)
+        bits = None
         fused_relu = getattr(torch, "_addmm_activation", None)
         if (w.is_contiguous() and act in (kernels.ACT_NONE, kernels.ACT_RELU) and kernels.rowgemm16_usable(P, w.shape[0], w.shape[1])
                 and w.data_ptr() % 16 == 0):
-            out = kernels.rowgemm_act(P, w, bias, False, act)     # product, bias and activation in one launch (csrc/rowgemm.hip)
+            if act == kernels.ACT_RELU and kernels.rowgemm_bits_usable(P, w.shape[0], w.shape[1]):
+                out, bits = kernels.rowgemm_relu_bits(P, w, bias)  # ... and [out > 0] as bits for the backward (16 bytes per row)
+            else:
+                out = kernels.rowgemm_act(P, w, bias, False, act)  # product, bias and activation in one launch (csrc/rowgemm.hip)
         elif bias is not None and w.is_contiguous() and (act == kernels.ACT_NONE or fused_relu is not None):
             # bias (+ ReLU) in the library GEMM's epilogue (hipBLASLt): 0.36 ms at [1M, 128] x [128, 128] against
             # 0.42 + 0.17 for rocBLAS + one more pass
@@ -414,6 +444,9 @@ class _InputLayer(torch.autograd.Function):
             kernels.bias_act_fwd_(out, bias, act)
         ctx.save_for_backward(P, out if act != kernels.ACT_NONE else norm.new_empty(0))
         ctx.act, ctx.has_bias, ctx.w = act, bias is not None, w
+        ctx.relu_bits = bits
+        if bits is not None:
+            _tag(out, "_stg_relu_bits", bits)
         return out
 
     @staticmethod
@@ -424,6 +457,11 @@ class _InputLayer(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1]
         gb = gw = None
         native = _use_native(P, P.shape[0], P.shape[1], g.shape[1])
+        masked = _tagged(g, "_stg_relu_masked")
+        if ctx.act == kernels.ACT_RELU and want_w and native and masked is not None and masked is ctx.relu_bits:
+            # the consumer's backward already multiplied g by [out > 0] (_MM.backward): the plain contraction and its column sums
+            gwt, gb = kernels.gemm_tn(g, P, colsum=True)
+            return None, gwt.t().contiguous(), (gb if want_b else None), None, None, None, None, None
         if ctx.act == kernels.ACT_RELU and want_w and native and (int(P.shape[0]) * max(P.shape[1], g.shape[1]) < (1 << 29)):
             # nothing but dW and db needs the masked gradient (the input carries none): one launch forms
             # (g * [out > 0])^T P and its column sums, g * [out > 0] is never written

@@ -156,3 +156,104 @@ def test_gcn_training_step_with_the_split_products_matches_the_fp32_products(cud
     torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=0)
     for a, b in zip(res[0][1], res[1][1]):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (float((a - b).abs().max()), float(b.abs().max()))
+
+
+def _decode_bits(bits, N, M):
+    """[N, M] bool from the words of stg_rowgemm_act_bits_f32, by the layout include/stgraph_hip.h states."""
+    dev = bits.device
+    row = torch.arange(N, device=dev).view(N, 1)
+    col = torch.arange(M, device=dev).view(1, M)
+    word = 64 * (row >> 4) + (row & 7) + 8 * ((col >> 4) & 1) + 16 * ((col >> 2) & 3)
+    bit = 8 * (col >> 5) + 4 * ((row >> 3) & 1) + (col & 3)
+    return ((bits.long()[word] >> bit) & 1).bool()
+
+
+@pytest.mark.parametrize("N", [1, 31, 33, 4096, 70_001])
+@pytest.mark.parametrize("K,M", [(128, 128), (64, 128), (128, 64), (64, 64)])
+def test_relu_sign_pattern_as_bits(cuda, N, K, M):
+    """stg_rowgemm_act_bits_f32: the ReLU forward leaves [y > 0] as one bit per element (the documented layout), and the
+    transposed product of the layer above multiplies by it -- both bit-equal to the launches without the pattern."""
+    from stgraph_amd import _C, kernels
+    gen = torch.Generator(device=cuda).manual_seed(N + K + 3 * M)
+    x = torch.randn(N, K, device=cuda, generator=gen)
+    w = torch.randn(K, M, device=cuda, generator=gen)
+    b = torch.randn(M, device=cuda, generator=gen)
+    g = torch.randn(N, K, device=cuda, generator=gen)           # gradient of the layer above: [N, K2] with K2 = K here
+    w2 = torch.randn(M, K, device=cuda, generator=gen)          # that layer's weight, [in = M][out = K]
+    assert _C.lib.stg_rowgemm_bits_supported(N, K, M) and _C.lib.stg_rowgemm_bits_words(N) == ((N + 31) // 32) * 128
+    _C.set_tuning("rowgemm_x3", 2)
+    try:
+        y_plain = kernels.rowgemm_act(x, w, b, False, kernels.ACT_RELU)
+        gx_plain = kernels.rowgemm_act(g, w2, None, True)
+        y, bits = kernels.rowgemm_relu_bits(x, w, b)
+        gx = kernels.rowgemm_masked_t(g, w2, bits)
+    finally:
+        _C.set_tuning("rowgemm_x3", 0)
+    assert torch.equal(y, y_plain)
+    assert torch.equal(_decode_bits(bits, N, M), y > 0)
+    assert torch.equal(gx, gx_plain * (y > 0))
+    # argument checks
+    with pytest.raises(RuntimeError):
+        _C.check(_C.lib.stg_rowgemm_act_bits_f32(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), N, K, M, 0, kernels.ACT_RELU, None, None, None))
+    with pytest.raises(RuntimeError):
+        _C.check(_C.lib.stg_rowgemm_act_bits_f32(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), N, K, M, 1, kernels.ACT_RELU, None,
+                                                 bits.data_ptr(), None))
+    assert not _C.lib.stg_rowgemm_bits_supported(N, 96, M)
+
+
+def test_gcn_training_step_with_the_relu_pattern_as_bits(cuda):
+    """The 2-layer GCN of cfg2's widths on 70 K vertices with real ReLU decisions: the input layer leaves its sign pattern as
+    bits, the layer above masks its input gradient with them, the input layer's weight gradient is the plain contraction --
+    against the same step with the pattern re-read from the layer's output (kernels.set_relu_bits(False)).  The masks are
+    the same bits either way; the gradients differ by the rounding of two split-K orders."""
+    import numpy as np
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd.nn.pytorch.static.gcn_conv import GCNConv
+    from tests.util import gcn_norm, random_graph
+    n, f = 70_001, 128
+    src, dst = random_graph(5, n, 600_000)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    g.set_ndata("norm", torch.from_numpy(gcn_norm(np.bincount(dst, minlength=n))).to(cuda))
+    gen = torch.Generator(device=cuda).manual_seed(2)
+    x = torch.randn(n, f, device=cuda, generator=gen)
+    labels = torch.randint(0, f, (n,), device=cuda, generator=gen)
+    res = []
+    for on in (True, False):
+        kernels.set_relu_bits(on)
+        try:
+            torch.manual_seed(4)
+            layers = torch.nn.ModuleList([GCNConv(f, f, torch.relu), GCNConv(f, f, None)]).to(cuda)
+            rec = []
+            kernels.enable_launch_timing(rec)
+            h1 = layers[0](g, x)
+            h = layers[1](g, h1)
+            loss = SF.cross_entropy(h, labels, n)
+            loss.backward()
+        finally:
+            kernels.enable_launch_timing(None)
+            kernels.set_relu_bits(True)
+        masked_form = 4 * n * (2 * f + f) + 4 * f * f               # bytes of gemm_tn_relu_mask's record
+        assert any(r[0] == "gemm_tn" and r[3] == masked_form for r in rec) == (not on), [(r[0], r[3]) for r in rec]
+        assert float((h1 == 0).float().mean()) > 0.2                # the ReLU does decide
+        res.append((loss.detach().clone(), h1.detach().clone(), [p.grad.clone() for p in layers.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_relu_pattern_is_dropped_when_the_output_is_written_again(cuda):
+    """The pattern rides on the tensor object with its version: an in-place write of the ReLU output between the layers
+    (here `h1 += 1`) makes the layer above fall back to the plain input gradient, and the result is still right."""
+    from stgraph_amd.nn import functional as SF
+    from stgraph_amd import kernels
+    n, f = 70_016, 128
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    x = torch.randn(n, f, device=cuda, generator=gen)
+    w1 = torch.randn(f, f, device=cuda, generator=gen).requires_grad_()
+    h1, bits = kernels.rowgemm_relu_bits(x, w1.detach(), None)
+    SF._tag(h1, "_stg_relu_bits", bits)
+    assert SF._tagged(h1, "_stg_relu_bits") is bits
+    h1 += 1
+    assert SF._tagged(h1, "_stg_relu_bits") is None
