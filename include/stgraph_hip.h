@@ -32,7 +32,8 @@ extern "C" {
  *  23: stg_gat_fwd_k1_uniform, stg_gat_fc_out, stg_gat_fwd_k1_scored, stg_gat_bwd_factored_elu; knob "rowgemm_x3".
  *  24: stg_tgcn_step_fwd_args gains w_fold, b_fold, fold_status (last fields): the folded form of the forward step launch; x3 / da3 of
  *      the step launches optional; stg_tgcn_unfold_gate_grads.
- *  25: stg_rowgemm_act_bits_f32, stg_rowgemm_bits_words, stg_rowgemm_bits_supported: a ReLU layer's sign pattern as bits. */
+ *  25: stg_rowgemm_act_bits_f32, stg_rowgemm_bits_words, stg_rowgemm_bits_supported: a ReLU layer's sign pattern as bits;
+ *      stg_xent_fwd_grad, stg_xent_scale_grad: cross-entropy forward and gradient in one pass. */
 #define STG_ABI_VERSION 25
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -838,6 +839,17 @@ size_t stg_xent_bwd_colsum_workspace_bytes(int64_t n_total, int32_t K);
 int stg_xent_bwd_colsum(const float *g_loss, const float *logits, const int64_t *labels, const float *lse,
                         const float *n_counted, float *dlogits, float *colsum, int64_t n, int64_t n_total, int32_t K,
                         void *workspace, size_t workspace_bytes, void *stream);
+/* Forward and gradient in ONE pass over the logits, for a loss that is going to be differentiated (train.py:63-101:
+ * `loss = loss_fcn(...)`, `loss.backward()`): loss, lse and n_counted as stg_xent_fwd, and dlogits [n_total, K] / colsum [K] as
+ * stg_xent_bwd_colsum would return them for g_loss = 1 -- a count launch over the labels first (the gradient's 1 / n_counted must
+ * be known before the first row), then each row in registers once.  stg_xent_scale_grad multiplies dlogits (and colsum, nullable)
+ * by g_loss [dev scalar] in place in the backward pass; when g_loss is exactly 1 -- what `loss.backward()` passes -- every
+ * workgroup reads it and leaves.  Shapes as stg_xent_bwd_colsum (workspace bytes 0 = not covered). */
+size_t stg_xent_fwd_grad_workspace_bytes(int64_t n_total, int32_t K);
+int stg_xent_fwd_grad(const float *logits, const int64_t *labels, float *lse, float *loss, float *n_counted, int32_t *status,
+                      float *dlogits, float *colsum, int64_t n, int64_t n_total, int32_t K, void *workspace,
+                      size_t workspace_bytes, void *stream);
+int stg_xent_scale_grad(float *dlogits, float *colsum, const float *g_loss, int64_t n_total, int32_t K, void *stream);
 
 /* ----------------------------------------------- dense neighbour: the TGCN harness head
  * The model head and loss of the static-temporal TGCN training step

@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = (
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
-    "stg_xent_workspace_bytes", "stg_xent_fwd", "stg_xent_bwd", "stg_xent_bwd_colsum_workspace_bytes", "stg_xent_bwd_colsum",
+    "stg_xent_workspace_bytes", "stg_xent_fwd", "stg_xent_bwd", "stg_xent_bwd_colsum_workspace_bytes", "stg_xent_bwd_colsum", "stg_xent_fwd_grad_workspace_bytes", "stg_xent_fwd_grad", "stg_xent_scale_grad",
     "stg_link_head_supported", "stg_link_head_workspace_bytes", "stg_link_head_fwd", "stg_link_head_bwd",
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
@@ -283,6 +283,12 @@ def _load() -> ctypes.CDLL:
     lib.stg_xent_bwd.argtypes = [vp] * 6 + [i64, i64, i32, vp]
     lib.stg_xent_bwd_colsum_workspace_bytes.restype = ctypes.c_size_t
     lib.stg_xent_bwd_colsum_workspace_bytes.argtypes = [i64, i32]
+    lib.stg_xent_fwd_grad_workspace_bytes.restype = ctypes.c_size_t
+    lib.stg_xent_fwd_grad_workspace_bytes.argtypes = [i64, i32]
+    lib.stg_xent_fwd_grad.restype = ctypes.c_int
+    lib.stg_xent_fwd_grad.argtypes = [vp] * 8 + [i64, i64, i32, vp, ctypes.c_size_t, vp]
+    lib.stg_xent_scale_grad.restype = ctypes.c_int
+    lib.stg_xent_scale_grad.argtypes = [vp, vp, vp, i64, i32, vp]
     lib.stg_xent_bwd_colsum.restype = ctypes.c_int
     lib.stg_xent_bwd_colsum.argtypes = [vp] * 7 + [i64, i64, i32, vp, ctypes.c_size_t, vp]
     lib.stg_link_head_supported.restype = ctypes.c_int

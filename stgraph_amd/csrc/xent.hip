@@ -309,6 +309,188 @@ __global__ __launch_bounds__(kBlock) void xent_colsum_finish_kernel(const float 
     }
 }
 
+// ---- forward and gradient in ONE pass over the logits ---------------------------------------------------------------------------
+// The training step reads the logits twice (lse in the forward, softmax - onehot in the backward: 81 + 140 us at [1 M, 128]
+// with 600 K live rows).  When the loss is going to be differentiated, the row is in registers once: lse, the loss term, and
+// the gradient for an upstream gradient of 1 -- what `loss.backward()` passes -- written at once, column sums included.  Its
+// scale 1 / (rows counted) must be known before the first row: a count launch over the labels alone (8 bytes per row) leaves
+// partial counts that every workgroup adds up in the same order.  The backward then only multiplies by g when g != 1
+// (xent_scale_grad_kernel: every workgroup reads g and leaves).  The launch is bound by its vector instructions (the accurate
+// expf is ~20 of them): the softmax is exp(x - m) / sum from the exponentials of the sum, not a second expf per element.
+constexpr int kXentCountParts = 512;
+
+__global__ __launch_bounds__(kBlock) void xent_count_kernel(const int64_t *__restrict__ labels, int64_t n, int K, int *__restrict__ parts)
+{
+    __shared__ int s[kBlock];
+    int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t t = labels[i];
+        c += (t >= 0 && t < K) ? 1 : 0;
+    }
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) parts[blockIdx.x] = s[0];
+}
+
+template <int G, int CH>
+__global__ __launch_bounds__(kBlock) void xent_fwd_grad_kernel(const float *__restrict__ logits, const int64_t *__restrict__ labels,
+                                                               float *__restrict__ lse, float *__restrict__ dlogits,
+                                                               float *__restrict__ partial, int *__restrict__ partial_cnt,
+                                                               float *__restrict__ cs_partial, const int *__restrict__ cnt_parts,
+                                                               int n_parts, int64_t n, int64_t n_total, int K, int *__restrict__ status)
+{
+    constexpr int ROWS = kBlock / G, R = 2;
+    __shared__ float s[ROWS];
+    __shared__ int sc[ROWS];
+    __shared__ int total_s;
+    __shared__ float4 red[kBlock * 2];
+    if (threadIdx.x < kWave) {
+        int c = 0;
+        for (int i = threadIdx.x; i < n_parts; i += kWave) c += cnt_parts[i];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
+        if (threadIdx.x == 0) total_s = c;
+    }
+    __syncthreads();
+    const float scale = 1.0f / (float)total_s;                   // = g / n_counted of the backward launch at g = 1
+    const int g = threadIdx.x / G, j = threadIdx.x % G;
+    float term = 0.f;
+    int counted = 0;
+    float4 cs[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) cs[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t stride = (int64_t)gridDim.x * ROWS;
+    // The NEXT trip's rows are asked for before this trip's are worked on: the chain load -> max -> exp -> sum -> log -> exp -> store
+    // of a trip is long, and two rows per lane group in flight do not cover it.  For the loads to stay in flight across the trip
+    // they sit behind no branch (a row past the live ones re-reads row n - 1, a column past K its last piece; the values are
+    // replaced afterwards) and the row's target logit comes out of the registers (a group sum with one non-zero term) instead of
+    // a load of its own, which drains the queue: 170 us at [1 M, 128] with the loads behind their bounds checks.
+    auto load_rows = [&](int64_t row0, float4 (&v)[R][CH], int64_t (&lab)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = std::min<int64_t>(row0 + r * stride, n - 1);
+            lab[r] = labels[row];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) v[r][c] = *reinterpret_cast<const float4 *>(logits + row * K + std::min((j + c * G) * 4, K - 4));
+        }
+    };
+    float4 vn[R][CH];
+    int64_t labn[R];
+    load_rows((int64_t)blockIdx.x * ROWS + g, vn, labn);
+    for (int64_t row0 = (int64_t)blockIdx.x * ROWS + g; row0 < n; row0 += R * stride) {
+        float4 v[R][CH];
+        int64_t lab[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            lab[r] = labn[r];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                v[r][c] = (j + c * G) * 4 < K ? vn[r][c] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+        load_rows(row0 + R * stride, vn, labn);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + r * stride;
+            const int64_t t = lab[r];
+            const bool live = row < n, valid = live && t >= 0 && t < K;
+            float m = -INFINITY, sum = 0.f, xt = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) m = fmaxf(fmaxf(m, fmaxf(v[r][c].x, v[r][c].y)), fmaxf(v[r][c].z, v[r][c].w));
+            m = group_max<G>(m);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if ((j + c * G) * 4 < K) {
+                    const int tc = (int)t - (j + c * G) * 4;      // the lane that holds column t contributes it, the others 0
+                    xt += tc == 0 ? v[r][c].x : tc == 1 ? v[r][c].y : tc == 2 ? v[r][c].z : tc == 3 ? v[r][c].w : 0.f;
+                    v[r][c] = make_float4(expf(v[r][c].x - m), expf(v[r][c].y - m), expf(v[r][c].z - m), expf(v[r][c].w - m));
+                    sum = sum + v[r][c].x;                         // (the order of xent_fwd_reg_kernel)
+                    sum = sum + v[r][c].y;
+                    sum = sum + v[r][c].z;
+                    sum = sum + v[r][c].w;
+                }
+            }
+            sum = group_sum<G>(sum);
+            xt = group_sum<G>(xt);
+            const float l = m + logf(sum), inv = 1.0f / sum;
+            if (j == 0 && live) {
+                lse[row] = l;
+                if (valid) term = term + (l - xt), ++counted;
+                else if (t != kIgnoreIndex) atomicOr(status, 1);
+            }
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int col = (j + c * G) * 4;
+                    if (col >= K) continue;
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (valid) {                                 // rows not counted get no gradient
+                        // softmax = exp(x - m) / sum from the exponentials the sum was made of (the backward launch, which has
+                        // only lse, takes exp(x - lse): the same value up to the rounding of lse, ~1e-7 relative either way)
+                        const int tc = (int)t - col;
+                        o.x = (v[r][c].x * inv - (tc == 0 ? 1.f : 0.f)) * scale;
+                        o.y = (v[r][c].y * inv - (tc == 1 ? 1.f : 0.f)) * scale;
+                        o.z = (v[r][c].z * inv - (tc == 2 ? 1.f : 0.f)) * scale;
+                        o.w = (v[r][c].w * inv - (tc == 3 ? 1.f : 0.f)) * scale;
+                    }
+                    *reinterpret_cast<float4 *>(dlogits + row * K + col) = o;
+                    cs[c] = make_float4(cs[c].x + o.x, cs[c].y + o.y, cs[c].z + o.z, cs[c].w + o.w);
+                }
+            }
+        }
+    }
+    // rows [n, n_total) took no part in the loss: zeros (the flat range dealt to all threads, 16 bytes each)
+    {
+        float4 *z = reinterpret_cast<float4 *>(dlogits + n * K);
+        const int64_t count = (n_total - n) * (int64_t)(K / 4);
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock)
+            z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (j == 0) s[g] = term, sc[g] = counted;
+    red[threadIdx.x] = cs[0];
+    red[kBlock + threadIdx.x] = CH > 1 ? cs[CH - 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        int c = 0;
+        for (int i = 0; i < ROWS; ++i) t = t + s[i], c += sc[i];
+        partial[blockIdx.x] = t;
+        partial_cnt[blockIdx.x] = c;
+    }
+    if ((int)threadIdx.x < 2 * G) {                              // as xent_bwd_rows_kernel
+        const int chunk = threadIdx.x / G, jj = threadIdx.x % G, col = (jj + chunk * G) * 4;
+        if (col < K) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < ROWS; ++q) {
+                const float4 v = red[chunk * kBlock + q * G + jj];
+                t = make_float4(t.x + v.x, t.y + v.y, t.z + v.z, t.w + v.w);
+            }
+            *reinterpret_cast<float4 *>(cs_partial + (int64_t)blockIdx.x * K + col) = t;
+        }
+    }
+}
+
+// d *= g, colsum *= g -- unless g is exactly 1 (loss.backward()), when every workgroup reads g and leaves
+__global__ __launch_bounds__(kBlock) void xent_scale_grad_kernel(float *__restrict__ d, float *__restrict__ colsum,
+                                                                 const float *__restrict__ g_loss, int64_t total4, int64_t tail0,
+                                                                 int64_t total, int K)
+{
+    const float g = g_loss[0];
+    if (g == 1.0f) return;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+        float4 v = reinterpret_cast<float4 *>(d)[i];
+        reinterpret_cast<float4 *>(d)[i] = make_float4(v.x * g, v.y * g, v.z * g, v.w * g);
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = tail0 + threadIdx.x; i < total; i += kBlock) d[i] = d[i] * g;
+        if (colsum)
+            for (int k = threadIdx.x; k < K; k += kBlock) colsum[k] = colsum[k] * g;
+    }
+}
+
 constexpr int kXentGrid = 2048;
 
 inline int xent_lanes(int K) { return K <= 32 ? 8 : K <= 256 ? 32 : 64; }
@@ -443,4 +625,65 @@ extern "C" int stg_xent_bwd_colsum(const float *g_loss, const float *logits, con
     xent_bwd_launch(g_loss, logits, labels, lse, n_counted, dlogits, colsum, static_cast<float *>(workspace), n, n_total, K,
                     static_cast<hipStream_t>(stream_));
     return check_launch("stg_xent_bwd_colsum");
+}
+
+// ---- one pass: loss, lse and the gradient at g = 1 (see xent_fwd_grad_kernel) -----------------------------------------------------
+extern "C" size_t stg_xent_fwd_grad_workspace_bytes(int64_t n_total, int32_t K)
+{
+    if (n_total <= 0 || K <= 0 || K % 4 != 0 || K > 8 * stg::xent_lanes(K)) return 0;          // 0: shape not covered
+    const size_t blocks = (size_t)stg::xent_bwd_row_blocks(n_total, K);
+    return sizeof(float) * blocks * (size_t)K + 2 * sizeof(float) * blocks + sizeof(int) * stg::kXentCountParts;
+}
+
+extern "C" int stg_xent_fwd_grad(const float *logits, const int64_t *labels, float *lse, float *loss, float *n_counted,
+                                 int32_t *status, float *dlogits, float *colsum, int64_t n, int64_t n_total, int32_t K,
+                                 void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace stg;
+    if (n <= 0 || K <= 0 || n_total < n) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_fwd_grad: bad shape n=%lld n_total=%lld K=%d",
+                                                    (long long)n, (long long)n_total, K);
+    if (!logits || !labels || !lse || !loss || !n_counted || !status || !dlogits || !colsum || !workspace)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_fwd_grad: NULL pointer argument");
+    const size_t need = stg_xent_fwd_grad_workspace_bytes(n_total, K);
+    if (need == 0 || reinterpret_cast<uintptr_t>(logits) % 16 != 0 || reinterpret_cast<uintptr_t>(dlogits) % 16 != 0 ||
+        reinterpret_cast<uintptr_t>(workspace) % 16 != 0)
+        return fail(STG_ERR_UNSUPPORTED, "stg_xent_fwd_grad: needs K %% 4 == 0, K <= 8 lanes-per-row and 16-byte aligned matrices (K=%d)", K);
+    if (workspace_bytes < need) return fail(STG_ERR_WORKSPACE, "stg_xent_fwd_grad: workspace %zu < required %zu", workspace_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    // one resident round of workgroups (8 per CU): the partial sums the finish launches add up stay few
+    const int blocks = std::min(xent_bwd_row_blocks(n_total, K), 2048);
+    float *cs_partial = static_cast<float *>(workspace);
+    float *partial = cs_partial + (size_t)blocks * K;
+    int *partial_cnt = reinterpret_cast<int *>(partial + blocks);
+    int *cnt_parts = partial_cnt + blocks;
+    const int parts = (int)std::min<int64_t>((n + kBlock * 4 - 1) / (kBlock * 4), kXentCountParts);
+    hipLaunchKernelGGL(xent_count_kernel, dim3(parts), dim3(kBlock), 0, st, labels, n, K, cnt_parts);
+    const int G = xent_lanes(K);
+    const bool one = K <= 4 * G;
+#define STG_XFG(G_, CH_)                                                                                                        \
+    hipLaunchKernelGGL((xent_fwd_grad_kernel<G_, CH_>), dim3(blocks), dim3(kBlock), 0, st, logits, labels, lse, dlogits, partial,  \
+                       partial_cnt, cs_partial, cnt_parts, parts, n, n_total, K, status)
+    switch (G) {
+        case 8: if (one) STG_XFG(8, 1); else STG_XFG(8, 2); break;
+        case 32: if (one) STG_XFG(32, 1); else STG_XFG(32, 2); break;
+        default: if (one) STG_XFG(64, 1); else STG_XFG(64, 2); break;
+    }
+#undef STG_XFG
+    hipLaunchKernelGGL(xent_finish_kernel, dim3(1), dim3(kBlock), 0, st, partial, partial_cnt, blocks, loss, n_counted);
+    hipLaunchKernelGGL(xent_colsum_finish_kernel, dim3((K + 7) / 8), dim3(kBlock), 0, st, cs_partial, colsum, blocks, K);
+    return check_launch("stg_xent_fwd_grad");
+}
+
+extern "C" int stg_xent_scale_grad(float *dlogits, float *colsum, const float *g_loss, int64_t n_total, int32_t K, void *stream_)
+{
+    using namespace stg;
+    if (n_total <= 0 || K <= 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_scale_grad: bad shape");
+    if (!dlogits || !g_loss) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_scale_grad: NULL pointer argument");
+    const int64_t total = n_total * (int64_t)K;
+    const bool v4 = reinterpret_cast<uintptr_t>(dlogits) % 16 == 0;
+    const int64_t total4 = v4 ? total / 4 : 0;
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>((total4 + kBlock - 1) / kBlock, 1), 256 * 8);
+    hipLaunchKernelGGL(xent_scale_grad_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream_), dlogits, colsum, g_loss,
+                       total4, total4 * 4, total, K);
+    return check_launch("stg_xent_scale_grad");
 }

@@ -1995,6 +1995,54 @@ def xent_fwd(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None
     return loss, lse, n_counted, status
 
 
+_XENT_ONE_PASS = os.environ.get("STGRAPH_AMD_XENT_ONE_PASS", "1") != "0"
+
+
+def set_xent_one_pass(on: bool) -> None:
+    """False: the cross-entropy's gradient comes from its own pass over the logits in the backward (the form before
+    stg_xent_fwd_grad)."""
+    global _XENT_ONE_PASS
+    _XENT_ONE_PASS = bool(on)
+
+
+def xent_fwd_grad_usable(logits: torch.Tensor) -> bool:
+    n_total, K = logits.shape
+    return (_XENT_ONE_PASS and logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and n_total > 0
+            and logits.data_ptr() % 16 == 0 and int(_C.lib.stg_xent_fwd_grad_workspace_bytes(int(n_total), int(K))) > 0)
+
+
+def xent_fwd_grad(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None):
+    """:func:`xent_fwd` and, from the same pass, the gradient of the whole logits matrix for an upstream gradient of 1 with its
+    column sums (stg_xent_fwd_grad).  Returns (loss, lse, n_counted, status, dlogits, colsum); :func:`xent_scale_grad` applies
+    the upstream gradient."""
+    n_total, K = logits.shape
+    n = n_total if rows is None else int(rows)
+    dev = logits.device
+    if not labels.is_cuda or labels.device != dev:
+        raise ValueError(f"xent_fwd_grad: labels on {labels.device}, logits on {dev}")
+    lse = torch.empty(n, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    n_counted = torch.empty(1, dtype=torch.float32, device=dev)
+    status = _XENT_STATUS.get(dev)
+    if status is None:
+        status = _XENT_STATUS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    d = torch.empty_like(logits)
+    cs = torch.empty(K, dtype=torch.float32, device=dev)
+    ws_bytes = int(_C.lib.stg_xent_fwd_grad_workspace_bytes(n_total, K))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _Timed("xent_fwd_grad", 4 * n * (2 * K + 3) + 8 * n + 4 * (n_total - n) * K, 4 * n * K):
+        _C.check(_C.lib.stg_xent_fwd_grad(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(loss), _ptr(n_counted), _ptr(status), _ptr(d),
+                                          _ptr(cs), n, n_total, K, _ptr(ws), ws_bytes, _stream_ptr(dev)))
+    return loss, lse, n_counted, status, d, cs
+
+
+def xent_scale_grad(d: torch.Tensor, colsum: torch.Tensor | None, g_loss: torch.Tensor) -> None:
+    """``d *= g_loss`` (and ``colsum``) in place; a launch that returns at once when ``g_loss`` is exactly 1."""
+    n_total, K = d.shape
+    with torch.cuda.device(d.device):
+        _C.check(_C.lib.stg_xent_scale_grad(_ptr(d), _ptr(colsum), _ptr(g_loss), n_total, K, _stream_ptr(d.device)))
+
+
 def xent_bwd(g_loss: torch.Tensor, logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor,
              n_counted: torch.Tensor, want_colsum: bool = False):
     """Gradient of xent_fwd for the WHOLE logits matrix: rows beyond ``lse.shape[0]`` (not part of the loss) and rows

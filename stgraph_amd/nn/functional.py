@@ -234,14 +234,24 @@ class _CrossEntropy(torch.autograd.Function):
     def forward(ctx, logits, labels, rows=None):
         logits = logits.contiguous()
         labels = labels.contiguous()
-        loss, lse, n_counted, _ = kernels.xent_fwd(logits, labels, rows)
+        ctx.d = ctx.colsum = None
+        if ctx.needs_input_grad[0] and kernels.xent_fwd_grad_usable(logits):
+            # the loss is going to be differentiated: the gradient for an upstream gradient of 1 from the same pass over the logits
+            loss, lse, n_counted, _, ctx.d, ctx.colsum = kernels.xent_fwd_grad(logits, labels, rows)
+        else:
+            loss, lse, n_counted, _ = kernels.xent_fwd(logits, labels, rows)
         ctx.save_for_backward(logits, labels, lse, n_counted)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         logits, labels, lse, n_counted = ctx.saved_tensors
-        d, colsum = kernels.xent_bwd(g.contiguous(), logits, labels, lse, n_counted, want_colsum=True)
+        if ctx.d is not None:
+            d, colsum = ctx.d, ctx.colsum
+            ctx.d = ctx.colsum = None                    # scaled in place below: a second backward takes the two-pass form
+            kernels.xent_scale_grad(d, colsum, g.contiguous().float())
+        else:
+            d, colsum = kernels.xent_bwd(g.contiguous(), logits, labels, lse, n_counted, want_colsum=True)
         if colsum is not None:
             # the gradient's column sums ride along on the tensor object: a bias layer right below the loss (GCNConv's
             # `h + self.bias`) takes them as its bias gradient instead of re-reading the matrix (_GcnLayerTail.backward).

@@ -183,3 +183,73 @@ def test_bias_gradient_of_the_layer_below_the_loss_comes_from_the_loss_backward(
     finally:
         kernels.bias_act_bwd = real
     torch.testing.assert_close(fused, conv.bias.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_total,n,K", [(1000, 600, 128), (70_001, 70_001, 128), (5000, 4999, 8), (3000, 100, 256), (2708, 1624, 16),
+                                         (1, 1, 4), (600_000, 360_000, 128)])
+def test_forward_and_gradient_in_one_pass(cuda, n_total, n, K):
+    """stg_xent_fwd_grad: loss, lse, count, gradient and its column sums from ONE pass over the logits (with labels that are
+    ignored) against the forward launch followed by the backward launch: lse and the count bit-equal, the loss up to the order of
+    its partial sums, the gradient up to the rounding of exp(x - m) / sum against exp(x - lse); stg_xent_scale_grad for g != 1."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(n_total + K)
+    logits = torch.randn(n_total, K, device=cuda, generator=gen) * 3
+    labels = torch.randint(0, K, (n_total,), device=cuda, generator=gen)
+    if n > 10:
+        labels[3] = -100
+        labels[n - 2] = -100
+    assert kernels.xent_fwd_grad_usable(logits)
+    loss2, lse2, cnt2, _ = kernels.xent_fwd(logits, labels, n)
+    one = torch.ones(1, device=cuda)
+    d2, cs2 = kernels.xent_bwd(one, logits, labels, lse2, cnt2, want_colsum=True)
+    loss1, lse1, cnt1, _, d1, cs1 = kernels.xent_fwd_grad(logits, labels, n)
+    assert torch.equal(lse1, lse2) and torch.equal(cnt1, cnt2)
+    torch.testing.assert_close(loss1, loss2, rtol=2e-6, atol=0)
+    # exp(x - m) / sum here, exp(x - lse) there: fp32 rounding of lse apart
+    assert float((d1 - d2).abs().max()) <= 2e-6 * float(d2.abs().max())
+    torch.testing.assert_close(cs1, cs2, rtol=2e-5, atol=1e-6 * float(d2.abs().max()) * (n ** 0.5))
+    assert not d1[n:].any()
+    # g = 1: the scale launch leaves every bit alone; g = 0.37: the gradient of 0.37 * loss
+    keep = d1.clone()
+    kernels.xent_scale_grad(d1, cs1, one)
+    assert torch.equal(d1, keep)
+    g = torch.full((1,), 0.37, device=cuda)
+    kernels.xent_scale_grad(d1, cs1, g)
+    d3, cs3 = kernels.xent_bwd(g, logits, labels, lse2, cnt2, want_colsum=True)
+    assert float((d1 - d3).abs().max()) <= 2e-6 * float(d3.abs().max())
+    torch.testing.assert_close(cs1, cs3, rtol=2e-5, atol=1e-6 * float(d3.abs().max()) * (n ** 0.5))
+
+
+def test_one_pass_loss_backward_twice_and_switched_off(cuda):
+    """SF.cross_entropy takes the one-pass form when the logits need a gradient; a second backward through the same graph
+    (retain_graph) falls back to the backward launch; kernels.set_xent_one_pass(False) gives the same gradient."""
+    from stgraph_amd import kernels
+    from stgraph_amd.nn import functional as SF
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    logits = torch.randn(5000, 64, device=cuda, generator=gen)
+    labels = torch.randint(0, 64, (5000,), device=cuda, generator=gen)
+    grads = []
+    for on in (True, False):
+        kernels.set_xent_one_pass(on)
+        try:
+            x = logits.clone().requires_grad_(True)
+            rec = []
+            kernels.enable_launch_timing(rec)
+            loss = SF.cross_entropy(x, labels, 3000)
+            loss.backward(retain_graph=True)
+            first = x.grad.clone()
+            loss.backward()
+            kernels.enable_launch_timing(None)
+            assert float((x.grad - 2 * first).abs().max()) <= 4e-6 * float(first.abs().max())
+            assert ("xent_fwd_grad" in {r[0] for r in rec}) == on
+            grads.append(first)
+            # no gradient wanted: the plain forward
+            rec = []
+            kernels.enable_launch_timing(rec)
+            SF.cross_entropy(logits, labels, 3000)
+            kernels.enable_launch_timing(None)
+            assert {r[0] for r in rec} == {"xent_fwd"}
+        finally:
+            kernels.enable_launch_timing(None)
+            kernels.set_xent_one_pass(True)
+    assert float((grads[0] - grads[1]).abs().max()) <= 2e-6 * float(grads[1].abs().max())
