@@ -63,7 +63,8 @@ const char *stg_last_error_string(void);
  * split form at every N, 3 = its lane-owns-row-pieces load / store variant (diagnosis); the second such knob: both forms inside the
  * fp32 kernel's error bound against fp64, integer data exact in both), "step_spread"
  * (0 = one workgroup per CU when there are fewer tiles than wave slots, 1 = packed grid), "gemm_wide" (tall-skinny weight
- * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_cyclic" (its row-group hand-out: 0 .. 2),
+ * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_cyclic" (its row-group hand-out: 0 .. 2), "gemm_xcd_pair" (its
+ * workgroup order when M x N takes several workgroups per K slice: 0 = those of a slice on one XCD, 1 = dealt in turn),
  * "gcn_wide_long" (rows of >= 1024 edges at F >= 128: 0 = feature-sliced workgroups beside the main launch, 1 = never, 2 = behind
  * it on the same stream), "build_lds_count" (stg_graph_build_direct2_device: 0 = histograms in LDS when |V| <= 40 K and the graph
  * is dense enough, 1 = whenever |V| fits, 2 = never), "store_rows" (stg_edgeset_step_device given the old set's row offsets: 0 = the

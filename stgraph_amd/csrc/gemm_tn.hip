@@ -310,7 +310,7 @@ constexpr int kWideDepth = 4;
 template <int WA, int CA, int WB, int CB, bool CS, bool AMASK, int D = kWideDepth, int MINW = 2>
 __global__ __launch_bounds__(kBlock, MINW) void gemm_tn_wide_kernel(
     const GemmSegs segs, const GemmForm form, float *__restrict__ slab, int64_t K, int M, int N, int64_t kslice_wave,
-    int m_groups, int n_groups, int s_per_seg, int cyclic)
+    int m_groups, int n_groups, int s_per_seg, int cyclic_flags)
 {
     constexpr int TA = WA * CA, TB = WB * CB;
     static_assert(TA * TB <= 32, "accumulator tiles per wave");
@@ -318,10 +318,26 @@ __global__ __launch_bounds__(kBlock, MINW) void gemm_tn_wide_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n16 = lane & 15, kq = lane >> 4;
-    const int mi = blockIdx.x % m_groups;
-    const int t = blockIdx.x / m_groups;
-    const int nj = t % n_groups;
-    const int s = t / n_groups;                          // slab index = segment * s_per_seg + slice
+    // The m / n groups of one K slice read the same rows of B / A.  Workgroups go to the 8 XCDs in turn, each with an L2 of
+    // its own: dealt (mi fastest) the two m groups of cfg2's 128 x 128 products sit on DIFFERENT XCDs and B comes from HBM twice
+    // (1.5 GB for 1 GB of operands).  flags bit 3: the groups of slice s are workgroups xcd + 8 g of a run of 8 G, i.e. on the
+    // same XCD and resident together, so the second reader hits in L2.
+    int grp, s;                                          // s: slab index = segment * s_per_seg + slice
+    {
+        const int G = m_groups * n_groups, b = blockIdx.x, S_all = (int)gridDim.x / G, full = S_all & ~7;
+        if ((cyclic_flags & 8) && b < full * G) {
+            const int run = b / (8 * G), within = b - run * 8 * G;
+            s = run * 8 + (within & 7);
+            grp = within >> 3;
+        } else {
+            const int r = (cyclic_flags & 8) ? b - full * G : b;
+            grp = r % G;
+            s = ((cyclic_flags & 8) ? full : 0) + r / G;
+        }
+    }
+    const int cyclic = cyclic_flags & 7;
+    const int mi = grp % m_groups;
+    const int nj = grp / m_groups;
     const int seg = s / s_per_seg;
     const int sl = s - seg * s_per_seg;
     const float *__restrict__ A = segs.a[seg];
@@ -749,6 +765,7 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         int cyclic = tuning().gemm_cyclic;
         if (cyclic == 1 && 4 * p.kslice_wave * max_ld_ * 4 >= (int64_t)INT32_MAX) cyclic = 0;
         if (cyclic == 2 && K * max_ld_ * 4 >= (int64_t)INT32_MAX) cyclic = 0;
+        if (tuning().gemm_xcd_pair == 0 && p.m_tiles * p.n_groups > 1) cyclic |= 8;      // the groups of a K slice on one XCD
 #define STG_WIDE_L(WA_, CA_, WB_, CB_, CS_, AM_)                                                                   \
     hipLaunchKernelGGL((gemm_tn_wide_kernel<WA_, CA_, WB_, CB_, CS_, AM_>), dim3((unsigned)blocks), dim3(kBlock), wlds, stream, segs, \
                        form, slab, K, M, N, p.kslice_wave, p.m_tiles, p.n_groups, p.S, cyclic)

@@ -141,6 +141,7 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().gemm_wide = value;
         return 0;
     }
+    if (!std::strcmp(key, "gemm_xcd_pair")) { tuning().gemm_xcd_pair = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "gemm_cyclic")) {
         if (value < 0 || value > 2) return fail(STG_ERR_INVALID_ARGUMENT, "gemm_cyclic must be 0, 1 or 2");
         tuning().gemm_cyclic = value;

@@ -42,6 +42,7 @@ struct Tuning {
     int rowgemm16 = 0;             // stg_rowgemm_f32 at K, M in {64, 128}: 0 = the 16-row row-piece kernel, 1 = never
     int gemm_wide = 0;             // tall-skinny weight gradient: 0 = auto (16-byte-per-lane form where the widths allow), 1 = never
     int gemm_cyclic = 0;           // its K distribution inside a block: 0 = a contiguous quarter per wave, 1 = 4-row groups in turn
+    int gemm_xcd_pair = 0;         // its workgroup order with several M / N groups: 0 = the groups of a K slice on one XCD (shared operand from L2), 1 = dealt in turn
     int step_fold = 0;             // stg_tgcn_step_fwd given folded gate weights: 0 = the fp32-instruction folded form (needs fold_bound, x3 == NULL), 1 = the matrix-core folded form
     int rowgemm_x3 = 0;            // row products at K, M in {64, 128}: 0 = auto (3-term bf16 split on the matrix cores from 64 K rows), 1 = never, 2 = whenever legal
 };
