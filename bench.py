@@ -652,7 +652,7 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
     # every kernel against the roofline that bounds it: the dense ones (fc + projection epilogue, the split-K weight
     # gradients, row GEMMs) against the fp32 matrix rate (157.3 TFLOP/s: v_mfma_f32_*_f32, the guide's F32 row), the
     # gather / elementwise ones against HBM on the bytes they actually MOVE
-    dense = ("gat_fc", "gat_fc_out", "gemm_tn", "gemm_tn_multi", "rowgemm", "rowgemm_wide")
+    dense = ("gat_fc", "gat_fc_out", "gat_bwd_gw", "gemm_tn", "gemm_tn_multi", "rowgemm", "rowgemm_wide")
     ktab = {}
     for k, v in tab.items():
         ms = float(np.mean(v["ms"]))
@@ -696,7 +696,10 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
     k1 = ktab[dom_name]
     dom_symbol = {"gat_k1": "stg::gat_k1_kernel", "gat_k1_uniform": "stg::gat_k1_kernel",
                   "gat_bwd": "stg::gat_bwd_fact_h8d64_kernel (+ its per-vertex prepass stg::gat_bwd_prepass_h8d64_kernel, "
-                             "one C-ABI call: stg_gat_bwd_factored)"}.get(dom_name, dom_name)
+                             "one C-ABI call: stg_gat_bwd_factored)",
+                  "gat_bwd_uniform": "stg::gat_ubwd_t_kernel + stg::gat_ubwd_src_kernel (the backward unit in the uniform-attention "
+                                     "form, one C-ABI call: stg_gat_bwd_uniform_edges; bytes = what the two passes move)",
+                  "gat_bwd_prepass": "stg::gat_bwd_prepass_h8d64_kernel"}.get(dom_name, dom_name)
     layer = {"ms_per_fwd_bwd": dt * 1e3, "edges_feat_per_s": 2 * e * H * D / dt, "kernels": ktab}
     del conv, x, R
     torch.cuda.empty_cache()

@@ -33,7 +33,8 @@ extern "C" {
  *  24: stg_tgcn_step_fwd_args gains w_fold, b_fold, fold_status (last fields): the folded form of the forward step launch; x3 / da3 of
  *      the step launches optional; stg_tgcn_unfold_gate_grads.
  *  25: stg_rowgemm_act_bits_f32, stg_rowgemm_bits_words, stg_rowgemm_bits_supported: a ReLU layer's sign pattern as bits;
- *      stg_xent_fwd_grad, stg_xent_scale_grad: cross-entropy forward and gradient in one pass. */
+ *      stg_xent_fwd_grad, stg_xent_scale_grad: cross-entropy forward and gradient in one pass; stg_gat_bwd_uniform_*,
+ *      stg_gat_bwd_prepass, stg_gemm_tn_gated_f32: the GAT backward unit in the uniform-attention form. */
 #define STG_ABI_VERSION 25
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -469,6 +470,30 @@ int stg_gat_bwd_factored(const float *A, const float *S, const float *out, const
                          const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
                          const int32_t *node_ids, int32_t N, int32_t H, int32_t D, float slope, float *grad_er,
                          const int32_t *ones_flag, void *stream);
+/* K2 of the GATConv whose attention is uniform (every A = 1.0f: ones_flag clear) and whose features are feat = x fc.weight^T, at
+ * H = 8, D = 64, fin = 64 (stg_gat_bwd_uniform_supported) -- BASELINE configs[2].  No row of width H D is gathered per edge:
+ * the dot product of T is  g[v,h,:] . feat[u,h,:] = gW[v,h,:] . x[u,:]  with gW [H][N][fin] = g[:,h,:] W_h (the caller's batched
+ * product), and grad_feat is only used through grad_feat W = sum over out-edges of gsW[v] (gsW = sum_h gW[v,h,:] / S[v,h]) and
+ * grad_feat^T x = g^T xm (the forward's mean of x).  Call order:
+ *   stg_gat_bwd_prepass(S, out, g, g_pre, pack, ...)      pack [N][16] = S | P; g_pre (nullable) = gradient through the fused elu;
+ *                                                         grad_er (nullable) as stg_gat_bwd_factored
+ *   gW = batched g_pre[:, h, :] @ W_h                     (library GEMM, H batches)
+ *   stg_gat_bwd_uniform_edges(...)                        forward CSR: T [E][H], gsW [N][fin]; backward CSR: grad_el [N][H],
+ *                                                         gxa [N][fin] = grad_feat W
+ * When ones_flag is set (a non-finite score) the general unit runs inside the same call instead: it fills grad_feat [N][H D]
+ * and T, gsW / gxa come out 0, and the caller adds grad_feat W (stg_gat_bwd_uniform_gx_fallback, a no-op otherwise) and takes
+ * the weight gradient from grad_feat^T x instead of g^T xm -- both decided on the device (stg_gemm_tn_gated_f32). */
+int stg_gat_bwd_uniform_supported(int32_t H, int32_t D, int32_t fin);
+int stg_gat_bwd_prepass(const float *S, const float *out, const float *g, float *g_pre, float *pack, int32_t N, int32_t H,
+                        int32_t D, float slope, float *grad_er, void *stream);
+int stg_gat_bwd_uniform_edges(const float *A, const float *pack, const float *gq, const float *feat, const float *x,
+                              const float *gW, float *T, float *gsW, float *grad_feat, float *grad_el, float *gxa,
+                              const int32_t *fwd_row_offsets, const int32_t *fwd_column_indices, const int32_t *fwd_eids,
+                              const int32_t *fwd_node_ids, const int32_t *bwd_row_offsets, const int32_t *bwd_column_indices,
+                              const int32_t *bwd_eids, const int32_t *bwd_node_ids, int32_t N, float slope,
+                              const int32_t *ones_flag, void *stream);
+int stg_gat_bwd_uniform_gx_fallback(const float *grad_feat, const float *W, float *gx, int32_t N, const int32_t *ones_flag,
+                                    void *stream);
 int stg_gat_bwd_er(const float *T, float *grad_er,
                    const int32_t *row_offsets, const int32_t *eids, const int32_t *node_ids,
                    int32_t N, int32_t H, int32_t H_active, void *stream);
@@ -516,6 +541,11 @@ size_t stg_gemm_tn_workspace_bytes(int64_t K, int32_t M, int32_t N);
 int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t K, int32_t M, int32_t N,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* stg_gemm_tn_f32 decided on the device: the launch (slabs and reduction) runs only if *gate == 0 (gate_when = 1) or only if
+ * *gate != 0 (gate_when = 2) and leaves C alone otherwise.  Two calls on the same word, one of each kind, with the same C: the
+ * product that applies is chosen without a host read (inside a HIP graph too).  Workspace: stg_gemm_tn_workspace_bytes. */
+int stg_gemm_tn_gated_f32(const float *A, const float *B, float *C, int64_t K, int32_t M, int32_t N, void *workspace,
+                          size_t workspace_bytes, const int32_t *gate, int gate_when, void *stream);
 /* Same, additionally colsum_A[m] = sum_k A[k][m] (the bias gradient that goes with the weight
  * gradient) from one extra MFMA per k-pair; colsum_A [dev, M floats]. */
 int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *colsum_A, int64_t K, int32_t M,

@@ -594,12 +594,16 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_h8d64_kernel(
     const float *__restrict__ A, const float *__restrict__ pack, const float *__restrict__ g,
     const float *__restrict__ feat, float *__restrict__ grad_feat, float *__restrict__ grad_el,
     float *__restrict__ T, const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
-    const int *__restrict__ eids, const int *__restrict__ node_ids, int N, float slope, const int *__restrict__ flag)
+    const int *__restrict__ eids, const int *__restrict__ node_ids, int N, float slope, const int *__restrict__ flag,
+    int unless_uniform)
 {
     constexpr int H = 8, HD = 512, U = UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
-    const RowInfo ri = row_prologue<6>(row_offsets, node_ids, N);
     const bool ones = all_ones(flag);
+    // unless_uniform: the launch of the uniform-attention backward (gat_ubwd_* below) that stands in when some score is not
+    // finite -- nothing to do otherwise; T (required then) carries the grad_el terms to the pass that sums them
+    if (unless_uniform && ones) return;
+    const RowInfo ri = row_prologue<6>(row_offsets, node_ids, N);
     float a13[2][4], fu[2][4];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
@@ -673,10 +677,192 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_h8d64_kernel(
         }
     }
     if (ri.valid) {
-        if (lane < H) grad_el[(int64_t)ri.r * H + lane] = gel;
+        if (lane < H && !unless_uniform) grad_el[(int64_t)ri.r * H + lane] = gel;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) vec_store<4>(grad_feat + (int64_t)ri.r * HD + ch * 256 + lane * 4, a13[ch]);
     }
+}
+
+// ----------------------------------------- K2 in the uniform-attention form, H = 8 heads of D = 64 over fin = 64 inputs
+// With every A = 1.0f (all_ones) and feat = x W^T the backward unit needs no row of width H D per EDGE:
+//   * the per-edge dot product of T is  g[v,h,:] . feat[u,h,:] = (W_h^T g[v,h,:]) . x[u,:] = gW[v,h,:] . x[u,:]  -- gW [H][N][fin]
+//     is one block-diagonal product per vertex (the caller's batched GEMM), and an edge gathers x[u] (256 bytes) instead of
+//     g[v] (2 KB): a pass over the FORWARD CSR (one wave per target v, gW[v] in registers) writes T[eid, 0..7];
+//   * grad_feat is only ever used through  grad_feat W = A_hat^T (gs W)  and  grad_feat^T x = g^T xm  (xm = the forward's
+//     mean of x over the in-edges, gs = g / S): gsW[v,:] = sum_h gW[v,h,:] / S[v,h] leaves the same pass, and a pass over
+//     the BACKWARD CSR sums gsW over a source's out-edges (256 bytes per edge) and T into grad_el (32 bytes per edge).
+// 16.4 GB of gathered g rows (2.53 ms) become 2 x 2 GB + 0.5 GB of T.  The regrouped dot product is the same sum in another
+// order (the reference adds these terms with atomicAdd in no order at all: tests to 1e-4 as for the factored form).
+__device__ __forceinline__ float row16_sum_all(float v)     // every lane of the DPP row gets the row's sum (row_ror 8, 4, 2, 1)
+{
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+// forward CSR: rows = targets v, columns = sources u.  A wave owns a target and takes its in-edges 16 at a time as ONE small
+// product on the fp32 matrix instruction: D[edge][head] = X[16 edges][64] . gW[v][64][8 heads (of 16 columns)], sixteen
+// v_mfma_f32_16x16x4_f32.  Lane (i = lane & 15, kq = lane >> 4) loads x[u_i][16 j + 4 kq .. + 3] (four 16-byte loads: the 256
+// bytes of a row over its four kq lanes) and, as the B operand, gW[h = i][v] at the same columns -- the k index is permuted the
+// same way on both sides, which a sum over k does not see.  (As vector FMAs with DPP row sums the same pass took 0.62 ms: 82
+// instruction cycles per edge against ~ 37 here.)  If some score is not finite (flag set) the launch only zeroes gsW[v]: the
+// general kernel (unless_uniform) writes T, and the row sums below then add nothing to gx.
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+
+template <int U>
+__global__ __launch_bounds__(kBlock) void gat_ubwd_t_kernel(
+    const float *__restrict__ gW, const float *__restrict__ pack, const float *__restrict__ x, float *__restrict__ T,
+    float *__restrict__ gsW, const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
+    const int *__restrict__ eids, const int *__restrict__ node_ids, int N, float slope, const int *__restrict__ flag)
+{
+    constexpr int H = 8, FIN = 64;
+    const int lane = threadIdx.x & (kWave - 1), i16 = lane & 15, kq = lane >> 4;
+    const RowInfo ri = row_prologue<6>(row_offsets, node_ids, N);
+    if (!all_ones(flag)) {
+        if (ri.valid && lane < 16) *reinterpret_cast<float4 *>(gsW + (int64_t)ri.r * FIN + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    float bw[4][4];                                  // B operand: head i16 (zeros for i16 >= 8), columns 16 j + 4 kq + comp
+    float pv = 0.f, inv = 1.f, sv = 1.f;             // head i16 of this target
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bw[j][q] = 0.f;
+    if (ri.valid && i16 < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vec_load<4>(bw[j], gW + ((int64_t)i16 * N + ri.r) * FIN + 16 * j + 4 * kq);
+        sv = pack[(int64_t)ri.r * 16 + i16];
+        pv = pack[(int64_t)ri.r * 16 + 8 + i16];
+        inv = 1.0f / sv;
+    }
+    if (ri.valid) {
+        // gsW[v, k] = sum_h gW[h, v, k] / S[v, h]  (alpha = A / S with A = 1: the unit's division): the heads are the lanes of a DPP row
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = row16_sum_all(bw[j][q] / sv);
+            if (i16 == 0) vec_store<4>(gsW + (int64_t)ri.r * FIN + 16 * j + 4 * kq, o);
+        }
+    }
+    for (int base = 0; base < ri.max_deg; base += kWave) {
+        const int cnt = ri.deg - base;
+        const int cnt_max = min(kWave, ri.max_deg - base);
+        int cidx = 0, ev = 0;
+        if (lane < cnt) {
+            cidx = column_indices[ri.beg + base + lane];
+            ev = eids[ri.beg + base + lane];
+        }
+        for (int k = 0; k < cnt_max; k += 16 * U) {
+            float xv[U][4][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = k + 16 * u + i16;                              // this lane's edge of the group (source 0 past the last: a valid row)
+                const int ck = __builtin_amdgcn_ds_bpermute((kk & (kWave - 1)) * 4, cidx);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vec_load<4>(xv[u][j], x + (int64_t)ck * FIN + 16 * j + 4 * kq);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k + 16 * u >= cnt_max) break;                             // wave-uniform
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][j][q], bw[j][q], acc, 0, 0, 0);
+                // acc[r] = (edge 4 kq + r of the group) . (head i16)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = k + 16 * u + 4 * kq + r;
+                    const int ek = __builtin_amdgcn_ds_bpermute((kk & (kWave - 1)) * 4, ev);
+                    const float tv = ((acc[r] * inv - pv) * 1.0f) * slope;   // the unit's term with A = 1.0f
+                    if (kk < cnt && i16 < H) T[(int64_t)ek * H + i16] = tv;
+                }
+            }
+        }
+    }
+}
+
+// backward CSR: rows = sources u, columns = targets v.  grad_el[u, h] = sum over u's out-edges of T[eid, h];
+// gxa[u, :] = sum over them of gsW[v, :] (= grad_feat[u] W, see above).  Four edges at a time, one per DPP row.
+template <int U>
+__global__ __launch_bounds__(kBlock) void gat_ubwd_src_kernel(
+    const float *__restrict__ T, const float *__restrict__ gsW, float *__restrict__ grad_el, float *__restrict__ gxa,
+    const int *__restrict__ row_offsets, const int *__restrict__ column_indices, const int *__restrict__ eids,
+    const int *__restrict__ node_ids, int N)
+{
+    constexpr int H = 8, FIN = 64;
+    const int lane = threadIdx.x & (kWave - 1), slot = lane >> 4, c = lane & 15;
+    const RowInfo ri = row_prologue<6>(row_offsets, node_ids, N);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float tacc = 0.f;                                // lanes c < 8: head c
+    for (int base = 0; base < ri.max_deg; base += kWave) {
+        const int cnt = ri.deg - base;
+        const int cnt_max = min(kWave, ri.max_deg - base);
+        int cidx = 0, ev = 0;
+        if (lane < cnt) {
+            cidx = column_indices[ri.beg + base + lane];
+            ev = eids[ri.beg + base + lane];
+        }
+        for (int k = 0; k < cnt_max; k += 4 * U) {
+            float gv[U][4], tv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = k + 4 * u + slot;
+                const int ck = __builtin_amdgcn_ds_bpermute((kk & (kWave - 1)) * 4, cidx);
+                const int ek = __builtin_amdgcn_ds_bpermute((kk & (kWave - 1)) * 4, ev);
+                const bool ok = kk < cnt;
+                vec_load<4>(gv[u], gsW + (int64_t)ck * FIN + 4 * c);
+                tv[u] = T[(int64_t)ek * H + (c & 7)];
+                if (!ok) {
+                    tv[u] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[u][i] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                tacc = tacc + tv[u];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = acc[i] + gv[u][i];
+            }
+        }
+    }
+    // the four DPP rows' partial sums: rows 0 + 2 and 1 + 3, then the pair
+    tacc = tacc + __shfl_xor(tacc, 32, kWave);
+    tacc = tacc + __shfl_xor(tacc, 16, kWave);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[i] = acc[i] + __shfl_xor(acc[i], 32, kWave);
+        acc[i] = acc[i] + __shfl_xor(acc[i], 16, kWave);
+    }
+    if (ri.valid && slot == 0) {
+        if (c < H) grad_el[(int64_t)ri.r * H + c] = tacc;
+        vec_store<4>(gxa + (int64_t)ri.r * FIN + 4 * c, acc);
+    }
+}
+
+// the stand-in's input gradient when some score is not finite: gx[u, :] += gf[u, :] W  (W [512][64]; a wave per row; rare and
+// mostly NaN by then, so plain FMAs)
+__global__ __launch_bounds__(kBlock) void gat_ubwd_gx_fallback_kernel(const float *__restrict__ gf, const float *__restrict__ W,
+                                                                      float *__restrict__ gx, int N, const int *__restrict__ flag)
+{
+    if (all_ones(flag)) return;
+    constexpr int HD = 512, FIN = 64;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= N) return;
+    float acc = gx[(int64_t)r * FIN + lane];
+    for (int j0 = 0; j0 < HD; j0 += kWave) {
+        const float gvl = gf[(int64_t)r * HD + j0 + lane];
+        for (int j = 0; j < kWave; ++j) {
+            const float gj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gvl), j));
+            acc = __builtin_fmaf(gj, W[(int64_t)(j0 + j) * FIN + lane], acc);
+        }
+    }
+    gx[(int64_t)r * FIN + lane] = acc;
 }
 
 // -------------------------------------------------------------------------- bwd_er
@@ -915,7 +1101,7 @@ int bwd_factored(const char *what, const float *A, const float *S, const float *
         hipLaunchKernelGGL(gat_bwd_prepass_h8d64_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)),
                            dim3(kBlock), 0, st, S, out, g, P, N, grad_er, slope, g_pre);
         hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, P, gq, feat,
-                           grad_feat, grad_el, T, row_offsets, column_indices, eids, node_ids, N, slope, ones_flag);
+                           grad_feat, grad_el, T, row_offsets, column_indices, eids, node_ids, N, slope, ones_flag, 0);
         return check_launch(what);
     }
 #define STG_K2F(VEC, CH, UN, P2)                                                                           \
@@ -972,6 +1158,64 @@ extern "C" int stg_gat_bwd_factored_elu(const float *A, const float *S, const fl
     if (!g_pre) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_factored_elu: NULL g_pre");
     return stg::bwd_factored("stg_gat_bwd_factored_elu", A, S, out, g_act, g_pre, feat, grad_feat, grad_el, T, P,
                              row_offsets, column_indices, eids, node_ids, N, H, D, slope, grad_er, ones_flag, stream);
+}
+
+// ---- K2 in the uniform-attention form (gat_ubwd_* kernels above): H = 8, D = 64, fin = 64 ------------------------------------------
+extern "C" int stg_gat_bwd_uniform_supported(int32_t H, int32_t D, int32_t fin) { return H == 8 && D == 64 && fin == 64 ? 1 : 0; }
+
+extern "C" int stg_gat_bwd_prepass(const float *S, const float *out, const float *g, float *g_pre, float *pack, int32_t N,
+                                   int32_t H, int32_t D, float slope, float *grad_er, void *stream)
+{
+    using namespace stg;
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_prepass: negative N");
+    if (H != 8 || D != 64) return fail(STG_ERR_UNSUPPORTED, "stg_gat_bwd_prepass: H = 8, D = 64 only (got %d, %d)", H, D);
+    if (N == 0) return 0;
+    if (!S || !out || !g || !pack) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_prepass: NULL pointer argument");
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(g_pre)) % 16 != 0)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_prepass: out, g and g_pre must be 16-byte aligned");
+    hipLaunchKernelGGL(gat_bwd_prepass_h8d64_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), S, out, g, pack, N, grad_er, slope, g_pre);
+    return check_launch("stg_gat_bwd_prepass");
+}
+
+extern "C" int stg_gat_bwd_uniform_edges(const float *A, const float *pack, const float *gq, const float *feat, const float *x,
+                                         const float *gW, float *T, float *gsW, float *grad_feat, float *grad_el, float *gxa,
+                                         const int32_t *fwd_row_offsets, const int32_t *fwd_column_indices, const int32_t *fwd_eids,
+                                         const int32_t *fwd_node_ids, const int32_t *bwd_row_offsets,
+                                         const int32_t *bwd_column_indices, const int32_t *bwd_eids, const int32_t *bwd_node_ids,
+                                         int32_t N, float slope, const int32_t *ones_flag, void *stream)
+{
+    using namespace stg;
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_uniform_edges: negative N");
+    if (N == 0) return 0;
+    if (!A || !pack || !gq || !feat || !x || !gW || !T || !gsW || !grad_feat || !grad_el || !gxa || !fwd_row_offsets ||
+        !fwd_column_indices || !fwd_eids || !bwd_row_offsets || !bwd_column_indices || !bwd_eids || !ones_flag)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_uniform_edges: NULL pointer argument");
+    if ((reinterpret_cast<uintptr_t>(gq) | reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(x) |
+         reinterpret_cast<uintptr_t>(gW) | reinterpret_cast<uintptr_t>(gsW) | reinterpret_cast<uintptr_t>(grad_feat) |
+         reinterpret_cast<uintptr_t>(gxa)) % 16 != 0)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_uniform_edges: matrices must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // every score finite: T and gsW from the pass over the targets; otherwise gsW = 0 and the general unit writes T and grad_feat
+    hipLaunchKernelGGL(gat_ubwd_t_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, gW, pack, x, T, gsW, fwd_row_offsets,
+                       fwd_column_indices, fwd_eids, fwd_node_ids, N, slope, ones_flag);
+    hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, pack, gq, feat, grad_feat, grad_el,
+                       T, bwd_row_offsets, bwd_column_indices, bwd_eids, bwd_node_ids, N, slope, ones_flag, 1);
+    hipLaunchKernelGGL(gat_ubwd_src_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, T, gsW, grad_el, gxa, bwd_row_offsets,
+                       bwd_column_indices, bwd_eids, bwd_node_ids, N);
+    return check_launch("stg_gat_bwd_uniform_edges");
+}
+
+extern "C" int stg_gat_bwd_uniform_gx_fallback(const float *grad_feat, const float *W, float *gx, int32_t N, const int32_t *ones_flag,
+                                               void *stream)
+{
+    using namespace stg;
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_uniform_gx_fallback: negative N");
+    if (N == 0) return 0;
+    if (!grad_feat || !W || !gx || !ones_flag) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_bwd_uniform_gx_fallback: NULL pointer argument");
+    hipLaunchKernelGGL(gat_ubwd_gx_fallback_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), grad_feat, W, gx, N, ones_flag);
+    return check_launch("stg_gat_bwd_uniform_gx_fallback");
 }
 
 extern "C" int stg_gat_bwd_er(const float *T, float *grad_er, const int32_t *row_offsets,

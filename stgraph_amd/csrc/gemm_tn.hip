@@ -49,7 +49,17 @@ struct GemmForm {
     int a_mask;                          // 1: A is taken as A * [am > 0] -- the backward of a ReLU applied while loading:
                                          // dW = (g * [out > 0])^T X and its column sums (the bias gradient) in one launch,
                                          // the masked gradient never written
+    const int *gate;                     // gate_when 1: the launch (slabs and reduction) does nothing unless *gate == 0; 2: unless
+    int gate_when;                       // *gate != 0.  Two products gated on the same word, one of each kind, write the same C:
+                                         // which one is decided on the device (stg_gemm_tn_gated_f32)
 };
+
+__device__ __forceinline__ bool gemm_gated_off(const int *gate, int when)
+{
+    if (when == 0 || gate == nullptr) return false;
+    const bool zero = __builtin_amdgcn_readfirstlane(*gate) == 0;
+    return when == 1 ? !zero : zero;
+}
 
 // MT = 32-row M tiles per wave: every B dword a wave loads feeds MT MFMAs and every A dword NT of them.  With MT = 1
 // a k-pair costs 1 + NT dword loads for NT MFMAs; the kernel then runs at the rate the texture addresser issues
@@ -60,6 +70,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_tn_partial_kernel(
     const GemmSegs segs, const GemmForm form, float *__restrict__ slab, int64_t K, int M, int N, int64_t kslice_wave,
     int m_groups, int n_groups, int s_per_seg)
 {
+    if (gemm_gated_off(form.gate, form.gate_when)) return;
     extern __shared__ float lds[];                       // one wave's accumulators: (MT * NT) x 16 x 64 floats (+ 64 * MT)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -312,6 +323,7 @@ __global__ __launch_bounds__(kBlock, MINW) void gemm_tn_wide_kernel(
     const GemmSegs segs, const GemmForm form, float *__restrict__ slab, int64_t K, int M, int N, int64_t kslice_wave,
     int m_groups, int n_groups, int s_per_seg, int cyclic_flags)
 {
+    if (gemm_gated_off(form.gate, form.gate_when)) return;
     constexpr int TA = WA * CA, TB = WB * CB;
     static_assert(TA * TB <= 32, "accumulator tiles per wave");
     extern __shared__ float lds[];                       // one wave's accumulators: TA x TB x 4 x 64 floats (+ TA x 64)
@@ -519,8 +531,10 @@ __global__ __launch_bounds__(kBlock, MINW) void gemm_tn_wide_kernel(
 // flight each) and are combined in wave order through LDS -- fixed order, deterministic.
 __global__ __launch_bounds__(kBlock) void gemm_tn_reduce_kernel(const float *__restrict__ slab,
                                                                 float *__restrict__ C, float *__restrict__ CS,
-                                                                int64_t MNc, int64_t MN, int S)
+                                                                int64_t MNc, int64_t MN, int S, const int *__restrict__ gate = nullptr,
+                                                                int gate_when = 0)
 {
+    if (gemm_gated_off(gate, gate_when)) return;
     __shared__ float part[kWavesPerBlock][kWave];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = threadIdx.x >> 6;
@@ -787,7 +801,7 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
             return check_launch(what);
         }
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MNc + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
-                           slab, C, colsum, MNc, MN, S_total);
+                           slab, C, colsum, MNc, MN, S_total, form.gate, form.gate_when);
         return check_launch(what);
     }
     const size_t lds = ((size_t)p.mt * p.nt * 16 + p.mt) * kWave * sizeof(float);
@@ -816,7 +830,7 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         return check_launch(what);
     }
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MNc + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
-                       slab, C, colsum, MNc, MN, S_total);
+                       slab, C, colsum, MNc, MN, S_total, form.gate, form.gate_when);
     return check_launch(what);
 }
 }  // namespace
@@ -826,6 +840,17 @@ extern "C" int stg_gemm_tn_f32(const float *A, const float *B, float *C, int64_t
                                void *workspace, size_t workspace_bytes, void *stream)
 {
     return stg::gemm_tn_run(&A, &B, 1, C, nullptr, K, M, N, workspace, workspace_bytes, stream, "stg_gemm_tn_f32");
+}
+
+extern "C" int stg_gemm_tn_gated_f32(const float *A, const float *B, float *C, int64_t K, int32_t M, int32_t N, void *workspace,
+                                     size_t workspace_bytes, const int32_t *gate, int gate_when, void *stream)
+{
+    using namespace stg;
+    if (!gate || (gate_when != 1 && gate_when != 2))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_gated_f32: gate [dev] and gate_when 1 (run if *gate == 0) or 2 (run if != 0)");
+    if (K <= 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_gated_f32: K must be positive");
+    GemmForm form{M, N, 0, N, STG_GEMM_B_NONE, 0.f, 0.f, 0, gate, gate_when};
+    return gemm_tn_run(&A, &B, 1, C, nullptr, K, M, N, workspace, workspace_bytes, stream, "stg_gemm_tn_gated_f32", nullptr, &form);
 }
 
 extern "C" int stg_gemm_tn_colsum_f32(const float *A, const float *B, float *C, float *colsum_A, int64_t K,

@@ -1026,6 +1026,7 @@ def gat_fwd_uniform(x: torch.Tensor, W: torch.Tensor, el: torch.Tensor, er: torc
             _C.check(_C.lib.stg_gat_fwd_k1_scored(_ptr(A), _ptr(S), _ptr(feat), _ptr(out), _ptr(act), _ptr(csr.row_offset),
                                                   _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, D, _ptr(flag), st))
     A._stg_ones = flag
+    A._stg_xm = xm                                     # the in-neighbour mean of x (valid unless *flag): gat_bwd_uniform's g^T xm
     return out, act, A, S
 
 
@@ -1108,6 +1109,87 @@ def gat_bwd(A, S, out, g, el, er, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: f
             _C.check(_C.lib.stg_gat_bwd_er(_ptr(T), _ptr(grad_er), _ptr(fwd.row_offset), _ptr(fwd.eids),
                                            _ptr(fwd.node_ids_if_ready if use_node_ids else None), N, H, h_touched, st))
     return grad_feat, grad_el, grad_er
+
+
+_GAT_UNIFORM_BWD = os.environ.get("STGRAPH_AMD_GAT_UNIFORM_BWD", "1") != "0"
+
+
+def set_gat_uniform_backward(on: bool) -> None:
+    """False: the fused GATConv's backward unit gathers rows of width H * D per edge (stg_gat_bwd_factored) also when the forward
+    ran in the uniform-attention form."""
+    global _GAT_UNIFORM_BWD
+    _GAT_UNIFORM_BWD = bool(on)
+
+
+def gat_bwd_uniform_usable(A: torch.Tensor, x: torch.Tensor, H: int, D: int) -> bool:
+    """``A`` from :func:`gat_fwd_uniform` (it carries the flag and the mean of x), shapes of stg_gat_bwd_uniform_supported."""
+    return (_GAT_UNIFORM_BWD and _GAT_FACTORED and _GAT_REGROUPED_ER and getattr(A, "_stg_ones", None) is not None
+            and getattr(A, "_stg_xm", None) is not None and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+            and x.data_ptr() % 16 == 0 and active_columns(H) == H and active_columns(H * D) == H * D
+            and bool(_C.lib.stg_gat_bwd_uniform_supported(int(H), int(D), int(x.shape[1]))))
+
+
+def gat_bwd_uniform(A, S, out, g, x, W, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: float, use_node_ids: bool = False,
+                    elu: bool = False):
+    """The backward unit K2 of a layer that ran :func:`gat_fwd_uniform`, without a gather of width H * D per edge
+    (include/stgraph_hip.h, stg_gat_bwd_uniform_edges).  Returns ``(gxa, grad_el, grad_er, gq, grad_feat, flag, xm)``:
+    ``gxa`` [N, fin] = grad_feat @ W when every score is finite (0 otherwise: add grad_feat @ W with
+    :func:`gat_bwd_uniform_gx_fallback`), ``gq`` the gradient of the pre-activation ``out`` (the weight gradient is ``gq^T xm``
+    -- or ``grad_feat^T x`` when the flag is set: :func:`gemm_tn_gated`), ``grad_feat`` [N, H, D] only written in that case."""
+    feat = _f32(feat, "feat_src")
+    dev = feat.device
+    N, H, D = feat.shape
+    fin = int(x.shape[1])
+    A, S, out, g, x, W = (_f32(t, n, dev) for t, n in ((A, "A"), (S, "S"), (out, "out"), (g, "grad_out"), (x, "x"), (W, "fc.weight")))
+    E = bwd.num_edges
+    if (g.shape != feat.shape or out.shape != feat.shape or A.numel() != E * H or S.numel() != N * H or fwd.num_edges != E
+            or bwd.num_nodes != N or tuple(W.shape) != (H * D, fin) or x.shape[0] != N):
+        raise ValueError("gat_bwd_uniform: operands do not match the graph / the layer")
+    flag, xm = A._stg_ones, A._stg_xm
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    pack, grad_er, grad_el = new(N, 16), new(N, H, 1), new(N, H, 1)
+    g_pre = torch.empty_like(g) if elu else None
+    T, gsW, gxa, grad_feat = new(E, H), new(N, fin), new(N, fin), new(N, H, D)
+    idx = 4 * (N + 1) + 8 * E
+    with torch.cuda.device(dev):
+        st = _stream_ptr(dev)
+        with _Timed("gat_bwd_prepass", 4 * N * H * D * (3 if elu else 2) + 4 * N * 16 + 8 * N * H, 4 * N * H * D):
+            _C.check(_C.lib.stg_gat_bwd_prepass(_ptr(S), _ptr(out), _ptr(g), _ptr(g_pre), _ptr(pack), N, H, D, float(slope),
+                                                _ptr(grad_er), st))
+        gq = g_pre if elu else g
+        with _Timed("gat_bwd_gw", 4 * N * H * (D + fin) + 4 * H * D * fin, 2 * N * H * D * fin):
+            gW = torch.bmm(gq.view(N, H, D).transpose(0, 1), W.view(H, D, fin))       # [H, N, fin]: gW[h, v] = W_h^T g[v, h, :]
+        moved = (4 * N * H * fin + 4 * E * fin + 4 * E * H + 4 * N * fin + 4 * N * 16 + idx            # targets: gW, x[u], T, gsW, pack
+                 + 4 * E * H + 4 * E * fin + 4 * N * (fin + H) + idx)                                   # sources: T, gsW[v], grad_el, gxa
+        with _Timed("gat_bwd_uniform", moved, 2 * E * H * fin):
+            _C.check(_C.lib.stg_gat_bwd_uniform_edges(
+                _ptr(A), _ptr(pack), _ptr(gq), _ptr(feat), _ptr(x), _ptr(gW), _ptr(T), _ptr(gsW), _ptr(grad_feat), _ptr(grad_el),
+                _ptr(gxa), _ptr(fwd.row_offset), _ptr(fwd.column_indices), _ptr(fwd.eids),
+                _ptr(fwd.node_ids_if_ready if use_node_ids else None), _ptr(bwd.row_offset), _ptr(bwd.column_indices),
+                _ptr(bwd.eids), _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, float(slope), _ptr(flag), st))
+    return gxa, grad_el, grad_er, gq, grad_feat, flag, xm
+
+
+def gat_bwd_uniform_gx_fallback(grad_feat: torch.Tensor, W: torch.Tensor, gx: torch.Tensor, flag: torch.Tensor) -> None:
+    """``gx += grad_feat @ W`` in place when ``*flag`` is set (a non-finite score); a launch that returns at once otherwise."""
+    N = int(gx.shape[0])
+    with torch.cuda.device(gx.device):
+        _C.check(_C.lib.stg_gat_bwd_uniform_gx_fallback(_ptr(grad_feat), _ptr(W), _ptr(gx), N, _ptr(flag), _stream_ptr(gx.device)))
+
+
+def gemm_tn_gated(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, gate: torch.Tensor, run_if_zero: bool) -> None:
+    """``c = a.T @ b`` only if ``*gate == 0`` (``run_if_zero``) / only if ``*gate != 0``; ``c`` is left alone otherwise
+    (stg_gemm_tn_gated_f32).  Two calls on the same word, one of each kind, fill ``c`` whichever way the device decides."""
+    a, b = _f32(a, "a"), _f32(b, "b", a.device)
+    K, M = a.shape
+    N = int(b.shape[1])
+    if b.shape[0] != K or tuple(c.shape) != (M, N) or not c.is_contiguous() or c.dtype != torch.float32:
+        raise ValueError("gemm_tn_gated: a [K, M], b [K, N], c [M, N] contiguous fp32")
+    ws_bytes = int(_C.lib.stg_gemm_tn_workspace_bytes(K, M, N))
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device), _Timed("gemm_tn", 4 * K * (M + N) + 4 * M * N, 2 * K * M * N):
+        _C.check(_C.lib.stg_gemm_tn_gated_f32(_ptr(a), _ptr(b), _ptr(c), K, M, N, _ptr(ws), ws_bytes, _ptr(gate),
+                                              1 if run_if_zero else 2, _stream_ptr(a.device)))
 
 
 # ------------------------------------------------------- dense neighbour: weight gradient

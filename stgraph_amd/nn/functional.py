@@ -581,6 +581,8 @@ class _GatFcLayer(torch.autograd.Function):
     def backward(ctx, g):
         x, w, feat, attn_l, attn_r, el, er, A, S, out = ctx.saved_tensors
         fwd_csr, bwd_csr = ctx.csrs
+        if _GAT_PROJ_FOLD and kernels.gat_bwd_uniform_usable(A, x, feat.shape[1], feat.shape[2]):
+            return _GatFcLayer._backward_uniform(ctx, g)
         gf, gel, ger = kernels.gat_bwd(A, S, out, g.contiguous(), el, er, feat, fwd_csr, bwd_csr, ctx.slope, ctx.use_nid,
                                        elu=ctx.elu)
         small = None
@@ -623,6 +625,38 @@ class _GatFcLayer(torch.autograd.Function):
                 if small is not None:
                     gw = gw + small
         return gx, gw, dal.view_as(attn_l), dar.view_as(attn_r), None, None, None, None, None, None, None
+
+
+def _gat_backward_uniform(ctx, g):
+    """_GatFcLayer.backward when the forward ran in the uniform-attention form at the shapes of stg_gat_bwd_uniform_edges: the
+    backward unit gathers x (width fin) and per-vertex products of g with W instead of g rows of width H * D per edge, and what
+    grad_feat was needed for comes from  grad_feat W = A_hat^T (gs W)  and  grad_feat^T x = g^T xm.  The attention projections'
+    terms at width H as in backward().  A device flag (a non-finite score) switches every step to the general unit's results."""
+    x, w, feat, attn_l, attn_r, el, er, A, S, out = ctx.saved_tensors
+    fwd_csr, bwd_csr = ctx.csrs
+    N, fin = x.shape
+    H, D = feat.shape[1], feat.shape[2]
+    gxa, gel, ger, gq, gf, flag, xm = kernels.gat_bwd_uniform(A, S, out, g.contiguous(), x, w, feat, fwd_csr, bwd_csr, ctx.slope,
+                                                                ctx.use_nid, elu=ctx.elu)
+    ge = torch.cat([gel.view(N, H), ger.view(N, H)], 1)
+    G = kernels.gemm_tn(ge, x) if _use_native(x, N, 2 * H, fin) else torch.mm(ge.t(), x)
+    Wh = w.view(H, D, fin)
+    al, ar = attn_l.reshape(H, D), attn_r.reshape(H, D)
+    dal, dar = torch.einsum("hdf,hf->hd", Wh, G[:H]), torch.einsum("hdf,hf->hd", Wh, G[H:])
+    gx = gw = None
+    if ctx.needs_input_grad[0]:
+        Aw = torch.cat([torch.einsum("hdf,hd->hf", Wh, al), torch.einsum("hdf,hd->hf", Wh, ar)], 0)
+        gx = torch.addmm(gxa, ge, Aw)
+        kernels.gat_bwd_uniform_gx_fallback(gf, w, gx, flag)
+    if ctx.needs_input_grad[1]:
+        gw = torch.empty(H * D, fin, dtype=torch.float32, device=x.device)
+        kernels.gemm_tn_gated(gq.view(N, H * D), xm, gw, flag, True)         # every score finite: g^T (mean of x over in-edges)
+        kernels.gemm_tn_gated(gf.view(N, H * D), x, gw, flag, False)         # otherwise: the general unit's grad_feat^T x
+        gw += (al.unsqueeze(2) * G[:H].unsqueeze(1) + ar.unsqueeze(2) * G[H:].unsqueeze(1)).reshape(H * D, fin)
+    return gx, gw, dal.view_as(attn_l), dar.view_as(attn_r), None, None, None, None, None, None, None
+
+
+_GatFcLayer._backward_uniform = staticmethod(_gat_backward_uniform)
 
 
 def gat_fc_layer_usable(graph, x: torch.Tensor, fc, H: int, D: int) -> bool:

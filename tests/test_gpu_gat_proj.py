@@ -261,3 +261,63 @@ def test_projection_backward_at_width_H_equals_the_full_width_one(cuda, fin, H, 
     for a, b, name in zip(res[0], res[1], ("x", "attn_l", "attn_r", "fc.weight")):
         atol = 5e-5 if name == "attn_r" else 1e-5 * float(b.abs().max() + 1)      # attn_r: rounding noise around 0 (see above)
         torch.testing.assert_close(a, b, rtol=1e-4, atol=atol, msg=lambda m, nm=name: f"{nm}: {m}")
+
+
+@pytest.mark.parametrize("act", ["elu", "none"])
+@pytest.mark.parametrize("bad", [False, True])
+def test_uniform_backward_unit_equals_the_factored_one(cuda, act, bad):
+    """The backward of the uniform-attention layer at H = 8, D = 64, fin = 64 without a gather of width H * D per edge
+    (stg_gat_bwd_uniform_edges: x gathered against per-vertex products of g with W, grad_feat only through grad_feat W and
+    g^T xm) against the factored unit: every gradient.  `bad`: one non-finite input row sets the device flag -- every step
+    then takes the general unit's results (grad_feat, T) through the gated launches, NaNs in the same places."""
+    import torch.nn.functional as F
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
+    fin, H, D, n, e = 64, 8, 64, 70_003, 700_000
+    src, dst = random_graph(23, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    torch.manual_seed(8)
+    conv = GATConv(fin, D, H, activation=F.elu if act == "elu" else None).to(cuda)
+    x0 = torch.randn(n, fin, device=cuda)
+    if bad:
+        x0[int(src[5]), 3] = float("inf")
+    R = torch.randn(n, H, D, device=cuda)
+    res = []
+    for on in (True, False):
+        kernels.set_gat_uniform_backward(on)
+        try:
+            rec = []
+            kernels.enable_launch_timing(rec)
+            conv.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            out = conv(g, x)
+            out.backward(R)
+        finally:
+            kernels.enable_launch_timing(None)
+            kernels.set_gat_uniform_backward(True)
+        names = {r[0] for r in rec}
+        assert ("gat_bwd_uniform" in names) == on and ("gat_bwd" in names) == (not on), names
+        res.append((out.detach().clone(), x.grad.clone(), conv.attn_l.grad.clone(), conv.attn_r.grad.clone(),
+                    conv.fc.weight.grad.clone()))
+    assert torch.equal(res[0][0].isnan(), res[1][0].isnan()) and bool(res[0][0].isnan().any()) == bad
+    for a, b, name in zip(res[0], res[1], ("out", "x", "attn_l", "attn_r", "fc.weight")):
+        assert torch.equal(a.isnan(), b.isnan()), name
+        fin_b = b[~b.isnan()]
+        atol = 5e-5 if name == "attn_r" else 2e-5 * float(fin_b.abs().max() + 1 if fin_b.numel() else 1)
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=atol, equal_nan=True, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_gated_contraction_runs_on_the_device_word(cuda):
+    """stg_gemm_tn_gated_f32: of two products gated on the same word, one of each kind, exactly one writes C."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    a1, b1 = torch.randn(70_000, 512, device=cuda, generator=gen), torch.randn(70_000, 64, device=cuda, generator=gen)
+    a2, b2 = torch.randn(70_000, 512, device=cuda, generator=gen), torch.randn(70_000, 64, device=cuda, generator=gen)
+    for word in (0, 1):
+        gate = torch.full((1,), word, dtype=torch.int32, device=cuda)
+        c = torch.full((512, 64), 7.0, device=cuda)
+        kernels.gemm_tn_gated(a1, b1, c, gate, True)
+        kernels.gemm_tn_gated(a2, b2, c, gate, False)
+        want = kernels.gemm_tn(a2, b2) if word else kernels.gemm_tn(a1, b1)
+        assert torch.equal(c, want)
