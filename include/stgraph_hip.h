@@ -34,7 +34,7 @@ extern "C" {
  *      the step launches optional; stg_tgcn_unfold_gate_grads.
  *  25: stg_rowgemm_act_bits_f32, stg_rowgemm_bits_words, stg_rowgemm_bits_supported: a ReLU layer's sign pattern as bits;
  *      stg_xent_fwd_grad, stg_xent_scale_grad: cross-entropy forward and gradient in one pass; stg_gat_bwd_uniform_*,
- *      stg_gat_bwd_prepass, stg_gemm_tn_gated_f32: the GAT backward unit in the uniform-attention form. */
+ *      stg_gat_bwd_prepass, stg_gemm_tn_gated_f32, stg_rowgemm_heads_f32: the GAT backward unit in the uniform-attention form. */
 #define STG_ABI_VERSION 25
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -605,6 +605,11 @@ int stg_rowgemm_act_f32(const float *X, const float *W, const float *bias, float
  * 8 (col >> 5) + 4 ((row >> 3) & 1) + (col & 3) of word 64 (row >> 4) + (row & 7) + 8 ((col >> 4) & 1) + 16 ((col >> 2) & 3) -- the
  * arrangement in which a lane of the kernel holds its 32 outputs of a 16-row tile.  Always the 3-term bf16 split on the matrix
  * cores; stg_rowgemm_bits_supported: K, M in {64, 128}, N K and N M < 2^30, knob "rowgemm_x3" neither 1 nor 3. */
+/* Y [heads][N][M]: Y_h = X[:, h K : (h + 1) K] W_h for the column blocks of X [N, heads K] and W [heads][K][M] -- the per-head
+ * products of a multi-head layer's gradient with its fc weight (GATConv: g[:, h, :] W_h, stg_gat_bwd_uniform_edges' gW) as
+ * `heads` launches of the split-form row product; K, M in {64, 128}, N heads K < 2^30 (stg_rowgemm_heads_supported). */
+int stg_rowgemm_heads_supported(int64_t N, int32_t K, int32_t M, int32_t heads);
+int stg_rowgemm_heads_f32(const float *X, const float *W, float *Y, int64_t N, int32_t K, int32_t M, int32_t heads, void *stream);
 size_t stg_rowgemm_bits_words(int64_t N);
 int stg_rowgemm_bits_supported(int64_t N, int32_t K, int32_t M);
 int stg_rowgemm_act_bits_f32(const float *X, const float *W, const float *bias, float *Y, int64_t N, int32_t K, int32_t M,

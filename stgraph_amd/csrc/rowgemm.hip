@@ -324,6 +324,29 @@ extern "C" int stg_rowgemm_act_f32(const float *X, const float *W, const float *
     return rowgemm16_launch<64, 64>(X, W, bias, Y, N, tw, relu, st, M);
 }
 
+// ---- per-head products of a [N, heads K] matrix (rowgemm_x3.hip) ----------------------------------------------------------------
+extern "C" int stg_rowgemm_heads_supported(int64_t N, int32_t K, int32_t M, int32_t heads)
+{
+    using namespace stg;
+    const int mode = tuning().rowgemm_x3;
+    return rowgemm16_shape(K, M) && heads > 0 && N > 0 && N * heads * K < ((int64_t)1 << 30) && mode != 1 && mode != 3 ? 1 : 0;
+}
+
+extern "C" int stg_rowgemm_heads_f32(const float *X, const float *W, float *Y, int64_t N, int32_t K, int32_t M, int32_t heads,
+                                     void *stream)
+{
+    using namespace stg;
+    if (N < 0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_heads_f32: negative N");
+    if (N == 0) return 0;
+    if (!stg_rowgemm_heads_supported(N, K, M, heads))
+        return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_heads_f32: K, M in {64, 128}, N heads K < 2^30 (got N=%lld K=%d M=%d heads=%d)",
+                    (long long)N, K, M, heads);
+    if (!X || !W || !Y) return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_heads_f32: NULL pointer argument");
+    if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Y)) % 16 != 0)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_rowgemm_heads_f32: X, W and Y must be 16-byte aligned");
+    return rowgemm_x3_heads_launch(K, M, X, W, Y, N, heads, stream);
+}
+
 // ---- the ReLU sign pattern as bits (rowgemm_x3.hip) --------------------------------------------------------------------------
 extern "C" size_t stg_rowgemm_bits_words(int64_t N) { return N > 0 ? (size_t)((N + 31) / 32) * 128 : 0; }
 

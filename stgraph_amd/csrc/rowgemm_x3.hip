@@ -69,7 +69,8 @@ __device__ __forceinline__ void mfma6x4(f32x4 &a0, f32x4 &a1, f32x4 &b0, f32x4 &
 template <int K, int M, bool TRANS_W, bool RELU, bool LINES, int BITS = 0>
 __global__ __launch_bounds__(kX3Waves * kWave, 1) void rowgemm_x3_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                                         const float *__restrict__ bias, float *__restrict__ Y,
-                                                                        int64_t N, int num_pairs, int ldy, uint32_t *__restrict__ bits)
+                                                                        int64_t N, int num_pairs, int ldy, uint32_t *__restrict__ bits,
+                                                                        int ldx)
 {
     static_assert(BITS == 0 || LINES, "the bit pattern follows the whole-line arrangement");
     constexpr int KB = K / 32, CT = M / 16, AHEAD = 2;
@@ -93,9 +94,11 @@ __global__ __launch_bounds__(kX3Waves * kWave, 1) void rowgemm_x3_kernel(const f
     // X through a buffer descriptor (the launcher checks N K < 2^30): a plain global load is free to sink to its first use
     // -- the compiler put every one of them right in front of the split that consumes it, a full memory round trip per
     // K-block -- while the buffer-load intrinsic keeps its place between the scheduling fences below.
-    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)(N * K * (int64_t)sizeof(float)), 0x00020000);
+    // (ldx >= K: rows of X inside a wider matrix -- a head's columns of [N, H D])
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)(((N - 1) * ldx + K) * (int64_t)sizeof(float)),
+                                                       0x00020000);
     auto load16 = [&](int64_t row, int col) {
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)((row * K + col) * (int64_t)sizeof(float)), 0, 0);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)((row * ldx + col) * (int64_t)sizeof(float)), 0, 0);
         const unsigned u0 = v[0], u1 = v[1], u2 = v[2], u3 = v[3];     // (element by element: see load_vec in gemm_tn.hip)
         return make_float4(__uint_as_float(u0), __uint_as_float(u1), __uint_as_float(u2), __uint_as_float(u3));
     };
@@ -271,11 +274,12 @@ __global__ __launch_bounds__(kX3Waves * kWave, 1) void rowgemm_x3_kernel(const f
 }
 
 template <int K, int M, bool TW, bool RELU, bool LINES, int BITS = 0>
-int rowgemm_x3_launch3(const float *X, const float *W, const float *bias, float *Y, int64_t N, hipStream_t st, int ldy, uint32_t *bits = nullptr)
+int rowgemm_x3_launch3(const float *X, const float *W, const float *bias, float *Y, int64_t N, hipStream_t st, int ldy, uint32_t *bits = nullptr,
+                       int ldx = K)
 {
     constexpr size_t lds = (size_t)(M / 16) * (K / 32) * kXTerms * kFragBytes + sizeof(float) * M;
     const int64_t pairs = (N + 31) / 32;
-    if (N * K >= (int64_t)1 << 30) return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: the split form addresses X with 32 bits (N K < 2^30)");
+    if (N * ldx >= (int64_t)1 << 30) return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_f32: the split form addresses X with 32 bits (N ldx < 2^30)");
     static PerDeviceOnce once;
     bool *raised = once.slot();
     if (lds > 64 * 1024 && !*raised) {
@@ -289,7 +293,7 @@ int rowgemm_x3_launch3(const float *X, const float *W, const float *bias, float 
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const unsigned blocks = (unsigned)std::min<int64_t>((pairs + kX3Waves - 1) / kX3Waves, cus);
     hipLaunchKernelGGL((rowgemm_x3_kernel<K, M, TW, RELU, LINES, BITS>), dim3(blocks), dim3(kX3Waves * kWave), lds, st, X, W, bias, Y, N,
-                       (int)pairs, ldy, bits);
+                       (int)pairs, ldy, bits, ldx);
     return check_launch("stg_rowgemm_f32");
 }
 
@@ -320,6 +324,25 @@ int rowgemm_x3_bits_launch(int K, int M, const float *X, const float *W, const f
     STG_X3(64, 64)
 #undef STG_X3
     return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_act_bits_f32: the split form covers K, M in {64, 128} (got %d, %d)", K, M);
+}
+
+// Y_h [N, M] = X[:, h K : (h + 1) K] W_h for the `heads` column blocks of X [N, heads K], W [heads][K][M], Y [heads][N][M]: one
+// launch per block (the weight image of one is the workgroup's LDS)
+int rowgemm_x3_heads_launch(int K, int M, const float *X, const float *W, float *Y, int64_t N, int heads, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int h = 0; h < heads; ++h) {
+        const float *x = X + (int64_t)h * K, *w = W + (int64_t)h * K * M;
+        float *y = Y + (int64_t)h * N * M;
+        int rc;
+        if (K == 64 && M == 64) rc = rowgemm_x3_launch3<64, 64, false, false, true>(x, w, nullptr, y, N, st, M, nullptr, heads * K);
+        else if (K == 64 && M == 128) rc = rowgemm_x3_launch3<64, 128, false, false, true>(x, w, nullptr, y, N, st, M, nullptr, heads * K);
+        else if (K == 128 && M == 64) rc = rowgemm_x3_launch3<128, 64, false, false, true>(x, w, nullptr, y, N, st, M, nullptr, heads * K);
+        else if (K == 128 && M == 128) rc = rowgemm_x3_launch3<128, 128, false, false, true>(x, w, nullptr, y, N, st, M, nullptr, heads * K);
+        else return fail(STG_ERR_UNSUPPORTED, "stg_rowgemm_heads_f32: K, M in {64, 128} (got %d, %d)", K, M);
+        if (rc != 0) return rc;
+    }
+    return 0;
 }
 
 int rowgemm_x3_launch(int K, int M, const float *X, const float *W, const float *bias, float *Y, int64_t N, bool tw, bool relu,

@@ -51,6 +51,7 @@ int rowgemm_x3_launch(int K, int M, const float *X, const float *W, const float 
                       void *stream, int ldy);
 // the same with the ReLU sign pattern as bits (layout: rowgemm_x3.hip): bits_out with the ReLU forward (W [K][M]), bits_in with the
 // input gradient of the layer above (W [M][K]); Y contiguous [N, M]
+int rowgemm_x3_heads_launch(int K, int M, const float *X, const float *W, float *Y, int64_t N, int heads, void *stream);
 int rowgemm_x3_bits_launch(int K, int M, const float *X, const float *W, const float *bias, float *Y, int64_t N, const uint32_t *bits_in,
                            uint32_t *bits_out, void *stream);
 Tuning &tuning();

@@ -1158,7 +1158,12 @@ def gat_bwd_uniform(A, S, out, g, x, W, feat, fwd: DeviceCSR, bwd: DeviceCSR, sl
                                                 _ptr(grad_er), st))
         gq = g_pre if elu else g
         with _Timed("gat_bwd_gw", 4 * N * H * (D + fin) + 4 * H * D * fin, 2 * N * H * D * fin):
-            gW = torch.bmm(gq.view(N, H, D).transpose(0, 1), W.view(H, D, fin))       # [H, N, fin]: gW[h, v] = W_h^T g[v, h, :]
+            # [H, N, fin]: gW[h, v] = W_h^T g[v, h, :]
+            if N >= ROWGEMM16_MIN_ROWS and _C.lib.stg_rowgemm_heads_supported(N, D, fin, H) and gq.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0:
+                gW = new(H, N, fin)
+                _C.check(_C.lib.stg_rowgemm_heads_f32(_ptr(gq), _ptr(W), _ptr(gW), N, D, fin, H, st))
+            else:
+                gW = torch.bmm(gq.view(N, H, D).transpose(0, 1), W.view(H, D, fin))
         moved = (4 * N * H * fin + 4 * E * fin + 4 * E * H + 4 * N * fin + 4 * N * 16 + idx            # targets: gW, x[u], T, gsW, pack
                  + 4 * E * H + 4 * E * fin + 4 * N * (fin + H) + idx)                                   # sources: T, gsW[v], grad_el, gxa
         with _Timed("gat_bwd_uniform", moved, 2 * E * H * fin):

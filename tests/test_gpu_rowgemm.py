@@ -257,3 +257,22 @@ def test_relu_pattern_is_dropped_when_the_output_is_written_again(cuda):
     assert SF._tagged(h1, "_stg_relu_bits") is bits
     h1 += 1
     assert SF._tagged(h1, "_stg_relu_bits") is None
+
+
+@pytest.mark.parametrize("N", [1, 33, 70_001])
+@pytest.mark.parametrize("K,M,heads", [(64, 64, 8), (128, 64, 2), (64, 128, 3)])
+def test_per_head_products_of_a_wide_matrix(cuda, N, K, M, heads):
+    """stg_rowgemm_heads_f32: Y[h] = X[:, h K : (h + 1) K] @ W[h] for the column blocks of X [N, heads K] (rows read with the
+    wide matrix's stride) against fp64."""
+    from stgraph_amd import _C
+    gen = torch.Generator(device=cuda).manual_seed(N + K + M + heads)
+    x = torch.randn(N, heads * K, device=cuda, generator=gen)
+    w = torch.randn(heads, K, M, device=cuda, generator=gen)
+    y = torch.empty(heads, N, M, device=cuda)
+    assert _C.lib.stg_rowgemm_heads_supported(N, K, M, heads)
+    _C.check(_C.lib.stg_rowgemm_heads_f32(x.data_ptr(), w.data_ptr(), y.data_ptr(), N, K, M, heads, None))
+    torch.cuda.synchronize()
+    xd = x.double().view(N, heads, K).transpose(0, 1)
+    want = torch.bmm(xd, w.double())
+    scale = torch.bmm(xd.abs(), w.double().abs()) + 1
+    assert ((y.double() - want).abs() <= 2e-6 * scale).all()
