@@ -786,37 +786,38 @@ __global__ __launch_bounds__(kBlock) void gat_ubwd_t_kernel(
 }
 
 // backward CSR: rows = sources u, columns = targets v.  grad_el[u, h] = sum over u's out-edges of T[eid, h];
-// gxa[u, :] = sum over them of gsW[v, :] (= grad_feat[u] W, see above).  Four edges at a time, one per DPP row.
+// gxa[u, :] = sum over them of gsW[v, :] (= grad_feat[u] W, see above).  K1's shape at width 64: a row per 16 lanes (16 bytes of
+// gsW[v] each), four rows per wave, U edges of each in flight (one row per wave with 8 edges in flight: 0.42 ms, 5.4 TB/s;
+// K1 itself runs the same 2 GB gather at 0.94 of the roofline).
 template <int U>
 __global__ __launch_bounds__(kBlock) void gat_ubwd_src_kernel(
     const float *__restrict__ T, const float *__restrict__ gsW, float *__restrict__ grad_el, float *__restrict__ gxa,
     const int *__restrict__ row_offsets, const int *__restrict__ column_indices, const int *__restrict__ eids,
     const int *__restrict__ node_ids, int N)
 {
-    constexpr int H = 8, FIN = 64;
-    const int lane = threadIdx.x & (kWave - 1), slot = lane >> 4, c = lane & 15;
-    const RowInfo ri = row_prologue<6>(row_offsets, node_ids, N);
+    constexpr int H = 8, FIN = 64, G = 16;
+    const int c = threadIdx.x & (G - 1);
+    const RowInfo ri = row_prologue<4>(row_offsets, node_ids, N);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     float tacc = 0.f;                                // lanes c < 8: head c
-    for (int base = 0; base < ri.max_deg; base += kWave) {
+    for (int base = 0; base < ri.max_deg; base += G) {
         const int cnt = ri.deg - base;
-        const int cnt_max = min(kWave, ri.max_deg - base);
+        const int cnt_max = min(G, ri.max_deg - base);
         int cidx = 0, ev = 0;
-        if (lane < cnt) {
-            cidx = column_indices[ri.beg + base + lane];
-            ev = eids[ri.beg + base + lane];
+        if (c < cnt) {
+            cidx = column_indices[ri.beg + base + c];
+            ev = eids[ri.beg + base + c];
         }
-        for (int k = 0; k < cnt_max; k += 4 * U) {
+        for (int k = 0; k < cnt_max; k += U) {
             float gv[U][4], tv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int kk = k + 4 * u + slot;
-                const int ck = __builtin_amdgcn_ds_bpermute((kk & (kWave - 1)) * 4, cidx);
-                const int ek = __builtin_amdgcn_ds_bpermute((kk & (kWave - 1)) * 4, ev);
-                const bool ok = kk < cnt;
+                const int kk = k + u;
+                const int ck = gbcast_i<G>(cidx, kk & (G - 1));              // (edge 0 / target 0 past the row's last: valid addresses)
+                const int ek = gbcast_i<G>(ev, kk & (G - 1));
                 vec_load<4>(gv[u], gsW + (int64_t)ck * FIN + 4 * c);
                 tv[u] = T[(int64_t)ek * H + (c & 7)];
-                if (!ok) {
+                if (kk >= cnt) {
                     tv[u] = 0.f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) gv[u][i] = 0.f;
@@ -830,15 +831,7 @@ __global__ __launch_bounds__(kBlock) void gat_ubwd_src_kernel(
             }
         }
     }
-    // the four DPP rows' partial sums: rows 0 + 2 and 1 + 3, then the pair
-    tacc = tacc + __shfl_xor(tacc, 32, kWave);
-    tacc = tacc + __shfl_xor(tacc, 16, kWave);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        acc[i] = acc[i] + __shfl_xor(acc[i], 32, kWave);
-        acc[i] = acc[i] + __shfl_xor(acc[i], 16, kWave);
-    }
-    if (ri.valid && slot == 0) {
+    if (ri.valid) {
         if (c < H) grad_el[(int64_t)ri.r * H + c] = tacc;
         vec_store<4>(gxa + (int64_t)ri.r * FIN + 4 * c, acc);
     }
@@ -1201,7 +1194,7 @@ extern "C" int stg_gat_bwd_uniform_edges(const float *A, const float *pack, cons
                        fwd_column_indices, fwd_eids, fwd_node_ids, N, slope, ones_flag);
     hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, pack, gq, feat, grad_feat, grad_el,
                        T, bwd_row_offsets, bwd_column_indices, bwd_eids, bwd_node_ids, N, slope, ones_flag, 1);
-    hipLaunchKernelGGL(gat_ubwd_src_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, T, gsW, grad_el, gxa, bwd_row_offsets,
+    hipLaunchKernelGGL(gat_ubwd_src_kernel<8>, dim3(grid_for(N, 4)), dim3(kBlock), 0, st, T, gsW, grad_el, gxa, bwd_row_offsets,
                        bwd_column_indices, bwd_eids, bwd_node_ids, N);
     return check_launch("stg_gat_bwd_uniform_edges");
 }
