@@ -34,7 +34,8 @@ extern "C" {
  *      the step launches optional; stg_tgcn_unfold_gate_grads.
  *  25: stg_rowgemm_act_bits_f32, stg_rowgemm_bits_words, stg_rowgemm_bits_supported: a ReLU layer's sign pattern as bits;
  *      stg_xent_fwd_grad, stg_xent_scale_grad: cross-entropy forward and gradient in one pass; stg_gat_bwd_uniform_*,
- *      stg_gat_bwd_prepass, stg_gemm_tn_gated_f32, stg_rowgemm_heads_f32: the GAT backward unit in the uniform-attention form. */
+ *      stg_gat_bwd_prepass, stg_gemm_tn_gated_f32, stg_rowgemm_heads_f32: the GAT backward unit in the uniform-attention form;
+ *      stg_gat_fc_fwd accepts feat == NULL, stg_gat_fc_feat_if. */
 #define STG_ABI_VERSION 25
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -519,6 +520,11 @@ int stg_gat_fwd_k1_uniform(const float *S, int32_t H, const float *x, float *xm,
                            const int32_t *ones_flag, void *stream);
 int stg_gat_fc_out(const float *xm, const float *W, float *out, float *act_out, int32_t N, int32_t fin, int32_t H,
                    int32_t D, void *stream);
+/* The input side without its feat: stg_gat_fc_fwd accepts feat == NULL (el / er only, from the same accumulators) -- the
+ * uniform-attention form never reads feat; stg_gat_fc_feat_if writes feat = x W^T afterwards only if *only_if != 0 (the flag of
+ * stg_gat_score_flag: some score is not finite and the general units, which gather feat, are going to run). */
+int stg_gat_fc_feat_if(const float *x, const float *W, float *feat, int32_t N, int32_t fin, int32_t H, int32_t D,
+                       const int32_t *only_if, void *stream);
 int stg_gat_fwd_k1_scored(const float *A, const float *S, const float *feat, float *out, float *act_out,
                           const int32_t *row_offsets, const int32_t *column_indices, const int32_t *eids,
                           const int32_t *node_ids, int32_t N, int32_t H, int32_t D, const int32_t *ones_flag,

@@ -30,10 +30,13 @@ template <int FIN, bool PROJ>
 __global__ __launch_bounds__(kFcWaves * 64) void gat_fc_kernel(
     const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ attn_l,
     const float *__restrict__ attn_r, float *__restrict__ feat, float *__restrict__ el, float *__restrict__ er,
-    int N, int H, float *__restrict__ act_out)
+    int N, int H, float *__restrict__ act_out, const int *__restrict__ only_if)
 {
     constexpr int NT = kFcWaves * 64, LD = FIN + 8, J = FIN / 16, D = 64;     // 8 mod 16 dwords: conflict-free ds_read_b128 (tgcn_step.hpp)
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // only_if: the launch that materialises feat for the general units when some score is not finite (stg_gat_fc_feat_if): the
+    // uniform-attention form never reads feat, so the input side leaves it unwritten (feat == nullptr below) -- kernel-uniform
+    if (only_if && __builtin_amdgcn_readfirstlane(*only_if) == 0) return;
     const int HD = H * D;
     float *Wl = lds, *al = Wl + HD * LD, *ar = al + HD;
     stage_rows<NT>(Wl, LD, W, HD, FIN);
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(kFcWaves * 64) void gat_fc_kernel(
 #pragma unroll
             for (int ct = 0; ct < kFcCT; ++ct) {
                 const int col = g * 128 + ct * 16;
-                if (ok) *reinterpret_cast<float4 *>(frow + col) = to_f4(acc[ct]);
+                if (ok && feat) *reinterpret_cast<float4 *>(frow + col) = to_f4(acc[ct]);
                 if constexpr (!PROJ) {
                     if (ok && act_out) {                      // kernel-uniform; torch's elu: x <= 0 ? exp(x) - 1 : x
                         float4 y;
@@ -115,12 +118,13 @@ extern "C" int stg_gat_fc_supported(int32_t fin, int32_t H, int32_t D) { return 
 namespace stg {
 namespace {
 int fc_launch(const char *what, bool proj, const float *x, const float *W, const float *attn_l, const float *attn_r,
-              float *feat, float *el, float *er, float *act_out, int32_t N, int32_t fin, int32_t H, int32_t D, void *stream)
+              float *feat, float *el, float *er, float *act_out, int32_t N, int32_t fin, int32_t H, int32_t D, void *stream,
+              const int32_t *only_if = nullptr)
 {
     if (N < 0 || !fc_shape_ok(fin, H, D))
         return fail(STG_ERR_UNSUPPORTED, "%s: unsupported shape N=%d fin=%d H=%d D=%d", what, N, fin, H, D);
     if (N == 0) return 0;
-    if (!x || !W || !feat || (proj && (!attn_l || !attn_r || !el || !er)))
+    if (!x || !W || (!feat && !proj) || (proj && (!attn_l || !attn_r || !el || !er)))
         return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
     if ((int64_t)N * H * D > 0x7fffffffll * 4)
         return fail(STG_ERR_UNSUPPORTED, "%s: N * H * D too large", what);
@@ -140,7 +144,7 @@ int fc_launch(const char *what, bool proj, const float *x, const float *W, const
             *done = true;
         }
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kFcWaves * 64), lds, st, x, W, attn_l, attn_r, feat, el,
-                           er, N, H, act_out);
+                           er, N, H, act_out, only_if);
         return 0;
     };
     static PerDeviceOnce once32p, once64p, once32, once64;
@@ -163,4 +167,13 @@ extern "C" int stg_gat_fc_out(const float *xm, const float *W, float *out, float
 {
     return stg::fc_launch("stg_gat_fc_out", false, xm, W, nullptr, nullptr, out, nullptr, nullptr, act_out, N, fin, H, D,
                           stream);
+}
+
+// feat = x W^T only if *only_if != 0 (see the kernel): after stg_gat_fc_fwd with feat == NULL
+extern "C" int stg_gat_fc_feat_if(const float *x, const float *W, float *feat, int32_t N, int32_t fin, int32_t H, int32_t D,
+                                  const int32_t *only_if, void *stream)
+{
+    if (!only_if) return stg::fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_fc_feat_if: NULL flag");
+    return stg::fc_launch("stg_gat_fc_feat_if", false, x, W, nullptr, nullptr, feat, nullptr, nullptr, nullptr, N, fin, H, D, stream,
+                          only_if);
 }

@@ -982,7 +982,7 @@ def gat_uniform_usable(x: torch.Tensor, H: int, D: int) -> bool:
 
 
 def gat_fwd_uniform(x: torch.Tensor, W: torch.Tensor, el: torch.Tensor, er: torch.Tensor, feat: torch.Tensor,
-                    csr: DeviceCSR, slope: float, use_node_ids: bool = False, elu: bool = False):
+                    csr: DeviceCSR, slope: float, use_node_ids: bool = False, elu: bool = False, feat_unwritten: bool = False):
     """K0 + K1 of a layer whose ``feat = x @ W.T`` ([N, fin] -> [N, H, D], fin < H*D), in the uniform-attention form
     (stgraph_hip.h, ABI 23).  ``emb - max([emb])`` is +0 for every finite score (reference gat_conv.py:50, SURVEY.md
     D2), every A is then 1.0f and K1 is the in-neighbour mean of ``feat`` -- linear in x: the gather runs over x at
@@ -1014,6 +1014,8 @@ def gat_fwd_uniform(x: torch.Tensor, W: torch.Tensor, el: torch.Tensor, er: torc
         st = _stream_ptr(dev)
         flag = torch.empty(1, dtype=torch.int32, device=dev)
         _C.check(_C.lib.stg_gat_score_flag(_ptr(el), _ptr(er), N * H, _ptr(flag), st))
+        if feat_unwritten:                              # gat_fc_fwd(store_feat=False): the general units below gather feat
+            _C.check(_C.lib.stg_gat_fc_feat_if(_ptr(x), _ptr(W), _ptr(feat), N, fin, H, D, _ptr(flag), st))
         with _Timed("gat_k0", ab["gat_k0"], E * H):
             _C.check(_C.lib.stg_gat_fwd_k0(_ptr(el), _ptr(er), _ptr(A), _ptr(S), _ptr(csr.row_offset),
                                            _ptr(csr.column_indices), _ptr(csr.eids), nid, N, H, H, float(slope), _ptr(flag), st))
@@ -1121,12 +1123,17 @@ def set_gat_uniform_backward(on: bool) -> None:
     _GAT_UNIFORM_BWD = bool(on)
 
 
-def gat_bwd_uniform_usable(A: torch.Tensor, x: torch.Tensor, H: int, D: int) -> bool:
-    """``A`` from :func:`gat_fwd_uniform` (it carries the flag and the mean of x), shapes of stg_gat_bwd_uniform_supported."""
-    return (_GAT_UNIFORM_BWD and _GAT_FACTORED and _GAT_REGROUPED_ER and getattr(A, "_stg_ones", None) is not None
-            and getattr(A, "_stg_xm", None) is not None and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+def gat_bwd_uniform_shape(x: torch.Tensor, H: int, D: int) -> bool:
+    """Switches and shapes of :func:`gat_bwd_uniform` (what the forward can know)."""
+    return (_GAT_UNIFORM_BWD and _GAT_FACTORED and _GAT_REGROUPED_ER and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
             and x.data_ptr() % 16 == 0 and active_columns(H) == H and active_columns(H * D) == H * D
             and bool(_C.lib.stg_gat_bwd_uniform_supported(int(H), int(D), int(x.shape[1]))))
+
+
+def gat_bwd_uniform_usable(A: torch.Tensor, x: torch.Tensor, H: int, D: int) -> bool:
+    """``A`` from :func:`gat_fwd_uniform` (it carries the flag and the mean of x), shapes of stg_gat_bwd_uniform_supported."""
+    return (gat_bwd_uniform_shape(x, H, D) and getattr(A, "_stg_ones", None) is not None
+            and getattr(A, "_stg_xm", None) is not None)
 
 
 def gat_bwd_uniform(A, S, out, g, x, W, feat, fwd: DeviceCSR, bwd: DeviceCSR, slope: float, use_node_ids: bool = False,
@@ -1206,9 +1213,10 @@ def gat_fc_supported(fin: int, H: int, D: int) -> bool:
     return bool(_C.lib.stg_gat_fc_supported(int(fin), int(H), int(D)))
 
 
-def gat_fc_fwd(x: torch.Tensor, W: torch.Tensor, attn_l: torch.Tensor, attn_r: torch.Tensor, H: int, D: int):
+def gat_fc_fwd(x: torch.Tensor, W: torch.Tensor, attn_l: torch.Tensor, attn_r: torch.Tensor, H: int, D: int, store_feat: bool = True):
     """(feat [N,H,D], el, er [N,H,1]): ``feat = x @ W.T`` and the attention projections from its accumulators, one
-    launch (stg_gat_fc_fwd)."""
+    launch (stg_gat_fc_fwd).  ``store_feat=False``: ``feat`` is allocated but NOT written (the uniform-attention form never reads
+    it; :func:`gat_fc_feat_if` fills it when the general units are going to run)."""
     x = _f32(x, "x")
     dev = x.device
     N, fin = x.shape
@@ -1219,10 +1227,22 @@ def gat_fc_fwd(x: torch.Tensor, W: torch.Tensor, attn_l: torch.Tensor, attn_r: t
     feat = torch.empty(N, H, D, dtype=torch.float32, device=dev)
     el = torch.empty(N, H, 1, dtype=torch.float32, device=dev)
     er = torch.empty(N, H, 1, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _Timed("gat_fc", 4 * N * (fin + H * D + 2 * H) + 4 * H * D * fin, 2 * N * fin * H * D):
-        _C.check(_C.lib.stg_gat_fc_fwd(_ptr(x), _ptr(W), _ptr(al), _ptr(ar), _ptr(feat), _ptr(el), _ptr(er),
+    with torch.cuda.device(dev), _Timed("gat_fc", 4 * N * (fin + (H * D if store_feat else 0) + 2 * H) + 4 * H * D * fin, 2 * N * fin * H * D):
+        _C.check(_C.lib.stg_gat_fc_fwd(_ptr(x), _ptr(W), _ptr(al), _ptr(ar), _ptr(feat if store_feat else None), _ptr(el), _ptr(er),
                                        N, fin, H, D, _stream_ptr(dev)))
     return feat, el, er
+
+
+def gat_fc_feat_if(x: torch.Tensor, W: torch.Tensor, feat: torch.Tensor, flag: torch.Tensor | None) -> None:
+    """``feat[...] = x @ W.T`` if ``*flag != 0`` (``flag`` None: always) -- the rows :func:`gat_fc_fwd` left unwritten."""
+    N, H, D = feat.shape
+    fin = int(x.shape[1])
+    dev = feat.device
+    with torch.cuda.device(dev):
+        if flag is None:
+            _C.check(_C.lib.stg_gat_fc_out(_ptr(x), _ptr(W), _ptr(feat), None, N, fin, H, D, _stream_ptr(dev)))
+        else:
+            _C.check(_C.lib.stg_gat_fc_feat_if(_ptr(x), _ptr(W), _ptr(feat), N, fin, H, D, _ptr(flag), _stream_ptr(dev)))
 
 
 def gat_proj_fwd(feat: torch.Tensor, attn_l: torch.Tensor, attn_r: torch.Tensor):

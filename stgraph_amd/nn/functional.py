@@ -566,15 +566,19 @@ class _GatFcLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, attn_l, attn_r, fwd_csr, bwd_csr, use_nid, slope, H, D, elu):
-        feat, el, er = kernels.gat_fc_fwd(x, w, attn_l, attn_r, H, D)
-        if kernels.gat_uniform_usable(x, H, D):
+        uniform = kernels.gat_uniform_usable(x, H, D)
+        # the uniform-attention form with its own backward unit never reads feat: left unwritten unless a score is not finite
+        lazy = uniform and _GAT_PROJ_FOLD and kernels.gat_bwd_uniform_shape(x, H, D)
+        feat, el, er = kernels.gat_fc_fwd(x, w, attn_l, attn_r, H, D, store_feat=not lazy)
+        if uniform:
             # K1 at the input width, then the product with W (and the layer's elu in its epilogue)
-            out, act, A, S = kernels.gat_fwd_uniform(x, w, el, er, feat, fwd_csr, slope, use_nid, elu)
+            out, act, A, S = kernels.gat_fwd_uniform(x, w, el, er, feat, fwd_csr, slope, use_nid, elu, feat_unwritten=lazy)
         else:
             out, A, S = kernels.gat_fwd(el, er, feat, fwd_csr, slope, use_nid, ones_shortcut=True)
             act = F.elu(out) if elu else None
         ctx.save_for_backward(x, w, feat, attn_l, attn_r, el, er, A, S, out)     # `out`: the pre-activation rows
         ctx.csrs, ctx.use_nid, ctx.slope, ctx.w, ctx.elu = (fwd_csr, bwd_csr), use_nid, slope, w, bool(elu)
+        ctx.feat_lazy = lazy
         return act if elu else out
 
     @staticmethod
@@ -583,6 +587,9 @@ class _GatFcLayer(torch.autograd.Function):
         fwd_csr, bwd_csr = ctx.csrs
         if _GAT_PROJ_FOLD and kernels.gat_bwd_uniform_usable(A, x, feat.shape[1], feat.shape[2]):
             return _GatFcLayer._backward_uniform(ctx, g)
+        if ctx.feat_lazy:                                   # (a switch moved between forward and backward: the unit below gathers feat)
+            kernels.gat_fc_feat_if(x, w, feat, None)
+            ctx.feat_lazy = False
         gf, gel, ger = kernels.gat_bwd(A, S, out, g.contiguous(), el, er, feat, fwd_csr, bwd_csr, ctx.slope, ctx.use_nid,
                                        elu=ctx.elu)
         small = None
