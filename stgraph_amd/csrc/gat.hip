@@ -460,6 +460,12 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
     const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
     const bool ones = all_ones(flag);
     const float *__restrict__ invS = P + (int64_t)N * H;
+    // Every A = 1.0f and no T wanted (grad_er comes from the per-vertex pass): alpha = 1.0f / S is the very quotient the T term
+    // multiplies the dot product by, so  sum_e (g_e . f)(1 / S_e) = f . sum_e g_e alpha_e = f . grad_feat[u]  -- ONE dot product
+    // per row after the loop instead of one (and its cross-lane sum) per edge; grad_el = slope (f . grad_feat - sum_e P_e).
+    // Kernel-uniform.  (Narrow rows -- the 1-head output layer of the GAT model, 4 lanes per row -- are bound by these
+    // per-edge instructions, not by their 64-byte gathers: 305 -> 2xx us at cfg3's second layer.)
+    const bool lite = ones && T == nullptr;
 
     for (int fbase = 0; fbase < HD; fbase += G * VEC * CHUNKS) {
         float a13[CHUNKS][VEC], fu[CHUNKS][VEC], gel[CHUNKS];
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
                         if (kk < cnt && fok[ch]) {
                             av[u][ch] = ones ? 1.0f : A[(int64_t)ek[u] * H + hh[ch]];
                             sv[u][ch] = S[(int64_t)ck * H + hh[ch]];
-                            iv[u][ch] = invS[(int64_t)ck * H + hh[ch]];          // 1.0f / S
+                            iv[u][ch] = lite ? 1.f : invS[(int64_t)ck * H + hh[ch]];          // 1.0f / S
                             pv[u][ch] = P[(int64_t)ck * H + hh[ch]];
                             vec_load<VEC>(gv[u][ch], g + (int64_t)ck * HD + foff[ch]);
                         } else {
@@ -522,6 +528,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
                                 p = __builtin_fmaf(gv[u][ch][i], fu[ch][i], p);     // (a regrouped sum either way)
                             }
                         }
+                        if (lite) {
+                            if (on && lead[ch]) gel[ch] = gel[ch] + pv[u][ch];     // sum of P over the out-edges
+                            continue;
+                        }
                         float dot;
                         if constexpr (ROW16) dot = row16_sum_lane0(p);
                         else dot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
@@ -532,6 +542,18 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_kernel(
                         }
                     }
                 }
+            }
+        }
+        if (lite) {
+#pragma unroll
+            for (int ch = 0; ch < CHUNKS; ++ch) {
+                float p = 0.f;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) p = __builtin_fmaf(a13[ch][i], fu[ch][i], p);
+                float dot;
+                if constexpr (ROW16) dot = row16_sum_lane0(p);
+                else dot = head_sum<POW2>(p, LH, lds_wave, lane, j, G);
+                gel[ch] = (dot - gel[ch]) * slope;
             }
         }
 #pragma unroll
