@@ -35,7 +35,7 @@ extern "C" {
  *  25: stg_rowgemm_act_bits_f32, stg_rowgemm_bits_words, stg_rowgemm_bits_supported: a ReLU layer's sign pattern as bits;
  *      stg_xent_fwd_grad, stg_xent_scale_grad: cross-entropy forward and gradient in one pass; stg_gat_bwd_uniform_*,
  *      stg_gat_bwd_prepass, stg_gemm_tn_gated_f32, stg_rowgemm_heads_f32: the GAT backward unit in the uniform-attention form;
- *      stg_gat_fc_fwd accepts feat == NULL, stg_gat_fc_feat_if. */
+ *      stg_gat_fc_fwd accepts feat == NULL, stg_gat_fc_feat_if; stg_tgcn_step_bwd_args gains ld_d (last field). */
 #define STG_ABI_VERSION 25
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -788,6 +788,10 @@ typedef struct stg_tgcn_step_bwd_args {
      * with da3_g = d_g Wg[:, :C] (320 matrix instructions per tile instead of 512), da3 is not formed and neither x3 nor clamp_mask
      * read -- exact for an inactive clamp (stg_tgcn_step_fwd_args::fold_status tells).  Wcat may then be NULL. */
     const float *w_fold_t;
+    /* Row stride of dzl / drl / dhl in floats (ABI 25): 0 or C = three [N, C] matrices; 3 C = the column blocks of ONE [N, 3C] matrix
+     * (dzl = D, drl = D + C, dhl = D + 2 C, say), so that a window's weight gradients contract [d_z | d_r] against [H | P] as one
+     * operand -- the shared operand is read once (stg_gemm_tn_form_f32 with lda = 3 C).  The matrix-core form (w_image) takes 0 / C. */
+    int32_t ld_d;
 } stg_tgcn_step_bwd_args;
 int    stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh);
 size_t stg_tgcn_step_loss_partials(int64_t N);

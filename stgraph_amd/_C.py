@@ -95,7 +95,8 @@ class TgcnStepBwdArgs(ctypes.Structure):
                  ("head", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)] +
                 _ptr_fields("link_row_ptr link_other link_eid link_y link_logits link_target") + [("link_inv_m", ctypes.c_float),
                                                                                                     ("w_image", ctypes.c_void_p),
-                                                                                                    ("w_fold_t", ctypes.c_void_p)])
+                                                                                                    ("w_fold_t", ctypes.c_void_p),
+                                                                                                    ("ld_d", ctypes.c_int32)])
 
 
 class StgError(RuntimeError):

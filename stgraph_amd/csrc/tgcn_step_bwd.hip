@@ -13,6 +13,7 @@ struct BwdArgs {
     const float *WzT, *WrT, *WhT, *Wcat, *W1T, *W2;
     const float *At;                                           // FOLD: [3 Fin][C], rows g Fin + f = the folded gate weights' P part, transposed
     float *dzl, *drl, *dhl, *da3, *dH, *z, *dyt, *dyo;
+    int d_wide;                    // dzl / drl / dhl are column blocks of ONE [N, 3C] matrix (rows 3C floats apart)
     const unsigned *mask;
     const int *link_row_ptr, *link_other, *link_eid;           // node side of the link loss's backward (head == 1; NULL: not here)
     const float *link_y, *link_logits, *link_target;
@@ -113,6 +114,11 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         const unsigned oC = (row * C + 4u * kq) * 4u, o3 = (row * (3u * C) + 4u * kq) * 4u, oF = (row * FH + 4u * kq) * 4u;
         auto ldC = [&](const float *p, int j) { return ld_f4(p, oC, 64 * j); };          // p must not be NULL
         auto stC = [&](float *p, int j, const float4 &v) { st_f4(p, oC, 64 * j, v); };
+        // the gate gradients: [N, C] each, or the column blocks of one [N, 3C] matrix (stg_tgcn_step_bwd_args::ld_d), so that
+        // the window's weight gradients read d_z | d_r as ONE operand against [H | P]
+        const unsigned oD = a.d_wide ? o3 : oC;
+        auto ldD = [&](const float *p, int j) { return ld_f4(p, oD, 64 * j); };
+        auto stD = [&](float *p, int j, const float4 &v) { st_f4(p, oD, 64 * j, v); };
 
         // clamp mask of the 3C columns of x3 as 48 bits (used by three later phases: 2 registers)
         unsigned mlo = 0u, mhi = 0u;
@@ -247,8 +253,8 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
             const float4 dz = make_float4((g.x * (h.x - t.x)) * (z.x * (1.0f - z.x)), (g.y * (h.y - t.y)) * (z.y * (1.0f - z.y)),
                                           (g.z * (h.z - t.z)) * (z.z * (1.0f - z.z)), (g.w * (h.w - t.w)) * (z.w * (1.0f - z.w)));
             dHa[j] = make_float4(g.x * z.x, g.y * z.y, g.z * z.z, g.w * z.w);
-            stC(a.dhl, j, dhl[j]);
-            stC(a.dzl, j, dz);
+            stD(a.dhl, j, dhl[j]);
+            stD(a.dzl, j, dz);
         }
         // (left free, `g * z` is sunk to the dHR stage, keeping g and z -- 32 registers, 12 of them spilled -- instead of dHa)
 #pragma unroll
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
 #pragma unroll
         for (int j = 0; j < PC; ++j) rr[j] = ldC(a.R, j);
 #pragma unroll
-        for (int j = 0; j < PC; ++j) hb[j] = zero4, dzl[j] = ldC(a.dzl, j);      // this lane's own stores, above
+        for (int j = 0; j < PC; ++j) hb[j] = zero4, dzl[j] = ldD(a.dzl, j);      // this lane's own stores, above
         if (a.H) {
 #pragma unroll
             for (int j = 0; j < PC; ++j) hb[j] = ldC(a.H, j);
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
                                    (d.z * h.z) * (r.z * (1.0f - r.z)), (d.w * h.w) * (r.w * (1.0f - r.w)));
             dHa[blk] = make_float4(dHa[blk].x + d.x * r.x, dHa[blk].y + d.y * r.y, dHa[blk].z + d.z * r.z,
                                    dHa[blk].w + d.w * r.w);
-            stC(a.drl, blk, drl[blk]);
+            stD(a.drl, blk, drl[blk]);
         }
         // ---- dCZ = dzl Wz,  dCR = drl Wr: d(hz), d(hr) -> da3;  second halves -> dH (dCZ's first, then dCR's) -------
         STG_TRACE_MARK(5);
@@ -414,7 +420,10 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     if (p->link_row_ptr && (p->head != 1 || !p->link_other || !p->link_eid || !p->link_y || !p->link_logits || !p->link_target || !p->g_cost ||
                             !(p->link_inv_m > 0.f)))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: the link-loss arguments need head == 1, g_cost and every link_* field");
-    if (p->w_image && !p->node_ids && p->head >= 1 && p->clamp_mask && tuning().step_impl == 0) {
+    if (p->ld_d != 0 && p->ld_d != p->C && p->ld_d != 3 * p->C)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: ld_d must be 0 / C ([N, C] each) or 3 C (column blocks of one [N, 3C] matrix)");
+    const bool d_wide = p->ld_d == 3 * p->C;
+    if (p->w_image && !p->node_ids && p->head >= 1 && p->clamp_mask && tuning().step_impl == 0 && !d_wide) {
         if (reinterpret_cast<uintptr_t>(p->w_image) & 15) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: w_image must be 16-byte aligned");
         return stg_tgcn_stepx_bwd_launch(p, stream_);
     }
@@ -434,6 +443,7 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
         a.link_y = p->link_y; a.link_logits = p->link_logits; a.link_target = p->link_target; a.link_inv_m = p->link_inv_m;
     }
     a.dzl = p->dzl; a.drl = p->drl; a.dhl = p->dhl; a.da3 = p->da3; a.dH = p->dH; a.z = p->z; a.dyt = p->dyt; a.dyo = p->dyo;
+    a.d_wide = d_wide ? 1 : 0;
     a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.two_over_n = 2.0f / (float)p->N; a.num_tiles = (int)((p->N + 15) / 16);
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const bool w16 = tuning().step_waves == 16;

@@ -1725,6 +1725,16 @@ def set_step_matrix_core(enabled: bool) -> None:
 STEP_FOLDED = os.environ.get("STGRAPH_AMD_STEP_FOLDED", "1") != "0"
 
 
+STEP_WGRAD_ZR_TOGETHER = os.environ.get("STGRAPH_AMD_STEP_WGRAD_ZR_TOGETHER", "1") != "0"
+
+
+def set_step_wgrad_zr_together(on: bool) -> None:
+    """True (default): the window nodes keep the gate gradients as column blocks of one [N, 3C] matrix
+    (stg_tgcn_step_bwd_args::ld_d) and contract [d_z | d_r] against [H | P] as ONE operand; False: one contraction per gate."""
+    global STEP_WGRAD_ZR_TOGETHER
+    STEP_WGRAD_ZR_TOGETHER = bool(on)
+
+
 def set_step_folded(enabled: bool) -> None:
     global STEP_FOLDED
     STEP_FOLDED = bool(enabled)
@@ -1839,8 +1849,9 @@ def tgcn_step_loss_partials(N: int) -> int:
 _STEP_INT_FIELDS = ("row_offsets", "column_indices", "node_ids", "link_row_ptr", "link_other", "link_eid")
 
 
-def _fill_step_args(args, what: str, dev: torch.device, tensors: dict) -> None:
-    """Check and store the device pointers of a stg_tgcn_step_*_args block (None -> NULL)."""
+def _fill_step_args(args, what: str, dev: torch.device, tensors: dict, row_stride: dict | None = None) -> None:
+    """Check and store the device pointers of a stg_tgcn_step_*_args block (None -> NULL).  ``row_stride``: names whose tensors are
+    [N, cols] column blocks of a wider row-major matrix with that row stride (instead of contiguous)."""
     names = {f[0] for f in args._fields_}
     for name, t in tensors.items():
         if name not in names:
@@ -1853,6 +1864,12 @@ def _fill_step_args(args, what: str, dev: torch.device, tensors: dict) -> None:
             setattr(args, name, t.data_ptr())
             continue
         want = torch.int32 if name in _STEP_INT_FIELDS or name in ("clamp_mask", "fold_status") else torch.float32
+        if row_stride and name in row_stride:
+            if (not torch.is_tensor(t) or t.dtype != want or t.device != dev or t.dim() != 2 or t.stride(1) != 1
+                    or (t.shape[0] > 1 and t.stride(0) != row_stride[name]) or t.data_ptr() % 16):
+                raise TypeError(f"{what}: {name} must be a [N, cols] {want} column block with row stride {row_stride[name]} on {dev}")
+            setattr(args, name, t.data_ptr())
+            continue
         if not torch.is_tensor(t) or t.dtype != want or not t.is_cuda or t.device != dev or not t.is_contiguous():
             raise TypeError(f"{what}: {name} must be a contiguous {want} tensor on {dev}")
         setattr(args, name, t.data_ptr())
@@ -1919,7 +1936,7 @@ def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
 
 
 def tgcn_step_bwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: float, device, link_edges: int = 0,
-                  **tensors) -> None:
+                  ld_d: int = 0, **tensors) -> None:
     """One TGCN step backward in one launch (stg_tgcn_step_bwd); ``tensors``: the pointer fields of
     stg_tgcn_step_bwd_args by name.  With ``link_row_ptr / link_other / link_eid / link_y / link_logits / link_target`` (and
     ``link_edges`` = the number of label edges) the node side of the link loss's backward runs inside the launch."""
@@ -1927,9 +1944,11 @@ def tgcn_step_bwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     a = _C.TgcnStepBwdArgs()
     if tensors.get("column_indices") is not None and tensors["column_indices"].numel() == 0:
         tensors = dict(tensors, w_image=None)
-    _fill_step_args(a, "tgcn_step_bwd", dev, tensors)
+    wide = int(ld_d) not in (0, int(C))
+    _fill_step_args(a, "tgcn_step_bwd", dev, tensors, {"dzl": int(ld_d), "drl": int(ld_d), "dhl": int(ld_d)} if wide else None)
     a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
     a.link_inv_m = 1.0 / float(link_edges) if link_edges else 0.0
+    a.ld_d = int(ld_d)                                 # 3 C: dzl / drl / dhl are column blocks of one [N, 3C] matrix
     per_row = 4 * (6 * C + 3 * C + 3 * C + (3 * C if tensors.get("da3") is not None else 0) + C + Fin + (2 * Fh + 3 if head else 0))
     with torch.cuda.device(dev), _Timed("tgcn_step_bwd", N * per_row, 2 * N * (6 * C * C + 3 * C * Fin + (Fh * C if head else 0))):
         _C.check(_C.lib.stg_tgcn_step_bwd(ctypes.byref(a), _stream_ptr(dev)))

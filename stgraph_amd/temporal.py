@@ -218,7 +218,13 @@ class _TGCNWindow(torch.autograd.Function):
         g = g_cost.reshape(1).contiguous().float()
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         from_p = X3 is None                                     # weight gradients from P (kernels.STEP_WGRAD_FROM_P): no x3, no da3
-        dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), (None if from_p else new(B, N, 3 * C))
+        wide_d = from_p and kernels.STEP_WGRAD_ZR_TOGETHER and ctx.img_b is None
+        if wide_d:
+            # the gate gradients as the column blocks of ONE matrix: [d_z | d_r] is then one operand against [H | P]
+            D3 = new(B, N, 3 * C)
+            dzl, drl, dhl, da3 = D3[:, :, :C], D3[:, :, C:2 * C], D3[:, :, 2 * C:], None
+        else:
+            dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), (None if from_p else new(B, N, 3 * C))
         dyt, dyo = new(B, N, Fh), new(B, N)
         dH, zbuf = new(2, N, C), new(2, N, Fin)
         WzT, WrT, WhT, W1T = ctx.packed_T
@@ -237,7 +243,7 @@ class _TGCNWindow(torch.autograd.Function):
                                   y_out=Yout[t], target=targets[t], WzT=WzT, WrT=WrT, WhT=WhT, Wcat=Wcat, W1T=W1T, W2=W2v,
                                   dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=None if from_p else da3[t], dH=dH[t & 1],
                                   z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t], dyo=dyo[t],
-                                  w_image=ctx.img_b, w_fold_t=ctx.w_fold_t if from_p else None)
+                                  w_image=ctx.img_b, w_fold_t=ctx.w_fold_t if from_p else None, ld_d=3 * C if wide_d else 0)
         dx0 = kernels.gcn_agg(zbuf[0], norm, norm, bwd, ew=ew, use_node_ids=ctx.use_nid) if want_dx0 else None
         # weight gradients: one split-K launch per parameter over the window's snapshots
         steps = range(B)
@@ -257,18 +263,14 @@ class _TGCNWindow(torch.autograd.Function):
             # per gate d_g^T Hx [C, C] (+ column sums) and d_g^T P [C, Fin]; the gate and conv parameters' gradients follow from them in
             # a few small products (_unfold_gate_grads)
             Wcz, Wcr, Wch, bcz, bcr, bch, Wz_p, _, Wr_p, _, Wh_p, _ = ctx.params[:12]
-            seconds = (Hprev, Hprev, [HR[t] for t in steps])
-            ds = (dzl, drl, dhl)
-            # one contraction per gate: d_g^T [Hx | P] -> [C, C + Fin] (+ column sums): d_g is read once
-            res = kernels.gemm_tn_form_batch(
-                [dict(As=[d[t] for t in steps], Bs=sec, B2s=[P[t] for t in steps], M=C, N=C + Fin, nsplit=C, colsum=True)
-                 for d, sec in zip(ds, seconds)] + head_calls)
+            Rg, csg, nres = _gate_contractions(kernels, D3 if wide_d else None, (dzl, drl, dhl), Hprev, [HR[t] for t in steps],
+                                               [P[t] for t in steps], steps, C, Fin, head_calls)
             gates = kernels.tgcn_unfold_gate_grads(
-                [res[k][0] for k in range(3)], [res[k][1] for k in range(3)], (Wcz, Wcr, Wch), (bcz, bcr, bch), (Wz_p, Wr_p, Wh_p),
+                Rg, csg, (Wcz, Wcr, Wch), (bcz, bcr, bch), (Wz_p, Wr_p, Wh_p),
                 outs=[(sinks[6 + 2 * k], sinks[7 + 2 * k], sinks[k], sinks[3 + k]) for k in range(3)] if sinks else None)
             if sinks:
                 return (dx0,) + (None,) * 24
-            (dW1, db1), (dW2, db2) = res[3], res[4]
+            (dW1, db1), (dW2, db2) = nres
             return (dx0, None, None, None, None, None, None, None, None, *[g[2] for g in gates], *[g[3] for g in gates],
                     gates[0][0], gates[0][1], gates[1][0], gates[1][1], gates[2][0], gates[2][1], dW1, db1, dW2.view(1, Fh), db2)
         conv = dict(As=[da3[t] for t in steps], Bs=[P[t] for t in steps], M=3 * C, N=Fin, colsum=True)
@@ -283,6 +285,25 @@ class _TGCNWindow(torch.autograd.Function):
         conv_b = [db3[k * C:(k + 1) * C] for k in range(3)]
         return (dx0, None, None, None, None, None, None, None, None, *conv_w, *conv_b, dWz, dbz, dWr, dbr, dWh, dbh,
                 dW1, db1, dW2.view(1, Fh), db2)
+
+
+def _gate_contractions(kernels, D3, ds, Hprev, HRs, Ps, steps, C, Fin, more_calls):
+    """The window's gate contractions d_g^T [Hx | P] -> [C, C + Fin] (+ column sums), reduced in one launch together with
+    ``more_calls``.  ``D3`` [B, N, 3C] (the gate gradients as column blocks of one matrix, ``ds`` its views): [d_z | d_r] is ONE
+    operand against [H | P], which both gates share -- two workgroups per K slice on the same XCD read it once (knob
+    gemm_xcd_pair) -- and d_h goes against [H (.) R | P]; without it one contraction per gate.  Returns (R per gate, column sums
+    per gate, the results of ``more_calls``)."""
+    if D3 is None:
+        seconds = (Hprev, Hprev, HRs)
+        res = kernels.gemm_tn_form_batch(
+            [dict(As=[d[t] for t in steps], Bs=sec, B2s=Ps, M=C, N=C + Fin, nsplit=C, colsum=True) for d, sec in zip(ds, seconds)]
+            + list(more_calls))
+        return [res[k][0] for k in range(3)], [res[k][1] for k in range(3)], res[3:]
+    res = kernels.gemm_tn_form_batch(
+        [dict(As=[D3[t][:, :2 * C] for t in steps], Bs=Hprev, B2s=Ps, M=2 * C, N=C + Fin, nsplit=C, colsum=True),
+         dict(As=[ds[2][t] for t in steps], Bs=HRs, B2s=Ps, M=C, N=C + Fin, nsplit=C, colsum=True)] + list(more_calls))
+    (Rzr, cszr), (Rh, csh) = res[0], res[1]
+    return [Rzr[:C], Rzr[C:], Rh], [cszr[:C], cszr[C:], csh], res[2:]
 
 
 def window_cost_usable(model, graph, x0, edge_weight, targets) -> bool:
@@ -594,7 +615,12 @@ class _TGCNDynWindow(torch.autograd.Function):
         g = g_cost.reshape(1).contiguous().float()
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         from_p = X3 is None
-        dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), (None if from_p else new(B, N, 3 * C))
+        wide_d = from_p and kernels.STEP_WGRAD_ZR_TOGETHER and ctx.img_b is None      # as in _TGCNWindow.backward
+        if wide_d:
+            D3 = new(B, N, 3 * C)
+            dzl, drl, dhl, da3 = D3[:, :, :C], D3[:, :, C:2 * C], D3[:, :, 2 * C:], None
+        else:
+            dzl, drl, dhl, da3 = new(B, N, C), new(B, N, C), new(B, N, C), (None if from_p else new(B, N, 3 * C))
         dyt = new(B, N, Fh)
         dH, zbuf = new(2, N, C), new(2, N, Fin)
         WzT, WrT, WhT, W1T = ctx.packed_T
@@ -619,7 +645,7 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   H=None if t == 0 else Hn[t - 1], Hn=Hn[t], clamp_mask=mask[t], WzT=WzT, WrT=WrT, WhT=WhT,
                                   Wcat=Wcat, W1T=W1T, dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=None if from_p else da3[t], dH=dH[t & 1],
                                   z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t], w_image=ctx.img_b,
-                                  w_fold_t=ctx.w_fold_t if from_p else None, **kw)
+                                  w_fold_t=ctx.w_fold_t if from_p else None, ld_d=3 * C if wide_d else 0, **kw)
         dx0 = None
         if want_dx0:
             s0 = steps[0]
@@ -635,17 +661,15 @@ class _TGCNDynWindow(torch.autograd.Function):
         head_call = dict(As=[dyt[t] for t in rng], Bs=[Hn[t] for t in rng], M=Fh, N=C, b_op=kernels.GEMM_B_RELU, colsum=True, **dst(12, 13))
         if from_p:                                               # as in _TGCNWindow.backward
             Wcz, Wcr, Wch, bcz, bcr, bch, Wz_p, _, Wr_p, _, Wh_p, _ = ctx.params[:12]
-            ds, seconds = (dzl, drl, dhl), (Hprev, Hprev, [HR[t] for t in rng])
-            res = kernels.gemm_tn_form_batch(
-                [dict(As=[d[t] for t in rng], Bs=sec, B2s=[P[t] for t in rng], M=C, N=C + Fin, nsplit=C, colsum=True)
-                 for d, sec in zip(ds, seconds)] + [head_call])
+            Rg, csg, nres = _gate_contractions(kernels, D3 if wide_d else None, (dzl, drl, dhl), Hprev, [HR[t] for t in rng],
+                                               [P[t] for t in rng], rng, C, Fin, [head_call])
             gates = kernels.tgcn_unfold_gate_grads(
-                [res[k][0] for k in range(3)], [res[k][1] for k in range(3)], (Wcz, Wcr, Wch), (bcz, bcr, bch), (Wz_p, Wr_p, Wh_p),
+                Rg, csg, (Wcz, Wcr, Wch), (bcz, bcr, bch), (Wz_p, Wr_p, Wh_p),
                 outs=[(sinks[6 + 2 * k], sinks[7 + 2 * k], sinks[k], sinks[3 + k]) for k in range(3)] if sinks else None)
             ctx.steps = None
             if sinks:
                 return (dx0,) + (None,) * 18
-            dW1, db1 = res[3]
+            dW1, db1 = nres[0]
             return (dx0, None, None, None, None, *[g[2] for g in gates], *[g[3] for g in gates],
                     gates[0][0], gates[0][1], gates[1][0], gates[1][1], gates[2][0], gates[2][1], dW1, db1)
         conv = dict(As=[da3[t] for t in rng], Bs=[P[t] for t in rng], M=3 * C, N=Fin, colsum=True)

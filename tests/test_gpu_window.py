@@ -328,3 +328,35 @@ def test_window_on_data_the_fold_refuses_falls_back_to_the_reference_formulation
     finally:
         kernels.set_step_folded(was[0]), kernels.set_step_wgrad_from_p(was[1])
         kernels.step_fold_status_word(cuda).zero_()
+
+
+def test_gate_gradients_as_one_matrix_give_the_same_weight_gradients(cuda):
+    """kernels.STEP_WGRAD_ZR_TOGETHER: the backward step launches write d_z | d_r | d_h as the column blocks of ONE [N, 3C]
+    matrix (stg_tgcn_step_bwd_args::ld_d) and the window contracts [d_z | d_r] against [H | P] as one operand -- against one
+    contraction per gate over three [N, C] matrices: the same sums in the same split-K order, bit for bit."""
+    from stgraph_amd import kernels, temporal
+    n, e, B = 70_001, 500_000, 5
+    g, ew, targets, gen = _setup(cuda, n, e, B, 13)
+    x0 = torch.randn(n, 32, device=cuda, generator=gen).requires_grad_(True)
+    torch.manual_seed(3)
+    model = temporal.STGraphTGCN(32, 64, 1).to(cuda)
+    res = []
+    for on in (True, False):
+        kernels.set_step_wgrad_zr_together(on)
+        try:
+            model.zero_grad()
+            x0.grad = None
+            rec = []
+            kernels.enable_launch_timing(rec)
+            cost = temporal.window_cost_of(model, g, x0, ew, targets) / (B + 1)
+            cost.backward()
+        finally:
+            kernels.enable_launch_timing(None)
+            kernels.set_step_wgrad_zr_together(True)
+        kernels.check_step_fold_status(cuda)
+        assert sum(r[0] == "gemm_tn_form" for r in rec) == (4 if on else 5), [r[0] for r in rec]
+        res.append((cost.detach().clone(), x0.grad.clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        a, b = res[0][2][k], res[1][2][k]
+        assert float((a - b).abs().max()) <= 1e-6 * (float(b.abs().max()) + 1e-12), k
