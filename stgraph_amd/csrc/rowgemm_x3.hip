@@ -27,23 +27,6 @@ namespace {
 
 constexpr int kX3Waves = 8;
 
-__device__ __forceinline__ void mfma6x2(f32x4 &a0, f32x4 &a1, const Frag3 &w, const Frag3 &x0, const Frag3 &x1)
-{
-    // small terms first; the two tiles alternate so that no instruction waits for its predecessor's accumulator
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[0], x0.t[2], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[0], x1.t[2], a1, 0, 0, 0);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[2], x0.t[0], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[2], x1.t[0], a1, 0, 0, 0);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[1], x0.t[1], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[1], x1.t[1], a1, 0, 0, 0);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[0], x0.t[1], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[0], x1.t[1], a1, 0, 0, 0);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[1], x0.t[0], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[1], x1.t[0], a1, 0, 0, 0);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[0], x0.t[0], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.t[0], x1.t[0], a1, 0, 0, 0);
-}
-
 __device__ __forceinline__ void mfma6x4(f32x4 &a0, f32x4 &a1, f32x4 &b0, f32x4 &b1, const Frag3 &wa, const Frag3 &wb, const Frag3 &x0,
                                         const Frag3 &x1)
 {
