@@ -404,6 +404,8 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
         return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_bwd: C=%d Fin=%d Fh=%d not supported (64 / 32 / 32)", p->C, p->Fin, p->Fh);
     if (p->N < 0 || p->N > (int64_t)16 * 0x7ffffff0) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: bad N");
     if (p->head < 0 || p->head > 2) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: head must be 0, 1 or 2");
+    if (p->ld_d != 0 && p->ld_d != p->C && p->ld_d != 3 * p->C)
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: ld_d must be 0 / C ([N, C] each) or 3 C (column blocks of one [N, 3C] matrix)");
     if (p->N == 0) return 0;
     const bool gather = p->head != 0 && p->zn != nullptr;
     if (gather && (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm))
@@ -420,8 +422,6 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     if (p->link_row_ptr && (p->head != 1 || !p->link_other || !p->link_eid || !p->link_y || !p->link_logits || !p->link_target || !p->g_cost ||
                             !(p->link_inv_m > 0.f)))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: the link-loss arguments need head == 1, g_cost and every link_* field");
-    if (p->ld_d != 0 && p->ld_d != p->C && p->ld_d != 3 * p->C)
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: ld_d must be 0 / C ([N, C] each) or 3 C (column blocks of one [N, 3C] matrix)");
     const bool d_wide = p->ld_d == 3 * p->C;
     if (p->w_image && !p->node_ids && p->head >= 1 && p->clamp_mask && tuning().step_impl == 0 && !d_wide) {
         if (reinterpret_cast<uintptr_t>(p->w_image) & 15) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: w_image must be 16-byte aligned");
