@@ -3,48 +3,28 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Main line, N = 1: BASELINE.json configs[1] -- 2-layer GCN 128->128->128 on a synthetic CSR
-with |V| = 1M, |E| = 16M (uniform, duplicate-free, seed 1).  One step = one training epoch
-(forward, cross-entropy on the train mask, backward, Adam), inputs resident in HBM.
-`value` = edges*feat/s = sum of E x F over the aggregation launches executed in the timed region / wall time, whole job
-(SURVEY.md 8(d)).  The step executes 3 aggregations: the first layer's input carries no gradient, so it aggregates before
-its weight product and its backward needs none (nn/functional._InputLayer); `value_reference_formulation` counts the 4
-the same step has in the reference's order (2 layers, forward + backward), and that step is timed beside it
-(`reference_order`: 4 executed).
-N > 1: N independent replicas of that workload (a single-graph GCN does not shard:
-SURVEY.md 8(e) "replicas only"), `value` = sum over ranks.
+Output: the LAST stdout line is one JSON object of <= 6 KB (``final_line``): the contract's keys + ``roofline`` + ``cpu_baseline`` of
+the headline and a short summary per BASELINE config.  Everything long (per-kernel tables, byte models, sample descriptions) is the
+full record in ``bench_detail.json`` next to this script, also printed on an EARLIER stdout line prefixed ``# bench_detail ``.
 
-Every line also carries a "cora" object (BASELINE configs[0]: GCN on a Cora-shaped graph, epochs/s, plus
-"roofline_x1024": the aggregation at the Cora widths on 1024 disjoint replicas of that graph, fraction of the
-HBM roofline -- rank 0 only) and a "tgcn" object: BASELINE.json configs[3] (static-temporal TGCN,
-|V| = 50K, |E| = 500K, T = 1000, feat 32, hidden 64, backprop_every 25 => 40 BPTT windows)
-with the windows sharded over the N ranks and ONE RCCL all-reduce of the flattened gradient
-bucket per optimizer step -- the path the north star scales to 8 GPUs ("scaling": "strong":
-the epoch is fixed, ranks split its windows).
+N = 1 headline: BASELINE.json configs[1] -- 2-layer GCN 128->128->128 on a synthetic CSR with |V| = 1M, |E| = 16M (uniform,
+duplicate-free, seed 1).  One step = one training epoch (forward, cross-entropy on the train mask, backward, Adam), inputs
+resident in HBM.  `value` = edges*feat/s = sum of E x F over the aggregation launches EXECUTED in the timed region / wall time
+(SURVEY.md 8(d)); the step executes 3 aggregations (the first layer's input carries no gradient, nn/functional._InputLayer),
+`value_reference_formulation` counts the 4 of the reference's order.  "roofline": dominant kernel gcn_agg -- algorithmic bytes per
+launch over its mean launch time (HIP events on the launch stream inside the timed region); "traffic" = HBM bytes per launch from
+rocprofv3 --pmc child passes (tools/pmc_gcn.py; the committed passes under profiles/ if a child run fails);
+"roofline.north_star" = the aggregation at the Cora widths on 1024 replicas of the Cora-shaped graph (the >= 60 % target).
+"cpu_baseline": the same epoch in plain torch on the host (SURVEY.md 8(d) variant (i)), bounded sample, rank 0 at N = 1 only.
+The other configs ride along as objects: "cora" (configs[0]), "gat" (configs[2]: the default uniform-attention form and
+`general_form` = the emitted K0/K1/K2 at full width), "tgcn" (configs[3]), "dynamic" (configs[4]); each has its own achieved
+`roofline.frac`, `edges_feat_per_s` counted on executed launches, and `cpu_baseline`.
 
-A "dynamic" object carries BASELINE configs[4] (dynamic-temporal TGCN): epochs/s with the per-snapshot device
-CSR rebuild (its `value`), with every snapshot's CSR resident as the reference's NaiveGraph keeps them (both replayed
-from one HIP graph per BPTT window after an eager epoch; the rebuilds of a window's snapshots share the launches of one build)
-and on the dynamic edge stores (PCSRGraph, GPMAGraph: one merge launch per timestamp inside the same per-window HIP graphs),
-windows sharded over the ranks; `csr_build_share` = 1 - resident / rebuild.  At N = 1 its `value` is quoted at BASELINE.md's own
-T = 40; the T = 160 stream the multi-rank runs shard is the `T160` sub-object (and the `value` at N > 1).
-
-A "gat" object carries BASELINE configs[2] (GAT, 8 heads, |V| = 256K, |E| = 8M): one GATConv layer forward +
-backward(R) with a per-kernel table, and the 2-layer model of benchmarking/gat/seastar/model.py as epochs/s, eagerly and
-with the whole epoch replayed from a HIP graph (its `value`; rank 0 only); its "roofline" names the layer's dominant launch by time.
-
-"roofline": dominant kernel gcn_agg -- algorithmic bytes per launch over its
-mean launch time, measured with HIP events on the launch stream inside the timed region; "traffic" = HBM bytes per
-launch from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate child runs of tools/pmc_gcn.py made by this
-script at N = 1, corrected as the microarchitecture guide prescribes; the committed passes under profiles/ if a child
-run fails).  "roofline.north_star" is the figure the north star's >= 60 % target is stated on: the fused GCN
-aggregation forward + backward at the Cora widths on 1024 replicas of the Cora-shaped graph.  Every config object
-("cora", "gat", "tgcn", "dynamic") carries its own "roofline" whose "frac" is ACHIEVED -- the bytes this build moves over the measured
-time over the peak -- next to the byte model of the reference's formulation, and its own "cpu_baseline" (a bounded sample of the same
-workload in plain torch on the host, with the host's sockets / physical / logical cores).
-"cpu_baseline": the same training epoch (forward, loss, backward, Adam) in plain torch on this host's cores --
-torch.sparse_csr_tensor(A_hat) @ dense, SURVEY.md 8(d) variant (i) -- on a bounded sample (rank 0, N = 1 only), with
-the C oracle's OpenMP aggregation (variant (ii)) beside it; "cora.cpu_baseline" is BASELINE configs[0]'s CPU path.
+N > 1 headline: BASELINE.json configs[3], the path that shards: one step = one training epoch of the static-temporal
+TGCN (T = 1000, 40 BPTT windows dealt round-robin to the ranks, ONE RCCL all-reduce of the 133 KB gradient bucket per optimizer
+step); `value` = whole-job epochs/s, "scaling": "strong".  cfg5 (windows sharded) and N independent cfg2 replicas ("gcn_replicas",
+weak) are sub-objects.  `python3 bench.py --gpus N` without a launcher starts its own N ranks as child processes
+(torch.distributed.run) before touching the GPU; under the driver's torch.distributed.run form it reads RANK / WORLD_SIZE.
 """
 from __future__ import annotations
 
@@ -67,6 +47,157 @@ import torch.nn.functional as F  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (f32 in, exact f32): same guide, Matrix cores table
+
+FINAL_LINE_MAX_BYTES = 6144     # the driver reads the LAST stdout line; everything long goes to bench_detail.json
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+CPU_THREADS_RULE = ("cfg2/cfg3 (few large ops): every usable logical CPU; cfg4/cfg5 (thousands of small ops): min(32, usable); "
+                    "cfg1 (2708 vertices): faster of {16, all}")
+
+
+def _sig(x, digits=6):
+    """Floats to ``digits`` significant digits (a machine-read line carries no 17-digit noise); NaN / inf -> None."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _clip(x, limit, by_key=None, key=None):
+    """Every string of a nested record cut to ``limit`` characters (``by_key``: per-key limits): a machine-read line is no place for prose."""
+    if isinstance(x, str):
+        n = (by_key or {}).get(key, limit)
+        return x if len(x) <= n else x[:n - 3] + "..."
+    if isinstance(x, dict):
+        return {k: _clip(v, limit, by_key, k) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_clip(v, limit, by_key, key) for v in x]
+    return x
+
+
+def _pick(d, *keys):
+    """Sub-dict of the keys present (and not None) in ``d``; {} for a missing object."""
+    return {k: d[k] for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+def _config_summary(obj, extra=()):
+    """<= 400 bytes per config: value, unit, achieved roofline fraction + its kernel, the CPU baseline's value."""
+    if not isinstance(obj, dict):
+        return None
+    roof, cpu = obj.get("roofline") or {}, obj.get("cpu_baseline") or {}
+    out = {"metric": obj.get("metric"), "value": obj.get("value"),
+           "edges_feat_per_s": obj.get("edges_feat_per_s"),
+           "roofline": _pick(roof, "bound", "frac", "kernel"),
+           "cpu_baseline": _pick(cpu, "value", "cores")}
+    if roof.get("x1024_frac") is not None:          # cfg1: the single 2708-vertex graph is launch bound; its bandwidth-bound variant
+        out["roofline"]["x1024_frac"] = roof["x1024_frac"]
+    if isinstance(out["roofline"].get("kernel"), str):
+        out["roofline"]["kernel"] = out["roofline"]["kernel"][:64]
+    for k in extra:
+        if obj.get(k) is not None:
+            out[k] = obj[k]
+    return {k: v for k, v in out.items() if v not in (None, {})}
+
+
+def final_line(detail):
+    """The ONE machine-read stdout line (contract: task statement; <= FINAL_LINE_MAX_BYTES) from the full ``detail``
+    record: the contract's keys, ``roofline`` and ``cpu_baseline`` of the headline, and a short summary per config.
+    Paragraph-length strings and per-kernel tables stay in bench_detail.json."""
+    roof = detail.get("roofline") or {}
+    cpu = detail.get("cpu_baseline")
+    line = {k: detail.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                       "scaling", "vs_baseline", "dtype", "data")}
+    cfg = detail.get("config") or {}
+    line["config"] = _pick(cfg, "workload", "parallelism", "aggregations_executed_per_step", "edges_feat_per_step",
+                           "windows_per_epoch", "optimizer_steps_per_epoch", "backprop_every")
+    line["roofline"] = _pick(roof, "bound", "achieved", "peak", "unit", "frac", "kernel", "algorithmic_bytes_per_launch",
+                             "flops_per_launch", "mean_launch_ms", "launches_timed", "gcn_agg_share_of_step", "hbm_frac")
+    line["roofline"]["traffic"] = roof.get("traffic")
+    if roof.get("north_star"):
+        line["roofline"]["north_star"] = _pick(roof["north_star"], "frac", "frac_F16", "frac_F7")
+    if cpu:
+        host = cpu.get("host") or {}
+        line["cpu_baseline"] = _pick(cpu, "value", "unit", "cores", "kind", "seconds_per_epoch")
+        line["cpu_baseline"]["sample"] = (cpu.get("sample_short") or cpu.get("sample") or "")[:160]
+        line["cpu_baseline"]["host"] = (f"{host.get('sockets')} x {host.get('cpu_model')}, {host.get('physical_cores')} cores / "
+                                        f"{host.get('logical_cores')} threads")[:96]
+    else:
+        line["cpu_baseline"] = None
+    for k in ("value_reference_formulation", "epochs_per_s"):
+        if detail.get(k) is not None:
+            line[k] = detail[k]
+    if detail.get("allreduce"):
+        line["allreduce"] = _pick(detail["allreduce"], "bytes", "calls_per_epoch", "share_of_epoch", "in_graph")
+    if detail.get("process_group"):
+        pg = detail["process_group"]
+        line["process_group"] = {"world_size": pg.get("world_size"), "backend": pg.get("backend"),
+                                 "distinct_devices": pg.get("distinct_devices"),
+                                 "devices": [str(r.get("name"))[:24] for r in pg.get("ranks", [])][:8]}
+    configs = {}
+    extras = {"cora": ("eager_epochs_per_s",), "gat": ("ms_per_epoch", "general_form"),
+              "tgcn": ("us_per_snapshot", "n_gpus"), "dynamic": ("csr_build_share", "resident_epochs_per_s", "T"),
+              "gcn_replicas": ("ms_per_step", "n_gpus")}
+    for name, ex in extras.items():
+        summ = _config_summary(detail.get(name), ex)
+        if summ:
+            configs[name] = summ
+    line["configs"] = configs
+    line["detail_file"] = os.path.basename(DETAIL_FILE)
+    line = _clip(_sig(line), 96, {"workload": 240, "metric": 120, "parallelism": 160, "sample": 160})
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > FINAL_LINE_MAX_BYTES:        # never let a summary cost the measurement: values only, then fail loudly
+        line["configs"] = {k: _pick(v, "value") for k, v in line["configs"].items()}
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > FINAL_LINE_MAX_BYTES:
+        raise RuntimeError(f"final bench line is {len(text)} bytes (limit {FINAL_LINE_MAX_BYTES})")
+    return text
+
+
+def emit(detail):
+    """bench_detail.json next to this script, the same record on an EARLIER stdout line, then the final line."""
+    full = json.dumps(_sig(detail, 9), allow_nan=False)
+    try:
+        with open(DETAIL_FILE, "w") as f:
+            f.write(full + "\n")
+        for extra_dir in (os.path.join(ROOT, "gpurun_out"),):
+            if os.path.isdir(extra_dir):
+                with open(os.path.join(extra_dir, "bench_detail.json"), "w") as f:
+                    f.write(full + "\n")
+    except OSError as exc:
+        progress(f"could not write {DETAIL_FILE}: {exc}")
+    text = final_line(detail)
+    print("# bench_detail " + full, flush=True)
+    progress(f"line sizes: detail {len(full)} bytes, final {len(text)} bytes")
+    print(text, flush=True)
+
+
+def launch_ranks(gpus, argv):
+    """``python3 bench.py --gpus N`` without a launcher (WORLD_SIZE unset, N > 1): start the N ranks as CHILD processes through
+    torch.distributed.run -- before this process has touched the GPU, never an exec -- relay their output and return their
+    status.  The driver's own ``python -m torch.distributed.run ... bench.py --gpus N`` form sets WORLD_SIZE and never comes here."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    progress(f"--gpus {gpus} without WORLD_SIZE: starting {gpus} ranks: {' '.join(cmd[1:8])} ...")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 class GCN(nn.Module):
@@ -252,7 +383,7 @@ def cpu_baseline_epoch_gcn(meta, ntrain, labels, executed_per_step, budget_s=20.
                         "line's `value` (the CPU epoch itself performs the reference formulation's 4 sparse products: "
                         "value_reference_formulation)",
             "value_reference_formulation": meta["agg_launches_per_step"] * meta["e"] * meta["feat"] / sec,
-            "cores": threads, "kind": "port", "seconds_per_epoch": sec,
+            "cores": threads, "threads_rule": CPU_THREADS_RULE, "kind": "port", "seconds_per_epoch": sec,
             "sample": f"{timed} full training epoch(s) of the same model and graph (|V|={meta['n']}, |E|={meta['e']}, "
                       f"{meta['feat']}->{meta['feat']}->{meta['feat']}) in plain torch on the host: "
                       "torch.sparse_csr_tensor(A_hat) @ dense per layer, cross-entropy, backward, Adam "
@@ -350,7 +481,7 @@ def cpu_baseline_tgcn(g, ew, targets, n, e, T, feat, hidden, B, budget_s=12.0):
         cost.backward()
         opt.step()
     sps, steps = _cpu_window_sample(run_window, B, budget_s)
-    return {"value": 1.0 / (sps * T), "unit": "epochs/s", "cores": threads, "kind": "port",
+    return {"value": 1.0 / (sps * T), "unit": "epochs/s", "cores": threads, "threads_rule": CPU_THREADS_RULE, "kind": "port",
             "seconds_per_snapshot": sps,
             "sample": f"one BPTT window of {steps} snapshot(s) (of the epoch's {T}: forward, loss, backward through time, Adam) "
                       f"on the same graph (|V|={n}, |E|={e}, edge weights) and model shape in plain torch on the host: "
@@ -394,7 +525,7 @@ def cpu_baseline_dynamic(snaps, pn_edges, pn_targets, n, T, feat, hidden, B, bud
         cost.backward()
         opt.step()
     sps, steps = _cpu_window_sample(run_window, use, budget_s)
-    return {"value": 1.0 / (sps * (T - 1)), "unit": "epochs/s", "cores": threads, "kind": "port",
+    return {"value": 1.0 / (sps * (T - 1)), "unit": "epochs/s", "cores": threads, "threads_rule": CPU_THREADS_RULE, "kind": "port",
             "seconds_per_snapshot": sps,
             "sample": f"one BPTT window of {steps} snapshot(s) of the T = {T} stream (|V|={n}; one un-weighted A_hat per snapshot, "
                       "built outside the timed region) in plain torch on the host: sparse_csr @ dense TGCN cell, link head "
@@ -437,7 +568,7 @@ def cpu_baseline_gat(g, feats, labels, ntrain, n, e, fin, H, D, classes, budget_
         if time.time() - t_start > budget_s:
             break
     sec = float(np.mean(dur))
-    return {"value": 1.0 / sec, "unit": "epochs/s", "cores": threads, "kind": "port", "seconds_per_epoch": sec,
+    return {"value": 1.0 / sec, "unit": "epochs/s", "cores": threads, "threads_rule": CPU_THREADS_RULE, "kind": "port", "seconds_per_epoch": sec,
             "sample": f"{len(dur)} full training epoch(s) of the same 2-layer model and graph (|V|={n}, |E|={e}, "
                       f"{fin} -> {H} x {D} -> {classes}) in plain torch on the host: fc, mean aggregation as "
                       "torch.sparse_csr_tensor @ dense, ELU, cross-entropy, backward, Adam",
@@ -533,7 +664,7 @@ def cora_run(device, epochs=200, cpu_baseline=False):
             tried[th] = (sec, timed)
         threads = min(tried, key=lambda k: tried[k][0])
         sec, timed = tried[threads]
-        out["cpu_baseline"] = {"value": 1.0 / sec, "unit": "epochs/s", "cores": threads, "kind": "port",
+        out["cpu_baseline"] = {"value": 1.0 / sec, "unit": "epochs/s", "cores": threads, "threads_rule": CPU_THREADS_RULE, "kind": "port",
                                "edges_feat_per_s": 2 * e * (16 + 7) / sec, "ms_per_epoch": sec * 1e3,
                                "ms_per_epoch_by_threads": {str(k): v[0] * 1e3 for k, v in tried.items()},
                                "sample": f"{timed} epochs of the same model on the same graph in plain torch on the host "
@@ -614,158 +745,191 @@ class GAT(nn.Module):
         return self.gat_layers[-1](self.g, h).mean(1)
 
 
+# launches whose record's `units` field is the edges*feat the launch actually gathers (sum of E x F_launch)
+TGCN_DENSE = ("tgcn_step_fwd", "tgcn_step_bwd", "gemm_tn_form", "gemm_tn", "gemm_tn_multi", "gemm_tn_wide", "rowgemm")
+AGG_LAUNCHES = ("gcn_agg", "gcn_agg_transform", "gat_k1", "gat_k1_uniform", "gat_bwd", "gat_bwd_uniform")
+GAT_DENSE = ("gat_fc", "gat_fc_out", "gat_bwd_gw", "gemm_tn", "gemm_tn_multi", "rowgemm", "rowgemm_wide")
+
+
+def executed_edges_feat(records):
+    """Sum of E x F over the aggregation launches in ``records`` (kernels.enable_launch_timing tuples)."""
+    return float(sum(r[4] for r in records if r[0] in AGG_LAUNCHES))
+
+
+def kernel_table(records, iters, dense):
+    """Per launch name: launches per iteration, mean time, the bytes it moves / its flops (summed over the launches, so that
+    one name covering two shapes is priced on what all of them did), the fraction of the roofline that bounds it."""
+    tab = {}
+    for name, a, b, nbytes, units in records:
+        d = tab.setdefault(name, {"ms": 0.0, "bytes": 0.0, "units": 0.0, "n": 0})
+        d["ms"] += a.elapsed_time(b)
+        d["bytes"] += nbytes
+        d["units"] += units
+        d["n"] += 1
+    out = {}
+    for k, v in tab.items():
+        ent = {"launches_per_iter": v["n"] / iters, "mean_ms": v["ms"] / v["n"], "bytes": v["bytes"] / v["n"]}
+        if k in dense:
+            tf = v["units"] / v["ms"] / 1e9
+            ent.update({"bound": "mfma", "flops": v["units"] / v["n"], "achieved_TFLOPs": tf, "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS,
+                        "frac": tf / FP32_MFMA_PEAK_TFLOPS, "hbm_frac": v["bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS})
+        else:
+            gb = v["bytes"] / v["ms"] / 1e6
+            ent.update({"bound": "hbm", "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS})
+        out[k] = ent
+    return out
+
+
 def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer_iters=10, epochs=23, cpu_baseline=False):
     """BASELINE configs[2]: (a) one GATConv(64 -> 8 x 64) forward + backward with per-kernel HIP-event times, each
-    against its SURVEY.md 8(d) byte model; (b) the 2-layer model of benchmarking/gat/seastar/model.py
+    against the bytes it moves; (b) the 2-layer model of benchmarking/gat/seastar/model.py
     (GATConv(64, 64, 8 heads, elu) -> GATConv(512, classes, 1 head), mean over heads), cross-entropy on the first 60 %,
-    Adam(5e-3, wd 5e-4) as gat/seastar/train.py runs it: epochs/s by the reference's timing rule."""
+    Adam(5e-3, wd 5e-4) as gat/seastar/train.py runs it: epochs/s by the reference's timing rule.  Both are measured twice:
+    in the default form (uniform attention: the vertex function's scores are identically +0, SURVEY.md D2, so K1 / K2 run at
+    the input width) and as ``general_form`` -- the emitted K0 / K1 / K2 as hand-written units at width H x D, what any
+    non-degenerate edge softmax runs (kernels.set_gat_uniform_form(False), set_gat_uniform_backward(False))."""
     from stgraph_amd import kernels
+    from stgraph_amd.capture import CapturedTrainStep
     from stgraph_amd.graph import StaticGraph
     from stgraph_amd.nn import functional as SF
     from stgraph_amd.nn.pytorch.static.gat_conv import GATConv
     src, dst = synthetic_graph(n, e, 2, device)
     g = StaticGraph((src, dst), None, n, device=device, sort_inplace=False)
     gen = torch.Generator(device=device).manual_seed(2)
-    torch.manual_seed(2)
-    conv = GATConv(fin, D, H).to(device)
-    x = torch.randn(n, fin, device=device, generator=gen).requires_grad_(True)
+    xl = torch.randn(n, fin, device=device, generator=gen)
     R = torch.randn(n, H, D, device=device, generator=gen)
-    # forward + backward of the LAYER: the upstream gradient R is handed to backward() as it is (a `(out * R).sum()`
-    # loss costs three more passes over [N, H, D] each way that are not the layer's)
-    for _ in range(3):
-        conv(g, x).backward(R)
-    rec = []
-    kernels.enable_launch_timing(rec)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(layer_iters):
-        conv.zero_grad()
-        x.grad = None
-        conv(g, x).backward(R)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / layer_iters
-    kernels.enable_launch_timing(None)
-    tab = {}
-    for name, a, b, nbytes, units in rec:
-        d = tab.setdefault(name, {"ms": [], "bytes": nbytes, "units": units})
-        d["ms"].append(a.elapsed_time(b))
-    # every kernel against the roofline that bounds it: the dense ones (fc + projection epilogue, the split-K weight
-    # gradients, row GEMMs) against the fp32 matrix rate (157.3 TFLOP/s: v_mfma_f32_*_f32, the guide's F32 row), the
-    # gather / elementwise ones against HBM on the bytes they actually MOVE
-    dense = ("gat_fc", "gat_fc_out", "gat_bwd_gw", "gemm_tn", "gemm_tn_multi", "rowgemm", "rowgemm_wide")
-    ktab = {}
-    for k, v in tab.items():
-        ms = float(np.mean(v["ms"]))
-        ent = {"launches_per_iter": len(v["ms"]) / layer_iters, "mean_ms": ms}
-        if k in dense:
-            ent.update({"bound": "mfma", "flops": v["units"], "achieved_TFLOPs": v["units"] / ms / 1e9,
-                        "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS, "frac": v["units"] / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS,
-                        "bytes": v["bytes"], "frac_of_hbm_peak_for_reference": v["bytes"] / ms / 1e6 / HBM_PEAK_GBS})
-        else:
-            ent.update({"bound": "hbm", "bytes": v["bytes"], "achieved_GBps": v["bytes"] / ms / 1e6,
-                        "frac": v["bytes"] / ms / 1e6 / HBM_PEAK_GBS})
-        ktab[k] = ent
-    if "gat_k0" in ktab and ktab["gat_k0"]["frac"] > 1.0:
-        # finite scores: A == 1.0f, S == in-degree (the literal `emb - max([emb])` of the vertex function is +0), so K0
-        # writes S from the row offsets and visits no edge: priced on what it moves, not on the emitted unit's model
-        moved = 4 * n * H + 8 * n
-        ktab["gat_k0"].update({"bytes": moved, "achieved_GBps": moved / ktab["gat_k0"]["mean_ms"] / 1e6,
-                               "frac": moved / ktab["gat_k0"]["mean_ms"] / 1e6 / HBM_PEAK_GBS,
-                               "bytes_are": "moved (S from the row offsets; all scores finite: A neither written nor read)",
-                               "note": "a latency-bound pass over N rows"})
-    if "gat_bwd" in ktab:   # the factored backward does not perform K2's second E*H*D gather: priced on what it moves
-        moved = 4 * e * H * D + 12 * e * H + 16 * n * H * D
-        emitted = ktab["gat_bwd"]["bytes"]
-        ktab["gat_bwd"].update({"bytes": moved, "achieved_GBps": moved / ktab["gat_bwd"]["mean_ms"] / 1e6,
-                                "frac": moved / ktab["gat_bwd"]["mean_ms"] / 1e6 / HBM_PEAK_GBS,
-                                "bytes_are": "moved by the factored form (one E*H*D gather)",
-                                "emitted_unit_bytes_SURVEY_8d": emitted})
-    if "gat_k1_scored" in ktab:
-        ktab["gat_k1_scored"].update({"note": "the full-width K1 that replaces the result when some score is inf / NaN: the "
-                                              "device flag says none is, the launch returns at once (bytes: the flag)"})
-    if "gat_k1_uniform" in ktab:
-        ktab["gat_k1_uniform"].update({
-            "bytes_are": "moved: K1 at the input width (all scores finite: out = (mean of x over in-neighbours) W^T, the "
-                         "product is gat_fc_out)",
-            "emitted_unit_bytes_SURVEY_8d": kernels.gat_algorithmic_bytes(n, e, H, D)["gat_k1"],
-            "emitted_unit_equivalent_GBps": kernels.gat_algorithmic_bytes(n, e, H, D)["gat_k1"] / 1e6 / (
-                ktab["gat_k1_uniform"]["mean_ms"] + ktab.get("gat_fc_out", {}).get("mean_ms", 0.0))})
-    moved_layer = sum(v["bytes"] * v["launches_per_iter"] for v in ktab.values())
-    hbm_kernels = {k: v for k, v in ktab.items() if v["bound"] == "hbm"}
-    dom_name = max(hbm_kernels, key=lambda k: hbm_kernels[k]["mean_ms"] * hbm_kernels[k]["launches_per_iter"])
-    k1 = ktab[dom_name]
-    dom_symbol = {"gat_k1": "stg::gat_k1_kernel", "gat_k1_uniform": "stg::gat_k1_kernel",
-                  "gat_bwd": "stg::gat_bwd_fact_h8d64_kernel (+ its per-vertex prepass stg::gat_bwd_prepass_h8d64_kernel, "
-                             "one C-ABI call: stg_gat_bwd_factored)",
-                  "gat_bwd_uniform": "stg::gat_ubwd_t_kernel + stg::gat_ubwd_src_kernel (the backward unit in the uniform-attention "
-                                     "form, one C-ABI call: stg_gat_bwd_uniform_edges; bytes = what the two passes move)",
-                  "gat_bwd_prepass": "stg::gat_bwd_prepass_h8d64_kernel"}.get(dom_name, dom_name)
-    layer = {"ms_per_fwd_bwd": dt * 1e3, "edges_feat_per_s": 2 * e * H * D / dt, "kernels": ktab}
-    del conv, x, R
-    torch.cuda.empty_cache()
-
-    # (b) 2-layer model, training epochs
-    torch.manual_seed(2)
     feats = torch.randn(n, fin, device=device, generator=gen)
     labels = torch.randint(0, classes, (n,), device=device, generator=gen)
     ntrain = int(0.6 * n)
-    from stgraph_amd.capture import CapturedTrainStep
-    modes = {}
-    for mode in ("eager", "hip_graph"):
+    emitted = kernels.gat_algorithmic_bytes(n, e, H, D)
+
+    def measure_layer():
+        """forward + backward of the LAYER: the upstream gradient R is handed to backward() as it is (a `(out * R).sum()`
+        loss costs three more passes over [N, H, D] each way that are not the layer's)."""
         torch.manual_seed(2)
-        model = GAT(g, 1, fin, D, classes, [H, 1], F.elu).to(device)
-        # gat/seastar/train.py defaults; captured mode: the same rule as torch's single-kernel capturable Adam
-        opt = (torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4, capturable=True, fused=True)
-               if mode == "hip_graph" else torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4))
-
-        def step():
-            model.train()
-            logits = model(feats)
-            loss = SF.cross_entropy(logits, labels, ntrain)    # = CrossEntropyLoss()(logits[train_mask], labels[train_mask])
-            opt.zero_grad(set_to_none=False)
-            loss.backward()
-            opt.step()
-            return loss.detach()
-
-        run = step if mode == "eager" else CapturedTrainStep(step, opt, list(model.parameters()))
-        dur = []
-        for ep in range(epochs):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            loss = run()
-            torch.cuda.synchronize()
-            if ep >= 3:
-                dur.append(time.perf_counter() - t0)
-        modes[mode] = {"epochs_per_s": 1.0 / float(np.mean(dur)), "ms_per_epoch": float(np.mean(dur)) * 1e3,
-                       "final_loss": float(loss)}
-        del model, opt, run
+        conv = GATConv(fin, D, H).to(device)
+        x = xl.clone().requires_grad_(True)
+        for _ in range(3):
+            conv(g, x).backward(R)
+        rec = []
+        kernels.enable_launch_timing(rec)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(layer_iters):
+            conv.zero_grad()
+            x.grad = None
+            conv(g, x).backward(R)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / layer_iters
+        kernels.enable_launch_timing(None)
+        ktab = kernel_table(rec, layer_iters, GAT_DENSE)
+        if "gat_k0" in ktab and ktab["gat_k0"]["frac"] > 1.0:
+            # finite scores: A == 1.0f, S == in-degree, so K0 writes S from the row offsets and visits no edge: priced on what it moves
+            moved = 4 * n * H + 8 * n
+            ktab["gat_k0"].update({"bytes": moved, "achieved_GBps": moved / ktab["gat_k0"]["mean_ms"] / 1e6,
+                                   "frac": moved / ktab["gat_k0"]["mean_ms"] / 1e6 / HBM_PEAK_GBS})
+        if "gat_bwd" in ktab:   # the factored backward does not perform K2's second E*H*D gather: priced on what it moves
+            moved = 4 * e * H * D + 12 * e * H + 16 * n * H * D
+            ktab["gat_bwd"].update({"bytes": moved, "achieved_GBps": moved / ktab["gat_bwd"]["mean_ms"] / 1e6,
+                                    "frac": moved / ktab["gat_bwd"]["mean_ms"] / 1e6 / HBM_PEAK_GBS,
+                                    "emitted_unit_bytes_SURVEY_8d": emitted["gat_bwd"]})
+        if "gat_k1_uniform" in ktab:
+            ktab["gat_k1_uniform"]["emitted_unit_bytes_SURVEY_8d"] = emitted["gat_k1"]
+        hbm = {k: v for k, v in ktab.items() if v["bound"] == "hbm"}
+        dom = max(hbm, key=lambda k: hbm[k]["mean_ms"] * hbm[k]["launches_per_iter"])
+        ef = executed_edges_feat(rec) / layer_iters
+        del conv, x
         torch.cuda.empty_cache()
+        return {"ms_per_fwd_bwd": dt * 1e3, "edges_feat_per_s": ef / dt, "edges_feat_executed_per_fwd_bwd": ef,
+                "edges_feat_per_s_reference_formulation": 2 * e * H * D / dt, "dominant_kernel": dom,
+                "moved_bytes_frac_of_hbm_peak": sum(v["bytes"] * v["launches_per_iter"] for v in ktab.values()) / dt / 1e9 / HBM_PEAK_GBS,
+                "kernels": ktab}
+
+    def measure_model(modes_wanted):
+        modes = {}
+        ef_epoch = None
+        for mode in modes_wanted:
+            torch.manual_seed(2)
+            model = GAT(g, 1, fin, D, classes, [H, 1], F.elu).to(device)
+            # gat/seastar/train.py defaults; captured mode: the same rule as torch's single-kernel capturable Adam
+            opt = (torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4, capturable=True, fused=True)
+                   if mode == "hip_graph" else torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4))
+
+            def step():
+                model.train()
+                logits = model(feats)
+                loss = SF.cross_entropy(logits, labels, ntrain)    # = CrossEntropyLoss()(logits[train_mask], labels[train_mask])
+                opt.zero_grad(set_to_none=False)
+                loss.backward()
+                opt.step()
+                return loss.detach()
+
+            if ef_epoch is None:            # the aggregation launches of ONE epoch, from an eager pass with launch records
+                rec = []
+                kernels.enable_launch_timing(rec)
+                step()
+                torch.cuda.synchronize()
+                kernels.enable_launch_timing(None)
+                ef_epoch = executed_edges_feat(rec)
+                del rec
+            run = step if mode == "eager" else CapturedTrainStep(step, opt, list(model.parameters()))
+            dur = []
+            for ep in range(epochs):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loss = run()
+                torch.cuda.synchronize()
+                if ep >= 3:
+                    dur.append(time.perf_counter() - t0)
+            modes[mode] = {"epochs_per_s": 1.0 / float(np.mean(dur)), "ms_per_epoch": float(np.mean(dur)) * 1e3,
+                           "final_loss": float(loss), "epochs_timed": len(dur)}
+            del model, opt, run
+            torch.cuda.empty_cache()
+        return modes, ef_epoch
+
+    layer = measure_layer()
+    modes, ef_epoch = measure_model(("eager", "hip_graph"))
     sec = modes["hip_graph"]["ms_per_epoch"] * 1e-3
-    ef_epoch = 2 * e * (H * D + classes)                        # K1 + K2 of both layers
+    # the same layer and model with the emitted units at full width (edge-softmax fused aggregation as BASELINE configs[2] names it)
+    progress("cfg3: GAT, general form (K0 / K1 / K2 at width H x D)")
+    kernels.set_gat_uniform_form(False)
+    kernels.set_gat_uniform_backward(False)
+    try:
+        g_layer = measure_layer()
+        g_modes, g_ef_epoch = measure_model(("hip_graph",))
+    finally:
+        kernels.set_gat_uniform_form(True)
+        kernels.set_gat_uniform_backward(True)
+    g_sec = g_modes["hip_graph"]["ms_per_epoch"] * 1e-3
+    g_dom = g_layer["kernels"][g_layer["dominant_kernel"]]
+    general = {"what": "set_gat_uniform_form(False) + set_gat_uniform_backward(False): K0 / K1 / K2 as hand-written units at width H x D",
+               "metric": "epochs/s", "value": 1.0 / g_sec, "ms_per_epoch": g_sec * 1e3,
+               "edges_feat_per_s": g_ef_epoch / g_sec, "layer_ms_per_fwd_bwd": g_layer["ms_per_fwd_bwd"],
+               "dominant_kernel": g_layer["dominant_kernel"], "dominant_kernel_frac": g_dom["frac"],
+               "dominant_kernel_mean_ms": g_dom["mean_ms"], "layer": g_layer}
     if cpu_baseline:
         progress("cfg3: CPU baseline")
     cpu = cpu_baseline_gat(g, feats, labels, ntrain, n, e, fin, H, D, classes) if cpu_baseline else None
+    k1 = layer["kernels"][layer["dominant_kernel"]]
     return {"cpu_baseline": cpu,
             "workload": f"GAT |V|={n} |E|={e} in={fin} heads={H} D={D} negative_slope=0.2 (BASELINE configs[2]); "
                         f"layer = GATConv({fin}, {D}, {H}) forward + backward; model = GATConv({fin},{D},{H},elu) -> "
                         f"GATConv({H * D},{classes},1), cross-entropy, Adam (benchmarking/gat/seastar)",
-            "metric": "epochs/s", "value": 1.0 / sec, "ms_per_epoch": sec * 1e3, "epochs_timed": len(dur),
-            "value_is": "the whole epoch (forward + loss + backward + Adam) replayed from one HIP graph, as for the Cora "
-                        "configuration; the eager loop of the reference script beside it (its ~ 60 launches per epoch "
-                        "leave the device idle 5-15 % depending on the host)",
+            "metric": "epochs/s", "value": 1.0 / sec, "ms_per_epoch": sec * 1e3, "epochs_timed": modes["hip_graph"]["epochs_timed"],
+            "value_is": "the whole epoch (forward + loss + backward + Adam) replayed from one HIP graph; uniform-attention form "
+                        "(identical results: scores are +0, SURVEY.md D2); general_form = the emitted units at full width",
             "eager": modes["eager"], "hip_graph": modes["hip_graph"],
-            "edges_feat_per_s": ef_epoch / sec, "final_loss": modes["hip_graph"]["final_loss"],
+            "edges_feat_per_s": ef_epoch / sec, "edges_feat_executed_per_epoch": ef_epoch,
+            "edges_feat_per_s_reference_formulation": 2 * e * (H * D + classes) / sec,
+            "final_loss": modes["hip_graph"]["final_loss"],
+            "general_form": {k: v for k, v in general.items() if k != "layer"}, "general_form_layer": g_layer,
             "layer": layer,
-            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": dom_symbol,
-                         "kernel_is": "the layer's dominant launch by time (layer.kernels has every one)",
-                         "achieved": k1.get("achieved_GBps"),
-                         "frac": k1.get("frac"),
-                         "algorithmic_bytes_per_launch": k1.get("bytes"),
-                         "mean_launch_ms": k1.get("mean_ms"),
-                         "layer_frac_on_moved_bytes": moved_layer / dt / 1e9 / HBM_PEAK_GBS,
-                         "layer_bytes_model": "bytes every native launch of the layer moves (forward + backward, dense kernels "
-                                              "included) over the WHOLE layer time; the dense kernels are MFMA-bound: see "
-                                              "layer.kernels[*].bound"}}
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": layer["dominant_kernel"],
+                         "kernel_is": "the layer's dominant launch by time, priced on the bytes it moves (layer.kernels has every one)",
+                         "achieved": k1.get("achieved_GBps"), "frac": k1.get("frac"),
+                         "algorithmic_bytes_per_launch": k1.get("bytes"), "mean_launch_ms": k1.get("mean_ms"),
+                         "layer_frac_on_moved_bytes": layer["moved_bytes_frac_of_hbm_peak"],
+                         "general_form": {"kernel": g_layer["dominant_kernel"], "frac": g_dom["frac"], "mean_launch_ms": g_dom["mean_ms"]}}}
 
 
 # ----------------------------------------------------------------------------- TGCN (cfg 4)
@@ -837,13 +1001,14 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
                                                            rank=rank, world=world, timed_comm=True), 1)
     kernels.enable_launch_timing(None)
     comm = bucket.collect_comm_time()
-    ktab = {}
-    for name, a, b, nbytes, _ in records:                        # per-kernel HIP-event times of the eager epoch
-        d = ktab.setdefault(name, {"ms": [], "bytes": nbytes})
-        d["ms"].append(a.elapsed_time(b))
+    # per-kernel HIP-event times of the eager epoch, each against the roofline that bounds it: the step launches and the
+    # weight-gradient contractions run on the fp32-input matrix instruction (157.3 TFLOP/s), everything else moves bytes
     native_bytes_epoch = float(sum(r[3] for r in records))       # byte models of this build's own kernels, one epoch
-    ktab = {k: {"launches": len(v["ms"]), "mean_ms": float(np.mean(v["ms"])),
-                "algorithmic_GBps": v["bytes"] / float(np.mean(v["ms"])) / 1e6} for k, v in ktab.items()}
+    ktab = kernel_table(records, 1, TGCN_DENSE)
+    step_launches = sum(1 for r in records if r[0] in ("tgcn_step_fwd", "tgcn_step_bwd"))
+    # edges*feat EXECUTED by rank 0 in one epoch: each step launch gathers P = A_hat x at the INPUT width (E x feat), plus whatever
+    # separate aggregation launches ran (none in the fused form)
+    ef_rank0_epoch = step_launches * e * feat + executed_edges_feat(records)
     records = [r for r in records if r[0] in ("gcn_agg", "gcn_agg_transform")]
     agg_s = float(np.sum([a.elapsed_time(b) for (_, a, b, _, _) in records])) * 1e-3
     agg_launches = len(records)
@@ -922,6 +1087,15 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
                 "bytes_per_snapshot": ref_bytes,
                 "equivalent_GBps": ref_bytes / sec_per_snapshot / 1e9,
                 "equivalent_frac_of_hbm_peak": ref_bytes / sec_per_snapshot / 1e9 / HBM_PEAK_GBS}}
+    step_k = {k: ktab[k] for k in ("tgcn_step_fwd", "tgcn_step_bwd") if k in ktab}
+    if step_k:          # the dominant launch by time, against the roofline that bounds it (fp32-input matrix instruction)
+        dom = max(step_k, key=lambda k: step_k[k]["mean_ms"] * step_k[k]["launches_per_iter"])
+        roof["dominant_kernel"] = {"kernel": "stg::" + dom + "_kernel", "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS,
+                                   "achieved": step_k[dom]["achieved_TFLOPs"], "frac": step_k[dom]["frac"],
+                                   "flops_per_launch": step_k[dom]["flops"], "mean_launch_ms": step_k[dom]["mean_ms"],
+                                   "hbm_frac": step_k[dom]["hbm_frac"], "timed": "HIP events, eager epoch of rank 0"}
+        roof["kernel"] = "whole snapshot on moved bytes; dominant launch: " + dom
+    roof["kernels"] = ktab
     if cpu_baseline:
         progress("cfg4: CPU baseline")
     cpu = cpu_baseline_tgcn(g, ew, targets, n, e, T, feat, hidden, B) if cpu_baseline else None
@@ -941,7 +1115,11 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
                     "the compute of each BPTT window (fwd + bwd through time) replayed from a HIP graph, then one eager "
                     "all-reduce of the gradient bucket and one Adam step",
         "metric": "epochs/s", "value": epochs / dt, "epochs": epochs, "seconds_per_epoch": dt / epochs,
-        "edges_feat_per_s": agg_per_step * T * e * width * epochs / dt,
+        "edges_feat_per_s": ef_rank0_epoch * (T / max(steps_rank0, 1)) * epochs / dt,
+        "edges_feat_per_s_is": "sum of E x F over the gathers EXECUTED (each step launch aggregates at the input width: 2 x T x E x feat "
+                               "per epoch), whole job / wall time; edges_feat_per_s_reference_formulation counts the reference's six width-hidden aggregations per snapshot",
+        "edges_feat_per_s_reference_formulation": agg_per_step * T * e * width * epochs / dt,
+        "us_per_snapshot": sec_per_snapshot * 1e6,
         "scaling": "strong", "n_gpus": world,
         "windows_per_epoch": temporal.num_windows(T, B),
         "optimizer_steps_per_epoch": (temporal.num_windows(T, B) + world - 1) // world,
@@ -1038,6 +1216,8 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
             epoch(0)
             kernels.enable_launch_timing(None)
             own_bytes = float(sum(r[3] for r in recs))       # byte models of the native launches of one eager epoch
+            # edges*feat executed by this rank in one epoch: every step launch gathers A_hat x at the input width over e0 edges
+            ef_rank = sum(1 for r in recs if r[0] in ("tgcn_step_fwd", "tgcn_step_bwd")) * e0 * feat + executed_edges_feat(recs)
             del recs
             epoch(1)                                     # captures
             epoch(2)                                     # first pure replay (warm-up; epochs 0-2 discarded as the reference does)
@@ -1054,7 +1234,8 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
             if mode in ("pcsr_store", "gpma_store"):
                 G.check()
             out[mode] = {"epochs_per_s": epochs / dt, "seconds_per_epoch": dt / epochs, "hip_graph_per_window": True,
-                         "epochs_timed": epochs, "epochs_discarded": 3, "native_launch_bytes_per_epoch": own_bytes}
+                         "epochs_timed": epochs, "epochs_discarded": 3, "native_launch_bytes_per_epoch": own_bytes,
+                         "edges_feat_executed_per_epoch_this_rank": ef_rank}
             del G, model, opt, bucket, cd
             torch.cuda.empty_cache()
         return out
@@ -1086,7 +1267,11 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
                     "equivalent_frac_of_hbm_peak": ref_bytes / sps / 1e9 / HBM_PEAK_GBS}}
     res = {"workload": f"dynamic-temporal TGCN |V|={n} E0={e0} +-{churn} edges/step T={T} backprop_every={B} feat={feat} "
                        f"hidden={hidden} (BASELINE configs[4]), link-prediction loss, windows sharded over {world} rank(s)",
-           "metric": "epochs/s", "value": out["rebuild_per_snapshot"]["epochs_per_s"],
+           "metric": "epochs/s", "value": out["rebuild_per_snapshot"]["epochs_per_s"], "T": T,
+           "resident_epochs_per_s": out["resident_snapshots"]["epochs_per_s"],
+           "edges_feat_per_s": out["rebuild_per_snapshot"]["edges_feat_executed_per_epoch_this_rank"] * ((T - 1) / max(steps_rank0, 1))
+                               * out["rebuild_per_snapshot"]["epochs_per_s"],
+           "edges_feat_per_s_reference_formulation": 6 * (T - 1) * e0 * hidden * out["rebuild_per_snapshot"]["epochs_per_s"],
            "value_is": "rebuild_per_snapshot -- the configuration BASELINE.md names (a fresh device CSR build per snapshot "
                        "and epoch, O(window) memory).  resident_snapshots is NaiveGraph as the reference keeps it (T forward "
                        "+ T backward CSRs built once at construction, graph/dynamic/naive/naive_graph.py); the two "
@@ -1163,55 +1348,17 @@ def live_pmc_traffic(iters=2, timeout_s=170):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-tgcn", action="store_true")
-    ap.add_argument("--nodes", type=int, default=1_000_000)
-    ap.add_argument("--edges", type=int, default=16_000_000)
-    ap.add_argument("--feat", type=int, default=128)
-    ap.add_argument("--tgcn-epochs", type=int, default=20, help="timed epochs (the reference: >= 20, the first three discarded)")
-    ap.add_argument("--tgcn-timestamps", type=int, default=1000)
-    ap.add_argument("--no-cora", action="store_true")
-    ap.add_argument("--no-dynamic", action="store_true")
-    ap.add_argument("--no-gat", action="store_true")
-    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed PMC passes")
-    ap.add_argument("--dynamic-epochs", type=int, default=20)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo + --share-device: exercise the multi-rank logic on a single GPU (testing only)")
-    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (testing only)")
-    ap.add_argument("--allreduce-in-graph", action="store_true",
-                    help="N > 1: capture the gradient all-reduce into the optimizer-tail HIP graph (default: eager between the replays)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; no HIP device is visible (there is no CPU fallback)")
-    dev_index = 0 if args.share_device else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group("gloo")
-
+def cfg2_run(args, device, rank, world, want_cpu):
+    """BASELINE configs[1] (the N = 1 headline; N > 1: one independent replica per rank): K timed training steps of the 2-layer GCN
+    between barrier + device sync, MAX over ranks; the dominant kernel's launches timed with HIP events inside the region."""
     from stgraph_amd import kernels
+    from stgraph_amd.nn import functional as SF
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if rank == 0:
-        progress("cfg2: building the graph and the model")
     step, meta = gcn_setup(device, seed=1 + rank, n=args.nodes, e=args.edges, feat=args.feat)
     for _ in range(args.warmup):
         step()
@@ -1230,7 +1377,6 @@ def main():
         dt = float(t.item())
 
     # the same step with every layer in the reference's order (x W first): 4 aggregation launches
-    from stgraph_amd.nn import functional as SF
     SF.set_input_layer_reorder(False)
     try:
         step()
@@ -1245,6 +1391,7 @@ def main():
         SF.set_input_layer_reorder(True)
 
     ef_per_step = meta["agg_launches_per_step"] * meta["e"] * meta["feat"]
+    other = kernel_table([r for r in records if r[0] != "gcn_agg"], args.steps, ("gemm_tn", "gemm_tn_wide", "rowgemm", "rowgemm_wide"))
     gemm_ms = [a.elapsed_time(b) for (name, a, b, _, _) in records if name == "gemm_tn"]
     records = [r for r in records if r[0] == "gcn_agg"]           # the dominant kernel
     ms = [a.elapsed_time(b) for (_, a, b, _, _) in records]
@@ -1264,13 +1411,11 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "epochs_per_s": world * args.steps / dt,
-        "config": {"workload": f"2-layer GCN {args.feat}->{args.feat}->{args.feat} on a synthetic CSR |V|={meta['n']} "
+        "config": {"workload": f"2-layer GCN {args.feat}->{args.feat}->{args.feat}, synthetic CSR |V|={meta['n']} "
                                f"|E|={meta['e']} (BASELINE configs[1]); step = fwd + cross-entropy + bwd + Adam",
                    "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
-                   "agg_launches_per_step": meta["agg_launches_per_step"],
-                   "agg_launches_per_step_is": "of the reference's formulation (2 layers x forward + backward); executed: "
-                                               "see aggregations_executed_per_step",
-                   "aggregations_executed_per_step": None,
+                   "agg_launches_per_step_reference_formulation": meta["agg_launches_per_step"],
+                   "aggregations_executed_per_step": executed,
                    "edges_feat_per_step": ef_executed,
                    "edges_feat_per_step_reference_formulation": ef_per_step,
                    "reference_compat_D1": kernels.reference_compat()},
@@ -1279,40 +1424,25 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_alg, "mean_launch_ms": mean_ms,
                      "launches_timed": len(ms),
                      "gcn_agg_share_of_step": float(np.sum(ms)) * 1e-3 / dt,
-                     "weight_grad_gemm_tn_mean_ms": float(np.mean(gemm_ms)) if gemm_ms else None},
+                     "weight_grad_gemm_tn_mean_ms": float(np.mean(gemm_ms)) if gemm_ms else None,
+                     "other_kernels_of_the_step": other},
     }
-    line["config"]["aggregations_executed_per_step"] = executed
     line["reference_order"] = {
         "ms_per_step": dt_ref * 1e3, "value": world * ef_per_step / dt_ref, "steps": k_ref, "aggregations_executed_per_step": 4,
-        "what": "the same training step with every GCNConv in the reference's order (x W, then aggregate: 4 aggregation "
-                "launches); the default runs the first layer aggregate-first because its input carries no gradient, which "
-                "leaves its backward without an aggregation (identical gradients up to fp32 rounding; "
-                "tests/test_gpu_input_layer.py).  Measured at this exact shape against the reference-order oracle "
-                "(profiles/r03_input_layer_error.json): every gradient within 2.6e-8 ABSOLUTE; relative to each gradient "
-                "tensor's largest entry the worst figure is 4.4e-4 (the reference order evaluated on the same GPU: 8.2e-4) -- "
-                "both from the 57 first-layer pre-activations within 1e-7 of the ReLU kink, i.e. the north star's 1e-4 holds "
-                "absolutely, not relative to the tensor maximum, for either order",
-        "gradient_error_vs_reference_order_oracle": {"max_abs": 2.6e-8, "max_rel_to_tensor_max": 4.4e-4,
-                                                     "reference_order_on_gpu_rel_to_tensor_max": 8.2e-4,
-                                                     "source": "profiles/r03_input_layer_error.json"}}
-    # HBM-side traffic per launch: PMC counters cannot be read inside this process, so the figure
-    # comes from the committed rocprofv3 --pmc passes over the SAME kernel/shape (tools/pmc_gcn.py,
-    # FETCH_SIZE corrected with the factor measured on a known-bytes launch, + WRITE_SIZE).
+        "what": "the same step with every GCNConv in the reference's order (x W, then aggregate: 4 aggregation launches); the default runs "
+                "the first layer aggregate-first (its input carries no gradient): tests/test_gpu_input_layer.py, profiles/r03_input_layer_error.json"}
+    # HBM-side traffic per launch: PMC counters cannot be read inside this process; the committed rocprofv3 --pmc passes over the
+    # SAME kernel / shape first, replaced by this run's own child passes at the end (live_pmc_traffic)
     if (meta["n"], meta["e"], meta["feat"]) == (1_000_000, 16_000_000, 128):
         import glob
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gcn_agg_edge*.json")))
         if pmc_files:
             pmc = json.load(open(pmc_files[-1]))
-            line["roofline"]["traffic"] = 0.5 * (pmc["cfg2_forward_csr"]["traffic_bytes"] +
-                                                 pmc["cfg2_backward_csr"]["traffic_bytes"])
+            line["roofline"]["traffic"] = 0.5 * (pmc["cfg2_forward_csr"]["traffic_bytes"] + pmc["cfg2_backward_csr"]["traffic_bytes"])
             line["roofline"]["traffic_source"] = os.path.relpath(pmc_files[-1], ROOT)
-            # the same counters under the microarch guide's flat rule (FETCH_SIZE x 2 for wide coalesced reads);
-            # `traffic` uses the factor measured on a known-bytes launch of this kernel's own access shape
-            # (tools/pmc_gcn.py), see DESIGN.md section 3
             line["roofline"]["traffic_guide_x2_rule"] = 0.5 * (pmc["cfg2_forward_csr"]["traffic_bytes_x2_rule"] +
                                                                pmc["cfg2_backward_csr"]["traffic_bytes_x2_rule"])
     cpu = None
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if want_cpu:
         progress("cfg2: CPU baseline (torch epoch, then the OpenMP aggregation)")
         cpu = cpu_baseline_epoch_gcn(meta, int(0.6 * meta["n"]), meta["labels"], executed)
@@ -1320,43 +1450,140 @@ def main():
     line["cpu_baseline"] = cpu
     del step, meta
     torch.cuda.empty_cache()
-    if rank == 0 and not args.no_cora:
-        progress("cfg1: Cora-shaped GCN")
-        line["cora"] = cora_run(device, cpu_baseline=want_cpu)
-        x1024 = line["cora"]["roofline_x1024"]
-        line["roofline"]["north_star"] = {
-            "workload": "fused GCN aggregation forward + backward at the Cora model's widths (F = 16 and F = 7) on 1024 "
-                        "disjoint replicas of the Cora-shaped graph (SURVEY.md 8(d) 'Cora x K'); target >= 0.60",
-            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": x1024["achieved"], "frac": x1024["frac"],
-            "frac_F16": x1024["F16"]["frac_of_hbm_peak"], "frac_F7": x1024["F7"]["frac_of_hbm_peak"]}
-    if rank == 0 and not args.no_gat:
-        progress("cfg3: GAT")
-        line["gat"] = gat_run(device, cpu_baseline=want_cpu)
-        torch.cuda.empty_cache()
-    if not args.no_tgcn:
-        if rank == 0:
+    return line
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tgcn", action="store_true")
+    ap.add_argument("--nodes", type=int, default=1_000_000)
+    ap.add_argument("--edges", type=int, default=16_000_000)
+    ap.add_argument("--feat", type=int, default=128)
+    ap.add_argument("--tgcn-epochs", type=int, default=20, help="N = 1: timed epochs of the tgcn object (the reference: >= 20, the first three "
+                                                                "discarded); at N > 1 the TGCN epoch IS the step: --steps / --warmup")
+    ap.add_argument("--tgcn-timestamps", type=int, default=1000)
+    ap.add_argument("--no-cora", action="store_true")
+    ap.add_argument("--no-dynamic", action="store_true")
+    ap.add_argument("--no-gat", action="store_true")
+    ap.add_argument("--no-gcn", action="store_true", help="N > 1: skip the cfg2 replicas sub-object")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed PMC passes")
+    ap.add_argument("--dynamic-epochs", type=int, default=20)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-device: exercise the multi-rank logic on a single GPU (testing only)")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (testing only)")
+    ap.add_argument("--allreduce-in-graph", action="store_true",
+                    help="N > 1: capture the gradient all-reduce into the optimizer-tail HIP graph (default: eager between the replays)")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python3 bench.py --gpus N`: this process becomes the launcher (it has not touched the GPU and never will)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    if not args.share_device and torch.cuda.device_count() < world:          # device_count() does not initialise the GPU
+        raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} HIP device(s) visible: every rank needs its own GPU "
+                         "(--backend gloo --share-device rehearses the multi-rank logic on one)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no HIP device is visible (there is no CPU fallback)")
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+
+    from stgraph_amd import kernels
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+
+    if world == 1:
+        progress("cfg2: building the graph and the model")
+        line = cfg2_run(args, device, rank, world, want_cpu)
+        if not args.no_cora:
+            progress("cfg1: Cora-shaped GCN")
+            line["cora"] = cora_run(device, cpu_baseline=want_cpu)
+            x1024 = line["cora"]["roofline_x1024"]
+            line["roofline"]["north_star"] = {
+                "workload": "fused GCN aggregation forward + backward at the Cora model's widths (F = 16 and F = 7) on 1024 "
+                            "disjoint replicas of the Cora-shaped graph (SURVEY.md 8(d) 'Cora x K'); target >= 0.60",
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": x1024["achieved"], "frac": x1024["frac"],
+                "frac_F16": x1024["F16"]["frac_of_hbm_peak"], "frac_F7": x1024["F7"]["frac_of_hbm_peak"]}
+        if not args.no_gat:
+            progress("cfg3: GAT")
+            line["gat"] = gat_run(device, cpu_baseline=want_cpu)
+            torch.cuda.empty_cache()
+        if not args.no_tgcn:
             progress("cfg4: static-temporal TGCN")
-        line["tgcn"] = tgcn_run(device, rank, world, epochs=args.tgcn_epochs, warmup_epochs=3, n=50_000, e=500_000,
-                                T=args.tgcn_timestamps, feat=32, hidden=64, B=25, allreduce_in_graph=args.allreduce_in_graph,
-                                cpu_baseline=want_cpu, share_device=args.share_device)
-    if not args.no_dynamic:
-        if rank == 0:
+            line["tgcn"] = tgcn_run(device, rank, world, epochs=args.tgcn_epochs, warmup_epochs=3, n=50_000, e=500_000,
+                                    T=args.tgcn_timestamps, feat=32, hidden=64, B=25, allreduce_in_graph=args.allreduce_in_graph,
+                                    cpu_baseline=want_cpu, share_device=args.share_device)
+        if not args.no_dynamic:
             progress("cfg5: dynamic-temporal TGCN")
-        line["dynamic"] = dynamic_run(device, rank, world, epochs=args.dynamic_epochs, cpu_baseline=want_cpu)
-    if rank == 0 and world == 1 and not args.no_live_pmc and line["roofline"].get("traffic") is not None:
-        torch.cuda.empty_cache()
-        progress("cfg2: rocprofv3 --pmc child passes (HBM traffic of gcn_agg)")
-        live = live_pmc_traffic()
-        if live is not None:
-            line["roofline"]["traffic_committed_passes"] = line["roofline"]["traffic"]
-            line["roofline"]["traffic"] = live["traffic"]
-            line["roofline"]["traffic_guide_x2_rule"] = live["traffic_guide_x2_rule"]
-            line["roofline"]["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child "
-                                                  "passes over tools/pmc_gcn.py (same kernel, same shape)")
-            line["roofline"]["traffic_detail"] = {k: live[k] for k in ("fetch_correction_measured",
-                                                                       "write_calibration_ratio", "per_csr")}
+            line["dynamic"] = dynamic_run(device, rank, world, epochs=args.dynamic_epochs, cpu_baseline=want_cpu)
+        if not args.no_live_pmc and line["roofline"].get("traffic") is not None:
+            torch.cuda.empty_cache()
+            progress("cfg2: rocprofv3 --pmc child passes (HBM traffic of gcn_agg)")
+            live = live_pmc_traffic()
+            if live is not None:
+                line["roofline"]["traffic_committed_passes"] = line["roofline"]["traffic"]
+                line["roofline"]["traffic"] = live["traffic"]
+                line["roofline"]["traffic_guide_x2_rule"] = live["traffic_guide_x2_rule"]
+                line["roofline"]["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child "
+                                                      "passes over tools/pmc_gcn.py (same kernel, same shape)")
+                line["roofline"]["traffic_detail"] = {k: live[k] for k in ("fetch_correction_measured",
+                                                                           "write_calibration_ratio", "per_csr")}
+    else:
+        # N > 1: the path that SHARDS is the headline (BASELINE.json: "TGCN 1/2/4/8 MI355X"): one step = one training epoch of the
+        # static-temporal TGCN (40 BPTT windows dealt to the ranks, one RCCL all-reduce of the gradient bucket per optimizer
+        # step), `value` = whole-job epochs/s, scaling "strong" (the epoch is fixed, ranks split it)
+        if rank == 0:
+            progress(f"cfg4: static-temporal TGCN on {world} ranks (the headline at N > 1)")
+        tg = tgcn_run(device, rank, world, epochs=args.steps, warmup_epochs=max(args.warmup, 1), n=50_000, e=500_000,
+                      T=args.tgcn_timestamps, feat=32, hidden=64, B=25, allreduce_in_graph=args.allreduce_in_graph,
+                      cpu_baseline=False, share_device=args.share_device)
+        dk = tg["roofline"].get("dominant_kernel") or {}
+        line = {"metric": "epochs/s (static-temporal TGCN, BASELINE configs[3], BPTT windows sharded over the ranks)",
+                "value": tg["value"], "unit": "epochs/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+                "ms_per_step": tg["seconds_per_epoch"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"static-temporal TGCN |V|=50000 |E|=500000 T={args.tgcn_timestamps} feat=32 hidden=64 backprop_every=25; "
+                                       "step = one training epoch",
+                           "parallelism": f"dp{world}: window w on rank w mod {world}, one all-reduce(sum)/N of the 133 KB gradient bucket per optimizer step",
+                           "windows_per_epoch": tg["windows_per_epoch"], "optimizer_steps_per_epoch": tg["optimizer_steps_per_epoch"],
+                           "backprop_every": 25},
+                "roofline": {"bound": dk.get("bound", "mfma"), "achieved": dk.get("achieved"), "peak": dk.get("peak"), "unit": dk.get("unit"),
+                             "frac": dk.get("frac"), "traffic": None, "kernel": dk.get("kernel"), "flops_per_launch": dk.get("flops_per_launch"),
+                             "mean_launch_ms": dk.get("mean_launch_ms"), "hbm_frac": dk.get("hbm_frac"),
+                             "snapshot_on_moved_bytes_frac_of_hbm": tg["roofline"]["frac"]},
+                "cpu_baseline": None,
+                "allreduce": tg["allreduce"], "process_group": tg["process_group"], "edges_feat_per_s": tg["edges_feat_per_s"],
+                "tgcn": tg}
+        if not args.no_dynamic:
+            if rank == 0:
+                progress("cfg5: dynamic-temporal TGCN (windows sharded)")
+            line["dynamic"] = dynamic_run(device, rank, world, epochs=args.dynamic_epochs, cpu_baseline=False)
+        if not args.no_gcn:
+            if rank == 0:
+                progress("cfg2: one independent replica per rank (a single-graph GCN does not shard: SURVEY.md 8(e))")
+            rep = cfg2_run(args, device, rank, world, False)
+            line["gcn_replicas"] = {"metric": rep["metric"], "value": rep["value"], "unit": rep["unit"], "scaling": "weak", "n_gpus": world,
+                                    "ms_per_step": rep["ms_per_step"], "roofline": rep["roofline"], "config": rep["config"]}
+    line["knobs"] = kernels.knobs() if hasattr(kernels, "knobs") else None
+    line["cpu_threads_rule"] = CPU_THREADS_RULE
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1173,7 +1173,7 @@ def gat_bwd_uniform(A, S, out, g, x, W, feat, fwd: DeviceCSR, bwd: DeviceCSR, sl
                 gW = torch.bmm(gq.view(N, H, D).transpose(0, 1), W.view(H, D, fin))
         moved = (4 * N * H * fin + 4 * E * fin + 4 * E * H + 4 * N * fin + 4 * N * 16 + idx            # targets: gW, x[u], T, gsW, pack
                  + 4 * E * H + 4 * E * fin + 4 * N * (fin + H) + idx)                                   # sources: T, gsW[v], grad_el, gxa
-        with _Timed("gat_bwd_uniform", moved, 2 * E * H * fin):
+        with _Timed("gat_bwd_uniform", moved, E * (2 * fin + H)):      # units: executed gather = x[u] (fin) + gsW[v] (fin) + T[e] (H)
             _C.check(_C.lib.stg_gat_bwd_uniform_edges(
                 _ptr(A), _ptr(pack), _ptr(gq), _ptr(feat), _ptr(x), _ptr(gW), _ptr(T), _ptr(gsW), _ptr(grad_feat), _ptr(grad_el),
                 _ptr(gxa), _ptr(fwd.row_offset), _ptr(fwd.column_indices), _ptr(fwd.eids),
@@ -1931,7 +1931,9 @@ def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
     # byte model: gathered input rows + index arrays + what the launch reads and writes per row
     per_row = 4 * (Fin + (3 * C if tensors.get("x3") is not None else 0) + 6 * C + (Fh + 2 if head else 0))
-    with torch.cuda.device(dev), _Timed("tgcn_step_fwd", N * per_row, 2 * N * (3 * C * Fin + 6 * C * C + (Fh * C if head else 0))):
+    # flops EXECUTED: the folded form multiplies [P | Hx] (K = Fin + C) per gate, the reference formulation x3 (K = Fin) then [x3 | Hx] (K = 2C)
+    gate_macs = 3 * C * (Fin + C) if tensors.get("w_fold") is not None else 3 * C * Fin + 6 * C * C
+    with torch.cuda.device(dev), _Timed("tgcn_step_fwd", N * per_row, 2 * N * (gate_macs + (Fh * C if head else 0))):
         _C.check(_C.lib.stg_tgcn_step_fwd(ctypes.byref(a), _stream_ptr(dev)))
 
 
@@ -1950,7 +1952,8 @@ def tgcn_step_bwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     a.link_inv_m = 1.0 / float(link_edges) if link_edges else 0.0
     a.ld_d = int(ld_d)                                 # 3 C: dzl / drl / dhl are column blocks of one [N, 3C] matrix
     per_row = 4 * (6 * C + 3 * C + 3 * C + (3 * C if tensors.get("da3") is not None else 0) + C + Fin + (2 * Fh + 3 if head else 0))
-    with torch.cuda.device(dev), _Timed("tgcn_step_bwd", N * per_row, 2 * N * (6 * C * C + 3 * C * Fin + (Fh * C if head else 0))):
+    gate_macs = 3 * C * (Fin + C) if tensors.get("da3") is None else 3 * C * Fin + 6 * C * C       # folded: no da3 (see tgcn_step_fwd)
+    with torch.cuda.device(dev), _Timed("tgcn_step_bwd", N * per_row, 2 * N * (gate_macs + (Fh * C if head else 0))):
         _C.check(_C.lib.stg_tgcn_step_bwd(ctypes.byref(a), _stream_ptr(dev)))
 
 
