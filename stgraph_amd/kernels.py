@@ -52,11 +52,28 @@ def active_columns(feat_size: int) -> int:
 _TIMING: list | None = None
 
 
-def enable_launch_timing(records: list | None) -> None:
+_EVENTS: list = []
+
+
+def enable_launch_timing(records: list | None, prepare: int = 0) -> None:
     """Bracket every aggregation launch with HIP events on its own stream (bench.py uses this
-    to measure the dominant kernel inside the timed region).  ``None`` switches it off."""
+    to measure the dominant kernel inside the timed region).  ``None`` switches it off.
+    ``prepare``: that many event pairs are created AND recorded once now, so that the timed region finds them made (a first
+    hipEventCreate / first record of a fresh event is a runtime allocation: measured up to 4 ms of host time per 30 events on
+    a cold process, which made an otherwise device-bound step host-bound)."""
     global _TIMING
     _TIMING = records
+    del _EVENTS[:]
+    if records is not None and prepare > 0 and torch.cuda.is_available():
+        for _ in range(2 * int(prepare)):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            _EVENTS.append(ev)
+        torch.cuda.synchronize()
+
+
+def _event():
+    return _EVENTS.pop() if _EVENTS else torch.cuda.Event(enable_timing=True)
 
 
 class _Timed:
@@ -67,7 +84,7 @@ class _Timed:
 
     def __enter__(self):
         if _TIMING is not None:
-            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0, self.e1 = _event(), _event()
             self.e0.record()
         return self
 
@@ -1773,7 +1790,9 @@ def step_fold_status_word(device) -> torch.Tensor:
 
 
 def check_step_fold_status(device=None, clear: bool = True) -> None:
-    """Raise if a folded step launch since the last check met a clamped conv output (its results are then wrong).  Synchronises."""
+    """Raise if a folded step launch since the last check met a clamped conv output (its results are then wrong).  Synchronises.
+    For callers that drive the step launches themselves: the epoch functions of stgraph_amd.temporal do not raise -- they keep a
+    snapshot of the training state, read this word once per epoch and rerun the epoch in the reference formulation (_FoldGuard)."""
     for key, t in list(_FOLD_STATUS.items()):
         if device is not None:
             dev = torch.device(device)

@@ -81,7 +81,11 @@ class _MM(torch.autograd.Function):
             if w.is_contiguous() and kernels.rowgemm16_usable(g, w.shape[1], w.shape[0]) and w.data_ptr() % 16 == 0:
                 g = g.contiguous()
                 bits = ctx.relu_bits
-                if bits is not None and kernels.rowgemm_bits_usable(g, w.shape[1], w.shape[0]):
+                # the masked product is the gradient of the ReLU's PRE-activation, not of x: taken only while nobody can see x's
+                # own gradient (x.retain_grad() / x.register_hook(), looked up NOW -- the saved input is the caller's tensor).
+                # torch.autograd.grad(loss, x) cannot be seen from here: kernels.set_relu_bits(False) for that
+                observed = x.retains_grad or bool(getattr(x, "_backward_hooks", None))
+                if bits is not None and not observed and kernels.rowgemm_bits_usable(g, w.shape[1], w.shape[0]):
                     # the ReLU below masks this gradient anyway (and again whatever autograd adds to it: masking twice is
                     # masking once); done here it costs 16 bytes per row instead of a pass over the ReLU's output
                     gx = kernels.rowgemm_masked_t(g, w, bits)

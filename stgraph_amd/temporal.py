@@ -98,31 +98,100 @@ def _grad_sinks(params, needs):
     return sinks
 
 
-def _check_step_fold(device) -> None:
-    """End of an epoch: refuse its results if a step launch met a clamped conv output while a form that assumes none was in use
-    (kernels.STEP_WGRAD_FROM_P / STEP_FOLDED; one 4-byte read-back per epoch)."""
+# True while an epoch function holds a snapshot of the training state and reads the fold status word itself at the end of the
+# epoch (_FoldGuard): the window nodes then skip their own per-window read-back -- a blocking host sync per BPTT window.
+_EPOCH_GUARD = [False]
+
+
+def _fold_switch_off(where: str) -> None:
     from . import kernels
-    if kernels.STEP_WGRAD_FROM_P or kernels.STEP_FOLDED:
-        kernels.check_step_fold_status(device)
+    import warnings
+    kernels.set_step_folded(False)
+    kernels.set_step_wgrad_from_p(False)
+    warnings.warn("stgraph_amd: a TGCN conv output may leave [-1e6, 1e6] on this data (reference nn/pytorch/temporal/tgcn.py:23 clamps there): "
+                  "the folded step formulation is switched off for this process (kernels.set_step_folded / set_step_wgrad_from_p) and "
+                  f"{where} recomputed in the reference formulation", RuntimeWarning, stacklevel=3)
+
+
+class _FoldGuard:
+    """What makes an epoch on the folded step formulation safe to run without a host read per window: a snapshot of every
+    parameter and of the optimizer's state taken at the start of the epoch (a few ``_foreach_copy_`` launches over ~ 400 KB; only
+    while kernels.STEP_FOLDED / STEP_WGRAD_FROM_P are on), ONE read of the device's sticky status word at its end (agreed over the
+    ranks with a MAX all-reduce: every rank must take the same branch), and ``restore()`` -- the training state exactly as the
+    epoch found it.  The epoch function then switches the formulation off, re-captures what it replays and runs the epoch again:
+    no optimizer step taken on gradients of the invalid formulation survives, nothing is raised (a drop-in must not fail on
+    data the reference handles).  ``owner``: an object that keeps the snapshot buffers between epochs."""
+
+    def __init__(self, optimizer, device, world: int = 1, group=None, owner=None):
+        from . import kernels
+        self.active = bool(kernels.STEP_FOLDED or kernels.STEP_WGRAD_FROM_P)
+        self.device, self.world, self.group, self.optimizer = torch.device(device), world, group, optimizer
+        self.prev = False
+        if not self.active:
+            return
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.had_state = len(optimizer.state) > 0
+        live = [p.data for p in params]
+        for p in params:
+            live += [v for v in optimizer.state.get(p, {}).values() if torch.is_tensor(v)]
+        saved = getattr(owner, "_fold_guard_buffers", None)
+        if saved is None or len(saved) != len(live) or any(a.shape != b.shape or a.dtype != b.dtype or a.device != b.device
+                                                          for a, b in zip(saved, live)):
+            saved = [torch.empty_like(t) for t in live]
+            if owner is not None:
+                owner._fold_guard_buffers = saved
+        self.live, self.saved = live, saved
+        self._copy(saved, live)
+
+    @staticmethod
+    def _copy(dst, src):
+        with torch.no_grad():
+            on_gpu = [(d, s) for d, s in zip(dst, src) if d.is_cuda]
+            if on_gpu:
+                torch._foreach_copy_([d for d, _ in on_gpu], [s for _, s in on_gpu])
+            for d, s in zip(dst, src):
+                if not d.is_cuda:                       # a non-capturable optimizer keeps its step counters on the host
+                    d.copy_(s)
+
+    def __enter__(self):
+        self.prev, _EPOCH_GUARD[0] = _EPOCH_GUARD[0], (self.active or _EPOCH_GUARD[0])
+        return self
+
+    def __exit__(self, *exc):
+        _EPOCH_GUARD[0] = self.prev
+        return False
+
+    def tripped(self) -> bool:
+        """Did a step launch of this epoch (on ANY rank) refuse the folded formulation?  One 4-byte read-back; clears the word."""
+        if not self.active:
+            return False
+        from . import kernels
+        word = kernels.step_fold_status_word(self.device)
+        if self.world > 1:
+            dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group)
+        hit = int(word.item()) != 0
+        if hit:
+            word.zero_()
+        return hit
+
+    def restore(self) -> None:
+        self._copy(self.live, self.saved)
+        if not self.had_state:                          # the optimizer created its state during the epoch: back to none
+            self.optimizer.state.clear()
 
 
 def _fold_refused(fold_status) -> bool:
     """After the forward step launches of a window node, OUTSIDE a stream capture: did one of them refuse the folded formulation
     (a conv output that may leave the clamp range)?  Then the formulation is switched off for the process, with a warning, and the
     caller recomputes the window in the reference formulation -- a drop-in must not fail on data the reference handles.  Inside a
-    capture nothing can be read back: the epoch functions check the word once per epoch (``_check_step_fold``) and raise."""
-    if fold_status is None or torch.cuda.is_current_stream_capturing():
+    capture nothing can be read back, and inside an epoch function nothing NEEDS to be (``_EPOCH_GUARD``): the epoch functions hold a
+    snapshot of the training state, read the word once at the end of the epoch and run the epoch again (``_FoldGuard``)."""
+    if fold_status is None or _EPOCH_GUARD[0] or torch.cuda.is_current_stream_capturing():
         return False
     if int(fold_status.item()) == 0:
         return False
-    from . import kernels
-    import warnings
     fold_status.zero_()
-    kernels.set_step_folded(False)
-    kernels.set_step_wgrad_from_p(False)
-    warnings.warn("stgraph_amd: a TGCN conv output may leave [-1e6, 1e6] on this data (reference nn/pytorch/temporal/tgcn.py:23 clamps there): "
-                  "the folded step formulation is switched off for this process (kernels.set_step_folded / set_step_wgrad_from_p) and "
-                  "the window recomputed in the reference formulation", RuntimeWarning, stacklevel=3)
+    _fold_switch_off("the window")
     return True
 
 
@@ -489,17 +558,22 @@ def train_epoch_static(model, graph, edge_weight, targets, backprop_every: int, 
         backprop_every = total
     n = graph.get_num_nodes()
     losses = []
-    for _, w in windows_of_rank(total, backprop_every, rank, world):
-        bucket.zero()
-        if w is not None:
-            y_hat = window_input(n, feat_size, epoch, w, targets.device, seed)
-            cost = window_cost_of(model, graph, y_hat, edge_weight, targets[w * backprop_every:(w + 1) * backprop_every])
-            cost = cost / (backprop_every + 1)
-            cost.backward()
-            losses.append(cost.detach())
-        bucket.all_reduce_mean(world, group, timed_comm)
-        optimizer.step()
-    _check_step_fold(targets.device)
+    with _FoldGuard(optimizer, targets.device, world, group, owner=bucket) as guard:
+        for _, w in windows_of_rank(total, backprop_every, rank, world):
+            bucket.zero()
+            if w is not None:
+                y_hat = window_input(n, feat_size, epoch, w, targets.device, seed)
+                cost = window_cost_of(model, graph, y_hat, edge_weight, targets[w * backprop_every:(w + 1) * backprop_every])
+                cost = cost / (backprop_every + 1)
+                cost.backward()
+                losses.append(cost.detach())
+            bucket.all_reduce_mean(world, group, timed_comm)
+            optimizer.step()
+    if guard.tripped():            # a window of this epoch met data the folded formulation refuses: the epoch again, without it
+        guard.restore()
+        _fold_switch_off("the epoch")
+        return train_epoch_static(model, graph, edge_weight, targets, backprop_every, optimizer, bucket, feat_size, epoch, rank,
+                                  world, group, seed, timed_comm)
     return losses
 
 
@@ -729,42 +803,47 @@ def train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_e
     dev = pos_neg_targets[0].device
     losses = []
     graph.reset_graph()
-    for _, w in windows_of_rank(total, backprop_every, rank, world):
-        bucket.zero()
-        if w is not None:
-            cost = 0
-            hidden = None
-            y_hat = window_input(n, feat_size, epoch, w, dev, seed)
-            graph.get_graph(w * backprop_every)
-            ts = range(w * backprop_every, min((w + 1) * backprop_every, total - 1))
-            fused = dyn_window_usable(model, graph, y_hat) and len(ts) > 0 and all(
-                pos_neg_edges[t].dtype == torch.int64 and pos_neg_edges[t].is_contiguous() and pos_neg_edges[t].dim() == 2
-                and pos_neg_edges[t].shape == pos_neg_edges[ts[0]].shape and pos_neg_edges[t].shape[1] > 0
-                and pos_neg_targets[t].dtype == torch.float32 and pos_neg_targets[t].is_contiguous()
-                and pos_neg_targets[t].numel() == pos_neg_edges[t].shape[1] for t in ts)
-            steps = []
-            for k in range(backprop_every):
-                t = w * backprop_every + k
-                if t >= total - 1:
-                    break
-                graph.get_graph(t)
-                if graph.get_ndata("norm") is None:
-                    graph.set_ndata("norm", norm_fn(graph))
-                if fused:                                   # one autograd node for the window: collect the snapshots
-                    steps.append(dict(fwd=graph.csr("fwd"), bwd=graph.csr("bwd"), norm=graph.get_ndata("norm"),
-                                      edges=pos_neg_edges[t], targets=pos_neg_targets[t],
-                                      incidence=SF._incidence_of(pos_neg_edges[t], n)))
-                else:
-                    cost, y_hat, hidden = model.step_loss(graph, y_hat, None, hidden, pos_neg_edges[t], pos_neg_targets[t], cost)
-            if fused and steps:
-                cost = dyn_window_cost(model, graph, y_hat, steps)
-            if not isinstance(cost, int):
-                cost = cost / (backprop_every + 1)
-                cost.backward()
-                losses.append(cost.detach())
-        bucket.all_reduce_mean(world, group, timed_comm)
-        optimizer.step()
-    _check_step_fold(next(model.parameters()).device)
+    with _FoldGuard(optimizer, dev, world, group, owner=bucket) as guard:
+        for _, w in windows_of_rank(total, backprop_every, rank, world):
+            bucket.zero()
+            if w is not None:
+                cost = 0
+                hidden = None
+                y_hat = window_input(n, feat_size, epoch, w, dev, seed)
+                graph.get_graph(w * backprop_every)
+                ts = range(w * backprop_every, min((w + 1) * backprop_every, total - 1))
+                fused = dyn_window_usable(model, graph, y_hat) and len(ts) > 0 and all(
+                    pos_neg_edges[t].dtype == torch.int64 and pos_neg_edges[t].is_contiguous() and pos_neg_edges[t].dim() == 2
+                    and pos_neg_edges[t].shape == pos_neg_edges[ts[0]].shape and pos_neg_edges[t].shape[1] > 0
+                    and pos_neg_targets[t].dtype == torch.float32 and pos_neg_targets[t].is_contiguous()
+                    and pos_neg_targets[t].numel() == pos_neg_edges[t].shape[1] for t in ts)
+                steps = []
+                for k in range(backprop_every):
+                    t = w * backprop_every + k
+                    if t >= total - 1:
+                        break
+                    graph.get_graph(t)
+                    if graph.get_ndata("norm") is None:
+                        graph.set_ndata("norm", norm_fn(graph))
+                    if fused:                                   # one autograd node for the window: collect the snapshots
+                        steps.append(dict(fwd=graph.csr("fwd"), bwd=graph.csr("bwd"), norm=graph.get_ndata("norm"),
+                                          edges=pos_neg_edges[t], targets=pos_neg_targets[t],
+                                          incidence=SF._incidence_of(pos_neg_edges[t], n)))
+                    else:
+                        cost, y_hat, hidden = model.step_loss(graph, y_hat, None, hidden, pos_neg_edges[t], pos_neg_targets[t], cost)
+                if fused and steps:
+                    cost = dyn_window_cost(model, graph, y_hat, steps)
+                if not isinstance(cost, int):
+                    cost = cost / (backprop_every + 1)
+                    cost.backward()
+                    losses.append(cost.detach())
+            bucket.all_reduce_mean(world, group, timed_comm)
+            optimizer.step()
+    if guard.tripped():            # see train_epoch_static
+        guard.restore()
+        _fold_switch_off("the epoch")
+        return train_epoch_dynamic(model, graph, pos_neg_edges, pos_neg_targets, backprop_every, optimizer, bucket, feat_size, epoch,
+                                   rank, world, group, seed, norm_fn, timed_comm)
     return losses
 
 
@@ -861,24 +940,33 @@ class CapturedStaticWindow:
                 cost.backward()
             self.costs.index_copy_(0, self.widx, cost.detach().reshape(1))
 
-        # Warm up on a side stream (allocator, lazily built per-edge caches, tracing).  The body
-        # only writes gradients, so warming up and capturing leave the training state untouched.
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                body()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with _graph_capture(self.graph):
-            body()
-        bucket.zero()
+        self._body, self._warmup, self.graph = body, warmup, None
+        self.recapture()
 
         # second graph: what follows the all-reduce
         self.step_graph = None
         if all(g.get("capturable", False) for g in optimizer.param_groups):
             self._capture_step(dev)
+
+    def recapture(self) -> None:
+        """(Re-)capture the window graph in the step formulation that is current NOW (kernels.STEP_FOLDED / STEP_WGRAD_FROM_P): at
+        construction, and again by ``train_epoch_static_captured`` after an epoch met data the folded formulation refuses."""
+        dev = self.dev
+        self.graph = None                           # the old graph's pool goes back before the new one is built
+        # Warm up on a side stream (allocator, lazily built per-edge caches, tracing).  The body
+        # only writes gradients, so warming up and capturing leave the training state untouched.
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(self._warmup):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with _graph_capture(graph):
+            self._body()
+        self.graph = graph
+        self.bucket.zero()
 
     def _capture_step(self, dev):
         """``grad /= world`` + ``optimizer.step()`` + ``widx += world`` as one graph.  Capturing runs the optimizer
@@ -950,31 +1038,39 @@ def train_epoch_static_captured(cw: CapturedStaticWindow, model, graph, edge_wei
     tensor (views into the captured window's per-epoch buffer, cloned once at the end)."""
     total = cw.total                                     # (``targets`` may be None: the window object holds this rank's share)
     B = cw.B
-    cw.begin_epoch(epoch, seed)
     slots, eager = [], {}
-    for _, w in windows_of_rank(total, B, rank, world):
-        if w is not None and w < cw.full_windows:
-            cw.run(w, timed_comm)
-            slots.append(w)
-            continue
-        bucket.zero()
-        if w is not None:
-            y_hat = cw.inputs[w // world]
-            tw = cw.targets_tail if cw.targets_tail is not None else targets[w * B:min((w + 1) * B, total)]
-            cost = window_cost_of(model, graph, y_hat, edge_weight, tw)
-            cost = cost / (B + 1)
-            cost.backward()
-            eager[w] = cost.detach()
-            slots.append(w)
-        bucket.all_reduce_mean(world, group)
-        optimizer.step()
-        cw.widx.add_(world)
-        cw.slot.add_(1)
+    with _FoldGuard(optimizer, cw.dev, world, group, owner=cw) as guard:
+        cw.begin_epoch(epoch, seed)
+        for _, w in windows_of_rank(total, B, rank, world):
+            if w is not None and w < cw.full_windows:
+                cw.run(w, timed_comm)
+                slots.append(w)
+                continue
+            bucket.zero()
+            if w is not None:
+                y_hat = cw.inputs[w // world]
+                tw = cw.targets_tail if cw.targets_tail is not None else targets[w * B:min((w + 1) * B, total)]
+                cost = window_cost_of(model, graph, y_hat, edge_weight, tw)
+                cost = cost / (B + 1)
+                cost.backward()
+                eager[w] = cost.detach()
+                slots.append(w)
+            bucket.all_reduce_mean(world, group)
+            optimizer.step()
+            cw.widx.add_(world)
+            cw.slot.add_(1)
+    if guard.tripped():
+        # a replayed window met data the folded formulation refuses (nothing can be read back inside a graph): every optimizer
+        # step of this epoch is undone, the window graph is captured again in the reference formulation and the epoch rerun
+        guard.restore()
+        _fold_switch_off("the epoch (its window graph captured again)")
+        cw.recapture()
+        return train_epoch_static_captured(cw, model, graph, edge_weight, targets, optimizer, bucket, feat_size, epoch, rank,
+                                           world, group, seed, timed_comm)
     out = cw.costs[slots].clone() if slots else cw.costs[:0].clone()
     for i, w in enumerate(slots):
         if w in eager:
             out[i] = eager[w]
-    _check_step_fold(out.device)
     return list(out.unbind(0))
 
 
@@ -1032,6 +1128,17 @@ class CapturedDynamicWindows:
         self._probe = None
         self.allreduce_in_graph = False
         self._want_allreduce_in_graph = bool(allreduce_in_graph) and (world > 1 or group is not None)
+
+    def invalidate(self) -> None:
+        """Drop every captured window graph (they are captured again the next time their window is met): after a change of the
+        step formulation."""
+        self.graphs.clear()
+        self.costs.clear()
+        self.inputs.clear()
+        self._end_state.clear()
+        if not self._store and not self.graph._resident:
+            self.graph._snapshots.clear()            # tensors of the dropped graphs' pools
+        self.graph._ndata.clear()
 
     def timestamps(self, w: int):
         return range(w * self.B, min((w + 1) * self.B, self.total - 1))
@@ -1170,16 +1277,24 @@ def train_epoch_dynamic_captured(cd: CapturedDynamicWindows, epoch: int = 0, see
     the window is replayed again)."""
     losses = []
     cd.graph.reset_graph()
-    for _, w in windows_of_rank(cd.total, cd.B, cd.rank, cd.world):
-        if w is not None and cd.usable(w):
-            losses.append(cd.run(w, epoch, seed, timed_comm))
-            continue
-        cd.bucket.zero()
-        if w is not None and len(cd.timestamps(w)) > 0:
-            raise RuntimeError("CapturedDynamicWindows: window %d is not covered by the fused window path" % w)
-        cd.bucket.all_reduce_mean(cd.world, cd.group, timed_comm)
-        cd.optimizer.step()
-    _check_step_fold(next(cd.model.parameters()).device)
+    with _FoldGuard(cd.optimizer, cd.dev, cd.world, cd.group, owner=cd) as guard:
+        for _, w in windows_of_rank(cd.total, cd.B, cd.rank, cd.world):
+            if w is not None and cd.usable(w):
+                losses.append(cd.run(w, epoch, seed, timed_comm))
+                continue
+            cd.bucket.zero()
+            if w is not None and len(cd.timestamps(w)) > 0:
+                raise RuntimeError("CapturedDynamicWindows: window %d is not covered by the fused window path" % w)
+            cd.bucket.all_reduce_mean(cd.world, cd.group, timed_comm)
+            cd.optimizer.step()
+    if guard.tripped():
+        # as train_epoch_static_captured; the per-window graphs are dropped (they are captured again, lazily, by the next
+        # captured epoch) and THIS epoch is rerun eagerly -- the eager epoch the lazy captures expect to have come before them
+        guard.restore()
+        _fold_switch_off("the epoch (eagerly; the window graphs are captured again)")
+        cd.invalidate()
+        return train_epoch_dynamic(cd.model, cd.graph, cd.edges, cd.targets, cd.B, cd.optimizer, cd.bucket, cd.feat, epoch, cd.rank,
+                                   cd.world, cd.group, seed, cd.norm_fn, timed_comm)
     return losses
 
 

@@ -159,3 +159,51 @@ def test_aggregate_first_layer_against_the_reference_order_oracle(cuda, use_ew):
         w = a.grad.numpy()
         err = np.abs(b.grad.cpu().numpy() - w).max() / np.abs(w).max()
         assert err <= 1e-4, (k, float(err))
+
+
+@pytest.mark.parametrize("observe", ["retain_grad", "hook"])
+def test_hidden_gradient_observed_by_the_caller_is_torch_s(cuda, observe):
+    """The layer above an _InputLayer may multiply its input gradient by the ReLU's sign bits in the launch that forms it -- the
+    gradient of the PRE-activation.  That is only invisible while nobody looks at the hidden tensor's own gradient: with
+    ``hidden.retain_grad()`` or a hook on it, ``hidden.grad`` must be ``g @ W^T`` unmasked, as torch gives it (nonzero where the
+    hidden value is 0), and the parameter gradients must not change."""
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    n, f = 70_000, 128
+    src, dst = random_graph(3, n, 400_000)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    g.set_ndata("norm", torch.from_numpy(gcn_norm(np.bincount(dst, minlength=n))).to(cuda))
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    x = torch.randn(n, f, device=cuda, generator=gen)
+    R = torch.randn(n, f, device=cuda, generator=gen)
+    layers = _model(f, f, f, 2, cuda)
+    seen = {}
+
+    def run(watch):
+        layers.zero_grad()
+        hidden = layers[0](g, x)
+        if watch == "retain_grad":
+            hidden.retain_grad()
+        elif watch == "hook":
+            hidden.register_hook(lambda gr: seen.__setitem__("g", gr.clone()))
+        rec = []
+        kernels.enable_launch_timing(rec)
+        try:
+            layers[1](g, hidden).backward(R)
+        finally:
+            kernels.enable_launch_timing(None)
+        return hidden, [p.grad.clone() for p in layers.parameters()]
+
+    assert kernels.rowgemm_bits_usable(R, f, f)
+    hidden0, grads0 = run(None)                                    # nobody looks: the masked launch may run
+    hidden, grads = run(observe)
+    got = hidden.grad if observe == "retain_grad" else seen["g"]
+    with torch.no_grad():
+        agg = kernels.gcn_agg(R, g.get_ndata("norm"), g.get_ndata("norm"), g.csr("bwd"))
+        want = agg @ layers[1].weight.t()                          # d loss / d hidden of layers[1] = A_hat^T R W^T
+    dead = hidden.detach() == 0
+    assert dead.float().mean() > 0.2
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert float(got[dead].abs().max()) > 0                        # NOT masked where the ReLU is off
+    for a, b in zip(grads0, grads):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9

@@ -360,3 +360,113 @@ def test_gate_gradients_as_one_matrix_give_the_same_weight_gradients(cuda):
     for k in res[0][2]:
         a, b = res[0][2][k], res[1][2][k]
         assert float((a - b).abs().max()) <= 1e-6 * (float(b.abs().max()) + 1e-12), k
+
+
+@contextlib.contextmanager
+def _folded_on(cuda):
+    from stgraph_amd import kernels
+    was = kernels.STEP_FOLDED, kernels.STEP_WGRAD_FROM_P
+    kernels.set_step_folded(True), kernels.set_step_wgrad_from_p(True)
+    kernels.step_fold_status_word(cuda).zero_()
+    try:
+        yield
+    finally:
+        kernels.set_step_folded(was[0]), kernels.set_step_wgrad_from_p(was[1])
+        kernels.step_fold_status_word(cuda).zero_()
+
+
+def _trip(model):
+    """A conv bias of 2e6: the conv output of every row leaves [-1e6, 1e6] (the reference clamps it; the folded formulation
+    refuses it through its bound)."""
+    with torch.no_grad():
+        model.temporal.conv_z.bias.fill_(2e6)
+
+
+@pytest.mark.parametrize("captured", [False, True])
+def test_static_epoch_on_data_the_fold_refuses_is_rerun_in_the_reference_formulation(cuda, captured):
+    """The epoch functions never read the status word per window (no host sync) and never raise: they keep a snapshot of
+    parameters + Adam state, read the word once at the end of the epoch, restore, switch the folded formulation off, capture
+    the window graph again and rerun.  Result == the same epochs with the folded formulation off from the start: costs, every
+    parameter, the Adam state -- bit for bit (the same launches on the same values)."""
+    import warnings
+    from stgraph_amd import kernels, temporal
+    n, e, T, B = 3000, 24000, 12, 4
+    g, ew, targets, _ = _setup(cuda, n, e, T, 21)
+    runs = []
+    for folded_first in (True, False):
+        torch.manual_seed(3)
+        model = temporal.STGraphTGCN(32, 64, 1).to(cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
+        bucket = temporal.GradBucket(model.parameters())
+        with _folded_on(cuda):
+            kernels.set_step_folded(False), kernels.set_step_wgrad_from_p(False)
+            temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, 32, epoch=0)      # a healthy epoch, the same in both runs
+            kernels.set_step_folded(folded_first), kernels.set_step_wgrad_from_p(folded_first)
+            cw = temporal.CapturedStaticWindow(model, g, ew, targets, B, opt, bucket, 32) if captured else None
+            _trip(model)
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                costs = []
+                for ep in (1, 2):
+                    if captured:
+                        costs += temporal.train_epoch_static_captured(cw, model, g, ew, targets, opt, bucket, 32, epoch=ep)
+                    else:
+                        costs += temporal.train_epoch_static(model, g, ew, targets, B, opt, bucket, 32, epoch=ep)
+            warned = [w for w in rec if "folded step formulation is switched off" in str(w.message)]
+            assert len(warned) == (1 if folded_first else 0)            # once: the second epoch already runs the reference formulation
+            assert not kernels.STEP_FOLDED and not kernels.STEP_WGRAD_FROM_P
+            assert int(kernels.step_fold_status_word(cuda).item()) == 0
+        state = [v.clone() for p in model.parameters() for v in opt.state[p].values() if torch.is_tensor(v)]
+        runs.append((torch.stack([c.reshape(()) for c in costs]).clone(), [p.detach().clone() for p in model.parameters()], state))
+    assert torch.isfinite(runs[0][0]).all()
+    assert torch.equal(runs[0][0], runs[1][0])
+    for k in (1, 2):
+        for a, b in zip(runs[0][k], runs[1][k]):
+            assert torch.equal(a, b)
+
+
+def test_captured_dynamic_epoch_on_data_the_fold_refuses_is_rerun(cuda):
+    """CapturedDynamicWindows: same contract; the tripped epoch is rerun eagerly, the window graphs are dropped and captured again
+    (in the reference formulation) by the next captured epoch."""
+    import warnings
+    import numpy as np
+    from stgraph_amd import kernels, temporal
+    from stgraph_amd.graph import NaiveGraph
+    n, e0, churn, T, B, feat, hid, m = 3000, 20000, 500, 9, 4, 32, 64, 1000
+    rng = np.random.default_rng(5)
+    stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
+    snaps, pn_edges, pn_targets = [], [], []
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    for t in range(T):
+        keys = stream[t * churn: t * churn + e0]
+        s, d = (keys // n).astype(np.int32), (keys % n).astype(np.int32)
+        snaps.append((torch.from_numpy(s).to(cuda), torch.from_numpy(d).to(cuda)))
+        pos = torch.from_numpy(np.stack([s[:m], d[:m]]).astype(np.int64)).to(cuda)
+        pn_edges.append(torch.cat([pos, torch.randint(0, n, (2, m), device=cuda, generator=gen)], 1))
+        pn_targets.append(torch.cat([torch.ones(m, device=cuda), torch.zeros(m, device=cuda)]))
+    runs = []
+    for folded_first in (True, False):
+        G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False, resident=True)
+        torch.manual_seed(4)
+        model = temporal.DynamicSTGraphTGCN(feat, hid).to(cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
+        bucket = temporal.GradBucket(model.parameters())
+        with _folded_on(cuda):
+            kernels.set_step_folded(False), kernels.set_step_wgrad_from_p(False)
+            temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=0)     # healthy, the same in both runs
+            kernels.set_step_folded(folded_first), kernels.set_step_wgrad_from_p(folded_first)
+            cd = temporal.CapturedDynamicWindows(model, G, pn_edges, pn_targets, B, opt, bucket, feat)
+            _trip(model)
+            # the FIRST captured epoch both captures (in the folded formulation, if on) and trips
+            costs = []
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                for ep in (1, 2):
+                    costs += [c.clone() for c in temporal.train_epoch_dynamic_captured(cd, epoch=ep)]
+            assert sum("folded step formulation is switched off" in str(w.message) for w in rec) == (1 if folded_first else 0)
+            assert not kernels.STEP_FOLDED and len(cd.graphs) == 2                # captured again by epoch 2
+        runs.append((torch.stack([c.reshape(()) for c in costs]), [p.detach().clone() for p in model.parameters()]))
+    assert torch.isfinite(runs[0][0]).all()
+    torch.testing.assert_close(runs[0][0], runs[1][0], rtol=1e-6, atol=0)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
