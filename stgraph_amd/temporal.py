@@ -953,6 +953,10 @@ class CapturedStaticWindow:
         construction, and again by ``train_epoch_static_captured`` after an epoch met data the folded formulation refuses."""
         dev = self.dev
         self.graph = None                           # the old graph's pool goes back before the new one is built
+        # the body gathers its input / target slot and scatters its cost through these device counters: after an epoch they point
+        # one past the last window (an out-of-range gather is a device assertion) -- warm up and capture on window 0
+        self.widx.zero_()
+        self.slot.zero_()
         # Warm up on a side stream (allocator, lazily built per-edge caches, tracing).  The body
         # only writes gradients, so warming up and capturing leave the training state untouched.
         side = torch.cuda.Stream(device=dev)
