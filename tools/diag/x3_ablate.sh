@@ -1,10 +1,9 @@
 #!/bin/bash
-# on the GPU box: time the split-form row product of every diagnosis build under stgraph_amd/lib/x3diag/
+# on the GPU box: time the split-form row product of every diagnosis build under stgraph_amd/lib/x3diag/.
+# The diagnosis builds compute WRONG products by construction: they are loaded through STGRAPH_AMD_LIB, the product
+# library stgraph_amd/lib/libstgraph_hip.so is never touched.
 cd "$GRAFT_REPO_ROOT"
-cp stgraph_amd/lib/libstgraph_hip.so /tmp/product.so
 for f in stgraph_amd/lib/x3diag/*.so; do
-  cp "$f" stgraph_amd/lib/libstgraph_hip.so
   echo "== $(basename $f)"
-  timeout -k 10 120 python tools/microbench_x3.py quick 2>&1 | grep -v amdgpu.ids
+  STGRAPH_AMD_LIB="$PWD/$f" timeout -k 10 120 python tools/microbench_x3.py quick 2>&1 | grep -v amdgpu.ids
 done
-cp /tmp/product.so stgraph_amd/lib/libstgraph_hip.so
