@@ -35,8 +35,12 @@ extern "C" {
  *  25: stg_rowgemm_act_bits_f32, stg_rowgemm_bits_words, stg_rowgemm_bits_supported: a ReLU layer's sign pattern as bits;
  *      stg_xent_fwd_grad, stg_xent_scale_grad: cross-entropy forward and gradient in one pass; stg_gat_bwd_uniform_*,
  *      stg_gat_bwd_prepass, stg_gemm_tn_gated_f32, stg_rowgemm_heads_f32: the GAT backward unit in the uniform-attention form;
- *      stg_gat_fc_fwd accepts feat == NULL, stg_gat_fc_feat_if; stg_tgcn_step_bwd_args gains ld_d (last field). */
-#define STG_ABI_VERSION 25
+ *      stg_gat_fc_fwd accepts feat == NULL, stg_gat_fc_feat_if; stg_tgcn_step_bwd_args gains ld_d (last field).
+ *  26: the bf16-split forms of the step launches are RETIRED (measured slower than the fp32 / folded fp32 forms: profiles/r04_stepx_*,
+ *      r04_stepf_*; sources in git history before round 5): stg_tgcn_pack_weights_x3, stg_tgcn_step_image_bytes and the knobs
+ *      "step_impl" / "step_fold" are gone, `w_image` of both argument blocks is reserved and must be NULL, w_fold now REQUIRES
+ *      fold_bound (the folded launch runs on the fp32 matrix instruction only). */
+#define STG_ABI_VERSION 26
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -57,13 +61,11 @@ const char *stg_last_error_string(void);
  * "gcn_tile_rows" (its rows per workgroup: 0 = one per lane group, else 8 .. 256), "gcn_tile_pipe" (its
  * persistent, software-pipelined form: 0 / 1 = off, 2 = whenever the tile kernel runs; measured equal),
  * "xw_waves" (0 = auto; 4 / 8 waves per workgroup of stg_gcn_agg_transform), "cell_rows" (0 = auto; 16 / 32 rows
- * per tile of stg_tgcn_cell_fused_fwd), "step_waves" (stg_tgcn_step_*: 0 = auto, 12 / 16 waves per workgroup), "step_impl" (stg_tgcn_step_* given a
- * weight image: 0 = the matrix-core form, 1 = always the fp32 form; the one knob that selects between two ARITHMETICS -- both
- * within 1e-5 of fp64), "step_fold" (stg_tgcn_step_fwd given w_fold: 0 = the folded form on the fp32 instruction when fold_bound is
- * given and x3 is not asked for, 1 = always the matrix-core folded form), "rowgemm_x3" (stg_rowgemm_f32 / _strided_f32 / _act_f32 at K, M in {64, 128} and N K < 2^30: 0 = from 64 K rows
+ * per tile of stg_tgcn_cell_fused_fwd), "step_waves" (stg_tgcn_step_*: 0 = auto, 12 / 16 waves per workgroup),
+ * "rowgemm_x3" (stg_rowgemm_f32 / _strided_f32 / _act_f32 at K, M in {64, 128} and N K < 2^30: 0 = from 64 K rows
  * every product as a 3-term bf16 split on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, 1 = always v_mfma_f32_16x16x4_f32, 2 = the
- * split form at every N, 3 = its lane-owns-row-pieces load / store variant (diagnosis); the second such knob: both forms inside the
- * fp32 kernel's error bound against fp64, integer data exact in both), "step_spread"
+ * split form at every N, 3 = its lane-owns-row-pieces load / store variant (diagnosis); the one knob that selects between two
+ * ARITHMETICS: both forms inside the fp32 kernel's error bound against fp64, integer data exact in both), "step_spread"
  * (0 = one workgroup per CU when there are fewer tiles than wave slots, 1 = packed grid), "gemm_wide" (tall-skinny weight
  * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_cyclic" (its row-group hand-out: 0 .. 2), "gemm_xcd_pair" (its
  * workgroup order when M x N takes several workgroups per K slice: 0 = those of a slice on one XCD, 1 = dealt in turn),
@@ -738,28 +740,21 @@ typedef struct stg_tgcn_step_fwd_args {
     int64_t N;
     int32_t C, Fin, Fh, head;
     float lo, hi;
-    /* Optional (NULL: not used).  The forward weight image of stg_tgcn_pack_weights_x3: with it, x != NULL, node_ids == NULL and
-     * head >= 1 the launch takes the MATRIX-CORE form (csrc/tgcn_stepx_fwd.hip: every product as a 3-term bf16 split with fp32
-     * accumulation -- fp32-class results, 1e-5 of the fp32 form; P bit-identical) unless the knob "step_impl" is 1.  clamp_mask is
-     * then written in that form's layout (one byte per row piece) and must be consumed by a backward launch given the backward image. */
+    /* Reserved: must be NULL (ABI 22-25: the weight image of the retired bf16-split form). */
     const void *w_image;
-    /* Optional (NULL: not used; ABI 24).  The FOLDED form of the forward launch (csrc/tgcn_stepf_fwd.hip): w_fold [3C][Fin + C], rows
+    /* Optional (NULL: not used; ABI 24).  The FOLDED form of the forward launch: w_fold [3C][Fin + C], rows
      * g C + c = [ (Wc_g Wg[:, :C]^T)^T | Wg[:, C:] ] and b_fold [3C] = bc_g Wg[:, :C]^T + bg -- the conv output folded into the gate
-     * Linears, formed once per window by the caller.  With them, x != NULL, node_ids == NULL, head >= 1 and the knob "step_impl"
-     * != 1 every product runs as a 3-term bf16 split on the matrix cores with all weights in LDS.  Same outputs and saved tensors
-     * (x3 and the clamp mask in the fp32 form's layout included: any backward launch may follow); results fp32-class (1e-5 of the
-     * fp32 form).  The fold is only valid while no element of x3 is clamped: if one is, *fold_status |= 1 (sticky, never cleared by
-     * the library) and THAT launch's Z / R / Ht / Hn / HR / y are wrong -- the caller must check it and redo the work without
-     * w_fold.  The three go together -- except that fold_status alone may be given to the fp32 form, which then ORs a 1 into it
-     * when an element of x3 is clamped (callers that form the weight gradients from P^T d_g instead of x3 and da3 -- both then
-     * optional: x3 may be NULL when clamp_mask is given, stg_tgcn_step_bwd_args::da3 may be NULL when z is wanted -- need to know). */
+     * Linears, formed once per window by the caller (stg_tgcn_fold_weights).  Needs x != NULL, head >= 1, x3 == NULL and all four of
+     * w_fold, b_fold, fold_bound, fold_status.  The gate products run straight from P on the folded weights -- 320 fp32 matrix
+     * instructions per tile instead of 512, no x3 formed.  The fold is only valid while no element of x3 is clamped, and x3 cannot be
+     * looked at, so the launch bounds it: |P[r, :]|_1 fold_bound[0] + fold_bound[1] ({max |Wcat|, max |b3|}: stg_tgcn_fold_weights
+     * writes them) outside [lo, hi] sets *fold_status |= 1 (sticky, never cleared by the library) and THAT launch's Z / R / Ht / Hn /
+     * HR / y are wrong -- the caller must check it and redo the work without w_fold.  clamp_mask is not written (an inactive clamp's
+     * mask is all ones: 0xffff in every word).  fold_status alone may be given to the un-folded form, which then ORs a 1 into it when an
+     * element of x3 is clamped (callers that form the weight gradients from P^T d_g instead of x3 and da3 -- both then optional: x3
+     * may be NULL when clamp_mask is given, stg_tgcn_step_bwd_args::da3 may be NULL when z is wanted -- need to know). */
     const float *w_fold, *b_fold;
     int32_t *fold_status;
-    /* With fold_bound ({max |Wcat|, max |b3|}, two floats: stg_tgcn_fold_weights writes them) and x3 == NULL the folded launch runs
-     * on the fp32 matrix instruction instead (knob "step_fold" 0, the default; 1 = always the matrix-core folded form): the gate
-     * products straight from P on the folded weights -- 320 matrix instructions per tile instead of 512, no x3 formed.  The clamp
-     * cannot be looked at then, so the launch bounds it: |P[r, :]|_1 max |Wcat| + max |b3| outside [lo, hi] sets *fold_status.
-     * clamp_mask is not written (an inactive clamp's mask is all ones: 0xffff in every word). */
     const float *fold_bound;
 } stg_tgcn_step_fwd_args;
 typedef struct stg_tgcn_step_bwd_args {
@@ -780,8 +775,7 @@ typedef struct stg_tgcn_step_bwd_args {
     const int32_t *link_row_ptr, *link_other, *link_eid;
     const float *link_y, *link_logits, *link_target;
     float link_inv_m;
-    /* Optional (NULL: not used): the backward weight image of stg_tgcn_pack_weights_x3 -- the matrix-core form of the backward
-     * launch (csrc/tgcn_stepx_bwd.hip), for a clamp_mask written by the matrix-core forward launch. */
+    /* Reserved: must be NULL (ABI 22-25: the weight image of the retired bf16-split form). */
     const void *w_image;
     /* Optional (NULL: not used; ABI 24): [3 Fin][C], rows g Fin + f = the folded gate weights' P part transposed (stg_tgcn_fold_weights'
      * w_fold_t).  With it, da3 == NULL and head >= 1 the launch takes its FOLDED form: z = sum_g d_g w_fold_t_g^T instead of da3 Wcat^T
@@ -790,7 +784,7 @@ typedef struct stg_tgcn_step_bwd_args {
     const float *w_fold_t;
     /* Row stride of dzl / drl / dhl in floats (ABI 25): 0 or C = three [N, C] matrices; 3 C = the column blocks of ONE [N, 3C] matrix
      * (dzl = D, drl = D + C, dhl = D + 2 C, say), so that a window's weight gradients contract [d_z | d_r] against [H | P] as one
-     * operand -- the shared operand is read once (stg_gemm_tn_form_f32 with lda = 3 C).  The matrix-core form (w_image) takes 0 / C. */
+     * operand -- the shared operand is read once (stg_gemm_tn_form_f32 with lda = 3 C). */
     int32_t ld_d;
 } stg_tgcn_step_bwd_args;
 int    stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh);
@@ -804,15 +798,6 @@ int    stg_tgcn_pack_weights(const float *Wcz, const float *Wcr, const float *Wc
                              float *WcatT, float *b3, float *WzT, float *WrT, float *WhT, float *W1T, int32_t C, int32_t Fin,
                              int32_t Fh, void *stream);
 int    stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *args, void *stream);
-/* The weights of a window as bf16 fragment images for the matrix-core form of the two step launches (one launch per window):
- * every weight as three bf16 terms (w = h + m + l to 2^-25 |w|), laid out as the MFMA A operands of the wave that owns them
- * (csrc/tgcn_stepx.hpp), followed by the fp32 biases.  fwd_image / bwd_image: stg_tgcn_step_image_bytes(0 / 1) bytes, 16-byte
- * aligned.  W2 / b2 may be NULL (dynamic-temporal model: no second Linear).  C = 64, Fin = Fh = 32. */
-size_t stg_tgcn_step_image_bytes(int32_t backward);
-int    stg_tgcn_pack_weights_x3(const float *Wcz, const float *Wcr, const float *Wch, const float *bcz, const float *bcr,
-                                const float *bch, const float *Wz, const float *bz, const float *Wr, const float *br,
-                                const float *Wh, const float *bh, const float *W1, const float *b1, const float *W2,
-                                const float *b2, void *fwd_image, void *bwd_image, int32_t C, int32_t Fin, int32_t Fh, void *stream);
 /* The gate and conv parameter gradients of a window from contractions that need neither x3 nor da3 (ABI 24).  Tables of three
  * device pointers, one per gate (z, r, h).  Inputs: R_g [C, C + Fin] = d_g^T [Hx | P] and cs_g [C] = column sums of d_g (d_g: gradient
  * of the gate's pre-activation over the window's rows -- stg_gemm_tn_form_f32 with the column sums), the conv weight Wc_g [Fin, C]

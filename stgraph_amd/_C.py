@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # STGRAPH_AMD_LIB: a diagnosis build of the same library (tools/diag/build_*_trace.sh); the product never sets it
 LIB_PATH = os.environ.get("STGRAPH_AMD_LIB") or os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "stg_gat_fwd_k1_uniform", "stg_gat_fc_out", "stg_gat_fwd_k1_scored", "stg_gat_bwd_factored_elu",
     "stg_gat_fc_supported", "stg_gat_fc_fwd", "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32", "stg_gemm_tn_relu_mask_f32",
-    "stg_gat_fc_feat_if", "stg_gat_bwd_uniform_supported", "stg_gat_bwd_prepass", "stg_gat_bwd_uniform_edges", "stg_gat_bwd_uniform_gx_fallback", "stg_gemm_tn_gated_f32", "stg_rowgemm_heads_supported", "stg_rowgemm_heads_f32", "stg_rowgemm_bits_words", "stg_rowgemm_bits_supported", "stg_rowgemm_act_bits_f32", "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_tgcn_pack_weights_x3", "stg_tgcn_unfold_gate_grads", "stg_tgcn_fold_weights", "stg_tgcn_step_image_bytes", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
+    "stg_gat_fc_feat_if", "stg_gat_bwd_uniform_supported", "stg_gat_bwd_prepass", "stg_gat_bwd_uniform_edges", "stg_gat_bwd_uniform_gx_fallback", "stg_gemm_tn_gated_f32", "stg_rowgemm_heads_supported", "stg_rowgemm_heads_f32", "stg_rowgemm_bits_words", "stg_rowgemm_bits_supported", "stg_rowgemm_act_bits_f32", "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_tgcn_unfold_gate_grads", "stg_tgcn_fold_weights", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
@@ -341,10 +341,6 @@ def _load() -> ctypes.CDLL:
     lib.stg_link_decode_fwd_multi.argtypes = [i32, vp, vp, vp, vp, vp, i64, i32, vp]
     lib.stg_tgcn_pack_weights.restype = ctypes.c_int
     lib.stg_tgcn_pack_weights.argtypes = [vp] * 17 + [i32, i32, i32, vp]
-    lib.stg_tgcn_pack_weights_x3.restype = ctypes.c_int
-    lib.stg_tgcn_pack_weights_x3.argtypes = [vp] * 18 + [i32, i32, i32, vp]
-    lib.stg_tgcn_step_image_bytes.restype = ctypes.c_size_t
-    lib.stg_tgcn_step_image_bytes.argtypes = [i32]
     lib.stg_tgcn_step_supported.restype = ctypes.c_int
     lib.stg_tgcn_step_supported.argtypes = [i32, i32, i32]
     lib.stg_tgcn_step_loss_partials.restype = ctypes.c_size_t
@@ -376,5 +372,19 @@ def check(rc: int) -> None:
         raise StgError(rc, lib.stg_last_error_string().decode(errors="replace"))
 
 
+# launch-time knobs of the native library (performance only; "rowgemm_x3" alone selects between two arithmetics, both inside the
+# fp32 kernel's error bound): include/stgraph_hip.h, stg_set_tuning.  Every key defaults to 0 (= auto).
+TUNING_KEYS = ("gcn_lanes_per_row", "gcn_unroll", "gcn_long_threshold", "xw_rows", "xw_waves", "cell_rows", "gcn_tile", "gcn_block",
+               "gcn_addr32", "gcn_tile_pipe", "gcn_tile_rows", "gcn_xcd_tile", "step_waves", "gcn_wide_long", "step_spread",
+               "build_lds_count", "store_rows", "rowgemm16", "rowgemm_x3", "gemm_wide", "gemm_xcd_pair", "gemm_cyclic")
+_TUNING_SET = {}
+
+
 def set_tuning(key: str, value: int) -> None:
     check(lib.stg_set_tuning(key.encode(), int(value)))
+    _TUNING_SET[key] = int(value)
+
+
+def tuning_values() -> dict:
+    """Every native knob -> the value last set through this module (0 = the library's default)."""
+    return {k: _TUNING_SET.get(k, 0) for k in TUNING_KEYS}

@@ -1,5 +1,5 @@
 // Y[N,M] = act(X[N,K] * op(W) + bias) for many rows and K, M in {64, 128} on the bf16 MATRIX cores of gfx950, every product
-// as a 3-term bf16 split with fp32 accumulation (the arithmetic of tgcn_stepx.hpp: x = h + m + l exactly, x w taken as
+// as a 3-term bf16 split with fp32 accumulation (the arithmetic of bf16_split.hpp: x = h + m + l exactly, x w taken as
 // h h + h m + m h + h l + l h + m m; what is dropped is below 2^-23 |x w|, one fp32 rounding).
 //
 // Why: v_mfma_f32_16x16x4_f32 is 157 TFLOP/s and runs on the vector lanes (profiles/r04_coexec_f32mfma.jsonl): cfg2's three
@@ -13,14 +13,14 @@
 // n16 of a 16-row tile), so lane (n16 = lane & 15, kq = lane >> 4) receives output columns 16 ct + 4 kq .. + 3 of ITS row:
 // 16-byte stores (the row-piece scheme of tgcn_step.hpp).  The lane's eight k values of K-block b are the CONTIGUOUS
 // columns 32 b + 8 kq .. + 7 of its row (two adjacent 16-byte loads; the four kq groups cover 128 contiguous bytes; measured:
-// the sector-aligned alternative -- xcol of tgcn_stepx.hpp, 64 contiguous bytes of a row per instruction -- is 15 % SLOWER).  The
+// the sector-aligned alternative -- xcol of bf16_split.hpp, 64 contiguous bytes of a row per instruction -- is 15 % SLOWER).  The
 // weights are split once per workgroup into an LDS image [ct][b][term][lane] x 16 bytes (96 KB at 128 x 128) and read back
 // as three ds_read_b128 per (ct, b); a wave works on TWO 16-row tiles at a time so that each weight fragment read feeds
 // twelve matrix instructions (LDS: 62 of 128 bytes per clock).  One workgroup of 8 waves per CU, tile pairs dealt wave-major,
 // the rows two K-blocks ahead are in flight under the current block's products.
 #include <algorithm>
 
-#include "tgcn_stepx.hpp"
+#include "bf16_split.hpp"
 
 namespace stg {
 namespace {

@@ -118,11 +118,6 @@ extern "C" int stg_set_tuning(const char *key, int value)
         return 0;
     }
     if (!std::strcmp(key, "step_spread")) { tuning().step_spread = value; return 0; }
-    if (!std::strcmp(key, "step_impl")) {
-        if (value != 0 && value != 1) return fail(STG_ERR_INVALID_ARGUMENT, "step_impl must be 0 (matrix-core form) or 1 (fp32 form)");
-        tuning().step_impl = value;
-        return 0;
-    }
     if (!std::strcmp(key, "build_lds_count")) {
         if (value < 0 || value > 2) return fail(STG_ERR_INVALID_ARGUMENT, "build_lds_count must be 0 (auto), 1 (always when |V| fits) or 2 (never)");
         tuning().build_lds_count = value;
@@ -130,7 +125,6 @@ extern "C" int stg_set_tuning(const char *key, int value)
     }
     if (!std::strcmp(key, "store_rows")) { tuning().store_rows = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "rowgemm16")) { tuning().rowgemm16 = value ? 1 : 0; return 0; }
-    if (!std::strcmp(key, "step_fold")) { tuning().step_fold = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "rowgemm_x3")) {
         if (value < 0 || value > 3) return fail(STG_ERR_INVALID_ARGUMENT, "rowgemm_x3 must be 0 .. 3");
         tuning().rowgemm_x3 = value;

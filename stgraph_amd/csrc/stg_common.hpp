@@ -35,7 +35,6 @@ struct Tuning {
     int gcn_xcd_tile = 0;          // 0 = auto; 1 = workgroups round-robin over XCDs; T = runs of T workgroups per XCD
     int step_waves = 0;            // one-launch TGCN step: 0 = auto, 12 / 16 waves per workgroup (168 / 128 registers)
     int gcn_wide_long = 0;         // hubs of rows >= 64 lanes wide: 0 = feature-sliced workgroups (F % 4 == 0, F <= 256), 1 = never
-    int step_impl = 0;             // one-launch TGCN step given a weight image: 0 = matrix-core (3-term bf16 split) form, 1 = fp32 form
     int step_spread = 0;           // one-launch TGCN step with fewer tiles than wave slots: 0 = one workgroup per CU, 1 = packed grid
     int store_rows = 0;            // stg_edgeset_step_device with row-offset hints: 0 = new row offsets derived from them inside the merge launch, 1 = searched in their own launch
     int build_lds_count = 0;       // per-snapshot CSR build: 0 = auto (histograms in LDS when |V| fits and the graph is dense enough), 1 = always when |V| fits, 2 = never
@@ -43,7 +42,6 @@ struct Tuning {
     int gemm_wide = 0;             // tall-skinny weight gradient: 0 = auto (16-byte-per-lane form where the widths allow), 1 = never
     int gemm_cyclic = 0;           // its K distribution inside a block: 0 = a contiguous quarter per wave, 1 = 4-row groups in turn
     int gemm_xcd_pair = 0;         // its workgroup order with several M / N groups: 0 = the groups of a K slice on one XCD (shared operand from L2), 1 = dealt in turn
-    int step_fold = 0;             // stg_tgcn_step_fwd given folded gate weights: 0 = the fp32-instruction folded form (needs fold_bound, x3 == NULL), 1 = the matrix-core folded form
     int rowgemm_x3 = 0;            // row products at K, M in {64, 128}: 0 = auto (3-term bf16 split on the matrix cores from 64 K rows), 1 = never, 2 = whenever legal
 };
 // rowgemm_x3.hip: the split form of the row product (X, W, Y 16-byte aligned, ldy % 4 == 0)

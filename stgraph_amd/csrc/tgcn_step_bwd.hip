@@ -394,8 +394,6 @@ extern "C" int stg_debug_set_step_trace_bwd(void *buf)
 }
 #endif
 
-int stg_tgcn_stepx_bwd_launch(const stg_tgcn_step_bwd_args *p, void *stream_);      // tgcn_stepx_bwd.hip
-
 extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
 {
     using namespace stg;
@@ -411,8 +409,9 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     if (gather && (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL graph pointer");
     if ((int64_t)p->N * 3 * p->C >= ((int64_t)1 << 30)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_bwd: too many rows for 32-bit offsets");
-    // folded form: w_fold_t given, no da3 asked for, head >= 1 (knob "step_impl" 1 never takes it)
-    const bool fold = p->w_fold_t && !p->da3 && p->head >= 1 && tuning().step_impl == 0;
+    if (p->w_image) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_bwd: w_image (the bf16-split form, ABI 22-25) was retired in ABI 26: pass NULL");
+    // folded form: w_fold_t given, no da3 asked for, head >= 1
+    const bool fold = p->w_fold_t && !p->da3 && p->head >= 1;
     if (!p->Z || !p->R || !p->Ht || (!p->x3 && !p->clamp_mask && !fold) || !p->WzT || !p->WrT || !p->WhT || !p->dzl || !p->drl || !p->dhl || (!p->da3 && !p->z) || !p->dH)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: NULL cell pointer");
     if (p->z && !p->Wcat && !fold) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: z wanted but Wcat is NULL");
@@ -423,10 +422,6 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
                             !(p->link_inv_m > 0.f)))
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: the link-loss arguments need head == 1, g_cost and every link_* field");
     const bool d_wide = p->ld_d == 3 * p->C;
-    if (p->w_image && !p->node_ids && p->head >= 1 && p->clamp_mask && tuning().step_impl == 0 && !d_wide) {
-        if (reinterpret_cast<uintptr_t>(p->w_image) & 15) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_bwd: w_image must be 16-byte aligned");
-        return stg_tgcn_stepx_bwd_launch(p, stream_);
-    }
     BwdArgs a{};
     a.row_offsets = p->row_offsets; a.column_indices = p->column_indices; a.node_ids = p->node_ids;
     a.nc_edge = p->norm_col_edge; a.ew_edge = p->ew_edge; a.norm = p->norm;

@@ -408,9 +408,6 @@ extern "C" int stg_tgcn_step_supported(int32_t C, int32_t Fin, int32_t Fh)
 
 extern "C" size_t stg_tgcn_step_loss_partials(int64_t N) { return N > 0 ? (size_t)((N + 15) / 16) : 0; }
 
-int stg_tgcn_stepx_fwd_launch(const stg_tgcn_step_fwd_args *p, void *stream_);      // tgcn_stepx_fwd.hip
-int stg_tgcn_stepf_fwd_launch(const stg_tgcn_step_fwd_args *p, void *stream_);      // tgcn_stepf_fwd.hip
-
 extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
 {
     using namespace stg;
@@ -421,13 +418,11 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
     if (p->head < 0 || p->head > 2) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: head must be 0, 1 or 2");
     if (p->N == 0) return 0;
     const bool gather = p->x != nullptr;
-    // folded gate weights: knob "step_fold" 0 = the fp32-instruction folded form below (x3 is then not formed: it must not be asked
-    // for), 1 = the matrix-core folded form (tgcn_stepf_fwd.hip)
-    const bool fold32 = p->w_fold && gather && p->head >= 1 && !p->x3 && p->fold_bound && tuning().step_impl == 0 && tuning().step_fold == 0;
-    if (p->w_fold && !fold32 && (gather || (!p->a3 && p->P && p->WcatT)) && !p->node_ids && p->head >= 1 && tuning().step_impl == 0)
-        return stg_tgcn_stepf_fwd_launch(p, stream_);
-    if (fold32 && (!p->b_fold || !p->fold_status))
-        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: w_fold, b_fold, fold_bound and fold_status go together");
+    if (p->w_image) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_fwd: w_image (the bf16-split form, ABI 22-25) was retired in ABI 26: pass NULL");
+    // folded gate weights: x3 is then not formed (it must not be asked for) and the launch bounds it instead
+    const bool fold32 = p->w_fold != nullptr;
+    if (fold32 && (!gather || p->head < 1 || p->x3 || !p->b_fold || !p->fold_bound || !p->fold_status))
+        return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: the folded form needs x, head >= 1, x3 == NULL and w_fold, b_fold, fold_bound, fold_status together");
     if (gather ? (!p->row_offsets || !p->column_indices || !p->norm_col_edge || !p->norm || !p->WcatT || !p->P) : !p->a3)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL graph / input pointer");
     if (!p->b3 || !p->Wz || !p->bz || !p->Wr || !p->br || !p->Wh || !p->bh || (!p->x3 && !p->clamp_mask && !fold32) || !p->Z || !p->R || !p->Ht || !p->Hn || !p->HR)
@@ -437,10 +432,6 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
         return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: NULL loss pointer");
     if ((int64_t)p->N * 3 * p->C >= ((int64_t)1 << 30)) return fail(STG_ERR_UNSUPPORTED, "stg_tgcn_step_fwd: too many rows for 32-bit offsets");
 
-    if (p->w_image && gather && !p->node_ids && p->head >= 1 && tuning().step_impl == 0) {
-        if (reinterpret_cast<uintptr_t>(p->w_image) & 15) return fail(STG_ERR_INVALID_ARGUMENT, "stg_tgcn_step_fwd: w_image must be 16-byte aligned");
-        return stg_tgcn_stepx_fwd_launch(p, stream_);
-    }
     FwdArgs a{};
     a.row_offsets = p->row_offsets; a.column_indices = p->column_indices; a.node_ids = p->node_ids;
     a.nc_edge = p->norm_col_edge; a.ew_edge = p->ew_edge; a.norm = p->norm;

@@ -1720,25 +1720,11 @@ def gemm_tn_form_batch(calls):
 
 
 # ------------------------------------------------------------- one TGCN step per launch (csrc/tgcn_step.hip)
-# True: the window nodes of stgraph_amd.temporal hand the step launches bf16 fragment images of the weights
-# (tgcn_pack_weights_x3) and so take their matrix-core form (csrc/tgcn_stepx_*.hip: every product as a 3-term bf16 split with
-# fp32 accumulation, fp32-class results, same tests and tolerances); False (default): the fp32-instruction form
-# (csrc/tgcn_step_*.hip).  The default is the MEASURED faster one: 56 + 59 us per snapshot at cfg4 against 77 + 87 us
-# (profiles/r04_stepx_*.json; DESIGN.md section 0 has the anatomy of why the column-split form is latency-bound).
-STEP_MATRIX_CORE = False
-
-
-def set_step_matrix_core(enabled: bool) -> None:
-    global STEP_MATRIX_CORE
-    STEP_MATRIX_CORE = bool(enabled)
-
-
-# True: the window nodes hand the FORWARD step launch the gate Linears with the conv folded in (tgcn_fold_weights) and it runs in its
-# folded form (csrc/tgcn_stepf_fwd.hip: every product a 3-term bf16 split on the matrix cores, all weights in LDS, one wave per
-# 16-row tile).  The fold is exact only while no conv output is clamped (|.| <= 1e6 always holds on sane data): the launch raises a
-# sticky per-device status word otherwise, which check_step_fold_status() turns into an error.  With STEP_WGRAD_FROM_P (nobody reads
-# x3 then) the launch takes the fp32-instruction folded form of csrc/tgcn_step_fwd.hip instead (knob "step_fold" 0): the gate products
-# straight from P, 320 matrix instructions per tile instead of 512, the clamp BOUNDED instead of looked at.  True (default).
+# True (default): the window nodes hand the FORWARD step launch the gate Linears with the conv folded in (tgcn_fold_weights) and it
+# runs in its folded form (csrc/tgcn_step_fwd.hip, FOLD): the gate products straight from P on the fp32 matrix instruction, 320 per
+# tile instead of 512, no x3 formed, the clamp BOUNDED instead of looked at.  The fold is exact only while no conv output is clamped
+# (|.| <= 1e6 always holds on sane data): the launch raises a sticky per-device status word otherwise; the epoch functions of
+# stgraph_amd.temporal then rerun the epoch in the reference formulation (_FoldGuard).  Needs STEP_WGRAD_FROM_P (nobody may read x3).
 STEP_FOLDED = os.environ.get("STGRAPH_AMD_STEP_FOLDED", "1") != "0"
 
 
@@ -1878,10 +1864,7 @@ def _fill_step_args(args, what: str, dev: torch.device, tensors: dict, row_strid
         if t is None:
             continue
         if name == "w_image":
-            if not torch.is_tensor(t) or t.dtype != torch.uint8 or t.device != dev or not t.is_contiguous() or t.data_ptr() % 16:
-                raise TypeError(f"{what}: w_image must be the uint8 image of tgcn_pack_weights_x3 on {dev}")
-            setattr(args, name, t.data_ptr())
-            continue
+            raise TypeError(f"{what}: w_image belonged to the retired bf16-split form (ABI 26)")
         want = torch.int32 if name in _STEP_INT_FIELDS or name in ("clamp_mask", "fold_status") else torch.float32
         if row_stride and name in row_stride:
             if (not torch.is_tensor(t) or t.dtype != want or t.device != dev or t.dim() != 2 or t.stride(1) != 1
@@ -1911,37 +1894,11 @@ def tgcn_pack_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1):
     return out
 
 
-def tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2=None, b2=None):
-    """``(forward image, backward image)``: the weights of a window as bf16 fragment images (every weight = three bf16 terms,
-    laid out as the MFMA operands of the wave that owns them) for the matrix-core form of tgcn_step_fwd / _bwd
-    (stg_tgcn_pack_weights_x3; csrc/tgcn_stepx.hpp).  One launch per window.  ``W2`` / ``b2``: the second head Linear of the
-    static-temporal model ([1, Fh] or [Fh], [1]); None for the dynamic-temporal model."""
-    src = [_f32(t, "weight") for t in (Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)]
-    dev = src[0].device
-    Fin, C = (int(v) for v in src[0].shape)
-    Fh = int(src[12].shape[0])
-    opt = [None if t is None else _f32(t, "weight").reshape(-1) for t in (W2, b2)]
-    if (any(t.device != dev for t in src) or any(tuple(t.shape) != (Fin, C) for t in src[:3]) or any(tuple(t.shape) != (C,) for t in src[3:6])
-            or any(tuple(src[i].shape) != (C, 2 * C) for i in (6, 8, 10)) or any(tuple(src[i].shape) != (C,) for i in (7, 9, 11))
-            or tuple(src[12].shape) != (Fh, C) or tuple(src[13].shape) != (Fh,)
-            or (opt[0] is not None and (opt[0].numel() != Fh or opt[1] is None or opt[1].numel() != 1))):
-        raise ValueError("tgcn_pack_weights_x3: conv weights [Fin, C], conv biases [C], gate weights [C, 2C] + biases [C], head [Fh, C] + [Fh], W2 [Fh], b2 [1]")
-    fwd = torch.empty(int(_C.lib.stg_tgcn_step_image_bytes(0)), dtype=torch.uint8, device=dev)
-    bwd = torch.empty(int(_C.lib.stg_tgcn_step_image_bytes(1)), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        _C.check(_C.lib.stg_tgcn_pack_weights_x3(*[_ptr(t) for t in src], _ptr(opt[0]) if opt[0] is not None else None,
-                                                 _ptr(opt[1]) if opt[1] is not None else None, _ptr(fwd), _ptr(bwd), C, Fin, Fh,
-                                                 _stream_ptr(dev)))
-    return fwd, bwd
-
-
 def tgcn_step_fwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: float, device, **tensors) -> None:
     """One TGCN step forward in one launch (stg_tgcn_step_fwd); ``tensors``: the pointer fields of
     stg_tgcn_step_fwd_args by name (include/stgraph_hip.h).  Outputs are written in place."""
     dev = torch.device(device)
     a = _C.TgcnStepFwdArgs()
-    if tensors.get("column_indices") is not None and tensors["column_indices"].numel() == 0:
-        tensors = dict(tensors, w_image=None, w_fold=None, b_fold=None, fold_bound=None)   # the matrix-core forms assume |E| >= 1 (their gathers have no guarded loads)
     if tensors.get("w_fold") is None:
         tensors = dict(tensors, b_fold=None, fold_bound=None)
     if tensors.get("w_fold") is not None and tensors.get("fold_status") is None:
@@ -1963,8 +1920,6 @@ def tgcn_step_bwd(N: int, C: int, Fin: int, Fh: int, head: int, lo: float, hi: f
     ``link_edges`` = the number of label edges) the node side of the link loss's backward runs inside the launch."""
     dev = torch.device(device)
     a = _C.TgcnStepBwdArgs()
-    if tensors.get("column_indices") is not None and tensors["column_indices"].numel() == 0:
-        tensors = dict(tensors, w_image=None)
     wide = int(ld_d) not in (0, int(C))
     _fill_step_args(a, "tgcn_step_bwd", dev, tensors, {"dzl": int(ld_d), "drl": int(ld_d), "dhl": int(ld_d)} if wide else None)
     a.N, a.C, a.Fin, a.Fh, a.head, a.lo, a.hi = int(N), int(C), int(Fin), int(Fh), int(head), float(lo), float(hi)
@@ -2337,3 +2292,64 @@ def tgcn_cell_call(name: str, tensors, N: int, C: int, *scalars) -> None:
     fn = getattr(_C.lib, "stg_tgcn_cell_" + name)
     with torch.cuda.device(dev):
         _C.check(fn(*[_ptr(t) for t in tensors], N, C, *[float(x) for x in scalars], _stream_ptr(dev)))
+
+
+# ------------------------------------------------------------------------------------------------------- every switch, in one place
+# (name, module, attribute, default, environment variable or None, what it selects).  Setters: ``set_<name>`` in the named module
+# unless noted; results never depend on a switch beyond fp32 rounding (reference_compat excepted: it reproduces reference defect D1).
+_KNOBS = (
+    ("reference_compat", "stgraph_amd.kernels", "_REF_COMPAT", False, None, "reproduce reference defect D1 (columns >= the power-of-two width stay 0 for F < 64)"),
+    ("direct_build", "stgraph_amd.kernels", "_DIRECT_BUILD", True, None, "counting-sort CSR build for graphs of <= 2M edges (else the radix-sort build)"),
+    ("fused_rebuild", "stgraph_amd.kernels", "FUSED_REBUILD", True, None, "re-builds of a validated edge list as one fused launch sequence"),
+    ("long_row_path", "stgraph_amd.kernels", "_LONG_ROWS", True, None, "hub rows of the aggregation on their own workgroups"),
+    ("edge_cache", "stgraph_amd.kernels", "_EDGE_CACHE", True, None, "per-edge pre-gathered norm / weight scalars kept on the CSR object"),
+    ("gat_ones_shortcut", "stgraph_amd.kernels", "_GAT_ONES", True, None, "GAT K0 without the A write when every score is finite (device flag)"),
+    ("gat_uniform_form", "stgraph_amd.kernels", "_GAT_UNIFORM", True, None, "GAT K1 at the input width when every A == 1 (SURVEY.md D2)"),
+    ("gat_uniform_backward", "stgraph_amd.kernels", "_GAT_UNIFORM_BWD", True, "STGRAPH_AMD_GAT_UNIFORM_BWD", "GAT K2 at the input width, likewise"),
+    ("gat_factored_backward", "stgraph_amd.kernels", "_GAT_FACTORED", True, None, "GAT K2 with one E x H x D gather instead of the emitted unit's two"),
+    ("gat_regrouped_er", "stgraph_amd.kernels", "_GAT_REGROUPED_ER", True, None, "grad_er summed per target without atomics"),
+    ("native_rowgemm", "stgraph_amd.kernels", "_ROWGEMM", False, "STGRAPH_AMD_ROWGEMM", "round-3 fp32 row-product kernel for every tall product (off: only the 16-row form below)"),
+    ("rowgemm16", "stgraph_amd.kernels", "_ROWGEMM16", True, "STGRAPH_AMD_ROWGEMM16", "tall row products at K, M in {64, 128} on the native kernels (bf16 split from 64 K rows)"),
+    ("relu_bits", "stgraph_amd.kernels", "_RELU_BITS", True, "STGRAPH_AMD_RELU_BITS", "ReLU sign pattern as bits; the layer above masks its input gradient in the launch that forms it"),
+    ("step_folded", "stgraph_amd.kernels", "STEP_FOLDED", True, "STGRAPH_AMD_STEP_FOLDED", "TGCN step launches with the conv folded into the gate Linears"),
+    ("step_wgrad_from_p", "stgraph_amd.kernels", "STEP_WGRAD_FROM_P", True, "STGRAPH_AMD_STEP_WGRAD_FROM_P", "TGCN weight gradients from P (no x3 / da3 stored)"),
+    ("step_wgrad_zr_together", "stgraph_amd.kernels", "STEP_WGRAD_ZR_TOGETHER", True, "STGRAPH_AMD_STEP_WGRAD_ZR_TOGETHER", "[d_z | d_r] contracted as one operand"),
+    ("xent_one_pass", "stgraph_amd.kernels", "_XENT_ONE_PASS", True, "STGRAPH_AMD_XENT_ONE_PASS", "cross-entropy loss and its gradient in one pass"),
+    ("native_weight_grad", "stgraph_amd.nn.functional", "_NATIVE_WGRAD", True, None, "tall-skinny weight gradients on the split-K kernels instead of rocBLAS"),
+    ("deferred_weight_grads", "stgraph_amd.nn.functional", "_DEFER", True, None, "weight gradients of a window contracted once, at the end of the backward pass"),
+    ("input_layer_reorder", "stgraph_amd.nn.functional", "_INPUT_LAYER", True, None, "a GCNConv whose input needs no gradient aggregates first"),
+    ("gat_fc", "stgraph_amd.nn.functional", "_GAT_FC", True, None, "GATConv projection + el / er in one launch"),
+    ("gat_proj_fold", "stgraph_amd.nn.functional", "_GAT_PROJ_FOLD", True, None, "GAT projection backward folded into the input / weight gradients"),
+    ("fused_head", "stgraph_amd.temporal", "_FUSED_HEAD", True, None, "relu + both Linears + loss of the temporal harness model in one launch"),
+    ("fused_window", "stgraph_amd.temporal", "_FUSED_WINDOW", True, None, "one autograd node per BPTT window over the step launches"),
+    ("fused_forward", "stgraph_amd.nn.pytorch.temporal.cell", "_FUSED_FWD", True, None, "TGCN cell row-local chain in one launch (per-step API path)"),
+    ("fused_backward", "stgraph_amd.nn.pytorch.temporal.cell", "_FUSED_BWD", True, None, "its backward, likewise"),
+    ("fused_dx", "stgraph_amd.nn.pytorch.temporal.cell", "_FUSED_DX", True, None, "da3 Wcat^T inside that backward launch"),
+    ("pcsr_fused_step", "stgraph_amd.graph.dynamic.pcsr.pcsr", "FUSED_STEP", True, None, "dynamic edge store: merge + CSR emission as one device step (module attribute, no setter)"),
+    ("force_generated", "stgraph_amd.compiler.dispatch", "_FORCE_GENERATED", False, None, "always run the generated (hiprtc) kernel instead of a hand-written unit"),
+)
+ENVIRONMENT = ("STGRAPH_AMD_LIB",) + tuple(k[4] for k in _KNOBS if k[4])
+
+
+def knobs() -> dict:
+    """Every switch of the package and the native library: name -> {value, default, env, module, what} (bench.py prints it into
+    bench_detail.json; ``native`` = stg_set_tuning keys, 0 = auto)."""
+    import importlib
+    out = {}
+    for name, module, attr, default, env, what in _KNOBS:
+        try:
+            value = getattr(importlib.import_module(module), attr)
+        except Exception as exc:                                     # noqa: BLE001  (a listing must not fail the caller)
+            value = f"unavailable: {type(exc).__name__}"
+        out[name] = {"value": value, "default": default, "env": env, "module": module, "what": what}
+    out["native"] = _C.tuning_values()
+    out["library"] = {"path": _C.LIB_PATH, "env": "STGRAPH_AMD_LIB", "abi": _C.ABI_VERSION}
+    return out
+
+
+def non_default_knobs() -> dict:
+    """The switches that differ from their defaults (what a bench line should say about its configuration)."""
+    k = knobs()
+    out = {n: v["value"] for n, v in k.items() if isinstance(v, dict) and "default" in v and v["value"] != v["default"]}
+    out.update({"native." + n: v for n, v in k["native"].items() if v})
+    return out

@@ -226,14 +226,11 @@ class _TGCNWindow(torch.autograd.Function):
         # Wcat [Fin, 3C], its transpose, b3 and the transposed gate / head weights of the backward pass: one launch
         Wcat, WcatT, b3, WzT, WrT, WhT, W1T = kernels.tgcn_pack_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1)
         ctx.packed_T = (WzT, WrT, WhT, W1T)
-        # the same weights as bf16 fragment images: with them the step launches take their matrix-core form (csrc/tgcn_stepx.hpp)
-        img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2, b2)
-                            if kernels.STEP_MATRIX_CORE else (None, None))
-        # the gate Linears with the conv folded in: the forward launch's folded form (csrc/tgcn_stepf_fwd.hip)
+        # the gate Linears with the conv folded in: the forward launch's folded form (nobody may read x3: only with from_p)
+        from_p = kernels.STEP_WGRAD_FROM_P                      # weight gradients from P: no x3, no da3
         w_fold, b_fold, f_bound, ctx.w_fold_t = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound=True)
-                                   if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None, None, None))
+                                   if kernels.STEP_FOLDED and from_p else (None, None, None, None))
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
-        from_p = kernels.STEP_WGRAD_FROM_P and not kernels.STEP_MATRIX_CORE       # weight gradients from P: no x3, no da3
         P, X3 = new(B, N, Fin), (None if from_p else new(B, N, 3 * C))
         fold_status = kernels.step_fold_status_word(dev) if (from_p or w_fold is not None) else None
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
@@ -260,8 +257,8 @@ class _TGCNWindow(torch.autograd.Function):
                                   x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1], target=targets[t],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
                                   W2=W2v, b2=b2_, P=P[t], x3=None if from_p else X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t],
-                                  HR=HR[t], y=Y[t], y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t], w_image=img_f,
-                                  w_fold=w_fold, b_fold=b_fold, fold_bound=f_bound if from_p else None, fold_status=fold_status)
+                                  HR=HR[t], y=Y[t], y_out=Yout[t], loss_partial=partial[t], clamp_mask=mask[t],
+                                  w_fold=w_fold, b_fold=b_fold, fold_bound=f_bound, fold_status=fold_status)
         if _fold_refused(fold_status):
             return _TGCNWindow.forward(ctx, x0, targets, norm, ew, fwd, bwd, use_nid, lo, hi,
                                        Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1, W2, b2)
@@ -287,7 +284,7 @@ class _TGCNWindow(torch.autograd.Function):
         g = g_cost.reshape(1).contiguous().float()
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         from_p = X3 is None                                     # weight gradients from P (kernels.STEP_WGRAD_FROM_P): no x3, no da3
-        wide_d = from_p and kernels.STEP_WGRAD_ZR_TOGETHER and ctx.img_b is None
+        wide_d = from_p and kernels.STEP_WGRAD_ZR_TOGETHER
         if wide_d:
             # the gate gradients as the column blocks of ONE matrix: [d_z | d_r] is then one operand against [H | P]
             D3 = new(B, N, 3 * C)
@@ -312,7 +309,7 @@ class _TGCNWindow(torch.autograd.Function):
                                   y_out=Yout[t], target=targets[t], WzT=WzT, WrT=WrT, WhT=WhT, Wcat=Wcat, W1T=W1T, W2=W2v,
                                   dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=None if from_p else da3[t], dH=dH[t & 1],
                                   z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t], dyo=dyo[t],
-                                  w_image=ctx.img_b, w_fold_t=ctx.w_fold_t if from_p else None, ld_d=3 * C if wide_d else 0)
+                                  w_fold_t=ctx.w_fold_t if from_p else None, ld_d=3 * C if wide_d else 0)
         dx0 = kernels.gcn_agg(zbuf[0], norm, norm, bwd, ew=ew, use_node_ids=ctx.use_nid) if want_dx0 else None
         # weight gradients: one split-K launch per parameter over the window's snapshots
         steps = range(B)
@@ -637,12 +634,10 @@ class _TGCNDynWindow(torch.autograd.Function):
         x0 = x0.contiguous()
         Wcat, WcatT, b3, WzT, WrT, WhT, W1T = kernels.tgcn_pack_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, Wr, Wh, W1)
         ctx.packed_T = (WzT, WrT, WhT, W1T)
-        img_f, ctx.img_b = (kernels.tgcn_pack_weights_x3(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)
-                            if kernels.STEP_MATRIX_CORE else (None, None))          # matrix-core form: see _TGCNWindow.forward
+        from_p = kernels.STEP_WGRAD_FROM_P                      # weight gradients from P: no x3, no da3 (_TGCNWindow)
         w_fold, b_fold, f_bound, ctx.w_fold_t = (kernels.tgcn_fold_weights(Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, with_bound=True)
-                                   if kernels.STEP_FOLDED and not kernels.STEP_MATRIX_CORE else (None, None, None, None))      # folded form: likewise
+                                   if kernels.STEP_FOLDED and from_p else (None, None, None, None))      # folded form: likewise
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
-        from_p = kernels.STEP_WGRAD_FROM_P and not kernels.STEP_MATRIX_CORE       # weight gradients from P: no x3, no da3 (_TGCNWindow)
         P, X3 = new(B, N, Fin), (None if from_p else new(B, N, 3 * C))
         fold_status = kernels.step_fold_status_word(dev) if (from_p or w_fold is not None) else None
         Z, R, Ht, Hn, HR = (new(B, N, C) for _ in range(5))
@@ -666,8 +661,8 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   norm=st["normv"], x=x0 if t == 0 else Y[t - 1], H=None if t == 0 else Hn[t - 1],
                                   WcatT=WcatT, b3=b3, Wz=Wz_, bz=bz_, Wr=Wr_, br=br_, Wh=Wh_, bh=bh_, W1=W1_, b1=b1_,
                                   P=P[t], x3=None if from_p else X3[t], Z=Z[t], R=R[t], Ht=Ht[t], Hn=Hn[t], HR=HR[t], y=Y[t],
-                                  clamp_mask=mask[t], w_image=img_f, w_fold=w_fold, b_fold=b_fold,
-                                  fold_bound=f_bound if from_p else None, fold_status=fold_status)
+                                  clamp_mask=mask[t], w_fold=w_fold, b_fold=b_fold,
+                                  fold_bound=f_bound, fold_status=fold_status)
         if _fold_refused(fold_status):
             return _TGCNDynWindow.forward(ctx, x0, steps, use_nid, lo, hi, Wcz, Wcr, Wch, bcz, bcr, bch, Wz, bz, Wr, br, Wh, bh, W1, b1)
         # the decoder + loss of every snapshot behind the last step, in one launch: a snapshot's loss feeds nothing in the next one
@@ -689,7 +684,7 @@ class _TGCNDynWindow(torch.autograd.Function):
         g = g_cost.reshape(1).contiguous().float()
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         from_p = X3 is None
-        wide_d = from_p and kernels.STEP_WGRAD_ZR_TOGETHER and ctx.img_b is None      # as in _TGCNWindow.backward
+        wide_d = from_p and kernels.STEP_WGRAD_ZR_TOGETHER      # as in _TGCNWindow.backward
         if wide_d:
             D3 = new(B, N, 3 * C)
             dzl, drl, dhl, da3 = D3[:, :, :C], D3[:, :, C:2 * C], D3[:, :, 2 * C:], None
@@ -718,7 +713,7 @@ class _TGCNDynWindow(torch.autograd.Function):
                                   Z=Z[t], R=R[t], Ht=Ht[t],
                                   H=None if t == 0 else Hn[t - 1], Hn=Hn[t], clamp_mask=mask[t], WzT=WzT, WrT=WrT, WhT=WhT,
                                   Wcat=Wcat, W1T=W1T, dzl=dzl[t], drl=drl[t], dhl=dhl[t], da3=None if from_p else da3[t], dH=dH[t & 1],
-                                  z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t], w_image=ctx.img_b,
+                                  z=zbuf[t & 1] if (t > 0 or want_dx0 or from_p) else None, dyt=dyt[t],
                                   w_fold_t=ctx.w_fold_t if from_p else None, ld_d=3 * C if wide_d else 0, **kw)
         dx0 = None
         if want_dx0:

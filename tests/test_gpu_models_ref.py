@@ -71,18 +71,19 @@ def _params_close_where_adam_is_well_conditioned(model, d, tag, lr):
 def _defaults():
     from stgraph_amd import kernels
     stgraph_amd.set_reference_compat(False)
-    kernels.set_step_matrix_core(False)
+    was = kernels.STEP_FOLDED, kernels.STEP_WGRAD_FROM_P
     yield
     stgraph_amd.set_reference_compat(False)
-    kernels.set_step_matrix_core(False)
+    kernels.set_step_folded(was[0]), kernels.set_step_wgrad_from_p(was[1])
 
 
-@pytest.fixture(params=[False, True], ids=["f32_step", "matrix_core_step"])
+@pytest.fixture(params=[True, False], ids=["folded_step", "reference_formulation_step"])
 def step_form(request):
-    """Both forms of the one-launch TGCN step behind the window nodes: the fp32-instruction form (default) and the matrix-core
-    form (3-term bf16 split, csrc/tgcn_stepx_*.hip) -- against the SAME reference vectors with the SAME tolerances."""
+    """Both formulations of the one-launch TGCN step behind the window nodes: folded (default: the conv folded into the gate
+    Linears, weight gradients from P) and the reference's (x3 and da3 formed) -- against the SAME reference vectors with the SAME
+    tolerances."""
     from stgraph_amd import kernels
-    kernels.set_step_matrix_core(request.param)
+    kernels.set_step_folded(request.param), kernels.set_step_wgrad_from_p(request.param)
     return request.param
 
 

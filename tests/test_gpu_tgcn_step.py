@@ -86,31 +86,19 @@ def _alloc(cuda, n):
                 clamp_mask=torch.zeros(n, 12, dtype=torch.int32, device=cuda))
 
 
-def _images(p):
-    """The bf16 fragment images of ``_params`` (matrix-core form of the step launches)."""
-    from stgraph_amd import kernels
-    Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
-    bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
-    return kernels.tgcn_pack_weights_x3(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"], p["W1"], p["b1"],
-                                        p["W2"], p["b2"])
-
-
 def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, hi=HI, x3form=False):
     from stgraph_amd import kernels
     out = _alloc(cuda, n)
-    if x3form in ("folded", "folded32"):      # the conv folded into the gate Linears: csrc/tgcn_stepf_fwd.hip (matrix cores) /
-        Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]      # the FOLD form of csrc/tgcn_step_fwd.hip (fp32 instruction)
+    if x3form == "folded32":                  # the conv folded into the gate Linears: the FOLD form of csrc/tgcn_step_fwd.hip
+        Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
         bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
         out["w_fold"], out["b_fold"], bound, w_fold_t = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"],
                                                                                   p["bh"], with_bound=True)
         assert torch.equal(w_fold_t.view(3, FIN, C), out["w_fold"].view(3, C, FIN + C)[:, :, :FIN].transpose(1, 2))
         assert out["w_fold"].shape == (3 * C, FIN + C) and out["b_fold"].shape == (3 * C,)
         assert float(bound[0]) == float(p["Wcat"].abs().max()) and float(bound[1]) == float(p["b3"].abs().max())
-        if x3form == "folded32":               # x3 is not formed (nor asked for), the clamp is bounded instead of looked at
-            out["fold_bound"], out["x3"] = bound, None
-            out["clamp_mask"] = kernels.step_ones_mask(n, cuda)
-    elif x3form:
-        out["w_image"] = _images(p)[0]
+        out["fold_bound"], out["x3"] = bound, None     # x3 is not formed (nor asked for), the clamp is bounded instead of looked at
+        out["clamp_mask"] = kernels.step_ones_mask(n, cuda)
     nc = kernels._edge_gathered(g.fwd, "norm", norm, g.fwd.column_indices)
     ew_e = None if ew is None else kernels._edge_gathered(g.fwd, "ew", ew, g.fwd.eids)
     kernels.tgcn_step_fwd(n, C, FIN, FH, head, lo, hi, cuda, row_offsets=g.fwd.row_offset, column_indices=g.fwd.column_indices,
@@ -118,7 +106,7 @@ def _fwd(cuda, g, norm, ew, p, x, H, target, n, head=2, node_ids=False, lo=LO, h
                           x=x, H=H, target=target, WcatT=p["Wcat"].t().contiguous(), b3=p["b3"], Wz=p["Wz"], bz=p["bz"],
                           Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"], W1=p["W1"], b1=p["b1"],
                           W2=p["W2"].view(-1).contiguous(), b2=p["b2"], **out)
-    for k in ("w_image", "w_fold", "b_fold", "fold_bound"):
+    for k in ("w_fold", "b_fold", "fold_bound"):
         out.pop(k, None)
     if x3form == "folded32":                   # the launch formed no x3: what the checks downstream read is P Wcat + b3
         out["x3"] = out["P"] @ p["Wcat"] + p["b3"]
@@ -138,10 +126,6 @@ def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True
         out["da3"], use_mask = None, True
         if not want_z:
             out["z"] = new(n, FIN)
-    elif x3form == "folded":                     # the matrix-core folded forward leaves the fp32 form's saved tensors: the fp32 backward follows
-        use_mask = True
-    elif x3form:                                 # the matrix-core form reads the mask its forward twin wrote
-        out["w_image"], use_mask = _images(p)[1], True
     nc = kernels._edge_gathered(g.bwd, "norm", norm, g.bwd.column_indices)
     ew_e = None if ew is None else kernels._edge_gathered(g.bwd, "ew", ew, g.bwd.eids)
     kernels.tgcn_step_bwd(n, C, FIN, FH, head, lo, hi, cuda, row_offsets=g.bwd.row_offset, column_indices=g.bwd.column_indices,
@@ -151,7 +135,6 @@ def _bwd(cuda, g, norm, ew, p, saved, H, target, n, zn, dHn, g_cost, want_z=True
                           clamp_mask=saved["clamp_mask"] if use_mask else None, y_out=saved["y_out"], target=target,
                           WzT=p["Wz"].t().contiguous(), WrT=p["Wr"].t().contiguous(), WhT=p["Wh"].t().contiguous(),
                           Wcat=p["Wcat"], W1T=p["W1"].t().contiguous(), W2=p["W2"].view(-1).contiguous(), **out)
-    out.pop("w_image", None)
     if out.pop("w_fold_t", None) is not None:    # the launch formed no da3: what the checks downstream read is d_g Wg[:, :C]
         out["da3"] = torch.cat([out["dzl"] @ p["Wz"][:, :C], out["drl"] @ p["Wr"][:, :C], out["dhl"] @ p["Wh"][:, :C]], 1)
         if not want_z:
@@ -171,15 +154,12 @@ def _close(got, want, what, tol=2e-5):
                                                  # 7501 tiles on 3072 wave slots, one row in the last tile: every wave takes
                                                  # further tiles off the workgroup's counter
                                                  (120_001, 1_000_000, False, False)])
-@pytest.mark.parametrize("x3form", [False, True, "folded", "folded32"])
+@pytest.mark.parametrize("x3form", [False, "folded32"])
 def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3form):
-    """``x3form``: the matrix-core form of both launches (a weight image in the argument block; csrc/tgcn_stepx_*.hip) -- the SAME
-    fp64 reference and the SAME tolerances as the fp32 form.  ``"folded"``: the folded forward launch (csrc/tgcn_stepf_fwd.hip)
-    followed by the fp32 backward launch, likewise; its status word stays clear."""
+    """``x3form`` "folded32": the folded form of both launches (the conv folded into the gate Linears, no x3 / da3 formed) -- the
+    SAME fp64 reference and the SAME tolerances as the reference formulation; its status word stays clear."""
     from stgraph_amd import kernels
     kernels.step_fold_status_word(cuda).zero_()
-    if x3form and node_ids:
-        pytest.skip("the matrix-core form visits rows in vertex order (as the window nodes do); node_ids takes the fp32 form")
     g, e = _graph(cuda, n, e, seed=n)
     gen = torch.Generator(device=cuda).manual_seed(n + 1)
     deg = (g.fwd.row_offset[1:] - g.fwd.row_offset[:-1]).float()
@@ -201,7 +181,7 @@ def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3f
     b0_again = _bwd(cuda, g, norm, ew, p, s0, None, t0, n, zn=b1["z"], dHn=b1["dH"], g_cost=g_cost, node_ids=node_ids, x3form=x3form)
     assert all(torch.equal(b0[k], b0_again[k]) for k in b0)            # deterministic: no atomics, fixed orders
     assert int(kernels.step_fold_status_word(cuda).item()) == 0
-    if x3form in ("folded", "folded32"):
+    if x3form == "folded32":
         s0_again = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, node_ids=node_ids, x3form=x3form)
         assert all(torch.equal(s0[k], s0_again[k]) for k in s0)
         assert bool((s0["clamp_mask"] == 0xffff).all())
@@ -267,9 +247,10 @@ def test_two_chained_steps_match_fp64_autograd(cuda, n, e, use_ew, node_ids, x3f
     _close((b0["dyo"].double() @ s0["y"].double() + b1["dyo"].double() @ s1["y"].double()).view(1, -1), pd["W2"].grad, "dW2", btol)
 
 
-def test_folded_form_reports_a_clamp_that_bites(cuda):
-    """With a clamp range the conv output leaves, the folded forward launch still writes the exact x3 and clamp mask (the fp32
-    form's, bit for bit in the mask) and raises the sticky status word that makes check_step_fold_status() refuse the results."""
+def test_folded_form_reports_a_clamp_that_may_bite(cuda):
+    """The folded forward launch does not form x3: it refuses on its BOUND |P_r|_1 max |Wcat| + max |b3| (conservative) by raising the
+    sticky status word that check_step_fold_status() turns into an error (the epoch functions of stgraph_amd.temporal read the
+    same word and rerun instead) -- and stays silent where the bound holds (the layer's own +-1e6)."""
     from stgraph_amd import kernels
     n, lo, hi = 200, -0.25, 0.4
     g, e = _graph(cuda, n, 1500, seed=5)
@@ -279,33 +260,48 @@ def test_folded_form_reports_a_clamp_that_bites(cuda):
     x0, t0, H = torch.randn(n, FIN, device=cuda), torch.randn(n, device=cuda), torch.randn(n, C, device=cuda) * 0.3
     kernels.step_fold_status_word(cuda).zero_()
     kernels.check_step_fold_status(cuda)
-    sf = _fwd(cuda, g, norm, None, p, x0, H, t0, n, lo=lo, hi=hi, x3form="folded")
-    s0 = _fwd(cuda, g, norm, None, p, x0, H, t0, n, lo=lo, hi=hi)
-    _close(sf["x3"], s0["x3"], "x3", 1e-5)
-    far = ((s0["x3"] - lo).abs() > 1e-4) & ((s0["x3"] - hi).abs() > 1e-4)          # bits of elements not within rounding of a bound
-    def bits(m):
-        # mask word [row][gate][kq], bit 4 ct + i <-> column 16 ct + 4 kq + i
-        out = torch.zeros(n, 3, C, dtype=torch.bool, device=cuda)
-        for ct in range(4):
-            for kq in range(4):
-                for i in range(4):
-                    out[:, :, 16 * ct + 4 * kq + i] = ((m.view(n, 3, 4)[:, :, kq] >> (4 * ct + i)) & 1).bool()
-        return out.view(n, 3 * C)
-    assert torch.equal(bits(sf["clamp_mask"])[far], bits(s0["clamp_mask"])[far])
-    with pytest.raises(RuntimeError, match="folded step form"):
-        kernels.check_step_fold_status(cuda)
-    kernels.check_step_fold_status(cuda)             # cleared by the failed check
-    # the fp32-instruction folded form does not form x3: it refuses on its BOUND |P_r|_1 max |Wcat| + max |b3| (conservative: here
-    # it exceeds the range for every row) ...
     _fwd(cuda, g, norm, None, p, x0, H, t0, n, lo=lo, hi=hi, x3form="folded32")
     with pytest.raises(RuntimeError, match="folded step form"):
         kernels.check_step_fold_status(cuda)
-    # ... and stays silent where the bound holds (the layer's own +-1e6), as does the fp32 form given the status word alone
+    kernels.check_step_fold_status(cuda)             # cleared by the failed check
     _fwd(cuda, g, norm, None, p, x0, H, t0, n, x3form="folded32")
     kernels.check_step_fold_status(cuda)
+    # the un-folded form given the status word alone reports an ACTUAL clamp the same way
+    out = _alloc(cuda, n)
+    out["x3"] = None
+    nc = kernels._edge_gathered(g.fwd, "norm", norm, g.fwd.column_indices)
+    kernels.tgcn_step_fwd(n, C, FIN, FH, 2, lo, hi, cuda, row_offsets=g.fwd.row_offset, column_indices=g.fwd.column_indices, norm_col_edge=nc,
+                          norm=norm.view(-1), x=x0, H=H, target=t0, WcatT=p["Wcat"].t().contiguous(), b3=p["b3"], Wz=p["Wz"], bz=p["bz"],
+                          Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"], W1=p["W1"], b1=p["b1"], W2=p["W2"].view(-1).contiguous(),
+                          b2=p["b2"], fold_status=kernels.step_fold_status_word(cuda), **out)
+    with pytest.raises(RuntimeError, match="folded step form"):
+        kernels.check_step_fold_status(cuda)
 
 
-@pytest.mark.parametrize("x3form", [False, True])
+def test_retired_forms_are_refused(cuda):
+    """ABI 26: `w_image` (the bf16-split form) must be NULL; w_fold needs fold_bound, x3 == NULL, head >= 1 -- errors, not fallbacks."""
+    import ctypes
+    from stgraph_amd import _C
+    a = _C.TgcnStepFwdArgs()
+    a.N, a.C, a.Fin, a.Fh, a.head = 16, C, FIN, FH, 2
+    buf = torch.zeros(64, device=cuda)
+    a.w_image = buf.data_ptr()
+    with pytest.raises(_C.StgError, match="retired"):
+        _C.check(_C.lib.stg_tgcn_step_fwd(ctypes.byref(a), None))
+    b = _C.TgcnStepBwdArgs()
+    b.N, b.C, b.Fin, b.Fh, b.head = 16, C, FIN, FH, 2
+    b.w_image = buf.data_ptr()
+    with pytest.raises(_C.StgError, match="retired"):
+        _C.check(_C.lib.stg_tgcn_step_bwd(ctypes.byref(b), None))
+    a.w_image = None
+    a.w_fold = a.x = buf.data_ptr()                    # without b_fold / fold_bound / fold_status
+    with pytest.raises(_C.StgError, match="folded form needs"):
+        _C.check(_C.lib.stg_tgcn_step_fwd(ctypes.byref(a), None))
+    with pytest.raises(_C.StgError):
+        _C.set_tuning("step_impl", 1)
+
+
+@pytest.mark.parametrize("x3form", [False])
 def test_clamp_is_honoured(cuda, x3form):
     """A clamp that bites ([-0.25, 0.4] instead of the layer's +-1e6): forward clamps, x3 is kept unclamped, backward
     blocks the gradient exactly where x3 is outside [lo, hi]."""
@@ -354,7 +350,7 @@ def test_cell_only_mode_matches_the_gather_mode(cuda):
         _close(out[k], full[k], k, 1e-5)
 
 
-@pytest.mark.parametrize("x3form", [False, True])
+@pytest.mark.parametrize("x3form", [False])
 @pytest.mark.parametrize("n,e,m", [(3001, 30000, 5000), (17, 60, 40), (25_000, 250_000, 12_500)])
 def test_link_loss_backward_inside_the_step_launch(cuda, n, e, m, x3form):
     """head == 1 with the link_* fields: the node side of the link-prediction loss's backward (stg_link_decode_bwd) taken inside
@@ -368,7 +364,6 @@ def test_link_loss_backward_inside_the_step_launch(cuda, n, e, m, x3form):
     x0 = torch.randn(n, FIN, device=cuda, generator=gen)
     H = torch.randn(n, C, device=cuda, generator=gen) * 0.3
     s = _fwd(cuda, g, norm, None, p, x0, H, torch.zeros(n, device=cuda), n, head=1, x3form=x3form)
-    img = _images(p)[1] if x3form else None
     edge_index = torch.randint(0, n, (2, m), device=cuda, generator=gen)
     target = (torch.rand(m, device=cuda, generator=gen) < 0.5).float()
     y = s["y"]
@@ -385,7 +380,7 @@ def test_link_loss_backward_inside_the_step_launch(cuda, n, e, m, x3form):
         kernels.tgcn_step_bwd(n, C, FIN, FH, 1, LO, HI, cuda, row_offsets=g.bwd.row_offset, column_indices=g.bwd.column_indices,
                               norm_col_edge=nc, norm=norm.view(-1), zn=zn, dHn=dHn, Z=s["Z"], R=s["R"], Ht=s["Ht"], H=H,
                               Hn=s["Hn"], clamp_mask=s["clamp_mask"], WzT=p["Wz"].t().contiguous(), WrT=p["Wr"].t().contiguous(),
-                              WhT=p["Wh"].t().contiguous(), Wcat=p["Wcat"], W1T=p["W1"].t().contiguous(), w_image=img, **out, **kw)
+                              WhT=p["Wh"].t().contiguous(), Wcat=p["Wcat"], W1T=p["W1"].t().contiguous(), **out, **kw)
         return out
     dy = torch.empty(n, FH, device=cuda)
     kernels.link_decode_bwd(g_cost, y, logits, target, inc, dy)
@@ -412,97 +407,6 @@ def _bf16_terms_to_f64(words):
     """[..., 3 terms, 8] uint16 bf16 bit patterns -> the fp64 sum of the three terms."""
     u = words.astype(np.uint32) << 16
     return u.view(np.float32).astype(np.float64).sum(-2)
-
-
-def test_pack_weights_x3_images(cuda):
-    """stg_tgcn_pack_weights_x3: every weight of the images is the sum of its three bf16 terms to 2^-24 relative, and sits where
-    csrc/tgcn_stepx.hpp says (lane (m16, kq), element i of K-block b <-> input column 32 b + 16 (i >> 2) + 4 kq + (i & 3))."""
-    p = _params(cuda, 11)
-    fwd, bwd = _images(p)
-    W = {k: v.cpu().numpy().astype(np.float64) for k, v in p.items()}
-    xcol = lambda b, kq, i: 32 * b + 16 * (i >> 2) + 4 * kq + (i & 3)  # noqa: E731
-    m16, kq, i8 = np.arange(64) % 16, np.arange(64) // 16, np.arange(8)
-    cols = lambda b: xcol(b, kq[:, None], i8[None, :])  # noqa: E731  [lane, 8]
-
-    def section(img, offset, nfrag):                      # -> [nfrag / 3, lane, 3 terms, 8] fp64 sums [.., lane, 8]
-        raw = img[offset:offset + nfrag * 1024].cpu().numpy().view(np.uint16).reshape(nfrag // 3, 3, 64, 8)
-        return _bf16_terms_to_f64(raw.transpose(0, 2, 1, 3))
-
-    def check(got, want, what):
-        err = np.abs(got - want).max() / np.abs(want).max()
-        assert err <= 2.0 ** -23, (what, err)
-
-    gates = [W["Wz"], W["Wr"], W["Wh"]]
-    f_gate = section(fwd, 0, 4 * 36).reshape(4, 3, 4, 64, 8)
-    for ct in range(4):
-        for g in range(3):
-            for b in range(4):
-                check(f_gate[ct, g, b], gates[g][(16 * ct + m16)[:, None], cols(b)], f"fwd gate {ct} {g} {b}")
-    f_cat = section(fwd, 4 * 36 * 1024, 4 * 9).reshape(4, 3, 64, 8)
-    for ct in range(4):
-        for g in range(3):
-            check(f_cat[ct, g], W["Wcat"][cols(0), (g * C + 16 * ct + m16)[:, None]], f"fwd cat {ct} {g}")
-    f_head = section(fwd, (4 * 36 + 4 * 9) * 1024, 2 * 6).reshape(2, 2, 64, 8)
-    for ft in range(2):
-        for b in range(2):
-            check(f_head[ft, b], W["W1"][(16 * ft + m16)[:, None], cols(b)], f"fwd head {ft} {b}")
-    tail = fwd[(4 * 36 + 4 * 9 + 2 * 6) * 1024:].cpu().numpy().view(np.float32)
-    want = np.concatenate([p[k].cpu().numpy().reshape(-1) for k in ("b3", "bz", "br", "bh", "b1", "W2", "b2")])
-    assert np.array_equal(tail[:want.size], want)
-    b_gate = section(bwd, 0, 4 * 36).reshape(4, 3, 2, 2, 64, 8)
-    for ct in range(4):
-        for g in range(3):
-            for half in range(2):
-                for b in range(2):
-                    check(b_gate[ct, g, half, b], gates[g][cols(b), (half * C + 16 * ct + m16)[:, None]], f"bwd gate {ct} {g} {half} {b}")
-    b_head = section(bwd, 4 * 36 * 1024, 4 * 3).reshape(4, 64, 8)
-    for ct in range(4):
-        check(b_head[ct], W["W1"][cols(0), (16 * ct + m16)[:, None]], f"bwd head {ct}")
-    b_cat = section(bwd, (4 * 36 + 4 * 3) * 1024, 2 * 18).reshape(2, 6, 64, 8)
-    for ft in range(2):
-        for b in range(6):
-            check(b_cat[ft, b], W["Wcat"][(16 * ft + m16)[:, None], cols(b)], f"bwd cat {ft} {b}")
-
-
-@pytest.mark.parametrize("n,e,use_ew,head", [(300, 2400, True, 2), (3001, 30000, False, 2), (17, 60, True, 2), (1, 1, False, 2),
-                                              (50_000, 500_000, True, 2), (25_000, 250_000, False, 1), (120_001, 1_000_000, False, 2)])
-def test_matrix_core_forward_matches_the_fp32_form(cuda, n, e, use_ew, head):
-    """stg_tgcn_step_fwd given a weight image (csrc/tgcn_stepx_fwd.hip: 3-term bf16 split on the matrix cores) against the fp32
-    form of the same launch on the same inputs: P bit for bit (same gather arithmetic), every other output to 1e-5 of its largest
-    entry -- fp32-class: the fp32 form itself stands 2e-5 from fp64 (test_two_chained_steps_match_fp64_autograd) --, two
-    chained steps so that H != 0 is exercised."""
-    from stgraph_amd import _C
-    g, e = _graph(cuda, n, e, seed=n + 7) if n > 1 else _graph(cuda, 2, 1, seed=1)
-    n = max(n, 2)
-    gen = torch.Generator(device=cuda).manual_seed(n + 1)
-    deg = (g.fwd.row_offset[1:] - g.fwd.row_offset[:-1]).float()
-    norm = torch.where(deg > 0, deg.clamp(min=1) ** -0.5, torch.zeros_like(deg)).view(-1, 1)
-    ew = (torch.rand(e, 1, device=cuda, generator=gen) + 0.5) if use_ew else None
-    p = _params(cuda, n + 2)
-    x0 = torch.randn(n, FIN, device=cuda, generator=gen)
-    t0, t1 = torch.randn(n, device=cuda, generator=gen), torch.randn(n, device=cuda, generator=gen)
-    res = []
-    for x3form in (False, True):
-        s0 = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, head=head, x3form=x3form)
-        s1 = _fwd(cuda, g, norm, ew, p, s0["y"], s0["Hn"], t1, n, head=head, x3form=x3form)
-        res.append((s0, s1))
-    keys = ["x3", "Z", "R", "Ht", "Hn", "HR", "y"] + (["y_out", "loss_partial"] if head == 2 else [])
-    for k_step in range(2):
-        a, b = res[0][k_step], res[1][k_step]
-        if k_step == 0:
-            assert torch.equal(a["P"], b["P"])
-        for k in keys:
-            _close(b[k], a[k], f"step {k_step} {k}", 1e-5)
-    # the matrix-core form is deterministic: a second launch gives the same bits
-    again = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, head=head, x3form=True)
-    assert all(torch.equal(again[k], res[1][0][k]) for k in keys + ["P", "clamp_mask"])
-    # the knob forces the fp32 form even with an image: bit-identical to the launch without one
-    _C.set_tuning("step_impl", 1)
-    try:
-        s0 = _fwd(cuda, g, norm, ew, p, x0, None, t0, n, head=head, x3form=True)
-    finally:
-        _C.set_tuning("step_impl", 0)
-    assert all(torch.equal(s0[k], res[0][0][k]) for k in keys + ["P"])
 
 
 def test_unfold_gate_grads_kernel_against_its_torch_statement(cuda):

@@ -82,26 +82,9 @@ def main():
     out["x3"], bo["da3"] = None, None
     res["step_fwd_no_x3_us"], res["step_bwd_no_da3_us"] = timed(fwd), timed(bwd)
     out["x3"], bo["da3"] = keep
-    # the matrix-core form of the same two launches (csrc/tgcn_stepx_*.hip): a weight image in the argument block
     Wc = [p["Wcat"][:, k * C:(k + 1) * C].contiguous() for k in range(3)]
     bc = [p["b3"][k * C:(k + 1) * C].contiguous() for k in range(3)]
-    img_f, img_b = kernels.tgcn_pack_weights_x3(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"], p["W1"], p["b1"],
-                                                p["W2"], p["b2"])
-    res["pack_weights_x3_us"] = timed(lambda: kernels.tgcn_pack_weights_x3(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"],
-                                                                           p["bh"], p["W1"], p["b1"], p["W2"], p["b2"]))
-    out["w_image"], bo["w_image"] = img_f, img_b
-    fwd()                                                          # the mask in the matrix-core layout for its backward twin
-    res["stepx_fwd_us"], res["stepx_bwd_us"] = timed(fwd), timed(bwd)
-    del out["w_image"], bo["w_image"]
-    # the folded form of the forward launch (csrc/tgcn_stepf_fwd.hip): the conv folded into the gate Linears
-    w_fold, b_fold = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"])
-    res["fold_weights_us"] = timed(lambda: kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"]))
     ref = {k: v.clone() for k, v in out.items()}
-    out["w_fold"], out["b_fold"] = w_fold, b_fold
-    fwd()
-    res["stepf_fwd_us"] = timed(fwd)
-    res["stepf_status"] = int(kernels.step_fold_status_word(dev).item())
-    res["stepf_max_err_vs_fp32_form"] = {k: float((out[k] - ref[k]).abs().max()) for k in ("x3", "Z", "R", "Ht", "Hn", "HR", "y", "y_out")}
     # the folded form on the fp32 instruction (the default of the window nodes): forward from P on the folded weights, no x3;
     # backward with z from d_g and the folded weights' transposed P part, no da3
     w_fold2, b_fold2, bound, w_fold_t = kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"], p["bh"],
@@ -109,20 +92,13 @@ def main():
     res["fold_weights_with_bound_us"] = timed(lambda: kernels.tgcn_fold_weights(*Wc, *bc, p["Wz"], p["bz"], p["Wr"], p["br"], p["Wh"],
                                                                                 p["bh"], with_bound=True))
     keep2 = out["x3"], bo["da3"]
-    out["fold_bound"], out["x3"], bo["w_fold_t"], bo["da3"] = bound, None, w_fold_t, None
+    out["w_fold"], out["b_fold"], out["fold_bound"], out["x3"], bo["w_fold_t"], bo["da3"] = w_fold2, b_fold2, bound, None, w_fold_t, None
     fwd()
     res["step_fwd_folded_fp32_us"], res["step_bwd_folded_fp32_us"] = timed(fwd), timed(bwd)
     res["step_folded_fp32_max_err_vs_fp32_form"] = {k: float((out[k] - ref[k]).abs().max()) for k in ("Z", "R", "Ht", "Hn", "HR", "y", "y_out")}
-    del out["fold_bound"], bo["w_fold_t"]
+    del out["fold_bound"], bo["w_fold_t"], out["w_fold"], out["b_fold"]
     out["x3"], bo["da3"] = keep2
-    # ... and the same launch given P (no gather inside), next to the aggregation launch that would produce it
-    def fwd_noagg():
-        kernels.tgcn_step_fwd(n, C, FIN, FH, 2, -1e6, 1e6, dev, norm=norm.view(-1), H=H, target=tgt, WcatT=WcatT,
-                              b3=p["b3"], Wz=p["Wz"], bz=p["bz"], Wr=p["Wr"], br=p["br"], Wh=p["Wh"], bh=p["bh"],
-                              W1=p["W1"], b1=p["b1"], W2=p["W2"], b2=p["b2"], **out)
-    res["stepf_fwd_given_P_us"] = timed(fwd_noagg)
     res["gcn_agg_F32_us"] = timed(lambda: kernels.gcn_agg(x, norm, norm, f, ew=ew))
-    del out["w_fold"], out["b_fold"]
     fwd()
 
     # ablations: which phase costs what
