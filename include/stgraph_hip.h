@@ -66,7 +66,8 @@ const char *stg_last_error_string(void);
  * every product as a 3-term bf16 split on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, 1 = always v_mfma_f32_16x16x4_f32, 2 = the
  * split form at every N, 3 = its lane-owns-row-pieces load / store variant (diagnosis); the one knob that selects between two
  * ARITHMETICS: both forms inside the fp32 kernel's error bound against fp64, integer data exact in both), "step_spread"
- * (0 = one workgroup per CU when there are fewer tiles than wave slots, 1 = packed grid), "gemm_wide" (tall-skinny weight
+ * (0 = one workgroup per CU when there are fewer tiles than wave slots, 1 = packed grid), "step_coop" (stg_tgcn_step_*, tiles of the
+ * last partial round: 0 = each shared by four waves of its workgroup -- bit-identical results --, 1 = one wave each), "gemm_wide" (tall-skinny weight
  * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_cyclic" (its row-group hand-out: 0 .. 2), "gemm_xcd_pair" (its
  * workgroup order when M x N takes several workgroups per K slice: 0 = those of a slice on one XCD, 1 = dealt in turn),
  * "gcn_wide_long" (rows of >= 1024 edges at F >= 128: 0 = feature-sliced workgroups beside the main launch, 1 = never, 2 = behind

@@ -280,8 +280,8 @@ extern "C" int stg_graph_build_device(const int32_t *src, const int32_t *dst, in
     size_t sort_tmp_bytes = L.sort_tmp_bytes;
 
     const int bits = key_bits_for(N);
-    hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), stream);
-    if (e != hipSuccess) return fail((int)e, "stg_graph_build_device: memset: %s", hipGetErrorString(e));
+    if (const int rc = zero_async(status, sizeof(int32_t), stream)) return rc;
+    hipError_t e = hipSuccess;
 
     const int threads = kBlock;
     const int eblocks = (int)std::min<int64_t>((E + threads - 1) / threads, 256 * 16);

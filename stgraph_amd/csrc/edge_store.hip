@@ -563,8 +563,8 @@ extern "C" int stg_edgeset_update_device(const uint64_t *keys_fwd_in, const uint
     void *sort_tmp = ws + L.sort_tmp;
     const unsigned end_bit = (unsigned)(kStoreBits + key_bits_for(N));
 
-    hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), stream);
-    if (e != hipSuccess) return fail((int)e, "stg_edgeset_update_device: memset: %s", hipGetErrorString(e));
+    if (const int rc = zero_async(status, sizeof(int32_t), stream)) return rc;
+    hipError_t e = hipSuccess;
 
     // pack + sort the two batches in both orientations (batches are small next to E)
     for (int which = 0; which < 2; ++which) {
@@ -580,8 +580,7 @@ extern "C" int stg_edgeset_update_device(const uint64_t *keys_fwd_in, const uint
         tmp = L.sort_tmp_bytes;
         e = rocprim::radix_sort_keys(sort_tmp, tmp, kb, staging, (size_t)n, 0, end_bit, stream);
         if (e != hipSuccess) return fail((int)e, "stg_edgeset_update_device: sort: %s", hipGetErrorString(e));
-        e = hipMemcpyAsync(kb, staging, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return fail((int)e, "stg_edgeset_update_device: copy: %s", hipGetErrorString(e));
+        if (const int rc = copy_async(kb, staging, sizeof(uint64_t) * (size_t)n, stream)) return rc;
     }
     for (int side = 0; side < 2; ++side) {
         const uint64_t *old = side == 0 ? keys_fwd_in : keys_bwd_in;

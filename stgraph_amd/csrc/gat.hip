@@ -1255,8 +1255,7 @@ extern "C" int stg_gat_score_flag(const float *el, const float *er, int64_t n, i
     using namespace stg;
     if (n < 0 || !flag) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_score_flag: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
-    if (e != hipSuccess) return fail((int)e, "stg_gat_score_flag: %s", hipGetErrorString(e));
+    if (const int rc = zero_async(flag, sizeof(int32_t), st)) return rc;
     if (n == 0) return 0;
     if (!el || !er) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_score_flag: NULL pointer argument");
     const unsigned grid = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 256 * 8);

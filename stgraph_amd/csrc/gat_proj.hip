@@ -179,10 +179,8 @@ extern "C" int stg_gat_proj_bwd(const float *feat, const float *attn_l, const fl
     if (N < 0 || !proj_shape_ok(H, D)) return fail(STG_ERR_UNSUPPORTED, "stg_gat_proj_bwd: unsupported shape N=%lld H=%d D=%d", (long long)N, H, D);
     if (!dattn_l || !dattn_r) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_proj_bwd: NULL pointer argument");
     if (N == 0) {
-        hipError_t e = hipMemsetAsync(dattn_l, 0, sizeof(float) * (size_t)H * D, stream);
-        if (e == hipSuccess) e = hipMemsetAsync(dattn_r, 0, sizeof(float) * (size_t)H * D, stream);
-        if (e != hipSuccess) return fail((int)e, "stg_gat_proj_bwd: %s", hipGetErrorString(e));
-        return 0;
+        if (const int rc = zero_async(dattn_l, sizeof(float) * (size_t)H * D, stream)) return rc;
+        return zero_async(dattn_r, sizeof(float) * (size_t)H * D, stream);
     }
     if (!feat || !attn_l || !attn_r || !del || !der || !dfeat) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_proj_bwd: NULL pointer argument");
     const int blocks = proj_grid(N, H, D);

@@ -184,7 +184,7 @@ extern "C" int stg_bias_act_bwd(const float *g, const float *out, float *g_act, 
     Shape s;
     if (!shape_for(std::max(N, 1), F, s)) return fail(STG_ERR_UNSUPPORTED, "stg_bias_act_bwd: F=%d too wide", F);
     if (N == 0) {
-        if (colsum) return (int)hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)F, stream);
+        if (colsum) return zero_async(colsum, sizeof(float) * (size_t)F, stream);
         return 0;
     }
     if (!g) return fail(STG_ERR_INVALID_ARGUMENT, "stg_bias_act_bwd: NULL pointer argument");

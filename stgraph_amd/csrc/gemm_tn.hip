@@ -728,9 +728,8 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
     if (!C) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL output", what);
     if (K == 0 && defer_slabs) return fail(STG_ERR_INVALID_ARGUMENT, "%s: K = 0 has no slabs to defer", what);
     if (K == 0) {
-        hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, stream);
-        if (e == hipSuccess && colsum) e = hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)M, stream);
-        return e == hipSuccess ? 0 : fail((int)e, "%s: %s", what, hipGetErrorString(e));
+        if (const int rc = zero_async(C, sizeof(float) * (size_t)M * N, stream)) return rc;
+        return colsum ? zero_async(colsum, sizeof(float) * (size_t)M, stream) : 0;
     }
     if (!As || !Bs || !workspace) return fail(STG_ERR_INVALID_ARGUMENT, "%s: NULL pointer argument", what);
     GemmForm form{M, N, 0, N, STG_GEMM_B_NONE, 0.f, 0.f, 0};

@@ -1,4 +1,6 @@
 // Error reporting, ABI version and tuning knobs of libstgraph_hip.so.
+#include <algorithm>
+
 #include "stg_common.hpp"
 
 #include <cstring>
@@ -33,6 +35,40 @@ Tuning &tuning()
     return t;
 }
 
+}  // namespace stg
+
+namespace stg {
+namespace {
+__global__ __launch_bounds__(kBlock) void zero_words_kernel(uint32_t *__restrict__ p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) p[i] = 0u;
+}
+__global__ __launch_bounds__(kBlock) void copy_words_kernel(uint32_t *__restrict__ d, const uint32_t *__restrict__ s, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) d[i] = s[i];
+}
+}  // namespace
+
+int zero_async(void *dst, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return 0;
+    if (!dst || (bytes & 3) || (reinterpret_cast<uintptr_t>(dst) & 3)) return fail(STG_ERR_INVALID_ARGUMENT, "zero_async: bad destination");
+    const size_t n = bytes / 4;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0, stream,
+                       static_cast<uint32_t *>(dst), n);
+    return check_launch("zero_async");
+}
+
+int copy_async(void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return 0;
+    if (!dst || !src || (bytes & 3) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 3))
+        return fail(STG_ERR_INVALID_ARGUMENT, "copy_async: bad operands");
+    const size_t n = bytes / 4;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0, stream,
+                       static_cast<uint32_t *>(dst), static_cast<const uint32_t *>(src), n);
+    return check_launch("copy_async");
+}
 }  // namespace stg
 
 extern "C" int stg_abi_version(void) { return STG_ABI_VERSION; }
@@ -118,6 +154,7 @@ extern "C" int stg_set_tuning(const char *key, int value)
         return 0;
     }
     if (!std::strcmp(key, "step_spread")) { tuning().step_spread = value; return 0; }
+    if (!std::strcmp(key, "step_coop")) { tuning().step_coop = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "build_lds_count")) {
         if (value < 0 || value > 2) return fail(STG_ERR_INVALID_ARGUMENT, "build_lds_count must be 0 (auto), 1 (always when |V| fits) or 2 (never)");
         tuning().build_lds_count = value;

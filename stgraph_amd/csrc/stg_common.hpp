@@ -19,6 +19,13 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 char *last_error_buffer();
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
+// Zero-fill / device-to-device copy AS KERNELS.  hipMemsetAsync / hipMemcpyAsync become memset / copy NODES when the stream is being
+// captured, and a replayed HIP graph did not always order such a node before the kernel node that follows it (round 5: the two
+// floats stg_tgcn_fold_weights zeroes before its atomicMax kept the pool's old bits -- NaN -- in about one replayed window of 150;
+// the step launch then reported a clamp that never happened).  A kernel node is ordered like every other launch of the library.
+// bytes % 4 == 0, 4-byte aligned pointers.
+int zero_async(void *dst, size_t bytes, hipStream_t stream);
+int copy_async(void *dst, const void *src, size_t bytes, hipStream_t stream);
 
 struct Tuning {
     int gcn_lanes_per_row = 0;     // 0 = auto
@@ -35,6 +42,7 @@ struct Tuning {
     int gcn_xcd_tile = 0;          // 0 = auto; 1 = workgroups round-robin over XCDs; T = runs of T workgroups per XCD
     int step_waves = 0;            // one-launch TGCN step: 0 = auto, 12 / 16 waves per workgroup (168 / 128 registers)
     int gcn_wide_long = 0;         // hubs of rows >= 64 lanes wide: 0 = feature-sliced workgroups (F % 4 == 0, F <= 256), 1 = never
+    int step_coop = 0;             // one-launch TGCN step, tiles of the last partial round: 0 = shared by four waves (one per SIMD) where that helps, 1 = one wave each
     int step_spread = 0;           // one-launch TGCN step with fewer tiles than wave slots: 0 = one workgroup per CU, 1 = packed grid
     int store_rows = 0;            // stg_edgeset_step_device with row-offset hints: 0 = new row offsets derived from them inside the merge launch, 1 = searched in their own launch
     int build_lds_count = 0;       // per-snapshot CSR build: 0 = auto (histograms in LDS when |V| fits and the graph is dense enough), 1 = always when |V| fits, 2 = never

@@ -21,6 +21,7 @@ struct BwdArgs {
     int64_t N;
     float lo, hi, two_over_n;
     int num_tiles;
+    int no_coop;                                               // knob "step_coop" 1
 };
 
 // FOLD: the input gradient z = da3 Wcat^T with da3_g = d_g Wg[:, :C] is  sum_g d_g At_g^T  with At_g [Fin][C] = (the folded gate
@@ -34,7 +35,10 @@ struct BwdShape {
     static constexpr int kCat = FOLD ? 3 * FIN * LDB : FIN * LDX;     // Wcat [FIN][LDX] (FOLD: At [3 FIN][LDB])
     static constexpr int kHead = HEAD ? C * LDT : 0;          // W1T [C][LDT]
     static constexpr int kBias = FH + 4;                      // W2
-    static constexpr int kFloats = kGate + kCat + kHead + kBias;
+    // shared tiles of the partial round (tgcn_step_fwd.hip): per group of four waves three [16][LDXB] exchange buffers (d_h, d_z, d_r)
+    static constexpr int GROUPS = WAVES / 8, LDXB = C + 8;
+    static constexpr int kCoop = (FOLD && GATHER && HEAD == 2) ? GROUPS * 3 * 16 * LDXB + 8 : 0;
+    static constexpr int kFloats = kGate + kCat + kHead + kBias + kCoop;
     static constexpr size_t kLds = sizeof(float) * (size_t)kFloats;
     static_assert(kLds <= 160 * 1024, "the weights must fit one CU's LDS");
 };
@@ -59,7 +63,21 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
     STG_TRACE_MARK(0);
     STG_TRACE_MARK(14);
     if (threadIdx.x == 0) *next_w = WAVES;
-    int tile = wave * (int)gridDim.x + (int)blockIdx.x;
+    // hand-out order, full rounds and the partial round shared four waves to a tile: see tgcn_step_fwd.hip
+    const int grid = (int)gridDim.x, blk = (int)blockIdx.x;
+    const int full_rounds = a.num_tiles / (WAVES * grid);
+    const int rem = a.num_tiles - full_rounds * WAVES * grid;
+    const int cnt_b = rem > blk ? (rem - blk - 1) / grid + 1 : 0;
+    constexpr bool kCanCoop = FOLD && GATHER && HEAD == 2;
+    const bool coop = kCanCoop && full_rounds >= 1 && cnt_b > 0 && 8 * cnt_b <= WAVES && !a.node_ids && !a.no_coop && a.z != nullptr;
+    const int seq_end = full_rounds * WAVES + (coop ? 0 : cnt_b);
+    int seq = wave;
+    int *const coop_cnt = reinterpret_cast<int *>(bs + S::kBias);
+    float *const xbuf = bs + S::kBias + 8;
+    if constexpr (kCanCoop) {
+        if (threadIdx.x < 8) coop_cnt[threadIdx.x] = 0;
+    }
+    int tile = seq * grid + blk;
     const bool want_z = a.z != nullptr;                // block-uniform
     constexpr int kStage4 = ((FOLD ? 3 * C * C : 3 * 2 * C * C) + FIN * 3 * C + (HEAD ? C * FH : 0)) / 4;
     constexpr int GR = FOLD ? C : 2 * C;                // rows of a gate's block in LDS (FOLD: its H half, rows C .. 2C - 1 of W_g^T)
@@ -78,9 +96,13 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         return a.node_ids ? a.node_ids[gidx] : (int)gidx;
     };
     stager.issue(segs);
+    float sv = 0.f;                                    // W2: its load in flight with the staging loads (tgcn_step_fwd.hip)
+    if constexpr (HEAD == 2) {
+        if ((int)threadIdx.x < FH) sv = a.W2[threadIdx.x];
+    }
     stager.commit(segs);
     if constexpr (HEAD == 2) {
-        for (int i = threadIdx.x; i < FH; i += NT) bs[i] = a.W2[i];
+        if ((int)threadIdx.x < FH) bs[threadIdx.x] = sv;
     }
     __syncthreads();
     STG_TRACE_MARK(1);
@@ -90,7 +112,113 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
     const float *const wg_l = WgT + pinned((unsigned)(n16 * LDB + 4 * kq)), *const wcrow = Wc + pinned((unsigned)(n16 * (FOLD ? LDB : LDX) + 4 * kq));
     const float *const w1_l = W1T + pinned((unsigned)(n16 * LDT + 4 * kq)), *const bs_l = bs + pinned((unsigned)(4 * kq));
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    while (tile < a.num_tiles) {
+
+    // ---- the partial round first, four waves per tile, each one 16-column block of every product (tgcn_step_fwd.hip); what a later
+    // product needs at full width -- d_h and d_z, then d_r -- crosses through LDS.  Same chains in the same order: bit-identical.
+    if constexpr (kCanCoop) {
+        if (coop && (wave >> 2) < cnt_b) {
+            constexpr int LDXB = S::LDXB;
+            const int grp = wave >> 2, cb = wave & 3;
+            float *const xb_l = xbuf + grp * 3 * 16 * LDXB + pinned((unsigned)(n16 * LDXB + 4 * kq));
+            volatile int *const cnt = coop_cnt + grp;
+            int phase = 0;
+            auto group_sync = [&]() {
+                phase += 4;
+                __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): this wave's LDS writes before its counter bump
+                if (lane == 0) atomicAdd(const_cast<int *>(cnt), 1);
+                while (*cnt < phase) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+            };
+            for (int ct = grp; ct < cnt_b; ct += S::GROUPS) {
+                const int ctile = (full_rounds * WAVES + ct) * grid + blk;
+                STG_TRACE_MARK(10);
+                float4 gp[PH];
+#pragma unroll
+                for (int j = 0; j < PH; ++j) gp[j] = zero4;
+                if (do_gather) {
+                    RowGather32<HAS_EW> rg;
+                    rg.begin(a.row_offsets, a.norm, gather_row(ctile));
+                    rg.indices(a.column_indices, a.nc_edge, a.ew_edge, 0, q);
+                    float p8[8];
+                    rg.run(p8, a.zn, a.column_indices, a.nc_edge, a.ew_edge, q);
+                    gather_to_pieces(p8, gp, n16, kq);
+                }
+                const unsigned row = (unsigned)std::min<int64_t>((int64_t)ctile * 16 + n16, a.N - 1);
+                const unsigned oC = (row * C + 4u * kq) * 4u + 64u * cb, o3 = (row * (3u * C) + 4u * kq) * 4u + 64u * cb;
+                const unsigned oF = (row * FH + 4u * kq) * 4u, oD = a.d_wide ? o3 : oC;
+                // this wave's column block of the row-local operands; the head's input at full width (every wave forms it)
+                float4 gy[PH];
+#pragma unroll
+                for (int j = 0; j < PH; ++j) gy[j] = a.gy ? ld_f4(a.gy, oF, 64 * j) : zero4;
+                const float yo = ld_f1(a.y_out, row * 4u), tg = ld_f1(a.target, row * 4u), gc = a.g_cost[0];
+                const float4 hn = ld_f4(a.Hn, oC, 0), zz = ld_f4(a.Z, oC, 0), tt = ld_f4(a.Ht, oC, 0), rr = ld_f4(a.R, oC, 0);
+                float4 dhn = a.dHn ? ld_f4(a.dHn, oC, 0) : zero4;
+                const float4 hh = a.H ? ld_f4(a.H, oC, 0) : zero4;
+#pragma unroll
+                for (int j = 0; j < PH; ++j) gy[j] = make_float4(gy[j].x + gp[j].x, gy[j].y + gp[j].y, gy[j].z + gp[j].z, gy[j].w + gp[j].w);
+                const float dyo = ((yo - tg) * a.two_over_n) * gc;
+                if (cb == 0 && kq == 0) st_f1(a.dyo, row * 4u, dyo);
+#pragma unroll
+                for (int j = 0; j < PH; ++j) {
+                    const float4 w2 = *reinterpret_cast<const float4 *>(bs_l + 16 * j);
+                    gy[j] = make_float4(gy[j].x + dyo * w2.x, gy[j].y + dyo * w2.y, gy[j].z + dyo * w2.z, gy[j].w + dyo * w2.w);
+                }
+                if (cb == 0) {
+#pragma unroll
+                    for (int j = 0; j < PH; ++j) st_f4(a.dyt, oF, 64 * j, gy[j]);
+                }
+                f32x4 acc[1];
+                acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_pieces<1, PH, false>(acc, w1_l + 16 * cb * LDT, LDT, [&](int j) { return gy[j]; });
+                dhn.x = dhn.x + (hn.x > 0.f ? acc[0][0] : 0.f);
+                dhn.y = dhn.y + (hn.y > 0.f ? acc[0][1] : 0.f);
+                dhn.z = dhn.z + (hn.z > 0.f ? acc[0][2] : 0.f);
+                dhn.w = dhn.w + (hn.w > 0.f ? acc[0][3] : 0.f);
+                const float4 g = dhn, z = zz, t = tt, h = hh;
+                const float4 dhl1 = make_float4((g.x * (1.0f - z.x)) * (1.0f - t.x * t.x), (g.y * (1.0f - z.y)) * (1.0f - t.y * t.y),
+                                                (g.z * (1.0f - z.z)) * (1.0f - t.z * t.z), (g.w * (1.0f - z.w)) * (1.0f - t.w * t.w));
+                const float4 dz1 = make_float4((g.x * (h.x - t.x)) * (z.x * (1.0f - z.x)), (g.y * (h.y - t.y)) * (z.y * (1.0f - z.y)),
+                                               (g.z * (h.z - t.z)) * (z.z * (1.0f - z.z)), (g.w * (h.w - t.w)) * (z.w * (1.0f - z.w)));
+                float4 dHa = make_float4(g.x * z.x, g.y * z.y, g.z * z.z, g.w * z.w);
+                st_f4(a.dhl, oD, 0, dhl1);
+                st_f4(a.dzl, oD, 0, dz1);
+                *reinterpret_cast<float4 *>(xb_l + 16 * cb) = dhl1;
+                *reinterpret_cast<float4 *>(xb_l + 16 * LDXB + 16 * cb) = dz1;
+                group_sync();
+                float4 dhl[PC], dzl[PC];
+#pragma unroll
+                for (int j = 0; j < PC; ++j) dhl[j] = *reinterpret_cast<const float4 *>(xb_l + 16 * j), dzl[j] = *reinterpret_cast<const float4 *>(xb_l + 16 * LDXB + 16 * j);
+                // z (FIN = 2 column blocks: waves 0 and 1 of the group), gates in the tile loop's order h, z, r
+                f32x4 zacc[1];
+                zacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (cb < PF) gemm_pieces<1, PC, false>(zacc, wcrow + (2 * FIN + 16 * cb) * LDB, LDB, [&](int j) { return dhl[j]; });
+                acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_pieces<1, PC, false>(acc, wg_l + (2 * C + 16 * cb) * LDB, LDB, [&](int j) { return dhl[j]; });
+                const float4 d = to_f4(acc[0]);
+                const float4 drl1 = make_float4((d.x * h.x) * (rr.x * (1.0f - rr.x)), (d.y * h.y) * (rr.y * (1.0f - rr.y)),
+                                                (d.z * h.z) * (rr.z * (1.0f - rr.z)), (d.w * h.w) * (rr.w * (1.0f - rr.w)));
+                dHa = make_float4(dHa.x + d.x * rr.x, dHa.y + d.y * rr.y, dHa.z + d.z * rr.z, dHa.w + d.w * rr.w);
+                st_f4(a.drl, oD, 0, drl1);
+                *reinterpret_cast<float4 *>(xb_l + 2 * 16 * LDXB + 16 * cb) = drl1;
+                if (cb < PF) gemm_pieces<1, PC, false>(zacc, wcrow + (0 * FIN + 16 * cb) * LDB, LDB, [&](int j) { return dzl[j]; });
+                acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_pieces<1, PC, false>(acc, wg_l + (0 * C + 16 * cb) * LDB, LDB, [&](int j) { return dzl[j]; });
+                dHa = make_float4(dHa.x + acc[0][0], dHa.y + acc[0][1], dHa.z + acc[0][2], dHa.w + acc[0][3]);
+                group_sync();
+                float4 drl[PC];
+#pragma unroll
+                for (int j = 0; j < PC; ++j) drl[j] = *reinterpret_cast<const float4 *>(xb_l + 2 * 16 * LDXB + 16 * j);
+                if (cb < PF) gemm_pieces<1, PC, false>(zacc, wcrow + (1 * FIN + 16 * cb) * LDB, LDB, [&](int j) { return drl[j]; });
+                acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_pieces<1, PC, false>(acc, wg_l + (1 * C + 16 * cb) * LDB, LDB, [&](int j) { return drl[j]; });
+                st_f4(a.dH, oC, 0, make_float4(dHa.x + acc[0][0], dHa.y + acc[0][1], dHa.z + acc[0][2], dHa.w + acc[0][3]));
+                if (cb < PF) st_f4(a.z, oF + 64u * cb, 0, to_f4(zacc[0]));
+                STG_TRACE_MARK(11);
+            }
+        }
+    }
+
+    while (seq < seq_end) {
         // A_hat^T zn of the tile's rows (the next step's input gradient, aggregated here) as row pieces.  First: the gather loop
         // is the register-hungry part of the kernel and nothing else is live yet.
         float4 gp[PH];
@@ -355,7 +483,8 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_bwd_kernel(const BwdAr
         STG_TRACE_MARK(15);
         int w = 0;
         if (lane == 0) w = atomicAdd(next_w, 1);
-        tile = __builtin_amdgcn_readfirstlane(w) * (int)gridDim.x + (int)blockIdx.x;
+        seq = __builtin_amdgcn_readfirstlane(w);
+        tile = seq * grid + blk;
     }
 }
 
@@ -440,6 +569,7 @@ extern "C" int stg_tgcn_step_bwd(const stg_tgcn_step_bwd_args *p, void *stream_)
     a.dzl = p->dzl; a.drl = p->drl; a.dhl = p->dhl; a.da3 = p->da3; a.dH = p->dH; a.z = p->z; a.dyt = p->dyt; a.dyo = p->dyo;
     a.d_wide = d_wide ? 1 : 0;
     a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.two_over_n = 2.0f / (float)p->N; a.num_tiles = (int)((p->N + 15) / 16);
+    a.no_coop = tuning().step_coop;
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const bool w16 = tuning().step_waves == 16;
 #define STG_STEP_BWD(G_, EW_, HD_)                                                         \

@@ -16,6 +16,7 @@ struct FwdArgs {
     int64_t N;
     float lo, hi;
     int num_tiles;
+    int no_coop;                                       // knob "step_coop" 1
 };
 
 // FOLD (GATHER only): the conv output enters the gates only through their Linears, so the gate products run on
@@ -29,7 +30,10 @@ struct FwdShape {
     static constexpr int kCat = (GATHER && !FOLD) ? 3 * C * LDC : 0;
     static constexpr int kHead = HEAD ? FH * LD1 : 0;
     static constexpr int kBias = 6 * C + 2 * FH + 4;          // b3 | bz br bh | b1 | W2 | b2
-    static constexpr int kFloats = kGate + kCat + kHead + kBias;
+    // cooperative tiles (FOLD): per group of four waves two [16][LDXB] exchange buffers (H*R, relu(Hn)) + one counter per group
+    static constexpr int GROUPS = WAVES / 8, LDXB = C + 8;    // groups that can be busy: a shared tile pays while 8 cnt_b <= WAVES
+    static constexpr int kCoop = FOLD ? GROUPS * 2 * 16 * LDXB + 8 : 0;
+    static constexpr int kFloats = kGate + kCat + kHead + kBias + kCoop;
     static constexpr size_t kLds = sizeof(float) * (size_t)kFloats;
     static_assert(kLds <= 160 * 1024, "the weights must fit one CU's LDS");
 };
@@ -57,7 +61,26 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     STG_TRACE_MARK(0);
     STG_TRACE_MARK(14);
     if (threadIdx.x == 0) *next_w = WAVES;
-    int tile = wave * (int)gridDim.x + (int)blockIdx.x;
+    // The workgroup's tiles in hand-out order: seq k <-> tile k * grid + block.  Rounds of WAVES tiles; every wave of every workgroup
+    // has a tile in a FULL round.  The last, partial round gives this workgroup cnt_b tiles (|V| = 50 K on 256 CUs: 12 full + one on
+    // 53 workgroups): run by one wave each they leave ONE SIMD of the CU with a fourth tile while 971 SIMDs are done -- 4 x 7 us of
+    // matrix work where every other SIMD has 3 x 7 (profiles/r04_step_folded_trace.json: last SIMD 42 us, median 32.5).  FOLD: a
+    // tile of the partial round is instead shared by the FOUR waves of a group (waves 4 g .. 4 g + 3: one per SIMD), each taking one
+    // 16-column block of every gate (a quarter of the matrix instructions); H * R and relu(Hn), which the next product needs at
+    // full width, cross through LDS.  Every column block is the same chain of products in the same order: results bit-identical.
+    const int grid = (int)gridDim.x, blk = (int)blockIdx.x;
+    const int full_rounds = a.num_tiles / (WAVES * grid);
+    const int rem = a.num_tiles - full_rounds * WAVES * grid;
+    const int cnt_b = rem > blk ? (rem - blk - 1) / grid + 1 : 0;
+    const bool coop = FOLD && HEAD == 2 && full_rounds >= 1 && cnt_b > 0 && 8 * cnt_b <= WAVES && !a.node_ids && !a.no_coop;
+    const int seq_end = full_rounds * WAVES + (coop ? 0 : cnt_b);
+    int seq = wave;
+    int *const coop_cnt = reinterpret_cast<int *>(bs + S::kBias);
+    float *const xbuf = bs + S::kBias + 8;
+    if constexpr (FOLD) {
+        if (threadIdx.x < 8) coop_cnt[threadIdx.x] = 0;
+    }
+    int tile = seq * grid + blk;
 
     // Weights and biases: every global load of the staging in flight at once, then the LDS writes.  Measured and dropped, both
     // SLOWER: gathering the first tile between the two halves (the workgroup barrier then waits for the slowest wave's gather,
@@ -77,26 +100,35 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
         const int64_t gidx = std::min<int64_t>((int64_t)t * 16 + grow, a.N - 1);
         return a.node_ids ? a.node_ids[gidx] : (int)gidx;
     };
+    // (measured and dropped, round 5: the first gather's extent / index loads issued around the staging loads -- 36.0-36.7 us
+    //  against 36.3; the three waves of a SIMD issuing their first row loads one after the other -- 37.7-38.2: the head of the
+    //  launch is bound by the L2 / fabric rate of all gathers together, not by the order of their requests)
     stager.issue(segs);
-    stager.commit(segs);
+    // the small vectors (biases, W2): their loads in flight WITH the staging loads, not a round trip of their own after the LDS writes
+    static_assert(NT >= 6 * C && NT >= 2 * FH + 1, "one element per thread");
+    const int tid = (int)threadIdx.x;
+    float sv0 = 0.f, sv1 = 0.f;
     if constexpr (FOLD) {
-        for (int i = threadIdx.x; i < 3 * C; i += NT) bs[3 * C + i] = a.bgf[i];
+        if (tid < 3 * C) sv0 = a.bgf[tid];                                   // -> bs[3C + tid]
     } else {
-        for (int i = threadIdx.x; i < 3 * C; i += NT) bs[i] = a.b3[i];
-        for (int i = threadIdx.x; i < C; i += NT) {
-            bs[3 * C + i] = a.bz[i];
-            bs[4 * C + i] = a.br[i];
-            bs[5 * C + i] = a.bh[i];
-        }
+        if (tid < 3 * C) sv0 = a.b3[tid];                                    // -> bs[tid]
+        else if (tid < 4 * C) sv0 = a.bz[tid - 3 * C];                       // -> bs[tid]  (bz | br | bh follow b3)
+        else if (tid < 5 * C) sv0 = a.br[tid - 4 * C];
+        else if (tid < 6 * C) sv0 = a.bh[tid - 5 * C];
     }
     if constexpr (HEAD != 0) {
-        for (int i = threadIdx.x; i < FH; i += NT) {
-            bs[6 * C + i] = a.b1[i];
-            if constexpr (HEAD == 2) bs[6 * C + FH + i] = a.W2[i];
-        }
-        if constexpr (HEAD == 2) {
-            if (threadIdx.x == 0) bs[6 * C + 2 * FH] = a.b2[0];
-        }
+        if (tid < FH) sv1 = a.b1[tid];                                       // -> bs[6C + tid]
+        else if (HEAD == 2 && tid < 2 * FH) sv1 = a.W2[tid - FH];            // -> bs[6C + tid]
+        else if (HEAD == 2 && tid == 2 * FH) sv1 = a.b2[0];                  // -> bs[6C + 2 FH]
+    }
+    stager.commit(segs);
+    if constexpr (FOLD) {
+        if (tid < 3 * C) bs[3 * C + tid] = sv0;
+    } else {
+        if (tid < 6 * C) bs[tid] = sv0;
+    }
+    if constexpr (HEAD != 0) {
+        if (tid < (HEAD == 2 ? 2 * FH + 1 : FH)) bs[6 * C + tid] = sv1;
     }
     __syncthreads();
     STG_TRACE_MARK(1);
@@ -105,7 +137,129 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
     // this lane's row / piece inside each LDS matrix (tgcn_step.hpp: pinned)
     const float *const wg_l = Wg + pinned((unsigned)(n16 * LDW + 4 * kq)), *const wc_l = WcT + pinned((unsigned)(n16 * LDC + 4 * kq));
     const float *const w1_l = W1s + pinned((unsigned)(n16 * LD1 + 4 * kq)), *const bs_l = bs + pinned((unsigned)(4 * kq));
-    while (tile < a.num_tiles) {
+    // ---- the partial round FIRST, four waves per tile (see above): run after the full rounds it would start when the launch should
+    // end (measured: the four waves reach it at 24-34 us and need 7-14 us for it -- a gather of three dependent round trips and two
+    // group syncs; profiles/r05_step_coop_trace.jsonl) -----------------------------------------------------------------------------
+    if constexpr (FOLD && HEAD == 2) {
+        if (coop) {
+            constexpr int LDXB = S::LDXB;
+            const int grp = wave >> 2, cb = wave & 3;
+            float *const xb = xbuf + grp * 2 * 16 * LDXB;
+            volatile int *const cnt = coop_cnt + grp;
+            float *const xb_l = xb + pinned((unsigned)(n16 * LDXB + 4 * kq));
+            int phase = 0;
+            auto group_sync = [&]() {
+                // this wave's LDS writes are ordered before its counter bump (one in-order LDS pipe per CU); waves of a workgroup are
+                // all resident, so the wait always ends
+                phase += 4;
+                __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
+                if (lane == 0) atomicAdd(const_cast<int *>(cnt), 1);
+                while (*cnt < phase) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+            };
+            for (int ct = grp; ct < cnt_b; ct += S::GROUPS) {
+                const int ctile = (full_rounds * WAVES + ct) * grid + blk;
+                STG_TRACE_MARK(10);
+                float4 p[PF];
+                {
+                    const int gr = gather_row(ctile);
+                    RowGather32<HAS_EW> rg;
+                    rg.begin(a.row_offsets, a.norm, gr);
+                    rg.indices(a.column_indices, a.nc_edge, a.ew_edge, 0, q);
+                    float p8[8];
+                    rg.run(p8, a.x, a.column_indices, a.nc_edge, a.ew_edge, q);
+                    if (cb == 0) {
+                        const unsigned off = (unsigned)gr * (FIN * 4u) + 32u * q;
+                        st_f4(a.P, off, 0, make_float4(p8[0], p8[1], p8[2], p8[3]));
+                        st_f4(a.P, off, 16, make_float4(p8[4], p8[5], p8[6], p8[7]));
+                    }
+                    gather_to_pieces(p8, p, n16, kq);
+                }
+                if (cb == 0) {
+                    float s1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < PF; ++j) s1 = s1 + ((fabsf(p[j].x) + fabsf(p[j].y)) + (fabsf(p[j].z) + fabsf(p[j].w)));
+                    s1 = s1 + __shfl_xor(s1, 16, kWave);
+                    s1 = s1 + __shfl_xor(s1, 32, kWave);
+                    const float bnd = s1 * a.bound[0] + a.bound[1];
+                    if (!(bnd <= a.hi && -bnd >= a.lo)) atomicOr(a.status, 1);
+                }
+                const int64_t idx = (int64_t)ctile * 16 + n16;
+                const bool rok = idx < a.N;
+                const unsigned row = (unsigned)std::min<int64_t>(idx, a.N - 1);
+                const unsigned oC = (row * C + 4u * kq) * 4u, oF = (row * FH + 4u * kq) * 4u;
+                float4 hh[PC];
+#pragma unroll
+                for (int j = 0; j < PC; ++j) {
+                    hh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.H) hh[j] = ld_f4(a.H, oC, 64 * j);
+                }
+                float4 hmine = hh[0];                                     // this wave's own block of H: piece cb
+#pragma unroll
+                for (int j = 1; j < PC; ++j) hmine = cb == j ? hh[j] : hmine;
+                // one 16-column block of gate g: bg'[16 cb ..] + [P | second] Ag_g[16 cb .., :]^T
+                auto gate1 = [&](int g, const float4 (&second)[PC], f32x4 (&acc)[1]) {
+                    acc[0] = to_x4(*reinterpret_cast<const float4 *>(bs_l + (3 + g) * C + 16 * cb));
+                    gemm_pieces<1, PF + PC>(acc, wg_l + (g * C + 16 * cb) * LDW, LDW, [&](int j) { return j < PF ? p[j % PF] : second[(j - PF) % PC]; });
+                };
+                f32x4 acc[1];
+                gate1(0, hh, acc);
+                const float4 zz = make_float4(sigmoid_(acc[0][0]), sigmoid_(acc[0][1]), sigmoid_(acc[0][2]), sigmoid_(acc[0][3]));
+                st_f4(a.Z, oC + 64u * cb, 0, zz);
+                gate1(1, hh, acc);
+                const float4 r = make_float4(sigmoid_(acc[0][0]), sigmoid_(acc[0][1]), sigmoid_(acc[0][2]), sigmoid_(acc[0][3]));
+                const float4 hr1 = make_float4(hmine.x * r.x, hmine.y * r.y, hmine.z * r.z, hmine.w * r.w);
+                st_f4(a.R, oC + 64u * cb, 0, r);
+                st_f4(a.HR, oC + 64u * cb, 0, hr1);
+                *reinterpret_cast<float4 *>(xb_l + 16 * cb) = hr1;
+                group_sync();
+                float4 hr[PC];
+#pragma unroll
+                for (int j = 0; j < PC; ++j) hr[j] = *reinterpret_cast<const float4 *>(xb_l + 16 * j);
+                gate1(2, hr, acc);
+                const float4 t = make_float4(tanh_(acc[0][0]), tanh_(acc[0][1]), tanh_(acc[0][2]), tanh_(acc[0][3]));
+                const float4 hn1 = make_float4(zz.x * hmine.x + (1.0f - zz.x) * t.x, zz.y * hmine.y + (1.0f - zz.y) * t.y,
+                                               zz.z * hmine.z + (1.0f - zz.z) * t.z, zz.w * hmine.w + (1.0f - zz.w) * t.w);
+                st_f4(a.Ht, oC + 64u * cb, 0, t);
+                st_f4(a.Hn, oC + 64u * cb, 0, hn1);
+                *reinterpret_cast<float4 *>(xb_l + 16 * LDXB + 16 * cb) =
+                    make_float4(hn1.x < 0.f ? 0.f : hn1.x, hn1.y < 0.f ? 0.f : hn1.y, hn1.z < 0.f ? 0.f : hn1.z, hn1.w < 0.f ? 0.f : hn1.w);
+                group_sync();
+                if (cb == 0) {                                            // the head (32 matrix instructions) by one wave, as in the tile loop
+                    const float tg = ld_f1(a.target, row * 4u);
+                    float4 hn[PC];
+#pragma unroll
+                    for (int j = 0; j < PC; ++j) hn[j] = *reinterpret_cast<const float4 *>(xb_l + 16 * LDXB + 16 * j);
+                    f32x4 accy[PH];
+#pragma unroll
+                    for (int ft = 0; ft < PH; ++ft) accy[ft] = to_x4(*reinterpret_cast<const float4 *>(bs_l + 6 * C + 16 * ft));
+                    gemm_pieces<PH, PC>(accy, w1_l, LD1, [&](int j) { return hn[j]; });
+#pragma unroll
+                    for (int ft = 0; ft < PH; ++ft) st_f4(a.y, oF, 64 * ft, to_f4(accy[ft]));
+                    float s = 0.f;
+#pragma unroll
+                    for (int ft = 0; ft < PH; ++ft) {
+                        const float4 w2 = *reinterpret_cast<const float4 *>(bs_l + 6 * C + FH + 16 * ft);
+                        s = s + accy[ft][0] * w2.x;
+                        s = s + accy[ft][1] * w2.y;
+                        s = s + accy[ft][2] * w2.z;
+                        s = s + accy[ft][3] * w2.w;
+                    }
+                    s = s + __shfl_xor(s, 16, kWave);
+                    s = s + __shfl_xor(s, 32, kWave);
+                    const float yo = s + bs[6 * C + 2 * FH];
+                    if (kq == 0) st_f1(a.y_out, row * 4u, yo);
+                    const float d = yo - tg;
+                    float sq = (rok && kq == 0) ? d * d : 0.f;
+                    sq = row16_sum(sq);
+                    if (lane == 15) a.partial[ctile] = sq;
+                }
+                STG_TRACE_MARK(11);
+            }
+        }
+    }
+
+    while (seq < seq_end) {
         // P = A_hat x of the tile, handed from the gather layout to row pieces on the LDS crossbar (no LDS memory)
         float4 p[PF];
 #pragma unroll
@@ -325,7 +479,8 @@ __global__ __launch_bounds__(WAVES *kWave) void tgcn_step_fwd_kernel(const FwdAr
         STG_TRACE_MARK(15);
         int w = 0;
         if (lane == 0) w = atomicAdd(next_w, 1);
-        tile = __builtin_amdgcn_readfirstlane(w) * (int)gridDim.x + (int)blockIdx.x;
+        seq = __builtin_amdgcn_readfirstlane(w);
+        tile = seq * grid + blk;
     }
 }
 
@@ -442,6 +597,7 @@ extern "C" int stg_tgcn_step_fwd(const stg_tgcn_step_fwd_args *p, void *stream_)
     a.P = p->P; a.x3 = p->x3; a.Z = p->Z; a.R = p->R; a.Ht = p->Ht; a.Hn = p->Hn; a.HR = p->HR; a.y = p->y;
     a.y_out = p->y_out; a.partial = p->loss_partial; a.mask = p->clamp_mask; a.status = p->fold_status;
     a.N = p->N; a.lo = p->lo; a.hi = p->hi; a.num_tiles = (int)((p->N + 15) / 16);
+    a.no_coop = tuning().step_coop;
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const bool w16 = tuning().step_waves == 16;
 #define STG_STEP_FWD(G_, EW_, HD_)                                                         \

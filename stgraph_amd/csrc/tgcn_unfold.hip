@@ -141,8 +141,7 @@ extern "C" int stg_tgcn_fold_weights(const float *const *Wc, const float *const 
     }
     a.w_fold = w_fold; a.b_fold = b_fold; a.bound = bound; a.w_fold_t = w_fold_t; a.C = C; a.Fin = Fin;
     const int total = 3 * C * (Fin + C) + 3 * C;
-    const hipError_t e = hipMemsetAsync(bound, 0, 2 * sizeof(float), static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return fail((int)e, "stg_tgcn_fold_weights: %s", hipGetErrorString(e));
+    if (const int rc = zero_async(bound, 2 * sizeof(float), static_cast<hipStream_t>(stream))) return rc;
     hipLaunchKernelGGL(tgcn_fold_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), a);
     return check_launch("stg_tgcn_fold_weights");

@@ -3,7 +3,7 @@
 # Run in the build container after `make -C stgraph_amd/csrc`; tools/diag/step_trace.py uses it on the GPU box.
 set -e
 cd "$(dirname "$0")/../../stgraph_amd/csrc"
-FLAGS="-O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 -DSTG_STEP_TRACE"
+FLAGS="-O3 --offload-arch=gfx950 --offload-compress -fPIC -ffp-contract=off -std=c++17 -DSTG_STEP_TRACE"
 mkdir -p ../../build/trace
 for f in tgcn_step_fwd tgcn_step_bwd; do /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o ../../build/trace/$f.o; done
 OBJS=$(ls ../../build/obj/*.o | grep -v tgcn_step_)
