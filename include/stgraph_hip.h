@@ -68,7 +68,9 @@ const char *stg_last_error_string(void);
  * ARITHMETICS: both forms inside the fp32 kernel's error bound against fp64, integer data exact in both), "step_spread"
  * (0 = one workgroup per CU when there are fewer tiles than wave slots, 1 = packed grid), "step_coop" (stg_tgcn_step_*, tiles of the
  * last partial round: 0 = each shared by four waves of its workgroup -- bit-identical results --, 1 = one wave each), "gemm_wide" (tall-skinny weight
- * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_cyclic" (its row-group hand-out: 0 .. 2), "gemm_xcd_pair" (its
+ * gradients: 0 = the 16-byte-per-lane form where the widths allow, 1 = never), "gemm_x3" (the same contractions at M in {32, 64, 128},
+ * N in {64, 96, 128}: 0 = every product as a 3-term bf16 split on v_mfma_f32_32x32x16_bf16 from 64 K rows in all, 1 = never, 2 = always;
+ * like "rowgemm_x3" a choice between two arithmetics inside the fp32 form's error bound against fp64), "gemm_cyclic" (its row-group hand-out: 0 .. 2), "gemm_xcd_pair" (its
  * workgroup order when M x N takes several workgroups per K slice: 0 = those of a slice on one XCD, 1 = dealt in turn),
  * "gcn_wide_long" (rows of >= 1024 edges at F >= 128: 0 = feature-sliced workgroups beside the main launch, 1 = never, 2 = behind
  * it on the same stream), "build_lds_count" (stg_graph_build_direct2_device: 0 = histograms in LDS when |V| <= 40 K and the graph

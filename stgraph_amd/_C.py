@@ -376,7 +376,7 @@ def check(rc: int) -> None:
 # fp32 kernel's error bound): include/stgraph_hip.h, stg_set_tuning.  Every key defaults to 0 (= auto).
 TUNING_KEYS = ("gcn_lanes_per_row", "gcn_unroll", "gcn_long_threshold", "xw_rows", "xw_waves", "cell_rows", "gcn_tile", "gcn_block",
                "gcn_addr32", "gcn_tile_pipe", "gcn_tile_rows", "gcn_xcd_tile", "step_waves", "gcn_wide_long", "step_spread", "step_coop",
-               "build_lds_count", "store_rows", "rowgemm16", "rowgemm_x3", "gemm_wide", "gemm_xcd_pair", "gemm_cyclic")
+               "build_lds_count", "store_rows", "rowgemm16", "rowgemm_x3", "gemm_wide", "gemm_x3", "gemm_xcd_pair", "gemm_cyclic")
 _TUNING_SET = {}
 
 

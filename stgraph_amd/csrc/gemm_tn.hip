@@ -15,7 +15,7 @@
 // loop-invariant 32-bit lane offset), so the two in-flight operand sets cost no address VGPRs.
 // LDS is used only to add the 4 waves of a block (4 adjacent K sub-slices of the same output tile)
 // before one slab write.
-#include "stg_common.hpp"
+#include "gemm_tn.hpp"
 
 namespace stg {
 
@@ -29,38 +29,6 @@ constexpr int kGemmKStep = 16;             // K slices are multiples of this (co
 // Operand segments: C = sum_t A_t^T B_t over up to kGemmMaxSeg (A_t, B_t) pairs of K rows each, passed
 // BY VALUE in the kernel arguments (no device-side pointer table to build, HIP-graph capturable).
 // This is how a BPTT window's weight gradient -- one contribution per timestep -- becomes ONE launch.
-constexpr int kGemmMaxSeg = 32;
-struct GemmSegs {
-    const float *a[kGemmMaxSeg];
-    const float *b[kGemmMaxSeg];
-    const float *b2[kGemmMaxSeg];        // columns [nsplit, N) of B_t live in a second matrix (GemmForm::nsplit < N)
-    const float *am[kGemmMaxSeg];        // GemmForm::a_mask: A_t[k][m] counts only where am_t[k][m] > 0 (same shape and stride)
-};
-
-// Operand forms.  A_t is [K, M] with row stride lda.  B_t is [K, N] given as ONE or TWO row-major matrices side by
-// side: columns [0, nsplit) from b (row stride ldb), columns [nsplit, N) from b2 (row stride ldb2); nsplit is a multiple
-// of 32 or N.  b_op transforms the values of b as they are loaded (b2 is taken as is): the weight gradients of the
-// one-launch TGCN step contract dzl with [clamp(x3[:, gate]) | H] and dyt with relu(Hn) without those operands ever
-// being written out.
-struct GemmForm {
-    int lda, ldb, ldb2, nsplit;
-    int b_op;                            // STG_GEMM_B_NONE / _CLAMP / _RELU
-    float lo, hi;
-    int a_mask;                          // 1: A is taken as A * [am > 0] -- the backward of a ReLU applied while loading:
-                                         // dW = (g * [out > 0])^T X and its column sums (the bias gradient) in one launch,
-                                         // the masked gradient never written
-    const int *gate;                     // gate_when 1: the launch (slabs and reduction) does nothing unless *gate == 0; 2: unless
-    int gate_when;                       // *gate != 0.  Two products gated on the same word, one of each kind, write the same C:
-                                         // which one is decided on the device (stg_gemm_tn_gated_f32)
-};
-
-__device__ __forceinline__ bool gemm_gated_off(const int *gate, int when)
-{
-    if (when == 0 || gate == nullptr) return false;
-    const bool zero = __builtin_amdgcn_readfirstlane(*gate) == 0;
-    return when == 1 ? !zero : zero;
-}
-
 // MT = 32-row M tiles per wave: every B dword a wave loads feeds MT MFMAs and every A dword NT of them.  With MT = 1
 // a k-pair costs 1 + NT dword loads for NT MFMAs; the kernel then runs at the rate the texture addresser issues
 // those loads (16 cycles per wave instruction, 8 waves per CU: 262 us of address cycles against 210 us of MFMA at
@@ -692,7 +660,8 @@ size_t workspace_need(int T, int64_t K, int M, int N, int max_ld)
     const WideShape w = wide_shape(M, N, N);
     if (w.wa) S = std::max(S, plan_gemm_tn(K, M, N, T, max_ld, &w).S);
     if (S < 1) return 0;
-    return (size_t)T * (size_t)S * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+    const size_t x3_slabs = (size_t)gemm_tn_x3_slabs(M, N, K, T);              // the split form's slab count (gemm_tn_x3.hip)
+    return std::max((size_t)T * (size_t)S, x3_slabs) * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
 }
 
 }  // namespace
@@ -757,6 +726,27 @@ int gemm_tn_run(const float *const *As, const float *const *Bs, int T, float *C,
         const uintptr_t bits = reinterpret_cast<uintptr_t>(segs.a[t]) | reinterpret_cast<uintptr_t>(segs.b[t]) |
                                reinterpret_cast<uintptr_t>(segs.b2[t]) | reinterpret_cast<uintptr_t>(segs.am[t]);
         if (bits & 15) wide.wa = 0;
+    }
+    // the 3-term bf16 split form (gemm_tn_x3.hip) where it covers the shape: from 64 K rows in all (knob "gemm_x3": 1 = never, 2 = always)
+    {
+        bool x3 = tuning().gemm_x3 != 1 && (tuning().gemm_x3 == 2 || (int64_t)K * T >= 65536) && gemm_tn_x3_covers(M, N, form, K, T);
+        for (int t = 0; t < T && x3; ++t) {
+            const uintptr_t bits = reinterpret_cast<uintptr_t>(segs.a[t]) | reinterpret_cast<uintptr_t>(segs.b[t]) | reinterpret_cast<uintptr_t>(segs.b2[t]);
+            if (bits & 15) x3 = false;
+        }
+        const bool cs3 = colsum != nullptr;
+        const int64_t MN3 = (int64_t)M * N, MNc3 = MN3 + (cs3 ? M : 0);
+        if (x3 && workspace_bytes >= (size_t)gemm_tn_x3_slabs(M, N, K, T) * (size_t)MNc3 * sizeof(float)) {
+            int slabs = 0;
+            if (const int rc = gemm_tn_x3_launch(segs, form, static_cast<float *>(workspace), K, M, N, T, cs3, &slabs, stream)) return rc;
+            if (defer_slabs) {
+                *defer_slabs = slabs;
+                return 0;
+            }
+            hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((MNc3 + kWave - 1) / kWave)), dim3(kBlock), 0, stream,
+                               static_cast<float *>(workspace), C, colsum, MNc3, MN3, slabs, form.gate, form.gate_when);
+            return check_launch(what);
+        }
     }
     const GemmPlan p = plan_gemm_tn(K, M, N, T, std::max(form.lda, std::max(form.ldb, form.ldb2)), wide.wa ? &wide : nullptr);
     if (p.S < 1 || (int64_t)T * p.S > INT32_MAX / 2)

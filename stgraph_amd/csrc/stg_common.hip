@@ -167,6 +167,11 @@ extern "C" int stg_set_tuning(const char *key, int value)
         tuning().rowgemm_x3 = value;
         return 0;
     }
+    if (!std::strcmp(key, "gemm_x3")) {
+        if (value < 0 || value > 2) return fail(STG_ERR_INVALID_ARGUMENT, "gemm_x3 must be 0 (auto), 1 (never) or 2 (whenever covered)");
+        tuning().gemm_x3 = value;
+        return 0;
+    }
     if (!std::strcmp(key, "gemm_wide")) {
         if (value != 0 && value != 1) return fail(STG_ERR_INVALID_ARGUMENT, "gemm_wide must be 0 (auto) or 1 (never)");
         tuning().gemm_wide = value;

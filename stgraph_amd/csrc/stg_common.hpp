@@ -48,6 +48,7 @@ struct Tuning {
     int build_lds_count = 0;       // per-snapshot CSR build: 0 = auto (histograms in LDS when |V| fits and the graph is dense enough), 1 = always when |V| fits, 2 = never
     int rowgemm16 = 0;             // stg_rowgemm_f32 at K, M in {64, 128}: 0 = the 16-row row-piece kernel, 1 = never
     int gemm_wide = 0;             // tall-skinny weight gradient: 0 = auto (16-byte-per-lane form where the widths allow), 1 = never
+    int gemm_x3 = 0;               // tall-skinny contractions at M in {32, 64, 128}, N in {64, 96, 128}: 0 = 3-term bf16 split from 64 K rows, 1 = never, 2 = always
     int gemm_cyclic = 0;           // its K distribution inside a block: 0 = a contiguous quarter per wave, 1 = 4-row groups in turn
     int gemm_xcd_pair = 0;         // its workgroup order with several M / N groups: 0 = the groups of a K slice on one XCD (shared operand from L2), 1 = dealt in turn
     int rowgemm_x3 = 0;            // row products at K, M in {64, 128}: 0 = auto (3-term bf16 split on the matrix cores from 64 K rows), 1 = never, 2 = whenever legal

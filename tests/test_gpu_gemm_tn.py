@@ -131,10 +131,12 @@ def test_relu_mask_on_load(cuda, K, M, N):
     # pinned to it here (its 16-byte-per-lane kernel splits K differently and agrees to fp32 rounding, as checked above)
     from stgraph_amd import _C
     _C.set_tuning("gemm_wide", 1)
+    _C.set_tuning("gemm_x3", 1)                       # (nor the bf16-split form, which large plain products take by default)
     try:
         two, two_cs = kernels.gemm_tn((g * (out > 0)), x, colsum=True)
     finally:
         _C.set_tuning("gemm_wide", 0)
+        _C.set_tuning("gemm_x3", 0)
     assert torch.equal(c, two) and torch.equal(cs, two_cs)
 
 
@@ -196,3 +198,52 @@ def test_batched_reduction_into_transposed_row_blocks(cuda, colsum):
     with pytest.raises(ValueError):
         kernels.gemm_tn_form_batch([other, dict(As=da3, Bs=P, M=3 * C, N=Fin, colsum=False,
                                                 out_blocks_t=[torch.empty(Fin, 3 * C // 5, device=cuda)] * 5)])
+
+
+@pytest.mark.parametrize("M,N,nsplit,lda,b_op", [(128, 128, 128, 128, 0), (128, 96, 64, 192, 0), (64, 96, 64, 192, 0), (32, 64, 64, 32, 2),
+                                                 (64, 128, 128, 64, 1), (128, 64, 64, 128, 0), (32, 96, 64, 32, 0)])
+@pytest.mark.parametrize("K,T", [(70_001, 1), (9_000, 9), (50_000, 25)])
+def test_split_form_against_fp64_and_the_fp32_form(cuda, M, N, nsplit, lda, b_op, K, T):
+    """gemm_tn_x3.hip (knob "gemm_x3" 2): C = sum_t A_t^T [op(B_t) | B2_t] with every product a 3-term bf16 split -- against fp64 inside the
+    fp32 form's own bound (both within 1 ulp of sum |a| |b|; the split form may not be more than twice the fp32 form's error + 0.25),
+    column sums exact to fp32 summation, operands as column windows of wider matrices (lda > M), ragged K (the last slice's tail
+    reads as zeros), clamp / ReLU applied to the first matrix while loading."""
+    from stgraph_amd import _C, kernels
+    gen = torch.Generator(device=cuda).manual_seed(M + N + K)
+    wide = [torch.randn(K, lda, device=cuda, generator=gen) for _ in range(T)]
+    As = [w[:, :M] for w in wide]
+    Bs = [torch.randn(K, nsplit, device=cuda, generator=gen) for _ in range(T)]
+    B2s = [torch.randn(K, N - nsplit, device=cuda, generator=gen) for _ in range(T)] if nsplit < N else None
+    lo, hi = -0.5, 0.7
+    op = {0: lambda t: t, 1: lambda t: t.clamp(lo, hi), 2: torch.relu}[b_op]
+    Bfull = [torch.cat([op(b), b2], 1) if B2s else op(b) for b, b2 in zip(Bs, B2s or Bs)]
+    want = sum(a.double().t() @ b.double() for a, b in zip(As, Bfull))
+    scale = sum(a.double().abs().t() @ b.double().abs() for a, b in zip(As, Bfull)) * 2.0 ** -24
+    want_cs = sum(a.double().sum(0) for a in As)
+    err = {}
+    for name, knob in (("f32", 1), ("x3", 2)):
+        _C.set_tuning("gemm_x3", knob)
+        try:
+            c, cs = kernels.gemm_tn_form(As, Bs, M, N, B2s=B2s, nsplit=nsplit, b_op=b_op, lo=lo, hi=hi, colsum=True)
+            c2 = kernels.gemm_tn_form(As, Bs, M, N, B2s=B2s, nsplit=nsplit, b_op=b_op, lo=lo, hi=hi)
+        finally:
+            _C.set_tuning("gemm_x3", 0)
+        assert torch.equal(c, c2)                                      # with and without the column sums: the same products
+        err[name] = float(((c.double() - want).abs() / scale).max())
+        assert float((cs.double() - want_cs).abs().max()) <= 1e-5 * float(want_cs.abs().max()) + 1e-3
+    assert err["f32"] <= 1.0 and err["x3"] <= 1.0, err
+    assert err["x3"] <= 2 * err["f32"] + 0.25, err
+
+
+def test_split_form_is_exact_on_small_integers(cuda):
+    """Integers up to 255 are one bf16 term each: every product and every fp32 partial sum is exact in both forms."""
+    from stgraph_amd import _C, kernels
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    A = torch.randint(-200, 200, (80_000, 128), device=cuda, generator=gen).float()
+    B = torch.randint(-3, 4, (80_000, 128), device=cuda, generator=gen).float()
+    _C.set_tuning("gemm_x3", 2)
+    try:
+        c = kernels.gemm_tn(A, B)
+    finally:
+        _C.set_tuning("gemm_x3", 0)
+    assert torch.equal(c.double(), A.double().t() @ B.double())
