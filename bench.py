@@ -1143,7 +1143,7 @@ def tgcn_run(device, rank, world, epochs, warmup_epochs, n, e, T, feat, hidden, 
 
 
 def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, T=None, B=20, feat=32, hidden=64,
-                cpu_baseline=False):
+                cpu_baseline=False, only_modes=None):
     """BASELINE.json configs[4]: dynamic-temporal TGCN (benchmarking/dynamic-temporal-tgcn/seastar/train.py loop:
     link prediction on a sliding window over an edge stream, un-weighted GCN gates), once with the per-snapshot
     device CSR rebuild (NaiveGraph(resident=False)), with all snapshots resident as the reference's NaiveGraph keeps
@@ -1241,6 +1241,8 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
         return out
 
     all_modes = ("resident_snapshots", "rebuild_per_snapshot", "pcsr_store", "gpma_store")
+    if only_modes:                                               # (profiling runs: tools/diag/dyn_only.py)
+        return run_modes(T, tuple(only_modes), epochs)
     if T == 40:
         epochs = max(epochs, 20)                                 # the reference's rule: >= 20 epochs, the first three discarded
     out = run_modes(T, all_modes, epochs, cpu=cpu_baseline)

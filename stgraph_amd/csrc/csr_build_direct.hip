@@ -138,6 +138,28 @@ __device__ __forceinline__ int rank_in_row(const uint64_t *__restrict__ key, int
     return r;
 }
 
+// The batched build keeps a placed edge as ONE 16-byte record {key (8 bytes), row, pad}: placing an edge is then one scattered
+// store instead of two (an 8-byte key and a 4-byte row each paid a 64-byte sector of their own: direct2_place 71 -> see
+// profiles/r05_build_records.json), and the rank passes read key and row of their entry with one coalesced 16-byte load.
+struct __attribute__((aligned(16))) EdgeRec {
+    uint64_t key;
+    int row, pad;
+};
+__device__ __forceinline__ int rank_in_row(const EdgeRec *__restrict__ rec, int beg, int end, uint64_t mine)
+{
+    int r = 0;
+    int t = beg;
+    for (; t + 8 <= end; t += 8) {                     // eight independent loads in flight (see above)
+        uint64_t k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k[u] = rec[t + u].key;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r += k[u] < mine ? 1 : 0;
+    }
+    for (; t < end; ++t) r += rec[t].key < mine ? 1 : 0;
+    return r;
+}
+
 __global__ void direct_rank_fwd(const uint64_t *__restrict__ key, const int *__restrict__ row, int64_t E,
                                 const int *__restrict__ fwd_ro, const int *__restrict__ bwd_ro,
                                 int *__restrict__ cursor_b, int *__restrict__ fwd_col, int *__restrict__ fwd_eid,
@@ -204,8 +226,8 @@ struct BJob {
     int *fwd_ro, *fwd_col, *fwd_eid, *bwd_ro, *bwd_col, *bwd_eid, *in_deg, *out_deg;
     float *norm, *nc_f, *nc_b;
     int *cnt;                               // 2 npad counters, zero between builds
-    uint64_t *key_f, *key_b;
-    int *row_f, *row_b, *pos_f, *pos_b, *part;
+    EdgeRec *rec_f, *rec_b;                  // placed edges, forward / backward rows (16-byte records)
+    int *pos_f, *pos_b, *part;
     int chunk_shift, lds;                   // lds != 0: counted by direct3_count (per-chunk histograms in LDS) and combined
 };
 constexpr int kBuildBatchMax = STG_BUILD_BATCH_MAX;
@@ -417,8 +439,7 @@ __global__ __launch_bounds__(kBlock) void direct2_place(const BuildJobs<CAP> job
     if (*status) return;
     const BJob &J = jobs.j[blockIdx.z];
     const int *__restrict__ src = J.src, *__restrict__ dst = J.dst, *__restrict__ fwd_ro = J.fwd_ro, *__restrict__ pos_f = J.pos_f;
-    uint64_t *__restrict__ key = J.key_f;
-    int *__restrict__ row = J.row_f;
+    EdgeRec *__restrict__ rec = J.rec_f;
     const int *__restrict__ base_f = J.lds ? J.part : nullptr;
     const int chunk_shift = J.chunk_shift;
     const int64_t E = J.E;
@@ -427,8 +448,8 @@ __global__ __launch_bounds__(kBlock) void direct2_place(const BuildJobs<CAP> job
         const int d = dst[i];
         int slot = fwd_ro[d] + pos_f[i];
         if (base_f) slot += base_f[(i >> chunk_shift) * npad + d];
-        key[slot] = ((uint64_t)(unsigned)src[i] << 32) | (uint64_t)(unsigned)i;
-        row[slot] = d;
+        // one 16-byte store: {key = src << 32 | i, row = d}
+        *reinterpret_cast<uint4 *>(rec + slot) = make_uint4((unsigned)i, (unsigned)src[i], (unsigned)d, 0u);
     }
 }
 
@@ -437,11 +458,11 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const BuildJobs<CAP> 
 {
     if (*status) return;
     const BJob &J = jobs.j[blockIdx.z];
-    const uint64_t *__restrict__ key = J.key_f;
-    const int *__restrict__ row = J.row_f, *__restrict__ fwd_ro = J.fwd_ro, *__restrict__ bwd_ro = J.bwd_ro, *__restrict__ pos_b = J.pos_b;
-    int *__restrict__ fwd_col = J.fwd_col, *__restrict__ fwd_eid = J.fwd_eid, *__restrict__ row_b = J.row_b;
+    const EdgeRec *__restrict__ rec = J.rec_f;
+    const int *__restrict__ fwd_ro = J.fwd_ro, *__restrict__ bwd_ro = J.bwd_ro, *__restrict__ pos_b = J.pos_b;
+    int *__restrict__ fwd_col = J.fwd_col, *__restrict__ fwd_eid = J.fwd_eid;
     int64_t *__restrict__ perm_fwd = J.perm;
-    uint64_t *__restrict__ key_b = J.key_b;
+    EdgeRec *__restrict__ rec_b = J.rec_b;
     const float *__restrict__ norm = J.norm;
     float *__restrict__ nc_fwd = J.nc_f;
     const int *__restrict__ base_b = J.lds ? J.part + (size_t)kLdsChunks * npad : nullptr;
@@ -449,20 +470,21 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const BuildJobs<CAP> 
     const int64_t E = J.E;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < E; t += stride) {
-        const uint64_t mine = key[t];
-        const int d = row[t];
+        const uint4 r4 = *reinterpret_cast<const uint4 *>(rec + t);
+        const uint64_t mine = ((uint64_t)r4.y << 32) | r4.x;
+        const int d = (int)r4.z;
         const int beg = fwd_ro[d];
-        const int e = beg + rank_in_row(key, beg, fwd_ro[d + 1], mine);   // = eid
-        const int s = (int)(mine >> 32);
-        const unsigned i = (unsigned)mine;                                // caller position
+        const int e = beg + rank_in_row(rec, beg, fwd_ro[d + 1], mine);   // = eid
+        const int s = (int)r4.y;
+        const unsigned i = r4.x;                                          // caller position
         fwd_col[e] = s;
         fwd_eid[e] = e;
         perm_fwd[e] = (int64_t)i;
         if (nc_fwd) nc_fwd[e] = norm[s];
         int slot = bwd_ro[s] + pos_b[i];
         if (base_b) slot += base_b[(i >> chunk_shift) * npad + s];
-        key_b[slot] = ((uint64_t)(unsigned)e << 32) | (uint64_t)(unsigned)d;
-        row_b[slot] = s;
+        // {key = eid << 32 | dst, row = s} into its backward row, one store
+        *reinterpret_cast<uint4 *>(rec_b + slot) = make_uint4((unsigned)d, (unsigned)e, (unsigned)s, 0u);
     }
 }
 
@@ -470,8 +492,8 @@ template <int CAP>
 __global__ __launch_bounds__(kBlock) void direct2_rank_bwd(const BuildJobs<CAP> jobs, int npad, const int *__restrict__ status)
 {
     const BJob &J = jobs.j[blockIdx.z];
-    const uint64_t *__restrict__ key_b = J.key_b;
-    const int *__restrict__ row_b = J.row_b, *__restrict__ bwd_ro = J.bwd_ro;
+    const EdgeRec *__restrict__ rec_b = J.rec_b;
+    const int *__restrict__ bwd_ro = J.bwd_ro;
     int *__restrict__ bwd_col = J.bwd_col, *__restrict__ bwd_eid = J.bwd_eid, *__restrict__ cnt = J.cnt;
     const float *__restrict__ norm = J.norm;
     float *__restrict__ nc_bwd = J.nc_b;
@@ -481,12 +503,13 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_bwd(const BuildJobs<CAP> 
     for (int64_t v = first; v < 2 * (int64_t)npad; v += stride) cnt[v] = 0;  // nobody reads the counters any more
     if (*status) return;
     for (int64_t t = first; t < E; t += stride) {
-        const uint64_t mine = key_b[t];
-        const int s = row_b[t];
+        const uint4 r4 = *reinterpret_cast<const uint4 *>(rec_b + t);
+        const uint64_t mine = ((uint64_t)r4.y << 32) | r4.x;
+        const int s = (int)r4.z;
         const int beg = bwd_ro[s];
-        const int o = beg + rank_in_row(key_b, beg, bwd_ro[s + 1], mine);
-        const int d = (int)(unsigned)mine;
-        bwd_eid[o] = (int)(mine >> 32);
+        const int o = beg + rank_in_row(rec_b, beg, bwd_ro[s + 1], mine);
+        const int d = (int)r4.x;
+        bwd_eid[o] = (int)r4.y;
         bwd_col[o] = d;
         if (nc_bwd) nc_bwd[o] = norm[d];
     }
@@ -506,9 +529,9 @@ DirectLayout direct_layout(int64_t E, int32_t N)
     L.sort_tmp_bytes = t;
     size_t off = 0;
     auto take = [&off](size_t bytes) { const size_t o = off; off += align_up(bytes); return o; };
-    L.key_f = take(e * 8);
+    L.key_f = take(e * 16);             // the batched build's 16-byte records (the single build uses the first 8 E bytes as keys)
     L.row_f = take(e * 4);
-    L.key_b = take(e * 8);
+    L.key_b = take(e * 16);
     L.row_b = take(e * 4);
     L.cursors = take(2 * n * 4);
     L.pos_f = take(e * 4);
@@ -531,8 +554,7 @@ BJob make_job(const DirectLayout &L, char *ws, const int32_t *src, const int32_t
     j.src = src, j.dst = dst, j.E = E, j.perm = perm_fwd;
     j.fwd_ro = fwd_ro, j.fwd_col = fwd_col, j.fwd_eid = fwd_eid, j.bwd_ro = bwd_ro, j.bwd_col = bwd_col, j.bwd_eid = bwd_eid;
     j.in_deg = in_deg, j.out_deg = out_deg, j.norm = norm, j.nc_f = nc_f, j.nc_b = nc_b, j.cnt = counters;
-    j.key_f = reinterpret_cast<uint64_t *>(ws + L.key_f), j.key_b = reinterpret_cast<uint64_t *>(ws + L.key_b);
-    j.row_f = reinterpret_cast<int *>(ws + L.row_f), j.row_b = reinterpret_cast<int *>(ws + L.row_b);
+    j.rec_f = reinterpret_cast<EdgeRec *>(ws + L.key_f), j.rec_b = reinterpret_cast<EdgeRec *>(ws + L.key_b);
     j.pos_f = reinterpret_cast<int *>(ws + L.pos_f), j.pos_b = reinterpret_cast<int *>(ws + L.pos_b);
     j.part = reinterpret_cast<int *>(ws + L.part);
     // histograms in LDS when |V| fits it and there are enough edges per vertex to pay for writing and combining 2 x 16 x |V| counts

@@ -14,7 +14,7 @@ from stgraph_amd.graph import StaticGraph  # noqa: E402
 C, FIN, FH = 64, 32, 32
 
 
-def timed(fn, iters=200, warm=20):
+def timed(fn, iters=int(os.environ.get('STEP_ITERS', '200')), warm=int(os.environ.get('STEP_WARM', '20'))):
     for _ in range(warm):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -8,8 +8,8 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 out=/tmp/pmc_${tag}_mfma
 rm -rf "$out"
-echo "pass: SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
-timeout -k 10 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out" -- python3 "$@" > gpurun_out/pmc_${tag}_mfma.stdout 2> gpurun_out/pmc_${tag}_mfma.stderr || echo "pass failed"
+echo "pass: SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
+timeout -k 10 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out" -- python3 "$@" > gpurun_out/pmc_${tag}_mfma.stdout 2> gpurun_out/pmc_${tag}_mfma.stderr || echo "pass failed"
 find "$out" -name "*counter_collection.csv" -exec cp {} gpurun_out/pmc_${tag}_mfma.csv \;
 python3 - "$tag" "$match" <<'PY'
 import csv, sys, collections
