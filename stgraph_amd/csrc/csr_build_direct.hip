@@ -143,7 +143,7 @@ __device__ __forceinline__ int rank_in_row(const uint64_t *__restrict__ key, int
 // profiles/r05_build_records.json), and the rank passes read key and row of their entry with one coalesced 16-byte load.
 struct __attribute__((aligned(16))) EdgeRec {
     uint64_t key;
-    int row, pad;
+    int row, aux;              // aux (forward records): the edge's slot in its backward row
 };
 __device__ __forceinline__ int rank_in_row(const EdgeRec *__restrict__ rec, int beg, int end, uint64_t mine)
 {
@@ -439,8 +439,10 @@ __global__ __launch_bounds__(kBlock) void direct2_place(const BuildJobs<CAP> job
     if (*status) return;
     const BJob &J = jobs.j[blockIdx.z];
     const int *__restrict__ src = J.src, *__restrict__ dst = J.dst, *__restrict__ fwd_ro = J.fwd_ro, *__restrict__ pos_f = J.pos_f;
+    const int *__restrict__ bwd_ro = J.bwd_ro, *__restrict__ pos_b = J.pos_b;
     EdgeRec *__restrict__ rec = J.rec_f;
     const int *__restrict__ base_f = J.lds ? J.part : nullptr;
+    const int *__restrict__ base_b = J.lds ? J.part + (size_t)kLdsChunks * npad : nullptr;
     const int chunk_shift = J.chunk_shift;
     const int64_t E = J.E;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -448,8 +450,13 @@ __global__ __launch_bounds__(kBlock) void direct2_place(const BuildJobs<CAP> job
         const int d = dst[i];
         int slot = fwd_ro[d] + pos_f[i];
         if (base_f) slot += base_f[(i >> chunk_shift) * npad + d];
-        // one 16-byte store: {key = src << 32 | i, row = d}
-        *reinterpret_cast<uint4 *>(rec + slot) = make_uint4((unsigned)i, (unsigned)src[i], (unsigned)d, 0u);
+        // the edge's slot in its BACKWARD row is known here too (pos_b[i] is a coalesced read in this pass, a random one in the
+        // rank pass): it rides in the record's fourth word
+        const int s = src[i];
+        int slot_b = bwd_ro[s] + pos_b[i];
+        if (base_b) slot_b += base_b[(i >> chunk_shift) * npad + s];
+        // one 16-byte store: {key = src << 32 | i, row = d, backward slot}
+        *reinterpret_cast<uint4 *>(rec + slot) = make_uint4((unsigned)i, (unsigned)s, (unsigned)d, (unsigned)slot_b);
     }
 }
 
@@ -459,14 +466,12 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const BuildJobs<CAP> 
     if (*status) return;
     const BJob &J = jobs.j[blockIdx.z];
     const EdgeRec *__restrict__ rec = J.rec_f;
-    const int *__restrict__ fwd_ro = J.fwd_ro, *__restrict__ bwd_ro = J.bwd_ro, *__restrict__ pos_b = J.pos_b;
+    const int *__restrict__ fwd_ro = J.fwd_ro;
     int *__restrict__ fwd_col = J.fwd_col, *__restrict__ fwd_eid = J.fwd_eid;
     int64_t *__restrict__ perm_fwd = J.perm;
     EdgeRec *__restrict__ rec_b = J.rec_b;
     const float *__restrict__ norm = J.norm;
     float *__restrict__ nc_fwd = J.nc_f;
-    const int *__restrict__ base_b = J.lds ? J.part + (size_t)kLdsChunks * npad : nullptr;
-    const int chunk_shift = J.chunk_shift;
     const int64_t E = J.E;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < E; t += stride) {
@@ -481,10 +486,8 @@ __global__ __launch_bounds__(kBlock) void direct2_rank_fwd(const BuildJobs<CAP> 
         fwd_eid[e] = e;
         perm_fwd[e] = (int64_t)i;
         if (nc_fwd) nc_fwd[e] = norm[s];
-        int slot = bwd_ro[s] + pos_b[i];
-        if (base_b) slot += base_b[(i >> chunk_shift) * npad + s];
-        // {key = eid << 32 | dst, row = s} into its backward row, one store
-        *reinterpret_cast<uint4 *>(rec_b + slot) = make_uint4((unsigned)d, (unsigned)e, (unsigned)s, 0u);
+        // {key = eid << 32 | dst, row = s} into its backward row (slot found by direct2_place), one store
+        *reinterpret_cast<uint4 *>(rec_b + r4.w) = make_uint4((unsigned)d, (unsigned)e, (unsigned)s, 0u);
     }
 }
 

@@ -124,8 +124,9 @@ class _FoldGuard:
 
     def __init__(self, optimizer, device, world: int = 1, group=None, owner=None):
         from . import kernels
-        self.active = bool(kernels.STEP_FOLDED or kernels.STEP_WGRAD_FROM_P)
         self.device, self.world, self.group, self.optimizer = torch.device(device), world, group, optimizer
+        # (the folded launches exist on the GPU only: a CPU run -- the oracle-backed layers of tests/test_distributed_cpu.py -- has no word)
+        self.active = bool(kernels.STEP_FOLDED or kernels.STEP_WGRAD_FROM_P) and self.device.type == "cuda"
         self.prev = False
         if not self.active:
             return
