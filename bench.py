@@ -746,9 +746,11 @@ class GAT(nn.Module):
 
 
 # launches whose record's `units` field is the edges*feat the launch actually gathers (sum of E x F_launch)
-TGCN_DENSE = ("tgcn_step_fwd", "tgcn_step_bwd", "gemm_tn_form", "gemm_tn", "gemm_tn_multi", "gemm_tn_wide", "rowgemm")
+# launches priced against the fp32 matrix rate (they run v_mfma_f32_*_f32).  The row products and the weight-gradient contractions run
+# as 3-term bf16 splits on the bf16 instruction since rounds 4 / 5 and are bound by their operand streams: priced on bytes.
+TGCN_DENSE = ("tgcn_step_fwd", "tgcn_step_bwd")
 AGG_LAUNCHES = ("gcn_agg", "gcn_agg_transform", "gat_k1", "gat_k1_uniform", "gat_bwd", "gat_bwd_uniform")
-GAT_DENSE = ("gat_fc", "gat_fc_out", "gat_bwd_gw", "gemm_tn", "gemm_tn_multi", "rowgemm", "rowgemm_wide")
+GAT_DENSE = ("gat_fc", "gat_fc_out", "gat_bwd_gw")
 
 
 def executed_edges_feat(records):
@@ -1399,7 +1401,7 @@ def cfg2_run(args, device, rank, world, want_cpu):
 
     ef_per_step = meta["agg_launches_per_step"] * meta["e"] * meta["feat"]
     # (the row products run as bf16 triples on the bf16 matrix instruction and are bound by their access pattern: priced on bytes)
-    other = kernel_table([r for r in records if r[0] != "gcn_agg"], args.steps, ("gemm_tn", "gemm_tn_multi", "gemm_tn_wide"))
+    other = kernel_table([r for r in records if r[0] != "gcn_agg"], args.steps, ())
     gemm_ms = [a.elapsed_time(b) for (name, a, b, _, _) in records if name == "gemm_tn"]
     records = [r for r in records if r[0] == "gcn_agg"]           # the dominant kernel
     ms = [a.elapsed_time(b) for (_, a, b, _, _) in records]

@@ -281,21 +281,46 @@ FUSED_REBUILD = True     # re-builds of a validated edge list go through stg_gra
 BUILD_SLOTS = 16         # counter buffers per (device, |V|): that many rebuilds may be in flight (side streams, or the jobs of a batch)
 BUILD_BATCH_MAX_NODES = 1 << 18     # batched rebuilds (and their 16 counter buffers of 8 |V| bytes) are for small snapshots; above: 4 slots
 _BUILD_COUNTERS = {}
+_BUILD_COUNTER_PINS = {}        # (device, N) -> number of live owners of captured graphs that hold raw pointers into its buffers
+BUILD_COUNTER_SIZES_KEPT = 8    # distinct (device, |V|) whose counter buffers stay cached when nobody pins them
+
+
+def pin_build_counters(owner, device, N: int) -> None:
+    """``owner`` (an object whose captured HIP graphs hold RAW POINTERS into the counter buffers of (device, N): a replay adds into
+    them assuming they are zero) keeps them alive: they are not evicted until the last such owner is garbage."""
+    import weakref
+    key = (str(device), int(N))
+    _BUILD_COUNTER_PINS[key] = _BUILD_COUNTER_PINS.get(key, 0) + 1
+
+    def _unpin(k=key):
+        n = _BUILD_COUNTER_PINS.get(k, 0) - 1
+        if n <= 0:
+            _BUILD_COUNTER_PINS.pop(k, None)
+        else:
+            _BUILD_COUNTER_PINS[k] = n
+    weakref.finalize(owner, _unpin)
 
 
 def _build_counters(device, N: int, slot: int = 0):
     """(2 N zeroed counters, sticky status word) of ``device`` for stg_graph_build_direct2_device: the counters are zero
     between builds by that function's contract, so one buffer per (device, N) serves every rebuild on a stream; builds
-    issued on CONCURRENT streams take different ``slot``s."""
+    issued on CONCURRENT streams take different ``slot``s.  The slots of a (device, N) are made one at a time, on first use
+    (8 N bytes each).  Buffers of the ``BUILD_COUNTER_SIZES_KEPT`` most recently used sizes stay cached; older sizes are dropped
+    unless an owner of captured graphs pinned them (``pin_build_counters``) -- a process that builds graphs of many distinct |V|
+    no longer grows without bound."""
     key = (str(device), int(N), int(slot))
-    hit = _BUILD_COUNTERS.get(key)
+    hit = _BUILD_COUNTERS.pop(key, None)
     if hit is None:
-        # Kept for the life of the process, never evicted: captured HIP graphs (CapturedDynamicWindows in rebuild mode, the
-        # batched builds) hold raw pointers into these buffers and into the sticky status word, and a replay adds into them
-        # assuming they are zero -- memory handed back to the caching allocator could by then belong to a live tensor.  The
-        # slots of a (device, N) are made one at a time, on first use (8 N bytes each).
-        hit = _BUILD_COUNTERS[key] = (torch.zeros(2 * ((max(N, 1) + 3) & ~3), dtype=torch.int32, device=device),
-                                      _build_status_word(device))
+        hit = (torch.zeros(2 * ((max(N, 1) + 3) & ~3), dtype=torch.int32, device=device), _build_status_word(device))
+        sizes = []
+        for k in _BUILD_COUNTERS:                                  # insertion order = least recently used first
+            if (k[0], k[1]) not in sizes:
+                sizes.append((k[0], k[1]))
+        unpinned = [sz for sz in sizes if sz not in _BUILD_COUNTER_PINS and sz != (key[0], key[1])]
+        for sz in unpinned[:max(0, len(unpinned) - (BUILD_COUNTER_SIZES_KEPT - 1))]:
+            for k in [k for k in _BUILD_COUNTERS if (k[0], k[1]) == sz]:
+                del _BUILD_COUNTERS[k]
+    _BUILD_COUNTERS[key] = hit                                     # (re-inserted: most recently used last)
     return hit
 
 

@@ -1106,6 +1106,9 @@ class CapturedDynamicWindows:
         if not (isinstance(graph, DynamicGraph) and hasattr(graph, "csr")):
             raise TypeError("CapturedDynamicWindows needs a dynamic graph that hands out device CSRs (NaiveGraph, PCSRGraph, GPMAGraph)")
         self._store = not isinstance(graph, NaiveGraph)
+        if not self._store and not graph._resident:
+            from . import kernels
+            kernels.pin_build_counters(self, pos_neg_targets[0].device, graph.get_num_nodes())   # rebuilds inside the window graphs
         self._end_state = {}
         self._side = None
         # rebuild mode: snapshot builds on parallel branches of the window's graph.  Off: measured 30.2 against 31.7 epochs/s

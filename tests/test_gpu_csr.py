@@ -308,3 +308,27 @@ def test_naive_graph_prebuilds_a_window(cuda):
     G._snapshots.clear()
     assert G.prebuild(range(0, 6)) == 5                                  # max_cached bounds a batch
     G.reset_graph()                                                      # deferred status words: clean
+
+
+def test_build_counter_buffers_are_bounded_and_pinnable(cuda):
+    """kernels._build_counters: buffers of at most BUILD_COUNTER_SIZES_KEPT distinct |V| stay cached unless an owner of captured graphs
+    pinned theirs (raw pointers inside HIP graphs); a dead owner unpins."""
+    import gc
+    from stgraph_amd import kernels
+
+    class Owner:
+        pass
+    kernels._BUILD_COUNTERS.clear()
+    o = Owner()
+    kernels.pin_build_counters(o, cuda, 1001)
+    pinned = kernels._build_counters(cuda, 1001, 0)[0]
+    for n in range(2000, 2000 + 3 * kernels.BUILD_COUNTER_SIZES_KEPT):
+        c, st = kernels._build_counters(cuda, n, 0)
+        assert c.numel() >= 2 * n and int(c.abs().sum()) == 0
+    sizes = {(k[0], k[1]) for k in kernels._BUILD_COUNTERS}
+    assert (str(cuda), 1001) in sizes and len(sizes) <= kernels.BUILD_COUNTER_SIZES_KEPT + 1
+    assert kernels._build_counters(cuda, 1001, 0)[0].data_ptr() == pinned.data_ptr()
+    del o
+    gc.collect()
+    assert (str(cuda), 1001) not in kernels._BUILD_COUNTER_PINS
+    kernels._BUILD_COUNTERS.clear()

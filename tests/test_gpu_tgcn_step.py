@@ -438,3 +438,37 @@ def test_unfold_gate_grads_kernel_against_its_torch_statement(cuda):
         for a, o, b in zip(got[g], outs[g], want[g]):
             torch.testing.assert_close(a.double(), b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
             assert torch.equal(a, o)
+
+
+@pytest.mark.parametrize("n,waves", [(50_000, 12), (49_990, 12), (70_001, 16), (66_000, 16)])
+def test_shared_tiles_of_the_partial_round_are_bit_identical(cuda, n, waves):
+    """Tiles of the last, partial round shared by four waves (knob "step_coop" 0, default) against one wave each (1): every output
+    of the folded forward and backward launches, bit for bit.  |V| = 50 000 on 12-wave workgroups: 53 workgroups with one such
+    tile (49 990: the last tile ragged); 16-wave workgroups at 66-70 K rows: up to two shared tiles per workgroup, two groups."""
+    from stgraph_amd import _C, kernels
+    g, e = _graph(cuda, n, 10 * n, seed=n)
+    gen = torch.Generator(device=cuda).manual_seed(n + 1)
+    deg = (g.fwd.row_offset[1:] - g.fwd.row_offset[:-1]).float()
+    norm = torch.where(deg > 0, deg.clamp(min=1) ** -0.5, torch.zeros_like(deg)).view(-1, 1)
+    ew = torch.rand(e, 1, device=cuda, generator=gen) + 0.5
+    p = _params(cuda, n + 2)
+    x0 = torch.randn(n, FIN, device=cuda, generator=gen)
+    H = torch.randn(n, C, device=cuda, generator=gen) * 0.3
+    t0 = torch.randn(n, device=cuda, generator=gen)
+    zn, dHn = torch.randn(n, FIN, device=cuda, generator=gen), torch.randn(n, C, device=cuda, generator=gen)
+    g_cost = torch.tensor([0.37], device=cuda)
+    res = []
+    _C.set_tuning("step_waves", waves)
+    try:
+        for coop_off in (0, 1):
+            _C.set_tuning("step_coop", coop_off)
+            s = _fwd(cuda, g, norm, ew, p, x0, H, t0, n, x3form="folded32")
+            b = _bwd(cuda, g, norm, ew, p, s, H, t0, n, zn=zn, dHn=dHn, g_cost=g_cost, x3form="folded32")
+            res.append({**{k: v for k, v in s.items() if torch.is_tensor(v)}, **{"b_" + k: v for k, v in b.items() if torch.is_tensor(v)}})
+    finally:
+        _C.set_tuning("step_coop", 0)
+        _C.set_tuning("step_waves", 0)
+    assert int(kernels.step_fold_status_word(cuda).item()) == 0
+    for k in res[0]:
+        assert not bool(torch.isnan(res[0][k].float()).any()), k
+        assert torch.equal(res[0][k], res[1][k]), k
