@@ -357,6 +357,9 @@ struct RowGather32 {
             if (base > 0) indices(column_indices, nc_edge, ew_edge, base, q);
             const int cnt = deg - base;
             const int cnt_max = min(kR, max_deg - base);
+            // (round 5, measured and dropped: every load unconditional -- slots past the end of a row reading row 0 -- with the values
+            //  selected to +0 and no guard around the adds: 37.2 / 40.8 us against 35.6 / 39.3 forward / backward.  With ~10 of 16 slots
+            //  in use the exec-mask branches SKIP a third of the arithmetic; 8 selects per slot cost more than they save)
 #pragma unroll
             for (int k = 0; k < kR; k += kU) {
                 if (k < cnt_max) {
