@@ -62,20 +62,37 @@ constexpr int kX3Step = 16;                 // rows per step (K of the instructi
 // WA: floats per lane of A (M = 32 WA); WB0 / WB1: of B's first / second matrix (N = 32 (WB0 + WB1); WB1 = 0: one matrix)
 template <int WA, int WB0, int WB1, bool CS, int D = (WA * (WB0 + WB1) >= 16 ? 2 : (WA * (WB0 + WB1) >= 12 ? 3 : 4))>
 __global__ __launch_bounds__(kBlock, 1) void gemm_tn_x3_kernel(const GemmSegs segs, const GemmForm form, float *__restrict__ slab,
-                                                               int64_t K, int64_t kslice_wave, int s_per_seg)
+                                                               int64_t K, int64_t kslice_wave, int s_per_seg, int n_groups)
 {
     if (gemm_gated_off(form.gate, form.gate_when)) return;
-    constexpr int TB = WB0 + WB1, M = 32 * WA, N = 32 * TB;
+    constexpr int TB = WB0 + WB1, M = 32 * WA, N = 32 * TB;     // N: the columns THIS workgroup covers (n_groups of them side by side)
     extern __shared__ float lds[];                       // one wave's accumulators: WA x TB x 16 x 64 floats (+ WA x 64)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, kgrp = lane >> 5;
-    const int s = blockIdx.x;                            // slab = segment * s_per_seg + slice
+    // n_groups == 2 (128 x 128: 16 tiles would need all 256 accumulator registers -- it spilled and ran at 261 us where its loads
+    // alone take 185): two workgroups share a K slice, each taking 64 of B's columns.  Workgroups go to the 8 XCDs in turn, so the
+    // two of a slice are made xcd, xcd + 8 of a run of 16: same XCD, resident together -- A's second read is an L2 hit.
+    int s, nj = 0;                                       // slab = segment * s_per_seg + slice
+    if (n_groups == 2) {
+        const int b = blockIdx.x, run = b >> 4, within = b & 15, total = (int)gridDim.x >> 1, full = total & ~7;
+        if (run * 8 < full) {
+            s = run * 8 + (within & 7);
+            nj = within >> 3;
+        } else {
+            const int r = b - 2 * full;
+            s = full + (r >> 1);
+            nj = r & 1;
+        }
+    } else {
+        s = blockIdx.x;
+    }
     const int seg = s / s_per_seg, sl = s - seg * s_per_seg;
     const float *__restrict__ A = segs.a[seg];
-    const float *__restrict__ B = segs.b[seg];
+    const float *__restrict__ B = segs.b[seg] + nj * N;
     const float *__restrict__ B2 = segs.b2[seg];
     const int lda = form.lda, ldb = form.ldb, ldb2 = form.ldb2;
+    const int Nt = N * n_groups;                         // row length of the slab
     const int64_t k0 = ((int64_t)sl * kWavesPerBlock + wave) * kslice_wave;     // wave-uniform, inside the segment
     const int64_t k1 = min(K, k0 + kslice_wave);
     const int64_t rows = k1 > k0 ? k1 - k0 : 0;
@@ -108,6 +125,20 @@ __global__ __launch_bounds__(kBlock, 1) void gemm_tn_x3_kernel(const GemmSegs se
         float a[8][WA], b[8][WB0], b2[8][WB1 ? WB1 : 1];
     };
     auto load_set = [&](Set &v, int r0) {                                       // r0: first row of the step inside the slice (uniform)
+#if defined(STG_X3G_ABLATE) && STG_X3G_ABLATE == 2        // diagnosis build: the splits and products without the loads
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int r = 0; r < WA; ++r) v.a[t][r] = __int_as_float(r0 + t + r + lane);
+#pragma unroll
+            for (int r = 0; r < WB0; ++r) v.b[t][r] = __int_as_float(r0 - t + r + lane);
+            if constexpr (WB1 > 0) {
+#pragma unroll
+                for (int r = 0; r < WB1; ++r) v.b2[t][r] = __int_as_float(r0 + 3 * t + r + lane);
+            }
+        }
+        return;
+#endif
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             x3_load<WA>(v.a[t], rsA, voA, (r0 + t) * lda * (int)sizeof(float));
@@ -116,6 +147,22 @@ __global__ __launch_bounds__(kBlock, 1) void gemm_tn_x3_kernel(const GemmSegs se
         }
     };
     auto consume = [&](Set &v) {
+#if defined(STG_X3G_ABLATE) && STG_X3G_ABLATE == 1        // diagnosis build: the loads without the splits and products
+        float keep = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int r = 0; r < WA; ++r) keep += v.a[t][r];
+#pragma unroll
+            for (int r = 0; r < WB0; ++r) keep += v.b[t][r];
+            if constexpr (WB1 > 0) {
+#pragma unroll
+                for (int r = 0; r < WB1; ++r) keep += v.b2[t][r];
+            }
+        }
+        acc[0][0][0] += keep;
+        return;
+#endif
         if (b_op != STG_GEMM_B_NONE) {                                          // wave-uniform: transform of the first matrix' values
 #pragma unroll
             for (int t = 0; t < 8; ++t)
@@ -208,17 +255,17 @@ __global__ __launch_bounds__(kBlock, 1) void gemm_tn_x3_kernel(const GemmSegs se
     }
     if (wave == 0) {
         // acc[ra][rb][r] = C[WA i + ra][chunk + WB j + rb], i = (r & 3) + 8 (r >> 2) + 4 kgrp (the 32 x 32 instruction's C map), j = c
-        float *out = slab + (int64_t)s * ((int64_t)M * N + (CS ? M : 0));
+        float *out = slab + (int64_t)s * ((int64_t)M * Nt + (CS ? M : 0)) + nj * N;
 #pragma unroll
         for (int ra = 0; ra < WA; ++ra) {
             if constexpr (CS) {
                 const float tot = cs[ra] + __shfl_xor(cs[ra], 32, kWave);       // the two row groups of column WA c + ra
-                if (kgrp == 0) out[(int64_t)M * N + WA * c + ra] = tot;
+                if (kgrp == 0 && nj == 0) out[(int64_t)M * Nt + WA * c + ra] = tot;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = WA * ((r & 3) + 8 * (r >> 2) + 4 * kgrp) + ra;
-                float *o = out + (int64_t)m * N;
+                float *o = out + (int64_t)m * Nt;
                 if constexpr (WB0 == 4) *reinterpret_cast<float4 *>(o + 4 * c) = make_float4(acc[ra][0][r], acc[ra][1][r], acc[ra][2][r], acc[ra][3][r]);
                 else if constexpr (WB0 == 2) *reinterpret_cast<float2 *>(o + 2 * c) = make_float2(acc[ra][0][r], acc[ra][1][r]);
                 else o[c] = acc[ra][0][r];
@@ -249,11 +296,11 @@ X3Plan x3_plan(int64_t K, int T)
 
 template <int WA, int WB0, int WB1>
 int x3_launch_shape(const GemmSegs &segs, const GemmForm &form, float *slab, int64_t K, int T, bool colsum, const X3Plan &p,
-                    hipStream_t stream)
+                    hipStream_t stream, int n_groups = 1)
 {
     constexpr int TB = WB0 + WB1;
     const size_t lds = ((size_t)WA * TB * 16 + WA) * kWave * sizeof(float);
-    const unsigned blocks = (unsigned)(T * p.S);
+    const unsigned blocks = (unsigned)(T * p.S * n_groups);
     auto go = [&](auto kern) {
         static PerDeviceOnce once;
         bool *raised = once.slot();
@@ -262,7 +309,7 @@ int x3_launch_shape(const GemmSegs &segs, const GemmForm &form, float *slab, int
             if (e != hipSuccess) return fail((int)e, "gemm_tn_x3: %s", hipGetErrorString(e));
             *raised = true;
         }
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), lds, stream, segs, form, slab, K, p.kslice_wave, p.S);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), lds, stream, segs, form, slab, K, p.kslice_wave, p.S, n_groups);
         return check_launch("gemm_tn_x3");
     };
     return colsum ? go(gemm_tn_x3_kernel<WA, WB0, WB1, true>) : go(gemm_tn_x3_kernel<WA, WB0, WB1, false>);
@@ -270,14 +317,16 @@ int x3_launch_shape(const GemmSegs &segs, const GemmForm &form, float *slab, int
 
 // (WA, WB0, WB1) of a shape, or WA = 0
 struct X3Shape {
-    int wa, wb0, wb1;
+    int wa, wb0, wb1, n_groups;
 };
 X3Shape x3_shape(int M, int N, int nsplit)
 {
-    X3Shape s{0, 0, 0};
+    X3Shape s{0, 0, 0, 1};
     if (M != 32 && M != 64 && M != 128) return s;
-    if (nsplit == N && (N == 64 || N == 128)) s = {M / 32, N / 32, 0};
-    else if (nsplit == 64 && N == 96) s = {M / 32, 2, 1};
+    // (128 x 128 as two XCD-paired workgroups of 8 tiles per K slice -- n_groups = 2, no spills -- measured SLOWER than one
+    //  workgroup of 16 tiles with its 130-byte spill: 279 against 232-261 us; A's second read through L2 costs more than the spill)
+    if (nsplit == N && (N == 64 || N == 128)) s = {M / 32, N / 32, 0, 1};
+    else if (nsplit == 64 && N == 96) s = {M / 32, 2, 1, 1};
     return s;
 }
 
@@ -306,7 +355,7 @@ int gemm_tn_x3_launch(const GemmSegs &segs, const GemmForm &form, float *slab, i
     const X3Plan p = x3_plan(K, T);
     *slabs = T * p.S;
 #define STG_X3(WA_, WB0_, WB1_) \
-    if (sh.wa == WA_ && sh.wb0 == WB0_ && sh.wb1 == WB1_) return x3_launch_shape<WA_, WB0_, WB1_>(segs, form, slab, K, T, colsum, p, stream)
+    if (sh.wa == WA_ && sh.wb0 == WB0_ && sh.wb1 == WB1_) return x3_launch_shape<WA_, WB0_, WB1_>(segs, form, slab, K, T, colsum, p, stream, sh.n_groups)
     STG_X3(4, 4, 0);
     STG_X3(4, 2, 0);
     STG_X3(4, 2, 1);
