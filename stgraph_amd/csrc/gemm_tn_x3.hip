@@ -323,6 +323,9 @@ X3Shape x3_shape(int M, int N, int nsplit)
 {
     X3Shape s{0, 0, 0, 1};
     if (M != 32 && M != 64 && M != 128) return s;
+    // (the 128 x 128 spill is an ACCUMULATOR tile: 16 tiles are all 256 AccVGPRs and the allocator parks a few other values there.
+    //  Loading A's and B's next rows at different times, and scheduling barriers around every B tile's products, left the
+    //  allocation unchanged: 132-152 bytes of scratch either way)
     // (128 x 128 as two XCD-paired workgroups of 8 tiles per K slice -- n_groups = 2, no spills -- measured SLOWER than one
     //  workgroup of 16 tiles with its 130-byte spill: 279 against 232-261 us; A's second read through L2 costs more than the spill)
     if (nsplit == N && (N == 64 || N == 128)) s = {M / 32, N / 32, 0, 1};
