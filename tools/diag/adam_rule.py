@@ -17,8 +17,8 @@ from tests.util import golden
 dev = torch.device("cuda", 0)
 d = golden("tgcn_native.npz")
 out = {}
-for matrix_core in (True, False):
-    kernels.set_step_matrix_core(matrix_core)
+for folded in (True, False):
+    kernels.set_step_folded(folded)
     for mode in ("eager", "hip_graph", "capturable", "capturable_fused"):
         g, targets, ew, n, T = _static_setup(d, dev, True)
         feat, hid, B = int(d["feat"]), int(d["hidden"]), 3
@@ -44,5 +44,5 @@ for matrix_core in (True, False):
             top = np.argsort(err)[-3:][::-1]
             rep[k] = {"max_err": float(err.max()), "gmax": float(gs.max()), "frac_gt_2e-5": float((err > 2e-5).mean()),
                       "top": [{"err": float(err[i]), "g": [float(v) for v in gs[:, i]]} for i in top]}
-        out[f"{'x3' if matrix_core else 'f32'}:{mode}"] = rep
+        out[f"{'folded' if folded else 'reference_form'}:{mode}"] = rep
 print(json.dumps(out))
