@@ -90,10 +90,11 @@ class NaiveGraph(DynamicGraph):
             self._snapshots.move_to_end(t)
         return g
 
-    def prebuild(self, timestamps) -> int:
+    def prebuild(self, timestamps, counters_base: int = 0) -> int:
         """Rebuild the not-yet-cached snapshots among ``timestamps`` (each validated by an earlier build on the counting
         path, non-empty) as one batched device build -- the launches of ONE snapshot's rebuild, bit-identical CSRs.  What
-        does not qualify is left to ``_snapshot``.  Returns the number of snapshots built."""
+        does not qualify is left to ``_snapshot``.  Returns the number of snapshots built.  ``counters_base``: see
+        ``kernels.build_graph_csr_batch`` (builds issued on a second stream)."""
         cap = kernels._C.BUILD_BATCH_MAX
         if not self._resident and self._max_cached is not None:          # never more snapshots alive than the cache allows
             cap = min(cap, max(1, self._max_cached) - len(self._snapshots))
@@ -105,7 +106,7 @@ class NaiveGraph(DynamicGraph):
                 or not 0 < self.max_num_nodes <= kernels.BUILD_BATCH_MAX_NODES or any(self._edges[t][0].numel() > kernels.DIRECT_BUILD_MAX_EDGES for t in ts)):
             return 0
         t0 = time.time()
-        built = kernels.build_graph_csr_batch([self._edges[t] for t in ts], self.max_num_nodes, self._device)
+        built = kernels.build_graph_csr_batch([self._edges[t] for t in ts], self.max_num_nodes, self._device, counters_base)
         for t, g in zip(ts, built):
             self._snapshots[t] = g
         if not any(built[0].unchecked_status is p for p in self._pending_status[-1:]):

@@ -336,10 +336,12 @@ def _build_status_word(device) -> torch.Tensor:
     return w
 
 
-def build_graph_csr_batch(edge_lists, num_nodes: int, device: torch.device | str) -> list:
+def build_graph_csr_batch(edge_lists, num_nodes: int, device: torch.device | str, counters_base: int = 0) -> list:
     """The re-builds of SEVERAL validated edge lists over the same vertex set -- the snapshots of a BPTT window -- in the
     launches of one (stg_graph_build_direct2_batch_device; <= _C.BUILD_BATCH_MAX lists).  Every GraphCSR is bit-identical
-    to ``build_graph_csr(s, d, N, device, lazy_node_ids=True, known_path='direct')`` of its list."""
+    to ``build_graph_csr(s, d, N, device, lazy_node_ids=True, known_path='direct')`` of its list.
+    ``counters_base``: first counter slot of the batch (``_build_counters``); a build issued on a second stream beside builds of the
+    same |V| on another takes a disjoint range (temporal.CapturedDynamicWindows: ``_C.BUILD_BATCH_MAX``)."""
     device = torch.device(device)
     N = int(num_nodes)
     n = len(edge_lists)
@@ -365,7 +367,7 @@ def build_graph_csr_batch(edge_lists, num_nodes: int, device: torch.device | str
         nc_b = torch.empty(E, dtype=torch.float32, device=device)
         ws_bytes = int(_C.lib.stg_graph_build_direct_workspace_bytes(E, N))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        counters = _build_counters(device, N, k)[0]
+        counters = _build_counters(device, N, int(counters_base) + k)[0]
         j = jobs[k]
         j.src, j.dst, j.E = _ptr(s), _ptr(d), E
         j.perm_fwd = _ptr(perm)

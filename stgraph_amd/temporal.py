@@ -1117,6 +1117,15 @@ class CapturedDynamicWindows:
         # rebuild mode: the window's snapshots as ONE batched build (stg_graph_build_direct2_batch_device)
         self.batched_builds = True
         self.deferred_emission = True
+        # rebuild mode: a window's snapshot builds as a HIP graph of their own, replayed on a SECOND STREAM one window ahead of the
+        # training graph that reads them.  The builds read the edge lists only, so the builds of this rank's next window (the
+        # first window of the next epoch after the last) run beside the current window's step launches, which leave most of the
+        # chip idle at |V| = 25 K; every snapshot is still built once per epoch.  A rank with ONE window has nothing to run ahead of.
+        self.prefetch_builds = True
+        self.build_stream_low_priority = True
+        self._build_graphs, self._built, self._build_done, self._train_done, self._build_pending = {}, {}, {}, {}, {}
+        self._build_stream = None
+        self._order = None
         self.model, self.graph, self.edges, self.targets = model, graph, pos_neg_edges, pos_neg_targets
         self.total = len(pos_neg_edges)
         self.B = backprop_every or self.total
@@ -1132,9 +1141,25 @@ class CapturedDynamicWindows:
         self.allreduce_in_graph = False
         self._want_allreduce_in_graph = bool(allreduce_in_graph) and (world > 1 or group is not None)
 
+    def __del__(self):
+        # a build replayed ahead may still be writing into its graph's pool when the last reference goes
+        st = getattr(self, "_build_stream", None)
+        if st is not None:
+            try:
+                st.synchronize()
+            except Exception:                                    # interpreter shutdown
+                pass
+
     def invalidate(self) -> None:
         """Drop every captured window graph (they are captured again the next time their window is met): after a change of the
         step formulation."""
+        if self._build_graphs:
+            torch.cuda.synchronize(self.dev)                     # a build replay may still be running on the second stream
+        self._build_graphs.clear()
+        self._built.clear()
+        self._build_done.clear()
+        self._train_done.clear()
+        self._build_pending.clear()
         self.graphs.clear()
         self.costs.clear()
         self.inputs.clear()
@@ -1182,11 +1207,47 @@ class CapturedDynamicWindows:
         for st in used:
             cur.wait_stream(st)
 
+    def _build_body(self, w: int) -> None:
+        """Rebuild mode, ``prefetch_builds``: every snapshot of window ``w`` (both CSRs, degrees, norms, per-edge coefficients)."""
+        from . import kernels
+        g = self.graph
+        base = kernels._C.BUILD_BATCH_MAX                        # counter slots of their own: beside eager builds on another stream
+        while g.prebuild(self.timestamps(w), counters_base=base):
+            pass
+        for t in self.timestamps(w):
+            g._snapshot(t, counters_slot=base)                   # what the batched build does not cover
+
+    def _next_window(self, w: int):
+        """This rank's window after ``w`` (cyclically: the first window of the next epoch after the last)."""
+        if self._order is None:
+            self._order = [v for _, v in windows_of_rank(self.total, self.B, self.rank, self.world) if v is not None and self.usable(v)]
+        if w not in self._order or len(self._order) < 2:
+            return None
+        return self._order[(self._order.index(w) + 1) % len(self._order)]
+
+    def _launch_build(self, w: int) -> None:
+        if self._build_stream is None:
+            # LOWEST priority: a step launch wants every register of a CU for its workgroup, and waits for whatever build waves sit
+            # there.  Measured with equal priorities: forward step launches beside a build 55 us against 24 alone (the builds'
+            # thousands of short workgroups keep taking the slots a step workgroup waits for); the builds are to fill gaps only.
+            least = torch.cuda.Stream.priority_range()[0]
+            self._build_stream = torch.cuda.Stream(device=self.dev, priority=least if self.build_stream_low_priority else 0)
+        st = self._build_stream
+        if w in self._train_done:
+            st.wait_event(self._train_done[w])                   # the previous reader of these buffers
+        with torch.cuda.stream(st):
+            self._build_graphs[w].replay()
+            ev = self._build_done.get(w)
+            if ev is None:
+                ev = self._build_done[w] = torch.cuda.Event()
+            ev.record(st)
+        self._build_pending[w] = True
+
     def _body(self, w: int) -> torch.Tensor:
         from .nn import functional as SF
         g = self.graph
         self.bucket.zero()
-        if not self._store and not g._resident:
+        if not self._store and not g._resident and w not in self._build_graphs:
             if self.parallel_builds:
                 self._prebuild(w)
             elif self.batched_builds:
@@ -1218,6 +1279,14 @@ class CapturedDynamicWindows:
         if self._store:
             g._ndata.clear()                     # per-timestamp norms of an eager epoch: recomputed inside the graph
         torch.cuda.synchronize(self.dev)
+        fits = g._max_cached is None or g._max_cached >= len(self.timestamps(w)) if rebuild else False
+        if rebuild and self.prefetch_builds and not self.parallel_builds and fits:      # (all of the window's snapshots alive at once)
+            cb = torch.cuda.CUDAGraph()
+            with _graph_capture(cb):
+                self._build_body(w)
+            # the snapshots are tensors of the build graph's pool: kept (the training graph below reads them on every replay)
+            self._built[w] = {t: g._snapshots[t] for t in self.timestamps(w)}
+            self._build_graphs[w] = cb
         cg = torch.cuda.CUDAGraph()
         with _graph_capture(cg):
             self.costs[w] = self._body(w)
@@ -1257,7 +1326,22 @@ class CapturedDynamicWindows:
         if w not in self.graphs:
             self._capture(w)
         self.inputs[w].copy_(window_input(self.n, self.feat, epoch, w, self.dev, seed))
-        self.graphs[w].replay()
+        if w in self._build_graphs:
+            cur = torch.cuda.current_stream(self.dev)
+            if not self._build_pending.get(w):                   # nobody built it ahead (first use, one-window rank)
+                self._launch_build(w)
+            cur.wait_event(self._build_done[w])
+            self._build_pending[w] = False
+            nxt = self._next_window(w)
+            if nxt is not None and nxt in self._build_graphs and not self._build_pending.get(nxt):
+                self._launch_build(nxt)                          # beside this window's training graph
+            self.graphs[w].replay()
+            ev = self._train_done.get(w)
+            if ev is None:
+                ev = self._train_done[w] = torch.cuda.Event()
+            ev.record(cur)
+        else:
+            self.graphs[w].replay()
         if self._store:
             import copy
             fg, ts = self._end_state[w]

@@ -285,6 +285,8 @@ def test_captured_dynamic_windows_match_the_eager_loop(cuda, kind, optim):
                 losses += temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep)
         if captured:
             assert cd is not None and len(cd.graphs) == 3 and (cd.step_graph is not None) == (optim == "adam")   # window 3 = {t = 12}: no target
+            # rebuild mode: the builds are graphs of their own, replayed one window ahead on the second stream
+            assert len(cd._build_graphs) == (3 if kind == "naive_rebuild" else 0)
             if not kind.startswith("naive"):
                 G.check()                       # the store's stream contract held through the replays
                 assert G.current_timestamp == 11
@@ -292,6 +294,55 @@ def test_captured_dynamic_windows_match_the_eager_loop(cuda, kind, optim):
     torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-7)
     for a, b in zip(out[0][1], out[1][1]):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_builds_one_window_ahead_on_a_second_stream_change_nothing(cuda):
+    """CapturedDynamicWindows.prefetch_builds (rebuild mode: a window's snapshot builds replayed on a second stream while the
+    previous window trains) against the same builds at the head of the window's training graph: bit-identical costs and parameters over
+    five replayed epochs of three windows -- an ordering mistake between the two streams (a build overwriting CSRs a training graph
+    still reads, a training graph starting before its builds ended) would show here."""
+    import numpy as np
+    from stgraph_amd import temporal
+    from stgraph_amd.graph import NaiveGraph
+    n, e0, churn, T, B, feat, hid, m = 6000, 60000, 1500, 13, 4, 32, 64, 1500
+    rng = np.random.default_rng(12)
+    stream = rng.choice(n * n, size=e0 + churn * T, replace=False)
+    snaps, pn_edges, pn_targets = [], [], []
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    for t in range(T):
+        keys = stream[t * churn: t * churn + e0]
+        s, d = (keys // n).astype(np.int32), (keys % n).astype(np.int32)
+        snaps.append((torch.from_numpy(s).to(cuda), torch.from_numpy(d).to(cuda)))
+        pos = torch.from_numpy(np.stack([s[:m], d[:m]]).astype(np.int64)).to(cuda)
+        neg = torch.randint(0, n, (2, m), device=cuda, generator=gen)
+        pn_edges.append(torch.cat([pos, neg], 1))
+        pn_targets.append(torch.cat([torch.ones(m, device=cuda), torch.zeros(m, device=cuda)]))
+    out = []
+    for prefetch in (True, False):
+        G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False, resident=False, max_cached=B + 1)
+        torch.manual_seed(4)
+        model = temporal.DynamicSTGraphTGCN(feat, hid).to(cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, fused=True)
+        bucket = temporal.GradBucket(model.parameters())
+        cd, losses = None, []
+        for ep in range(6):
+            G._snapshots.clear()
+            G._ndata.clear()
+            if ep >= 1:
+                if cd is None:
+                    cd = temporal.CapturedDynamicWindows(model, G, pn_edges, pn_targets, B, opt, bucket, feat)
+                    cd.prefetch_builds = prefetch
+                losses += [x.clone() for x in temporal.train_epoch_dynamic_captured(cd, epoch=ep)]
+            else:
+                losses += temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep)
+        assert len(cd._build_graphs) == (3 if prefetch else 0)
+        if prefetch:
+            assert cd._build_pending.get(0) is True              # the last window of an epoch built the next epoch's first
+        torch.cuda.synchronize()
+        out.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+    assert torch.equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b)
 
 
 def test_window_on_data_the_fold_refuses_falls_back_to_the_reference_formulation(cuda):
