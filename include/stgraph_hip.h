@@ -39,8 +39,11 @@ extern "C" {
  *  26: the bf16-split forms of the step launches are RETIRED (measured slower than the fp32 / folded fp32 forms: profiles/r04_stepx_*,
  *      r04_stepf_*; sources in git history before round 5): stg_tgcn_pack_weights_x3, stg_tgcn_step_image_bytes and the knobs
  *      "step_impl" / "step_fold" are gone, `w_image` of both argument blocks is reserved and must be NULL, w_fold now REQUIRES
- *      fold_bound (the folded launch runs on the fp32 matrix instruction only). */
-#define STG_ABI_VERSION 26
+ *      fold_bound (the folded launch runs on the fp32 matrix instruction only).
+ *  27: stg_xent_small_supported / _fwd / _bwd: softmax cross-entropy of a SMALL logits matrix as one launch each way (the graph of
+ *      a captured Cora epoch is launch-count bound); stg_bias_act_bwd finishes the column sums in its own launch when one
+ *      workgroup covers the matrix (no signature change). */
+#define STG_ABI_VERSION 27
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
 #define STG_ERR_UNSUPPORTED      10002   /* shape outside what the kernels cover     */
@@ -884,6 +887,17 @@ int stg_xent_fwd_grad(const float *logits, const int64_t *labels, float *lse, fl
                       float *dlogits, float *colsum, int64_t n, int64_t n_total, int32_t K, void *workspace,
                       size_t workspace_bytes, void *stream);
 int stg_xent_scale_grad(float *dlogits, float *colsum, const float *g_loss, int64_t n_total, int32_t K, void *stream);
+/* The same loss and gradient for a SMALL matrix (stg_xent_small_supported: K <= 64 and about n_total * K' <= 32768, K' = K rounded up
+ * to a power of two -- one workgroup holds it in registers; the 2708 x 7 logits of
+ * Cora, benchmarking/gcn/seastar/train.py:63-101) as ONE one-workgroup launch each way: fwd = stg_xent_fwd (no workspace, no finish
+ * launch), bwd = stg_xent_bwd_colsum for any K (colsum nullable).  Inside a replayed HIP graph a launch costs ~ 4.5 us whatever
+ * it does; the general entry points need five for what these two do.  Sums in a fixed order: run-to-run identical; against the
+ * general path equal to fp32 rounding (another order of the same additions). */
+int stg_xent_small_supported(int64_t n_total, int32_t K);
+int stg_xent_small_fwd(const float *logits, const int64_t *labels, float *lse, float *loss, float *n_counted, int32_t *status,
+                       int64_t n, int32_t K, void *stream);
+int stg_xent_small_bwd(const float *g_loss, const float *logits, const int64_t *labels, const float *lse, const float *n_counted,
+                       float *dlogits, float *colsum, int64_t n, int64_t n_total, int32_t K, void *stream);
 
 /* ----------------------------------------------- dense neighbour: the TGCN harness head
  * The model head and loss of the static-temporal TGCN training step

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # STGRAPH_AMD_LIB: a diagnosis build of the same library (tools/diag/build_*_trace.sh); the product never sets it
 LIB_PATH = os.environ.get("STGRAPH_AMD_LIB") or os.path.join(_HERE, "lib", "libstgraph_hip.so")
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 STG_ERR_INVALID_ARGUMENT = 10001
 STG_ERR_UNSUPPORTED = 10002
@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = (
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
     "stg_xent_workspace_bytes", "stg_xent_fwd", "stg_xent_bwd", "stg_xent_bwd_colsum_workspace_bytes", "stg_xent_bwd_colsum", "stg_xent_fwd_grad_workspace_bytes", "stg_xent_fwd_grad", "stg_xent_scale_grad",
+    "stg_xent_small_supported", "stg_xent_small_fwd", "stg_xent_small_bwd",
     "stg_link_head_supported", "stg_link_head_workspace_bytes", "stg_link_head_fwd", "stg_link_head_bwd",
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
@@ -306,6 +307,12 @@ def _load() -> ctypes.CDLL:
     lib.stg_xent_fwd_grad.argtypes = [vp] * 8 + [i64, i64, i32, vp, ctypes.c_size_t, vp]
     lib.stg_xent_scale_grad.restype = ctypes.c_int
     lib.stg_xent_scale_grad.argtypes = [vp, vp, vp, i64, i32, vp]
+    lib.stg_xent_small_supported.restype = ctypes.c_int
+    lib.stg_xent_small_supported.argtypes = [i64, i32]
+    lib.stg_xent_small_fwd.restype = ctypes.c_int
+    lib.stg_xent_small_fwd.argtypes = [vp] * 6 + [i64, i32, vp]
+    lib.stg_xent_small_bwd.restype = ctypes.c_int
+    lib.stg_xent_small_bwd.argtypes = [vp] * 7 + [i64, i64, i32, vp]
     lib.stg_xent_bwd_colsum.restype = ctypes.c_int
     lib.stg_xent_bwd_colsum.argtypes = [vp] * 7 + [i64, i64, i32, vp, ctypes.c_size_t, vp]
     lib.stg_link_head_supported.restype = ctypes.c_int

@@ -106,6 +106,68 @@ __global__ __launch_bounds__(kBlock) void colsum_finish_kernel(const float *__re
     }
 }
 
+// A matrix ONE workgroup can hold in registers (Cora's 2708 x 16): every load of a thread issued before the first value is used
+// (what a small launch costs beyond its ~ 4.5 us is its number of dependent memory round trips), column sums by a tree over the
+// row lanes in LDS, written by this launch -- no partials, no finish launch.  L lanes of VEC floats per row, R = 1024 / L rows per
+// pass, P passes.
+constexpr int kSmallBlock = 1024;
+
+template <int VEC, int P, bool MASK>
+__global__ __launch_bounds__(kSmallBlock) void bias_act_bwd_small_kernel(const float *__restrict__ g, const float *__restrict__ out,
+                                                                          float *__restrict__ g_act, float *__restrict__ colsum,
+                                                                          int N, int F, int L)
+{
+    __shared__ float red[kSmallBlock * VEC];
+    const int R = kSmallBlock / L;
+    const int cl = (int)threadIdx.x % L, rl = (int)threadIdx.x / L;
+    const int col = cl * VEC;
+    const bool live = rl < R && col < F;
+    float gv[P][VEC], ov[P][VEC];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int r = rl + p * R;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gv[p][i] = 0.f, ov[p][i] = 1.f;
+        if (live && r < N) {
+            vec_load<VEC>(gv[p], g + (int64_t)r * F + col);
+            if constexpr (MASK) vec_load<VEC>(ov[p], out + (int64_t)r * F + col);
+        }
+    }
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int r = rl + p * R;
+        if (live && r < N) {
+            if constexpr (MASK) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) gv[p][i] = ov[p][i] > 0.f ? gv[p][i] : 0.f;      // threshold_backward
+                vec_store<VEC>(g_act + (int64_t)r * F + col, gv[p]);
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += gv[p][i];
+        }
+    }
+    if (!colsum) return;                                         // kernel-uniform
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[threadIdx.x * VEC + i] = live ? acc[i] : 0.f;
+    __syncthreads();
+    int top = 1;
+    while (top < R) top <<= 1;
+    for (int off = top / 2; off > 0; off >>= 1) {                // over the row lanes, fixed order (R need not be a power of two)
+        if (rl < off && rl + off < R) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) red[threadIdx.x * VEC + i] += red[(threadIdx.x + off * L) * VEC + i];
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && col < F) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) colsum[col + i] = red[threadIdx.x * VEC + i];
+    }
+}
+
 struct Shape {
     int vec, L, slots, grid;
 };
@@ -196,6 +258,30 @@ extern "C" int stg_bias_act_bwd(const float *g, const float *out, float *g_act, 
         if (s.slots > kMaxSlots) return fail(STG_ERR_UNSUPPORTED, "stg_bias_act_bwd: F=%d too wide for unaligned rows", F);
     }
     float *partial = nullptr;
+    // a matrix one workgroup holds in registers (Cora's 2708 x 16): one launch, no partials (bias_act_bwd_small_kernel)
+    {
+        const int vec = (F % 4 == 0 && align % 16 == 0) ? 4 : 1;
+        const int L = (F + vec - 1) / vec;
+        if (colsum && L <= kSmallBlock) {
+            const int R = kSmallBlock / L, passes = (N + R - 1) / R;
+            const int pmax = vec == 4 ? 12 : 48;
+            if (passes <= pmax) {
+#define STG_BAS(V_, P_)                                                                                                            \
+    do {                                                                                                                           \
+        if (out) hipLaunchKernelGGL((bias_act_bwd_small_kernel<V_, P_, true>), dim3(1), dim3(kSmallBlock), 0, stream, g, out, g_act, colsum, N, F, L); \
+        else hipLaunchKernelGGL((bias_act_bwd_small_kernel<V_, P_, false>), dim3(1), dim3(kSmallBlock), 0, stream, g, out, g_act, colsum, N, F, L); \
+    } while (0)
+                if (vec == 4) {
+                    if (passes <= 4) STG_BAS(4, 4);
+                    else STG_BAS(4, 12);
+                } else {
+                    STG_BAS(1, 48);                              // (a 16-pass instance of the scalar form spills 800 registers: compiler)
+                }
+#undef STG_BAS
+                return check_launch("stg_bias_act_bwd");
+            }
+        }
+    }
     if (colsum) {
         const size_t need = (size_t)s.grid * (size_t)F * sizeof(float);
         if (!workspace || workspace_bytes < need)

@@ -493,6 +493,129 @@ __global__ __launch_bounds__(kBlock) void xent_scale_grad_kernel(float *__restri
 
 constexpr int kXentGrid = 2048;
 
+// ---- small matrices (the 2708 x 7 logits of Cora): ONE workgroup each way ---------------------------------------------------------
+// A launch inside a replayed HIP graph costs ~ 4.5 us whatever it does, and the epoch of a 2708-vertex graph is 18 of them
+// (tools/diag/cora_kernels.py).  The general path above is forward + finish + backward + column sums + their finish = 5; for a
+// matrix one workgroup can hold in registers the same results take 2.  What such a launch costs beyond its 4.5 us is the number
+// of DEPENDENT memory round trips (~ 1.5 us each): every load of a thread is issued before the first value is used (a first
+// version that walked the rows in a loop took 7 + 10 us).
+constexpr int kSmallBlock = 1024;
+constexpr int kSmallPerThread = 64;            // elements a thread may hold (forward: rows x padded columns)
+constexpr int kSmallBwdPasses = 32;            // backward: rows per (row lane, column) thread -- 3 registers each of 128
+
+// thread = row (rows t, t + 1024, ..: PASSES of them), the row's KP >= K values in registers
+template <int KP, int PASSES>
+__global__ __launch_bounds__(kSmallBlock) void xent_small_fwd_kernel(const float *__restrict__ logits, const int64_t *__restrict__ labels,
+                                                                      float *__restrict__ lse, float *__restrict__ loss,
+                                                                      float *__restrict__ n_counted, int *__restrict__ status, int n, int K)
+{
+    __shared__ float s[kSmallBlock];
+    __shared__ int c[kSmallBlock];
+    float x[PASSES][KP];
+    int64_t lab[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int row = (int)threadIdx.x + p * kSmallBlock;
+        lab[p] = kIgnoreIndex;
+        if (row < n) lab[p] = labels[row];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            x[p][k] = -INFINITY;
+            if (row < n && k < K) x[p][k] = logits[(int64_t)row * K + k];
+        }
+    }
+    float term = 0.f;
+    int counted = 0;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int row = (int)threadIdx.x + p * kSmallBlock;
+        if (row < n) {
+            float m = -INFINITY, sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) m = fmaxf(m, x[p][k]);
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+                if (k < K) sum = sum + expf(x[p][k] - m);
+            const float l = m + logf(sum);
+            lse[row] = l;
+            const int64_t t = lab[p];
+            if (t >= 0 && t < K) {
+                float xt = 0.f;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) xt = k == (int)t ? x[p][k] : xt;
+                term = term + (l - xt), ++counted;
+            } else if (t != kIgnoreIndex) {
+                atomicOr(status, 1);
+            }
+        }
+    }
+    s[threadIdx.x] = term;
+    c[threadIdx.x] = counted;
+    __syncthreads();
+    for (int off = kSmallBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + off];
+            c[threadIdx.x] += c[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float cnt = (float)c[0];
+        n_counted[0] = cnt;
+        loss[0] = s[0] / cnt;                                    // no counted row: 0 / 0 = NaN, as torch
+    }
+}
+
+// KP = columns padded to a power of two: thread = (row lane r, column c), kSmallBlock / KP rows per pass, PASSES passes
+template <int KP, int PASSES>
+__global__ __launch_bounds__(kSmallBlock) void xent_small_bwd_kernel(const float *__restrict__ g_loss, const float *__restrict__ logits,
+                                                                      const int64_t *__restrict__ labels, const float *__restrict__ lse,
+                                                                      const float *__restrict__ n_counted, float *__restrict__ dlogits,
+                                                                      float *__restrict__ colsum, int n, int n_total, int K)
+{
+    constexpr int R = kSmallBlock / KP;
+    __shared__ float s[kSmallBlock];
+    const int c = (int)threadIdx.x % KP, r = (int)threadIdx.x / KP;
+    const float gl = g_loss[0], cnt = n_counted[0];
+    float x[PASSES], l[PASSES];
+    int lab[PASSES];                                             // -1: not a counted row
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int row = r + p * R;
+        x[p] = l[p] = 0.f;
+        lab[p] = -1;
+        if (row < n && c < K) {
+            x[p] = logits[(int64_t)row * K + c], l[p] = lse[row];
+            const int64_t t = labels[row];
+            lab[p] = t >= 0 && t < K ? (int)t : -1;
+        }
+    }
+    const float scale = gl / cnt;
+    float acc = 0.f;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int row = r + p * R;
+        if (row < n_total && c < K) {
+            float v = 0.f;
+            if (lab[p] >= 0) v = (expf(x[p] - l[p]) - (lab[p] == c ? 1.f : 0.f)) * scale;
+            dlogits[(int64_t)row * K + c] = v;
+            acc = acc + v;
+        }
+    }
+    if (!colsum) return;                                         // kernel-uniform
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = R / 2; off > 0; off >>= 1) {                  // over the row lanes of a column, fixed order
+        if (r < off) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + off * KP];
+        __syncthreads();
+    }
+    if (r == 0 && c < K) colsum[c] = s[c];
+}
+
+inline int small_kp(int K) { return K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 64; }
+
+constexpr int kSmallMaxK = 64;
+
 inline int xent_lanes(int K) { return K <= 32 ? 8 : K <= 256 ? 32 : 64; }
 inline int xent_blocks(int64_t n, int K)
 {
@@ -686,4 +809,74 @@ extern "C" int stg_xent_scale_grad(float *dlogits, float *colsum, const float *g
     hipLaunchKernelGGL(xent_scale_grad_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream_), dlogits, colsum, g_loss,
                        total4, total4 * 4, total, K);
     return check_launch("stg_xent_scale_grad");
+}
+
+extern "C" int stg_xent_small_supported(int64_t n_total, int32_t K)
+{
+    // both kernels hold a thread's share of the matrix in registers: (rows per thread) x (padded columns) <= kSmallPerThread
+    if (n_total <= 0 || K <= 0 || K > stg::kSmallMaxK) return 0;
+    const int kp = stg::small_kp(K);
+    const int64_t fwd_passes = (n_total + stg::kSmallBlock - 1) / stg::kSmallBlock;
+    const int64_t bwd_passes = (n_total + stg::kSmallBlock / kp - 1) / (stg::kSmallBlock / kp);
+    return fwd_passes * kp <= stg::kSmallPerThread && bwd_passes <= stg::kSmallBwdPasses;
+}
+
+extern "C" int stg_xent_small_fwd(const float *logits, const int64_t *labels, float *lse, float *loss, float *n_counted, int32_t *status,
+                                  int64_t n, int32_t K, void *stream_)
+{
+    using namespace stg;
+    if (n <= 0 || !stg_xent_small_supported(n, K)) return fail(STG_ERR_UNSUPPORTED, "stg_xent_small_fwd: n=%lld K=%d is not a small matrix", (long long)n, K);
+    if (!logits || !labels || !lse || !loss || !n_counted || !status) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_small_fwd: NULL pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const int kp = small_kp(K), passes = (int)((n + kSmallBlock - 1) / kSmallBlock);
+#define STG_XSF(KP_, P_)                                                                                                          \
+    hipLaunchKernelGGL((xent_small_fwd_kernel<KP_, P_>), dim3(1), dim3(kSmallBlock), 0, st, logits, labels, lse, loss, n_counted, status, (int)n, K)
+#define STG_XSF_P(KP_)                                                                                                            \
+    do {                                                                                                                          \
+        if (passes <= 1) STG_XSF(KP_, 1);                                                                                         \
+        else if (passes <= 2 && 2 * KP_ <= kSmallPerThread) STG_XSF(KP_, (2 * KP_ <= kSmallPerThread ? 2 : 1));                   \
+        else if (passes <= 4 && 4 * KP_ <= kSmallPerThread) STG_XSF(KP_, (4 * KP_ <= kSmallPerThread ? 4 : 1));                   \
+        else if (passes <= 8 && 8 * KP_ <= kSmallPerThread) STG_XSF(KP_, (8 * KP_ <= kSmallPerThread ? 8 : 1));                   \
+        else STG_XSF(KP_, (16 * KP_ <= kSmallPerThread ? 16 : 1));                                                                \
+    } while (0)
+    switch (kp) {
+        case 4: STG_XSF_P(4); break;
+        case 8: STG_XSF_P(8); break;
+        case 16: STG_XSF_P(16); break;
+        case 32: STG_XSF_P(32); break;
+        default: STG_XSF_P(64); break;
+    }
+#undef STG_XSF_P
+#undef STG_XSF
+    return check_launch("stg_xent_small_fwd");
+}
+
+extern "C" int stg_xent_small_bwd(const float *g_loss, const float *logits, const int64_t *labels, const float *lse, const float *n_counted,
+                                  float *dlogits, float *colsum, int64_t n, int64_t n_total, int32_t K, void *stream_)
+{
+    using namespace stg;
+    if (n <= 0 || n_total < n || !stg_xent_small_supported(n_total, K))
+        return fail(STG_ERR_UNSUPPORTED, "stg_xent_small_bwd: n=%lld n_total=%lld K=%d is not a small matrix", (long long)n, (long long)n_total, K);
+    if (!g_loss || !logits || !labels || !lse || !n_counted || !dlogits) return fail(STG_ERR_INVALID_ARGUMENT, "stg_xent_small_bwd: NULL pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const int kp = small_kp(K), passes = (int)((n_total + kSmallBlock / kp - 1) / (kSmallBlock / kp));
+#define STG_XSB(KP_, P_)                                                                                                          \
+    hipLaunchKernelGGL((xent_small_bwd_kernel<KP_, P_>), dim3(1), dim3(kSmallBlock), 0, st, g_loss, logits, labels, lse, n_counted,   \
+                       dlogits, colsum, (int)n, (int)n_total, K)
+#define STG_XSB_P(KP_)                                                                                                            \
+    do {                                                                                                                          \
+        if (passes <= 8) STG_XSB(KP_, 8);                                                                                         \
+        else if (passes <= 24) STG_XSB(KP_, 24);                                                                                  \
+        else STG_XSB(KP_, kSmallBwdPasses);                                                                                       \
+    } while (0)
+    switch (kp) {
+        case 4: STG_XSB_P(4); break;
+        case 8: STG_XSB_P(8); break;
+        case 16: STG_XSB_P(16); break;
+        case 32: STG_XSB_P(32); break;
+        default: STG_XSB_P(64); break;
+    }
+#undef STG_XSB_P
+#undef STG_XSB
+    return check_launch("stg_xent_small_bwd");
 }

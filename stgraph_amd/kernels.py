@@ -2166,6 +2166,52 @@ def xent_fwd_grad(logits: torch.Tensor, labels: torch.Tensor, rows: int | None =
     return loss, lse, n_counted, status, d, cs
 
 
+def xent_small_usable(logits: torch.Tensor) -> bool:
+    """A logits matrix one workgroup walks in a few passes (Cora's 2708 x 7): loss and gradient as ONE launch each way."""
+    return (_XENT_SMALL and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.is_contiguous()
+            and bool(_C.lib.stg_xent_small_supported(int(logits.shape[0]), int(logits.shape[1]))))
+
+
+_XENT_SMALL = True
+
+
+def set_xent_small(on: bool) -> None:
+    """False: small logits matrices take the general launches too (tests; the A / B of tools/diag/cora_kernels.py)."""
+    global _XENT_SMALL
+    _XENT_SMALL = bool(on)
+
+
+def xent_small_fwd(logits: torch.Tensor, labels: torch.Tensor, rows: int | None = None):
+    """:func:`xent_fwd` for a small matrix (stg_xent_small_fwd: one launch, no workspace).  Returns (loss, lse, n_counted, status)."""
+    n_total, K = logits.shape
+    n = n_total if rows is None else int(rows)
+    dev = logits.device
+    if not labels.is_cuda or labels.device != dev:
+        raise ValueError(f"xent_small_fwd: labels on {labels.device}, logits on {dev}")
+    lse = torch.empty(n, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    n_counted = torch.empty(1, dtype=torch.float32, device=dev)
+    status = _XENT_STATUS.get(dev)
+    if status is None:
+        status = _XENT_STATUS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev), _Timed("xent_small_fwd", 4 * n * (K + 1) + 8 * n, 4 * n * K):
+        _C.check(_C.lib.stg_xent_small_fwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(loss), _ptr(n_counted), _ptr(status), n, K,
+                                           _stream_ptr(dev)))
+    return loss, lse, n_counted, status
+
+
+def xent_small_bwd(g_loss: torch.Tensor, logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor, n_counted: torch.Tensor):
+    """(gradient of the whole logits matrix, its column sums) from one launch (stg_xent_small_bwd); shapes of :func:`xent_small_usable`."""
+    n_total, K = logits.shape
+    n = int(lse.shape[0])
+    d = torch.empty_like(logits)
+    cs = torch.empty(K, dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device), _Timed("xent_small_bwd", 4 * n * K + 4 * n_total * K + 12 * n, 4 * n * K):
+        _C.check(_C.lib.stg_xent_small_bwd(_ptr(g_loss), _ptr(logits), _ptr(labels), _ptr(lse), _ptr(n_counted), _ptr(d), _ptr(cs),
+                                           n, n_total, K, _stream_ptr(logits.device)))
+    return d, cs
+
+
 def xent_scale_grad(d: torch.Tensor, colsum: torch.Tensor | None, g_loss: torch.Tensor) -> None:
     """``d *= g_loss`` (and ``colsum``) in place; a launch that returns at once when ``g_loss`` is exactly 1."""
     n_total, K = d.shape
@@ -2342,6 +2388,7 @@ _KNOBS = (
     ("step_wgrad_from_p", "stgraph_amd.kernels", "STEP_WGRAD_FROM_P", True, "STGRAPH_AMD_STEP_WGRAD_FROM_P", "TGCN weight gradients from P (no x3 / da3 stored)"),
     ("step_wgrad_zr_together", "stgraph_amd.kernels", "STEP_WGRAD_ZR_TOGETHER", True, "STGRAPH_AMD_STEP_WGRAD_ZR_TOGETHER", "[d_z | d_r] contracted as one operand"),
     ("xent_one_pass", "stgraph_amd.kernels", "_XENT_ONE_PASS", True, "STGRAPH_AMD_XENT_ONE_PASS", "cross-entropy loss and its gradient in one pass"),
+    ("xent_small", "stgraph_amd.kernels", "_XENT_SMALL", True, None, "cross-entropy of a small logits matrix (one workgroup holds it in registers; K <= 64) as one launch each way"),
     ("native_weight_grad", "stgraph_amd.nn.functional", "_NATIVE_WGRAD", True, None, "tall-skinny weight gradients on the split-K kernels instead of rocBLAS"),
     ("deferred_weight_grads", "stgraph_amd.nn.functional", "_DEFER", True, None, "weight gradients of a window contracted once, at the end of the backward pass"),
     ("input_layer_reorder", "stgraph_amd.nn.functional", "_INPUT_LAYER", True, None, "a GCNConv whose input needs no gradient aggregates first"),

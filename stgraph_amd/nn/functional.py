@@ -239,7 +239,11 @@ class _CrossEntropy(torch.autograd.Function):
         logits = logits.contiguous()
         labels = labels.contiguous()
         ctx.d = ctx.colsum = None
-        if ctx.needs_input_grad[0] and kernels.xent_fwd_grad_usable(logits):
+        ctx.small = kernels.xent_small_usable(logits)
+        if ctx.small:
+            # a matrix one workgroup covers (Cora): one launch each way instead of five -- launch count is what a small graph's epoch costs
+            loss, lse, n_counted, _ = kernels.xent_small_fwd(logits, labels, rows)
+        elif ctx.needs_input_grad[0] and kernels.xent_fwd_grad_usable(logits):
             # the loss is going to be differentiated: the gradient for an upstream gradient of 1 from the same pass over the logits
             loss, lse, n_counted, _, ctx.d, ctx.colsum = kernels.xent_fwd_grad(logits, labels, rows)
         else:
@@ -250,7 +254,9 @@ class _CrossEntropy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         logits, labels, lse, n_counted = ctx.saved_tensors
-        if ctx.d is not None:
+        if ctx.small:
+            d, colsum = kernels.xent_small_bwd(g.contiguous().float(), logits, labels, lse, n_counted)
+        elif ctx.d is not None:
             d, colsum = ctx.d, ctx.colsum
             ctx.d = ctx.colsum = None                    # scaled in place below: a second backward takes the two-pass form
             kernels.xent_scale_grad(d, colsum, g.contiguous().float())

@@ -253,3 +253,83 @@ def test_one_pass_loss_backward_twice_and_switched_off(cuda):
             kernels.enable_launch_timing(None)
             kernels.set_xent_one_pass(True)
     assert float((grads[0] - grads[1]).abs().max()) <= 2e-6 * float(grads[1].abs().max())
+
+
+@pytest.mark.parametrize("n_total,n,K", [(2708, 1624, 7), (1, 1, 1), (500, 500, 64), (8192, 5000, 4), (5, 3, 33), (2000, 1, 13)])
+def test_small_matrix_one_launch_each_way(cuda, n_total, n, K):
+    """stg_xent_small_fwd / _bwd (a matrix one workgroup covers: Cora's 2708 x 7) against the general launches on the same inputs:
+    lse, loss, gradient and column sums to fp32 rounding (another order of the same
+    additions), the tail rows zero, ignore_index rows out of everything, a bad label in the status word; run twice: identical."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(n_total + K)
+    logits = torch.randn(n_total, K, device=cuda, generator=gen) * 3
+    labels = torch.randint(0, K, (n_total,), device=cuda, generator=gen)
+    if n > 4:
+        labels[::5] = -100
+    assert kernels.xent_small_usable(logits)
+    loss, lse, cnt, status = kernels.xent_small_fwd(logits, labels, n)
+    loss_g, lse_g, cnt_g, _ = kernels.xent_fwd(logits, labels, n)
+    assert int(status.item()) == 0 and float(cnt) == float(cnt_g)
+    torch.testing.assert_close(lse, lse_g, rtol=1e-6, atol=2e-6)
+    torch.testing.assert_close(loss, loss_g, rtol=1e-5, atol=1e-7)
+    g = torch.tensor([0.7], device=cuda)
+    d, cs = kernels.xent_small_bwd(g, logits, labels, lse, cnt)
+    want = kernels.xent_bwd(g, logits, labels, lse, cnt)
+    torch.testing.assert_close(d, want, rtol=1e-6, atol=1e-9)
+    assert not d[n:].any()
+    ref = want.double().sum(0)
+    assert ((cs.double() - ref).abs() <= 1e-5 * want.double().abs().sum(0) + 1e-12).all()
+    d2, cs2 = kernels.xent_small_bwd(g, logits, labels, lse, cnt)
+    loss2, *_ = kernels.xent_small_fwd(logits, labels, n)
+    assert torch.equal(d, d2) and torch.equal(cs, cs2) and torch.equal(loss, loss2)
+    if K > 1:
+        labels[0] = K                                   # neither a class nor ignore_index
+        *_, status = kernels.xent_small_fwd(logits, labels, n)
+        assert int(status.item()) != 0
+        with pytest.raises(kernels._C.StgError):
+            kernels.check_xent_status(cuda)
+
+
+def test_small_matrix_path_is_taken_by_the_loss_and_can_be_switched_off(cuda):
+    from stgraph_amd import kernels
+    from stgraph_amd.nn import functional as SF
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    base = torch.randn(2708, 7, device=cuda, generator=gen)
+    labels = torch.randint(0, 7, (2708,), device=cuda, generator=gen)
+    out = []
+    for on in (True, False):
+        kernels.set_xent_small(on)
+        try:
+            recs = []
+            kernels.enable_launch_timing(recs)
+            x = base.clone().requires_grad_(True)
+            (SF.cross_entropy(x, labels, 1624) * 1.3).backward()
+            kernels.enable_launch_timing(None)
+            names = [r[0] for r in recs]
+            assert (names == ["xent_small_fwd", "xent_small_bwd"]) == on, names
+            out.append(x.grad)
+        finally:
+            kernels.enable_launch_timing(None)
+            kernels.set_xent_small(True)
+    torch.testing.assert_close(out[0], out[1], rtol=1e-5, atol=1e-9)
+    big = torch.randn(70_000, 7, device=cuda)
+    assert not kernels.xent_small_usable(big) and not kernels.xent_small_usable(torch.randn(10, 65, device=cuda))
+    with pytest.raises(kernels._C.StgError):
+        kernels.xent_small_fwd(big, torch.zeros(70_000, dtype=torch.int64, device=cuda))
+
+
+@pytest.mark.parametrize("N,F,mask", [(2708, 16, True), (2708, 7, False), (100, 33, True), (4096, 16, True), (1, 4, False)])
+def test_bias_act_bwd_of_a_small_matrix_finishes_its_column_sums_itself(cuda, N, F, mask):
+    """stg_bias_act_bwd with N F <= 65536: one workgroup, the column sums written by the same launch (no finish launch): masked
+    gradient bit for bit, column sums against a 64-bit sum."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(N + F)
+    g = torch.randn(N, F, device=cuda, generator=gen)
+    out = torch.randn(N, F, device=cuda, generator=gen) if mask else None
+    g_act, cs = kernels.bias_act_bwd(g, out, want_colsum=True)
+    want = g * (out > 0) if mask else g
+    assert torch.equal(g_act, want)
+    ref = want.double().sum(0)
+    assert ((cs.double() - ref).abs() <= 1e-5 * want.double().abs().sum(0) + 1e-12).all()
+    _, cs2 = kernels.bias_act_bwd(g, out, want_colsum=True)
+    assert torch.equal(cs, cs2)
