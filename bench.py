@@ -750,7 +750,7 @@ class GAT(nn.Module):
 # as 3-term bf16 splits on the bf16 instruction since rounds 4 / 5 and are bound by their operand streams: priced on bytes.
 TGCN_DENSE = ("tgcn_step_fwd", "tgcn_step_bwd")
 AGG_LAUNCHES = ("gcn_agg", "gcn_agg_transform", "gat_k1", "gat_k1_uniform", "gat_bwd", "gat_bwd_uniform")
-GAT_DENSE = ("gat_fc", "gat_fc_out", "gat_bwd_gw")
+GAT_DENSE = ("gat_bwd_gw",)            # (gat_fc / gat_fc_out run in the bf16 split form since round 5: bound by their stores)
 
 
 def executed_edges_feat(records):

@@ -42,7 +42,8 @@ extern "C" {
  *      fold_bound (the folded launch runs on the fp32 matrix instruction only).
  *  27: stg_xent_small_supported / _fwd / _bwd: softmax cross-entropy of a SMALL logits matrix as one launch each way (the graph of
  *      a captured Cora epoch is launch-count bound); stg_bias_act_bwd finishes the column sums in its own launch when one
- *      workgroup covers the matrix (no signature change). */
+ *      workgroup covers the matrix (no signature change); stg_gat_bwd_prepass_heads(_supported); stg_gat_fc_fwd / stg_gat_fc_out take the
+ *      3-term bf16 split form at H % 4 == 0 heads of 64 over 64 inputs (results equal to fp32 rounding). */
 #define STG_ABI_VERSION 27
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -495,6 +496,14 @@ int stg_gat_bwd_factored(const float *A, const float *S, const float *out, const
 int stg_gat_bwd_uniform_supported(int32_t H, int32_t D, int32_t fin);
 int stg_gat_bwd_prepass(const float *S, const float *out, const float *g, float *g_pre, float *pack, int32_t N, int32_t H,
                         int32_t D, float slope, float *grad_er, void *stream);
+/* The first two steps above as ONE pass over g and out (H % 4 == 0 heads of D = 64 over fin = 64, N H D < 2^29; knob "rowgemm_x3" not
+ * 1 or 3: stg_gat_bwd_prepass_heads_supported): g_pre, pack and grad_er as stg_gat_bwd_prepass (equal to fp32 rounding: the
+ * per-head dot products add the same terms in another order), and gW [H][N][fin] = g_pre[:, h, :] W_h in the 3-term bf16 split
+ * form of stg_rowgemm_heads_f32, four heads per launch.  out, g, g_pre, W, gW 16-byte aligned; g_pre == NULL: g is already the
+ * gradient of `out`. */
+int stg_gat_bwd_prepass_heads_supported(int64_t N, int32_t H, int32_t D, int32_t fin);
+int stg_gat_bwd_prepass_heads(const float *S, const float *out, const float *g, float *g_pre, float *pack, float *grad_er,
+                              const float *W, float *gW, int64_t N, int32_t H, int32_t D, int32_t fin, float slope, void *stream);
 int stg_gat_bwd_uniform_edges(const float *A, const float *pack, const float *gq, const float *feat, const float *x,
                               const float *gW, float *T, float *gsW, float *grad_feat, float *grad_el, float *gxa,
                               const int32_t *fwd_row_offsets, const int32_t *fwd_column_indices, const int32_t *fwd_eids,

@@ -129,6 +129,13 @@ int fc_launch(const char *what, bool proj, const float *x, const float *W, const
     if ((int64_t)N * H * D > 0x7fffffffll * 4)
         return fail(STG_ERR_UNSUPPORTED, "%s: N * H * D too large", what);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        // the split form on the bf16 matrix cores (gat_heads_x3.hip): bound by its stores, not by 512 fp32 matrix instructions per tile
+        const uintptr_t align = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(feat) |
+                                reinterpret_cast<uintptr_t>(act_out);
+        if (!only_if && align % 16 == 0 && gat_heads_x3_wanted(N, H, D, fin))
+            return gat_heads_fc_x3_launch(what, x, W, attn_l, attn_r, feat, act_out, proj ? el : nullptr, proj ? er : nullptr, N, H, stream);
+    }
     const size_t lds = fc_lds_bytes(fin, H);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;

@@ -59,6 +59,10 @@ int rowgemm_x3_launch(int K, int M, const float *X, const float *W, const float 
 // the same with the ReLU sign pattern as bits (layout: rowgemm_x3.hip): bits_out with the ReLU forward (W [K][M]), bits_in with the
 // input gradient of the layer above (W [M][K]); Y contiguous [N, M]
 int rowgemm_x3_heads_launch(int K, int M, const float *X, const float *W, float *Y, int64_t N, int heads, void *stream);
+// gat_heads_x3.hip: a GAT layer's per-head products (H % 4 == 0 heads of D = 64 over fin = 64) in the split form, four heads per launch
+bool gat_heads_x3_wanted(int64_t N, int H, int D, int fin);
+int gat_heads_fc_x3_launch(const char *what, const float *x, const float *W, const float *attn_l, const float *attn_r, float *out, float *act,
+                           float *el, float *er, int64_t N, int H, void *stream);
 int rowgemm_x3_bits_launch(int K, int M, const float *X, const float *W, const float *bias, float *Y, int64_t N, const uint32_t *bits_in,
                            uint32_t *bits_out, void *stream);
 Tuning &tuning();

@@ -1204,17 +1204,26 @@ def gat_bwd_uniform(A, S, out, g, x, W, feat, fwd: DeviceCSR, bwd: DeviceCSR, sl
     idx = 4 * (N + 1) + 8 * E
     with torch.cuda.device(dev):
         st = _stream_ptr(dev)
-        with _Timed("gat_bwd_prepass", 4 * N * H * D * (3 if elu else 2) + 4 * N * 16 + 8 * N * H, 4 * N * H * D):
-            _C.check(_C.lib.stg_gat_bwd_prepass(_ptr(S), _ptr(out), _ptr(g), _ptr(g_pre), _ptr(pack), N, H, D, float(slope),
-                                                _ptr(grad_er), st))
         gq = g_pre if elu else g
-        with _Timed("gat_bwd_gw", 4 * N * H * (D + fin) + 4 * H * D * fin, 2 * N * H * D * fin):
-            # [H, N, fin]: gW[h, v] = W_h^T g[v, h, :]
-            if N >= ROWGEMM16_MIN_ROWS and _C.lib.stg_rowgemm_heads_supported(N, D, fin, H) and gq.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0:
-                gW = new(H, N, fin)
-                _C.check(_C.lib.stg_rowgemm_heads_f32(_ptr(gq), _ptr(W), _ptr(gW), N, D, fin, H, st))
-            else:
-                gW = torch.bmm(gq.view(N, H, D).transpose(0, 1), W.view(H, D, fin))
+        aligned = all(t is None or t.data_ptr() % 16 == 0 for t in (out, g, g_pre, W))
+        if _GAT_PREPASS_HEADS and N >= ROWGEMM16_MIN_ROWS and aligned and _C.lib.stg_gat_bwd_prepass_heads_supported(N, H, D, fin):
+            # the per-vertex pass and gW [H, N, fin] (gW[h, v] = W_h^T g_pre[v, h, :]) from ONE read of g and out (csrc/gat_heads_x3.hip)
+            gW = new(H, N, fin)
+            with _Timed("gat_bwd_prepass_heads", 4 * N * H * D * (3 if elu else 2) + 4 * N * 16 + 8 * N * H + 4 * N * H * fin + 4 * H * D * fin,
+                        2 * N * H * D * fin):
+                _C.check(_C.lib.stg_gat_bwd_prepass_heads(_ptr(S), _ptr(out), _ptr(g), _ptr(g_pre), _ptr(pack), _ptr(grad_er), _ptr(W),
+                                                          _ptr(gW), N, H, D, fin, float(slope), st))
+        else:
+            with _Timed("gat_bwd_prepass", 4 * N * H * D * (3 if elu else 2) + 4 * N * 16 + 8 * N * H, 4 * N * H * D):
+                _C.check(_C.lib.stg_gat_bwd_prepass(_ptr(S), _ptr(out), _ptr(g), _ptr(g_pre), _ptr(pack), N, H, D, float(slope),
+                                                    _ptr(grad_er), st))
+            with _Timed("gat_bwd_gw", 4 * N * H * (D + fin) + 4 * H * D * fin, 2 * N * H * D * fin):
+                # [H, N, fin]: gW[h, v] = W_h^T g[v, h, :]
+                if N >= ROWGEMM16_MIN_ROWS and _C.lib.stg_rowgemm_heads_supported(N, D, fin, H) and gq.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0:
+                    gW = new(H, N, fin)
+                    _C.check(_C.lib.stg_rowgemm_heads_f32(_ptr(gq), _ptr(W), _ptr(gW), N, D, fin, H, st))
+                else:
+                    gW = torch.bmm(gq.view(N, H, D).transpose(0, 1), W.view(H, D, fin))
         moved = (4 * N * H * fin + 4 * E * fin + 4 * E * H + 4 * N * fin + 4 * N * 16 + idx            # targets: gW, x[u], T, gsW, pack
                  + 4 * E * H + 4 * E * fin + 4 * N * (fin + H) + idx)                                   # sources: T, gsW[v], grad_el, gxa
         with _Timed("gat_bwd_uniform", moved, E * (2 * fin + H)):      # units: executed gather = x[u] (fin) + gsW[v] (fin) + T[e] (H)
@@ -1224,6 +1233,16 @@ def gat_bwd_uniform(A, S, out, g, x, W, feat, fwd: DeviceCSR, bwd: DeviceCSR, sl
                 _ptr(fwd.node_ids_if_ready if use_node_ids else None), _ptr(bwd.row_offset), _ptr(bwd.column_indices),
                 _ptr(bwd.eids), _ptr(bwd.node_ids_if_ready if use_node_ids else None), N, float(slope), _ptr(flag), st))
     return gxa, grad_el, grad_er, gq, grad_feat, flag, xm
+
+
+_GAT_PREPASS_HEADS = True
+
+
+def set_gat_prepass_heads(on: bool) -> None:
+    """False: the uniform-attention backward runs its per-vertex pass and the per-head products g_pre W_h as separate launches
+    (rounds 3-4) instead of stg_gat_bwd_prepass_heads."""
+    global _GAT_PREPASS_HEADS
+    _GAT_PREPASS_HEADS = bool(on)
 
 
 def gat_bwd_uniform_gx_fallback(grad_feat: torch.Tensor, W: torch.Tensor, gx: torch.Tensor, flag: torch.Tensor) -> None:
@@ -2381,6 +2400,7 @@ _KNOBS = (
     ("gat_uniform_backward", "stgraph_amd.kernels", "_GAT_UNIFORM_BWD", True, "STGRAPH_AMD_GAT_UNIFORM_BWD", "GAT K2 at the input width, likewise"),
     ("gat_factored_backward", "stgraph_amd.kernels", "_GAT_FACTORED", True, None, "GAT K2 with one E x H x D gather instead of the emitted unit's two"),
     ("gat_regrouped_er", "stgraph_amd.kernels", "_GAT_REGROUPED_ER", True, None, "grad_er summed per target without atomics"),
+    ("gat_prepass_heads", "stgraph_amd.kernels", "_GAT_PREPASS_HEADS", True, None, "uniform GAT backward: per-vertex pass and the per-head products g W_h in one pass over g and out"),
     ("native_rowgemm", "stgraph_amd.kernels", "_ROWGEMM", False, "STGRAPH_AMD_ROWGEMM", "round-3 fp32 row-product kernel for every tall product (off: only the 16-row form below)"),
     ("rowgemm16", "stgraph_amd.kernels", "_ROWGEMM16", True, "STGRAPH_AMD_ROWGEMM16", "tall row products at K, M in {64, 128} on the native kernels (bf16 split from 64 K rows)"),
     ("relu_bits", "stgraph_amd.kernels", "_RELU_BITS", True, "STGRAPH_AMD_RELU_BITS", "ReLU sign pattern as bits; the layer above masks its input gradient in the launch that forms it"),

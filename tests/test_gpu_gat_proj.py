@@ -361,7 +361,7 @@ def test_uniform_launches_at_the_full_cfg3_shape(cuda):
             kernels.set_gat_uniform_backward(True)
         names = {r[0] for r in rec}
         if form == "uniform":
-            assert {"gat_k1_uniform", "gat_fc_out", "gat_bwd_prepass", "gat_bwd_gw", "gat_bwd_uniform"} <= names, sorted(names)
+            assert {"gat_k1_uniform", "gat_fc_out", "gat_bwd_prepass_heads", "gat_bwd_uniform"} <= names, sorted(names)
             assert "gat_k1" not in names and "gat_bwd" not in names, sorted(names)
         else:
             assert {"gat_k1", "gat_bwd"} <= names and "gat_k1_uniform" not in names and "gat_bwd_uniform" not in names, sorted(names)
@@ -386,3 +386,74 @@ def test_uniform_launches_at_the_full_cfg3_shape(cuda):
     assert float((gu[4] - gg[4]).abs().max()) <= 1e-4 * float(gg[3].abs().max())
     for t in gu:
         assert bool(torch.isfinite(t).all())
+
+
+@pytest.mark.parametrize("N", [1, 31, 4099, 70_001])
+def test_heads_products_in_the_split_form(cuda, N):
+    """csrc/gat_heads_x3.hip at 8 heads of 64 over 64 inputs: stg_gat_fc_fwd (feat, el, er), stg_gat_fc_out (out, elu(out)) against fp64
+    -- error no worse than the fp32-instruction kernels' (knob rowgemm_x3 = 1) -- and against those kernels to fp32 rounding."""
+    import torch.nn.functional as F
+    from stgraph_amd import _C, kernels
+    fin, H, D = 64, 8, 64
+    gen = torch.Generator(device=cuda).manual_seed(N)
+    x = torch.randn(N, fin, device=cuda, generator=gen)
+    W = torch.randn(H * D, fin, device=cuda, generator=gen) / 8
+    al, ar = torch.randn(H, D, device=cuda, generator=gen), torch.randn(H, D, device=cuda, generator=gen)
+    res = {}
+    for knob in (0, 1):
+        _C.set_tuning("rowgemm_x3", knob)
+        try:
+            feat, el, er = kernels.gat_fc_fwd(x, W, al, ar, H, D)
+            _, el2, er2 = kernels.gat_fc_fwd(x, W, al, ar, H, D, store_feat=False)
+            out = torch.empty(N, H, D, device=cuda)
+            act = torch.empty(N, H, D, device=cuda)
+            _C.check(_C.lib.stg_gat_fc_out(kernels._ptr(x), kernels._ptr(W), kernels._ptr(out), kernels._ptr(act), N, fin, H, D,
+                                           kernels._stream_ptr(cuda)))
+            assert torch.equal(el, el2) and torch.equal(er, er2)
+            res[knob] = (feat, el, er, out, act)
+        finally:
+            _C.set_tuning("rowgemm_x3", 0)
+    ref = (x.double() @ W.double().t()).view(N, H, D)
+    refs = (ref, (ref * al.double()).sum(-1, keepdim=True), (ref * ar.double()).sum(-1, keepdim=True), ref, F.elu(ref))
+    for i, name in enumerate(("feat", "el", "er", "out", "elu(out)")):
+        scale = float(refs[i].abs().max()) + 1e-30
+        e_new = float((res[0][i].double() - refs[i]).abs().max()) / scale
+        e_old = float((res[1][i].double() - refs[i]).abs().max()) / scale
+        assert e_new <= max(2 * e_old, 2e-6), (name, e_new, e_old)
+        torch.testing.assert_close(res[0][i], res[1][i], rtol=1e-5, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("elu", [True, False])
+@pytest.mark.parametrize("N", [65536 + 17, 70_003])
+def test_prepass_and_heads_products_in_one_pass(cuda, N, elu):
+    """stg_gat_bwd_prepass_heads against stg_gat_bwd_prepass + stg_rowgemm_heads_f32 on the same inputs: g_pre and gW bit for bit (the
+    same formula per element; the same split product), pack and grad_er to fp32 rounding (the per-head dot products add the same
+    terms in another order); a vertex without an in-edge (S = 0) gets grad_er = 0 in both."""
+    from stgraph_amd import _C, kernels
+    fin, H, D = 64, 8, 64
+    gen = torch.Generator(device=cuda).manual_seed(N + elu)
+    S = torch.rand(N, H, 1, device=cuda, generator=gen) * 5 + 0.5
+    S[7] = 0.0
+    out = torch.randn(N, H, D, device=cuda, generator=gen)
+    g = torch.randn(N, H, D, device=cuda, generator=gen)
+    W = torch.randn(H * D, fin, device=cuda, generator=gen) / 8
+    st = kernels._stream_ptr(cuda)
+    P = kernels._ptr
+    new = lambda *s: torch.full(s, float("nan"), device=cuda)  # noqa: E731
+    gp0, pack0, ger0 = (new(N, H, D) if elu else None), new(N, 16), new(N, H, 1)
+    _C.check(_C.lib.stg_gat_bwd_prepass(P(S), P(out), P(g), P(gp0), P(pack0), N, H, D, 0.2, P(ger0), st))
+    gW0 = new(H, N, fin)
+    _C.check(_C.lib.stg_rowgemm_heads_f32(P(gp0 if elu else g), P(W), P(gW0), N, D, fin, H, st))
+    assert _C.lib.stg_gat_bwd_prepass_heads_supported(N, H, D, fin)
+    gp1, pack1, ger1, gW1 = (new(N, H, D) if elu else None), new(N, 16), new(N, H, 1), new(H, N, fin)
+    _C.check(_C.lib.stg_gat_bwd_prepass_heads(P(S), P(out), P(g), P(gp1), P(pack1), P(ger1), P(W), P(gW1), N, H, D, fin, 0.2, st))
+    if elu:
+        assert torch.equal(gp0, gp1)
+    assert torch.equal(gW0, gW1)
+    assert torch.equal(pack0[:, :8], pack1[:, :8])
+    keep = torch.ones(N, dtype=torch.bool, device=cuda)
+    keep[7] = False                                    # S = 0: the P term is inf / nan in both
+    torch.testing.assert_close(pack1[keep, 8:], pack0[keep, 8:], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(ger1[keep], ger0[keep], rtol=1e-5, atol=1e-4)
+    assert not ger1[7].any() and not ger0[7].any()
+    assert not _C.lib.stg_gat_bwd_prepass_heads_supported(N, 6, D, fin) and not _C.lib.stg_gat_bwd_prepass_heads_supported(N, H, 32, fin)
