@@ -240,6 +240,12 @@ __global__ __launch_bounds__(kHxWaves *kWave, 1) void gat_heads_fc_x3_kernel(con
     }
 }
 
+// 1: P = sum_d (g_pre / S) out with a division per element, as gat_bwd_prepass_h8d64_kernel forms it; 0: (g_pre . out) / S -- equal to
+// fp32 rounding, 31 divisions per lane and head fewer
+#ifndef STG_HX_DIV_PER_ELEMENT
+#define STG_HX_DIV_PER_ELEMENT 0
+#endif
+
 struct HeadsBwdArgs {
     const float *g, *outp, *S, *W;
     float *g_pre, *pack, *grad_er, *gW;
@@ -314,11 +320,13 @@ __global__ __launch_bounds__(kHxWaves *kWave, 1) void gat_heads_bwd_x3_kernel(co
                             *reinterpret_cast<float4 *>(a.g_pre + e) = gv;
                             G[b][t][j] = gv;
                         }
+#if STG_HX_DIV_PER_ELEMENT
                         const float sh = sv[t][j];
                         p[t][j] = p[t][j] + (gv.x / sh) * ov.x;
                         p[t][j] = p[t][j] + (gv.y / sh) * ov.y;
                         p[t][j] = p[t][j] + (gv.z / sh) * ov.z;
                         p[t][j] = p[t][j] + (gv.w / sh) * ov.w;
+#endif
                         q[t][j] = q[t][j] + gv.x * ov.x;
                         q[t][j] = q[t][j] + gv.y * ov.y;
                         q[t][j] = q[t][j] + gv.z * ov.z;
@@ -341,6 +349,9 @@ __global__ __launch_bounds__(kHxWaves *kWave, 1) void gat_heads_bwd_x3_kernel(co
                     if (lane < 8) {                                              // upper = 0, kq = 0: r8 = lane
                         const int64_t row = j == 0 ? ra : rb;
                         const float sh = sv[t][j];
+#if !STG_HX_DIV_PER_ELEMENT
+                        pv = qv / sh;                                            // sum_d (g / S) out = (g . out) / S: ONE division per (vertex, head)
+#endif
                         a.pack[row * 16 + h] = sh;
                         a.pack[row * 16 + 8 + h] = pv;
                         if (a.grad_er) a.grad_er[row * a.H + h] = sh == 0.f ? 0.f : a.slope * (qv - pv * sh);   // S = 0: no in-edge
