@@ -1187,9 +1187,9 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
                 progress(f"cfg5 T={T}: {mode}")
             if mode == "resident_snapshots":         # NaiveGraph as the reference defines it: all 2T CSRs built up front
                 G = NaiveGraph(snaps, n, device=device, sort_inplace=False)
-            elif mode in ("rebuild_per_snapshot", "rebuild_inline"):
-                # rebuild_inline: the window's builds at the head of its training graph (rounds 3-4) instead of a graph of their own
-                # replayed one window ahead on a second stream (CapturedDynamicWindows.prefetch_builds)
+            elif mode in ("rebuild_per_snapshot", "rebuild_prefetch"):
+                # rebuild_prefetch: the window's builds as a graph of their own, replayed one window ahead on a second stream
+                # (CapturedDynamicWindows.prefetch_builds; an option) instead of at the head of the window's training graph
                 G = NaiveGraph(snaps, n, device=device, sort_inplace=False, resident=False, max_cached=B + 1)
             else:
                 G = (PCSRGraph if mode == "pcsr_store" else GPMAGraph)(snaps, n, device=device)
@@ -1204,14 +1204,14 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
 
             def epoch(ep):
                 nonlocal cd
-                if mode in ("rebuild_per_snapshot", "rebuild_inline"):
+                if mode in ("rebuild_per_snapshot", "rebuild_prefetch"):
                     G._snapshots.clear()                 # every epoch rebuilds every snapshot it touches
                 G._ndata.clear()
                 if ep >= 1:
                     if cd is None:
                         cd = temporal.CapturedDynamicWindows(model, G, pn_edges, pn_targets, B, opt, bucket, feat, world=world,
                                                              rank=rank)
-                        cd.prefetch_builds = mode != "rebuild_inline"
+                        cd.prefetch_builds = mode == "rebuild_prefetch"
                     temporal.train_epoch_dynamic_captured(cd, epoch=ep)
                 else:
                     temporal.train_epoch_dynamic(model, G, pn_edges, pn_targets, B, opt, bucket, feat, epoch=ep, rank=rank,
@@ -1245,7 +1245,7 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
             torch.cuda.empty_cache()
         return out
 
-    all_modes = ("resident_snapshots", "rebuild_per_snapshot", "rebuild_inline", "pcsr_store", "gpma_store")
+    all_modes = ("resident_snapshots", "rebuild_per_snapshot", "rebuild_prefetch", "pcsr_store", "gpma_store")
     if only_modes:                                               # (profiling runs: tools/diag/dyn_only.py)
         return run_modes(T, tuple(only_modes), epochs)
     if T == 40:
@@ -1288,11 +1288,10 @@ def dynamic_run(device, rank, world, epochs, n=25_000, e0=250_000, churn=6_250, 
                         "T = 160 instead of BASELINE.md's 40: 40 snapshots are 2 windows of 20, which 8 ranks cannot share"),
            "csr_build_share": 1.0 - out["resident_snapshots"]["seconds_per_epoch"] / out["rebuild_per_snapshot"]["seconds_per_epoch"],
            "csr_build_share_is": "1 - seconds_per_epoch(resident_snapshots) / seconds_per_epoch(rebuild_per_snapshot): what the "
-                                 "per-snapshot builds (and the per-edge coefficient gathers that follow a new CSR) ADD to the epoch. "
-                                 "The builds of a window run as a HIP graph of their own on a second stream, one window ahead of the "
-                                 "training graph that reads them (every snapshot is still built once per epoch); _inline = the same "
-                                 "builds at the head of the window's training graph",
-           "csr_build_share_inline": 1.0 - out["resident_snapshots"]["seconds_per_epoch"] / out["rebuild_inline"]["seconds_per_epoch"],
+                                 "per-snapshot builds (and the per-edge coefficient gathers that follow a new CSR) add to the epoch; "
+                                 "_prefetch = the same builds as a HIP graph of their own on a second stream, one window ahead of the "
+                                 "training graph that reads them (an option: the step launches slow down beside them)",
+           "csr_build_share_prefetch": 1.0 - out["resident_snapshots"]["seconds_per_epoch"] / out["rebuild_prefetch"]["seconds_per_epoch"],
            "scaling": "strong", "cpu_baseline": cpu,
            "n_gpus": world, "epochs": epochs, "windows_per_epoch": temporal.num_windows(T, B), "roofline": roofline,
            **out}

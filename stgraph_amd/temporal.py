@@ -1117,11 +1117,15 @@ class CapturedDynamicWindows:
         # rebuild mode: the window's snapshots as ONE batched build (stg_graph_build_direct2_batch_device)
         self.batched_builds = True
         self.deferred_emission = True
-        # rebuild mode: a window's snapshot builds as a HIP graph of their own, replayed on a SECOND STREAM one window ahead of the
-        # training graph that reads them.  The builds read the edge lists only, so the builds of this rank's next window (the
-        # first window of the next epoch after the last) run beside the current window's step launches, which leave most of the
-        # chip idle at |V| = 25 K; every snapshot is still built once per epoch.  A rank with ONE window has nothing to run ahead of.
-        self.prefetch_builds = True
+        # rebuild mode, OPTION (off): a window's snapshot builds as a HIP graph of their own, replayed on a SECOND STREAM one window
+        # ahead of the training graph that reads them.  The builds read the edge lists only, so the builds of this rank's next window
+        # (the first window of the next epoch after the last) run beside the current window's step launches; every snapshot is
+        # still built once per epoch.  Bit-identical results (tests/test_gpu_window.py).  MEASURED at cfg5 (round 5): 80 % of the
+        # builds' device time does run beside another launch (profiles/r05_dyn_build_overlap.json), but a step launch wants every
+        # register of a CU for its workgroup and waits for whatever build waves sit there -- forward step launches beside a build take
+        # 55 us against 24 alone, whatever the build stream's priority -- so the epoch gains between -1.5 and +2.5 %
+        # (bench.py, dynamic.rebuild_prefetch): not a default.
+        self.prefetch_builds = False
         self.build_stream_low_priority = True
         self._build_graphs, self._built, self._build_done, self._train_done, self._build_pending = {}, {}, {}, {}, {}
         self._build_stream = None
