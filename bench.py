@@ -679,7 +679,7 @@ def kernels_bytes(n, e, f, ew=False):
     return kernels.gcn_agg_algorithmic_bytes(n, e, f, ew)
 
 
-def cora_roofline(device, src, dst, n, K=1024, iters=10):
+def cora_roofline(device, src, dst, n, K=1024, iters=40):
     """SURVEY.md 8(d) "Cora x K": K disjoint replicas of the Cora-shaped graph (block diagonal, |V| = 2.77M,
     |E| = 10.8M), so that the aggregation at the layer widths of the Cora model (16, 7) is bandwidth- instead of
     launch-bound.  Forward + backward launch per width, HIP events, algorithmic bytes of SURVEY.md 8(d)."""
@@ -697,7 +697,7 @@ def cora_roofline(device, src, dst, n, K=1024, iters=10):
         nbytes = kernels.gcn_agg_algorithmic_bytes(N, E, F_, False)
         ms = []
         for csr in (g.fwd, g.bwd):
-            for _ in range(2):
+            for _ in range(5):
                 kernels.gcn_agg(x, norm, norm, csr)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
