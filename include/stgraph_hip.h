@@ -189,6 +189,10 @@ typedef struct stg_build_job {
     int32_t *zero_counters;
     void *workspace;
     size_t workspace_bytes;
+    /* The caller's name for this build, 1 .. 2^23 - 1 (0: none; ABI 27).  The sticky word is shared by every build of a device:
+     * the FIRST build that fails leaves (id << 8) beside its code bits (bits 0 .. 7: 1 = endpoint out of range,
+     * STG_BUILD_NEEDS_SORT), later failures only OR their code bits in -- whoever reads the word can name the edge list. */
+    int32_t id;
 } stg_build_job;
 int stg_graph_build_direct2_batch_device(const stg_build_job *jobs, int32_t n_jobs, int32_t N, int32_t *sticky_status,
                                          void *stream);

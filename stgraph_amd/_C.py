@@ -75,7 +75,7 @@ class BuildJob(ctypes.Structure):
                 [(k, ctypes.c_void_p) for k in ("perm_fwd", "fwd_row_offset", "fwd_column_indices", "fwd_eids", "bwd_row_offset",
                                                 "bwd_column_indices", "bwd_eids", "in_degrees", "out_degrees", "norm",
                                                 "norm_col_fwd", "norm_col_bwd", "zero_counters", "workspace")] +
-                [("workspace_bytes", ctypes.c_size_t)])
+                [("workspace_bytes", ctypes.c_size_t), ("id", ctypes.c_int32)])
 
 
 class TgcnStepFwdArgs(ctypes.Structure):

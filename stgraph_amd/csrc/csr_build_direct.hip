@@ -229,7 +229,17 @@ struct BJob {
     EdgeRec *rec_f, *rec_b;                  // placed edges, forward / backward rows (16-byte records)
     int *pos_f, *pos_b, *part;
     int chunk_shift, lds;                   // lds != 0: counted by direct3_count (per-chunk histograms in LDS) and combined
+    int id;                                 // the caller's name for this build (stg_build_job::id; 0: none)
 };
+
+// The sticky word is shared by every build of a device: the FIRST build that fails leaves its id in bits 8 .. 30 beside the code
+// bits (0 .. 7), later failures only add their code bits -- the reader can name the build (a bad edge list was
+// reported by whichever graph's check ran next).
+__device__ __forceinline__ void report_build(int *status, int code, int id)
+{
+    const int old = atomicCAS(status, 0, code | ((id & 0x7fffff) << 8));
+    if (old != 0) atomicOr(status, code);
+}
 constexpr int kBuildBatchMax = STG_BUILD_BATCH_MAX;
 template <int CAP>
 struct BuildJobs {
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void direct2_count(const BuildJobs<CAP> job
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
         const int s = src[i], d = dst[i];
         if ((unsigned)s >= (unsigned)N || (unsigned)d >= (unsigned)N) {
-            atomicOr(status, 1);
+            report_build(status, 1, J.id);
             pos_f[i] = -1;
             continue;
         }
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(kScanThreads) void direct3_count(const BuildJobs<CA
             if (i >= hi) continue;
             if ((unsigned)s[u] >= (unsigned)N || (unsigned)d[u] >= (unsigned)N) {
                 if (side == 0) {
-                    atomicOr(status, 1);
+                    report_build(status, 1, J.id);
                     pos_f[i] = -1;
                 }
                 continue;
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(kScanThreads) void direct2_scan(const BuildJobs<CAP
         __syncthreads();                                              // wsum / wtot are rewritten by the next group
     }
     if (tid == 0) ro[N] = carry;
-    if (longest > kDirectMaxRow) atomicOr(status, STG_BUILD_NEEDS_SORT);
+    if (longest > kDirectMaxRow) report_build(status, STG_BUILD_NEEDS_SORT, J.id);
 }
 
 // (base != NULL: pos_f / pos_b count inside (chunk, row) -- direct3_count -- and base[chunk][row] is added; npad = its row stride)
@@ -752,6 +762,7 @@ extern "C" int stg_graph_build_direct2_batch_device(const stg_build_job *jobs_in
         jobs.j[i] = make_job(L, static_cast<char *>(q.workspace), q.src, q.dst, q.E, N, q.perm_fwd, q.fwd_row_offset, q.fwd_column_indices,
                              q.fwd_eids, q.bwd_row_offset, q.bwd_column_indices, q.bwd_eids, q.in_degrees, q.out_degrees, q.norm,
                              q.norm_col_fwd, q.norm_col_bwd, q.zero_counters);
+        jobs.j[i].id = q.id;
     }
     if (const int rc = run_direct2(jobs, n_jobs, N, sticky_status, stream, who)) return rc;
     return check_launch(who);

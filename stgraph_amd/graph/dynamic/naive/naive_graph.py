@@ -106,7 +106,8 @@ class NaiveGraph(DynamicGraph):
                 or not 0 < self.max_num_nodes <= kernels.BUILD_BATCH_MAX_NODES or any(self._edges[t][0].numel() > kernels.DIRECT_BUILD_MAX_EDGES for t in ts)):
             return 0
         t0 = time.time()
-        built = kernels.build_graph_csr_batch([self._edges[t] for t in ts], self.max_num_nodes, self._device, counters_base)
+        built = kernels.build_graph_csr_batch([self._edges[t] for t in ts], self.max_num_nodes, self._device, counters_base,
+                                              ids=[t + 1 for t in ts])
         for t, g in zip(ts, built):
             self._snapshots[t] = g
         if not any(built[0].unchecked_status is p for p in self._pending_status[-1:]):

@@ -266,8 +266,11 @@ def check_build_statuses(statuses) -> None:
         for s_, c in zip(statuses, codes):
             if c != 0:
                 s_.zero_()                 # a sticky word (fused rebuild) is shared by later builds: reported once, then clean
+        # a batched build leaves the id of the FIRST list that failed in bits 8 .. 30 (stg_build_job::id; NaiveGraph: timestamp + 1)
+        code, who = bad[0] & 0xff, bad[0] >> 8
+        where = f" (first: build id {who}" + (f" = timestamp {who - 1} of a NaiveGraph" if who else "") + ")" if who else ""
         raise ValueError(f"{len(bad)} per-snapshot CSR build(s) whose validation was deferred failed "
-                         f"(libstgraph_hip status {bad[0]}): the edge list changed after it was first built")
+                         f"(libstgraph_hip status {code}){where}: the edge list changed after it was first built")
 
 
 def set_direct_build(enabled: bool) -> None:
@@ -336,12 +339,14 @@ def _build_status_word(device) -> torch.Tensor:
     return w
 
 
-def build_graph_csr_batch(edge_lists, num_nodes: int, device: torch.device | str, counters_base: int = 0) -> list:
+def build_graph_csr_batch(edge_lists, num_nodes: int, device: torch.device | str, counters_base: int = 0, ids=None) -> list:
     """The re-builds of SEVERAL validated edge lists over the same vertex set -- the snapshots of a BPTT window -- in the
     launches of one (stg_graph_build_direct2_batch_device; <= _C.BUILD_BATCH_MAX lists).  Every GraphCSR is bit-identical
     to ``build_graph_csr(s, d, N, device, lazy_node_ids=True, known_path='direct')`` of its list.
     ``counters_base``: first counter slot of the batch (``_build_counters``); a build issued on a second stream beside builds of the
-    same |V| on another takes a disjoint range (temporal.CapturedDynamicWindows: ``_C.BUILD_BATCH_MAX``)."""
+    same |V| on another takes a disjoint range (temporal.CapturedDynamicWindows: ``_C.BUILD_BATCH_MAX``).  ``ids``: a name per list
+    (1 .. 2^23 - 1; NaiveGraph: timestamp + 1) that the shared sticky status word carries when THAT list fails its validation
+    (:func:`check_build_statuses` reports it)."""
     device = torch.device(device)
     N = int(num_nodes)
     n = len(edge_lists)
@@ -376,6 +381,7 @@ def build_graph_csr_batch(edge_lists, num_nodes: int, device: torch.device | str
         j.in_degrees, j.out_degrees = _ptr(indeg), _ptr(outdeg)
         j.norm, j.norm_col_fwd, j.norm_col_bwd = _ptr(norm), _ptr(nc_f), _ptr(nc_b)
         j.zero_counters, j.workspace, j.workspace_bytes = _ptr(counters), _ptr(ws), ws_bytes
+        j.id = 0 if ids is None else int(ids[k]) & 0x7fffff
         keep.append((s, d, ws))
         g = GraphCSR(N, fwd, bwd, indeg, outdeg, perm)
         g.built_by = "direct"

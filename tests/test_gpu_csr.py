@@ -156,6 +156,34 @@ def test_rebuilt_snapshots_are_verified_in_bulk(cuda):
     G.reset_graph()
 
 
+def test_a_failed_batched_rebuild_names_its_snapshot(cuda):
+    """The sticky status word is one per device: the batched rebuild leaves the id of the FIRST edge list that failed its
+    validation beside the code (stg_build_job::id = timestamp + 1), and the bulk check names that timestamp (ADVICE r4: the failure
+    used to be reported without saying whose it was)."""
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import NaiveGraph
+    n = 800
+    rng = np.random.default_rng(3)
+    snaps = []
+    for t in range(6):
+        keys = rng.choice(n * n, size=6000, replace=False)
+        snaps.append((torch.from_numpy((keys // n).astype(np.int32)).to(cuda), torch.from_numpy((keys % n).astype(np.int32)).to(cuda)))
+    G = NaiveGraph(snaps, n, device=cuda, sort_inplace=False, resident=False, max_cached=8)
+    for t in range(6):
+        G.csr("fwd", t)                                                      # first builds: validated
+    G.reset_graph()
+    G._snapshots.clear()
+    G._edges[4][1][11] = -2                                                  # snapshot 4: an endpoint out of range, in place
+    assert G.prebuild(range(6)) == 6
+    with pytest.raises(ValueError, match=r"build id 5 = timestamp 4"):
+        G.verify_builds()
+    assert kernels._build_status_word(cuda).item() == 0                      # reported once, then clean
+    G._edges[4][1][11] = 2
+    G._snapshots.clear()
+    assert G.prebuild(range(6)) == 6
+    G.verify_builds()
+
+
 @pytest.mark.parametrize("lds_count", [0, 1, 2])
 @pytest.mark.parametrize("n,e", [(1, 1), (64, 400), (2708, 10556), (25_000, 250_000), (40_960, 300_000), (70_000, 300_000)])
 def test_fused_rebuild_equals_the_first_build(cuda, n, e, lds_count):
