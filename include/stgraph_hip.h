@@ -43,7 +43,8 @@ extern "C" {
  *  27: stg_xent_small_supported / _fwd / _bwd: softmax cross-entropy of a SMALL logits matrix as one launch each way (the graph of
  *      a captured Cora epoch is launch-count bound); stg_bias_act_bwd finishes the column sums in its own launch when one
  *      workgroup covers the matrix (no signature change); stg_gat_bwd_prepass_heads(_supported); stg_gat_fc_fwd / stg_gat_fc_out take the
- *      3-term bf16 split form at H % 4 == 0 heads of 64 over 64 inputs (results equal to fp32 rounding). */
+ *      3-term bf16 split form at H % 4 == 0 heads of 64 over 64 inputs (results equal to fp32 rounding); stg_build_job gains `id`
+ *      (last field); stg_mm_bwd_small(_supported). */
 #define STG_ABI_VERSION 27
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -906,6 +907,14 @@ int stg_xent_scale_grad(float *dlogits, float *colsum, const float *g_loss, int6
  * launch), bwd = stg_xent_bwd_colsum for any K (colsum nullable).  Inside a replayed HIP graph a launch costs ~ 4.5 us whatever
  * it does; the general entry points need five for what these two do.  Sums in a fixed order: run-to-run identical; against the
  * general path equal to fp32 rounding (another order of the same additions). */
+/* The backward of a SMALL dense layer y = x W (nn/pytorch/static/gcn_conv.py:158 `torch.mm(h, self.weight)`; x [N, K], W [K, M], g = dy
+ * [N, M]) as ONE one-workgroup launch: gx [N, K] = g W^T and gw [K, M] = x^T g (N <= 65536, K, M <= 16: Cora's second
+ * layer, 2708 x 16 -> 7).  Fixed summation order (run-to-run identical); against the library GEMMs equal to fp32 rounding.
+ * relu_colsum [K] (nullable): x is the OUTPUT of a ReLU layer (gcn_conv.py:185-188 below this one): gx comes out as
+ * (g W^T) * [x > 0], the gradient of that layer's pre-activation, and relu_colsum = its column sums, that layer's bias gradient. */
+int stg_mm_bwd_small_supported(int64_t N, int32_t K, int32_t M);
+int stg_mm_bwd_small(const float *g, const float *x, const float *W, float *gx, float *gw, float *relu_colsum, int64_t N, int32_t K,
+                     int32_t M, void *stream);
 int stg_xent_small_supported(int64_t n_total, int32_t K);
 int stg_xent_small_fwd(const float *logits, const int64_t *labels, float *lse, float *loss, float *n_counted, int32_t *status,
                        int64_t n, int32_t K, void *stream);

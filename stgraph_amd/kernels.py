@@ -2191,6 +2191,38 @@ def xent_fwd_grad(logits: torch.Tensor, labels: torch.Tensor, rows: int | None =
     return loss, lse, n_counted, status, d, cs
 
 
+_MM_BWD_SMALL = True
+
+
+def set_mm_bwd_small(on: bool) -> None:
+    """False: the backward of a small dense layer runs as two library GEMMs instead of stg_mm_bwd_small."""
+    global _MM_BWD_SMALL
+    _MM_BWD_SMALL = bool(on)
+
+
+def mm_bwd_small_usable(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> bool:
+    """``y = x @ w`` with x [N, K], w [K, M] small enough for one workgroup (Cora's second layer: 2708 x 16 -> 7)."""
+    return (_MM_BWD_SMALL and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and w.dtype == torch.float32
+            and g.dim() == 2 and x.dim() == 2 and w.dim() == 2 and x.is_contiguous() and w.is_contiguous()
+            and x.shape[0] == g.shape[0] and tuple(w.shape) == (x.shape[1], g.shape[1])
+            and bool(_C.lib.stg_mm_bwd_small_supported(int(x.shape[0]), int(x.shape[1]), int(g.shape[1]))))
+
+
+def mm_bwd_small(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor, relu_input: bool = False):
+    """(g @ w.T, x.T @ g) in ONE launch (stg_mm_bwd_small); shapes of :func:`mm_bwd_small_usable`.  ``relu_input``: x is the output
+    of a ReLU layer -- returns ((g @ w.T) * (x > 0), x.T @ g, column sums of the first): the gradient of that layer's
+    pre-activation and its bias gradient from the same launch."""
+    g = _f32(g, "g")
+    N, K = x.shape
+    M = int(g.shape[1])
+    gx = torch.empty(N, K, dtype=torch.float32, device=g.device)
+    gw = torch.empty(K, M, dtype=torch.float32, device=g.device)
+    cs = torch.empty(K, dtype=torch.float32, device=g.device) if relu_input else None
+    with torch.cuda.device(g.device), _Timed("mm_bwd_small", 4 * N * (2 * K + M) + 8 * K * M, 4 * N * K * M):
+        _C.check(_C.lib.stg_mm_bwd_small(_ptr(g), _ptr(x), _ptr(w), _ptr(gx), _ptr(gw), _ptr(cs), N, K, M, _stream_ptr(g.device)))
+    return (gx, gw, cs) if relu_input else (gx, gw)
+
+
 def xent_small_usable(logits: torch.Tensor) -> bool:
     """A logits matrix one workgroup walks in a few passes (Cora's 2708 x 7): loss and gradient as ONE launch each way."""
     return (_XENT_SMALL and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.is_contiguous()
@@ -2414,6 +2446,7 @@ _KNOBS = (
     ("step_wgrad_from_p", "stgraph_amd.kernels", "STEP_WGRAD_FROM_P", True, "STGRAPH_AMD_STEP_WGRAD_FROM_P", "TGCN weight gradients from P (no x3 / da3 stored)"),
     ("step_wgrad_zr_together", "stgraph_amd.kernels", "STEP_WGRAD_ZR_TOGETHER", True, "STGRAPH_AMD_STEP_WGRAD_ZR_TOGETHER", "[d_z | d_r] contracted as one operand"),
     ("xent_one_pass", "stgraph_amd.kernels", "_XENT_ONE_PASS", True, "STGRAPH_AMD_XENT_ONE_PASS", "cross-entropy loss and its gradient in one pass"),
+    ("mm_bwd_small", "stgraph_amd.kernels", "_MM_BWD_SMALL", True, None, "backward of a small dense layer (N <= 65536, K, M <= 16) as one launch instead of two library GEMMs"),
     ("xent_small", "stgraph_amd.kernels", "_XENT_SMALL", True, None, "cross-entropy of a small logits matrix (one workgroup holds it in registers; K <= 64) as one launch each way"),
     ("native_weight_grad", "stgraph_amd.nn.functional", "_NATIVE_WGRAD", True, None, "tall-skinny weight gradients on the split-K kernels instead of rocBLAS"),
     ("deferred_weight_grads", "stgraph_amd.nn.functional", "_DEFER", True, None, "weight gradients of a window contracted once, at the end of the backward pass"),

@@ -71,12 +71,26 @@ class _MM(torch.autograd.Function):
         ctx.w = w
         # x = relu(...) of _InputLayer with its sign pattern as bits: the backward multiplies g w^T by it in the same launch
         ctx.relu_bits = _tagged(x, "_stg_relu_bits")
+        # x = the ReLU output of a GCNConv tail (_GcnLayerTail): a small layer's backward masks its input gradient and sums its
+        # columns in the launch that forms it
+        ctx.relu_out = _tagged(x, "_stg_relu_out") is not None
         return _mm(x, w)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         gx = gw = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.relu_bits is None and kernels.mm_bwd_small_usable(g, x, w):
+            # a layer one workgroup holds (Cora's 16 -> 7): both gradients from ONE launch -- launch count is what a small graph's
+            # epoch costs.  Below a ReLU layer (and while nobody can see x's own gradient: see the masked product further down) the
+            # same launch applies that ReLU's mask and leaves its bias gradient on the tensor.
+            observed = x.retains_grad or bool(getattr(x, "_backward_hooks", None))
+            if ctx.relu_out and not observed:
+                gx, gw, cs = kernels.mm_bwd_small(g, x, w, relu_input=True)
+                _tag(gx, "_stg_relu_masked_out", x)
+                gx._stg_colsum = (cs, gx._version, gx.data_ptr())
+                return gx, gw
+            return kernels.mm_bwd_small(g, x, w)
         if ctx.needs_input_grad[0]:
             if w.is_contiguous() and kernels.rowgemm16_usable(g, w.shape[1], w.shape[0]) and w.data_ptr() % 16 == 0:
                 g = g.contiguous()
@@ -366,8 +380,14 @@ def link_head(h, W1, b1, edge_index, target, cost=None):
     return y, loss if cost is None else cost + loss
 
 
+def _small_layer(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """A dense layer one workgroup holds (Cora's 2708 x 16 -> 7): its backward is one launch (kernels.mm_bwd_small)."""
+    return (x.is_cuda and x.dtype == torch.float32 and w.dim() == 2 and x.requires_grad and w.requires_grad
+            and bool(kernels._MM_BWD_SMALL) and bool(kernels._C.lib.stg_mm_bwd_small_supported(int(x.shape[0]), int(x.shape[1]), int(w.shape[1]))))
+
+
 def mm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    if x.dim() == 2 and _use_native(x, x.shape[0], x.shape[1], w.shape[1]):
+    if x.dim() == 2 and (_use_native(x, x.shape[0], x.shape[1], w.shape[1]) or _small_layer(x, w)):
         return _MM.apply(x, w)
     return torch.mm(x, w)
 
@@ -416,17 +436,24 @@ class _GcnLayerTail(torch.autograd.Function):
                               ew if ew is not None else norm.new_empty(0))
         ctx.has_ew, ctx.act, ctx.has_bias = ew is not None, act, bias is not None
         ctx.bwd_csr, ctx.use_nid, ctx.bias = bwd_csr, use_nid, bias
+        if act == kernels.ACT_RELU:
+            _tag(out, "_stg_relu_out", True)
         return out
 
     @staticmethod
     def backward(ctx, g):
         out, norm, ew = ctx.saved_tensors
         ew = ew if ctx.has_ew else None
-        known = _known_colsum(g)                         # column sums of THIS tensor object, left by the loss's backward
+        known = _known_colsum(g)                         # column sums of THIS tensor object, left by the loss's / the consumer's backward
+        masked_by = _tagged(g, "_stg_relu_masked_out")   # the consumer's backward already multiplied g by [out > 0] (_MM.backward, small layers)
         g = g.contiguous()
         want_b = ctx.has_bias and ctx.needs_input_grad[1]
         gb = None
-        if ctx.act == kernels.ACT_NONE and want_b and known is not None and known.numel() == g.shape[-1] and g.dim() == 2:
+        same = (masked_by is not None and masked_by.data_ptr() == out.data_ptr() and masked_by.shape == out.shape
+                and masked_by._version == out._version)
+        if (ctx.act == kernels.ACT_RELU and same and known is not None and known.numel() == g.shape[-1] and g.dim() == 2):
+            gb = known if want_b else None
+        elif ctx.act == kernels.ACT_NONE and want_b and known is not None and known.numel() == g.shape[-1] and g.dim() == 2:
             gb = known
         elif ctx.act != kernels.ACT_NONE or want_b:
             g, gb = kernels.bias_act_bwd(g, out if ctx.act != kernels.ACT_NONE else None, want_colsum=want_b)

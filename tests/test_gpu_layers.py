@@ -426,3 +426,97 @@ def test_gatconv_on_naive_graph_snapshots(cuda):
         o0 = orc.gat_k1(A0, S0, feat.detach().cpu().numpy(), og.fwd, use_node_ids=True)
         np.testing.assert_allclose(outs[t].detach().cpu().numpy(), o0, rtol=1e-5, atol=1e-6)
         assert xs[t].grad is not None and bool(torch.isfinite(xs[t].grad).all())
+
+
+@pytest.mark.parametrize("N,K,M", [(2708, 16, 7), (1, 1, 1), (3072, 8, 16), (777, 16, 8), (100, 3, 5), (20000, 12, 12), (65536, 16, 16)])
+def test_small_dense_layer_backward_in_one_launch(cuda, N, K, M):
+    """stg_mm_bwd_small (gx = g W^T and gw = x^T g of y = x W for a layer one workgroup holds) against fp64, no worse than the two
+    library GEMMs it replaces; run twice: identical; SF.mm takes it (launch record) and can be switched off."""
+    from stgraph_amd import kernels
+    from stgraph_amd.nn import functional as SF
+    gen = torch.Generator(device=cuda).manual_seed(N + K + M)
+    x = torch.randn(N, K, device=cuda, generator=gen)
+    w = torch.randn(K, M, device=cuda, generator=gen)
+    g = torch.randn(N, M, device=cuda, generator=gen)
+    assert kernels.mm_bwd_small_usable(g, x, w)
+    gx, gw = kernels.mm_bwd_small(g, x, w)
+    gx2, gw2 = kernels.mm_bwd_small(g, x, w)
+    assert torch.equal(gx, gx2) and torch.equal(gw, gw2)
+    for got, lib, ref in ((gx, g @ w.t(), g.double() @ w.double().t()), (gw, x.t() @ g, x.double().t() @ g.double())):
+        scale = float(ref.abs().max()) + 1e-30
+        e_new, e_lib = float((got.double() - ref).abs().max()) / scale, float((lib.double() - ref).abs().max()) / scale
+        assert e_new <= max(2 * e_lib, 2e-6), (e_new, e_lib)
+    out = []
+    for on in (True, False):
+        kernels.set_mm_bwd_small(on)
+        try:
+            recs = []
+            kernels.enable_launch_timing(recs)
+            xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            SF.mm(xa, wa).backward(g)
+            kernels.enable_launch_timing(None)
+            assert ("mm_bwd_small" in [r[0] for r in recs]) == on
+            out.append((xa.grad, wa.grad))
+        finally:
+            kernels.enable_launch_timing(None)
+            kernels.set_mm_bwd_small(True)
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-4, atol=1e-4 * float(out[1][1].abs().max()))
+    assert not kernels.mm_bwd_small_usable(torch.randn(70000, 7, device=cuda), torch.randn(70000, 16, device=cuda), torch.randn(16, 7, device=cuda))
+    assert not kernels.mm_bwd_small_usable(torch.randn(100, 17, device=cuda), torch.randn(100, 16, device=cuda), torch.randn(16, 17, device=cuda))
+
+
+def test_small_layer_below_a_relu_layer_masks_and_sums_in_its_backward_launch(cuda):
+    """Two GCNConv layers of Cora's widths on a small graph: the second layer's backward launch (stg_mm_bwd_small) applies the first
+    layer's ReLU mask and leaves its bias gradient on the tensor, so no bias_act_bwd launch runs -- every parameter gradient and the
+    input gradient equal the unfused path's; with a hook on the hidden activation the fusion steps aside and the hook sees torch's value."""
+    import torch.nn.functional as F
+    from stgraph_amd import kernels
+    from stgraph_amd.graph import StaticGraph
+    from stgraph_amd.nn.pytorch.static.gcn_conv import GCNConv
+    from tests.util import gcn_norm, random_graph
+    stgraph_amd.set_reference_compat(False)                  # (the file's fixture turns it on: the layer tail is off then)
+    n, e = 2708, 10556
+    src, dst = random_graph(5, n, e)
+    g = StaticGraph((src, dst), None, n, device=cuda, sort_inplace=False)
+    g.set_ndata("norm", torch.from_numpy(gcn_norm(np.bincount(dst, minlength=n))).to(cuda))
+    torch.manual_seed(3)
+    l1, l2 = GCNConv(40, 16, activation=F.relu).to(cuda), GCNConv(16, 7, activation=None).to(cuda)
+    x0 = torch.randn(n, 40, device=cuda)
+    R = torch.randn(n, 7, device=cuda)
+    res = []
+    for mode in ("fused", "unfused", "hooked"):
+        kernels.set_mm_bwd_small(mode != "unfused")
+        try:
+            for p in list(l1.parameters()) + list(l2.parameters()):
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            recs, seen = [], []
+            kernels.enable_launch_timing(recs)
+            h = l1(g, x)
+            if mode == "hooked":
+                h.register_hook(lambda t: seen.append(t.clone()))
+            l2(g, h).backward(R)
+            kernels.enable_launch_timing(None)
+            names = [r[0] for r in recs]
+            assert ("mm_bwd_small" in names) == (mode != "unfused"), names
+            # (one bias_act_bwd is the second layer's own bias gradient; the other the first layer's ReLU mask + bias gradient)
+            assert names.count("bias_act_bwd") == (1 if mode == "fused" else 2), names
+            res.append([x.grad.clone()] + [p.grad.clone() for p in list(l1.parameters()) + list(l2.parameters())] + seen)
+        finally:
+            kernels.enable_launch_timing(None)
+            kernels.set_mm_bwd_small(True)
+    for a, b in zip(res[0], res[1]):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max() + 1))
+    for a, b in zip(res[2][:-1], res[1]):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max() + 1))
+    assert len(res[2]) == len(res[1]) + 1                       # the hook ran once and saw the UNMASKED gradient of h
+    kernels.set_mm_bwd_small(False)
+    try:
+        x = x0.clone().requires_grad_(True)
+        h = l1(g, x)
+        h.retain_grad()
+        l2(g, h).backward(R)
+        torch.testing.assert_close(res[2][-1], h.grad, rtol=2e-4, atol=1e-5)
+    finally:
+        kernels.set_mm_bwd_small(True)
