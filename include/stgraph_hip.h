@@ -44,7 +44,7 @@ extern "C" {
  *      a captured Cora epoch is launch-count bound); stg_bias_act_bwd finishes the column sums in its own launch when one
  *      workgroup covers the matrix (no signature change); stg_gat_bwd_prepass_heads(_supported); stg_gat_fc_fwd / stg_gat_fc_out take the
  *      3-term bf16 split form at H % 4 == 0 heads of 64 over 64 inputs (results equal to fp32 rounding); stg_build_job gains `id`
- *      (last field); stg_mm_bwd_small(_supported). */
+ *      (last field); stg_mm_bwd_small(_supported), stg_gemm_tn_small_f32(_supported). */
 #define STG_ABI_VERSION 27
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -912,6 +912,10 @@ int stg_xent_scale_grad(float *dlogits, float *colsum, const float *g_loss, int6
  * layer, 2708 x 16 -> 7).  Fixed summation order (run-to-run identical); against the library GEMMs equal to fp32 rounding.
  * relu_colsum [K] (nullable): x is the OUTPUT of a ReLU layer (gcn_conv.py:185-188 below this one): gx comes out as
  * (g W^T) * [x > 0], the gradient of that layer's pre-activation, and relu_colsum = its column sums, that layer's bias gradient. */
+/* c [Ka, Mb] = a^T b for a [N, Ka] of any width, b [N, Mb <= 16], N <= 65536 (the weight gradient x^T g of a layer on a small graph:
+ * Cora's first, 1433 x 2708 by 2708 x 16) -- one workgroup per 16 columns of a; fixed summation order. */
+int stg_gemm_tn_small_supported(int64_t N, int32_t Ka, int32_t Mb);
+int stg_gemm_tn_small_f32(const float *a, const float *b, float *c, int64_t N, int32_t Ka, int32_t Mb, void *stream);
 int stg_mm_bwd_small_supported(int64_t N, int32_t K, int32_t M);
 int stg_mm_bwd_small(const float *g, const float *x, const float *W, float *gx, float *gw, float *relu_colsum, int64_t N, int32_t K,
                      int32_t M, void *stream);

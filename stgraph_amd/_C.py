@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
     "stg_xent_workspace_bytes", "stg_xent_fwd", "stg_xent_bwd", "stg_xent_bwd_colsum_workspace_bytes", "stg_xent_bwd_colsum", "stg_xent_fwd_grad_workspace_bytes", "stg_xent_fwd_grad", "stg_xent_scale_grad",
-    "stg_xent_small_supported", "stg_xent_small_fwd", "stg_xent_small_bwd", "stg_mm_bwd_small_supported", "stg_mm_bwd_small",
+    "stg_xent_small_supported", "stg_xent_small_fwd", "stg_xent_small_bwd", "stg_mm_bwd_small_supported", "stg_mm_bwd_small", "stg_gemm_tn_small_supported", "stg_gemm_tn_small_f32",
     "stg_link_head_supported", "stg_link_head_workspace_bytes", "stg_link_head_fwd", "stg_link_head_bwd",
     "stg_tgcn_cell_prep_fwd", "stg_tgcn_cell_gates_fwd", "stg_tgcn_cell_update_fwd",
     "stg_tgcn_cell_update_bwd", "stg_tgcn_cell_gates_bwd", "stg_tgcn_cell_prep_bwd",
@@ -311,6 +311,10 @@ def _load() -> ctypes.CDLL:
     lib.stg_xent_fwd_grad.argtypes = [vp] * 8 + [i64, i64, i32, vp, ctypes.c_size_t, vp]
     lib.stg_xent_scale_grad.restype = ctypes.c_int
     lib.stg_xent_scale_grad.argtypes = [vp, vp, vp, i64, i32, vp]
+    lib.stg_gemm_tn_small_supported.restype = ctypes.c_int
+    lib.stg_gemm_tn_small_supported.argtypes = [i64, i32, i32]
+    lib.stg_gemm_tn_small_f32.restype = ctypes.c_int
+    lib.stg_gemm_tn_small_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp]
     lib.stg_mm_bwd_small_supported.restype = ctypes.c_int
     lib.stg_mm_bwd_small_supported.argtypes = [i64, i32, i32]
     lib.stg_mm_bwd_small.restype = ctypes.c_int

@@ -131,8 +131,71 @@ __global__ __launch_bounds__(kSdThreads) void mm_bwd_small_kernel(const float *_
     }
 }
 
+// c [Ka, Mb] = a^T b for a [N, Ka] of any width and b [N, Mb <= 16] (Cora's first layer: x^T g, 1433 x 2708 by 2708 x 16 -- 14.7 us on
+// the library GEMM): one 16-wave workgroup per 16 columns of a, the rows' 4-row groups dealt to its waves exactly as in the gw part
+// above (every load of a chunk before the first product), the waves' 16 x 16 sums added in LDS in a fixed order.
+__global__ __launch_bounds__(kSdThreads) void gemm_tn_small_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                                   float *__restrict__ c, int N, int Ka, int Mb)
+{
+    __shared__ float red[kSdWaves][256];
+    const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int m0 = (int)blockIdx.x * 16;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a), 0, (int)((int64_t)N * Ka * 4), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b), 0, (int)((int64_t)N * Mb * 4), 0x00020000);
+    auto ld = [](const __amdgpu_buffer_rsrc_t &rs, unsigned voff, unsigned soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+    };
+    constexpr unsigned kNone = 0x80000000u;
+    sd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int groups = (N + 3) / 4;
+    constexpr int UG = 44;
+    const unsigned va = m0 + n16 < Ka ? (unsigned)((wave * 4 + kq) * Ka + m0 + n16) * 4u : kNone;
+    const unsigned vb = n16 < Mb ? (unsigned)((wave * 4 + kq) * Mb + n16) * 4u : kNone;
+    const unsigned sa = (unsigned)(kSdWaves * 4 * Ka) * 4u, sb = (unsigned)(kSdWaves * 4 * Mb) * 4u;
+    for (int base = 0; base < groups; base += kSdWaves * UG) {
+        float av[UG], bv[UG];
+        const unsigned ba = (unsigned)base * 4u * (unsigned)Ka * 4u, bb = (unsigned)base * 4u * (unsigned)Mb * 4u;
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            av[u] = ld(rsA, va, ba + u * sa);
+            bv[u] = ld(rsB, vb, bb + u * sb);
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * kq + r) * 16 + n16] = acc[r];
+    __syncthreads();
+    if (tid < 256) {
+        const int k = tid >> 4, m = tid & 15;
+        if (m0 + k < Ka && m < Mb) {
+            float s = 0.f;
+            for (int w = 0; w < kSdWaves; ++w) s = s + red[w][tid];
+            c[(int64_t)(m0 + k) * Mb + m] = s;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace stg
+
+extern "C" int stg_gemm_tn_small_supported(int64_t N, int32_t Ka, int32_t Mb)
+{
+    // (32-bit byte offsets into a and b)
+    return N > 0 && N <= 65536 && Ka > 0 && Mb > 0 && Mb <= 16 && N * (int64_t)Ka < ((int64_t)1 << 29);
+}
+
+extern "C" int stg_gemm_tn_small_f32(const float *a, const float *b, float *c, int64_t N, int32_t Ka, int32_t Mb, void *stream_)
+{
+    using namespace stg;
+    if (!stg_gemm_tn_small_supported(N, Ka, Mb))
+        return fail(STG_ERR_UNSUPPORTED, "stg_gemm_tn_small_f32: N=%lld Ka=%d Mb=%d (N <= 65536, Mb <= 16, N Ka < 2^29)", (long long)N, Ka, Mb);
+    if (!a || !b || !c) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gemm_tn_small_f32: NULL pointer argument");
+    hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)((Ka + 15) / 16)), dim3(kSdThreads), 0, static_cast<hipStream_t>(stream_), a, b, c,
+                       (int)N, Ka, Mb);
+    return check_launch("stg_gemm_tn_small_f32");
+}
 
 extern "C" int stg_mm_bwd_small_supported(int64_t N, int32_t K, int32_t M)
 {

@@ -2223,6 +2223,23 @@ def mm_bwd_small(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor, relu_input: 
     return (gx, gw, cs) if relu_input else (gx, gw)
 
 
+def gemm_tn_small_usable(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """``a.T @ b`` for a [N, Ka] of any width and b [N, Mb <= 16] on a small graph (N <= 65536): stg_gemm_tn_small_f32."""
+    return (_MM_BWD_SMALL and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
+            and a.shape[0] == b.shape[0] and a.is_contiguous()
+            and bool(_C.lib.stg_gemm_tn_small_supported(int(a.shape[0]), int(a.shape[1]), int(b.shape[1]))))
+
+
+def gemm_tn_small(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    b = _f32(b, "b")
+    N, Ka = a.shape
+    Mb = int(b.shape[1])
+    c = torch.empty(Ka, Mb, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device), _Timed("gemm_tn_small", 4 * N * (Ka + Mb) + 4 * Ka * Mb, 2 * N * Ka * Mb):
+        _C.check(_C.lib.stg_gemm_tn_small_f32(_ptr(a), _ptr(b), _ptr(c), N, Ka, Mb, _stream_ptr(a.device)))
+    return c
+
+
 def xent_small_usable(logits: torch.Tensor) -> bool:
     """A logits matrix one workgroup walks in a few passes (Cora's 2708 x 7): loss and gradient as ONE launch each way."""
     return (_XENT_SMALL and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.is_contiguous()

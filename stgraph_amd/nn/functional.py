@@ -108,7 +108,9 @@ class _MM(torch.autograd.Function):
                     gx = kernels.rowgemm(g, w, None, trans_w=True)           # g @ w.T with w read in place ([in][out] = [M][K])
             else:
                 gx = _mm(g, w.t().contiguous()) if g.shape[0] >= LT_MIN_ROWS else torch.mm(g, w.t())
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and kernels.gemm_tn_small_usable(x, g) and not _use_native(x, x.shape[0], x.shape[1], g.shape[1]):
+            gw = kernels.gemm_tn_small(x, g)                      # a small graph: one launch (the library GEMM reduces K on a few workgroups)
+        elif ctx.needs_input_grad[1]:
             native = _use_native(x, x.shape[0], x.shape[1], g.shape[1])
             if native and deferred_weight_grads() and ctx.w.is_leaf:
                 W = ctx.w
@@ -386,8 +388,14 @@ def _small_layer(x: torch.Tensor, w: torch.Tensor) -> bool:
             and bool(kernels._MM_BWD_SMALL) and bool(kernels._C.lib.stg_mm_bwd_small_supported(int(x.shape[0]), int(x.shape[1]), int(w.shape[1]))))
 
 
+def _small_graph_layer(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """A layer on a small graph whose weight gradient x^T g is one launch of kernels.gemm_tn_small (any input width, <= 16 outputs)."""
+    return (x.is_cuda and x.dtype == torch.float32 and w.dim() == 2 and w.requires_grad and not x.requires_grad
+            and kernels.gemm_tn_small_usable(x, w.new_empty(x.shape[0], w.shape[1])))
+
+
 def mm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    if x.dim() == 2 and (_use_native(x, x.shape[0], x.shape[1], w.shape[1]) or _small_layer(x, w)):
+    if x.dim() == 2 and (_use_native(x, x.shape[0], x.shape[1], w.shape[1]) or _small_layer(x, w) or _small_graph_layer(x, w)):
         return _MM.apply(x, w)
     return torch.mm(x, w)
 

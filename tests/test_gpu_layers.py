@@ -520,3 +520,33 @@ def test_small_layer_below_a_relu_layer_masks_and_sums_in_its_backward_launch(cu
         torch.testing.assert_close(res[2][-1], h.grad, rtol=2e-4, atol=1e-5)
     finally:
         kernels.set_mm_bwd_small(True)
+
+
+@pytest.mark.parametrize("N,Ka,Mb", [(2708, 1433, 16), (1, 1, 1), (3000, 17, 7), (65536, 40, 16), (5, 300, 3)])
+def test_small_graph_weight_gradient_in_one_launch(cuda, N, Ka, Mb):
+    """stg_gemm_tn_small_f32 (a^T b, a of any width, b <= 16 columns, N <= 65536) against fp64, no worse than the library GEMM; twice
+    the same; taken by SF.mm's backward for a layer whose input carries no gradient."""
+    from stgraph_amd import kernels
+    from stgraph_amd.nn import functional as SF
+    gen = torch.Generator(device=cuda).manual_seed(N + Ka)
+    a = torch.randn(N, Ka, device=cuda, generator=gen)
+    b = torch.randn(N, Mb, device=cuda, generator=gen)
+    assert kernels.gemm_tn_small_usable(a, b)
+    c, c2 = kernels.gemm_tn_small(a, b), kernels.gemm_tn_small(a, b)
+    assert torch.equal(c, c2)
+    ref = a.double().t() @ b.double()
+    scale = float(ref.abs().max()) + 1e-30
+    e_new, e_lib = float((c.double() - ref).abs().max()) / scale, float(((a.t() @ b).double() - ref).abs().max()) / scale
+    assert e_new <= max(2 * e_lib, 2e-6), (e_new, e_lib)
+    w = torch.randn(Ka, Mb, device=cuda, generator=gen).requires_grad_(True)
+    recs = []
+    kernels.enable_launch_timing(recs)
+    try:
+        SF.mm(a, w).backward(b)
+    finally:
+        kernels.enable_launch_timing(None)
+    # (from 4096 rows the split-K contraction of the large graphs takes the weight gradient: functional.MIN_K)
+    assert ("gemm_tn_small" in [r[0] for r in recs]) == (N < 4096), [r[0] for r in recs]
+    if N < 4096:
+        torch.testing.assert_close(w.grad.double(), ref, rtol=1e-4, atol=1e-5 * scale)
+    assert not kernels.gemm_tn_small_usable(torch.randn(10, 5, device=cuda), torch.randn(10, 17, device=cuda))
