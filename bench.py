@@ -861,7 +861,7 @@ def gat_run(device, n=256_000, e=8_000_000, fin=64, H=8, D=64, classes=16, layer
                 model.train()
                 logits = model(feats)
                 loss = SF.cross_entropy(logits, labels, ntrain)    # = CrossEntropyLoss()(logits[train_mask], labels[train_mask])
-                opt.zero_grad(set_to_none=False)
+                opt.zero_grad()                                    # (gat/seastar/train.py: optimizer.zero_grad(); today's default drops the grads)
                 loss.backward()
                 opt.step()
                 return loss.detach()

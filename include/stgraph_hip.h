@@ -44,7 +44,7 @@ extern "C" {
  *      a captured Cora epoch is launch-count bound); stg_bias_act_bwd finishes the column sums in its own launch when one
  *      workgroup covers the matrix (no signature change); stg_gat_bwd_prepass_heads(_supported); stg_gat_fc_fwd / stg_gat_fc_out take the
  *      3-term bf16 split form at H % 4 == 0 heads of 64 over 64 inputs (results equal to fp32 rounding); stg_build_job gains `id`
- *      (last field); stg_mm_bwd_small(_supported), stg_gemm_tn_small_f32(_supported). */
+ *      (last field); stg_mm_bwd_small(_supported), stg_gemm_tn_small_f32(_supported), stg_gat_attn_fold. */
 #define STG_ABI_VERSION 27
 
 #define STG_ERR_INVALID_ARGUMENT 10001   /* NULL pointer, negative size, bad shape  */
@@ -506,6 +506,11 @@ int stg_gat_bwd_prepass(const float *S, const float *out, const float *g, float 
  * per-head dot products add the same terms in another order), and gW [H][N][fin] = g_pre[:, h, :] W_h in the 3-term bf16 split
  * form of stg_rowgemm_heads_f32, four heads per launch.  out, g, g_pre, W, gW 16-byte aligned; g_pre == NULL: g is already the
  * gradient of `out`. */
+/* The small products of that fold in ONE launch (W [H D][fin] = fc.weight, G [2H][fin] = [grad_el | grad_er]^T h, attn_l / attn_r [H][D]):
+ * dattn_l[h, d] = sum_f W[h D + d, f] G[h, f] (dattn_r with G[H + h]); Aw [2H][fin] (nullable) with Aw[h, f] = sum_d W[h D + d, f]
+ * attn_l[h, d] (rows H .. with attn_r); gw [H D][fin] (nullable) += attn_l[h, d] G[h, f] + attn_r[h, d] G[H + h, f].  D fin <= ~16 K. */
+int stg_gat_attn_fold(const float *W, const float *G, const float *attn_l, const float *attn_r, float *dattn_l, float *dattn_r,
+                      float *Aw, float *gw, int32_t H, int32_t D, int32_t fin, void *stream);
 int stg_gat_bwd_prepass_heads_supported(int64_t N, int32_t H, int32_t D, int32_t fin);
 int stg_gat_bwd_prepass_heads(const float *S, const float *out, const float *g, float *g_pre, float *pack, float *grad_er,
                               const float *W, float *gW, int64_t N, int32_t H, int32_t D, int32_t fin, float slope, void *stream);

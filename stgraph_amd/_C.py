@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "stg_gat_fwd_k1_uniform", "stg_gat_fc_out", "stg_gat_fwd_k1_scored", "stg_gat_bwd_factored_elu",
     "stg_gat_fc_supported", "stg_gat_fc_fwd", "stg_gat_proj_supported", "stg_gat_proj_fwd", "stg_gat_proj_bwd_workspace_bytes", "stg_gat_proj_bwd",
     "stg_gemm_tn_workspace_bytes", "stg_gemm_tn_f32", "stg_gemm_tn_colsum_f32", "stg_gemm_tn_relu_mask_f32",
-    "stg_gat_fc_feat_if", "stg_gat_bwd_uniform_supported", "stg_gat_bwd_prepass", "stg_gat_bwd_prepass_heads_supported", "stg_gat_bwd_prepass_heads", "stg_gat_bwd_uniform_edges", "stg_gat_bwd_uniform_gx_fallback", "stg_gemm_tn_gated_f32", "stg_rowgemm_heads_supported", "stg_rowgemm_heads_f32", "stg_rowgemm_bits_words", "stg_rowgemm_bits_supported", "stg_rowgemm_act_bits_f32", "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_tgcn_unfold_gate_grads", "stg_tgcn_fold_weights", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
+    "stg_gat_fc_feat_if", "stg_gat_bwd_uniform_supported", "stg_gat_bwd_prepass", "stg_gat_bwd_prepass_heads_supported", "stg_gat_bwd_prepass_heads", "stg_gat_attn_fold", "stg_gat_bwd_uniform_edges", "stg_gat_bwd_uniform_gx_fallback", "stg_gemm_tn_gated_f32", "stg_rowgemm_heads_supported", "stg_rowgemm_heads_f32", "stg_rowgemm_bits_words", "stg_rowgemm_bits_supported", "stg_rowgemm_act_bits_f32", "stg_gemm_tn_multi_workspace_bytes", "stg_gemm_tn_multi_f32", "stg_gemm_tn_form_workspace_bytes", "stg_gemm_tn_form_f32", "stg_gemm_tn_form_partial_f32", "stg_gemm_tn_reduce_multi_f32", "stg_gemm_tn_reduce_multi_blocks_f32", "stg_tgcn_pack_weights", "stg_tgcn_unfold_gate_grads", "stg_tgcn_fold_weights", "stg_link_decode_fwd_multi", "stg_rowgemm_supported", "stg_rowgemm_f32", "stg_rowgemm_strided_f32", "stg_rowgemm_act_supported", "stg_rowgemm_act_f32",
     "stg_tgcn_cell_fused_supported", "stg_tgcn_cell_fused_fwd", "stg_tgcn_cell_fused_bwd",
     "stg_tgcn_cell_fused_bwd_dx_supported", "stg_tgcn_cell_fused_bwd_dx",
     "stg_tgcn_head_supported", "stg_tgcn_head_workspace_bytes", "stg_tgcn_head_fwd", "stg_tgcn_head_fwd_acc", "stg_tgcn_head_bwd",
@@ -249,6 +249,8 @@ def _load() -> ctypes.CDLL:
     lib.stg_gat_fc_feat_if.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.stg_gat_bwd_uniform_supported.restype = ctypes.c_int
     lib.stg_gat_bwd_uniform_supported.argtypes = [i32, i32, i32]
+    lib.stg_gat_attn_fold.restype = ctypes.c_int
+    lib.stg_gat_attn_fold.argtypes = [vp] * 8 + [i32, i32, i32, vp]
     lib.stg_gat_bwd_prepass_heads_supported.restype = ctypes.c_int
     lib.stg_gat_bwd_prepass_heads_supported.argtypes = [i64, i32, i32, i32]
     lib.stg_gat_bwd_prepass_heads.restype = ctypes.c_int

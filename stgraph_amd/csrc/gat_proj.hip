@@ -109,13 +109,24 @@ __global__ __launch_bounds__(kBlock) void gat_proj_finish_kernel(const float *__
     float sl = 0.f, sr = 0.f;
     if (f < HD) {
         const int fq = f / 4;
-        for (int b = grp; b < blocks; b += kGroups) {
-            const int start = (int)(((int64_t)b * kBlock) % q4);             // first column position of workgroup b
-            const int rel = (fq - start + q4) % q4;
-            if (rel < (q4 < kBlock ? q4 : kBlock)) {
-                sl += partial_l[(int64_t)b * HD + f];
-                sr += partial_r[(int64_t)b * HD + f];
+        // eight partial rows in flight per thread (loads unconditional -- a row that does not hold this column reads a valid word and
+        // adds +0 -- then the adds in row order): one row per round trip took 27 us for the 2 x 16 columns of cfg3's second layer
+        constexpr int U = 8;
+        for (int b0 = grp; b0 < blocks; b0 += kGroups * U) {
+            float vl[U], vr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + u * kGroups;
+                const int bb = b < blocks ? b : blocks - 1;
+                const int start = (int)(((int64_t)bb * kBlock) % q4);        // first column position of workgroup b
+                const int rel = (fq - start + q4) % q4;
+                const bool ok = b < blocks && rel < (q4 < kBlock ? q4 : kBlock);
+                const float l = partial_l[(int64_t)bb * HD + f], r = partial_r[(int64_t)bb * HD + f];
+                vl[u] = ok ? l : 0.f;
+                vr[u] = ok ? r : 0.f;
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) sl += vl[u], sr += vr[u];
         }
     }
     red[0][grp][c] = sl;
@@ -191,4 +202,72 @@ extern "C" int stg_gat_proj_bwd(const float *feat, const float *attn_l, const fl
     hipLaunchKernelGGL(gat_proj_bwd_kernel, dim3(blocks), dim3(kBlock), 0, stream, feat, attn_l, attn_r, del, der, g, dfeat, pl, pr, N, H, D);
     hipLaunchKernelGGL(gat_proj_finish_kernel, dim3((H * D + 7) / 8), dim3(kBlock), 0, stream, pl, pr, dattn_l, dattn_r, blocks, H * D);
     return check_launch("stg_gat_proj_bwd");
+}
+
+
+// The small products of the projection fold (nn/functional._gat_backward_uniform; gat_conv.py:43-48 differentiated at width H instead of
+// H * D), ONE launch, workgroup h = head h with W_h [D][fin] in LDS:
+//   dattn_l[h, d] = sum_f W_h[d, f] G[h, f],  dattn_r[h, d] = sum_f W_h[d, f] G[H + h, f]            (G [2H][fin] = [grad_el | grad_er]^T x)
+//   Aw[h, f] = sum_d W_h[d, f] attn_l[h, d],  Aw[H + h, f] = sum_d W_h[d, f] attn_r[h, d]            (nullable: gx += [grad_el | grad_er] Aw)
+//   gw[h D + d, f] += attn_l[h, d] G[h, f] + attn_r[h, d] G[H + h, f]                                (nullable)
+// -- four einsums (two batched GEMMs each with their copies), a cat and five elementwise launches before: ~ 13 launches of ~ 5 us.
+namespace stg {
+namespace {
+__global__ __launch_bounds__(kBlock) void gat_attn_fold_kernel(const float *__restrict__ W, const float *__restrict__ G,
+                                                              const float *__restrict__ attn_l, const float *__restrict__ attn_r,
+                                                              float *__restrict__ dattn_l, float *__restrict__ dattn_r,
+                                                              float *__restrict__ Aw, float *__restrict__ gw, int H, int D, int fin)
+{
+    extern __shared__ float lds[];
+    float *Ws = lds, *gl = Ws + D * fin, *gr = gl + fin, *al = gr + fin, *ar = al + D;
+    const int h = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const float *Wh = W + (int64_t)h * D * fin;
+    for (int i = tid; i < D * fin; i += kBlock) Ws[i] = Wh[i];
+    for (int i = tid; i < fin; i += kBlock) gl[i] = G[(int64_t)h * fin + i], gr[i] = G[(int64_t)(H + h) * fin + i];
+    for (int i = tid; i < D; i += kBlock) al[i] = attn_l[h * D + i], ar[i] = attn_r[h * D + i];
+    __syncthreads();
+    for (int d = tid; d < D; d += kBlock) {
+        float sl = 0.f, sr = 0.f;
+        for (int f = 0; f < fin; ++f) {
+            const float w = Ws[d * fin + (f + d) % fin];                     // (rotated start: lanes d, d + 1 on different banks)
+            sl = sl + w * gl[(f + d) % fin];
+            sr = sr + w * gr[(f + d) % fin];
+        }
+        dattn_l[h * D + d] = sl;
+        dattn_r[h * D + d] = sr;
+    }
+    if (Aw) {
+        for (int f = tid; f < fin; f += kBlock) {
+            float sl = 0.f, sr = 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float w = Ws[d * fin + f];
+                sl = sl + w * al[d];
+                sr = sr + w * ar[d];
+            }
+            Aw[(int64_t)h * fin + f] = sl;
+            Aw[(int64_t)(H + h) * fin + f] = sr;
+        }
+    }
+    if (gw) {
+        float *gh = gw + (int64_t)h * D * fin;
+        for (int i = tid; i < D * fin; i += kBlock) {
+            const int d = i / fin, f = i - d * fin;
+            gh[i] = gh[i] + (al[d] * gl[f] + ar[d] * gr[f]);
+        }
+    }
+}
+}  // namespace
+}  // namespace stg
+
+extern "C" int stg_gat_attn_fold(const float *W, const float *G, const float *attn_l, const float *attn_r, float *dattn_l, float *dattn_r,
+                                 float *Aw, float *gw, int32_t H, int32_t D, int32_t fin, void *stream)
+{
+    using namespace stg;
+    const size_t lds = ((size_t)D * fin + 2 * (size_t)fin + 2 * (size_t)D) * sizeof(float);
+    if (H <= 0 || D <= 0 || fin <= 0 || lds > 64 * 1024)
+        return fail(STG_ERR_UNSUPPORTED, "stg_gat_attn_fold: H=%d D=%d fin=%d (one head's weights must fit 64 KB of LDS)", H, D, fin);
+    if (!W || !G || !attn_l || !attn_r || !dattn_l || !dattn_r) return fail(STG_ERR_INVALID_ARGUMENT, "stg_gat_attn_fold: NULL pointer argument");
+    hipLaunchKernelGGL(gat_attn_fold_kernel, dim3((unsigned)H), dim3(kBlock), lds, static_cast<hipStream_t>(stream), W, G, attn_l, attn_r,
+                       dattn_l, dattn_r, Aw, gw, H, D, fin);
+    return check_launch("stg_gat_attn_fold");
 }

@@ -1241,6 +1241,36 @@ def gat_bwd_uniform(A, S, out, g, x, W, feat, fwd: DeviceCSR, bwd: DeviceCSR, sl
     return gxa, grad_el, grad_er, gq, grad_feat, flag, xm
 
 
+def gat_attn_fold_usable(W: torch.Tensor, H: int, D: int, fin: int) -> bool:
+    return (_GAT_ATTN_FOLD and W.is_cuda and W.dtype == torch.float32 and W.is_contiguous() and tuple(W.shape) == (H * D, fin)
+            and 4 * (D * fin + 2 * fin + 2 * D) <= 64 * 1024)
+
+
+def gat_attn_fold(W, G, attn_l, attn_r, H: int, D: int, fin: int, want_aw: bool, gw: torch.Tensor | None):
+    """(dattn_l [H, D], dattn_r [H, D], Aw [2H, fin] or None) and ``gw += attn (x) G`` in place -- the small products of the projection
+    fold of the GAT layer's backward in one launch (stg_gat_attn_fold)."""
+    dev = W.device
+    G, al, ar = _f32(G, "G", dev), _f32(attn_l, "attn_l", dev).reshape(H, D), _f32(attn_r, "attn_r", dev).reshape(H, D)
+    if tuple(G.shape) != (2 * H, fin) or (gw is not None and (tuple(gw.shape) != (H * D, fin) or not gw.is_contiguous())):
+        raise ValueError("gat_attn_fold: G [2H, fin], gw [H D, fin] contiguous")
+    dal = torch.empty(H, D, dtype=torch.float32, device=dev)
+    dar = torch.empty(H, D, dtype=torch.float32, device=dev)
+    Aw = torch.empty(2 * H, fin, dtype=torch.float32, device=dev) if want_aw else None
+    with torch.cuda.device(dev), _Timed("gat_attn_fold", 4 * (H * D * fin * (3 if gw is not None else 1) + 4 * H * fin), 6 * H * D * fin):
+        _C.check(_C.lib.stg_gat_attn_fold(_ptr(W), _ptr(G), _ptr(al), _ptr(ar), _ptr(dal), _ptr(dar), _ptr(Aw), _ptr(gw), H, D, fin,
+                                          _stream_ptr(dev)))
+    return dal, dar, Aw
+
+
+_GAT_ATTN_FOLD = True
+
+
+def set_gat_attn_fold(on: bool) -> None:
+    """False: the projection fold's small products run as torch einsums / elementwise launches (rounds 3-4)."""
+    global _GAT_ATTN_FOLD
+    _GAT_ATTN_FOLD = bool(on)
+
+
 _GAT_PREPASS_HEADS = True
 
 
@@ -2455,6 +2485,7 @@ _KNOBS = (
     ("gat_uniform_backward", "stgraph_amd.kernels", "_GAT_UNIFORM_BWD", True, "STGRAPH_AMD_GAT_UNIFORM_BWD", "GAT K2 at the input width, likewise"),
     ("gat_factored_backward", "stgraph_amd.kernels", "_GAT_FACTORED", True, None, "GAT K2 with one E x H x D gather instead of the emitted unit's two"),
     ("gat_regrouped_er", "stgraph_amd.kernels", "_GAT_REGROUPED_ER", True, None, "grad_er summed per target without atomics"),
+    ("gat_attn_fold", "stgraph_amd.kernels", "_GAT_ATTN_FOLD", True, None, "GAT projection fold: its small products (attention gradients, A_w, the weight-gradient correction) in one launch"),
     ("gat_prepass_heads", "stgraph_amd.kernels", "_GAT_PREPASS_HEADS", True, None, "uniform GAT backward: per-vertex pass and the per-head products g W_h in one pass over g and out"),
     ("native_rowgemm", "stgraph_amd.kernels", "_ROWGEMM", False, "STGRAPH_AMD_ROWGEMM", "round-3 fp32 row-product kernel for every tall product (off: only the 16-row form below)"),
     ("rowgemm16", "stgraph_amd.kernels", "_ROWGEMM16", True, "STGRAPH_AMD_ROWGEMM16", "tall row products at K, M in {64, 128} on the native kernels (bf16 split from 64 K rows)"),

@@ -694,17 +694,23 @@ def _gat_backward_uniform(ctx, g):
     G = kernels.gemm_tn(ge, x) if _use_native(x, N, 2 * H, fin) else torch.mm(ge.t(), x)
     Wh = w.view(H, D, fin)
     al, ar = attn_l.reshape(H, D), attn_r.reshape(H, D)
-    dal, dar = torch.einsum("hdf,hf->hd", Wh, G[:H]), torch.einsum("hdf,hf->hd", Wh, G[H:])
     gx = gw = None
-    if ctx.needs_input_grad[0]:
-        Aw = torch.cat([torch.einsum("hdf,hd->hf", Wh, al), torch.einsum("hdf,hd->hf", Wh, ar)], 0)
-        gx = torch.addmm(gxa, ge, Aw)
-        kernels.gat_bwd_uniform_gx_fallback(gf, w, gx, flag)
     if ctx.needs_input_grad[1]:
         gw = torch.empty(H * D, fin, dtype=torch.float32, device=x.device)
         kernels.gemm_tn_gated(gq.view(N, H * D), xm, gw, flag, True)         # every score finite: g^T (mean of x over in-edges)
         kernels.gemm_tn_gated(gf.view(N, H * D), x, gw, flag, False)         # otherwise: the general unit's grad_feat^T x
-        gw += (al.unsqueeze(2) * G[:H].unsqueeze(1) + ar.unsqueeze(2) * G[H:].unsqueeze(1)).reshape(H * D, fin)
+    if kernels.gat_attn_fold_usable(w, H, D, fin):
+        # the fold's small products in ONE launch: the attention gradients, A_w for gx and the correction of gw (in place, after the
+        # gated contractions above)
+        dal, dar, Aw = kernels.gat_attn_fold(w, G, al, ar, H, D, fin, want_aw=ctx.needs_input_grad[0], gw=gw)
+    else:
+        dal, dar = torch.einsum("hdf,hf->hd", Wh, G[:H]), torch.einsum("hdf,hf->hd", Wh, G[H:])
+        Aw = (torch.cat([torch.einsum("hdf,hd->hf", Wh, al), torch.einsum("hdf,hd->hf", Wh, ar)], 0) if ctx.needs_input_grad[0] else None)
+        if gw is not None:
+            gw += (al.unsqueeze(2) * G[:H].unsqueeze(1) + ar.unsqueeze(2) * G[H:].unsqueeze(1)).reshape(H * D, fin)
+    if ctx.needs_input_grad[0]:
+        gx = torch.addmm(gxa, ge, Aw)
+        kernels.gat_bwd_uniform_gx_fallback(gf, w, gx, flag)
     return gx, gw, dal.view_as(attn_l), dar.view_as(attn_r), None, None, None, None, None, None, None
 
 

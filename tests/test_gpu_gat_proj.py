@@ -457,3 +457,28 @@ def test_prepass_and_heads_products_in_one_pass(cuda, N, elu):
     torch.testing.assert_close(ger1[keep], ger0[keep], rtol=1e-5, atol=1e-4)
     assert not ger1[7].any() and not ger0[7].any()
     assert not _C.lib.stg_gat_bwd_prepass_heads_supported(N, 6, D, fin) and not _C.lib.stg_gat_bwd_prepass_heads_supported(N, H, 32, fin)
+
+
+@pytest.mark.parametrize("H,D,fin", [(8, 64, 64), (1, 16, 512), (4, 32, 64), (2, 64, 33)])
+def test_projection_fold_products_in_one_launch(cuda, H, D, fin):
+    """stg_gat_attn_fold against the einsums / elementwise launches it replaces (fp64 reference): attention gradients, A_w, and the
+    correction added into gw in place."""
+    from stgraph_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(H * D + fin)
+    W = torch.randn(H * D, fin, device=cuda, generator=gen)
+    G = torch.randn(2 * H, fin, device=cuda, generator=gen)
+    al, ar = torch.randn(H, D, device=cuda, generator=gen), torch.randn(H, D, device=cuda, generator=gen)
+    gw0 = torch.randn(H * D, fin, device=cuda, generator=gen)
+    if not kernels.gat_attn_fold_usable(W, H, D, fin):
+        assert 4 * (D * fin + 2 * fin + 2 * D) > 64 * 1024
+        return
+    gw = gw0.clone()
+    dal, dar, Aw = kernels.gat_attn_fold(W, G, al, ar, H, D, fin, want_aw=True, gw=gw)
+    Wh, Gd, ald, ard = W.double().view(H, D, fin), G.double(), al.double(), ar.double()
+    want = (torch.einsum("hdf,hf->hd", Wh, Gd[:H]), torch.einsum("hdf,hf->hd", Wh, Gd[H:]),
+            torch.cat([torch.einsum("hdf,hd->hf", Wh, ald), torch.einsum("hdf,hd->hf", Wh, ard)], 0),
+            gw0.double() + (ald.unsqueeze(2) * Gd[:H].unsqueeze(1) + ard.unsqueeze(2) * Gd[H:].unsqueeze(1)).reshape(H * D, fin))
+    for got, ref, name in zip((dal, dar, Aw, gw), want, ("dattn_l", "dattn_r", "A_w", "gw")):
+        torch.testing.assert_close(got.double(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()), msg=lambda m, n=name: f"{n}: {m}")
+    dal2, dar2, none = kernels.gat_attn_fold(W, G, al, ar, H, D, fin, want_aw=False, gw=None)
+    assert none is None and torch.equal(dal, dal2) and torch.equal(dar, dar2)

@@ -27,7 +27,7 @@ def step():
     model.train()
     logits = model(feats)
     loss = SF.cross_entropy(logits, labels, ntrain)
-    opt.zero_grad(set_to_none=False)
+    opt.zero_grad()
     loss.backward()
     opt.step()
     return loss.detach()
