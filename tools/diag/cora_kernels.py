@@ -15,7 +15,8 @@ for r in rows:
     cur.append((r["Kernel_Name"][:100], s, t))
     last = t
 groups.append(cur)
-g = groups[-2]
+pick = int(sys.argv[2]) if len(sys.argv) > 2 else -2                     # which group (default: the last complete replay)
+g = groups[pick]
 out, prev = [], None
 for nm, s, t in g:
     out.append({"kernel": nm, "us": (t - s) / 1e3, "gap_us": 0.0 if prev is None else (s - prev) / 1e3})
