@@ -390,8 +390,9 @@ def _small_layer(x: torch.Tensor, w: torch.Tensor) -> bool:
 
 def _small_graph_layer(x: torch.Tensor, w: torch.Tensor) -> bool:
     """A layer on a small graph whose weight gradient x^T g is one launch of kernels.gemm_tn_small (any input width, <= 16 outputs)."""
-    return (x.is_cuda and x.dtype == torch.float32 and w.dim() == 2 and w.requires_grad and not x.requires_grad
-            and kernels.gemm_tn_small_usable(x, w.new_empty(x.shape[0], w.shape[1])))
+    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 2 and w.requires_grad
+            and not x.requires_grad and x.is_contiguous() and bool(kernels._MM_BWD_SMALL)
+            and bool(kernels._C.lib.stg_gemm_tn_small_supported(int(x.shape[0]), int(x.shape[1]), int(w.shape[1]))))
 
 
 def mm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
