@@ -32,13 +32,16 @@ struct RowInfo {
     bool valid;
 };
 
+// (vblock: the workgroup's position in the grid that has one workgroup per row block -- blockIdx.x unless a launch with FEWER
+//  workgroups walks the row blocks with a stride: the fallback launches of the uniform-attention form, whose 64 K workgroups
+//  otherwise cost 16 us to dispatch only to return on the device flag)
 template <int LOG2G>
 __device__ __forceinline__ RowInfo row_prologue(const int *__restrict__ row_offsets,
-                                                const int *__restrict__ node_ids, int N)
+                                                const int *__restrict__ node_ids, int N, int vblock = -1)
 {
     constexpr int G = 1 << LOG2G;
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int wave_global = (vblock < 0 ? (int)blockIdx.x : vblock) * kWavesPerBlock + (threadIdx.x >> 6);
     const int idx = wave_global * (kWave / G) + (lane >> LOG2G);
     RowInfo ri{0, 0, 0, 0, idx < N};
     if (ri.valid) {
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void gat_k0_kernel(
 
 // ------------------------------------------------------------------------------ K1
 enum { kK1Always = 0, kK1IfUniform = 1, kK1UnlessUniform = 2 };
+constexpr unsigned kFallbackGrid = 4096;           // workgroups of a launch that almost always returns on the device flag
 
 // torch's elu (alpha = 1) as its device kernel forms it: x <= 0 ? exp(x) - 1 : x
 __device__ __forceinline__ float elu1(float x) { return x <= 0.f ? expf(x) - 1.0f : x; }
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void gat_k1_kernel(
     float *__restrict__ out, const int *__restrict__ row_offsets,
     const int *__restrict__ column_indices, const int *__restrict__ eids,
     const int *__restrict__ node_ids, int N, int H, int D, int HD_active, const int *__restrict__ flag,
-    int s_stride, int when, float *__restrict__ act_out)
+    int s_stride, int when, float *__restrict__ act_out, int nblocks)
 {
     constexpr int G = 1 << LOG2G;
     constexpr int U = UNROLL < G ? UNROLL : G;
@@ -154,7 +158,9 @@ __global__ __launch_bounds__(kBlock) void gat_k1_kernel(
     // when: kK1Always | kK1IfUniform (the narrow-width pass of the uniform-attention form: only meaningful when every
     // A is 1.0f) | kK1UnlessUniform (the full-width pass that replaces its result otherwise): kernel-uniform exits
     if ((when == kK1IfUniform && !ones) || (when == kK1UnlessUniform && ones)) return;
-    const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N);
+    // (nblocks row blocks on gridDim.x workgroups: one each, except for the capped grid of the kK1UnlessUniform launch)
+    for (int vb = (int)blockIdx.x; vb < nblocks; vb += (int)gridDim.x) {
+    const RowInfo ri = row_prologue<LOG2G>(row_offsets, node_ids, N, vb);
 
     for (int fbase = 0; fbase < HD_active; fbase += G * VEC * CHUNKS) {
         float acc[CHUNKS][VEC];
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(kBlock) void gat_k1_kernel(
                 }
             }
         }
+    }
     }
 }
 
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_h8d64_kernel(
     const float *__restrict__ feat, float *__restrict__ grad_feat, float *__restrict__ grad_el,
     float *__restrict__ T, const int *__restrict__ row_offsets, const int *__restrict__ column_indices,
     const int *__restrict__ eids, const int *__restrict__ node_ids, int N, float slope, const int *__restrict__ flag,
-    int unless_uniform)
+    int unless_uniform, int nblocks)
 {
     constexpr int H = 8, HD = 512, U = UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
@@ -625,7 +632,8 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_h8d64_kernel(
     // unless_uniform: the launch of the uniform-attention backward (gat_ubwd_* below) that stands in when some score is not
     // finite -- nothing to do otherwise; T (required then) carries the grad_el terms to the pass that sums them
     if (unless_uniform && ones) return;
-    const RowInfo ri = row_prologue<6>(row_offsets, node_ids, N);
+    for (int vb = (int)blockIdx.x; vb < nblocks; vb += (int)gridDim.x) {     // (one row block each unless the grid is capped: row_prologue)
+    const RowInfo ri = row_prologue<6>(row_offsets, node_ids, N, vb);
     float a13[2][4], fu[2][4];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
@@ -702,6 +710,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_fact_h8d64_kernel(
         if (lane < H && !unless_uniform) grad_el[(int64_t)ri.r * H + lane] = gel;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) vec_store<4>(grad_feat + (int64_t)ri.r * HD + ch * 256 + lane * 4, a13[ch]);
+    }
     }
 }
 
@@ -997,9 +1006,10 @@ int launch_k1(const char *what, const float *A, const float *S, int s_stride, co
 #define STG_K1(VEC, CH, UN)                                                                              \
     STG_SWITCH_LOG2G(p.chunks > 1 ? 6 : p.log2g,                                                         \
                      hipLaunchKernelGGL((gat_k1_kernel<VEC, (CH > 1 ? 6 : LG), CH, UN>),                 \
-                                        dim3(grid_for(N, (CH > 1 ? 6 : LG))), dim3(kBlock), 0, st, A, S, \
+                                        dim3(when == kK1UnlessUniform ? std::min<unsigned>(grid_for(N, (CH > 1 ? 6 : LG)), kFallbackGrid) \
+                                                                      : grid_for(N, (CH > 1 ? 6 : LG))), dim3(kBlock), 0, st, A, S, \
                                         feat, out, row_offsets, column_indices, eids, node_ids, N, H, D, \
-                                        HD_active, ones_flag, s_stride, when, act_out))
+                                        HD_active, ones_flag, s_stride, when, act_out, (int)grid_for(N, (CH > 1 ? 6 : LG))))
 #define STG_K1_VEC(VEC)                          \
     if (p.chunks == 4) { STG_K1(VEC, 4, 2); }    \
     else if (p.chunks == 2) { STG_K1(VEC, 2, 4); } \
@@ -1116,7 +1126,7 @@ int bwd_factored(const char *what, const float *A, const float *S, const float *
         hipLaunchKernelGGL(gat_bwd_prepass_h8d64_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)),
                            dim3(kBlock), 0, st, S, out, g, P, N, grad_er, slope, g_pre);
         hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, P, gq, feat,
-                           grad_feat, grad_el, T, row_offsets, column_indices, eids, node_ids, N, slope, ones_flag, 0);
+                           grad_feat, grad_el, T, row_offsets, column_indices, eids, node_ids, N, slope, ones_flag, 0, (int)grid_for(N, 6));
         return check_launch(what);
     }
 #define STG_K2F(VEC, CH, UN, P2)                                                                           \
@@ -1214,8 +1224,10 @@ extern "C" int stg_gat_bwd_uniform_edges(const float *A, const float *pack, cons
     // every score finite: T and gsW from the pass over the targets; otherwise gsW = 0 and the general unit writes T and grad_feat
     hipLaunchKernelGGL(gat_ubwd_t_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, gW, pack, x, T, gsW, fwd_row_offsets,
                        fwd_column_indices, fwd_eids, fwd_node_ids, N, slope, ones_flag);
-    hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(grid_for(N, 6)), dim3(kBlock), 0, st, A, pack, gq, feat, grad_feat, grad_el,
-                       T, bwd_row_offsets, bwd_column_indices, bwd_eids, bwd_node_ids, N, slope, ones_flag, 1);
+    // (the general unit standing in: a capped grid walking the row blocks -- it almost always returns on the flag)
+    hipLaunchKernelGGL(gat_bwd_fact_h8d64_kernel<2>, dim3(std::min<unsigned>(grid_for(N, 6), kFallbackGrid)), dim3(kBlock), 0, st, A, pack, gq,
+                       feat, grad_feat, grad_el, T, bwd_row_offsets, bwd_column_indices, bwd_eids, bwd_node_ids, N, slope, ones_flag, 1,
+                       (int)grid_for(N, 6));
     hipLaunchKernelGGL(gat_ubwd_src_kernel<8>, dim3(grid_for(N, 4)), dim3(kBlock), 0, st, T, gsW, grad_el, gxa, bwd_row_offsets,
                        bwd_column_indices, bwd_eids, bwd_node_ids, N);
     return check_launch("stg_gat_bwd_uniform_edges");
